@@ -1,0 +1,181 @@
+"""Deterministic synthetic inputs for the hot path.
+
+numpy only; used by tests/ and bench.py on both boxes (no dataset, no network).  Seeds are fixed so
+the CPU oracle and the HIP path always see identical bytes.
+
+  * stereo stream  S(stream_id): 1241x376 u8 left/right pairs, scene shifted by (2t, 0) px per frame
+  * CALC weights   N(0, 1/fan_in), seed 0xCA1C (the real caffemodel is not available)
+  * loop database  |N(0,1)|^1064 rows, L2-normalised, seed 0xDB
+  * BA window      10 key-frames x 300 landmarks, K = KITTI00, seed 0xBA
+"""
+import numpy as np
+
+KITTI00 = dict(fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, bf=386.1448)   # config/stereo/gray/KITTI00-02.yaml
+IMG_H, IMG_W = 376, 1241
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.PCG64(int(seed)))
+
+
+def _value_noise(rng, h, w, cell):
+    gh, gw = h // cell + 2, w // cell + 2
+    g = rng.uniform(-1.0, 1.0, size=(gh, gw))
+    ys = np.arange(h) / cell
+    xs = np.arange(w) / cell
+    y0 = ys.astype(int); x0 = xs.astype(int)
+    fy = (ys - y0)[:, None]; fx = (xs - x0)[None, :]
+    a = g[y0][:, x0]; b = g[y0][:, x0 + 1]; c = g[y0 + 1][:, x0]; d = g[y0 + 1][:, x0 + 1]
+    return (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
+
+
+def make_scene(stream_id=0, h=IMG_H, w=IMG_W, n_rect=6000):
+    """Base scene (float64, un-clamped) for a stream; wraps horizontally."""
+    rng = _rng(0x5EED0000 + stream_id)
+    img = np.full((h, w), 128.0)
+    img += 48.0 * (_value_noise(rng, h, w, 64) + 0.5 * _value_noise(rng, h, w, 16) + 0.25 * _value_noise(rng, h, w, 4)) / 1.75
+    # 6000 axis-aligned rectangles via a 2-D difference array
+    x0 = rng.integers(0, w, n_rect); y0 = rng.integers(0, h, n_rect)
+    sw = rng.integers(3, 25, n_rect); sh = rng.integers(3, 25, n_rect)
+    val = rng.uniform(-90.0, 90.0, n_rect)
+    x1 = np.minimum(x0 + sw, w); y1 = np.minimum(y0 + sh, h)
+    diff = np.zeros((h + 1, w + 1))
+    np.add.at(diff, (y0, x0), val); np.add.at(diff, (y0, x1), -val)
+    np.add.at(diff, (y1, x0), -val); np.add.at(diff, (y1, x1), val)
+    img += np.cumsum(np.cumsum(diff, axis=0), axis=1)[:h, :w]
+    return img
+
+
+def _depth_map(stream_id, h, w):
+    rng = _rng(0xDE97 + stream_id)
+    nplanes = 8
+    z = rng.uniform(5.0, 50.0, nplanes + 1)
+    xs = np.linspace(0, nplanes, w)
+    i = np.minimum(xs.astype(int), nplanes - 1)
+    f = xs - i
+    zrow = z[i] * (1 - f) + z[i + 1] * f
+    tilt = np.linspace(1.15, 0.85, h)[:, None]          # nearer towards the bottom of the image
+    return zrow[None, :] * tilt
+
+
+def stereo_pair(stream_id=0, t=0, h=IMG_H, w=IMG_W, scene=None, bf=KITTI00["bf"]):
+    """(left, right) uint8 images of frame t of stream `stream_id`."""
+    if scene is None:
+        scene = make_scene(stream_id, h, w)
+    rng = _rng((0x5EED0000 + stream_id) * 1000003 + t)
+    base = np.roll(scene, -2 * t, axis=1)
+    left = base + rng.uniform(-3.0, 3.0, size=base.shape)
+    d = bf / _depth_map(stream_id, h, w)                 # right(x) = left(x + d)
+    xs = np.arange(w)[None, :] + d
+    x0 = np.floor(xs).astype(int); fx = xs - x0
+    x0c = np.clip(x0, 0, w - 1); x1c = np.clip(x0 + 1, 0, w - 1)
+    rows = np.arange(h)[:, None]
+    right = base[rows, x0c] * (1 - fx) + base[rows, x1c] * fx + rng.uniform(-3.0, 3.0, size=base.shape)
+    to_u8 = lambda a: np.clip(np.rint(a), 0, 255).astype(np.uint8)
+    return to_u8(left), to_u8(right)
+
+
+def stereo_batch(n_pairs, stream_id=0, t0=0, h=IMG_H, w=IMG_W):
+    """[n_pairs, 2, h, w] uint8: frames t0.. of one stream (left=[:,0], right=[:,1])."""
+    scene = make_scene(stream_id, h, w)
+    out = np.empty((n_pairs, 2, h, w), np.uint8)
+    for i in range(n_pairs):
+        out[i, 0], out[i, 1] = stereo_pair(stream_id, t0 + i, h, w, scene)
+    return out
+
+
+def random_image(seed, h, w, kind="texture"):
+    """Small seeded test images for parity tests."""
+    rng = _rng(seed)
+    if kind == "noise":
+        return rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+    img = 128 + 40 * _value_noise(rng, h, w, 16) + 25 * _value_noise(rng, h, w, 4)
+    n_rect = max(8, (h * w) // 80)
+    x0 = rng.integers(0, w, n_rect); y0 = rng.integers(0, h, n_rect)
+    sw = rng.integers(3, 25, n_rect); sh = rng.integers(3, 25, n_rect)
+    val = rng.uniform(-90.0, 90.0, n_rect)
+    x1 = np.minimum(x0 + sw, w); y1 = np.minimum(y0 + sh, h)
+    diff = np.zeros((h + 1, w + 1))
+    np.add.at(diff, (y0, x0), val); np.add.at(diff, (y0, x1), -val)
+    np.add.at(diff, (y1, x0), -val); np.add.at(diff, (y1, x1), val)
+    img += np.cumsum(np.cumsum(diff, axis=0), axis=1)[:h, :w]
+    img += rng.uniform(-3, 3, size=(h, w))
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+# ----------------------------------------------------------------------------------------------
+CALC_SHAPES = [("conv1.w", (64, 1, 5, 5)), ("conv1.b", (64,)), ("conv2.w", (128, 64, 4, 4)), ("conv2.b", (128,)),
+               ("conv3.w", (4, 128, 3, 3)), ("conv3.b", (4,))]
+
+
+def calc_weights(seed=0xCA1C):
+    """Flat f32 blob in the layout both oracle and HIP path use (137 476 floats)."""
+    rng = _rng(seed)
+    parts = []
+    for name, shp in CALC_SHAPES:
+        if name.endswith(".w"):
+            fan_in = shp[1] * shp[2] * shp[3]
+            parts.append(rng.normal(0.0, np.sqrt(1.0 / fan_in), size=shp).astype(np.float32).ravel())
+        else:
+            parts.append(rng.uniform(0.0, 0.1, size=shp).astype(np.float32).ravel())
+    return np.concatenate(parts)
+
+
+def lcd_database(n, seed=0xDB, dim=1064):
+    rng = _rng(seed)
+    db = np.abs(rng.standard_normal(size=(n, dim))).astype(np.float32)
+    db /= np.linalg.norm(db, axis=1, keepdims=True).astype(np.float32)
+    return np.ascontiguousarray(db, np.float32)
+
+
+# ----------------------------------------------------------------------------------------------
+def _quat_from_yaw(yaw):
+    return np.array([0.0, np.sin(yaw / 2), 0.0, np.cos(yaw / 2)])      # rotation about camera y
+
+
+def _quat_to_R(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def ba_problem(seed=0xBA, n_kf=10, n_mp=300, noise_px=0.5, outlier_frac=0.03, perturb=True, K=KITTI00,
+               h=IMG_H, w=IMG_W):
+    """A sliding-window BA instance: poses (n_kf,7: qx qy qz qw tx ty tz, Tcw), points (n_mp,3),
+    edges (pose_idx, pt_idx, obs uv), fixed flags.  ~n_kf*n_mp edges."""
+    rng = _rng(seed)
+    poses = np.zeros((n_kf, 7))
+    for i in range(n_kf):
+        yaw = np.deg2rad(5.0) * (i / max(n_kf - 1, 1) - 0.5) * 2
+        twc = np.array([0.15 * np.sin(i * 0.7), 0.0, 1.0 * i])          # 1 m spacing along z
+        q = _quat_from_yaw(yaw)                                         # Rwc
+        Rwc = _quat_to_R(q)
+        Rcw = Rwc.T
+        tcw = -Rcw @ twc
+        poses[i, :4] = [-q[0], -q[1], -q[2], q[3]]
+        poses[i, 4:] = tcw
+    pts = np.stack([rng.uniform(-10, 10, n_mp), rng.uniform(-3, 3, n_mp), rng.uniform(5, 40, n_mp) + n_kf], axis=1)
+    ep, el, obs = [], [], []
+    for j in range(n_mp):
+        for i in range(n_kf):
+            R = _quat_to_R(poses[i, :4]); pc = R @ pts[j] + poses[i, 4:]
+            if pc[2] < 0.5:
+                continue
+            u = K["fx"] * pc[0] / pc[2] + K["cx"]; v = K["fy"] * pc[1] / pc[2] + K["cy"]
+            if not (0 <= u < w and 0 <= v < h):
+                continue
+            ep.append(i); el.append(j); obs.append([u, v])
+    ep = np.array(ep, np.int32); el = np.array(el, np.int32); obs = np.array(obs, np.float64).reshape(-1, 2)
+    obs += rng.normal(0, noise_px, size=obs.shape)
+    nout = int(outlier_frac * len(ep))
+    if nout:
+        idx = rng.choice(len(ep), nout, replace=False)
+        obs[idx] += rng.uniform(-40, 40, size=(nout, 2))
+    fixed = (rng.uniform(size=n_mp) < 0.1).astype(np.uint8)            # landmarks first seen outside the window
+    if perturb:
+        pts = pts + rng.normal(0, 0.05, size=pts.shape) * (1 - fixed)[:, None]
+        poses = poses.copy()
+        poses[:, 4:] += rng.normal(0, 0.02, size=(n_kf, 3))
+    Kt = (K["fx"], K["fy"], K["cx"], K["cy"])
+    return poses, pts, ep, el, obs, fixed, Kt

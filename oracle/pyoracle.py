@@ -1,0 +1,307 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: may be imported from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py — never from the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".h", ".inc"))]
+    if (not force and os.path.exists(_LIB)
+            and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in srcs)):
+        return _LIB
+    subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+class KeyPoint(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("size", C.c_float), ("angle", C.c_float),
+                ("response", C.c_float), ("octave", C.c_int32), ("class_id", C.c_int32)]
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28 == C.sizeof(KeyPoint)
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int),
+                ("ini_th_fast", C.c_int), ("min_th_fast", C.c_int)]
+
+
+def _p(a, t=C.c_void_p):
+    return a.ctypes.data_as(t)
+
+
+class Oracle:
+    def __init__(self):
+        self.lib = C.CDLL(build())
+        L = self.lib
+        L.orc_orb_pattern.restype = C.POINTER(C.c_int8)
+        L.orc_fast_atan2.restype = C.c_float
+        L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orc_ic_angle.restype = C.c_float
+        L.orc_lcd_score.restype = C.c_float
+        L.orc_calc_nweights.restype = C.c_size_t
+        L.orc_sincos.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+
+    # ---- tables ----
+    @staticmethod
+    def params(nfeatures=2000, scale=1.2, nlevels=8, ini=20, mn=7):
+        return OrbParams(nfeatures, scale, nlevels, ini, mn)
+
+    def orb_tables(self, p):
+        n = p.nlevels
+        sc = np.zeros(n, np.float32); isc = np.zeros(n, np.float32)
+        npl = np.zeros(n, np.int32); umax = np.zeros(16, np.int32)
+        rc = self.lib.orc_orb_tables(C.byref(p), _p(sc), _p(isc), _p(npl), _p(umax))
+        assert rc == 0
+        return sc, isc, npl, umax
+
+    def level_size(self, cols, rows, inv_scale):
+        w = C.c_int(); h = C.c_int()
+        self.lib.orc_level_size(cols, rows, C.c_float(inv_scale), C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def pattern(self):
+        return np.ctypeslib.as_array(self.lib.orc_orb_pattern(), shape=(1024,)).copy()
+
+    # ---- image primitives ----
+    def resize(self, src, dw, dh):
+        src = np.ascontiguousarray(src, np.uint8)
+        dst = np.zeros((dh, dw), np.uint8)
+        rc = self.lib.orc_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.strides[0],
+                                           _p(dst), dw, dh, dw)
+        assert rc == 0
+        return dst
+
+    def blur7(self, src, kind=0):
+        src = np.ascontiguousarray(src, np.uint8)
+        dst = np.zeros_like(src)
+        rc = self.lib.orc_gaussian_blur7_u8(_p(src), src.shape[1], src.shape[0], src.strides[0],
+                                            _p(dst), dst.strides[0], kind)
+        assert rc == 0
+        return dst
+
+    def pyramid(self, p, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        _, isc, _, _ = self.orb_tables(p)
+        lv = []
+        for l in range(p.nlevels):
+            w, h = self.level_size(img.shape[1], img.shape[0], float(isc[l]))
+            lv.append(np.zeros((h, w), np.uint8))
+        ptrs = (C.c_void_p * p.nlevels)(*[a.ctypes.data for a in lv])
+        rc = self.lib.orc_build_pyramid(C.byref(p), _p(img), img.shape[0], img.shape[1], img.strides[0], ptrs)
+        assert rc == 0, rc
+        return lv
+
+    # ---- FAST ----
+    def fast_score_map(self, img, th):
+        img = np.ascontiguousarray(img, np.uint8)
+        out = np.zeros_like(img)
+        self.lib.orc_fast_score_map(_p(img), img.shape[1], img.shape[0], img.strides[0], th, _p(out))
+        return out
+
+    def fast_detect(self, img, th):
+        img = np.ascontiguousarray(img, np.uint8)
+        cap = img.size
+        xs = np.zeros(cap, np.int32); ys = np.zeros(cap, np.int32); sc = np.zeros(cap, np.int32)
+        n = C.c_int()
+        rc = self.lib.orc_fast_detect(_p(img), img.shape[1], img.shape[0], img.strides[0], th,
+                                      _p(xs), _p(ys), _p(sc), cap, C.byref(n))
+        assert rc == 0
+        return xs[:n.value], ys[:n.value], sc[:n.value]
+
+    def is_fast_corner(self, img, x, y, th):
+        img = np.ascontiguousarray(img, np.uint8)
+        return bool(self.lib.orc_is_fast_corner(_p(img), img.strides[0], x, y, th))
+
+    def grid_fast(self, img, ini=20, mn=7, mask=None):
+        img = np.ascontiguousarray(img, np.uint8)
+        cap = img.size // 2 + 16
+        xs = np.zeros(cap, np.int32); ys = np.zeros(cap, np.int32); sc = np.zeros(cap, np.int32)
+        n = C.c_int()
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, np.uint8)
+        rc = self.lib.orc_grid_fast(_p(img), img.shape[1], img.shape[0], img.strides[0],
+                                    _p(mask) if mask is not None else None,
+                                    mask.strides[0] if mask is not None else 0,
+                                    ini, mn, _p(xs), _p(ys), _p(sc), cap, C.byref(n))
+        assert rc == 0, rc
+        return xs[:n.value].copy(), ys[:n.value].copy(), sc[:n.value].copy()
+
+    def octree(self, xs, ys, sc, minX, maxX, minY, maxY, N):
+        xs = np.ascontiguousarray(xs, np.int32); ys = np.ascontiguousarray(ys, np.int32)
+        sc = np.ascontiguousarray(sc, np.int32)
+        cap = len(xs) + 8
+        out = np.zeros(cap, np.int32)
+        n = C.c_int()
+        rc = self.lib.orc_distribute_octree(_p(xs), _p(ys), _p(sc), len(xs), minX, maxX, minY, maxY, N,
+                                            _p(out), cap, C.byref(n))
+        assert rc == 0, rc
+        return out[:n.value].copy()
+
+    # ---- orientation / descriptor ----
+    def fast_atan2(self, y, x):
+        return self.lib.orc_fast_atan2(C.c_float(y), C.c_float(x))
+
+    def ic_angle(self, img, x, y):
+        img = np.ascontiguousarray(img, np.uint8)
+        return self.lib.orc_ic_angle(_p(img), img.strides[0], x, y)
+
+    def sincos(self, rad):
+        s = C.c_float(); c = C.c_float()
+        self.lib.orc_sincos(C.c_float(rad), C.byref(s), C.byref(c))
+        return s.value, c.value
+
+    def brief(self, blurred, x, y, angle_deg):
+        blurred = np.ascontiguousarray(blurred, np.uint8)
+        d = np.zeros(32, np.uint8)
+        self.lib.orc_brief(_p(blurred), blurred.strides[0], x, y, C.c_float(angle_deg), _p(d))
+        return d
+
+    # ---- operators ----
+    def detect_and_compute(self, p, img, mask=None, cap=None):
+        img = np.ascontiguousarray(img, np.uint8)
+        cap = cap or (p.nfeatures * 2 + 64)
+        kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int()
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, np.uint8)
+        rc = self.lib.orc_detect_and_compute(C.byref(p), _p(img), img.shape[0], img.shape[1], img.strides[0],
+                                             _p(mask) if mask is not None else None,
+                                             mask.strides[0] if mask is not None else 0,
+                                             _p(kps), _p(desc), cap, C.byref(n))
+        assert rc == 0, rc
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def detect(self, p, img, mask=None, cap=None):
+        img = np.ascontiguousarray(img, np.uint8)
+        cap = cap or (p.nfeatures * 2 + 64)
+        kps = np.zeros(cap, KP_DTYPE)
+        n = C.c_int()
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, np.uint8)
+        rc = self.lib.orc_detect(C.byref(p), _p(img), img.shape[0], img.shape[1], img.strides[0],
+                                 _p(mask) if mask is not None else None,
+                                 mask.strides[0] if mask is not None else 0, _p(kps), cap, C.byref(n))
+        assert rc == 0, rc
+        return kps[:n.value].copy()
+
+    def screen(self, p, img, kps_in):
+        img = np.ascontiguousarray(img, np.uint8)
+        kin = np.ascontiguousarray(kps_in, KP_DTYPE).copy()
+        kout = np.zeros(len(kin) + 1, KP_DTYPE)
+        n = C.c_int()
+        rc = self.lib.orc_screen(C.byref(p), _p(img), img.shape[0], img.shape[1], img.strides[0],
+                                 _p(kin), len(kin), _p(kout), len(kout), C.byref(n))
+        assert rc == 0, rc
+        return kout[:n.value].copy()
+
+    def calc_descriptors(self, p, img, kps):
+        img = np.ascontiguousarray(img, np.uint8)
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc = np.zeros((len(kps), 32), np.uint8)
+        rc = self.lib.orc_calc_descriptors(C.byref(p), _p(img), img.shape[0], img.shape[1], img.strides[0],
+                                           _p(kps), len(kps), _p(desc))
+        assert rc == 0, rc
+        return desc
+
+    # ---- hamming / triangulation ----
+    def hamming_match(self, q, t):
+        q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+        idx = np.zeros(len(q), np.int32); dist = np.zeros(len(q), np.int32)
+        rc = self.lib.orc_hamming_match(_p(q), len(q), _p(t), len(t), _p(idx), _p(dist))
+        assert rc == 0
+        return idx, dist
+
+    def hamming_filter(self, dist):
+        dist = np.ascontiguousarray(dist, np.int32)
+        keep = np.zeros(len(dist), np.uint8)
+        mn = C.c_int()
+        self.lib.orc_hamming_filter(_p(dist), len(dist), _p(keep), C.byref(mn))
+        return keep.astype(bool), mn.value
+
+    def triangulate(self, poses, pts):
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 12)
+        pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
+        xyz = np.zeros(3); r = C.c_double()
+        rc = self.lib.orc_triangulate(_p(poses), _p(pts), len(poses), _p(xyz), C.byref(r))
+        assert rc == 0
+        return xyz, r.value
+
+    def triangulate_stereo(self, xl, yl, xr, yr, fx, fy, cx, cy, baseline):
+        xl, yl, xr, yr = [np.ascontiguousarray(a, np.float32) for a in (xl, yl, xr, yr)]
+        n = len(xl)
+        xyz = np.zeros((n, 3)); ok = np.zeros(n, np.uint8)
+        rc = self.lib.orc_triangulate_stereo(_p(xl), _p(yl), _p(xr), _p(yr), n, C.c_double(fx), C.c_double(fy),
+                                             C.c_double(cx), C.c_double(cy), C.c_double(baseline), _p(xyz), _p(ok))
+        assert rc == 0
+        return xyz, ok.astype(bool)
+
+    # ---- CALC ----
+    def calc_nweights(self):
+        return self.lib.orc_calc_nweights()
+
+    def calc_preproc(self, img, blur_in_place=False):
+        """returns (120x160 f32 input, image after the call)"""
+        img = np.ascontiguousarray(img, np.uint8).copy()
+        out = np.zeros((120, 160), np.float32)
+        rc = self.lib.orc_calc_preproc(_p(img), img.shape[0], img.shape[1], img.strides[0],
+                                       1 if blur_in_place else 0, _p(out))
+        assert rc == 0
+        return out, img
+
+    def calc_forward(self, weights, x):
+        weights = np.ascontiguousarray(weights, np.float32); x = np.ascontiguousarray(x, np.float32)
+        out = np.zeros(1064, np.float32)
+        rc = self.lib.orc_calc_forward(_p(weights), C.c_size_t(weights.size), _p(x), _p(out))
+        assert rc == 0, rc
+        return out
+
+    def lcddb_query(self, db, ids, q, cur_id, thr_low=0.92):
+        db = np.ascontiguousarray(db, np.float32); ids = np.ascontiguousarray(ids, np.uint64)
+        q = np.ascontiguousarray(q, np.float32)
+        best = C.c_uint64(); mx = C.c_float(); cnt = C.c_int()
+        rc = self.lib.orc_lcddb_query(_p(db), _p(ids), len(ids), _p(q), C.c_uint64(cur_id), C.c_float(thr_low),
+                                      C.byref(best), C.byref(mx), C.byref(cnt))
+        assert rc == 0
+        return best.value, mx.value, cnt.value
+
+    # ---- BA ----
+    def ba_build(self, poses, points, ep, el, obs, fixed, K, delta=5.991):
+        poses = np.ascontiguousarray(poses, np.float64); points = np.ascontiguousarray(points, np.float64)
+        ep = np.ascontiguousarray(ep, np.int32); el = np.ascontiguousarray(el, np.int32)
+        obs = np.ascontiguousarray(obs, np.float64); fixed = np.ascontiguousarray(fixed, np.uint8)
+        P, L, E = len(poses), len(points), len(ep)
+        Hpp = np.zeros((P, 6, 6)); Hll = np.zeros((L, 3, 3)); Hpl = np.zeros((E, 6, 3))
+        bp = np.zeros((P, 6)); bl = np.zeros((L, 3)); chi2 = np.zeros(E)
+        rc = self.lib.orc_ba_build(_p(poses), P, _p(points), L, _p(ep), _p(el), _p(obs), E, _p(fixed),
+                                   C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]),
+                                   C.c_double(delta), _p(Hpp), _p(Hll), _p(Hpl), _p(bp), _p(bl), _p(chi2))
+        assert rc == 0, rc
+        return Hpp, Hll, Hpl, bp, bl, chi2
+
+    def ba_optimize(self, poses, points, ep, el, obs, fixed, K, delta=5.991, iters=10):
+        poses = np.ascontiguousarray(poses, np.float64).copy(); points = np.ascontiguousarray(points, np.float64).copy()
+        ep = np.ascontiguousarray(ep, np.int32); el = np.ascontiguousarray(el, np.int32)
+        obs = np.ascontiguousarray(obs, np.float64); fixed = np.ascontiguousarray(fixed, np.uint8)
+        chi = C.c_double(); it = C.c_int()
+        rc = self.lib.orc_ba_optimize(_p(poses), len(poses), _p(points), len(points), _p(ep), _p(el), _p(obs), len(ep),
+                                      _p(fixed), C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]),
+                                      C.c_double(delta), iters, C.byref(chi), C.byref(it))
+        assert rc == 0, rc
+        return poses, points, chi.value, it.value
+
+    def se3_exp(self, xi):
+        xi = np.ascontiguousarray(xi, np.float64); out = np.zeros(7)
+        self.lib.orc_se3_exp(_p(xi), _p(out))
+        return out
