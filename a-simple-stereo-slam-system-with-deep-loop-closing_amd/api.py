@@ -1,0 +1,344 @@
+"""ctypes mirror of the reference's operator interface over libmyslam_hip.so (include/myslam_hip.h).
+
+Names follow the reference: ORBextractor (include/myslam/ORBextractor.h), DeepLCD
+(include/myslam/deeplcd.h), the BFMatcher-style `hamming_match`, `triangulation` (algorithm.h), the
+loop database of LoopClosing::DetectLoop and the BA block build of Backend::OptimizeActiveMap.
+Host-buffer calls take numpy arrays; *_batch calls take raw device pointers (e.g. torch.Tensor.data_ptr()).
+There is no CPU fallback: a missing library or GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmyslam_hip.so")
+
+OK, ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_UNSUPPORTED = 0, -1, -2, -3, -4
+LCD_DIM = 1064
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+
+class MyslamError(RuntimeError):
+    def __init__(self, where, code):
+        names = {-1: "INVALID", -2: "HIP", -3: "CAPACITY", -4: "UNSUPPORTED"}
+        super().__init__(f"{where} failed: {code} ({names.get(code, '?')})")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libmyslam_hip.so (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() / build.py first (no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.myslam_hip_version.restype = C.c_char_p
+        L.myslam_lcd_score.restype = C.c_float
+        L.myslam_lcd_nweights.restype = C.c_size_t
+        _lib = L
+    return _lib
+
+
+def _check(code, where):
+    if code != OK:
+        raise MyslamError(where, code)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def device_count():
+    return lib().myslam_hip_device_count()
+
+
+# ---------------------------------------------------------------------------------- profiling
+def prof_enable(on=True):
+    lib().myslam_prof_enable(1 if on else 0)
+
+
+def prof_reset():
+    lib().myslam_prof_reset()
+
+
+def prof_read():
+    """{kernel name: (total ms, launches)} since the last reset (synchronises)."""
+    L = lib()
+    out = {}
+    for i in range(L.myslam_prof_count()):
+        name = C.c_char_p(); ms = C.c_double(); n = C.c_long()
+        L.myslam_prof_get(i, C.byref(name), C.byref(ms), C.byref(n))
+        out[name.value.decode()] = (ms.value, n.value)
+    return out
+
+
+# ---------------------------------------------------------------------------------- ORB
+class ORBextractor:
+    """ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) — ORBextractor.h:55-56."""
+
+    def __init__(self, nfeatures=2000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, stream=None):
+        self._h = C.c_void_p()
+        _check(lib().myslam_orb_create(C.byref(self._h), int(nfeatures), C.c_float(scaleFactor), int(nlevels),
+                                       int(iniThFAST), int(minThFAST)), "myslam_orb_create")
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+        if stream is not None:
+            self.set_stream(stream)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value and _lib is not None:
+            _lib.myslam_orb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def set_stream(self, stream_ptr):
+        _check(lib().myslam_orb_set_stream(self._h, C.c_void_p(stream_ptr)), "myslam_orb_set_stream")
+
+    def tables(self):
+        n = self.nlevels
+        sc = np.zeros(n, np.float32); isc = np.zeros(n, np.float32); npl = np.zeros(n, np.int32); um = np.zeros(16, np.int32)
+        _check(lib().myslam_orb_get_tables(self._h, _p(sc), _p(isc), _p(npl), _p(um)), "myslam_orb_get_tables")
+        return sc, isc, npl, um
+
+    def max_keypoints(self):
+        return lib().myslam_orb_max_keypoints(self._h)
+
+    @staticmethod
+    def _img(img):
+        img = np.ascontiguousarray(img, np.uint8)
+        assert img.ndim == 2
+        return img
+
+    def DetectAndCompute(self, image, mask=None, cap=None):
+        img = self._img(image)
+        cap = cap or self.max_keypoints()
+        kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8); n = C.c_int()
+        m = self._img(mask) if mask is not None else None
+        _check(lib().myslam_orb_detect_and_compute(self._h, _p(img), img.shape[0], img.shape[1], img.strides[0],
+                                                   _p(m), m.strides[0] if m is not None else 0,
+                                                   _p(kps), _p(desc), cap, C.byref(n)), "myslam_orb_detect_and_compute")
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def Detect(self, image, mask=None, cap=None):
+        img = self._img(image)
+        cap = cap or self.max_keypoints()
+        kps = np.zeros(cap, KP_DTYPE); n = C.c_int()
+        m = self._img(mask) if mask is not None else None
+        _check(lib().myslam_orb_detect(self._h, _p(img), img.shape[0], img.shape[1], img.strides[0],
+                                       _p(m), m.strides[0] if m is not None else 0, _p(kps), cap, C.byref(n)),
+               "myslam_orb_detect")
+        return kps[:n.value].copy()
+
+    def ScreenAndComputeKPsParams(self, image, keypoints):
+        """returns (out_keypoints, keypoints as modified in place by the call)"""
+        img = self._img(image)
+        kin = np.ascontiguousarray(keypoints, KP_DTYPE).copy()
+        kout = np.zeros(max(len(kin), 1), KP_DTYPE); n = C.c_int()
+        _check(lib().myslam_orb_screen_and_compute_params(self._h, _p(img), img.shape[0], img.shape[1], img.strides[0],
+                                                          _p(kin), len(kin), _p(kout), len(kout), C.byref(n)),
+               "myslam_orb_screen_and_compute_params")
+        return kout[:n.value].copy(), kin
+
+    def CalcDescriptors(self, image, keypoints):
+        img = self._img(image)
+        k = np.ascontiguousarray(keypoints, KP_DTYPE)
+        desc = np.zeros((len(k), 32), np.uint8)
+        _check(lib().myslam_orb_calc_descriptors(self._h, _p(img), img.shape[0], img.shape[1], img.strides[0],
+                                                 _p(k), len(k), _p(desc)), "myslam_orb_calc_descriptors")
+        return desc
+
+    # device-resident batch (pointers are ints)
+    def detect_and_compute_batch(self, d_imgs, batch, rows, cols, step, img_stride, d_kps, d_desc, d_counts, d_status, cap,
+                                 d_masks=0):
+        _check(lib().myslam_orb_detect_and_compute_batch(self._h, C.c_void_p(d_imgs), batch, rows, cols, step,
+                                                         C.c_size_t(img_stride), C.c_void_p(d_masks or None),
+                                                         C.c_void_p(d_kps), C.c_void_p(d_desc), C.c_void_p(d_counts),
+                                                         C.c_void_p(d_status or None), cap),
+               "myslam_orb_detect_and_compute_batch")
+
+    def detect_batch(self, d_imgs, batch, rows, cols, step, img_stride, d_kps, d_counts, d_status, cap, d_masks=0):
+        _check(lib().myslam_orb_detect_batch(self._h, C.c_void_p(d_imgs), batch, rows, cols, step, C.c_size_t(img_stride),
+                                             C.c_void_p(d_masks or None), C.c_void_p(d_kps), C.c_void_p(d_counts),
+                                             C.c_void_p(d_status or None), cap), "myslam_orb_detect_batch")
+
+    # stage taps
+    def debug_pyramid(self, image, level, blurred=False):
+        img = self._img(image)
+        w = C.c_int(); h = C.c_int()
+        _check(lib().myslam_orb_debug_pyramid(self._h, _p(img), img.shape[0], img.shape[1], img.strides[0], level,
+                                              1 if blurred else 0, None, 0, C.byref(w), C.byref(h)), "debug_pyramid(size)")
+        out = np.zeros((h.value, w.value), np.uint8)
+        _check(lib().myslam_orb_debug_pyramid(self._h, _p(img), img.shape[0], img.shape[1], img.strides[0], level,
+                                              1 if blurred else 0, _p(out), out.strides[0], C.byref(w), C.byref(h)),
+               "debug_pyramid")
+        return out
+
+    def debug_candidates(self, image, level, mask=None):
+        img = self._img(image)
+        cap = 65536
+        xs = np.zeros(cap, np.int32); ys = np.zeros(cap, np.int32); sc = np.zeros(cap, np.int32); n = C.c_int()
+        m = self._img(mask) if mask is not None else None
+        _check(lib().myslam_orb_debug_candidates(self._h, _p(img), img.shape[0], img.shape[1], img.strides[0],
+                                                 _p(m), m.strides[0] if m is not None else 0, level,
+                                                 _p(xs), _p(ys), _p(sc), cap, C.byref(n)), "debug_candidates")
+        return xs[:n.value].copy(), ys[:n.value].copy(), sc[:n.value].copy()
+
+
+# ---------------------------------------------------------------------------------- Hamming / triangulation
+def hamming_match(query, train):
+    """cv::BFMatcher(NORM_HAMMING).match(query, train) -> (trainIdx, distance) per query row."""
+    q = np.ascontiguousarray(query, np.uint8).reshape(-1, 32); t = np.ascontiguousarray(train, np.uint8).reshape(-1, 32)
+    idx = np.zeros(len(q), np.int32); dist = np.zeros(len(q), np.int32)
+    _check(lib().myslam_hamming_match(_p(q), len(q), _p(t), len(t), _p(idx), _p(dist)), "myslam_hamming_match")
+    return idx, dist
+
+
+def hamming_match_batch(d_q, d_nq, d_t, d_nt, batch, cap, d_idx, d_dist, stream=0):
+    _check(lib().myslam_hamming_match_batch(C.c_void_p(d_q), C.c_void_p(d_nq), C.c_void_p(d_t), C.c_void_p(d_nt), batch, cap,
+                                            C.c_void_p(d_idx), C.c_void_p(d_dist), C.c_void_p(stream or None)),
+           "myslam_hamming_match_batch")
+
+
+def hamming_filter(dist):
+    d = np.ascontiguousarray(dist, np.int32)
+    keep = np.zeros(len(d), np.uint8); mn = C.c_int()
+    _check(lib().myslam_hamming_filter(_p(d), len(d), _p(keep), C.byref(mn)), "myslam_hamming_filter")
+    return keep.astype(bool), mn.value
+
+
+def triangulate_stereo(xl, yl, xr, yr, fx, fy, cx, cy, baseline):
+    xl, yl, xr, yr = [np.ascontiguousarray(a, np.float32) for a in (xl, yl, xr, yr)]
+    n = len(xl)
+    xyz = np.zeros((n, 3)); ok = np.zeros(n, np.uint8)
+    _check(lib().myslam_triangulate_stereo(_p(xl), _p(yl), _p(xr), _p(yr), n, C.c_double(fx), C.c_double(fy), C.c_double(cx),
+                                           C.c_double(cy), C.c_double(baseline), _p(xyz), _p(ok)), "myslam_triangulate_stereo")
+    return xyz, ok.astype(bool)
+
+
+def triangulate_stereo_batch(d_kl, d_kr, d_match, d_nl, batch, cap, K, baseline, d_xyz, d_ok, stream=0):
+    _check(lib().myslam_triangulate_stereo_batch(C.c_void_p(d_kl), C.c_void_p(d_kr), C.c_void_p(d_match), C.c_void_p(d_nl),
+                                                 batch, cap, C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]),
+                                                 C.c_double(K[3]), C.c_double(baseline), C.c_void_p(d_xyz), C.c_void_p(d_ok),
+                                                 C.c_void_p(stream or None)), "myslam_triangulate_stereo_batch")
+
+
+# ---------------------------------------------------------------------------------- DeepLCD
+class DeepLCD:
+    """DeepLCD(weights) — include/myslam/deeplcd.h:33 (the Caffe prototxt/caffemodel pair becomes one flat f32 blob)."""
+
+    def __init__(self, weights, stream=None):
+        w = np.ascontiguousarray(weights, np.float32).ravel()
+        self._h = C.c_void_p()
+        _check(lib().myslam_lcd_create(C.byref(self._h), _p(w), C.c_size_t(w.size)), "myslam_lcd_create")
+        if stream is not None:
+            _check(lib().myslam_lcd_set_stream(self._h, C.c_void_p(stream)), "myslam_lcd_set_stream")
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value and _lib is not None:
+            _lib.myslam_lcd_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def calcDescrOriginalImg(self, image, blur_in_place=True):
+        """returns (descriptor[1064], image after the call) — the reference blurs the caller's image in place."""
+        img = np.ascontiguousarray(image, np.uint8).copy()
+        d = np.zeros(LCD_DIM, np.float32)
+        _check(lib().myslam_lcd_calc_descr_original_img(self._h, _p(img), img.shape[0], img.shape[1], img.strides[0],
+                                                        1 if blur_in_place else 0, _p(d)), "myslam_lcd_calc_descr_original_img")
+        return d, img
+
+    def calcDescr(self, im160x120):
+        img = np.ascontiguousarray(im160x120, np.uint8)
+        assert img.shape == (120, 160)
+        d = np.zeros(LCD_DIM, np.float32)
+        _check(lib().myslam_lcd_calc_descr(self._h, _p(img), img.strides[0], _p(d)), "myslam_lcd_calc_descr")
+        return d
+
+    @staticmethod
+    def score(d1, d2):
+        a = np.ascontiguousarray(d1, np.float32); b = np.ascontiguousarray(d2, np.float32)
+        return float(lib().myslam_lcd_score(_p(a), _p(b)))
+
+    def describe_batch(self, d_imgs, batch, rows, cols, step, img_stride, d_out, blur_in_place=False):
+        _check(lib().myslam_lcd_describe_batch(self._h, C.c_void_p(d_imgs), batch, rows, cols, step, C.c_size_t(img_stride),
+                                               1 if blur_in_place else 0, C.c_void_p(d_out)), "myslam_lcd_describe_batch")
+
+    def debug_forward(self, x120x160, stage):
+        x = np.ascontiguousarray(x120x160, np.float32)
+        sizes = [62 * 82 * 64, 31 * 41 * 64, 32 * 42 * 128, 16 * 21 * 128, LCD_DIM]
+        out = np.zeros(sizes[stage], np.float32)
+        _check(lib().myslam_lcd_debug_forward(self._h, _p(x), _p(out), stage, C.c_size_t(out.size)), "myslam_lcd_debug_forward")
+        return out
+
+
+class LoopDatabase:
+    """LoopClosing::_mvDatabase + DetectLoop()/AddToDatabase() — loopclosing.cpp:124-161, 651-659."""
+
+    def __init__(self, capacity, stream=None):
+        self._h = C.c_void_p()
+        _check(lib().myslam_lcddb_create(C.byref(self._h), int(capacity)), "myslam_lcddb_create")
+        if stream is not None:
+            _check(lib().myslam_lcddb_set_stream(self._h, C.c_void_p(stream)), "myslam_lcddb_set_stream")
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value and _lib is not None:
+            _lib.myslam_lcddb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __len__(self):
+        return lib().myslam_lcddb_size(self._h)
+
+    def AddToDatabase(self, kf_id, descr):
+        d = np.ascontiguousarray(descr, np.float32)
+        _check(lib().myslam_lcddb_append(self._h, C.c_uint64(kf_id), _p(d)), "myslam_lcddb_append")
+
+    def append_batch(self, ids, d_descr, n):
+        ids = np.ascontiguousarray(ids, np.uint64)
+        _check(lib().myslam_lcddb_append_batch(self._h, _p(ids), C.c_void_p(d_descr), n), "myslam_lcddb_append_batch")
+
+    def query(self, descr, cur_id, thr_low=0.92):
+        d = np.ascontiguousarray(descr, np.float32)
+        best = C.c_uint64(); mx = C.c_float(); cnt = C.c_int()
+        _check(lib().myslam_lcddb_query(self._h, _p(d), C.c_uint64(cur_id), C.c_float(thr_low), C.byref(best), C.byref(mx),
+                                        C.byref(cnt)), "myslam_lcddb_query")
+        return best.value, mx.value, cnt.value
+
+    def DetectLoop(self, descr, cur_id, thr_high=0.94, thr_low=0.92):
+        """bool + candidate id, the decision rule of loopclosing.cpp:147."""
+        best, mx, cnt = self.query(descr, cur_id, thr_low)
+        if mx < thr_high or cnt > 3:
+            return False, None
+        return True, best
+
+    def query_batch(self, d_q, cur_ids, nq, d_best, d_max, d_cnt, thr_low=0.92):
+        cur = np.ascontiguousarray(cur_ids, np.uint64)
+        _check(lib().myslam_lcddb_query_batch(self._h, C.c_void_p(d_q), _p(cur), nq, C.c_float(thr_low), C.c_void_p(d_best),
+                                              C.c_void_p(d_max), C.c_void_p(d_cnt)), "myslam_lcddb_query_batch")
+
+
+# ---------------------------------------------------------------------------------- BA
+def ba_build(poses, points, edge_pose, edge_pt, obs, fixed, K, delta=5.991):
+    poses = np.ascontiguousarray(poses, np.float64); points = np.ascontiguousarray(points, np.float64)
+    ep = np.ascontiguousarray(edge_pose, np.int32); el = np.ascontiguousarray(edge_pt, np.int32)
+    obs = np.ascontiguousarray(obs, np.float64)
+    fixed = np.ascontiguousarray(fixed, np.uint8) if fixed is not None else None
+    P, L, E = len(poses), len(points), len(ep)
+    Hpp = np.zeros((P, 6, 6)); Hll = np.zeros((L, 3, 3)); Hpl = np.zeros((E, 6, 3)); bp = np.zeros((P, 6)); bl = np.zeros((L, 3))
+    chi2 = np.zeros(E)
+    _check(lib().myslam_ba_build(_p(poses), P, _p(points), L, _p(ep), _p(el), _p(obs), E, _p(fixed), C.c_double(K[0]),
+                                 C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]), C.c_double(delta), _p(Hpp), _p(Hll),
+                                 _p(Hpl), _p(bp), _p(bl), _p(chi2)), "myslam_ba_build")
+    return Hpp, Hll, Hpl, bp, bl, chi2
+
+
+def ba_build_batch(d_poses, d_points, d_ep, d_el, d_obs, d_fixed, d_sizes, nwin, maxP, maxL, maxE, K, delta,
+                   d_Hpp, d_Hll, d_Hpl, d_bp, d_bl, d_chi2, stream=0):
+    _check(lib().myslam_ba_build_batch(C.c_void_p(d_poses), C.c_void_p(d_points), C.c_void_p(d_ep), C.c_void_p(d_el),
+                                       C.c_void_p(d_obs), C.c_void_p(d_fixed or None), C.c_void_p(d_sizes), nwin, maxP, maxL, maxE,
+                                       C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]), C.c_double(delta),
+                                       C.c_void_p(d_Hpp), C.c_void_p(d_Hll), C.c_void_p(d_Hpl), C.c_void_p(d_bp), C.c_void_p(d_bl),
+                                       C.c_void_p(d_chi2), C.c_void_p(stream or None)), "myslam_ba_build_batch")

@@ -1,0 +1,72 @@
+"""Builds libmyslam_hip.so (gfx950) in-tree with hipcc.  No torch, no cmake: plain hipcc invocations.
+
+    python build.py            # incremental
+    python build.py --force
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libmyslam_hip.so")
+OBJDIR = os.path.join(HERE, "build")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+# float-derived integers (BRIEF coordinates, fastAtan2, resize tables) must not see FMA contraction
+EXACT = ["-ffp-contract=off"]
+UNITS = {
+    "orb_kernels.hip": EXACT,
+    "orb_engine.hip": EXACT,
+    "match_tri.hip": EXACT,
+    "calc.hip": [],
+    "lcddb.hip": [],
+    "ba.hip": [],
+    "prof.hip": [],
+}
+
+
+def _deps():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))] + \
+           [os.path.join(HERE, "..", "include", "myslam_hip.h")]
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJDIR, exist_ok=True)
+    deps = _deps()
+    jobs = []
+    for src, extra in UNITS.items():
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + deps):
+            jobs.append([HIPCC] + COMMON + extra + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for warn in ex.map(run, jobs):
+            if verbose and warn.strip():
+                print(warn)
+    objs = [os.path.join(OBJDIR, src.replace(".hip", ".o")) for src in UNITS]
+    if force or jobs or _stale(OUT, objs):
+        run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT] + objs)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,507 @@
+// calc.hip — DeepLCD / CALC descriptor network on gfx950 (replaces class DeepLCD, reference
+// include/myslam/deeplcd.h:21-48 and src/deeplcd.cpp:10-91; architecture SURVEY.md Appendix A.6).
+//
+//   u8 image --blur 7x7 (sigma<=0 table, optionally in place: reference quirk)--> resize 160x120 --> /255
+//   conv1 64@5x5 s2 p4 + ReLU -> maxpool 3x3 s2 (ceil) -> LRN(5,1e-4,.75)        [VALU, lane = channel]
+//   conv2 128@4x4 s1 p2 + ReLU                                                   [fp32 MFMA implicit GEMM]
+//   maxpool -> LRN -> conv3 4@3x3 + ReLU -> flatten (Caffe NCHW order) -> L2 normalise
+//
+// Activations are NHWC (channel-last) in HBM so that a wave's 64 lanes map to 64 channels (coalesced
+// 256-byte rows) and conv2's im2col rows are contiguous 64-byte channel runs.  All arithmetic is f32
+// (the reference runs Caffe in f32); conv2 uses v_mfma_f32_32x32x2_f32, which is an exact f32 FMA chain.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+#include "orb_plan.h"
+
+namespace myslam_hip {
+
+void launch_blur(const BlurArgs& a, int batch, hipStream_t s);
+void gauss_q8(int kind, int q[7]);
+
+constexpr int IN_H = 120, IN_W = 160;
+constexpr int C1 = 64, H1 = 62, W1 = 82, HP1 = 31, WP1 = 41;
+constexpr int C2 = 128, H2 = 32, W2 = 42, HP2 = 16, WP2 = 21;
+constexpr int C3 = 4, H3 = 14, W3 = 19;
+constexpr int K2 = 64 * 16;                 // conv2 reduction length
+constexpr int M2 = H2 * W2;                 // conv2 output pixels per image (1344)
+constexpr size_t NWEIGHTS = 64 * 25 + 64 + 128 * 64 * 16 + 128 + 4 * 128 * 9 + 4;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- input: bilinear 8U resize (same fixed-point arithmetic as the pyramid) + u8 -> f32 * (1/255) ----
+__global__ __launch_bounds__(256) void k_lcd_input(const uint8_t* __restrict__ src, int sw, int sh, int spitch, size_t sstride,
+                                                   const int32_t* __restrict__ xofs, const int16_t* __restrict__ xa,
+                                                   const int32_t* __restrict__ yofs, const int16_t* __restrict__ yb,
+                                                   float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= IN_H * IN_W) return;
+    const int dy = i / IN_W, dx = i - dy * IN_W;
+    const int sy = yofs[dy];
+    const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
+    const uint8_t* S0 = src + (size_t)b * sstride + (size_t)sy0 * spitch;
+    const uint8_t* S1 = src + (size_t)b * sstride + (size_t)sy1 * spitch;
+    const int sx = xofs[dx], sx1 = min(sx + 1, sw - 1);
+    const int a0 = xa[2 * dx], a1 = xa[2 * dx + 1], b0 = yb[2 * dy], b1 = yb[2 * dy + 1];
+    const int r0 = S0[sx] * a0 + S0[sx1] * a1, r1 = S1[sx] * a0 + S1[sx1] * a1;
+    int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    v = min(max(v, 0), 255);
+    out[(size_t)b * IN_H * IN_W + i] = (float)v * (float)(1.0 / 255.0);      // deeplcd.cpp:64 convertTo(CV_32F, 1/255.)
+}
+
+// ---- conv1 + ReLU: lane = output channel, one wave walks 8 output pixels ----
+__global__ __launch_bounds__(256) void k_conv1(const float* __restrict__ in, const float* __restrict__ w1t /*[25][64]*/,
+                                               const float* __restrict__ b1, float* __restrict__ out /*[H1*W1][64]*/) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float w[25];
+#pragma unroll
+    for (int k = 0; k < 25; k++) w[k] = w1t[k * 64 + lane];
+    const float bias = b1[lane];
+    const float* I = in + (size_t)b * IN_H * IN_W;
+    const int p0 = (blockIdx.x * 4 + wave) * 8;
+    for (int p = p0; p < min(p0 + 8, H1 * W1); p++) {
+        const int oy = p / W1, ox = p - oy * W1;
+        float acc = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 5; ky++) {
+            const int iy = oy * 2 + ky - 4;
+#pragma unroll
+            for (int kx = 0; kx < 5; kx++) {
+                const int ix = ox * 2 + kx - 4;
+                const float v = (iy >= 0 && iy < IN_H && ix >= 0 && ix < IN_W) ? I[iy * IN_W + ix] : 0.f;
+                acc += w[ky * 5 + kx] * v;
+            }
+        }
+        out[((size_t)b * H1 * W1 + p) * 64 + lane] = fmaxf(acc + bias, 0.f);
+    }
+}
+
+// ---- max-pool 3x3 s2 (Caffe ceil mode, clipped windows) + LRN across channels; one wave per output pixel ----
+template <int C>
+__global__ __launch_bounds__(256) void k_pool_lrn(const float* __restrict__ in, int H, int W, int OH, int OW,
+                                                  float* __restrict__ out) {
+    constexpr int PER = C / 64;
+    __shared__ float s_v[4][C + 4];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = blockIdx.x * 4 + wave;
+    if (p < OH * OW) {
+        const int oy = p / OW, ox = p - oy * OW;
+        const int y0 = oy * 2, x0 = ox * 2, y1 = min(y0 + 3, H), x1 = min(x0 + 3, W);
+        const float* I = in + (size_t)b * H * W * C;
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int c = lane + 64 * q;
+            float m = -INFINITY;
+            for (int y = y0; y < y1; y++)
+                for (int x = x0; x < x1; x++) m = fmaxf(m, I[((size_t)y * W + x) * C + c]);
+            s_v[wave][c + 2] = m;
+        }
+        if (lane < 2) { s_v[wave][lane] = 0.f; s_v[wave][C + 2 + lane] = 0.f; }
+    }
+    __syncthreads();
+    if (p < OH * OW) {
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int c = lane + 64 * q;
+            const float* v = &s_v[wave][c];          // v[0..4] = channels c-2..c+2 (zero padded)
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < 5; j++) ss += v[j] * v[j];
+            const float scale = 1.f + (1e-4f / 5.f) * ss;
+            out[((size_t)b * OH * OW + p) * C + c] = v[2] * powf(scale, -0.75f);
+        }
+    }
+}
+
+// ---- conv2 + ReLU as an fp32 MFMA implicit GEMM ----
+// C[M = batch*1344][N = 128] = A[M][K = 1024] * Wt[K][N];  k = (ky*4+kx)*64 + ic  (channel runs contiguous in NHWC)
+// block tile 128(M) x 128(N), 4 waves as 2x2, each wave 64x64 = 2x2 MFMA 32x32 tiles; BK = 16 per stage (64 stages),
+// register-staged double buffering through LDS.
+constexpr int CV_BM = 128, CV_BN = 128, CV_BK = 16, CV_PA = CV_BM + 4, CV_PB = CV_BN + 4;
+
+__global__ __launch_bounds__(256) void k_conv2_mfma(const float* __restrict__ in /*[B][31*41][64]*/,
+                                                    const float* __restrict__ wt /*[1024][128]*/, const float* __restrict__ b2,
+                                                    float* __restrict__ out /*[B*1344][128]*/, int Mtotal) {
+    __shared__ __attribute__((aligned(16))) float s_a[2][CV_BK * CV_PA];
+    __shared__ __attribute__((aligned(16))) float s_b[2][CV_BK * CV_PB];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int m0 = blockIdx.x * CV_BM;
+
+    // A staging role: thread -> (row m = t>>1, 8 consecutive k at (t&1)*8)
+    const int am = t >> 1, ak = (t & 1) * 8;
+    const int gm = m0 + am;
+    const bool mvalid = gm < Mtotal;
+    const int img = mvalid ? gm / M2 : 0;
+    const int pix = mvalid ? gm - img * M2 : 0;
+    const int oy = pix / W2, ox = pix - oy * W2;
+    const float* inb = in + (size_t)img * HP1 * WP1 * 64;
+    // B staging role: thread -> (k row = t>>4, 8 consecutive n at (t&15)*8)
+    const int bk = t >> 4, bn = (t & 15) * 8;
+
+    float4 ra0, ra1, rb0, rb1;
+    auto load_stage = [&](int s) {
+        const int tap = s >> 2, ic0 = (s & 3) * 16;
+        const int iy = oy + (tap >> 2) - 2, ix = ox + (tap & 3) - 2;
+        if (mvalid && iy >= 0 && iy < HP1 && ix >= 0 && ix < WP1) {
+            const float4* src = reinterpret_cast<const float4*>(inb + ((size_t)iy * WP1 + ix) * 64 + ic0 + ak);
+            ra0 = src[0]; ra1 = src[1];
+        } else {
+            ra0 = make_float4(0, 0, 0, 0); ra1 = ra0;
+        }
+        const float4* wsrc = reinterpret_cast<const float4*>(wt + (size_t)(s * CV_BK + bk) * CV_BN + bn);
+        rb0 = wsrc[0]; rb1 = wsrc[1];
+    };
+    auto store_stage = [&](int buf) {
+        float* a = s_a[buf];
+        a[(ak + 0) * CV_PA + am] = ra0.x; a[(ak + 1) * CV_PA + am] = ra0.y; a[(ak + 2) * CV_PA + am] = ra0.z; a[(ak + 3) * CV_PA + am] = ra0.w;
+        a[(ak + 4) * CV_PA + am] = ra1.x; a[(ak + 5) * CV_PA + am] = ra1.y; a[(ak + 6) * CV_PA + am] = ra1.z; a[(ak + 7) * CV_PA + am] = ra1.w;
+        float4* bdst = reinterpret_cast<float4*>(&s_b[buf][bk * CV_PB + bn]);
+        bdst[0] = rb0; bdst[1] = rb1;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    constexpr int NSTAGE = K2 / CV_BK;
+    const int lr = lane & 31, lk = lane >> 5;
+    for (int s = 0; s < NSTAGE; s++) {
+        const int buf = s & 1;
+        if (s + 1 < NSTAGE) load_stage(s + 1);
+        const float* a = s_a[buf];
+        const float* bb = s_b[buf];
+#pragma unroll
+        for (int kq = 0; kq < CV_BK / 2; kq++) {
+            const int k = 2 * kq + lk;
+            const float a0 = a[k * CV_PA + wm + lr], a1 = a[k * CV_PA + wm + 32 + lr];
+            const float b0 = bb[k * CV_PB + wn + lr], b1 = bb[k * CV_PB + wn + 32 + lr];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (s + 1 < NSTAGE) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int n = wn + j * 32 + lr;
+        const float bias = b2[n];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m < Mtotal) out[(size_t)m * CV_BN + n] = fmaxf(acc[i][j][r] + bias, 0.f);
+            }
+    }
+}
+
+// ---- conv3 + ReLU + flatten (NCHW order) + L2 normalise; one block per image ----
+__global__ __launch_bounds__(256) void k_conv3_norm(const float* __restrict__ in /*[B][16*21][128]*/,
+                                                    const float* __restrict__ w3t /*[1152][4]*/, const float* __restrict__ b3,
+                                                    float* __restrict__ out /*[B][1064]*/, int relu) {
+    __shared__ float s_o[C3 * H3 * W3];
+    __shared__ float s_red[4];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* I = in + (size_t)b * HP2 * WP2 * 128;
+    const float4* Wt = reinterpret_cast<const float4*>(w3t);
+    for (int p = wave; p < H3 * W3; p += 4) {
+        const int oy = p / W3, ox = p - oy * W3;
+        float4 acc = make_float4(0, 0, 0, 0);
+        for (int k = lane; k < 1152; k += 64) {
+            const int tap = k >> 7, ic = k & 127;
+            const float v = I[((size_t)(oy + tap / 3) * WP2 + ox + tap % 3) * 128 + ic];
+            const float4 w = Wt[k];
+            acc.x += v * w.x; acc.y += v * w.y; acc.z += v * w.z; acc.w += v * w.w;
+        }
+        acc.x = wave_reduce_sum(acc.x); acc.y = wave_reduce_sum(acc.y);
+        acc.z = wave_reduce_sum(acc.z); acc.w = wave_reduce_sum(acc.w);
+        if (lane == 0) {
+            float r[4] = {acc.x + b3[0], acc.y + b3[1], acc.z + b3[2], acc.w + b3[3]};
+#pragma unroll
+            for (int c = 0; c < 4; c++) s_o[c * H3 * W3 + p] = relu ? fmaxf(r[c], 0.f) : r[c];
+        }
+    }
+    __syncthreads();
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < MYSLAM_LCD_DIM; i += 256) ss += s_o[i] * s_o[i];
+    ss = wave_reduce_sum(ss);
+    if (lane == 0) s_red[wave] = ss;
+    __syncthreads();
+    const float nrm = sqrtf(s_red[0] + s_red[1] + s_red[2] + s_red[3]);       // deeplcd.cpp:88
+    for (int i = threadIdx.x; i < MYSLAM_LCD_DIM; i += 256) out[(size_t)b * MYSLAM_LCD_DIM + i] = s_o[i] / nrm;
+}
+
+static void lcd_resize_tables(int ssize, int dsize, bool is_x, std::vector<int32_t>& ofs, std::vector<int16_t>& coef) {
+    const double inv_scale = (double)dsize / ssize;
+    const double scale = 1. / inv_scale;
+    ofs.resize(dsize); coef.resize(2 * dsize);
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= s;
+        if (is_x) {
+            if (s < 0) { f = 0; s = 0; }
+            if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+        }
+        ofs[d] = s;
+        coef[2 * d] = (int16_t)lrintf((1.f - f) * 2048.f);
+        coef[2 * d + 1] = (int16_t)lrintf(f * 2048.f);
+    }
+}
+
+}  // namespace myslam_hip
+
+using namespace myslam_hip;
+
+struct myslam_lcd {
+    hipStream_t stream = nullptr;
+    float *d_w1t = nullptr, *d_b1 = nullptr, *d_w2t = nullptr, *d_b2 = nullptr, *d_w3t = nullptr, *d_b3 = nullptr;
+    int relu3 = 1;
+    // resize tables for the current source size
+    int rows = 0, cols = 0;
+    int32_t *d_xofs = nullptr, *d_yofs = nullptr; int16_t *d_xa = nullptr, *d_yb = nullptr;
+    // batch buffers
+    int batchCap = 0; size_t blurBytes = 0; int blurPitch = 0;
+    uint8_t* d_blur = nullptr;
+    float *d_in = nullptr, *d_a1 = nullptr, *d_p1 = nullptr, *d_a2 = nullptr, *d_p2 = nullptr;
+    // host-entry staging
+    uint8_t* d_stageImg = nullptr; size_t stageBytes = 0; float* d_stageOut = nullptr;
+
+    int ensure_tables(int r, int c);
+    int ensure_batch(int batch, int r, int c);
+    int forward(int batch);     // d_in -> d_out
+    int describe(uint8_t* d_imgs, int batch, int r, int c, int step, size_t stride, int blur_in_place, float* d_out);
+};
+
+template <typename T>
+static int lcd_alloc(T*& p, size_t n) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    if (!n) return MYSLAM_OK;
+    MYSLAM_HIP_CHECK(hipMalloc((void**)&p, n * sizeof(T)));
+    return MYSLAM_OK;
+}
+
+int myslam_lcd::ensure_tables(int r, int c) {
+    if (r == rows && c == cols) return MYSLAM_OK;
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(stream));
+    std::vector<int32_t> xo, yo; std::vector<int16_t> xa, yb;
+    lcd_resize_tables(c, IN_W, true, xo, xa);
+    lcd_resize_tables(r, IN_H, false, yo, yb);
+    int rc;
+    if ((rc = lcd_alloc(d_xofs, xo.size())) || (rc = lcd_alloc(d_xa, xa.size())) || (rc = lcd_alloc(d_yofs, yo.size())) ||
+        (rc = lcd_alloc(d_yb, yb.size())))
+        return rc;
+    MYSLAM_HIP_CHECK(hipMemcpy(d_xofs, xo.data(), xo.size() * 4, hipMemcpyHostToDevice));
+    MYSLAM_HIP_CHECK(hipMemcpy(d_xa, xa.data(), xa.size() * 2, hipMemcpyHostToDevice));
+    MYSLAM_HIP_CHECK(hipMemcpy(d_yofs, yo.data(), yo.size() * 4, hipMemcpyHostToDevice));
+    MYSLAM_HIP_CHECK(hipMemcpy(d_yb, yb.data(), yb.size() * 2, hipMemcpyHostToDevice));
+    rows = r; cols = c; batchCap = 0;
+    return MYSLAM_OK;
+}
+
+int myslam_lcd::ensure_batch(int batch, int r, int c) {
+    int rc = ensure_tables(r, c);
+    if (rc) return rc;
+    if (batch <= batchCap) return MYSLAM_OK;
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(stream));
+    blurPitch = (c + 63) / 64 * 64;
+    blurBytes = ((size_t)blurPitch * r + 255) / 256 * 256;
+    if ((rc = lcd_alloc(d_blur, blurBytes * batch))) return rc;
+    if ((rc = lcd_alloc(d_in, (size_t)batch * IN_H * IN_W))) return rc;
+    if ((rc = lcd_alloc(d_a1, (size_t)batch * H1 * W1 * C1))) return rc;
+    if ((rc = lcd_alloc(d_p1, (size_t)batch * HP1 * WP1 * C1))) return rc;
+    if ((rc = lcd_alloc(d_a2, (size_t)batch * H2 * W2 * C2))) return rc;
+    if ((rc = lcd_alloc(d_p2, (size_t)batch * HP2 * WP2 * C2))) return rc;
+    batchCap = batch;
+    return MYSLAM_OK;
+}
+
+static int lcd_forward(myslam_lcd* h, int batch, float* d_out) {
+    hipStream_t s = h->stream;
+    {
+        ScopedProf sp(P_CONV1, s);
+        hipLaunchKernelGGL(k_conv1, dim3((H1 * W1 + 31) / 32, batch), dim3(256), 0, s, h->d_in, h->d_w1t, h->d_b1, h->d_a1);
+        hipLaunchKernelGGL((k_pool_lrn<C1>), dim3((HP1 * WP1 + 3) / 4, batch), dim3(256), 0, s, h->d_a1, H1, W1, HP1, WP1, h->d_p1);
+    }
+    {
+        ScopedProf sp(P_CONV2, s);
+        const int Mtotal = batch * M2;
+        hipLaunchKernelGGL(k_conv2_mfma, dim3((Mtotal + CV_BM - 1) / CV_BM), dim3(256), 0, s, h->d_p1, h->d_w2t, h->d_b2, h->d_a2, Mtotal);
+    }
+    {
+        ScopedProf sp(P_CONV3, s);
+        hipLaunchKernelGGL((k_pool_lrn<C2>), dim3((HP2 * WP2 + 3) / 4, batch), dim3(256), 0, s, h->d_a2, H2, W2, HP2, WP2, h->d_p2);
+        hipLaunchKernelGGL(k_conv3_norm, dim3(batch), dim3(256), 0, s, h->d_p2, h->d_w3t, h->d_b3, d_out, h->relu3);
+    }
+    MYSLAM_HIP_CHECK(hipGetLastError());
+    return MYSLAM_OK;
+}
+
+int myslam_lcd::describe(uint8_t* d_imgs, int batch, int r, int c, int step, size_t stride, int blur_in_place, float* d_out) {
+    if (!d_imgs || batch <= 0 || r <= 0 || c <= 0 || step < c || !d_out) return MYSLAM_ERR_INVALID;
+    int rc = ensure_batch(batch, r, c);
+    if (rc) return rc;
+    {
+        ScopedProf sp(P_LCD_PRE, stream);
+        BlurArgs a;                                   // GaussianBlur(img, img, Size(7,7), 0)  deeplcd.cpp:46
+        a.src = d_imgs; a.dst = d_blur; a.w = c; a.h = r; a.spitch = step; a.dpitch = blurPitch; a.sstride = stride; a.dstride = blurBytes;
+        gauss_q8(1, a.q);
+        launch_blur(a, batch, stream);
+        if (blur_in_place)                            // the reference mutates the caller's pixels
+            for (int b = 0; b < batch; b++)
+                MYSLAM_HIP_CHECK(hipMemcpy2DAsync(d_imgs + (size_t)b * stride, step, d_blur + (size_t)b * blurBytes, blurPitch, c, r,
+                                                  hipMemcpyDeviceToDevice, stream));
+        hipLaunchKernelGGL(k_lcd_input, dim3((IN_H * IN_W + 255) / 256, batch), dim3(256), 0, stream, d_blur, c, r, blurPitch, blurBytes,
+                           d_xofs, d_xa, d_yofs, d_yb, d_in);       // cv::resize(.., Size(160,120))  deeplcd.cpp:48-50
+    }
+    return lcd_forward(this, batch, d_out);
+}
+
+extern "C" {
+
+size_t myslam_lcd_nweights(void) { return NWEIGHTS; }
+
+int myslam_lcd_create(myslam_lcd** out, const float* weights, size_t nweights) {
+    if (!out || !weights || nweights != NWEIGHTS) return MYSLAM_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MYSLAM_ERR_HIP;
+    const float* w1 = weights;            const float* b1 = w1 + 64 * 25;
+    const float* w2 = b1 + 64;            const float* b2 = w2 + 128 * 64 * 16;
+    const float* w3 = b2 + 128;           const float* b3 = w3 + 4 * 128 * 9;
+    std::vector<float> w1t(25 * 64), w2t((size_t)K2 * 128), w3t(1152 * 4);
+    for (int oc = 0; oc < 64; oc++) for (int k = 0; k < 25; k++) w1t[k * 64 + oc] = w1[oc * 25 + k];
+    for (int oc = 0; oc < 128; oc++)
+        for (int ic = 0; ic < 64; ic++)
+            for (int t = 0; t < 16; t++) w2t[((size_t)t * 64 + ic) * 128 + oc] = w2[((size_t)oc * 64 + ic) * 16 + t];
+    for (int oc = 0; oc < 4; oc++)
+        for (int ic = 0; ic < 128; ic++)
+            for (int t = 0; t < 9; t++) w3t[((size_t)t * 128 + ic) * 4 + oc] = w3[((size_t)oc * 128 + ic) * 9 + t];
+    myslam_lcd* h = new myslam_lcd();
+    auto up = [&](float*& d, const float* src, size_t n) -> int {
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&d, n * sizeof(float)));
+        MYSLAM_HIP_CHECK(hipMemcpy(d, src, n * sizeof(float), hipMemcpyHostToDevice));
+        return MYSLAM_OK;
+    };
+    int rc;
+    if ((rc = up(h->d_w1t, w1t.data(), w1t.size())) || (rc = up(h->d_b1, b1, 64)) || (rc = up(h->d_w2t, w2t.data(), w2t.size())) ||
+        (rc = up(h->d_b2, b2, 128)) || (rc = up(h->d_w3t, w3t.data(), w3t.size())) || (rc = up(h->d_b3, b3, 4))) {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return MYSLAM_OK;
+}
+
+// own flat model file: magic "CALCW1\0\0", uint64 count, then count f32 (little endian)
+int myslam_lcd_create_from_file(myslam_lcd** out, const char* path) {
+    if (!out || !path) return MYSLAM_ERR_INVALID;
+    FILE* f = fopen(path, "rb");
+    if (!f) return MYSLAM_ERR_INVALID;
+    char magic[8]; uint64_t n = 0;
+    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "CALCW1\0\0", 8) != 0 || fread(&n, 8, 1, f) != 1 || n != NWEIGHTS) { fclose(f); return MYSLAM_ERR_INVALID; }
+    std::vector<float> w(n);
+    const size_t got = fread(w.data(), sizeof(float), n, f);
+    fclose(f);
+    if (got != n) return MYSLAM_ERR_INVALID;
+    return myslam_lcd_create(out, w.data(), n);
+}
+
+int myslam_lcd_destroy(myslam_lcd* h) {
+    if (!h) return MYSLAM_ERR_INVALID;
+    (void)hipStreamSynchronize(h->stream);
+    void* ptrs[] = {h->d_w1t, h->d_b1, h->d_w2t, h->d_b2, h->d_w3t, h->d_b3, h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_blur,
+                    h->d_in, h->d_a1, h->d_p1, h->d_a2, h->d_p2, h->d_stageImg, h->d_stageOut};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    delete h;
+    return MYSLAM_OK;
+}
+
+int myslam_lcd_set_stream(myslam_lcd* h, void* s) {
+    if (!h) return MYSLAM_ERR_INVALID;
+    (void)hipStreamSynchronize(h->stream);
+    h->stream = (hipStream_t)s;
+    return MYSLAM_OK;
+}
+
+float myslam_lcd_score(const float* d1, const float* d2) {      // deeplcd.cpp:35-39 (host: 1064 FMAs)
+    float s = 0;
+    for (int i = 0; i < MYSLAM_LCD_DIM; i++) s += d1[i] * d2[i];
+    return s;
+}
+
+int myslam_lcd_describe_batch(myslam_lcd* h, uint8_t* d_imgs, int batch, int rows, int cols, int step, size_t img_stride,
+                              int blur_in_place, float* d_descr) {
+    if (!h) return MYSLAM_ERR_INVALID;
+    return h->describe(d_imgs, batch, rows, cols, step, img_stride, blur_in_place, d_descr);
+}
+
+static int lcd_stage(myslam_lcd* h, size_t bytes) {
+    if (bytes > h->stageBytes) { int rc = lcd_alloc(h->d_stageImg, bytes); if (rc) return rc; h->stageBytes = bytes; }
+    if (!h->d_stageOut) { int rc = lcd_alloc(h->d_stageOut, (size_t)MYSLAM_LCD_DIM); if (rc) return rc; }
+    return MYSLAM_OK;
+}
+
+int myslam_lcd_calc_descr_original_img(myslam_lcd* h, uint8_t* img, int rows, int cols, int step, int blur_in_place, float* descr) {
+    if (!h || !img || !descr || rows <= 0 || cols <= 0 || step < cols) return MYSLAM_ERR_INVALID;   // reference asserts !empty
+    int rc = lcd_stage(h, (size_t)rows * step);
+    if (rc) return rc;
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_stageImg, img, (size_t)rows * step, hipMemcpyHostToDevice, h->stream));
+    if ((rc = h->describe(h->d_stageImg, 1, rows, cols, step, (size_t)rows * step, blur_in_place, h->d_stageOut))) return rc;
+    if (blur_in_place) MYSLAM_HIP_CHECK(hipMemcpyAsync(img, h->d_stageImg, (size_t)rows * step, hipMemcpyDeviceToHost, h->stream));
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(descr, h->d_stageOut, sizeof(float) * MYSLAM_LCD_DIM, hipMemcpyDeviceToHost, h->stream));
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return MYSLAM_OK;
+}
+
+int myslam_lcd_calc_descr(myslam_lcd* h, const uint8_t* img, int step, float* descr) {
+    if (!h || !img || !descr || step < IN_W) return MYSLAM_ERR_INVALID;
+    int rc = lcd_stage(h, (size_t)IN_H * step);
+    if (rc) return rc;
+    if ((rc = h->ensure_batch(1, IN_H, IN_W))) return rc;
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_stageImg, img, (size_t)IN_H * step, hipMemcpyHostToDevice, h->stream));
+    // 160x120 -> 160x120 resize is the identity in this arithmetic (weights 2048/0); reuse the input kernel
+    hipLaunchKernelGGL(k_lcd_input, dim3((IN_H * IN_W + 255) / 256, 1), dim3(256), 0, h->stream, h->d_stageImg, IN_W, IN_H, step,
+                       (size_t)IN_H * step, h->d_xofs, h->d_xa, h->d_yofs, h->d_yb, h->d_in);
+    if ((rc = lcd_forward(h, 1, h->d_stageOut))) return rc;
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(descr, h->d_stageOut, sizeof(float) * MYSLAM_LCD_DIM, hipMemcpyDeviceToHost, h->stream));
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return MYSLAM_OK;
+}
+
+// stage taps: 0 = conv1+relu [62*82][64], 1 = pool1+lrn [31*41][64], 2 = conv2+relu [32*42][128],
+//             3 = pool2+lrn [16*21][128], 4 = descriptor [1064]
+int myslam_lcd_debug_forward(myslam_lcd* h, const float* in, float* out_stage, int stage, size_t cap_floats) {
+    if (!h || !in || !out_stage || stage < 0 || stage > 4) return MYSLAM_ERR_INVALID;
+    int rc = h->ensure_batch(1, h->rows ? h->rows : IN_H, h->cols ? h->cols : IN_W);
+    if (rc) return rc;
+    if ((rc = lcd_stage(h, 16))) return rc;
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_in, in, sizeof(float) * IN_H * IN_W, hipMemcpyHostToDevice, h->stream));
+    if ((rc = lcd_forward(h, 1, h->d_stageOut))) return rc;
+    const float* src[5] = {h->d_a1, h->d_p1, h->d_a2, h->d_p2, h->d_stageOut};
+    const size_t n[5] = {(size_t)H1 * W1 * C1, (size_t)HP1 * WP1 * C1, (size_t)H2 * W2 * C2, (size_t)HP2 * WP2 * C2, MYSLAM_LCD_DIM};
+    if (cap_floats < n[stage]) return MYSLAM_ERR_CAPACITY;
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(out_stage, src[stage], n[stage] * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return MYSLAM_OK;
+}
+
+}  // extern "C"

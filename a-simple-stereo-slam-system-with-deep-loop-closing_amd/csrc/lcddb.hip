@@ -1,0 +1,217 @@
+// lcddb.hip — key-frame descriptor database and cosine scan on gfx950.
+// Replaces LoopClosing::_mvDatabase + DetectLoop()/AddToDatabase() (reference include/myslam/loopclosing.h:67,120;
+// src/loopclosing.cpp:124-161, 651-659): ascending-id scan, stop at the first KF with cur_id - id < 20,
+// maxScore (init 0, strict '>': lowest id wins ties), cnt = #{score > thr_low}.
+//
+// HBM layout: row-major f32 [capacity][1064] (4256-byte rows), ids kept on the host (ascending).
+// Scan kernel: one wave per database row, the row lives in registers (17 floats per lane) and is dotted
+// against every query of the batch, so a batch of queries streams the database from HBM exactly once.
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+namespace myslam_hip {
+
+constexpr int DIM = MYSLAM_LCD_DIM;     // 1064 = 16*64 + 40
+constexpr int DB_WAVES = 4;             // waves per block
+constexpr int DB_ROWS_PER_WAVE = 8;
+
+struct Partial { float score; int32_t idx; int32_t cnt; };
+
+__global__ __launch_bounds__(256) void k_db_scan(const float* __restrict__ db, const float* __restrict__ q, int nq,
+                                                 const int32_t* __restrict__ nvalid, float thr_low,
+                                                 Partial* __restrict__ partials /*[nblocks][nq]*/) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_db[];
+    Partial* s_p = reinterpret_cast<Partial*>(smem_db);          // [DB_WAVES][nq]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < DB_WAVES * nq; i += 256) s_p[i] = {0.f, -1, 0};
+    __syncthreads();
+    const int row0 = (blockIdx.x * DB_WAVES + wave) * DB_ROWS_PER_WAVE;
+    for (int r = row0; r < row0 + DB_ROWS_PER_WAVE; r++) {
+        const float* row = db + (size_t)r * DIM;
+        float v[17];
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = row[k * 64 + lane];
+        v[16] = (lane < DIM - 1024) ? row[1024 + lane] : 0.f;
+        for (int qi = 0; qi < nq; qi++) {
+            if (r >= nvalid[qi]) continue;                      // cut-off rule, loopclosing.cpp:133 (uniform per wave)
+            const float* qq = q + (size_t)qi * DIM;
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; k++) acc += v[k] * qq[k * 64 + lane];
+            if (lane < DIM - 1024) acc += v[16] * qq[1024 + lane];
+            acc = wave_reduce_sum(acc);
+            if (lane == 0) {
+                Partial& p = s_p[wave * nq + qi];               // rows ascend within a wave: strict '>' keeps the lowest
+                if (acc > p.score) { p.score = acc; p.idx = r; }
+                if (acc > thr_low) p.cnt++;
+            }
+        }
+    }
+    __syncthreads();
+    for (int qi = threadIdx.x; qi < nq; qi += 256) {
+        Partial best = s_p[qi];
+        for (int w = 1; w < DB_WAVES; w++) {                    // waves own ascending row ranges
+            const Partial p = s_p[w * nq + qi];
+            if (p.score > best.score) { best.score = p.score; best.idx = p.idx; }
+            best.cnt += p.cnt;
+        }
+        partials[(size_t)blockIdx.x * nq + qi] = best;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_db_reduce(const Partial* __restrict__ partials, int nblocks, int nq,
+                                                   const uint64_t* __restrict__ ids, uint64_t* __restrict__ best_id,
+                                                   float* __restrict__ max_score, int32_t* __restrict__ cnt) {
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    float ms = 0.f; int bi = -1; int c = 0;
+    for (int b = 0; b < nblocks; b++) {                         // blocks own ascending row ranges
+        const Partial p = partials[(size_t)b * nq + qi];
+        if (p.score > ms) { ms = p.score; bi = p.idx; }
+        c += p.cnt;
+    }
+    best_id[qi] = (bi >= 0) ? ids[bi] : 0;                      // bestId initialised to 0, loopclosing.cpp:129
+    max_score[qi] = ms; cnt[qi] = c;
+}
+
+}  // namespace myslam_hip
+
+using namespace myslam_hip;
+
+struct myslam_lcddb {
+    hipStream_t stream = nullptr;
+    int capacity = 0, n = 0;
+    float* d_db = nullptr;
+    uint64_t* d_ids = nullptr;
+    std::vector<uint64_t> ids;
+    Partial* d_partials = nullptr; size_t partialsCap = 0;
+    int32_t* d_nvalid = nullptr; int nvalidCap = 0;
+    float* d_q1 = nullptr; uint64_t* d_best1 = nullptr; float* d_max1 = nullptr; int32_t* d_cnt1 = nullptr;
+
+    // index of the first row the reference's scan does NOT look at: it breaks at the first id with
+    // (cur - id) < 20 in unsigned arithmetic (loopclosing.cpp:133), i.e. id in [cur-19, cur] mod 2^64
+    int first_in(uint64_t a, uint64_t b) const {
+        auto it = std::lower_bound(ids.begin(), ids.end(), a);
+        if (it != ids.end() && *it <= b) return (int)(it - ids.begin());
+        return (int)ids.size();
+    }
+    int n_valid(uint64_t cur) const {
+        if (cur >= 19) return first_in(cur - 19, cur);
+        return std::min(first_in(0, cur), first_in(UINT64_MAX - (18 - cur), UINT64_MAX));
+    }
+};
+
+extern "C" {
+
+int myslam_lcddb_create(myslam_lcddb** out, int capacity) {
+    if (!out || capacity < 1) return MYSLAM_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MYSLAM_ERR_HIP;
+    myslam_lcddb* h = new myslam_lcddb();
+    const int rowsPerBlock = DB_WAVES * DB_ROWS_PER_WAVE;
+    h->capacity = (capacity + rowsPerBlock - 1) / rowsPerBlock * rowsPerBlock;      // scan reads whole blocks of rows
+    MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_db, (size_t)h->capacity * DIM * sizeof(float)));
+    MYSLAM_HIP_CHECK(hipMemset(h->d_db, 0, (size_t)h->capacity * DIM * sizeof(float)));
+    MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_ids, (size_t)h->capacity * sizeof(uint64_t)));
+    MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_q1, DIM * sizeof(float)));
+    MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_best1, 8)); MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_max1, 4));
+    MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_cnt1, 4));
+    *out = h;
+    return MYSLAM_OK;
+}
+
+int myslam_lcddb_destroy(myslam_lcddb* h) {
+    if (!h) return MYSLAM_ERR_INVALID;
+    (void)hipStreamSynchronize(h->stream);
+    void* ptrs[] = {h->d_db, h->d_ids, h->d_partials, h->d_nvalid, h->d_q1, h->d_best1, h->d_max1, h->d_cnt1};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    delete h;
+    return MYSLAM_OK;
+}
+
+int myslam_lcddb_set_stream(myslam_lcddb* h, void* s) {
+    if (!h) return MYSLAM_ERR_INVALID;
+    (void)hipStreamSynchronize(h->stream);
+    h->stream = (hipStream_t)s;
+    return MYSLAM_OK;
+}
+
+int myslam_lcddb_size(const myslam_lcddb* h) { return h ? h->n : MYSLAM_ERR_INVALID; }
+
+static int db_append(myslam_lcddb* h, const uint64_t* ids, const float* src, int n, hipMemcpyKind kind) {
+    if (!h || !ids || !src || n < 0) return MYSLAM_ERR_INVALID;
+    if (h->n + n > h->capacity) return MYSLAM_ERR_CAPACITY;
+    for (int i = 0; i < n; i++) {
+        const uint64_t prev = (i == 0) ? (h->ids.empty() ? 0 : h->ids.back()) : ids[i - 1];
+        const bool first = (i == 0 && h->ids.empty());
+        if (!first && ids[i] <= prev) return MYSLAM_ERR_INVALID;          // std::map order: strictly ascending keys
+    }
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_db + (size_t)h->n * DIM, src, (size_t)n * DIM * sizeof(float), kind, h->stream));
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_ids + h->n, ids, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));                    // ids is a host pointer
+    h->ids.insert(h->ids.end(), ids, ids + n);
+    h->n += n;
+    return MYSLAM_OK;
+}
+
+int myslam_lcddb_append(myslam_lcddb* h, uint64_t id, const float* descr) { return db_append(h, &id, descr, 1, hipMemcpyHostToDevice); }
+
+int myslam_lcddb_append_batch(myslam_lcddb* h, const uint64_t* ids, const float* d_descr, int n) {
+    return db_append(h, ids, d_descr, n, hipMemcpyDeviceToDevice);
+}
+
+static int db_query(myslam_lcddb* h, const float* d_q, const uint64_t* cur_ids_host, int nq, float thr_low, uint64_t* d_best,
+                    float* d_max, int32_t* d_cnt) {
+    const int rowsPerBlock = DB_WAVES * DB_ROWS_PER_WAVE;
+    std::vector<int32_t> nv(nq);
+    int maxv = 0;
+    for (int i = 0; i < nq; i++) { nv[i] = h->n_valid(cur_ids_host[i]); maxv = std::max(maxv, nv[i]); }
+    const int nblocks = std::max(1, (maxv + rowsPerBlock - 1) / rowsPerBlock);
+    if (nq > h->nvalidCap) {
+        if (h->d_nvalid) (void)hipFree(h->d_nvalid);
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_nvalid, sizeof(int32_t) * nq));
+        h->nvalidCap = nq;
+    }
+    const size_t need = (size_t)nblocks * nq;
+    if (need > h->partialsCap) {
+        if (h->d_partials) (void)hipFree(h->d_partials);
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_partials, need * sizeof(Partial)));
+        h->partialsCap = need;
+    }
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_nvalid, nv.data(), sizeof(int32_t) * nq, hipMemcpyHostToDevice, h->stream));
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));                    // nv is a stack/heap temporary
+    {
+        ScopedProf sp(P_DBSCAN, h->stream);
+        const size_t lds = sizeof(Partial) * DB_WAVES * nq;
+        hipLaunchKernelGGL(k_db_scan, dim3(nblocks), dim3(256), lds, h->stream, h->d_db, d_q, nq, h->d_nvalid, thr_low, h->d_partials);
+        hipLaunchKernelGGL(k_db_reduce, dim3((nq + 255) / 256), dim3(256), 0, h->stream, h->d_partials, nblocks, nq, h->d_ids, d_best,
+                           d_max, d_cnt);
+    }
+    MYSLAM_HIP_CHECK(hipGetLastError());
+    return MYSLAM_OK;
+}
+
+int myslam_lcddb_query_batch(myslam_lcddb* h, const float* d_q, const uint64_t* cur_ids, int nq, float thr_low,
+                             uint64_t* d_best_id, float* d_max_score, int32_t* d_cnt) {
+    if (!h || !d_q || !cur_ids || nq < 1 || nq > 1024 || !d_best_id || !d_max_score || !d_cnt) return MYSLAM_ERR_INVALID;
+    return db_query(h, d_q, cur_ids, nq, thr_low, d_best_id, d_max_score, d_cnt);
+}
+
+int myslam_lcddb_query(myslam_lcddb* h, const float* descr, uint64_t cur_id, float thr_low, uint64_t* best_id, float* max_score,
+                       int* cnt) {
+    if (!h || !descr || !best_id || !max_score || !cnt) return MYSLAM_ERR_INVALID;
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_q1, descr, DIM * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    int rc = db_query(h, h->d_q1, &cur_id, 1, thr_low, h->d_best1, h->d_max1, h->d_cnt1);
+    if (rc) return rc;
+    int32_t c = 0;
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(best_id, h->d_best1, 8, hipMemcpyDeviceToHost, h->stream));
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(max_score, h->d_max1, 4, hipMemcpyDeviceToHost, h->stream));
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(&c, h->d_cnt1, 4, hipMemcpyDeviceToHost, h->stream));
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    *cnt = c;
+    return MYSLAM_OK;
+}
+
+}  // extern "C"

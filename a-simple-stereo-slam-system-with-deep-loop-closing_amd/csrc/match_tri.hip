@@ -1,0 +1,235 @@
+// match_tri.hip — 256-bit Hamming brute-force matcher and stereo triangulation for gfx950.
+//
+// Hamming: replaces cv::BFMatcher(NORM_HAMMING)::match (reference src/loopclosing.cpp:33,172): one
+// best train row per query row, ties -> lowest train index.  Integer ALU bound (xor + v_bcnt), the
+// train set of a frame (<= ~2000 x 32 B) is staged through LDS and broadcast-read by all lanes.
+//
+// Triangulation: replaces triangulation() (reference include/myslam/algorithm.h:16-33) for the
+// stereo rig (src/system.cpp:108-116,141-145): DLT 4x4, smallest right singular vector by one-sided
+// Jacobi in f64, accept iff sigma3/sigma2 < 1e-2 and z > 0 (src/frontend.cpp:400,471).
+#include <algorithm>
+
+#include "common.h"
+
+namespace myslam_hip {
+
+constexpr int HM_T = 256;        // queries per block
+constexpr int HM_CHUNK = 512;    // train rows staged per LDS chunk (16 KiB)
+
+__global__ __launch_bounds__(HM_T) void k_hamming(const uint8_t* __restrict__ q, const int32_t* __restrict__ nqv,
+                                                  const uint8_t* __restrict__ tr, const int32_t* __restrict__ ntv,
+                                                  int cap, int nq_single, int nt_single,
+                                                  int32_t* __restrict__ out_idx, int32_t* __restrict__ out_dist) {
+    __shared__ __attribute__((aligned(16))) uint4 s_t[HM_CHUNK * 2];
+    const int p = blockIdx.y;
+    const int nq = nqv ? min(nqv[p], cap) : nq_single;
+    const int nt = ntv ? min(ntv[p], cap) : nt_single;
+    const int qi = blockIdx.x * HM_T + threadIdx.x;
+    if (blockIdx.x * HM_T >= nq) return;
+    const uint4* Q = reinterpret_cast<const uint4*>(q + (size_t)p * cap * 32);
+    const uint4* T = reinterpret_cast<const uint4*>(tr + (size_t)p * cap * 32);
+    uint4 a = make_uint4(0, 0, 0, 0), b = a;
+    if (qi < nq) { a = Q[2 * qi]; b = Q[2 * qi + 1]; }
+    int best = 0x7fffffff, bidx = -1;
+    for (int j0 = 0; j0 < nt; j0 += HM_CHUNK) {
+        const int m = min(HM_CHUNK, nt - j0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * m; i += HM_T) s_t[i] = T[2 * j0 + i];
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < m; j++) {
+            const uint4 c = s_t[2 * j], d = s_t[2 * j + 1];          // broadcast reads
+            int h = __popc(a.x ^ c.x);
+            h += __popc(a.y ^ c.y); h += __popc(a.z ^ c.z); h += __popc(a.w ^ c.w);
+            h += __popc(b.x ^ d.x); h += __popc(b.y ^ d.y); h += __popc(b.z ^ d.z); h += __popc(b.w ^ d.w);
+            if (h < best) { best = h; bidx = j0 + j; }               // strict <: first (lowest) train index wins
+        }
+    }
+    if (qi < nq) {
+        out_idx[(size_t)p * cap + qi] = bidx;
+        out_dist[(size_t)p * cap + qi] = (bidx < 0) ? -1 : best;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// one-sided Jacobi SVD of the 4x4 DLT matrix (f64), fully unrolled pair loop (no runtime register indexing)
+__device__ __forceinline__ void tri_solve(const double (&P)[2][12], const double (&pt)[2][2], double* xyz, double& ratio) {
+    double A[4][4], V[4][4];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            A[2 * i][c] = pt[i][0] * P[i][8 + c] - P[i][c];            // algorithm.h:23
+            A[2 * i + 1][c] = pt[i][1] * P[i][8 + c] - P[i][4 + c];    // algorithm.h:24
+        }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) V[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int q = p + 1; q < 4; q++) {
+                double alpha = 0, beta = 0, gamma = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) { alpha += A[i][p] * A[i][p]; beta += A[i][q] * A[i][q]; gamma += A[i][p] * A[i][q]; }
+                const double lim = 1e-30 + 1e-17 * sqrt(alpha * beta);
+                if (gamma != 0.0 && fabs(gamma) > lim) {
+                    off = fmax(off, fabs(gamma) / sqrt(alpha * beta + 1e-300));
+                    const double zeta = (beta - alpha) / (2.0 * gamma);
+                    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const double ap = A[i][p], aq = A[i][q];
+                        A[i][p] = c * ap - s * aq; A[i][q] = s * ap + c * aq;
+                        const double vp = V[i][p], vq = V[i][q];
+                        V[i][p] = c * vp - s * vq; V[i][q] = s * vp + c * vq;
+                    }
+                }
+            }
+        if (off < 1e-15) break;
+    }
+    double sv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) sv[j] = sqrt(A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j] + A[3][j] * A[3][j]);
+    // smallest and second smallest singular value; V column of the smallest
+    double s_min = sv[0], v0 = V[0][0], v1 = V[1][0], v2 = V[2][0], v3 = V[3][0];
+#pragma unroll
+    for (int j = 1; j < 4; j++)
+        if (sv[j] < s_min) { s_min = sv[j]; v0 = V[0][j]; v1 = V[1][j]; v2 = V[2][j]; v3 = V[3][j]; }
+    double s_2nd = 1e300;
+    bool skipped = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (!skipped && sv[j] == s_min) { skipped = true; continue; }
+        s_2nd = fmin(s_2nd, sv[j]);
+    }
+    xyz[0] = v0 / v3; xyz[1] = v1 / v3; xyz[2] = v2 / v3;              // algorithm.h:27
+    ratio = s_min / s_2nd;                                             // algorithm.h:29
+}
+
+__global__ __launch_bounds__(256) void k_triangulate(const float* __restrict__ xl, const float* __restrict__ yl,
+                                                     const float* __restrict__ xr, const float* __restrict__ yr,
+                                                     const myslam_keypoint* __restrict__ kl, const myslam_keypoint* __restrict__ kr,
+                                                     const int32_t* __restrict__ match, const int32_t* __restrict__ nlv,
+                                                     int cap, int n_single, double fx, double fy, double cx, double cy,
+                                                     double baseline, double* __restrict__ xyz, uint8_t* __restrict__ ok) {
+    const int p = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int n = nlv ? min(nlv[p], cap) : n_single;
+    if (i >= n) return;
+    const size_t o = (size_t)p * cap + i;
+    double ul, vl, ur, vr;
+    if (kl) {
+        const int j = match[o];
+        if (j < 0) { ok[o] = 0; xyz[3 * o] = xyz[3 * o + 1] = xyz[3 * o + 2] = 0; return; }
+        ul = kl[o].x; vl = kl[o].y;
+        const myslam_keypoint r = kr[(size_t)p * cap + j];
+        ur = r.x; vr = r.y;
+    } else { ul = xl[i]; vl = yl[i]; ur = xr[i]; vr = yr[i]; }
+    const double P[2][12] = {{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0},
+                             {1, 0, 0, -baseline, 0, 1, 0, 0, 0, 0, 1, 0}};      // system.cpp:108-116,141-145
+    const double pt[2][2] = {{(ul - cx) / fx, (vl - cy) / fy}, {(ur - cx) / fx, (vr - cy) / fy}};   // camera.cpp:22-26
+    double X[3], ratio;
+    tri_solve(P, pt, X, ratio);
+    xyz[3 * o] = X[0]; xyz[3 * o + 1] = X[1]; xyz[3 * o + 2] = X[2];
+    ok[o] = (ratio < 1e-2 && X[2] > 0) ? 1 : 0;
+}
+
+}  // namespace myslam_hip
+
+using namespace myslam_hip;
+
+extern "C" {
+
+int myslam_hamming_match_batch(const uint8_t* d_q, const int32_t* d_nq, const uint8_t* d_t, const int32_t* d_nt, int batch,
+                               int cap, int32_t* d_train_idx, int32_t* d_dist, void* hip_stream) {
+    if (!d_q || !d_t || !d_nq || !d_nt || batch <= 0 || cap <= 0 || !d_train_idx || !d_dist) return MYSLAM_ERR_INVALID;
+    hipStream_t s = (hipStream_t)hip_stream;
+    ScopedProf sp(P_MATCH, s);
+    hipLaunchKernelGGL(k_hamming, dim3((cap + HM_T - 1) / HM_T, batch), dim3(HM_T), 0, s, d_q, d_nq, d_t, d_nt, cap, 0, 0,
+                       d_train_idx, d_dist);
+    MYSLAM_HIP_CHECK(hipGetLastError());
+    return MYSLAM_OK;
+}
+
+int myslam_hamming_match(const uint8_t* query, int nq, const uint8_t* train, int nt, int32_t* train_idx, int32_t* dist) {
+    if (nq < 0 || nt < 0) return MYSLAM_ERR_INVALID;
+    if (nq == 0) return MYSLAM_OK;
+    if (!query || !train_idx || !dist || (nt > 0 && !train)) return MYSLAM_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MYSLAM_ERR_HIP;
+    uint8_t *dq = nullptr, *dt = nullptr; int32_t *di = nullptr, *dd = nullptr;
+    const int cap = std::max(nq, std::max(nt, 1));
+    MYSLAM_HIP_CHECK(hipMalloc((void**)&dq, (size_t)cap * 32)); MYSLAM_HIP_CHECK(hipMalloc((void**)&dt, (size_t)cap * 32));
+    MYSLAM_HIP_CHECK(hipMalloc((void**)&di, (size_t)cap * 4)); MYSLAM_HIP_CHECK(hipMalloc((void**)&dd, (size_t)cap * 4));
+    MYSLAM_HIP_CHECK(hipMemcpy(dq, query, (size_t)nq * 32, hipMemcpyHostToDevice));
+    if (nt) MYSLAM_HIP_CHECK(hipMemcpy(dt, train, (size_t)nt * 32, hipMemcpyHostToDevice));
+    {
+        ScopedProf sp(P_MATCH, nullptr);
+        hipLaunchKernelGGL(k_hamming, dim3((nq + HM_T - 1) / HM_T, 1), dim3(HM_T), 0, nullptr, dq, (const int32_t*)nullptr, dt,
+                           (const int32_t*)nullptr, cap, nq, nt, di, dd);
+    }
+    MYSLAM_HIP_CHECK(hipGetLastError());
+    MYSLAM_HIP_CHECK(hipMemcpy(train_idx, di, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    MYSLAM_HIP_CHECK(hipMemcpy(dist, dd, (size_t)nq * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(dq); (void)hipFree(dt); (void)hipFree(di); (void)hipFree(dd);
+    return MYSLAM_OK;
+}
+
+// src/loopclosing.cpp:175-186 — host bookkeeping (a handful of compares)
+int myslam_hamming_filter(const int32_t* dist, int n, uint8_t* keep, int* min_dist) {
+    if (n < 0 || (n > 0 && (!dist || !keep))) return MYSLAM_ERR_INVALID;
+    if (n == 0) { if (min_dist) *min_dist = 0; return MYSLAM_OK; }
+    int mn = dist[0];
+    for (int i = 1; i < n; i++) mn = std::min(mn, dist[i]);
+    const double lim = std::max(2.0 * (double)mn, 30.0);
+    for (int i = 0; i < n; i++) keep[i] = ((double)dist[i] <= lim) ? 1 : 0;
+    if (min_dist) *min_dist = mn;
+    return MYSLAM_OK;
+}
+
+int myslam_triangulate_stereo_batch(const myslam_keypoint* d_kps_l, const myslam_keypoint* d_kps_r, const int32_t* d_match,
+                                    const int32_t* d_nl, int batch, int cap, double fx, double fy, double cx, double cy,
+                                    double baseline, double* d_xyz, uint8_t* d_ok, void* hip_stream) {
+    if (!d_kps_l || !d_kps_r || !d_match || !d_nl || batch <= 0 || cap <= 0 || !d_xyz || !d_ok) return MYSLAM_ERR_INVALID;
+    hipStream_t s = (hipStream_t)hip_stream;
+    ScopedProf sp(P_TRI, s);
+    hipLaunchKernelGGL(k_triangulate, dim3((cap + 255) / 256, batch), dim3(256), 0, s, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, d_kps_l, d_kps_r, d_match, d_nl, cap, 0, fx, fy, cx, cy,
+                       baseline, d_xyz, d_ok);
+    MYSLAM_HIP_CHECK(hipGetLastError());
+    return MYSLAM_OK;
+}
+
+int myslam_triangulate_stereo(const float* xl, const float* yl, const float* xr, const float* yr, int n, double fx, double fy,
+                              double cx, double cy, double baseline, double* xyz, uint8_t* ok) {
+    if (n < 0) return MYSLAM_ERR_INVALID;
+    if (n == 0) return MYSLAM_OK;
+    if (!xl || !yl || !xr || !yr || !xyz || !ok) return MYSLAM_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MYSLAM_ERR_HIP;
+    float* d_in = nullptr; double* d_xyz = nullptr; uint8_t* d_ok = nullptr;
+    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_in, (size_t)n * 16)); MYSLAM_HIP_CHECK(hipMalloc((void**)&d_xyz, (size_t)n * 24));
+    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_ok, (size_t)n));
+    MYSLAM_HIP_CHECK(hipMemcpy(d_in, xl, (size_t)n * 4, hipMemcpyHostToDevice));
+    MYSLAM_HIP_CHECK(hipMemcpy(d_in + n, yl, (size_t)n * 4, hipMemcpyHostToDevice));
+    MYSLAM_HIP_CHECK(hipMemcpy(d_in + 2 * n, xr, (size_t)n * 4, hipMemcpyHostToDevice));
+    MYSLAM_HIP_CHECK(hipMemcpy(d_in + 3 * n, yr, (size_t)n * 4, hipMemcpyHostToDevice));
+    {
+        ScopedProf sp(P_TRI, nullptr);
+        hipLaunchKernelGGL(k_triangulate, dim3((n + 255) / 256, 1), dim3(256), 0, nullptr, d_in, d_in + n, d_in + 2 * n, d_in + 3 * n,
+                           (const myslam_keypoint*)nullptr, (const myslam_keypoint*)nullptr, (const int32_t*)nullptr,
+                           (const int32_t*)nullptr, n, n, fx, fy, cx, cy, baseline, d_xyz, d_ok);
+    }
+    MYSLAM_HIP_CHECK(hipGetLastError());
+    MYSLAM_HIP_CHECK(hipMemcpy(xyz, d_xyz, (size_t)n * 24, hipMemcpyDeviceToHost));
+    MYSLAM_HIP_CHECK(hipMemcpy(ok, d_ok, (size_t)n, hipMemcpyDeviceToHost));
+    (void)hipFree(d_in); (void)hipFree(d_xyz); (void)hipFree(d_ok);
+    return MYSLAM_OK;
+}
+
+}  // extern "C"

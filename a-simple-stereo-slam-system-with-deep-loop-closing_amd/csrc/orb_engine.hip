@@ -1,0 +1,533 @@
+// orb_engine.hip — host side of the ORB extractor: geometry plan, HBM buffers, kernel sequencing and
+// the C-ABI entry points that replace class ORBextractor (include/myslam/ORBextractor.h:52-110).
+//
+// Data layout in HBM (per image b of a batch, all planes 64-byte pitched, 256-byte aligned):
+//   pyramid block  : levels 0..L-1 back to back (level 0 is ingested from the caller's buffer)
+//   blurred block  : same geometry, 7x7 sigma=2 Gaussian of every level
+//   candidates     : per level a u32 list  py<<20 | px<<8 | score   (+ count)
+//   sort buffers   : per level 2 x u64 (path code<<32 | payload)
+//   selected keys  : per level <= N+3 payloads in oct-tree list order (+ count)
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+#include "orb_plan.h"
+
+namespace myslam_hip {
+
+void launch_resize(const ResizeArgs& a, int batch, hipStream_t s);
+void launch_blur(const BlurArgs& a, int batch, hipStream_t s);
+void launch_fast(const OrbPlan& P, const uint8_t* pyr, size_t pyrStride, const uint8_t* maskPyr, uint32_t* cand,
+                 int32_t* candCount, int batch, hipStream_t s);
+void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCount, uint64_t* sortbuf, uint32_t* selOut,
+                   int32_t* selCount, int32_t* status, int batch, hipStream_t s);
+void launch_describe(const OrbPlan& P, const uint8_t* pyr, const uint8_t* blur, size_t pyrStride, const uint32_t* selOut,
+                     const int32_t* selCount, myslam_keypoint* kps, uint8_t* desc, int32_t* counts, int32_t* status,
+                     int cap, int detectOnly, int batch, hipStream_t s);
+void launch_screen(const OrbPlan& P, const uint8_t* pyr, myslam_keypoint* kin, int n, myslam_keypoint* kout, uint8_t* keep,
+                   hipStream_t s);
+void launch_calc_desc(const OrbPlan& P, const uint8_t* blur, const myslam_keypoint* kps, int n, uint8_t* desc, hipStream_t s);
+void launch_unpack_cands(const uint32_t* cand, int n, int32_t* xs, int32_t* ys, int32_t* sc, hipStream_t s);
+void launch_ingest(const uint8_t* src, int rows, int cols, int step, size_t sstride, uint8_t* dst, int dpitch,
+                   size_t dstride, int batch, hipStream_t s);
+
+static inline int cv_round(float v) { return (int)lrintf(v); }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Gaussian taps in Q8 (sum 256).  kind 0: sigma = 2 (ORBextractor.cpp:966); kind 1: OpenCV's fixed
+// 7-tap table used when sigma <= 0 (deeplcd.cpp:46).
+void gauss_q8(int kind, int q[7]) {
+    if (kind == 1) { const int t[7] = {8, 28, 56, 72, 56, 28, 8}; memcpy(q, t, sizeof(t)); return; }
+    double g[7], sum = 0;
+    for (int i = 0; i < 7; i++) { double x = i - 3; g[i] = exp(-(x * x) / 8.0); sum += g[i]; }
+    int qs = 0;
+    for (int i = 0; i < 7; i++) { q[i] = (int)lrint(g[i] / sum * 256.0); qs += q[i]; }
+    q[3] += 256 - qs;
+}
+
+// cv::resize INTER_LINEAR coefficient tables (OpenCV 3.4 resize.cpp: fx = (dx+0.5)*scale-0.5, 11-bit weights)
+static void resize_tables(int ssize, int dsize, bool is_x, std::vector<int32_t>& ofs, std::vector<int16_t>& coef) {
+    const double inv_scale = (double)dsize / ssize;
+    const double scale = 1. / inv_scale;
+    ofs.resize(dsize); coef.resize(2 * dsize);
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= s;
+        if (is_x) {
+            if (s < 0) { f = 0; s = 0; }
+            if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+        }
+        ofs[d] = s;
+        coef[2 * d] = (int16_t)cv_round((1.f - f) * 2048.f);
+        coef[2 * d + 1] = (int16_t)cv_round(f * 2048.f);
+    }
+}
+
+template <typename T>
+static int dev_alloc(T*& p, size_t n) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    if (n == 0) return MYSLAM_OK;
+    MYSLAM_HIP_CHECK(hipMalloc((void**)&p, n * sizeof(T)));
+    return MYSLAM_OK;
+}
+
+}  // namespace myslam_hip
+
+using namespace myslam_hip;
+
+struct myslam_orb {
+    int nfeatures, nlevels, iniTh, minTh;
+    float scaleFactor;
+    std::vector<float> scale, invScale;
+    std::vector<int> nPerLevel;
+    int umax[16];
+    hipStream_t stream = nullptr;
+
+    // plan for the current image size
+    int rows = 0, cols = 0;
+    OrbPlan full{}, det{};
+    std::vector<int32_t*> d_xofs, d_yofs;
+    std::vector<int16_t*> d_xa, d_yb;
+
+    // batch buffers
+    int batchCap = 0;
+    bool maskAlloc = false;
+    uint8_t *d_pyr = nullptr, *d_blur = nullptr, *d_mask = nullptr;
+    uint32_t* d_cand = nullptr;
+    uint64_t* d_sort = nullptr;
+    int32_t *d_candCount = nullptr, *d_selCount = nullptr, *d_status = nullptr;
+    uint32_t* d_sel = nullptr;
+
+    // staging for the host-buffer entry points
+    uint8_t *d_stageImg = nullptr, *d_stageMask = nullptr; size_t stageImgBytes = 0, stageMaskBytes = 0;
+    myslam_keypoint *d_stageKps = nullptr, *d_stageKps2 = nullptr; uint8_t* d_stageDesc = nullptr; uint8_t* d_stageKeep = nullptr;
+    int32_t* d_stageCounts = nullptr; int stageCap = 0;
+
+    int make_tables();
+    int make_plan(int r, int c);
+    int ensure(int batch, int r, int c, bool needMask);
+    int ensure_stage(size_t imgBytes, size_t maskBytes, int cap);
+    int build_pyramids(const uint8_t* d_imgs, int batch, int step, size_t stride, const uint8_t* d_masks, int nlev);
+    int blur_levels(int batch, int nlev);
+    int run_batch(const uint8_t* d_imgs, int batch, int r, int c, int step, size_t stride, const uint8_t* d_masks,
+                  myslam_keypoint* d_kps, uint8_t* d_desc, int32_t* d_counts, int32_t* d_stat, int cap, bool detectOnly);
+    void free_all();
+};
+
+// ORBextractor::ORBextractor, src/ORBextractor.cpp:384-445
+int myslam_orb::make_tables() {
+    scale.assign(nlevels, 1.f); invScale.assign(nlevels, 1.f); nPerLevel.assign(nlevels, 0);
+    for (int i = 1; i < nlevels; i++) scale[i] = scale[i - 1] * scaleFactor;
+    for (int i = 0; i < nlevels; i++) invScale[i] = 1.0f / scale[i];
+    float factor = 1.0f / scaleFactor;
+    float nDesired = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int l = 0; l < nlevels - 1; l++) { nPerLevel[l] = cv_round(nDesired); sum += nPerLevel[l]; nDesired *= factor; }
+    nPerLevel[nlevels - 1] = std::max(nfeatures - sum, 0);
+    int v, v0, vmax = (int)floor(HALF_PATCH * sqrtf(2.f) / 2 + 1), vmin = (int)ceil(HALF_PATCH * sqrtf(2.f) / 2);
+    const double hp2 = HALF_PATCH * HALF_PATCH;
+    for (v = 0; v < 16; v++) umax[v] = 0;
+    for (v = 0; v <= vmax; ++v) umax[v] = (int)lrint(sqrt(hp2 - v * v));
+    for (v = HALF_PATCH, v0 = 0; v >= vmin; --v) { while (umax[v0] == umax[v0 + 1]) ++v0; umax[v] = v0; ++v0; }
+    const int expect[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};   // baked into c_umax
+    for (v = 0; v < 16; v++) if (umax[v] != expect[v]) return MYSLAM_ERR_INVALID;
+    return MYSLAM_OK;
+}
+
+static int ceil_log2(int v) { int b = 0; while ((1 << b) < v) b++; return b; }
+
+int myslam_orb::make_plan(int r, int c) {
+    OrbPlan P{};
+    P.nlevels = nlevels; P.rows = r; P.cols = c; P.iniTh = iniTh; P.minTh = minTh;
+    size_t imgOff = 0, keyOff = 0; int cellBase = 0, outBase = 0;
+    for (int l = 0; l < nlevels; l++) {
+        LevelGeom& g = P.lv[l];
+        g.w = cv_round((float)c * invScale[l]);                 // ORBextractor.cpp:1237-1238
+        g.h = cv_round((float)r * invScale[l]);
+        if (g.w < 1 || g.h < 1) return MYSLAM_ERR_UNSUPPORTED;
+        g.pitch = (int)align_up(g.w, 64);
+        g.maxBX = g.w - EDGE_THRESHOLD + 3; g.maxBY = g.h - EDGE_THRESHOLD + 3;
+        const float width = (float)(g.maxBX - MIN_BORDER), height = (float)(g.maxBY - MIN_BORDER);
+        const float W = 30;
+        g.nCols = (int)(width / W); g.nRows = (int)(height / W);  // :833-834
+        if (g.nCols < 1 || g.nRows < 1) return MYSLAM_ERR_UNSUPPORTED;      // reference divides by zero
+        g.wCell = (int)ceilf(width / g.nCols); g.hCell = (int)ceilf(height / g.nRows);
+        if (g.wCell > MAX_CELL || g.hCell > MAX_CELL) return MYSLAM_ERR_UNSUPPORTED;
+        if (g.maxBX + 3 > 4095 + MIN_BORDER || g.maxBY + 3 > 4095 + MIN_BORDER) return MYSLAM_ERR_UNSUPPORTED;
+        g.cellBase = cellBase; cellBase += g.nCols * g.nRows;
+        g.N = nPerLevel[l];
+        g.nIni = (int)roundf((float)(g.maxBX - MIN_BORDER) / (g.maxBY - MIN_BORDER));   // :590
+        if (g.nIni < 1 || g.nIni > 64) return MYSLAM_ERR_UNSUPPORTED;
+        g.hX = (float)(g.maxBX - MIN_BORDER) / g.nIni;                                  // :592
+        g.rootPasses = (ceil_log2(g.nIni) + 1) / 2;
+        const int rootW = (int)ceilf(g.hX) + 2, H = g.maxBY - MIN_BORDER;
+        g.ndepth = std::min(MAX_DEPTH, ceil_log2(std::max(rootW, H)) + 2);
+        g.keyCap = (int)std::min<size_t>(65535, std::max<size_t>(256, (size_t)g.w * g.h / 12));
+        g.nodeCap = (std::max(g.N + 4, 4 * g.nIni + 4) + 3) & ~3;
+        g.outBase = outBase; outBase += g.nodeCap;
+        g.scale = scale[l];
+        g.scaledPatch = (float)(int)(PATCH_SIZE * scale[l]);                            // :891
+        g.imgOff = imgOff; imgOff += align_up((size_t)g.pitch * g.h, 256);
+        g.keyOff = keyOff; keyOff += g.keyCap;
+    }
+    P.ncells = cellBase; P.totalKeyCap = (int)keyOff; P.totalOut = outBase; P.pyrBytes = imgOff;
+    full = P;
+    // Detect(): level 0 only, budget = nfeatures (ORBextractor.cpp:1064-1065)
+    det = P;
+    det.nlevels = 1;
+    det.ncells = P.lv[0].nCols * P.lv[0].nRows;
+    det.lv[0].N = nfeatures;
+    det.lv[0].nodeCap = (std::max(nfeatures + 4, 4 * P.lv[0].nIni + 4) + 3) & ~3;
+    det.lv[0].outBase = 0;
+    det.totalOut = det.lv[0].nodeCap;
+    // resize tables
+    for (auto p : d_xofs) if (p) (void)hipFree(p);
+    for (auto p : d_yofs) if (p) (void)hipFree(p);
+    for (auto p : d_xa) if (p) (void)hipFree(p);
+    for (auto p : d_yb) if (p) (void)hipFree(p);
+    d_xofs.assign(nlevels, nullptr); d_yofs.assign(nlevels, nullptr); d_xa.assign(nlevels, nullptr); d_yb.assign(nlevels, nullptr);
+    for (int l = 1; l < nlevels; l++) {
+        std::vector<int32_t> xo, yo; std::vector<int16_t> xa, yb;
+        resize_tables(P.lv[l - 1].w, P.lv[l].w, true, xo, xa);
+        resize_tables(P.lv[l - 1].h, P.lv[l].h, false, yo, yb);
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&d_xofs[l], xo.size() * 4)); MYSLAM_HIP_CHECK(hipMalloc((void**)&d_xa[l], xa.size() * 2));
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&d_yofs[l], yo.size() * 4)); MYSLAM_HIP_CHECK(hipMalloc((void**)&d_yb[l], yb.size() * 2));
+        MYSLAM_HIP_CHECK(hipMemcpy(d_xofs[l], xo.data(), xo.size() * 4, hipMemcpyHostToDevice));
+        MYSLAM_HIP_CHECK(hipMemcpy(d_xa[l], xa.data(), xa.size() * 2, hipMemcpyHostToDevice));
+        MYSLAM_HIP_CHECK(hipMemcpy(d_yofs[l], yo.data(), yo.size() * 4, hipMemcpyHostToDevice));
+        MYSLAM_HIP_CHECK(hipMemcpy(d_yb[l], yb.data(), yb.size() * 2, hipMemcpyHostToDevice));
+    }
+    rows = r; cols = c;
+    return MYSLAM_OK;
+}
+
+int myslam_orb::ensure(int batch, int r, int c, bool needMask) {
+    if (r != rows || c != cols) {
+        MYSLAM_HIP_CHECK(hipStreamSynchronize(stream));
+        int rc = make_plan(r, c);
+        if (rc) { rows = cols = 0; return rc; }
+        batchCap = 0;
+    }
+    const int detOut = det.totalOut;
+    const size_t selPer = (size_t)std::max(full.totalOut, detOut);
+    if (batch > batchCap) {
+        MYSLAM_HIP_CHECK(hipStreamSynchronize(stream));
+        int rc;
+        if ((rc = dev_alloc(d_pyr, (size_t)batch * full.pyrBytes))) return rc;
+        if ((rc = dev_alloc(d_blur, (size_t)batch * full.pyrBytes))) return rc;
+        if ((rc = dev_alloc(d_cand, (size_t)batch * full.totalKeyCap))) return rc;
+        if ((rc = dev_alloc(d_sort, (size_t)batch * full.totalKeyCap * 2))) return rc;
+        if ((rc = dev_alloc(d_candCount, (size_t)batch * MAXL))) return rc;
+        if ((rc = dev_alloc(d_selCount, (size_t)batch * MAXL))) return rc;
+        if ((rc = dev_alloc(d_status, (size_t)batch))) return rc;
+        if ((rc = dev_alloc(d_sel, (size_t)batch * selPer))) return rc;
+        if ((rc = dev_alloc(d_mask, 0))) return rc;
+        maskAlloc = false;
+        batchCap = batch;
+    }
+    if (needMask && !maskAlloc) {
+        int rc = dev_alloc(d_mask, (size_t)batchCap * full.pyrBytes);
+        if (rc) return rc;
+        maskAlloc = true;
+    }
+    return MYSLAM_OK;
+}
+
+int myslam_orb::build_pyramids(const uint8_t* d_imgs, int batch, int step, size_t stride, const uint8_t* d_masks, int nlev) {
+    const OrbPlan& P = full;
+    for (int pass = 0; pass < (d_masks ? 2 : 1); pass++) {
+        uint8_t* base = pass ? d_mask : d_pyr;
+        const uint8_t* src = pass ? d_masks : d_imgs;
+        launch_ingest(src, P.rows, P.cols, step, stride, base + P.lv[0].imgOff, P.lv[0].pitch, P.pyrBytes, batch, stream);
+        for (int l = 1; l < nlev; l++) {                       // ComputePyramid, ORBextractor.cpp:1235-1246
+            ScopedProf sp(P_RESIZE, stream);
+            ResizeArgs a;
+            a.src = base + P.lv[l - 1].imgOff; a.sw = P.lv[l - 1].w; a.sh = P.lv[l - 1].h; a.spitch = P.lv[l - 1].pitch; a.sstride = P.pyrBytes;
+            a.dst = base + P.lv[l].imgOff; a.dw = P.lv[l].w; a.dh = P.lv[l].h; a.dpitch = P.lv[l].pitch; a.dstride = P.pyrBytes;
+            a.xofs = d_xofs[l]; a.xa = d_xa[l]; a.yofs = d_yofs[l]; a.yb = d_yb[l];
+            launch_resize(a, batch, stream);
+        }
+    }
+    return MYSLAM_OK;
+}
+
+int myslam_orb::blur_levels(int batch, int nlev) {
+    const OrbPlan& P = full;
+    for (int l = 0; l < nlev; l++) {                           // ORBextractor.cpp:965-966 / :1194-1199
+        ScopedProf sp(P_BLUR, stream);
+        BlurArgs a;
+        a.src = d_pyr + P.lv[l].imgOff; a.dst = d_blur + P.lv[l].imgOff;
+        a.w = P.lv[l].w; a.h = P.lv[l].h; a.spitch = a.dpitch = P.lv[l].pitch; a.sstride = a.dstride = P.pyrBytes;
+        gauss_q8(0, a.q);
+        launch_blur(a, batch, stream);
+    }
+    return MYSLAM_OK;
+}
+
+int myslam_orb::run_batch(const uint8_t* d_imgs, int batch, int r, int c, int step, size_t stride, const uint8_t* d_masks,
+                          myslam_keypoint* d_kps, uint8_t* d_desc, int32_t* d_counts, int32_t* d_stat, int cap, bool detectOnly) {
+    if (!d_imgs || batch <= 0 || r <= 0 || c <= 0 || step < c || cap <= 0 || !d_kps || !d_counts) return MYSLAM_ERR_INVALID;
+    if (!detectOnly && !d_desc) return MYSLAM_ERR_INVALID;
+    int rc = ensure(batch, r, c, d_masks != nullptr);
+    if (rc) return rc;
+    const OrbPlan& P = detectOnly ? det : full;
+    int32_t* stat = d_stat ? d_stat : d_status;
+    MYSLAM_HIP_CHECK(hipMemsetAsync(d_candCount, 0, sizeof(int32_t) * (size_t)batch * MAXL, stream));
+    MYSLAM_HIP_CHECK(hipMemsetAsync(d_selCount, 0, sizeof(int32_t) * (size_t)batch * MAXL, stream));
+    MYSLAM_HIP_CHECK(hipMemsetAsync(stat, 0, sizeof(int32_t) * (size_t)batch, stream));
+    if ((rc = build_pyramids(d_imgs, batch, step, stride, d_masks, P.nlevels))) return rc;
+    {
+        ScopedProf sp(P_FAST, stream);
+        launch_fast(P, d_pyr, full.pyrBytes, d_masks ? d_mask : nullptr, d_cand, d_candCount, batch, stream);
+    }
+    {
+        ScopedProf sp(P_OCTREE, stream);
+        launch_octree(P, d_cand, d_candCount, d_sort, d_sel, d_selCount, stat, batch, stream);
+    }
+    if (!detectOnly && (rc = blur_levels(batch, P.nlevels))) return rc;
+    {
+        ScopedProf sp(P_DESC, stream);
+        launch_describe(P, d_pyr, d_blur, full.pyrBytes, d_sel, d_selCount, d_kps, d_desc, d_counts, stat, cap,
+                        detectOnly ? 1 : 0, batch, stream);
+    }
+    MYSLAM_HIP_CHECK(hipGetLastError());
+    return MYSLAM_OK;
+}
+
+int myslam_orb::ensure_stage(size_t imgBytes, size_t maskBytes, int cap) {
+    if (imgBytes > stageImgBytes) { int rc = dev_alloc(d_stageImg, imgBytes); if (rc) return rc; stageImgBytes = imgBytes; }
+    if (maskBytes > stageMaskBytes) { int rc = dev_alloc(d_stageMask, maskBytes); if (rc) return rc; stageMaskBytes = maskBytes; }
+    if (cap > stageCap) {
+        int rc;
+        if ((rc = dev_alloc(d_stageKps, (size_t)cap))) return rc;
+        if ((rc = dev_alloc(d_stageKps2, (size_t)cap))) return rc;
+        if ((rc = dev_alloc(d_stageDesc, (size_t)cap * 32))) return rc;
+        if ((rc = dev_alloc(d_stageKeep, (size_t)cap))) return rc;
+        if (!d_stageCounts && (rc = dev_alloc(d_stageCounts, 4))) return rc;
+        stageCap = cap;
+    }
+    return MYSLAM_OK;
+}
+
+void myslam_orb::free_all() {
+    void* ptrs[] = {d_pyr, d_blur, d_mask, d_cand, d_sort, d_candCount, d_selCount, d_status, d_sel, d_stageImg, d_stageMask,
+                    d_stageKps, d_stageKps2, d_stageDesc, d_stageKeep, d_stageCounts};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto p : d_xofs) if (p) (void)hipFree(p);
+    for (auto p : d_yofs) if (p) (void)hipFree(p);
+    for (auto p : d_xa) if (p) (void)hipFree(p);
+    for (auto p : d_yb) if (p) (void)hipFree(p);
+}
+
+// =================================================================================================
+extern "C" {
+
+int myslam_orb_create(myslam_orb** out, int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast) {
+    if (!out || nfeatures < 1 || nlevels < 1 || nlevels > MAXL || !(scale_factor > 1.0f) || ini_th_fast < 0 ||
+        min_th_fast < 1 || min_th_fast > ini_th_fast || ini_th_fast > 255)
+        return MYSLAM_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MYSLAM_ERR_HIP;   // no CPU fallback
+    myslam_orb* h = new myslam_orb();
+    h->nfeatures = nfeatures; h->scaleFactor = scale_factor; h->nlevels = nlevels; h->iniTh = ini_th_fast; h->minTh = min_th_fast;
+    int rc = h->make_tables();
+    if (rc) { delete h; return rc; }
+    *out = h;
+    return MYSLAM_OK;
+}
+
+int myslam_orb_destroy(myslam_orb* h) {
+    if (!h) return MYSLAM_ERR_INVALID;
+    (void)hipStreamSynchronize(h->stream);
+    h->free_all();
+    delete h;
+    return MYSLAM_OK;
+}
+
+int myslam_orb_set_stream(myslam_orb* h, void* s) {
+    if (!h) return MYSLAM_ERR_INVALID;
+    (void)hipStreamSynchronize(h->stream);
+    h->stream = (hipStream_t)s;
+    return MYSLAM_OK;
+}
+
+int myslam_orb_get_tables(const myslam_orb* h, float* scale, float* inv_scale, int* fpl, int* umax16) {
+    if (!h) return MYSLAM_ERR_INVALID;
+    for (int i = 0; i < h->nlevels; i++) {
+        if (scale) scale[i] = h->scale[i];
+        if (inv_scale) inv_scale[i] = h->invScale[i];
+        if (fpl) fpl[i] = h->nPerLevel[i];
+    }
+    if (umax16) for (int i = 0; i < 16; i++) umax16[i] = h->umax[i];
+    return MYSLAM_OK;
+}
+
+int myslam_orb_max_keypoints(const myslam_orb* h) {
+    if (!h) return MYSLAM_ERR_INVALID;
+    int s = 0;
+    for (int l = 0; l < h->nlevels; l++) s += h->nPerLevel[l] + 3;
+    return std::max(s, h->nfeatures + 3);
+}
+
+int myslam_orb_detect_and_compute_batch(myslam_orb* h, const uint8_t* d_imgs, int batch, int rows, int cols, int step,
+                                        size_t img_stride, const uint8_t* d_masks, myslam_keypoint* d_kps, uint8_t* d_desc,
+                                        int32_t* d_counts, int32_t* d_status, int cap) {
+    if (!h) return MYSLAM_ERR_INVALID;
+    return h->run_batch(d_imgs, batch, rows, cols, step, img_stride, d_masks, d_kps, d_desc, d_counts, d_status, cap, false);
+}
+
+int myslam_orb_detect_batch(myslam_orb* h, const uint8_t* d_imgs, int batch, int rows, int cols, int step, size_t img_stride,
+                            const uint8_t* d_masks, myslam_keypoint* d_kps, int32_t* d_counts, int32_t* d_status, int cap) {
+    if (!h) return MYSLAM_ERR_INVALID;
+    return h->run_batch(d_imgs, batch, rows, cols, step, img_stride, d_masks, d_kps, nullptr, d_counts, d_status, cap, true);
+}
+
+static int host_extract(myslam_orb* h, const uint8_t* img, int rows, int cols, int step, const uint8_t* mask, int mask_step,
+                        myslam_keypoint* kps, uint8_t* desc, int cap, int* n, bool detectOnly) {
+    if (!h || !n) return MYSLAM_ERR_INVALID;
+    *n = 0;
+    if (!img || rows <= 0 || cols <= 0) return MYSLAM_OK;            // reference: silent return on empty input (:924, :990)
+    if (detectOnly && !mask) { /* Detect() returns on empty mask (:990); NULL here means "all 255" */ }
+    if (step < cols || cap <= 0 || !kps || (!detectOnly && !desc)) return MYSLAM_ERR_INVALID;
+    if (mask && mask_step < cols) return MYSLAM_ERR_INVALID;
+    const int want = myslam_orb_max_keypoints(h);
+    const int dcap = std::max(cap, want);
+    int rc = h->ensure_stage((size_t)rows * step, mask ? (size_t)rows * mask_step : 0, dcap);
+    if (rc) return rc;
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_stageImg, img, (size_t)rows * step, hipMemcpyHostToDevice, h->stream));
+    if (mask) MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_stageMask, mask, (size_t)rows * mask_step, hipMemcpyHostToDevice, h->stream));
+    // masks share the image's pitch inside the engine: re-pitch on ingest through the same kernel (step may differ)
+    if (mask && mask_step != step) return MYSLAM_ERR_INVALID;
+    rc = h->run_batch(h->d_stageImg, 1, rows, cols, step, (size_t)rows * step, mask ? h->d_stageMask : nullptr,
+                      h->d_stageKps, h->d_stageDesc, h->d_stageCounts, h->d_stageCounts + 1, dcap, detectOnly);
+    if (rc) return rc;
+    int32_t res[2];
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(res, h->d_stageCounts, sizeof(res), hipMemcpyDeviceToHost, h->stream));
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (res[1] != 0) return res[1];
+    if (res[0] > cap) { *n = res[0]; return MYSLAM_ERR_CAPACITY; }
+    MYSLAM_HIP_CHECK(hipMemcpy(kps, h->d_stageKps, sizeof(myslam_keypoint) * res[0], hipMemcpyDeviceToHost));
+    if (!detectOnly) MYSLAM_HIP_CHECK(hipMemcpy(desc, h->d_stageDesc, (size_t)32 * res[0], hipMemcpyDeviceToHost));
+    *n = res[0];
+    return MYSLAM_OK;
+}
+
+int myslam_orb_detect_and_compute(myslam_orb* h, const uint8_t* img, int rows, int cols, int step, const uint8_t* mask,
+                                  int mask_step, myslam_keypoint* kps, uint8_t* desc, int cap, int* n) {
+    return host_extract(h, img, rows, cols, step, mask, mask_step, kps, desc, cap, n, false);
+}
+
+int myslam_orb_detect(myslam_orb* h, const uint8_t* img, int rows, int cols, int step, const uint8_t* mask, int mask_step,
+                      myslam_keypoint* kps, int cap, int* n) {
+    return host_extract(h, img, rows, cols, step, mask, mask_step, kps, nullptr, cap, n, true);
+}
+
+// shared front half of Screen / CalcDescriptors: upload, ComputePyramid (ORBextractor.cpp:1096, :1192)
+static int host_pyramid(myslam_orb* h, const uint8_t* img, int rows, int cols, int step, int ncap) {
+    int rc = h->ensure(1, rows, cols, false);
+    if (rc) return rc;
+    if ((rc = h->ensure_stage((size_t)rows * step, 0, ncap))) return rc;
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_stageImg, img, (size_t)rows * step, hipMemcpyHostToDevice, h->stream));
+    return h->build_pyramids(h->d_stageImg, 1, step, (size_t)rows * step, nullptr, h->nlevels);
+}
+
+int myslam_orb_screen_and_compute_params(myslam_orb* h, const uint8_t* img, int rows, int cols, int step,
+                                         myslam_keypoint* kps_in, int n_in, myslam_keypoint* kps_out, int cap, int* n_out) {
+    if (!h || !n_out) return MYSLAM_ERR_INVALID;
+    *n_out = 0;
+    if (!img || rows <= 0 || cols <= 0 || n_in <= 0) return MYSLAM_OK;       // :1085-1088 (logs + returns)
+    if (!kps_in || !kps_out || step < cols) return MYSLAM_ERR_INVALID;
+    for (int i = 0; i < n_in; i++) if (kps_in[i].octave < 0 || kps_in[i].octave >= h->nlevels) return MYSLAM_ERR_INVALID;
+    int rc = host_pyramid(h, img, rows, cols, step, n_in);
+    if (rc) return rc;
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_stageKps, kps_in, sizeof(myslam_keypoint) * n_in, hipMemcpyHostToDevice, h->stream));
+    {
+        ScopedProf sp(P_SCREEN, h->stream);
+        launch_screen(h->full, h->d_pyr, h->d_stageKps, n_in, h->d_stageKps2, h->d_stageKeep, h->stream);
+    }
+    std::vector<myslam_keypoint> tmp(n_in);
+    std::vector<uint8_t> keep(n_in);
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(kps_in, h->d_stageKps, sizeof(myslam_keypoint) * n_in, hipMemcpyDeviceToHost, h->stream));
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(tmp.data(), h->d_stageKps2, sizeof(myslam_keypoint) * n_in, hipMemcpyDeviceToHost, h->stream));
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(keep.data(), h->d_stageKeep, n_in, hipMemcpyDeviceToHost, h->stream));
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    int m = 0;
+    for (int i = 0; i < n_in; i++)                      // out_keypoints.push_back in input order (:1125)
+        if (keep[i]) { if (m >= cap) return MYSLAM_ERR_CAPACITY; kps_out[m++] = tmp[i]; }
+    *n_out = m;
+    return MYSLAM_OK;
+}
+
+int myslam_orb_calc_descriptors(myslam_orb* h, const uint8_t* img, int rows, int cols, int step, const myslam_keypoint* kps,
+                                int n, uint8_t* desc) {
+    if (!h) return MYSLAM_ERR_INVALID;
+    if (!img || rows <= 0 || cols <= 0 || n <= 0) return MYSLAM_OK;          // :1183-1186
+    if (!kps || !desc || step < cols) return MYSLAM_ERR_INVALID;
+    for (int i = 0; i < n; i++) if (kps[i].octave < 0 || kps[i].octave >= h->nlevels) return MYSLAM_ERR_INVALID;
+    int rc = host_pyramid(h, img, rows, cols, step, n);
+    if (rc) return rc;
+    if ((rc = h->blur_levels(1, h->nlevels))) return rc;
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_stageKps, kps, sizeof(myslam_keypoint) * n, hipMemcpyHostToDevice, h->stream));
+    {
+        ScopedProf sp(P_DESC, h->stream);
+        launch_calc_desc(h->full, h->d_blur, h->d_stageKps, n, h->d_stageDesc, h->stream);
+    }
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(desc, h->d_stageDesc, (size_t)32 * n, hipMemcpyDeviceToHost, h->stream));
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return MYSLAM_OK;
+}
+
+int myslam_orb_debug_pyramid(myslam_orb* h, const uint8_t* img, int rows, int cols, int step, int level, int blurred,
+                             uint8_t* out, int out_step, int* w, int* hgt) {
+    if (!h || !img || level < 0 || level >= h->nlevels) return MYSLAM_ERR_INVALID;
+    int rc = host_pyramid(h, img, rows, cols, step, 16);
+    if (rc) return rc;
+    if (blurred && (rc = h->blur_levels(1, h->nlevels))) return rc;
+    const LevelGeom& g = h->full.lv[level];
+    if (w) *w = g.w;
+    if (hgt) *hgt = g.h;
+    if (out) {
+        if (out_step < g.w) return MYSLAM_ERR_INVALID;
+        MYSLAM_HIP_CHECK(hipMemcpy2DAsync(out, out_step, (blurred ? h->d_blur : h->d_pyr) + g.imgOff, g.pitch, g.w, g.h,
+                                          hipMemcpyDeviceToHost, h->stream));
+    }
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    return MYSLAM_OK;
+}
+
+int myslam_orb_debug_candidates(myslam_orb* h, const uint8_t* img, int rows, int cols, int step, const uint8_t* mask,
+                                int mask_step, int level, int32_t* xs, int32_t* ys, int32_t* scores, int cap, int* n) {
+    if (!h || !img || !n || level < 0 || level >= h->nlevels) return MYSLAM_ERR_INVALID;
+    if (mask && mask_step != step) return MYSLAM_ERR_INVALID;
+    int rc = h->ensure(1, rows, cols, mask != nullptr);
+    if (rc) return rc;
+    if ((rc = h->ensure_stage((size_t)rows * step, mask ? (size_t)rows * step : 0, 16))) return rc;
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_stageImg, img, (size_t)rows * step, hipMemcpyHostToDevice, h->stream));
+    if (mask) MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_stageMask, mask, (size_t)rows * step, hipMemcpyHostToDevice, h->stream));
+    MYSLAM_HIP_CHECK(hipMemsetAsync(h->d_candCount, 0, sizeof(int32_t) * MAXL, h->stream));
+    if ((rc = h->build_pyramids(h->d_stageImg, 1, step, (size_t)rows * step, mask ? h->d_stageMask : nullptr, h->nlevels))) return rc;
+    launch_fast(h->full, h->d_pyr, h->full.pyrBytes, mask ? h->d_mask : nullptr, h->d_cand, h->d_candCount, 1, h->stream);
+    int32_t counts[MAXL];
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(counts, h->d_candCount, sizeof(counts), hipMemcpyDeviceToHost, h->stream));
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    const LevelGeom& g = h->full.lv[level];
+    *n = counts[level];
+    if (counts[level] > g.keyCap || counts[level] > cap) return MYSLAM_ERR_CAPACITY;
+    int32_t* d_tmp = nullptr;
+    const int m = counts[level];
+    if (m > 0) {
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&d_tmp, sizeof(int32_t) * 3 * m));
+        launch_unpack_cands(h->d_cand + g.keyOff, m, d_tmp, d_tmp + m, d_tmp + 2 * m, h->stream);
+        MYSLAM_HIP_CHECK(hipMemcpyAsync(xs, d_tmp, 4 * m, hipMemcpyDeviceToHost, h->stream));
+        MYSLAM_HIP_CHECK(hipMemcpyAsync(ys, d_tmp + m, 4 * m, hipMemcpyDeviceToHost, h->stream));
+        MYSLAM_HIP_CHECK(hipMemcpyAsync(scores, d_tmp + 2 * m, 4 * m, hipMemcpyDeviceToHost, h->stream));
+        MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+        (void)hipFree(d_tmp);
+    }
+    return MYSLAM_OK;
+}
+
+}  // extern "C"

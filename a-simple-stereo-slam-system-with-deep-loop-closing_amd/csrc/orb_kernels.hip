@@ -1,0 +1,954 @@
+// orb_kernels.hip — HIP kernels of the ORB extractor for gfx950 (wave64, LDS-tiled).
+//
+// Reference behaviour being reproduced (all paths relative to the reference tree):
+//   pyramid            src/ORBextractor.cpp:1229-1265   (cv::resize INTER_LINEAR cascade)
+//   grid FAST          src/ORBextractor.cpp:814-883     (cv::FAST + 3x3 NMS per 30-px cell, 20 -> 7 fallback)
+//   oct-tree           src/ORBextractor.cpp:526-810
+//   orientation        src/ORBextractor.cpp:27-55
+//   blur + rBRIEF      src/ORBextractor.cpp:58-98, :965-970
+//
+// Built with -ffp-contract=off: BRIEF sample coordinates and fastAtan2 are float expressions whose
+// integer/float results must be bit-identical to a non-contracting CPU evaluation.
+#include "common.h"
+#include "orb_plan.h"
+
+namespace myslam_hip {
+
+__constant__ int8_t c_pattern[1024] = {
+#include "orb_pattern.inc"
+};
+
+// circular patch rows: umax[v], ORBextractor.cpp:429-444 for HALF_PATCH_SIZE = 15 (a constant of the algorithm)
+__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+// ------------------------------------------------------------------------------------------------
+// K1: bilinear down-scale of one pyramid level from the previous one (fixed point, 11-bit weights)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize(ResizeArgs a) {
+    const int b = blockIdx.z;
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int dx4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    if (dy >= a.dh || dx4 >= a.dw) return;
+    const int sy = a.yofs[dy];
+    const int sy0 = min(max(sy, 0), a.sh - 1), sy1 = min(max(sy + 1, 0), a.sh - 1);
+    const int b0 = a.yb[2 * dy], b1 = a.yb[2 * dy + 1];
+    const uint8_t* S0 = a.src + (size_t)b * a.sstride + (size_t)sy0 * a.spitch;
+    const uint8_t* S1 = a.src + (size_t)b * a.sstride + (size_t)sy1 * a.spitch;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int dx = dx4 + k;
+        if (dx < a.dw) {
+            const int sx = a.xofs[dx];
+            const int sx1 = min(sx + 1, a.sw - 1);
+            const int a0 = a.xa[2 * dx], a1 = a.xa[2 * dx + 1];
+            const int r0 = S0[sx] * a0 + S0[sx1] * a1;
+            const int r1 = S1[sx] * a0 + S1[sx1] * a1;
+            int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            v = min(max(v, 0), 255);
+            packed |= (uint32_t)v << (8 * k);
+        }
+    }
+    *reinterpret_cast<uint32_t*>(a.dst + (size_t)b * a.dstride + (size_t)dy * a.dpitch + dx4) = packed;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: 7x7 separable Gaussian, Q8 coefficients, REFLECT_101.  64x16 outputs per 256-thread block.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = (p < 0) ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void k_blur7(BlurArgs a) {
+    constexpr int TW = 64, TH = 16, IW = TW + 6, IH = TH + 6, IP = 72;
+    __shared__ uint8_t s_in[IH * IP];
+    __shared__ uint16_t s_h[IH * TW];
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const uint8_t* src = a.src + (size_t)b * a.sstride;
+    for (int i = threadIdx.x; i < IH * IW; i += 256) {
+        const int r = i / IW, c = i - r * IW;
+        const int sy = reflect101(y0 + r - 3, a.h), sx = reflect101(x0 + c - 3, a.w);
+        s_in[r * IP + c] = src[(size_t)sy * a.spitch + sx];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < IH * TW; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        const uint8_t* p = &s_in[r * IP + c];
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) acc += a.q[k] * p[k];
+        s_h[i] = (uint16_t)acc;
+    }
+    __syncthreads();
+    const int tx = (threadIdx.x & 15) * 4, ty = threadIdx.x >> 4;
+    const int ox = x0 + tx, oy = y0 + ty;
+    if (oy >= a.h || ox >= a.w) return;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 7; j++) acc += (uint32_t)a.q[j] * s_h[(ty + j) * TW + tx + k];
+        uint32_t v = min((acc + 32768u) >> 16, 255u);
+        packed |= v << (8 * k);
+    }
+    // pitch is a multiple of 64 so the 4-byte store never leaves the row; bytes past w are padding
+    *reinterpret_cast<uint32_t*>(a.dst + (size_t)b * a.dstride + (size_t)oy * a.dpitch + ox) = packed;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: grid FAST.  One 256-thread block per 30-px grid cell: the cell's ROI (+3 px ring) is staged in
+// LDS, every interior pixel gets its FAST-9 score (largest threshold at which it is still a corner),
+// 3x3 strict-maximum NMS runs inside the cell only (as cv::FAST on the sub-Mat does), the 20 -> 7
+// threshold fallback is decided per cell, survivors are appended to the level's candidate list.
+// Candidate payload: py<<20 | px<<8 | score   (px,py border-relative as in ORBextractor.cpp:871-872).
+// ------------------------------------------------------------------------------------------------
+constexpr int FT_P = 72;                       // LDS pitch of the ROI tile (ROI width <= 65, +3 align slack)
+constexpr int FT_ROWS = MAX_CELL + 6;          // 65
+constexpr int FS_P = 64;                       // LDS pitch of the score tile (interior <= 59, +2 border)
+constexpr int FS_ROWS = MAX_CELL + 2;
+constexpr int FAST_MAX_LOCAL = 1024;           // strict 8-neighbour maxima in a 59x59 cell <= 30*30
+
+__device__ __forceinline__ int fast9_score(const uint8_t* p, int minTh) {
+    // ring order = reference makeOffsets(), ORBextractor.cpp:365-369
+    constexpr int RX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+    constexpr int RY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+    const int v = p[0];
+    int d[16];
+    unsigned dm = 0, bm = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        d[k] = v - (int)p[RX[k] + RY[k] * FT_P];
+        dm |= (unsigned)(d[k] > minTh) << k;
+        bm |= (unsigned)(d[k] < -minTh) << k;
+    }
+    // any 9-arc contains one pixel of every opposite pair (the reference's pre-tests, :466-478)
+    const bool cand = (((dm | (dm >> 8)) & 0xffu) == 0xffu) || (((bm | (bm >> 8)) & 0xffu) == 0xffu);
+    if (!cand) return 0;
+    int lo2[16], hi2[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
+    int lo4[16], hi4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
+    int best_dark = -1000, best_bright = -1000;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);     // min over arc k..k+8
+        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
+        best_dark = max(best_dark, lo9);
+        best_bright = max(best_bright, -hi9);
+    }
+    const int s = max(best_dark, best_bright) - 1;
+    return s >= minTh ? s : 0;
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(OrbPlan P, const uint8_t* __restrict__ pyr, size_t pyrStride,
+                                                    const uint8_t* __restrict__ maskPyr,
+                                                    uint32_t* __restrict__ cand, int32_t* __restrict__ candCount) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[FT_ROWS * FT_P];
+    __shared__ __attribute__((aligned(16))) uint8_t s_score[FS_ROWS * FS_P];
+    __shared__ uint32_t s_list[FAST_MAX_LOCAL];
+    __shared__ int s_cnt, s_base, s_npass, s_wr;
+
+    const int b = blockIdx.y;
+    int level = 0;
+    for (int l = 1; l < P.nlevels; l++) if ((int)blockIdx.x >= P.lv[l].cellBase) level = l;
+    const LevelGeom& g = P.lv[level];
+    const int cell = blockIdx.x - g.cellBase;
+    const int ci = cell / g.nCols, cj = cell - ci * g.nCols;
+    const int iniY = MIN_BORDER + ci * g.hCell, iniX = MIN_BORDER + cj * g.wCell;
+    if (iniY >= g.maxBY - 3 || iniX >= g.maxBX - 6) return;            // :843, :852
+    const int maxY = min(iniY + g.hCell + 6, g.maxBY), maxX = min(iniX + g.wCell + 6, g.maxBX);
+    const int wr = maxX - iniX, hr = maxY - iniY;                      // ROI
+    const int wc = wr - 6, hc = hr - 6;                                // detection interior
+    if (wc <= 0 || hc <= 0) return;
+
+    const uint8_t* img = pyr + (size_t)b * pyrStride + g.imgOff;
+    // stage ROI with aligned 4-byte loads (internal planes: 64-byte pitch, 256-byte base)
+    const int x0a = iniX & ~3, off = iniX - x0a;
+    const int ndw = (off + wr + 3) >> 2;
+    for (int i = threadIdx.x; i < hr * ndw; i += 256) {
+        const int r = i / ndw, k = i - r * ndw;
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(img + (size_t)(iniY + r) * g.pitch + x0a + 4 * k);
+        *reinterpret_cast<uint32_t*>(&s_tile[r * FT_P + 4 * k]) = v;
+    }
+    for (int i = threadIdx.x; i < (FS_ROWS * FS_P) / 4; i += 256) reinterpret_cast<uint32_t*>(s_score)[i] = 0;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+
+    const int npx = wc * hc;
+    for (int i = threadIdx.x; i < npx; i += 256) {
+        const int cy = i / wc, cx = i - cy * wc;
+        const int s = fast9_score(&s_tile[(cy + 3) * FT_P + off + cx + 3], P.minTh);
+        if (s) s_score[(cy + 1) * FS_P + cx + 1] = (uint8_t)s;
+    }
+    __syncthreads();
+
+    // NMS (strict > all 8 neighbours, zeros outside the cell interior): maxima go to an LDS list
+    int any_ini = 0;
+    for (int i = threadIdx.x; i < npx; i += 256) {
+        const int cy = i / wc, cx = i - cy * wc;
+        const uint8_t* sp = &s_score[(cy + 1) * FS_P + cx + 1];
+        const int s = sp[0];
+        if (s) {
+            const bool mx = s > sp[-1] && s > sp[1] && s > sp[-FS_P - 1] && s > sp[-FS_P] && s > sp[-FS_P + 1] &&
+                            s > sp[FS_P - 1] && s > sp[FS_P] && s > sp[FS_P + 1];
+            if (mx) {
+                const int px = cx + 3 + cj * g.wCell, py = cy + 3 + ci * g.hCell;     // border-relative
+                const int pos = atomicAdd(&s_cnt, 1);
+                if (pos < FAST_MAX_LOCAL) s_list[pos] = ((uint32_t)py << 20) | ((uint32_t)px << 8) | (uint32_t)s;
+                any_ini |= (s >= P.iniTh);
+            }
+        }
+    }
+    // does the cell have a corner at iniTh?  else fall back to minTh (:858-865)
+    const int cell_has_ini = __syncthreads_or(any_ini);
+    const int nloc = min(s_cnt, FAST_MAX_LOCAL);
+    const uint8_t* mimg = maskPyr ? maskPyr + (size_t)b * pyrStride + g.imgOff : nullptr;
+    auto passes = [&](uint32_t kp) -> bool {
+        if (cell_has_ini && (int)(kp & 0xff) < P.iniTh) return false;
+        if (mimg) {                                                                   // :873-877 (no +16: reference quirk)
+            const int px = (kp >> 8) & 0xfff, py = kp >> 20;
+            if (mimg[(size_t)py * g.pitch + px] == 0) return false;
+        }
+        return true;
+    };
+    int npass = 0;
+    for (int i = threadIdx.x; i < nloc; i += 256) npass += passes(s_list[i]) ? 1 : 0;
+    if (threadIdx.x == 0) { s_npass = 0; s_wr = 0; }
+    __syncthreads();
+    if (npass) atomicAdd(&s_npass, npass);
+    __syncthreads();
+    const int n = s_npass;
+    if (n == 0) return;
+    if (threadIdx.x == 0) s_base = atomicAdd(&candCount[b * MAXL + level], n);
+    __syncthreads();
+    uint32_t* out = cand + (size_t)b * P.totalKeyCap + g.keyOff;
+    for (int i = threadIdx.x; i < nloc; i += 256) {
+        const uint32_t kp = s_list[i];
+        if (!passes(kp)) continue;
+        const int dst = s_base + atomicAdd(&s_wr, 1);
+        if (dst < g.keyCap) out[dst] = kp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: oct-tree keypoint distribution, one 256-thread block per (level, image).
+//
+// The reference walks a std::list of nodes, splitting nodes into 4 children and re-bucketing their
+// key vectors (ORBextractor.cpp:586-810).  Here every key gets its full quad-tree PATH CODE up front
+// (root index + 2 bits per depth, derived with the reference's ceil-halving bounds), the keys are
+// radix-sorted by code once, and a node is just (depth, [lo,hi) range of the sorted array); children
+// are found by binary search on the next 2-bit digit.  The list order the reference produces
+// (push_front of n1..n4, erase of the parent, size-sorted expansion near the budget) is reproduced
+// with prefix sums.  Tie-break of the size sort (:731 sorts pair<int,Node*>, i.e. by heap address) is
+// creation order — the same deterministic choice the oracle makes.  Best key per node = max response,
+// first in the reference's candidate order (cell-major, then row-major) on ties (:795-804).
+// ------------------------------------------------------------------------------------------------
+constexpr int OT = 256;
+
+__device__ __forceinline__ uint64_t wave_incl_scan64(uint64_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t n = __shfl_up(v, o, 64);
+        if (lane >= o) v += n;
+    }
+    return v;
+}
+
+// exclusive block scan of a packed 64-bit counter; s_w = 4 uint64 of LDS scratch
+__device__ __forceinline__ uint64_t block_excl_scan64(uint64_t v, uint64_t* s_w, uint64_t& total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint64_t incl = wave_incl_scan64(v);
+    __syncthreads();                       // previous users of s_w are done
+    if (lane == 63) s_w[wid] = incl;
+    __syncthreads();
+    uint64_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < OT / 64; w++) { const uint64_t x = s_w[w]; if (w < wid) base += x; tot += x; }
+    total = tot;
+    return base + incl - v;
+}
+
+__device__ __forceinline__ uint32_t oct_code(int px, int py, const LevelGeom& g) {
+    int r = (int)__fdiv_rn((float)px, g.hX);                                  // :616
+    r = min(max(r, 0), g.nIni - 1);
+    int ULx = (int)__fmul_rn(g.hX, (float)r), URx = (int)__fmul_rn(g.hX, (float)(r + 1));   // :602-603
+    int ULy = 0, BRy = g.maxBY - MIN_BORDER;
+    uint32_t code = (uint32_t)r << ROOT_SHIFT;
+    for (int k = 1; k <= g.ndepth; k++) {
+        const int midX = ULx + ((URx - ULx + 1) >> 1);                        // ceil(w/2), :528-529
+        const int midY = ULy + ((BRy - ULy + 1) >> 1);
+        const uint32_t dx = px >= midX, dy = py >= midY;                      // :560-570
+        code |= (dx | (dy << 1)) << (ROOT_SHIFT - 2 * k);
+        if (dx) ULx = midX; else URx = midX;
+        if (dy) ULy = midY; else BRy = midY;
+    }
+    return code;
+}
+
+__device__ __forceinline__ int lower_bound_code(const uint64_t* __restrict__ s, int lo, int hi, uint32_t target) {
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((uint32_t)(s[mid] >> 32) < target) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// boundaries of the 4 children of node (depth d, [lo,hi)) in the sorted array
+__device__ __forceinline__ void child_bounds(const uint64_t* __restrict__ s, int lo, int hi, int d,
+                                             int& b1, int& b2, int& b3) {
+    const int shift = ROOT_SHIFT - 2 * (d + 1);
+    const uint32_t base = (uint32_t)(s[lo] >> 32) & ~((4u << shift) - 1u);
+    b2 = lower_bound_code(s, lo, hi, base | (2u << shift));
+    b1 = lower_bound_code(s, lo, b2, base | (1u << shift));
+    b3 = lower_bound_code(s, b2, hi, base | (3u << shift));
+}
+
+struct OctLds {
+    uint32_t *rng0, *rng1;      // node range lo | hi<<16 (double buffered)
+    uint8_t *dep0, *dep1;       // node depth
+    uint16_t *nb1, *nb2, *nb3;  // child boundaries (per list position / per sorted candidate)
+    uint32_t *ckey0, *ckey1;    // candidate sort key: size<<16 | creation index
+    uint16_t *cpos0, *cpos1;    // candidate -> list position
+    __device__ __forceinline__ uint32_t* rng(int i) const { return i ? rng1 : rng0; }
+    __device__ __forceinline__ uint8_t* dep(int i) const { return i ? dep1 : dep0; }
+    __device__ __forceinline__ uint32_t* ckey(int i) const { return i ? ckey1 : ckey0; }
+    __device__ __forceinline__ uint16_t* cpos(int i) const { return i ? cpos1 : cpos0; }
+    uint16_t* ord;         // rank -> candidate
+    uint16_t *kinc, *binc; // inclusive sums of children / big children over sorted candidates
+    uint8_t* kk;           // #non-empty children (0 = not expandable)
+    uint8_t* mark;
+};
+
+__global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __restrict__ cand,
+                                               const int32_t* __restrict__ candCount, uint64_t* __restrict__ sortbuf,
+                                               uint32_t* __restrict__ selOut, int32_t* __restrict__ selCount,
+                                               int32_t* __restrict__ status, int levelBase) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int t = threadIdx.x;
+    const int level = levelBase + blockIdx.x, b = blockIdx.y;
+    const LevelGeom& g = P.lv[level];
+    const int NC = g.nodeCap;
+
+    // carve LDS
+    uint64_t* s_w = reinterpret_cast<uint64_t*>(smem);          // 4 x u64 scan scratch
+    int* s_i = reinterpret_cast<int*>(smem + 32);               // 8 ints: [0]=m [1]=nc [2]=jstar [3]=Kc [4]=nbig
+    uint8_t* pcur = smem + 64;
+    OctLds L;
+    L.rng0 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
+    L.rng1 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
+    L.ckey0 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
+    L.ckey1 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
+    L.nb1 = reinterpret_cast<uint16_t*>(pcur); pcur += 2 * NC;
+    L.nb2 = reinterpret_cast<uint16_t*>(pcur); pcur += 2 * NC;
+    L.nb3 = reinterpret_cast<uint16_t*>(pcur); pcur += 2 * NC;
+    L.cpos0 = reinterpret_cast<uint16_t*>(pcur); pcur += 2 * NC;
+    L.cpos1 = reinterpret_cast<uint16_t*>(pcur); pcur += 2 * NC;
+    L.ord = reinterpret_cast<uint16_t*>(pcur); pcur += 2 * NC;
+    L.kinc = reinterpret_cast<uint16_t*>(pcur); pcur += 2 * NC;
+    L.binc = reinterpret_cast<uint16_t*>(pcur); pcur += 2 * NC;
+    L.dep0 = pcur; pcur += NC;
+    L.dep1 = pcur; pcur += NC;
+    L.kk = pcur; pcur += NC;
+    L.mark = pcur; pcur += NC;
+
+    const int cnt = candCount[b * MAXL + level];
+    int32_t* myCount = selCount + b * MAXL + level;
+    if (cnt > g.keyCap) {                      // candidate list overflowed: refuse rather than truncate
+        if (t == 0) { *myCount = 0; status[b] = MYSLAM_ERR_CAPACITY; }
+        return;
+    }
+    const int n = cnt;
+    if (n == 0) { if (t == 0) *myCount = 0; return; }
+
+    const uint32_t* keys = cand + (size_t)b * P.totalKeyCap + g.keyOff;
+    uint64_t* bufA = sortbuf + ((size_t)b * P.totalKeyCap + g.keyOff) * 2;
+    uint64_t* bufB = bufA + g.keyCap;
+
+    // ---- A: path codes ----
+    for (int i = t; i < n; i += OT) {
+        const uint32_t pay = keys[i];
+        const int px = (pay >> 8) & 0xfff, py = pay >> 20;
+        bufA[i] = ((uint64_t)oct_code(px, py, g) << 32) | pay;
+    }
+    __syncthreads();
+
+    // ---- B: LSD radix sort by code, 2 bits per pass (keys are distinct, so the result is unique) ----
+    {
+        uint64_t* src = bufA; uint64_t* dst = bufB;
+        const int c = (n + OT - 1) / OT;
+        const int beg = min(n, t * c), end = min(n, beg + c);
+        const int npass = g.ndepth + g.rootPasses;
+        for (int pass = 0; pass < npass; pass++) {
+            const int shift = 32 + ROOT_SHIFT - 2 * g.ndepth + 2 * pass;
+            uint64_t packed = 0;
+            for (int i = beg; i < end; i++) packed += 1ull << (16 * (int)((src[i] >> shift) & 3));
+            uint64_t total;
+            const uint64_t excl = block_excl_scan64(packed, s_w, total);
+            const uint64_t t0 = total & 0xffff, t1 = (total >> 16) & 0xffff, t2 = (total >> 32) & 0xffff;
+            uint64_t offs = excl + ((t0 << 16) | ((t0 + t1) << 32) | ((t0 + t1 + t2) << 48));
+            for (int i = beg; i < end; i++) {
+                const uint64_t v = src[i];
+                const int d = (int)((v >> shift) & 3);
+                dst[(offs >> (16 * d)) & 0xffff] = v;
+                offs += 1ull << (16 * d);
+            }
+            __syncthreads();
+            uint64_t* tmp = src; src = dst; dst = tmp;
+        }
+        bufA = src;                               // sorted
+    }
+    const uint64_t* S = bufA;
+
+    // ---- C: node list simulation ----
+    // roots (:599-632): non-empty roots in index order
+    if (t < g.nIni) {
+        const int lo = lower_bound_code(S, 0, n, (uint32_t)t << ROOT_SHIFT);
+        const int hi = (t + 1 < g.nIni) ? lower_bound_code(S, lo, n, (uint32_t)(t + 1) << ROOT_SHIFT) : n;
+        L.nb1[t] = (uint16_t)lo; L.nb2[t] = (uint16_t)hi;
+    }
+    __syncthreads();
+    if (t == 0) {
+        int m = 0;
+        for (int r = 0; r < g.nIni; r++) {
+            const int lo = L.nb1[r], hi = L.nb2[r];
+            if (hi > lo) { L.rng(0)[m] = (uint32_t)lo | ((uint32_t)hi << 16); L.dep(0)[m] = 0; m++; }
+        }
+        s_i[0] = m; s_i[1] = 0;
+    }
+    __syncthreads();
+
+    int cur = 0, ccur = 0, mode = 0;
+    const int N = g.N;
+    for (int round = 0; round < 96; round++) {
+        const int m = s_i[0];
+        const int prevSize = m;
+        int newM;
+        if (mode == 0) {
+            // ---------- full round (:645-712): every node with >1 key is split ----------
+            const int c = (m + OT - 1) / OT;
+            const int beg = min(m, t * c), end = min(m, beg + c);
+            uint64_t packed = 0;              // K | Non<<21 | Big<<42
+            for (int p = beg; p < end; p++) {
+                const uint32_t r = L.rng(cur)[p];
+                const int lo = r & 0xffff, hi = r >> 16, d = L.dep(cur)[p];
+                int k = 0;
+                if (hi - lo > 1 && d < g.ndepth) {
+                    int b1, b2, b3;
+                    child_bounds(S, lo, hi, d, b1, b2, b3);
+                    L.nb1[p] = (uint16_t)b1; L.nb2[p] = (uint16_t)b2; L.nb3[p] = (uint16_t)b3;
+                    const int c0 = b1 - lo, c1 = b2 - b1, c2 = b3 - b2, c3 = hi - b3;
+                    k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
+                    const int big = (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1);
+                    packed += (uint64_t)k | ((uint64_t)big << 42);
+                } else {
+                    packed += 1ull << 21;
+                }
+                L.kk[p] = (uint8_t)k;
+            }
+            uint64_t total;
+            uint64_t run = block_excl_scan64(packed, s_w, total);
+            const int Ktot = (int)(total & 0x1fffff), Ntot = (int)((total >> 21) & 0x1fffff), Btot = (int)(total >> 42);
+            const int nxt = cur ^ 1, cnxt = ccur ^ 1;
+            for (int p = beg; p < end; p++) {
+                const uint32_t r = L.rng(cur)[p];
+                const int lo = r & 0xffff, hi = r >> 16, d = L.dep(cur)[p];
+                const int k = L.kk[p];
+                if (k) {
+                    const int bnd[5] = {lo, L.nb1[p], L.nb2[p], L.nb3[p], hi};
+                    const int rk = (int)(run & 0x1fffff);
+                    int pos = Ktot - (rk + k);                           // children of later nodes come first
+                    int cidx = (int)(run >> 42);
+                    int childPos[4];
+#pragma unroll
+                    for (int q = 3; q >= 0; q--) {                       // list order n4,n3,n2,n1 (push_front)
+                        childPos[q] = pos;
+                        if (bnd[q + 1] > bnd[q]) {
+                            L.rng(nxt)[pos] = (uint32_t)bnd[q] | ((uint32_t)bnd[q + 1] << 16);
+                            L.dep(nxt)[pos] = (uint8_t)(d + 1);
+                            pos++;
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {                        // creation order n1..n4
+                        const int sz = bnd[q + 1] - bnd[q];
+                        if (sz > 1) {
+                            L.ckey(cnxt)[cidx] = ((uint32_t)sz << 16) | (uint32_t)cidx;
+                            L.cpos(cnxt)[cidx] = (uint16_t)childPos[q];
+                            cidx++;
+                        }
+                    }
+                    const int big = cidx - (int)(run >> 42);
+                    run += (uint64_t)k | ((uint64_t)big << 42);
+                } else {
+                    const int rn = (int)((run >> 21) & 0x1fffff);
+                    L.rng(nxt)[Ktot + rn] = r;
+                    L.dep(nxt)[Ktot + rn] = (uint8_t)d;
+                    run += 1ull << 21;
+                }
+            }
+            newM = Ktot + Ntot;
+            __syncthreads();
+            if (t == 0) { s_i[0] = newM; s_i[1] = Btot; }
+            cur = nxt; ccur = cnxt;
+            __syncthreads();
+            if (newM >= N || newM == prevSize) break;                    // :716
+            if (newM + 3 * Btot > N) mode = 1;                           // :720
+        } else {
+            // ---------- budget-limited pass (:723-784): largest nodes first, stop at N ----------
+            const int nc = s_i[1];
+            if (nc == 0) break;                                          // nothing to split -> size unchanged
+            // rank sort descending by (size, creation index)
+            for (int ci = t; ci < nc; ci += OT) {
+                const uint32_t key = L.ckey(ccur)[ci];
+                int rank = 0;
+                for (int cj = 0; cj < nc; cj++) rank += (L.ckey(ccur)[cj] > key);
+                L.ord[rank] = (uint16_t)ci;
+            }
+            for (int p = t; p < m; p += OT) L.mark[p] = 0;
+            if (t == 0) s_i[2] = nc - 1;
+            __syncthreads();
+            const int c = (nc + OT - 1) / OT;
+            const int beg = min(nc, t * c), end = min(nc, beg + c);
+            uint64_t packed = 0;                                         // K | Big<<32
+            for (int j = beg; j < end; j++) {
+                const int p = L.cpos(ccur)[L.ord[j]];
+                const uint32_t r = L.rng(cur)[p];
+                const int lo = r & 0xffff, hi = r >> 16, d = L.dep(cur)[p];
+                int k = 1, big = 1, b1 = hi, b2 = hi, b3 = hi;           // depth-exhausted node: one "child" = itself
+                if (d < g.ndepth) {
+                    child_bounds(S, lo, hi, d, b1, b2, b3);
+                    const int c0 = b1 - lo, c1 = b2 - b1, c2 = b3 - b2, c3 = hi - b3;
+                    k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
+                    big = (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1);
+                }
+                L.nb1[j] = (uint16_t)b1; L.nb2[j] = (uint16_t)b2; L.nb3[j] = (uint16_t)b3;
+                L.kk[j] = (uint8_t)k;
+                packed += (uint64_t)k | ((uint64_t)big << 32);
+            }
+            uint64_t total;
+            uint64_t run = block_excl_scan64(packed, s_w, total);
+            for (int j = beg; j < end; j++) {
+                // recompute big from the stored bounds
+                const int p = L.cpos(ccur)[L.ord[j]];
+                const uint32_t r = L.rng(cur)[p];
+                const int lo = r & 0xffff, hi = r >> 16;
+                const int b1 = L.nb1[j], b2 = L.nb2[j], b3 = L.nb3[j];
+                const int k = L.kk[j];
+                int big;
+                if (L.dep(cur)[p] < g.ndepth) big = (b1 - lo > 1) + (b2 - b1 > 1) + (b3 - b2 > 1) + (hi - b3 > 1);
+                else big = 1;
+                run += (uint64_t)k | ((uint64_t)big << 32);
+                const int kincl = (int)(run & 0xffffffffu);
+                L.kinc[j] = (uint16_t)kincl;
+                L.binc[j] = (uint16_t)(run >> 32);
+                if (m + kincl - (j + 1) >= N) atomicMin(&s_i[2], j);     // :777 break as soon as size >= N
+            }
+            __syncthreads();
+            const int ncmt = min(s_i[2] + 1, nc);
+            const int Kc = L.kinc[ncmt - 1];
+            const int nxt = cur ^ 1, cnxt = ccur ^ 1;
+            for (int j = t; j < ncmt; j += OT) L.mark[L.cpos(ccur)[L.ord[j]]] = 1;
+            __syncthreads();
+            // committed candidates: children in front, reverse processing order
+            for (int j = t; j < ncmt; j += OT) {
+                const int p = L.cpos(ccur)[L.ord[j]];
+                const uint32_t r = L.rng(cur)[p];
+                const int lo = r & 0xffff, hi = r >> 16, d = L.dep(cur)[p];
+                const int k = L.kk[j];
+                const int bnd[5] = {lo, L.nb1[j], L.nb2[j], L.nb3[j], hi};
+                int pos = Kc - L.kinc[j];
+                int childPos[4];
+                if (d < g.ndepth) {
+#pragma unroll
+                    for (int q = 3; q >= 0; q--) {
+                        childPos[q] = pos;
+                        if (bnd[q + 1] > bnd[q]) {
+                            L.rng(nxt)[pos] = (uint32_t)bnd[q] | ((uint32_t)bnd[q + 1] << 16);
+                            L.dep(nxt)[pos] = (uint8_t)(d + 1);
+                            pos++;
+                        }
+                    }
+                    int big = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) big += (bnd[q + 1] - bnd[q] > 1);
+                    int cidx = L.binc[j] - big;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int sz = bnd[q + 1] - bnd[q];
+                        if (sz > 1) {
+                            L.ckey(cnxt)[cidx] = ((uint32_t)sz << 16) | (uint32_t)cidx;
+                            L.cpos(cnxt)[cidx] = (uint16_t)childPos[q];
+                            cidx++;
+                        }
+                    }
+                } else {                                                // cannot happen for distinct keys; keep node
+                    L.rng(nxt)[pos] = r; L.dep(nxt)[pos] = (uint8_t)d;
+                    const int cidx = L.binc[j] - 1;
+                    L.ckey(cnxt)[cidx] = ((uint32_t)(hi - lo) << 16) | (uint32_t)cidx;
+                    L.cpos(cnxt)[cidx] = (uint16_t)pos;
+                }
+                (void)k;
+            }
+            // untouched nodes keep their relative order behind the new children
+            {
+                const int c2 = (m + OT - 1) / OT;
+                const int pb = min(m, t * c2), pe = min(m, pb + c2);
+                uint64_t un = 0;
+                for (int p = pb; p < pe; p++) un += (L.mark[p] == 0);
+                uint64_t tot2;
+                uint64_t ex = block_excl_scan64(un, s_w, tot2);
+                for (int p = pb; p < pe; p++) {
+                    if (L.mark[p] == 0) {
+                        L.rng(nxt)[Kc + (int)ex] = L.rng(cur)[p];
+                        L.dep(nxt)[Kc + (int)ex] = L.dep(cur)[p];
+                        ex++;
+                    }
+                }
+            }
+            newM = Kc + (m - ncmt);
+            const int newNc = L.binc[ncmt - 1];
+            __syncthreads();
+            if (t == 0) { s_i[0] = newM; s_i[1] = newNc; }
+            cur = nxt; ccur = cnxt;
+            __syncthreads();
+            if (newM >= N || newM == prevSize) break;                    // :781
+        }
+    }
+
+    // ---- D: best key per node (:788-807), list order ----
+    const int m = s_i[0];
+    uint32_t* out = selOut + (size_t)b * P.totalOut + g.outBase;
+    for (int p = t; p < m && p < NC; p += OT) {
+        const uint32_t r = L.rng(cur)[p];
+        const int lo = r & 0xffff, hi = r >> 16;
+        uint32_t best = (uint32_t)S[lo];
+        if (hi - lo > 1) {
+            int bs = best & 0xff;
+            uint64_t bo = ~0ull;
+            for (int i = lo; i < hi; i++) {
+                const uint32_t pay = (uint32_t)S[i];
+                const int s = pay & 0xff;
+                const int px = (pay >> 8) & 0xfff, py = pay >> 20;
+                const uint64_t ok = ((uint64_t)(((py - 3) / g.hCell) * g.nCols + (px - 3) / g.wCell) << 24) |
+                                    ((uint64_t)py << 12) | (uint64_t)px;   // candidate order of the reference
+                if (i == lo || s > bs || (s == bs && ok < bo)) { bs = s; bo = ok; best = pay; }
+            }
+        }
+        out[p] = best;
+    }
+    if (t == 0) *myCount = min(m, NC);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: orientation (intensity centroid) + steered BRIEF, one wave per keypoint.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {      // cv::fastAtan2 scalar form
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    const float eps = (float)2.2204460492503131e-16;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+// Deterministic sin/cos shared (by construction, not by code) with the oracle: double Cody-Waite
+// reduction + Taylor polynomials, plain IEEE mul/add in a fixed order, one final rounding to float.
+__device__ __forceinline__ void det_sincos(float rad, float& s_out, float& c_out) {
+    const double x = (double)rad;
+    const double kd = rint(__dmul_rn(x, 0.6366197723675814));
+    const int k = (int)kd;
+    const double y = __dsub_rn(__dsub_rn(x, __dmul_rn(kd, 1.5707963267948966)), __dmul_rn(kd, 6.123233995736766e-17));
+    const double y2 = __dmul_rn(y, y);
+    double ps = -7.647163731819816e-13;
+    ps = __dadd_rn(__dmul_rn(ps, y2), 1.6059043836821613e-10);
+    ps = __dadd_rn(__dmul_rn(ps, y2), -2.505210838544172e-08);
+    ps = __dadd_rn(__dmul_rn(ps, y2), 2.7557319223985893e-06);
+    ps = __dadd_rn(__dmul_rn(ps, y2), -0.0001984126984126984);
+    ps = __dadd_rn(__dmul_rn(ps, y2), 0.008333333333333333);
+    ps = __dadd_rn(__dmul_rn(ps, y2), -0.16666666666666666);
+    const double sn = __dadd_rn(y, __dmul_rn(y, __dmul_rn(y2, ps)));
+    double pc = 4.779477332387385e-14;
+    pc = __dadd_rn(__dmul_rn(pc, y2), -1.1470745597729725e-11);
+    pc = __dadd_rn(__dmul_rn(pc, y2), 2.08767569878681e-09);
+    pc = __dadd_rn(__dmul_rn(pc, y2), -2.755731922398589e-07);
+    pc = __dadd_rn(__dmul_rn(pc, y2), 2.48015873015873e-05);
+    pc = __dadd_rn(__dmul_rn(pc, y2), -0.001388888888888889);
+    pc = __dadd_rn(__dmul_rn(pc, y2), 0.041666666666666664);
+    pc = __dadd_rn(__dmul_rn(pc, y2), -0.5);
+    const double cs = __dadd_rn(1.0, __dmul_rn(y2, pc));
+    double s, c;
+    switch (k & 3) {
+        case 0: s = sn; c = cs; break;
+        case 1: s = cs; c = -sn; break;
+        case 2: s = -sn; c = -cs; break;
+        default: s = -cs; c = sn; break;
+    }
+    s_out = (float)s;
+    c_out = (float)c;
+}
+
+// IC_Angle over the 749-px disc, all 64 lanes; returns the angle on every lane
+__device__ __forceinline__ float wave_ic_angle(const uint8_t* __restrict__ img, int pitch, int x, int y) {
+    const int lane = threadIdx.x & 63;
+    int m10 = 0, m01 = 0;
+    // 31 rows; lanes 2r and 2r+1 share row r (v = r-15): left half incl. centre / right half
+    const int r = lane >> 1;
+    if (r < 31) {
+        const int v = r - 15;
+        const int d = c_umax[v < 0 ? -v : v];
+        const uint8_t* row = img + (size_t)(y + v) * pitch + x;
+        const int u0 = (lane & 1) ? 1 : -d, u1 = (lane & 1) ? d : 0;
+        int sI = 0;
+        for (int u = u0; u <= u1; u++) { const int I = row[u]; m10 += u * I; sI += I; }
+        m01 = v * sI;
+    }
+    m10 = wave_reduce_sum(m10);
+    m01 = wave_reduce_sum(m01);
+    return fast_atan2_deg((float)m01, (float)m10);
+}
+
+// 256-bit rBRIEF; lane l produces bits 4l..4l+3; result bytes assembled with shuffles; lanes 0,8,..,56 hold a u32
+__device__ __forceinline__ uint32_t wave_brief(const uint8_t* __restrict__ img, int pitch, int x, int y, float angle_deg) {
+    const int lane = threadIdx.x & 63;
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    const float ang = __fmul_rn(angle_deg, factorPI);
+    float a, b;
+    det_sincos(ang, b, a);
+    const uint8_t* center = img + (size_t)y * pitch + x;
+    uint32_t nib = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int8_t* pp = &c_pattern[(lane * 4 + j) * 4];
+        const float x0 = (float)pp[0], y0 = (float)pp[1], x1 = (float)pp[2], y1 = (float)pp[3];
+        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+        const int t0 = center[r0 * pitch + c0], t1 = center[r1 * pitch + c1];
+        nib |= (uint32_t)(t0 < t1) << j;
+    }
+    uint32_t byte = nib | (__shfl_down(nib, 1, 64) << 4);            // valid on even lanes
+    uint32_t w = byte | (__shfl_down(byte, 2, 64) << 8);
+    w |= (__shfl_down(byte, 4, 64) << 16) | (__shfl_down(byte, 6, 64) << 24);   // valid on lanes % 8 == 0
+    return w;
+}
+
+__global__ __launch_bounds__(256) void k_describe(OrbPlan P, const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
+                                                  size_t pyrStride, const uint32_t* __restrict__ selOut,
+                                                  const int32_t* __restrict__ selCount, myslam_keypoint* __restrict__ kps,
+                                                  uint8_t* __restrict__ desc, int32_t* __restrict__ counts,
+                                                  int32_t* __restrict__ status, int cap, int detectOnly) {
+    const int b = blockIdx.y;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    int level = -1, local = 0, total = 0;
+    for (int l = 0; l < P.nlevels; l++) {
+        const int c = selCount[b * MAXL + l];
+        if (level < 0 && slot < total + c) { level = l; local = slot - total; }
+        total += c;
+    }
+    if (slot == 0 && lane == 0) {
+        counts[b] = min(total, cap);
+        if (total > cap && status) status[b] = MYSLAM_ERR_CAPACITY;
+    }
+    if (level < 0 || slot >= cap) return;
+    const LevelGeom& g = P.lv[level];
+    const uint32_t pay = selOut[(size_t)b * P.totalOut + g.outBase + local];
+    const int x = (int)((pay >> 8) & 0xfff) + MIN_BORDER, y = (int)(pay >> 20) + MIN_BORDER;    // :897-898
+    myslam_keypoint kp;
+    kp.response = (float)(pay & 0xff);
+    kp.class_id = -1;
+    if (detectOnly) {                         // ORBextractor::Detect: raw cv::FAST keypoints
+        kp.x = (float)x; kp.y = (float)y; kp.size = 7.f; kp.angle = -1.f; kp.octave = 0;
+        if (lane == 0) kps[(size_t)b * cap + slot] = kp;
+        return;
+    }
+    const uint8_t* img = pyr + (size_t)b * pyrStride + g.imgOff;
+    const uint8_t* bl = blur + (size_t)b * pyrStride + g.imgOff;
+    const float angle = wave_ic_angle(img, g.pitch, x, y);                                        // :905-906
+    const uint32_t w = wave_brief(bl, g.pitch, x, y, angle);                                      // :970
+    if ((lane & 7) == 0) reinterpret_cast<uint32_t*>(desc + ((size_t)b * cap + slot) * 32)[lane >> 3] = w;
+    if (lane == 0) {
+        kp.x = (level != 0) ? __fmul_rn((float)x, g.scale) : (float)x;                            // :975-981
+        kp.y = (level != 0) ? __fmul_rn((float)y, g.scale) : (float)y;
+        kp.size = g.scaledPatch; kp.angle = angle; kp.octave = level;
+        kps[(size_t)b * cap + slot] = kp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6/K7: per-keypoint operators of the loop-closing path (one image, n keypoints; wave per keypoint)
+// ------------------------------------------------------------------------------------------------
+// isFastCorner (ORBextractor.cpp:449-511): > 8 contiguous ring pixels darker / brighter than v -/+ th
+__device__ __forceinline__ bool is_fast_corner(const uint8_t* __restrict__ img, int pitch, int x, int y, int th) {
+    constexpr int RX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+    constexpr int RY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+    th = min(max(th, 0), 255);
+    const uint8_t* p = img + (size_t)y * pitch + x;
+    const int v = p[0];
+    unsigned dm = 0, bm = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int pv = p[RX[k] + RY[k] * pitch];
+        dm |= (unsigned)(pv < v - th) << k;
+        bm |= (unsigned)(pv > v + th) << k;
+    }
+    auto run9 = [](unsigned m) {
+        unsigned x = m | (m << 16);       // unrolled ring
+        unsigned r = x & (x >> 1);
+        r &= r >> 2;
+        r &= r >> 4;                      // runs of 8
+        r &= x >> 8;                      // runs of 9
+        return (r & 0xffffu) != 0;
+    };
+    return run9(dm) || run9(bm);
+}
+
+// ScreenAndComputeKPsParams (ORBextractor.cpp:1098-1127): in/out keypoint i, keep flag
+__global__ __launch_bounds__(256) void k_screen(OrbPlan P, const uint8_t* __restrict__ pyr, myslam_keypoint* __restrict__ kin,
+                                                int n, myslam_keypoint* __restrict__ kout, uint8_t* __restrict__ keep) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= n) return;
+    myslam_keypoint k = kin[i];
+    const int level = k.octave;
+    if (level < 0 || level >= P.nlevels) { if (lane == 0) keep[i] = 0; return; }
+    const LevelGeom& g = P.lv[level];
+    const float scale = g.scale;
+    k.x = __fdiv_rn(k.x, scale); k.y = __fdiv_rn(k.y, scale);                                   // :1104
+    bool ok = (__fsub_rn(k.y, (float)EDGE_THRESHOLD) >= 0 && __fadd_rn(k.y, (float)EDGE_THRESHOLD) < (float)g.h &&
+               __fsub_rn(k.x, (float)EDGE_THRESHOLD) >= 0 && __fadd_rn(k.x, (float)EDGE_THRESHOLD) < (float)g.w);
+    const uint8_t* img = pyr + g.imgOff;
+    int px = 0, py = 0;
+    if (ok) {
+        px = __float2int_rn(k.x); py = __float2int_rn(k.y);
+        ok = is_fast_corner(img, g.pitch, px, py, P.minTh);                                     // :1112
+    }
+    if (ok) {                                                                                   // wave-uniform
+        k.angle = wave_ic_angle(img, g.pitch, px, py);                                          // :1118
+        k.size = __fmul_rn((float)PATCH_SIZE, scale);                                           // :1121
+    }
+    k.x = __fmul_rn(k.x, scale); k.y = __fmul_rn(k.y, scale);                                   // :1108/1113/1123
+    if (lane == 0) { kin[i] = k; kout[i] = k; keep[i] = ok ? 1 : 0; }
+}
+
+// CalcDescriptors (ORBextractor.cpp:1210-1223)
+__global__ __launch_bounds__(256) void k_calc_desc(OrbPlan P, const uint8_t* __restrict__ blur, const myslam_keypoint* __restrict__ kps,
+                                                   int n, uint8_t* __restrict__ desc) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const myslam_keypoint k = kps[i];
+    const int level = min(max(k.octave, 0), P.nlevels - 1);
+    const LevelGeom& g = P.lv[level];
+    const int px = __float2int_rn(__fdiv_rn(k.x, g.scale)), py = __float2int_rn(__fdiv_rn(k.y, g.scale));
+    const uint32_t w = wave_brief(blur + g.imgOff, g.pitch, px, py, k.angle);
+    if ((lane & 7) == 0) reinterpret_cast<uint32_t*>(desc + (size_t)i * 32)[lane >> 3] = w;
+}
+
+// unpack a level's candidate list for the debug tap
+__global__ void k_unpack_cands(const uint32_t* __restrict__ cand, int n, int32_t* xs, int32_t* ys, int32_t* sc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = cand[i];
+    xs[i] = (p >> 8) & 0xfff; ys[i] = p >> 20; sc[i] = p & 0xff;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0: ingest level 0 from the caller's buffer (any pitch/alignment) into the 64-byte pitched plane
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ src, int rows, int cols, int step, size_t sstride,
+                                                uint8_t* __restrict__ dst, int dpitch, size_t dstride) {
+    const int b = blockIdx.z, y = blockIdx.y;
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x4 >= cols) return;
+    const uint8_t* s = src + (size_t)b * sstride + (size_t)y * step + x4;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (x4 + k < cols) v |= (uint32_t)s[k] << (8 * k);
+    *reinterpret_cast<uint32_t*>(dst + (size_t)b * dstride + (size_t)y * dpitch + x4) = v;
+}
+
+void launch_ingest(const uint8_t* src, int rows, int cols, int step, size_t sstride, uint8_t* dst, int dpitch,
+                   size_t dstride, int batch, hipStream_t s) {
+    dim3 grid((cols + 1023) / 1024, rows, batch);
+    hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, s, src, rows, cols, step, sstride, dst, dpitch, dstride);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers (called from orb_engine.hip)
+// ------------------------------------------------------------------------------------------------
+void launch_resize(const ResizeArgs& a, int batch, hipStream_t s) {
+    dim3 grid((a.dw + 255) / 256, (a.dh + 3) / 4, batch);
+    hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, a);
+}
+
+void launch_blur(const BlurArgs& a, int batch, hipStream_t s) {
+    dim3 grid((a.w + 63) / 64, (a.h + 15) / 16, batch);
+    hipLaunchKernelGGL(k_blur7, grid, dim3(256), 0, s, a);
+}
+
+void launch_fast(const OrbPlan& P, const uint8_t* pyr, size_t pyrStride, const uint8_t* maskPyr, uint32_t* cand,
+                 int32_t* candCount, int batch, hipStream_t s) {
+    hipLaunchKernelGGL(k_fast_cells, dim3(P.ncells, batch), dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount);
+}
+
+size_t octree_lds_bytes(int nodeCap) { return 64 + (size_t)nodeCap * 36 + 16; }
+
+void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCount, uint64_t* sortbuf, uint32_t* selOut,
+                   int32_t* selCount, int32_t* status, int batch, hipStream_t s) {
+    // one launch per level: LDS is sized by the level's node capacity
+    static size_t lds_attr = 0;
+    for (int l = 0; l < P.nlevels; l++) {
+        const size_t lds = octree_lds_bytes(P.lv[l].nodeCap);
+        if (lds > 48 * 1024 && lds > lds_attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            lds_attr = lds;
+        }
+        hipLaunchKernelGGL(k_octree, dim3(1, batch), dim3(OT), lds, s, P, cand, candCount, sortbuf, selOut, selCount, status, l);
+    }
+}
+
+void launch_describe(const OrbPlan& P, const uint8_t* pyr, const uint8_t* blur, size_t pyrStride, const uint32_t* selOut,
+                     const int32_t* selCount, myslam_keypoint* kps, uint8_t* desc, int32_t* counts, int32_t* status,
+                     int cap, int detectOnly, int batch, hipStream_t s) {
+    const int slots = min(cap, P.totalOut);
+    hipLaunchKernelGGL(k_describe, dim3((slots + 3) / 4, batch), dim3(256), 0, s, P, pyr, blur, pyrStride, selOut, selCount,
+                       kps, desc, counts, status, cap, detectOnly);
+}
+
+void launch_screen(const OrbPlan& P, const uint8_t* pyr, myslam_keypoint* kin, int n, myslam_keypoint* kout, uint8_t* keep,
+                   hipStream_t s) {
+    hipLaunchKernelGGL(k_screen, dim3((n + 3) / 4), dim3(256), 0, s, P, pyr, kin, n, kout, keep);
+}
+
+void launch_calc_desc(const OrbPlan& P, const uint8_t* blur, const myslam_keypoint* kps, int n, uint8_t* desc, hipStream_t s) {
+    hipLaunchKernelGGL(k_calc_desc, dim3((n + 3) / 4), dim3(256), 0, s, P, blur, kps, n, desc);
+}
+
+void launch_unpack_cands(const uint32_t* cand, int n, int32_t* xs, int32_t* ys, int32_t* sc, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_unpack_cands, dim3((n + 255) / 256), dim3(256), 0, s, cand, n, xs, ys, sc);
+}
+
+}  // namespace myslam_hip

@@ -1,0 +1,60 @@
+// orb_plan.h — geometry of one ORB extraction configuration (image size x extractor params).
+// Host computes it once per (rows, cols); kernels receive it by value.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace myslam_hip {
+
+constexpr int MAXL = 12;              // max pyramid levels supported
+constexpr int EDGE_THRESHOLD = 19;    // reference ORBextractor.cpp:25
+constexpr int MIN_BORDER = 16;        // EDGE_THRESHOLD-3, ORBextractor.cpp:822
+constexpr int PATCH_SIZE = 31;
+constexpr int HALF_PATCH = 15;
+constexpr int MAX_CELL = 59;          // FAST grid cell interior is < 60 px for any image (W=30)
+constexpr int MAX_DEPTH = 13;         // quad-tree digits stored in the 32-bit path code
+constexpr int ROOT_SHIFT = 26;        // code = root<<26 | d1<<24 | ... | d13
+
+struct LevelGeom {
+    int w, h, pitch;                  // level image size and internal row pitch (bytes, multiple of 64)
+    int nCols, nRows, wCell, hCell;   // FAST grid, ORBextractor.cpp:830-836
+    int maxBX, maxBY;                 // maxBorderX/Y, :824-825
+    int cellBase;                     // first cell index of this level in the per-image cell list
+    int N;                            // oct-tree budget mnFeaturesPerLevel[l] (:410-421) or nfeatures (Detect)
+    int nIni;                         // root nodes, :590
+    float hX;                         // :592
+    int rootPasses;                   // radix passes covering the root index bits
+    int ndepth;                       // quad-tree depth digits that can ever matter (<= MAX_DEPTH)
+    int keyCap;                       // candidate capacity of the level
+    int nodeCap;                      // node-list capacity (>= N+3)
+    int outBase;                      // first slot of this level in the per-image selected-key array
+    float scale;                      // mvScaleFactor[l]
+    float scaledPatch;                // (int)(31*scale) as float, :891
+    size_t imgOff;                    // byte offset of the level plane inside one image's pyramid block
+    size_t keyOff;                    // element offset of the level's candidate list inside one image's block
+};
+
+struct OrbPlan {
+    int nlevels;
+    int rows, cols;
+    int ncells;                       // total FAST cells per image
+    int iniTh, minTh;
+    int totalKeyCap;                  // sum keyCap
+    int totalOut;                     // sum nodeCap
+    size_t pyrBytes;                  // bytes of one image's pyramid block
+    LevelGeom lv[MAXL];
+};
+
+struct ResizeArgs {
+    const uint8_t* src; int sw, sh, spitch; size_t sstride;
+    uint8_t* dst; int dw, dh, dpitch; size_t dstride;
+    const int32_t* xofs; const int16_t* xa;      // dw, dw*2 (11-bit weights)
+    const int32_t* yofs; const int16_t* yb;      // dh, dh*2
+};
+
+struct BlurArgs {
+    const uint8_t* src; uint8_t* dst; int w, h, spitch, dpitch; size_t sstride, dstride;
+    int q[7];                                    // Q8 taps, sum 256
+};
+
+}  // namespace myslam_hip

@@ -1,0 +1,92 @@
+// prof.hip — per-kernel HIP-event timing + library-wide entry points.
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+namespace myslam_hip {
+
+static const char* kNames[P_COUNT] = {"resize", "fast_cells", "octree", "blur7", "describe", "hamming_match", "triangulate",
+                                      "lcd_preproc", "calc_conv1", "calc_conv2", "calc_conv3", "lcddb_scan", "ba_build", "screen"};
+struct Pending { int id; hipEvent_t a, b; };
+static bool g_on = false;
+static std::mutex g_mu;
+static std::vector<Pending> g_pending;
+static std::vector<hipEvent_t> g_pool;
+static double g_ms[P_COUNT];
+static long g_calls[P_COUNT];
+static thread_local hipEvent_t t_start[P_COUNT];
+
+static hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void prof_begin(int id, hipStream_t s) {
+    if (!g_on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    t_start[id] = get_event();
+    (void)hipEventRecord(t_start[id], s);
+}
+
+void prof_end(int id, hipStream_t s) {
+    if (!g_on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    hipEvent_t e = get_event();
+    (void)hipEventRecord(e, s);
+    g_pending.push_back({id, t_start[id], e});
+}
+
+static void drain() {
+    for (auto& p : g_pending) {
+        (void)hipEventSynchronize(p.b);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { g_ms[p.id] += ms; g_calls[p.id]++; }
+        g_pool.push_back(p.a); g_pool.push_back(p.b);
+    }
+    g_pending.clear();
+}
+
+}  // namespace myslam_hip
+
+using namespace myslam_hip;
+
+extern "C" {
+
+int myslam_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* myslam_hip_version(void) { return "myslam_hip 0.1 (gfx950)"; }
+
+int myslam_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!on) drain();
+    g_on = on != 0;
+    return MYSLAM_OK;
+}
+
+int myslam_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    drain();
+    for (int i = 0; i < P_COUNT; i++) { g_ms[i] = 0; g_calls[i] = 0; }
+    return MYSLAM_OK;
+}
+
+int myslam_prof_count(void) { return P_COUNT; }
+
+int myslam_prof_get(int i, const char** name, double* total_ms, long* launches) {
+    if (i < 0 || i >= P_COUNT) return MYSLAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(g_mu);
+    drain();
+    if (name) *name = kNames[i];
+    if (total_ms) *total_ms = g_ms[i];
+    if (launches) *launches = g_calls[i];
+    return MYSLAM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py — stereo frames/s of the per-frame dense path on MI355X (BASELINE.json metric).
+
+A "step" = one pass of the hot path over one batch of synthetic 1241x376 stereo pairs resident in HBM:
+  ORB DetectAndCompute (2000 features) on left+right -> L/R 256-bit Hamming match -> stereo triangulation
+  -> DeepLCD descriptor of the left image -> cosine scan of the key-frame database -> local-BA block build
+  (one 10 KF x 300 landmark window per frame).           [BASELINE.json configs[3]; --workload orb_match = configs[1]]
+
+One process per GPU (launched by torch.distributed.run for --gpus N > 1).  Frames shard across ranks
+(stream r on rank r, no data-path collective); the loop database is sharded by key-frame id range and the only
+exchange is an all-gather of the query descriptors and of the per-shard (score, id, count) candidates (RCCL).
+
+Prints ONE JSON line (rank 0).  PyTorch is used for device memory, streams and torch.distributed only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+H, W = 376, 1241
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+PYR_PX = 1444097               # sum of the 8 level areas
+# algorithmic bytes per IMAGE of each ORB kernel (SURVEY.md §8(d) accounting)
+ALGO_BYTES = {
+    "resize": 1407767 + 977481,            # read levels 0-6, write levels 1-7
+    "fast_cells": PYR_PX + 4 * 20000,      # read every level once + candidate list
+    "blur7": 2 * PYR_PX,                   # read + write every level
+    "describe": 2000 * (749 + 512 + 60),   # IC patch + BRIEF samples + outputs
+    "octree": 2 * 4 * 56000,               # candidates in, selected out (latency bound in practice)
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step per GPU")
+    ap.add_argument("--workload", default="full", choices=["full", "orb_match", "orb_match_lcd"])
+    ap.add_argument("--db", type=int, default=0, help="key-frame database size (default 10000, or 6250 per GPU when sharded)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=6)
+    return ap.parse_args()
+
+
+def cpu_baseline(synth, workload, n_pairs, db_np):
+    """The oracle (a single-threaded port) timed on this host over a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from pyoracle import Oracle
+    o = Oracle()
+    p = o.params(2000)
+    K = synth.KITTI00
+    w = synth.calc_weights()
+    ids = np.arange(len(db_np), dtype=np.uint64)
+    ba = synth.ba_problem()
+    frames = [synth.stereo_pair(0, t) for t in range(n_pairs)]
+    t0 = time.perf_counter()
+    for L, R in frames:
+        kl, dl = o.detect_and_compute(p, L); kr, dr = o.detect_and_compute(p, R)
+        idx, dist = o.hamming_match(dl, dr)
+        o.triangulate_stereo(kl["x"], kl["y"], kr["x"][idx], kr["y"][idx], K["fx"], K["fy"], K["cx"], K["cy"], K["bf"] / K["fx"])
+        if workload != "orb_match":
+            x, _ = o.calc_preproc(L)
+            d = o.calc_forward(w, x)
+            o.lcddb_query(db_np, ids, d, len(db_np) + 20)
+        if workload == "full":
+            o.ba_build(*ba[:6], ba[6])
+    dt = time.perf_counter() - t0
+    return {"value": n_pairs / dt, "unit": "stereo frames/s", "cores": 1, "kind": "port",
+            "sample": f"{n_pairs} synthetic 1241x376 stereo pairs, same stages as the GPU workload, oracle single thread, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    pkg = load_package()
+    api, synth = pkg.api, pkg.synth
+    assert api.device_count() >= 1
+    stream = torch.cuda.current_stream().cuda_stream
+    P = args.pairs
+    K = synth.KITTI00
+    Kt = (K["fx"], K["fy"], K["cx"], K["cy"])
+
+    # ---- inputs resident in HBM before the timed region ----
+    frames = synth.stereo_batch(P, stream_id=rank)                      # [P, 2, H, W]
+    imgs = np.concatenate([frames[:, 0], frames[:, 1]], axis=0)         # all left images, then all right images
+    d_imgs = torch.from_numpy(imgs).to(dev)
+    ext = api.ORBextractor(2000, stream=stream)
+    cap = ext.max_keypoints()
+    d_kps = torch.zeros(2 * P * cap * 28, dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros(2 * P * cap * 32, dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(2 * P, dtype=torch.int32, device=dev)
+    d_stat = torch.zeros(2 * P, dtype=torch.int32, device=dev)
+    d_midx = torch.zeros(P * cap, dtype=torch.int32, device=dev)
+    d_mdist = torch.zeros(P * cap, dtype=torch.int32, device=dev)
+    d_xyz = torch.zeros(P * cap * 3, dtype=torch.float64, device=dev)
+    d_ok = torch.zeros(P * cap, dtype=torch.uint8, device=dev)
+    use_lcd = args.workload != "orb_match"
+    use_ba = args.workload == "full"
+    n_db_local = args.db or (10000 if world == 1 else 6250)
+    db_np = None
+    if use_lcd:
+        lcd = api.DeepLCD(synth.calc_weights(), stream=stream)
+        d_descr = torch.zeros(P, 1064, device=dev)
+        db_np = synth.lcd_database(n_db_local, seed=0xDB + rank)
+        D = api.LoopDatabase(n_db_local, stream=stream)
+        ids = np.arange(rank * n_db_local, (rank + 1) * n_db_local, dtype=np.uint64)     # contiguous id range per shard
+        t_db = torch.from_numpy(db_np).to(dev)
+        D.append_batch(ids, t_db.data_ptr(), n_db_local)
+        NQ = P * world
+        cur_ids = np.full(NQ, world * n_db_local + 20, np.uint64)
+        d_allq = torch.zeros(NQ, 1064, device=dev)
+        d_best = torch.zeros(NQ, dtype=torch.int64, device=dev)
+        d_max = torch.zeros(NQ, device=dev); d_dbcnt = torch.zeros(NQ, dtype=torch.int32, device=dev)
+    if use_ba:
+        poses, pts, ep, el, obs, fixed, _ = synth.ba_problem()
+        maxP, maxL, maxE = len(poses), len(pts), len(ep)
+        rep = lambda a: torch.from_numpy(np.ascontiguousarray(np.broadcast_to(a, (P,) + a.shape))).to(dev)
+        b_in = [rep(poses), rep(pts), rep(ep), rep(el), rep(obs), rep(fixed),
+                torch.tensor([[maxP, maxL, maxE]] * P, dtype=torch.int32, device=dev)]
+        b_out = [torch.zeros(P, n, dtype=torch.float64, device=dev) for n in (maxP * 36, maxL * 9, maxE * 18, maxP * 6, maxL * 3, maxE)]
+
+    def step():
+        ext.detect_and_compute_batch(d_imgs.data_ptr(), 2 * P, H, W, W, H * W, d_kps.data_ptr(), d_desc.data_ptr(),
+                                     d_cnt.data_ptr(), d_stat.data_ptr(), cap)
+        api.hamming_match_batch(d_desc.data_ptr(), d_cnt.data_ptr(), d_desc.data_ptr() + P * cap * 32, d_cnt.data_ptr() + 4 * P,
+                                P, cap, d_midx.data_ptr(), d_mdist.data_ptr(), stream)
+        api.triangulate_stereo_batch(d_kps.data_ptr(), d_kps.data_ptr() + P * cap * 28, d_midx.data_ptr(), d_cnt.data_ptr(), P, cap,
+                                     Kt, K["bf"] / K["fx"], d_xyz.data_ptr(), d_ok.data_ptr(), stream)
+        if use_lcd:
+            lcd.describe_batch(d_imgs.data_ptr(), P, H, W, W, H * W, d_descr.data_ptr(), blur_in_place=False)
+            if world > 1:       # every shard scores every rank's queries; candidates are merged after an all-gather
+                dist.all_gather_into_tensor(d_allq, d_descr)
+                D.query_batch(d_allq.data_ptr(), cur_ids, NQ, d_best.data_ptr(), d_max.data_ptr(), d_dbcnt.data_ptr())
+                pkg.sharded_db.merge_candidates(d_best, d_max, d_dbcnt, world)
+            else:
+                D.query_batch(d_descr.data_ptr(), cur_ids, NQ, d_best.data_ptr(), d_max.data_ptr(), d_dbcnt.data_ptr())
+        if use_ba:
+            api.ba_build_batch(*[t.data_ptr() for t in b_in], P, maxP, maxL, maxE, Kt, 5.991, *[t.data_ptr() for t in b_out], stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    assert int(d_stat.abs().sum()) == 0, "ORB capacity overflow"
+    n_kp = d_cnt.float().mean().item()
+
+    api.prof_reset(); api.prof_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    api.prof_enable(False)
+    prof = api.prof_read()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = world * P * args.steps / dt
+        # dominant kernel and its roofline position (HIP events on the launch stream, over the timed region)
+        busy = {k: v for k, v in prof.items() if v[1] > 0}
+        dom = max(busy, key=lambda k: busy[k][0])
+        dom_ms, dom_n = busy[dom]
+        per_launch_ms = dom_ms / dom_n
+        imgs_per_launch = 2 * P
+        launches_per_step = dom_n / args.steps
+        if dom in ALGO_BYTES:
+            algo = ALGO_BYTES[dom] * imgs_per_launch / launches_per_step        # bytes per launch
+            achieved = algo / (per_launch_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": per_launch_ms,
+                    "algorithmic_bytes_per_launch": algo}
+        else:
+            roof = {"bound": "hbm", "kernel": dom, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                    "traffic": None, "avg_launch_ms": per_launch_ms}
+        out = {
+            "metric": "stereo frames/sec (ORB+match+LCD+BA-build) @1241x376",
+            "value": value, "unit": "stereo frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/int32 (ORB, Hamming), f32 (CALC, DB scan), f64 (triangulation, BA)", "data": "synthetic",
+            "config": {"workload": {"full": "configs[3]: ORB extract L+R (2000 feats) + L/R Hamming match + triangulation + DeepLCD descriptor + "
+                                            f"{n_db_local * world}-KF cosine DB scan + local-BA (10 KF x 300 MP) block build per frame",
+                                    "orb_match": "configs[1]: ORB extract L+R (2000 feats) + L/R Hamming match + triangulation",
+                                    "orb_match_lcd": f"configs[2]: configs[1] + DeepLCD descriptor + {n_db_local * world}-KF cosine DB scan"}[args.workload],
+                       "pairs_per_step_per_gpu": P, "image": "1241x376 u8", "keypoints_per_image": n_kp,
+                       "parallelism": f"frame-sharded x{world}" + (", id-range sharded DB + all-gather of candidates" if world > 1 else "")},
+            "roofline": roof,
+            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in busy.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(synth, args.workload, args.cpu_pairs, db_np if db_np is not None else synth.lcd_database(16))
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

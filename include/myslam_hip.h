@@ -1,0 +1,201 @@
+/*
+ * myslam_hip.h — C ABI of libmyslam_hip.so: the MI355X (gfx950) implementation of the per-frame
+ * dense path of "A Simple Stereo SLAM System with Deep Loop Closing".
+ *
+ * The reference has no FFI/plugin layer: the path sits behind C++ member functions of libmyslam.so
+ * (SURVEY.md §8b).  Each entry point below names the reference interface it replaces
+ * (file:line under the reference tree).  A maintainer's binding is shown in INTEGRATION.md; the
+ * C++ facade with the reference's own class names lives in <pkg>/host/.
+ *
+ * Conventions: caller-owned buffers; plain pointers and sizes; int status (0 = ok, <0 = error);
+ * no exceptions cross the ABI.  "_batch" entry points take DEVICE pointers, are asynchronous on
+ * the handle's HIP stream and never synchronise; the others take HOST pointers and return when the
+ * result is in the caller's buffers.  There is NO CPU fallback: every call fails with
+ * MYSLAM_ERR_HIP when no gfx950 device is usable.
+ */
+#ifndef MYSLAM_HIP_H
+#define MYSLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MYSLAM_OK 0
+#define MYSLAM_ERR_INVALID (-1)     /* bad argument */
+#define MYSLAM_ERR_HIP (-2)         /* HIP runtime error / no device */
+#define MYSLAM_ERR_CAPACITY (-3)    /* an output or internal buffer was too small */
+#define MYSLAM_ERR_UNSUPPORTED (-4) /* image too small for the 30-px FAST grid etc. */
+
+/* cv::KeyPoint layout (28 bytes): pt.x pt.y size angle response octave class_id */
+typedef struct myslam_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} myslam_keypoint;
+
+#define MYSLAM_DESC_BYTES 32   /* 256-bit rBRIEF */
+#define MYSLAM_LCD_DIM 1064    /* DeepLCD::DescrVector, include/myslam/deeplcd.h:25 */
+
+/* ------------------------------------------------------------------------------------------
+ * Library-wide
+ * ------------------------------------------------------------------------------------------ */
+int myslam_hip_device_count(void);
+const char* myslam_hip_version(void);
+/* per-kernel HIP-event timing: enable, run, synchronise, then read (name, total ms, launches) */
+int myslam_prof_enable(int on);
+int myslam_prof_reset(void);
+int myslam_prof_count(void);
+int myslam_prof_get(int i, const char** name, double* total_ms, long* launches);
+
+/* ------------------------------------------------------------------------------------------
+ * ORB extractor — replaces class ORBextractor (include/myslam/ORBextractor.h:52-110)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct myslam_orb myslam_orb;
+
+/* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)  ORBextractor.h:55-56 */
+int myslam_orb_create(myslam_orb** out, int nfeatures, float scale_factor, int nlevels,
+                      int ini_th_fast, int min_th_fast);
+int myslam_orb_destroy(myslam_orb* h);
+/* all work of this handle is issued on `hip_stream` (a hipStream_t; NULL = default stream) */
+int myslam_orb_set_stream(myslam_orb* h, void* hip_stream);
+/* getters ORBextractor.h:87-107 */
+int myslam_orb_get_tables(const myslam_orb* h, float* scale, float* inv_scale, int* features_per_level, int* umax16);
+/* upper bound of keypoints DetectAndCompute can return for one image (octree may exceed nfeatures) */
+int myslam_orb_max_keypoints(const myslam_orb* h);
+
+/* void DetectAndCompute(image, mask, keypoints, descriptors)   ORBextractor.h:61-63, .cpp:922-985
+ * mask may be NULL (= all 255).  desc: cap x 32 bytes. */
+int myslam_orb_detect_and_compute(myslam_orb* h, const uint8_t* img, int rows, int cols, int step,
+                                  const uint8_t* mask, int mask_step,
+                                  myslam_keypoint* kps, uint8_t* desc, int cap, int* n);
+/* void Detect(image, mask, keypoints)   ORBextractor.h:70-71, .cpp:989-1074 (level 0 only) */
+int myslam_orb_detect(myslam_orb* h, const uint8_t* img, int rows, int cols, int step,
+                      const uint8_t* mask, int mask_step, myslam_keypoint* kps, int cap, int* n);
+/* void ScreenAndComputeKPsParams(image, keypoints, out_keypoints)   ORBextractor.h:83-84, .cpp:1083-1129
+ * kps_in is modified in place exactly as the reference does (pt /= scale ... pt *= scale). */
+int myslam_orb_screen_and_compute_params(myslam_orb* h, const uint8_t* img, int rows, int cols, int step,
+                                         myslam_keypoint* kps_in, int n_in,
+                                         myslam_keypoint* kps_out, int cap, int* n_out);
+/* void CalcDescriptors(image, keypoints, descriptors)   ORBextractor.h:65-67, .cpp:1180-1226 */
+int myslam_orb_calc_descriptors(myslam_orb* h, const uint8_t* img, int rows, int cols, int step,
+                                const myslam_keypoint* kps, int n, uint8_t* desc);
+
+/* Batched DetectAndCompute over `batch` same-sized images resident in HBM.
+ *   d_imgs : batch images, image b at d_imgs + b*img_stride, row pitch `step` bytes
+ *   d_masks: NULL or same layout
+ *   d_kps  : batch x cap keypoints, d_desc: batch x cap x 32, d_counts: batch
+ *   d_status: batch int32 (0 ok / MYSLAM_ERR_CAPACITY), may be NULL
+ * level_only0 != 0 runs Detect() semantics (level 0, N = nfeatures, no angle/descriptor). */
+int myslam_orb_detect_and_compute_batch(myslam_orb* h, const uint8_t* d_imgs, int batch, int rows, int cols,
+                                        int step, size_t img_stride, const uint8_t* d_masks,
+                                        myslam_keypoint* d_kps, uint8_t* d_desc, int32_t* d_counts,
+                                        int32_t* d_status, int cap);
+int myslam_orb_detect_batch(myslam_orb* h, const uint8_t* d_imgs, int batch, int rows, int cols,
+                            int step, size_t img_stride, const uint8_t* d_masks,
+                            myslam_keypoint* d_kps, int32_t* d_counts, int32_t* d_status, int cap);
+
+/* debug/inspection taps used by the stage-level parity tests (host buffers, one image) */
+int myslam_orb_debug_pyramid(myslam_orb* h, const uint8_t* img, int rows, int cols, int step,
+                             int level, int blurred, uint8_t* out, int out_step, int* w, int* hgt);
+int myslam_orb_debug_candidates(myslam_orb* h, const uint8_t* img, int rows, int cols, int step,
+                                const uint8_t* mask, int mask_step, int level,
+                                int32_t* xs, int32_t* ys, int32_t* scores, int cap, int* n);
+
+/* ------------------------------------------------------------------------------------------
+ * Hamming brute force — replaces cv::BFMatcher(NORM_HAMMING)::match as used at
+ * src/loopclosing.cpp:33,172 and the filter at :175-194.  One match per query row, ties -> lowest
+ * train index.  nt == 0 -> train_idx = -1, dist = -1.
+ * ------------------------------------------------------------------------------------------ */
+int myslam_hamming_match(const uint8_t* query, int nq, const uint8_t* train, int nt,
+                         int32_t* train_idx, int32_t* dist);
+/* batch: pair p uses d_q + p*cap*32 (d_nq[p] rows) vs d_t + p*cap*32 (d_nt[p] rows) */
+int myslam_hamming_match_batch(const uint8_t* d_q, const int32_t* d_nq, const uint8_t* d_t, const int32_t* d_nt,
+                               int batch, int cap, int32_t* d_train_idx, int32_t* d_dist, void* hip_stream);
+/* keep[i] = dist[i] <= max(2*min_dist, 30.0)   (loopclosing.cpp:175-186); host-side bookkeeping */
+int myslam_hamming_filter(const int32_t* dist, int n, uint8_t* keep, int* min_dist);
+
+/* ------------------------------------------------------------------------------------------
+ * Triangulation — replaces triangulation() include/myslam/algorithm.h:16-33 with the stereo rig
+ * of src/system.cpp:108-116,141-145 and Camera::pixel2camera src/camera.cpp:22-26.
+ * ok[i] = (sigma3/sigma2 < 1e-2) && z > 0   (frontend.cpp:400, 471).
+ * ------------------------------------------------------------------------------------------ */
+int myslam_triangulate_stereo(const float* xl, const float* yl, const float* xr, const float* yr, int n,
+                              double fx, double fy, double cx, double cy, double baseline,
+                              double* xyz, uint8_t* ok);
+/* batch: left keypoint i of pair p is matched to right keypoint d_match[p*cap+i] (<0 = none) */
+int myslam_triangulate_stereo_batch(const myslam_keypoint* d_kps_l, const myslam_keypoint* d_kps_r,
+                                    const int32_t* d_match, const int32_t* d_nl, int batch, int cap,
+                                    double fx, double fy, double cx, double cy, double baseline,
+                                    double* d_xyz, uint8_t* d_ok, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------
+ * DeepLCD — replaces class DeepLCD (include/myslam/deeplcd.h:21-48, src/deeplcd.cpp:10-91)
+ * weights: flat f32 blob conv1.w[64][1][5][5] conv1.b[64] conv2.w[128][64][4][4] conv2.b[128]
+ *          conv3.w[4][128][3][3] conv3.b[4]  (137476 floats; the Caffe model is not redistributable)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct myslam_lcd myslam_lcd;
+int myslam_lcd_create(myslam_lcd** out, const float* weights, size_t nweights);
+int myslam_lcd_create_from_file(myslam_lcd** out, const char* path);
+int myslam_lcd_destroy(myslam_lcd* h);
+int myslam_lcd_set_stream(myslam_lcd* h, void* hip_stream);
+size_t myslam_lcd_nweights(void);
+/* DescrVector calcDescrOriginalImg(const cv::Mat&)  deeplcd.cpp:43-52.  blur_in_place != 0 reproduces
+ * the reference's side effect (the caller's image is Gaussian-blurred). */
+int myslam_lcd_calc_descr_original_img(myslam_lcd* h, uint8_t* img, int rows, int cols, int step,
+                                       int blur_in_place, float* descr1064);
+/* const DescrVector calcDescr(const cv::Mat& im)  deeplcd.cpp:55-91; im = 160x120 u8 */
+int myslam_lcd_calc_descr(myslam_lcd* h, const uint8_t* img160x120, int step, float* descr1064);
+/* const float score(d1, d2)  deeplcd.cpp:35-39 */
+float myslam_lcd_score(const float* d1, const float* d2);
+int myslam_lcd_describe_batch(myslam_lcd* h, uint8_t* d_imgs, int batch, int rows, int cols, int step,
+                              size_t img_stride, int blur_in_place, float* d_descr /* batch x 1064 */);
+/* stage taps for parity tests (host buffers, one image) */
+int myslam_lcd_debug_forward(myslam_lcd* h, const float* in120x160, float* out_stage, int stage, size_t cap_floats);
+
+/* ------------------------------------------------------------------------------------------
+ * Loop database — replaces LoopClosing::_mvDatabase + DetectLoop()/AddToDatabase()
+ * (include/myslam/loopclosing.h:67,120; src/loopclosing.cpp:124-161, 651-659).
+ * ids must be appended in ascending order (std::map iteration order).
+ * query: scan ascending, stop at the first id with cur_id - id < 20, max score (strict >, init 0),
+ *        cnt = #{score > thr_low}.  The caller applies maxScore >= thr_high && cnt <= 3.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct myslam_lcddb myslam_lcddb;
+int myslam_lcddb_create(myslam_lcddb** out, int capacity);
+int myslam_lcddb_destroy(myslam_lcddb* h);
+int myslam_lcddb_set_stream(myslam_lcddb* h, void* hip_stream);
+int myslam_lcddb_size(const myslam_lcddb* h);
+int myslam_lcddb_append(myslam_lcddb* h, uint64_t id, const float* descr1064);
+int myslam_lcddb_append_batch(myslam_lcddb* h, const uint64_t* ids /*host*/, const float* d_descr, int n);
+int myslam_lcddb_query(myslam_lcddb* h, const float* descr1064, uint64_t cur_id, float thr_low,
+                       uint64_t* best_id, float* max_score, int* cnt);
+/* nq queries at once: d_q nq x 1064 (device), cur_ids nq (HOST); outputs nq each (device).  nq <= 1024. */
+int myslam_lcddb_query_batch(myslam_lcddb* h, const float* d_q, const uint64_t* cur_ids /*host*/, int nq, float thr_low,
+                             uint64_t* d_best_id, float* d_max_score, int32_t* d_cnt);
+
+/* ------------------------------------------------------------------------------------------
+ * Local BA linear-system build — replaces the per-edge work g2o does for
+ * Backend::OptimizeActiveMap (src/backend.cpp:126-232): EdgeProjection::computeError /
+ * linearizeOplus (include/myslam/g2o_types.h:115-144), Huber(delta) and the block quadratic form.
+ * poses  nposes x 7  (qx qy qz qw tx ty tz), Tcw;  points npts x 3;  obs nedges x 2
+ * Hpp nposes x 36, Hll npts x 9, Hpl nedges x 18 (6x3 row-major), bp nposes x 6, bl npts x 3,
+ * chi2 nedges (un-robustified e^T e, what edge->chi2() returns at backend.cpp:219,238)
+ * ------------------------------------------------------------------------------------------ */
+int myslam_ba_build(const double* poses, int nposes, const double* points, int npts,
+                    const int32_t* edge_pose, const int32_t* edge_pt, const double* obs, int nedges,
+                    const uint8_t* fixed_pt, double fx, double fy, double cx, double cy, double huber_delta,
+                    double* Hpp, double* Hll, double* Hpl, double* bp, double* bl, double* chi2);
+/* batch of `nwin` windows with identical capacities (max_poses, max_pts, max_edges); window w's arrays
+ * start at base + w*capacity*elemsize; d_sizes = nwin x 3 (nposes, npts, nedges) */
+int myslam_ba_build_batch(const double* d_poses, const double* d_points, const int32_t* d_edge_pose,
+                          const int32_t* d_edge_pt, const double* d_obs, const uint8_t* d_fixed,
+                          const int32_t* d_sizes, int nwin, int max_poses, int max_pts, int max_edges,
+                          double fx, double fy, double cx, double cy, double huber_delta,
+                          double* d_Hpp, double* d_Hll, double* d_Hpl, double* d_bp, double* d_bl, double* d_chi2,
+                          void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MYSLAM_HIP_H */

@@ -1,0 +1,41 @@
+"""The oracle must keep reproducing the committed golden fixtures (CPU); the HIP path must too (GPU)."""
+import os
+
+import numpy as np
+import pytest
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_oracle_reproduces_golden(oracle, synth):
+    g = np.load(os.path.join(G, "orb_small.npz"))
+    kps, desc = oracle.detect_and_compute(oracle.params(int(g["nfeatures"])), g["image"])
+    assert kps.tobytes() == g["kps"].tobytes() and np.array_equal(desc, g["desc"])
+    assert oracle.detect(oracle.params(100), g["image"]).tobytes() == g["detect100"].tobytes()
+    assert np.array_equal(g["image"], synth.random_image(4242, 240, 320))          # the generator is part of the contract
+    h = np.load(os.path.join(G, "hamming_small.npz"))
+    idx, dist = oracle.hamming_match(h["q"], h["t"])
+    assert np.array_equal(idx, h["idx"]) and np.array_equal(dist, h["dist"])
+    c = np.load(os.path.join(G, "calc_small.npz"))
+    assert np.abs(oracle.calc_forward(synth.calc_weights(int(c["weights_seed"])), c["x"]) - c["descr"]).max() < 1e-7
+    b = np.load(os.path.join(G, "ba_small.npz"))
+    got = oracle.ba_build(b["poses"], b["pts"], b["ep"], b["el"], b["obs"], b["fixed"], tuple(b["K"]))
+    for a, name in zip(got, ["Hpp", "Hll", "Hpl", "bp", "bl", "chi2"]):
+        assert np.allclose(a, b[name], rtol=1e-13, atol=1e-9), name
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_golden(api, synth):
+    g = np.load(os.path.join(G, "orb_small.npz"))
+    kps = api.ORBextractor(100).Detect(g["image"])
+    assert kps.tobytes() == g["detect100"].tobytes()
+    h = np.load(os.path.join(G, "hamming_small.npz"))
+    idx, dist = api.hamming_match(h["q"], h["t"])
+    assert np.array_equal(idx, h["idx"]) and np.array_equal(dist, h["dist"])
+    c = np.load(os.path.join(G, "calc_small.npz"))
+    lcd = api.DeepLCD(synth.calc_weights(int(c["weights_seed"])))
+    assert np.abs(lcd.debug_forward(c["x"], 4) - c["descr"]).max() < 2e-5
+    b = np.load(os.path.join(G, "ba_small.npz"))
+    got = api.ba_build(b["poses"], b["pts"], b["ep"], b["el"], b["obs"], b["fixed"], tuple(b["K"]))
+    for a, name in zip(got, ["Hpp", "Hll", "Hpl", "bp", "bl", "chi2"]):
+        assert np.allclose(a, b[name], rtol=1e-10, atol=1e-7), name

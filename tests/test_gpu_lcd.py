@@ -1,0 +1,141 @@
+"""GPU parity: DeepLCD/CALC descriptor (f32, stated tolerance) and the loop-database scan."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+# f32 network, different summation order on the GPU (MFMA k-order, wave reductions) and powf implementations:
+# descriptor entries are O(0.03) after normalisation; 2e-5 absolute is ~1e-3 relative of a typical entry.
+DESC_ATOL = 2e-5
+SCORE_ATOL = 2e-5
+
+
+def _nhwc_to_nchw(a, h, w, c):
+    return a.reshape(h, w, c).transpose(2, 0, 1)
+
+
+def test_preproc_and_descriptor(api, oracle, synth):
+    w = synth.calc_weights()
+    lcd = api.DeepLCD(w)
+    for sid in (0, 1):
+        L, _ = synth.stereo_pair(sid, 2)
+        d, after = lcd.calcDescrOriginalImg(L, blur_in_place=True)
+        x, rafter = oracle.calc_preproc(L, blur_in_place=True)
+        assert np.array_equal(after, rafter), "in-place 7x7 blur (deeplcd.cpp:46) must be bit-exact"
+        ref = oracle.calc_forward(w, x)
+        assert np.abs(d - ref).max() < DESC_ATOL, np.abs(d - ref).max()
+        assert abs(np.linalg.norm(d) - 1) < 1e-5
+        d2, after2 = lcd.calcDescrOriginalImg(L, blur_in_place=False)
+        assert np.array_equal(after2, L) and np.array_equal(d, d2)
+        small = oracle.resize(oracle.blur7(L, 1), 160, 120)
+        d3 = lcd.calcDescr(small)                                   # DeepLCD::calcDescr on the already-resized image
+        assert np.abs(d3 - ref).max() < DESC_ATOL
+
+
+def test_layer_taps_against_torch(api, synth):
+    import torch
+    import torch.nn.functional as F
+    w = synth.calc_weights(); lcd = api.DeepLCD(w)
+    x = synth._rng(21).uniform(0, 1, (120, 160)).astype(np.float32)
+    o = [0]
+    def take(shape):
+        n = int(np.prod(shape)); t = torch.from_numpy(w[o[0]:o[0] + n].reshape(shape).copy()).double(); o[0] += n
+        return t
+    w1, b1, w2, b2, w3, b3 = take((64, 1, 5, 5)), take((64,)), take((128, 64, 4, 4)), take((128,)), take((4, 128, 3, 3)), take((4,))
+    t = torch.from_numpy(x)[None, None].double()
+    a1 = F.relu(F.conv2d(t, w1, b1, stride=2, padding=4))
+    p1 = F.local_response_norm(F.max_pool2d(a1, 3, 2, ceil_mode=True), 5, alpha=1e-4, beta=0.75, k=1.0)
+    a2 = F.relu(F.conv2d(p1, w2, b2, stride=1, padding=2))
+    p2 = F.local_response_norm(F.max_pool2d(a2, 3, 2, ceil_mode=True), 5, alpha=1e-4, beta=0.75, k=1.0)
+    refs = [(a1, 62, 82, 64), (p1, 31, 41, 64), (a2, 32, 42, 128), (p2, 16, 21, 128)]
+    for stage, (r, h, ww, c) in enumerate(refs):
+        got = _nhwc_to_nchw(lcd.debug_forward(x, stage), h, ww, c)
+        ref = r[0].numpy()
+        err = np.abs(got - ref).max() / max(1e-6, np.abs(ref).max())
+        assert err < 2e-5, (stage, err)                              # asymmetric weights: a transposed tile would fail here
+
+
+def test_describe_batch(api, oracle, synth):
+    import torch
+    w = synth.calc_weights(); lcd = api.DeepLCD(w)
+    B = 5
+    imgs = np.stack([synth.stereo_pair(0, t)[0] for t in range(B)])
+    d_imgs = torch.from_numpy(imgs).cuda(); d_out = torch.zeros(B, 1064, device="cuda")
+    lcd.describe_batch(d_imgs.data_ptr(), B, 376, 1241, 1241, 376 * 1241, d_out.data_ptr(), blur_in_place=False)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    assert np.array_equal(d_imgs.cpu().numpy(), imgs)
+    for b in range(B):
+        x, _ = oracle.calc_preproc(imgs[b])
+        assert np.abs(out[b] - oracle.calc_forward(w, x)).max() < DESC_ATOL
+    lcd.describe_batch(d_imgs.data_ptr(), B, 376, 1241, 1241, 376 * 1241, d_out.data_ptr(), blur_in_place=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_imgs.cpu().numpy()[2], oracle.blur7(imgs[2], 1))
+    assert np.abs(d_out.cpu().numpy() - out).max() == 0
+
+
+def test_score(api, oracle, synth):
+    db = synth.lcd_database(4)
+    assert api.DeepLCD.score(db[0], db[1]) == pytest.approx(oracle.lib.orc_lcd_score(db[0].ctypes.data, db[1].ctypes.data), abs=1e-6)
+
+
+@pytest.mark.parametrize("n", [60, 1000, 10000])
+def test_loop_database_scan(api, oracle, synth, n):
+    db = synth.lcd_database(n)
+    ids = (np.arange(n, dtype=np.uint64) * 3 + 5)
+    D = api.LoopDatabase(n + 7)
+    for i in range(min(n, 40)):
+        D.AddToDatabase(int(ids[i]), db[i])                          # one-by-one like LoopClosing::AddToDatabase
+    if n > 40:
+        import torch
+        t = torch.from_numpy(db[40:]).cuda()
+        D.append_batch(ids[40:], t.data_ptr(), n - 40)
+    assert len(D) == n
+    rng = np.random.default_rng(n)
+    for trial in range(6):
+        q = db[rng.integers(0, n)] * 0.97 + 0.03 * synth.lcd_database(1, seed=trial + 1)[0]
+        q = (q / np.linalg.norm(q)).astype(np.float32)
+        cur = int(ids[-1] + 20) if trial < 3 else int(ids[rng.integers(n // 2, n)])
+        best, mx, cnt = D.query(q, cur)
+        rbest, rmx, rcnt = oracle.lcddb_query(db, ids, q, cur)
+        assert best == rbest and abs(mx - rmx) < SCORE_ATOL
+        scores = db @ q
+        near = np.abs(scores - 0.92) < 1e-5                          # counts may only differ for scores within float noise of the threshold
+        assert abs(cnt - rcnt) <= int(near.sum())
+    with pytest.raises(api.MyslamError):
+        D.AddToDatabase(int(ids[-1]), db[0])                         # ids must ascend (std::map order)
+
+
+def test_loop_database_rules(api, oracle, synth):
+    db = synth.lcd_database(100); ids = np.arange(100, dtype=np.uint64) * 2
+    D = api.LoopDatabase(100)
+    for i in range(100):
+        D.AddToDatabase(int(ids[i]), db[i])
+    db2 = db.copy()
+    assert D.query(db[37], 300)[0] == 74
+    assert D.query(db[37], 5) == (0, 0.0, 0)                         # nothing older than 20 ids -> bestId 0, maxScore 0
+    for cur in (19, 20, 21, 39, 40, 41, 90, 197, 198, 199, 218, 219):
+        got = D.query(db[10], cur); ref = oracle.lcddb_query(db2, ids, db[10], cur)
+        assert got[0] == ref[0] and abs(got[1] - ref[1]) < SCORE_ATOL and got[2] == ref[2], cur
+    ok, cand = D.DetectLoop(db[37], 300)
+    assert ok and cand == 74
+    assert D.DetectLoop(synth.lcd_database(1, seed=5)[0], 300) == (False, None)
+
+
+def test_loop_database_batch_queries(api, oracle, synth):
+    import torch
+    n, nq = 3000, 37
+    db = synth.lcd_database(n); ids = np.arange(n, dtype=np.uint64)
+    D = api.LoopDatabase(n)
+    t = torch.from_numpy(db).cuda(); D.append_batch(ids, t.data_ptr(), n)
+    rng = np.random.default_rng(8)
+    q = db[rng.integers(0, n, nq)] * 0.9 + 0.1 * synth.lcd_database(nq, seed=77)
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    cur = rng.integers(100, n + 40, nq).astype(np.uint64)
+    dq = torch.from_numpy(q).cuda()
+    dbest = torch.zeros(nq, dtype=torch.int64, device="cuda"); dmax = torch.zeros(nq, device="cuda"); dcnt = torch.zeros(nq, dtype=torch.int32, device="cuda")
+    D.query_batch(dq.data_ptr(), cur, nq, dbest.data_ptr(), dmax.data_ptr(), dcnt.data_ptr())
+    torch.cuda.synchronize()
+    for i in range(nq):
+        rb, rm, rc = oracle.lcddb_query(db, ids, q[i], int(cur[i]))
+        assert int(dbest[i]) == rb and abs(float(dmax[i]) - rm) < SCORE_ATOL and int(dcnt[i]) == rc

@@ -1,0 +1,77 @@
+"""GPU parity: Hamming brute force (bit-exact) and stereo triangulation (f64, stated tolerance)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (7, 3), (300, 513), (2000, 2000), (2011, 1987), (5, 0)])
+def test_hamming_match_bitexact(api, oracle, nq, nt):
+    rng = np.random.default_rng(nq * 7919 + nt)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    if nt > 20:                                     # plant exact duplicates and near matches -> exercises tie-breaking
+        t[nt // 2] = t[3]; q[0] = t[3]
+        q[1] = t[7]; q[1, 0] ^= 1
+    idx, dist = api.hamming_match(q, t)
+    ridx, rdist = oracle.hamming_match(q, t)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    if nt > 20:
+        assert idx[0] == 3 and dist[0] == 0 and dist[1] == 1
+    if nt == 0:
+        assert (idx == -1).all() and (dist == -1).all()
+
+
+def test_hamming_on_real_descriptors_and_filter(api, oracle, synth):
+    L, R = synth.stereo_pair(1, 0)
+    kl, dl = oracle.detect_and_compute(oracle.params(2000), L)
+    kr, dr = oracle.detect_and_compute(oracle.params(2000), R)
+    idx, dist = api.hamming_match(dl, dr)
+    ridx, rdist = oracle.hamming_match(dl, dr)
+    assert np.array_equal(idx, ridx) and np.array_equal(dist, rdist)
+    keep, mn = api.hamming_filter(dist); rkeep, rmn = oracle.hamming_filter(rdist)
+    assert mn == rmn and np.array_equal(keep, rkeep)
+    # size-independent properties: self-match is the identity with distance 0; distances are symmetric
+    sidx, sdist = api.hamming_match(dl, dl)
+    assert (sdist == 0).all()
+    uniq = np.unique(dl, axis=0, return_index=True)[1]
+    assert np.array_equal(sidx[uniq], uniq)
+
+
+def test_hamming_batch(api, oracle):
+    import torch
+    rng = np.random.default_rng(3)
+    B, cap = 5, 700
+    nq = np.array([700, 1, 350, 0, 512], np.int32); nt = np.array([650, 700, 2, 10, 0], np.int32)
+    q = rng.integers(0, 256, (B, cap, 32), dtype=np.uint8); t = rng.integers(0, 256, (B, cap, 32), dtype=np.uint8)
+    dq, dt = torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()
+    dnq, dnt = torch.from_numpy(nq).cuda(), torch.from_numpy(nt).cuda()
+    di = torch.full((B, cap), -7, dtype=torch.int32, device="cuda"); dd = torch.full((B, cap), -7, dtype=torch.int32, device="cuda")
+    api.hamming_match_batch(dq.data_ptr(), dnq.data_ptr(), dt.data_ptr(), dnt.data_ptr(), B, cap, di.data_ptr(), dd.data_ptr(),
+                            torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    gi, gd = di.cpu().numpy(), dd.cpu().numpy()
+    for b in range(B):
+        ri, rd = oracle.hamming_match(q[b, :nq[b]], t[b, :nt[b]])
+        assert np.array_equal(gi[b, :nq[b]], ri) and np.array_equal(gd[b, :nq[b]], rd)
+        assert (gi[b, nq[b]:] == -7).all()          # rows past the count are never written
+
+
+def test_triangulate_stereo(api, oracle, synth):
+    K = synth.KITTI00
+    b = K["bf"] / K["fx"]
+    rng = np.random.default_rng(4)
+    n = 3000
+    Z = rng.uniform(3, 80, n); X = rng.uniform(-15, 15, n); Y = rng.uniform(-3, 3, n)
+    xl = (K["fx"] * X / Z + K["cx"]).astype(np.float32); yl = (K["fy"] * Y / Z + K["cy"]).astype(np.float32)
+    xr = (K["fx"] * (X - b) / Z + K["cx"] + rng.normal(0, 0.3, n)).astype(np.float32)
+    yr = (yl + rng.normal(0, 0.3, n)).astype(np.float32)
+    yr[:50] += 30                                    # gross epipolar violations -> rejected by the sigma ratio
+    xr[50:80] = xl[50:80] + 5                        # negative disparity -> z < 0
+    xyz, ok = api.triangulate_stereo(xl, yl, xr, yr, K["fx"], K["fy"], K["cx"], K["cy"], b)
+    rxyz, rok = oracle.triangulate_stereo(xl, yl, xr, yr, K["fx"], K["fy"], K["cx"], K["cy"], b)
+    assert np.array_equal(ok, rok)
+    assert not ok[:80].any() and ok[80:].mean() > 0.95
+    # tolerance: f64 one-sided Jacobi on both sides; agreement far below the measurement noise
+    assert np.allclose(xyz[ok], rxyz[ok], rtol=1e-9, atol=1e-9)
+    assert np.allclose(xyz[ok][:, 2], Z[ok], rtol=0.2)

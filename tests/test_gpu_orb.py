@@ -1,0 +1,209 @@
+"""GPU parity tests of the ORB extractor: HIP path (through the C ABI) vs the CPU oracle, bit-exact.
+
+Every stage is integer work or float work whose integer consequences must agree (BRIEF sample coordinates,
+fastAtan2 angles), so the bar is exact equality of keypoint coordinates/order, angles (f32 bits) and
+descriptor bytes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(240, 320), (376, 1241), (255, 333), (480, 640)]
+
+
+def _kp_equal(a, b):
+    if len(a) != len(b):
+        return False
+    return all(np.array_equal(a[f], b[f]) for f in a.dtype.names)
+
+
+def _explain(a, b):
+    msg = [f"n: {len(a)} vs {len(b)}"]
+    n = min(len(a), len(b))
+    for f in a.dtype.names:
+        bad = np.nonzero(a[f][:n] != b[f][:n])[0]
+        if len(bad):
+            i = bad[0]
+            msg.append(f"{f}: {len(bad)} differ, first at {i}: {a[i]} vs {b[i]}")
+    return "; ".join(msg)
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+def test_pyramid_and_blur_bitexact(api, oracle, synth, h, w):
+    img = synth.random_image(100 + h, h, w)
+    ext = api.ORBextractor(1000)
+    ref = oracle.pyramid(oracle.params(1000), img)
+    for l in range(8):
+        got = ext.debug_pyramid(img, l)
+        assert got.shape == ref[l].shape
+        assert np.array_equal(got, ref[l]), f"level {l}: {np.count_nonzero(got != ref[l])} px differ"
+        gb = ext.debug_pyramid(img, l, blurred=True)
+        rb = oracle.blur7(ref[l], 0)
+        assert np.array_equal(gb, rb), f"blur level {l}: {np.count_nonzero(gb != rb)} px differ"
+
+
+@pytest.mark.parametrize("h,w", SIZES[:3])
+def test_fast_candidates_equal_as_sets(api, oracle, synth, h, w):
+    img = synth.random_image(200 + w, h, w)
+    ext = api.ORBextractor(1000)
+    pyr = oracle.pyramid(oracle.params(1000), img)
+    for l in range(8):
+        xs, ys, sc = ext.debug_candidates(img, l)
+        rx, ry, rs = oracle.grid_fast(pyr[l])
+        got = set(zip(xs.tolist(), ys.tolist(), sc.tolist())); ref = set(zip(rx.tolist(), ry.tolist(), rs.tolist()))
+        assert len(xs) == len(got)
+        assert got == ref, f"level {l}: {len(got - ref)} extra, {len(ref - got)} missing; e.g. {sorted(got ^ ref)[:5]}"
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+@pytest.mark.parametrize("nfeat", [500, 2000])
+def test_detect_and_compute_bitexact(api, oracle, synth, h, w, nfeat):
+    img = synth.random_image(300 + h + nfeat, h, w)
+    ext = api.ORBextractor(nfeat)
+    kps, desc = ext.DetectAndCompute(img)
+    rk, rd = oracle.detect_and_compute(oracle.params(nfeat), img)
+    assert _kp_equal(kps, rk), _explain(kps, rk)
+    assert np.array_equal(desc, rd), f"{np.count_nonzero((desc != rd).any(axis=1))} descriptors differ"
+    assert len(kps) > nfeat // 3
+
+
+def test_kitti_resolution_stereo_pair(api, oracle, synth):
+    L, R = synth.stereo_pair(0, 3)
+    ext = api.ORBextractor(2000)
+    for img in (L, R):
+        kps, desc = ext.DetectAndCompute(img)
+        rk, rd = oracle.detect_and_compute(oracle.params(2000), img)
+        assert _kp_equal(kps, rk), _explain(kps, rk)
+        assert np.array_equal(desc, rd)
+        assert 1990 <= len(kps) <= 2024
+
+
+@pytest.mark.parametrize("nfeat", [100, 300, 2000])
+def test_detect_level0_bitexact(api, oracle, synth, nfeat):
+    img = synth.random_image(400 + nfeat, 376, 1241)
+    ext = api.ORBextractor(nfeat)
+    kps = ext.Detect(img)
+    rk = oracle.detect(oracle.params(nfeat), img)
+    assert _kp_equal(kps, rk), _explain(kps, rk)
+
+
+def test_mask_quirk_reproduced(api, oracle, synth):
+    img = synth.random_image(500, 300, 420)
+    mask = np.full_like(img, 255); mask[:, :150] = 0; mask[200:, :] = 0
+    ext = api.ORBextractor(800)
+    kps, desc = ext.DetectAndCompute(img, mask)
+    rk, rd = oracle.detect_and_compute(oracle.params(800), img, mask)
+    assert _kp_equal(kps, rk), _explain(kps, rk)
+    assert np.array_equal(desc, rd)
+    k0 = ext.Detect(img, mask); r0 = oracle.detect(oracle.params(800), img, mask)
+    assert _kp_equal(k0, r0), _explain(k0, r0)
+    assert len(kps) < len(oracle.detect_and_compute(oracle.params(800), img)[0])
+
+
+def test_other_extractor_configs(api, oracle, synth):
+    img = synth.random_image(600, 200, 260)
+    for nfeat, sf, nl, ini, mn in [(300, 1.2, 3, 20, 7), (150, 1.5, 2, 30, 10), (64, 1.1, 1, 12, 5)]:
+        ext = api.ORBextractor(nfeat, sf, nl, ini, mn)
+        kps, desc = ext.DetectAndCompute(img)
+        rk, rd = oracle.detect_and_compute(oracle.params(nfeat, sf, nl, ini, mn), img)
+        assert _kp_equal(kps, rk), (nfeat, sf, nl, _explain(kps, rk))
+        assert np.array_equal(desc, rd)
+
+
+def test_flat_and_sparse_images(api, oracle):
+    flat = np.full((240, 320), 90, np.uint8)
+    ext = api.ORBextractor(500)
+    kps, desc = ext.DetectAndCompute(flat)
+    assert len(kps) == 0 and desc.shape == (0, 32)
+    one = flat.copy(); one[100:140, 150:200] = 200                        # a single bright rectangle: 4 corners, th-7 fallback cells
+    kps, desc = ext.DetectAndCompute(one)
+    rk, rd = oracle.detect_and_compute(oracle.params(500), one)
+    assert _kp_equal(kps, rk), _explain(kps, rk)
+    assert np.array_equal(desc, rd) and len(kps) >= 4
+    assert len(ext.Detect(flat)) == 0
+
+
+def test_unsupported_and_empty_inputs(api, pkg):
+    ext = api.ORBextractor(500)
+    tiny = np.zeros((100, 120), np.uint8)                                 # 8 levels: level 7 is 28x33 -> no 30-px cell fits
+    with pytest.raises(api.MyslamError) as e:
+        ext.DetectAndCompute(tiny)
+    assert e.value.code == api.ERR_UNSUPPORTED
+    n = C.c_int(123)
+    kp = np.zeros(8, api.KP_DTYPE); d = np.zeros((8, 32), np.uint8)
+    rc = api.lib().myslam_orb_detect_and_compute(ext._h, None, 0, 0, 0, None, 0, kp.ctypes.data_as(C.c_void_p),
+                                                 d.ctypes.data_as(C.c_void_p), 8, C.byref(n))
+    assert rc == 0 and n.value == 0                                       # reference: silent return on empty image (:924)
+    img = pkg.synth.random_image(1, 240, 320)
+    with pytest.raises(api.MyslamError) as e:                            # caller's buffer too small -> CAPACITY, never truncation
+        ext.DetectAndCompute(img, cap=10)
+    assert e.value.code == api.ERR_CAPACITY
+
+
+def test_row_pitch_is_honoured(api, oracle, synth):
+    base = synth.random_image(700, 260, 400)
+    view = base[:, 7:7 + 333]                                             # non-contiguous view -> api copies; build an explicit padded buffer too
+    ext = api.ORBextractor(400)
+    kps, desc = ext.DetectAndCompute(view)
+    rk, rd = oracle.detect_and_compute(oracle.params(400), np.ascontiguousarray(view))
+    assert _kp_equal(kps, rk) and np.array_equal(desc, rd)
+    padded = np.zeros((260, 352), np.uint8); padded[:, :333] = view      # step 352 != cols 333
+    n = C.c_int()
+    cap = ext.max_keypoints()
+    kp = np.zeros(cap, api.KP_DTYPE); d = np.zeros((cap, 32), np.uint8)
+    rc = api.lib().myslam_orb_detect_and_compute(ext._h, padded.ctypes.data_as(C.c_void_p), 260, 333, 352, None, 0,
+                                                 kp.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), cap, C.byref(n))
+    assert rc == 0 and _kp_equal(kp[:n.value], rk) and np.array_equal(d[:n.value], rd)
+
+
+def test_screen_and_calc_descriptors_bitexact(api, oracle, synth):
+    """The loop-closing path: LoopClosing::ProcessNewKF (loopclosing.cpp:94-112)."""
+    img = synth.random_image(800, 376, 1241)
+    p = oracle.params(300)
+    feats = oracle.detect(p, img)                                         # frontend features (level-0 FAST)
+    pyr_kps = np.repeat(feats, 8)                                         # expand to 8 pyramid keypoints each (:94-105)
+    pyr_kps["octave"] = np.tile(np.arange(8), len(feats)); pyr_kps["response"] = -1
+    pyr_kps["class_id"] = np.repeat(np.arange(len(feats)), 8)
+    ext = api.ORBextractor(300)
+    out, kin_after = ext.ScreenAndComputeKPsParams(img, pyr_kps)
+    rout = oracle.screen(p, img, pyr_kps)
+    assert _kp_equal(out, rout), _explain(out, rout)
+    assert len(out) >= len(feats)                                         # level 0 always survives away from the border
+    d = ext.CalcDescriptors(img, out)
+    rd = oracle.calc_descriptors(p, img, rout)
+    assert np.array_equal(d, rd), f"{np.count_nonzero((d != rd).any(axis=1))} of {len(d)} descriptors differ"
+
+
+def test_batch_equals_single_and_oracle(api, oracle, synth):
+    import torch
+    B = 6
+    imgs = np.stack([synth.random_image(900 + i, 300, 420) for i in range(B)])
+    ext = api.ORBextractor(700)
+    cap = ext.max_keypoints()
+    d_imgs = torch.from_numpy(imgs).cuda()
+    d_kps = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
+    d_desc = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros(B, dtype=torch.int32, device="cuda"); d_st = torch.ones(B, dtype=torch.int32, device="cuda")
+    ext.set_stream(torch.cuda.current_stream().cuda_stream)
+    for rep in range(2):                                                  # twice: buffers are reused, counters must be reset
+        ext.detect_and_compute_batch(d_imgs.data_ptr(), B, 300, 420, 420, 300 * 420, d_kps.data_ptr(), d_desc.data_ptr(),
+                                     d_cnt.data_ptr(), d_st.data_ptr(), cap)
+        torch.cuda.synchronize()
+        cnt = d_cnt.cpu().numpy(); assert (d_st.cpu().numpy() == 0).all()
+        kps = d_kps.cpu().numpy().view(api.KP_DTYPE).reshape(B, cap)
+        desc = d_desc.cpu().numpy().reshape(B, cap, 32)
+        for b in range(B):
+            rk, rd = oracle.detect_and_compute(oracle.params(700), imgs[b])
+            assert _kp_equal(kps[b, :cnt[b]], rk), (rep, b, _explain(kps[b, :cnt[b]], rk))
+            assert np.array_equal(desc[b, :cnt[b]], rd)
+
+
+def test_golden_fixture(api):
+    """Committed oracle outputs (tests/golden/orb_small.npz): the HIP path must reproduce them byte for byte."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "orb_small.npz"))
+    ext = api.ORBextractor(int(g["nfeatures"]))
+    kps, desc = ext.DetectAndCompute(g["image"])
+    assert kps.tobytes() == g["kps"].tobytes() and np.array_equal(desc, g["desc"])
