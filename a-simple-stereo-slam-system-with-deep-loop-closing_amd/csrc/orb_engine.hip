@@ -8,6 +8,7 @@
 //   sort buffers   : per level 2 x u64 (path code<<32 | payload)
 //   selected keys  : per level <= N+3 payloads in oct-tree list order (+ count)
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -278,7 +279,14 @@ int myslam_orb::run_batch(const uint8_t* d_imgs, int batch, int r, int c, int st
     MYSLAM_HIP_CHECK(hipMemsetAsync(d_candCount, 0, sizeof(int32_t) * (size_t)batch * MAXL, stream));
     MYSLAM_HIP_CHECK(hipMemsetAsync(d_selCount, 0, sizeof(int32_t) * (size_t)batch * MAXL, stream));
     MYSLAM_HIP_CHECK(hipMemsetAsync(stat, 0, sizeof(int32_t) * (size_t)batch, stream));
+    const char* dbg_stop = getenv("MYSLAM_DEBUG_STOP");      // stage-isolation aid for the parity tests
+    const int stop = dbg_stop ? atoi(dbg_stop) : 0;
+    if (stop == 1) {
+        launch_ingest(d_imgs, full.rows, full.cols, step, stride, d_pyr + full.lv[0].imgOff, full.lv[0].pitch, full.pyrBytes, batch, stream);
+        return MYSLAM_OK;
+    }
     if ((rc = build_pyramids(d_imgs, batch, step, stride, d_masks, P.nlevels))) return rc;
+    if (stop == 2) return MYSLAM_OK;
     {
         ScopedProf sp(P_FAST, stream);
         launch_fast(P, d_pyr, full.pyrBytes, d_masks ? d_mask : nullptr, d_cand, d_candCount, batch, stream);
@@ -287,7 +295,9 @@ int myslam_orb::run_batch(const uint8_t* d_imgs, int batch, int r, int c, int st
         ScopedProf sp(P_OCTREE, stream);
         launch_octree(P, d_cand, d_candCount, d_sort, d_sel, d_selCount, stat, batch, stream);
     }
+    if (stop == 3) return MYSLAM_OK;
     if (!detectOnly && (rc = blur_levels(batch, P.nlevels))) return rc;
+    if (stop == 4) return MYSLAM_OK;
     {
         ScopedProf sp(P_DESC, stream);
         launch_describe(P, d_pyr, d_blur, full.pyrBytes, d_sel, d_selCount, d_kps, d_desc, d_counts, stat, cap,
@@ -528,6 +538,40 @@ int myslam_orb_debug_candidates(myslam_orb* h, const uint8_t* img, int rows, int
         (void)hipFree(d_tmp);
     }
     return MYSLAM_OK;
+}
+
+// raw readback of the engine's batch buffers after a *_batch call (stage-level parity tests)
+//   what: 0 pyramid plane (w*h bytes, tight), 1 blurred plane, 2 candidate count, 3 candidate payloads (u32),
+//         4 selected count, 5 selected payloads (u32, oct-tree list order)
+int myslam_orb_debug_readback(myslam_orb* h, int what, int b, int level, void* out, size_t cap_bytes, int detect_plan) {
+    if (!h || !out || h->rows == 0 || b < 0 || b >= h->batchCap || level < 0 || level >= h->nlevels) return MYSLAM_ERR_INVALID;
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    const OrbPlan& P = detect_plan ? h->det : h->full;
+    const LevelGeom& g = P.lv[level];
+    switch (what) {
+        case 0: case 1: {
+            if (cap_bytes < (size_t)g.w * g.h) return MYSLAM_ERR_CAPACITY;
+            const uint8_t* base = (what ? h->d_blur : h->d_pyr) + (size_t)b * h->full.pyrBytes + g.imgOff;
+            MYSLAM_HIP_CHECK(hipMemcpy2D(out, g.w, base, g.pitch, g.w, g.h, hipMemcpyDeviceToHost));
+            return MYSLAM_OK;
+        }
+        case 2: case 4: {
+            if (cap_bytes < 4) return MYSLAM_ERR_CAPACITY;
+            MYSLAM_HIP_CHECK(hipMemcpy(out, (what == 2 ? h->d_candCount : h->d_selCount) + b * MAXL + level, 4, hipMemcpyDeviceToHost));
+            return MYSLAM_OK;
+        }
+        case 3: {
+            if (cap_bytes < (size_t)g.keyCap * 4) return MYSLAM_ERR_CAPACITY;
+            MYSLAM_HIP_CHECK(hipMemcpy(out, h->d_cand + (size_t)b * P.totalKeyCap + g.keyOff, (size_t)g.keyCap * 4, hipMemcpyDeviceToHost));
+            return MYSLAM_OK;
+        }
+        case 5: {
+            if (cap_bytes < (size_t)g.nodeCap * 4) return MYSLAM_ERR_CAPACITY;
+            MYSLAM_HIP_CHECK(hipMemcpy(out, h->d_sel + (size_t)b * P.totalOut + g.outBase, (size_t)g.nodeCap * 4, hipMemcpyDeviceToHost));
+            return MYSLAM_OK;
+        }
+    }
+    return MYSLAM_ERR_INVALID;
 }
 
 }  // extern "C"

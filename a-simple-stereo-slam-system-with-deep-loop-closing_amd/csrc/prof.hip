@@ -79,6 +79,12 @@ int myslam_prof_reset(void) {
 
 int myslam_prof_count(void) { return P_COUNT; }
 
+// debug: copy n bytes from a device pointer with this library's HIP runtime (diagnoses runtime/VA mismatches)
+int myslam_debug_peek(const void* d_ptr, void* out, size_t n) {
+    MYSLAM_HIP_CHECK(hipMemcpy(out, d_ptr, n, hipMemcpyDeviceToHost));
+    return MYSLAM_OK;
+}
+
 int myslam_prof_get(int i, const char** name, double* total_ms, long* launches) {
     if (i < 0 || i >= P_COUNT) return MYSLAM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(g_mu);

@@ -71,7 +71,7 @@ def stereo_pair(stream_id=0, t=0, h=IMG_H, w=IMG_W, scene=None, bf=KITTI00["bf"]
     x0c = np.clip(x0, 0, w - 1); x1c = np.clip(x0 + 1, 0, w - 1)
     rows = np.arange(h)[:, None]
     right = base[rows, x0c] * (1 - fx) + base[rows, x1c] * fx + rng.uniform(-3.0, 3.0, size=base.shape)
-    to_u8 = lambda a: np.clip(np.rint(a), 0, 255).astype(np.uint8)
+    to_u8 = lambda a: np.ascontiguousarray(np.clip(np.rint(a), 0, 255).astype(np.uint8))
     return to_u8(left), to_u8(right)
 
 
@@ -100,7 +100,7 @@ def random_image(seed, h, w, kind="texture"):
     np.add.at(diff, (y1, x0), -val); np.add.at(diff, (y1, x1), val)
     img += np.cumsum(np.cumsum(diff, axis=0), axis=1)[:h, :w]
     img += rng.uniform(-3, 3, size=(h, w))
-    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(np.clip(np.rint(img), 0, 255).astype(np.uint8))      # C order: row pitch = width
 
 
 # ----------------------------------------------------------------------------------------------

@@ -48,6 +48,8 @@ int myslam_prof_enable(int on);
 int myslam_prof_reset(void);
 int myslam_prof_count(void);
 int myslam_prof_get(int i, const char** name, double* total_ms, long* launches);
+/* debug: device->host copy of n bytes through this library's HIP runtime */
+int myslam_debug_peek(const void* d_ptr, void* out, size_t n);
 
 /* ------------------------------------------------------------------------------------------
  * ORB extractor — replaces class ORBextractor (include/myslam/ORBextractor.h:52-110)
@@ -102,6 +104,10 @@ int myslam_orb_debug_pyramid(myslam_orb* h, const uint8_t* img, int rows, int co
 int myslam_orb_debug_candidates(myslam_orb* h, const uint8_t* img, int rows, int cols, int step,
                                 const uint8_t* mask, int mask_step, int level,
                                 int32_t* xs, int32_t* ys, int32_t* scores, int cap, int* n);
+
+/* raw readback of the engine's HBM buffers after a *_batch call: what = 0 pyramid plane (w*h, tight), 1 blurred
+ * plane, 2 candidate count (i32), 3 candidate payloads (u32 py<<20|px<<8|score), 4 selected count, 5 selected payloads */
+int myslam_orb_debug_readback(myslam_orb* h, int what, int b, int level, void* out, size_t cap_bytes, int detect_plan);
 
 /* ------------------------------------------------------------------------------------------
  * Hamming brute force — replaces cv::BFMatcher(NORM_HAMMING)::match as used at

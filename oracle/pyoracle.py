@@ -267,6 +267,11 @@ class Oracle:
         assert rc == 0, rc
         return out
 
+    def lcd_score(self, a, b):
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+        self.lib.orc_lcd_score.argtypes = [C.c_void_p, C.c_void_p]
+        return float(self.lib.orc_lcd_score(_p(a), _p(b)))
+
     def lcddb_query(self, db, ids, q, cur_id, thr_low=0.92):
         db = np.ascontiguousarray(db, np.float32); ids = np.ascontiguousarray(ids, np.uint64)
         q = np.ascontiguousarray(q, np.float32)

@@ -45,6 +45,9 @@ def oracle():
 @pytest.fixture(scope="session")
 def api(pkg):
     """The HIP product path.  GPU tests must never silently pass without it."""
+    # torch ships its own HIP runtime: import it BEFORE libmyslam_hip.so so that one runtime serves the process
+    # (the tests use torch only to hold device buffers for the *_batch entry points)
+    import torch  # noqa: F401
     if not os.path.exists(pkg.api.LIB_PATH):
         pkg.build_library()
     a = pkg.api

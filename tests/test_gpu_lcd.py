@@ -60,7 +60,8 @@ def test_describe_batch(api, oracle, synth):
     w = synth.calc_weights(); lcd = api.DeepLCD(w)
     B = 5
     imgs = np.stack([synth.stereo_pair(0, t)[0] for t in range(B)])
-    d_imgs = torch.from_numpy(imgs).cuda(); d_out = torch.zeros(B, 1064, device="cuda")
+    d_imgs = torch.from_numpy(np.ascontiguousarray(imgs)).cuda()
+    assert d_imgs.is_contiguous(); d_out = torch.zeros(B, 1064, device="cuda")
     lcd.describe_batch(d_imgs.data_ptr(), B, 376, 1241, 1241, 376 * 1241, d_out.data_ptr(), blur_in_place=False)
     torch.cuda.synchronize()
     out = d_out.cpu().numpy()
@@ -76,7 +77,8 @@ def test_describe_batch(api, oracle, synth):
 
 def test_score(api, oracle, synth):
     db = synth.lcd_database(4)
-    assert api.DeepLCD.score(db[0], db[1]) == pytest.approx(oracle.lib.orc_lcd_score(db[0].ctypes.data, db[1].ctypes.data), abs=1e-6)
+    assert api.DeepLCD.score(db[0], db[1]) == pytest.approx(oracle.lcd_score(db[0], db[1]), abs=1e-6)
+    assert api.DeepLCD.score(db[2], db[2]) == pytest.approx(1.0, abs=1e-5)
 
 
 @pytest.mark.parametrize("n", [60, 1000, 10000])

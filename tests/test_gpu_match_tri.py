@@ -74,4 +74,4 @@ def test_triangulate_stereo(api, oracle, synth):
     assert not ok[:80].any() and ok[80:].mean() > 0.95
     # tolerance: f64 one-sided Jacobi on both sides; agreement far below the measurement noise
     assert np.allclose(xyz[ok], rxyz[ok], rtol=1e-9, atol=1e-9)
-    assert np.allclose(xyz[ok][:, 2], Z[ok], rtol=0.2)
+    assert np.median(np.abs(xyz[ok][:, 2] - Z[ok]) / Z[ok]) < 0.05       # 0.3 px noise on 5..130 px disparities

@@ -182,7 +182,8 @@ def test_batch_equals_single_and_oracle(api, oracle, synth):
     imgs = np.stack([synth.random_image(900 + i, 300, 420) for i in range(B)])
     ext = api.ORBextractor(700)
     cap = ext.max_keypoints()
-    d_imgs = torch.from_numpy(imgs).cuda()
+    d_imgs = torch.from_numpy(np.ascontiguousarray(imgs)).cuda()
+    assert d_imgs.is_contiguous()
     d_kps = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
     d_desc = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
     d_cnt = torch.zeros(B, dtype=torch.int32, device="cuda"); d_st = torch.ones(B, dtype=torch.int32, device="cuda")
