@@ -163,9 +163,10 @@ int myslam_orb::make_plan(int r, int c) {
         g.nIni = (int)roundf((float)(g.maxBX - MIN_BORDER) / (g.maxBY - MIN_BORDER));   // :590
         if (g.nIni < 1 || g.nIni > 64) return MYSLAM_ERR_UNSUPPORTED;
         g.hX = (float)(g.maxBX - MIN_BORDER) / g.nIni;                                  // :592
-        g.rootPasses = (ceil_log2(g.nIni) + 1) / 2;
         const int rootW = (int)ceilf(g.hX) + 2, H = g.maxBY - MIN_BORDER;
         g.ndepth = std::min(MAX_DEPTH, ceil_log2(std::max(rootW, H)) + 2);
+        g.sortDepth = 0;
+        while (g.sortDepth + 1 <= g.ndepth && (g.nIni << (2 * (g.sortDepth + 1))) <= 4096) g.sortDepth++;
         g.keyCap = (int)std::min<size_t>(65535, std::max<size_t>(256, (size_t)g.w * g.h / 12));
         g.nodeCap = (std::max(g.N + 4, 4 * g.nIni + 4) + 3) & ~3;
         g.outBase = outBase; outBase += g.nodeCap;

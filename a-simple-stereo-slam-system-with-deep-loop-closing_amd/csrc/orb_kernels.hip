@@ -237,19 +237,25 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlan P, const uint8_t* __
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: oct-tree keypoint distribution, one 256-thread block per (level, image).
+// K4: oct-tree keypoint distribution, one 256-thread block per (level, image), all levels in one launch.
 //
 // The reference walks a std::list of nodes, splitting nodes into 4 children and re-bucketing their
-// key vectors (ORBextractor.cpp:586-810).  Here every key gets its full quad-tree PATH CODE up front
-// (root index + 2 bits per depth, derived with the reference's ceil-halving bounds), the keys are
-// radix-sorted by code once, and a node is just (depth, [lo,hi) range of the sorted array); children
-// are found by binary search on the next 2-bit digit.  The list order the reference produces
-// (push_front of n1..n4, erase of the parent, size-sorted expansion near the budget) is reproduced
-// with prefix sums.  Tie-break of the size sort (:731 sorts pair<int,Node*>, i.e. by heap address) is
-// creation order — the same deterministic choice the oracle makes.  Best key per node = max response,
-// first in the reference's candidate order (cell-major, then row-major) on ties (:795-804).
+// key vectors (ORBextractor.cpp:586-810).  Here every key gets its quad-tree PATH CODE up front (root
+// index + 2 bits per depth, derived with the reference's ceil-halving bounds).  Keys are bucketed by the
+// first D levels of the code with ONE counting sort whose histogram lives in LDS (D chosen so that
+// nIni*4^D <= 4096 buckets); the exclusive bucket offsets then give the key range of ANY node of depth
+// <= D, and of its 4 children, by table lookup — the node-list simulation touches no global memory.
+// A node deeper than D (only reached when many keys crowd into one ~10-px cell) is split on demand by
+// partitioning its own key range in place on the next code digit.  Order inside a node is irrelevant:
+// child counts do not depend on it and the best key per node is chosen by (max response, first in the
+// reference's cell-major / row-major candidate order) explicitly (:795-804).
+// The list order the reference produces (push_front of n1..n4, erase of the parent, size-sorted
+// expansion near the budget, stop as soon as >= N nodes) is rebuilt with block-wide prefix sums.
+// Tie-break of the size sort (:731 sorts pair<int,Node*>, i.e. by heap address) = creation order, the
+// same deterministic choice the oracle makes.
 // ------------------------------------------------------------------------------------------------
 constexpr int OT = 256;
+constexpr int OT_MAXB = 4096;        // buckets of the counting sort
 
 __device__ __forceinline__ uint64_t wave_incl_scan64(uint64_t v) {
     const int lane = threadIdx.x & 63;
@@ -292,59 +298,91 @@ __device__ __forceinline__ uint32_t oct_code(int px, int py, const LevelGeom& g)
     return code;
 }
 
-__device__ __forceinline__ int lower_bound_code(const uint64_t* __restrict__ s, int lo, int hi, uint32_t target) {
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if ((uint32_t)(s[mid] >> 32) < target) lo = mid + 1; else hi = mid;
+// in-place 4-way partition of S[lo,hi) on the 2-bit digit at bit position sh (deep nodes only; one thread)
+__device__ __noinline__ void partition4(uint64_t* __restrict__ S, int lo, int hi, int sh, int& b1, int& b2, int& b3) {
+    int c0 = 0, c1 = 0, c2 = 0;
+    for (int i = lo; i < hi; i++) {
+        const int d = (int)((S[i] >> sh) & 3);
+        c0 += (d == 0); c1 += (d == 1); c2 += (d == 2);
     }
-    return lo;
-}
-
-// boundaries of the 4 children of node (depth d, [lo,hi)) in the sorted array
-__device__ __forceinline__ void child_bounds(const uint64_t* __restrict__ s, int lo, int hi, int d,
-                                             int& b1, int& b2, int& b3) {
-    const int shift = ROOT_SHIFT - 2 * (d + 1);
-    const uint32_t base = (uint32_t)(s[lo] >> 32) & ~((4u << shift) - 1u);
-    b2 = lower_bound_code(s, lo, hi, base | (2u << shift));
-    b1 = lower_bound_code(s, lo, b2, base | (1u << shift));
-    b3 = lower_bound_code(s, b2, hi, base | (3u << shift));
+    b1 = lo + c0; b2 = b1 + c1; b3 = b2 + c2;
+    int p0 = lo, p1 = b1, p2 = b2, p3 = b3;                  // next free slot of every bucket
+    auto take = [&](int d) -> int { int r; if (d == 0) r = p0++; else if (d == 1) r = p1++; else if (d == 2) r = p2++; else r = p3++; return r; };
+    const int ends[4] = {b1, b2, b3, hi};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {                            // bucket 3 is in place once 0..2 are
+        int i = (k == 0) ? p0 : (k == 1) ? p1 : p2;
+        while (i < ends[k]) {
+            uint64_t v = S[i];
+            int d = (int)((v >> sh) & 3);
+            while (d != k) {                                 // cycle the element into its bucket
+                const int j = take(d);
+                const uint64_t w = S[j];
+                S[j] = v; v = w;
+                d = (int)((v >> sh) & 3);
+                // skip slots of bucket d that already hold a d-element is unnecessary: take() hands out fresh slots
+            }
+            S[i] = v;
+            i++;
+            if (k == 0) p0 = i; else if (k == 1) p1 = i; else p2 = i;
+        }
+    }
 }
 
 struct OctLds {
     uint32_t *rng0, *rng1;      // node range lo | hi<<16 (double buffered)
+    uint16_t *pfx0, *pfx1;      // node bucket prefix (valid while depth <= D)
     uint8_t *dep0, *dep1;       // node depth
     uint16_t *nb1, *nb2, *nb3;  // child boundaries (per list position / per sorted candidate)
     uint32_t *ckey0, *ckey1;    // candidate sort key: size<<16 | creation index
     uint16_t *cpos0, *cpos1;    // candidate -> list position
+    uint16_t* ord;              // rank -> candidate
+    uint16_t *kinc, *binc;      // inclusive sums of children / big children over sorted candidates
+    uint8_t* kk;                // #non-empty children (0 = not expandable)
+    uint8_t* mark;
+    uint16_t* offs;             // exclusive bucket offsets [NB+1]
     __device__ __forceinline__ uint32_t* rng(int i) const { return i ? rng1 : rng0; }
+    __device__ __forceinline__ uint16_t* pfx(int i) const { return i ? pfx1 : pfx0; }
     __device__ __forceinline__ uint8_t* dep(int i) const { return i ? dep1 : dep0; }
     __device__ __forceinline__ uint32_t* ckey(int i) const { return i ? ckey1 : ckey0; }
     __device__ __forceinline__ uint16_t* cpos(int i) const { return i ? cpos1 : cpos0; }
-    uint16_t* ord;         // rank -> candidate
-    uint16_t *kinc, *binc; // inclusive sums of children / big children over sorted candidates
-    uint8_t* kk;           // #non-empty children (0 = not expandable)
-    uint8_t* mark;
 };
+
+// boundaries of the 4 children of node (depth d, prefix pfx, [lo,hi))
+__device__ __forceinline__ void child_bounds(const OctLds& L, uint64_t* __restrict__ S, int D, int lo, int hi, int d, int pfx,
+                                             int& b1, int& b2, int& b3) {
+    if (d < D) {
+        const int sb = 2 * (D - d - 1);
+        const int base = pfx << 2;
+        b1 = L.offs[(base + 1) << sb]; b2 = L.offs[(base + 2) << sb]; b3 = L.offs[(base + 3) << sb];
+    } else {
+        partition4(S, lo, hi, 32 + ROOT_SHIFT - 2 * (d + 1), b1, b2, b3);
+    }
+}
 
 __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __restrict__ cand,
                                                const int32_t* __restrict__ candCount, uint64_t* __restrict__ sortbuf,
                                                uint32_t* __restrict__ selOut, int32_t* __restrict__ selCount,
-                                               int32_t* __restrict__ status, int levelBase) {
+                                               int32_t* __restrict__ status, int NCmax) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int t = threadIdx.x;
-    const int level = levelBase + blockIdx.x, b = blockIdx.y;
+    const int level = blockIdx.x, b = blockIdx.y;
     const LevelGeom& g = P.lv[level];
-    const int NC = g.nodeCap;
+    const int NC = NCmax;
 
     // carve LDS
     uint64_t* s_w = reinterpret_cast<uint64_t*>(smem);          // 4 x u64 scan scratch
-    int* s_i = reinterpret_cast<int*>(smem + 32);               // 8 ints: [0]=m [1]=nc [2]=jstar [3]=Kc [4]=nbig
+    int* s_i = reinterpret_cast<int*>(smem + 32);               // [0]=m [1]=nc [2]=jstar
     uint8_t* pcur = smem + 64;
+    uint32_t* s_cursor = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * OT_MAXB;
     OctLds L;
     L.rng0 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
     L.rng1 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
     L.ckey0 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
     L.ckey1 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
+    L.offs = reinterpret_cast<uint16_t*>(pcur); pcur += 2 * (OT_MAXB + 2);
+    L.pfx0 = reinterpret_cast<uint16_t*>(pcur); pcur += 2 * NC;
+    L.pfx1 = reinterpret_cast<uint16_t*>(pcur); pcur += 2 * NC;
     L.nb1 = reinterpret_cast<uint16_t*>(pcur); pcur += 2 * NC;
     L.nb2 = reinterpret_cast<uint16_t*>(pcur); pcur += 2 * NC;
     L.nb3 = reinterpret_cast<uint16_t*>(pcur); pcur += 2 * NC;
@@ -369,56 +407,53 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
 
     const uint32_t* keys = cand + (size_t)b * P.totalKeyCap + g.keyOff;
     uint64_t* bufA = sortbuf + ((size_t)b * P.totalKeyCap + g.keyOff) * 2;
-    uint64_t* bufB = bufA + g.keyCap;
+    uint64_t* S = bufA + g.keyCap;
+    const int D = g.sortDepth;                                   // bucket = code >> (ROOT_SHIFT - 2D)
+    const int NB = g.nIni << (2 * D);
+    const int bsh = ROOT_SHIFT - 2 * D;
 
-    // ---- A: path codes ----
+    // ---- A: path codes + bucket histogram (LDS atomics) ----
+    for (int i = t; i < NB; i += OT) s_cursor[i] = 0;
+    __syncthreads();
     for (int i = t; i < n; i += OT) {
         const uint32_t pay = keys[i];
         const int px = (pay >> 8) & 0xfff, py = pay >> 20;
-        bufA[i] = ((uint64_t)oct_code(px, py, g) << 32) | pay;
+        const uint32_t code = oct_code(px, py, g);
+        bufA[i] = ((uint64_t)code << 32) | pay;
+        atomicAdd(&s_cursor[code >> bsh], 1u);
     }
     __syncthreads();
-
-    // ---- B: LSD radix sort by code, 2 bits per pass (keys are distinct, so the result is unique) ----
+    // ---- B: exclusive offsets, then scatter (order inside a bucket is irrelevant) ----
     {
-        uint64_t* src = bufA; uint64_t* dst = bufB;
-        const int c = (n + OT - 1) / OT;
-        const int beg = min(n, t * c), end = min(n, beg + c);
-        const int npass = g.ndepth + g.rootPasses;
-        for (int pass = 0; pass < npass; pass++) {
-            const int shift = 32 + ROOT_SHIFT - 2 * g.ndepth + 2 * pass;
-            uint64_t packed = 0;
-            for (int i = beg; i < end; i++) packed += 1ull << (16 * (int)((src[i] >> shift) & 3));
-            uint64_t total;
-            const uint64_t excl = block_excl_scan64(packed, s_w, total);
-            const uint64_t t0 = total & 0xffff, t1 = (total >> 16) & 0xffff, t2 = (total >> 32) & 0xffff;
-            uint64_t offs = excl + ((t0 << 16) | ((t0 + t1) << 32) | ((t0 + t1 + t2) << 48));
-            for (int i = beg; i < end; i++) {
-                const uint64_t v = src[i];
-                const int d = (int)((v >> shift) & 3);
-                dst[(offs >> (16 * d)) & 0xffff] = v;
-                offs += 1ull << (16 * d);
-            }
-            __syncthreads();
-            uint64_t* tmp = src; src = dst; dst = tmp;
+        const int c = (NB + OT - 1) / OT;
+        const int beg = min(NB, t * c), end = min(NB, beg + c);
+        uint64_t sum = 0;
+        for (int i = beg; i < end; i++) sum += s_cursor[i];
+        uint64_t total;
+        uint64_t run = block_excl_scan64(sum, s_w, total);
+        for (int i = beg; i < end; i++) {
+            const uint32_t h = s_cursor[i];
+            L.offs[i] = (uint16_t)run;
+            s_cursor[i] = (uint32_t)run;
+            run += h;
         }
-        bufA = src;                               // sorted
+        if (t == 0) L.offs[NB] = (uint16_t)n;
     }
-    const uint64_t* S = bufA;
+    __syncthreads();
+    for (int i = t; i < n; i += OT) {
+        const uint64_t v = bufA[i];
+        const uint32_t pos = atomicAdd(&s_cursor[(uint32_t)(v >> 32) >> bsh], 1u);
+        S[pos] = v;
+    }
+    __syncthreads();
 
     // ---- C: node list simulation ----
     // roots (:599-632): non-empty roots in index order
-    if (t < g.nIni) {
-        const int lo = lower_bound_code(S, 0, n, (uint32_t)t << ROOT_SHIFT);
-        const int hi = (t + 1 < g.nIni) ? lower_bound_code(S, lo, n, (uint32_t)(t + 1) << ROOT_SHIFT) : n;
-        L.nb1[t] = (uint16_t)lo; L.nb2[t] = (uint16_t)hi;
-    }
-    __syncthreads();
     if (t == 0) {
         int m = 0;
         for (int r = 0; r < g.nIni; r++) {
-            const int lo = L.nb1[r], hi = L.nb2[r];
-            if (hi > lo) { L.rng(0)[m] = (uint32_t)lo | ((uint32_t)hi << 16); L.dep(0)[m] = 0; m++; }
+            const int lo = L.offs[r << (2 * D)], hi = L.offs[(r + 1) << (2 * D)];
+            if (hi > lo) { L.rng0[m] = (uint32_t)lo | ((uint32_t)hi << 16); L.dep0[m] = 0; L.pfx0[m] = (uint16_t)r; m++; }
         }
         s_i[0] = m; s_i[1] = 0;
     }
@@ -441,7 +476,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
                 int k = 0;
                 if (hi - lo > 1 && d < g.ndepth) {
                     int b1, b2, b3;
-                    child_bounds(S, lo, hi, d, b1, b2, b3);
+                    child_bounds(L, S, D, lo, hi, d, L.pfx(cur)[p], b1, b2, b3);
                     L.nb1[p] = (uint16_t)b1; L.nb2[p] = (uint16_t)b2; L.nb3[p] = (uint16_t)b3;
                     const int c0 = b1 - lo, c1 = b2 - b1, c2 = b3 - b2, c3 = hi - b3;
                     k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
@@ -459,6 +494,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
             for (int p = beg; p < end; p++) {
                 const uint32_t r = L.rng(cur)[p];
                 const int lo = r & 0xffff, hi = r >> 16, d = L.dep(cur)[p];
+                const int pf = L.pfx(cur)[p];
                 const int k = L.kk[p];
                 if (k) {
                     const int bnd[5] = {lo, L.nb1[p], L.nb2[p], L.nb3[p], hi};
@@ -472,6 +508,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
                         if (bnd[q + 1] > bnd[q]) {
                             L.rng(nxt)[pos] = (uint32_t)bnd[q] | ((uint32_t)bnd[q + 1] << 16);
                             L.dep(nxt)[pos] = (uint8_t)(d + 1);
+                            L.pfx(nxt)[pos] = (uint16_t)((pf << 2) | q);
                             pos++;
                         }
                     }
@@ -490,6 +527,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
                     const int rn = (int)((run >> 21) & 0x1fffff);
                     L.rng(nxt)[Ktot + rn] = r;
                     L.dep(nxt)[Ktot + rn] = (uint8_t)d;
+                    L.pfx(nxt)[Ktot + rn] = (uint16_t)pf;
                     run += 1ull << 21;
                 }
             }
@@ -523,27 +561,19 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
                 const int lo = r & 0xffff, hi = r >> 16, d = L.dep(cur)[p];
                 int k = 1, big = 1, b1 = hi, b2 = hi, b3 = hi;           // depth-exhausted node: one "child" = itself
                 if (d < g.ndepth) {
-                    child_bounds(S, lo, hi, d, b1, b2, b3);
+                    child_bounds(L, S, D, lo, hi, d, L.pfx(cur)[p], b1, b2, b3);
                     const int c0 = b1 - lo, c1 = b2 - b1, c2 = b3 - b2, c3 = hi - b3;
                     k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
                     big = (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1);
                 }
                 L.nb1[j] = (uint16_t)b1; L.nb2[j] = (uint16_t)b2; L.nb3[j] = (uint16_t)b3;
-                L.kk[j] = (uint8_t)k;
+                L.kk[j] = (uint8_t)(k | (big << 4));
                 packed += (uint64_t)k | ((uint64_t)big << 32);
             }
             uint64_t total;
             uint64_t run = block_excl_scan64(packed, s_w, total);
             for (int j = beg; j < end; j++) {
-                // recompute big from the stored bounds
-                const int p = L.cpos(ccur)[L.ord[j]];
-                const uint32_t r = L.rng(cur)[p];
-                const int lo = r & 0xffff, hi = r >> 16;
-                const int b1 = L.nb1[j], b2 = L.nb2[j], b3 = L.nb3[j];
-                const int k = L.kk[j];
-                int big;
-                if (L.dep(cur)[p] < g.ndepth) big = (b1 - lo > 1) + (b2 - b1 > 1) + (b3 - b2 > 1) + (hi - b3 > 1);
-                else big = 1;
+                const int k = L.kk[j] & 15, big = L.kk[j] >> 4;
                 run += (uint64_t)k | ((uint64_t)big << 32);
                 const int kincl = (int)(run & 0xffffffffu);
                 L.kinc[j] = (uint16_t)kincl;
@@ -561,7 +591,8 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
                 const int p = L.cpos(ccur)[L.ord[j]];
                 const uint32_t r = L.rng(cur)[p];
                 const int lo = r & 0xffff, hi = r >> 16, d = L.dep(cur)[p];
-                const int k = L.kk[j];
+                const int pf = L.pfx(cur)[p];
+                const int big = L.kk[j] >> 4;
                 const int bnd[5] = {lo, L.nb1[j], L.nb2[j], L.nb3[j], hi};
                 int pos = Kc - L.kinc[j];
                 int childPos[4];
@@ -572,12 +603,10 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
                         if (bnd[q + 1] > bnd[q]) {
                             L.rng(nxt)[pos] = (uint32_t)bnd[q] | ((uint32_t)bnd[q + 1] << 16);
                             L.dep(nxt)[pos] = (uint8_t)(d + 1);
+                            L.pfx(nxt)[pos] = (uint16_t)((pf << 2) | q);
                             pos++;
                         }
                     }
-                    int big = 0;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) big += (bnd[q + 1] - bnd[q] > 1);
                     int cidx = L.binc[j] - big;
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
@@ -589,12 +618,11 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
                         }
                     }
                 } else {                                                // cannot happen for distinct keys; keep node
-                    L.rng(nxt)[pos] = r; L.dep(nxt)[pos] = (uint8_t)d;
+                    L.rng(nxt)[pos] = r; L.dep(nxt)[pos] = (uint8_t)d; L.pfx(nxt)[pos] = (uint16_t)pf;
                     const int cidx = L.binc[j] - 1;
                     L.ckey(cnxt)[cidx] = ((uint32_t)(hi - lo) << 16) | (uint32_t)cidx;
                     L.cpos(cnxt)[cidx] = (uint16_t)pos;
                 }
-                (void)k;
             }
             // untouched nodes keep their relative order behind the new children
             {
@@ -608,6 +636,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
                     if (L.mark[p] == 0) {
                         L.rng(nxt)[Kc + (int)ex] = L.rng(cur)[p];
                         L.dep(nxt)[Kc + (int)ex] = L.dep(cur)[p];
+                        L.pfx(nxt)[Kc + (int)ex] = L.pfx(cur)[p];
                         ex++;
                     }
                 }
@@ -625,7 +654,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
     // ---- D: best key per node (:788-807), list order ----
     const int m = s_i[0];
     uint32_t* out = selOut + (size_t)b * P.totalOut + g.outBase;
-    for (int p = t; p < m && p < NC; p += OT) {
+    for (int p = t; p < m && p < g.nodeCap; p += OT) {
         const uint32_t r = L.rng(cur)[p];
         const int lo = r & 0xffff, hi = r >> 16;
         uint32_t best = (uint32_t)S[lo];
@@ -643,7 +672,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
         }
         out[p] = best;
     }
-    if (t == 0) *myCount = min(m, NC);
+    if (t == 0) *myCount = min(m, g.nodeCap);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -913,20 +942,20 @@ void launch_fast(const OrbPlan& P, const uint8_t* pyr, size_t pyrStride, const u
     hipLaunchKernelGGL(k_fast_cells, dim3(P.ncells, batch), dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount);
 }
 
-size_t octree_lds_bytes(int nodeCap) { return 64 + (size_t)nodeCap * 36 + 16; }
+size_t octree_lds_bytes(int nodeCap) { return 64 + 4 * (size_t)OT_MAXB + 2 * (size_t)(OT_MAXB + 2) + (size_t)nodeCap * 40 + 16; }
 
 void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCount, uint64_t* sortbuf, uint32_t* selOut,
                    int32_t* selCount, int32_t* status, int batch, hipStream_t s) {
-    // one launch per level: LDS is sized by the level's node capacity
+    // one launch for all levels: the small levels fill the gaps the large ones leave
+    int ncmax = 0;
+    for (int l = 0; l < P.nlevels; l++) ncmax = max(ncmax, P.lv[l].nodeCap);
+    const size_t lds = octree_lds_bytes(ncmax);
     static size_t lds_attr = 0;
-    for (int l = 0; l < P.nlevels; l++) {
-        const size_t lds = octree_lds_bytes(P.lv[l].nodeCap);
-        if (lds > 48 * 1024 && lds > lds_attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            lds_attr = lds;
-        }
-        hipLaunchKernelGGL(k_octree, dim3(1, batch), dim3(OT), lds, s, P, cand, candCount, sortbuf, selOut, selCount, status, l);
+    if (lds > 48 * 1024 && lds > lds_attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_attr = lds;
     }
+    hipLaunchKernelGGL(k_octree, dim3(P.nlevels, batch), dim3(OT), lds, s, P, cand, candCount, sortbuf, selOut, selCount, status, ncmax);
 }
 
 void launch_describe(const OrbPlan& P, const uint8_t* pyr, const uint8_t* blur, size_t pyrStride, const uint32_t* selOut,
