@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_resize(ResizeArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: 7x7 separable Gaussian, Q8 coefficients, REFLECT_101.  64x16 outputs per 256-thread block.
+// K2: 7x7 separable Gaussian, Q8 coefficients, REFLECT_101.  128x32 outputs per 256-thread block, dword I/O.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int reflect101(int p, int len) {
     if (len == 1) return 0;
@@ -61,42 +61,84 @@ __device__ __forceinline__ int reflect101(int p, int len) {
     return p;
 }
 
+// tile: 128 x 32 outputs per block; input tile covers columns x0-4 .. x0+131 (dword aligned), rows y0-3 .. y0+34
+constexpr int BT_W = 128, BT_H = 32, BI_H = BT_H + 6, BI_P = BT_W + 8, BI_DW = BI_P / 4;
+
 __global__ __launch_bounds__(256) void k_blur7(BlurArgs a) {
-    constexpr int TW = 64, TH = 16, IW = TW + 6, IH = TH + 6, IP = 72;
-    __shared__ uint8_t s_in[IH * IP];
-    __shared__ uint16_t s_h[IH * TW];
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[BI_H * BI_P];
+    __shared__ __attribute__((aligned(16))) uint16_t s_h[BI_H * BT_W];
+    const int t = threadIdx.x;
     const int b = blockIdx.z;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int x0 = blockIdx.x * BT_W, y0 = blockIdx.y * BT_H;
     const uint8_t* src = a.src + (size_t)b * a.sstride;
-    for (int i = threadIdx.x; i < IH * IW; i += 256) {
-        const int r = i / IW, c = i - r * IW;
-        const int sy = reflect101(y0 + r - 3, a.h), sx = reflect101(x0 + c - 3, a.w);
-        s_in[r * IP + c] = src[(size_t)sy * a.spitch + sx];
+    const bool aligned = ((a.spitch & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 3) == 0);
+    // 1. stage the input tile (rows reflected; columns outside [0,w) are fixed up in step 2)
+    for (int i = t; i < BI_H * BI_DW; i += 256) {
+        const int r = i / BI_DW, k = i - r * BI_DW;
+        const int gy = reflect101(y0 + r - 3, a.h);
+        const int gx = x0 - 4 + 4 * k;
+        const uint8_t* row = src + (size_t)gy * a.spitch;
+        uint32_t v;
+        if (aligned && gx >= 0 && gx + 4 <= a.spitch) {
+            v = *reinterpret_cast<const uint32_t*>(row + gx);
+        } else {
+            v = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) v |= (uint32_t)row[min(max(gx + j, 0), a.spitch - 1)] << (8 * j);
+        }
+        *reinterpret_cast<uint32_t*>(&s_in[r * BI_P + 4 * k]) = v;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < IH * TW; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        const uint8_t* p = &s_in[r * IP + c];
-        int acc = 0;
-#pragma unroll
-        for (int k = 0; k < 7; k++) acc += a.q[k] * p[k];
-        s_h[i] = (uint16_t)acc;
+    // 2. BORDER_REFLECT_101 columns: x in [-3,-1] and [w, w+2]; their mirror images are inside this tile
+    for (int i = t; i < BI_H * 6; i += 256) {
+        const int r = i / 6, j = i - r * 6;
+        const int x = (j < 3) ? j - 3 : a.w + (j - 3);
+        const int c = x - (x0 - 4);
+        if (c >= 0 && c < BI_P) {
+            const int cr = reflect101(x, a.w) - (x0 - 4);
+            if (cr >= 0 && cr < BI_P) s_in[r * BI_P + c] = s_in[r * BI_P + cr];
+        }
     }
     __syncthreads();
-    const int tx = (threadIdx.x & 15) * 4, ty = threadIdx.x >> 4;
-    const int ox = x0 + tx, oy = y0 + ty;
-    if (oy >= a.h || ox >= a.w) return;
-    uint32_t packed = 0;
+    // 3. horizontal pass: 4 outputs per iteration from 3 aligned dwords
+    for (int i = t; i < BI_H * (BT_W / 4); i += 256) {
+        const int r = i >> 5, qd = i & 31;
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(&s_in[r * BI_P + 4 * qd]);
+        const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+        int px[12];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        uint32_t acc = 0;
+        for (int k = 0; k < 4; k++) { px[k] = (w0 >> (8 * k)) & 0xff; px[4 + k] = (w1 >> (8 * k)) & 0xff; px[8 + k] = (w2 >> (8 * k)) & 0xff; }
+        uint32_t o[4];
 #pragma unroll
-        for (int j = 0; j < 7; j++) acc += (uint32_t)a.q[j] * s_h[(ty + j) * TW + tx + k];
-        uint32_t v = min((acc + 32768u) >> 16, 255u);
-        packed |= v << (8 * k);
+        for (int j = 0; j < 4; j++) {                         // output x0+4qd+j uses tile columns 4qd+1+j .. 4qd+7+j
+            int acc = 0;
+#pragma unroll
+            for (int k = 0; k < 7; k++) acc += a.q[k] * px[1 + j + k];
+            o[j] = (uint32_t)acc;
+        }
+        uint2 pk = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+        *reinterpret_cast<uint2*>(&s_h[r * BT_W + 4 * qd]) = pk;
     }
-    // pitch is a multiple of 64 so the 4-byte store never leaves the row; bytes past w are padding
-    *reinterpret_cast<uint32_t*>(a.dst + (size_t)b * a.dstride + (size_t)oy * a.dpitch + ox) = packed;
+    __syncthreads();
+    // 4. vertical pass + rounding, one dword store per 4 outputs
+    uint8_t* dst = a.dst + (size_t)b * a.dstride;
+    for (int i = t; i < BT_H * (BT_W / 4); i += 256) {
+        const int y = i >> 5, qd = i & 31;
+        const int oy = y0 + y, ox = x0 + 4 * qd;
+        if (oy >= a.h || ox >= a.w) continue;
+        uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const uint2 v = *reinterpret_cast<const uint2*>(&s_h[(y + j) * BT_W + 4 * qd]);
+            const uint32_t qj = (uint32_t)a.q[j];
+            acc0 += qj * (v.x & 0xffff); acc1 += qj * (v.x >> 16);
+            acc2 += qj * (v.y & 0xffff); acc3 += qj * (v.y >> 16);
+        }
+        const uint32_t r0 = min((acc0 + 32768u) >> 16, 255u), r1 = min((acc1 + 32768u) >> 16, 255u);
+        const uint32_t r2 = min((acc2 + 32768u) >> 16, 255u), r3 = min((acc3 + 32768u) >> 16, 255u);
+        // destination pitch is a multiple of 64: the 4-byte store never leaves the row; bytes past w are padding
+        *reinterpret_cast<uint32_t*>(dst + (size_t)oy * a.dpitch + ox) = r0 | (r1 << 8) | (r2 << 16) | (r3 << 24);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -933,7 +975,7 @@ void launch_resize(const ResizeArgs& a, int batch, hipStream_t s) {
 }
 
 void launch_blur(const BlurArgs& a, int batch, hipStream_t s) {
-    dim3 grid((a.w + 63) / 64, (a.h + 15) / 16, batch);
+    dim3 grid((a.w + BT_W - 1) / BT_W, (a.h + BT_H - 1) / BT_H, batch);
     hipLaunchKernelGGL(k_blur7, grid, dim3(256), 0, s, a);
 }
 
