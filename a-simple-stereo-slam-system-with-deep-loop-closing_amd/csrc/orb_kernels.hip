@@ -154,22 +154,38 @@ constexpr int FS_P = 64;                       // LDS pitch of the score tile (i
 constexpr int FS_ROWS = MAX_CELL + 2;
 constexpr int FAST_MAX_LOCAL = 1024;           // strict 8-neighbour maxima in a 59x59 cell <= 30*30
 
-__device__ __forceinline__ int fast9_score(const uint8_t* p, int minTh) {
-    // ring order = reference makeOffsets(), ORBextractor.cpp:365-369
-    constexpr int RX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
-    constexpr int RY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+// ring order = reference makeOffsets(), ORBextractor.cpp:365-369
+#define FAST_RING_X {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1}
+#define FAST_RING_Y {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3}
+
+// necessary condition for a FAST-9 corner at threshold th: any arc of 9 contains one pixel of every opposite
+// pair (k, k+8) — the reference's pre-tests (:466-478).  Comparisons stay in wave lane-masks (SALU and/or).
+__device__ __forceinline__ bool fast9_pretest(const uint8_t* p, int th) {
+    constexpr int RX[16] = FAST_RING_X;
+    constexpr int RY[16] = FAST_RING_Y;
     const int v = p[0];
-    int d[16];
-    unsigned dm = 0, bm = 0;
+    const int lo = v - th, hi = v + th;
+    bool dk[16], br[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        d[k] = v - (int)p[RX[k] + RY[k] * FT_P];
-        dm |= (unsigned)(d[k] > minTh) << k;
-        bm |= (unsigned)(d[k] < -minTh) << k;
+        const int q = p[RX[k] + RY[k] * FT_P];
+        dk[k] = q < lo; br[k] = q > hi;
     }
-    // any 9-arc contains one pixel of every opposite pair (the reference's pre-tests, :466-478)
-    const bool cand = (((dm | (dm >> 8)) & 0xffu) == 0xffu) || (((bm | (bm >> 8)) & 0xffu) == 0xffu);
-    if (!cand) return 0;
+    bool d = true, b = true;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { d = d && (dk[k] || dk[k + 8]); b = b && (br[k] || br[k + 8]); }
+    return d || b;
+}
+
+// FAST-9 score = largest threshold at which the pixel is still a corner (cv::cornerScore<16> without the
+// threshold seed): max over the 16 arcs of 9 of min(v - p) and of min(p - v), minus 1; 0 if below minTh.
+__device__ __forceinline__ int fast9_score(const uint8_t* p, int minTh) {
+    constexpr int RX[16] = FAST_RING_X;
+    constexpr int RY[16] = FAST_RING_Y;
+    const int v = p[0];
+    int d[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) d[k] = v - (int)p[RX[k] + RY[k] * FT_P];
     int lo2[16], hi2[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
@@ -194,7 +210,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlan P, const uint8_t* __
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[FT_ROWS * FT_P];
     __shared__ __attribute__((aligned(16))) uint8_t s_score[FS_ROWS * FS_P];
     __shared__ uint32_t s_list[FAST_MAX_LOCAL];
-    __shared__ int s_cnt, s_base, s_npass, s_wr;
+    __shared__ uint16_t s_cl[MAX_CELL * MAX_CELL + 7];
+    __shared__ int s_cnt, s_base, s_npass, s_wr, s_ncl;
 
     const int b = blockIdx.y;
     int level = 0;
@@ -219,12 +236,33 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlan P, const uint8_t* __
         *reinterpret_cast<uint32_t*>(&s_tile[r * FT_P + 4 * k]) = v;
     }
     for (int i = threadIdx.x; i < (FS_ROWS * FS_P) / 4; i += 256) reinterpret_cast<uint32_t*>(s_score)[i] = 0;
-    if (threadIdx.x == 0) s_cnt = 0;
+    if (threadIdx.x == 0) { s_cnt = 0; s_ncl = 0; }
     __syncthreads();
 
-    const int npx = wc * hc;
-    for (int i = threadIdx.x; i < npx; i += 256) {
-        const int cy = i / wc, cx = i - cy * wc;
+    // thread -> pixel mapping without integer division: lane x = t & 31 (+32), rows t >> 5 (+8)
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    // phase 1: cheap necessary test on every pixel; survivors are compacted into an LDS work list (cy<<8 | cx)
+    for (int cy0 = 0; cy0 < hc; cy0 += 8) {
+        for (int cx0 = 0; cx0 < wc; cx0 += 32) {
+            const int cy = cy0 + ty, cx = cx0 + tx;
+            bool pass = false;
+            if (cy < hc && cx < wc) pass = fast9_pretest(&s_tile[(cy + 3) * FT_P + off + cx + 3], P.minTh);
+            const unsigned long long m = __ballot(pass);
+            if (m) {
+                const int lane = threadIdx.x & 63;
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_ncl, __popcll(m));
+                base = __shfl(base, 0, 64);
+                if (pass) s_cl[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((cy << 8) | cx);
+            }
+        }
+    }
+    __syncthreads();
+    // phase 2: full score only for the survivors (dense lanes)
+    const int ncl = s_ncl;
+    for (int q = threadIdx.x; q < ncl; q += 256) {
+        const int i = s_cl[q];
+        const int cy = i >> 8, cx = i & 0xff;
         const int s = fast9_score(&s_tile[(cy + 3) * FT_P + off + cx + 3], P.minTh);
         if (s) s_score[(cy + 1) * FS_P + cx + 1] = (uint8_t)s;
     }
@@ -232,18 +270,21 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlan P, const uint8_t* __
 
     // NMS (strict > all 8 neighbours, zeros outside the cell interior): maxima go to an LDS list
     int any_ini = 0;
-    for (int i = threadIdx.x; i < npx; i += 256) {
-        const int cy = i / wc, cx = i - cy * wc;
-        const uint8_t* sp = &s_score[(cy + 1) * FS_P + cx + 1];
-        const int s = sp[0];
-        if (s) {
-            const bool mx = s > sp[-1] && s > sp[1] && s > sp[-FS_P - 1] && s > sp[-FS_P] && s > sp[-FS_P + 1] &&
-                            s > sp[FS_P - 1] && s > sp[FS_P] && s > sp[FS_P + 1];
-            if (mx) {
-                const int px = cx + 3 + cj * g.wCell, py = cy + 3 + ci * g.hCell;     // border-relative
-                const int pos = atomicAdd(&s_cnt, 1);
-                if (pos < FAST_MAX_LOCAL) s_list[pos] = ((uint32_t)py << 20) | ((uint32_t)px << 8) | (uint32_t)s;
-                any_ini |= (s >= P.iniTh);
+    for (int cy0 = 0; cy0 < hc; cy0 += 8) {
+        for (int cx0 = 0; cx0 < wc; cx0 += 32) {
+            const int cy = cy0 + ty, cx = cx0 + tx;
+            if (cy >= hc || cx >= wc) continue;
+            const uint8_t* sp = &s_score[(cy + 1) * FS_P + cx + 1];
+            const int s = sp[0];
+            if (s) {
+                const bool mx = s > sp[-1] && s > sp[1] && s > sp[-FS_P - 1] && s > sp[-FS_P] && s > sp[-FS_P + 1] &&
+                                s > sp[FS_P - 1] && s > sp[FS_P] && s > sp[FS_P + 1];
+                if (mx) {
+                    const int px = cx + 3 + cj * g.wCell, py = cy + 3 + ci * g.hCell;     // border-relative
+                    const int pos = atomicAdd(&s_cnt, 1);
+                    if (pos < FAST_MAX_LOCAL) s_list[pos] = ((uint32_t)py << 20) | ((uint32_t)px << 8) | (uint32_t)s;
+                    any_ini |= (s >= P.iniTh);
+                }
             }
         }
     }
