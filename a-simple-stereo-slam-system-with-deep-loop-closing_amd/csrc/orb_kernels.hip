@@ -865,13 +865,24 @@ __device__ __forceinline__ uint32_t wave_brief(const uint8_t* __restrict__ img, 
     return w;
 }
 
+// LDS patches of one keypoint (one wave): the 31x31 intensity-centroid patch of the level image and the
+// 37x37 window of the blurred level that the steered 31x31 BRIEF pattern can reach (|rotated coord| <= 18).
+// Both are fetched with aligned dword loads issued back to back (one HBM/L2 round trip per keypoint).
+constexpr int DA_ROWS = 31, DA_DW = 9, DA_P = DA_DW * 4;      // x-15.. : 3 (align) + 31 -> 9 dwords
+constexpr int DB_R = 18, DB_ROWS = 2 * DB_R + 1, DB_DW = 11, DB_P = DB_DW * 4;   // 3 + 37 -> 11 dwords
+constexpr int DA_N = DA_ROWS * DA_DW, DB_N = DB_ROWS * DB_DW;              // 279, 407 dwords
+constexpr int DA_IT = (DA_N + 63) / 64, DB_IT = (DB_N + 63) / 64;          // 5, 7 loads per lane
+
 __global__ __launch_bounds__(256) void k_describe(OrbPlan P, const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                                   size_t pyrStride, const uint32_t* __restrict__ selOut,
                                                   const int32_t* __restrict__ selCount, myslam_keypoint* __restrict__ kps,
                                                   uint8_t* __restrict__ desc, int32_t* __restrict__ counts,
                                                   int32_t* __restrict__ status, int cap, int detectOnly) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_a[4][DA_N];
+    __shared__ __attribute__((aligned(16))) uint32_t s_b[4][DB_N];
     const int b = blockIdx.y;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wave = threadIdx.x >> 6;
+    const int slot = blockIdx.x * 4 + wave;
     const int lane = threadIdx.x & 63;
     int level = -1, local = 0, total = 0;
     for (int l = 0; l < P.nlevels; l++) {
@@ -883,22 +894,89 @@ __global__ __launch_bounds__(256) void k_describe(OrbPlan P, const uint8_t* __re
         counts[b] = min(total, cap);
         if (total > cap && status) status[b] = MYSLAM_ERR_CAPACITY;
     }
-    if (level < 0 || slot >= cap) return;
-    const LevelGeom& g = P.lv[level];
-    const uint32_t pay = selOut[(size_t)b * P.totalOut + g.outBase + local];
+    const bool active = (level >= 0 && slot < cap);
+    const LevelGeom& g = P.lv[active ? level : 0];
+    uint32_t pay = 0;
+    if (active) pay = selOut[(size_t)b * P.totalOut + g.outBase + local];
     const int x = (int)((pay >> 8) & 0xfff) + MIN_BORDER, y = (int)(pay >> 20) + MIN_BORDER;    // :897-898
     myslam_keypoint kp;
     kp.response = (float)(pay & 0xff);
     kp.class_id = -1;
     if (detectOnly) {                         // ORBextractor::Detect: raw cv::FAST keypoints
         kp.x = (float)x; kp.y = (float)y; kp.size = 7.f; kp.angle = -1.f; kp.octave = 0;
-        if (lane == 0) kps[(size_t)b * cap + slot] = kp;
+        if (active && lane == 0) kps[(size_t)b * cap + slot] = kp;
         return;
     }
     const uint8_t* img = pyr + (size_t)b * pyrStride + g.imgOff;
     const uint8_t* bl = blur + (size_t)b * pyrStride + g.imgOff;
-    const float angle = wave_ic_angle(img, g.pitch, x, y);                                        // :905-906
-    const uint32_t w = wave_brief(bl, g.pitch, x, y, angle);                                      // :970
+    // --- fetch both patches (keypoints keep >= 19 px from every border, ORBextractor.cpp:25, so all rows exist) ---
+    const int xa0 = (x - HALF_PATCH) & ~3, offA = (x - HALF_PATCH) - xa0;
+    const int xb0 = (x - DB_R) & ~3, offB = (x - DB_R) - xb0;
+    uint32_t ra[DA_IT], rb[DB_IT];
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < DA_IT; k++) {
+            const int i = lane + 64 * k;
+            const int r = i / DA_DW, c = i - r * DA_DW;
+            ra[k] = (i < DA_N) ? *reinterpret_cast<const uint32_t*>(img + (size_t)(y - HALF_PATCH + r) * g.pitch + xa0 + 4 * c) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < DB_IT; k++) {
+            const int i = lane + 64 * k;
+            const int r = i / DB_DW, c = i - r * DB_DW;
+            rb[k] = (i < DB_N) ? *reinterpret_cast<const uint32_t*>(bl + (size_t)(y - DB_R + r) * g.pitch + xb0 + 4 * c) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < DA_IT; k++) { const int i = lane + 64 * k; if (i < DA_N) s_a[wave][i] = ra[k]; }
+#pragma unroll
+        for (int k = 0; k < DB_IT; k++) { const int i = lane + 64 * k; if (i < DB_N) s_b[wave][i] = rb[k]; }
+    }
+    __syncthreads();
+    if (!active) return;
+    // --- IC_Angle (:27-55): lanes 2r / 2r+1 take the left (incl. centre) / right half of patch row r ---
+    const uint8_t* pa = reinterpret_cast<const uint8_t*>(s_a[wave]);
+    int m10 = 0, m01 = 0;
+    {
+        const int r = lane >> 1;
+        if (r < DA_ROWS) {
+            const int v = r - HALF_PATCH;
+            const int d = c_umax[v < 0 ? -v : v];
+            const uint8_t* row = pa + r * DA_P + offA + HALF_PATCH;        // &patch(row v, u = 0)
+            const int right = lane & 1;
+            int sI = 0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int u = right ? (j + 1) : -j;
+                const bool ok = right ? (j + 1 <= d) : (j <= d);
+                const int I = ok ? (int)row[u] : 0;
+                m10 += u * I; sI += I;
+            }
+            m01 = v * sI;
+        }
+    }
+    m10 = wave_reduce_sum(m10);
+    m01 = wave_reduce_sum(m01);
+    const float angle = fast_atan2_deg((float)m01, (float)m10);                                    // :54
+    // --- steered BRIEF (:58-98) from the blurred window ---
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    float ca, sb;
+    det_sincos(__fmul_rn(angle, factorPI), sb, ca);
+    const uint8_t* center = reinterpret_cast<const uint8_t*>(s_b[wave]) + DB_R * DB_P + offB + DB_R;
+    uint32_t nib = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int8_t* pp = &c_pattern[(lane * 4 + j) * 4];
+        const float x0 = (float)pp[0], y0 = (float)pp[1], x1 = (float)pp[2], y1 = (float)pp[3];
+        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, sb), __fmul_rn(y0, ca)));
+        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sb)));
+        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sb), __fmul_rn(y1, ca)));
+        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sb)));
+        const int t0 = center[r0 * DB_P + c0], t1 = center[r1 * DB_P + c1];
+        nib |= (uint32_t)(t0 < t1) << j;
+    }
+    const uint32_t byte = nib | (__shfl_down(nib, 1, 64) << 4);            // valid on even lanes
+    uint32_t w = byte | (__shfl_down(byte, 2, 64) << 8);
+    w |= (__shfl_down(byte, 4, 64) << 16) | (__shfl_down(byte, 6, 64) << 24);   // valid on lanes % 8 == 0
     if ((lane & 7) == 0) reinterpret_cast<uint32_t*>(desc + ((size_t)b * cap + slot) * 32)[lane >> 3] = w;
     if (lane == 0) {
         kp.x = (level != 0) ? __fmul_rn((float)x, g.scale) : (float)x;                            // :975-981
