@@ -49,7 +49,7 @@ void gauss_q8(int kind, int q[7]) {
 }
 
 // cv::resize INTER_LINEAR coefficient tables (OpenCV 3.4 resize.cpp: fx = (dx+0.5)*scale-0.5, 11-bit weights)
-static void resize_tables(int ssize, int dsize, bool is_x, std::vector<int32_t>& ofs, std::vector<int16_t>& coef) {
+[[maybe_unused]] static void resize_tables(int ssize, int dsize, bool is_x, std::vector<int32_t>& ofs, std::vector<int16_t>& coef) {
     const double inv_scale = (double)dsize / ssize;
     const double scale = 1. / inv_scale;
     ofs.resize(dsize); coef.resize(2 * dsize);
@@ -90,8 +90,6 @@ struct myslam_orb {
     // plan for the current image size
     int rows = 0, cols = 0;
     OrbPlan full{}, det{};
-    std::vector<int32_t*> d_xofs, d_yofs;
-    std::vector<int16_t*> d_xa, d_yb;
 
     // batch buffers
     int batchCap = 0;
@@ -185,23 +183,6 @@ int myslam_orb::make_plan(int r, int c) {
     det.lv[0].nodeCap = (std::max(nfeatures + 4, 4 * P.lv[0].nIni + 4) + 3) & ~3;
     det.lv[0].outBase = 0;
     det.totalOut = det.lv[0].nodeCap;
-    // resize tables
-    for (auto p : d_xofs) if (p) (void)hipFree(p);
-    for (auto p : d_yofs) if (p) (void)hipFree(p);
-    for (auto p : d_xa) if (p) (void)hipFree(p);
-    for (auto p : d_yb) if (p) (void)hipFree(p);
-    d_xofs.assign(nlevels, nullptr); d_yofs.assign(nlevels, nullptr); d_xa.assign(nlevels, nullptr); d_yb.assign(nlevels, nullptr);
-    for (int l = 1; l < nlevels; l++) {
-        std::vector<int32_t> xo, yo; std::vector<int16_t> xa, yb;
-        resize_tables(P.lv[l - 1].w, P.lv[l].w, true, xo, xa);
-        resize_tables(P.lv[l - 1].h, P.lv[l].h, false, yo, yb);
-        MYSLAM_HIP_CHECK(hipMalloc((void**)&d_xofs[l], xo.size() * 4)); MYSLAM_HIP_CHECK(hipMalloc((void**)&d_xa[l], xa.size() * 2));
-        MYSLAM_HIP_CHECK(hipMalloc((void**)&d_yofs[l], yo.size() * 4)); MYSLAM_HIP_CHECK(hipMalloc((void**)&d_yb[l], yb.size() * 2));
-        MYSLAM_HIP_CHECK(hipMemcpy(d_xofs[l], xo.data(), xo.size() * 4, hipMemcpyHostToDevice));
-        MYSLAM_HIP_CHECK(hipMemcpy(d_xa[l], xa.data(), xa.size() * 2, hipMemcpyHostToDevice));
-        MYSLAM_HIP_CHECK(hipMemcpy(d_yofs[l], yo.data(), yo.size() * 4, hipMemcpyHostToDevice));
-        MYSLAM_HIP_CHECK(hipMemcpy(d_yb[l], yb.data(), yb.size() * 2, hipMemcpyHostToDevice));
-    }
     rows = r; cols = c;
     return MYSLAM_OK;
 }
@@ -249,7 +230,7 @@ int myslam_orb::build_pyramids(const uint8_t* d_imgs, int batch, int step, size_
             ResizeArgs a;
             a.src = base + P.lv[l - 1].imgOff; a.sw = P.lv[l - 1].w; a.sh = P.lv[l - 1].h; a.spitch = P.lv[l - 1].pitch; a.sstride = P.pyrBytes;
             a.dst = base + P.lv[l].imgOff; a.dw = P.lv[l].w; a.dh = P.lv[l].h; a.dpitch = P.lv[l].pitch; a.dstride = P.pyrBytes;
-            a.xofs = d_xofs[l]; a.xa = d_xa[l]; a.yofs = d_yofs[l]; a.yb = d_yb[l];
+            a.scale_x = 1. / ((double)a.dw / a.sw); a.scale_y = 1. / ((double)a.dh / a.sh);
             launch_resize(a, batch, stream);
         }
     }
@@ -327,10 +308,6 @@ void myslam_orb::free_all() {
     void* ptrs[] = {d_pyr, d_blur, d_mask, d_cand, d_sort, d_candCount, d_selCount, d_status, d_sel, d_stageImg, d_stageMask,
                     d_stageKps, d_stageKps2, d_stageDesc, d_stageKeep, d_stageCounts};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    for (auto p : d_xofs) if (p) (void)hipFree(p);
-    for (auto p : d_yofs) if (p) (void)hipFree(p);
-    for (auto p : d_xa) if (p) (void)hipFree(p);
-    for (auto p : d_yb) if (p) (void)hipFree(p);
 }
 
 // =================================================================================================
@@ -338,7 +315,7 @@ extern "C" {
 
 int myslam_orb_create(myslam_orb** out, int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast) {
     if (!out || nfeatures < 1 || nlevels < 1 || nlevels > MAXL || !(scale_factor > 1.0f) || ini_th_fast < 0 ||
-        min_th_fast < 1 || min_th_fast > ini_th_fast || ini_th_fast > 255)
+        min_th_fast < 1 || min_th_fast > ini_th_fast || ini_th_fast > 255 || scale_factor > 2.5f)
         return MYSLAM_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MYSLAM_ERR_HIP;   // no CPU fallback

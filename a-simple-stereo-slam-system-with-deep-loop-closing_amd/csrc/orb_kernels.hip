@@ -24,30 +24,60 @@ __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9
 // ------------------------------------------------------------------------------------------------
 // K1: bilinear down-scale of one pyramid level from the previous one (fixed point, 11-bit weights)
 // ------------------------------------------------------------------------------------------------
+// source coordinate + 11-bit weights of destination index d (OpenCV resize.cpp: fx = (dx+0.5)*scale - 0.5)
+__device__ __forceinline__ void resize_coord(int d, double scale, int ssize, bool is_x, int& s, int& c0, int& c1) {
+    float f = (float)__dsub_rn(__dmul_rn((double)d + 0.5, scale), 0.5);
+    int si = (int)floorf(f);
+    f = __fsub_rn(f, (float)si);
+    if (is_x) {
+        if (si < 0) { f = 0.f; si = 0; }
+        if (si >= ssize - 1) { f = 0.f; si = ssize - 1; }
+    }
+    s = si;
+    c0 = __float2int_rn(__fmul_rn(__fsub_rn(1.f, f), 2048.f));
+    c1 = __float2int_rn(__fmul_rn(f, 2048.f));
+}
+
+// 4 destination pixels per thread; the <= 16 source bytes they need come from 4 aligned dwords per source row
 __global__ __launch_bounds__(256) void k_resize(ResizeArgs a) {
     const int b = blockIdx.z;
     const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int dx4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
     if (dy >= a.dh || dx4 >= a.dw) return;
-    const int sy = a.yofs[dy];
+    int sy, b0, b1;
+    resize_coord(dy, a.scale_y, a.sh, false, sy, b0, b1);
     const int sy0 = min(max(sy, 0), a.sh - 1), sy1 = min(max(sy + 1, 0), a.sh - 1);
-    const int b0 = a.yb[2 * dy], b1 = a.yb[2 * dy + 1];
     const uint8_t* S0 = a.src + (size_t)b * a.sstride + (size_t)sy0 * a.spitch;
     const uint8_t* S1 = a.src + (size_t)b * a.sstride + (size_t)sy1 * a.spitch;
+    int sx[4], a0[4], a1[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) resize_coord(min(dx4 + k, a.dw - 1), a.scale_x, a.sw, true, sx[k], a0[k], a1[k]);
+    const int xal = sx[0] & ~3;
+    uint32_t w0[4], w1[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int xo = xal + 4 * j;
+        const bool ok = xo + 4 <= a.spitch;
+        w0[j] = ok ? *reinterpret_cast<const uint32_t*>(S0 + xo) : 0u;
+        w1[j] = ok ? *reinterpret_cast<const uint32_t*>(S1 + xo) : 0u;
+    }
     uint32_t packed = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int dx = dx4 + k;
-        if (dx < a.dw) {
-            const int sx = a.xofs[dx];
-            const int sx1 = min(sx + 1, a.sw - 1);
-            const int a0 = a.xa[2 * dx], a1 = a.xa[2 * dx + 1];
-            const int r0 = S0[sx] * a0 + S0[sx1] * a1;
-            const int r1 = S1[sx] * a0 + S1[sx1] * a1;
-            int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-            v = min(max(v, 0), 255);
-            packed |= (uint32_t)v << (8 * k);
-        }
+        const int o = sx[k] - xal;                       // 0 .. 12 for scale factors up to 2.6
+        const int q = o >> 2;
+        const uint32_t lo0 = (q == 0) ? w0[0] : (q == 1) ? w0[1] : (q == 2) ? w0[2] : w0[3];
+        const uint32_t hi0 = (q == 0) ? w0[1] : (q == 1) ? w0[2] : (q == 2) ? w0[3] : 0u;
+        const uint32_t lo1 = (q == 0) ? w1[0] : (q == 1) ? w1[1] : (q == 2) ? w1[2] : w1[3];
+        const uint32_t hi1 = (q == 0) ? w1[1] : (q == 1) ? w1[2] : (q == 2) ? w1[3] : 0u;
+        const uint32_t v0 = __builtin_amdgcn_alignbyte(hi0, lo0, (uint32_t)(o & 3));      // bytes sx, sx+1 of row 0
+        const uint32_t v1 = __builtin_amdgcn_alignbyte(hi1, lo1, (uint32_t)(o & 3));
+        // at the right border sx = sw-1 and the weight of sx+1 is 0 (OpenCV clamps fx there), so its value is irrelevant
+        const int r0 = (int)(v0 & 0xff) * a0[k] + (int)((v0 >> 8) & 0xff) * a1[k];
+        const int r1 = (int)(v1 & 0xff) * a0[k] + (int)((v1 >> 8) & 0xff) * a1[k];
+        int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        v = min(max(v, 0), 255);
+        packed |= (uint32_t)v << (8 * k);
     }
     *reinterpret_cast<uint32_t*>(a.dst + (size_t)b * a.dstride + (size_t)dy * a.dpitch + dx4) = packed;
 }

@@ -48,8 +48,7 @@ struct OrbPlan {
 struct ResizeArgs {
     const uint8_t* src; int sw, sh, spitch; size_t sstride;
     uint8_t* dst; int dw, dh, dpitch; size_t dstride;
-    const int32_t* xofs; const int16_t* xa;      // dw, dw*2 (11-bit weights)
-    const int32_t* yofs; const int16_t* yb;      // dh, dh*2
+    double scale_x, scale_y;                     // 1 / ((double)dsize / ssize), as cv::resize computes it
 };
 
 struct BlurArgs {
