@@ -9,6 +9,8 @@
 //
 // Built with -ffp-contract=off: BRIEF sample coordinates and fastAtan2 are float expressions whose
 // integer/float results must be bit-identical to a non-contracting CPU evaluation.
+#include <stdlib.h>
+
 #include "common.h"
 #include "orb_plan.h"
 
@@ -178,69 +180,92 @@ __global__ __launch_bounds__(256) void k_blur7(BlurArgs a) {
 // threshold fallback is decided per cell, survivors are appended to the level's candidate list.
 // Candidate payload: py<<20 | px<<8 | score   (px,py border-relative as in ORBextractor.cpp:871-872).
 // ------------------------------------------------------------------------------------------------
-constexpr int FT_P = 72;                       // LDS pitch of the ROI tile (ROI width <= 65, +3 align slack)
-constexpr int FT_ROWS = MAX_CELL + 6;          // 65
-constexpr int FS_P = 64;                       // LDS pitch of the score tile (interior <= 59, +2 border)
-constexpr int FS_ROWS = MAX_CELL + 2;
-constexpr int FAST_MAX_LOCAL = 1024;           // strict 8-neighbour maxima in a 59x59 cell <= 30*30
-
 // ring order = reference makeOffsets(), ORBextractor.cpp:365-369
 #define FAST_RING_X {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1}
 #define FAST_RING_Y {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3}
 
 // necessary condition for a FAST-9 corner at threshold th: any arc of 9 contains one pixel of every opposite
-// pair (k, k+8) — the reference's pre-tests (:466-478).  Comparisons stay in wave lane-masks (SALU and/or).
+// pair (k, k+8) — the reference's pre-tests (:466-478).  "every pair has a member darker than v-th" is
+// max_k min(p_k, p_k+8) < v-th (and symmetrically for brighter): 30 two-cycle min/max ops instead of 32
+// four-cycle compares into lane masks.
+template <int TP>
 __device__ __forceinline__ bool fast9_pretest(const uint8_t* p, int th) {
     constexpr int RX[16] = FAST_RING_X;
     constexpr int RY[16] = FAST_RING_Y;
     const int v = p[0];
-    const int lo = v - th, hi = v + th;
-    bool dk[16], br[16];
+    int mx_of_min = 0, mn_of_max = 255;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int q = p[RX[k] + RY[k] * FT_P];
-        dk[k] = q < lo; br[k] = q > hi;
+    for (int k = 0; k < 8; k++) {
+        const int a = p[RX[k] + RY[k] * TP], b = p[RX[k + 8] + RY[k + 8] * TP];
+        mx_of_min = max(mx_of_min, min(a, b));
+        mn_of_max = min(mn_of_max, max(a, b));
     }
-    bool d = true, b = true;
-#pragma unroll
-    for (int k = 0; k < 8; k++) { d = d && (dk[k] || dk[k + 8]); b = b && (br[k] || br[k + 8]); }
-    return d || b;
+    return (mx_of_min < v - th) || (mn_of_max > v + th);
 }
 
 // FAST-9 score = largest threshold at which the pixel is still a corner (cv::cornerScore<16> without the
 // threshold seed): max over the 16 arcs of 9 of min(v - p) and of min(p - v), minus 1; 0 if below minTh.
+// Packed 16-bit evaluation: register j holds (d[j], d[j+8]); the sliding minima/maxima over windows of
+// 2, 4, 8, 9 ring positions are v_pk_min/max_i16 on those pairs (the wrap-around is a half swap).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ s16x2 hswap(s16x2 x) { return __builtin_shufflevector(x, x, 1, 0); }
+__device__ __forceinline__ s16x2 pmin(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ s16x2 pmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+
+template <int TP>
 __device__ __forceinline__ int fast9_score(const uint8_t* p, int minTh) {
     constexpr int RX[16] = FAST_RING_X;
     constexpr int RY[16] = FAST_RING_Y;
     const int v = p[0];
-    int d[16];
+    const s16x2 vv = {(short)v, (short)v};
+    s16x2 P[8], Ps[8];
 #pragma unroll
-    for (int k = 0; k < 16; k++) d[k] = v - (int)p[RX[k] + RY[k] * FT_P];
-    int lo2[16], hi2[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
-    int lo4[16], hi4[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
-    int best_dark = -1000, best_bright = -1000;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);     // min over arc k..k+8
-        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
-        best_dark = max(best_dark, lo9);
-        best_bright = max(best_bright, -hi9);
+    for (int j = 0; j < 8; j++) {
+        const s16x2 q = {(short)p[RX[j] + RY[j] * TP], (short)p[RX[j + 8] + RY[j + 8] * TP]};
+        P[j] = vv - q;                       // (d[j], d[j+8])
+        Ps[j] = hswap(P[j]);                 // (d[j+8], d[j])
     }
+    s16x2 A[8], B[8], C[8], Am[8], Bm[8], Cm[8];
+#pragma unroll
+    for (int j = 0; j < 7; j++) { A[j] = pmin(P[j], P[j + 1]); Am[j] = pmax(P[j], P[j + 1]); }
+    A[7] = pmin(P[7], Ps[0]); Am[7] = pmax(P[7], Ps[0]);
+#pragma unroll
+    for (int j = 0; j < 6; j++) { B[j] = pmin(A[j], A[j + 2]); Bm[j] = pmax(Am[j], Am[j + 2]); }
+    B[6] = pmin(A[6], hswap(A[0])); B[7] = pmin(A[7], hswap(A[1]));
+    Bm[6] = pmax(Am[6], hswap(Am[0])); Bm[7] = pmax(Am[7], hswap(Am[1]));
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        C[j] = pmin(B[j], B[j + 4]); Cm[j] = pmax(Bm[j], Bm[j + 4]);
+        C[j + 4] = pmin(B[j + 4], hswap(B[j])); Cm[j + 4] = pmax(Bm[j + 4], hswap(Bm[j]));
+    }
+    s16x2 dark = {-1000, -1000}, brt = {1000, 1000};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        dark = pmax(dark, pmin(C[j], Ps[j]));        // min over arc k..k+8 for k = j and k = j+8
+        brt = pmin(brt, pmax(Cm[j], Ps[j]));         // max over the same arcs
+    }
+    const int best_dark = max((int)dark.x, (int)dark.y);
+    const int best_bright = -min((int)brt.x, (int)brt.y);
     const int s = max(best_dark, best_bright) - 1;
     return s >= minTh ? s : 0;
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(OrbPlan P, const uint8_t* __restrict__ pyr, size_t pyrStride,
-                                                    const uint8_t* __restrict__ maskPyr,
-                                                    uint32_t* __restrict__ cand, int32_t* __restrict__ candCount) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_tile[FT_ROWS * FT_P];
-    __shared__ __attribute__((aligned(16))) uint8_t s_score[FS_ROWS * FS_P];
-    __shared__ uint32_t s_list[FAST_MAX_LOCAL];
-    __shared__ uint16_t s_cl[MAX_CELL * MAX_CELL + 7];
+// T threads per cell (64 = one wave per cell: no inter-wave barriers, every wave runs its cell independently);
+// CW = largest cell interior edge the instantiation supports (LDS is sized by it).
+template <int T, int CW>
+__global__ __launch_bounds__(T) void k_fast_cells(OrbPlan P, const uint8_t* __restrict__ pyr, size_t pyrStride,
+                                                  const uint8_t* __restrict__ maskPyr,
+                                                  uint32_t* __restrict__ cand, int32_t* __restrict__ candCount) {
+    constexpr int TP = (CW + 15) & ~3;            // ROI tile pitch: 3 (align) + CW + 6 (+3 dword slack)
+    constexpr int TROWS = CW + 6;
+    constexpr int SP = (CW + 2 + 3) & ~3;         // score tile pitch (1-px zero border)
+    constexpr int SROWS = CW + 2;
+    constexpr int NLOC = ((CW + 1) / 2) * ((CW + 1) / 2);   // strict 8-neighbour maxima a cell can hold
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[TROWS * TP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_score[SROWS * SP];
+    __shared__ uint32_t s_list[NLOC];
+    __shared__ uint16_t s_cl[CW * CW + 8];
     __shared__ int s_cnt, s_base, s_npass, s_wr, s_ncl;
 
     const int b = blockIdx.y;
@@ -260,26 +285,28 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlan P, const uint8_t* __
     // stage ROI with aligned 4-byte loads (internal planes: 64-byte pitch, 256-byte base)
     const int x0a = iniX & ~3, off = iniX - x0a;
     const int ndw = (off + wr + 3) >> 2;
-    for (int i = threadIdx.x; i < hr * ndw; i += 256) {
-        const int r = i / ndw, k = i - r * ndw;
-        const uint32_t v = *reinterpret_cast<const uint32_t*>(img + (size_t)(iniY + r) * g.pitch + x0a + 4 * k);
-        *reinterpret_cast<uint32_t*>(&s_tile[r * FT_P + 4 * k]) = v;
+    for (int r = threadIdx.x / 32; r < hr; r += T / 32) {             // ndw <= 18 dwords per ROI row
+        const int k = threadIdx.x & 31;
+        if (k < ndw) {
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(img + (size_t)(iniY + r) * g.pitch + x0a + 4 * k);
+            *reinterpret_cast<uint32_t*>(&s_tile[r * TP + 4 * k]) = v;
+        }
     }
-    for (int i = threadIdx.x; i < (FS_ROWS * FS_P) / 4; i += 256) reinterpret_cast<uint32_t*>(s_score)[i] = 0;
+    for (int i = threadIdx.x; i < (SROWS * SP) / 4; i += T) reinterpret_cast<uint32_t*>(s_score)[i] = 0;
     if (threadIdx.x == 0) { s_cnt = 0; s_ncl = 0; }
     __syncthreads();
 
-    // thread -> pixel mapping without integer division: lane x = t & 31 (+32), rows t >> 5 (+8)
+    // thread -> pixel mapping without integer division: lane x = t & 31 (+32), rows t >> 5 (+T/32)
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int lane = threadIdx.x & 63;
     // phase 1: cheap necessary test on every pixel; survivors are compacted into an LDS work list (cy<<8 | cx)
-    for (int cy0 = 0; cy0 < hc; cy0 += 8) {
+    for (int cy0 = 0; cy0 < hc; cy0 += T / 32) {
         for (int cx0 = 0; cx0 < wc; cx0 += 32) {
             const int cy = cy0 + ty, cx = cx0 + tx;
             bool pass = false;
-            if (cy < hc && cx < wc) pass = fast9_pretest(&s_tile[(cy + 3) * FT_P + off + cx + 3], P.minTh);
+            if (cy < hc && cx < wc) pass = fast9_pretest<TP>(&s_tile[(cy + 3) * TP + off + cx + 3], P.minTh);
             const unsigned long long m = __ballot(pass);
             if (m) {
-                const int lane = threadIdx.x & 63;
                 int base = 0;
                 if (lane == 0) base = atomicAdd(&s_ncl, __popcll(m));
                 base = __shfl(base, 0, 64);
@@ -290,37 +317,35 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlan P, const uint8_t* __
     __syncthreads();
     // phase 2: full score only for the survivors (dense lanes)
     const int ncl = s_ncl;
-    for (int q = threadIdx.x; q < ncl; q += 256) {
+    for (int q = threadIdx.x; q < ncl; q += T) {
         const int i = s_cl[q];
         const int cy = i >> 8, cx = i & 0xff;
-        const int s = fast9_score(&s_tile[(cy + 3) * FT_P + off + cx + 3], P.minTh);
-        if (s) s_score[(cy + 1) * FS_P + cx + 1] = (uint8_t)s;
+        const int s = fast9_score<TP>(&s_tile[(cy + 3) * TP + off + cx + 3], P.minTh);
+        if (s) s_score[(cy + 1) * SP + cx + 1] = (uint8_t)s;
     }
     __syncthreads();
 
-    // NMS (strict > all 8 neighbours, zeros outside the cell interior): maxima go to an LDS list
+    // NMS (strict > all 8 neighbours, zeros outside the cell interior): only phase-2 survivors can be maxima
     int any_ini = 0;
-    for (int cy0 = 0; cy0 < hc; cy0 += 8) {
-        for (int cx0 = 0; cx0 < wc; cx0 += 32) {
-            const int cy = cy0 + ty, cx = cx0 + tx;
-            if (cy >= hc || cx >= wc) continue;
-            const uint8_t* sp = &s_score[(cy + 1) * FS_P + cx + 1];
-            const int s = sp[0];
-            if (s) {
-                const bool mx = s > sp[-1] && s > sp[1] && s > sp[-FS_P - 1] && s > sp[-FS_P] && s > sp[-FS_P + 1] &&
-                                s > sp[FS_P - 1] && s > sp[FS_P] && s > sp[FS_P + 1];
-                if (mx) {
-                    const int px = cx + 3 + cj * g.wCell, py = cy + 3 + ci * g.hCell;     // border-relative
-                    const int pos = atomicAdd(&s_cnt, 1);
-                    if (pos < FAST_MAX_LOCAL) s_list[pos] = ((uint32_t)py << 20) | ((uint32_t)px << 8) | (uint32_t)s;
-                    any_ini |= (s >= P.iniTh);
-                }
+    for (int q = threadIdx.x; q < ncl; q += T) {
+        const int i = s_cl[q];
+        const int cy = i >> 8, cx = i & 0xff;
+        const uint8_t* sp = &s_score[(cy + 1) * SP + cx + 1];
+        const int s = sp[0];
+        if (s) {
+            const bool mx = s > sp[-1] && s > sp[1] && s > sp[-SP - 1] && s > sp[-SP] && s > sp[-SP + 1] &&
+                            s > sp[SP - 1] && s > sp[SP] && s > sp[SP + 1];
+            if (mx) {
+                const int px = cx + 3 + cj * g.wCell, py = cy + 3 + ci * g.hCell;     // border-relative
+                const int pos = atomicAdd(&s_cnt, 1);
+                if (pos < NLOC) s_list[pos] = ((uint32_t)py << 20) | ((uint32_t)px << 8) | (uint32_t)s;
+                any_ini |= (s >= P.iniTh);
             }
         }
     }
     // does the cell have a corner at iniTh?  else fall back to minTh (:858-865)
     const int cell_has_ini = __syncthreads_or(any_ini);
-    const int nloc = min(s_cnt, FAST_MAX_LOCAL);
+    const int nloc = min(s_cnt, NLOC);
     const uint8_t* mimg = maskPyr ? maskPyr + (size_t)b * pyrStride + g.imgOff : nullptr;
     auto passes = [&](uint32_t kp) -> bool {
         if (cell_has_ini && (int)(kp & 0xff) < P.iniTh) return false;
@@ -331,7 +356,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlan P, const uint8_t* __
         return true;
     };
     int npass = 0;
-    for (int i = threadIdx.x; i < nloc; i += 256) npass += passes(s_list[i]) ? 1 : 0;
+    for (int i = threadIdx.x; i < nloc; i += T) npass += passes(s_list[i]) ? 1 : 0;
     if (threadIdx.x == 0) { s_npass = 0; s_wr = 0; }
     __syncthreads();
     if (npass) atomicAdd(&s_npass, npass);
@@ -341,7 +366,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbPlan P, const uint8_t* __
     if (threadIdx.x == 0) s_base = atomicAdd(&candCount[b * MAXL + level], n);
     __syncthreads();
     uint32_t* out = cand + (size_t)b * P.totalKeyCap + g.keyOff;
-    for (int i = threadIdx.x; i < nloc; i += 256) {
+    for (int i = threadIdx.x; i < nloc; i += T) {
         const uint32_t kp = s_list[i];
         if (!passes(kp)) continue;
         const int dst = s_base + atomicAdd(&s_wr, 1);
@@ -1130,7 +1155,17 @@ void launch_blur(const BlurArgs& a, int batch, hipStream_t s) {
 
 void launch_fast(const OrbPlan& P, const uint8_t* pyr, size_t pyrStride, const uint8_t* maskPyr, uint32_t* cand,
                  int32_t* candCount, int batch, hipStream_t s) {
-    hipLaunchKernelGGL(k_fast_cells, dim3(P.ncells, batch), dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount);
+    int cw = 0;
+    for (int l = 0; l < P.nlevels; l++) cw = max(cw, max(P.lv[l].wCell, P.lv[l].hCell));
+    static const char* env = getenv("MYSLAM_FAST_T");           // tuning aid: threads per cell (64 | 256)
+    const int T = env ? atoi(env) : 256;
+    if (cw <= 40) {
+        if (T == 64) hipLaunchKernelGGL((k_fast_cells<64, 40>), dim3(P.ncells, batch), dim3(64), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount);
+        else hipLaunchKernelGGL((k_fast_cells<256, 40>), dim3(P.ncells, batch), dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount);
+    } else {
+        if (T == 64) hipLaunchKernelGGL((k_fast_cells<64, MAX_CELL>), dim3(P.ncells, batch), dim3(64), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount);
+        else hipLaunchKernelGGL((k_fast_cells<256, MAX_CELL>), dim3(P.ncells, batch), dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount);
+    }
 }
 
 size_t octree_lds_bytes(int nodeCap) { return 64 + 4 * (size_t)OT_MAXB + 2 * (size_t)(OT_MAXB + 2) + (size_t)nodeCap * 40 + 16; }
