@@ -374,6 +374,179 @@ __global__ __launch_bounds__(T) void k_fast_cells(OrbPlan P, const uint8_t* __re
     }
 }
 
+// ---- register-tile variant -------------------------------------------------------------------------
+// Each lane owns 4 horizontally adjacent pixels: it pulls the 7 x 16-byte window they share out of LDS with
+// dword reads (3.5 LDS instructions per pixel instead of 17 byte reads), shifts it into place with
+// v_alignbyte, and builds the packed (d[j], d[j+8]) operands of the score tree straight from registers with
+// v_perm_b32 (compile-time byte selectors).  NMS works the same way on the score tile.
+template <int C>
+__device__ __forceinline__ int fast9_score_regs(const uint32_t (&r)[7][3], int minTh) {
+    constexpr int RX[16] = FAST_RING_X;
+    constexpr int RY[16] = FAST_RING_Y;
+    constexpr int xc = 3 + C;
+    const uint32_t cw = r[3][xc >> 2];
+    const uint32_t vv_u = __builtin_amdgcn_perm(cw, cw, 0x0c000c00u | ((4u + (xc & 3)) << 16) | (uint32_t)(xc & 3));
+    s16x2 vv; __builtin_memcpy(&vv, &vv_u, 4);
+    s16x2 P[8], Ps[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int xa = xc + RX[j], ya = 3 + RY[j], xb = xc + RX[j + 8], yb = 3 + RY[j + 8];
+        const uint32_t qu = __builtin_amdgcn_perm(r[yb][xb >> 2], r[ya][xa >> 2],
+                                                  0x0c000c00u | ((4u + (uint32_t)(xb & 3)) << 16) | (uint32_t)(xa & 3));
+        s16x2 q; __builtin_memcpy(&q, &qu, 4);
+        P[j] = vv - q;                       // (d[j], d[j+8])
+        Ps[j] = hswap(P[j]);
+    }
+    s16x2 A[8], B[8], Cn[8], Am[8], Bm[8], Cm[8];
+#pragma unroll
+    for (int j = 0; j < 7; j++) { A[j] = pmin(P[j], P[j + 1]); Am[j] = pmax(P[j], P[j + 1]); }
+    A[7] = pmin(P[7], Ps[0]); Am[7] = pmax(P[7], Ps[0]);
+#pragma unroll
+    for (int j = 0; j < 6; j++) { B[j] = pmin(A[j], A[j + 2]); Bm[j] = pmax(Am[j], Am[j + 2]); }
+    B[6] = pmin(A[6], hswap(A[0])); B[7] = pmin(A[7], hswap(A[1]));
+    Bm[6] = pmax(Am[6], hswap(Am[0])); Bm[7] = pmax(Am[7], hswap(Am[1]));
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        Cn[j] = pmin(B[j], B[j + 4]); Cm[j] = pmax(Bm[j], Bm[j + 4]);
+        Cn[j + 4] = pmin(B[j + 4], hswap(B[j])); Cm[j + 4] = pmax(Bm[j + 4], hswap(Bm[j]));
+    }
+    s16x2 dark = {-1000, -1000}, brt = {1000, 1000};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        dark = pmax(dark, pmin(Cn[j], Ps[j]));
+        brt = pmin(brt, pmax(Cm[j], Ps[j]));
+    }
+    const int s = max(max((int)dark.x, (int)dark.y), -min((int)brt.x, (int)brt.y)) - 1;
+    return s >= minTh ? s : 0;
+}
+
+template <int C>
+__device__ __forceinline__ bool nms_regs(const uint32_t (&m)[3][3], int& s_out) {
+    auto by = [&](int row, int x) -> int { return (int)((m[row][x >> 2] >> (8 * (x & 3))) & 0xff); };
+    constexpr int x = 4 + C;
+    const int s = by(1, x);
+    s_out = s;
+    if (!s) return false;
+    return s > by(0, x - 1) && s > by(0, x) && s > by(0, x + 1) && s > by(1, x - 1) && s > by(1, x + 1) &&
+           s > by(2, x - 1) && s > by(2, x) && s > by(2, x + 1);
+}
+
+template <int T, int CW>
+__global__ __launch_bounds__(T) void k_fast_cells_v3(OrbPlan P, const uint8_t* __restrict__ pyr, size_t pyrStride,
+                                                     const uint8_t* __restrict__ maskPyr,
+                                                     uint32_t* __restrict__ cand, int32_t* __restrict__ candCount) {
+    constexpr int TP = (CW + 18) & ~3;            // ROI tile pitch: lanes read 16 bytes from column 4*gi <= CW-1
+    constexpr int TROWS = CW + 6;
+    constexpr int SP = (CW + 4 + 8 + 3) & ~3;     // score tile: interior starts at column 4 (dword aligned), row 1
+    constexpr int SROWS = CW + 2;
+    constexpr int NLOC = ((CW + 1) / 2) * ((CW + 1) / 2);
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[TROWS * TP + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t s_score[SROWS * SP + 16];
+    __shared__ uint32_t s_list[NLOC];
+    __shared__ int s_cnt, s_base, s_npass, s_wr;
+
+    const int b = blockIdx.y;
+    int level = 0;
+    for (int l = 1; l < P.nlevels; l++) if ((int)blockIdx.x >= P.lv[l].cellBase) level = l;
+    const LevelGeom& g = P.lv[level];
+    const int cell = blockIdx.x - g.cellBase;
+    const int ci = cell / g.nCols, cj = cell - ci * g.nCols;
+    const int iniY = MIN_BORDER + ci * g.hCell, iniX = MIN_BORDER + cj * g.wCell;
+    if (iniY >= g.maxBY - 3 || iniX >= g.maxBX - 6) return;            // :843, :852
+    const int maxY = min(iniY + g.hCell + 6, g.maxBY), maxX = min(iniX + g.wCell + 6, g.maxBX);
+    const int wr = maxX - iniX, hr = maxY - iniY;                      // ROI
+    const int wc = wr - 6, hc = hr - 6;                                // detection interior
+    if (wc <= 0 || hc <= 0) return;
+
+    const uint8_t* img = pyr + (size_t)b * pyrStride + g.imgOff;
+    const int x0a = iniX & ~3, off = iniX - x0a;
+    const int ndw = (off + wr + 3) >> 2;
+    for (int r = threadIdx.x / 32; r < hr; r += T / 32) {             // ndw <= 18 dwords per ROI row
+        const int k = threadIdx.x & 31;
+        if (k < ndw) {
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(img + (size_t)(iniY + r) * g.pitch + x0a + 4 * k);
+            *reinterpret_cast<uint32_t*>(&s_tile[r * TP + 4 * k]) = v;
+        }
+    }
+    for (int i = threadIdx.x; i < (SROWS * SP) / 4; i += T) reinterpret_cast<uint32_t*>(s_score)[i] = 0;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+
+    const int ngr = (wc + 3) >> 2, ngroups = ngr * hc;
+    // scores: 4 pixels per lane from a 7 x 12-byte register window
+    for (int q = threadIdx.x; q < ngroups; q += T) {
+        const int cy = q / ngr, gi = q - cy * ngr;
+        uint32_t r[7][3];
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const uint32_t* rp = reinterpret_cast<const uint32_t*>(&s_tile[(cy + j) * TP + 4 * gi]);
+            const uint32_t w0 = rp[0], w1 = rp[1], w2 = rp[2], w3 = rp[3];
+            r[j][0] = __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)off);
+            r[j][1] = __builtin_amdgcn_alignbyte(w2, w1, (uint32_t)off);
+            r[j][2] = __builtin_amdgcn_alignbyte(w3, w2, (uint32_t)off);
+        }
+        const int cx = 4 * gi;
+        uint32_t s0 = fast9_score_regs<0>(r, P.minTh), s1 = fast9_score_regs<1>(r, P.minTh);
+        uint32_t s2 = fast9_score_regs<2>(r, P.minTh), s3 = fast9_score_regs<3>(r, P.minTh);
+        if (cx + 1 >= wc) s1 = 0;
+        if (cx + 2 >= wc) s2 = 0;
+        if (cx + 3 >= wc) s3 = 0;
+        *reinterpret_cast<uint32_t*>(&s_score[(cy + 1) * SP + 4 + cx]) = s0 | (s1 << 8) | (s2 << 16) | (s3 << 24);
+    }
+    __syncthreads();
+
+    // NMS (strict > all 8 neighbours, zeros outside the cell interior)
+    int any_ini = 0;
+    for (int q = threadIdx.x; q < ngroups; q += T) {
+        const int cy = q / ngr, gi = q - cy * ngr;
+        uint32_t m[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const uint32_t* rp = reinterpret_cast<const uint32_t*>(&s_score[(cy + j) * SP + 4 * gi]);
+            m[j][0] = rp[0]; m[j][1] = rp[1]; m[j][2] = rp[2];
+        }
+        int sc[4]; bool mx[4];
+        mx[0] = nms_regs<0>(m, sc[0]); mx[1] = nms_regs<1>(m, sc[1]); mx[2] = nms_regs<2>(m, sc[2]); mx[3] = nms_regs<3>(m, sc[3]);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (mx[c]) {
+                const int px = 4 * gi + c + 3 + cj * g.wCell, py = cy + 3 + ci * g.hCell;     // border-relative
+                const int pos = atomicAdd(&s_cnt, 1);
+                if (pos < NLOC) s_list[pos] = ((uint32_t)py << 20) | ((uint32_t)px << 8) | (uint32_t)sc[c];
+                any_ini |= (sc[c] >= P.iniTh);
+            }
+        }
+    }
+    const int cell_has_ini = __syncthreads_or(any_ini);
+    const int nloc = min(s_cnt, NLOC);
+    const uint8_t* mimg = maskPyr ? maskPyr + (size_t)b * pyrStride + g.imgOff : nullptr;
+    auto passes = [&](uint32_t kp) -> bool {
+        if (cell_has_ini && (int)(kp & 0xff) < P.iniTh) return false;
+        if (mimg) {                                                                   // :873-877 (no +16: reference quirk)
+            const int px = (kp >> 8) & 0xfff, py = kp >> 20;
+            if (mimg[(size_t)py * g.pitch + px] == 0) return false;
+        }
+        return true;
+    };
+    int npass = 0;
+    for (int i = threadIdx.x; i < nloc; i += T) npass += passes(s_list[i]) ? 1 : 0;
+    if (threadIdx.x == 0) { s_npass = 0; s_wr = 0; }
+    __syncthreads();
+    if (npass) atomicAdd(&s_npass, npass);
+    __syncthreads();
+    const int n = s_npass;
+    if (n == 0) return;
+    if (threadIdx.x == 0) s_base = atomicAdd(&candCount[b * MAXL + level], n);
+    __syncthreads();
+    uint32_t* out = cand + (size_t)b * P.totalKeyCap + g.keyOff;
+    for (int i = threadIdx.x; i < nloc; i += T) {
+        const uint32_t kp = s_list[i];
+        if (!passes(kp)) continue;
+        const int dst = s_base + atomicAdd(&s_wr, 1);
+        if (dst < g.keyCap) out[dst] = kp;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K4: oct-tree keypoint distribution, one 256-thread block per (level, image), all levels in one launch.
 //
@@ -1159,6 +1332,13 @@ void launch_fast(const OrbPlan& P, const uint8_t* pyr, size_t pyrStride, const u
     for (int l = 0; l < P.nlevels; l++) cw = max(cw, max(P.lv[l].wCell, P.lv[l].hCell));
     static const char* env = getenv("MYSLAM_FAST_T");           // tuning aid: threads per cell (64 | 256)
     const int T = env ? atoi(env) : 256;
+    static const char* envv = getenv("MYSLAM_FAST_V");          // tuning aid: 2 = LDS byte-read two-phase kernel, 3 = register tiles
+    const int V = envv ? atoi(envv) : 3;
+    if (V == 3) {
+        if (cw <= 40) hipLaunchKernelGGL((k_fast_cells_v3<256, 40>), dim3(P.ncells, batch), dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount);
+        else hipLaunchKernelGGL((k_fast_cells_v3<256, MAX_CELL>), dim3(P.ncells, batch), dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount);
+        return;
+    }
     if (cw <= 40) {
         if (T == 64) hipLaunchKernelGGL((k_fast_cells<64, 40>), dim3(P.ncells, batch), dim3(64), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount);
         else hipLaunchKernelGGL((k_fast_cells<256, 40>), dim3(P.ncells, batch), dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount);
