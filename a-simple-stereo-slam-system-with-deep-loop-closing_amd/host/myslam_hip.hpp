@@ -1,0 +1,201 @@
+// myslam_hip.hpp — C++ facade over the C ABI (include/myslam_hip.h) with the reference's own class and method
+// names, so that Frontend / LoopClosing / Backend code of libmyslam.so keeps compiling against it:
+//
+//   myslam::ORBextractor   include/myslam/ORBextractor.h:52-110   (Detect, DetectAndCompute,
+//                                                                  ScreenAndComputeKPsParams, CalcDescriptors, getters)
+//   myslam::DeepLCD        include/myslam/deeplcd.h:21-48          (calcDescrOriginalImg, calcDescr, score, DescrVector)
+//   myslam::BFMatcherHamming::match                                 (cv::BFMatcher use at src/loopclosing.cpp:33,172)
+//   myslam::triangulation  include/myslam/algorithm.h:16-33        (stereo rig form)
+//   myslam::LoopDatabase   LoopClosing::DetectLoop / AddToDatabase  src/loopclosing.cpp:124-161, 651-659
+//   myslam::LocalBA::Build per-edge work of Backend::OptimizeActiveMap  src/backend.cpp:126-232
+//
+// No OpenCV / Eigen / g2o: images are (data, rows, cols, step) views, cv::KeyPoint is the layout-compatible
+// myslam_keypoint, DescrVector is std::array<float,1064>.  Errors the reference reports by logging + return keep
+// that behaviour (empty inputs are no-ops); everything else throws std::runtime_error.  There is no CPU fallback.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/myslam_hip.h"
+
+namespace myslam {
+
+struct ImageView {            // cv::Mat CV_8UC1 stand-in
+    uint8_t* data = nullptr;
+    int rows = 0, cols = 0, step = 0;
+    bool empty() const { return !data || rows <= 0 || cols <= 0; }
+};
+using KeyPoint = myslam_keypoint;                       // cv::KeyPoint layout
+struct DMatch { int queryIdx, trainIdx, imgIdx; float distance; };
+using Descriptors = std::vector<uint8_t>;               // N x 32, row-major (cv::Mat CV_8UC1 N x 32)
+
+inline void check(int rc, const char* what) {
+    if (rc != MYSLAM_OK) throw std::runtime_error(std::string(what) + " failed with status " + std::to_string(rc));
+}
+
+class ORBextractor {
+   public:
+    ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
+        : nfeatures_(nfeatures), nlevels_(nlevels) {
+        check(myslam_orb_create(&h_, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST), "myslam_orb_create");
+        mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels); mnFeaturesPerLevel.resize(nlevels); umax.resize(16);
+        check(myslam_orb_get_tables(h_, mvScaleFactor.data(), mvInvScaleFactor.data(), mnFeaturesPerLevel.data(), umax.data()),
+              "myslam_orb_get_tables");
+        mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
+        for (int i = 0; i < nlevels; i++) { mvLevelSigma2[i] = mvScaleFactor[i] * mvScaleFactor[i]; mvInvLevelSigma2[i] = 1.0f / mvLevelSigma2[i]; }
+    }
+    ~ORBextractor() { if (h_) myslam_orb_destroy(h_); }
+    ORBextractor(const ORBextractor&) = delete;
+    ORBextractor& operator=(const ORBextractor&) = delete;
+
+    // ORBextractor.h:61-63
+    void DetectAndCompute(const ImageView& image, const ImageView& mask, std::vector<KeyPoint>& keypoints, Descriptors& descriptors) {
+        keypoints.clear(); descriptors.clear();
+        if (image.empty()) return;                                               // ORBextractor.cpp:924
+        const int cap = myslam_orb_max_keypoints(h_);
+        keypoints.resize(cap); descriptors.resize((size_t)cap * 32);
+        int n = 0;
+        check(myslam_orb_detect_and_compute(h_, image.data, image.rows, image.cols, image.step, mask.empty() ? nullptr : mask.data,
+                                            mask.step, keypoints.data(), descriptors.data(), cap, &n), "myslam_orb_detect_and_compute");
+        keypoints.resize(n); descriptors.resize((size_t)n * 32);
+    }
+    // ORBextractor.h:70-71
+    void Detect(const ImageView& image, const ImageView& mask, std::vector<KeyPoint>& keypoints) {
+        keypoints.clear();
+        if (image.empty()) return;                                               // ORBextractor.cpp:990
+        const int cap = myslam_orb_max_keypoints(h_);
+        keypoints.resize(cap);
+        int n = 0;
+        check(myslam_orb_detect(h_, image.data, image.rows, image.cols, image.step, mask.empty() ? nullptr : mask.data, mask.step,
+                                keypoints.data(), cap, &n), "myslam_orb_detect");
+        keypoints.resize(n);
+    }
+    // ORBextractor.h:83-84 (keypoints is updated in place exactly as the reference's loop does)
+    void ScreenAndComputeKPsParams(const ImageView& image, std::vector<KeyPoint>& keypoints, std::vector<KeyPoint>& out_keypoints) {
+        out_keypoints.clear();
+        if (image.empty() || keypoints.empty()) return;                          // ORBextractor.cpp:1085-1088
+        out_keypoints.resize(keypoints.size());
+        int n = 0;
+        check(myslam_orb_screen_and_compute_params(h_, image.data, image.rows, image.cols, image.step, keypoints.data(),
+                                                   (int)keypoints.size(), out_keypoints.data(), (int)out_keypoints.size(), &n),
+              "myslam_orb_screen_and_compute_params");
+        out_keypoints.resize(n);
+    }
+    // ORBextractor.h:65-67
+    void CalcDescriptors(const ImageView& image, const std::vector<KeyPoint>& keypoints, Descriptors& descriptors) {
+        descriptors.clear();
+        if (image.empty() || keypoints.empty()) return;                          // ORBextractor.cpp:1183-1186
+        descriptors.resize(keypoints.size() * 32);
+        check(myslam_orb_calc_descriptors(h_, image.data, image.rows, image.cols, image.step, keypoints.data(), (int)keypoints.size(),
+                                          descriptors.data()), "myslam_orb_calc_descriptors");
+    }
+    // getters, ORBextractor.h:87-107
+    int GetLevels() const { return nlevels_; }
+    float GetScaleFactor() const { return mvScaleFactor.size() > 1 ? mvScaleFactor[1] : 1.f; }
+    const std::vector<float>& GetScaleFactors() const { return mvScaleFactor; }
+    const std::vector<float>& GetInverseScaleFactors() const { return mvInvScaleFactor; }
+    const std::vector<float>& GetScaleSigmaSquares() const { return mvLevelSigma2; }
+    const std::vector<float>& GetInverseScaleSigmaSquares() const { return mvInvLevelSigma2; }
+    myslam_orb* handle() { return h_; }
+
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+    std::vector<int> mnFeaturesPerLevel, umax;
+
+   private:
+    myslam_orb* h_ = nullptr;
+    int nfeatures_, nlevels_;
+};
+
+class DeepLCD {
+   public:
+    using DescrVector = std::array<float, MYSLAM_LCD_DIM>;     // Eigen::Matrix<float,1064,1>, deeplcd.h:25
+    // the Caffe prototxt + caffemodel pair becomes one flat weight file
+    explicit DeepLCD(const std::string& weights_file) { check(myslam_lcd_create_from_file(&h_, weights_file.c_str()), "myslam_lcd_create_from_file"); }
+    DeepLCD(const float* weights, size_t n) { check(myslam_lcd_create(&h_, weights, n), "myslam_lcd_create"); }
+    ~DeepLCD() { if (h_) myslam_lcd_destroy(h_); }
+    DeepLCD(const DeepLCD&) = delete;
+    DeepLCD& operator=(const DeepLCD&) = delete;
+    float score(const DescrVector& d1, const DescrVector& d2) const { return myslam_lcd_score(d1.data(), d2.data()); }   // deeplcd.cpp:35-39
+    // deeplcd.cpp:43-52 — blurs originalImg in place, like the reference
+    DescrVector calcDescrOriginalImg(const ImageView& originalImg) {
+        DescrVector d;
+        check(myslam_lcd_calc_descr_original_img(h_, originalImg.data, originalImg.rows, originalImg.cols, originalImg.step, 1, d.data()),
+              "myslam_lcd_calc_descr_original_img");
+        return d;
+    }
+    DescrVector calcDescr(const ImageView& im160x120) {            // deeplcd.cpp:55-91
+        DescrVector d;
+        check(myslam_lcd_calc_descr(h_, im160x120.data, im160x120.step, d.data()), "myslam_lcd_calc_descr");
+        return d;
+    }
+
+   private:
+    myslam_lcd* h_ = nullptr;
+};
+
+struct BFMatcherHamming {      // cv::DescriptorMatcher::create("BruteForce-Hamming")->match(query, train, matches)
+    static void match(const Descriptors& query, const Descriptors& train, std::vector<DMatch>& matches) {
+        const int nq = (int)(query.size() / 32), nt = (int)(train.size() / 32);
+        std::vector<int32_t> idx(nq), dist(nq);
+        check(myslam_hamming_match(query.data(), nq, train.data(), nt, idx.data(), dist.data()), "myslam_hamming_match");
+        matches.resize(nq);
+        for (int i = 0; i < nq; i++) matches[i] = DMatch{i, idx[i], 0, (float)dist[i]};
+    }
+};
+
+// triangulation() of algorithm.h:16-33 for the stereo rig (left ext = I, right ext t = (-baseline,0,0)); ok = success && z > 0
+inline void triangulation(const std::vector<float>& xl, const std::vector<float>& yl, const std::vector<float>& xr,
+                          const std::vector<float>& yr, double fx, double fy, double cx, double cy, double baseline,
+                          std::vector<std::array<double, 3>>& pts, std::vector<uint8_t>& ok) {
+    const int n = (int)xl.size();
+    pts.resize(n); ok.resize(n);
+    check(myslam_triangulate_stereo(xl.data(), yl.data(), xr.data(), yr.data(), n, fx, fy, cx, cy, baseline,
+                                    reinterpret_cast<double*>(pts.data()), ok.data()), "myslam_triangulate_stereo");
+}
+
+class LoopDatabase {           // LoopClosing::_mvDatabase + DetectLoop + AddToDatabase
+   public:
+    explicit LoopDatabase(int capacity, float thresHigh = 0.94f, float thresLow = 0.92f) : th1_(thresHigh), th2_(thresLow) {
+        check(myslam_lcddb_create(&h_, capacity), "myslam_lcddb_create");
+    }
+    ~LoopDatabase() { if (h_) myslam_lcddb_destroy(h_); }
+    LoopDatabase(const LoopDatabase&) = delete;
+    LoopDatabase& operator=(const LoopDatabase&) = delete;
+    void AddToDatabase(unsigned long kfId, const DeepLCD::DescrVector& d) { check(myslam_lcddb_append(h_, kfId, d.data()), "myslam_lcddb_append"); }
+    size_t size() const { return (size_t)myslam_lcddb_size(h_); }
+    // loopclosing.cpp:124-161: true + loop KF id when maxScore >= high threshold and at most 3 scores exceed the low one
+    bool DetectLoop(unsigned long curKFId, const DeepLCD::DescrVector& d, unsigned long& loopKFId, float* maxScore = nullptr) {
+        uint64_t best = 0; float mx = 0; int cnt = 0;
+        check(myslam_lcddb_query(h_, d.data(), curKFId, th2_, &best, &mx, &cnt), "myslam_lcddb_query");
+        if (maxScore) *maxScore = mx;
+        if (mx < th1_ || cnt > 3) return false;
+        loopKFId = best;
+        return true;
+    }
+
+   private:
+    myslam_lcddb* h_ = nullptr;
+    float th1_, th2_;
+};
+
+struct LocalBA {               // flat-array form of the graph Backend::OptimizeActiveMap builds (backend.cpp:139-206)
+    std::vector<double> poses, points, obs;          // nposes x 7 (qx qy qz qw tx ty tz = KeyFrame::Pose()), npts x 3, nedges x 2
+    std::vector<int32_t> edge_pose, edge_pt;
+    std::vector<uint8_t> fixed;                      // setFixed rule of backend.cpp:175-177
+    double fx = 0, fy = 0, cx = 0, cy = 0, huber_delta = 5.991;   // backend.cpp:155,199
+    std::vector<double> Hpp, Hll, Hpl, bp, bl, chi2;
+    void Build() {
+        const int P = (int)(poses.size() / 7), L = (int)(points.size() / 3), E = (int)edge_pose.size();
+        Hpp.assign((size_t)P * 36, 0); Hll.assign((size_t)L * 9, 0); Hpl.assign((size_t)E * 18, 0);
+        bp.assign((size_t)P * 6, 0); bl.assign((size_t)L * 3, 0); chi2.assign(E, 0);
+        check(myslam_ba_build(poses.data(), P, points.data(), L, edge_pose.data(), edge_pt.data(), obs.data(), E,
+                              fixed.empty() ? nullptr : fixed.data(), fx, fy, cx, cy, huber_delta, Hpp.data(), Hll.data(), Hpl.data(),
+                              bp.data(), bl.data(), chi2.data()), "myslam_ba_build");
+    }
+};
+
+}  // namespace myslam
