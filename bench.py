@@ -37,16 +37,31 @@ ALGO_BYTES = {
 }
 
 
+def pmc_traffic(kernel, pairs):
+    """HBM bytes per launch of `kernel` from the committed PMC run (separate rocprofv3 --pmc passes, tools/gpu_traffic.sh)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    tag = {"fast_cells": "k_fast_cells", "octree": "k_octree", "blur7": "k_blur7", "resize": "k_resize", "describe": "k_describe"}.get(kernel)
+    for name, v in d["kernels"].items():
+        if tag and name.startswith(tag):
+            kb = v.get("FETCH_SIZE_KB_per_launch", 0) + v.get("WRITE_SIZE_KB_per_launch", 0)
+            return kb * 1024.0 * pairs / d["pairs_per_step"]
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=64, help="stereo pairs per step per GPU")
+    ap.add_argument("--pairs", type=int, default=256, help="stereo pairs per step per GPU")
     ap.add_argument("--workload", default="full", choices=["full", "orb_match", "orb_match_lcd"])
     ap.add_argument("--db", type=int, default=0, help="key-frame database size (default 10000, or 6250 per GPU when sharded)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=6)
+    ap.add_argument("--cpu-pairs", type=int, default=32)
     return ap.parse_args()
 
 
@@ -198,8 +213,9 @@ def main():
             algo = ALGO_BYTES[dom] * imgs_per_launch / launches_per_step        # bytes per launch
             achieved = algo / (per_launch_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": per_launch_ms,
-                    "algorithmic_bytes_per_launch": algo}
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, P), "avg_launch_ms": per_launch_ms,
+                    "algorithmic_bytes_per_launch": algo,
+                    "note": "integer-ALU bound in practice (~120 packed ops per pixel); traffic = FETCH_SIZE+WRITE_SIZE of a separate rocprofv3 --pmc run (profiles/), uncorrected"}
         else:
             roof = {"bound": "hbm", "kernel": dom, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                     "traffic": None, "avg_launch_ms": per_launch_ms}
