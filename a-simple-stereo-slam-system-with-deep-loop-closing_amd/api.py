@@ -342,3 +342,26 @@ def ba_build_batch(d_poses, d_points, d_ep, d_el, d_obs, d_fixed, d_sizes, nwin,
                                        C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]), C.c_double(delta),
                                        C.c_void_p(d_Hpp), C.c_void_p(d_Hll), C.c_void_p(d_Hpl), C.c_void_p(d_bp), C.c_void_p(d_bl),
                                        C.c_void_p(d_chi2), C.c_void_p(stream or None)), "myslam_ba_build_batch")
+
+
+def ba_optimize(poses, points, edge_pose, edge_pt, obs, fixed, K, delta=5.991, iters=10):
+    """optimizer.optimize(iters) of Backend::OptimizeActiveMap (backend.cpp:212-214) on the device: returns
+    (poses, points, robust chi2, iterations)."""
+    poses = np.ascontiguousarray(poses, np.float64).copy(); points = np.ascontiguousarray(points, np.float64).copy()
+    ep = np.ascontiguousarray(edge_pose, np.int32); el = np.ascontiguousarray(edge_pt, np.int32)
+    obs = np.ascontiguousarray(obs, np.float64)
+    fixed = np.ascontiguousarray(fixed, np.uint8) if fixed is not None else None
+    chi = C.c_double(); it = C.c_int()
+    _check(lib().myslam_ba_optimize(_p(poses), len(poses), _p(points), len(points), _p(ep), _p(el), _p(obs), len(ep), _p(fixed),
+                                    C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]), C.c_double(delta),
+                                    int(iters), C.byref(chi), C.byref(it)), "myslam_ba_optimize")
+    return poses, points, chi.value, it.value
+
+
+def ba_optimize_batch(d_poses, d_points, d_ep, d_el, d_obs, d_fixed, d_sizes, nwin, maxP, maxL, maxE, K, delta, iters,
+                      d_scratch, d_chi2, d_iters, d_status, stream=0):
+    _check(lib().myslam_ba_optimize_batch(C.c_void_p(d_poses), C.c_void_p(d_points), C.c_void_p(d_ep), C.c_void_p(d_el),
+                                          C.c_void_p(d_obs), C.c_void_p(d_fixed or None), C.c_void_p(d_sizes), nwin, maxP, maxL, maxE,
+                                          C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]), C.c_double(delta),
+                                          int(iters), C.c_void_p(d_scratch), C.c_void_p(d_chi2), C.c_void_p(d_iters),
+                                          C.c_void_p(d_status), C.c_void_p(stream or None)), "myslam_ba_optimize_batch")

@@ -123,6 +123,379 @@ __global__ __launch_bounds__(256) void k_ba_build(BaArgs a) {
     for (int i = t; i < L * 3; i += 256) a.bl[(size_t)w * a.maxL * 3 + i] = sbl[i];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Levenberg-Marquardt on device: what g2o's OptimizationAlgorithmLevenberg + BlockSolver_6_3 do for
+// optimizer.optimize(n) in Backend::OptimizeActiveMap (src/backend.cpp:212-214):
+// per iteration build H/b, then up to 10 trials of { (H + lambda I) x = b via Schur complement on the
+// landmarks, dense Cholesky of the reduced 6P x 6P system, back-substitution, oplus (SE3 left update,
+// g2o_types.h:32-37; additive points :50-54), gain ratio, lambda update }.  One block per window, the whole
+// state (poses, points, backups, Hpp/Hll/Hinv, the reduced system) lives in LDS; only the per-edge 6x3
+// blocks go through HBM scratch.  Edges must be grouped by landmark (as the reference builds them,
+// backend.cpp:161-205: for each map point, its observations).
+// ------------------------------------------------------------------------------------------------
+struct BaOptArgs {
+    double* poses; double* points; const int32_t* ep; const int32_t* el; const double* obs; const uint8_t* fixed;
+    const int32_t* sizes; int nposes, npts, nedges; int maxP, maxL, maxE;
+    double fx, fy, cx, cy, delta; int max_iters;
+    double* W;            // scratch: nwin x maxE x 18
+    double* final_chi2; int32_t* iters; int32_t* status;
+};
+
+__device__ __forceinline__ void ba_edge(const double* R, const double* pw, const double* z, double fx, double fy, double cx, double cy,
+                                        double& e0, double& e1, double* J, double* Jp) {
+    const double X = R[0] * pw[0] + R[1] * pw[1] + R[2] * pw[2] + R[9];
+    const double Y = R[3] * pw[0] + R[4] * pw[1] + R[5] * pw[2] + R[10];
+    const double Z = R[6] * pw[0] + R[7] * pw[1] + R[8] * pw[2] + R[11];
+    e0 = z[0] - (fx * X / Z + cx);
+    e1 = z[1] - (fy * Y / Z + cy);
+    if (!J) return;
+    const double Zinv = 1.0 / (Z + 1e-18), Zinv2 = Zinv * Zinv;
+    J[0] = -fx * Zinv; J[1] = 0; J[2] = fx * X * Zinv2; J[3] = fx * X * Y * Zinv2; J[4] = -fx - fx * X * X * Zinv2; J[5] = fx * Y * Zinv;
+    J[6] = 0; J[7] = -fy * Zinv; J[8] = fy * Y * Zinv2; J[9] = fy + fy * Y * Y * Zinv2; J[10] = -fy * X * Y * Zinv2; J[11] = -fy * X * Zinv;
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) Jp[r * 3 + c] = J[r * 6] * R[c] + J[r * 6 + 1] * R[3 + c] + J[r * 6 + 2] * R[6 + c];
+}
+
+__device__ __forceinline__ double block_sum(double v, double* s_red) {
+    v = wave_reduce_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+// Sophus SE3d::exp(d) * T, d = (upsilon, omega); R|t stored as 12 doubles
+__device__ void pose_oplus(double* T, const double* d) {
+    const double wx = d[3], wy = d[4], wz = d[5];
+    const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
+    double A, B, C;
+    if (th < 1e-8) { A = 1 - th2 / 6; B = 0.5 - th2 / 24; C = 1.0 / 6 - th2 / 120; }
+    else { A = sin(th) / th; B = (1 - cos(th)) / th2; C = (th - sin(th)) / (th2 * th); }
+    const double Wm[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double W2[9], Rd[9], V[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) W2[i * 3 + j] = Wm[i * 3] * Wm[j] + Wm[i * 3 + 1] * Wm[3 + j] + Wm[i * 3 + 2] * Wm[6 + j];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const double I = (i % 4 == 0) ? 1.0 : 0.0;
+        Rd[i] = I + A * Wm[i] + B * W2[i];
+        V[i] = I + B * Wm[i] + C * W2[i];
+    }
+    double td[3], N[12];
+#pragma unroll
+    for (int i = 0; i < 3; i++) td[i] = V[i * 3] * d[0] + V[i * 3 + 1] * d[1] + V[i * 3 + 2] * d[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) N[i * 3 + j] = Rd[i * 3] * T[j] + Rd[i * 3 + 1] * T[3 + j] + Rd[i * 3 + 2] * T[6 + j];
+        N[9 + i] = Rd[i * 3] * T[9] + Rd[i * 3 + 1] * T[10] + Rd[i * 3 + 2] * T[11] + td[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) T[i] = N[i];
+}
+
+__global__ __launch_bounds__(256) void k_ba_optimize(BaOptArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double s_d[];
+    __shared__ double s_red[4];
+    __shared__ double s_sc[8];      // [0] lambda [1] ni [2] curChi [3] tmpChi [4] rho [5] ok
+    const int w = blockIdx.x, t = threadIdx.x;
+    const int P = a.sizes ? a.sizes[3 * w] : a.nposes;
+    const int L = a.sizes ? a.sizes[3 * w + 1] : a.npts;
+    const int E = a.sizes ? a.sizes[3 * w + 2] : a.nedges;
+    const int n = 6 * P;
+    double* sR = s_d;                         // maxP x 12
+    double* sRb = sR + a.maxP * 12;
+    double* sHpp = sRb + a.maxP * 12;         // maxP x 21
+    double* sbp = sHpp + a.maxP * 21;         // maxP x 6
+    double* sPt = sbp + a.maxP * 6;           // maxL x 3
+    double* sPtb = sPt + a.maxL * 3;
+    double* sHll = sPtb + a.maxL * 3;         // maxL x 6
+    double* sbl = sHll + a.maxL * 6;          // maxL x 3
+    double* sHinv = sbl + a.maxL * 3;         // maxL x 6
+    double* sxl = sHinv + a.maxL * 6;         // maxL x 3
+    double* sS = sxl + a.maxL * 3;            // (6 maxP)^2
+    double* srhs = sS + 36 * a.maxP * a.maxP; // 6 maxP
+    int* lbeg = reinterpret_cast<int*>(srhs + 6 * a.maxP);   // maxL
+    int* lend = lbeg + a.maxL;
+    int* s_bad = lend + a.maxL;
+    double* poses = a.poses + (size_t)w * a.maxP * 7;
+    double* pts = a.points + (size_t)w * a.maxL * 3;
+    const int32_t* ep = a.ep + (size_t)w * a.maxE;
+    const int32_t* el = a.el + (size_t)w * a.maxE;
+    const double* obs = a.obs + (size_t)w * a.maxE * 2;
+    const uint8_t* fixed = a.fixed ? a.fixed + (size_t)w * a.maxL : nullptr;
+    double* Wk = a.W + (size_t)w * a.maxE * 18;
+
+    // ---- load state, landmark -> edge range ----
+    for (int p = t; p < P; p += 256) {
+        double x = poses[7 * p], y = poses[7 * p + 1], z = poses[7 * p + 2], q = poses[7 * p + 3];
+        const double nn = sqrt(x * x + y * y + z * z + q * q);
+        x /= nn; y /= nn; z /= nn; q /= nn;
+        double* R = sR + 12 * p;
+        R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * q);     R[2] = 2 * (x * z + y * q);
+        R[3] = 2 * (x * y + z * q);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * q);
+        R[6] = 2 * (x * z - y * q);     R[7] = 2 * (y * z + x * q);     R[8] = 1 - 2 * (x * x + y * y);
+        R[9] = poses[7 * p + 4]; R[10] = poses[7 * p + 5]; R[11] = poses[7 * p + 6];
+    }
+    for (int i = t; i < 3 * L; i += 256) sPt[i] = pts[i];
+    for (int l = t; l < L; l += 256) { lbeg[l] = 0; lend[l] = 0; }
+    if (t == 0) *s_bad = 0;
+    __syncthreads();
+    for (int k = t; k < E; k += 256) {
+        const int l = el[k], p = ep[k];
+        if (l < 0 || l >= L || p < 0 || p >= P) { atomicAdd(s_bad, 1); continue; }
+        if (k == 0 || el[k - 1] != l) { lbeg[l] = k; atomicAdd(&lend[l], 1); }      // first edge of a group
+    }
+    __syncthreads();
+    // lend[l] now counts the groups of landmark l: more than one group = edges not grouped by landmark
+    for (int l = t; l < L; l += 256) if (lend[l] > 1) atomicAdd(s_bad, 1);
+    __syncthreads();
+    if (*s_bad) { if (t == 0) { a.status[w] = MYSLAM_ERR_INVALID; a.iters[w] = 0; a.final_chi2[w] = 0; } return; }
+    for (int l = t; l < L; l += 256) {
+        if (lend[l] == 0) { lbeg[l] = 0; continue; }
+        int k = lbeg[l];
+        while (k < E && el[k] == l) k++;
+        lend[l] = k;
+    }
+    __syncthreads();
+
+    auto robust_chi2 = [&]() -> double {          // activeRobustChi2()
+        double acc = 0;
+        for (int k = t; k < E; k += 256) {
+            double e0, e1;
+            ba_edge(sR + 12 * ep[k], sPt + 3 * el[k], obs + 2 * k, a.fx, a.fy, a.cx, a.cy, e0, e1, nullptr, nullptr);
+            const double e2 = e0 * e0 + e1 * e1, d2 = a.delta * a.delta;
+            acc += (e2 <= d2) ? e2 : 2 * sqrt(e2) * a.delta - d2;
+        }
+        return block_sum(acc, s_red);
+    };
+
+    int it = 0;
+    for (; it < a.max_iters; it++) {
+        // ---- build H, b at the current estimate ----
+        for (int i = t; i < a.maxP * 27; i += 256) sHpp[i] = 0.0;     // sHpp (maxP x 21) and sbp (maxP x 6) are contiguous
+        for (int i = t; i < a.maxL * 9; i += 256) sHll[i] = 0.0;      // sHll (maxL x 6) and sbl (maxL x 3) are contiguous
+        __syncthreads();
+        double acc = 0;
+        for (int k = t; k < E; k += 256) {
+            const int ip = ep[k], il = el[k];
+            double e0, e1, J[12], Jp[6];
+            ba_edge(sR + 12 * ip, sPt + 3 * il, obs + 2 * k, a.fx, a.fy, a.cx, a.cy, e0, e1, J, Jp);
+            const double e2 = e0 * e0 + e1 * e1, d2 = a.delta * a.delta;
+            const double wgt = (e2 <= d2) ? 1.0 : a.delta / sqrt(e2);
+            acc += (e2 <= d2) ? e2 : 2 * sqrt(e2) * a.delta - d2;
+            double* hp = sHpp + 21 * ip;
+            int u = 0;
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+#pragma unroll
+                for (int c = r; c < 6; c++) atomicAdd(&hp[u++], wgt * (J[r] * J[c] + J[6 + r] * J[6 + c]));
+                atomicAdd(&sbp[6 * ip + r], -wgt * (J[r] * e0 + J[6 + r] * e1));
+            }
+            const bool fx_pt = fixed && fixed[il];
+            if (!fx_pt) {
+                double* hl = sHll + 6 * il;
+                int v = 0;
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+#pragma unroll
+                    for (int c = r; c < 3; c++) atomicAdd(&hl[v++], wgt * (Jp[r] * Jp[c] + Jp[3 + r] * Jp[3 + c]));
+                    atomicAdd(&sbl[3 * il + r], -wgt * (Jp[r] * e0 + Jp[3 + r] * e1));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) Wk[(size_t)k * 18 + r * 3 + c] = fx_pt ? 0.0 : wgt * (J[r] * Jp[c] + J[6 + r] * Jp[3 + c]);
+        }
+        const double curChi0 = block_sum(acc, s_red);
+        if (it == 0) {                               // computeLambdaInit: tau * max |diag(H)|
+            double mx = 0;
+            for (int i = t; i < P * 6; i += 256) { const int p = i / 6, r = i % 6; mx = fmax(mx, fabs(sHpp[21 * p + r * 6 - r * (r - 1) / 2])); }
+            for (int i = t; i < L * 3; i += 256) { const int l = i / 3, r = i % 3; if (!(fixed && fixed[l])) mx = fmax(mx, fabs(sHll[6 * l + r * 3 - r * (r - 1) / 2])); }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+            __syncthreads();
+            if ((t & 63) == 0) s_red[t >> 6] = mx;
+            __syncthreads();
+            if (t == 0) { s_sc[0] = 1e-5 * fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3])); s_sc[1] = 2.0; }
+        }
+        if (t == 0) s_sc[2] = curChi0;
+        __syncthreads();
+
+        int qmax = 0;
+        double rho = 0;
+        do {
+            const double lambda = s_sc[0];
+            // backup (optimizer->push())
+            for (int i = t; i < P * 12; i += 256) sRb[i] = sR[i];
+            for (int i = t; i < L * 3; i += 256) sPtb[i] = sPt[i];
+            // reduced system: S = Hpp + lambda I, rhs = bp
+            for (int i = t; i < n * n; i += 256) sS[i] = 0.0;
+            __syncthreads();
+            for (int i = t; i < P * 36; i += 256) {
+                const int p = i / 36, r = (i % 36) / 6, c = i % 6;
+                const int rr = min(r, c), cc = max(r, c);
+                sS[(6 * p + r) * n + 6 * p + c] = sHpp[21 * p + rr * 6 - rr * (rr - 1) / 2 + (cc - rr)] + (r == c ? lambda : 0.0);
+            }
+            for (int i = t; i < n; i += 256) srhs[i] = sbp[i];
+            if (t == 0) s_sc[5] = 1.0;
+            __syncthreads();
+            // landmarks: Hinv = (Hll + lambda I)^-1, Schur complement into S / rhs
+            for (int l = t; l < L; l += 256) {
+                const int kb = lbeg[l], ke = lend[l];
+                if ((fixed && fixed[l]) || ke <= kb) { for (int i = 0; i < 6; i++) sHinv[6 * l + i] = 0.0; continue; }
+                const double* h = sHll + 6 * l;
+                const double a00 = h[0] + lambda, a01 = h[1], a02 = h[2], a11 = h[3] + lambda, a12 = h[4], a22 = h[5] + lambda;
+                const double c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+                const double det = a00 * c00 + a01 * c01 + a02 * c02;
+                if (det == 0.0 || !isfinite(det)) { s_sc[5] = 0.0; continue; }
+                const double id = 1.0 / det;
+                const double Hi[9] = {c00 * id, c01 * id, c02 * id, c01 * id, (a00 * a22 - a02 * a02) * id, (a01 * a02 - a00 * a12) * id,
+                                      c02 * id, (a01 * a02 - a00 * a12) * id, (a00 * a11 - a01 * a01) * id};
+                sHinv[6 * l] = Hi[0]; sHinv[6 * l + 1] = Hi[1]; sHinv[6 * l + 2] = Hi[2]; sHinv[6 * l + 3] = Hi[4]; sHinv[6 * l + 4] = Hi[5]; sHinv[6 * l + 5] = Hi[8];
+                const double b0 = sbl[3 * l], b1 = sbl[3 * l + 1], b2 = sbl[3 * l + 2];
+                for (int k1 = kb; k1 < ke; k1++) {
+                    const double* W1 = Wk + (size_t)k1 * 18;
+                    double WH[18];
+#pragma unroll
+                    for (int r = 0; r < 6; r++)
+#pragma unroll
+                        for (int c = 0; c < 3; c++) WH[r * 3 + c] = W1[r * 3] * Hi[c] + W1[r * 3 + 1] * Hi[3 + c] + W1[r * 3 + 2] * Hi[6 + c];
+                    const int p1 = ep[k1];
+#pragma unroll
+                    for (int r = 0; r < 6; r++) atomicAdd(&srhs[6 * p1 + r], -(WH[r * 3] * b0 + WH[r * 3 + 1] * b1 + WH[r * 3 + 2] * b2));
+                    for (int k2 = kb; k2 < ke; k2++) {
+                        const double* W2 = Wk + (size_t)k2 * 18;
+                        const int p2 = ep[k2];
+#pragma unroll
+                        for (int r = 0; r < 6; r++)
+#pragma unroll
+                            for (int c = 0; c < 6; c++)
+                                atomicAdd(&sS[(6 * p1 + r) * n + 6 * p2 + c], -(WH[r * 3] * W2[c * 3] + WH[r * 3 + 1] * W2[c * 3 + 1] + WH[r * 3 + 2] * W2[c * 3 + 2]));
+                    }
+                }
+            }
+            __syncthreads();
+            // dense Cholesky of S (lower triangle), right-looking
+            for (int j = 0; j < n; j++) {
+                if (t == 0) {
+                    const double d = sS[j * n + j];
+                    if (!(d > 0.0)) { s_sc[5] = 0.0; sS[j * n + j] = 1.0; } else sS[j * n + j] = sqrt(d);
+                }
+                __syncthreads();
+                const double djj = sS[j * n + j];
+                for (int i = j + 1 + t; i < n; i += 256) sS[i * n + j] /= djj;
+                __syncthreads();
+                const int m = n - j - 1;
+                for (int idx = t; idx < m * m; idx += 256) {
+                    const int i = j + 1 + idx / m, k = j + 1 + idx % m;
+                    if (k <= i) sS[i * n + k] -= sS[i * n + j] * sS[k * n + j];
+                }
+                __syncthreads();
+            }
+            // forward / backward substitution by one wave (lane = row)
+            if (t < 64) {
+                double y = (t < n) ? srhs[t] : 0.0;
+                for (int j = 0; j < n; j++) {
+                    const double xj = __shfl(y, j, 64) / sS[j * n + j];
+                    if (t == j) y = xj; else if (t > j && t < n) y -= sS[t * n + j] * xj;
+                }
+                for (int j = n - 1; j >= 0; j--) {
+                    const double xj = __shfl(y, j, 64) / sS[j * n + j];
+                    if (t == j) y = xj; else if (t < j) y -= sS[j * n + t] * xj;
+                }
+                if (t < n) srhs[t] = y;               // xp
+            }
+            __syncthreads();
+            const bool ok = s_sc[5] != 0.0;
+            // xl = Hinv (bl - W^T xp); scale = x^T (lambda x + b)
+            double sc = 0;
+            for (int l = t; l < L; l += 256) {
+                const int kb = lbeg[l], ke = lend[l];
+                double r0 = sbl[3 * l], r1 = sbl[3 * l + 1], r2 = sbl[3 * l + 2];
+                const bool act = !((fixed && fixed[l]) || ke <= kb);
+                for (int k = kb; k < ke && act; k++) {
+                    const double* Wp = Wk + (size_t)k * 18;
+                    const double* xp = srhs + 6 * ep[k];
+#pragma unroll
+                    for (int r = 0; r < 6; r++) { r0 -= Wp[r * 3] * xp[r]; r1 -= Wp[r * 3 + 1] * xp[r]; r2 -= Wp[r * 3 + 2] * xp[r]; }
+                }
+                const double* Hi = sHinv + 6 * l;
+                const double x0 = act ? Hi[0] * r0 + Hi[1] * r1 + Hi[2] * r2 : 0.0;
+                const double x1 = act ? Hi[1] * r0 + Hi[3] * r1 + Hi[4] * r2 : 0.0;
+                const double x2 = act ? Hi[2] * r0 + Hi[4] * r1 + Hi[5] * r2 : 0.0;
+                sxl[3 * l] = x0; sxl[3 * l + 1] = x1; sxl[3 * l + 2] = x2;
+                if (act) sc += x0 * (lambda * x0 + sbl[3 * l]) + x1 * (lambda * x1 + sbl[3 * l + 1]) + x2 * (lambda * x2 + sbl[3 * l + 2]);
+            }
+            for (int i = t; i < n; i += 256) sc += srhs[i] * (lambda * srhs[i] + sbp[i]);
+            const double scale = block_sum(sc, s_red) + 1e-3;
+            // oplus
+            if (ok) {
+                for (int p = t; p < P; p += 256) pose_oplus(sR + 12 * p, srhs + 6 * p);
+                for (int i = t; i < 3 * L; i += 256) sPt[i] += sxl[i];
+            }
+            __syncthreads();
+            const double tmpChi = ok ? robust_chi2() : 1e300;
+            rho = (s_sc[2] - tmpChi) / scale;
+            __syncthreads();
+            if (rho > 0 && isfinite(tmpChi) && ok) {
+                if (t == 0) {
+                    double alpha = 1. - pow(2 * rho - 1, 3);
+                    alpha = fmin(alpha, 2. / 3.);
+                    s_sc[0] = lambda * fmax(1. / 3., alpha); s_sc[1] = 2.0; s_sc[2] = tmpChi;
+                }
+            } else {
+                if (t == 0) { s_sc[0] = lambda * s_sc[1]; s_sc[1] *= 2.0; }
+                for (int i = t; i < P * 12; i += 256) sR[i] = sRb[i];      // optimizer->pop()
+                for (int i = t; i < L * 3; i += 256) sPt[i] = sPtb[i];
+            }
+            __syncthreads();
+            qmax++;
+        } while (rho < 0 && qmax < 10 && isfinite(s_sc[0]));
+        if (qmax == 10 || rho == 0 || !isfinite(s_sc[0])) { it++; break; }
+    }
+    // ---- write back: R -> quaternion, points, final chi2 ----
+    const double fin = robust_chi2();
+    for (int p = t; p < P; p += 256) {
+        const double* R = sR + 12 * p;
+        const double tr = R[0] + R[4] + R[8];
+        double x, y, z, q;
+        if (tr > 0) { const double s = sqrt(tr + 1.0) * 2; q = 0.25 * s; x = (R[7] - R[5]) / s; y = (R[2] - R[6]) / s; z = (R[3] - R[1]) / s; }
+        else if (R[0] > R[4] && R[0] > R[8]) { const double s = sqrt(1.0 + R[0] - R[4] - R[8]) * 2; x = 0.25 * s; q = (R[7] - R[5]) / s; y = (R[1] + R[3]) / s; z = (R[2] + R[6]) / s; }
+        else if (R[4] > R[8]) { const double s = sqrt(1.0 + R[4] - R[0] - R[8]) * 2; y = 0.25 * s; q = (R[2] - R[6]) / s; x = (R[1] + R[3]) / s; z = (R[5] + R[7]) / s; }
+        else { const double s = sqrt(1.0 + R[8] - R[0] - R[4]) * 2; z = 0.25 * s; q = (R[3] - R[1]) / s; x = (R[2] + R[6]) / s; y = (R[5] + R[7]) / s; }
+        poses[7 * p] = x; poses[7 * p + 1] = y; poses[7 * p + 2] = z; poses[7 * p + 3] = q;
+        poses[7 * p + 4] = R[9]; poses[7 * p + 5] = R[10]; poses[7 * p + 6] = R[11];
+    }
+    for (int i = t; i < 3 * L; i += 256) pts[i] = sPt[i];
+    if (t == 0) { a.final_chi2[w] = fin; a.iters[w] = it; a.status[w] = MYSLAM_OK; }
+}
+
+static size_t ba_opt_lds(int maxP, int maxL) {
+    return sizeof(double) * ((size_t)maxP * (12 + 12 + 21 + 6) + (size_t)maxL * (3 + 3 + 6 + 3 + 6 + 3) + 36 * (size_t)maxP * maxP + 6 * (size_t)maxP) +
+           sizeof(int) * (2 * (size_t)maxL + 4);
+}
+
+static int ba_opt_launch(const BaOptArgs& a, int nwin, hipStream_t s) {
+    if (a.maxP > 10) return MYSLAM_ERR_CAPACITY;          // substitution runs on one wave: 6P <= 64
+    const size_t lds = ba_opt_lds(a.maxP, a.maxL);
+    if (lds > 160 * 1024 - 256) return MYSLAM_ERR_CAPACITY;
+    static size_t attr = 0;
+    if (lds > 48 * 1024 && lds > attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_optimize), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = lds;
+    }
+    ScopedProf sp(P_BA, s);
+    hipLaunchKernelGGL(k_ba_optimize, dim3(nwin), dim3(256), lds, s, a);
+    MYSLAM_HIP_CHECK(hipGetLastError());
+    return MYSLAM_OK;
+}
+
 static size_t ba_lds(int maxP, int maxL) { return sizeof(double) * ((size_t)maxP * 39 + (size_t)maxL * 9); }
 
 static int ba_launch(const BaArgs& a, int nwin, hipStream_t s) {
@@ -198,6 +571,50 @@ int myslam_ba_build(const double* poses, int nposes, const double* points, int n
     }
     (void)hipFree(d); (void)hipFree(di); (void)hipFree(df);
     return MYSLAM_OK;
+}
+
+int myslam_ba_optimize_batch(double* d_poses, double* d_points, const int32_t* d_edge_pose, const int32_t* d_edge_pt, const double* d_obs,
+                             const uint8_t* d_fixed, const int32_t* d_sizes, int nwin, int max_poses, int max_pts, int max_edges,
+                             double fx, double fy, double cx, double cy, double huber_delta, int max_iters, double* d_scratch,
+                             double* d_final_chi2, int32_t* d_iters, int32_t* d_status, void* hip_stream) {
+    if (!d_poses || !d_points || !d_edge_pose || !d_edge_pt || !d_obs || !d_sizes || nwin < 1 || max_poses < 1 || max_pts < 1 ||
+        max_edges < 1 || max_iters < 1 || !d_scratch || !d_final_chi2 || !d_iters || !d_status)
+        return MYSLAM_ERR_INVALID;
+    BaOptArgs a{d_poses, d_points, d_edge_pose, d_edge_pt, d_obs, d_fixed, d_sizes, 0, 0, 0, max_poses, max_pts, max_edges,
+                fx, fy, cx, cy, huber_delta, max_iters, d_scratch, d_final_chi2, d_iters, d_status};
+    return ba_opt_launch(a, nwin, (hipStream_t)hip_stream);
+}
+
+int myslam_ba_optimize(double* poses, int nposes, double* points, int npts, const int32_t* edge_pose, const int32_t* edge_pt,
+                       const double* obs, int nedges, const uint8_t* fixed_pt, double fx, double fy, double cx, double cy,
+                       double huber_delta, int max_iters, double* final_chi2, int* iters) {
+    if (!poses || !points || nposes < 1 || npts < 1 || nedges < 1 || !edge_pose || !edge_pt || !obs || max_iters < 1) return MYSLAM_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MYSLAM_ERR_HIP;
+    double *d_p = nullptr, *d_x = nullptr, *d_o = nullptr, *d_w = nullptr, *d_chi = nullptr; int32_t *d_i = nullptr, *d_st = nullptr; uint8_t* d_f = nullptr;
+    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_p, sizeof(double) * nposes * 7)); MYSLAM_HIP_CHECK(hipMalloc((void**)&d_x, sizeof(double) * npts * 3));
+    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_o, sizeof(double) * nedges * 2)); MYSLAM_HIP_CHECK(hipMalloc((void**)&d_w, sizeof(double) * nedges * 18));
+    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_chi, sizeof(double))); MYSLAM_HIP_CHECK(hipMalloc((void**)&d_i, sizeof(int32_t) * (2 * nedges + 2)));
+    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_f, npts)); d_st = d_i + 2 * nedges;
+    MYSLAM_HIP_CHECK(hipMemcpy(d_p, poses, sizeof(double) * nposes * 7, hipMemcpyHostToDevice));
+    MYSLAM_HIP_CHECK(hipMemcpy(d_x, points, sizeof(double) * npts * 3, hipMemcpyHostToDevice));
+    MYSLAM_HIP_CHECK(hipMemcpy(d_o, obs, sizeof(double) * nedges * 2, hipMemcpyHostToDevice));
+    MYSLAM_HIP_CHECK(hipMemcpy(d_i, edge_pose, sizeof(int32_t) * nedges, hipMemcpyHostToDevice));
+    MYSLAM_HIP_CHECK(hipMemcpy(d_i + nedges, edge_pt, sizeof(int32_t) * nedges, hipMemcpyHostToDevice));
+    if (fixed_pt) MYSLAM_HIP_CHECK(hipMemcpy(d_f, fixed_pt, npts, hipMemcpyHostToDevice));
+    BaOptArgs a{d_p, d_x, d_i, d_i + nedges, d_o, fixed_pt ? d_f : nullptr, nullptr, nposes, npts, nedges, nposes, npts, nedges,
+                fx, fy, cx, cy, huber_delta, max_iters, d_w, d_chi, d_st + 1, d_st};
+    int rc = ba_opt_launch(a, 1, nullptr);
+    if (rc) return rc;
+    int32_t st[2]; double chi;
+    MYSLAM_HIP_CHECK(hipMemcpy(st, d_st, sizeof(st), hipMemcpyDeviceToHost));
+    MYSLAM_HIP_CHECK(hipMemcpy(&chi, d_chi, sizeof(double), hipMemcpyDeviceToHost));
+    MYSLAM_HIP_CHECK(hipMemcpy(poses, d_p, sizeof(double) * nposes * 7, hipMemcpyDeviceToHost));
+    MYSLAM_HIP_CHECK(hipMemcpy(points, d_x, sizeof(double) * npts * 3, hipMemcpyDeviceToHost));
+    (void)hipFree(d_p); (void)hipFree(d_x); (void)hipFree(d_o); (void)hipFree(d_w); (void)hipFree(d_chi); (void)hipFree(d_i); (void)hipFree(d_f);
+    if (final_chi2) *final_chi2 = chi;
+    if (iters) *iters = st[1];
+    return st[0];
 }
 
 }  // extern "C"

@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=256, help="stereo pairs per step per GPU")
-    ap.add_argument("--workload", default="full", choices=["full", "orb_match", "orb_match_lcd"])
+    ap.add_argument("--workload", default="full", choices=["full", "orb_match", "orb_match_lcd", "full_solve"])
     ap.add_argument("--db", type=int, default=0, help="key-frame database size (default 10000, or 6250 per GPU when sharded)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=32)
@@ -85,8 +85,10 @@ def cpu_baseline(synth, workload, n_pairs, db_np):
             x, _ = o.calc_preproc(L)
             d = o.calc_forward(w, x)
             o.lcddb_query(db_np, ids, d, len(db_np) + 20)
-        if workload == "full":
+        if workload in ("full", "full_solve"):
             o.ba_build(*ba[:6], ba[6])
+        if workload == "full_solve":
+            o.ba_optimize(*ba[:6], ba[6], iters=10)
     dt = time.perf_counter() - t0
     return {"value": n_pairs / dt, "unit": "stereo frames/s", "cores": 1, "kind": "port",
             "sample": f"{n_pairs} synthetic 1241x376 stereo pairs, same stages as the GPU workload, oracle single thread, {dt:.1f} s"}
@@ -132,7 +134,8 @@ def main():
     d_xyz = torch.zeros(P * cap * 3, dtype=torch.float64, device=dev)
     d_ok = torch.zeros(P * cap, dtype=torch.uint8, device=dev)
     use_lcd = args.workload != "orb_match"
-    use_ba = args.workload == "full"
+    use_ba = args.workload in ("full", "full_solve")
+    use_solve = args.workload == "full_solve"
     n_db_local = args.db or (10000 if world == 1 else 6250)
     db_np = None
     if use_lcd:
@@ -155,6 +158,10 @@ def main():
         b_in = [rep(poses), rep(pts), rep(ep), rep(el), rep(obs), rep(fixed),
                 torch.tensor([[maxP, maxL, maxE]] * P, dtype=torch.int32, device=dev)]
         b_out = [torch.zeros(P, n, dtype=torch.float64, device=dev) for n in (maxP * 36, maxL * 9, maxE * 18, maxP * 6, maxL * 3, maxE)]
+        if use_solve:       # optimize(10) updates poses/points in place: every step starts from the pristine window
+            s_poses, s_pts = b_in[0].clone(), b_in[1].clone()
+            s_chi = torch.zeros(P, dtype=torch.float64, device=dev)
+            s_it = torch.zeros(P, dtype=torch.int32, device=dev); s_st = torch.zeros(P, dtype=torch.int32, device=dev)
 
     def step():
         ext.detect_and_compute_batch(d_imgs.data_ptr(), 2 * P, H, W, W, H * W, d_kps.data_ptr(), d_desc.data_ptr(),
@@ -173,6 +180,10 @@ def main():
                 D.query_batch(d_descr.data_ptr(), cur_ids, NQ, d_best.data_ptr(), d_max.data_ptr(), d_dbcnt.data_ptr())
         if use_ba:
             api.ba_build_batch(*[t.data_ptr() for t in b_in], P, maxP, maxL, maxE, Kt, 5.991, *[t.data_ptr() for t in b_out], stream)
+            if use_solve:
+                s_poses.copy_(b_in[0]); s_pts.copy_(b_in[1])
+                api.ba_optimize_batch(s_poses.data_ptr(), s_pts.data_ptr(), *[t.data_ptr() for t in b_in[2:]], P, maxP, maxL, maxE, Kt,
+                                      5.991, 10, b_out[2].data_ptr(), s_chi.data_ptr(), s_it.data_ptr(), s_st.data_ptr(), stream)
 
     def barrier():
         if world > 1:
@@ -226,6 +237,8 @@ def main():
             "dtype": "u8/int32 (ORB, Hamming), f32 (CALC, DB scan), f64 (triangulation, BA)", "data": "synthetic",
             "config": {"workload": {"full": "configs[3]: ORB extract L+R (2000 feats) + L/R Hamming match + triangulation + DeepLCD descriptor + "
                                             f"{n_db_local * world}-KF cosine DB scan + local-BA (10 KF x 300 MP) block build per frame",
+                                    "full_solve": "configs[3] incl. solve: as 'full' + Levenberg-Marquardt optimize(10) (Schur + Cholesky) of the "
+                                                  "10 KF x 300 MP window per frame",
                                     "orb_match": "configs[1]: ORB extract L+R (2000 feats) + L/R Hamming match + triangulation",
                                     "orb_match_lcd": f"configs[2]: configs[1] + DeepLCD descriptor + {n_db_local * world}-KF cosine DB scan"}[args.workload],
                        "pairs_per_step_per_gpu": P, "image": "1241x376 u8", "keypoints_per_image": n_kp,

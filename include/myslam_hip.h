@@ -201,6 +201,19 @@ int myslam_ba_build_batch(const double* d_poses, const double* d_points, const i
                           double* d_Hpp, double* d_Hll, double* d_Hpl, double* d_bp, double* d_bl, double* d_chi2,
                           void* hip_stream);
 
+/* Levenberg-Marquardt with Schur complement on device — replaces optimizer.optimize(n) of
+ * Backend::OptimizeActiveMap (src/backend.cpp:212-214: g2o OptimizationAlgorithmLevenberg + BlockSolver_6_3 +
+ * CSparse).  poses/points are updated in place.  Edges must be grouped by landmark
+ * (backend.cpp:161-205 builds them that way); max_poses <= 10.  d_scratch: nwin x max_edges x 18 doubles. */
+int myslam_ba_optimize(double* poses, int nposes, double* points, int npts, const int32_t* edge_pose, const int32_t* edge_pt,
+                       const double* obs, int nedges, const uint8_t* fixed_pt, double fx, double fy, double cx, double cy,
+                       double huber_delta, int max_iters, double* final_chi2, int* iters);
+int myslam_ba_optimize_batch(double* d_poses, double* d_points, const int32_t* d_edge_pose, const int32_t* d_edge_pt,
+                             const double* d_obs, const uint8_t* d_fixed, const int32_t* d_sizes, int nwin, int max_poses,
+                             int max_pts, int max_edges, double fx, double fy, double cx, double cy, double huber_delta,
+                             int max_iters, double* d_scratch, double* d_final_chi2, int32_t* d_iters, int32_t* d_status,
+                             void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

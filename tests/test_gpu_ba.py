@@ -61,3 +61,52 @@ def test_ba_build_batch(api, oracle, synth):
         _close(Hpl[w, :E].cpu().numpy().reshape(E, 6, 3), ref[2], "Hpl")
         _close(bp[w, :P].cpu().numpy(), ref[3], "bp"); _close(bl[w, :L].cpu().numpy(), ref[4], "bl")
         _close(chi[w, :E].cpu().numpy(), ref[5], "chi2")
+
+
+@pytest.mark.parametrize("n_kf,n_mp,seed", [(10, 300, 0xBA), (7, 120, 3), (4, 40, 9), (10, 300, 77)])
+def test_ba_optimize_matches_oracle_lm(api, oracle, synth, n_kf, n_mp, seed):
+    """LM + Schur on device vs the oracle's restatement of g2o's Levenberg loop (Appendix A.7).  Both run the same
+    algorithm in f64; summation order differs (LDS atomics), so iterates agree to ~1e-9, not bitwise."""
+    poses, pts, ep, el, obs, fixed, K = synth.ba_problem(seed=seed, n_kf=n_kf, n_mp=n_mp)
+    for iters in (1, 10):
+        gp, gx, gchi, git = api.ba_optimize(poses, pts, ep, el, obs, fixed, K, iters=iters)
+        rp, rx, rchi, rit = oracle.ba_optimize(poses, pts, ep, el, obs, fixed, K, iters=iters)
+        assert git == rit
+        assert gchi == pytest.approx(rchi, rel=1e-8)
+        assert np.allclose(gp, rp, rtol=1e-7, atol=1e-8) and np.allclose(gx, rx, rtol=1e-7, atol=1e-7)
+    chi0 = oracle.ba_build(poses, pts, ep, el, obs, fixed, K)[5]
+    rho0 = np.where(chi0 <= 5.991 ** 2, chi0, 2 * np.sqrt(chi0) * 5.991 - 5.991 ** 2).sum()   # Huber-robustified start value
+    assert gchi < 0.9 * rho0                                                                    # it actually optimised
+    assert np.array_equal(gx[fixed.astype(bool)], pts[fixed.astype(bool)])                      # fixed landmarks never move
+
+
+def test_ba_optimize_rejects_ungrouped_edges(api, synth):
+    poses, pts, ep, el, obs, fixed, K = synth.ba_problem(n_kf=4, n_mp=30)
+    perm = np.random.default_rng(0).permutation(len(ep))
+    with pytest.raises(api.MyslamError) as e:
+        api.ba_optimize(poses, pts, ep[perm], el[perm], obs[perm], fixed, K)
+    assert e.value.code == api.ERR_INVALID
+
+
+def test_ba_optimize_batch(api, oracle, synth):
+    import torch
+    W, maxP, maxL, maxE = 4, 10, 300, 3000
+    probs = [synth.ba_problem(seed=200 + w, n_kf=5 + w, n_mp=100 + 50 * w) for w in range(W)]
+    poses = np.zeros((W, maxP, 7)); poses[..., 3] = 1
+    pts = np.zeros((W, maxL, 3)); ep = np.zeros((W, maxE), np.int32); el = np.zeros((W, maxE), np.int32)
+    obs = np.zeros((W, maxE, 2)); fixed = np.zeros((W, maxL), np.uint8); sizes = np.zeros((W, 3), np.int32)
+    for w, (p, x, a, b, o, f, K) in enumerate(probs):
+        poses[w, :len(p)] = p; pts[w, :len(x)] = x; ep[w, :len(a)] = a; el[w, :len(a)] = b; obs[w, :len(a)] = o; fixed[w, :len(f)] = f
+        sizes[w] = (len(p), len(x), len(a))
+    d = [torch.from_numpy(a).cuda() for a in (poses, pts, ep, el, obs, fixed, sizes)]
+    scratch = torch.zeros(W * maxE * 18, dtype=torch.float64, device="cuda")
+    chi = torch.zeros(W, dtype=torch.float64, device="cuda"); it = torch.zeros(W, dtype=torch.int32, device="cuda"); st = torch.ones(W, dtype=torch.int32, device="cuda")
+    api.ba_optimize_batch(*[t.data_ptr() for t in d], W, maxP, maxL, maxE, probs[0][6], 5.991, 10, scratch.data_ptr(), chi.data_ptr(),
+                          it.data_ptr(), st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert (st.cpu().numpy() == 0).all()
+    for w, (p, x, a, b, o, f, K) in enumerate(probs):
+        rp, rx, rchi, rit = oracle.ba_optimize(p, x, a, b, o, f, K, iters=10)
+        assert int(it[w]) == rit and float(chi[w]) == pytest.approx(rchi, rel=1e-8)
+        assert np.allclose(d[0][w, :len(p)].cpu().numpy(), rp, rtol=1e-7, atol=1e-8)
+        assert np.allclose(d[1][w, :len(x)].cpu().numpy(), rx, rtol=1e-7, atol=1e-7)
