@@ -165,8 +165,10 @@ int myslam_orb::make_plan(int r, int c) {
         g.ndepth = std::min(MAX_DEPTH, ceil_log2(std::max(rootW, H)) + 2);
         g.sortDepth = 0;
         while (g.sortDepth + 1 <= g.ndepth && (g.nIni << (2 * (g.sortDepth + 1))) <= 4096) g.sortDepth++;
-        g.keyCap = (int)std::min<size_t>(65535, std::max<size_t>(256, (size_t)g.w * g.h / 12));
+        // a cell interior of a x b pixels holds at most ceil(a/2)*ceil(b/2) strict 8-neighbour maxima: no overflow possible
+        g.keyCap = (int)std::min<size_t>(262143, std::max<size_t>(256, (size_t)((g.w + 1) / 2) * ((g.h + 1) / 2)));
         g.nodeCap = (std::max(g.N + 4, 4 * g.nIni + 4) + 3) & ~3;
+        if (g.nodeCap > 4092) return MYSLAM_ERR_UNSUPPORTED;          // oct-tree node list lives in LDS
         g.outBase = outBase; outBase += g.nodeCap;
         g.scale = scale[l];
         g.scaledPatch = (float)(int)(PATCH_SIZE * scale[l]);                            // :891
@@ -181,6 +183,7 @@ int myslam_orb::make_plan(int r, int c) {
     det.ncells = P.lv[0].nCols * P.lv[0].nRows;
     det.lv[0].N = nfeatures;
     det.lv[0].nodeCap = (std::max(nfeatures + 4, 4 * P.lv[0].nIni + 4) + 3) & ~3;
+    if (det.lv[0].nodeCap > 4092) return MYSLAM_ERR_UNSUPPORTED;
     det.lv[0].outBase = 0;
     det.totalOut = det.lv[0].nodeCap;
     rows = r; cols = c;
@@ -355,9 +358,11 @@ int myslam_orb_get_tables(const myslam_orb* h, float* scale, float* inv_scale, i
 
 int myslam_orb_max_keypoints(const myslam_orb* h) {
     if (!h) return MYSLAM_ERR_INVALID;
+    // per level the oct-tree returns < N + 3 nodes, except that the very first split of the nIni = round(w/h) root
+    // nodes is unconditional (ORBextractor.cpp:645-716) and can already yield 4*nIni; aspect ratios up to 8 are covered
     int s = 0;
-    for (int l = 0; l < h->nlevels; l++) s += h->nPerLevel[l] + 3;
-    return std::max(s, h->nfeatures + 3);
+    for (int l = 0; l < h->nlevels; l++) s += std::max(h->nPerLevel[l] + 3, 32);
+    return std::max(s, std::max(h->nfeatures + 3, 32));
 }
 
 int myslam_orb_detect_and_compute_batch(myslam_orb* h, const uint8_t* d_imgs, int batch, int rows, int cols, int step,
@@ -381,10 +386,10 @@ static int host_extract(myslam_orb* h, const uint8_t* img, int rows, int cols, i
     if (detectOnly && !mask) { /* Detect() returns on empty mask (:990); NULL here means "all 255" */ }
     if (step < cols || cap <= 0 || !kps || (!detectOnly && !desc)) return MYSLAM_ERR_INVALID;
     if (mask && mask_step < cols) return MYSLAM_ERR_INVALID;
-    const int want = myslam_orb_max_keypoints(h);
-    const int dcap = std::max(cap, want);
-    int rc = h->ensure_stage((size_t)rows * step, mask ? (size_t)rows * mask_step : 0, dcap);
+    int rc = h->ensure(1, rows, cols, mask != nullptr);          // plan first: the exact slot count depends on the image shape
     if (rc) return rc;
+    const int dcap = std::max(cap, std::max(h->full.totalOut, h->det.totalOut));
+    if ((rc = h->ensure_stage((size_t)rows * step, mask ? (size_t)rows * mask_step : 0, dcap))) return rc;
     MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_stageImg, img, (size_t)rows * step, hipMemcpyHostToDevice, h->stream));
     if (mask) MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_stageMask, mask, (size_t)rows * mask_step, hipMemcpyHostToDevice, h->stream));
     // masks share the image's pitch inside the engine: re-pitch on ingest through the same kernel (step may differ)

@@ -641,18 +641,19 @@ __device__ __noinline__ void partition4(uint64_t* __restrict__ S, int lo, int hi
 }
 
 struct OctLds {
-    uint32_t *rng0, *rng1;      // node range lo | hi<<16 (double buffered)
+    uint32_t *lo0, *lo1, *hi0, *hi1;   // node key range [lo, hi) (double buffered)
     uint16_t *pfx0, *pfx1;      // node bucket prefix (valid while depth <= D)
     uint8_t *dep0, *dep1;       // node depth
-    uint16_t *nb1, *nb2, *nb3;  // child boundaries (per list position / per sorted candidate)
-    uint32_t *ckey0, *ckey1;    // candidate sort key: size<<16 | creation index
+    uint32_t *nb1, *nb2, *nb3;  // child boundaries (per list position / per sorted candidate)
+    uint32_t *ckey0, *ckey1;    // candidate sort key: size<<14 | creation index (size < 2^18, <= 16383 candidates)
     uint16_t *cpos0, *cpos1;    // candidate -> list position
     uint16_t* ord;              // rank -> candidate
     uint16_t *kinc, *binc;      // inclusive sums of children / big children over sorted candidates
     uint8_t* kk;                // #non-empty children (0 = not expandable)
     uint8_t* mark;
-    uint16_t* offs;             // exclusive bucket offsets [NB+1]
-    __device__ __forceinline__ uint32_t* rng(int i) const { return i ? rng1 : rng0; }
+    uint32_t* offs;             // exclusive bucket offsets [NB+1]
+    __device__ __forceinline__ uint32_t* lo(int i) const { return i ? lo1 : lo0; }
+    __device__ __forceinline__ uint32_t* hi(int i) const { return i ? hi1 : hi0; }
     __device__ __forceinline__ uint16_t* pfx(int i) const { return i ? pfx1 : pfx0; }
     __device__ __forceinline__ uint8_t* dep(int i) const { return i ? dep1 : dep0; }
     __device__ __forceinline__ uint32_t* ckey(int i) const { return i ? ckey1 : ckey0; }
@@ -687,16 +688,18 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
     uint8_t* pcur = smem + 64;
     uint32_t* s_cursor = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * OT_MAXB;
     OctLds L;
-    L.rng0 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
-    L.rng1 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
+    L.lo0 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
+    L.lo1 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
+    L.hi0 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
+    L.hi1 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
+    L.nb1 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
+    L.nb2 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
+    L.nb3 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
+    L.offs = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * (OT_MAXB + 2);
     L.ckey0 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
     L.ckey1 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
-    L.offs = reinterpret_cast<uint16_t*>(pcur); pcur += 2 * (OT_MAXB + 2);
     L.pfx0 = reinterpret_cast<uint16_t*>(pcur); pcur += 2 * NC;
     L.pfx1 = reinterpret_cast<uint16_t*>(pcur); pcur += 2 * NC;
-    L.nb1 = reinterpret_cast<uint16_t*>(pcur); pcur += 2 * NC;
-    L.nb2 = reinterpret_cast<uint16_t*>(pcur); pcur += 2 * NC;
-    L.nb3 = reinterpret_cast<uint16_t*>(pcur); pcur += 2 * NC;
     L.cpos0 = reinterpret_cast<uint16_t*>(pcur); pcur += 2 * NC;
     L.cpos1 = reinterpret_cast<uint16_t*>(pcur); pcur += 2 * NC;
     L.ord = reinterpret_cast<uint16_t*>(pcur); pcur += 2 * NC;
@@ -744,11 +747,11 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
         uint64_t run = block_excl_scan64(sum, s_w, total);
         for (int i = beg; i < end; i++) {
             const uint32_t h = s_cursor[i];
-            L.offs[i] = (uint16_t)run;
+            L.offs[i] = (uint32_t)run;
             s_cursor[i] = (uint32_t)run;
             run += h;
         }
-        if (t == 0) L.offs[NB] = (uint16_t)n;
+        if (t == 0) L.offs[NB] = (uint32_t)n;
     }
     __syncthreads();
     for (int i = t; i < n; i += OT) {
@@ -764,7 +767,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
         int m = 0;
         for (int r = 0; r < g.nIni; r++) {
             const int lo = L.offs[r << (2 * D)], hi = L.offs[(r + 1) << (2 * D)];
-            if (hi > lo) { L.rng0[m] = (uint32_t)lo | ((uint32_t)hi << 16); L.dep0[m] = 0; L.pfx0[m] = (uint16_t)r; m++; }
+            if (hi > lo) { L.lo0[m] = (uint32_t)lo; L.hi0[m] = (uint32_t)hi; L.dep0[m] = 0; L.pfx0[m] = (uint16_t)r; m++; }
         }
         s_i[0] = m; s_i[1] = 0;
     }
@@ -782,13 +785,12 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
             const int beg = min(m, t * c), end = min(m, beg + c);
             uint64_t packed = 0;              // K | Non<<21 | Big<<42
             for (int p = beg; p < end; p++) {
-                const uint32_t r = L.rng(cur)[p];
-                const int lo = r & 0xffff, hi = r >> 16, d = L.dep(cur)[p];
+                const int lo = (int)L.lo(cur)[p], hi = (int)L.hi(cur)[p], d = L.dep(cur)[p];
                 int k = 0;
                 if (hi - lo > 1 && d < g.ndepth) {
                     int b1, b2, b3;
                     child_bounds(L, S, D, lo, hi, d, L.pfx(cur)[p], b1, b2, b3);
-                    L.nb1[p] = (uint16_t)b1; L.nb2[p] = (uint16_t)b2; L.nb3[p] = (uint16_t)b3;
+                    L.nb1[p] = (uint32_t)b1; L.nb2[p] = (uint32_t)b2; L.nb3[p] = (uint32_t)b3;
                     const int c0 = b1 - lo, c1 = b2 - b1, c2 = b3 - b2, c3 = hi - b3;
                     k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
                     const int big = (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1);
@@ -803,12 +805,11 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
             const int Ktot = (int)(total & 0x1fffff), Ntot = (int)((total >> 21) & 0x1fffff), Btot = (int)(total >> 42);
             const int nxt = cur ^ 1, cnxt = ccur ^ 1;
             for (int p = beg; p < end; p++) {
-                const uint32_t r = L.rng(cur)[p];
-                const int lo = r & 0xffff, hi = r >> 16, d = L.dep(cur)[p];
+                const int lo = (int)L.lo(cur)[p], hi = (int)L.hi(cur)[p], d = L.dep(cur)[p];
                 const int pf = L.pfx(cur)[p];
                 const int k = L.kk[p];
                 if (k) {
-                    const int bnd[5] = {lo, L.nb1[p], L.nb2[p], L.nb3[p], hi};
+                    const int bnd[5] = {lo, (int)L.nb1[p], (int)L.nb2[p], (int)L.nb3[p], hi};
                     const int rk = (int)(run & 0x1fffff);
                     int pos = Ktot - (rk + k);                           // children of later nodes come first
                     int cidx = (int)(run >> 42);
@@ -817,7 +818,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
                     for (int q = 3; q >= 0; q--) {                       // list order n4,n3,n2,n1 (push_front)
                         childPos[q] = pos;
                         if (bnd[q + 1] > bnd[q]) {
-                            L.rng(nxt)[pos] = (uint32_t)bnd[q] | ((uint32_t)bnd[q + 1] << 16);
+                            L.lo(nxt)[pos] = (uint32_t)bnd[q]; L.hi(nxt)[pos] = (uint32_t)bnd[q + 1];
                             L.dep(nxt)[pos] = (uint8_t)(d + 1);
                             L.pfx(nxt)[pos] = (uint16_t)((pf << 2) | q);
                             pos++;
@@ -827,7 +828,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
                     for (int q = 0; q < 4; q++) {                        // creation order n1..n4
                         const int sz = bnd[q + 1] - bnd[q];
                         if (sz > 1) {
-                            L.ckey(cnxt)[cidx] = ((uint32_t)sz << 16) | (uint32_t)cidx;
+                            L.ckey(cnxt)[cidx] = ((uint32_t)sz << 14) | (uint32_t)cidx;
                             L.cpos(cnxt)[cidx] = (uint16_t)childPos[q];
                             cidx++;
                         }
@@ -836,7 +837,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
                     run += (uint64_t)k | ((uint64_t)big << 42);
                 } else {
                     const int rn = (int)((run >> 21) & 0x1fffff);
-                    L.rng(nxt)[Ktot + rn] = r;
+                    L.lo(nxt)[Ktot + rn] = (uint32_t)lo; L.hi(nxt)[Ktot + rn] = (uint32_t)hi;
                     L.dep(nxt)[Ktot + rn] = (uint8_t)d;
                     L.pfx(nxt)[Ktot + rn] = (uint16_t)pf;
                     run += 1ull << 21;
@@ -868,8 +869,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
             uint64_t packed = 0;                                         // K | Big<<32
             for (int j = beg; j < end; j++) {
                 const int p = L.cpos(ccur)[L.ord[j]];
-                const uint32_t r = L.rng(cur)[p];
-                const int lo = r & 0xffff, hi = r >> 16, d = L.dep(cur)[p];
+                const int lo = (int)L.lo(cur)[p], hi = (int)L.hi(cur)[p], d = L.dep(cur)[p];
                 int k = 1, big = 1, b1 = hi, b2 = hi, b3 = hi;           // depth-exhausted node: one "child" = itself
                 if (d < g.ndepth) {
                     child_bounds(L, S, D, lo, hi, d, L.pfx(cur)[p], b1, b2, b3);
@@ -877,7 +877,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
                     k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
                     big = (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1);
                 }
-                L.nb1[j] = (uint16_t)b1; L.nb2[j] = (uint16_t)b2; L.nb3[j] = (uint16_t)b3;
+                L.nb1[j] = (uint32_t)b1; L.nb2[j] = (uint32_t)b2; L.nb3[j] = (uint32_t)b3;
                 L.kk[j] = (uint8_t)(k | (big << 4));
                 packed += (uint64_t)k | ((uint64_t)big << 32);
             }
@@ -900,11 +900,10 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
             // committed candidates: children in front, reverse processing order
             for (int j = t; j < ncmt; j += OT) {
                 const int p = L.cpos(ccur)[L.ord[j]];
-                const uint32_t r = L.rng(cur)[p];
-                const int lo = r & 0xffff, hi = r >> 16, d = L.dep(cur)[p];
+                const int lo = (int)L.lo(cur)[p], hi = (int)L.hi(cur)[p], d = L.dep(cur)[p];
                 const int pf = L.pfx(cur)[p];
                 const int big = L.kk[j] >> 4;
-                const int bnd[5] = {lo, L.nb1[j], L.nb2[j], L.nb3[j], hi};
+                const int bnd[5] = {lo, (int)L.nb1[j], (int)L.nb2[j], (int)L.nb3[j], hi};
                 int pos = Kc - L.kinc[j];
                 int childPos[4];
                 if (d < g.ndepth) {
@@ -912,7 +911,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
                     for (int q = 3; q >= 0; q--) {
                         childPos[q] = pos;
                         if (bnd[q + 1] > bnd[q]) {
-                            L.rng(nxt)[pos] = (uint32_t)bnd[q] | ((uint32_t)bnd[q + 1] << 16);
+                            L.lo(nxt)[pos] = (uint32_t)bnd[q]; L.hi(nxt)[pos] = (uint32_t)bnd[q + 1];
                             L.dep(nxt)[pos] = (uint8_t)(d + 1);
                             L.pfx(nxt)[pos] = (uint16_t)((pf << 2) | q);
                             pos++;
@@ -923,15 +922,15 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
                     for (int q = 0; q < 4; q++) {
                         const int sz = bnd[q + 1] - bnd[q];
                         if (sz > 1) {
-                            L.ckey(cnxt)[cidx] = ((uint32_t)sz << 16) | (uint32_t)cidx;
+                            L.ckey(cnxt)[cidx] = ((uint32_t)sz << 14) | (uint32_t)cidx;
                             L.cpos(cnxt)[cidx] = (uint16_t)childPos[q];
                             cidx++;
                         }
                     }
                 } else {                                                // cannot happen for distinct keys; keep node
-                    L.rng(nxt)[pos] = r; L.dep(nxt)[pos] = (uint8_t)d; L.pfx(nxt)[pos] = (uint16_t)pf;
+                    L.lo(nxt)[pos] = (uint32_t)lo; L.hi(nxt)[pos] = (uint32_t)hi; L.dep(nxt)[pos] = (uint8_t)d; L.pfx(nxt)[pos] = (uint16_t)pf;
                     const int cidx = L.binc[j] - 1;
-                    L.ckey(cnxt)[cidx] = ((uint32_t)(hi - lo) << 16) | (uint32_t)cidx;
+                    L.ckey(cnxt)[cidx] = ((uint32_t)(hi - lo) << 14) | (uint32_t)cidx;
                     L.cpos(cnxt)[cidx] = (uint16_t)pos;
                 }
             }
@@ -945,7 +944,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
                 uint64_t ex = block_excl_scan64(un, s_w, tot2);
                 for (int p = pb; p < pe; p++) {
                     if (L.mark[p] == 0) {
-                        L.rng(nxt)[Kc + (int)ex] = L.rng(cur)[p];
+                        L.lo(nxt)[Kc + (int)ex] = L.lo(cur)[p]; L.hi(nxt)[Kc + (int)ex] = L.hi(cur)[p];
                         L.dep(nxt)[Kc + (int)ex] = L.dep(cur)[p];
                         L.pfx(nxt)[Kc + (int)ex] = L.pfx(cur)[p];
                         ex++;
@@ -966,8 +965,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
     const int m = s_i[0];
     uint32_t* out = selOut + (size_t)b * P.totalOut + g.outBase;
     for (int p = t; p < m && p < g.nodeCap; p += OT) {
-        const uint32_t r = L.rng(cur)[p];
-        const int lo = r & 0xffff, hi = r >> 16;
+        const int lo = (int)L.lo(cur)[p], hi = (int)L.hi(cur)[p];
         uint32_t best = (uint32_t)S[lo];
         if (hi - lo > 1) {
             int bs = best & 0xff;
@@ -1348,7 +1346,7 @@ void launch_fast(const OrbPlan& P, const uint8_t* pyr, size_t pyrStride, const u
     }
 }
 
-size_t octree_lds_bytes(int nodeCap) { return 64 + 4 * (size_t)OT_MAXB + 2 * (size_t)(OT_MAXB + 2) + (size_t)nodeCap * 40 + 16; }
+size_t octree_lds_bytes(int nodeCap) { return 64 + 4 * (size_t)OT_MAXB + 4 * (size_t)(OT_MAXB + 2) + (size_t)nodeCap * 54 + 16; }
 
 void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCount, uint64_t* sortbuf, uint32_t* selOut,
                    int32_t* selCount, int32_t* status, int batch, hipStream_t s) {

@@ -64,7 +64,8 @@ int myslam_orb_destroy(myslam_orb* h);
 int myslam_orb_set_stream(myslam_orb* h, void* hip_stream);
 /* getters ORBextractor.h:87-107 */
 int myslam_orb_get_tables(const myslam_orb* h, float* scale, float* inv_scale, int* features_per_level, int* umax16);
-/* upper bound of keypoints DetectAndCompute can return for one image (octree may exceed nfeatures) */
+/* upper bound of keypoints DetectAndCompute / Detect can return for one image: sum over levels of
+ * max(N_level + 3, 32) — the oct-tree stops only after a split pushed it to >= N, and its first round is unconditional */
 int myslam_orb_max_keypoints(const myslam_orb* h);
 
 /* void DetectAndCompute(image, mask, keypoints, descriptors)   ORBextractor.h:61-63, .cpp:922-985

@@ -208,3 +208,44 @@ def test_golden_fixture(api):
     ext = api.ORBextractor(int(g["nfeatures"]))
     kps, desc = ext.DetectAndCompute(g["image"])
     assert kps.tobytes() == g["kps"].tobytes() and np.array_equal(desc, g["desc"])
+
+
+def _clustered_image(seed, h=240, w=320):
+    """Flat background + a few tiny, extremely corner-dense patches: forces the oct-tree far below the depth the
+    LDS counting sort covers (the on-demand in-place partition path) and cells that need the th=7 fallback."""
+    rng = np.random.default_rng(seed)
+    img = np.full((h, w), 100, np.uint8)
+    for _ in range(3):
+        y0 = int(rng.integers(30, h - 70)); x0 = int(rng.integers(30, w - 70))
+        patch = rng.integers(0, 2, (20, 20)).astype(np.uint8) * int(rng.integers(60, 150))
+        img[y0:y0 + 40, x0:x0 + 40] = 100 + np.kron(patch, np.ones((2, 2), np.uint8))
+    ys = rng.integers(25, h - 25, 25); xs = rng.integers(25, w - 25, 25)       # a few isolated weak corners
+    for y, x in zip(ys, xs):
+        img[y:y + 3, x:x + 3] = 100 + int(rng.integers(9, 30))
+    return img
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("nfeat", [60, 400, 1500])
+def test_clustered_corners_deep_octree(api, oracle, seed, nfeat):
+    img = _clustered_image(seed)
+    ext = api.ORBextractor(nfeat)
+    kps, desc = ext.DetectAndCompute(img)
+    rk, rd = oracle.detect_and_compute(oracle.params(nfeat), img)
+    assert _kp_equal(kps, rk), _explain(kps, rk)
+    assert np.array_equal(desc, rd)
+    k0 = ext.Detect(img); r0 = oracle.detect(oracle.params(nfeat), img)
+    assert _kp_equal(k0, r0), _explain(k0, r0)
+
+
+def test_many_random_images_small(api, oracle, synth):
+    """Breadth: 40 seeded images of assorted sizes / budgets, all bit-exact."""
+    rng = np.random.default_rng(123)
+    for i in range(40):
+        h = int(rng.integers(230, 420)); w = int(rng.integers(230, 700)); nfeat = int(rng.choice([50, 200, 777, 2500]))
+        img = synth.random_image(5000 + i, h, w, kind="noise" if i % 7 == 0 else "texture")
+        ext = api.ORBextractor(nfeat)
+        kps, desc = ext.DetectAndCompute(img)
+        rk, rd = oracle.detect_and_compute(oracle.params(nfeat), img)
+        assert _kp_equal(kps, rk), (i, h, w, nfeat, _explain(kps, rk))
+        assert np.array_equal(desc, rd), (i, h, w, nfeat)
