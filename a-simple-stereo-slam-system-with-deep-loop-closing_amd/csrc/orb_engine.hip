@@ -141,7 +141,7 @@ static int ceil_log2(int v) { int b = 0; while ((1 << b) < v) b++; return b; }
 int myslam_orb::make_plan(int r, int c) {
     OrbPlan P{};
     P.nlevels = nlevels; P.rows = r; P.cols = c; P.iniTh = iniTh; P.minTh = minTh;
-    size_t imgOff = 0, keyOff = 0; int cellBase = 0, outBase = 0;
+    size_t imgOff = 0, keyOff = 0; int cellBase = 0, outBase = 0, stripBase = 0;
     for (int l = 0; l < nlevels; l++) {
         LevelGeom& g = P.lv[l];
         g.w = cv_round((float)c * invScale[l]);                 // ORBextractor.cpp:1237-1238
@@ -157,6 +157,7 @@ int myslam_orb::make_plan(int r, int c) {
         if (g.wCell > MAX_CELL || g.hCell > MAX_CELL) return MYSLAM_ERR_UNSUPPORTED;
         if (g.maxBX + 3 > 4095 + MIN_BORDER || g.maxBY + 3 > 4095 + MIN_BORDER) return MYSLAM_ERR_UNSUPPORTED;
         g.cellBase = cellBase; cellBase += g.nCols * g.nRows;
+        g.stripBase = stripBase; stripBase += g.nRows * ((g.nCols + 3) / 4);
         g.N = nPerLevel[l];
         g.nIni = (int)roundf((float)(g.maxBX - MIN_BORDER) / (g.maxBY - MIN_BORDER));   // :590
         if (g.nIni < 1 || g.nIni > 64) return MYSLAM_ERR_UNSUPPORTED;
@@ -175,12 +176,13 @@ int myslam_orb::make_plan(int r, int c) {
         g.imgOff = imgOff; imgOff += align_up((size_t)g.pitch * g.h, 256);
         g.keyOff = keyOff; keyOff += g.keyCap;
     }
-    P.ncells = cellBase; P.totalKeyCap = (int)keyOff; P.totalOut = outBase; P.pyrBytes = imgOff;
+    P.ncells = cellBase; P.nstrips = stripBase; P.totalKeyCap = (int)keyOff; P.totalOut = outBase; P.pyrBytes = imgOff;
     full = P;
     // Detect(): level 0 only, budget = nfeatures (ORBextractor.cpp:1064-1065)
     det = P;
     det.nlevels = 1;
     det.ncells = P.lv[0].nCols * P.lv[0].nRows;
+    det.nstrips = P.lv[0].nRows * ((P.lv[0].nCols + 3) / 4);
     det.lv[0].N = nfeatures;
     det.lv[0].nodeCap = (std::max(nfeatures + 4, 4 * P.lv[0].nIni + 4) + 3) & ~3;
     if (det.lv[0].nodeCap > 4092) return MYSLAM_ERR_UNSUPPORTED;

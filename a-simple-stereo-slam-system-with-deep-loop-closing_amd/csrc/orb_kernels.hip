@@ -547,6 +547,147 @@ __global__ __launch_bounds__(T) void k_fast_cells_v3(OrbPlan P, const uint8_t* _
     }
 }
 
+// ---- strip variant: one block scores G horizontally adjacent cells -----------------------------------
+// Same arithmetic as k_fast_cells_v3 per cell (NMS and the 20 -> 7 fallback never cross a cell border), but the
+// ROI rows of G cells are staged once (shared 6-px halos), block dispatch / barriers / the global append are
+// amortised over G cells.
+template <int CW, int G>
+__global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __restrict__ pyr, size_t pyrStride,
+                                                    const uint8_t* __restrict__ maskPyr,
+                                                    uint32_t* __restrict__ cand, int32_t* __restrict__ candCount) {
+    constexpr int T = 256;
+    constexpr int TP = (3 + G * CW + 6 + 16 + 3) & ~3;
+    constexpr int TROWS = CW + 6;
+    constexpr int SP = (CW + 4 + 8 + 3) & ~3;
+    constexpr int SROWS = CW + 2;
+    constexpr int NLOC = ((CW + 1) / 2) * ((CW + 1) / 2);
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[TROWS * TP + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t s_score[G][SROWS * SP + 16];
+    __shared__ uint32_t s_list[G][NLOC];
+    __shared__ int s_cnt[G], s_ini[G], s_base, s_npass, s_wr;
+
+    const int b = blockIdx.y;
+    int level = 0;
+    for (int l = 1; l < P.nlevels; l++) if ((int)blockIdx.x >= P.lv[l].stripBase) level = l;
+    const LevelGeom& g = P.lv[level];
+    const int spr = (g.nCols + G - 1) / G;                             // strips per cell row
+    const int strip = blockIdx.x - g.stripBase;
+    const int ci = strip / spr, cj0 = (strip - ci * spr) * G;
+    const int iniY = MIN_BORDER + ci * g.hCell;
+    if (iniY >= g.maxBY - 3) return;                                   // :843
+    const int maxY = min(iniY + g.hCell + 6, g.maxBY);
+    const int hr = maxY - iniY, hc = hr - 6;
+    if (hc <= 0) return;
+    // cells of this strip: interior widths (0 = cell skipped, :852)
+    int wcs[G];
+    int ncell = 0;
+#pragma unroll
+    for (int c = 0; c < G; c++) {
+        const int cj = cj0 + c;
+        const int iniX = MIN_BORDER + cj * g.wCell;
+        int wc = 0;
+        if (cj < g.nCols && iniX < g.maxBX - 6) wc = max(0, min(iniX + g.wCell + 6, g.maxBX) - iniX - 6);
+        wcs[c] = wc;
+        if (wc > 0) ncell = c + 1;
+    }
+    if (ncell == 0) return;
+    const int iniX0 = MIN_BORDER + cj0 * g.wCell;
+    const int endX = MIN_BORDER + (cj0 + ncell - 1) * g.wCell + wcs[ncell - 1] + 6;     // exclusive right edge of the last ROI
+    const uint8_t* img = pyr + (size_t)b * pyrStride + g.imgOff;
+    const int x0a = iniX0 & ~3, off = iniX0 - x0a;
+    const int ndw = (endX - x0a + 3) >> 2;
+    for (int i = threadIdx.x; i < hr * 64; i += T) {                   // ndw <= 64 dwords per row
+        const int r = i >> 6, k = i & 63;
+        if (k < ndw) *reinterpret_cast<uint32_t*>(&s_tile[r * TP + 4 * k]) =
+            *reinterpret_cast<const uint32_t*>(img + (size_t)(iniY + r) * g.pitch + x0a + 4 * k);
+    }
+    for (int i = threadIdx.x; i < G * ((SROWS * SP + 16) / 4); i += T) reinterpret_cast<uint32_t*>(&s_score[0][0])[i] = 0;
+    if (threadIdx.x < G) { s_cnt[threadIdx.x] = 0; s_ini[threadIdx.x] = 0; }
+    __syncthreads();
+
+    const int ngr = (g.wCell + 3) >> 2, per_cell = ngr * hc, nitems = ncell * per_cell;
+    for (int q = threadIdx.x; q < nitems; q += T) {
+        const int c = q / per_cell, rem = q - c * per_cell;
+        const int cy = rem / ngr, gi = rem - cy * ngr;
+        const int wc = (c == 0) ? wcs[0] : (c == 1) ? wcs[1 % G] : (c == 2) ? wcs[2 % G] : wcs[3 % G];
+        const int cx = 4 * gi;
+        if (cx >= wc) continue;
+        const int col = off + c * g.wCell + cx;                        // tile byte of ROI column cx of cell c
+        const uint32_t sh = (uint32_t)(col & 3);
+        uint32_t r[7][3];
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const uint32_t* rp = reinterpret_cast<const uint32_t*>(&s_tile[(cy + j) * TP + (col & ~3)]);
+            const uint32_t w0 = rp[0], w1 = rp[1], w2 = rp[2], w3 = rp[3];
+            r[j][0] = __builtin_amdgcn_alignbyte(w1, w0, sh);
+            r[j][1] = __builtin_amdgcn_alignbyte(w2, w1, sh);
+            r[j][2] = __builtin_amdgcn_alignbyte(w3, w2, sh);
+        }
+        uint32_t s0 = fast9_score_regs<0>(r, P.minTh), s1 = fast9_score_regs<1>(r, P.minTh);
+        uint32_t s2 = fast9_score_regs<2>(r, P.minTh), s3 = fast9_score_regs<3>(r, P.minTh);
+        if (cx + 1 >= wc) s1 = 0;
+        if (cx + 2 >= wc) s2 = 0;
+        if (cx + 3 >= wc) s3 = 0;
+        *reinterpret_cast<uint32_t*>(&s_score[c][(cy + 1) * SP + 4 + cx]) = s0 | (s1 << 8) | (s2 << 16) | (s3 << 24);
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < nitems; q += T) {
+        const int c = q / per_cell, rem = q - c * per_cell;
+        const int cy = rem / ngr, gi = rem - cy * ngr;
+        const int wc = (c == 0) ? wcs[0] : (c == 1) ? wcs[1 % G] : (c == 2) ? wcs[2 % G] : wcs[3 % G];
+        if (4 * gi >= wc) continue;
+        uint32_t m[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const uint32_t* rp = reinterpret_cast<const uint32_t*>(&s_score[c][(cy + j) * SP + 4 * gi]);
+            m[j][0] = rp[0]; m[j][1] = rp[1]; m[j][2] = rp[2];
+        }
+        int sc[4]; bool mx[4];
+        mx[0] = nms_regs<0>(m, sc[0]); mx[1] = nms_regs<1>(m, sc[1]); mx[2] = nms_regs<2>(m, sc[2]); mx[3] = nms_regs<3>(m, sc[3]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (mx[k]) {
+                const int px = 4 * gi + k + 3 + (cj0 + c) * g.wCell, py = cy + 3 + ci * g.hCell;     // border-relative
+                const int pos = atomicAdd(&s_cnt[c], 1);
+                if (pos < NLOC) s_list[c][pos] = ((uint32_t)py << 20) | ((uint32_t)px << 8) | (uint32_t)sc[k];
+                if (sc[k] >= P.iniTh) s_ini[c] = 1;
+            }
+        }
+    }
+    if (threadIdx.x == 0) { s_npass = 0; s_wr = 0; }
+    __syncthreads();
+    const uint8_t* mimg = maskPyr ? maskPyr + (size_t)b * pyrStride + g.imgOff : nullptr;
+    auto passes = [&](uint32_t kp, int has_ini) -> bool {
+        if (has_ini && (int)(kp & 0xff) < P.iniTh) return false;      // :858-865: th 20 if the cell has any, else th 7
+        if (mimg) {                                                   // :873-877 (no +16: reference quirk)
+            const int px = (kp >> 8) & 0xfff, py = kp >> 20;
+            if (mimg[(size_t)py * g.pitch + px] == 0) return false;
+        }
+        return true;
+    };
+    int npass = 0;
+    for (int c = 0; c < ncell; c++) {
+        const int nloc = min(s_cnt[c], NLOC), hi = s_ini[c];
+        for (int i = threadIdx.x; i < nloc; i += T) npass += passes(s_list[c][i], hi) ? 1 : 0;
+    }
+    if (npass) atomicAdd(&s_npass, npass);
+    __syncthreads();
+    const int n = s_npass;
+    if (n == 0) return;
+    if (threadIdx.x == 0) s_base = atomicAdd(&candCount[b * MAXL + level], n);
+    __syncthreads();
+    uint32_t* out = cand + (size_t)b * P.totalKeyCap + g.keyOff;
+    for (int c = 0; c < ncell; c++) {
+        const int nloc = min(s_cnt[c], NLOC), hi = s_ini[c];
+        for (int i = threadIdx.x; i < nloc; i += T) {
+            const uint32_t kp = s_list[c][i];
+            if (!passes(kp, hi)) continue;
+            const int dst = s_base + atomicAdd(&s_wr, 1);
+            if (dst < g.keyCap) out[dst] = kp;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K4: oct-tree keypoint distribution, one 256-thread block per (level, image), all levels in one launch.
 //
@@ -1331,7 +1472,12 @@ void launch_fast(const OrbPlan& P, const uint8_t* pyr, size_t pyrStride, const u
     static const char* env = getenv("MYSLAM_FAST_T");           // tuning aid: threads per cell (64 | 256)
     const int T = env ? atoi(env) : 256;
     static const char* envv = getenv("MYSLAM_FAST_V");          // tuning aid: 2 = LDS byte-read two-phase kernel, 3 = register tiles
-    const int V = envv ? atoi(envv) : 3;
+    const int V = envv ? atoi(envv) : 4;
+    if (V == 4) {      // strips of 4 cells per block
+        if (cw <= 40) hipLaunchKernelGGL((k_fast_strip<40, 4>), dim3(P.nstrips, batch), dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount);
+        else hipLaunchKernelGGL((k_fast_strip<MAX_CELL, 4>), dim3(P.nstrips, batch), dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount);
+        return;
+    }
     if (V == 3) {
         if (cw <= 40) hipLaunchKernelGGL((k_fast_cells_v3<256, 40>), dim3(P.ncells, batch), dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount);
         else hipLaunchKernelGGL((k_fast_cells_v3<256, MAX_CELL>), dim3(P.ncells, batch), dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount);

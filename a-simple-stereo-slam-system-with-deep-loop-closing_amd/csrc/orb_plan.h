@@ -20,6 +20,7 @@ struct LevelGeom {
     int nCols, nRows, wCell, hCell;   // FAST grid, ORBextractor.cpp:830-836
     int maxBX, maxBY;                 // maxBorderX/Y, :824-825
     int cellBase;                     // first cell index of this level in the per-image cell list
+    int stripBase;                    // first strip (4 horizontally adjacent cells) of this level
     int N;                            // oct-tree budget mnFeaturesPerLevel[l] (:410-421) or nfeatures (Detect)
     int nIni;                         // root nodes, :590
     float hX;                         // :592
@@ -38,6 +39,7 @@ struct OrbPlan {
     int nlevels;
     int rows, cols;
     int ncells;                       // total FAST cells per image
+    int nstrips;                      // total 4-cell strips per image
     int iniTh, minTh;
     int totalKeyCap;                  // sum keyCap
     int totalOut;                     // sum nodeCap
