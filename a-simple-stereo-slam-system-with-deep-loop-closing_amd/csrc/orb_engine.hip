@@ -165,7 +165,7 @@ int myslam_orb::make_plan(int r, int c) {
         const int rootW = (int)ceilf(g.hX) + 2, H = g.maxBY - MIN_BORDER;
         g.ndepth = std::min(MAX_DEPTH, ceil_log2(std::max(rootW, H)) + 2);
         g.sortDepth = 0;
-        while (g.sortDepth + 1 <= g.ndepth && (g.nIni << (2 * (g.sortDepth + 1))) <= 4096) g.sortDepth++;
+        while (g.sortDepth + 1 <= g.ndepth && (g.nIni << (2 * (g.sortDepth + 1))) <= 1024) g.sortDepth++;
         // a cell interior of a x b pixels holds at most ceil(a/2)*ceil(b/2) strict 8-neighbour maxima: no overflow possible
         g.keyCap = (int)std::min<size_t>(262143, std::max<size_t>(256, (size_t)((g.w + 1) / 2) * ((g.h + 1) / 2)));
         g.nodeCap = (std::max(g.N + 4, 4 * g.nIni + 4) + 3) & ~3;

@@ -695,7 +695,7 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
 // key vectors (ORBextractor.cpp:586-810).  Here every key gets its quad-tree PATH CODE up front (root
 // index + 2 bits per depth, derived with the reference's ceil-halving bounds).  Keys are bucketed by the
 // first D levels of the code with ONE counting sort whose histogram lives in LDS (D chosen so that
-// nIni*4^D <= 4096 buckets); the exclusive bucket offsets then give the key range of ANY node of depth
+// nIni*4^D <= 1024 buckets); the exclusive bucket offsets then give the key range of ANY node of depth
 // <= D, and of its 4 children, by table lookup — the node-list simulation touches no global memory.
 // A node deeper than D (only reached when many keys crowd into one ~10-px cell) is split on demand by
 // partitioning its own key range in place on the next code digit.  Order inside a node is irrelevant:
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
 // same deterministic choice the oracle makes.
 // ------------------------------------------------------------------------------------------------
 constexpr int OT = 256;
-constexpr int OT_MAXB = 4096;        // buckets of the counting sort
+constexpr int OT_MAXB = 1024;        // buckets of the counting sort
 
 __device__ __forceinline__ uint64_t wave_incl_scan64(uint64_t v) {
     const int lane = threadIdx.x & 63;

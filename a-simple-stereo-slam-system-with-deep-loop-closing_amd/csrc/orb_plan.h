@@ -24,7 +24,7 @@ struct LevelGeom {
     int N;                            // oct-tree budget mnFeaturesPerLevel[l] (:410-421) or nfeatures (Detect)
     int nIni;                         // root nodes, :590
     float hX;                         // :592
-    int sortDepth;                    // D: quad-tree levels covered by the LDS counting sort (nIni*4^D <= 4096 buckets)
+    int sortDepth;                    // D: quad-tree levels covered by the LDS counting sort (nIni*4^D <= 1024 buckets)
     int ndepth;                       // quad-tree depth digits that can ever matter (<= MAX_DEPTH)
     int keyCap;                       // candidate capacity of the level
     int nodeCap;                      // node-list capacity (>= N+3)
