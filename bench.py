@@ -44,7 +44,7 @@ def pmc_traffic(kernel, pairs):
     if not files:
         return None
     d = json.load(open(files[-1]))
-    tag = {"fast_cells": "k_fast_cells", "octree": "k_octree", "blur7": "k_blur7", "resize": "k_resize", "describe": "k_describe"}.get(kernel)
+    tag = {"fast_cells": "k_fast", "octree": "k_octree", "blur7": "k_blur7", "resize": "k_resize", "describe": "k_describe"}.get(kernel)
     for name, v in d["kernels"].items():
         if tag and name.startswith(tag):
             kb = v.get("FETCH_SIZE_KB_per_launch", 0) + v.get("WRITE_SIZE_KB_per_launch", 0)
