@@ -158,12 +158,19 @@ __device__ __forceinline__ void ba_edge(const double* R, const double* pw, const
         for (int c = 0; c < 3; c++) Jp[r * 3 + c] = J[r * 6] * R[c] + J[r * 6 + 1] * R[3 + c] + J[r * 6 + 2] * R[6 + c];
 }
 
+constexpr int BA_NT = 512;             // threads per window
+constexpr int BA_NW = BA_NT / 64;
+constexpr int BA_CL = 32;              // landmarks per Schur chunk
+
 __device__ __forceinline__ double block_sum(double v, double* s_red) {
     v = wave_reduce_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
     __syncthreads();
-    return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < BA_NW; i++) s += s_red[i];
+    return s;
 }
 
 // Sophus SE3d::exp(d) * T, d = (upsilon, omega); R|t stored as 12 doubles
@@ -198,11 +205,24 @@ __device__ void pose_oplus(double* T, const double* d) {
     for (int i = 0; i < 12; i++) T[i] = N[i];
 }
 
-__global__ __launch_bounds__(256) void k_ba_optimize(BaOptArgs a) {
+// Work decomposition (one 512-thread block per window, nothing but the per-pose edge index leaves LDS):
+//   build     pose pass: one wave per pose walks that pose's edge list (stable, built once by ballot scans), 27 register
+//             accumulators (Hpp upper triangle + bp), wave reduction, no atomics;
+//             landmark pass: one thread per landmark walks its edge group -> Hll, bl, robust chi2.
+//   Schur     per trial: G_l with (Hll+lambda I)^-1 = G G^T (G = L^-T of the 3x3 Cholesky); landmarks are processed in
+//             chunks of 32: V_{l,p} = W_{l,p} G_l (6x3, W recomputed from the edge) is staged in LDS, then thread
+//             (pose pair p1>=p2, 4-landmark slice) accumulates the 6x6 block sum V_{l,p1} V_{l,p2}^T in registers over ALL
+//             chunks and adds it to S once at the end (8 partial sums per entry).
+//   Cholesky  6x6-blocked right-looking factorisation of the 6P x 6P lower triangle (3 barriers per block column).
+//   solve     one wave, lane = row, shuffles; landmark back-substitution one thread per landmark.
+__global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
     extern __shared__ __attribute__((aligned(16))) double s_d[];
-    __shared__ double s_red[4];
-    __shared__ double s_sc[8];      // [0] lambda [1] ni [2] curChi [3] tmpChi [4] rho [5] ok
-    const int w = blockIdx.x, t = threadIdx.x;
+    __shared__ double s_red[BA_NW];
+    __shared__ double s_sc[8];      // [0] lambda [1] ni [2] curChi [5] ok
+    __shared__ int s_poff[16];
+    __shared__ int s_mask[BA_CL];
+    __shared__ int s_bad;
+    const int w = blockIdx.x, t = threadIdx.x, wv = t >> 6, lane = t & 63;
     const int P = a.sizes ? a.sizes[3 * w] : a.nposes;
     const int L = a.sizes ? a.sizes[3 * w + 1] : a.npts;
     const int E = a.sizes ? a.sizes[3 * w + 2] : a.nedges;
@@ -215,23 +235,24 @@ __global__ __launch_bounds__(256) void k_ba_optimize(BaOptArgs a) {
     double* sPtb = sPt + a.maxL * 3;
     double* sHll = sPtb + a.maxL * 3;         // maxL x 6
     double* sbl = sHll + a.maxL * 6;          // maxL x 3
-    double* sHinv = sbl + a.maxL * 3;         // maxL x 6
-    double* sxl = sHinv + a.maxL * 6;         // maxL x 3
-    double* sS = sxl + a.maxL * 3;            // (6 maxP)^2
+    double* sG = sbl + a.maxL * 3;            // maxL x 6   upper-triangular G (g00 g01 g02 g11 g12 g22)
+    double* sS = sG + a.maxL * 6;             // (6 maxP)^2
     double* srhs = sS + 36 * a.maxP * a.maxP; // 6 maxP
-    int* lbeg = reinterpret_cast<int*>(srhs + 6 * a.maxP);   // maxL
+    double* sinvd = srhs + 6 * a.maxP;        // 6 maxP     1 / diag(chol(S))
+    double* sV = sinvd + 6 * a.maxP;          // BA_CL x maxP x 18
+    int* lbeg = reinterpret_cast<int*>(sV + BA_CL * a.maxP * 18);   // maxL
     int* lend = lbeg + a.maxL;
-    int* s_bad = lend + a.maxL;
     double* poses = a.poses + (size_t)w * a.maxP * 7;
     double* pts = a.points + (size_t)w * a.maxL * 3;
     const int32_t* ep = a.ep + (size_t)w * a.maxE;
     const int32_t* el = a.el + (size_t)w * a.maxE;
     const double* obs = a.obs + (size_t)w * a.maxE * 2;
     const uint8_t* fixed = a.fixed ? a.fixed + (size_t)w * a.maxL : nullptr;
-    double* Wk = a.W + (size_t)w * a.maxE * 18;
+    int* plist = reinterpret_cast<int*>(a.W + (size_t)w * a.maxE * 18);     // edges sorted by pose (stable)
+    const double d2 = a.delta * a.delta;
 
     // ---- load state, landmark -> edge range ----
-    for (int p = t; p < P; p += 256) {
+    for (int p = t; p < P; p += BA_NT) {
         double x = poses[7 * p], y = poses[7 * p + 1], z = poses[7 * p + 2], q = poses[7 * p + 3];
         const double nn = sqrt(x * x + y * y + z * z + q * q);
         x /= nn; y /= nn; z /= nn; q /= nn;
@@ -241,88 +262,148 @@ __global__ __launch_bounds__(256) void k_ba_optimize(BaOptArgs a) {
         R[6] = 2 * (x * z - y * q);     R[7] = 2 * (y * z + x * q);     R[8] = 1 - 2 * (x * x + y * y);
         R[9] = poses[7 * p + 4]; R[10] = poses[7 * p + 5]; R[11] = poses[7 * p + 6];
     }
-    for (int i = t; i < 3 * L; i += 256) sPt[i] = pts[i];
-    for (int l = t; l < L; l += 256) { lbeg[l] = 0; lend[l] = 0; }
-    if (t == 0) *s_bad = 0;
+    for (int i = t; i < 3 * L; i += BA_NT) sPt[i] = pts[i];
+    for (int l = t; l < L; l += BA_NT) { lbeg[l] = 0; lend[l] = 0; }
+    if (t == 0) s_bad = 0;
     __syncthreads();
-    for (int k = t; k < E; k += 256) {
+    for (int k = t; k < E; k += BA_NT) {
         const int l = el[k], p = ep[k];
-        if (l < 0 || l >= L || p < 0 || p >= P) { atomicAdd(s_bad, 1); continue; }
+        if (l < 0 || l >= L || p < 0 || p >= P) { atomicAdd(&s_bad, 1); continue; }
         if (k == 0 || el[k - 1] != l) { lbeg[l] = k; atomicAdd(&lend[l], 1); }      // first edge of a group
     }
     __syncthreads();
     // lend[l] now counts the groups of landmark l: more than one group = edges not grouped by landmark
-    for (int l = t; l < L; l += 256) if (lend[l] > 1) atomicAdd(s_bad, 1);
+    for (int l = t; l < L; l += BA_NT) if (lend[l] > 1) atomicAdd(&s_bad, 1);
     __syncthreads();
-    if (*s_bad) { if (t == 0) { a.status[w] = MYSLAM_ERR_INVALID; a.iters[w] = 0; a.final_chi2[w] = 0; } return; }
-    for (int l = t; l < L; l += 256) {
+    if (s_bad) { if (t == 0) { a.status[w] = MYSLAM_ERR_INVALID; a.iters[w] = 0; a.final_chi2[w] = 0; } return; }
+    for (int l = t; l < L; l += BA_NT) {
         if (lend[l] == 0) { lbeg[l] = 0; continue; }
         int k = lbeg[l];
         while (k < E && el[k] == l) k++;
         lend[l] = k;
     }
+    // ---- per-pose edge lists, in edge order (ballot scan: deterministic) ----
+    for (int p = wv; p < P; p += BA_NW) {
+        int cnt = 0;
+        for (int k0 = 0; k0 < E; k0 += 64) {
+            const int k = k0 + lane;
+            cnt += __popcll(__ballot(k < E && ep[k] == p));
+        }
+        if (lane == 0) s_poff[p + 1] = cnt;
+    }
+    __syncthreads();
+    if (t == 0) { s_poff[0] = 0; for (int p = 0; p < P; p++) s_poff[p + 1] += s_poff[p]; }
+    __syncthreads();
+    for (int p = wv; p < P; p += BA_NW) {
+        int base = s_poff[p];
+        for (int k0 = 0; k0 < E; k0 += 64) {
+            const int k = k0 + lane;
+            const bool m = k < E && ep[k] == p;
+            const unsigned long long bm = __ballot(m);
+            if (m) plist[base + __popcll(bm & ((1ull << lane) - 1ull))] = k;
+            base += __popcll(bm);
+        }
+    }
     __syncthreads();
 
     auto robust_chi2 = [&]() -> double {          // activeRobustChi2()
         double acc = 0;
-        for (int k = t; k < E; k += 256) {
+        for (int k = t; k < E; k += BA_NT) {
             double e0, e1;
             ba_edge(sR + 12 * ep[k], sPt + 3 * el[k], obs + 2 * k, a.fx, a.fy, a.cx, a.cy, e0, e1, nullptr, nullptr);
-            const double e2 = e0 * e0 + e1 * e1, d2 = a.delta * a.delta;
+            const double e2 = e0 * e0 + e1 * e1;
             acc += (e2 <= d2) ? e2 : 2 * sqrt(e2) * a.delta - d2;
         }
         return block_sum(acc, s_red);
     };
 
+    // the (pose pair, landmark slice) this thread owns in the Schur accumulation
+    const int npairs = P * (P + 1) / 2;
+    constexpr int NSL = 8, SLW = BA_CL / NSL;            // 8 slices of 4 landmarks per chunk
+    int sp1 = -1, sp2 = -1, ssl = 0;
+    {
+        // unit u = slice * npairs + pair (P <= 10 -> at most 440 units, one per thread)
+        const int u = t;
+        if (u < npairs * NSL) {
+            ssl = u / npairs;
+            int pr = u % npairs, r = 0;
+            while (pr >= r + 1) { pr -= r + 1; r++; }    // pair index -> (row r, col pr), r >= pr
+            sp1 = r; sp2 = pr;
+        }
+    }
+
     int it = 0;
     for (; it < a.max_iters; it++) {
         // ---- build H, b at the current estimate ----
-        for (int i = t; i < a.maxP * 27; i += 256) sHpp[i] = 0.0;     // sHpp (maxP x 21) and sbp (maxP x 6) are contiguous
-        for (int i = t; i < a.maxL * 9; i += 256) sHll[i] = 0.0;      // sHll (maxL x 6) and sbl (maxL x 3) are contiguous
-        __syncthreads();
-        double acc = 0;
-        for (int k = t; k < E; k += 256) {
-            const int ip = ep[k], il = el[k];
-            double e0, e1, J[12], Jp[6];
-            ba_edge(sR + 12 * ip, sPt + 3 * il, obs + 2 * k, a.fx, a.fy, a.cx, a.cy, e0, e1, J, Jp);
-            const double e2 = e0 * e0 + e1 * e1, d2 = a.delta * a.delta;
-            const double wgt = (e2 <= d2) ? 1.0 : a.delta / sqrt(e2);
-            acc += (e2 <= d2) ? e2 : 2 * sqrt(e2) * a.delta - d2;
-            double* hp = sHpp + 21 * ip;
-            int u = 0;
+        for (int p = wv; p < P; p += BA_NW) {
+            double h[27];
 #pragma unroll
-            for (int r = 0; r < 6; r++) {
+            for (int u = 0; u < 27; u++) h[u] = 0.0;
+            for (int i = s_poff[p] + lane; i < s_poff[p + 1]; i += 64) {
+                const int k = plist[i];
+                double e0, e1, J[12], Jp[6];
+                ba_edge(sR + 12 * p, sPt + 3 * el[k], obs + 2 * k, a.fx, a.fy, a.cx, a.cy, e0, e1, J, Jp);
+                const double e2 = e0 * e0 + e1 * e1;
+                const double wgt = (e2 <= d2) ? 1.0 : a.delta / sqrt(e2);
+                int u = 0;
 #pragma unroll
-                for (int c = r; c < 6; c++) atomicAdd(&hp[u++], wgt * (J[r] * J[c] + J[6 + r] * J[6 + c]));
-                atomicAdd(&sbp[6 * ip + r], -wgt * (J[r] * e0 + J[6 + r] * e1));
+                for (int r = 0; r < 6; r++) {
+#pragma unroll
+                    for (int c = r; c < 6; c++) h[u++] += wgt * (J[r] * J[c] + J[6 + r] * J[6 + c]);
+                }
+#pragma unroll
+                for (int r = 0; r < 6; r++) h[21 + r] += -wgt * (J[r] * e0 + J[6 + r] * e1);
             }
-            const bool fx_pt = fixed && fixed[il];
-            if (!fx_pt) {
-                double* hl = sHll + 6 * il;
+#pragma unroll
+            for (int u = 0; u < 27; u++) h[u] = wave_reduce_sum(h[u]);
+            if (lane == 0) {
+#pragma unroll
+                for (int u = 0; u < 21; u++) sHpp[21 * p + u] = h[u];
+#pragma unroll
+                for (int r = 0; r < 6; r++) sbp[6 * p + r] = h[21 + r];
+            }
+        }
+        double acc = 0;
+        for (int l = t; l < L; l += BA_NT) {
+            double hl[9];
+#pragma unroll
+            for (int u = 0; u < 9; u++) hl[u] = 0.0;
+            const bool fx_pt = fixed && fixed[l];
+            for (int k = lbeg[l]; k < lend[l]; k++) {
+                double e0, e1, J[12], Jp[6];
+                ba_edge(sR + 12 * ep[k], sPt + 3 * l, obs + 2 * k, a.fx, a.fy, a.cx, a.cy, e0, e1, J, Jp);
+                const double e2 = e0 * e0 + e1 * e1;
+                const double wgt = (e2 <= d2) ? 1.0 : a.delta / sqrt(e2);
+                acc += (e2 <= d2) ? e2 : 2 * sqrt(e2) * a.delta - d2;
                 int v = 0;
 #pragma unroll
                 for (int r = 0; r < 3; r++) {
 #pragma unroll
-                    for (int c = r; c < 3; c++) atomicAdd(&hl[v++], wgt * (Jp[r] * Jp[c] + Jp[3 + r] * Jp[3 + c]));
-                    atomicAdd(&sbl[3 * il + r], -wgt * (Jp[r] * e0 + Jp[3 + r] * e1));
+                    for (int c = r; c < 3; c++) hl[v++] += wgt * (Jp[r] * Jp[c] + Jp[3 + r] * Jp[3 + c]);
                 }
+#pragma unroll
+                for (int r = 0; r < 3; r++) hl[6 + r] += -wgt * (Jp[r] * e0 + Jp[3 + r] * e1);
             }
 #pragma unroll
-            for (int r = 0; r < 6; r++)
+            for (int u = 0; u < 6; u++) sHll[6 * l + u] = fx_pt ? 0.0 : hl[u];
 #pragma unroll
-                for (int c = 0; c < 3; c++) Wk[(size_t)k * 18 + r * 3 + c] = fx_pt ? 0.0 : wgt * (J[r] * Jp[c] + J[6 + r] * Jp[3 + c]);
+            for (int r = 0; r < 3; r++) sbl[3 * l + r] = fx_pt ? 0.0 : hl[6 + r];
         }
         const double curChi0 = block_sum(acc, s_red);
         if (it == 0) {                               // computeLambdaInit: tau * max |diag(H)|
             double mx = 0;
-            for (int i = t; i < P * 6; i += 256) { const int p = i / 6, r = i % 6; mx = fmax(mx, fabs(sHpp[21 * p + r * 6 - r * (r - 1) / 2])); }
-            for (int i = t; i < L * 3; i += 256) { const int l = i / 3, r = i % 3; if (!(fixed && fixed[l])) mx = fmax(mx, fabs(sHll[6 * l + r * 3 - r * (r - 1) / 2])); }
+            for (int i = t; i < P * 6; i += BA_NT) { const int p = i / 6, r = i % 6; mx = fmax(mx, fabs(sHpp[21 * p + r * 6 - r * (r - 1) / 2])); }
+            for (int i = t; i < L * 3; i += BA_NT) { const int l = i / 3, r = i % 3; if (!(fixed && fixed[l])) mx = fmax(mx, fabs(sHll[6 * l + r * 3 - r * (r - 1) / 2])); }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
             __syncthreads();
-            if ((t & 63) == 0) s_red[t >> 6] = mx;
+            if (lane == 0) s_red[wv] = mx;
             __syncthreads();
-            if (t == 0) { s_sc[0] = 1e-5 * fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3])); s_sc[1] = 2.0; }
+            if (t == 0) {
+                double m = 0;
+                for (int i = 0; i < BA_NW; i++) m = fmax(m, s_red[i]);
+                s_sc[0] = 1e-5 * m; s_sc[1] = 2.0;
+            }
         }
         if (t == 0) s_sc[2] = curChi0;
         __syncthreads();
@@ -332,69 +413,169 @@ __global__ __launch_bounds__(256) void k_ba_optimize(BaOptArgs a) {
         do {
             const double lambda = s_sc[0];
             // backup (optimizer->push())
-            for (int i = t; i < P * 12; i += 256) sRb[i] = sR[i];
-            for (int i = t; i < L * 3; i += 256) sPtb[i] = sPt[i];
-            // reduced system: S = Hpp + lambda I, rhs = bp
-            for (int i = t; i < n * n; i += 256) sS[i] = 0.0;
+            for (int i = t; i < P * 12; i += BA_NT) sRb[i] = sR[i];
+            for (int i = t; i < L * 3; i += BA_NT) sPtb[i] = sPt[i];
+            // reduced system: S = Hpp + lambda I (lower triangle), rhs = bp
+            for (int i = t; i < n * n; i += BA_NT) sS[i] = 0.0;
+            if (t == 0) s_sc[5] = 1.0;
             __syncthreads();
-            for (int i = t; i < P * 36; i += 256) {
+            for (int i = t; i < P * 36; i += BA_NT) {
                 const int p = i / 36, r = (i % 36) / 6, c = i % 6;
                 const int rr = min(r, c), cc = max(r, c);
                 sS[(6 * p + r) * n + 6 * p + c] = sHpp[21 * p + rr * 6 - rr * (rr - 1) / 2 + (cc - rr)] + (r == c ? lambda : 0.0);
             }
-            for (int i = t; i < n; i += 256) srhs[i] = sbp[i];
-            if (t == 0) s_sc[5] = 1.0;
-            __syncthreads();
-            // landmarks: Hinv = (Hll + lambda I)^-1, Schur complement into S / rhs
-            for (int l = t; l < L; l += 256) {
-                const int kb = lbeg[l], ke = lend[l];
-                if ((fixed && fixed[l]) || ke <= kb) { for (int i = 0; i < 6; i++) sHinv[6 * l + i] = 0.0; continue; }
+            for (int i = t; i < n; i += BA_NT) srhs[i] = sbp[i];
+            // landmarks: (Hll + lambda I) = Lc Lc^T, G = Lc^-T (upper), so that (Hll + lambda I)^-1 = G G^T
+            for (int l = t; l < L; l += BA_NT) {
+                double* g = sG + 6 * l;
+                if ((fixed && fixed[l]) || lend[l] <= lbeg[l]) { for (int i = 0; i < 6; i++) g[i] = 0.0; continue; }
                 const double* h = sHll + 6 * l;
                 const double a00 = h[0] + lambda, a01 = h[1], a02 = h[2], a11 = h[3] + lambda, a12 = h[4], a22 = h[5] + lambda;
-                const double c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
-                const double det = a00 * c00 + a01 * c01 + a02 * c02;
-                if (det == 0.0 || !isfinite(det)) { s_sc[5] = 0.0; continue; }
-                const double id = 1.0 / det;
-                const double Hi[9] = {c00 * id, c01 * id, c02 * id, c01 * id, (a00 * a22 - a02 * a02) * id, (a01 * a02 - a00 * a12) * id,
-                                      c02 * id, (a01 * a02 - a00 * a12) * id, (a00 * a11 - a01 * a01) * id};
-                sHinv[6 * l] = Hi[0]; sHinv[6 * l + 1] = Hi[1]; sHinv[6 * l + 2] = Hi[2]; sHinv[6 * l + 3] = Hi[4]; sHinv[6 * l + 4] = Hi[5]; sHinv[6 * l + 5] = Hi[8];
-                const double b0 = sbl[3 * l], b1 = sbl[3 * l + 1], b2 = sbl[3 * l + 2];
-                for (int k1 = kb; k1 < ke; k1++) {
-                    const double* W1 = Wk + (size_t)k1 * 18;
-                    double WH[18];
+                const double l00 = sqrt(a00), l10 = a01 / l00, l20 = a02 / l00;
+                const double d11 = a11 - l10 * l10, l11 = sqrt(d11), l21 = (a12 - l20 * l10) / l11;
+                const double d22 = a22 - l20 * l20 - l21 * l21, l22 = sqrt(d22);
+                if (!(a00 > 0.0) || !(d11 > 0.0) || !(d22 > 0.0) || !isfinite(l22)) { s_sc[5] = 0.0; for (int i = 0; i < 6; i++) g[i] = 0.0; continue; }
+                // M = Lc^-1 (lower): m00 = 1/l00, m11 = 1/l11, m22 = 1/l22, m10 = -l10 m00 m11, m21 = -l21 m11 m22,
+                // m20 = -(l20 m00 + l21 m10) m22;  G = M^T
+                const double m00 = 1.0 / l00, m11 = 1.0 / l11, m22 = 1.0 / l22;
+                const double m10 = -l10 * m00 * m11, m21 = -l21 * m11 * m22, m20 = -(l20 * m00 + l21 * m10) * m22;
+                g[0] = m00; g[1] = m10; g[2] = m20; g[3] = m11; g[4] = m21; g[5] = m22;
+            }
+            __syncthreads();
+            // ---- Schur complement, chunk by chunk ----
+            double sacc[36], racc[6];
 #pragma unroll
-                    for (int r = 0; r < 6; r++)
+            for (int i = 0; i < 36; i++) sacc[i] = 0.0;
 #pragma unroll
-                        for (int c = 0; c < 3; c++) WH[r * 3 + c] = W1[r * 3] * Hi[c] + W1[r * 3 + 1] * Hi[3 + c] + W1[r * 3 + 2] * Hi[6 + c];
-                    const int p1 = ep[k1];
+            for (int i = 0; i < 6; i++) racc[i] = 0.0;
+            for (int l0 = 0; l0 < L; l0 += BA_CL) {
+                const int nl = min(BA_CL, L - l0);
+                for (int i = t; i < nl * a.maxP * 18; i += BA_NT) sV[i] = 0.0;
+                if (t < BA_CL) s_mask[t] = 0;
+                __syncthreads();
+                // stage V_{l,p} = sum over the (l,p) edges of W_k G_l, W_k = w J^T Jp
+                for (int ll = t >> 4; ll < nl; ll += BA_NT / 16) {
+                    const int l = l0 + ll;
+                    if (fixed && fixed[l]) continue;
+                    const double* g = sG + 6 * l;
+                    const double g00 = g[0], g01 = g[1], g02 = g[2], g11 = g[3], g12 = g[4], g22 = g[5];
+                    for (int k = lbeg[l] + (t & 15); k < lend[l]; k += 16) {
+                        const int p = ep[k];
+                        double e0, e1, J[12], Jp[6];
+                        ba_edge(sR + 12 * p, sPt + 3 * l, obs + 2 * k, a.fx, a.fy, a.cx, a.cy, e0, e1, J, Jp);
+                        const double e2 = e0 * e0 + e1 * e1;
+                        const double wgt = (e2 <= d2) ? 1.0 : a.delta / sqrt(e2);
+                        double* v = sV + ((size_t)ll * a.maxP + p) * 18;
 #pragma unroll
-                    for (int r = 0; r < 6; r++) atomicAdd(&srhs[6 * p1 + r], -(WH[r * 3] * b0 + WH[r * 3 + 1] * b1 + WH[r * 3 + 2] * b2));
-                    for (int k2 = kb; k2 < ke; k2++) {
-                        const double* W2 = Wk + (size_t)k2 * 18;
-                        const int p2 = ep[k2];
-#pragma unroll
-                        for (int r = 0; r < 6; r++)
-#pragma unroll
-                            for (int c = 0; c < 6; c++)
-                                atomicAdd(&sS[(6 * p1 + r) * n + 6 * p2 + c], -(WH[r * 3] * W2[c * 3] + WH[r * 3 + 1] * W2[c * 3 + 1] + WH[r * 3 + 2] * W2[c * 3 + 2]));
+                        for (int r = 0; r < 6; r++) {
+                            const double w0 = wgt * (J[r] * Jp[0] + J[6 + r] * Jp[3]);
+                            const double w1 = wgt * (J[r] * Jp[1] + J[6 + r] * Jp[4]);
+                            const double w2 = wgt * (J[r] * Jp[2] + J[6 + r] * Jp[5]);
+                            atomicAdd(&v[r * 3], w0 * g00);
+                            atomicAdd(&v[r * 3 + 1], w0 * g01 + w1 * g11);
+                            atomicAdd(&v[r * 3 + 2], w0 * g02 + w1 * g12 + w2 * g22);
+                        }
+                        atomicOr(&s_mask[ll], 1 << p);
                     }
+                }
+                __syncthreads();
+                if (sp1 >= 0) {
+                    const int lb = ssl * SLW, le = min(nl, lb + SLW);
+                    for (int ll = lb; ll < le; ll++) {
+                        const int m = s_mask[ll];
+                        if (!((m >> sp1) & 1) || !((m >> sp2) & 1)) continue;
+                        const double* v1 = sV + ((size_t)ll * a.maxP + sp1) * 18;
+                        const double* v2 = sV + ((size_t)ll * a.maxP + sp2) * 18;
+                        double A[18];
+#pragma unroll
+                        for (int i = 0; i < 18; i++) A[i] = v1[i];
+#pragma unroll
+                        for (int c = 0; c < 6; c++) {
+                            const double b0 = v2[c * 3], b1 = v2[c * 3 + 1], b2 = v2[c * 3 + 2];
+#pragma unroll
+                            for (int r = 0; r < 6; r++) sacc[r * 6 + c] += A[r * 3] * b0 + A[r * 3 + 1] * b1 + A[r * 3 + 2] * b2;
+                        }
+                        if (sp1 == sp2) {               // rhs -= W Hinv bl = V (G^T bl)
+                            const int l = l0 + ll;
+                            const double* g = sG + 6 * l;
+                            const double b0 = sbl[3 * l], b1 = sbl[3 * l + 1], b2 = sbl[3 * l + 2];
+                            const double y0 = g[0] * b0, y1 = g[1] * b0 + g[3] * b1, y2 = g[2] * b0 + g[4] * b1 + g[5] * b2;
+#pragma unroll
+                            for (int r = 0; r < 6; r++) racc[r] += A[r * 3] * y0 + A[r * 3 + 1] * y1 + A[r * 3 + 2] * y2;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            if (sp1 >= 0) {
+#pragma unroll
+                for (int r = 0; r < 6; r++)
+#pragma unroll
+                    for (int c = 0; c < 6; c++) atomicAdd(&sS[(6 * sp1 + r) * n + 6 * sp2 + c], -sacc[r * 6 + c]);
+                if (sp1 == sp2) {
+#pragma unroll
+                    for (int r = 0; r < 6; r++) atomicAdd(&srhs[6 * sp1 + r], -racc[r]);
                 }
             }
             __syncthreads();
-            // dense Cholesky of S (lower triangle), right-looking
-            for (int j = 0; j < n; j++) {
-                if (t == 0) {
-                    const double d = sS[j * n + j];
-                    if (!(d > 0.0)) { s_sc[5] = 0.0; sS[j * n + j] = 1.0; } else sS[j * n + j] = sqrt(d);
+            // ---- blocked Cholesky of S (lower triangle), 6x6 blocks ----
+            for (int jb = 0; jb < P; jb++) {
+                const int j0 = 6 * jb;
+                if (t == 0) {                                     // diagonal block
+                    double Ld[21];
+#pragma unroll
+                    for (int r = 0; r < 6; r++)
+#pragma unroll
+                        for (int c = 0; c <= r; c++) Ld[r * (r + 1) / 2 + c] = sS[(j0 + r) * n + j0 + c];
+                    bool good = true;
+#pragma unroll
+                    for (int c = 0; c < 6; c++) {
+                        double d = Ld[c * (c + 1) / 2 + c];
+#pragma unroll
+                        for (int k = 0; k < c; k++) d -= Ld[c * (c + 1) / 2 + k] * Ld[c * (c + 1) / 2 + k];
+                        if (!(d > 0.0)) { good = false; d = 1.0; }
+                        const double ljj = sqrt(d), inv = 1.0 / ljj;
+                        Ld[c * (c + 1) / 2 + c] = ljj;
+                        sinvd[j0 + c] = inv;
+#pragma unroll
+                        for (int r = c + 1; r < 6; r++) {
+                            double v = Ld[r * (r + 1) / 2 + c];
+#pragma unroll
+                            for (int k = 0; k < c; k++) v -= Ld[r * (r + 1) / 2 + k] * Ld[c * (c + 1) / 2 + k];
+                            Ld[r * (r + 1) / 2 + c] = v * inv;
+                        }
+                    }
+                    if (!good) s_sc[5] = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 6; r++)
+#pragma unroll
+                        for (int c = 0; c <= r; c++) sS[(j0 + r) * n + j0 + c] = Ld[r * (r + 1) / 2 + c];
                 }
                 __syncthreads();
-                const double djj = sS[j * n + j];
-                for (int i = j + 1 + t; i < n; i += 256) sS[i * n + j] /= djj;
+                const int m = n - j0 - 6;                          // rows below the diagonal block
+                if (t < m) {                                       // panel: row i of L_{i,jb} = A_{i,jb} L_jj^-T
+                    double* row = sS + (size_t)(j0 + 6 + t) * n + j0;
+                    double x[6];
+#pragma unroll
+                    for (int c = 0; c < 6; c++) {
+                        double v = row[c];
+#pragma unroll
+                        for (int k = 0; k < c; k++) v -= x[k] * sS[(j0 + c) * n + j0 + k];
+                        x[c] = v * sinvd[j0 + c];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 6; c++) row[c] = x[c];
+                }
                 __syncthreads();
-                const int m = n - j - 1;
-                for (int idx = t; idx < m * m; idx += 256) {
-                    const int i = j + 1 + idx / m, k = j + 1 + idx % m;
-                    if (k <= i) sS[i * n + k] -= sS[i * n + j] * sS[k * n + j];
+                for (int idx = t; idx < m * m; idx += BA_NT) {     // trailing update, lower triangle
+                    const int i = idx / m, k = idx % m;
+                    if (k > i) continue;
+                    const double* ri = sS + (size_t)(j0 + 6 + i) * n + j0;
+                    const double* rk = sS + (size_t)(j0 + 6 + k) * n + j0;
+                    double v = 0;
+#pragma unroll
+                    for (int c = 0; c < 6; c++) v += ri[c] * rk[c];
+                    sS[(size_t)(j0 + 6 + i) * n + j0 + 6 + k] -= v;
                 }
                 __syncthreads();
             }
@@ -402,43 +583,44 @@ __global__ __launch_bounds__(256) void k_ba_optimize(BaOptArgs a) {
             if (t < 64) {
                 double y = (t < n) ? srhs[t] : 0.0;
                 for (int j = 0; j < n; j++) {
-                    const double xj = __shfl(y, j, 64) / sS[j * n + j];
+                    const double xj = __shfl(y, j, 64) * sinvd[j];
                     if (t == j) y = xj; else if (t > j && t < n) y -= sS[t * n + j] * xj;
                 }
                 for (int j = n - 1; j >= 0; j--) {
-                    const double xj = __shfl(y, j, 64) / sS[j * n + j];
+                    const double xj = __shfl(y, j, 64) * sinvd[j];
                     if (t == j) y = xj; else if (t < j) y -= sS[j * n + t] * xj;
                 }
                 if (t < n) srhs[t] = y;               // xp
             }
             __syncthreads();
             const bool ok = s_sc[5] != 0.0;
-            // xl = Hinv (bl - W^T xp); scale = x^T (lambda x + b)
+            // xl = Hinv (bl - W^T xp); scale = x^T (lambda x + b); oplus on the landmarks
             double sc = 0;
-            for (int l = t; l < L; l += 256) {
+            for (int l = t; l < L; l += BA_NT) {
                 const int kb = lbeg[l], ke = lend[l];
+                if ((fixed && fixed[l]) || ke <= kb) continue;
                 double r0 = sbl[3 * l], r1 = sbl[3 * l + 1], r2 = sbl[3 * l + 2];
-                const bool act = !((fixed && fixed[l]) || ke <= kb);
-                for (int k = kb; k < ke && act; k++) {
-                    const double* Wp = Wk + (size_t)k * 18;
-                    const double* xp = srhs + 6 * ep[k];
+                for (int k = kb; k < ke; k++) {
+                    const int p = ep[k];
+                    double e0, e1, J[12], Jp[6];
+                    ba_edge(sRb + 12 * p, sPtb + 3 * l, obs + 2 * k, a.fx, a.fy, a.cx, a.cy, e0, e1, J, Jp);
+                    const double e2 = e0 * e0 + e1 * e1;
+                    const double wgt = (e2 <= d2) ? 1.0 : a.delta / sqrt(e2);
+                    const double* xp = srhs + 6 * p;
+                    double s0 = 0, s1 = 0;
 #pragma unroll
-                    for (int r = 0; r < 6; r++) { r0 -= Wp[r * 3] * xp[r]; r1 -= Wp[r * 3 + 1] * xp[r]; r2 -= Wp[r * 3 + 2] * xp[r]; }
+                    for (int r = 0; r < 6; r++) { s0 += J[r] * xp[r]; s1 += J[6 + r] * xp[r]; }
+                    r0 -= wgt * (Jp[0] * s0 + Jp[3] * s1); r1 -= wgt * (Jp[1] * s0 + Jp[4] * s1); r2 -= wgt * (Jp[2] * s0 + Jp[5] * s1);
                 }
-                const double* Hi = sHinv + 6 * l;
-                const double x0 = act ? Hi[0] * r0 + Hi[1] * r1 + Hi[2] * r2 : 0.0;
-                const double x1 = act ? Hi[1] * r0 + Hi[3] * r1 + Hi[4] * r2 : 0.0;
-                const double x2 = act ? Hi[2] * r0 + Hi[4] * r1 + Hi[5] * r2 : 0.0;
-                sxl[3 * l] = x0; sxl[3 * l + 1] = x1; sxl[3 * l + 2] = x2;
-                if (act) sc += x0 * (lambda * x0 + sbl[3 * l]) + x1 * (lambda * x1 + sbl[3 * l + 1]) + x2 * (lambda * x2 + sbl[3 * l + 2]);
+                const double* g = sG + 6 * l;
+                const double y0 = g[0] * r0, y1 = g[1] * r0 + g[3] * r1, y2 = g[2] * r0 + g[4] * r1 + g[5] * r2;   // G^T r
+                const double x0 = g[0] * y0 + g[1] * y1 + g[2] * y2, x1 = g[3] * y1 + g[4] * y2, x2 = g[5] * y2;    // G y
+                sc += x0 * (lambda * x0 + sbl[3 * l]) + x1 * (lambda * x1 + sbl[3 * l + 1]) + x2 * (lambda * x2 + sbl[3 * l + 2]);
+                if (ok) { sPt[3 * l] += x0; sPt[3 * l + 1] += x1; sPt[3 * l + 2] += x2; }
             }
-            for (int i = t; i < n; i += 256) sc += srhs[i] * (lambda * srhs[i] + sbp[i]);
+            for (int i = t; i < n; i += BA_NT) sc += srhs[i] * (lambda * srhs[i] + sbp[i]);
             const double scale = block_sum(sc, s_red) + 1e-3;
-            // oplus
-            if (ok) {
-                for (int p = t; p < P; p += 256) pose_oplus(sR + 12 * p, srhs + 6 * p);
-                for (int i = t; i < 3 * L; i += 256) sPt[i] += sxl[i];
-            }
+            if (ok) for (int p = t; p < P; p += BA_NT) pose_oplus(sR + 12 * p, srhs + 6 * p);
             __syncthreads();
             const double tmpChi = ok ? robust_chi2() : 1e300;
             rho = (s_sc[2] - tmpChi) / scale;
@@ -451,8 +633,8 @@ __global__ __launch_bounds__(256) void k_ba_optimize(BaOptArgs a) {
                 }
             } else {
                 if (t == 0) { s_sc[0] = lambda * s_sc[1]; s_sc[1] *= 2.0; }
-                for (int i = t; i < P * 12; i += 256) sR[i] = sRb[i];      // optimizer->pop()
-                for (int i = t; i < L * 3; i += 256) sPt[i] = sPtb[i];
+                for (int i = t; i < P * 12; i += BA_NT) sR[i] = sRb[i];      // optimizer->pop()
+                for (int i = t; i < L * 3; i += BA_NT) sPt[i] = sPtb[i];
             }
             __syncthreads();
             qmax++;
@@ -461,7 +643,7 @@ __global__ __launch_bounds__(256) void k_ba_optimize(BaOptArgs a) {
     }
     // ---- write back: R -> quaternion, points, final chi2 ----
     const double fin = robust_chi2();
-    for (int p = t; p < P; p += 256) {
+    for (int p = t; p < P; p += BA_NT) {
         const double* R = sR + 12 * p;
         const double tr = R[0] + R[4] + R[8];
         double x, y, z, q;
@@ -472,26 +654,27 @@ __global__ __launch_bounds__(256) void k_ba_optimize(BaOptArgs a) {
         poses[7 * p] = x; poses[7 * p + 1] = y; poses[7 * p + 2] = z; poses[7 * p + 3] = q;
         poses[7 * p + 4] = R[9]; poses[7 * p + 5] = R[10]; poses[7 * p + 6] = R[11];
     }
-    for (int i = t; i < 3 * L; i += 256) pts[i] = sPt[i];
+    for (int i = t; i < 3 * L; i += BA_NT) pts[i] = sPt[i];
     if (t == 0) { a.final_chi2[w] = fin; a.iters[w] = it; a.status[w] = MYSLAM_OK; }
 }
 
 static size_t ba_opt_lds(int maxP, int maxL) {
-    return sizeof(double) * ((size_t)maxP * (12 + 12 + 21 + 6) + (size_t)maxL * (3 + 3 + 6 + 3 + 6 + 3) + 36 * (size_t)maxP * maxP + 6 * (size_t)maxP) +
-           sizeof(int) * (2 * (size_t)maxL + 4);
+    return sizeof(double) * ((size_t)maxP * (12 + 12 + 21 + 6) + (size_t)maxL * (3 + 3 + 6 + 3 + 6) + 36 * (size_t)maxP * maxP + 12 * (size_t)maxP +
+                             (size_t)BA_CL * maxP * 18) +
+           sizeof(int) * (2 * (size_t)maxL);
 }
 
 static int ba_opt_launch(const BaOptArgs& a, int nwin, hipStream_t s) {
-    if (a.maxP > 10) return MYSLAM_ERR_CAPACITY;          // substitution runs on one wave: 6P <= 64
+    if (a.maxP > 10) return MYSLAM_ERR_CAPACITY;          // substitution runs on one wave: 6P <= 64; 55 pose pairs x 8 slices <= 512 threads
     const size_t lds = ba_opt_lds(a.maxP, a.maxL);
-    if (lds > 160 * 1024 - 256) return MYSLAM_ERR_CAPACITY;
+    if (lds > 160 * 1024 - 512) return MYSLAM_ERR_CAPACITY;
     static size_t attr = 0;
     if (lds > 48 * 1024 && lds > attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_optimize), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = lds;
     }
     ScopedProf sp(P_BA, s);
-    hipLaunchKernelGGL(k_ba_optimize, dim3(nwin), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(k_ba_optimize, dim3(nwin), dim3(BA_NT), lds, s, a);
     MYSLAM_HIP_CHECK(hipGetLastError());
     return MYSLAM_OK;
 }
