@@ -158,9 +158,33 @@ __device__ __forceinline__ void ba_edge(const double* R, const double* pw, const
         for (int c = 0; c < 3; c++) Jp[r * 3 + c] = J[r * 6] * R[c] + J[r * 6 + 1] * R[3 + c] + J[r * 6 + 2] * R[6 + c];
 }
 
+typedef double ba_d4 __attribute__((ext_vector_type(4)));
+
+// f64 wave sum on the DPP network (no LDS crossbar): the total lands in lane 63
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_shift_add(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double wave_sum_lane63(double v) {
+    v = dpp_shift_add<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
+    v = dpp_shift_add<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
+    v = dpp_shift_add<0x141, 0xf>(v);     // row_half_mirror
+    v = dpp_shift_add<0x140, 0xf>(v);     // row_mirror: every lane holds its 16-lane row sum
+    v = dpp_shift_add<0x142, 0xa>(v);     // row_bcast15 into rows 1 and 3
+    v = dpp_shift_add<0x143, 0xc>(v);     // row_bcast31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ double bcast_lane(double v, int srcLane) {       // srcLane must be wave-uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), srcLane), __builtin_amdgcn_readlane(__double2loint(v), srcLane));
+}
+
 constexpr int BA_NT = 512;             // threads per window
 constexpr int BA_NW = BA_NT / 64;
 constexpr int BA_CL = 32;              // landmarks per Schur chunk
+constexpr int BA_VS = 3 * BA_CL + 2;   // row stride of the staged V chunk (doubles): 2 mod 32 -> conflict-free MFMA operand reads
 
 __device__ __forceinline__ double block_sum(double v, double* s_red) {
     v = wave_reduce_sum(v);
@@ -215,13 +239,18 @@ __device__ void pose_oplus(double* T, const double* d) {
 //             chunks and adds it to S once at the end (8 partial sums per entry).
 //   Cholesky  6x6-blocked right-looking factorisation of the 6P x 6P lower triangle (3 barriers per block column).
 //   solve     one wave, lane = row, shuffles; landmark back-substitution one thread per landmark.
+#ifdef MYSLAM_BA_TIMING           // developer aid: per-phase s_memtime ticks of window 0 go to the tail of its scratch
+#define BA_TICK(i) do { if (w == 0 && t == 0) { const long long now_ = (long long)__builtin_readcyclecounter(); tk[i] += now_ - tlast; tlast = now_; } } while (0)
+#else
+#define BA_TICK(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
     extern __shared__ __attribute__((aligned(16))) double s_d[];
     __shared__ double s_red[BA_NW];
     __shared__ double s_sc[8];      // [0] lambda [1] ni [2] curChi [5] ok
     __shared__ int s_poff[16];
-    __shared__ int s_mask[BA_CL];
-    __shared__ int s_bad;
+    __shared__ int s_bad, s_dup;
     const int w = blockIdx.x, t = threadIdx.x, wv = t >> 6, lane = t & 63;
     const int P = a.sizes ? a.sizes[3 * w] : a.nposes;
     const int L = a.sizes ? a.sizes[3 * w + 1] : a.npts;
@@ -238,9 +267,11 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
     double* sG = sbl + a.maxL * 3;            // maxL x 6   upper-triangular G (g00 g01 g02 g11 g12 g22)
     double* sS = sG + a.maxL * 6;             // (6 maxP)^2
     double* srhs = sS + 36 * a.maxP * a.maxP; // 6 maxP
-    double* sinvd = srhs + 6 * a.maxP;        // 6 maxP     1 / diag(chol(S))
-    double* sV = sinvd + 6 * a.maxP;          // BA_CL x maxP x 18
-    int* lbeg = reinterpret_cast<int*>(sV + BA_CL * a.maxP * 18);   // maxL
+    double* sLinv = srhs + 6 * a.maxP;        // maxP x 21  inverses of the diagonal blocks of chol(S)
+    double* sy = sLinv + 21 * a.maxP;         // 3 BA_CL    G^T bl of the chunk's landmarks
+    double* sV = sy + 3 * BA_CL;              // vrows x BA_VS: V of the chunk, row = 6 pose + r, column = 3 landmark + c
+    const int vrows = 16 * ((6 * a.maxP + 15) / 16);
+    int* lbeg = reinterpret_cast<int*>(sV + vrows * BA_VS);   // maxL
     int* lend = lbeg + a.maxL;
     double* poses = a.poses + (size_t)w * a.maxP * 7;
     double* pts = a.points + (size_t)w * a.maxL * 3;
@@ -250,6 +281,9 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
     const uint8_t* fixed = a.fixed ? a.fixed + (size_t)w * a.maxL : nullptr;
     int* plist = reinterpret_cast<int*>(a.W + (size_t)w * a.maxE * 18);     // edges sorted by pose (stable)
     const double d2 = a.delta * a.delta;
+#ifdef MYSLAM_BA_TIMING
+    long long tk[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = (long long)__builtin_readcyclecounter();
+#endif
 
     // ---- load state, landmark -> edge range ----
     for (int p = t; p < P; p += BA_NT) {
@@ -264,7 +298,7 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
     }
     for (int i = t; i < 3 * L; i += BA_NT) sPt[i] = pts[i];
     for (int l = t; l < L; l += BA_NT) { lbeg[l] = 0; lend[l] = 0; }
-    if (t == 0) s_bad = 0;
+    if (t == 0) { s_bad = 0; s_dup = 0; }
     __syncthreads();
     for (int k = t; k < E; k += BA_NT) {
         const int l = el[k], p = ep[k];
@@ -279,7 +313,13 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
     for (int l = t; l < L; l += BA_NT) {
         if (lend[l] == 0) { lbeg[l] = 0; continue; }
         int k = lbeg[l];
-        while (k < E && el[k] == l) k++;
+        unsigned seen = 0;
+        while (k < E && el[k] == l) {
+            const unsigned bit = 1u << ep[k];
+            if (seen & bit) s_dup = 1;               // two edges between the same (pose, landmark): staged V needs atomics
+            seen |= bit;
+            k++;
+        }
         lend[l] = k;
     }
     // ---- per-pose edge lists, in edge order (ballot scan: deterministic) ----
@@ -317,20 +357,8 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
         return block_sum(acc, s_red);
     };
 
-    // the (pose pair, landmark slice) this thread owns in the Schur accumulation
-    const int npairs = P * (P + 1) / 2;
-    constexpr int NSL = 8, SLW = BA_CL / NSL;            // 8 slices of 4 landmarks per chunk
-    int sp1 = -1, sp2 = -1, ssl = 0;
-    {
-        // unit u = slice * npairs + pair (P <= 10 -> at most 440 units, one per thread)
-        const int u = t;
-        if (u < npairs * NSL) {
-            ssl = u / npairs;
-            int pr = u % npairs, r = 0;
-            while (pr >= r + 1) { pr -= r + 1; r++; }    // pair index -> (row r, col pr), r >= pr
-            sp1 = r; sp2 = pr;
-        }
-    }
+    BA_TICK(0);
+    const int nb = (n + 15) / 16;                       // 16-row blocks of the reduced system
 
     int it = 0;
     for (; it < a.max_iters; it++) {
@@ -355,8 +383,8 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
                 for (int r = 0; r < 6; r++) h[21 + r] += -wgt * (J[r] * e0 + J[6 + r] * e1);
             }
 #pragma unroll
-            for (int u = 0; u < 27; u++) h[u] = wave_reduce_sum(h[u]);
-            if (lane == 0) {
+            for (int u = 0; u < 27; u++) h[u] = wave_sum_lane63(h[u]);
+            if (lane == 63) {
 #pragma unroll
                 for (int u = 0; u < 21; u++) sHpp[21 * p + u] = h[u];
 #pragma unroll
@@ -407,6 +435,7 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
         }
         if (t == 0) s_sc[2] = curChi0;
         __syncthreads();
+        BA_TICK(1);
 
         int qmax = 0;
         double rho = 0;
@@ -442,134 +471,184 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
                 g[0] = m00; g[1] = m10; g[2] = m20; g[3] = m11; g[4] = m21; g[5] = m22;
             }
             __syncthreads();
-            // ---- Schur complement, chunk by chunk ----
-            double sacc[36], racc[6];
-#pragma unroll
-            for (int i = 0; i < 36; i++) sacc[i] = 0.0;
-#pragma unroll
-            for (int i = 0; i < 6; i++) racc[i] = 0.0;
+            BA_TICK(2);
+            // ---- Schur complement S -= V V^T, rhs -= V y on the f64 matrix cores, chunk by chunk ----
+            // 16x16 tiles of the lower triangle, q -> (ti,tj): 0:(0,0) 1:(1,0) 2:(1,1) 3:(2,0) 4:(2,1) 5:(2,2) 6:(3,0) 7:(3,1) 8:(3,2) 9:(3,3).
+            // wave wv owns tile wv for all k; tiles 8 and 9 (only when nb == 4) are split over k between the 8 waves, which
+            // balances the four SIMDs (60 MFMAs per chunk each).  rhs rows ride along in the waves whose tile is (i,0)/(1,1).
+            const int ntile = nb * (nb + 1) / 2;
+            int ti = 0, tj = 0;
+            { int q = wv; while (q >= ti + 1) { q -= ti + 1; ti++; } tj = q; }      // tile wv -> (ti, tj)
+            const bool own = wv < ntile;
+            ba_d4 acc = ba_d4{0.0, 0.0, 0.0, 0.0}, acc8 = ba_d4{0.0, 0.0, 0.0, 0.0}, acc9 = ba_d4{0.0, 0.0, 0.0, 0.0};
+            double rpart = 0.0;
+            const bool do_rhs = own && tj == 0;                                     // q = 0, 1, 3, 6 <-> row blocks 0..3
             for (int l0 = 0; l0 < L; l0 += BA_CL) {
                 const int nl = min(BA_CL, L - l0);
-                for (int i = t; i < nl * a.maxP * 18; i += BA_NT) sV[i] = 0.0;
-                if (t < BA_CL) s_mask[t] = 0;
+                for (int i = t; i < 16 * nb * BA_VS; i += BA_NT) sV[i] = 0.0;
                 __syncthreads();
-                // stage V_{l,p} = sum over the (l,p) edges of W_k G_l, W_k = w J^T Jp
-                for (int ll = t >> 4; ll < nl; ll += BA_NT / 16) {
-                    const int l = l0 + ll;
-                    if (fixed && fixed[l]) continue;
-                    const double* g = sG + 6 * l;
-                    const double g00 = g[0], g01 = g[1], g02 = g[2], g11 = g[3], g12 = g[4], g22 = g[5];
-                    for (int k = lbeg[l] + (t & 15); k < lend[l]; k += 16) {
-                        const int p = ep[k];
-                        double e0, e1, J[12], Jp[6];
-                        ba_edge(sR + 12 * p, sPt + 3 * l, obs + 2 * k, a.fx, a.fy, a.cx, a.cy, e0, e1, J, Jp);
-                        const double e2 = e0 * e0 + e1 * e1;
-                        const double wgt = (e2 <= d2) ? 1.0 : a.delta / sqrt(e2);
-                        double* v = sV + ((size_t)ll * a.maxP + p) * 18;
-#pragma unroll
-                        for (int r = 0; r < 6; r++) {
-                            const double w0 = wgt * (J[r] * Jp[0] + J[6 + r] * Jp[3]);
-                            const double w1 = wgt * (J[r] * Jp[1] + J[6 + r] * Jp[4]);
-                            const double w2 = wgt * (J[r] * Jp[2] + J[6 + r] * Jp[5]);
-                            atomicAdd(&v[r * 3], w0 * g00);
-                            atomicAdd(&v[r * 3 + 1], w0 * g01 + w1 * g11);
-                            atomicAdd(&v[r * 3 + 2], w0 * g02 + w1 * g12 + w2 * g22);
-                        }
-                        atomicOr(&s_mask[ll], 1 << p);
+                // stage V_{l,p} = sum over the (l,p) edges of W_k G_l, W_k = w J^T Jp;  y_l = G_l^T bl_l
+                {
+                    const int ll = t >> 4, l = l0 + ll;
+                    const bool live = ll < nl && !(fixed && fixed[l]);
+                    const double* g = sG + 6 * (live ? l : 0);
+                    const double g00 = live ? g[0] : 0.0, g01 = live ? g[1] : 0.0, g02 = live ? g[2] : 0.0;
+                    const double g11 = live ? g[3] : 0.0, g12 = live ? g[4] : 0.0, g22 = live ? g[5] : 0.0;
+                    if ((t & 15) == 0) {
+                        const double b0 = live ? sbl[3 * l] : 0.0, b1 = live ? sbl[3 * l + 1] : 0.0, b2 = live ? sbl[3 * l + 2] : 0.0;
+                        sy[3 * ll] = g00 * b0; sy[3 * ll + 1] = g01 * b0 + g11 * b1; sy[3 * ll + 2] = g02 * b0 + g12 * b1 + g22 * b2;
                     }
-                }
-                __syncthreads();
-                if (sp1 >= 0) {
-                    const int lb = ssl * SLW, le = min(nl, lb + SLW);
-                    for (int ll = lb; ll < le; ll++) {
-                        const int m = s_mask[ll];
-                        if (!((m >> sp1) & 1) || !((m >> sp2) & 1)) continue;
-                        const double* v1 = sV + ((size_t)ll * a.maxP + sp1) * 18;
-                        const double* v2 = sV + ((size_t)ll * a.maxP + sp2) * 18;
-                        double A[18];
+                    if (live) {
+                        for (int k = lbeg[l] + (t & 15); k < lend[l]; k += 16) {
+                            const int p = ep[k];
+                            double e0, e1, J[12], Jp[6];
+                            ba_edge(sR + 12 * p, sPt + 3 * l, obs + 2 * k, a.fx, a.fy, a.cx, a.cy, e0, e1, J, Jp);
+                            const double e2 = e0 * e0 + e1 * e1;
+                            const double wgt = (e2 <= d2) ? 1.0 : a.delta / sqrt(e2);
+                            double* v = sV + (size_t)(6 * p) * BA_VS + 3 * ll;
+                            const double q0 = wgt * (Jp[0] * g00), q1 = wgt * (Jp[0] * g01 + Jp[1] * g11), q2 = wgt * (Jp[0] * g02 + Jp[1] * g12 + Jp[2] * g22);
+                            const double q3 = wgt * (Jp[3] * g00), q4 = wgt * (Jp[3] * g01 + Jp[4] * g11), q5 = wgt * (Jp[3] * g02 + Jp[4] * g12 + Jp[5] * g22);
+                            if (!s_dup) {
 #pragma unroll
-                        for (int i = 0; i < 18; i++) A[i] = v1[i];
+                                for (int r = 0; r < 6; r++) {                   // V = J^T (w Jp G)
+                                    v[r * BA_VS] = J[r] * q0 + J[6 + r] * q3;
+                                    v[r * BA_VS + 1] = J[r] * q1 + J[6 + r] * q4;
+                                    v[r * BA_VS + 2] = J[r] * q2 + J[6 + r] * q5;
+                                }
+                            } else {                                            // an (l,p) pair carries several edges: accumulate
 #pragma unroll
-                        for (int c = 0; c < 6; c++) {
-                            const double b0 = v2[c * 3], b1 = v2[c * 3 + 1], b2 = v2[c * 3 + 2];
-#pragma unroll
-                            for (int r = 0; r < 6; r++) sacc[r * 6 + c] += A[r * 3] * b0 + A[r * 3 + 1] * b1 + A[r * 3 + 2] * b2;
-                        }
-                        if (sp1 == sp2) {               // rhs -= W Hinv bl = V (G^T bl)
-                            const int l = l0 + ll;
-                            const double* g = sG + 6 * l;
-                            const double b0 = sbl[3 * l], b1 = sbl[3 * l + 1], b2 = sbl[3 * l + 2];
-                            const double y0 = g[0] * b0, y1 = g[1] * b0 + g[3] * b1, y2 = g[2] * b0 + g[4] * b1 + g[5] * b2;
-#pragma unroll
-                            for (int r = 0; r < 6; r++) racc[r] += A[r * 3] * y0 + A[r * 3 + 1] * y1 + A[r * 3 + 2] * y2;
+                                for (int r = 0; r < 6; r++) {
+                                    atomicAdd(&v[r * BA_VS], J[r] * q0 + J[6 + r] * q3);
+                                    atomicAdd(&v[r * BA_VS + 1], J[r] * q1 + J[6 + r] * q4);
+                                    atomicAdd(&v[r * BA_VS + 2], J[r] * q2 + J[6 + r] * q5);
+                                }
+                            }
                         }
                     }
                 }
                 __syncthreads();
+                BA_TICK(3);
+                if (own) {
+                    const double* pa = sV + (size_t)(16 * ti + (lane & 15)) * BA_VS + (lane >> 4);
+                    const double* pb = sV + (size_t)(16 * tj + (lane & 15)) * BA_VS + (lane >> 4);
+#pragma unroll 4
+                    for (int ks = 0; ks < 3 * BA_CL / 4; ks++) {
+                        const double av = pa[4 * ks], bv = pb[4 * ks];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                        if (do_rhs) rpart += av * sy[4 * ks + (lane >> 4)];
+                    }
+                }
+                if (ntile == 10) {
+                    const double* p2 = sV + (size_t)(32 + (lane & 15)) * BA_VS + (lane >> 4);
+                    const double* p3 = sV + (size_t)(48 + (lane & 15)) * BA_VS + (lane >> 4);
+#pragma unroll
+                    for (int kk = 0; kk < 3; kk++) {
+                        const int ks = wv + BA_NW * kk;
+                        const double a2 = p2[4 * ks], a3 = p3[4 * ks];
+                        acc8 = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, a2, acc8, 0, 0, 0);
+                        acc9 = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, a3, acc9, 0, 0, 0);
+                    }
+                }
+                __syncthreads();
+                BA_TICK(4);
             }
-            if (sp1 >= 0) {
+            // flush: D row = (lane>>4) + 4 v, col = lane & 15.  Owned tiles subtract directly; the split tiles go through LDS.
+            if (own) {
 #pragma unroll
-                for (int r = 0; r < 6; r++)
+                for (int v = 0; v < 4; v++) {
+                    const int row = 16 * ti + (lane >> 4) + 4 * v, col = 16 * tj + (lane & 15);
+                    if (row < n && col < n && col <= row) sS[row * n + col] -= acc[v];
+                }
+                if (do_rhs) {
+                    rpart += __shfl_xor(rpart, 16, 64);
+                    rpart += __shfl_xor(rpart, 32, 64);
+                    const int row = 16 * ti + lane;
+                    if (lane < 16 && row < n) srhs[row] -= rpart;
+                }
+            }
+            if (ntile == 10) {
 #pragma unroll
-                    for (int c = 0; c < 6; c++) atomicAdd(&sS[(6 * sp1 + r) * n + 6 * sp2 + c], -sacc[r * 6 + c]);
-                if (sp1 == sp2) {
+                for (int v = 0; v < 4; v++) {
+                    sV[(wv * 2) * 256 + v * 64 + lane] = acc8[v];
+                    sV[(wv * 2 + 1) * 256 + v * 64 + lane] = acc9[v];
+                }
+                __syncthreads();
+                {
+                    const int tile = t >> 8, e = t & 255, v = e >> 6, ln = e & 63;      // 512 threads = 2 tiles x 256 entries
+                    double sum = 0;
 #pragma unroll
-                    for (int r = 0; r < 6; r++) atomicAdd(&srhs[6 * sp1 + r], -racc[r]);
+                    for (int u = 0; u < BA_NW; u++) sum += sV[(u * 2 + tile) * 256 + e];
+                    const int row = 48 + (ln >> 4) + 4 * v, col = (tile ? 48 : 32) + (ln & 15);
+                    if (row < n && col < n && col <= row) sS[row * n + col] -= sum;
                 }
             }
             __syncthreads();
-            // ---- blocked Cholesky of S (lower triangle), 6x6 blocks ----
+            BA_TICK(5);
+            // ---- blocked Cholesky of S (lower triangle), 6x6 blocks.  Every panel thread factors the diagonal block
+            // redundantly in registers (same latency as one thread doing it, one barrier less per block column) ----
             for (int jb = 0; jb < P; jb++) {
                 const int j0 = 6 * jb;
-                if (t == 0) {                                     // diagonal block
-                    double Ld[21];
+                const int m = n - j0 - 6;                          // rows below the diagonal block
+                if (t <= m) {
+                    double Ld[21], iv[6];
 #pragma unroll
                     for (int r = 0; r < 6; r++)
 #pragma unroll
                         for (int c = 0; c <= r; c++) Ld[r * (r + 1) / 2 + c] = sS[(j0 + r) * n + j0 + c];
+                    double x[6];
+                    if (t < m) {
+#pragma unroll
+                        for (int c = 0; c < 6; c++) x[c] = sS[(size_t)(j0 + 6 + t) * n + j0 + c];
+                    }
                     bool good = true;
 #pragma unroll
-                    for (int c = 0; c < 6; c++) {
+                    for (int c = 0; c < 6; c++) {                  // right-looking inside the block: short dependency chains
                         double d = Ld[c * (c + 1) / 2 + c];
-#pragma unroll
-                        for (int k = 0; k < c; k++) d -= Ld[c * (c + 1) / 2 + k] * Ld[c * (c + 1) / 2 + k];
                         if (!(d > 0.0)) { good = false; d = 1.0; }
-                        const double ljj = sqrt(d), inv = 1.0 / ljj;
-                        Ld[c * (c + 1) / 2 + c] = ljj;
-                        sinvd[j0 + c] = inv;
+                        const double inv = rsqrt(d);
+                        iv[c] = inv;
+                        Ld[c * (c + 1) / 2 + c] = d * inv;
 #pragma unroll
-                        for (int r = c + 1; r < 6; r++) {
-                            double v = Ld[r * (r + 1) / 2 + c];
+                        for (int r = c + 1; r < 6; r++) Ld[r * (r + 1) / 2 + c] *= inv;
 #pragma unroll
-                            for (int k = 0; k < c; k++) v -= Ld[r * (r + 1) / 2 + k] * Ld[c * (c + 1) / 2 + k];
-                            Ld[r * (r + 1) / 2 + c] = v * inv;
+                        for (int r = c + 1; r < 6; r++)
+#pragma unroll
+                            for (int k = c + 1; k <= r; k++) Ld[r * (r + 1) / 2 + k] -= Ld[r * (r + 1) / 2 + c] * Ld[k * (k + 1) / 2 + c];
+                    }
+                    if (t < m) {                                   // panel row: x L_jj^T = a
+#pragma unroll
+                        for (int c = 0; c < 6; c++) {
+                            double v = x[c];
+#pragma unroll
+                            for (int k = 0; k < c; k++) v -= x[k] * Ld[c * (c + 1) / 2 + k];
+                            x[c] = v * iv[c];
                         }
+#pragma unroll
+                        for (int c = 0; c < 6; c++) sS[(size_t)(j0 + 6 + t) * n + j0 + c] = x[c];
+                    } else {                                       // t == m: publishes the inverse of the diagonal block (lower), which is
+                        if (!good) s_sc[5] = 0.0;                  // all the substitutions need of it (sS keeps the unfactored block)
+                        double M[21];
+#pragma unroll
+                        for (int c = 0; c < 6; c++) {
+                            M[c * (c + 1) / 2 + c] = iv[c];
+#pragma unroll
+                            for (int r = c + 1; r < 6; r++) {
+                                double v = 0;
+#pragma unroll
+                                for (int k = c; k < r; k++) v += Ld[r * (r + 1) / 2 + k] * M[k * (k + 1) / 2 + c];
+                                M[r * (r + 1) / 2 + c] = -v * iv[r];
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < 21; i++) sLinv[21 * jb + i] = M[i];
                     }
-                    if (!good) s_sc[5] = 0.0;
-#pragma unroll
-                    for (int r = 0; r < 6; r++)
-#pragma unroll
-                        for (int c = 0; c <= r; c++) sS[(j0 + r) * n + j0 + c] = Ld[r * (r + 1) / 2 + c];
                 }
                 __syncthreads();
-                const int m = n - j0 - 6;                          // rows below the diagonal block
-                if (t < m) {                                       // panel: row i of L_{i,jb} = A_{i,jb} L_jj^-T
-                    double* row = sS + (size_t)(j0 + 6 + t) * n + j0;
-                    double x[6];
-#pragma unroll
-                    for (int c = 0; c < 6; c++) {
-                        double v = row[c];
-#pragma unroll
-                        for (int k = 0; k < c; k++) v -= x[k] * sS[(j0 + c) * n + j0 + k];
-                        x[c] = v * sinvd[j0 + c];
-                    }
-#pragma unroll
-                    for (int c = 0; c < 6; c++) row[c] = x[c];
-                }
-                __syncthreads();
-                for (int idx = t; idx < m * m; idx += BA_NT) {     // trailing update, lower triangle
-                    const int i = idx / m, k = idx % m;
-                    if (k > i) continue;
+                for (int idx = t; idx < m * (m + 1) / 2; idx += BA_NT) {     // trailing update, lower triangle: idx = i (i+1)/2 + k
+                    int i = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+                    if (i * (i + 1) / 2 > idx) i--;
+                    if ((i + 1) * (i + 2) / 2 <= idx) i++;
+                    const int k = idx - i * (i + 1) / 2;
                     const double* ri = sS + (size_t)(j0 + 6 + i) * n + j0;
                     const double* rk = sS + (size_t)(j0 + 6 + k) * n + j0;
                     double v = 0;
@@ -579,20 +658,55 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
                 }
                 __syncthreads();
             }
-            // forward / backward substitution by one wave (lane = row)
+            BA_TICK(6);
+            // block forward / backward substitution by one wave (lane = row); values move over readlane
             if (t < 64) {
                 double y = (t < n) ? srhs[t] : 0.0;
-                for (int j = 0; j < n; j++) {
-                    const double xj = __shfl(y, j, 64) * sinvd[j];
-                    if (t == j) y = xj; else if (t > j && t < n) y -= sS[t * n + j] * xj;
+                const int tr = min(t, n - 1);
+                for (int jb = 0; jb < P; jb++) {
+                    const int j0 = 6 * jb;
+                    const double* M = sLinv + 21 * jb;
+                    double yb[6], xb[6];
+#pragma unroll
+                    for (int c = 0; c < 6; c++) yb[c] = bcast_lane(y, j0 + c);
+#pragma unroll
+                    for (int r = 0; r < 6; r++) {
+                        double v = 0;
+#pragma unroll
+                        for (int c = 0; c <= r; c++) v += M[r * (r + 1) / 2 + c] * yb[c];
+                        xb[r] = v;
+                    }
+                    double upd = 0;
+#pragma unroll
+                    for (int c = 0; c < 6; c++) upd += sS[tr * n + j0 + c] * xb[c];
+                    if (t >= j0 + 6 && t < n) y -= upd;
+#pragma unroll
+                    for (int c = 0; c < 6; c++) if (t == j0 + c) y = xb[c];
                 }
-                for (int j = n - 1; j >= 0; j--) {
-                    const double xj = __shfl(y, j, 64) * sinvd[j];
-                    if (t == j) y = xj; else if (t < j) y -= sS[j * n + t] * xj;
+                for (int jb = P - 1; jb >= 0; jb--) {
+                    const int j0 = 6 * jb;
+                    const double* M = sLinv + 21 * jb;
+                    double yb[6], xb[6];
+#pragma unroll
+                    for (int c = 0; c < 6; c++) yb[c] = bcast_lane(y, j0 + c);
+#pragma unroll
+                    for (int r = 0; r < 6; r++) {                  // x = M^T y
+                        double v = 0;
+#pragma unroll
+                        for (int c = r; c < 6; c++) v += M[c * (c + 1) / 2 + r] * yb[c];
+                        xb[r] = v;
+                    }
+                    double upd = 0;
+#pragma unroll
+                    for (int c = 0; c < 6; c++) upd += sS[(j0 + c) * n + tr] * xb[c];
+                    if (t < j0) y -= upd;
+#pragma unroll
+                    for (int c = 0; c < 6; c++) if (t == j0 + c) y = xb[c];
                 }
                 if (t < n) srhs[t] = y;               // xp
             }
             __syncthreads();
+            BA_TICK(7);
             const bool ok = s_sc[5] != 0.0;
             // xl = Hinv (bl - W^T xp); scale = x^T (lambda x + b); oplus on the landmarks
             double sc = 0;
@@ -637,6 +751,7 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
                 for (int i = t; i < L * 3; i += BA_NT) sPt[i] = sPtb[i];
             }
             __syncthreads();
+            BA_TICK(8);
             qmax++;
         } while (rho < 0 && qmax < 10 && isfinite(s_sc[0]));
         if (qmax == 10 || rho == 0 || !isfinite(s_sc[0])) { it++; break; }
@@ -656,11 +771,16 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
     }
     for (int i = t; i < 3 * L; i += BA_NT) pts[i] = sPt[i];
     if (t == 0) { a.final_chi2[w] = fin; a.iters[w] = it; a.status[w] = MYSLAM_OK; }
+#ifdef MYSLAM_BA_TIMING
+    BA_TICK(9);
+    if (w == 0 && t == 0) for (int i = 0; i < 10; i++) a.W[(size_t)a.maxE * 18 - 10 + i] = (double)tk[i];
+#endif
 }
 
 static size_t ba_opt_lds(int maxP, int maxL) {
-    return sizeof(double) * ((size_t)maxP * (12 + 12 + 21 + 6) + (size_t)maxL * (3 + 3 + 6 + 3 + 6) + 36 * (size_t)maxP * maxP + 12 * (size_t)maxP +
-                             (size_t)BA_CL * maxP * 18) +
+    const size_t vrows = 16 * (((size_t)6 * maxP + 15) / 16);
+    return sizeof(double) * ((size_t)maxP * (12 + 12 + 21 + 6) + (size_t)maxL * (3 + 3 + 6 + 3 + 6) + 36 * (size_t)maxP * maxP + (6 + 21) * (size_t)maxP +
+                             3 * BA_CL + vrows * BA_VS) +
            sizeof(int) * (2 * (size_t)maxL);
 }
 
