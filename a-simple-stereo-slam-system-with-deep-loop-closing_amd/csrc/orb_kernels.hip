@@ -16,6 +16,8 @@
 
 namespace myslam_hip {
 
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
 __constant__ int8_t c_pattern[1024] = {
 #include "orb_pattern.inc"
 };
@@ -82,6 +84,73 @@ __global__ __launch_bounds__(256) void k_resize(ResizeArgs a) {
         packed |= (uint32_t)v << (8 * k);
     }
     *reinterpret_cast<uint32_t*>(a.dst + (size_t)b * a.dstride + (size_t)dy * a.dpitch + dx4) = packed;
+}
+
+// K1b: the same arithmetic, register-only column strips.  Lane l owns destination columns 4l..4l+3 of a 256-column strip
+// and walks RS_R destination rows: x coordinates / weights are computed once, every needed source row is sampled once
+// (one unaligned 2-byte load per pixel = the two horizontal taps, v_perm + v_dot2_u32_u16 = the 11-bit interpolation) and
+// reused by the destination rows that share it (the OpenCV row cache), all row decisions are wave-uniform.
+constexpr int RS_R = 8;
+
+__global__ __launch_bounds__(256) void k_resize_strip(ResizeArgs a, int nstrips, int nbands) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= nstrips * nbands) return;
+    const int strip = wid % nstrips, band = wid / nstrips;
+    const int b = blockIdx.z;
+    const int dx4 = strip * 256 + 4 * lane;
+    const bool has = dx4 < a.dw;
+    const uint8_t* src = a.src + (size_t)b * a.sstride;
+    uint8_t* dst = a.dst + (size_t)b * a.dstride;
+    int sx[4]; uint32_t aw[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int c0, c1;
+        resize_coord(min(dx4 + k, a.dw - 1), a.scale_x, a.sw, true, sx[k], c0, c1);
+        aw[k] = (uint32_t)c0 | ((uint32_t)c1 << 16);
+    }
+    // horizontal interpolation of source row r for the 4 columns, already >> 4 (the only form the vertical step uses)
+    auto hrow = [&](int r, int* t) {
+        const uint8_t* row = src + (size_t)r * a.spitch;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint16_t v = 0;
+            // at the right border sx = sw-1 and the weight of sx+1 is 0 (OpenCV clamps fx there): that byte's value is irrelevant
+            if (has) __builtin_memcpy(&v, row + sx[k], 2);
+            const uint32_t pp = __builtin_amdgcn_perm(0u, (uint32_t)v, 0x0c010c00u);       // (p0, p1) as two u16
+            t[k] = (int)(__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pp), __builtin_bit_cast(u16x2, aw[k]), 0u, false) >> 4);
+        }
+    };
+    int rowA = -1, rowB = -1, tA[4] = {0, 0, 0, 0}, tB[4] = {0, 0, 0, 0};
+    const int dy0 = band * RS_R, dy1 = min(dy0 + RS_R, a.dh);
+    for (int dy = dy0; dy < dy1; dy++) {
+        int sy, b0, b1;
+        resize_coord(dy, a.scale_y, a.sh, false, sy, b0, b1);
+        sy = __builtin_amdgcn_readfirstlane(sy); b0 = __builtin_amdgcn_readfirstlane(b0); b1 = __builtin_amdgcn_readfirstlane(b1);
+        const int sy0 = min(max(sy, 0), a.sh - 1), sy1 = min(max(sy + 1, 0), a.sh - 1);
+        if (sy0 != rowA) {
+            if (sy0 == rowB) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) tA[k] = tB[k];
+            } else hrow(sy0, tA);
+            rowA = sy0;
+        }
+        if (sy1 != rowB) {
+            if (sy1 == rowA) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) tB[k] = tA[k];
+            } else hrow(sy1, tB);
+            rowB = sy1;
+        }
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int v = (((b0 * tA[k]) >> 16) + ((b1 * tB[k]) >> 16) + 2) >> 2;
+            v = min(max(v, 0), 255);
+            packed |= (uint32_t)v << (8 * k);
+        }
+        if (has) *reinterpret_cast<uint32_t*>(dst + (size_t)dy * a.dpitch + dx4) = packed;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -170,6 +239,226 @@ __global__ __launch_bounds__(256) void k_blur7(BlurArgs a) {
         const uint32_t r2 = min((acc2 + 32768u) >> 16, 255u), r3 = min((acc3 + 32768u) >> 16, 255u);
         // destination pitch is a multiple of 64: the 4-byte store never leaves the row; bytes past w are padding
         *reinterpret_cast<uint32_t*>(dst + (size_t)oy * a.dpitch + ox) = r0 | (r1 << 8) | (r2 << 16) | (r3 << 24);
+    }
+}
+
+// K2b: the same filter on the dot-product units.  Taps <= 255 (true for every kernel this library builds):
+// horizontal pass = 2 x v_dot4_u32_u8 per pixel on byte-aligned windows (v_alignbyte), two rows at a time so that the
+// u16 results are stored as vertical pairs (h[2j][x], h[2j+1][x]); vertical pass = 4 x v_dot2_u32_u16 per pixel on
+// those pairs with the rounding constant as accumulator seed.  128 x 64 outputs per block.
+constexpr int B2_W = 128, B2_H = 32, B2_IH = B2_H + 6, B2_IP = B2_W + 8, B2_IDW = B2_IP / 4, B2_PR = B2_IH / 2;
+
+__global__ __launch_bounds__(256) void k_blur7_dot(BlurArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[B2_IH * B2_IP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_hp[B2_PR * B2_W];
+    const int t = threadIdx.x;
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * B2_W, y0 = blockIdx.y * B2_H;
+    const uint8_t* src = a.src + (size_t)b * a.sstride;
+    const bool aligned = ((a.spitch & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 3) == 0);
+    const int nout = min(B2_H, a.h - y0);                  // output rows of this tile
+    const int nrp = (nout + 6 + 1) >> 1;                   // input row pairs needed
+    // 1. stage the input tile (rows reflected; columns outside [0,w) are fixed up in step 2)
+    for (int i = t; i < 2 * nrp * B2_IDW; i += 256) {
+        const int r = i / B2_IDW, k = i - r * B2_IDW;
+        const int gy = reflect101(y0 + r - 3, a.h);
+        const int gx = x0 - 4 + 4 * k;
+        const uint8_t* row = src + (size_t)gy * a.spitch;
+        uint32_t v;
+        if (aligned && gx >= 0 && gx + 4 <= a.spitch) {
+            v = *reinterpret_cast<const uint32_t*>(row + gx);
+        } else {
+            v = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) v |= (uint32_t)row[min(max(gx + j, 0), a.spitch - 1)] << (8 * j);
+        }
+        *reinterpret_cast<uint32_t*>(&s_in[r * B2_IP + 4 * k]) = v;
+    }
+    __syncthreads();
+    // 2. BORDER_REFLECT_101 columns: x in [-3,-1] and [w, w+2]; their mirror images are inside this tile
+    for (int i = t; i < 2 * nrp * 6; i += 256) {
+        const int r = i / 6, j = i - r * 6;
+        const int x = (j < 3) ? j - 3 : a.w + (j - 3);
+        const int c = x - (x0 - 4);
+        if (c >= 0 && c < B2_IP) {
+            const int cr = reflect101(x, a.w) - (x0 - 4);
+            if (cr >= 0 && cr < B2_IP) s_in[r * B2_IP + c] = s_in[r * B2_IP + cr];
+        }
+    }
+    __syncthreads();
+    // 3. horizontal pass, 4 x-positions x 2 rows per item
+    const uint32_t qa = (uint32_t)a.q[0] | ((uint32_t)a.q[1] << 8) | ((uint32_t)a.q[2] << 16) | ((uint32_t)a.q[3] << 24);
+    const uint32_t qb = (uint32_t)a.q[4] | ((uint32_t)a.q[5] << 8) | ((uint32_t)a.q[6] << 16);
+    for (int i = t; i < nrp * (B2_W / 4); i += 256) {
+        const int rp = i >> 5, qd = i & 31;
+        uint32_t hh[2][4];
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(&s_in[(2 * rp + rr) * B2_IP + 4 * qd]);
+            const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+            const uint32_t A0 = __builtin_amdgcn_alignbyte(w1, w0, 1u), A1 = __builtin_amdgcn_alignbyte(w1, w0, 2u);
+            const uint32_t A2 = __builtin_amdgcn_alignbyte(w1, w0, 3u), A3 = w1;
+            const uint32_t B0 = __builtin_amdgcn_alignbyte(w2, w1, 1u), B1 = __builtin_amdgcn_alignbyte(w2, w1, 2u);
+            const uint32_t B2 = __builtin_amdgcn_alignbyte(w2, w1, 3u), B3 = w2;
+            hh[rr][0] = __builtin_amdgcn_udot4(A0, qa, __builtin_amdgcn_udot4(B0, qb, 0u, false), false);
+            hh[rr][1] = __builtin_amdgcn_udot4(A1, qa, __builtin_amdgcn_udot4(B1, qb, 0u, false), false);
+            hh[rr][2] = __builtin_amdgcn_udot4(A2, qa, __builtin_amdgcn_udot4(B2, qb, 0u, false), false);
+            hh[rr][3] = __builtin_amdgcn_udot4(A3, qa, __builtin_amdgcn_udot4(B3, qb, 0u, false), false);
+        }
+        *reinterpret_cast<uint4*>(&s_hp[rp * B2_W + 4 * qd]) =
+            make_uint4(hh[0][0] | (hh[1][0] << 16), hh[0][1] | (hh[1][1] << 16), hh[0][2] | (hh[1][2] << 16), hh[0][3] | (hh[1][3] << 16));
+    }
+    __syncthreads();
+    // 4. vertical pass: output rows (2 yp, 2 yp + 1) x 4 x-positions per item
+    const uint32_t t01 = (uint32_t)a.q[0] | ((uint32_t)a.q[1] << 16), t23 = (uint32_t)a.q[2] | ((uint32_t)a.q[3] << 16);
+    const uint32_t t45 = (uint32_t)a.q[4] | ((uint32_t)a.q[5] << 16), t6_ = (uint32_t)a.q[6];
+    const uint32_t t_0 = (uint32_t)a.q[0] << 16, t12 = (uint32_t)a.q[1] | ((uint32_t)a.q[2] << 16);
+    const uint32_t t34 = (uint32_t)a.q[3] | ((uint32_t)a.q[4] << 16), t56 = (uint32_t)a.q[5] | ((uint32_t)a.q[6] << 16);
+    uint8_t* dst = a.dst + (size_t)b * a.dstride;
+    for (int i = t; i < ((nout + 1) >> 1) * (B2_W / 4); i += 256) {
+        const int yp = i >> 5, qd = i & 31;
+        const int oy = y0 + 2 * yp, ox = x0 + 4 * qd;
+        if (ox >= a.w) continue;
+        uint4 D[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) D[j] = *reinterpret_cast<const uint4*>(&s_hp[(yp + j) * B2_W + 4 * qd]);
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int xi = 0; xi < 4; xi++) {
+            const uint32_t d0 = xi == 0 ? D[0].x : xi == 1 ? D[0].y : xi == 2 ? D[0].z : D[0].w;
+            const uint32_t d1 = xi == 0 ? D[1].x : xi == 1 ? D[1].y : xi == 2 ? D[1].z : D[1].w;
+            const uint32_t d2 = xi == 0 ? D[2].x : xi == 1 ? D[2].y : xi == 2 ? D[2].z : D[2].w;
+            const uint32_t d3 = xi == 0 ? D[3].x : xi == 1 ? D[3].y : xi == 2 ? D[3].z : D[3].w;
+            uint32_t s0 = 32768u, s1 = 32768u;
+#define DOT2(d, tp, acc) __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, d), __builtin_bit_cast(u16x2, tp), acc, false)
+            s0 = DOT2(d0, t01, s0); s0 = DOT2(d1, t23, s0); s0 = DOT2(d2, t45, s0); s0 = DOT2(d3, t6_, s0);
+            s1 = DOT2(d0, t_0, s1); s1 = DOT2(d1, t12, s1); s1 = DOT2(d2, t34, s1); s1 = DOT2(d3, t56, s1);
+#undef DOT2
+            lo |= (s0 >> 16) << (8 * xi);
+            hi |= (s1 >> 16) << (8 * xi);
+        }
+        // destination pitch is a multiple of 64: the 4-byte store never leaves the row; bytes past w are padding
+        *reinterpret_cast<uint32_t*>(dst + (size_t)oy * a.dpitch + ox) = lo;
+        if (oy + 1 < a.h) *reinterpret_cast<uint32_t*>(dst + (size_t)(oy + 1) * a.dpitch + ox) = hi;
+    }
+}
+
+// K2c: register-only variant of K2b.  One wave filters a 256-column x B3_R-row band walking down the rows: lane l owns
+// columns 4l..4l+3, loads ONE aligned dword per input row (a fully coalesced 256-byte row segment per wave), gets its
+// neighbours' dwords over the DPP network (wave_shr/shl), keeps the last four vertical pairs of horizontal sums in
+// registers and emits two output rows per two input rows.  No LDS, no barriers.  Needs w >= 8 and taps <= 255.
+constexpr int B3_R = 32;                       // output rows per wave
+
+__device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t dpp_wave_shl1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
+
+__global__ __launch_bounds__(256) void k_blur7_strip(BlurArgs a, int nstrips, int nbands) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);         // wave id -> (band, strip)
+    if (wid >= nstrips * nbands) return;
+    const int strip = wid % nstrips, band = wid / nstrips;
+    const int b = blockIdx.z;
+    const int x0 = strip * 256 + 4 * lane, y0 = band * B3_R;
+    const uint8_t* src = a.src + (size_t)b * a.sstride;
+    uint8_t* dst = a.dst + (size_t)b * a.dstride;
+    const int nout = min(B3_R, a.h - y0);
+    const int npair = (nout + 6 + 1) >> 1;                       // input row pairs to walk
+    // column roles
+    const bool has = x0 < a.w;                                   // owns at least one image column
+    const bool lastq = has && x0 + 4 >= a.w;                     // owns column w-1
+    const bool needL = lane == 0 && x0 > 0;                      // left neighbour lives in another wave
+    const bool needR = lane == 63 && x0 + 4 < a.w;
+    const int m = a.w - x0;                                      // valid bytes in the last dword (1..4) when lastq
+    uint32_t sel1 = 0x07060504u, sel2 = 0;
+    if (lastq) {                                                 // REFLECT_101 on the right: byte j >= m comes from relative offset 2m-2-j
+        sel1 = 0; 
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int o1 = j < m ? j : 2 * m - 2 - j, o2 = 2 * m - 2 - (4 + j);
+            sel1 |= (uint32_t)min(max(4 + o1, 0), 7) << (8 * j);
+            sel2 |= (uint32_t)min(max(4 + o2, 0), 7) << (8 * j);
+        }
+    }
+    // lane 63 whose right neighbour (in the next wave) is the image's last dword mirrors that dword's tail itself
+    uint32_t selR = 0x07060504u;
+    if (needR && x0 + 8 >= a.w) {
+        const int mr = a.w - (x0 + 4);
+        selR = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) selR |= (uint32_t)min(max(4 + (j < mr ? j : 2 * mr - 2 - j), 0), 7) << (8 * j);
+    }
+    const uint32_t qa = (uint32_t)a.q[0] | ((uint32_t)a.q[1] << 8) | ((uint32_t)a.q[2] << 16) | ((uint32_t)a.q[3] << 24);
+    const uint32_t qb = (uint32_t)a.q[4] | ((uint32_t)a.q[5] << 8) | ((uint32_t)a.q[6] << 16);
+    const uint32_t t01 = (uint32_t)a.q[0] | ((uint32_t)a.q[1] << 16), t23 = (uint32_t)a.q[2] | ((uint32_t)a.q[3] << 16);
+    const uint32_t t45 = (uint32_t)a.q[4] | ((uint32_t)a.q[5] << 16), t6_ = (uint32_t)a.q[6];
+    const uint32_t t_0 = (uint32_t)a.q[0] << 16, t12 = (uint32_t)a.q[1] | ((uint32_t)a.q[2] << 16);
+    const uint32_t t34 = (uint32_t)a.q[3] | ((uint32_t)a.q[4] << 16), t56 = (uint32_t)a.q[5] | ((uint32_t)a.q[6] << 16);
+
+    // the three dwords of one input row this lane needs: own, left neighbour, right neighbour (loads only)
+    auto load_row = [&](int j, uint32_t& c, uint32_t& l, uint32_t& r) {
+        const uint8_t* row = src + (size_t)reflect101(y0 - 3 + j, a.h) * a.spitch;
+        c = has ? *reinterpret_cast<const uint32_t*>(row + x0) : 0u;
+        l = needL ? *reinterpret_cast<const uint32_t*>(row + x0 - 4) : 0u;
+        r = needR ? *reinterpret_cast<const uint32_t*>(row + x0 + 4) : 0u;
+    };
+    // horizontal pass of one row: 4 sums (<= 65280)
+    auto hrow = [&](uint32_t c, uint32_t l, uint32_t r, uint32_t* h) {
+        uint32_t w0 = dpp_wave_shr1(c);
+        if (lane == 0) w0 = x0 > 0 ? l : __builtin_amdgcn_perm(c, c, 0x01020300u);     // x = -3..-1 mirror x = 3..1
+        uint32_t w1 = c;
+        if (lastq) w1 = __builtin_amdgcn_perm(c, w0, sel1);
+        uint32_t w2 = dpp_wave_shl1(w1);
+        if (lane == 63) w2 = __builtin_amdgcn_perm(r, c, selR);
+        if (lastq) w2 = __builtin_amdgcn_perm(c, w0, sel2);
+        const uint32_t A0 = __builtin_amdgcn_alignbyte(w1, w0, 1u), A1 = __builtin_amdgcn_alignbyte(w1, w0, 2u);
+        const uint32_t A2 = __builtin_amdgcn_alignbyte(w1, w0, 3u), A3 = w1;
+        const uint32_t B0 = __builtin_amdgcn_alignbyte(w2, w1, 1u), B1 = __builtin_amdgcn_alignbyte(w2, w1, 2u);
+        const uint32_t B2 = __builtin_amdgcn_alignbyte(w2, w1, 3u), B3 = w2;
+        h[0] = __builtin_amdgcn_udot4(A0, qa, __builtin_amdgcn_udot4(B0, qb, 0u, false), false);
+        h[1] = __builtin_amdgcn_udot4(A1, qa, __builtin_amdgcn_udot4(B1, qb, 0u, false), false);
+        h[2] = __builtin_amdgcn_udot4(A2, qa, __builtin_amdgcn_udot4(B2, qb, 0u, false), false);
+        h[3] = __builtin_amdgcn_udot4(A3, qa, __builtin_amdgcn_udot4(B3, qb, 0u, false), false);
+    };
+    uint32_t D[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) D[u][k] = 0;
+    uint32_t c0, l0, r0, c1, l1, r1;
+    load_row(0, c0, l0, r0); load_row(1, c1, l1, r1);
+    for (int base = 0; base < npair; base += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int pi = base + u;
+            if (pi < npair) {
+                uint32_t nc0 = 0, nl0 = 0, nr0 = 0, nc1 = 0, nl1 = 0, nr1 = 0;
+                if (pi + 1 < npair) { load_row(2 * pi + 2, nc0, nl0, nr0); load_row(2 * pi + 3, nc1, nl1, nr1); }     // prefetch
+                uint32_t he[4], ho[4];
+                hrow(c0, l0, r0, he); hrow(c1, l1, r1, ho);
+#pragma unroll
+                for (int k = 0; k < 4; k++) D[u][k] = he[k] | (ho[k] << 16);
+                if (pi >= 3) {
+                    const int oy = y0 + 2 * (pi - 3);
+                    uint32_t lo = 0, hi = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t d0 = D[(u + 1) & 3][k], d1 = D[(u + 2) & 3][k], d2 = D[(u + 3) & 3][k], d3 = D[u][k];
+                        uint32_t s0 = 32768u, s1 = 32768u;
+#define DOT2(d, tp, acc) __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, d), __builtin_bit_cast(u16x2, tp), acc, false)
+                        s0 = DOT2(d0, t01, s0); s0 = DOT2(d1, t23, s0); s0 = DOT2(d2, t45, s0); s0 = DOT2(d3, t6_, s0);
+                        s1 = DOT2(d0, t_0, s1); s1 = DOT2(d1, t12, s1); s1 = DOT2(d2, t34, s1); s1 = DOT2(d3, t56, s1);
+#undef DOT2
+                        lo |= (s0 >> 16) << (8 * k);
+                        hi |= (s1 >> 16) << (8 * k);
+                    }
+                    if (has) {      // destination pitch is a multiple of 64: the dword never leaves the row; bytes past w are padding
+                        *reinterpret_cast<uint32_t*>(dst + (size_t)oy * a.dpitch + x0) = lo;
+                        if (oy + 1 < a.h) *reinterpret_cast<uint32_t*>(dst + (size_t)(oy + 1) * a.dpitch + x0) = hi;
+                    }
+                }
+                c0 = nc0; l0 = nl0; r0 = nr0; c1 = nc1; l1 = nl1; r1 = nr1;
+            }
+        }
     }
 }
 
@@ -1435,32 +1724,64 @@ __global__ void k_unpack_cands(const uint32_t* __restrict__ cand, int n, int32_t
 // K0: ingest level 0 from the caller's buffer (any pitch/alignment) into the 64-byte pitched plane
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ src, int rows, int cols, int step, size_t sstride,
-                                                uint8_t* __restrict__ dst, int dpitch, size_t dstride) {
-    const int b = blockIdx.z, y = blockIdx.y;
-    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (x4 >= cols) return;
-    const uint8_t* s = src + (size_t)b * sstride + (size_t)y * step + x4;
-    uint32_t v = 0;
+                                                uint8_t* __restrict__ dst, int dpitch, size_t dstride, int tpr, int rpb) {
+    // 16 destination bytes per thread (one aligned 16-byte store) from 5 aligned source dwords + v_alignbyte; tpr threads per row
+    const int b = blockIdx.z;
+    const int y = blockIdx.y * rpb + (int)threadIdx.x / tpr;
+    const int x16 = (blockIdx.x * 256 + (int)threadIdx.x % tpr) * 16;
+    if ((int)threadIdx.x >= tpr * rpb || y >= rows || x16 >= cols) return;
+    const uint8_t* s = src + (size_t)b * sstride + (size_t)y * step + x16;
+    const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(s) & 3);
+    const uint32_t* sa = reinterpret_cast<const uint32_t*>(s - sh);
+    const int nvalid = cols - x16;                                   // bytes of this row still to copy (>= 1)
+    uint32_t d[5];
 #pragma unroll
-    for (int k = 0; k < 4; k++) if (x4 + k < cols) v |= (uint32_t)s[k] << (8 * k);
-    *reinterpret_cast<uint32_t*>(dst + (size_t)b * dstride + (size_t)y * dpitch + x4) = v;
+    for (int j = 0; j < 5; j++) d[j] = (4 * j < (int)sh + nvalid) ? sa[j] : 0u;     // a dword is read only if it holds a byte of the row
+    uint4 o;
+    o.x = __builtin_amdgcn_alignbyte(d[1], d[0], sh); o.y = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
+    o.z = __builtin_amdgcn_alignbyte(d[3], d[2], sh); o.w = __builtin_amdgcn_alignbyte(d[4], d[3], sh);
+    uint8_t* q = dst + (size_t)b * dstride + (size_t)y * dpitch + x16;
+    if (x16 + 16 <= dpitch) *reinterpret_cast<uint4*>(q) = o;        // pitch is a multiple of 64: padding bytes may be written
+    else { uint32_t w[4] = {o.x, o.y, o.z, o.w}; for (int j = 0; j < 4 && x16 + 4 * j < dpitch; j++) reinterpret_cast<uint32_t*>(q)[j] = w[j]; }
 }
 
 void launch_ingest(const uint8_t* src, int rows, int cols, int step, size_t sstride, uint8_t* dst, int dpitch,
                    size_t dstride, int batch, hipStream_t s) {
-    dim3 grid((cols + 1023) / 1024, rows, batch);
-    hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, s, src, rows, cols, step, sstride, dst, dpitch, dstride);
+    const int t = (cols + 15) / 16;
+    const int tpr = t < 256 ? t : 256, rpb = t < 256 ? 256 / t : 1;
+    dim3 grid((t + 255) / 256, (rows + rpb - 1) / rpb, batch);
+    hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, s, src, rows, cols, step, sstride, dst, dpitch, dstride, tpr, rpb);
 }
 
 // ------------------------------------------------------------------------------------------------
 // launch helpers (called from orb_engine.hip)
 // ------------------------------------------------------------------------------------------------
 void launch_resize(const ResizeArgs& a, int batch, hipStream_t s) {
+    static const char* env = getenv("MYSLAM_RESIZE_V");           // tuning aid: 1 = one row per wave kernel
+    if (!(env && atoi(env) == 1)) {
+        const int nstrips = (a.dw + 255) / 256, nbands = (a.dh + RS_R - 1) / RS_R;
+        hipLaunchKernelGGL(k_resize_strip, dim3((nstrips * nbands + 3) / 4, 1, batch), dim3(256), 0, s, a, nstrips, nbands);
+        return;
+    }
     dim3 grid((a.dw + 255) / 256, (a.dh + 3) / 4, batch);
     hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, a);
 }
 
 void launch_blur(const BlurArgs& a, int batch, hipStream_t s) {
+    bool small = true;
+    for (int j = 0; j < 7; j++) small = small && a.q[j] >= 0 && a.q[j] <= 255;
+    static const char* env = getenv("MYSLAM_BLUR_V");             // tuning aid: 1 = multiply-add kernel, 2 = LDS dot kernel, 3 = register strips
+    const int v = env ? atoi(env) : 3;
+    if (small && v == 3 && a.w >= 8 && (a.spitch & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.src) | a.sstride) & 3) == 0) {
+        const int nstrips = (a.w + 255) / 256, nbands = (a.h + B3_R - 1) / B3_R;
+        hipLaunchKernelGGL(k_blur7_strip, dim3((nstrips * nbands + 3) / 4, 1, batch), dim3(256), 0, s, a, nstrips, nbands);
+        return;
+    }
+    if (small && v != 1) {
+        dim3 grid((a.w + B2_W - 1) / B2_W, (a.h + B2_H - 1) / B2_H, batch);
+        hipLaunchKernelGGL(k_blur7_dot, grid, dim3(256), 0, s, a);
+        return;
+    }
     dim3 grid((a.w + BT_W - 1) / BT_W, (a.h + BT_H - 1) / BT_H, batch);
     hipLaunchKernelGGL(k_blur7, grid, dim3(256), 0, s, a);
 }

@@ -44,6 +44,19 @@ def test_pyramid_and_blur_bitexact(api, oracle, synth, h, w):
         assert np.array_equal(gb, rb), f"blur level {l}: {np.count_nonzero(gb != rb)} px differ"
 
 
+@pytest.mark.parametrize("w", [252, 255, 256, 257, 258, 259, 260, 263, 264, 509, 512, 513, 516, 519, 771])
+def test_blur_strip_borders_bitexact(api, oracle, synth, w):
+    """The register-strip blur exchanges neighbour dwords between lanes and mirrors the right border with byte permutes whose
+    selectors depend on w mod 4 and on where the border falls inside a 256-column wave strip: sweep those cases (odd heights too)."""
+    h = 131 + (w % 3)
+    img = synth.random_image(7000 + w, h, w)
+    ext = api.ORBextractor(500, nlevels=2)
+    gb = ext.debug_pyramid(img, 0, blurred=True)
+    rb = oracle.blur7(img, 0)
+    assert gb.shape == rb.shape
+    assert np.array_equal(gb, rb), f"{np.count_nonzero(gb != rb)} px differ, first at {np.argwhere(gb != rb)[:3].tolist()}"
+
+
 @pytest.mark.parametrize("h,w", SIZES[:3])
 def test_fast_candidates_equal_as_sets(api, oracle, synth, h, w):
     img = synth.random_image(200 + w, h, w)
