@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void k_blur7_dot(BlurArgs a) {
 // columns 4l..4l+3, loads ONE aligned dword per input row (a fully coalesced 256-byte row segment per wave), gets its
 // neighbours' dwords over the DPP network (wave_shr/shl), keeps the last four vertical pairs of horizontal sums in
 // registers and emits two output rows per two input rows.  No LDS, no barriers.  Needs w >= 8 and taps <= 255.
-constexpr int B3_R = 32;                       // output rows per wave
+constexpr int B3_R = 16;                       // output rows per wave
 
 __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ uint32_t dpp_wave_shl1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
@@ -709,6 +709,46 @@ __device__ __forceinline__ int fast9_score_regs(const uint32_t (&r)[7][3], int m
     return s >= minTh ? s : 0;
 }
 
+// Two-pixel packing of the same score: register i holds ring position i of two horizontally adjacent pixels (raw u8
+// values in 16-bit lanes), so no difference to the centre is taken until the end:
+//   bright = max over arcs (min over the arc of p) - v,   dark = v - min over arcs (max over the arc of p).
+// The 16 arcs of 9 are covered from the 8 even-aligned windows of 8: arc [2k, 2k+8] = m8[k] + p[2k+8] and
+// arc [2k-1, 2k+7] = p[2k-1] + m8[k], and max(min(m, a), min(m, b)) = min(m, max(a, b)) — 47 packed ops per polarity
+// for two pixels.  Returns z = score - (minTh - 1) for corners at minTh, 0 otherwise (an order-preserving shift: the
+// NMS compares z, the append adds minTh - 1 back).  PAIR selects pixels (2 PAIR, 2 PAIR + 1) of the lane's four.
+template <int PAIR>
+__device__ __forceinline__ s16x2 fast9_score_pair(const uint32_t (&r)[7][3], s16x2 thv) {
+    constexpr int RX[16] = FAST_RING_X;
+    constexpr int RY[16] = FAST_RING_Y;
+    constexpr int xc = 3 + 2 * PAIR;
+    auto pick = [&](int row, int a) -> s16x2 {          // bytes a, a+1 of window row `row` as two 16-bit lanes
+        const int d0 = a >> 2, d1 = ((a & 3) == 3) ? d0 + 1 : d0;
+        const uint32_t u = __builtin_amdgcn_perm(r[row][d1], r[row][d0],
+                                                 0x0c000c00u | ((((a & 3) == 3) ? 4u : (uint32_t)(a & 3) + 1u) << 16) | (uint32_t)(a & 3));
+        s16x2 q; __builtin_memcpy(&q, &u, 4);
+        return q;
+    };
+    const s16x2 vv = pick(3, xc);
+    s16x2 p[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) p[i] = pick(3 + RY[i], xc + RX[i]);
+    s16x2 n2[8], x2[8], n4[8], x4[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { n2[k] = pmin(p[2 * k], p[2 * k + 1]); x2[k] = pmax(p[2 * k], p[2 * k + 1]); }
+#pragma unroll
+    for (int k = 0; k < 8; k++) { n4[k] = pmin(n2[k], n2[(k + 1) & 7]); x4[k] = pmax(x2[k], x2[(k + 1) & 7]); }
+    s16x2 brt = {0, 0}, drk = {255, 255};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const s16x2 n8 = pmin(n4[k], n4[(k + 2) & 7]), x8 = pmax(x4[k], x4[(k + 2) & 7]);       // ring positions 2k .. 2k+7
+        const s16x2 a = p[(2 * k + 8) & 15], c = p[(2 * k + 15) & 15];
+        brt = pmax(brt, pmin(n8, pmax(a, c)));
+        drk = pmin(drk, pmax(x8, pmin(a, c)));
+    }
+    const s16x2 sraw = pmax(brt - vv, vv - drk);             // score + 1
+    return pmax(sraw, thv) - thv;
+}
+
 template <int C>
 __device__ __forceinline__ bool nms_regs(const uint32_t (&m)[3][3], int& s_out) {
     auto by = [&](int row, int x) -> int { return (int)((m[row][x >> 2] >> (8 * (x & 3))) & 0xff); };
@@ -894,6 +934,8 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
     if (threadIdx.x < G) { s_cnt[threadIdx.x] = 0; s_ini[threadIdx.x] = 0; }
     __syncthreads();
 
+    const s16x2 thv = {(short)P.minTh, (short)P.minTh};
+    const int zoff = P.minTh - 1;                                      // the score map holds z = score - zoff
     const int ngr = (g.wCell + 3) >> 2, per_cell = ngr * hc, nitems = ncell * per_cell;
     for (int q = threadIdx.x; q < nitems; q += T) {
         const int c = q / per_cell, rem = q - c * per_cell;
@@ -912,12 +954,12 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
             r[j][1] = __builtin_amdgcn_alignbyte(w2, w1, sh);
             r[j][2] = __builtin_amdgcn_alignbyte(w3, w2, sh);
         }
-        uint32_t s0 = fast9_score_regs<0>(r, P.minTh), s1 = fast9_score_regs<1>(r, P.minTh);
-        uint32_t s2 = fast9_score_regs<2>(r, P.minTh), s3 = fast9_score_regs<3>(r, P.minTh);
-        if (cx + 1 >= wc) s1 = 0;
-        if (cx + 2 >= wc) s2 = 0;
-        if (cx + 3 >= wc) s3 = 0;
-        *reinterpret_cast<uint32_t*>(&s_score[c][(cy + 1) * SP + 4 + cx]) = s0 | (s1 << 8) | (s2 << 16) | (s3 << 24);
+        const s16x2 za = fast9_score_pair<0>(r, thv), zb = fast9_score_pair<1>(r, thv);
+        uint32_t ua, ub;
+        __builtin_memcpy(&ua, &za, 4); __builtin_memcpy(&ub, &zb, 4);
+        uint32_t packed = __builtin_amdgcn_perm(ub, ua, 0x06040200u);           // the four z bytes
+        if (wc - cx < 4) packed &= (1u << (8 * (wc - cx))) - 1u;
+        *reinterpret_cast<uint32_t*>(&s_score[c][(cy + 1) * SP + 4 + cx]) = packed;
     }
     __syncthreads();
     for (int q = threadIdx.x; q < nitems; q += T) {
@@ -938,8 +980,8 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
             if (mx[k]) {
                 const int px = 4 * gi + k + 3 + (cj0 + c) * g.wCell, py = cy + 3 + ci * g.hCell;     // border-relative
                 const int pos = atomicAdd(&s_cnt[c], 1);
-                if (pos < NLOC) s_list[c][pos] = ((uint32_t)py << 20) | ((uint32_t)px << 8) | (uint32_t)sc[k];
-                if (sc[k] >= P.iniTh) s_ini[c] = 1;
+                if (pos < NLOC) s_list[c][pos] = ((uint32_t)py << 20) | ((uint32_t)px << 8) | (uint32_t)(sc[k] + zoff);
+                if (sc[k] + zoff >= P.iniTh) s_ini[c] = 1;
             }
         }
     }
