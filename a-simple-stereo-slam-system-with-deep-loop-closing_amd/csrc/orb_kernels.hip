@@ -876,6 +876,30 @@ __global__ __launch_bounds__(T) void k_fast_cells_v3(OrbPlan P, const uint8_t* _
     }
 }
 
+// 3x3 strict-maximum test for pixels (2 PAIR, 2 PAIR + 1) of the lane's four, on 16-bit lanes: 9 byte-pair picks,
+// 7 packed max, one packed subtract.  m = 3 rows x 12 bytes of the score map, the lane's pixels at bytes 4..7.
+// Returns bit 0 / bit 1 = pixel is a strict maximum (which implies its score is non-zero); zc = the two centre scores.
+template <int PAIR>
+__device__ __forceinline__ int nms_pair(const uint32_t (&m)[3][3], uint32_t& zc) {
+    constexpr int x = 4 + 2 * PAIR;
+    auto pick = [&](int row, int a) -> s16x2 {
+        const int d0 = a >> 2, d1 = ((a & 3) == 3) ? d0 + 1 : d0;
+        const uint32_t u = __builtin_amdgcn_perm(m[row][d1], m[row][d0],
+                                                 0x0c000c00u | ((((a & 3) == 3) ? 4u : (uint32_t)(a & 3) + 1u) << 16) | (uint32_t)(a & 3));
+        s16x2 q; __builtin_memcpy(&q, &u, 4);
+        return q;
+    };
+    const s16x2 c = pick(1, x);
+    s16x2 nb = pmax(pick(0, x - 1), pick(0, x));
+    nb = pmax(nb, pick(0, x + 1));
+    nb = pmax(nb, pmax(pick(1, x - 1), pick(1, x + 1)));
+    nb = pmax(nb, pmax(pick(2, x - 1), pick(2, x)));
+    nb = pmax(nb, pick(2, x + 1));
+    const s16x2 d = c - nb;
+    __builtin_memcpy(&zc, &c, 4);
+    return ((int)d.x > 0 ? 1 : 0) | ((int)d.y > 0 ? 2 : 0);
+}
+
 // ---- strip variant: one block scores G horizontally adjacent cells -----------------------------------
 // Same arithmetic as k_fast_cells_v3 per cell (NMS and the 20 -> 7 fallback never cross a cell border), but the
 // ROI rows of G cells are staged once (shared 6-px halos), block dispatch / barriers / the global append are
@@ -885,7 +909,8 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
                                                     const uint8_t* __restrict__ maskPyr,
                                                     uint32_t* __restrict__ cand, int32_t* __restrict__ candCount) {
     constexpr int T = 256;
-    constexpr int TP = (3 + G * CW + 6 + 16 + 3) & ~3;
+    constexpr int TP = (15 + G * CW + 6 + 16 + 15) & ~15;              // row pitch of the staged tile (16-byte aligned rows)
+    constexpr int NQ = TP / 16;                                        // 16-byte groups per row
     constexpr int TROWS = CW + 6;
     constexpr int SP = (CW + 4 + 8 + 3) & ~3;
     constexpr int SROWS = CW + 2;
@@ -923,16 +948,30 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
     const int iniX0 = MIN_BORDER + cj0 * g.wCell;
     const int endX = MIN_BORDER + (cj0 + ncell - 1) * g.wCell + wcs[ncell - 1] + 6;     // exclusive right edge of the last ROI
     const uint8_t* img = pyr + (size_t)b * pyrStride + g.imgOff;
-    const int x0a = iniX0 & ~3, off = iniX0 - x0a;
-    const int ndw = (endX - x0a + 3) >> 2;
-    for (int i = threadIdx.x; i < hr * 64; i += T) {                   // ndw <= 64 dwords per row
-        const int r = i >> 6, k = i & 63;
-        if (k < ndw) *reinterpret_cast<uint32_t*>(&s_tile[r * TP + 4 * k]) =
-            *reinterpret_cast<const uint32_t*>(img + (size_t)(iniY + r) * g.pitch + x0a + 4 * k);
+    const int x0a = iniX0 & ~15, off = iniX0 - x0a;                    // level planes are 256-byte aligned with 64-byte pitch
+    const int nq = min((endX - x0a + 15) >> 4, NQ);
+    {   // all loads of a thread are issued before its LDS stores
+        constexpr int NIT = (TROWS * NQ + T - 1) / T;
+        uint4 v[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; u++) {
+            const int i = threadIdx.x + u * T, r = i / NQ, k = i - r * NQ;
+            if (r < hr && k < nq && x0a + 16 * k < g.pitch)
+                v[u] = *reinterpret_cast<const uint4*>(img + (size_t)(iniY + r) * g.pitch + x0a + 16 * k);
+            else v[u] = make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; u++) {
+            const int i = threadIdx.x + u * T, r = i / NQ, k = i - r * NQ;
+            if (r < hr && k < nq) *reinterpret_cast<uint4*>(&s_tile[r * TP + 16 * k]) = v[u];
+        }
     }
     for (int i = threadIdx.x; i < G * ((SROWS * SP + 16) / 4); i += T) reinterpret_cast<uint32_t*>(&s_score[0][0])[i] = 0;
     if (threadIdx.x < G) { s_cnt[threadIdx.x] = 0; s_ini[threadIdx.x] = 0; }
     __syncthreads();
+#if defined(MYSLAM_FAST_STOP) && MYSLAM_FAST_STOP == 1
+    return;
+#endif
 
     const s16x2 thv = {(short)P.minTh, (short)P.minTh};
     const int zoff = P.minTh - 1;                                      // the score map holds z = score - zoff
@@ -962,6 +1001,9 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
         *reinterpret_cast<uint32_t*>(&s_score[c][(cy + 1) * SP + 4 + cx]) = packed;
     }
     __syncthreads();
+#if defined(MYSLAM_FAST_STOP) && MYSLAM_FAST_STOP == 2
+    return;
+#endif
     for (int q = threadIdx.x; q < nitems; q += T) {
         const int c = q / per_cell, rem = q - c * per_cell;
         const int cy = rem / ngr, gi = rem - cy * ngr;
@@ -973,8 +1015,12 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
             const uint32_t* rp = reinterpret_cast<const uint32_t*>(&s_score[c][(cy + j) * SP + 4 * gi]);
             m[j][0] = rp[0]; m[j][1] = rp[1]; m[j][2] = rp[2];
         }
-        int sc[4]; bool mx[4];
-        mx[0] = nms_regs<0>(m, sc[0]); mx[1] = nms_regs<1>(m, sc[1]); mx[2] = nms_regs<2>(m, sc[2]); mx[3] = nms_regs<3>(m, sc[3]);
+        if (m[1][1] == 0) continue;                                    // none of the four pixels is a corner
+        uint32_t za, zb;
+        const int ma = nms_pair<0>(m, za), mb = nms_pair<1>(m, zb);
+        if ((ma | mb) == 0) continue;
+        const int sc[4] = {(int)(za & 0xffff), (int)(za >> 16), (int)(zb & 0xffff), (int)(zb >> 16)};
+        const bool mx[4] = {(ma & 1) != 0, (ma & 2) != 0, (mb & 1) != 0, (mb & 2) != 0};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (mx[k]) {
@@ -987,6 +1033,9 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
     }
     if (threadIdx.x == 0) { s_npass = 0; s_wr = 0; }
     __syncthreads();
+#if defined(MYSLAM_FAST_STOP) && MYSLAM_FAST_STOP == 3
+    return;
+#endif
     const uint8_t* mimg = maskPyr ? maskPyr + (size_t)b * pyrStride + g.imgOff : nullptr;
     auto passes = [&](uint32_t kp, int has_ini) -> bool {
         if (has_ini && (int)(kp & 0xff) < P.iniTh) return false;      // :858-865: th 20 if the cell has any, else th 7
