@@ -914,11 +914,10 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
     constexpr int TROWS = CW + 6;
     constexpr int SP = (CW + 4 + 8 + 3) & ~3;
     constexpr int SROWS = CW + 2;
-    constexpr int NLOC = ((CW + 1) / 2) * ((CW + 1) / 2);
+    constexpr int NIT = (G * ((CW + 3) / 4) * CW + T - 1) / T;         // work items (4 pixels each) per thread, upper bound
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[TROWS * TP + 16];
     __shared__ __attribute__((aligned(16))) uint8_t s_score[G][SROWS * SP + 16];
-    __shared__ uint32_t s_list[G][NLOC];
-    __shared__ int s_cnt[G], s_ini[G], s_base, s_npass, s_wr;
+    __shared__ int s_ini[G];
 
     const int b = blockIdx.y;
     int level = 0;
@@ -967,7 +966,7 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
         }
     }
     for (int i = threadIdx.x; i < G * ((SROWS * SP + 16) / 4); i += T) reinterpret_cast<uint32_t*>(&s_score[0][0])[i] = 0;
-    if (threadIdx.x < G) { s_cnt[threadIdx.x] = 0; s_ini[threadIdx.x] = 0; }
+    if (threadIdx.x < G) s_ini[threadIdx.x] = 0;
     __syncthreads();
 #if defined(MYSLAM_FAST_STOP) && MYSLAM_FAST_STOP == 1
     return;
@@ -976,9 +975,19 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
     const s16x2 thv = {(short)P.minTh, (short)P.minTh};
     const int zoff = P.minTh - 1;                                      // the score map holds z = score - zoff
     const int ngr = (g.wCell + 3) >> 2, per_cell = ngr * hc, nitems = ncell * per_cell;
+    // q -> (cell c, row cy, 4-pixel group gi) without integer division: q < 2^12, so a float reciprocal + one fix-up is exact
+    const float inv_pc = 1.0f / (float)per_cell, inv_ngr = 1.0f / (float)ngr;
+    auto split = [&](int q, int& c, int& cy, int& gi) {
+        c = (int)(((float)q + 0.5f) * inv_pc);
+        int rem = q - c * per_cell;
+        if (rem < 0) { c--; rem += per_cell; } else if (rem >= per_cell) { c++; rem -= per_cell; }
+        cy = (int)(((float)rem + 0.5f) * inv_ngr);
+        gi = rem - cy * ngr;
+        if (gi < 0) { cy--; gi += ngr; } else if (gi >= ngr) { cy++; gi -= ngr; }
+    };
     for (int q = threadIdx.x; q < nitems; q += T) {
-        const int c = q / per_cell, rem = q - c * per_cell;
-        const int cy = rem / ngr, gi = rem - cy * ngr;
+        int c, cy, gi;
+        split(q, c, cy, gi);
         const int wc = (c == 0) ? wcs[0] : (c == 1) ? wcs[1 % G] : (c == 2) ? wcs[2 % G] : wcs[3 % G];
         const int cx = 4 * gi;
         if (cx >= wc) continue;
@@ -1004,9 +1013,17 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
 #if defined(MYSLAM_FAST_STOP) && MYSLAM_FAST_STOP == 2
     return;
 #endif
-    for (int q = threadIdx.x; q < nitems; q += T) {
-        const int c = q / per_cell, rem = q - c * per_cell;
-        const int cy = rem / ngr, gi = rem - cy * ngr;
+    // NMS: strict maxima stay in registers (position, 4 z bytes, 4-bit mask per work item); only the per-cell
+    // "has a corner at iniTh" flag goes through LDS.
+    uint32_t rpos[NIT], rz[NIT];
+    uint64_t rmask = 0;
+#pragma unroll
+    for (int u = 0; u < NIT; u++) {
+        const int q = threadIdx.x + u * T;
+        rpos[u] = 0; rz[u] = 0;
+        if (q >= nitems) continue;
+        int c, cy, gi;
+        split(q, c, cy, gi);
         const int wc = (c == 0) ? wcs[0] : (c == 1) ? wcs[1 % G] : (c == 2) ? wcs[2 % G] : wcs[3 % G];
         if (4 * gi >= wc) continue;
         uint32_t m[3][3];
@@ -1018,52 +1035,64 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
         if (m[1][1] == 0) continue;                                    // none of the four pixels is a corner
         uint32_t za, zb;
         const int ma = nms_pair<0>(m, za), mb = nms_pair<1>(m, zb);
-        if ((ma | mb) == 0) continue;
-        const int sc[4] = {(int)(za & 0xffff), (int)(za >> 16), (int)(zb & 0xffff), (int)(zb >> 16)};
-        const bool mx[4] = {(ma & 1) != 0, (ma & 2) != 0, (mb & 1) != 0, (mb & 2) != 0};
+        const int mk = ma | (mb << 2);
+        if (mk == 0) continue;
+        const int px = 4 * gi + 3 + (cj0 + c) * g.wCell, py = cy + 3 + ci * g.hCell;     // border-relative, of pixel 0
+        rpos[u] = ((uint32_t)py << 20) | ((uint32_t)px << 8) | (uint32_t)c;
+        rz[u] = m[1][1];
+        rmask |= (uint64_t)mk << (4 * u);
+        int zmax = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (mx[k]) {
-                const int px = 4 * gi + k + 3 + (cj0 + c) * g.wCell, py = cy + 3 + ci * g.hCell;     // border-relative
-                const int pos = atomicAdd(&s_cnt[c], 1);
-                if (pos < NLOC) s_list[c][pos] = ((uint32_t)py << 20) | ((uint32_t)px << 8) | (uint32_t)(sc[k] + zoff);
-                if (sc[k] + zoff >= P.iniTh) s_ini[c] = 1;
-            }
-        }
+        for (int k2 = 0; k2 < 4; k2++) if ((mk >> k2) & 1) zmax = max(zmax, (int)((m[1][1] >> (8 * k2)) & 0xff));
+        if (zmax + zoff >= P.iniTh) s_ini[c] = 1;
     }
-    if (threadIdx.x == 0) { s_npass = 0; s_wr = 0; }
     __syncthreads();
-#if defined(MYSLAM_FAST_STOP) && MYSLAM_FAST_STOP == 3
-    return;
-#endif
+    // filter (:858-865: th 20 if the cell has any such corner, else th 7; mask :873-877) and append: one global atomic per wave
     const uint8_t* mimg = maskPyr ? maskPyr + (size_t)b * pyrStride + g.imgOff : nullptr;
-    auto passes = [&](uint32_t kp, int has_ini) -> bool {
-        if (has_ini && (int)(kp & 0xff) < P.iniTh) return false;      // :858-865: th 20 if the cell has any, else th 7
-        if (mimg) {                                                   // :873-877 (no +16: reference quirk)
-            const int px = (kp >> 8) & 0xfff, py = kp >> 20;
-            if (mimg[(size_t)py * g.pitch + px] == 0) return false;
-        }
-        return true;
-    };
+    int ini_bits = 0;
+#pragma unroll
+    for (int c = 0; c < G; c++) ini_bits |= (s_ini[c] ? 1 : 0) << c;
     int npass = 0;
-    for (int c = 0; c < ncell; c++) {
-        const int nloc = min(s_cnt[c], NLOC), hi = s_ini[c];
-        for (int i = threadIdx.x; i < nloc; i += T) npass += passes(s_list[c][i], hi) ? 1 : 0;
+    uint64_t keep = 0;
+#pragma unroll
+    for (int u = 0; u < NIT; u++) {
+        const int mk = (int)((rmask >> (4 * u)) & 0xf);
+        if (!mk) continue;
+        const int c = rpos[u] & 0xff, px0 = (rpos[u] >> 8) & 0xfff, py = rpos[u] >> 20;
+        const bool hi = (ini_bits >> c) & 1;
+#pragma unroll
+        for (int k2 = 0; k2 < 4; k2++) {
+            if (!((mk >> k2) & 1)) continue;
+            const int sc = (int)((rz[u] >> (8 * k2)) & 0xff) + zoff;
+            if (hi && sc < P.iniTh) continue;
+            if (mimg && mimg[(size_t)py * g.pitch + px0 + k2] == 0) continue;           // (no +16: reference quirk)
+            keep |= 1ull << (4 * u + k2);
+            npass++;
+        }
     }
-    if (npass) atomicAdd(&s_npass, npass);
-    __syncthreads();
-    const int n = s_npass;
-    if (n == 0) return;
-    if (threadIdx.x == 0) s_base = atomicAdd(&candCount[b * MAXL + level], n);
-    __syncthreads();
+    // wave-wide exclusive prefix of npass
+    const int lane = threadIdx.x & 63;
+    int incl = npass;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int n2 = __shfl_up(incl, o, 64); if (lane >= o) incl += n2; }
+    const int total = __shfl(incl, 63, 64);
+    if (total == 0) return;
+    int base = 0;
+    if (lane == 63) base = atomicAdd(&candCount[b * MAXL + level], total);
+    base = __shfl(base, 63, 64);
     uint32_t* out = cand + (size_t)b * P.totalKeyCap + g.keyOff;
-    for (int c = 0; c < ncell; c++) {
-        const int nloc = min(s_cnt[c], NLOC), hi = s_ini[c];
-        for (int i = threadIdx.x; i < nloc; i += T) {
-            const uint32_t kp = s_list[c][i];
-            if (!passes(kp, hi)) continue;
-            const int dst = s_base + atomicAdd(&s_wr, 1);
+    int dst = base + incl - npass;
+#pragma unroll
+    for (int u = 0; u < NIT; u++) {
+        const int kb = (int)((keep >> (4 * u)) & 0xf);
+        if (!kb) continue;
+#pragma unroll
+        for (int k2 = 0; k2 < 4; k2++) {
+            if (!((kb >> k2) & 1)) continue;
+            const uint32_t sc = ((rz[u] >> (8 * k2)) & 0xff) + (uint32_t)zoff;
+            const uint32_t kp = (rpos[u] & 0xfff00000u) | ((((rpos[u] >> 8) & 0xfff) + (uint32_t)k2) << 8) | sc;
             if (dst < g.keyCap) out[dst] = kp;
+            dst++;
         }
     }
 }
