@@ -11,6 +11,7 @@
 // (the reference runs Caffe in f32); conv2 uses v_mfma_f32_32x32x2_f32, which is an exact f32 FMA chain.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -24,6 +25,8 @@ void launch_blur(const BlurArgs& a, int batch, hipStream_t s);
 void gauss_q8(int kind, int q[7]);
 
 constexpr int IN_H = 120, IN_W = 160;
+// the network input lives in a zero-padded plane (conv1 pad 4 + what the clipped pool windows still touch): no bounds tests
+constexpr int IN_PAD = 4, IN_PH = IN_H + IN_PAD + 5, IN_PW = 176, IN_PLANE = IN_PH * IN_PW;
 constexpr int C1 = 64, H1 = 62, W1 = 82, HP1 = 31, WP1 = 41;
 constexpr int C2 = 128, H2 = 32, W2 = 42, HP2 = 16, WP2 = 21;
 constexpr int C3 = 4, H3 = 14, W3 = 19;
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void k_lcd_input(const uint8_t* __restrict__ s
     const int r0 = S0[sx] * a0 + S0[sx1] * a1, r1 = S1[sx] * a0 + S1[sx1] * a1;
     int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
     v = min(max(v, 0), 255);
-    out[(size_t)b * IN_H * IN_W + i] = (float)v * (float)(1.0 / 255.0);      // deeplcd.cpp:64 convertTo(CV_32F, 1/255.)
+    out[(size_t)b * IN_PLANE + (dy + IN_PAD) * IN_PW + dx + IN_PAD] = (float)v * (float)(1.0 / 255.0);      // deeplcd.cpp:64 convertTo(CV_32F, 1/255.)
 }
 
 // ---- conv1 + ReLU: lane = output channel, one wave walks 8 output pixels ----
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(256) void k_conv1(const float* __restrict__ in, con
 #pragma unroll
     for (int k = 0; k < 25; k++) w[k] = w1t[k * 64 + lane];
     const float bias = b1[lane];
-    const float* I = in + (size_t)b * IN_H * IN_W;
+    const float* I = in + (size_t)b * IN_PLANE;
     const int p0 = (blockIdx.x * 4 + wave) * 8;
     for (int p = p0; p < min(p0 + 8, H1 * W1); p++) {
         const int oy = p / W1, ox = p - oy * W1;
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256) void k_conv1(const float* __restrict__ in, con
 #pragma unroll
             for (int kx = 0; kx < 5; kx++) {
                 const int ix = ox * 2 + kx - 4;
-                const float v = (iy >= 0 && iy < IN_H && ix >= 0 && ix < IN_W) ? I[iy * IN_W + ix] : 0.f;
+                const float v = I[(iy + IN_PAD) * IN_PW + ix + IN_PAD];
                 acc += w[ky * 5 + kx] * v;
             }
         }
@@ -118,6 +121,61 @@ __global__ __launch_bounds__(256) void k_pool_lrn(const float* __restrict__ in, 
             out[((size_t)b * OH * OW + p) * C + c] = v[2] * powf(scale, -0.75f);
         }
     }
+}
+
+// ---- conv1 + ReLU + max-pool + LRN fused: one wave per POOLED pixel, lane = channel ----
+// The 3x3 (clipped) pool window needs 9 conv1 outputs = a 9x9 input window, which is wave-uniform: it is fetched with
+// scalar loads and fed to v_fmac as SGPR operands, so the conv1 activation map (1.3 MB per image) never exists in HBM.
+// Same operation order per output as k_conv1 + k_pool_lrn (tap order ky,kx; LRN sum over c-2..c+2), so the results are
+// identical to the unfused pair; the LRN neighbours come over lane shuffles instead of LDS.
+__global__ __launch_bounds__(256) void k_conv1_pool_lrn(const float* __restrict__ in, const float* __restrict__ w1t /*[25][64]*/,
+                                                        const float* __restrict__ b1, float* __restrict__ out /*[HP1*WP1][64]*/) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int p = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (p >= HP1 * WP1) return;
+    float w[25];
+#pragma unroll
+    for (int k = 0; k < 25; k++) w[k] = w1t[k * 64 + lane];
+    const float bias = b1[lane];
+    const int oy = p / WP1, ox = p - oy * WP1;
+    const float* I = in + (size_t)b * IN_PLANE + (4 * oy) * IN_PW + 4 * ox;      // window origin (input row 4 oy - 4, col 4 ox - 4)
+    float win[9][9];
+#pragma unroll
+    for (int r = 0; r < 9; r++)
+#pragma unroll
+        for (int c = 0; c < 9; c++) win[r][c] = I[r * IN_PW + c];
+    float m = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) {
+            float acc = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 5; ky++)
+#pragma unroll
+                for (int kx = 0; kx < 5; kx++) acc += w[ky * 5 + kx] * win[2 * dy + ky][2 * dx + kx];
+            const bool inside = 2 * oy + dy < H1 && 2 * ox + dx < W1;      // Caffe ceil-mode pooling: clipped window
+            m = fmaxf(m, inside ? fmaxf(acc + bias, 0.f) : -INFINITY);
+        }
+    // LRN(5, 1e-4, 0.75) across the 64 channels (zero padded)
+    const float um1 = __shfl_up(m, 1, 64), um2 = __shfl_up(m, 2, 64), dp1 = __shfl_down(m, 1, 64), dp2 = __shfl_down(m, 2, 64);
+    const float v0 = lane >= 2 ? um2 : 0.f, v1 = lane >= 1 ? um1 : 0.f, v3 = lane <= 62 ? dp1 : 0.f, v4 = lane <= 61 ? dp2 : 0.f;
+    float ss = 0.f;
+    ss += v0 * v0; ss += v1 * v1; ss += m * m; ss += v3 * v3; ss += v4 * v4;
+    const float scale = 1.f + (1e-4f / 5.f) * ss;
+    out[((size_t)b * HP1 * WP1 + p) * 64 + lane] = m * powf(scale, -0.75f);
+}
+
+// f32 wave sum on the DPP network; the total lands in lane 63
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add_f32(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_lane63_f32(float v) {
+    v = dpp_add_f32<0xB1, 0xf>(v); v = dpp_add_f32<0x4E, 0xf>(v); v = dpp_add_f32<0x141, 0xf>(v); v = dpp_add_f32<0x140, 0xf>(v);
+    v = dpp_add_f32<0x142, 0xa>(v); v = dpp_add_f32<0x143, 0xc>(v);
+    return v;
 }
 
 // ---- conv2 + ReLU as an fp32 MFMA implicit GEMM ----
@@ -213,28 +271,35 @@ __global__ __launch_bounds__(256) void k_conv2_mfma(const float* __restrict__ in
     }
 }
 
-// ---- conv3 + ReLU + flatten (NCHW order) + L2 normalise; one block per image ----
-__global__ __launch_bounds__(256) void k_conv3_norm(const float* __restrict__ in /*[B][16*21][128]*/,
-                                                    const float* __restrict__ w3t /*[1152][4]*/, const float* __restrict__ b3,
-                                                    float* __restrict__ out /*[B][1064]*/, int relu) {
+// ---- conv3 + ReLU + flatten (NCHW order) + L2 normalise; one 1024-thread block per image ----
+// 16 waves share the 266 output pixels; each lane keeps its 18 weight quadruples (k = lane + 64 j) in registers.
+constexpr int CV3_T = 1024, CV3_NW = CV3_T / 64;
+__global__ __launch_bounds__(CV3_T) void k_conv3_norm(const float* __restrict__ in /*[B][16*21][128]*/,
+                                                      const float* __restrict__ w3t /*[1152][4]*/, const float* __restrict__ b3,
+                                                      float* __restrict__ out /*[B][1064]*/, int relu) {
     __shared__ float s_o[C3 * H3 * W3];
-    __shared__ float s_red[4];
+    __shared__ float s_red[CV3_NW];
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* I = in + (size_t)b * HP2 * WP2 * 128;
     const float4* Wt = reinterpret_cast<const float4*>(w3t);
-    for (int p = wave; p < H3 * W3; p += 4) {
+    float4 w[18];
+#pragma unroll
+    for (int j = 0; j < 18; j++) w[j] = Wt[lane + 64 * j];
+    for (int p = wave; p < H3 * W3; p += CV3_NW) {
         const int oy = p / W3, ox = p - oy * W3;
-        float4 acc = make_float4(0, 0, 0, 0);
-        for (int k = lane; k < 1152; k += 64) {
-            const int tap = k >> 7, ic = k & 127;
-            const float v = I[((size_t)(oy + tap / 3) * WP2 + ox + tap % 3) * 128 + ic];
-            const float4 w = Wt[k];
-            acc.x += v * w.x; acc.y += v * w.y; acc.z += v * w.z; acc.w += v * w.w;
+        float v[18];
+#pragma unroll
+        for (int j = 0; j < 18; j++) {
+            const int k = lane + 64 * j, tap = k >> 7, ic = k & 127;
+            v[j] = I[((size_t)(oy + tap / 3) * WP2 + ox + tap % 3) * 128 + ic];
         }
-        acc.x = wave_reduce_sum(acc.x); acc.y = wave_reduce_sum(acc.y);
-        acc.z = wave_reduce_sum(acc.z); acc.w = wave_reduce_sum(acc.w);
-        if (lane == 0) {
+        float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 18; j++) { acc.x += v[j] * w[j].x; acc.y += v[j] * w[j].y; acc.z += v[j] * w[j].z; acc.w += v[j] * w[j].w; }
+        acc.x = wave_sum_lane63_f32(acc.x); acc.y = wave_sum_lane63_f32(acc.y);
+        acc.z = wave_sum_lane63_f32(acc.z); acc.w = wave_sum_lane63_f32(acc.w);
+        if (lane == 63) {
             float r[4] = {acc.x + b3[0], acc.y + b3[1], acc.z + b3[2], acc.w + b3[3]};
 #pragma unroll
             for (int c = 0; c < 4; c++) s_o[c * H3 * W3 + p] = relu ? fmaxf(r[c], 0.f) : r[c];
@@ -242,12 +307,15 @@ __global__ __launch_bounds__(256) void k_conv3_norm(const float* __restrict__ in
     }
     __syncthreads();
     float ss = 0.f;
-    for (int i = threadIdx.x; i < MYSLAM_LCD_DIM; i += 256) ss += s_o[i] * s_o[i];
-    ss = wave_reduce_sum(ss);
-    if (lane == 0) s_red[wave] = ss;
+    for (int i = threadIdx.x; i < MYSLAM_LCD_DIM; i += CV3_T) ss += s_o[i] * s_o[i];
+    ss = wave_sum_lane63_f32(ss);
+    if (lane == 63) s_red[wave] = ss;
     __syncthreads();
-    const float nrm = sqrtf(s_red[0] + s_red[1] + s_red[2] + s_red[3]);       // deeplcd.cpp:88
-    for (int i = threadIdx.x; i < MYSLAM_LCD_DIM; i += 256) out[(size_t)b * MYSLAM_LCD_DIM + i] = s_o[i] / nrm;
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < CV3_NW; i++) tot += s_red[i];
+    const float nrm = sqrtf(tot);                                             // deeplcd.cpp:88
+    for (int i = threadIdx.x; i < MYSLAM_LCD_DIM; i += CV3_T) out[(size_t)b * MYSLAM_LCD_DIM + i] = s_o[i] / nrm;
 }
 
 static void lcd_resize_tables(int ssize, int dsize, bool is_x, std::vector<int32_t>& ofs, std::vector<int16_t>& coef) {
@@ -326,7 +394,8 @@ int myslam_lcd::ensure_batch(int batch, int r, int c) {
     blurPitch = (c + 63) / 64 * 64;
     blurBytes = ((size_t)blurPitch * r + 255) / 256 * 256;
     if ((rc = lcd_alloc(d_blur, blurBytes * batch))) return rc;
-    if ((rc = lcd_alloc(d_in, (size_t)batch * IN_H * IN_W))) return rc;
+    if ((rc = lcd_alloc(d_in, (size_t)batch * IN_PLANE))) return rc;
+    MYSLAM_HIP_CHECK(hipMemsetAsync(d_in, 0, (size_t)batch * IN_PLANE * sizeof(float), stream));     // the padding stays zero: writers touch the interior only
     if ((rc = lcd_alloc(d_a1, (size_t)batch * H1 * W1 * C1))) return rc;
     if ((rc = lcd_alloc(d_p1, (size_t)batch * HP1 * WP1 * C1))) return rc;
     if ((rc = lcd_alloc(d_a2, (size_t)batch * H2 * W2 * C2))) return rc;
@@ -339,8 +408,13 @@ static int lcd_forward(myslam_lcd* h, int batch, float* d_out) {
     hipStream_t s = h->stream;
     {
         ScopedProf sp(P_CONV1, s);
-        hipLaunchKernelGGL(k_conv1, dim3((H1 * W1 + 31) / 32, batch), dim3(256), 0, s, h->d_in, h->d_w1t, h->d_b1, h->d_a1);
-        hipLaunchKernelGGL((k_pool_lrn<C1>), dim3((HP1 * WP1 + 3) / 4, batch), dim3(256), 0, s, h->d_a1, H1, W1, HP1, WP1, h->d_p1);
+        static const char* env = getenv("MYSLAM_CONV1_V");        // tuning aid: 1 = unfused conv1 -> pool/LRN pair
+        if (env && atoi(env) == 1) {
+            hipLaunchKernelGGL(k_conv1, dim3((H1 * W1 + 31) / 32, batch), dim3(256), 0, s, h->d_in, h->d_w1t, h->d_b1, h->d_a1);
+            hipLaunchKernelGGL((k_pool_lrn<C1>), dim3((HP1 * WP1 + 3) / 4, batch), dim3(256), 0, s, h->d_a1, H1, W1, HP1, WP1, h->d_p1);
+        } else {
+            hipLaunchKernelGGL(k_conv1_pool_lrn, dim3((HP1 * WP1 + 3) / 4, batch), dim3(256), 0, s, h->d_in, h->d_w1t, h->d_b1, h->d_p1);
+        }
     }
     {
         ScopedProf sp(P_CONV2, s);
@@ -350,7 +424,7 @@ static int lcd_forward(myslam_lcd* h, int batch, float* d_out) {
     {
         ScopedProf sp(P_CONV3, s);
         hipLaunchKernelGGL((k_pool_lrn<C2>), dim3((HP2 * WP2 + 3) / 4, batch), dim3(256), 0, s, h->d_a2, H2, W2, HP2, WP2, h->d_p2);
-        hipLaunchKernelGGL(k_conv3_norm, dim3(batch), dim3(256), 0, s, h->d_p2, h->d_w3t, h->d_b3, d_out, h->relu3);
+        hipLaunchKernelGGL(k_conv3_norm, dim3(batch), dim3(CV3_T), 0, s, h->d_p2, h->d_w3t, h->d_b3, d_out, h->relu3);
     }
     MYSLAM_HIP_CHECK(hipGetLastError());
     return MYSLAM_OK;
@@ -494,8 +568,11 @@ int myslam_lcd_debug_forward(myslam_lcd* h, const float* in, float* out_stage, i
     int rc = h->ensure_batch(1, h->rows ? h->rows : IN_H, h->cols ? h->cols : IN_W);
     if (rc) return rc;
     if ((rc = lcd_stage(h, 16))) return rc;
-    MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_in, in, sizeof(float) * IN_H * IN_W, hipMemcpyHostToDevice, h->stream));
+    MYSLAM_HIP_CHECK(hipMemcpy2DAsync(h->d_in + IN_PAD * IN_PW + IN_PAD, IN_PW * sizeof(float), in, IN_W * sizeof(float), IN_W * sizeof(float), IN_H,
+                                      hipMemcpyHostToDevice, h->stream));
     if ((rc = lcd_forward(h, 1, h->d_stageOut))) return rc;
+    if (stage == 0)      // the conv1 activation map is not materialised by the fused kernel: produce the tap on request
+        hipLaunchKernelGGL(k_conv1, dim3((H1 * W1 + 31) / 32, 1), dim3(256), 0, h->stream, h->d_in, h->d_w1t, h->d_b1, h->d_a1);
     const float* src[5] = {h->d_a1, h->d_p1, h->d_a2, h->d_p2, h->d_stageOut};
     const size_t n[5] = {(size_t)H1 * W1 * C1, (size_t)HP1 * WP1 * C1, (size_t)H2 * W2 * C2, (size_t)HP2 * WP2 * C2, MYSLAM_LCD_DIM};
     if (cap_floats < n[stage]) return MYSLAM_ERR_CAPACITY;
