@@ -22,7 +22,7 @@ void launch_resize(const ResizeArgs& a, int batch, hipStream_t s);
 void launch_blur(const BlurArgs& a, int batch, hipStream_t s);
 void launch_fast(const OrbPlan& P, const uint8_t* pyr, size_t pyrStride, const uint8_t* maskPyr, uint32_t* cand,
                  int32_t* candCount, int batch, hipStream_t s);
-void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCount, uint64_t* sortbuf, uint32_t* selOut,
+void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCount, uint64_t* sortbuf, const uint32_t* octTab, uint32_t* selOut,
                    int32_t* selCount, int32_t* status, int batch, hipStream_t s);
 void launch_describe(const OrbPlan& P, const uint8_t* pyr, const uint8_t* blur, size_t pyrStride, const uint32_t* selOut,
                      const int32_t* selCount, myslam_keypoint* kps, uint8_t* desc, int32_t* counts, int32_t* status,
@@ -99,6 +99,7 @@ struct myslam_orb {
     uint64_t* d_sort = nullptr;
     int32_t *d_candCount = nullptr, *d_selCount = nullptr, *d_status = nullptr;
     uint32_t* d_sel = nullptr;
+    uint32_t* d_octTab = nullptr;      // per-level oct-tree path-code / cell-index tables (see make_plan)
 
     // staging for the host-buffer entry points
     uint8_t *d_stageImg = nullptr, *d_stageMask = nullptr; size_t stageImgBytes = 0, stageMaskBytes = 0;
@@ -177,6 +178,49 @@ int myslam_orb::make_plan(int r, int c) {
         g.keyOff = keyOff; keyOff += g.keyCap;
     }
     P.ncells = cellBase; P.nstrips = stripBase; P.totalKeyCap = (int)keyOff; P.totalOut = outBase; P.pyrBytes = imgOff;
+    // Oct-tree lookup tables.  A key's quad-tree path splits x and y independently (ExtractorNode::DivideNode halves each
+    // axis with ceil, ORBextractor.cpp:526-582), so its path code is xcode[px] | ycode[py]: root index (:616) and the x
+    // digits in one table, the y digits in the other, both already spread to their bit positions.  xcell/ycell give the
+    // FAST grid cell of a key ((px-3)/wCell, ((py-3)/hCell)*nCols): the reference's candidate order is cell-major.
+    {
+        std::vector<uint32_t> tab;
+        for (int l = 0; l < nlevels; l++) {
+            LevelGeom& g = P.lv[l];
+            g.tabX = g.maxBX - MIN_BORDER + 8; g.tabY = g.maxBY - MIN_BORDER + 8; g.tabOff = (int)tab.size();
+            tab.resize(tab.size() + 2 * (size_t)(g.tabX + g.tabY), 0u);
+            uint32_t* xcode = tab.data() + g.tabOff; uint32_t* ycode = xcode + g.tabX;
+            uint32_t* xcell = ycode + g.tabY; uint32_t* ycell = xcell + g.tabX;
+            for (int px = 0; px < g.tabX; px++) {
+                int r = (int)((float)px / g.hX);                                         // :616
+                r = std::min(std::max(r, 0), g.nIni - 1);
+                int UL = (int)(g.hX * (float)r), UR = (int)(g.hX * (float)(r + 1));      // :602-603
+                uint32_t code = (uint32_t)r << ROOT_SHIFT;
+                for (int k = 1; k <= g.ndepth; k++) {
+                    const int mid = UL + ((UR - UL + 1) >> 1);                           // ceil(w/2), :528-529
+                    const uint32_t d = px >= mid;
+                    code |= d << (ROOT_SHIFT - 2 * k);
+                    if (d) UL = mid; else UR = mid;
+                }
+                xcode[px] = code;
+                xcell[px] = (uint32_t)(std::max(px - 3, 0) / g.wCell);
+            }
+            for (int py = 0; py < g.tabY; py++) {
+                int UL = 0, BR = g.maxBY - MIN_BORDER;
+                uint32_t code = 0;
+                for (int k = 1; k <= g.ndepth; k++) {
+                    const int mid = UL + ((BR - UL + 1) >> 1);
+                    const uint32_t d = py >= mid;
+                    code |= (d << 1) << (ROOT_SHIFT - 2 * k);
+                    if (d) UL = mid; else BR = mid;
+                }
+                ycode[py] = code;
+                ycell[py] = (uint32_t)((std::max(py - 3, 0) / g.hCell) * g.nCols);
+            }
+        }
+        int rc = dev_alloc(d_octTab, tab.size());
+        if (rc) return rc;
+        MYSLAM_HIP_CHECK(hipMemcpy(d_octTab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     full = P;
     // Detect(): level 0 only, budget = nfeatures (ORBextractor.cpp:1064-1065)
     det = P;
@@ -280,7 +324,7 @@ int myslam_orb::run_batch(const uint8_t* d_imgs, int batch, int r, int c, int st
     }
     {
         ScopedProf sp(P_OCTREE, stream);
-        launch_octree(P, d_cand, d_candCount, d_sort, d_sel, d_selCount, stat, batch, stream);
+        launch_octree(P, d_cand, d_candCount, d_sort, d_octTab, d_sel, d_selCount, stat, batch, stream);
     }
     if (stop == 3) return MYSLAM_OK;
     if (!detectOnly && (rc = blur_levels(batch, P.nlevels))) return rc;
@@ -310,7 +354,7 @@ int myslam_orb::ensure_stage(size_t imgBytes, size_t maskBytes, int cap) {
 }
 
 void myslam_orb::free_all() {
-    void* ptrs[] = {d_pyr, d_blur, d_mask, d_cand, d_sort, d_candCount, d_selCount, d_status, d_sel, d_stageImg, d_stageMask,
+    void* ptrs[] = {d_octTab, d_pyr, d_blur, d_mask, d_cand, d_sort, d_candCount, d_selCount, d_status, d_sel, d_stageImg, d_stageMask,
                     d_stageKps, d_stageKps2, d_stageDesc, d_stageKeep, d_stageCounts};
     for (void* p : ptrs) if (p) (void)hipFree(p);
 }

@@ -9,6 +9,7 @@
 //
 // Built with -ffp-contract=off: BRIEF sample coordinates and fastAtan2 are float expressions whose
 // integer/float results must be bit-identical to a non-contracting CPU evaluation.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -1115,7 +1116,7 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
 // Tie-break of the size sort (:731 sorts pair<int,Node*>, i.e. by heap address) = creation order, the
 // same deterministic choice the oracle makes.
 // ------------------------------------------------------------------------------------------------
-constexpr int OT = 256;
+constexpr int OT = 512;       // threads per (image, level) block: the key passes (codes, scatter, best key) are latency-bound at 4 waves
 constexpr int OT_MAXB = 1024;        // buckets of the counting sort
 
 __device__ __forceinline__ uint64_t wave_incl_scan64(uint64_t v) {
@@ -1128,7 +1129,7 @@ __device__ __forceinline__ uint64_t wave_incl_scan64(uint64_t v) {
     return v;
 }
 
-// exclusive block scan of a packed 64-bit counter; s_w = 4 uint64 of LDS scratch
+// exclusive block scan of a packed 64-bit counter; s_w = OT/64 uint64 of LDS scratch
 __device__ __forceinline__ uint64_t block_excl_scan64(uint64_t v, uint64_t* s_w, uint64_t& total) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const uint64_t incl = wave_incl_scan64(v);
@@ -1224,6 +1225,7 @@ __device__ __forceinline__ void child_bounds(const OctLds& L, uint64_t* __restri
 
 __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __restrict__ cand,
                                                const int32_t* __restrict__ candCount, uint64_t* __restrict__ sortbuf,
+                                               const uint32_t* __restrict__ octTab,
                                                uint32_t* __restrict__ selOut, int32_t* __restrict__ selCount,
                                                int32_t* __restrict__ status, int NCmax) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1233,9 +1235,9 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
     const int NC = NCmax;
 
     // carve LDS
-    uint64_t* s_w = reinterpret_cast<uint64_t*>(smem);          // 4 x u64 scan scratch
-    int* s_i = reinterpret_cast<int*>(smem + 32);               // [0]=m [1]=nc [2]=jstar
-    uint8_t* pcur = smem + 64;
+    uint64_t* s_w = reinterpret_cast<uint64_t*>(smem);          // OT/64 x u64 scan scratch
+    int* s_i = reinterpret_cast<int*>(smem + 128);              // [0]=m [1]=nc [2]=jstar
+    uint8_t* pcur = smem + 192;
     uint32_t* s_cursor = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * OT_MAXB;
     OctLds L;
     L.lo0 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
@@ -1276,17 +1278,25 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
     const int NB = g.nIni << (2 * D);
     const int bsh = ROOT_SHIFT - 2 * D;
 
+#ifdef MYSLAM_OCT_TIMING
+    long long tk0 = (long long)__builtin_readcyclecounter(), tkA = 0, tkB = 0, tkC = 0; int nrounds = 0;
+#endif
+    const uint32_t* xcode = octTab + g.tabOff; const uint32_t* ycode = xcode + g.tabX;
+    const uint32_t* xcell = ycode + g.tabY; const uint32_t* ycell = xcell + g.tabX;
     // ---- A: path codes + bucket histogram (LDS atomics) ----
     for (int i = t; i < NB; i += OT) s_cursor[i] = 0;
     __syncthreads();
     for (int i = t; i < n; i += OT) {
         const uint32_t pay = keys[i];
         const int px = (pay >> 8) & 0xfff, py = pay >> 20;
-        const uint32_t code = oct_code(px, py, g);
+        const uint32_t code = xcode[px] | ycode[py];                // == oct_code(px, py, g), tabulated per axis at plan time
         bufA[i] = ((uint64_t)code << 32) | pay;
         atomicAdd(&s_cursor[code >> bsh], 1u);
     }
     __syncthreads();
+#ifdef MYSLAM_OCT_TIMING
+    tkA = (long long)__builtin_readcyclecounter();
+#endif
     // ---- B: exclusive offsets, then scatter (order inside a bucket is irrelevant) ----
     {
         const int c = (NB + OT - 1) / OT;
@@ -1311,6 +1321,9 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
     }
     __syncthreads();
 
+#ifdef MYSLAM_OCT_TIMING
+    tkB = (long long)__builtin_readcyclecounter();
+#endif
     // ---- C: node list simulation ----
     // roots (:599-632): non-empty roots in index order
     if (t == 0) {
@@ -1328,6 +1341,9 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
     for (int round = 0; round < 96; round++) {
         const int m = s_i[0];
         const int prevSize = m;
+#ifdef MYSLAM_OCT_TIMING
+        nrounds++;
+#endif
         int newM;
         if (mode == 0) {
             // ---------- full round (:645-712): every node with >1 key is split ----------
@@ -1511,27 +1527,45 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
         }
     }
 
-    // ---- D: best key per node (:788-807), list order ----
+#ifdef MYSLAM_OCT_TIMING
+    tkC = (long long)__builtin_readcyclecounter();
+#endif
+    // ---- D: best key per node (:788-807), list order.  16 lanes per node: max of (response, -candidate order) ----
     const int m = s_i[0];
     uint32_t* out = selOut + (size_t)b * P.totalOut + g.outBase;
-    for (int p = t; p < m && p < g.nodeCap; p += OT) {
-        const int lo = (int)L.lo(cur)[p], hi = (int)L.hi(cur)[p];
-        uint32_t best = (uint32_t)S[lo];
-        if (hi - lo > 1) {
-            int bs = best & 0xff;
-            uint64_t bo = ~0ull;
-            for (int i = lo; i < hi; i++) {
+    {
+        const int sub = t & 15;
+        for (int p0 = (t >> 4); p0 < ((min(m, g.nodeCap) + OT / 16 - 1) / (OT / 16)) * (OT / 16); p0 += OT / 16) {
+            const bool live = p0 < m && p0 < g.nodeCap;
+            const int lo = live ? (int)L.lo(cur)[p0] : 0, hi = live ? (int)L.hi(cur)[p0] : 0;
+            uint64_t bestK = 0;
+            for (int i = lo + sub; i < hi; i += 16) {
                 const uint32_t pay = (uint32_t)S[i];
-                const int s = pay & 0xff;
                 const int px = (pay >> 8) & 0xfff, py = pay >> 20;
-                const uint64_t ok = ((uint64_t)(((py - 3) / g.hCell) * g.nCols + (px - 3) / g.wCell) << 24) |
-                                    ((uint64_t)py << 12) | (uint64_t)px;   // candidate order of the reference
-                if (i == lo || s > bs || (s == bs && ok < bo)) { bs = s; bo = ok; best = pay; }
+                // candidate order of the reference: cell-major (row of cells, then column), then row-major inside the cell
+                const uint64_t ok = ((uint64_t)(ycell[py] + xcell[px]) << 24) | ((uint64_t)py << 12) | (uint64_t)px;
+                // response first, then the EARLIEST candidate; px, py stay recoverable from ok
+                bestK = max(bestK, ((uint64_t)(pay & 0xff) << 44) | (0xfffffffffffull - ok));
+            }
+            // 16-lane max
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                const uint64_t other = __shfl_xor(bestK, o, 64);
+                bestK = max(bestK, other);
+            }
+            if (live && sub == 0) {
+                const uint64_t ok = 0xfffffffffffull - (bestK & 0xfffffffffffull);
+                const uint32_t px = (uint32_t)(ok & 0xfff), py = (uint32_t)((ok >> 12) & 0xfff), sc = (uint32_t)(bestK >> 44);
+                out[p0] = (py << 20) | (px << 8) | sc;
             }
         }
-        out[p] = best;
     }
     if (t == 0) *myCount = min(m, g.nodeCap);
+#ifdef MYSLAM_OCT_TIMING
+    __syncthreads();
+    if (b == 0 && t == 0) printf("oct L%d n=%d m=%d rounds=%d  A=%lld B=%lld C=%lld D=%lld ticks\n", level, n, m, nrounds, tkA - tk0, tkB - tkA, tkC - tkB,
+                                 (long long)__builtin_readcyclecounter() - tkC);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1933,9 +1967,9 @@ void launch_fast(const OrbPlan& P, const uint8_t* pyr, size_t pyrStride, const u
     }
 }
 
-size_t octree_lds_bytes(int nodeCap) { return 64 + 4 * (size_t)OT_MAXB + 4 * (size_t)(OT_MAXB + 2) + (size_t)nodeCap * 54 + 16; }
+size_t octree_lds_bytes(int nodeCap) { return 192 + 4 * (size_t)OT_MAXB + 4 * (size_t)(OT_MAXB + 2) + (size_t)nodeCap * 54 + 16; }
 
-void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCount, uint64_t* sortbuf, uint32_t* selOut,
+void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCount, uint64_t* sortbuf, const uint32_t* octTab, uint32_t* selOut,
                    int32_t* selCount, int32_t* status, int batch, hipStream_t s) {
     // one launch for all levels: the small levels fill the gaps the large ones leave
     int ncmax = 0;
@@ -1946,7 +1980,7 @@ void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCo
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_attr = lds;
     }
-    hipLaunchKernelGGL(k_octree, dim3(P.nlevels, batch), dim3(OT), lds, s, P, cand, candCount, sortbuf, selOut, selCount, status, ncmax);
+    hipLaunchKernelGGL(k_octree, dim3(P.nlevels, batch), dim3(OT), lds, s, P, cand, candCount, sortbuf, octTab, selOut, selCount, status, ncmax);
 }
 
 void launch_describe(const OrbPlan& P, const uint8_t* pyr, const uint8_t* blur, size_t pyrStride, const uint32_t* selOut,

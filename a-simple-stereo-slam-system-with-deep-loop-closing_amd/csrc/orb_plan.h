@@ -33,6 +33,7 @@ struct LevelGeom {
     float scaledPatch;                // (int)(31*scale) as float, :891
     size_t imgOff;                    // byte offset of the level plane inside one image's pyramid block
     size_t keyOff;                    // element offset of the level's candidate list inside one image's block
+    int tabOff, tabX, tabY;           // oct-tree lookup tables of the level: [xcode tabX][ycode tabY][xcell tabX][ycell tabY] (u32 each)
 };
 
 struct OrbPlan {
