@@ -1286,12 +1286,19 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
     // ---- A: path codes + bucket histogram (LDS atomics) ----
     for (int i = t; i < NB; i += OT) s_cursor[i] = 0;
     __syncthreads();
-    for (int i = t; i < n; i += OT) {
-        const uint32_t pay = keys[i];
-        const int px = (pay >> 8) & 0xfff, py = pay >> 20;
-        const uint32_t code = xcode[px] | ycode[py];                // == oct_code(px, py, g), tabulated per axis at plan time
-        bufA[i] = ((uint64_t)code << 32) | pay;
-        atomicAdd(&s_cursor[code >> bsh], 1u);
+    for (int i0 = t; i0 < n; i0 += 4 * OT) {                       // 4 keys in flight per thread: the pass is latency-bound
+        uint32_t pay[4], cx[4], cy[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) pay[u] = (i0 + u * OT < n) ? keys[i0 + u * OT] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; u++) { cx[u] = xcode[(pay[u] >> 8) & 0xfff]; cy[u] = ycode[pay[u] >> 20]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (i0 + u * OT >= n) continue;
+            const uint32_t code = cx[u] | cy[u];                    // == oct_code(px, py, g), tabulated per axis at plan time
+            bufA[i0 + u * OT] = ((uint64_t)code << 32) | pay[u];
+            atomicAdd(&s_cursor[code >> bsh], 1u);
+        }
     }
     __syncthreads();
 #ifdef MYSLAM_OCT_TIMING
@@ -1314,10 +1321,16 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
         if (t == 0) L.offs[NB] = (uint32_t)n;
     }
     __syncthreads();
-    for (int i = t; i < n; i += OT) {
-        const uint64_t v = bufA[i];
-        const uint32_t pos = atomicAdd(&s_cursor[(uint32_t)(v >> 32) >> bsh], 1u);
-        S[pos] = v;
+    for (int i0 = t; i0 < n; i0 += 4 * OT) {
+        uint64_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = (i0 + u * OT < n) ? bufA[i0 + u * OT] : 0ull;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (i0 + u * OT >= n) continue;
+            const uint32_t pos = atomicAdd(&s_cursor[(uint32_t)(v[u] >> 32) >> bsh], 1u);
+            S[pos] = v[u];
+        }
     }
     __syncthreads();
 
@@ -1530,34 +1543,32 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
 #ifdef MYSLAM_OCT_TIMING
     tkC = (long long)__builtin_readcyclecounter();
 #endif
-    // ---- D: best key per node (:788-807), list order.  16 lanes per node: max of (response, -candidate order) ----
+    // ---- D: best key per node (:788-807), list order.  16 lanes per node.  Pass 1 finds the node's largest response;
+    // pass 2 breaks ties by the reference's candidate order (cell-major, row-major inside a cell), so the cell tables
+    // are only read for keys that carry that response. ----
     const int m = s_i[0];
     uint32_t* out = selOut + (size_t)b * P.totalOut + g.outBase;
     {
         const int sub = t & 15;
-        for (int p0 = (t >> 4); p0 < ((min(m, g.nodeCap) + OT / 16 - 1) / (OT / 16)) * (OT / 16); p0 += OT / 16) {
-            const bool live = p0 < m && p0 < g.nodeCap;
+        const int mm = min(m, g.nodeCap);
+        for (int p0 = (t >> 4); p0 < ((mm + OT / 16 - 1) / (OT / 16)) * (OT / 16); p0 += OT / 16) {
+            const bool live = p0 < mm;
             const int lo = live ? (int)L.lo(cur)[p0] : 0, hi = live ? (int)L.hi(cur)[p0] : 0;
-            uint64_t bestK = 0;
+            uint32_t best = 0;
+#pragma unroll 2
+            for (int i = lo + sub; i < hi; i += 16) best = max(best, (uint32_t)S[i] & 0xffu);
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) best = max(best, (uint32_t)__shfl_xor((int)best, o, 64));
+            uint64_t bo = ~0ull;
             for (int i = lo + sub; i < hi; i += 16) {
                 const uint32_t pay = (uint32_t)S[i];
-                const int px = (pay >> 8) & 0xfff, py = pay >> 20;
-                // candidate order of the reference: cell-major (row of cells, then column), then row-major inside the cell
-                const uint64_t ok = ((uint64_t)(ycell[py] + xcell[px]) << 24) | ((uint64_t)py << 12) | (uint64_t)px;
-                // response first, then the EARLIEST candidate; px, py stay recoverable from ok
-                bestK = max(bestK, ((uint64_t)(pay & 0xff) << 44) | (0xfffffffffffull - ok));
+                if ((pay & 0xffu) != best) continue;
+                const uint32_t px = (pay >> 8) & 0xfff, py = pay >> 20;
+                bo = min(bo, ((uint64_t)(ycell[py] + xcell[px]) << 24) | ((uint64_t)py << 12) | (uint64_t)px);
             }
-            // 16-lane max
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                const uint64_t other = __shfl_xor(bestK, o, 64);
-                bestK = max(bestK, other);
-            }
-            if (live && sub == 0) {
-                const uint64_t ok = 0xfffffffffffull - (bestK & 0xfffffffffffull);
-                const uint32_t px = (uint32_t)(ok & 0xfff), py = (uint32_t)((ok >> 12) & 0xfff), sc = (uint32_t)(bestK >> 44);
-                out[p0] = (py << 20) | (px << 8) | sc;
-            }
+            for (int o = 1; o < 16; o <<= 1) bo = min(bo, (uint64_t)__shfl_xor((unsigned long long)bo, o, 64));
+            if (live && sub == 0) out[p0] = ((uint32_t)((bo >> 12) & 0xfff) << 20) | ((uint32_t)(bo & 0xfff) << 8) | best;
         }
     }
     if (t == 0) *myCount = min(m, g.nodeCap);
