@@ -1807,6 +1807,173 @@ __global__ __launch_bounds__(256) void k_describe(OrbPlan P, const uint8_t* __re
     }
 }
 
+// K5b: the same operator, phased per block of 64 keypoints so that nothing scalar runs 64-wide:
+//   0  thread per keypoint: slot -> (level, x, y, response)
+//   A  wave per keypoint  : intensity-centroid moments straight from global memory; lane = one aligned dword of the
+//                           31-row patch, the circular mask and the column weights u+16 come from a constant table
+//                           indexed by (alignment, dword): m10 = sum dot4(I, w) - 16 sum dot4(I, 1), m01 = sum v dot4(I, 1)
+//   B  thread per keypoint: fastAtan2, deterministic sin/cos, cv::KeyPoint fields
+//   C  wave per keypoint  : blurred 37x37 window -> LDS, 4 steered BRIEF tests per lane
+struct IcwEntry { uint32_t w, o; };
+struct IcwTable { IcwEntry e[4 * DA_N]; };
+constexpr IcwTable make_icw_table() {
+    IcwTable t{};
+    constexpr int um[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};      // umax, ORBextractor.cpp:429-444
+    for (int off = 0; off < 4; off++)
+        for (int i = 0; i < DA_N; i++) {
+            const int r = i / DA_DW, c = i % DA_DW, v = r - HALF_PATCH, d = um[v < 0 ? -v : v];
+            uint32_t w = 0, o = 0;
+            for (int j = 0; j < 4; j++) {
+                const int u = 4 * c + j - off - HALF_PATCH;
+                if (u >= -d && u <= d) { w |= (uint32_t)(u + 16) << (8 * j); o |= 1u << (8 * j); }
+            }
+            t.e[off * DA_N + i].w = w; t.e[off * DA_N + i].o = o;
+        }
+    return t;
+}
+__device__ const IcwTable c_icw = make_icw_table();
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_add_i32(int v) { return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false); }
+__device__ __forceinline__ int wave_sum_lane63_i32(int v) {
+    v = dpp_add_i32<0xB1, 0xf>(v); v = dpp_add_i32<0x4E, 0xf>(v); v = dpp_add_i32<0x141, 0xf>(v); v = dpp_add_i32<0x140, 0xf>(v);
+    v = dpp_add_i32<0x142, 0xa>(v); v = dpp_add_i32<0x143, 0xc>(v);
+    return v;
+}
+
+constexpr int KD_KPB = 64;                                       // keypoints per block
+
+__global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
+                                                   size_t pyrStride, const uint32_t* __restrict__ selOut,
+                                                   const int32_t* __restrict__ selCount, myslam_keypoint* __restrict__ kps,
+                                                   uint8_t* __restrict__ desc, int32_t* __restrict__ counts,
+                                                   int32_t* __restrict__ status, int cap, int nchunk, int batch) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_b[4][DB_N];
+    __shared__ int s_x[KD_KPB], s_y[KD_KPB], s_lv[KD_KPB], s_m10[KD_KPB], s_m01[KD_KPB];
+    __shared__ float s_ca[KD_KPB], s_sb[KD_KPB];
+    __shared__ __attribute__((aligned(8))) IcwEntry s_icw[4 * DA_N];
+    // XCD-aware block order: the dispatcher places block i on XCD i % 8, each XCD has a private L2, and the ~32 blocks of one
+    // image read overlapping windows of the same two pyramids.  Logical block ids (image-major) are handed out so that every
+    // XCD walks a contiguous range of images (bijective remap, any grid size): without it every XCD pulls every image
+    // through its own L2 (measured 3.2 GB instead of ~1.3 GB of HBM reads per 512 images).
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+    const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int b = logical / nchunk, t = threadIdx.x;
+    if (b >= batch) return;
+    for (int i = t; i < 4 * DA_N; i += 256) s_icw[i] = c_icw.e[i];
+    const int wave = t >> 6, lane = t & 63;
+    const int slot0 = (logical - b * nchunk) * KD_KPB;
+    // ---- 0 ----
+    float resp = 0.f;
+    if (t < KD_KPB) {
+        const int slot = slot0 + t;
+        int level = -1, local = 0, total = 0;
+        for (int l = 0; l < P.nlevels; l++) {
+            const int c = selCount[b * MAXL + l];
+            if (level < 0 && slot < total + c) { level = l; local = slot - total; }
+            total += c;
+        }
+        if (slot == 0) {
+            counts[b] = min(total, cap);
+            if (total > cap && status) status[b] = MYSLAM_ERR_CAPACITY;
+        }
+        const bool active = (level >= 0 && slot < cap);
+        uint32_t pay = 0;
+        if (active) pay = selOut[(size_t)b * P.totalOut + P.lv[level].outBase + local];
+        s_lv[t] = active ? level : -1;
+        s_x[t] = (int)((pay >> 8) & 0xfff) + MIN_BORDER; s_y[t] = (int)(pay >> 20) + MIN_BORDER;      // :897-898
+        resp = (float)(pay & 0xff);
+    }
+    __syncthreads();
+    // ---- A ----
+    for (int j = 0; j < KD_KPB / 4; j++) {
+        const int k = wave * (KD_KPB / 4) + j;
+        const int level = s_lv[k];
+        if (level < 0) continue;                                          // wave-uniform
+        const LevelGeom& g = P.lv[level];
+        const int x = s_x[k], y = s_y[k];
+        const uint8_t* img = pyr + (size_t)b * pyrStride + g.imgOff;
+        // keypoints keep >= 19 px from every border (ORBextractor.cpp:25), so all patch rows exist
+        const int xa0 = (x - HALF_PATCH) & ~3, offA = (x - HALF_PATCH) - xa0;
+        int A = 0, B = 0, Cn = 0;
+#pragma unroll
+        for (int q = 0; q < DA_IT; q++) {
+            const int i = lane + 64 * q;
+            if (i < DA_N) {
+                const int r = i / DA_DW, c = i - r * DA_DW;
+                const uint32_t I = *reinterpret_cast<const uint32_t*>(img + (size_t)(y - HALF_PATCH + r) * g.pitch + xa0 + 4 * c);
+                const IcwEntry e = s_icw[offA * DA_N + i];
+                const int sI = (int)__builtin_amdgcn_udot4(I, e.o, 0u, false);
+                A += (int)__builtin_amdgcn_udot4(I, e.w, 0u, false);
+                Cn += sI;
+                B += (r - HALF_PATCH) * sI;
+            }
+        }
+        A = wave_sum_lane63_i32(A); B = wave_sum_lane63_i32(B); Cn = wave_sum_lane63_i32(Cn);
+        if (lane == 63) { s_m10[k] = A - 16 * Cn; s_m01[k] = B; }
+    }
+    __syncthreads();
+    // ---- B ----
+    if (t < KD_KPB && s_lv[t] >= 0) {
+        const int level = s_lv[t];
+        const LevelGeom& g = P.lv[level];
+        const float angle = fast_atan2_deg((float)s_m01[t], (float)s_m10[t]);                      // :54
+        const float factorPI = (float)(3.14159265358979323846 / 180.f);
+        float ca, sb;
+        det_sincos(__fmul_rn(angle, factorPI), sb, ca);
+        s_ca[t] = ca; s_sb[t] = sb;
+        const int x = s_x[t], y = s_y[t];
+        myslam_keypoint kp;
+        kp.x = (level != 0) ? __fmul_rn((float)x, g.scale) : (float)x;                            // :975-981
+        kp.y = (level != 0) ? __fmul_rn((float)y, g.scale) : (float)y;
+        kp.size = g.scaledPatch; kp.angle = angle; kp.response = resp; kp.octave = level; kp.class_id = -1;
+        kps[(size_t)b * cap + slot0 + t] = kp;
+    }
+    __syncthreads();
+    // ---- C ----
+    for (int j = 0; j < KD_KPB / 4; j++) {
+        const int k = wave * (KD_KPB / 4) + j;
+        const int level = s_lv[k];
+        if (level < 0) continue;
+        const LevelGeom& g = P.lv[level];
+        const int x = s_x[k], y = s_y[k];
+        const float ca = s_ca[k], sb = s_sb[k];
+        const uint8_t* bl = blur + (size_t)b * pyrStride + g.imgOff;
+        const int xb0 = (x - DB_R) & ~3, offB = (x - DB_R) - xb0;
+        uint32_t rb[DB_IT];
+#pragma unroll
+        for (int q = 0; q < DB_IT; q++) {
+            const int i = lane + 64 * q;
+            const int r = i / DB_DW, c = i - r * DB_DW;
+            rb[q] = (i < DB_N) ? *reinterpret_cast<const uint32_t*>(bl + (size_t)(y - DB_R + r) * g.pitch + xb0 + 4 * c) : 0u;
+        }
+        __builtin_amdgcn_wave_barrier();                                  // previous keypoint's window reads are done (same wave)
+#pragma unroll
+        for (int q = 0; q < DB_IT; q++) { const int i = lane + 64 * q; if (i < DB_N) s_b[wave][i] = rb[q]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint8_t* center = reinterpret_cast<const uint8_t*>(s_b[wave]) + DB_R * DB_P + offB + DB_R;
+        uint32_t nib = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int8_t* pp = &c_pattern[(lane * 4 + q) * 4];
+            const float x0 = (float)pp[0], y0 = (float)pp[1], x1 = (float)pp[2], y1 = (float)pp[3];
+            const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, sb), __fmul_rn(y0, ca)));
+            const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sb)));
+            const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sb), __fmul_rn(y1, ca)));
+            const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sb)));
+            const int t0 = center[r0 * DB_P + c0], t1 = center[r1 * DB_P + c1];
+            nib |= (uint32_t)(t0 < t1) << q;
+        }
+        const uint32_t byte = nib | (__shfl_down(nib, 1, 64) << 4);            // valid on even lanes
+        uint32_t w = byte | (__shfl_down(byte, 2, 64) << 8);
+        w |= (__shfl_down(byte, 4, 64) << 16) | (__shfl_down(byte, 6, 64) << 24);   // valid on lanes % 8 == 0
+        if ((lane & 7) == 0) reinterpret_cast<uint32_t*>(desc + ((size_t)b * cap + slot0 + k) * 32)[lane >> 3] = w;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K6/K7: per-keypoint operators of the loop-closing path (one image, n keypoints; wave per keypoint)
 // ------------------------------------------------------------------------------------------------
@@ -1998,6 +2165,13 @@ void launch_describe(const OrbPlan& P, const uint8_t* pyr, const uint8_t* blur, 
                      const int32_t* selCount, myslam_keypoint* kps, uint8_t* desc, int32_t* counts, int32_t* status,
                      int cap, int detectOnly, int batch, hipStream_t s) {
     const int slots = min(cap, P.totalOut);
+    static const char* env = getenv("MYSLAM_DESC_V");             // tuning aid: 1 = one wave per keypoint end to end
+    if (!detectOnly && !(env && atoi(env) == 1)) {
+        const int nchunk = (slots + KD_KPB - 1) / KD_KPB;
+        hipLaunchKernelGGL(k_describe2, dim3(nchunk * batch), dim3(256), 0, s, P, pyr, blur, pyrStride, selOut, selCount,
+                           kps, desc, counts, status, cap, nchunk, batch);
+        return;
+    }
     hipLaunchKernelGGL(k_describe, dim3((slots + 3) / 4, batch), dim3(256), 0, s, P, pyr, blur, pyrStride, selOut, selCount,
                        kps, desc, counts, status, cap, detectOnly);
 }
