@@ -365,3 +365,28 @@ def ba_optimize_batch(d_poses, d_points, d_ep, d_el, d_obs, d_fixed, d_sizes, nw
                                           C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]), C.c_double(delta),
                                           int(iters), C.c_void_p(d_scratch), C.c_void_p(d_chi2), C.c_void_p(d_iters),
                                           C.c_void_p(d_status), C.c_void_p(stream or None)), "myslam_ba_optimize_batch")
+
+
+def ba_optimize_active_map(poses, points, edge_pose, edge_pt, obs, fixed, K, delta=5.991, chi2_th=5.991, rounds=5, iters=10):
+    """The solve stage of Backend::OptimizeActiveMap (src/backend.cpp:208-243).
+    Returns (poses, points, edge_chi2, outlier flags, failed rounds, outlier count)."""
+    poses = np.ascontiguousarray(poses, np.float64).copy(); points = np.ascontiguousarray(points, np.float64).copy()
+    ep = np.ascontiguousarray(edge_pose, np.int32); el = np.ascontiguousarray(edge_pt, np.int32)
+    obs = np.ascontiguousarray(obs, np.float64)
+    fixed = np.ascontiguousarray(fixed, np.uint8) if fixed is not None else None
+    chi = np.zeros(len(ep)); out = np.zeros(len(ep), np.uint8); r = C.c_int(); no = C.c_int()
+    _check(lib().myslam_ba_optimize_active_map(_p(poses), len(poses), _p(points), len(points), _p(ep), _p(el), _p(obs), len(ep), _p(fixed),
+                                               C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]), C.c_double(delta),
+                                               C.c_double(chi2_th), int(rounds), int(iters), _p(chi), _p(out), C.byref(r), C.byref(no)),
+           "myslam_ba_optimize_active_map")
+    return poses, points, chi, out, r.value, no.value
+
+
+def ba_optimize_active_map_batch(d_poses, d_points, d_ep, d_el, d_obs, d_fixed, d_sizes, nwin, maxP, maxL, maxE, K, delta, chi2_th,
+                                 rounds, iters, d_scratch, d_edge_chi2, d_outlier, d_rounds, d_nout, d_status, stream=0):
+    _check(lib().myslam_ba_optimize_active_map_batch(
+        C.c_void_p(d_poses), C.c_void_p(d_points), C.c_void_p(d_ep), C.c_void_p(d_el), C.c_void_p(d_obs), C.c_void_p(d_fixed or None),
+        C.c_void_p(d_sizes), nwin, maxP, maxL, maxE, C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]),
+        C.c_double(delta), C.c_double(chi2_th), int(rounds), int(iters), C.c_void_p(d_scratch), C.c_void_p(d_edge_chi2),
+        C.c_void_p(d_outlier), C.c_void_p(d_rounds), C.c_void_p(d_nout), C.c_void_p(d_status), C.c_void_p(stream or None)),
+        "myslam_ba_optimize_active_map_batch")

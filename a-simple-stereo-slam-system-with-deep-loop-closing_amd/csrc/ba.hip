@@ -139,6 +139,8 @@ struct BaOptArgs {
     double fx, fy, cx, cy, delta; int max_iters;
     double* W;            // scratch: nwin x maxE x 18
     double* final_chi2; int32_t* iters; int32_t* status;
+    // Backend::OptimizeActiveMap outer loop (backend.cpp:208-243); edge_chi2 == nullptr -> a single optimize(max_iters)
+    int rounds; double chi2_th; double* edge_chi2; uint8_t* outlier; int32_t* rounds_out; int32_t* nout_out;
 };
 
 __device__ __forceinline__ void ba_edge(const double* R, const double* pw, const double* z, double fx, double fy, double cx, double cy,
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
     // lend[l] now counts the groups of landmark l: more than one group = edges not grouped by landmark
     for (int l = t; l < L; l += BA_NT) if (lend[l] > 1) atomicAdd(&s_bad, 1);
     __syncthreads();
-    if (s_bad) { if (t == 0) { a.status[w] = MYSLAM_ERR_INVALID; a.iters[w] = 0; a.final_chi2[w] = 0; } return; }
+    if (s_bad) { if (t == 0) { a.status[w] = MYSLAM_ERR_INVALID; if (a.iters) a.iters[w] = 0; if (a.final_chi2) a.final_chi2[w] = 0; } return; }
     for (int l = t; l < L; l += BA_NT) {
         if (lend[l] == 0) { lbeg[l] = 0; continue; }
         int k = lbeg[l];
@@ -346,12 +348,14 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
     }
     __syncthreads();
 
-    auto robust_chi2 = [&]() -> double {          // activeRobustChi2()
+    double* echi = a.edge_chi2 ? a.edge_chi2 + (size_t)w * a.maxE : nullptr;      // what edge->chi2() returns: e^T e of the last evaluation
+    auto robust_chi2 = [&](bool record) -> double {          // computeActiveErrors() + activeRobustChi2()
         double acc = 0;
         for (int k = t; k < E; k += BA_NT) {
             double e0, e1;
             ba_edge(sR + 12 * ep[k], sPt + 3 * el[k], obs + 2 * k, a.fx, a.fy, a.cx, a.cy, e0, e1, nullptr, nullptr);
             const double e2 = e0 * e0 + e1 * e1;
+            if (record && echi) echi[k] = e2;
             acc += (e2 <= d2) ? e2 : 2 * sqrt(e2) * a.delta - d2;
         }
         return block_sum(acc, s_red);
@@ -360,7 +364,9 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
     BA_TICK(0);
     const int nb = (n + 15) / 16;                       // 16-row blocks of the reduced system
 
-    int it = 0;
+    int it = 0, rnd = 0, cntOut = 0;
+  for (;;) {                                   // rounds of { initializeOptimization(); optimize(max_iters) }, backend.cpp:212-232
+    it = 0;
     for (; it < a.max_iters; it++) {
         // ---- build H, b at the current estimate ----
         for (int p = wv; p < P; p += BA_NW) {
@@ -403,6 +409,7 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
                 const double e2 = e0 * e0 + e1 * e1;
                 const double wgt = (e2 <= d2) ? 1.0 : a.delta / sqrt(e2);
                 acc += (e2 <= d2) ? e2 : 2 * sqrt(e2) * a.delta - d2;
+                if (echi) echi[k] = e2;
                 int v = 0;
 #pragma unroll
                 for (int r = 0; r < 3; r++) {
@@ -736,7 +743,7 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
             const double scale = block_sum(sc, s_red) + 1e-3;
             if (ok) for (int p = t; p < P; p += BA_NT) pose_oplus(sR + 12 * p, srhs + 6 * p);
             __syncthreads();
-            const double tmpChi = ok ? robust_chi2() : 1e300;
+            const double tmpChi = ok ? robust_chi2(true) : 1e300;       // the edges keep this error even if the step is rejected
             rho = (s_sc[2] - tmpChi) / scale;
             __syncthreads();
             if (rho > 0 && isfinite(tmpChi) && ok) {
@@ -756,8 +763,23 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
         } while (rho < 0 && qmax < 10 && isfinite(s_sc[0]));
         if (qmax == 10 || rho == 0 || !isfinite(s_sc[0])) { it++; break; }
     }
+    if (!echi) break;
+    {   // every thread reads back the entries it wrote itself (same k = t + j BA_NT mapping everywhere)
+        double c = 0;
+        for (int k = t; k < E; k += BA_NT) c += (echi[k] > a.chi2_th) ? 1.0 : 0.0;
+        cntOut = (int)block_sum(c, s_red);
+    }
+    if ((double)(E - cntOut) / (double)E > 0.5) break;          // inlierRatio > 0.5, backend.cpp:225-227
+    rnd++;
+    if (rnd >= a.rounds) break;
+    __syncthreads();
+  }
+    if (echi) {
+        for (int k = t; k < E; k += BA_NT) a.outlier[(size_t)w * a.maxE + k] = echi[k] > a.chi2_th ? 1 : 0;
+        if (t == 0) { a.rounds_out[w] = rnd; a.nout_out[w] = cntOut; }
+    }
     // ---- write back: R -> quaternion, points, final chi2 ----
-    const double fin = robust_chi2();
+    const double fin = robust_chi2(false);
     for (int p = t; p < P; p += BA_NT) {
         const double* R = sR + 12 * p;
         const double tr = R[0] + R[4] + R[8];
@@ -770,7 +792,7 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
         poses[7 * p + 4] = R[9]; poses[7 * p + 5] = R[10]; poses[7 * p + 6] = R[11];
     }
     for (int i = t; i < 3 * L; i += BA_NT) pts[i] = sPt[i];
-    if (t == 0) { a.final_chi2[w] = fin; a.iters[w] = it; a.status[w] = MYSLAM_OK; }
+    if (t == 0) { if (a.final_chi2) a.final_chi2[w] = fin; if (a.iters) a.iters[w] = it; a.status[w] = MYSLAM_OK; }
 #ifdef MYSLAM_BA_TIMING
     BA_TICK(9);
     if (w == 0 && t == 0) for (int i = 0; i < 10; i++) a.W[(size_t)a.maxE * 18 - 10 + i] = (double)tk[i];
@@ -884,7 +906,7 @@ int myslam_ba_optimize_batch(double* d_poses, double* d_points, const int32_t* d
         max_edges < 1 || max_iters < 1 || !d_scratch || !d_final_chi2 || !d_iters || !d_status)
         return MYSLAM_ERR_INVALID;
     BaOptArgs a{d_poses, d_points, d_edge_pose, d_edge_pt, d_obs, d_fixed, d_sizes, 0, 0, 0, max_poses, max_pts, max_edges,
-                fx, fy, cx, cy, huber_delta, max_iters, d_scratch, d_final_chi2, d_iters, d_status};
+                fx, fy, cx, cy, huber_delta, max_iters, d_scratch, d_final_chi2, d_iters, d_status, 1, 0.0, nullptr, nullptr, nullptr, nullptr};
     return ba_opt_launch(a, nwin, (hipStream_t)hip_stream);
 }
 
@@ -906,7 +928,7 @@ int myslam_ba_optimize(double* poses, int nposes, double* points, int npts, cons
     MYSLAM_HIP_CHECK(hipMemcpy(d_i + nedges, edge_pt, sizeof(int32_t) * nedges, hipMemcpyHostToDevice));
     if (fixed_pt) MYSLAM_HIP_CHECK(hipMemcpy(d_f, fixed_pt, npts, hipMemcpyHostToDevice));
     BaOptArgs a{d_p, d_x, d_i, d_i + nedges, d_o, fixed_pt ? d_f : nullptr, nullptr, nposes, npts, nedges, nposes, npts, nedges,
-                fx, fy, cx, cy, huber_delta, max_iters, d_w, d_chi, d_st + 1, d_st};
+                fx, fy, cx, cy, huber_delta, max_iters, d_w, d_chi, d_st + 1, d_st, 1, 0.0, nullptr, nullptr, nullptr, nullptr};
     int rc = ba_opt_launch(a, 1, nullptr);
     if (rc) return rc;
     int32_t st[2]; double chi;
@@ -917,6 +939,56 @@ int myslam_ba_optimize(double* poses, int nposes, double* points, int npts, cons
     (void)hipFree(d_p); (void)hipFree(d_x); (void)hipFree(d_o); (void)hipFree(d_w); (void)hipFree(d_chi); (void)hipFree(d_i); (void)hipFree(d_f);
     if (final_chi2) *final_chi2 = chi;
     if (iters) *iters = st[1];
+    return st[0];
+}
+
+int myslam_ba_optimize_active_map_batch(double* d_poses, double* d_points, const int32_t* d_edge_pose, const int32_t* d_edge_pt,
+                                        const double* d_obs, const uint8_t* d_fixed, const int32_t* d_sizes, int nwin, int max_poses,
+                                        int max_pts, int max_edges, double fx, double fy, double cx, double cy, double huber_delta,
+                                        double chi2_th, int max_rounds, int iters_per_round, double* d_scratch, double* d_edge_chi2,
+                                        uint8_t* d_outlier, int32_t* d_rounds, int32_t* d_n_outliers, int32_t* d_status, void* hip_stream) {
+    if (!d_poses || !d_points || !d_edge_pose || !d_edge_pt || !d_obs || !d_sizes || nwin < 1 || max_poses < 1 || max_pts < 1 ||
+        max_edges < 1 || max_rounds < 1 || iters_per_round < 1 || !d_scratch || !d_edge_chi2 || !d_outlier || !d_rounds || !d_n_outliers || !d_status)
+        return MYSLAM_ERR_INVALID;
+    BaOptArgs a{d_poses, d_points, d_edge_pose, d_edge_pt, d_obs, d_fixed, d_sizes, 0, 0, 0, max_poses, max_pts, max_edges,
+                fx, fy, cx, cy, huber_delta, iters_per_round, d_scratch, nullptr, nullptr, d_status,
+                max_rounds, chi2_th, d_edge_chi2, d_outlier, d_rounds, d_n_outliers};
+    return ba_opt_launch(a, nwin, (hipStream_t)hip_stream);
+}
+
+int myslam_ba_optimize_active_map(double* poses, int nposes, double* points, int npts, const int32_t* edge_pose, const int32_t* edge_pt,
+                                  const double* obs, int nedges, const uint8_t* fixed_pt, double fx, double fy, double cx, double cy,
+                                  double huber_delta, double chi2_th, int max_rounds, int iters_per_round,
+                                  double* edge_chi2, uint8_t* outlier, int* rounds, int* n_outliers) {
+    if (!poses || !points || nposes < 1 || npts < 1 || nedges < 1 || !edge_pose || !edge_pt || !obs || max_rounds < 1 || iters_per_round < 1 ||
+        !edge_chi2 || !outlier)
+        return MYSLAM_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MYSLAM_ERR_HIP;
+    double *d_p = nullptr, *d_x = nullptr, *d_o = nullptr, *d_w = nullptr, *d_chi = nullptr; int32_t *d_i = nullptr, *d_st = nullptr; uint8_t *d_f = nullptr, *d_out = nullptr;
+    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_p, sizeof(double) * nposes * 7)); MYSLAM_HIP_CHECK(hipMalloc((void**)&d_x, sizeof(double) * npts * 3));
+    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_o, sizeof(double) * nedges * 2)); MYSLAM_HIP_CHECK(hipMalloc((void**)&d_w, sizeof(double) * nedges * 18));
+    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_chi, sizeof(double) * nedges)); MYSLAM_HIP_CHECK(hipMalloc((void**)&d_i, sizeof(int32_t) * (2 * nedges + 3)));
+    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_f, npts)); MYSLAM_HIP_CHECK(hipMalloc((void**)&d_out, nedges)); d_st = d_i + 2 * nedges;
+    MYSLAM_HIP_CHECK(hipMemcpy(d_p, poses, sizeof(double) * nposes * 7, hipMemcpyHostToDevice));
+    MYSLAM_HIP_CHECK(hipMemcpy(d_x, points, sizeof(double) * npts * 3, hipMemcpyHostToDevice));
+    MYSLAM_HIP_CHECK(hipMemcpy(d_o, obs, sizeof(double) * nedges * 2, hipMemcpyHostToDevice));
+    MYSLAM_HIP_CHECK(hipMemcpy(d_i, edge_pose, sizeof(int32_t) * nedges, hipMemcpyHostToDevice));
+    MYSLAM_HIP_CHECK(hipMemcpy(d_i + nedges, edge_pt, sizeof(int32_t) * nedges, hipMemcpyHostToDevice));
+    if (fixed_pt) MYSLAM_HIP_CHECK(hipMemcpy(d_f, fixed_pt, npts, hipMemcpyHostToDevice));
+    BaOptArgs a{d_p, d_x, d_i, d_i + nedges, d_o, fixed_pt ? d_f : nullptr, nullptr, nposes, npts, nedges, nposes, npts, nedges,
+                fx, fy, cx, cy, huber_delta, iters_per_round, d_w, nullptr, nullptr, d_st, max_rounds, chi2_th, d_chi, d_out, d_st + 1, d_st + 2};
+    int rc = ba_opt_launch(a, 1, nullptr);
+    if (rc) return rc;
+    int32_t st[3];
+    MYSLAM_HIP_CHECK(hipMemcpy(st, d_st, sizeof(st), hipMemcpyDeviceToHost));
+    MYSLAM_HIP_CHECK(hipMemcpy(edge_chi2, d_chi, sizeof(double) * nedges, hipMemcpyDeviceToHost));
+    MYSLAM_HIP_CHECK(hipMemcpy(outlier, d_out, nedges, hipMemcpyDeviceToHost));
+    MYSLAM_HIP_CHECK(hipMemcpy(poses, d_p, sizeof(double) * nposes * 7, hipMemcpyDeviceToHost));
+    MYSLAM_HIP_CHECK(hipMemcpy(points, d_x, sizeof(double) * npts * 3, hipMemcpyDeviceToHost));
+    (void)hipFree(d_p); (void)hipFree(d_x); (void)hipFree(d_o); (void)hipFree(d_w); (void)hipFree(d_chi); (void)hipFree(d_i); (void)hipFree(d_f); (void)hipFree(d_out);
+    if (rounds) *rounds = st[1];
+    if (n_outliers) *n_outliers = st[2];
     return st[0];
 }
 

@@ -7,7 +7,7 @@
 //   myslam::BFMatcherHamming::match                                 (cv::BFMatcher use at src/loopclosing.cpp:33,172)
 //   myslam::triangulation  include/myslam/algorithm.h:16-33        (stereo rig form)
 //   myslam::LoopDatabase   LoopClosing::DetectLoop / AddToDatabase  src/loopclosing.cpp:124-161, 651-659
-//   myslam::LocalBA::Build per-edge work of Backend::OptimizeActiveMap  src/backend.cpp:126-232
+//   myslam::LocalBA::{Build,Optimize,OptimizeActiveMap}  Backend::OptimizeActiveMap  src/backend.cpp:126-243
 //
 // No OpenCV / Eigen / g2o: images are (data, rows, cols, step) views, cv::KeyPoint is the layout-compatible
 // myslam_keypoint, DescrVector is std::array<float,1064>.  Errors the reference reports by logging + return keep
@@ -195,6 +195,28 @@ struct LocalBA {               // flat-array form of the graph Backend::Optimize
         check(myslam_ba_build(poses.data(), P, points.data(), L, edge_pose.data(), edge_pt.data(), obs.data(), E,
                               fixed.empty() ? nullptr : fixed.data(), fx, fy, cx, cy, huber_delta, Hpp.data(), Hll.data(), Hpl.data(),
                               bp.data(), bl.data(), chi2.data()), "myslam_ba_build");
+    }
+    // optimizer.optimize(n) of backend.cpp:212-214 on the device: poses / points are updated in place
+    int Optimize(int iterations = 10, double* final_chi2 = nullptr) {
+        const int P = (int)(poses.size() / 7), L = (int)(points.size() / 3), E = (int)edge_pose.size();
+        int it = 0;
+        check(myslam_ba_optimize(poses.data(), P, points.data(), L, edge_pose.data(), edge_pt.data(), obs.data(), E,
+                                 fixed.empty() ? nullptr : fixed.data(), fx, fy, cx, cy, huber_delta, iterations, final_chi2, &it),
+              "myslam_ba_optimize");
+        return it;
+    }
+    // the whole solve stage, backend.cpp:208-243: rounds of optimize(10) until the inlier ratio passes 0.5, then the outlier
+    // flags (outlier[k] != 0 <=> the reference sets feature->mbIsOutlier and detaches it, :232-249); chi2[k] = edge->chi2()
+    std::vector<uint8_t> outlier;
+    int OptimizeActiveMap(double chi2_th = 5.991, int max_rounds = 5, int iters_per_round = 10) {
+        const int P = (int)(poses.size() / 7), L = (int)(points.size() / 3), E = (int)edge_pose.size();
+        chi2.assign(E, 0); outlier.assign(E, 0);
+        int rounds = 0, nout = 0;
+        check(myslam_ba_optimize_active_map(poses.data(), P, points.data(), L, edge_pose.data(), edge_pt.data(), obs.data(), E,
+                                            fixed.empty() ? nullptr : fixed.data(), fx, fy, cx, cy, huber_delta, chi2_th, max_rounds,
+                                            iters_per_round, chi2.data(), outlier.data(), &rounds, &nout),
+              "myslam_ba_optimize_active_map");
+        return nout;
     }
 };
 

@@ -215,6 +215,22 @@ int myslam_ba_optimize_batch(double* d_poses, double* d_points, const int32_t* d
                              int max_iters, double* d_scratch, double* d_final_chi2, int32_t* d_iters, int32_t* d_status,
                              void* hip_stream);
 
+/* The whole solve stage of Backend::OptimizeActiveMap (src/backend.cpp:208-243): up to max_rounds (5) times
+ * { initializeOptimization(); optimize(iters_per_round = 10) }, stopping as soon as more than half of the edges have
+ * chi2() <= chi2_th (5.991); then the outlier flags of :232-249.  edge_chi2[k] is what edge->chi2() returns there: e^T e of
+ * the last error evaluation (the last Levenberg trial, accepted or not — a g2o property the reference inherits).
+ * *rounds = the reference's `iteration` counter (rounds that failed the inlier test).  Edges grouped by landmark, max_poses <= 10. */
+int myslam_ba_optimize_active_map(double* poses, int nposes, double* points, int npts, const int32_t* edge_pose, const int32_t* edge_pt,
+                                  const double* obs, int nedges, const uint8_t* fixed_pt, double fx, double fy, double cx, double cy,
+                                  double huber_delta, double chi2_th, int max_rounds, int iters_per_round,
+                                  double* edge_chi2, uint8_t* outlier, int* rounds, int* n_outliers);
+/* batched / device-resident form; d_edge_chi2, d_outlier: nwin x max_edges; d_rounds, d_n_outliers, d_status: nwin */
+int myslam_ba_optimize_active_map_batch(double* d_poses, double* d_points, const int32_t* d_edge_pose, const int32_t* d_edge_pt,
+                                        const double* d_obs, const uint8_t* d_fixed, const int32_t* d_sizes, int nwin, int max_poses,
+                                        int max_pts, int max_edges, double fx, double fy, double cx, double cy, double huber_delta,
+                                        double chi2_th, int max_rounds, int iters_per_round, double* d_scratch, double* d_edge_chi2,
+                                        uint8_t* d_outlier, int32_t* d_rounds, int32_t* d_n_outliers, int32_t* d_status, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

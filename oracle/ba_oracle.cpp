@@ -122,12 +122,14 @@ struct Problem {
     const uint8_t* fixed; Cam K; double delta;
 };
 
-double robust_chi2(const Problem& P) {
+// computeActiveErrors() + activeRobustChi2(); edge_chi2 (optional) receives what edge->chi2() would return afterwards
+double robust_chi2(const Problem& P, double* edge_chi2 = nullptr) {
     double s = 0;
     for (int k = 0; k < P.ne; k++) {
         double e[2];
         edge_eval(P.poses[P.ep[k]], &P.pts[3 * P.el[k]], P.obs + 2 * k, P.K, e, nullptr, nullptr);
         double r0, r1; huber(e[0] * e[0] + e[1] * e[1], P.delta, r0, r1);
+        if (edge_chi2) edge_chi2[k] = e[0] * e[0] + e[1] * e[1];
         s += r0;
     }
     return s;
@@ -296,10 +298,10 @@ int orc_ba_build(const double* poses, int nposes, const double* points, int npts
 }
 
 // g2o OptimizationAlgorithmLevenberg::solve x max_iters (Appendix A.7)
-int orc_ba_optimize(double* poses, int nposes, double* points, int npts,
-                    const int32_t* edge_pose, const int32_t* edge_pt, const double* obs, int nedges,
-                    const uint8_t* fixed_pt, double fx, double fy, double cx, double cy, double huber_delta,
-                    int max_iters, double* final_chi2, int* iters) {
+static int lm_optimize(double* poses, int nposes, double* points, int npts,
+                       const int32_t* edge_pose, const int32_t* edge_pt, const double* obs, int nedges,
+                       const uint8_t* fixed_pt, double fx, double fy, double cx, double cy, double huber_delta,
+                       int max_iters, double* final_chi2, int* iters, double* edge_chi2) {
     for (int k = 0; k < nedges; k++)
         if (edge_pose[k] < 0 || edge_pose[k] >= nposes || edge_pt[k] < 0 || edge_pt[k] >= npts) return -1;
     Problem P;
@@ -308,7 +310,7 @@ int orc_ba_optimize(double* poses, int nposes, double* points, int npts,
     double lambda = 0, ni = 2;
     int it = 0;
     for (; it < max_iters; it++) {
-        double currentChi = robust_chi2(P), tempChi = currentChi;
+        double currentChi = robust_chi2(P, edge_chi2), tempChi = currentChi;
         build(P, Hpp.data(), Hll.data(), Hpl.data(), bp.data(), bl.data(), nullptr);
         if (it == 0) {          // computeLambdaInit: tau * max diagonal
             double mx = 0;
@@ -326,7 +328,7 @@ int orc_ba_optimize(double* poses, int nposes, double* points, int npts,
             if (ok) {
                 for (int p = 0; p < nposes; p++) pose_oplus(P.poses[p], &xp[6 * p]);
                 for (int l = 0; l < npts; l++) for (int a = 0; a < 3; a++) P.pts[3 * l + a] += xl[3 * l + a];
-                tempChi = robust_chi2(P);
+                tempChi = robust_chi2(P, edge_chi2);      // the edges keep THIS error even if the step is rejected below
             } else tempChi = 1e300;
             rho = currentChi - tempChi;
             double scale = 1e-3;
@@ -357,6 +359,40 @@ int orc_ba_optimize(double* poses, int nposes, double* points, int npts,
     memcpy(points, P.pts.data(), sizeof(double) * 3 * npts);
     if (final_chi2) *final_chi2 = robust_chi2(P);
     if (iters) *iters = it;
+    return 0;
+}
+
+int orc_ba_optimize(double* poses, int nposes, double* points, int npts,
+                    const int32_t* edge_pose, const int32_t* edge_pt, const double* obs, int nedges,
+                    const uint8_t* fixed_pt, double fx, double fy, double cx, double cy, double huber_delta,
+                    int max_iters, double* final_chi2, int* iters) {
+    return lm_optimize(poses, nposes, points, npts, edge_pose, edge_pt, obs, nedges, fixed_pt, fx, fy, cx, cy, huber_delta, max_iters,
+                       final_chi2, iters, nullptr);
+}
+
+/* Backend::OptimizeActiveMap, src/backend.cpp:208-243: up to max_rounds x { initializeOptimization(); optimize(iters) }, after
+ * each round count edges with chi2() > chi2_th and stop as soon as the inlier ratio exceeds 0.5; then flag the outliers.
+ * edge->chi2() is e^T e of the LAST error evaluation g2o made (App. A.7: the last Levenberg trial, accepted or not). */
+int orc_ba_optimize_active_map(double* poses, int nposes, double* points, int npts,
+                               const int32_t* edge_pose, const int32_t* edge_pt, const double* obs, int nedges,
+                               const uint8_t* fixed_pt, double fx, double fy, double cx, double cy, double huber_delta,
+                               double chi2_th, int max_rounds, int iters_per_round,
+                               double* edge_chi2, uint8_t* outlier, int* rounds, int* n_outliers) {
+    if (nedges < 1 || !edge_chi2 || !outlier) return -1;
+    int r = 0, cntOut = 0;
+    while (r < max_rounds) {
+        int rc = lm_optimize(poses, nposes, points, npts, edge_pose, edge_pt, obs, nedges, fixed_pt, fx, fy, cx, cy, huber_delta,
+                             iters_per_round, nullptr, nullptr, edge_chi2);
+        if (rc) return rc;
+        cntOut = 0;
+        for (int k = 0; k < nedges; k++) cntOut += edge_chi2[k] > chi2_th;
+        const double inlierRatio = (nedges - cntOut) / double(nedges);
+        if (inlierRatio > 0.5) break;
+        r++;
+    }
+    for (int k = 0; k < nedges; k++) outlier[k] = edge_chi2[k] > chi2_th;
+    if (rounds) *rounds = r;              // the reference's `iteration` counter: rounds that FAILED the inlier test
+    if (n_outliers) *n_outliers = cntOut;
     return 0;
 }
 

@@ -131,6 +131,12 @@ int orc_ba_optimize(double* poses, int nposes, double* points, int npts,
                     const int32_t* edge_pose, const int32_t* edge_pt, const double* obs, int nedges,
                     const uint8_t* fixed_pt, double fx, double fy, double cx, double cy, double huber_delta,
                     int max_iters, double* final_chi2, int* iters);
+/* Backend::OptimizeActiveMap outer loop (src/backend.cpp:208-243); *rounds = rounds that failed the inlier-ratio test */
+int orc_ba_optimize_active_map(double* poses, int nposes, double* points, int npts,
+                               const int32_t* edge_pose, const int32_t* edge_pt, const double* obs, int nedges,
+                               const uint8_t* fixed_pt, double fx, double fy, double cx, double cy, double huber_delta,
+                               double chi2_th, int max_rounds, int iters_per_round,
+                               double* edge_chi2, uint8_t* outlier, int* rounds, int* n_outliers);
 void orc_se3_exp(const double* xi6, double* q_t7);
 
 #ifdef __cplusplus

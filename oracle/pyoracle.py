@@ -306,6 +306,18 @@ class Oracle:
         assert rc == 0, rc
         return poses, points, chi.value, it.value
 
+    def ba_optimize_active_map(self, poses, points, ep, el, obs, fixed, K, delta=5.991, chi2_th=5.991, rounds=5, iters=10):
+        poses = np.ascontiguousarray(poses, np.float64).copy(); points = np.ascontiguousarray(points, np.float64).copy()
+        ep = np.ascontiguousarray(ep, np.int32); el = np.ascontiguousarray(el, np.int32)
+        obs = np.ascontiguousarray(obs, np.float64); fixed = np.ascontiguousarray(fixed, np.uint8)
+        chi = np.zeros(len(ep)); out = np.zeros(len(ep), np.uint8); r = C.c_int(); no = C.c_int()
+        rc = self.lib.orc_ba_optimize_active_map(_p(poses), len(poses), _p(points), len(points), _p(ep), _p(el), _p(obs), len(ep),
+                                                 _p(fixed), C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]),
+                                                 C.c_double(delta), C.c_double(chi2_th), rounds, iters, _p(chi), _p(out),
+                                                 C.byref(r), C.byref(no))
+        assert rc == 0, rc
+        return poses, points, chi, out, r.value, no.value
+
     def se3_exp(self, xi):
         xi = np.ascontiguousarray(xi, np.float64); out = np.zeros(7)
         self.lib.orc_se3_exp(_p(xi), _p(out))

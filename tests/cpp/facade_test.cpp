@@ -60,6 +60,39 @@ int main() {
     EXPECT(D.DetectLoop(200, db[33], loop, &mx) && loop == 33 && mx > 0.999f);
     EXPECT(!D.DetectLoop(40, db[33], loop));          // id 33 is younger than cur-20 -> never scanned
 
+    // local BA: 6 key-frames on a line looking down +z, 80 landmarks, every landmark seen by every key-frame, noisy observations
+    {
+        myslam::LocalBA ba;
+        const int P = 6, L = 80;
+        ba.fx = 718.856; ba.fy = 718.856; ba.cx = 607.1928; ba.cy = 185.2157;
+        std::uniform_real_distribution<double> U(-1, 1);
+        std::vector<double> tx(P);
+        for (int p = 0; p < P; p++) { tx[p] = 0.4 * p; const double q[7] = {0, 0, 0, 1, -tx[p], 0, 0}; ba.poses.insert(ba.poses.end(), q, q + 7); }
+        for (int l = 0; l < L; l++) {
+            const double X[3] = {1.0 + 4 * U(rng), 1.5 * U(rng), 12 + 6 * U(rng)};
+            for (int p = 0; p < P; p++) {
+                const double xc = X[0] - tx[p], u = ba.fx * xc / X[2] + ba.cx, v = ba.fy * X[1] / X[2] + ba.cy;
+                ba.edge_pose.push_back(p); ba.edge_pt.push_back(l);
+                ba.obs.push_back(u + 0.5 * U(rng) + (l % 17 == 0 && p == 2 ? 25.0 : 0.0)); ba.obs.push_back(v + 0.5 * U(rng));
+            }
+            ba.points.push_back(X[0] + 0.05 * U(rng)); ba.points.push_back(X[1] + 0.05 * U(rng)); ba.points.push_back(X[2] + 0.05 * U(rng));
+            ba.fixed.push_back(l % 9 == 0);
+        }
+        const int E = (int)ba.edge_pose.size();
+        std::vector<double> rp = ba.poses, rx = ba.points, rchi(E); std::vector<uint8_t> rout(E); int rr = 0, rn2 = 0;
+        EXPECT(orc_ba_optimize_active_map(rp.data(), P, rx.data(), L, ba.edge_pose.data(), ba.edge_pt.data(), ba.obs.data(), E, ba.fixed.data(),
+                                          ba.fx, ba.fy, ba.cx, ba.cy, 5.991, 5.991, 5, 10, rchi.data(), rout.data(), &rr, &rn2) == 0);
+        const int nout = ba.OptimizeActiveMap();
+        EXPECT(nout == rn2 && nout >= 5);
+        double dmax = 0;
+        for (size_t i = 0; i < rp.size(); i++) dmax = std::max(dmax, std::fabs(rp[i] - ba.poses[i]));
+        for (size_t i = 0; i < rx.size(); i++) dmax = std::max(dmax, std::fabs(rx[i] - ba.points[i]));
+        EXPECT(dmax < 1e-7);
+        int flagdiff = 0;
+        for (int k = 0; k < E; k++) flagdiff += (ba.outlier[k] != rout[k]) && std::fabs(rchi[k] - 5.991) > 1e-6;
+        EXPECT(flagdiff == 0);
+    }
+
     printf(fails ? "FACADE TEST FAILED (%d)\n" : "FACADE TEST OK (%d failures)\n", fails);
     return fails ? 1 : 0;
 }

@@ -110,3 +110,46 @@ def test_ba_optimize_batch(api, oracle, synth):
         assert int(it[w]) == rit and float(chi[w]) == pytest.approx(rchi, rel=1e-8)
         assert np.allclose(d[0][w, :len(p)].cpu().numpy(), rp, rtol=1e-7, atol=1e-8)
         assert np.allclose(d[1][w, :len(x)].cpu().numpy(), rx, rtol=1e-7, atol=1e-7)
+
+
+@pytest.mark.parametrize("outlier_frac,seed", [(0.03, 0xBA), (0.3, 11), (0.6, 5)])
+def test_ba_optimize_active_map_matches_oracle(api, oracle, synth, outlier_frac, seed):
+    """Backend::OptimizeActiveMap's solve stage (backend.cpp:208-243): rounds of optimize(10) until the inlier ratio passes 0.5,
+    per-edge chi2 of the last evaluation, outlier flags.  0.6 gross outliers forces all five rounds."""
+    poses, pts, ep, el, obs, fixed, K = synth.ba_problem(seed=seed, outlier_frac=outlier_frac)
+    gp, gx, gchi, gout, gr, gn = api.ba_optimize_active_map(poses, pts, ep, el, obs, fixed, K)
+    rp, rx, rchi, rout, rr, rn = oracle.ba_optimize_active_map(poses, pts, ep, el, obs, fixed, K)
+    assert (gr, gn) == (rr, rn)
+    assert np.allclose(gp, rp, rtol=1e-7, atol=1e-8) and np.allclose(gx, rx, rtol=1e-7, atol=1e-7)
+    assert np.allclose(gchi, rchi, rtol=1e-6, atol=1e-9)
+    near = np.abs(rchi - 5.991) < 1e-6                        # flags may only differ where chi2 sits on the threshold
+    assert np.array_equal(gout[~near], rout[~near])
+    if outlier_frac >= 0.6:
+        assert rr == 5
+    else:
+        assert rr == 0
+
+
+def test_ba_optimize_active_map_batch(api, oracle, synth):
+    import torch
+    W, maxP, maxL, maxE = 3, 10, 300, 3000
+    probs = [synth.ba_problem(seed=300 + w, n_kf=6 + 2 * w, n_mp=120 + 60 * w, outlier_frac=0.05 + 0.3 * w) for w in range(W)]
+    poses = np.zeros((W, maxP, 7)); poses[..., 3] = 1
+    pts = np.zeros((W, maxL, 3)); ep = np.zeros((W, maxE), np.int32); el = np.zeros((W, maxE), np.int32)
+    obs = np.zeros((W, maxE, 2)); fixed = np.zeros((W, maxL), np.uint8); sizes = np.zeros((W, 3), np.int32)
+    for w, (p, x, a, b, o, f, K) in enumerate(probs):
+        poses[w, :len(p)] = p; pts[w, :len(x)] = x; ep[w, :len(a)] = a; el[w, :len(a)] = b; obs[w, :len(a)] = o; fixed[w, :len(f)] = f
+        sizes[w] = (len(p), len(x), len(a))
+    d = [torch.from_numpy(a).cuda() for a in (poses, pts, ep, el, obs, fixed, sizes)]
+    scratch = torch.zeros(W * maxE * 18, dtype=torch.float64, device="cuda")
+    chi = torch.zeros(W, maxE, dtype=torch.float64, device="cuda"); out = torch.zeros(W, maxE, dtype=torch.uint8, device="cuda")
+    rd = torch.zeros(W, dtype=torch.int32, device="cuda"); no = torch.zeros(W, dtype=torch.int32, device="cuda"); st = torch.ones(W, dtype=torch.int32, device="cuda")
+    api.ba_optimize_active_map_batch(*[t.data_ptr() for t in d], W, maxP, maxL, maxE, probs[0][6], 5.991, 5.991, 5, 10, scratch.data_ptr(),
+                                     chi.data_ptr(), out.data_ptr(), rd.data_ptr(), no.data_ptr(), st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert (st.cpu().numpy() == 0).all()
+    for w, (p, x, a, b, o, f, K) in enumerate(probs):
+        rp, rx, rchi, rout, rr, rn = oracle.ba_optimize_active_map(p, x, a, b, o, f, K)
+        assert (int(rd[w]), int(no[w])) == (rr, rn)
+        assert np.allclose(d[0][w, :len(p)].cpu().numpy(), rp, rtol=1e-7, atol=1e-8)
+        assert np.allclose(chi[w, :len(a)].cpu().numpy(), rchi, rtol=1e-6, atol=1e-9)
