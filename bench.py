@@ -65,33 +65,25 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(synth, workload, n_pairs, db_np):
-    """The oracle (a single-threaded port) timed on this host over a bounded sample of the same workload."""
+def cpu_baseline(synth, workload, n_pairs, db_np, gpu_frames):
+    """The oracle (a plain C++ port of the reference arithmetic, oracle/) timed on this host over a bounded sample of the same
+    frames and stages: frame-parallel over all host cores (std::thread pool, one frame per task, oracle/bench_oracle.cpp), plus
+    a single-thread figure (the reference runs every stage single-threaded inside its std::thread)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from pyoracle import Oracle
     o = Oracle()
-    p = o.params(2000)
-    K = synth.KITTI00
-    w = synth.calc_weights()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n_pairs = min(len(gpu_frames), max(n_pairs, 2 * cores))            # the same frames the GPU processed
+    stages = {"orb_match": 1, "orb_match_lcd": 2, "full": 3, "full_solve": 4}[workload]
     ids = np.arange(len(db_np), dtype=np.uint64)
-    ba = synth.ba_problem()
-    frames = [synth.stereo_pair(0, t) for t in range(n_pairs)]
-    t0 = time.perf_counter()
-    for L, R in frames:
-        kl, dl = o.detect_and_compute(p, L); kr, dr = o.detect_and_compute(p, R)
-        idx, dist = o.hamming_match(dl, dr)
-        o.triangulate_stereo(kl["x"], kl["y"], kr["x"][idx], kr["y"][idx], K["fx"], K["fy"], K["cx"], K["cy"], K["bf"] / K["fx"])
-        if workload != "orb_match":
-            x, _ = o.calc_preproc(L)
-            d = o.calc_forward(w, x)
-            o.lcddb_query(db_np, ids, d, len(db_np) + 20)
-        if workload in ("full", "full_solve"):
-            o.ba_build(*ba[:6], ba[6])
-        if workload == "full_solve":
-            o.ba_optimize(*ba[:6], ba[6], iters=10)
-    dt = time.perf_counter() - t0
-    return {"value": n_pairs / dt, "unit": "stereo frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n_pairs} synthetic 1241x376 stereo pairs, same stages as the GPU workload, oracle single thread, {dt:.1f} s"}
+    args = (synth.KITTI00, synth.calc_weights(), db_np, ids, synth.ba_problem())
+    n1 = min(6, n_pairs)
+    dt1 = o.bench_frames(gpu_frames[:n1], *args, stages=stages, threads=1)
+    dt = o.bench_frames(gpu_frames[:n_pairs], *args, stages=stages, threads=cores)
+    return {"value": n_pairs / dt, "unit": "stereo frames/s", "cores": cores, "kind": "port",
+            "value_1thread": n1 / dt1,
+            "sample": f"{n_pairs} of the GPU run's synthetic 1241x376 stereo pairs, same stages, oracle frame-parallel on {cores} "
+                      f"host threads in {dt:.1f} s (single thread: {n1} pairs in {dt1:.1f} s)"}
 
 
 def main():
@@ -158,10 +150,17 @@ def main():
         b_in = [rep(poses), rep(pts), rep(ep), rep(el), rep(obs), rep(fixed),
                 torch.tensor([[maxP, maxL, maxE]] * P, dtype=torch.int32, device=dev)]
         b_out = [torch.zeros(P, n, dtype=torch.float64, device=dev) for n in (maxP * 36, maxL * 9, maxE * 18, maxP * 6, maxL * 3, maxE)]
-        if use_solve:       # optimize(10) updates poses/points in place: every step starts from the pristine window
-            s_poses, s_pts = b_in[0].clone(), b_in[1].clone()
-            s_chi = torch.zeros(P, dtype=torch.float64, device=dev)
-            s_it = torch.zeros(P, dtype=torch.int32, device=dev); s_st = torch.zeros(P, dtype=torch.int32, device=dev)
+        # the solve updates poses/points in place: every step starts from the pristine window
+        s_poses, s_pts = b_in[0].clone(), b_in[1].clone()
+        s_echi = torch.zeros(P, maxE, dtype=torch.float64, device=dev); s_out = torch.zeros(P, maxE, dtype=torch.uint8, device=dev)
+        s_rd = torch.zeros(P, dtype=torch.int32, device=dev); s_no = torch.zeros(P, dtype=torch.int32, device=dev)
+        s_st = torch.zeros(P, dtype=torch.int32, device=dev)
+
+        def solve():        # Backend::OptimizeActiveMap solve stage: rounds of optimize(10) + outlier flags (backend.cpp:208-243)
+            s_poses.copy_(b_in[0]); s_pts.copy_(b_in[1])
+            api.ba_optimize_active_map_batch(s_poses.data_ptr(), s_pts.data_ptr(), *[t.data_ptr() for t in b_in[2:]], P, maxP, maxL, maxE, Kt,
+                                             5.991, 5.991, 5, 10, b_out[2].data_ptr(), s_echi.data_ptr(), s_out.data_ptr(), s_rd.data_ptr(),
+                                             s_no.data_ptr(), s_st.data_ptr(), stream)
 
     def step():
         ext.detect_and_compute_batch(d_imgs.data_ptr(), 2 * P, H, W, W, H * W, d_kps.data_ptr(), d_desc.data_ptr(),
@@ -181,9 +180,7 @@ def main():
         if use_ba:
             api.ba_build_batch(*[t.data_ptr() for t in b_in], P, maxP, maxL, maxE, Kt, 5.991, *[t.data_ptr() for t in b_out], stream)
             if use_solve:
-                s_poses.copy_(b_in[0]); s_pts.copy_(b_in[1])
-                api.ba_optimize_batch(s_poses.data_ptr(), s_pts.data_ptr(), *[t.data_ptr() for t in b_in[2:]], P, maxP, maxL, maxE, Kt,
-                                      5.991, 10, b_out[2].data_ptr(), s_chi.data_ptr(), s_it.data_ptr(), s_st.data_ptr(), stream)
+                solve()
 
     def barrier():
         if world > 1:
@@ -210,6 +207,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    solve_ms = None
+    if use_ba and not use_solve:        # the "g2o solve" half of configs[3], timed on its own (not part of `value`)
+        solve(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            solve()
+        torch.cuda.synchronize()
+        solve_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        assert int(s_st.abs().sum()) == 0
+
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = world * P * args.steps / dt
@@ -226,7 +233,7 @@ def main():
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, P), "avg_launch_ms": per_launch_ms,
                     "algorithmic_bytes_per_launch": algo,
-                    "note": "integer-ALU bound in practice (~120 packed ops per pixel); traffic = FETCH_SIZE+WRITE_SIZE of a separate rocprofv3 --pmc run (profiles/), uncorrected"}
+                    "note": "packed-integer VALU bound in practice (~70 VALU instructions per pixel, DESIGN.md section 6); traffic = FETCH_SIZE+WRITE_SIZE of a separate rocprofv3 --pmc run (profiles/), uncorrected"}
         else:
             roof = {"bound": "hbm", "kernel": dom, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                     "traffic": None, "avg_launch_ms": per_launch_ms}
@@ -237,17 +244,18 @@ def main():
             "dtype": "u8/int32 (ORB, Hamming), f32 (CALC, DB scan), f64 (triangulation, BA)", "data": "synthetic",
             "config": {"workload": {"full": "configs[3]: ORB extract L+R (2000 feats) + L/R Hamming match + triangulation + DeepLCD descriptor + "
                                             f"{n_db_local * world}-KF cosine DB scan + local-BA (10 KF x 300 MP) block build per frame",
-                                    "full_solve": "configs[3] incl. solve: as 'full' + Levenberg-Marquardt optimize(10) (Schur + Cholesky) of the "
-                                                  "10 KF x 300 MP window per frame",
+                                    "full_solve": "configs[3] incl. solve: as 'full' + the Backend::OptimizeActiveMap solve stage (rounds of Levenberg-Marquardt "
+                                                  "optimize(10) with Schur + Cholesky, outlier flags) of the 10 KF x 300 MP window per frame",
                                     "orb_match": "configs[1]: ORB extract L+R (2000 feats) + L/R Hamming match + triangulation",
                                     "orb_match_lcd": f"configs[2]: configs[1] + DeepLCD descriptor + {n_db_local * world}-KF cosine DB scan"}[args.workload],
                        "pairs_per_step_per_gpu": P, "image": "1241x376 u8", "keypoints_per_image": n_kp,
                        "parallelism": f"frame-sharded x{world}" + (", id-range sharded DB + all-gather of candidates" if world > 1 else "")},
             "roofline": roof,
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in busy.items()},
+            "ba_solve_ms_per_step": solve_ms,     # OptimizeActiveMap solve stage for the same windows, outside the timed region
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(synth, args.workload, args.cpu_pairs, db_np if db_np is not None else synth.lcd_database(16))
+            out["cpu_baseline"] = cpu_baseline(synth, args.workload, args.cpu_pairs, db_np if db_np is not None else synth.lcd_database(16), frames)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -318,6 +318,25 @@ class Oracle:
         assert rc == 0, rc
         return poses, points, chi, out, r.value, no.value
 
+    def bench_frames(self, frames, K, weights, db, ids, ba, stages=3, threads=1, nfeatures=2000):
+        """CPU-baseline driver (bench_oracle.cpp): frames [n,2,H,W] u8 through the whole per-frame pipeline on `threads` threads.
+        Returns wall seconds."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n, _, H, W = frames.shape
+        weights = np.ascontiguousarray(weights, np.float32); db = np.ascontiguousarray(db, np.float32)
+        ids = np.ascontiguousarray(ids, np.uint64)
+        poses, pts, ep, el, obs, fixed, _ = ba
+        poses = np.ascontiguousarray(poses, np.float64); pts = np.ascontiguousarray(pts, np.float64)
+        ep = np.ascontiguousarray(ep, np.int32); el = np.ascontiguousarray(el, np.int32)
+        obs = np.ascontiguousarray(obs, np.float64); fixed = np.ascontiguousarray(fixed, np.uint8)
+        sec = C.c_double()
+        rc = self.lib.orc_bench_frames(_p(frames), n, H, W, nfeatures, C.c_double(K["fx"]), C.c_double(K["fy"]), C.c_double(K["cx"]),
+                                       C.c_double(K["cy"]), C.c_double(K["bf"] / K["fx"]), _p(weights), C.c_size_t(weights.size),
+                                       _p(db), _p(ids), len(ids), _p(poses), len(poses), _p(pts), len(pts), _p(ep), _p(el), _p(obs),
+                                       len(ep), _p(fixed), int(stages), int(threads), C.byref(sec))
+        assert rc == 0, rc
+        return sec.value
+
     def se3_exp(self, xi):
         xi = np.ascontiguousarray(xi, np.float64); out = np.zeros(7)
         self.lib.orc_se3_exp(_p(xi), _p(out))
