@@ -390,3 +390,36 @@ def ba_optimize_active_map_batch(d_poses, d_points, d_ep, d_el, d_obs, d_fixed, 
         C.c_double(delta), C.c_double(chi2_th), int(rounds), int(iters), C.c_void_p(d_scratch), C.c_void_p(d_edge_chi2),
         C.c_void_p(d_outlier), C.c_void_p(d_rounds), C.c_void_p(d_nout), C.c_void_p(d_status), C.c_void_p(stream or None)),
         "myslam_ba_optimize_active_map_batch")
+
+
+# ---------------------------------------------------------------------------------- LK tracker
+class LKTracker:
+    """cv::calcOpticalFlowPyrLK(..., Size(11,11), 3, TermCriteria(COUNT+EPS, 30, 0.01), OPTFLOW_USE_INITIAL_FLOW) as the reference
+    calls it in Frontend::TrackLastFrame / FindFeaturesInRight (src/frontend.cpp:150-153, 358-361)."""
+
+    def __init__(self, win=11, max_level=3, max_iters=30, eps=0.01, min_eig=1e-4, stream=None):
+        self._h = C.c_void_p()
+        _check(lib().myslam_lk_create(C.byref(self._h), int(win), int(max_level), int(max_iters), C.c_float(eps), C.c_float(min_eig)),
+               "myslam_lk_create")
+        if stream is not None:
+            _check(lib().myslam_lk_set_stream(self._h, C.c_void_p(stream)), "myslam_lk_set_stream")
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value and _lib is not None:
+            lib().myslam_lk_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def track(self, prev, nxt, prev_pts, next_pts):
+        """host arrays; returns (next_pts, status bool, err)"""
+        prev = np.ascontiguousarray(prev, np.uint8); nxt = np.ascontiguousarray(nxt, np.uint8)
+        pp = np.ascontiguousarray(prev_pts, np.float32).reshape(-1, 2)
+        npts = np.ascontiguousarray(next_pts, np.float32).reshape(-1, 2).copy()
+        n = len(pp); st = np.zeros(max(n, 1), np.uint8); err = np.zeros(max(n, 1), np.float32)
+        _check(lib().myslam_lk_track(self._h, _p(prev), _p(nxt), prev.shape[0], prev.shape[1], prev.strides[0], nxt.strides[0],
+                                     _p(pp), _p(npts), n, _p(st), _p(err)), "myslam_lk_track")
+        return npts, st[:n].astype(bool), err[:n]
+
+    def track_batch(self, d_prev, d_next, batch, rows, cols, step, stride, d_prev_pts, d_next_pts, d_counts, cap, d_status, d_err=0):
+        _check(lib().myslam_lk_track_batch(self._h, C.c_void_p(d_prev), C.c_void_p(d_next), batch, rows, cols, step, C.c_size_t(stride),
+                                           C.c_void_p(d_prev_pts), C.c_void_p(d_next_pts), C.c_void_p(d_counts), cap,
+                                           C.c_void_p(d_status), C.c_void_p(d_err or None)), "myslam_lk_track_batch")

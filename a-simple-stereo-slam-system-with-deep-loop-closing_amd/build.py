@@ -25,6 +25,7 @@ UNITS = {
     "calc.hip": [],
     "lcddb.hip": [],
     "ba.hip": [],
+    "lk.hip": EXACT,
     "prof.hip": [],
 }
 

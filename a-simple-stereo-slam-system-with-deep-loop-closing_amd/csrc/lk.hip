@@ -1,0 +1,392 @@
+// lk.hip — pyramidal Lucas-Kanade tracker on gfx950, the operator the reference calls as
+//   cv::calcOpticalFlowPyrLK(prev, next, prevPts, nextPts, status, err, Size(11,11), 3,
+//                            TermCriteria(COUNT+EPS, 30, 0.01), OPTFLOW_USE_INITIAL_FLOW)
+// in Frontend::TrackLastFrame (src/frontend.cpp:150-153) and Frontend::FindFeaturesInRight (:358-361)  [SURVEY.md §8(f) rank 1].
+//
+// Arithmetic (OpenCV lkpyramid.cpp, restated in oracle/lk_oracle.cpp): pyrDown 5x5 [1 4 6 4 1]/16 REFLECT_101, 3x3 Scharr
+// derivatives as shorts (zero outside the image), W_BITS = 14 fixed-point bilinear patch extraction, 2x2 normal equations.
+// The window sums are exact integer sums converted to float once (the restatement's definition), so the tracker is bit-exact
+// against the oracle; every float expression uses explicit non-fused IEEE operations.
+//
+// One wave per point, all pyramid levels inside the wave (coarse to fine), no global scratch: the (win+3)^2 patch of I, its
+// Scharr derivatives and the (win+1)^2 window of J live in LDS; the template patch (I, Ix, Iy at the window pixels) stays in
+// registers (2 window pixels per lane).  Sums over the window are DPP wave reductions of 32-bit halves (exact).
+#include <math.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace myslam_hip {
+
+constexpr int LK_MAXL = 6;          // pyramid levels supported (the reference uses maxLevel = 3)
+constexpr int LK_MAXWIN = 15;       // window sizes up to 15x15 fit 4 window pixels per lane (11x11 -> 2 per lane)
+constexpr int LK_WPL = 4;
+
+struct LkGeom {
+    int levels;                     // top level index actually used
+    int w[LK_MAXL + 1], h[LK_MAXL + 1];
+    size_t off[LK_MAXL + 1];        // byte offset of level l >= 1 inside one image's pyramid block
+    size_t bytes;                   // pyramid block bytes per image (levels >= 1)
+};
+
+__device__ __forceinline__ int lk_reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = (p < 0) ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+// cv::pyrDown 8UC1: one thread per destination pixel
+__global__ __launch_bounds__(256) void k_pyr_down(const uint8_t* __restrict__ src, int sw, int sh, int sstep, size_t sstride,
+                                                  uint8_t* __restrict__ dst, int dw, int dh, size_t dstride) {
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    const uint8_t* S = src + (size_t)b * sstride;
+    int xs[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) xs[i] = lk_reflect101(2 * x + i - 2, sw);
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const uint8_t* row = S + (size_t)lk_reflect101(2 * y + j - 2, sh) * sstep;
+        const int r = row[xs[0]] + 4 * row[xs[1]] + 6 * row[xs[2]] + 4 * row[xs[3]] + row[xs[4]];
+        s += (j == 0 || j == 4) ? r : (j == 2 ? 6 * r : 4 * r);
+    }
+    dst[(size_t)b * dstride + (size_t)y * dw + x] = (uint8_t)((s + 128) >> 8);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int lk_dpp_add(int v) { return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false); }
+__device__ __forceinline__ int lk_wave_sum(int v) {                 // total in lane 63, broadcast to the wave
+    v = lk_dpp_add<0xB1, 0xf>(v); v = lk_dpp_add<0x4E, 0xf>(v); v = lk_dpp_add<0x141, 0xf>(v); v = lk_dpp_add<0x140, 0xf>(v);
+    v = lk_dpp_add<0x142, 0xa>(v); v = lk_dpp_add<0x143, 0xc>(v);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// exact wave sum of per-lane int32 partials whose total may exceed 32 bits: sum the high part and the low byte separately
+__device__ __forceinline__ long long lk_wave_sum64(int v) {
+    const int hi = lk_wave_sum(v >> 8), lo = lk_wave_sum(v & 0xff);
+    return (long long)hi * 256 + lo;
+}
+
+struct LkArgs {
+    const uint8_t* prev; const uint8_t* next; int rows, cols, pstep, nstep; size_t pstride, nstride;
+    const uint8_t* pyrP; const uint8_t* pyrN;        // levels >= 1 of every image
+    LkGeom g;
+    const float* prev_pts; float* next_pts; const int32_t* counts; int n_fixed, cap;
+    int win, max_iters; float eps2, min_eig;
+    uint8_t* status; float* err;
+};
+
+__global__ __launch_bounds__(256) void k_lk_track(LkArgs a) {
+    constexpr int PI_MAX = LK_MAXWIN + 3, PJ_MAX = LK_MAXWIN + 1;
+    __shared__ uint8_t s_I[4][PI_MAX * PI_MAX];
+    __shared__ short s_dx[4][PJ_MAX * PJ_MAX], s_dy[4][PJ_MAX * PJ_MAX];
+    __shared__ uint8_t s_J[4][PJ_MAX * PJ_MAX];
+    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pi = blockIdx.x * 4 + wave;
+    const int n = a.counts ? a.counts[b] : a.n_fixed;
+    if (pi >= n) return;                                            // wave-uniform
+    const int win = a.win, ww = win * win, pI = win + 3, pJ = win + 1;
+    const float halfWin = (float)(win - 1) * 0.5f;
+    const float* pp = a.prev_pts + ((size_t)b * a.cap + pi) * 2;
+    float* np_ = a.next_pts + ((size_t)b * a.cap + pi) * 2;
+    const float p0x = pp[0], p0y = pp[1];
+    float outx = np_[0], outy = np_[1];                             // nextPts[ptidx], carried across levels
+    int status = 1; float errv = 0.f;
+    uint8_t* sI = s_I[wave]; short* sdx = s_dx[wave]; short* sdy = s_dy[wave]; uint8_t* sJ = s_J[wave];
+    constexpr int W_BITS = 14;
+    const float FLT_SCALE = 1.f / (1 << 20);
+
+    for (int level = a.g.levels; level >= 0; level--) {
+        const int lw = a.g.w[level], lh = a.g.h[level];
+        const uint8_t* I; const uint8_t* J; int istep, jstep;
+        if (level == 0) { I = a.prev + (size_t)b * a.pstride; J = a.next + (size_t)b * a.nstride; istep = a.pstep; jstep = a.nstep; }
+        else { I = a.pyrP + (size_t)b * a.g.bytes + a.g.off[level]; J = a.pyrN + (size_t)b * a.g.bytes + a.g.off[level]; istep = jstep = lw; }
+        const float sc = (float)(1. / (1 << level));
+        float prx = __fmul_rn(p0x, sc), pry = __fmul_rn(p0y, sc);
+        float nx, ny;
+        if (level == a.g.levels) { nx = __fmul_rn(outx, sc); ny = __fmul_rn(outy, sc); }          // OPTFLOW_USE_INITIAL_FLOW
+        else { nx = __fmul_rn(outx, 2.f); ny = __fmul_rn(outy, 2.f); }
+        outx = nx; outy = ny;
+        prx = __fsub_rn(prx, halfWin); pry = __fsub_rn(pry, halfWin);
+        const int ipx = (int)floorf(prx), ipy = (int)floorf(pry);
+        if (ipx < -win || ipx >= lw || ipy < -win || ipy >= lh) {
+            if (level == 0) { status = 0; errv = 0.f; }
+            continue;
+        }
+        // ---- stage the (win+3)^2 patch of I (origin ipx-1, ipy-1), REFLECT_101 ----
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < pI * pI; i += 64) {
+            const int r = i / pI, c = i - r * pI;
+            sI[i] = I[(size_t)lk_reflect101(ipy - 1 + r, lh) * istep + lk_reflect101(ipx - 1 + c, lw)];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- Scharr derivatives at the (win+1)^2 positions the bilinear taps touch; zero outside the image ----
+        for (int i = lane; i < pJ * pJ; i += 64) {
+            const int r = i / pJ, c = i - r * pJ;
+            const int X = ipx + c, Y = ipy + r;
+            int dx = 0, dy = 0;
+            if (X >= 0 && X < lw && Y >= 0 && Y < lh) {
+                const uint8_t* q = sI + r * pI + c;                 // top-left of the 3x3 neighbourhood
+                const int a0 = q[0], a1 = q[1], a2 = q[2], b0 = q[pI], b2 = q[pI + 2], c0 = q[2 * pI], c1 = q[2 * pI + 1], c2 = q[2 * pI + 2];
+                const int b1 = q[pI + 1];
+                const int t00 = (a0 + c0) * 3 + b0 * 10, t02 = (a2 + c2) * 3 + b2 * 10;
+                const int t10 = c0 - a0, t11 = c1 - a1, t12 = c2 - a2;
+                (void)b1;
+                dx = t02 - t00;
+                dy = (t12 + t10) * 3 + t11 * 10;
+            }
+            sdx[i] = (short)dx; sdy[i] = (short)dy;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- template patch: I, Ix, Iy at the window pixels (registers), normal matrix ----
+        float fa = __fsub_rn(prx, (float)ipx), fb = __fsub_rn(pry, (float)ipy);
+        int iw00 = __float2int_rn(__fmul_rn(__fmul_rn(__fsub_rn(1.f, fa), __fsub_rn(1.f, fb)), (float)(1 << W_BITS)));
+        int iw01 = __float2int_rn(__fmul_rn(__fmul_rn(fa, __fsub_rn(1.f, fb)), (float)(1 << W_BITS)));
+        int iw10 = __float2int_rn(__fmul_rn(__fmul_rn(__fsub_rn(1.f, fa), fb), (float)(1 << W_BITS)));
+        int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+        int Ip[LK_WPL], Ix[LK_WPL], Iy[LK_WPL];
+        int s11 = 0, s12 = 0, s22 = 0;
+#pragma unroll
+        for (int k = 0; k < LK_WPL; k++) {
+            const int i = lane + 64 * k;
+            Ip[k] = Ix[k] = Iy[k] = 0;
+            if (i < ww) {
+                const int y = i / win, x = i - y * win;
+                const uint8_t* q = sI + (y + 1) * pI + x + 1;
+                Ip[k] = (q[0] * iw00 + q[1] * iw01 + q[pI] * iw10 + q[pI + 1] * iw11 + (1 << (W_BITS - 6))) >> (W_BITS - 5);
+                const short* dxp = sdx + y * pJ + x; const short* dyp = sdy + y * pJ + x;
+                Ix[k] = (dxp[0] * iw00 + dxp[1] * iw01 + dxp[pJ] * iw10 + dxp[pJ + 1] * iw11 + (1 << (W_BITS - 1))) >> W_BITS;
+                Iy[k] = (dyp[0] * iw00 + dyp[1] * iw01 + dyp[pJ] * iw10 + dyp[pJ + 1] * iw11 + (1 << (W_BITS - 1))) >> W_BITS;
+                s11 += Ix[k] * Ix[k]; s12 += Ix[k] * Iy[k]; s22 += Iy[k] * Iy[k];
+            }
+        }
+        const float A11 = __fmul_rn((float)lk_wave_sum64(s11), FLT_SCALE), A12 = __fmul_rn((float)lk_wave_sum64(s12), FLT_SCALE);
+        const float A22 = __fmul_rn((float)lk_wave_sum64(s22), FLT_SCALE);
+        float D = __fsub_rn(__fmul_rn(A11, A22), __fmul_rn(A12, A12));
+        const float dA = __fsub_rn(A11, A22);
+        const float minEig = __fdiv_rn(__fsub_rn(__fadd_rn(A22, A11), __fsqrt_rn(__fadd_rn(__fmul_rn(dA, dA), __fmul_rn(__fmul_rn(4.f, A12), A12)))),
+                                       (float)(2 * win * win));
+        if (minEig < a.min_eig || D < 1.19209290e-07f) {
+            if (level == 0) status = 0;
+            continue;
+        }
+        D = __fdiv_rn(1.f, D);
+        nx = __fsub_rn(nx, halfWin); ny = __fsub_rn(ny, halfWin);
+        float pdx = 0.f, pdy = 0.f;
+        for (int j = 0; j < a.max_iters; j++) {
+            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+            if (inx < -win || inx >= lw || iny < -win || iny >= lh) {
+                if (level == 0) status = 0;
+                break;
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int i = lane; i < pJ * pJ; i += 64) {
+                const int r = i / pJ, c = i - r * pJ;
+                sJ[i] = J[(size_t)lk_reflect101(iny + r, lh) * jstep + lk_reflect101(inx + c, lw)];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            fa = __fsub_rn(nx, (float)inx); fb = __fsub_rn(ny, (float)iny);
+            iw00 = __float2int_rn(__fmul_rn(__fmul_rn(__fsub_rn(1.f, fa), __fsub_rn(1.f, fb)), (float)(1 << W_BITS)));
+            iw01 = __float2int_rn(__fmul_rn(__fmul_rn(fa, __fsub_rn(1.f, fb)), (float)(1 << W_BITS)));
+            iw10 = __float2int_rn(__fmul_rn(__fmul_rn(__fsub_rn(1.f, fa), fb), (float)(1 << W_BITS)));
+            iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+            int sb1 = 0, sb2 = 0;
+#pragma unroll
+            for (int k = 0; k < LK_WPL; k++) {
+                const int i = lane + 64 * k;
+                if (i < ww) {
+                    const int y = i / win, x = i - y * win;
+                    const uint8_t* q = sJ + y * pJ + x;
+                    const int diff = ((q[0] * iw00 + q[1] * iw01 + q[pJ] * iw10 + q[pJ + 1] * iw11 + (1 << (W_BITS - 6))) >> (W_BITS - 5)) - Ip[k];
+                    sb1 += diff * Ix[k]; sb2 += diff * Iy[k];
+                }
+            }
+            const float b1 = __fmul_rn((float)lk_wave_sum64(sb1), FLT_SCALE), b2 = __fmul_rn((float)lk_wave_sum64(sb2), FLT_SCALE);
+            const float dx = __fmul_rn(__fsub_rn(__fmul_rn(A12, b2), __fmul_rn(A22, b1)), D);
+            const float dy = __fmul_rn(__fsub_rn(__fmul_rn(A12, b1), __fmul_rn(A11, b2)), D);
+            nx = __fadd_rn(nx, dx); ny = __fadd_rn(ny, dy);
+            outx = __fadd_rn(nx, halfWin); outy = __fadd_rn(ny, halfWin);
+            if (__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) <= a.eps2) break;
+            if (j > 0 && fabsf(__fadd_rn(dx, pdx)) < 0.01f && fabsf(__fadd_rn(dy, pdy)) < 0.01f) {
+                outx = __fsub_rn(outx, __fmul_rn(dx, 0.5f)); outy = __fsub_rn(outy, __fmul_rn(dy, 0.5f));
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+        if (status && level == 0) {          // patch error at the final position; also the last bounds test (err is always requested)
+            const float fx = __fsub_rn(outx, halfWin), fy = __fsub_rn(outy, halfWin);
+            const int inx = (int)floorf(fx), iny = (int)floorf(fy);
+            if (inx < -win || inx >= lw || iny < -win || iny >= lh) { status = 0; continue; }
+            __builtin_amdgcn_wave_barrier();
+            for (int i = lane; i < pJ * pJ; i += 64) {
+                const int r = i / pJ, c = i - r * pJ;
+                sJ[i] = J[(size_t)lk_reflect101(iny + r, lh) * jstep + lk_reflect101(inx + c, lw)];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            fa = __fsub_rn(fx, (float)inx); fb = __fsub_rn(fy, (float)iny);
+            iw00 = __float2int_rn(__fmul_rn(__fmul_rn(__fsub_rn(1.f, fa), __fsub_rn(1.f, fb)), (float)(1 << W_BITS)));
+            iw01 = __float2int_rn(__fmul_rn(__fmul_rn(fa, __fsub_rn(1.f, fb)), (float)(1 << W_BITS)));
+            iw10 = __float2int_rn(__fmul_rn(__fmul_rn(__fsub_rn(1.f, fa), fb), (float)(1 << W_BITS)));
+            iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+            int se = 0;
+#pragma unroll
+            for (int k = 0; k < LK_WPL; k++) {
+                const int i = lane + 64 * k;
+                if (i < ww) {
+                    const int y = i / win, x = i - y * win;
+                    const uint8_t* q = sJ + y * pJ + x;
+                    const int diff = ((q[0] * iw00 + q[1] * iw01 + q[pJ] * iw10 + q[pJ + 1] * iw11 + (1 << (W_BITS - 6))) >> (W_BITS - 5)) - Ip[k];
+                    se += diff < 0 ? -diff : diff;
+                }
+            }
+            errv = __fmul_rn((float)lk_wave_sum64(se), 1.f / (float)(32 * win * win));
+        }
+    }
+    if (lane == 0) {
+        np_[0] = outx; np_[1] = outy;
+        a.status[(size_t)b * a.cap + pi] = (uint8_t)status;
+        if (a.err) a.err[(size_t)b * a.cap + pi] = errv;
+    }
+}
+
+}  // namespace myslam_hip
+
+using namespace myslam_hip;
+
+struct myslam_lk {
+    hipStream_t stream = nullptr;
+    int win = 11, max_level = 3, max_iters = 30; float eps = 0.01f, min_eig = 1e-4f;
+    int rows = 0, cols = 0, batchCap = 0;
+    LkGeom g{};
+    uint8_t *d_pyrP = nullptr, *d_pyrN = nullptr;
+    // host-entry staging
+    uint8_t* d_img = nullptr; size_t imgBytes = 0; float* d_pts = nullptr; uint8_t* d_st = nullptr; int ptsCap = 0;
+};
+
+static int lk_plan(myslam_lk* h, int rows, int cols) {
+    LkGeom g{};
+    g.w[0] = cols; g.h[0] = rows; g.off[0] = 0; g.bytes = 0; g.levels = 0;
+    int w = cols, hh = rows;
+    for (int l = 0; l <= h->max_level; l++) {        // buildOpticalFlowPyramid: stop when the NEXT level would not exceed the window
+        if (l > 0) {
+            g.w[l] = (g.w[l - 1] + 1) / 2; g.h[l] = (g.h[l - 1] + 1) / 2;
+            g.off[l] = g.bytes; g.bytes += ((size_t)g.w[l] * g.h[l] + 255) & ~(size_t)255;
+        }
+        g.levels = l;
+        w = (w + 1) / 2; hh = (hh + 1) / 2;
+        if (w <= h->win || hh <= h->win) break;
+    }
+    h->g = g; h->rows = rows; h->cols = cols; h->batchCap = 0;
+    return MYSLAM_OK;
+}
+
+static int lk_ensure(myslam_lk* h, int batch, int rows, int cols) {
+    if (rows != h->rows || cols != h->cols) { MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream)); lk_plan(h, rows, cols); }
+    if (batch > h->batchCap) {
+        MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (h->d_pyrP) (void)hipFree(h->d_pyrP);
+        if (h->d_pyrN) (void)hipFree(h->d_pyrN);
+        h->d_pyrP = h->d_pyrN = nullptr;
+        const size_t nb = std::max<size_t>(256, (size_t)batch * h->g.bytes);
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_pyrP, nb));
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_pyrN, nb));
+        h->batchCap = batch;
+    }
+    return MYSLAM_OK;
+}
+
+static int lk_run(myslam_lk* h, const uint8_t* d_prev, const uint8_t* d_next, int batch, int rows, int cols, int pstep, int nstep,
+                  size_t pstride, size_t nstride, const float* d_prev_pts, float* d_next_pts, const int32_t* d_counts, int n_fixed, int cap,
+                  uint8_t* d_status, float* d_err) {
+    int rc = lk_ensure(h, batch, rows, cols);
+    if (rc) return rc;
+    hipStream_t s = h->stream;
+    const LkGeom& g = h->g;
+    for (int which = 0; which < 2; which++) {
+        const uint8_t* src0 = which ? d_next : d_prev; uint8_t* pyr = which ? h->d_pyrN : h->d_pyrP;
+        for (int l = 1; l <= g.levels; l++) {
+            const uint8_t* src = (l == 1) ? src0 : pyr + g.off[l - 1];
+            const int sstep = (l == 1) ? (which ? nstep : pstep) : g.w[l - 1];
+            const size_t sstride = (l == 1) ? (which ? nstride : pstride) : g.bytes;
+            hipLaunchKernelGGL(k_pyr_down, dim3((g.w[l] + 63) / 64, (g.h[l] + 3) / 4, batch), dim3(256), 0, s, src, g.w[l - 1], g.h[l - 1], sstep, sstride,
+                               pyr + g.off[l], g.w[l], g.h[l], g.bytes);
+        }
+    }
+    LkArgs a{d_prev, d_next, rows, cols, pstep, nstep, pstride, nstride, h->d_pyrP, h->d_pyrN, g, d_prev_pts, d_next_pts, d_counts, n_fixed, cap,
+             h->win, h->max_iters, h->eps * h->eps, h->min_eig, d_status, d_err};
+    hipLaunchKernelGGL(k_lk_track, dim3((cap + 3) / 4, batch), dim3(256), 0, s, a);
+    MYSLAM_HIP_CHECK(hipGetLastError());
+    return MYSLAM_OK;
+}
+
+extern "C" {
+
+int myslam_lk_create(myslam_lk** out, int win, int max_level, int max_iters, float eps, float min_eig_threshold) {
+    if (!out || win < 3 || win > LK_MAXWIN || (win & 1) == 0 || max_level < 0 || max_level > LK_MAXL || max_iters < 1 || !(eps >= 0)) return MYSLAM_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MYSLAM_ERR_HIP;
+    myslam_lk* h = new myslam_lk();
+    h->win = win; h->max_level = max_level; h->max_iters = max_iters; h->eps = eps; h->min_eig = min_eig_threshold;
+    *out = h;
+    return MYSLAM_OK;
+}
+
+int myslam_lk_destroy(myslam_lk* h) {
+    if (!h) return MYSLAM_ERR_INVALID;
+    (void)hipStreamSynchronize(h->stream);
+    void* ptrs[] = {h->d_pyrP, h->d_pyrN, h->d_img, h->d_pts, h->d_st};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    delete h;
+    return MYSLAM_OK;
+}
+
+int myslam_lk_set_stream(myslam_lk* h, void* s) {
+    if (!h) return MYSLAM_ERR_INVALID;
+    h->stream = (hipStream_t)s;
+    return MYSLAM_OK;
+}
+
+int myslam_lk_track_batch(myslam_lk* h, const uint8_t* d_prev, const uint8_t* d_next, int batch, int rows, int cols, int step, size_t stride,
+                          const float* d_prev_pts, float* d_next_pts, const int32_t* d_counts, int cap, uint8_t* d_status, float* d_err) {
+    if (!h || !d_prev || !d_next || batch < 1 || rows < 1 || cols < 1 || step < cols || !d_prev_pts || !d_next_pts || !d_counts || cap < 1 || !d_status)
+        return MYSLAM_ERR_INVALID;
+    return lk_run(h, d_prev, d_next, batch, rows, cols, step, step, stride, stride, d_prev_pts, d_next_pts, d_counts, 0, cap, d_status, d_err);
+}
+
+int myslam_lk_track(myslam_lk* h, const uint8_t* prev, const uint8_t* next, int rows, int cols, int prev_step, int next_step,
+                    const float* prev_pts, float* next_pts, int n, uint8_t* status, float* err) {
+    if (!h || n < 0 || (n > 0 && (!prev_pts || !next_pts || !status))) return MYSLAM_ERR_INVALID;
+    if (n == 0) return MYSLAM_OK;
+    if (!prev || !next || rows < 1 || cols < 1 || prev_step < cols || next_step < cols) return MYSLAM_ERR_INVALID;
+    const size_t ib = (size_t)rows * cols;
+    if (2 * ib > h->imgBytes) {
+        if (h->d_img) (void)hipFree(h->d_img);
+        h->d_img = nullptr; h->imgBytes = 0;
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_img, 2 * ib)); h->imgBytes = 2 * ib;
+    }
+    if (n > h->ptsCap) {
+        if (h->d_pts) (void)hipFree(h->d_pts);
+        if (h->d_st) (void)hipFree(h->d_st);
+        h->d_pts = nullptr; h->d_st = nullptr; h->ptsCap = 0;
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_pts, sizeof(float) * 5 * (size_t)n)); MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_st, (size_t)n));
+        h->ptsCap = n;
+    }
+    hipStream_t s = h->stream;
+    MYSLAM_HIP_CHECK(hipMemcpy2DAsync(h->d_img, cols, prev, prev_step, cols, rows, hipMemcpyHostToDevice, s));
+    MYSLAM_HIP_CHECK(hipMemcpy2DAsync(h->d_img + ib, cols, next, next_step, cols, rows, hipMemcpyHostToDevice, s));
+    float* d_pp = h->d_pts; float* d_np = d_pp + 2 * (size_t)h->ptsCap; float* d_err = d_np + 2 * (size_t)h->ptsCap;
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(d_pp, prev_pts, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(d_np, next_pts, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
+    int rc = lk_run(h, h->d_img, h->d_img + ib, 1, rows, cols, cols, cols, ib, ib, d_pp, d_np, nullptr, n, n, h->d_st, d_err);
+    if (rc) return rc;
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(next_pts, d_np, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, s));
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(status, h->d_st, n, hipMemcpyDeviceToHost, s));
+    if (err) MYSLAM_HIP_CHECK(hipMemcpyAsync(err, d_err, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    return MYSLAM_OK;
+}
+
+}  // extern "C"

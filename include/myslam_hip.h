@@ -231,6 +231,27 @@ int myslam_ba_optimize_active_map_batch(double* d_poses, double* d_points, const
                                         double chi2_th, int max_rounds, int iters_per_round, double* d_scratch, double* d_edge_chi2,
                                         uint8_t* d_outlier, int32_t* d_rounds, int32_t* d_n_outliers, int32_t* d_status, void* hip_stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Pyramidal Lucas-Kanade tracker — replaces
+ *   cv::calcOpticalFlowPyrLK(prev, next, prevPts, nextPts, status, err, Size(win,win), max_level,
+ *                            TermCriteria(COUNT+EPS, max_iters, eps), OPTFLOW_USE_INITIAL_FLOW)
+ * as called by Frontend::TrackLastFrame (src/frontend.cpp:150-153) and Frontend::FindFeaturesInRight (:358-361) with
+ * win 11, max_level 3, max_iters 30, eps 0.01 (minEigThreshold = OpenCV's default 1e-4).   [SURVEY.md §8(f) rank 1]
+ * next_pts is in/out: the initial flow on entry (the reference always passes one), the tracked positions on return;
+ * status[i] = 1 where the flow was found; err[i] (optional) = mean absolute patch difference / 32 at level 0.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct myslam_lk myslam_lk;
+int myslam_lk_create(myslam_lk** out, int win, int max_level, int max_iters, float eps, float min_eig_threshold);
+int myslam_lk_destroy(myslam_lk* h);
+int myslam_lk_set_stream(myslam_lk* h, void* hip_stream);
+/* host pointers (uploads, runs, downloads, synchronises); pts = n x (x, y) float */
+int myslam_lk_track(myslam_lk* h, const uint8_t* prev, const uint8_t* next, int rows, int cols, int prev_step, int next_step,
+                    const float* prev_pts, float* next_pts, int n, uint8_t* status, float* err);
+/* device pointers, asynchronous on the handle's stream: `batch` image pairs (image b at base + b*stride), points of pair b at
+ * pts + b*cap*2, d_counts[b] of them valid; d_status batch x cap, d_err batch x cap or NULL */
+int myslam_lk_track_batch(myslam_lk* h, const uint8_t* d_prev, const uint8_t* d_next, int batch, int rows, int cols, int step, size_t stride,
+                          const float* d_prev_pts, float* d_next_pts, const int32_t* d_counts, int cap, uint8_t* d_status, float* d_err);
+
 #ifdef __cplusplus
 }
 #endif

@@ -139,6 +139,12 @@ int orc_ba_optimize_active_map(double* poses, int nposes, double* points, int np
                                double* edge_chi2, uint8_t* outlier, int* rounds, int* n_outliers);
 void orc_se3_exp(const double* xi6, double* q_t7);
 
+/* ---- pyramidal LK tracker (cv::calcOpticalFlowPyrLK as called at frontend.cpp:150-153, 358-361; lk_oracle.cpp) ---- */
+int orc_pyr_down(const uint8_t* src, int w, int h, int sstep, uint8_t* dst, int dstep);
+int orc_lk_track(const uint8_t* prev, const uint8_t* next, int rows, int cols, int pstep, int nstep,
+                 const float* prev_pts, float* next_pts, int n, int win, int max_level, int max_iters, float eps,
+                 float min_eig_threshold, uint8_t* status, float* err);
+
 #ifdef __cplusplus
 }
 #endif

@@ -337,6 +337,23 @@ class Oracle:
         assert rc == 0, rc
         return sec.value
 
+    # ---- LK tracker ----
+    def pyr_down(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        out = np.zeros(((h + 1) // 2, (w + 1) // 2), np.uint8)
+        assert self.lib.orc_pyr_down(_p(img), w, h, img.strides[0], _p(out), out.strides[0]) == 0
+        return out
+
+    def lk_track(self, prev, nxt, prev_pts, next_pts, win=11, max_level=3, max_iters=30, eps=0.01, min_eig=1e-4):
+        prev = np.ascontiguousarray(prev, np.uint8); nxt = np.ascontiguousarray(nxt, np.uint8)
+        pp = np.ascontiguousarray(prev_pts, np.float32).reshape(-1, 2); npts = np.ascontiguousarray(next_pts, np.float32).reshape(-1, 2).copy()
+        n = len(pp); st = np.zeros(n, np.uint8); err = np.zeros(n, np.float32)
+        rc = self.lib.orc_lk_track(_p(prev), _p(nxt), prev.shape[0], prev.shape[1], prev.strides[0], nxt.strides[0], _p(pp), _p(npts), n,
+                                   win, max_level, max_iters, C.c_float(eps), C.c_float(min_eig), _p(st), _p(err))
+        assert rc >= 0, rc
+        return npts, st.astype(bool), err
+
     def se3_exp(self, xi):
         xi = np.ascontiguousarray(xi, np.float64); out = np.zeros(7)
         self.lib.orc_se3_exp(_p(xi), _p(out))

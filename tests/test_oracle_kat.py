@@ -475,3 +475,32 @@ def test_ba_lm_converges(oracle, synth):
     p2, x2, chi, it = oracle.ba_optimize(poses, pts, ep, el, obs, fixed, K, iters=10)
     assert it >= 1 and chi < 0.5 * chi0
     assert chi / len(ep) < 2.0                                              # ~ noise level (sigma 0.5 px -> E[e2] = 0.5)
+
+
+def test_pyr_down_matches_scipy(oracle, synth):
+    from scipy.ndimage import correlate1d
+    for (h, w) in ((37, 52), (64, 64), (5, 9)):
+        img = synth.random_image(40 + h, h, w)
+        k = np.array([1, 4, 6, 4, 1])
+        t = correlate1d(correlate1d(img.astype(np.int64), k, axis=1, mode="mirror"), k, axis=0, mode="mirror")     # mirror == REFLECT_101
+        ref = ((t[::2, ::2] + 128) >> 8).astype(np.uint8)
+        assert np.array_equal(oracle.pyr_down(img), ref)
+
+
+def test_lk_recovers_subpixel_translation(oracle, synth):
+    from scipy.ndimage import gaussian_filter, shift
+    rng = np.random.default_rng(3)
+    base = gaussian_filter(rng.uniform(0, 255, (200, 260)), 2.0)
+    base = (base - base.min()) / (base.max() - base.min()) * 255
+    a = np.clip(base, 0, 255).astype(np.uint8)
+    dx, dy = 3.3, -1.7
+    b = np.clip(shift(base, (dy, dx), order=3, mode="nearest"), 0, 255).astype(np.uint8)
+    pts = rng.uniform([40, 40], [220, 160], size=(60, 2)).astype(np.float32)
+    out, st, err = oracle.lk_track(a, b, pts, pts)
+    assert st.all()
+    d = out - pts
+    assert np.abs(d[:, 0] - dx).max() < 0.15 and np.abs(d[:, 1] - dy).max() < 0.15
+    # flat image: the minimum-eigenvalue test rejects every point
+    flat = np.full((100, 120), 90, np.uint8)
+    _, st2, _ = oracle.lk_track(flat, flat, pts[:10] / 2, pts[:10] / 2)
+    assert not st2.any()
