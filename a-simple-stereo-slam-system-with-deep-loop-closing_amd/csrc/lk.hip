@@ -3,7 +3,7 @@
 //                            TermCriteria(COUNT+EPS, 30, 0.01), OPTFLOW_USE_INITIAL_FLOW)
 // in Frontend::TrackLastFrame (src/frontend.cpp:150-153) and Frontend::FindFeaturesInRight (:358-361)  [SURVEY.md §8(f) rank 1].
 //
-// Arithmetic (OpenCV lkpyramid.cpp, restated in oracle/lk_oracle.cpp): pyrDown 5x5 [1 4 6 4 1]/16 REFLECT_101, 3x3 Scharr
+// Arithmetic (OpenCV lkpyramid.cpp, restated by the test oracle): pyrDown 5x5 [1 4 6 4 1]/16 REFLECT_101, 3x3 Scharr
 // derivatives as shorts (zero outside the image), W_BITS = 14 fixed-point bilinear patch extraction, 2x2 normal equations.
 // The window sums are exact integer sums converted to float once (the restatement's definition), so the tracker is bit-exact
 // against the oracle; every float expression uses explicit non-fused IEEE operations.
