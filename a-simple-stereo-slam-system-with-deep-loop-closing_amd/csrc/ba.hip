@@ -821,6 +821,209 @@ static int ba_opt_launch(const BaOptArgs& a, int nwin, hipStream_t s) {
     return MYSLAM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pose-only optimisation of the current frame: Frontend::EstimateCurrentPose, src/frontend.cpp:176-276 [SURVEY.md §8(f) rank 1].
+// One VertexPose, one EdgeProjectionPoseOnly (g2o_types.h:62-100) per tracked feature with a map point, Huber(delta = 1),
+// g2o Levenberg + dense 6x6 solve; `rounds` x { optimize(iters) over the level-0 edges; classify every edge by chi2() > chi2_th
+// (excluded edges are re-evaluated at the new estimate first), exclude / re-admit }; the robust kernel goes after round rounds-2.
+// One 512-thread block per frame; every thread owns edges t, t+512, ... (level, last chi2 and outlier flag live in registers).
+// ------------------------------------------------------------------------------------------------
+constexpr int PO_EPT = 8;                                  // edges per thread -> at most 4096 edges per frame
+
+struct PoseOnlyArgs {
+    double* poses; const double* pts3d; const double* obs; const int32_t* counts; int n_fixed, cap;
+    double fx, fy, cx, cy, chi2_th; int rounds, iters;
+    uint8_t* outlier; int32_t* n_inliers; int32_t* status;
+};
+
+__global__ __launch_bounds__(BA_NT) void k_pose_only(PoseOnlyArgs a) {
+    __shared__ double s_red[BA_NW];
+    __shared__ double sT[12], sTb[12], sH[27], sx[6], s_part[BA_NW][27];
+    __shared__ double s_sc[4];          // [0] lambda [1] ni [2] ok
+    const int f = blockIdx.x, t = threadIdx.x, wv = t >> 6, lane = t & 63;
+    const int n = a.counts ? a.counts[f] : a.n_fixed;
+    const double* P3 = a.pts3d + (size_t)f * a.cap * 3;
+    const double* Z2 = a.obs + (size_t)f * a.cap * 2;
+    double* pose = a.poses + (size_t)f * 7;
+    if (n > PO_EPT * BA_NT) { if (t == 0) { a.status[f] = MYSLAM_ERR_CAPACITY; a.n_inliers[f] = 0; } return; }
+    if (t == 0) {
+        double x = pose[0], y = pose[1], z = pose[2], q = pose[3];
+        const double nn = sqrt(x * x + y * y + z * z + q * q);
+        x /= nn; y /= nn; z /= nn; q /= nn;
+        sT[0] = 1 - 2 * (y * y + z * z); sT[1] = 2 * (x * y - z * q);     sT[2] = 2 * (x * z + y * q);
+        sT[3] = 2 * (x * y + z * q);     sT[4] = 1 - 2 * (x * x + z * z); sT[5] = 2 * (y * z - x * q);
+        sT[6] = 2 * (x * z - y * q);     sT[7] = 2 * (y * z + x * q);     sT[8] = 1 - 2 * (x * x + y * y);
+        sT[9] = pose[4]; sT[10] = pose[5]; sT[11] = pose[6];
+    }
+    __syncthreads();
+    unsigned level = 0, outl = 0;                          // bit k <-> edge t + k*BA_NT
+    double echi[PO_EPT];
+#pragma unroll
+    for (int k = 0; k < PO_EPT; k++) echi[k] = 0.0;
+    bool robust = true;
+    // e = z - (K (T p)) / (K (T p)).z  (g2o_types.h:71-75)
+    auto edge_err = [&](int i, double& e0, double& e1, double* pc) {
+        const double px = P3[3 * i], py = P3[3 * i + 1], pz = P3[3 * i + 2];
+        pc[0] = sT[0] * px + sT[1] * py + sT[2] * pz + sT[9];
+        pc[1] = sT[3] * px + sT[4] * py + sT[5] * pz + sT[10];
+        pc[2] = sT[6] * px + sT[7] * py + sT[8] * pz + sT[11];
+        const double u = a.fx * pc[0] + 0.0 * pc[1] + a.cx * pc[2], v = 0.0 * pc[0] + a.fy * pc[1] + a.cy * pc[2];
+        e0 = Z2[2 * i] - u / pc[2]; e1 = Z2[2 * i + 1] - v / pc[2];
+    };
+    auto active_chi2 = [&]() -> double {                   // computeActiveErrors + activeRobustChi2
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < PO_EPT; k++) {
+            const int i = t + k * BA_NT;
+            if (i < n && !((level >> k) & 1)) {
+                double e0, e1, pc[3];
+                edge_err(i, e0, e1, pc);
+                const double e2 = e0 * e0 + e1 * e1;
+                echi[k] = e2;
+                s += (!robust || e2 <= 1.0) ? e2 : 2 * sqrt(e2) - 1.0;
+            }
+        }
+        return block_sum(s, s_red);
+    };
+    int cntOut = 0;
+    for (int round = 0; round < a.rounds; round++) {
+        double na = 0;
+#pragma unroll
+        for (int k = 0; k < PO_EPT; k++) na += (t + k * BA_NT < n && !((level >> k) & 1)) ? 1.0 : 0.0;
+        const int nact = (int)block_sum(na, s_red);
+        if (nact > 0) {
+            for (int it = 0; it < a.iters; it++) {
+                double currentChi = active_chi2();
+                // ---- H (upper triangle, 21) and b (6) ----
+                double h[27];
+#pragma unroll
+                for (int u = 0; u < 27; u++) h[u] = 0.0;
+#pragma unroll
+                for (int k = 0; k < PO_EPT; k++) {
+                    const int i = t + k * BA_NT;
+                    if (i < n && !((level >> k) & 1)) {
+                        double e0, e1, pc[3];
+                        edge_err(i, e0, e1, pc);
+                        const double X = pc[0], Y = pc[1], Zc = pc[2], Zinv = 1.0 / (Zc + 1e-18), Zinv2 = Zinv * Zinv;      // g2o_types.h:79-92
+                        const double J[12] = {-a.fx * Zinv, 0, a.fx * X * Zinv2, a.fx * X * Y * Zinv2, -a.fx - a.fx * X * X * Zinv2, a.fx * Y * Zinv,
+                                              0, -a.fy * Zinv, a.fy * Y * Zinv2, a.fy + a.fy * Y * Y * Zinv2, -a.fy * X * Y * Zinv2, -a.fy * X * Zinv};
+                        const double e2 = e0 * e0 + e1 * e1;
+                        const double w = (!robust || e2 <= 1.0) ? 1.0 : 1.0 / sqrt(e2);
+                        int u = 0;
+#pragma unroll
+                        for (int r = 0; r < 6; r++) {
+#pragma unroll
+                            for (int c = r; c < 6; c++) h[u++] += w * (J[r] * J[c] + J[6 + r] * J[6 + c]);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 6; r++) h[21 + r] += -w * (J[r] * e0 + J[6 + r] * e1);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 27; u++) h[u] = wave_sum_lane63(h[u]);
+                if (lane == 63) {
+#pragma unroll
+                    for (int u = 0; u < 27; u++) s_part[wv][u] = h[u];
+                }
+                __syncthreads();
+                if (t < 27) { double s = 0; for (int w2 = 0; w2 < BA_NW; w2++) s += s_part[w2][t]; sH[t] = s; }
+                __syncthreads();
+                if (it == 0 && t == 0) {
+                    double mx = 0;
+                    for (int r = 0; r < 6; r++) mx = fmax(mx, fabs(sH[r * 6 - r * (r - 1) / 2]));
+                    s_sc[0] = 1e-5 * mx; s_sc[1] = 2.0;
+                }
+                __syncthreads();
+                double rho = 0; int qmax = 0;
+                do {
+                    const double lambda = s_sc[0];
+                    if (t < 12) sTb[t] = sT[t];
+                    if (t == 0) {                              // (H + lambda I) x = b, dense Cholesky (LinearSolverDense)
+                        double A[36], x[6];
+#pragma unroll
+                        for (int r = 0; r < 6; r++)
+#pragma unroll
+                            for (int c = 0; c < 6; c++) { const int rr = min(r, c), cc = max(r, c); A[r * 6 + c] = sH[rr * 6 - rr * (rr - 1) / 2 + (cc - rr)] + (r == c ? lambda : 0.0); }
+                        bool ok = true;
+#pragma unroll
+                        for (int j = 0; j < 6; j++) {
+                            double d = A[j * 6 + j];
+#pragma unroll
+                            for (int k2 = 0; k2 < j; k2++) d -= A[j * 6 + k2] * A[j * 6 + k2];
+                            if (!(d > 0)) { ok = false; d = 1.0; }
+                            A[j * 6 + j] = sqrt(d);
+#pragma unroll
+                            for (int i2 = j + 1; i2 < 6; i2++) {
+                                double v = A[i2 * 6 + j];
+#pragma unroll
+                                for (int k2 = 0; k2 < j; k2++) v -= A[i2 * 6 + k2] * A[j * 6 + k2];
+                                A[i2 * 6 + j] = v / A[j * 6 + j];
+                            }
+                        }
+#pragma unroll
+                        for (int i2 = 0; i2 < 6; i2++) { double v = sH[21 + i2]; for (int k2 = 0; k2 < i2; k2++) v -= A[i2 * 6 + k2] * x[k2]; x[i2] = v / A[i2 * 7]; }
+#pragma unroll
+                        for (int i2 = 5; i2 >= 0; i2--) { double v = x[i2]; for (int k2 = i2 + 1; k2 < 6; k2++) v -= A[k2 * 6 + i2] * x[k2]; x[i2] = v / A[i2 * 7]; }
+#pragma unroll
+                        for (int i2 = 0; i2 < 6; i2++) sx[i2] = x[i2];
+                        s_sc[2] = ok ? 1.0 : 0.0;
+                    }
+                    __syncthreads();
+                    const bool ok = s_sc[2] != 0.0;
+                    if (ok && t == 0) pose_oplus(sT, sx);
+                    __syncthreads();
+                    const double tempChi = ok ? active_chi2() : 1e300;
+                    double scale = 1e-3;
+                    if (ok) for (int r = 0; r < 6; r++) scale += sx[r] * (lambda * sx[r] + sH[21 + r]);
+                    rho = (currentChi - tempChi) / scale;
+                    __syncthreads();
+                    if (rho > 0 && isfinite(tempChi) && ok) {
+                        if (t == 0) {
+                            double alpha = 1. - pow(2 * rho - 1, 3);
+                            alpha = fmin(alpha, 2. / 3.);
+                            s_sc[0] = lambda * fmax(1. / 3., alpha); s_sc[1] = 2.0;
+                        }
+                        currentChi = tempChi;
+                    } else {
+                        if (t == 0) { s_sc[0] = lambda * s_sc[1]; s_sc[1] *= 2.0; }
+                        if (t < 12) sT[t] = sTb[t];
+                    }
+                    __syncthreads();
+                    qmax++;
+                } while (rho < 0 && qmax < 10 && isfinite(s_sc[0]));
+                if (qmax == 10 || rho == 0 || !isfinite(s_sc[0])) break;
+            }
+        }
+        // ---- classify every edge (frontend.cpp:229-242) ----
+        double co = 0;
+#pragma unroll
+        for (int k = 0; k < PO_EPT; k++) {
+            const int i = t + k * BA_NT;
+            if (i < n) {
+                if ((outl >> k) & 1) { double e0, e1, pc[3]; edge_err(i, e0, e1, pc); echi[k] = e0 * e0 + e1 * e1; }
+                if (echi[k] > a.chi2_th) { outl |= 1u << k; level |= 1u << k; co += 1.0; }
+                else { outl &= ~(1u << k); level &= ~(1u << k); }
+            }
+        }
+        cntOut = (int)block_sum(co, s_red);
+        if (round == a.rounds - 2) robust = false;            // :244-246
+    }
+    // ---- write back ----
+#pragma unroll
+    for (int k = 0; k < PO_EPT; k++) { const int i = t + k * BA_NT; if (i < n) a.outlier[(size_t)f * a.cap + i] = (outl >> k) & 1; }
+    if (t == 0) {
+        const double* R = sT;
+        const double tr = R[0] + R[4] + R[8];
+        double x, y, z, q;
+        if (tr > 0) { const double s = sqrt(tr + 1.0) * 2; q = 0.25 * s; x = (R[7] - R[5]) / s; y = (R[2] - R[6]) / s; z = (R[3] - R[1]) / s; }
+        else if (R[0] > R[4] && R[0] > R[8]) { const double s = sqrt(1.0 + R[0] - R[4] - R[8]) * 2; x = 0.25 * s; q = (R[7] - R[5]) / s; y = (R[1] + R[3]) / s; z = (R[2] + R[6]) / s; }
+        else if (R[4] > R[8]) { const double s = sqrt(1.0 + R[4] - R[0] - R[8]) * 2; y = 0.25 * s; q = (R[2] - R[6]) / s; x = (R[1] + R[3]) / s; z = (R[5] + R[7]) / s; }
+        else { const double s = sqrt(1.0 + R[8] - R[0] - R[4]) * 2; z = 0.25 * s; q = (R[3] - R[1]) / s; x = (R[2] + R[6]) / s; y = (R[5] + R[7]) / s; }
+        pose[0] = x; pose[1] = y; pose[2] = z; pose[3] = q; pose[4] = R[9]; pose[5] = R[10]; pose[6] = R[11];
+        a.n_inliers[f] = n - cntOut; a.status[f] = MYSLAM_OK;
+    }
+}
+
 static size_t ba_lds(int maxP, int maxL) { return sizeof(double) * ((size_t)maxP * 39 + (size_t)maxL * 9); }
 
 static int ba_launch(const BaArgs& a, int nwin, hipStream_t s) {
@@ -990,6 +1193,45 @@ int myslam_ba_optimize_active_map(double* poses, int nposes, double* points, int
     if (rounds) *rounds = st[1];
     if (n_outliers) *n_outliers = st[2];
     return st[0];
+}
+
+int myslam_pose_only_optimize_batch(double* d_poses, const double* d_pts3d, const double* d_obs, const int32_t* d_counts, int batch, int cap,
+                                    double fx, double fy, double cx, double cy, double chi2_th, int rounds, int iters,
+                                    uint8_t* d_outlier, int32_t* d_n_inliers, int32_t* d_status, void* hip_stream) {
+    if (!d_poses || !d_pts3d || !d_obs || !d_counts || batch < 1 || cap < 1 || rounds < 1 || iters < 1 || !d_outlier || !d_n_inliers || !d_status)
+        return MYSLAM_ERR_INVALID;
+    PoseOnlyArgs a{d_poses, d_pts3d, d_obs, d_counts, 0, cap, fx, fy, cx, cy, chi2_th, rounds, iters, d_outlier, d_n_inliers, d_status};
+    ScopedProf sp(P_BA, (hipStream_t)hip_stream);
+    hipLaunchKernelGGL(k_pose_only, dim3(batch), dim3(BA_NT), 0, (hipStream_t)hip_stream, a);
+    MYSLAM_HIP_CHECK(hipGetLastError());
+    return MYSLAM_OK;
+}
+
+int myslam_pose_only_optimize(double* pose7, const double* pts3d, const double* obs, int n, double fx, double fy, double cx, double cy,
+                              double chi2_th, int rounds, int iters, uint8_t* outlier, int* n_inliers) {
+    if (!pose7 || n < 0 || (n > 0 && (!pts3d || !obs || !outlier)) || rounds < 1 || iters < 1) return MYSLAM_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MYSLAM_ERR_HIP;
+    const int m = n > 0 ? n : 1;
+    double *d_p = nullptr, *d_x = nullptr, *d_o = nullptr; uint8_t* d_out = nullptr; int32_t* d_i = nullptr;
+    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_p, sizeof(double) * 7)); MYSLAM_HIP_CHECK(hipMalloc((void**)&d_x, sizeof(double) * 3 * m));
+    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_o, sizeof(double) * 2 * m)); MYSLAM_HIP_CHECK(hipMalloc((void**)&d_out, m));
+    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_i, sizeof(int32_t) * 2));
+    MYSLAM_HIP_CHECK(hipMemcpy(d_p, pose7, sizeof(double) * 7, hipMemcpyHostToDevice));
+    if (n) {
+        MYSLAM_HIP_CHECK(hipMemcpy(d_x, pts3d, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
+        MYSLAM_HIP_CHECK(hipMemcpy(d_o, obs, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
+    }
+    PoseOnlyArgs a{d_p, d_x, d_o, nullptr, n, m, fx, fy, cx, cy, chi2_th, rounds, iters, d_out, d_i, d_i + 1};
+    hipLaunchKernelGGL(k_pose_only, dim3(1), dim3(BA_NT), 0, nullptr, a);
+    MYSLAM_HIP_CHECK(hipGetLastError());
+    int32_t st[2];
+    MYSLAM_HIP_CHECK(hipMemcpy(st, d_i, sizeof(st), hipMemcpyDeviceToHost));
+    MYSLAM_HIP_CHECK(hipMemcpy(pose7, d_p, sizeof(double) * 7, hipMemcpyDeviceToHost));
+    if (n) MYSLAM_HIP_CHECK(hipMemcpy(outlier, d_out, n, hipMemcpyDeviceToHost));
+    (void)hipFree(d_p); (void)hipFree(d_x); (void)hipFree(d_o); (void)hipFree(d_out); (void)hipFree(d_i);
+    if (n_inliers) *n_inliers = st[0];
+    return st[1];
 }
 
 }  // extern "C"

@@ -8,6 +8,8 @@
 //   myslam::triangulation  include/myslam/algorithm.h:16-33        (stereo rig form)
 //   myslam::LoopDatabase   LoopClosing::DetectLoop / AddToDatabase  src/loopclosing.cpp:124-161, 651-659
 //   myslam::LocalBA::{Build,Optimize,OptimizeActiveMap}  Backend::OptimizeActiveMap  src/backend.cpp:126-243
+//   myslam::PyrLKTracker::calcOpticalFlowPyrLK        cv::calcOpticalFlowPyrLK call sites        src/frontend.cpp:150-153, 358-361
+//   myslam::EstimateCurrentPose                       g2o stage of Frontend::EstimateCurrentPose src/frontend.cpp:176-276
 //
 // No OpenCV / Eigen / g2o: images are (data, rows, cols, step) views, cv::KeyPoint is the layout-compatible
 // myslam_keypoint, DescrVector is std::array<float,1064>.  Errors the reference reports by logging + return keep
@@ -219,5 +221,41 @@ struct LocalBA {               // flat-array form of the graph Backend::Optimize
         return nout;
     }
 };
+
+// cv::calcOpticalFlowPyrLK(prev, next, prevPts, nextPts, status, err, Size(11,11), 3, TermCriteria(COUNT+EPS,30,0.01),
+// OPTFLOW_USE_INITIAL_FLOW) as Frontend::TrackLastFrame / FindFeaturesInRight call it (src/frontend.cpp:150-153, 358-361)
+struct Point2f { float x, y; };
+class PyrLKTracker {
+    myslam_lk* h_ = nullptr;
+public:
+    explicit PyrLKTracker(int win = 11, int maxLevel = 3, int maxCount = 30, float epsilon = 0.01f, float minEigThreshold = 1e-4f) {
+        check(myslam_lk_create(&h_, win, maxLevel, maxCount, epsilon, minEigThreshold), "myslam_lk_create");
+    }
+    ~PyrLKTracker() { if (h_) myslam_lk_destroy(h_); }
+    PyrLKTracker(const PyrLKTracker&) = delete; PyrLKTracker& operator=(const PyrLKTracker&) = delete;
+    // nextPts carries the initial flow on entry (the reference always provides one)
+    void calcOpticalFlowPyrLK(const ImageView& prevImg, const ImageView& nextImg, const std::vector<Point2f>& prevPts,
+                              std::vector<Point2f>& nextPts, std::vector<uint8_t>& status, std::vector<float>& err) {
+        const int n = (int)prevPts.size();
+        if ((int)nextPts.size() != n) nextPts = prevPts;
+        status.assign(n, 0); err.assign(n, 0.f);
+        if (n == 0) return;
+        check(myslam_lk_track(h_, prevImg.data, nextImg.data, prevImg.rows, prevImg.cols, prevImg.step, nextImg.step,
+                              reinterpret_cast<const float*>(prevPts.data()), reinterpret_cast<float*>(nextPts.data()), n, status.data(), err.data()),
+              "myslam_lk_track");
+    }
+};
+
+// the g2o stage of Frontend::EstimateCurrentPose (src/frontend.cpp:176-276); returns features.size() - cntOutliers
+inline int EstimateCurrentPose(double pose_qt[7], const std::vector<double>& mapPoints /*n x 3*/, const std::vector<double>& pixels /*n x 2*/,
+                               double fx, double fy, double cx, double cy, std::vector<uint8_t>& isOutlier,
+                               double chi2_th = 5.991, int numIterations = 4, int optimizeIters = 10) {
+    const int n = (int)(mapPoints.size() / 3);
+    isOutlier.assign(n, 0);
+    int inl = 0;
+    check(myslam_pose_only_optimize(pose_qt, mapPoints.data(), pixels.data(), n, fx, fy, cx, cy, chi2_th, numIterations, optimizeIters,
+                                    n ? isOutlier.data() : nullptr, &inl), "myslam_pose_only_optimize");
+    return inl;
+}
 
 }  // namespace myslam

@@ -396,4 +396,124 @@ int orc_ba_optimize_active_map(double* poses, int nposes, double* points, int np
     return 0;
 }
 
+/* Frontend::EstimateCurrentPose, src/frontend.cpp:176-276: one VertexPose, one EdgeProjectionPoseOnly (g2o_types.h:62-100) per
+ * tracked feature that has a map point, Huber (default delta = 1), g2o Levenberg with a dense 6x6 solve; `rounds` (4) times
+ * { initializeOptimization(); optimize(iters = 10) } over the level-0 edges, then every edge is classified by chi2() > chi2_th
+ * (an edge that was excluded gets computeError() at the new estimate first, :231-233) and excluded / re-admitted for the next
+ * round (:234-241); after round rounds-2 the robust kernel is removed (:244-246).  chi2() of an ACTIVE edge is e^T e of the
+ * last error evaluation g2o made (the last Levenberg trial, accepted or not).  Third-party internals: PARITY UNPINNED. */
+int orc_pose_only_optimize(double* pose7, const double* pts3d, const double* obs, int n, double fx, double fy, double cx, double cy,
+                           double chi2_th, int rounds, int iters, uint8_t* outlier, int* n_inliers) {
+    if (!pose7 || n < 0 || (n > 0 && (!pts3d || !obs || !outlier)) || rounds < 1 || iters < 1) return -1;
+    Pose T;
+    quat_to_R(pose7, T.R);
+    for (int k = 0; k < 3; k++) T.t[k] = pose7[4 + k];
+    std::vector<uint8_t> level(n, 0);                 // 1 = excluded from the optimisation (e->setLevel(1))
+    std::vector<double> echi(n, 0.0);
+    for (int i = 0; i < n; i++) outlier[i] = 0;
+    bool robust = true;
+    // e = z - (K (T p)) / (K (T p)).z   (:71-75)
+    auto edge_err = [&](const Pose& P, int i, double* e) {
+        double pc[3];
+        for (int r = 0; r < 3; r++) pc[r] = P.R[r * 3] * pts3d[3 * i] + P.R[r * 3 + 1] * pts3d[3 * i + 1] + P.R[r * 3 + 2] * pts3d[3 * i + 2] + P.t[r];
+        const double u = fx * pc[0] + 0.0 * pc[1] + cx * pc[2], v = 0.0 * pc[0] + fy * pc[1] + cy * pc[2];
+        e[0] = obs[2 * i] - u / pc[2]; e[1] = obs[2 * i + 1] - v / pc[2];
+    };
+    auto active_chi2 = [&](const Pose& P) {            // computeActiveErrors + activeRobustChi2
+        double s = 0;
+        for (int i = 0; i < n; i++) {
+            if (level[i]) continue;
+            double e[2]; edge_err(P, i, e);
+            const double e2 = e[0] * e[0] + e[1] * e[1];
+            echi[i] = e2;
+            double r0 = e2, r1 = 1;
+            if (robust) huber(e2, 1.0, r0, r1);
+            s += r0;
+        }
+        return s;
+    };
+    int cntOut = 0;
+    for (int round = 0; round < rounds; round++) {
+        int nact = 0;
+        for (int i = 0; i < n; i++) nact += !level[i];
+        if (nact > 0) {
+            double lambda = 0, ni = 2;
+            for (int it = 0; it < iters; it++) {
+                double currentChi = active_chi2(T), tempChi = currentChi;
+                double H[36] = {0}, b[6] = {0};
+                for (int i = 0; i < n; i++) {
+                    if (level[i]) continue;
+                    double pc[3];
+                    for (int r = 0; r < 3; r++) pc[r] = T.R[r * 3] * pts3d[3 * i] + T.R[r * 3 + 1] * pts3d[3 * i + 1] + T.R[r * 3 + 2] * pts3d[3 * i + 2] + T.t[r];
+                    const double X = pc[0], Y = pc[1], Z = pc[2], Zinv = 1.0 / (Z + 1e-18), Zinv2 = Zinv * Zinv;     // :79-92
+                    const double J[12] = {-fx * Zinv, 0, fx * X * Zinv2, fx * X * Y * Zinv2, -fx - fx * X * X * Zinv2, fx * Y * Zinv,
+                                          0, -fy * Zinv, fy * Y * Zinv2, fy + fy * Y * Y * Zinv2, -fy * X * Y * Zinv2, -fy * X * Zinv};
+                    double e[2]; edge_err(T, i, e);
+                    double r0, w = 1;
+                    if (robust) huber(e[0] * e[0] + e[1] * e[1], 1.0, r0, w);
+                    for (int r = 0; r < 6; r++) {
+                        for (int c = 0; c < 6; c++) H[r * 6 + c] += w * (J[r] * J[c] + J[6 + r] * J[6 + c]);
+                        b[r] += -w * (J[r] * e[0] + J[6 + r] * e[1]);
+                    }
+                }
+                if (it == 0) {
+                    double mx = 0;
+                    for (int a = 0; a < 6; a++) mx = std::max(mx, fabs(H[a * 7]));
+                    lambda = 1e-5 * mx; ni = 2;
+                }
+                double rho = 0; int qmax = 0;
+                do {
+                    const Pose saved = T;
+                    double A[36], x[6];
+                    memcpy(A, H, sizeof(A));
+                    for (int a = 0; a < 6; a++) A[a * 7] += lambda;
+                    bool ok = true;                     // dense Cholesky solve (LinearSolverDense)
+                    for (int j = 0; j < 6 && ok; j++) {
+                        double d = A[j * 6 + j];
+                        for (int k2 = 0; k2 < j; k2++) d -= A[j * 6 + k2] * A[j * 6 + k2];
+                        if (!(d > 0)) { ok = false; break; }
+                        A[j * 6 + j] = sqrt(d);
+                        for (int i2 = j + 1; i2 < 6; i2++) {
+                            double v = A[i2 * 6 + j];
+                            for (int k2 = 0; k2 < j; k2++) v -= A[i2 * 6 + k2] * A[j * 6 + k2];
+                            A[i2 * 6 + j] = v / A[j * 6 + j];
+                        }
+                    }
+                    if (ok) {
+                        for (int i2 = 0; i2 < 6; i2++) { double v = b[i2]; for (int k2 = 0; k2 < i2; k2++) v -= A[i2 * 6 + k2] * x[k2]; x[i2] = v / A[i2 * 7]; }
+                        for (int i2 = 5; i2 >= 0; i2--) { double v = x[i2]; for (int k2 = i2 + 1; k2 < 6; k2++) v -= A[k2 * 6 + i2] * x[k2]; x[i2] = v / A[i2 * 7]; }
+                        pose_oplus(T, x);
+                        tempChi = active_chi2(T);
+                    } else tempChi = 1e300;
+                    rho = currentChi - tempChi;
+                    double scale = 1e-3;
+                    if (ok) for (int a = 0; a < 6; a++) scale += x[a] * (lambda * x[a] + b[a]);
+                    rho /= scale;
+                    if (rho > 0 && std::isfinite(tempChi) && ok) {
+                        double alpha = 1. - pow(2 * rho - 1, 3);
+                        alpha = std::min(alpha, 2. / 3.);
+                        lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi;
+                    } else {
+                        lambda *= ni; ni *= 2; T = saved;
+                        if (!std::isfinite(lambda)) break;
+                    }
+                    qmax++;
+                } while (rho < 0 && qmax < 10);
+                if (qmax == 10 || rho == 0 || !std::isfinite(lambda)) break;
+            }
+        }
+        cntOut = 0;
+        for (int i = 0; i < n; i++) {
+            if (outlier[i]) { double e[2]; edge_err(T, i, e); echi[i] = e[0] * e[0] + e[1] * e[1]; }      // :231-233
+            if (echi[i] > chi2_th) { outlier[i] = 1; level[i] = 1; cntOut++; }
+            else { outlier[i] = 0; level[i] = 0; }
+        }
+        if (round == rounds - 2) robust = false;                                                           // :244-246
+    }
+    R_to_quat(T.R, pose7);
+    for (int k2 = 0; k2 < 3; k2++) pose7[4 + k2] = T.t[k2];
+    if (n_inliers) *n_inliers = n - cntOut;
+    return 0;
+}
+
 }  // extern "C"

@@ -138,6 +138,9 @@ int orc_ba_optimize_active_map(double* poses, int nposes, double* points, int np
                                double chi2_th, int max_rounds, int iters_per_round,
                                double* edge_chi2, uint8_t* outlier, int* rounds, int* n_outliers);
 void orc_se3_exp(const double* xi6, double* q_t7);
+/* Frontend::EstimateCurrentPose (src/frontend.cpp:176-276): pose7 = (qx qy qz qw tx ty tz) Tcw in/out */
+int orc_pose_only_optimize(double* pose7, const double* pts3d, const double* obs, int n, double fx, double fy, double cx, double cy,
+                           double chi2_th, int rounds, int iters, uint8_t* outlier, int* n_inliers);
 
 /* ---- pyramidal LK tracker (cv::calcOpticalFlowPyrLK as called at frontend.cpp:150-153, 358-361; lk_oracle.cpp) ---- */
 int orc_pyr_down(const uint8_t* src, int w, int h, int sstep, uint8_t* dst, int dstep);

@@ -93,6 +93,25 @@ int main() {
         EXPECT(flagdiff == 0);
     }
 
+    // LK tracker: the image against itself shifted by 2 px
+    {
+        std::vector<uint8_t> img2(img.size());
+        for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) img2[(size_t)y * W + x] = img[(size_t)y * W + std::min(W - 1, x + 2)];
+        myslam::ImageView iv2{img2.data(), H, W, W};
+        std::vector<myslam::Point2f> p0, p1; std::vector<uint8_t> st; std::vector<float> er;
+        for (size_t i = 0; i < k0.size() && i < 150; i++) p0.push_back({k0[i].x, k0[i].y});
+        p1 = p0;
+        myslam::PyrLKTracker lk;
+        lk.calcOpticalFlowPyrLK(iv, iv2, p0, p1, st, er);
+        std::vector<float> r1(2 * p0.size()); std::vector<uint8_t> rs(p0.size()); std::vector<float> re(p0.size());
+        for (size_t i = 0; i < p0.size(); i++) { r1[2 * i] = p0[i].x; r1[2 * i + 1] = p0[i].y; }
+        EXPECT(orc_lk_track(img.data(), img2.data(), H, W, W, W, reinterpret_cast<const float*>(p0.data()), r1.data(), (int)p0.size(), 11, 3, 30, 0.01f, 1e-4f,
+                            rs.data(), re.data()) >= 0);
+        EXPECT(std::memcmp(r1.data(), p1.data(), sizeof(float) * r1.size()) == 0 && std::memcmp(rs.data(), st.data(), rs.size()) == 0);
+        int good = 0; for (size_t i = 0; i < p0.size(); i++) good += st[i] && std::fabs(p1[i].x - p0[i].x + 2.f) < 0.2f;
+        EXPECT(good > (int)p0.size() * 8 / 10);
+    }
+
     printf(fails ? "FACADE TEST FAILED (%d)\n" : "FACADE TEST OK (%d failures)\n", fails);
     return fails ? 1 : 0;
 }

@@ -1,0 +1,63 @@
+"""Frontend::EstimateCurrentPose's g2o stage (src/frontend.cpp:176-276) on the GPU vs the oracle restatement: f64, same algorithm,
+different summation order -> poses agree to ~1e-9, outlier decisions identical away from the chi2 threshold."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(synth, oracle, seed, n, n_bad, noise=0.5):
+    rng = np.random.default_rng(seed)
+    K = synth.KITTI00; Kt = (K["fx"], K["fy"], K["cx"], K["cy"])
+    pts = np.stack([rng.uniform(-10, 10, n), rng.uniform(-3, 3, n), rng.uniform(5, 40, n)], 1)
+    T = oracle.se3_exp(np.array([0.3, -0.1, 0.5, 0.01, -0.02, 0.015]) * rng.uniform(0.5, 1.5))
+    x, y, z, w = T[:4]
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    pc = pts @ R.T + T[4:]
+    obs = np.stack([Kt[0] * pc[:, 0] / pc[:, 2] + Kt[2], Kt[1] * pc[:, 1] / pc[:, 2] + Kt[3]], 1) + rng.normal(0, noise, (n, 2))
+    bad = rng.choice(n, n_bad, replace=False)
+    obs[bad] += rng.uniform(-60, 60, (n_bad, 2))
+    return np.array([0, 0, 0, 1, 0, 0, 0.0]), pts, obs, Kt, T
+
+
+@pytest.mark.parametrize("n,n_bad,seed", [(200, 20, 0), (37, 3, 1), (1500, 400, 2), (600, 0, 3)])
+def test_pose_only_matches_oracle(api, oracle, synth, n, n_bad, seed):
+    T0, pts, obs, Kt, Ttrue = _problem(synth, oracle, seed, n, n_bad)
+    gp, gout, gni = api.pose_only_optimize(T0, pts, obs, Kt)
+    rp, rout, rni = oracle.pose_only_optimize(T0, pts, obs, Kt)
+    assert np.allclose(gp, rp, rtol=1e-8, atol=1e-9)
+    assert gni == rni and np.array_equal(gout, rout)
+    assert np.abs(rp - Ttrue).max() < 0.02 and rout.sum() >= n_bad * 0.9          # it converged to the generating pose
+
+
+def test_pose_only_rounds_and_degenerate_inputs(api, oracle, synth):
+    T0, pts, obs, Kt, _ = _problem(synth, oracle, 7, 120, 30)
+    for rounds, iters in ((1, 10), (2, 3), (4, 1), (6, 10)):
+        gp, gout, gni = api.pose_only_optimize(T0, pts, obs, Kt, rounds=rounds, iters=iters)
+        rp, rout, rni = oracle.pose_only_optimize(T0, pts, obs, Kt, rounds=rounds, iters=iters)
+        assert np.allclose(gp, rp, rtol=1e-8, atol=1e-9) and gni == rni and np.array_equal(gout, rout)
+    gp, gout, gni = api.pose_only_optimize(T0, pts[:0], obs[:0], Kt)                # no edges: pose untouched
+    assert np.array_equal(gp, T0) and gni == 0
+    gp, gout, gni = api.pose_only_optimize(T0, pts[:2], obs[:2], Kt)                # rank-deficient: still mirrors the oracle
+    rp, rout, rni = oracle.pose_only_optimize(T0, pts[:2], obs[:2], Kt)
+    assert np.allclose(gp, rp, rtol=1e-6, atol=1e-8) and gni == rni
+
+
+def test_pose_only_batch(api, oracle, synth):
+    import torch
+    B, cap = 4, 512
+    probs = [_problem(synth, oracle, 20 + b, 100 + 90 * b, 10 * b) for b in range(B)]
+    poses = np.stack([p[0] for p in probs]); pts = np.zeros((B, cap, 3)); obs = np.zeros((B, cap, 2)); cnt = np.zeros(B, np.int32)
+    for b, p in enumerate(probs):
+        n = len(p[1]); pts[b, :n] = p[1]; obs[b, :n] = p[2]; cnt[b] = n
+    d = [torch.from_numpy(x).cuda() for x in (poses, pts, obs, cnt)]
+    out = torch.zeros(B, cap, dtype=torch.uint8, device="cuda"); ni = torch.zeros(B, dtype=torch.int32, device="cuda"); st = torch.ones(B, dtype=torch.int32, device="cuda")
+    api.pose_only_optimize_batch(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), B, cap, probs[0][3], 5.991, 4, 10,
+                                 out.data_ptr(), ni.data_ptr(), st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert (st.cpu().numpy() == 0).all()
+    for b, p in enumerate(probs):
+        rp, rout, rni = oracle.pose_only_optimize(p[0], p[1], p[2], p[3])
+        assert np.allclose(d[0][b].cpu().numpy(), rp, rtol=1e-8, atol=1e-9) and int(ni[b]) == rni
+        assert np.array_equal(out[b, :cnt[b]].cpu().numpy().astype(bool), rout)

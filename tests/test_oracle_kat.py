@@ -504,3 +504,21 @@ def test_lk_recovers_subpixel_translation(oracle, synth):
     flat = np.full((100, 120), 90, np.uint8)
     _, st2, _ = oracle.lk_track(flat, flat, pts[:10] / 2, pts[:10] / 2)
     assert not st2.any()
+
+
+def test_pose_only_converges_and_flags_gross_outliers(oracle, synth):
+    rng = np.random.default_rng(11)
+    K = synth.KITTI00; Kt = (K["fx"], K["fy"], K["cx"], K["cy"])
+    n = 150
+    pts = np.stack([rng.uniform(-10, 10, n), rng.uniform(-3, 3, n), rng.uniform(5, 40, n)], 1)
+    T = oracle.se3_exp(np.array([0.2, 0.05, -0.3, -0.01, 0.02, 0.01]))
+    x, y, z, w = T[:4]
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    pc = pts @ R.T + T[4:]
+    obs = np.stack([Kt[0] * pc[:, 0] / pc[:, 2] + Kt[2], Kt[1] * pc[:, 1] / pc[:, 2] + Kt[3]], 1)
+    bad = np.arange(0, n, 10)
+    noisy = obs.copy(); noisy[bad] += 35.0
+    p, out, ni = oracle.pose_only_optimize(np.array([0, 0, 0, 1, 0, 0, 0.0]), pts, noisy, Kt)
+    assert np.abs(p - T).max() < 1e-6                       # exact observations for the inliers -> exact pose
+    assert set(np.where(out)[0]) == set(bad.tolist()) and ni == n - len(bad)
