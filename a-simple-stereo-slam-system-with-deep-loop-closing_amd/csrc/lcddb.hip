@@ -188,6 +188,7 @@ struct myslam_lcddb {
     std::vector<uint64_t> ids;
     Partial* d_partials = nullptr; size_t partialsCap = 0;
     int32_t* d_nvalid = nullptr; int nvalidCap = 0;
+    int32_t* h_nvalid = nullptr; hipEvent_t nvEvent = nullptr;      // pinned staging of the per-query row limits + "copy done" event
     float* d_q1 = nullptr; uint64_t* d_best1 = nullptr; float* d_max1 = nullptr; int32_t* d_cnt1 = nullptr;
 
     // index of the first row the reference's scan does NOT look at: it breaks at the first id with
@@ -227,6 +228,8 @@ int myslam_lcddb_destroy(myslam_lcddb* h) {
     (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->d_db, h->d_ids, h->d_partials, h->d_nvalid, h->d_q1, h->d_best1, h->d_max1, h->d_cnt1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (h->h_nvalid) (void)hipHostFree(h->h_nvalid);
+    if (h->nvEvent) (void)hipEventDestroy(h->nvEvent);
     delete h;
     return MYSLAM_OK;
 }
@@ -265,23 +268,31 @@ int myslam_lcddb_append_batch(myslam_lcddb* h, const uint64_t* ids, const float*
 static int db_query(myslam_lcddb* h, const float* d_q, const uint64_t* cur_ids_host, int nq, float thr_low, uint64_t* d_best,
                     float* d_max, int32_t* d_cnt) {
     const int rowsPerBlock = DB_WAVES * DB_ROWS_PER_WAVE;
-    std::vector<int32_t> nv(nq);
+    if (nq > h->nvalidCap) {
+        MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (h->d_nvalid) (void)hipFree(h->d_nvalid);
+        if (h->h_nvalid) (void)hipHostFree(h->h_nvalid);
+        h->d_nvalid = nullptr; h->h_nvalid = nullptr; h->nvalidCap = 0;
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_nvalid, sizeof(int32_t) * nq));
+        MYSLAM_HIP_CHECK(hipHostMalloc((void**)&h->h_nvalid, sizeof(int32_t) * nq));
+        if (!h->nvEvent) MYSLAM_HIP_CHECK(hipEventCreateWithFlags(&h->nvEvent, hipEventDisableTiming));
+        h->nvalidCap = nq;
+    } else {
+        MYSLAM_HIP_CHECK(hipEventSynchronize(h->nvEvent));               // the previous call's upload has left the pinned buffer
+    }
+    int32_t* nv = h->h_nvalid;
     int maxv = 0;
     for (int i = 0; i < nq; i++) { nv[i] = h->n_valid(cur_ids_host[i]); maxv = std::max(maxv, nv[i]); }
     const int nblocks = std::max(1, (maxv + rowsPerBlock - 1) / rowsPerBlock);
-    if (nq > h->nvalidCap) {
-        if (h->d_nvalid) (void)hipFree(h->d_nvalid);
-        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_nvalid, sizeof(int32_t) * nq));
-        h->nvalidCap = nq;
-    }
     const size_t need = (size_t)nblocks * nq;
     if (need > h->partialsCap) {
+        MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
         if (h->d_partials) (void)hipFree(h->d_partials);
         MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_partials, need * sizeof(Partial)));
         h->partialsCap = need;
     }
-    MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_nvalid, nv.data(), sizeof(int32_t) * nq, hipMemcpyHostToDevice, h->stream));
-    MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));                    // nv is a stack/heap temporary
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_nvalid, nv, sizeof(int32_t) * nq, hipMemcpyHostToDevice, h->stream));      // pinned -> no host sync
+    MYSLAM_HIP_CHECK(hipEventRecord(h->nvEvent, h->stream));
     {
         ScopedProf sp(P_DBSCAN, h->stream);
         int nparts = nblocks;
@@ -302,7 +313,7 @@ static int db_query(myslam_lcddb* h, const float* d_q, const uint64_t* cur_ids_h
 
 int myslam_lcddb_query_batch(myslam_lcddb* h, const float* d_q, const uint64_t* cur_ids, int nq, float thr_low,
                              uint64_t* d_best_id, float* d_max_score, int32_t* d_cnt) {
-    if (!h || !d_q || !cur_ids || nq < 1 || nq > 1024 || !d_best_id || !d_max_score || !d_cnt) return MYSLAM_ERR_INVALID;
+    if (!h || !d_q || !cur_ids || nq < 1 || nq > 65536 || !d_best_id || !d_max_score || !d_cnt) return MYSLAM_ERR_INVALID;
     return db_query(h, d_q, cur_ids, nq, thr_low, d_best_id, d_max_score, d_cnt);
 }
 

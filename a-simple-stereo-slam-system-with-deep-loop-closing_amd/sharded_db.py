@@ -48,14 +48,19 @@ def merge_shard_triples(scores, ids, counts, broke=None):
     return mx, best, counts.sum(dim=0)
 
 
-def merge_candidates(best_id, max_score, count, world, broke=None, group=None):
+def merge_candidates(best_id, max_score, count, world, broke=None, group=None, via_cpu=False):
     """In-place merge across ranks of per-shard results for the same Q queries (Q = len(best_id)).
-    broke: optional bool tensor [Q] from shard_breaks() (None = this shard never hits the early exit)."""
+    broke: optional bool tensor [Q] from shard_breaks() (None = this shard never hits the early exit).
+    via_cpu: stage the 32-byte-per-query payload through host memory (gloo process groups)."""
     q = best_id.shape[0]
     bk = torch.zeros(q, dtype=torch.float64, device=best_id.device) if broke is None else broke.to(torch.float64)
     packed = torch.stack([max_score.to(torch.float64), best_id.to(torch.float64), count.to(torch.float64), bk], dim=1).contiguous()
+    if via_cpu:
+        packed = packed.cpu()
     gathered = torch.empty((world, q, 4), dtype=torch.float64, device=packed.device)
     dist.all_gather_into_tensor(gathered.view(world * q, 4), packed, group=group)
+    if via_cpu:
+        gathered = gathered.to(best_id.device)
     mx, best, cnt = merge_shard_triples(gathered[:, :, 0], gathered[:, :, 1].to(torch.int64), gathered[:, :, 2].to(torch.int64),
                                         gathered[:, :, 3] > 0)
     max_score.copy_(mx.to(max_score.dtype)); best_id.copy_(best.to(best_id.dtype)); count.copy_(cnt.to(count.dtype))

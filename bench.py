@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--db", type=int, default=0, help="key-frame database size (default 10000, or 6250 per GPU when sharded)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=32)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = debugging aid: several ranks share GPU 0 and the collectives go through host memory")
     return ap.parse_args()
 
 
@@ -94,10 +96,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    via_cpu = args.backend == "gloo"
+    if via_cpu:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if via_cpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE {world}"
@@ -172,9 +180,14 @@ def main():
         if use_lcd:
             lcd.describe_batch(d_imgs.data_ptr(), P, H, W, W, H * W, d_descr.data_ptr(), blur_in_place=False)
             if world > 1:       # every shard scores every rank's queries; candidates are merged after an all-gather
-                dist.all_gather_into_tensor(d_allq, d_descr)
+                if via_cpu:
+                    h_all = torch.empty(d_allq.shape, dtype=d_allq.dtype)
+                    dist.all_gather_into_tensor(h_all, d_descr.cpu())
+                    d_allq.copy_(h_all)
+                else:
+                    dist.all_gather_into_tensor(d_allq, d_descr)
                 D.query_batch(d_allq.data_ptr(), cur_ids, NQ, d_best.data_ptr(), d_max.data_ptr(), d_dbcnt.data_ptr())
-                pkg.sharded_db.merge_candidates(d_best, d_max, d_dbcnt, world)
+                pkg.sharded_db.merge_candidates(d_best, d_max, d_dbcnt, world, via_cpu=via_cpu)
             else:
                 D.query_batch(d_descr.data_ptr(), cur_ids, NQ, d_best.data_ptr(), d_max.data_ptr(), d_dbcnt.data_ptr())
         if use_ba:
@@ -203,7 +216,7 @@ def main():
     api.prof_enable(False)
     prof = api.prof_read()
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if via_cpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

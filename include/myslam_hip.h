@@ -177,7 +177,7 @@ int myslam_lcddb_append(myslam_lcddb* h, uint64_t id, const float* descr1064);
 int myslam_lcddb_append_batch(myslam_lcddb* h, const uint64_t* ids /*host*/, const float* d_descr, int n);
 int myslam_lcddb_query(myslam_lcddb* h, const float* descr1064, uint64_t cur_id, float thr_low,
                        uint64_t* best_id, float* max_score, int* cnt);
-/* nq queries at once: d_q nq x 1064 (device), cur_ids nq (HOST); outputs nq each (device).  nq <= 1024. */
+/* nq queries at once: d_q nq x 1064 (device), cur_ids nq (HOST); outputs nq each (device).  nq <= 65536; no host synchronisation. */
 int myslam_lcddb_query_batch(myslam_lcddb* h, const float* d_q, const uint64_t* cur_ids /*host*/, int nq, float thr_low,
                              uint64_t* d_best_id, float* d_max_score, int32_t* d_cnt);
 

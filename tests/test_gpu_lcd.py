@@ -141,3 +141,28 @@ def test_loop_database_batch_queries(api, oracle, synth):
     for i in range(nq):
         rb, rm, rc = oracle.lcddb_query(db, ids, q[i], int(cur[i]))
         assert int(dbest[i]) == rb and abs(float(dmax[i]) - rm) < SCORE_ATOL and int(dcnt[i]) == rc
+
+
+def test_loop_database_many_queries_back_to_back(api, oracle, synth):
+    """2048 queries per call (what an 8-GPU run sends to every shard: 256 frames x 8 ranks), issued twice without a host
+    synchronisation in between (the per-query row limits travel through a pinned buffer)."""
+    import torch
+    n, nq = 700, 2048
+    db = synth.lcd_database(n); ids = np.arange(0, 2 * n, 2, dtype=np.uint64)
+    D = api.LoopDatabase(n)
+    t = torch.from_numpy(db).cuda(); D.append_batch(ids, t.data_ptr(), n)
+    rng = np.random.default_rng(9)
+    outs = []
+    for rep in range(2):
+        q = db[rng.integers(0, n, nq)] * 0.9 + 0.1 * synth.lcd_database(nq, seed=78 + rep)
+        q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+        cur = rng.integers(50, 2 * n + 60, nq).astype(np.uint64)
+        dq = torch.from_numpy(q).cuda()
+        dbest = torch.zeros(nq, dtype=torch.int64, device="cuda"); dmax = torch.zeros(nq, device="cuda"); dcnt = torch.zeros(nq, dtype=torch.int32, device="cuda")
+        D.query_batch(dq.data_ptr(), cur, nq, dbest.data_ptr(), dmax.data_ptr(), dcnt.data_ptr())
+        outs.append((q, cur, dq, dbest, dmax, dcnt))
+    torch.cuda.synchronize()
+    for q, cur, _, dbest, dmax, dcnt in outs:
+        for i in range(0, nq, 37):
+            rb, rm, rc = oracle.lcddb_query(db, ids, q[i], int(cur[i]))
+            assert int(dbest[i]) == rb and abs(float(dmax[i]) - rm) < SCORE_ATOL and int(dcnt[i]) == rc
