@@ -62,6 +62,10 @@ def parse():
     ap.add_argument("--db", type=int, default=0, help="key-frame database size (default 10000, or 6250 per GPU when sharded)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=32)
+    ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
+                    help="2 = the DeepLCD / loop-DB / BA chain runs on a second HIP stream beside ORB + match + triangulation")
+    ap.add_argument("--orb-split", type=int, default=1, choices=[1, 2],
+                    help="2 = left and right images go through two extractor handles on two streams")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = debugging aid: several ranks share GPU 0 and the collectives go through host memory")
     return ap.parse_args()
@@ -114,7 +118,12 @@ def main():
     pkg = load_package()
     api, synth = pkg.api, pkg.synth
     assert api.device_count() >= 1
-    stream = torch.cuda.current_stream().cuda_stream
+    main_stream = torch.cuda.current_stream()
+    stream = main_stream.cuda_stream
+    # the LCD -> DB -> BA chain only reads the input images: it runs beside the ORB chain on its own stream (MFMA conv2 under the
+    # VALU-bound FAST kernel, the latency-bound small kernels under each other) and is joined at the end of every step
+    side_stream = torch.cuda.Stream() if args.streams == 2 else main_stream
+    stream2 = side_stream.cuda_stream
     P = args.pairs
     K = synth.KITTI00
     Kt = (K["fx"], K["fy"], K["cx"], K["cy"])
@@ -125,6 +134,8 @@ def main():
     d_imgs = torch.from_numpy(imgs).to(dev)
     ext = api.ORBextractor(2000, stream=stream)
     cap = ext.max_keypoints()
+    orb_stream = torch.cuda.Stream() if args.orb_split == 2 else None
+    ext_r = api.ORBextractor(2000, stream=orb_stream.cuda_stream) if orb_stream else None
     d_kps = torch.zeros(2 * P * cap * 28, dtype=torch.uint8, device=dev)
     d_desc = torch.zeros(2 * P * cap * 32, dtype=torch.uint8, device=dev)
     d_cnt = torch.zeros(2 * P, dtype=torch.int32, device=dev)
@@ -139,10 +150,10 @@ def main():
     n_db_local = args.db or (10000 if world == 1 else 6250)
     db_np = None
     if use_lcd:
-        lcd = api.DeepLCD(synth.calc_weights(), stream=stream)
+        lcd = api.DeepLCD(synth.calc_weights(), stream=stream2)
         d_descr = torch.zeros(P, 1064, device=dev)
         db_np = synth.lcd_database(n_db_local, seed=0xDB + rank)
-        D = api.LoopDatabase(n_db_local, stream=stream)
+        D = api.LoopDatabase(n_db_local, stream=stream2)
         ids = np.arange(rank * n_db_local, (rank + 1) * n_db_local, dtype=np.uint64)     # contiguous id range per shard
         t_db = torch.from_numpy(db_np).to(dev)
         D.append_batch(ids, t_db.data_ptr(), n_db_local)
@@ -168,32 +179,43 @@ def main():
             s_poses.copy_(b_in[0]); s_pts.copy_(b_in[1])
             api.ba_optimize_active_map_batch(s_poses.data_ptr(), s_pts.data_ptr(), *[t.data_ptr() for t in b_in[2:]], P, maxP, maxL, maxE, Kt,
                                              5.991, 5.991, 5, 10, b_out[2].data_ptr(), s_echi.data_ptr(), s_out.data_ptr(), s_rd.data_ptr(),
-                                             s_no.data_ptr(), s_st.data_ptr(), stream)
+                                             s_no.data_ptr(), s_st.data_ptr(), stream2)
 
     def step():
-        ext.detect_and_compute_batch(d_imgs.data_ptr(), 2 * P, H, W, W, H * W, d_kps.data_ptr(), d_desc.data_ptr(),
-                                     d_cnt.data_ptr(), d_stat.data_ptr(), cap)
+        if ext_r is None:
+            ext.detect_and_compute_batch(d_imgs.data_ptr(), 2 * P, H, W, W, H * W, d_kps.data_ptr(), d_desc.data_ptr(),
+                                         d_cnt.data_ptr(), d_stat.data_ptr(), cap)
+        else:               # left images on the main stream, right images on a second one
+            orb_stream.wait_stream(main_stream)
+            ext.detect_and_compute_batch(d_imgs.data_ptr(), P, H, W, W, H * W, d_kps.data_ptr(), d_desc.data_ptr(),
+                                         d_cnt.data_ptr(), d_stat.data_ptr(), cap)
+            ext_r.detect_and_compute_batch(d_imgs.data_ptr() + P * H * W, P, H, W, W, H * W, d_kps.data_ptr() + P * cap * 28,
+                                           d_desc.data_ptr() + P * cap * 32, d_cnt.data_ptr() + 4 * P, d_stat.data_ptr() + 4 * P, cap)
+            main_stream.wait_stream(orb_stream)
         api.hamming_match_batch(d_desc.data_ptr(), d_cnt.data_ptr(), d_desc.data_ptr() + P * cap * 32, d_cnt.data_ptr() + 4 * P,
                                 P, cap, d_midx.data_ptr(), d_mdist.data_ptr(), stream)
         api.triangulate_stereo_batch(d_kps.data_ptr(), d_kps.data_ptr() + P * cap * 28, d_midx.data_ptr(), d_cnt.data_ptr(), P, cap,
                                      Kt, K["bf"] / K["fx"], d_xyz.data_ptr(), d_ok.data_ptr(), stream)
-        if use_lcd:
-            lcd.describe_batch(d_imgs.data_ptr(), P, H, W, W, H * W, d_descr.data_ptr(), blur_in_place=False)
-            if world > 1:       # every shard scores every rank's queries; candidates are merged after an all-gather
-                if via_cpu:
-                    h_all = torch.empty(d_allq.shape, dtype=d_allq.dtype)
-                    dist.all_gather_into_tensor(h_all, d_descr.cpu())
-                    d_allq.copy_(h_all)
+        with torch.cuda.stream(side_stream):
+            if use_lcd:
+                lcd.describe_batch(d_imgs.data_ptr(), P, H, W, W, H * W, d_descr.data_ptr(), blur_in_place=False)
+                if world > 1:       # every shard scores every rank's queries; candidates are merged after an all-gather
+                    if via_cpu:
+                        h_all = torch.empty(d_allq.shape, dtype=d_allq.dtype)
+                        dist.all_gather_into_tensor(h_all, d_descr.cpu())
+                        d_allq.copy_(h_all)
+                    else:
+                        dist.all_gather_into_tensor(d_allq, d_descr)
+                    D.query_batch(d_allq.data_ptr(), cur_ids, NQ, d_best.data_ptr(), d_max.data_ptr(), d_dbcnt.data_ptr())
+                    pkg.sharded_db.merge_candidates(d_best, d_max, d_dbcnt, world, via_cpu=via_cpu)
                 else:
-                    dist.all_gather_into_tensor(d_allq, d_descr)
-                D.query_batch(d_allq.data_ptr(), cur_ids, NQ, d_best.data_ptr(), d_max.data_ptr(), d_dbcnt.data_ptr())
-                pkg.sharded_db.merge_candidates(d_best, d_max, d_dbcnt, world, via_cpu=via_cpu)
-            else:
-                D.query_batch(d_descr.data_ptr(), cur_ids, NQ, d_best.data_ptr(), d_max.data_ptr(), d_dbcnt.data_ptr())
-        if use_ba:
-            api.ba_build_batch(*[t.data_ptr() for t in b_in], P, maxP, maxL, maxE, Kt, 5.991, *[t.data_ptr() for t in b_out], stream)
-            if use_solve:
-                solve()
+                    D.query_batch(d_descr.data_ptr(), cur_ids, NQ, d_best.data_ptr(), d_max.data_ptr(), d_dbcnt.data_ptr())
+            if use_ba:
+                api.ba_build_batch(*[t.data_ptr() for t in b_in], P, maxP, maxL, maxE, Kt, 5.991, *[t.data_ptr() for t in b_out], stream2)
+                if use_solve:
+                    solve()
+        if side_stream is not main_stream:
+            main_stream.wait_stream(side_stream)            # a step is complete when both chains are
 
     def barrier():
         if world > 1:
@@ -222,11 +244,12 @@ def main():
 
     solve_ms = None
     if use_ba and not use_solve:        # the "g2o solve" half of configs[3], timed on its own (not part of `value`)
-        solve(); torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            solve()
-        torch.cuda.synchronize()
+        with torch.cuda.stream(side_stream):
+            solve(); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                solve()
+            torch.cuda.synchronize()
         solve_ms = (time.perf_counter() - t1) / args.steps * 1e3
         assert int(s_st.abs().sum()) == 0
 
@@ -262,6 +285,7 @@ def main():
                                     "orb_match": "configs[1]: ORB extract L+R (2000 feats) + L/R Hamming match + triangulation",
                                     "orb_match_lcd": f"configs[2]: configs[1] + DeepLCD descriptor + {n_db_local * world}-KF cosine DB scan"}[args.workload],
                        "pairs_per_step_per_gpu": P, "image": "1241x376 u8", "keypoints_per_image": n_kp,
+                       "hip_streams": args.streams,
                        "parallelism": f"frame-sharded x{world}" + (", id-range sharded DB + all-gather of candidates" if world > 1 else "")},
             "roofline": roof,
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in busy.items()},
