@@ -64,8 +64,8 @@ def parse():
     ap.add_argument("--cpu-pairs", type=int, default=32)
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
                     help="2 = the DeepLCD / loop-DB / BA chain runs on a second HIP stream beside ORB + match + triangulation")
-    ap.add_argument("--orb-split", type=int, default=1, choices=[1, 2],
-                    help="2 = left and right images go through two extractor handles on two streams")
+    ap.add_argument("--orb-split", type=int, default=2, choices=[1, 2, 4, 8],
+                    help="S > 1 = the 2P images go through S extractor handles on S streams (S equal groups)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = debugging aid: several ranks share GPU 0 and the collectives go through host memory")
     return ap.parse_args()
@@ -134,8 +134,10 @@ def main():
     d_imgs = torch.from_numpy(imgs).to(dev)
     ext = api.ORBextractor(2000, stream=stream)
     cap = ext.max_keypoints()
-    orb_stream = torch.cuda.Stream() if args.orb_split == 2 else None
-    ext_r = api.ORBextractor(2000, stream=orb_stream.cuda_stream) if orb_stream else None
+    S = args.orb_split
+    assert (2 * P) % S == 0
+    orb_streams = [torch.cuda.Stream() for _ in range(S - 1)]
+    orb_exts = [api.ORBextractor(2000, stream=st.cuda_stream) for st in orb_streams]
     d_kps = torch.zeros(2 * P * cap * 28, dtype=torch.uint8, device=dev)
     d_desc = torch.zeros(2 * P * cap * 32, dtype=torch.uint8, device=dev)
     d_cnt = torch.zeros(2 * P, dtype=torch.int32, device=dev)
@@ -182,16 +184,19 @@ def main():
                                              s_no.data_ptr(), s_st.data_ptr(), stream2)
 
     def step():
-        if ext_r is None:
+        if S == 1:
             ext.detect_and_compute_batch(d_imgs.data_ptr(), 2 * P, H, W, W, H * W, d_kps.data_ptr(), d_desc.data_ptr(),
                                          d_cnt.data_ptr(), d_stat.data_ptr(), cap)
-        else:               # left images on the main stream, right images on a second one
-            orb_stream.wait_stream(main_stream)
-            ext.detect_and_compute_batch(d_imgs.data_ptr(), P, H, W, W, H * W, d_kps.data_ptr(), d_desc.data_ptr(),
-                                         d_cnt.data_ptr(), d_stat.data_ptr(), cap)
-            ext_r.detect_and_compute_batch(d_imgs.data_ptr() + P * H * W, P, H, W, W, H * W, d_kps.data_ptr() + P * cap * 28,
-                                           d_desc.data_ptr() + P * cap * 32, d_cnt.data_ptr() + 4 * P, d_stat.data_ptr() + 4 * P, cap)
-            main_stream.wait_stream(orb_stream)
+        else:               # S equal groups of images, group 0 on the main stream
+            G = 2 * P // S
+            for st in orb_streams:
+                st.wait_stream(main_stream)
+            for gi, e in enumerate([ext] + orb_exts):
+                o = gi * G
+                e.detect_and_compute_batch(d_imgs.data_ptr() + o * H * W, G, H, W, W, H * W, d_kps.data_ptr() + o * cap * 28,
+                                           d_desc.data_ptr() + o * cap * 32, d_cnt.data_ptr() + 4 * o, d_stat.data_ptr() + 4 * o, cap)
+            for st in orb_streams:
+                main_stream.wait_stream(st)
         api.hamming_match_batch(d_desc.data_ptr(), d_cnt.data_ptr(), d_desc.data_ptr() + P * cap * 32, d_cnt.data_ptr() + 4 * P,
                                 P, cap, d_midx.data_ptr(), d_mdist.data_ptr(), stream)
         api.triangulate_stereo_batch(d_kps.data_ptr(), d_kps.data_ptr() + P * cap * 28, d_midx.data_ptr(), d_cnt.data_ptr(), P, cap,

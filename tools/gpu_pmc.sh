@@ -3,7 +3,7 @@
 mkdir -p gpurun_out; export TMPDIR=/tmp
 R=${1:-pmc1}
 cd /tmp
-rocprofv3 --kernel-trace --pmc ${PMC:-SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS} --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$R -o a -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --pairs 64 --workload orb_match --no-cpu-baseline > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/$R.err
+rocprofv3 --kernel-trace --pmc ${PMC:-SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS} --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$R -o a -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --pairs 64 --workload ${WL:-orb_match} --streams 1 --no-cpu-baseline > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/$R.err
 cd $GRAFT_REPO_ROOT
 python - <<PY
 import csv, glob, collections
