@@ -40,4 +40,24 @@ poses, pts, ep, el, obs, fixed, K = synth.ba_problem(n_kf=4, n_mp=25)
 Hpp, Hll, Hpl, bp, bl, chi2 = o.ba_build(poses, pts, ep, el, obs, fixed, K)
 np.savez_compressed(os.path.join(HERE, "ba_small.npz"), poses=poses, pts=pts, ep=ep, el=el, obs=obs, fixed=fixed, K=np.array(K),
                     Hpp=Hpp, Hll=Hll, Hpl=Hpl, bp=bp, bl=bl, chi2=chi2)
+# frontend operators: LK tracking of the ORB keypoints into a shifted copy, pose-only optimisation
+img2 = np.roll(img, (1, -3), axis=(0, 1)).copy()
+k100 = o.detect(o.params(100), img)
+pts0 = np.stack([k100["x"], k100["y"]], 1).astype(np.float32)
+lk_pts, lk_st, lk_err = o.lk_track(img, img2, pts0, pts0)
+np.savez_compressed(os.path.join(HERE, "lk_small.npz"), prev=img, next=img2, pts=pts0, out=lk_pts, status=lk_st, err=lk_err)
+
+rng = np.random.default_rng(17)
+Kt = (718.856, 718.856, 607.1928, 185.2157)
+P3 = np.stack([rng.uniform(-10, 10, 90), rng.uniform(-3, 3, 90), rng.uniform(5, 40, 90)], 1)
+Tt = o.se3_exp(np.array([0.2, -0.05, 0.4, 0.01, -0.015, 0.02]))
+x, y, z, w_ = Tt[:4]
+Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w_), 2 * (x * z + y * w_)], [2 * (x * y + z * w_), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w_)],
+               [2 * (x * z - y * w_), 2 * (y * z + x * w_), 1 - 2 * (x * x + y * y)]])
+pc = P3 @ Rm.T + Tt[4:]
+uv = np.stack([Kt[0] * pc[:, 0] / pc[:, 2] + Kt[2], Kt[1] * pc[:, 1] / pc[:, 2] + Kt[3]], 1) + rng.normal(0, 0.4, (90, 2))
+uv[::9] += 30.0
+T0 = np.array([0, 0, 0, 1, 0, 0, 0.0])
+po_pose, po_out, po_inl = o.pose_only_optimize(T0, P3, uv, Kt)
+np.savez_compressed(os.path.join(HERE, "pose_only_small.npz"), pose0=T0, pts3d=P3, obs=uv, K=np.array(Kt), pose=po_pose, outlier=po_out, inliers=po_inl)
 print("golden fixtures written to", HERE)

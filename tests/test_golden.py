@@ -22,6 +22,12 @@ def test_oracle_reproduces_golden(oracle, synth):
     got = oracle.ba_build(b["poses"], b["pts"], b["ep"], b["el"], b["obs"], b["fixed"], tuple(b["K"]))
     for a, name in zip(got, ["Hpp", "Hll", "Hpl", "bp", "bl", "chi2"]):
         assert np.allclose(a, b[name], rtol=1e-13, atol=1e-9), name
+    k = np.load(os.path.join(G, "lk_small.npz"))
+    out, st, err = oracle.lk_track(k["prev"], k["next"], k["pts"], k["pts"])
+    assert np.array_equal(out, k["out"]) and np.array_equal(st, k["status"]) and np.array_equal(err, k["err"])
+    q = np.load(os.path.join(G, "pose_only_small.npz"))
+    pose, outl, inl = oracle.pose_only_optimize(q["pose0"], q["pts3d"], q["obs"], tuple(q["K"]))
+    assert np.allclose(pose, q["pose"], rtol=1e-12, atol=1e-12) and np.array_equal(outl, q["outlier"]) and inl == int(q["inliers"])
 
 
 @pytest.mark.gpu
@@ -39,3 +45,9 @@ def test_hip_reproduces_golden(api, synth):
     got = api.ba_build(b["poses"], b["pts"], b["ep"], b["el"], b["obs"], b["fixed"], tuple(b["K"]))
     for a, name in zip(got, ["Hpp", "Hll", "Hpl", "bp", "bl", "chi2"]):
         assert np.allclose(a, b[name], rtol=1e-10, atol=1e-7), name
+    k = np.load(os.path.join(G, "lk_small.npz"))
+    out, st, err = api.LKTracker().track(k["prev"], k["next"], k["pts"], k["pts"])
+    assert np.array_equal(out, k["out"]) and np.array_equal(st, k["status"]) and np.array_equal(err, k["err"])
+    q = np.load(os.path.join(G, "pose_only_small.npz"))
+    pose, outl, inl = api.pose_only_optimize(q["pose0"], q["pts3d"], q["obs"], tuple(q["K"]))
+    assert np.allclose(pose, q["pose"], rtol=1e-8, atol=1e-9) and np.array_equal(outl, q["outlier"]) and inl == int(q["inliers"])
