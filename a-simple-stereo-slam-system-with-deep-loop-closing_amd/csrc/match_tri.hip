@@ -30,24 +30,36 @@ __global__ __launch_bounds__(HM_T) void k_hamming(const uint8_t* __restrict__ q,
     const uint4* T = reinterpret_cast<const uint4*>(tr + (size_t)p * cap * 32);
     uint4 a = make_uint4(0, 0, 0, 0), b = a;
     if (qi < nq) { a = Q[2 * qi]; b = Q[2 * qi + 1]; }
-    int best = 0x7fffffff, bidx = -1;
+    // running minimum of the key (distance << 20 | train index): one v_min_u32 keeps the smallest distance and, among equal
+    // distances, the lowest train index (BFMatcher keeps the first minimum).  nt < 2^20.
+    uint32_t bestKey = 0xffffffffu;
     for (int j0 = 0; j0 < nt; j0 += HM_CHUNK) {
         const int m = min(HM_CHUNK, nt - j0);
         __syncthreads();
         for (int i = threadIdx.x; i < 2 * m; i += HM_T) s_t[i] = T[2 * j0 + i];
         __syncthreads();
-#pragma unroll 4
-        for (int j = 0; j < m; j++) {
+        auto row = [&](int j) {
             const uint4 c = s_t[2 * j], d = s_t[2 * j + 1];          // broadcast reads
-            int h = __popc(a.x ^ c.x);
-            h += __popc(a.y ^ c.y); h += __popc(a.z ^ c.z); h += __popc(a.w ^ c.w);
-            h += __popc(b.x ^ d.x); h += __popc(b.y ^ d.y); h += __popc(b.z ^ d.z); h += __popc(b.w ^ d.w);
-            if (h < best) { best = h; bidx = j0 + j; }               // strict <: first (lowest) train index wins
-        }
+            // v_bcnt_u32_b32 adds its second operand: one accumulate chain per row (four rows are in flight), no separate adds
+            uint32_t h;
+            asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(h) : "v"(a.x ^ c.x));
+            asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(h) : "v"(a.y ^ c.y), "v"(h));
+            asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(h) : "v"(a.z ^ c.z), "v"(h));
+            asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(h) : "v"(a.w ^ c.w), "v"(h));
+            asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(h) : "v"(b.x ^ d.x), "v"(h));
+            asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(h) : "v"(b.y ^ d.y), "v"(h));
+            asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(h) : "v"(b.z ^ d.z), "v"(h));
+            asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(h) : "v"(b.w ^ d.w), "v"(h));
+            bestKey = min(bestKey, (h << 20) | (uint32_t)(j0 + j));
+        };
+        int j = 0;
+        for (; j + 4 <= m; j += 4) { row(j); row(j + 1); row(j + 2); row(j + 3); }
+        for (; j < m; j++) row(j);
     }
     if (qi < nq) {
-        out_idx[(size_t)p * cap + qi] = bidx;
-        out_dist[(size_t)p * cap + qi] = (bidx < 0) ? -1 : best;
+        const bool any = nt > 0;
+        out_idx[(size_t)p * cap + qi] = any ? (int32_t)(bestKey & 0xfffffu) : -1;
+        out_dist[(size_t)p * cap + qi] = any ? (int32_t)(bestKey >> 20) : -1;
     }
 }
 
@@ -148,6 +160,7 @@ extern "C" {
 int myslam_hamming_match_batch(const uint8_t* d_q, const int32_t* d_nq, const uint8_t* d_t, const int32_t* d_nt, int batch,
                                int cap, int32_t* d_train_idx, int32_t* d_dist, void* hip_stream) {
     if (!d_q || !d_t || !d_nq || !d_nt || batch <= 0 || cap <= 0 || !d_train_idx || !d_dist) return MYSLAM_ERR_INVALID;
+    if (cap >= (1 << 20)) return MYSLAM_ERR_UNSUPPORTED;          // the running minimum packs (distance, train index) into 32 bits
     hipStream_t s = (hipStream_t)hip_stream;
     ScopedProf sp(P_MATCH, s);
     hipLaunchKernelGGL(k_hamming, dim3((cap + HM_T - 1) / HM_T, batch), dim3(HM_T), 0, s, d_q, d_nq, d_t, d_nt, cap, 0, 0,
@@ -160,6 +173,7 @@ int myslam_hamming_match(const uint8_t* query, int nq, const uint8_t* train, int
     if (nq < 0 || nt < 0) return MYSLAM_ERR_INVALID;
     if (nq == 0) return MYSLAM_OK;
     if (!query || !train_idx || !dist || (nt > 0 && !train)) return MYSLAM_ERR_INVALID;
+    if (nt >= (1 << 20)) return MYSLAM_ERR_UNSUPPORTED;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MYSLAM_ERR_HIP;
     uint8_t *dq = nullptr, *dt = nullptr; int32_t *di = nullptr, *dd = nullptr;

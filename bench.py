@@ -66,6 +66,7 @@ def parse():
                     help="2 = the DeepLCD / loop-DB / BA chain runs on a second HIP stream beside ORB + match + triangulation")
     ap.add_argument("--orb-split", type=int, default=2, choices=[1, 2, 4, 8],
                     help="S > 1 = the 2P images go through S extractor handles on S streams (S equal groups)")
+    ap.add_argument("--no-join", action="store_true", help="do not join the side stream at the end of every step (streaming across steps)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = debugging aid: several ranks share GPU 0 and the collectives go through host memory")
     return ap.parse_args()
@@ -219,7 +220,7 @@ def main():
                 api.ba_build_batch(*[t.data_ptr() for t in b_in], P, maxP, maxL, maxE, Kt, 5.991, *[t.data_ptr() for t in b_out], stream2)
                 if use_solve:
                     solve()
-        if side_stream is not main_stream:
+        if side_stream is not main_stream and not args.no_join:
             main_stream.wait_stream(side_stream)            # a step is complete when both chains are
 
     def barrier():
