@@ -95,7 +95,7 @@ constexpr int RS_R = 8;
 
 __global__ __launch_bounds__(256) void k_resize_strip(ResizeArgs a, int nstrips, int nbands) {
     const int lane = threadIdx.x & 63;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // scalar: row addressing goes to the SALU
     if (wid >= nstrips * nbands) return;
     const int strip = wid % nstrips, band = wid / nstrips;
     const int b = blockIdx.z;
@@ -355,7 +355,7 @@ __device__ __forceinline__ uint32_t dpp_wave_shl1(uint32_t v) { return (uint32_t
 
 __global__ __launch_bounds__(256) void k_blur7_strip(BlurArgs a, int nstrips, int nbands) {
     const int lane = threadIdx.x & 63;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);         // wave id -> (band, strip)
+    const int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // wave id -> (band, strip); scalar: row addressing goes to the SALU
     if (wid >= nstrips * nbands) return;
     const int strip = wid % nstrips, band = wid / nstrips;
     const int b = blockIdx.z;

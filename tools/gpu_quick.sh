@@ -1,9 +1,13 @@
 #!/bin/bash
-# quick GPU loop: ORB parity + golden + bench (no cpu baseline)
+# quick GPU loop: ORB parity + golden + bench (no cpu baseline): per-kernel times on one stream, then the default multi-stream step
 mkdir -p gpurun_out; export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_orb.py tests/test_golden.py -m gpu -q --tb=short --timeout 300 -p no:cacheprovider 2>&1 | tail -${TAILN:-8}
+timeout 600 python bench.py --steps 10 --warmup 2 --pairs ${PAIRS:-256} --streams 1 --orb-split 1 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('1 stream: value',round(d['value'],1),'ms/step',round(d['ms_per_step'],3))
+print({k:round(v,3) for k,v in d['kernel_ms_per_step'].items()})"
 timeout 600 python bench.py --steps 10 --warmup 2 --pairs ${PAIRS:-256} --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
-print('value',round(d['value'],1),'ms/step',round(d['ms_per_step'],3))
-print({k:round(v,3) for k,v in d['kernel_ms_per_step'].items()})"
+print('default: value',round(d['value'],1),'ms/step',round(d['ms_per_step'],3))"
