@@ -1862,7 +1862,7 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
     const int b = logical / nchunk, t = threadIdx.x;
     if (b >= batch) return;
     for (int i = t; i < 4 * DA_N; i += 256) s_icw[i] = c_icw.e[i];
-    const int wave = t >> 6, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;      // scalar: per-keypoint addressing goes to the SALU
     const int slot0 = (logical - b * nchunk) * KD_KPB;
     // ---- 0 ----
     float resp = 0.f;
@@ -1889,10 +1889,10 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
     // ---- A ----
     for (int j = 0; j < KD_KPB / 4; j++) {
         const int k = wave * (KD_KPB / 4) + j;
-        const int level = s_lv[k];
+        const int level = __builtin_amdgcn_readfirstlane(s_lv[k]);
         if (level < 0) continue;                                          // wave-uniform
         const LevelGeom& g = P.lv[level];
-        const int x = s_x[k], y = s_y[k];
+        const int x = __builtin_amdgcn_readfirstlane(s_x[k]), y = __builtin_amdgcn_readfirstlane(s_y[k]);
         const uint8_t* img = pyr + (size_t)b * pyrStride + g.imgOff;
         // keypoints keep >= 19 px from every border (ORBextractor.cpp:25), so all patch rows exist
         const int xa0 = (x - HALF_PATCH) & ~3, offA = (x - HALF_PATCH) - xa0;
@@ -1934,10 +1934,10 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
     // ---- C ----
     for (int j = 0; j < KD_KPB / 4; j++) {
         const int k = wave * (KD_KPB / 4) + j;
-        const int level = s_lv[k];
+        const int level = __builtin_amdgcn_readfirstlane(s_lv[k]);
         if (level < 0) continue;
         const LevelGeom& g = P.lv[level];
-        const int x = s_x[k], y = s_y[k];
+        const int x = __builtin_amdgcn_readfirstlane(s_x[k]), y = __builtin_amdgcn_readfirstlane(s_y[k]);
         const float ca = s_ca[k], sb = s_sb[k];
         const uint8_t* bl = blur + (size_t)b * pyrStride + g.imgOff;
         const int xb0 = (x - DB_R) & ~3, offB = (x - DB_R) - xb0;
