@@ -1886,6 +1886,12 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
         resp = (float)(pay & 0xff);
     }
     __syncthreads();
+    // lane-constant patch coordinates of the dwords this lane fetches (hoisted out of the keypoint loops)
+    int ra_[DA_IT], ca_[DA_IT], rb_[DB_IT], cb_[DB_IT];
+#pragma unroll
+    for (int q = 0; q < DA_IT; q++) { const int i = lane + 64 * q; ra_[q] = i / DA_DW; ca_[q] = 4 * (i - ra_[q] * DA_DW); }
+#pragma unroll
+    for (int q = 0; q < DB_IT; q++) { const int i = lane + 64 * q; rb_[q] = i / DB_DW; cb_[q] = 4 * (i - rb_[q] * DB_DW); }
     // ---- A ----
     for (int j = 0; j < KD_KPB / 4; j++) {
         const int k = wave * (KD_KPB / 4) + j;
@@ -1901,8 +1907,8 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
         for (int q = 0; q < DA_IT; q++) {
             const int i = lane + 64 * q;
             if (i < DA_N) {
-                const int r = i / DA_DW, c = i - r * DA_DW;
-                const uint32_t I = *reinterpret_cast<const uint32_t*>(img + (size_t)(y - HALF_PATCH + r) * g.pitch + xa0 + 4 * c);
+                const int r = ra_[q];
+                const uint32_t I = *reinterpret_cast<const uint32_t*>(img + (size_t)(y - HALF_PATCH) * g.pitch + xa0 + (r * g.pitch + ca_[q]));
                 const IcwEntry e = s_icw[offA * DA_N + i];
                 const int sI = (int)__builtin_amdgcn_udot4(I, e.o, 0u, false);
                 A += (int)__builtin_amdgcn_udot4(I, e.w, 0u, false);
@@ -1932,6 +1938,9 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
     }
     __syncthreads();
     // ---- C ----
+    float pat[16];                                                    // this lane's 4 test pairs (x0 y0 x1 y1), ORBextractor.cpp:101-359
+#pragma unroll
+    for (int q = 0; q < 16; q++) pat[q] = (float)c_pattern[lane * 16 + q];
     for (int j = 0; j < KD_KPB / 4; j++) {
         const int k = wave * (KD_KPB / 4) + j;
         const int level = __builtin_amdgcn_readfirstlane(s_lv[k]);
@@ -1945,8 +1954,7 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
 #pragma unroll
         for (int q = 0; q < DB_IT; q++) {
             const int i = lane + 64 * q;
-            const int r = i / DB_DW, c = i - r * DB_DW;
-            rb[q] = (i < DB_N) ? *reinterpret_cast<const uint32_t*>(bl + (size_t)(y - DB_R + r) * g.pitch + xb0 + 4 * c) : 0u;
+            rb[q] = (i < DB_N) ? *reinterpret_cast<const uint32_t*>(bl + (size_t)(y - DB_R) * g.pitch + xb0 + (rb_[q] * g.pitch + cb_[q])) : 0u;
         }
         __builtin_amdgcn_wave_barrier();                                  // previous keypoint's window reads are done (same wave)
 #pragma unroll
@@ -1958,8 +1966,7 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
         uint32_t nib = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int8_t* pp = &c_pattern[(lane * 4 + q) * 4];
-            const float x0 = (float)pp[0], y0 = (float)pp[1], x1 = (float)pp[2], y1 = (float)pp[3];
+            const float x0 = pat[4 * q], y0 = pat[4 * q + 1], x1 = pat[4 * q + 2], y1 = pat[4 * q + 3];
             const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, sb), __fmul_rn(y0, ca)));
             const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sb)));
             const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sb), __fmul_rn(y1, ca)));
