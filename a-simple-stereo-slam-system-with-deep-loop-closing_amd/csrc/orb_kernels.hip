@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void k_resize(ResizeArgs a) {
 // and walks RS_R destination rows: x coordinates / weights are computed once, every needed source row is sampled once
 // (one unaligned 2-byte load per pixel = the two horizontal taps, v_perm + v_dot2_u32_u16 = the 11-bit interpolation) and
 // reused by the destination rows that share it (the OpenCV row cache), all row decisions are wave-uniform.
-constexpr int RS_R = 8;
+constexpr int RS_R = 8;                      // destination rows per wave (power of two)
+constexpr int RS_MAXR = 12;                  // source rows a band may span: RS_R * scale_y + 2 (scale factors up to 1.25)
 
 __global__ __launch_bounds__(256) void k_resize_strip(ResizeArgs a, int nstrips, int nbands) {
     const int lane = threadIdx.x & 63;
@@ -110,39 +111,50 @@ __global__ __launch_bounds__(256) void k_resize_strip(ResizeArgs a, int nstrips,
         resize_coord(min(dx4 + k, a.dw - 1), a.scale_x, a.sw, true, sx[k], c0, c1);
         aw[k] = (uint32_t)c0 | ((uint32_t)c1 << 16);
     }
-    // horizontal interpolation of source row r for the 4 columns, already >> 4 (the only form the vertical step uses)
-    auto hrow = [&](int r, int* t) {
-        const uint8_t* row = src + (size_t)r * a.spitch;
+    const int dy0 = band * RS_R, dy1 = min(dy0 + RS_R, a.dh);
+    // the band's row coordinates: lane k computes row dy0 + k once, the loop reads them back as scalars
+    int ysy, yb0, yb1;
+    resize_coord(min(dy0 + (lane & (RS_R - 1)), a.dh - 1), a.scale_y, a.sh, false, ysy, yb0, yb1);
+    // every source row the band needs, fetched in ONE batch of loads (the kernel is latency-bound otherwise), interpolated
+    // horizontally once (the OpenCV row cache) and parked in LDS as 16-bit values for the vertical step
+    const int rfirst = min(max(__builtin_amdgcn_readlane(ysy, 0), 0), a.sh - 1);
+    const int rlast = min(max(__builtin_amdgcn_readlane(ysy, dy1 - 1 - dy0) + 1, 0), a.sh - 1);
+    const int nrows = rlast - rfirst + 1;                        // <= RS_MAXR (checked by the launcher)
+    __shared__ __attribute__((aligned(8))) uint16_t s_t[4][RS_MAXR][256];
+    uint16_t (*T)[256] = s_t[threadIdx.x >> 6];
+    uint32_t raw[RS_MAXR][4];
+#pragma unroll
+    for (int rr = 0; rr < RS_MAXR; rr++) {
+        const uint8_t* row = src + (size_t)(rfirst + min(rr, nrows - 1)) * a.spitch;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             uint16_t v = 0;
             // at the right border sx = sw-1 and the weight of sx+1 is 0 (OpenCV clamps fx there): that byte's value is irrelevant
-            if (has) __builtin_memcpy(&v, row + sx[k], 2);
-            const uint32_t pp = __builtin_amdgcn_perm(0u, (uint32_t)v, 0x0c010c00u);       // (p0, p1) as two u16
-            t[k] = (int)(__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pp), __builtin_bit_cast(u16x2, aw[k]), 0u, false) >> 4);
+            if (has && rr < nrows) __builtin_memcpy(&v, row + sx[k], 2);
+            raw[rr][k] = v;
         }
-    };
-    int rowA = -1, rowB = -1, tA[4] = {0, 0, 0, 0}, tB[4] = {0, 0, 0, 0};
-    const int dy0 = band * RS_R, dy1 = min(dy0 + RS_R, a.dh);
+    }
+#pragma unroll
+    for (int rr = 0; rr < RS_MAXR; rr++) {
+        if (rr < nrows) {
+            uint32_t t[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t pp = __builtin_amdgcn_perm(0u, raw[rr][k], 0x0c010c00u);       // (p0, p1) as two u16
+                t[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pp), __builtin_bit_cast(u16x2, aw[k]), 0u, false) >> 4;   // <= 32640
+            }
+            *reinterpret_cast<uint2*>(&T[rr][4 * lane]) = make_uint2(t[0] | (t[1] << 16), t[2] | (t[3] << 16));
+        }
+    }
+    // same lane reads what it wrote: no cross-lane dependency, program order suffices
     for (int dy = dy0; dy < dy1; dy++) {
-        int sy, b0, b1;
-        resize_coord(dy, a.scale_y, a.sh, false, sy, b0, b1);
-        sy = __builtin_amdgcn_readfirstlane(sy); b0 = __builtin_amdgcn_readfirstlane(b0); b1 = __builtin_amdgcn_readfirstlane(b1);
+        const int sy = __builtin_amdgcn_readlane(ysy, dy - dy0), b0 = __builtin_amdgcn_readlane(yb0, dy - dy0),
+                  b1 = __builtin_amdgcn_readlane(yb1, dy - dy0);
         const int sy0 = min(max(sy, 0), a.sh - 1), sy1 = min(max(sy + 1, 0), a.sh - 1);
-        if (sy0 != rowA) {
-            if (sy0 == rowB) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) tA[k] = tB[k];
-            } else hrow(sy0, tA);
-            rowA = sy0;
-        }
-        if (sy1 != rowB) {
-            if (sy1 == rowA) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) tB[k] = tA[k];
-            } else hrow(sy1, tB);
-            rowB = sy1;
-        }
+        const uint2 ta = *reinterpret_cast<const uint2*>(&T[sy0 - rfirst][4 * lane]);
+        const uint2 tb = *reinterpret_cast<const uint2*>(&T[sy1 - rfirst][4 * lane]);
+        const int tA[4] = {(int)(ta.x & 0xffff), (int)(ta.x >> 16), (int)(ta.y & 0xffff), (int)(ta.y >> 16)};
+        const int tB[4] = {(int)(tb.x & 0xffff), (int)(tb.x >> 16), (int)(tb.y & 0xffff), (int)(tb.y >> 16)};
         uint32_t packed = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -2097,7 +2109,7 @@ void launch_ingest(const uint8_t* src, int rows, int cols, int step, size_t sstr
 // ------------------------------------------------------------------------------------------------
 void launch_resize(const ResizeArgs& a, int batch, hipStream_t s) {
     static const char* env = getenv("MYSLAM_RESIZE_V");           // tuning aid: 1 = one row per wave kernel
-    if (!(env && atoi(env) == 1)) {
+    if (!(env && atoi(env) == 1) && (double)RS_R * a.scale_y + 2.0 <= (double)RS_MAXR) {
         const int nstrips = (a.dw + 255) / 256, nbands = (a.dh + RS_R - 1) / RS_R;
         hipLaunchKernelGGL(k_resize_strip, dim3((nstrips * nbands + 3) / 4, 1, batch), dim3(256), 0, s, a, nstrips, nbands);
         return;
