@@ -913,6 +913,17 @@ __device__ __forceinline__ int nms_pair(const uint32_t (&m)[3][3], uint32_t& zc)
     return ((int)d.x > 0 ? 1 : 0) | ((int)d.y > 0 ? 2 : 0);
 }
 
+// inclusive prefix sum over the 64 lanes on the DPP network (row_shr 1/2/4/8, then the two row broadcasts)
+__device__ __forceinline__ int wave_incl_scan_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);        // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);        // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);        // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);        // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);        // row_bcast15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);        // row_bcast31 -> rows 2, 3
+    return v;
+}
+
 // ---- strip variant: one block scores G horizontally adjacent cells -----------------------------------
 // Same arithmetic as k_fast_cells_v3 per cell (NMS and the 20 -> 7 fallback never cross a cell border), but the
 // ROI rows of G cells are staged once (shared 6-px halos), block dispatch / barriers / the global append are
@@ -927,10 +938,12 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
     constexpr int TROWS = CW + 6;
     constexpr int SP = (CW + 4 + 8 + 3) & ~3;
     constexpr int SROWS = CW + 2;
-    constexpr int NIT = (G * ((CW + 3) / 4) * CW + T - 1) / T;         // work items (4 pixels each) per thread, upper bound
+    constexpr int NLIST = G * ((CW + 1) / 2) * ((CW + 1) / 2);         // a cell of a x b pixels holds at most ceil(a/2) ceil(b/2) strict maxima
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[TROWS * TP + 16];
     __shared__ __attribute__((aligned(16))) uint8_t s_score[G][SROWS * SP + 16];
-    __shared__ int s_ini[G];
+    __shared__ uint32_t s_list[NLIST];                                 // strict maxima of the strip: py<<20 | px<<8 | z
+    __shared__ uint8_t s_listc[NLIST];                                 // ... and their cell
+    __shared__ int s_ini[G], s_nlist;
 
     const int b = blockIdx.y;
     int level = 0;
@@ -980,6 +993,7 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
     }
     for (int i = threadIdx.x; i < G * ((SROWS * SP + 16) / 4); i += T) reinterpret_cast<uint32_t*>(&s_score[0][0])[i] = 0;
     if (threadIdx.x < G) s_ini[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_nlist = 0;
     __syncthreads();
 #if defined(MYSLAM_FAST_STOP) && MYSLAM_FAST_STOP == 1
     return;
@@ -1026,86 +1040,77 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
 #if defined(MYSLAM_FAST_STOP) && MYSLAM_FAST_STOP == 2
     return;
 #endif
-    // NMS: strict maxima stay in registers (position, 4 z bytes, 4-bit mask per work item); only the per-cell
-    // "has a corner at iniTh" flag goes through LDS.
-    uint32_t rpos[NIT], rz[NIT];
-    uint64_t rmask = 0;
+    // NMS: every 4-pixel work item reports its strict maxima; they are appended to an LDS list with ONE returning LDS atomic
+    // per wave and iteration (DPP prefix sum over the lanes' counts), so the filter / append phase below runs on dense lanes.
+    const int lane = threadIdx.x & 63;
+    for (int q0 = 0; q0 < nitems; q0 += T) {                           // uniform trip count: the wave-wide scan needs every lane
+        const int q = q0 + threadIdx.x;
+        int mk = 0, c = 0, cy = 0, gi = 0;
+        uint32_t zc = 0;
+        if (q < nitems) {
+            split(q, c, cy, gi);
+            const int wc = (c == 0) ? wcs[0] : (c == 1) ? wcs[1 % G] : (c == 2) ? wcs[2 % G] : wcs[3 % G];
+            if (4 * gi < wc) {
+                uint32_t m[3][3];
 #pragma unroll
-    for (int u = 0; u < NIT; u++) {
-        const int q = threadIdx.x + u * T;
-        rpos[u] = 0; rz[u] = 0;
-        if (q >= nitems) continue;
-        int c, cy, gi;
-        split(q, c, cy, gi);
-        const int wc = (c == 0) ? wcs[0] : (c == 1) ? wcs[1 % G] : (c == 2) ? wcs[2 % G] : wcs[3 % G];
-        if (4 * gi >= wc) continue;
-        uint32_t m[3][3];
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const uint32_t* rp = reinterpret_cast<const uint32_t*>(&s_score[c][(cy + j) * SP + 4 * gi]);
-            m[j][0] = rp[0]; m[j][1] = rp[1]; m[j][2] = rp[2];
+                for (int j = 0; j < 3; j++) {
+                    const uint32_t* rp = reinterpret_cast<const uint32_t*>(&s_score[c][(cy + j) * SP + 4 * gi]);
+                    m[j][0] = rp[0]; m[j][1] = rp[1]; m[j][2] = rp[2];
+                }
+                if (m[1][1] != 0) {                                    // else none of the four pixels is a corner
+                    uint32_t za, zb;
+                    const int ma = nms_pair<0>(m, za), mb = nms_pair<1>(m, zb);
+                    mk = ma | (mb << 2);
+                    zc = m[1][1];
+                }
+            }
         }
-        if (m[1][1] == 0) continue;                                    // none of the four pixels is a corner
-        uint32_t za, zb;
-        const int ma = nms_pair<0>(m, za), mb = nms_pair<1>(m, zb);
-        const int mk = ma | (mb << 2);
-        if (mk == 0) continue;
-        const int px = 4 * gi + 3 + (cj0 + c) * g.wCell, py = cy + 3 + ci * g.hCell;     // border-relative, of pixel 0
-        rpos[u] = ((uint32_t)py << 20) | ((uint32_t)px << 8) | (uint32_t)c;
-        rz[u] = m[1][1];
-        rmask |= (uint64_t)mk << (4 * u);
-        int zmax = 0;
-#pragma unroll
-        for (int k2 = 0; k2 < 4; k2++) if ((mk >> k2) & 1) zmax = max(zmax, (int)((m[1][1] >> (8 * k2)) & 0xff));
-        if (zmax + zoff >= P.iniTh) s_ini[c] = 1;
+        int incl = __popc(mk);
+        const int cnt = incl;
+        incl = wave_incl_scan_dpp(incl);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        if (total == 0) continue;                                      // wave-uniform
+        int base = 0;
+        if (lane == 63) base = atomicAdd(&s_nlist, total);
+        base = __builtin_amdgcn_readlane(base, 63);
+        if (mk) {
+            const int px = 4 * gi + 3 + (cj0 + c) * g.wCell, py = cy + 3 + ci * g.hCell;     // border-relative, of pixel 0
+            int dst = base + incl - cnt, zmax = 0, bits = mk;
+            while (bits) {
+                const int k2 = __ffs(bits) - 1;
+                bits &= bits - 1;
+                const uint32_t z = (zc >> (8 * k2)) & 0xff;
+                if (dst < NLIST) { s_list[dst] = ((uint32_t)py << 20) | ((uint32_t)(px + k2) << 8) | z; s_listc[dst] = (uint8_t)c; }
+                dst++;
+                zmax = max(zmax, (int)z);
+            }
+            if (zmax + zoff >= P.iniTh) s_ini[c] = 1;
+        }
     }
     __syncthreads();
     // filter (:858-865: th 20 if the cell has any such corner, else th 7; mask :873-877) and append: one global atomic per wave
     const uint8_t* mimg = maskPyr ? maskPyr + (size_t)b * pyrStride + g.imgOff : nullptr;
-    int ini_bits = 0;
-#pragma unroll
-    for (int c = 0; c < G; c++) ini_bits |= (s_ini[c] ? 1 : 0) << c;
-    int npass = 0;
-    uint64_t keep = 0;
-#pragma unroll
-    for (int u = 0; u < NIT; u++) {
-        const int mk = (int)((rmask >> (4 * u)) & 0xf);
-        if (!mk) continue;
-        const int c = rpos[u] & 0xff, px0 = (rpos[u] >> 8) & 0xfff, py = rpos[u] >> 20;
-        const bool hi = (ini_bits >> c) & 1;
-#pragma unroll
-        for (int k2 = 0; k2 < 4; k2++) {
-            if (!((mk >> k2) & 1)) continue;
-            const int sc = (int)((rz[u] >> (8 * k2)) & 0xff) + zoff;
-            if (hi && sc < P.iniTh) continue;
-            if (mimg && mimg[(size_t)py * g.pitch + px0 + k2] == 0) continue;           // (no +16: reference quirk)
-            keep |= 1ull << (4 * u + k2);
-            npass++;
-        }
-    }
-    // wave-wide exclusive prefix of npass
-    const int lane = threadIdx.x & 63;
-    int incl = npass;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int n2 = __shfl_up(incl, o, 64); if (lane >= o) incl += n2; }
-    const int total = __shfl(incl, 63, 64);
-    if (total == 0) return;
-    int base = 0;
-    if (lane == 63) base = atomicAdd(&candCount[b * MAXL + level], total);
-    base = __shfl(base, 63, 64);
+    const int nl = min(s_nlist, NLIST);
     uint32_t* out = cand + (size_t)b * P.totalKeyCap + g.keyOff;
-    int dst = base + incl - npass;
-#pragma unroll
-    for (int u = 0; u < NIT; u++) {
-        const int kb = (int)((keep >> (4 * u)) & 0xf);
-        if (!kb) continue;
-#pragma unroll
-        for (int k2 = 0; k2 < 4; k2++) {
-            if (!((kb >> k2) & 1)) continue;
-            const uint32_t sc = ((rz[u] >> (8 * k2)) & 0xff) + (uint32_t)zoff;
-            const uint32_t kp = (rpos[u] & 0xfff00000u) | ((((rpos[u] >> 8) & 0xfff) + (uint32_t)k2) << 8) | sc;
+    for (int i0 = 0; i0 < nl; i0 += T) {
+        const int i = i0 + threadIdx.x;
+        bool pass = false;
+        uint32_t kp = 0;
+        if (i < nl) {
+            const uint32_t e = s_list[i];
+            const int sc = (int)(e & 0xff) + zoff;
+            kp = (e & 0xffffff00u) | (uint32_t)sc;
+            pass = !(s_ini[s_listc[i]] && sc < P.iniTh);
+            if (pass && mimg) pass = mimg[(size_t)(e >> 20) * g.pitch + ((e >> 8) & 0xfff)] != 0;      // (no +16: reference quirk)
+        }
+        const unsigned long long bm = __ballot(pass);
+        if (bm == 0) continue;
+        int gbase = 0;
+        if (lane == 0) gbase = atomicAdd(&candCount[b * MAXL + level], __popcll(bm));
+        gbase = __builtin_amdgcn_readfirstlane(gbase);
+        if (pass) {
+            const int dst = gbase + __popcll(bm & ((1ull << lane) - 1ull));
             if (dst < g.keyCap) out[dst] = kp;
-            dst++;
         }
     }
 }
