@@ -64,8 +64,9 @@ def parse():
     ap.add_argument("--cpu-pairs", type=int, default=32)
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
                     help="2 = the DeepLCD / loop-DB / BA chain runs on a second HIP stream beside ORB + match + triangulation")
-    ap.add_argument("--orb-split", type=int, default=2, choices=[1, 2, 4, 8],
-                    help="S > 1 = the 2P images go through S extractor handles on S streams (S equal groups)")
+    ap.add_argument("--orb-split", type=int, default=1, choices=[1, 2, 4, 8],
+                    help="S > 1 = the 2P images go through S extractor handles on S streams (S equal groups; 2 is ~2-3 % faster, "
+                         "but concurrent launches of the same kernel stretch each other, which blurs the per-launch roofline figure)")
     ap.add_argument("--no-join", action="store_true", help="do not join the side stream at the end of every step (streaming across steps)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = debugging aid: several ranks share GPU 0 and the collectives go through host memory")
