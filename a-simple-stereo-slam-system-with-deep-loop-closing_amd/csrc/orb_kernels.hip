@@ -729,8 +729,8 @@ __device__ __forceinline__ int fast9_score_regs(const uint32_t (&r)[7][3], int m
 // arc [2k-1, 2k+7] = p[2k-1] + m8[k], and max(min(m, a), min(m, b)) = min(m, max(a, b)) — 47 packed ops per polarity
 // for two pixels.  Returns z = score - (minTh - 1) for corners at minTh, 0 otherwise (an order-preserving shift: the
 // NMS compares z, the append adds minTh - 1 back).  PAIR selects pixels (2 PAIR, 2 PAIR + 1) of the lane's four.
-template <int PAIR>
-__device__ __forceinline__ s16x2 fast9_score_pair(const uint32_t (&r)[7][3], s16x2 thv) {
+template <int PAIR, int ROW = 0, int NR = 7>
+__device__ __forceinline__ s16x2 fast9_score_pair(const uint32_t (&r)[NR][3], s16x2 thv) {
     constexpr int RX[16] = FAST_RING_X;
     constexpr int RY[16] = FAST_RING_Y;
     constexpr int xc = 3 + 2 * PAIR;
@@ -741,10 +741,10 @@ __device__ __forceinline__ s16x2 fast9_score_pair(const uint32_t (&r)[7][3], s16
         s16x2 q; __builtin_memcpy(&q, &u, 4);
         return q;
     };
-    const s16x2 vv = pick(3, xc);
+    const s16x2 vv = pick(ROW + 3, xc);
     s16x2 p[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) p[i] = pick(3 + RY[i], xc + RX[i]);
+    for (int i = 0; i < 16; i++) p[i] = pick(ROW + 3 + RY[i], xc + RX[i]);
     s16x2 n2[8], x2[8], n4[8], x4[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) { n2[k] = pmin(p[2 * k], p[2 * k + 1]); x2[k] = pmax(p[2 * k], p[2 * k + 1]); }
@@ -892,8 +892,8 @@ __global__ __launch_bounds__(T) void k_fast_cells_v3(OrbPlan P, const uint8_t* _
 // 3x3 strict-maximum test for pixels (2 PAIR, 2 PAIR + 1) of the lane's four, on 16-bit lanes: 9 byte-pair picks,
 // 7 packed max, one packed subtract.  m = 3 rows x 12 bytes of the score map, the lane's pixels at bytes 4..7.
 // Returns bit 0 / bit 1 = pixel is a strict maximum (which implies its score is non-zero); zc = the two centre scores.
-template <int PAIR>
-__device__ __forceinline__ int nms_pair(const uint32_t (&m)[3][3], uint32_t& zc) {
+template <int PAIR, int ROW = 0, int NR = 3>
+__device__ __forceinline__ int nms_pair(const uint32_t (&m)[NR][3], uint32_t& zc) {
     constexpr int x = 4 + 2 * PAIR;
     auto pick = [&](int row, int a) -> s16x2 {
         const int d0 = a >> 2, d1 = ((a & 3) == 3) ? d0 + 1 : d0;
@@ -902,12 +902,12 @@ __device__ __forceinline__ int nms_pair(const uint32_t (&m)[3][3], uint32_t& zc)
         s16x2 q; __builtin_memcpy(&q, &u, 4);
         return q;
     };
-    const s16x2 c = pick(1, x);
-    s16x2 nb = pmax(pick(0, x - 1), pick(0, x));
-    nb = pmax(nb, pick(0, x + 1));
-    nb = pmax(nb, pmax(pick(1, x - 1), pick(1, x + 1)));
-    nb = pmax(nb, pmax(pick(2, x - 1), pick(2, x)));
-    nb = pmax(nb, pick(2, x + 1));
+    const s16x2 c = pick(ROW + 1, x);
+    s16x2 nb = pmax(pick(ROW, x - 1), pick(ROW, x));
+    nb = pmax(nb, pick(ROW, x + 1));
+    nb = pmax(nb, pmax(pick(ROW + 1, x - 1), pick(ROW + 1, x + 1)));
+    nb = pmax(nb, pmax(pick(ROW + 2, x - 1), pick(ROW + 2, x)));
+    nb = pmax(nb, pick(ROW + 2, x + 1));
     const s16x2 d = c - nb;
     __builtin_memcpy(&zc, &c, 4);
     return ((int)d.x > 0 ? 1 : 0) | ((int)d.y > 0 ? 2 : 0);
@@ -935,9 +935,9 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
     constexpr int T = 256;
     constexpr int TP = (15 + G * CW + 6 + 16 + 15) & ~15;              // row pitch of the staged tile (16-byte aligned rows)
     constexpr int NQ = TP / 16;                                        // 16-byte groups per row
-    constexpr int TROWS = CW + 6;
+    constexpr int TROWS = CW + 6 + 1;                                  // + 1: the second row of a work item reads one row further
     constexpr int SP = (CW + 4 + 8 + 3) & ~3;
-    constexpr int SROWS = CW + 2;
+    constexpr int SROWS = CW + 2 + 1;
     constexpr int NLIST = G * ((CW + 1) / 2) * ((CW + 1) / 2);         // a cell of a x b pixels holds at most ceil(a/2) ceil(b/2) strict maxima
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[TROWS * TP + 16];
     __shared__ __attribute__((aligned(16))) uint8_t s_score[G][SROWS * SP + 16];
@@ -1001,8 +1001,10 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
 
     const s16x2 thv = {(short)P.minTh, (short)P.minTh};
     const int zoff = P.minTh - 1;                                      // the score map holds z = score - zoff
-    const int ngr = (g.wCell + 3) >> 2, per_cell = ngr * hc, nitems = ncell * per_cell;
-    // q -> (cell c, row cy, 4-pixel group gi) without integer division: q < 2^12, so a float reciprocal + one fix-up is exact
+    // work item = 4 pixels x 2 rows: the two 7-row windows share 6 rows (8 rows x 16 bytes from LDS instead of 14)
+    const int hc2 = (hc + 1) >> 1;
+    const int ngr = (g.wCell + 3) >> 2, per_cell = ngr * hc2, nitems = ncell * per_cell;
+    // q -> (cell c, row pair cy2, 4-pixel group gi) without integer division: q < 2^12, so a float reciprocal + one fix-up is exact
     const float inv_pc = 1.0f / (float)per_cell, inv_ngr = 1.0f / (float)ngr;
     auto split = [&](int q, int& c, int& cy, int& gi) {
         c = (int)(((float)q + 0.5f) * inv_pc);
@@ -1013,28 +1015,35 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
         if (gi < 0) { cy--; gi += ngr; } else if (gi >= ngr) { cy++; gi -= ngr; }
     };
     for (int q = threadIdx.x; q < nitems; q += T) {
-        int c, cy, gi;
-        split(q, c, cy, gi);
+        int c, cy2, gi;
+        split(q, c, cy2, gi);
         const int wc = (c == 0) ? wcs[0] : (c == 1) ? wcs[1 % G] : (c == 2) ? wcs[2 % G] : wcs[3 % G];
-        const int cx = 4 * gi;
+        const int cx = 4 * gi, cy = 2 * cy2;
         if (cx >= wc) continue;
         const int col = off + c * g.wCell + cx;                        // tile byte of ROI column cx of cell c
         const uint32_t sh = (uint32_t)(col & 3);
-        uint32_t r[7][3];
+        uint32_t r[8][3];                                              // tile rows cy .. cy+7 (row cy+7 may lie below the ROI: staged as zeros / unused)
 #pragma unroll
-        for (int j = 0; j < 7; j++) {
+        for (int j = 0; j < 8; j++) {
             const uint32_t* rp = reinterpret_cast<const uint32_t*>(&s_tile[(cy + j) * TP + (col & ~3)]);
             const uint32_t w0 = rp[0], w1 = rp[1], w2 = rp[2], w3 = rp[3];
             r[j][0] = __builtin_amdgcn_alignbyte(w1, w0, sh);
             r[j][1] = __builtin_amdgcn_alignbyte(w2, w1, sh);
             r[j][2] = __builtin_amdgcn_alignbyte(w3, w2, sh);
         }
-        const s16x2 za = fast9_score_pair<0>(r, thv), zb = fast9_score_pair<1>(r, thv);
-        uint32_t ua, ub;
-        __builtin_memcpy(&ua, &za, 4); __builtin_memcpy(&ub, &zb, 4);
-        uint32_t packed = __builtin_amdgcn_perm(ub, ua, 0x06040200u);           // the four z bytes
-        if (wc - cx < 4) packed &= (1u << (8 * (wc - cx))) - 1u;
-        *reinterpret_cast<uint32_t*>(&s_score[c][(cy + 1) * SP + 4 + cx]) = packed;
+        const uint32_t keepm = (wc - cx < 4) ? (1u << (8 * (wc - cx))) - 1u : 0xffffffffu;
+        {
+            const s16x2 za = fast9_score_pair<0, 0, 8>(r, thv), zb = fast9_score_pair<1, 0, 8>(r, thv);
+            uint32_t ua, ub;
+            __builtin_memcpy(&ua, &za, 4); __builtin_memcpy(&ub, &zb, 4);
+            *reinterpret_cast<uint32_t*>(&s_score[c][(cy + 1) * SP + 4 + cx]) = __builtin_amdgcn_perm(ub, ua, 0x06040200u) & keepm;   // the four z bytes
+        }
+        if (cy + 1 < hc) {
+            const s16x2 za = fast9_score_pair<0, 1, 8>(r, thv), zb = fast9_score_pair<1, 1, 8>(r, thv);
+            uint32_t ua, ub;
+            __builtin_memcpy(&ua, &za, 4); __builtin_memcpy(&ub, &zb, 4);
+            *reinterpret_cast<uint32_t*>(&s_score[c][(cy + 2) * SP + 4 + cx]) = __builtin_amdgcn_perm(ub, ua, 0x06040200u) & keepm;
+        }
     }
     __syncthreads();
 #if defined(MYSLAM_FAST_STOP) && MYSLAM_FAST_STOP == 2
@@ -1045,23 +1054,30 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
     const int lane = threadIdx.x & 63;
     for (int q0 = 0; q0 < nitems; q0 += T) {                           // uniform trip count: the wave-wide scan needs every lane
         const int q = q0 + threadIdx.x;
-        int mk = 0, c = 0, cy = 0, gi = 0;
-        uint32_t zc = 0;
+        int mk = 0, c = 0, cy = 0, gi = 0;              // mk: bits 0-3 row cy, bits 4-7 row cy+1
+        uint32_t zc0 = 0, zc1 = 0;
         if (q < nitems) {
-            split(q, c, cy, gi);
+            int cy2;
+            split(q, c, cy2, gi);
+            cy = 2 * cy2;
             const int wc = (c == 0) ? wcs[0] : (c == 1) ? wcs[1 % G] : (c == 2) ? wcs[2 % G] : wcs[3 % G];
             if (4 * gi < wc) {
-                uint32_t m[3][3];
+                uint32_t m[4][3];                                      // score-map rows cy-1 .. cy+2 (the map has a zero border row)
 #pragma unroll
-                for (int j = 0; j < 3; j++) {
+                for (int j = 0; j < 4; j++) {
                     const uint32_t* rp = reinterpret_cast<const uint32_t*>(&s_score[c][(cy + j) * SP + 4 * gi]);
                     m[j][0] = rp[0]; m[j][1] = rp[1]; m[j][2] = rp[2];
                 }
-                if (m[1][1] != 0) {                                    // else none of the four pixels is a corner
-                    uint32_t za, zb;
-                    const int ma = nms_pair<0>(m, za), mb = nms_pair<1>(m, zb);
+                uint32_t za, zb;
+                if (m[1][1] != 0) {                                    // else none of the four pixels of this row is a corner
+                    const int ma = nms_pair<0, 0, 4>(m, za), mb = nms_pair<1, 0, 4>(m, zb);
                     mk = ma | (mb << 2);
-                    zc = m[1][1];
+                    zc0 = m[1][1];
+                }
+                if (cy + 1 < hc && m[2][1] != 0) {
+                    const int ma = nms_pair<0, 1, 4>(m, za), mb = nms_pair<1, 1, 4>(m, zb);
+                    mk |= (ma | (mb << 2)) << 4;
+                    zc1 = m[2][1];
                 }
             }
         }
@@ -1074,13 +1090,13 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
         if (lane == 63) base = atomicAdd(&s_nlist, total);
         base = __builtin_amdgcn_readlane(base, 63);
         if (mk) {
-            const int px = 4 * gi + 3 + (cj0 + c) * g.wCell, py = cy + 3 + ci * g.hCell;     // border-relative, of pixel 0
+            const int px = 4 * gi + 3 + (cj0 + c) * g.wCell, py = cy + 3 + ci * g.hCell;     // border-relative, of pixel 0 of the first row
             int dst = base + incl - cnt, zmax = 0, bits = mk;
             while (bits) {
                 const int k2 = __ffs(bits) - 1;
                 bits &= bits - 1;
-                const uint32_t z = (zc >> (8 * k2)) & 0xff;
-                if (dst < NLIST) { s_list[dst] = ((uint32_t)py << 20) | ((uint32_t)(px + k2) << 8) | z; s_listc[dst] = (uint8_t)c; }
+                const uint32_t z = (((k2 & 4) ? zc1 : zc0) >> (8 * (k2 & 3))) & 0xff;
+                if (dst < NLIST) { s_list[dst] = ((uint32_t)(py + (k2 >> 2)) << 20) | ((uint32_t)(px + (k2 & 3)) << 8) | z; s_listc[dst] = (uint8_t)c; }
                 dst++;
                 zmax = max(zmax, (int)z);
             }
