@@ -729,15 +729,25 @@ __device__ __forceinline__ int fast9_score_regs(const uint32_t (&r)[7][3], int m
 // arc [2k-1, 2k+7] = p[2k-1] + m8[k], and max(min(m, a), min(m, b)) = min(m, max(a, b)) — 47 packed ops per polarity
 // for two pixels.  Returns z = score - (minTh - 1) for corners at minTh, 0 otherwise (an order-preserving shift: the
 // NMS compares z, the append adds minTh - 1 back).  PAIR selects pixels (2 PAIR, 2 PAIR + 1) of the lane's four.
+// gfx950 has three-input packed minimum / maximum only for f16.  Ring values are carried as 0x6400 | p in each 16-bit lane:
+// that is the f16 number 1024 + p (exact, normal), whose bit patterns order exactly like the integers, so the two-input steps
+// stay v_pk_min/max_i16, the three-input steps are v_pk_minimum3/maximum3_f16 on the same registers, and differences of two
+// such values are plain 16-bit integer subtractions.
+__device__ __forceinline__ s16x2 pmin3(s16x2 a, s16x2 b, s16x2 c) { s16x2 d; asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ s16x2 pmax3(s16x2 a, s16x2 b, s16x2 c) { s16x2 d; asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+
 template <int PAIR, int ROW = 0, int NR = 7>
 __device__ __forceinline__ s16x2 fast9_score_pair(const uint32_t (&r)[NR][3], s16x2 thv) {
     constexpr int RX[16] = FAST_RING_X;
     constexpr int RY[16] = FAST_RING_Y;
     constexpr int xc = 3 + 2 * PAIR;
-    auto pick = [&](int row, int a) -> s16x2 {          // bytes a, a+1 of window row `row` as two 16-bit lanes
-        const int d0 = a >> 2, d1 = ((a & 3) == 3) ? d0 + 1 : d0;
-        const uint32_t u = __builtin_amdgcn_perm(r[row][d1], r[row][d0],
-                                                 0x0c000c00u | ((((a & 3) == 3) ? 4u : (uint32_t)(a & 3) + 1u) << 16) | (uint32_t)(a & 3));
+    constexpr uint32_t K64 = 0x64646464u;
+    auto pick = [&](int row, int a) -> s16x2 {          // bytes a, a+1 of window row `row` as (0x6400 | byte) in two 16-bit lanes
+        uint32_t u;
+        if ((a & 3) == 3)                               // the pair straddles two dwords: no room for the constant in the same v_perm
+            u = __builtin_amdgcn_perm(r[row][(a >> 2) + 1], r[row][a >> 2], 0x0c040c03u) | 0x64006400u;
+        else
+            u = __builtin_amdgcn_perm(K64, r[row][a >> 2], 0x04000400u | ((uint32_t)(a & 3) + 1u) << 16 | (uint32_t)(a & 3));
         s16x2 q; __builtin_memcpy(&q, &u, 4);
         return q;
     };
@@ -745,20 +755,20 @@ __device__ __forceinline__ s16x2 fast9_score_pair(const uint32_t (&r)[NR][3], s1
     s16x2 p[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) p[i] = pick(ROW + 3 + RY[i], xc + RX[i]);
-    s16x2 n2[8], x2[8], n4[8], x4[8];
+    s16x2 n2[8], x2[8], n4[8], x4[8], ub[8], ud[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) { n2[k] = pmin(p[2 * k], p[2 * k + 1]); x2[k] = pmax(p[2 * k], p[2 * k + 1]); }
 #pragma unroll
     for (int k = 0; k < 8; k++) { n4[k] = pmin(n2[k], n2[(k + 1) & 7]); x4[k] = pmax(x2[k], x2[(k + 1) & 7]); }
-    s16x2 brt = {0, 0}, drk = {255, 255};
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const s16x2 n8 = pmin(n4[k], n4[(k + 2) & 7]), x8 = pmax(x4[k], x4[(k + 2) & 7]);       // ring positions 2k .. 2k+7
         const s16x2 a = p[(2 * k + 8) & 15], c = p[(2 * k + 15) & 15];
-        brt = pmax(brt, pmin(n8, pmax(a, c)));
-        drk = pmin(drk, pmax(x8, pmin(a, c)));
+        ub[k] = pmin3(n4[k], n4[(k + 2) & 7], pmax(a, c));              // min over ring positions 2k .. 2k+7 and max(a, c)
+        ud[k] = pmax3(x4[k], x4[(k + 2) & 7], pmin(a, c));
     }
-    const s16x2 sraw = pmax(brt - vv, vv - drk);             // score + 1
+    const s16x2 brt = pmax(pmax3(pmax3(ub[0], ub[1], ub[2]), pmax3(ub[3], ub[4], ub[5]), ub[6]), ub[7]);
+    const s16x2 drk = pmin(pmin3(pmin3(ud[0], ud[1], ud[2]), pmin3(ud[3], ud[4], ud[5]), ud[6]), ud[7]);
+    const s16x2 sraw = pmax(brt - vv, vv - drk);             // score + 1 (the 0x6400 offsets cancel)
     return pmax(sraw, thv) - thv;
 }
 
