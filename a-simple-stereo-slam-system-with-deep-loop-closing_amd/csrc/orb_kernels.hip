@@ -951,8 +951,11 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
     constexpr int NLIST = G * ((CW + 1) / 2) * ((CW + 1) / 2);         // a cell of a x b pixels holds at most ceil(a/2) ceil(b/2) strict maxima
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[TROWS * TP + 16];
     __shared__ __attribute__((aligned(16))) uint8_t s_score[G][SROWS * SP + 16];
-    __shared__ uint32_t s_list[NLIST];                                 // strict maxima of the strip: py<<20 | px<<8 | z
-    __shared__ uint8_t s_listc[NLIST];                                 // ... and their cell
+    // strict maxima of the strip (py<<20 | px<<8 | z) and their cells: the list lives in the tile's LDS, which is dead once the
+    // scores are computed (5 bytes per entry, NLIST entries always fit: checked below)
+    static_assert(NLIST * 5 <= TROWS * TP, "maxima list must fit into the staged tile");
+    uint32_t* const s_list = reinterpret_cast<uint32_t*>(s_tile);
+    uint8_t* const s_listc = s_tile + 4 * NLIST;
     __shared__ int s_ini[G], s_nlist;
 
     const int b = blockIdx.y;
@@ -2177,7 +2180,9 @@ void launch_fast(const OrbPlan& P, const uint8_t* pyr, size_t pyrStride, const u
     static const char* envv = getenv("MYSLAM_FAST_V");          // tuning aid: 2 = LDS byte-read two-phase kernel, 3 = register tiles
     const int V = envv ? atoi(envv) : 4;
     if (V == 4) {      // strips of 4 cells per block
-        if (cw <= 40) hipLaunchKernelGGL((k_fast_strip<40, 4>), dim3(P.nstrips, batch), dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount);
+        static const char* envl = getenv("MYSLAM_FAST_LDS_PAD");      // tuning aid: extra dynamic LDS bytes (caps resident blocks per CU)
+        const size_t pad = envl ? (size_t)atoi(envl) : 0;
+        if (cw <= 40) hipLaunchKernelGGL((k_fast_strip<40, 4>), dim3(P.nstrips, batch), dim3(256), pad, s, P, pyr, pyrStride, maskPyr, cand, candCount);
         else hipLaunchKernelGGL((k_fast_strip<MAX_CELL, 4>), dim3(P.nstrips, batch), dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount);
         return;
     }
