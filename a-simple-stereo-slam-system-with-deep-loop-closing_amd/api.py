@@ -105,7 +105,9 @@ class ORBextractor:
         _check(lib().myslam_orb_get_tables(self._h, _p(sc), _p(isc), _p(npl), _p(um)), "myslam_orb_get_tables")
         return sc, isc, npl, um
 
-    def max_keypoints(self):
+    def max_keypoints(self, rows=None, cols=None):
+        if rows is not None:
+            return lib().myslam_orb_max_keypoints_for(self._h, int(rows), int(cols))
         return lib().myslam_orb_max_keypoints(self._h)
 
     @staticmethod
@@ -116,7 +118,7 @@ class ORBextractor:
 
     def DetectAndCompute(self, image, mask=None, cap=None):
         img = self._img(image)
-        cap = cap or self.max_keypoints()
+        cap = cap or self.max_keypoints(*img.shape)
         kps = np.zeros(cap, KP_DTYPE); desc = np.zeros((cap, 32), np.uint8); n = C.c_int()
         m = self._img(mask) if mask is not None else None
         _check(lib().myslam_orb_detect_and_compute(self._h, _p(img), img.shape[0], img.shape[1], img.strides[0],
@@ -126,7 +128,7 @@ class ORBextractor:
 
     def Detect(self, image, mask=None, cap=None):
         img = self._img(image)
-        cap = cap or self.max_keypoints()
+        cap = cap or self.max_keypoints(*img.shape)
         kps = np.zeros(cap, KP_DTYPE); n = C.c_int()
         m = self._img(mask) if mask is not None else None
         _check(lib().myslam_orb_detect(self._h, _p(img), img.shape[0], img.shape[1], img.strides[0],

@@ -411,6 +411,20 @@ int myslam_orb_max_keypoints(const myslam_orb* h) {
     return std::max(s, std::max(h->nfeatures + 3, 32));
 }
 
+int myslam_orb_max_keypoints_for(const myslam_orb* h, int rows, int cols) {
+    if (!h || rows < 1 || cols < 1) return MYSLAM_ERR_INVALID;
+    // exact bound for this image size: level l returns at most max(N_l + 3, 4 nIni_l) nodes, nIni_l = round of the level's aspect ratio
+    int s = 0, first = 0;
+    for (int l = 0; l < h->nlevels; l++) {
+        const int w = cv_round((float)cols * h->invScale[l]), hh = cv_round((float)rows * h->invScale[l]);
+        const int bx = w - EDGE_THRESHOLD + 3 - MIN_BORDER, by = hh - EDGE_THRESHOLD + 3 - MIN_BORDER;
+        const int nIni = (bx > 0 && by > 0) ? std::max(1, (int)roundf((float)bx / (float)by)) : 1;
+        s += std::max(h->nPerLevel[l] + 3, 4 * nIni);
+        if (l == 0) first = std::max(h->nfeatures + 3, 4 * nIni);
+    }
+    return std::max(std::max(s, first), 32);
+}
+
 int myslam_orb_detect_and_compute_batch(myslam_orb* h, const uint8_t* d_imgs, int batch, int rows, int cols, int step,
                                         size_t img_stride, const uint8_t* d_masks, myslam_keypoint* d_kps, uint8_t* d_desc,
                                         int32_t* d_counts, int32_t* d_status, int cap) {

@@ -58,7 +58,7 @@ class ORBextractor {
     void DetectAndCompute(const ImageView& image, const ImageView& mask, std::vector<KeyPoint>& keypoints, Descriptors& descriptors) {
         keypoints.clear(); descriptors.clear();
         if (image.empty()) return;                                               // ORBextractor.cpp:924
-        const int cap = myslam_orb_max_keypoints(h_);
+        const int cap = myslam_orb_max_keypoints_for(h_, image.rows, image.cols);
         keypoints.resize(cap); descriptors.resize((size_t)cap * 32);
         int n = 0;
         check(myslam_orb_detect_and_compute(h_, image.data, image.rows, image.cols, image.step, mask.empty() ? nullptr : mask.data,
@@ -69,7 +69,7 @@ class ORBextractor {
     void Detect(const ImageView& image, const ImageView& mask, std::vector<KeyPoint>& keypoints) {
         keypoints.clear();
         if (image.empty()) return;                                               // ORBextractor.cpp:990
-        const int cap = myslam_orb_max_keypoints(h_);
+        const int cap = myslam_orb_max_keypoints_for(h_, image.rows, image.cols);
         keypoints.resize(cap);
         int n = 0;
         check(myslam_orb_detect(h_, image.data, image.rows, image.cols, image.step, mask.empty() ? nullptr : mask.data, mask.step,

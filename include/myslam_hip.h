@@ -67,6 +67,9 @@ int myslam_orb_get_tables(const myslam_orb* h, float* scale, float* inv_scale, i
 /* upper bound of keypoints DetectAndCompute / Detect can return for one image: sum over levels of
  * max(N_level + 3, 32) — the oct-tree stops only after a split pushed it to >= N, and its first round is unconditional */
 int myslam_orb_max_keypoints(const myslam_orb* h);
+/* the same bound for one image size, exact for ANY aspect ratio (a level with nIni = round(width/height) root nodes can return
+ * 4*nIni key-points even when its budget is smaller, ORBextractor.cpp:645-716); use it to size kps / desc for that size */
+int myslam_orb_max_keypoints_for(const myslam_orb* h, int rows, int cols);
 
 /* void DetectAndCompute(image, mask, keypoints, descriptors)   ORBextractor.h:61-63, .cpp:922-985
  * mask may be NULL (= all 255).  desc: cap x 32 bytes. */

@@ -262,3 +262,19 @@ def test_many_random_images_small(api, oracle, synth):
         rk, rd = oracle.detect_and_compute(oracle.params(nfeat), img)
         assert _kp_equal(kps, rk), (i, h, w, nfeat, _explain(kps, rk))
         assert np.array_equal(desc, rd), (i, h, w, nfeat)
+
+
+def test_wide_image_small_budget_capacity(api, oracle, synth):
+    """A very wide image has many root nodes (nIni = round(w/h)); the first unconditional split returns up to 4*nIni key-points per
+    level even when the level's budget is smaller (ORBextractor.cpp:645-716).  The size-aware capacity query must cover it."""
+    img = synth.random_image(31337, 118, 1010)
+    ext = api.ORBextractor(60, 1.2, 3)
+    p = oracle.params(60); p.nlevels = 3
+    rk, rd = oracle.detect_and_compute(p, img)
+    gk, gd = ext.DetectAndCompute(img)
+    assert gk.tobytes() == rk.tobytes() and np.array_equal(gd, rd)
+    assert len(rk) > 60 + 3 * 3                               # more key-points than nfeatures: the reference behaves this way
+    assert ext.max_keypoints(118, 1010) >= len(rk)
+    with pytest.raises(api.MyslamError) as e:                 # an undersized caller buffer is refused, never truncated
+        ext.DetectAndCompute(img, cap=len(rk) - 1)
+    assert e.value.code == api.ERR_CAPACITY

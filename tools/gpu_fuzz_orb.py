@@ -1,0 +1,41 @@
+"""GPU fuzz: DetectAndCompute / pyramid / blur on random image sizes and parameters vs the oracle (bit-exact)."""
+import sys, numpy as np
+sys.path.insert(0, ".")
+import torch  # noqa: F401  (loads the HIP runtime torch ships before ours)
+import __graft_entry__ as g
+pkg = g.load_package(); api, synth = pkg.api, pkg.synth
+sys.path.insert(0, "oracle")
+from pyoracle import Oracle
+o = Oracle()
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+bad = 0
+for it in range(N):
+    h = int(rng.integers(110, 520)); w = int(rng.integers(140, 1300))
+    nf = int(rng.choice([60, 200, 500, 1000, 2000])); nl = int(rng.choice([1, 3, 5, 8])); sf = float(rng.choice([1.1, 1.2, 1.2, 1.3]))
+    kind = "noise" if rng.random() < 0.2 else "texture"
+    img = np.ascontiguousarray(synth.random_image(int(rng.integers(1 << 30)), h, w, kind))
+    try:
+        ext = api.ORBextractor(nf, sf, nl)
+    except Exception as e:
+        print("create failed", h, w, nf, nl, sf, e); continue
+    p = o.params(nf); p.scale_factor = sf; p.nlevels = nl
+    try:
+        gk, gd = ext.DetectAndCompute(img)
+    except api.MyslamError as e:
+        # image too small for the FAST grid at some level: the oracle must refuse as well
+        try:
+            o.detect_and_compute(p, img, cap=20000); print("GPU refused but oracle ran", h, w, nf, nl, sf, e); bad += 1
+        except AssertionError:
+            pass
+        continue
+    rk, rd = o.detect_and_compute(p, img, cap=ext.max_keypoints(h, w) + 8)
+    ok = gk.tobytes() == rk.tobytes() and np.array_equal(gd, rd)
+    if ok:
+        for l in range(nl):
+            ok = ok and np.array_equal(ext.debug_pyramid(img, l, blurred=True), o.blur7(o.pyramid(p, img)[l], 0))
+    if not ok:
+        bad += 1
+        print("MISMATCH", dict(h=h, w=w, nf=nf, nl=nl, sf=sf, kind=kind, n_gpu=len(gk), n_ref=len(rk)))
+print(f"fuzz done: {N} cases, {bad} mismatches")
+sys.exit(1 if bad else 0)
