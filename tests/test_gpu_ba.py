@@ -153,3 +153,33 @@ def test_ba_optimize_active_map_batch(api, oracle, synth):
         assert (int(rd[w]), int(no[w])) == (rr, rn)
         assert np.allclose(d[0][w, :len(p)].cpu().numpy(), rp, rtol=1e-7, atol=1e-8)
         assert np.allclose(chi[w, :len(a)].cpu().numpy(), rchi, rtol=1e-6, atol=1e-9)
+
+
+def test_ba_duplicate_edges_and_degenerate_landmarks(api, oracle, synth):
+    """Two edges between the same (pose, landmark) pair (their Hpl blocks add up: the staged Schur operand then needs the atomic
+    path), landmarks with a single view, landmarks without any edge, a window where every landmark is fixed."""
+    rng = np.random.default_rng(4)
+    poses, pts, ep, el, obs, fixed, K = synth.ba_problem(seed=77, n_kf=7, n_mp=90)
+    for k in (5, 200, 201, 400):                                   # duplicates inside their landmark group
+        ep = np.insert(ep, k, ep[k]); el = np.insert(el, k, el[k]); obs = np.insert(obs, k, obs[k] + rng.normal(0, 0.7, 2), axis=0)
+    keep = np.ones(len(ep), bool)
+    for l in (3, 17, 40):
+        keep[np.where(el == l)[0][1:]] = False                     # single view
+    keep[el == 60] = False                                         # no edge at all
+    ep, el, obs = ep[keep], el[keep], obs[keep]
+    for fx in (fixed, np.ones_like(fixed)):
+        H = api.ba_build(poses, pts, ep, el, obs, fx, K); Hr = oracle.ba_build(poses, pts, ep, el, obs, fx, K)
+        for a, b in zip(H, Hr):
+            assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max())
+        gp, gx, gchi, git = api.ba_optimize(poses, pts, ep, el, obs, fx, K, iters=10)
+        rp, rx, rchi, rit = oracle.ba_optimize(poses, pts, ep, el, obs, fx, K, iters=10)
+        # with every landmark fixed the problem converges before the 10th iteration: the gain ratio is then 0 +- rounding noise
+        # and the accept / reject decisions (hence the iteration count) are not reproducible across summation orders
+        converged = bool(fx.all())
+        assert converged or git == rit
+        assert gchi == pytest.approx(rchi, rel=1e-7)
+        tol = 1e-6 if converged else 1e-7
+        assert np.allclose(gp, rp, rtol=tol, atol=tol) and np.allclose(gx, rx, rtol=tol, atol=tol)
+    p1 = api.ba_optimize(poses[:1], pts, np.zeros_like(ep[el < 30]), el[el < 30], obs[el < 30], fixed, K, iters=5)      # one pose
+    r1 = oracle.ba_optimize(poses[:1], pts, np.zeros_like(ep[el < 30]), el[el < 30], obs[el < 30], fixed, K, iters=5)
+    assert p1[3] == r1[3] and np.allclose(p1[0], r1[0], rtol=1e-6, atol=1e-7)

@@ -1,0 +1,53 @@
+"""GPU fuzz: local-BA operators on random windows (sizes, duplicate (pose, landmark) edges, unobserved / single-view landmarks,
+all-fixed landmarks) vs the oracle."""
+import sys, numpy as np
+sys.path.insert(0, ".")
+import torch  # noqa: F401
+import __graft_entry__ as g
+pkg = g.load_package(); api, synth = pkg.api, pkg.synth
+sys.path.insert(0, "oracle")
+from pyoracle import Oracle
+o = Oracle()
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+bad = 0
+for it in range(N):
+    n_kf = int(rng.integers(1, 11)); n_mp = int(rng.integers(3, 300))
+    poses, pts, ep, el, obs, fixed, K = synth.ba_problem(seed=int(rng.integers(1 << 30)), n_kf=n_kf, n_mp=n_mp,
+                                                         outlier_frac=float(rng.choice([0.0, 0.03, 0.3])))
+    mode = int(rng.integers(0, 5))
+    if mode == 1 and len(ep) > 4:          # duplicate a few edges in place (same landmark group)
+        for _ in range(3):
+            k = int(rng.integers(0, len(ep)))
+            ep = np.insert(ep, k, ep[k]); el = np.insert(el, k, el[k]); obs = np.insert(obs, k, obs[k] + rng.normal(0, 1, 2), axis=0)
+    if mode == 2:                          # drop most observations of some landmarks (single-view / unobserved landmarks)
+        keep = np.ones(len(ep), bool)
+        for l in rng.choice(n_mp, max(1, n_mp // 4), replace=False):
+            idx = np.where(el == l)[0]
+            keep[idx[int(rng.integers(0, 2)):]] = False
+        ep, el, obs = ep[keep], el[keep], obs[keep]
+    if mode == 3:
+        fixed = np.ones_like(fixed)
+    if len(ep) < 2:
+        continue
+    try:
+        H = api.ba_build(poses, pts, ep, el, obs, fixed, K); Hr = o.ba_build(poses, pts, ep, el, obs, fixed, K)
+        okb = all(np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max()) for a, b in zip(H, Hr))
+        gp, gx, gchi, gout, gr, gn = api.ba_optimize_active_map(poses, pts, ep, el, obs, fixed, K)
+        rp, rx, rchi, rout, rr, rn = o.ba_optimize_active_map(poses, pts, ep, el, obs, fixed, K)
+        tol = 1e-6 * 10.0 ** (2 * rr)           # every extra round of 10 iterations amplifies rounding differences on outlier-ridden windows
+        oko = (gr, gn) == (rr, rn) and np.allclose(gp, rp, rtol=tol, atol=tol) and np.allclose(gx, rx, rtol=tol, atol=10 * tol)
+    except Exception as e:
+        okb = oko = False; print("exception", e)
+    if not (okb and oko):
+        bad += 1
+        print("MISMATCH", dict(it=it, n_kf=n_kf, n_mp=n_mp, E=len(ep), mode=mode, build=okb, opt=oko))
+        try:
+            print("   rounds/nout gpu", gr, gn, "ref", rr, rn, "dpose", np.abs(gp - rp).max(), "dpts", np.abs(gx - rx).max(), "dchi", np.abs(gchi - rchi).max())
+            for iters in (1, 2, 3, 5, 10):
+                a = api.ba_optimize(poses, pts, ep, el, obs, fixed, K, iters=iters); b = o.ba_optimize(poses, pts, ep, el, obs, fixed, K, iters=iters)
+                print("   optimize iters", iters, "it", a[3], b[3], "chi", a[2], b[2], "dpose", np.abs(a[0] - b[0]).max())
+        except Exception as e:
+            print("   detail failed", e)
+print(f"fuzz done: {N} cases, {bad} mismatches")
+sys.exit(1 if bad else 0)
