@@ -428,19 +428,20 @@ class LKTracker:
 
 
 # ---------------------------------------------------------------------------------- pose-only optimisation
-def pose_only_optimize(pose, pts3d, obs, K, chi2_th=5.991, rounds=4, iters=10):
+def pose_only_optimize(pose, pts3d, obs, K, chi2_th=5.991, rounds=4, iters=10, pre_optimize=0):
     """The g2o part of Frontend::EstimateCurrentPose (src/frontend.cpp:176-276).  Returns (pose7, outlier flags, inlier count)."""
     pose = np.ascontiguousarray(pose, np.float64).copy()
     pts3d = np.ascontiguousarray(pts3d, np.float64).reshape(-1, 3); obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 2)
     n = len(pts3d); out = np.zeros(max(n, 1), np.uint8); ni = C.c_int()
     _check(lib().myslam_pose_only_optimize(_p(pose), _p(pts3d), _p(obs), n, C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]),
-                                           C.c_double(K[3]), C.c_double(chi2_th), int(rounds), int(iters), _p(out), C.byref(ni)),
+                                           C.c_double(K[3]), C.c_double(chi2_th), int(rounds), int(iters), int(pre_optimize), _p(out), C.byref(ni)),
            "myslam_pose_only_optimize")
     return pose, out[:n].astype(bool), ni.value
 
 
-def pose_only_optimize_batch(d_poses, d_pts3d, d_obs, d_counts, batch, cap, K, chi2_th, rounds, iters, d_outlier, d_ninl, d_status, stream=0):
+def pose_only_optimize_batch(d_poses, d_pts3d, d_obs, d_counts, batch, cap, K, chi2_th, rounds, iters, d_outlier, d_ninl, d_status, stream=0,
+                             pre_optimize=0):
     _check(lib().myslam_pose_only_optimize_batch(C.c_void_p(d_poses), C.c_void_p(d_pts3d), C.c_void_p(d_obs), C.c_void_p(d_counts), batch, cap,
                                                  C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]), C.c_double(chi2_th),
-                                                 int(rounds), int(iters), C.c_void_p(d_outlier), C.c_void_p(d_ninl), C.c_void_p(d_status),
+                                                 int(rounds), int(iters), int(pre_optimize), C.c_void_p(d_outlier), C.c_void_p(d_ninl), C.c_void_p(d_status),
                                                  C.c_void_p(stream or None)), "myslam_pose_only_optimize_batch")

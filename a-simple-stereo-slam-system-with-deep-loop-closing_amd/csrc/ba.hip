@@ -832,7 +832,7 @@ constexpr int PO_EPT = 8;                                  // edges per thread -
 
 struct PoseOnlyArgs {
     double* poses; const double* pts3d; const double* obs; const int32_t* counts; int n_fixed, cap;
-    double fx, fy, cx, cy, chi2_th; int rounds, iters;
+    double fx, fy, cx, cy, chi2_th; int rounds, iters, pre;
     uint8_t* outlier; int32_t* n_inliers; int32_t* status;
 };
 
@@ -886,7 +886,7 @@ __global__ __launch_bounds__(BA_NT) void k_pose_only(PoseOnlyArgs a) {
         return block_sum(s, s_red);
     };
     int cntOut = 0;
-    for (int round = 0; round < a.rounds; round++) {
+    for (int round = -a.pre; round < a.rounds; round++) {       // round < 0: the unclassified optimize() of LoopClosing::OptimizeCurrentPose
         double na = 0;
 #pragma unroll
         for (int k = 0; k < PO_EPT; k++) na += (t + k * BA_NT < n && !((level >> k) & 1)) ? 1.0 : 0.0;
@@ -994,6 +994,7 @@ __global__ __launch_bounds__(BA_NT) void k_pose_only(PoseOnlyArgs a) {
                 if (qmax == 10 || rho == 0 || !isfinite(s_sc[0])) break;
             }
         }
+        if (round < 0) continue;
         // ---- classify every edge (frontend.cpp:229-242) ----
         double co = 0;
 #pragma unroll
@@ -1196,11 +1197,12 @@ int myslam_ba_optimize_active_map(double* poses, int nposes, double* points, int
 }
 
 int myslam_pose_only_optimize_batch(double* d_poses, const double* d_pts3d, const double* d_obs, const int32_t* d_counts, int batch, int cap,
-                                    double fx, double fy, double cx, double cy, double chi2_th, int rounds, int iters,
+                                    double fx, double fy, double cx, double cy, double chi2_th, int rounds, int iters, int pre_optimize,
                                     uint8_t* d_outlier, int32_t* d_n_inliers, int32_t* d_status, void* hip_stream) {
-    if (!d_poses || !d_pts3d || !d_obs || !d_counts || batch < 1 || cap < 1 || rounds < 1 || iters < 1 || !d_outlier || !d_n_inliers || !d_status)
+    if (!d_poses || !d_pts3d || !d_obs || !d_counts || batch < 1 || cap < 1 || rounds < 1 || iters < 1 || pre_optimize < 0 || !d_outlier ||
+        !d_n_inliers || !d_status)
         return MYSLAM_ERR_INVALID;
-    PoseOnlyArgs a{d_poses, d_pts3d, d_obs, d_counts, 0, cap, fx, fy, cx, cy, chi2_th, rounds, iters, d_outlier, d_n_inliers, d_status};
+    PoseOnlyArgs a{d_poses, d_pts3d, d_obs, d_counts, 0, cap, fx, fy, cx, cy, chi2_th, rounds, iters, pre_optimize, d_outlier, d_n_inliers, d_status};
     ScopedProf sp(P_BA, (hipStream_t)hip_stream);
     hipLaunchKernelGGL(k_pose_only, dim3(batch), dim3(BA_NT), 0, (hipStream_t)hip_stream, a);
     MYSLAM_HIP_CHECK(hipGetLastError());
@@ -1208,8 +1210,8 @@ int myslam_pose_only_optimize_batch(double* d_poses, const double* d_pts3d, cons
 }
 
 int myslam_pose_only_optimize(double* pose7, const double* pts3d, const double* obs, int n, double fx, double fy, double cx, double cy,
-                              double chi2_th, int rounds, int iters, uint8_t* outlier, int* n_inliers) {
-    if (!pose7 || n < 0 || (n > 0 && (!pts3d || !obs || !outlier)) || rounds < 1 || iters < 1) return MYSLAM_ERR_INVALID;
+                              double chi2_th, int rounds, int iters, int pre_optimize, uint8_t* outlier, int* n_inliers) {
+    if (!pose7 || n < 0 || (n > 0 && (!pts3d || !obs || !outlier)) || rounds < 1 || iters < 1 || pre_optimize < 0) return MYSLAM_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MYSLAM_ERR_HIP;
     const int m = n > 0 ? n : 1;
@@ -1222,7 +1224,7 @@ int myslam_pose_only_optimize(double* pose7, const double* pts3d, const double* 
         MYSLAM_HIP_CHECK(hipMemcpy(d_x, pts3d, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
         MYSLAM_HIP_CHECK(hipMemcpy(d_o, obs, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
     }
-    PoseOnlyArgs a{d_p, d_x, d_o, nullptr, n, m, fx, fy, cx, cy, chi2_th, rounds, iters, d_out, d_i, d_i + 1};
+    PoseOnlyArgs a{d_p, d_x, d_o, nullptr, n, m, fx, fy, cx, cy, chi2_th, rounds, iters, pre_optimize, d_out, d_i, d_i + 1};
     hipLaunchKernelGGL(k_pose_only, dim3(1), dim3(BA_NT), 0, nullptr, a);
     MYSLAM_HIP_CHECK(hipGetLastError());
     int32_t st[2];

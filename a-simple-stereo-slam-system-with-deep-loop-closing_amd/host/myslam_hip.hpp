@@ -246,15 +246,16 @@ public:
     }
 };
 
-// the g2o stage of Frontend::EstimateCurrentPose (src/frontend.cpp:176-276); returns features.size() - cntOutliers
+// the g2o stage of Frontend::EstimateCurrentPose (src/frontend.cpp:176-276); returns features.size() - cntOutliers.
+// preOptimize = 1 gives LoopClosing::OptimizeCurrentPose (src/loopclosing.cpp:339-433)
 inline int EstimateCurrentPose(double pose_qt[7], const std::vector<double>& mapPoints /*n x 3*/, const std::vector<double>& pixels /*n x 2*/,
                                double fx, double fy, double cx, double cy, std::vector<uint8_t>& isOutlier,
-                               double chi2_th = 5.991, int numIterations = 4, int optimizeIters = 10) {
+                               double chi2_th = 5.991, int numIterations = 4, int optimizeIters = 10, int preOptimize = 0) {
     const int n = (int)(mapPoints.size() / 3);
     isOutlier.assign(n, 0);
     int inl = 0;
     check(myslam_pose_only_optimize(pose_qt, mapPoints.data(), pixels.data(), n, fx, fy, cx, cy, chi2_th, numIterations, optimizeIters,
-                                    n ? isOutlier.data() : nullptr, &inl), "myslam_pose_only_optimize");
+                                    preOptimize, n ? isOutlier.data() : nullptr, &inl), "myslam_pose_only_optimize");
     return inl;
 }
 

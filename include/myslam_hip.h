@@ -241,12 +241,14 @@ int myslam_ba_optimize_active_map_batch(double* d_poses, double* d_points, const
  * edge by chi2 > chi2_th (5.991), exclude / re-admit }; the robust kernel is dropped after round rounds-2.   [§8(f) rank 1]
  * pose7 = (qx qy qz qw tx ty tz) Tcw in/out; pts3d n x 3 (MapPoint::Pos()); obs n x 2 (feature pixel); outlier[i] = the
  * feature's mbIsOutlier at :231-241; *n_inliers = features.size() - cntOutliers (:275).  n <= 4096.
+ * pre_optimize = number of plain optimize(iters) calls before the rounds: 0 for the frontend; 1 reproduces
+ * LoopClosing::OptimizeCurrentPose (src/loopclosing.cpp:339-433, extra optimize at :395-396; outlier[i] = vEdgeIsOutlier[i]).
  * ------------------------------------------------------------------------------------------ */
 int myslam_pose_only_optimize(double* pose7, const double* pts3d, const double* obs, int n, double fx, double fy, double cx, double cy,
-                              double chi2_th, int rounds, int iters, uint8_t* outlier, int* n_inliers);
+                              double chi2_th, int rounds, int iters, int pre_optimize, uint8_t* outlier, int* n_inliers);
 /* `batch` frames: d_poses batch x 7, d_pts3d batch x cap x 3, d_obs batch x cap x 2, d_counts batch, d_outlier batch x cap */
 int myslam_pose_only_optimize_batch(double* d_poses, const double* d_pts3d, const double* d_obs, const int32_t* d_counts, int batch, int cap,
-                                    double fx, double fy, double cx, double cy, double chi2_th, int rounds, int iters,
+                                    double fx, double fy, double cx, double cy, double chi2_th, int rounds, int iters, int pre_optimize,
                                     uint8_t* d_outlier, int32_t* d_n_inliers, int32_t* d_status, void* hip_stream);
 
 /* ------------------------------------------------------------------------------------------

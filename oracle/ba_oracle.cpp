@@ -396,15 +396,16 @@ int orc_ba_optimize_active_map(double* poses, int nposes, double* points, int np
     return 0;
 }
 
-/* Frontend::EstimateCurrentPose, src/frontend.cpp:176-276: one VertexPose, one EdgeProjectionPoseOnly (g2o_types.h:62-100) per
+/* Frontend::EstimateCurrentPose, src/frontend.cpp:176-276 (and LoopClosing::OptimizeCurrentPose, src/loopclosing.cpp:339-433, which
+ * runs one extra optimize(10) first): one VertexPose, one EdgeProjectionPoseOnly (g2o_types.h:62-100) per
  * tracked feature that has a map point, Huber (default delta = 1), g2o Levenberg with a dense 6x6 solve; `rounds` (4) times
  * { initializeOptimization(); optimize(iters = 10) } over the level-0 edges, then every edge is classified by chi2() > chi2_th
  * (an edge that was excluded gets computeError() at the new estimate first, :231-233) and excluded / re-admitted for the next
  * round (:234-241); after round rounds-2 the robust kernel is removed (:244-246).  chi2() of an ACTIVE edge is e^T e of the
  * last error evaluation g2o made (the last Levenberg trial, accepted or not).  Third-party internals: PARITY UNPINNED. */
 int orc_pose_only_optimize(double* pose7, const double* pts3d, const double* obs, int n, double fx, double fy, double cx, double cy,
-                           double chi2_th, int rounds, int iters, uint8_t* outlier, int* n_inliers) {
-    if (!pose7 || n < 0 || (n > 0 && (!pts3d || !obs || !outlier)) || rounds < 1 || iters < 1) return -1;
+                           double chi2_th, int rounds, int iters, int pre_optimize, uint8_t* outlier, int* n_inliers) {
+    if (!pose7 || n < 0 || (n > 0 && (!pts3d || !obs || !outlier)) || rounds < 1 || iters < 1 || pre_optimize < 0) return -1;
     Pose T;
     quat_to_R(pose7, T.R);
     for (int k = 0; k < 3; k++) T.t[k] = pose7[4 + k];
@@ -433,7 +434,8 @@ int orc_pose_only_optimize(double* pose7, const double* pts3d, const double* obs
         return s;
     };
     int cntOut = 0;
-    for (int round = 0; round < rounds; round++) {
+    // pre_optimize: unclassified optimize(iters) calls before the rounds (LoopClosing::OptimizeCurrentPose has one, loopclosing.cpp:395-396)
+    for (int round = -pre_optimize; round < rounds; round++) {
         int nact = 0;
         for (int i = 0; i < n; i++) nact += !level[i];
         if (nact > 0) {
@@ -502,6 +504,7 @@ int orc_pose_only_optimize(double* pose7, const double* pts3d, const double* obs
                 if (qmax == 10 || rho == 0 || !std::isfinite(lambda)) break;
             }
         }
+        if (round < 0) continue;
         cntOut = 0;
         for (int i = 0; i < n; i++) {
             if (outlier[i]) { double e[2]; edge_err(T, i, e); echi[i] = e[0] * e[0] + e[1] * e[1]; }      // :231-233

@@ -140,7 +140,7 @@ int orc_ba_optimize_active_map(double* poses, int nposes, double* points, int np
 void orc_se3_exp(const double* xi6, double* q_t7);
 /* Frontend::EstimateCurrentPose (src/frontend.cpp:176-276): pose7 = (qx qy qz qw tx ty tz) Tcw in/out */
 int orc_pose_only_optimize(double* pose7, const double* pts3d, const double* obs, int n, double fx, double fy, double cx, double cy,
-                           double chi2_th, int rounds, int iters, uint8_t* outlier, int* n_inliers);
+                           double chi2_th, int rounds, int iters, int pre_optimize, uint8_t* outlier, int* n_inliers);
 
 /* ---- pyramidal LK tracker (cv::calcOpticalFlowPyrLK as called at frontend.cpp:150-153, 358-361; lk_oracle.cpp) ---- */
 int orc_pyr_down(const uint8_t* src, int w, int h, int sstep, uint8_t* dst, int dstep);

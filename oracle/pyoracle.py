@@ -337,11 +337,11 @@ class Oracle:
         assert rc == 0, rc
         return sec.value
 
-    def pose_only_optimize(self, pose, pts3d, obs, K, chi2_th=5.991, rounds=4, iters=10):
+    def pose_only_optimize(self, pose, pts3d, obs, K, chi2_th=5.991, rounds=4, iters=10, pre_optimize=0):
         pose = np.ascontiguousarray(pose, np.float64).copy(); pts3d = np.ascontiguousarray(pts3d, np.float64); obs = np.ascontiguousarray(obs, np.float64)
         n = len(pts3d); out = np.zeros(max(n, 1), np.uint8); ni = C.c_int()
         rc = self.lib.orc_pose_only_optimize(_p(pose), _p(pts3d), _p(obs), n, C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]),
-                                             C.c_double(chi2_th), rounds, iters, _p(out), C.byref(ni))
+                                             C.c_double(chi2_th), rounds, iters, pre_optimize, _p(out), C.byref(ni))
         assert rc == 0, rc
         return pose, out[:n].astype(bool), ni.value
 

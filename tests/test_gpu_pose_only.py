@@ -37,6 +37,9 @@ def test_pose_only_rounds_and_degenerate_inputs(api, oracle, synth):
         gp, gout, gni = api.pose_only_optimize(T0, pts, obs, Kt, rounds=rounds, iters=iters)
         rp, rout, rni = oracle.pose_only_optimize(T0, pts, obs, Kt, rounds=rounds, iters=iters)
         assert np.allclose(gp, rp, rtol=1e-8, atol=1e-9) and gni == rni and np.array_equal(gout, rout)
+    gp, gout, gni = api.pose_only_optimize(T0, pts, obs, Kt, pre_optimize=1)          # LoopClosing::OptimizeCurrentPose
+    rp, rout, rni = oracle.pose_only_optimize(T0, pts, obs, Kt, pre_optimize=1)
+    assert np.allclose(gp, rp, rtol=1e-8, atol=1e-9) and gni == rni and np.array_equal(gout, rout)
     gp, gout, gni = api.pose_only_optimize(T0, pts[:0], obs[:0], Kt)                # no edges: pose untouched
     assert np.array_equal(gp, T0) and gni == 0
     gp, gout, gni = api.pose_only_optimize(T0, pts[:2], obs[:2], Kt)                # rank-deficient: still mirrors the oracle
