@@ -12,6 +12,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "orb_plan.h"
 
@@ -414,15 +416,23 @@ __global__ __launch_bounds__(256) void k_blur7_strip(BlurArgs a, int nstrips, in
         l = needL ? *reinterpret_cast<const uint32_t*>(row + x0 - 4) : 0u;
         r = needR ? *reinterpret_cast<const uint32_t*>(row + x0 + 4) : 0u;
     };
-    // horizontal pass of one row: 4 sums (<= 65280)
-    auto hrow = [&](uint32_t c, uint32_t l, uint32_t r, uint32_t* h) {
-        uint32_t w0 = dpp_wave_shr1(c);
-        if (lane == 0) w0 = x0 > 0 ? l : __builtin_amdgcn_perm(c, c, 0x01020300u);     // x = -3..-1 mirror x = 3..1
-        uint32_t w1 = c;
-        if (lastq) w1 = __builtin_amdgcn_perm(c, w0, sel1);
-        uint32_t w2 = dpp_wave_shl1(w1);
-        if (lane == 63) w2 = __builtin_amdgcn_perm(r, c, selR);
-        if (lastq) w2 = __builtin_amdgcn_perm(c, w0, sel2);
+    // horizontal pass of one row: 4 sums (<= 65280).  The neighbours' dwords arrive over DPP; lanes 0 / 63 have no DPP source and
+    // keep the `old` operand = the dword loaded from the adjacent strip.  Waves that touch an image border (edge_tag = true)
+    // additionally mirror the columns outside the image with byte permutes.
+    auto hrow = [&](auto edge_tag, uint32_t c, uint32_t l, uint32_t r, uint32_t* h) {
+        uint32_t w0, w1, w2;
+        if constexpr (decltype(edge_tag)::value) {
+            const uint32_t lfix = x0 > 0 ? l : __builtin_amdgcn_perm(c, c, 0x01020300u);            // x = -3..-1 mirror x = 3..1
+            w0 = (uint32_t)__builtin_amdgcn_update_dpp((int)lfix, (int)c, 0x138, 0xf, 0xf, false);
+            w1 = __builtin_amdgcn_perm(c, w0, sel1);                                                // identity unless this lane owns column w-1
+            const uint32_t rfix = __builtin_amdgcn_perm(r, c, selR);
+            w2 = (uint32_t)__builtin_amdgcn_update_dpp((int)rfix, (int)w1, 0x130, 0xf, 0xf, false);
+            if (lastq) w2 = __builtin_amdgcn_perm(c, w0, sel2);
+        } else {
+            w0 = (uint32_t)__builtin_amdgcn_update_dpp((int)l, (int)c, 0x138, 0xf, 0xf, false);
+            w1 = c;
+            w2 = (uint32_t)__builtin_amdgcn_update_dpp((int)r, (int)c, 0x130, 0xf, 0xf, false);
+        }
         const uint32_t A0 = __builtin_amdgcn_alignbyte(w1, w0, 1u), A1 = __builtin_amdgcn_alignbyte(w1, w0, 2u);
         const uint32_t A2 = __builtin_amdgcn_alignbyte(w1, w0, 3u), A3 = w1;
         const uint32_t B0 = __builtin_amdgcn_alignbyte(w2, w1, 1u), B1 = __builtin_amdgcn_alignbyte(w2, w1, 2u);
@@ -432,47 +442,52 @@ __global__ __launch_bounds__(256) void k_blur7_strip(BlurArgs a, int nstrips, in
         h[2] = __builtin_amdgcn_udot4(A2, qa, __builtin_amdgcn_udot4(B2, qb, 0u, false), false);
         h[3] = __builtin_amdgcn_udot4(A3, qa, __builtin_amdgcn_udot4(B3, qb, 0u, false), false);
     };
-    uint32_t D[4][4];
+    auto run = [&](auto edge_tag) {
+        uint32_t D[4][4];
 #pragma unroll
-    for (int u = 0; u < 4; u++)
+        for (int u = 0; u < 4; u++)
 #pragma unroll
-        for (int k = 0; k < 4; k++) D[u][k] = 0;
-    uint32_t c0, l0, r0, c1, l1, r1;
-    load_row(0, c0, l0, r0); load_row(1, c1, l1, r1);
-    for (int base = 0; base < npair; base += 4) {
+            for (int k = 0; k < 4; k++) D[u][k] = 0;
+        uint32_t c0, l0, r0, c1, l1, r1;
+        load_row(0, c0, l0, r0); load_row(1, c1, l1, r1);
+        for (int base = 0; base < npair; base += 4) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int pi = base + u;
-            if (pi < npair) {
-                uint32_t nc0 = 0, nl0 = 0, nr0 = 0, nc1 = 0, nl1 = 0, nr1 = 0;
-                if (pi + 1 < npair) { load_row(2 * pi + 2, nc0, nl0, nr0); load_row(2 * pi + 3, nc1, nl1, nr1); }     // prefetch
-                uint32_t he[4], ho[4];
-                hrow(c0, l0, r0, he); hrow(c1, l1, r1, ho);
+            for (int u = 0; u < 4; u++) {
+                const int pi = base + u;
+                if (pi < npair) {
+                    uint32_t nc0 = 0, nl0 = 0, nr0 = 0, nc1 = 0, nl1 = 0, nr1 = 0;
+                    if (pi + 1 < npair) { load_row(2 * pi + 2, nc0, nl0, nr0); load_row(2 * pi + 3, nc1, nl1, nr1); }     // prefetch
+                    uint32_t he[4], ho[4];
+                    hrow(edge_tag, c0, l0, r0, he); hrow(edge_tag, c1, l1, r1, ho);
 #pragma unroll
-                for (int k = 0; k < 4; k++) D[u][k] = he[k] | (ho[k] << 16);
-                if (pi >= 3) {
-                    const int oy = y0 + 2 * (pi - 3);
-                    uint32_t lo = 0, hi = 0;
+                    for (int k = 0; k < 4; k++) D[u][k] = he[k] | (ho[k] << 16);
+                    if (pi >= 3) {
+                        const int oy = y0 + 2 * (pi - 3);
+                        uint32_t lo = 0, hi = 0;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint32_t d0 = D[(u + 1) & 3][k], d1 = D[(u + 2) & 3][k], d2 = D[(u + 3) & 3][k], d3 = D[u][k];
-                        uint32_t s0 = 32768u, s1 = 32768u;
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t d0 = D[(u + 1) & 3][k], d1 = D[(u + 2) & 3][k], d2 = D[(u + 3) & 3][k], d3 = D[u][k];
+                            uint32_t s0 = 32768u, s1 = 32768u;
 #define DOT2(d, tp, acc) __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, d), __builtin_bit_cast(u16x2, tp), acc, false)
-                        s0 = DOT2(d0, t01, s0); s0 = DOT2(d1, t23, s0); s0 = DOT2(d2, t45, s0); s0 = DOT2(d3, t6_, s0);
-                        s1 = DOT2(d0, t_0, s1); s1 = DOT2(d1, t12, s1); s1 = DOT2(d2, t34, s1); s1 = DOT2(d3, t56, s1);
+                            s0 = DOT2(d0, t01, s0); s0 = DOT2(d1, t23, s0); s0 = DOT2(d2, t45, s0); s0 = DOT2(d3, t6_, s0);
+                            s1 = DOT2(d0, t_0, s1); s1 = DOT2(d1, t12, s1); s1 = DOT2(d2, t34, s1); s1 = DOT2(d3, t56, s1);
 #undef DOT2
-                        lo |= (s0 >> 16) << (8 * k);
-                        hi |= (s1 >> 16) << (8 * k);
+                            lo |= (s0 >> 16) << (8 * k);
+                            hi |= (s1 >> 16) << (8 * k);
+                        }
+                        if (has) {      // destination pitch is a multiple of 64: the dword never leaves the row; bytes past w are padding
+                            *reinterpret_cast<uint32_t*>(dst + (size_t)oy * a.dpitch + x0) = lo;
+                            if (oy + 1 < a.h) *reinterpret_cast<uint32_t*>(dst + (size_t)(oy + 1) * a.dpitch + x0) = hi;
+                        }
                     }
-                    if (has) {      // destination pitch is a multiple of 64: the dword never leaves the row; bytes past w are padding
-                        *reinterpret_cast<uint32_t*>(dst + (size_t)oy * a.dpitch + x0) = lo;
-                        if (oy + 1 < a.h) *reinterpret_cast<uint32_t*>(dst + (size_t)(oy + 1) * a.dpitch + x0) = hi;
-                    }
+                    c0 = nc0; l0 = nl0; r0 = nr0; c1 = nc1; l1 = nl1; r1 = nr1;
                 }
-                c0 = nc0; l0 = nl0; r0 = nr0; c1 = nc1; l1 = nl1; r1 = nr1;
             }
         }
-    }
+    };
+    // interior strips: no lane sees an image border, the neighbour dwords of lanes 0 / 63 are plain loads
+    const bool interior = strip > 0 && (strip + 1) * 256 + 4 <= a.w;
+    if (interior) run(std::false_type{}); else run(std::true_type{});
 }
 
 // ------------------------------------------------------------------------------------------------
