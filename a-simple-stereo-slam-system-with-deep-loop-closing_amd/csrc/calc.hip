@@ -85,6 +85,13 @@ __global__ __launch_bounds__(256) void k_conv1(const float* __restrict__ in, con
     }
 }
 
+// LRN denominator scale^-0.75 = rsqrt(scale) * sqrt(rsqrt(scale)) on the hardware rsq / sqrt units (scale >= 1; within 3 ulp of
+// powf, two orders of magnitude inside the descriptor tolerance) instead of the ~150-instruction powf expansion
+__device__ __forceinline__ float lrn_pow_m075(float scale) {
+    const float r = __builtin_amdgcn_rsqf(scale);
+    return r * __builtin_amdgcn_sqrtf(r);
+}
+
 // ---- max-pool 3x3 s2 (Caffe ceil mode, clipped windows) + LRN across channels; one wave per output pixel ----
 template <int C>
 __global__ __launch_bounds__(256) void k_pool_lrn(const float* __restrict__ in, int H, int W, int OH, int OW,
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(256) void k_pool_lrn(const float* __restrict__ in, 
 #pragma unroll
             for (int j = 0; j < 5; j++) ss += v[j] * v[j];
             const float scale = 1.f + (1e-4f / 5.f) * ss;
-            out[((size_t)b * OH * OW + p) * C + c] = v[2] * powf(scale, -0.75f);
+            out[((size_t)b * OH * OW + p) * C + c] = v[2] * lrn_pow_m075(scale);
         }
     }
 }
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(256) void k_conv1_pool_lrn(const float* __restrict_
     float ss = 0.f;
     ss += v0 * v0; ss += v1 * v1; ss += m * m; ss += v3 * v3; ss += v4 * v4;
     const float scale = 1.f + (1e-4f / 5.f) * ss;
-    out[((size_t)b * HP1 * WP1 + p) * 64 + lane] = m * powf(scale, -0.75f);
+    out[((size_t)b * HP1 * WP1 + p) * 64 + lane] = m * lrn_pow_m075(scale);
 }
 
 // f32 wave sum on the DPP network; the total lands in lane 63

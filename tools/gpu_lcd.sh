@@ -2,7 +2,7 @@
 # LCD parity + bench
 mkdir -p gpurun_out; export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_lcd.py tests/test_golden.py -m gpu -q --tb=short --timeout 300 -p no:cacheprovider 2>&1 | tail -${TAILN:-8}
-timeout 600 python bench.py --steps 10 --warmup 2 --pairs ${PAIRS:-256} --no-cpu-baseline 2>/dev/null | python -c "
+timeout 600 python bench.py --steps 10 --warmup 2 --pairs ${PAIRS:-256} --streams 1 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('value',round(d['value'],1),'ms/step',round(d['ms_per_step'],3))
