@@ -1,0 +1,45 @@
+"""The alternative kernels kept behind developer switches (one cell per block FAST, LDS-tile blur, one-row resize, one wave per
+key-point describe, unfused conv1) must stay bit-compatible with the default path: run the extractor + CALC against the oracle in
+child processes with the switches set (they are read once per process)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+CHILD = r'''
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+import torch
+import __graft_entry__ as g
+pkg = g.load_package(); api, synth = pkg.api, pkg.synth
+sys.path.insert(0, %(root)r + "/oracle")
+from pyoracle import Oracle
+o = Oracle()
+for (h, w, nf) in ((240, 320, 500), (301, 517, 1200)):
+    img = synth.random_image(1000 + h, h, w)
+    gk, gd = api.ORBextractor(nf).DetectAndCompute(img)
+    rk, rd = o.detect_and_compute(o.params(nf), img)
+    assert gk.tobytes() == rk.tobytes() and np.array_equal(gd, rd), "ORB differs"
+L, _ = synth.stereo_pair(0, 1)
+wts = synth.calc_weights()
+d, _ = api.DeepLCD(wts).calcDescrOriginalImg(L, blur_in_place=False)
+x, _ = o.calc_preproc(L)
+assert np.abs(d - o.calc_forward(wts, x)).max() < 2e-5, "CALC differs"
+print("FALLBACK OK")
+'''
+
+
+@pytest.mark.parametrize("env", [
+    {"MYSLAM_FAST_V": "3", "MYSLAM_BLUR_V": "2", "MYSLAM_RESIZE_V": "1", "MYSLAM_DESC_V": "1", "MYSLAM_CONV1_V": "1"},
+    {"MYSLAM_FAST_V": "2", "MYSLAM_BLUR_V": "1"},
+    {"MYSLAM_FAST_V": "2", "MYSLAM_FAST_T": "64"},
+])
+def test_alternative_kernels_match_oracle(env):
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FALLBACK OK" in r.stdout, (env, r.stdout[-2000:], r.stderr[-2000:])
