@@ -12,6 +12,10 @@
  * the handle's HIP stream and never synchronise; the others take HOST pointers and return when the
  * result is in the caller's buffers.  There is NO CPU fallback: every call fails with
  * MYSLAM_ERR_HIP when no gfx950 device is usable.
+ *
+ * Threading: a handle owns device scratch and one HIP stream, so it serves one thread at a time; handle-free functions are
+ * re-entrant.  The reference shares ONE ORBextractor between the frontend and the loop-closing thread (src/system.cpp:31,54,66):
+ * create one handle per thread instead.  Work of different handles on different streams runs concurrently on the device.
  */
 #ifndef MYSLAM_HIP_H
 #define MYSLAM_HIP_H
