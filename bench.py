@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — stereo frames/s of the per-frame dense path on MI355X (BASELINE.json metric).
 
-A "step" = one pass of the hot path over one batch of synthetic 1241x376 stereo pairs resident in HBM:
+A "step" = one pass of the hot path over one batch (default 512) of synthetic 1241x376 stereo pairs resident in HBM:
   ORB DetectAndCompute (2000 features) on left+right -> L/R 256-bit Hamming match -> stereo triangulation
   -> DeepLCD descriptor of the left image -> cosine scan of the key-frame database -> local-BA block build
   (one 10 KF x 300 landmark window per frame).           [BASELINE.json configs[3]; --workload orb_match = configs[1]]
@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=256, help="stereo pairs per step per GPU")
+    ap.add_argument("--pairs", type=int, default=512, help="stereo pairs per step per GPU")
     ap.add_argument("--workload", default="full", choices=["full", "orb_match", "orb_match_lcd", "full_solve"])
     ap.add_argument("--db", type=int, default=0, help="key-frame database size (default 10000, or 6250 per GPU when sharded)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
