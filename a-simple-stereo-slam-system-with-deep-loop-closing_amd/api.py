@@ -445,3 +445,26 @@ def pose_only_optimize_batch(d_poses, d_pts3d, d_obs, d_counts, batch, cap, K, c
                                                  C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]), C.c_double(chi2_th),
                                                  int(rounds), int(iters), int(pre_optimize), C.c_void_p(d_outlier), C.c_void_p(d_ninl), C.c_void_p(d_status),
                                                  C.c_void_p(stream or None)), "myslam_pose_only_optimize_batch")
+
+
+# ---------------------------------------------------------------------------------- loop correction
+def pose_graph_optimize(poses, fixed, edge_v0, edge_v1, meas, iters=20):
+    """The g2o part of LoopClosing::PoseGraphOptimization (src/loopclosing.cpp:537-610).  poses (n,7) Tcw; meas[k] = the
+    measured T[v0] * T[v1]^-1 of edge k.  Returns (poses, final chi2, iterations done)."""
+    poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7).copy(); fixed = np.ascontiguousarray(fixed, np.uint8)
+    e0 = np.ascontiguousarray(edge_v0, np.int32); e1 = np.ascontiguousarray(edge_v1, np.int32)
+    meas = np.ascontiguousarray(meas, np.float64).reshape(-1, 7)
+    assert len(fixed) == len(poses) and len(e0) == len(e1) == len(meas)
+    chi = C.c_double(); it = C.c_int()
+    _check(lib().myslam_pose_graph_optimize(_p(poses), len(poses), _p(fixed), _p(e0), _p(e1), _p(meas), len(e0), int(iters), C.byref(chi), C.byref(it)),
+           "myslam_pose_graph_optimize")
+    return poses, chi.value, it.value
+
+
+def correct_map_points(old_poses, new_poses, first_kf, points):
+    """src/loopclosing.cpp:621-633: every map point keeps its camera-frame position in the key-frame that first observed it."""
+    old_poses = np.ascontiguousarray(old_poses, np.float64).reshape(-1, 7); new_poses = np.ascontiguousarray(new_poses, np.float64).reshape(-1, 7)
+    first_kf = np.ascontiguousarray(first_kf, np.int32); points = np.ascontiguousarray(points, np.float64).reshape(-1, 3).copy()
+    assert old_poses.shape == new_poses.shape and len(first_kf) == len(points)
+    _check(lib().myslam_correct_map_points(_p(old_poses), _p(new_poses), len(old_poses), _p(first_kf), _p(points), len(points)), "myslam_correct_map_points")
+    return points

@@ -26,6 +26,7 @@ UNITS = {
     "lcddb.hip": [],
     "ba.hip": [],
     "lk.hip": EXACT,
+    "pgo.hip": [],
     "prof.hip": [],
 }
 

@@ -1,0 +1,902 @@
+// pgo.hip — loop correction on gfx950: LoopClosing::PoseGraphOptimization (src/loopclosing.cpp:537-646)   [SURVEY.md §8(f) rank 3]
+//
+// The reference hands g2o one VertexPose per key-frame (left-multiplied SE3 update, g2o_types.h:32-37), one EdgePoseGraph
+// (error = log(M^-1 v0 v1^-1), information I6, g2o_types.h:157-167) per (KF, previous KF) and per (KF, loop KF), lets g2o
+// differentiate the edges numerically (linearizeOplus is commented out, g2o_types.h:168-182: central differences, delta = 1e-9)
+// and runs Levenberg-Marquardt for 20 iterations over a sparse Cholesky.  Afterwards every map point outside the active
+// window moves rigidly with the key-frame that first observed it (:621-633).
+//
+// Device design.  A key-frame graph is a chain plus a handful of loop edges, so the normal equations are block tridiagonal
+// apart from the rows of a few "separator" key-frames S (one endpoint per off-chain edge; chosen on the host from the edge
+// list, at most PG_MAXS).  With T = the remaining free key-frames in index order:
+//      [ Htt  C  ] [xT]   [bT]       Htt block tridiagonal (6x6 blocks D_t, B_t)
+//      [ C^T  Hss] [xS] = [bS]       C = couplings T-S (sparse), Hss dense 6|S| x 6|S|
+//   linearize   one thread per (edge, vertex side, tangent coordinate): 2 error evaluations -> one Jacobian column
+//   assemble    one wave per 6x6 destination block, summing J^T J over that block's edge list in list order (deterministic)
+//   sweep       block Cholesky of Htt + lambda I down the chain fused with the forward substitution of the 6|S|+1 right-hand
+//               sides [C | bT]: one lane per right-hand side, the 6x6 factor chain recomputed in every lane (no barriers)
+//   syrk        Z^T Z with v_mfma_f64_16x16x4 (one wave per 16x16 tile and K chunk), Z = L^-1 [C | bT]
+//   schur       (Hss + lambda I - Z^T Z) xS = bS - Z^T z: dense Cholesky in one workgroup
+//   back        y = z - Z xS (row parallel), then the backward chain xT_t = L_t^-T (y_t - W_{t+1}^T xT_{t+1})
+//   update      pose <- exp(x) * pose per key-frame, chi2 per edge, fixed-order reductions
+// The Levenberg control flow (lambda, rho, accept / reject: g2o OptimizationAlgorithmLevenberg) runs on the host on three
+// scalars read back per trial; all arithmetic on poses, Jacobians and the linear system stays on the device, in double.
+#include <math.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <map>
+#include <tuple>
+#include <vector>
+
+#include "common.h"
+
+namespace myslam_hip {
+
+constexpr int PG_MAXS = 96;          // separator key-frames supported (dense Schur system up to 576 x 576)
+constexpr int PG_KS = 32;            // K chunks of the Z^T Z product
+constexpr double PG_EPS = 1e-10;     // Sophus::Constants<double>::epsilon()
+
+struct Se3 { double q[4]; double t[3]; };      // q = (x, y, z, w)
+
+__device__ __forceinline__ void pg_rot(const double* q, const double* v, double* o) {
+    double uv[3] = {q[1] * v[2] - q[2] * v[1], q[2] * v[0] - q[0] * v[2], q[0] * v[1] - q[1] * v[0]};
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+    o[0] = v[0] + q[3] * uv[0] + (q[1] * uv[2] - q[2] * uv[1]);
+    o[1] = v[1] + q[3] * uv[1] + (q[2] * uv[0] - q[0] * uv[2]);
+    o[2] = v[2] + q[3] * uv[2] + (q[0] * uv[1] - q[1] * uv[0]);
+}
+
+__device__ __forceinline__ void pg_qnorm(double* q) {
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+
+__device__ __forceinline__ Se3 pg_mul(const Se3& a, const Se3& b) {
+    Se3 r;
+    r.q[3] = a.q[3] * b.q[3] - a.q[0] * b.q[0] - a.q[1] * b.q[1] - a.q[2] * b.q[2];
+    r.q[0] = a.q[3] * b.q[0] + a.q[0] * b.q[3] + a.q[1] * b.q[2] - a.q[2] * b.q[1];
+    r.q[1] = a.q[3] * b.q[1] - a.q[0] * b.q[2] + a.q[1] * b.q[3] + a.q[2] * b.q[0];
+    r.q[2] = a.q[3] * b.q[2] + a.q[0] * b.q[1] - a.q[1] * b.q[0] + a.q[2] * b.q[3];
+    pg_qnorm(r.q);
+    double rt[3];
+    pg_rot(a.q, b.t, rt);
+    r.t[0] = a.t[0] + rt[0]; r.t[1] = a.t[1] + rt[1]; r.t[2] = a.t[2] + rt[2];
+    return r;
+}
+
+__device__ __forceinline__ Se3 pg_inv(const Se3& a) {
+    Se3 r;
+    r.q[0] = -a.q[0]; r.q[1] = -a.q[1]; r.q[2] = -a.q[2]; r.q[3] = a.q[3];
+    double rt[3];
+    pg_rot(r.q, a.t, rt);
+    r.t[0] = -rt[0]; r.t[1] = -rt[1]; r.t[2] = -rt[2];
+    return r;
+}
+
+// Sophus SE3::exp, tangent (upsilon, omega)
+__device__ Se3 pg_exp(const double* d) {
+    Se3 r;
+    const double wx = d[3], wy = d[4], wz = d[5];
+    const double th2 = wx * wx + wy * wy + wz * wz;
+    double imag, real, B, C;
+    if (th2 < PG_EPS * PG_EPS) {
+        const double th4 = th2 * th2;
+        imag = 0.5 - th2 / 48.0 + th4 / 3840.0;
+        real = 1.0 - th2 / 8.0 + th4 / 384.0;
+        B = 0.5; C = 1.0 / 6.0;
+    } else {
+        const double th = sqrt(th2), h = 0.5 * th;
+        imag = sin(h) / th;
+        real = cos(h);
+        B = (1.0 - cos(th)) / th2; C = (th - sin(th)) / (th2 * th);
+    }
+    r.q[0] = imag * wx; r.q[1] = imag * wy; r.q[2] = imag * wz; r.q[3] = real;
+    pg_qnorm(r.q);
+    const double u[3] = {d[0], d[1], d[2]};
+    const double wu[3] = {wy * u[2] - wz * u[1], wz * u[0] - wx * u[2], wx * u[1] - wy * u[0]};
+    const double wwu[3] = {wy * wu[2] - wz * wu[1], wz * wu[0] - wx * wu[2], wx * wu[1] - wy * wu[0]};
+    for (int k = 0; k < 3; k++) r.t[k] = u[k] + B * wu[k] + C * wwu[k];
+    return r;
+}
+
+// Sophus SE3::log -> (upsilon, omega)
+__device__ void pg_log(const Se3& T, double* d) {
+    const double n2 = T.q[0] * T.q[0] + T.q[1] * T.q[1] + T.q[2] * T.q[2], w = T.q[3];
+    double f;
+    if (n2 < PG_EPS * PG_EPS) f = 2.0 / w - 2.0 / 3.0 * n2 / (w * w * w);
+    else {
+        const double n = sqrt(n2);
+        if (fabs(w) < PG_EPS) f = (w > 0 ? M_PI : -M_PI) / n;
+        else f = 2.0 * atan(n / w) / n;
+    }
+    const double wx = f * T.q[0], wy = f * T.q[1], wz = f * T.q[2];
+    const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
+    double C;
+    if (th < PG_EPS) C = 1.0 / 12.0;
+    else { const double h = 0.5 * th; C = (1.0 - th * cos(h) / (2.0 * sin(h))) / th2; }
+    const double* t = T.t;
+    const double wt[3] = {wy * t[2] - wz * t[1], wz * t[0] - wx * t[2], wx * t[1] - wy * t[0]};
+    const double wwt[3] = {wy * wt[2] - wz * wt[1], wz * wt[0] - wx * wt[2], wx * wt[1] - wy * wt[0]};
+    for (int k = 0; k < 3; k++) d[k] = t[k] - 0.5 * wt[k] + C * wwt[k];
+    d[3] = wx; d[4] = wy; d[5] = wz;
+}
+
+__device__ __forceinline__ Se3 pg_load(const double* p) {
+    Se3 T;
+    T.q[0] = p[0]; T.q[1] = p[1]; T.q[2] = p[2]; T.q[3] = p[3]; T.t[0] = p[4]; T.t[1] = p[5]; T.t[2] = p[6];
+    return T;
+}
+__device__ __forceinline__ void pg_store(const Se3& T, double* p) {
+    p[0] = T.q[0]; p[1] = T.q[1]; p[2] = T.q[2]; p[3] = T.q[3]; p[4] = T.t[0]; p[5] = T.t[1]; p[6] = T.t[2];
+}
+
+// g2o_types.h:161-167
+__device__ __forceinline__ void pg_edge_error(const Se3& Minv, const Se3& v0, const Se3& v1, double* e) {
+    pg_log(pg_mul(pg_mul(Minv, v0), pg_inv(v1)), e);
+}
+
+// poses -> unit quaternions; measurements -> their inverses
+__global__ void k_pg_prepare(double* poses, int n, const double* meas, double* minv, int E) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { Se3 T = pg_load(poses + 7 * i); pg_qnorm(T.q); pg_store(T, poses + 7 * i); }
+    if (i < E) { Se3 M = pg_load(meas + 7 * i); pg_qnorm(M.q); pg_store(pg_inv(M), minv + 7 * i); }
+}
+
+// one thread per (edge, side, tangent coordinate): g2o BaseBinaryEdge::linearizeOplus numeric branch
+__global__ void k_pg_linearize(const double* __restrict__ poses, const double* __restrict__ minv, const int32_t* __restrict__ e0,
+                               const int32_t* __restrict__ e1, const uint8_t* __restrict__ fixedv, int E,
+                               double* __restrict__ J /*E x 2 x 36*/, double* __restrict__ err /*E x 6*/) {
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= 12 * E) return;
+    const int k = id / 12, rem = id - 12 * k, side = rem / 6, d = rem - 6 * side;
+    const int vi[2] = {e0[k], e1[k]};
+    const Se3 Mi = pg_load(minv + 7 * k);
+    const Se3 v0 = pg_load(poses + 7 * vi[0]), v1 = pg_load(poses + 7 * vi[1]);
+    if (rem == 0) {
+        double e[6]; pg_edge_error(Mi, v0, v1, e);
+        for (int a = 0; a < 6; a++) err[6 * k + a] = e[a];
+    }
+    double* Jc = J + ((size_t)k * 2 + side) * 36;
+    if (fixedv[vi[side]]) {
+        for (int r = 0; r < 6; r++) Jc[r * 6 + d] = 0.0;
+        return;
+    }
+    double add[6] = {0, 0, 0, 0, 0, 0}, ep[6], em[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) add[a] = (a == d) ? 1e-9 : 0.0;
+    Se3 vp = pg_mul(pg_exp(add), side ? v1 : v0);
+    pg_edge_error(Mi, side ? v0 : vp, side ? vp : v1, ep);
+#pragma unroll
+    for (int a = 0; a < 6; a++) add[a] = (a == d) ? -1e-9 : 0.0;
+    vp = pg_mul(pg_exp(add), side ? v1 : v0);
+    pg_edge_error(Mi, side ? v0 : vp, side ? vp : v1, em);
+    const double scalar = 1.0 / (2 * 1e-9);
+    for (int r = 0; r < 6; r++) Jc[r * 6 + d] = scalar * (ep[r] - em[r]);
+}
+
+// fixed-order block sum of `v` over 256 threads; valid in thread 0
+__device__ __forceinline__ double pg_block_sum256(double v, double* sm) {
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    return sm[0];
+}
+
+__global__ void __launch_bounds__(256) k_pg_chi2(const double* __restrict__ poses, const double* __restrict__ minv, const int32_t* __restrict__ e0,
+                                                 const int32_t* __restrict__ e1, int E, double* __restrict__ partial) {
+    __shared__ double sm[256];
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    double c = 0;
+    if (k < E) {
+        double e[6];
+        pg_edge_error(pg_load(minv + 7 * k), pg_load(poses + 7 * e0[k]), pg_load(poses + 7 * e1[k]), e);
+        for (int a = 0; a < 6; a++) c += e[a] * e[a];
+    }
+    const double s = pg_block_sum256(c, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// out[slot] = sum (mode 0) or max |.| (mode 1) of v[0..n), fixed order; one workgroup
+__global__ void __launch_bounds__(256) k_pg_reduce(const double* __restrict__ v, int n, double* out, int mode) {
+    __shared__ double sm[256];
+    double a = 0;
+    for (int i = threadIdx.x; i < n; i += 256) a = mode ? fmax(a, fabs(v[i])) : a + v[i];
+    sm[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] = mode ? fmax(sm[threadIdx.x], sm[threadIdx.x + s]) : sm[threadIdx.x] + sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sm[0];
+}
+
+// One wave per destination 6x6 block.  kind 0: D_t (+ bT_t into column mS of C)  1: B_t  2: C block (t, s)
+//                                      3: Hss diagonal block (+ bS)                4: Hss block (s > s')
+struct PgJob { int kind, a, b, begin, end; };
+
+__global__ void __launch_bounds__(64) k_pg_assemble(const PgJob* __restrict__ jobs, const int2* __restrict__ list, const double* __restrict__ J,
+                                                    const double* __restrict__ err, double* __restrict__ D, double* __restrict__ B,
+                                                    double* __restrict__ C, double* __restrict__ Hss, double* __restrict__ bS,
+                                                    double* __restrict__ diag, int ldz, int mS, int nT) {
+    const PgJob jb = jobs[blockIdx.x];
+    const int lane = threadIdx.x;
+    const bool isb = lane >= 36;
+    if (lane >= 42 || (isb && !(jb.kind == 0 || jb.kind == 3))) return;
+    const int r = isb ? lane - 36 : lane / 6, c = isb ? 0 : lane - 6 * r;
+    double sum = 0;
+    for (int i = jb.begin; i < jb.end; i++) {
+        const int2 en = list[i];
+        const double* Jr = J + ((size_t)en.x * 2 + (en.y & 1)) * 36;
+        const double* Jc = J + ((size_t)en.x * 2 + (en.y >> 1)) * 36;
+        double h = 0;
+        if (!isb) { for (int m = 0; m < 6; m++) h += Jr[m * 6 + r] * Jc[m * 6 + c]; }
+        else { for (int m = 0; m < 6; m++) h += Jr[m * 6 + r] * err[(size_t)en.x * 6 + m]; }
+        sum += h;
+    }
+    switch (jb.kind) {
+    case 0:
+        if (isb) C[(size_t)(6 * jb.a + r) * ldz + mS] = -sum;
+        else { D[(size_t)jb.a * 36 + r * 6 + c] = sum; if (r == c) diag[6 * jb.a + r] = sum; }
+        break;
+    case 1: B[(size_t)jb.a * 36 + r * 6 + c] = sum; break;
+    case 2: C[(size_t)(6 * jb.a + r) * ldz + 6 * jb.b + c] = sum; break;
+    case 3:
+        if (isb) bS[6 * jb.a + r] = -sum;
+        else { Hss[(size_t)(6 * jb.a + r) * ldz + 6 * jb.a + c] = sum; if (r == c) diag[6 * (nT + jb.a) + r] = sum; }
+        break;
+    default: Hss[(size_t)(6 * jb.a + r) * ldz + 6 * jb.b + c] = sum; break;
+    }
+}
+
+// 1 / sqrt(s) to double precision: v_rsq_f64 seed (~2^-23) + two cubic Newton steps — a fraction of the sqrt + divide sequences,
+// and this value sits on the serial dependency chain of the sweep
+__device__ __forceinline__ double pg_rsqrt(double s) {
+    double y = __builtin_amdgcn_rsq(s);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const double e = fma(-s * y, y, 1.0);
+        y = fma(y * e, fma(0.375, e, 0.5), y);
+    }
+    return y;
+}
+
+// Block Cholesky of Htt + lambda I fused with the forward substitution of the ldz right-hand-side columns (one per lane).
+//   W_t = B_t L_{t-1}^-T,  L_t L_t^T = D_t + lambda I - W_t W_t^T,  Z_t = L_t^-1 (C_t - W_t Z_{t-1})
+// Lw[t] = { L_t lower 6x6 with the INVERSE diagonal on the diagonal (36), W_t (36) }.
+// blockIdx.y = chain segment [seg[y], seg[y+1]): no block couples two segments (B = 0 at a segment start), so segments run in
+// parallel.  The loads of step t+1 are issued before the arithmetic of step t (they do not depend on the chain).
+__global__ void __launch_bounds__(64) k_pg_sweep(const double* __restrict__ D, const double* __restrict__ B, const double* __restrict__ C,
+                                                 double* __restrict__ Z, double* __restrict__ Lw, const int32_t* __restrict__ seg, int ldz,
+                                                 double lambda, int* __restrict__ status) {
+    const int col = blockIdx.x * 64 + threadIdx.x;
+    const bool act = col < ldz;
+    const int cc = act ? col : 0;
+    const int t0 = seg[blockIdx.y], t1 = seg[blockIdx.y + 1];
+    double L[6][6], W[6][6], zp[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        zp[i] = 0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) { L[i][j] = (i == j) ? 1.0 : 0.0; W[i][j] = 0; }
+    }
+    // The block data of a step is wave-uniform; loading it through an opaque per-lane zero keeps the prefetch in VGPRs
+    // (as scalar loads the 57 doubles do not fit the SGPR file next to the live step and the prefetch degenerates).
+    int vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+    double nB[36], nD[21], nr[6];
+    auto fetch = [&](int t) {
+        const double* Bt = B + (size_t)t * 36 + vzero;
+        const double* Dt = D + (size_t)t * 36 + vzero;
+#pragma unroll
+        for (int i = 0; i < 36; i++) nB[i] = Bt[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) nD[i * (i + 1) / 2 + j] = Dt[i * 6 + j];
+#pragma unroll
+        for (int i = 0; i < 6; i++) nr[i] = C[(size_t)(6 * t + i) * ldz + cc];
+    };
+    if (t0 < t1) fetch(t0);
+    bool bad = false;
+    for (int t = t0; t < t1; t++) {
+        double Bt[36], Dt[21], rr[6];
+#pragma unroll
+        for (int i = 0; i < 36; i++) Bt[i] = nB[i];
+#pragma unroll
+        for (int i = 0; i < 21; i++) Dt[i] = nD[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) rr[i] = nr[i];
+        if (t + 1 < t1) fetch(t + 1);
+        // W = B L^-T  (L holds 1/diag on its diagonal)
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                double s = Bt[i * 6 + j];
+#pragma unroll
+                for (int k = 0; k < j; k++) s -= W[i][k] * L[j][k];
+                W[i][j] = s * L[j][j];
+            }
+        }
+        // A = D + lambda I - W W^T (lower), factor in place into L
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+#pragma unroll
+            for (int j = 0; j <= i; j++) {
+                double s = Dt[i * (i + 1) / 2 + j] + ((i == j) ? lambda : 0.0);
+#pragma unroll
+                for (int k = 0; k < 6; k++) s -= W[i][k] * W[j][k];
+                L[i][j] = s;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            double s = L[j][j];
+#pragma unroll
+            for (int k = 0; k < j; k++) s -= L[j][k] * L[j][k];
+            if (!(s > 0)) { bad = true; s = 1.0; }
+            const double inv = pg_rsqrt(s);
+            L[j][j] = inv;
+#pragma unroll
+            for (int i = j + 1; i < 6; i++) {
+                double v = L[i][j];
+#pragma unroll
+                for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k];
+                L[i][j] = v * inv;
+            }
+        }
+        // this lane's right-hand side
+        double z[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            double s = rr[i];
+#pragma unroll
+            for (int k = 0; k < 6; k++) s -= W[i][k] * zp[k];
+#pragma unroll
+            for (int k = 0; k < i; k++) s -= L[i][k] * z[k];
+            z[i] = s * L[i][i];
+        }
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) Z[(size_t)(6 * t + i) * ldz + col] = z[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) zp[i] = z[i];
+        if (col == 0) {
+            double* o = Lw + (size_t)t * 72;
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j < 6; j++) { o[i * 6 + j] = (j <= i) ? L[i][j] : 0.0; o[36 + i * 6 + j] = W[i][j]; }
+        }
+    }
+    if (bad && col == 0) *status = 1;
+}
+
+// P[ks][tile][v][lane] = partial Z^T Z over K chunk ks for the lower 16x16 tile (ti >= tj); one wave per (tile, ks)
+typedef double pg_d4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(64) k_pg_syrk(const double* __restrict__ Z, double* __restrict__ P, int ldz, int k4 /*groups of 4 rows*/, int ntile) {
+    const int tile = blockIdx.x, ks = blockIdx.y, lane = threadIdx.x;
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= tile) ti++;
+    const int tj = tile - ti * (ti + 1) / 2;
+    const int per = (k4 + PG_KS - 1) / PG_KS, g0 = ks * per, g1 = min(k4, g0 + per);
+    pg_d4 acc = {0, 0, 0, 0};
+    const double* pa = Z + (size_t)(lane >> 4) * ldz + 16 * ti + (lane & 15);
+    const double* pb = Z + (size_t)(lane >> 4) * ldz + 16 * tj + (lane & 15);
+    for (int g = g0; g < g1; g++) {
+        const double av = pa[(size_t)g * 4 * ldz], bv = pb[(size_t)g * 4 * ldz];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+    double* o = P + ((size_t)ks * ntile + tile) * 256;
+#pragma unroll
+    for (int v = 0; v < 4; v++) o[v * 64 + lane] = acc[v];
+}
+
+__device__ __forceinline__ double pg_ztz(const double* __restrict__ P, int ntile, int i, int j) {      // (Z^T Z)(i, j), i-tile >= j-tile
+    const int ti = i >> 4, tj = j >> 4, tile = ti * (ti + 1) / 2 + tj, r = i & 15, c = j & 15;
+    const size_t o = (size_t)tile * 256 + (size_t)(r >> 2) * 64 + (r & 3) * 16 + c;
+    double s = 0;
+    for (int ks = 0; ks < PG_KS; ks++) s += P[(size_t)ks * ntile * 256 + o];
+    return s;
+}
+
+// (Hss + lambda I - Z^T Z) xS = bS - Z^T z   — blocked dense Cholesky in one workgroup (16 waves), matrix A (ld = ldz) in L2.
+// The right-hand side rides along as row mS of A, so the factorisation leaves L^-1 rhs there (no separate forward pass).
+// Per 16-column panel: wave 0 factors the 16x16 diagonal tile in LDS, one thread per row below solves its 16 panel entries
+// against it, then the trailing matrix takes A[ti][tj] -= X_ti X_tj^T as v_mfma_f64_16x16x4 tiles spread over the waves.
+// The backward substitution runs in wave 0 alone (rows of L are contiguous).
+#define PG_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+__global__ void __launch_bounds__(1024) k_pg_schur(const double* __restrict__ Hss, const double* __restrict__ bS, const double* __restrict__ P,
+                                                   double* __restrict__ A, double* __restrict__ xS, int mS, int ldz, int ntile, int haveZ,
+                                                   double lambda, int* __restrict__ status) {
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5, lane = tid & 63, wv = tid >> 6;
+    __shared__ double sD[16][17];
+    __shared__ double sInv[6 * PG_MAXS + 16];
+    __shared__ int sbad;
+    if (tid == 0) sbad = 0;
+    for (int i = ty; i < ldz; i += 32)
+        for (int j = tx; j < ldz; j += 32) {
+            double v = 0;
+            if (i <= mS && j <= i && j < mS) {
+                if (i < mS) v = Hss[(size_t)i * ldz + j] + ((i == j) ? lambda : 0.0);
+                else v = bS[j];
+                if (haveZ) v -= pg_ztz(P, ntile, i, j);
+            }
+            A[(size_t)i * ldz + j] = v;
+        }
+    __syncthreads();
+    const int nt = ldz >> 4;
+    for (int p = 0; 16 * p < mS; p++) {
+        const int c0 = 16 * p;
+        if (tid < 256) sD[tid >> 4][tid & 15] = A[(size_t)(c0 + (tid >> 4)) * ldz + c0 + (tid & 15)];
+        __syncthreads();
+        if (wv == 0) {                               // unblocked factor of the diagonal tile, lane r = row r
+            const int r = lane & 15;
+            for (int j = 0; j < 16 && c0 + j < mS; j++) {
+                double piv = sD[j][j];
+                if (!(piv > 0)) { if (lane == 0) sbad = 1; piv = 1.0; }
+                const double d = sqrt(piv), inv = 1.0 / d;
+                double l = 0;
+                if (lane < 16 && r > j) { l = sD[r][j] * inv; sD[r][j] = l; }
+                if (lane == j) { sD[j][j] = d; sInv[c0 + j] = inv; }
+                PG_WAVE_SYNC();
+                if (lane < 16 && r > j) for (int k = j + 1; k <= r; k++) sD[r][k] -= l * sD[k][j];
+                PG_WAVE_SYNC();
+            }
+        }
+        __syncthreads();
+        if (tid < 256 && (tid & 15) <= (tid >> 4)) A[(size_t)(c0 + (tid >> 4)) * ldz + c0 + (tid & 15)] = sD[tid >> 4][tid & 15];
+        const int ncol = min(16, mS - c0);
+        for (int i = c0 + 16 + tid; i <= mS; i += 1024) {       // panel rows below the tile: X = A_panel Ld^-T
+            double* row = A + (size_t)i * ldz + c0;
+            double x[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) x[j] = row[j];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                if (j < ncol) {
+                    double v = x[j];
+#pragma unroll
+                    for (int k = 0; k < j; k++) v -= x[k] * sD[j][k];
+                    x[j] = v * sInv[c0 + j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j++) row[j] = x[j];
+        }
+        __syncthreads();
+        // trailing update: tile (ti, tj), p < tj <= ti < nt; A-operand lane value X[16 ti + (lane & 15)][c0 + 4 g + (lane >> 4)]
+        const int nrem = nt - p - 1, ntr = nrem * (nrem + 1) / 2;
+        for (int q = wv; q < ntr; q += 16) {
+            int a = 0;
+            while ((a + 1) * (a + 2) / 2 <= q) a++;
+            const int ti = p + 1 + a, tj = p + 1 + (q - a * (a + 1) / 2);
+            const double* pa = A + (size_t)(16 * ti + (lane & 15)) * ldz + c0 + (lane >> 4);
+            const double* pb = A + (size_t)(16 * tj + (lane & 15)) * ldz + c0 + (lane >> 4);
+            double* pc = A + (size_t)(16 * ti + (lane >> 4)) * ldz + 16 * tj + (lane & 15);
+            double av[4], bv[4];
+            pg_d4 acc;
+#pragma unroll
+            for (int g = 0; g < 4; g++) { av[g] = pa[4 * g]; bv[g] = pb[4 * g]; }
+#pragma unroll
+            for (int v = 0; v < 4; v++) acc[v] = -pc[(size_t)4 * v * ldz];
+#pragma unroll
+            for (int g = 0; g < 4; g++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[g], bv[g], acc, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < 4; v++) pc[(size_t)4 * v * ldz] = -acc[v];
+        }
+        __syncthreads();
+    }
+    // backward substitution L^T x = y in wave 0: lane l owns x[l], x[l + 64], ...
+    if (tid < 64) {
+        constexpr int PER = (6 * PG_MAXS + 63) / 64;
+        double yv[PER];
+#pragma unroll
+        for (int q = 0; q < PER; q++) { const int k = tid + 64 * q; yv[q] = k < mS ? A[(size_t)mS * ldz + k] : 0.0; }
+        for (int j = mS - 1; j >= 0; j--) {
+            double mine = 0;
+#pragma unroll
+            for (int q = 0; q < PER; q++) if (q == (j >> 6)) mine = yv[q];
+            const double xj = __shfl(mine, j & 63, 64) * sInv[j];
+            if (tid == (j & 63)) {
+#pragma unroll
+                for (int q = 0; q < PER; q++) if (q == (j >> 6)) yv[q] = xj;
+            }
+            const double* Lj = A + (size_t)j * ldz;
+#pragma unroll
+            for (int q = 0; q < PER; q++) { const int k = tid + 64 * q; if (k < j) yv[q] -= Lj[k] * xj; }
+        }
+#pragma unroll
+        for (int q = 0; q < PER; q++) { const int k = tid + 64 * q; if (k < mS) xS[k] = yv[q]; }
+    }
+    if (tid == 0 && sbad) *status = 1;
+}
+
+// y = z - Z[:, 0..mS) xS, one thread per row
+__global__ void __launch_bounds__(256) k_pg_y(const double* __restrict__ Z, const double* __restrict__ xS, double* __restrict__ y, int rows, int ldz, int mS) {
+    __shared__ double sx[6 * PG_MAXS];
+    for (int i = threadIdx.x; i < mS; i += 256) sx[i] = xS[i];
+    __syncthreads();
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= rows) return;
+    const double* zr = Z + (size_t)k * ldz;
+    double s = zr[mS];
+    for (int j = 0; j < mS; j++) s -= zr[j] * sx[j];
+    y[k] = s;
+}
+
+// xT_t = L_t^-T (y_t - W_{t+1}^T xT_{t+1}), the backward chain of one segment per workgroup (W = 0 across segment boundaries).
+// Six lanes: lane i owns row i of the step (its row of W_{t+1}^T x and of the back substitution), values exchanged by readlane.
+__global__ void __launch_bounds__(64) k_pg_back(const double* __restrict__ Lw, const double* __restrict__ y, double* __restrict__ xT,
+                                                const int32_t* __restrict__ seg) {
+    const int lane = threadIdx.x, i = lane < 6 ? lane : 5;
+    const int t0 = seg[blockIdx.x], t1 = seg[blockIdx.x + 1];
+    double xn[6] = {0, 0, 0, 0, 0, 0};
+    double nLc[6], nWc[6], ny = 0;                 // column i of L_t (rows k), column i of W_{t+1} (rows k), y_t[i]
+    auto fetch = [&](int t) {
+        const double* L = Lw + (size_t)t * 72;
+#pragma unroll
+        for (int k = 0; k < 6; k++) nLc[k] = L[k * 6 + i];
+        if (t + 1 < t1) {
+            const double* Wn = Lw + (size_t)(t + 1) * 72 + 36;
+#pragma unroll
+            for (int k = 0; k < 6; k++) nWc[k] = Wn[k * 6 + i];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; k++) nWc[k] = 0;
+        }
+        ny = y[6 * t + i];
+    };
+    if (t0 < t1) fetch(t1 - 1);
+    for (int t = t1 - 1; t >= t0; t--) {
+        double Lc[6], Wc[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { Lc[k] = nLc[k]; Wc[k] = nWc[k]; }
+        double r = ny;
+        if (t > t0) fetch(t - 1);
+#pragma unroll
+        for (int k = 0; k < 6; k++) r -= Wc[k] * xn[k];
+        // back substitution L^T x = r: x[5] first; lane i subtracts L[k][i] x[k] for k > i as the x[k] become known
+        double x[6];
+#pragma unroll
+        for (int k = 5; k >= 0; k--) {
+            const double mine = r * Lc[k];         // valid in lane k (Lc[k] = L[k][i] = inverse diagonal when i == k)
+            const int lo = __builtin_amdgcn_readlane((int)(__double_as_longlong(mine) & 0xffffffffll), k);
+            const int hi = __builtin_amdgcn_readlane((int)(__double_as_longlong(mine) >> 32), k);
+            x[k] = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+            if (k > 0) r -= (i < k) ? Lc[k] * x[k] : 0.0;
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) xT[6 * t + k] = x[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) xn[k] = x[k];
+    }
+}
+
+// pose <- exp(x) * pose for every free key-frame; sc[v] = x . (lambda x + b)
+__global__ void __launch_bounds__(256) k_pg_update(double* __restrict__ poses, const int32_t* __restrict__ slot /*n: -1 fixed, t, or nT + s*/,
+                                                   int n, int nT, const double* __restrict__ xT, const double* __restrict__ xS,
+                                                   const double* __restrict__ C, const double* __restrict__ bS, int ldz, int mS, double lambda,
+                                                   double* __restrict__ sc) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= n) return;
+    const int sl = slot[v];
+    double s = 0;
+    if (sl >= 0) {
+        double x[6], b[6];
+        for (int a = 0; a < 6; a++) {
+            if (sl < nT) { x[a] = xT[6 * sl + a]; b[a] = C[(size_t)(6 * sl + a) * ldz + mS]; }
+            else { x[a] = xS[6 * (sl - nT) + a]; b[a] = bS[6 * (sl - nT) + a]; }
+            s += x[a] * (lambda * x[a] + b[a]);
+        }
+        pg_store(pg_mul(pg_exp(x), pg_load(poses + 7 * v)), poses + 7 * v);
+    }
+    sc[v] = s;
+}
+
+// src/loopclosing.cpp:621-633: p <- T_new[kf]^-1 * (T_old[kf] * p)
+__global__ void __launch_bounds__(256) k_correct_map_points(const double* __restrict__ oldp, const double* __restrict__ newp, int nposes,
+                                                            const int32_t* __restrict__ kf, double* __restrict__ pts, int npts, int* __restrict__ status) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= npts) return;
+    const int k = kf[i];
+    if (k < 0) return;
+    if (k >= nposes) { *status = MYSLAM_ERR_INVALID; return; }
+    Se3 To = pg_load(oldp + 7 * k), Tn = pg_load(newp + 7 * k);
+    pg_qnorm(To.q); pg_qnorm(Tn.q);
+    Tn = pg_inv(Tn);
+    double pc[3], pw[3];
+    pg_rot(To.q, pts + 3 * i, pc);
+    pc[0] += To.t[0]; pc[1] += To.t[1]; pc[2] += To.t[2];
+    pg_rot(Tn.q, pc, pw);
+    pts[3 * i] = pw[0] + Tn.t[0]; pts[3 * i + 1] = pw[1] + Tn.t[1]; pts[3 * i + 2] = pw[2] + Tn.t[2];
+}
+
+namespace {
+
+struct DevBuf {                       // frees on scope exit
+    std::vector<void*> ptrs;
+    ~DevBuf() { for (void* p : ptrs) (void)hipFree(p); }
+    template <typename T> hipError_t alloc(T** p, size_t count) {
+        hipError_t e = hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) ptrs.push_back(*p);
+        return e;
+    }
+};
+
+}  // namespace
+}  // namespace myslam_hip
+
+using namespace myslam_hip;
+
+extern "C" {
+
+int myslam_pose_graph_optimize(double* poses, int n, const uint8_t* fixed, const int32_t* edge_v0, const int32_t* edge_v1,
+                               const double* meas, int n_edges, int max_iters, double* final_chi2, int* iters) {
+    if (n < 0 || n_edges < 0 || max_iters < 0 || (n > 0 && !poses) || (n_edges > 0 && (!edge_v0 || !edge_v1 || !meas))) return MYSLAM_ERR_INVALID;
+    const int E = n_edges;
+    for (int k = 0; k < E; k++)
+        if (edge_v0[k] < 0 || edge_v0[k] >= n || edge_v1[k] < 0 || edge_v1[k] >= n || edge_v0[k] == edge_v1[k]) return MYSLAM_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MYSLAM_ERR_HIP;
+    if (final_chi2) *final_chi2 = 0;
+    if (iters) *iters = 0;
+    if (n == 0) return MYSLAM_OK;
+
+    // ---- structure: fixed / chain (T) / separator (S) key-frames ----
+    std::vector<uint8_t> fx(n, 0);
+    if (fixed) for (int i = 0; i < n; i++) fx[i] = fixed[i] ? 1 : 0;
+    std::vector<char> inS(n, 0);
+    std::vector<int> tpos(n, -1), deg(n);
+    int nS = 0, nT = 0;
+    for (;;) {
+        nT = 0;
+        for (int i = 0; i < n; i++) tpos[i] = (!fx[i] && !inS[i]) ? nT++ : -1;
+        std::fill(deg.begin(), deg.end(), 0);
+        bool any = false;
+        for (int k = 0; k < E; k++) {
+            const int a = tpos[edge_v0[k]], b = tpos[edge_v1[k]];
+            if (a >= 0 && b >= 0 && std::abs(a - b) > 1) { deg[edge_v0[k]]++; deg[edge_v1[k]]++; any = true; }
+        }
+        if (!any) break;
+        int best = -1;                                   // the key-frame on the most off-chain edges, latest on ties
+        for (int i = 0; i < n; i++) if (deg[i] > 0 && (best < 0 || deg[i] >= deg[best])) best = i;
+        inS[best] = 1;
+        if (++nS > PG_MAXS) return MYSLAM_ERR_UNSUPPORTED;
+    }
+    // Cut long chain runs with extra separators so that the serial sweeps (one step per key-frame of a run) become short and
+    // run in parallel: run length ~ sqrt(11 nT) (measured optimum at 1500 key-frames) balances them against the dense Schur system, which grows by 6 per cut.
+    auto chain_links = [&](std::vector<char>& link) {     // link[t] = an edge joins chain positions t-1 and t
+        link.assign(nT + 1, 0);
+        for (int k = 0; k < E; k++) {
+            const int a = tpos[edge_v0[k]], b = tpos[edge_v1[k]];
+            if (a >= 0 && b >= 0) link[std::max(a, b)] = 1;
+        }
+        if (nT > 0) link[0] = 0;
+        link[nT] = 0;
+    };
+    std::vector<char> link;
+    chain_links(link);
+    {
+        std::vector<int> tvert(nT);
+        for (int i = 0; i < n; i++) if (tpos[i] >= 0) tvert[tpos[i]] = i;
+        const char* lenv = getenv("MYSLAM_PGO_RUN");
+        int lmax = lenv ? atoi(lenv) : std::max(16, (int)std::ceil(std::sqrt(11.0 * nT)));
+        for (;; lmax *= 2) {
+            std::vector<int> cuts;
+            for (int s0 = 0; s0 < nT;) {
+                int e = s0 + 1;
+                while (e < nT && link[e]) e++;
+                const int len = e - s0, parts = (len + 1 + lmax) / (lmax + 1);
+                for (int i = 1; i < parts; i++) cuts.push_back(s0 + (int)((long long)i * len / parts));
+                s0 = e;
+            }
+            if (nS + (int)cuts.size() > PG_MAXS) continue;
+            for (int t : cuts) inS[tvert[t]] = 1;
+            nS += (int)cuts.size();
+            break;
+        }
+        nT = 0;
+        for (int i = 0; i < n; i++) tpos[i] = (!fx[i] && !inS[i]) ? nT++ : -1;
+        chain_links(link);
+    }
+    std::vector<int32_t> seg;                             // chain runs [seg[i], seg[i+1])
+    for (int t = 0; t < nT; t++) if (!link[t]) seg.push_back(t);
+    seg.push_back(nT);
+    const int nseg = (int)seg.size() - 1;
+    std::vector<int> spos(n, -1), slot(n, -1);
+    { int s2 = 0; for (int i = 0; i < n; i++) if (inS[i]) spos[i] = s2++; }
+    for (int i = 0; i < n; i++) slot[i] = tpos[i] >= 0 ? tpos[i] : (spos[i] >= 0 ? nT + spos[i] : -1);
+    const int nF = nT + nS, mS = 6 * nS, ldz = ((mS + 1 + 15) / 16) * 16, nt16 = ldz / 16, ntile = nt16 * (nt16 + 1) / 2;
+    const int rows = 6 * nT, k4 = (rows + 3) / 4, rowsPad = 4 * k4;
+
+    // ---- assembly jobs: destination block -> list of (edge, row side | col side << 1) ----
+    std::map<std::tuple<int, int, int>, std::vector<int2>> jobmap;
+    for (int k = 0; k < E; k++) {
+        const int v[2] = {edge_v0[k], edge_v1[k]};
+        for (int s = 0; s < 2; s++) {
+            if (slot[v[s]] < 0) continue;
+            if (tpos[v[s]] >= 0) jobmap[{0, tpos[v[s]], 0}].push_back(make_int2(k, s | (s << 1)));
+            else jobmap[{3, spos[v[s]], 0}].push_back(make_int2(k, s | (s << 1)));
+        }
+        if (slot[v[0]] < 0 || slot[v[1]] < 0) continue;
+        const bool t0 = tpos[v[0]] >= 0, t1 = tpos[v[1]] >= 0;
+        if (t0 && t1) {
+            const int rs = tpos[v[0]] > tpos[v[1]] ? 0 : 1;       // row block = the later key-frame of the chain
+            jobmap[{1, tpos[v[rs]], 0}].push_back(make_int2(k, rs | ((1 - rs) << 1)));
+        } else if (t0 != t1) {
+            const int rs = t0 ? 0 : 1;                             // rows = the chain key-frame, columns = the separator
+            jobmap[{2, tpos[v[rs]], spos[v[1 - rs]]}].push_back(make_int2(k, rs | ((1 - rs) << 1)));
+        } else {
+            const int rs = spos[v[0]] > spos[v[1]] ? 0 : 1;
+            jobmap[{4, spos[v[rs]], spos[v[1 - rs]]}].push_back(make_int2(k, rs | ((1 - rs) << 1)));
+        }
+    }
+    std::vector<PgJob> jobs;
+    std::vector<int2> list;
+    for (auto& kv : jobmap) {
+        PgJob j{std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first), (int)list.size(), 0};
+        list.insert(list.end(), kv.second.begin(), kv.second.end());
+        j.end = (int)list.size();
+        jobs.push_back(j);
+    }
+
+    // ---- device state ----
+    DevBuf mem;
+    double *d_pose, *d_save, *d_meas, *d_minv, *d_J, *d_err, *d_D, *d_B, *d_C, *d_Z, *d_Lw, *d_Hss, *d_bS, *d_A, *d_xS, *d_xT, *d_y, *d_P, *d_diag,
+        *d_sc, *d_part, *d_res;
+    int32_t *d_e0, *d_e1, *d_slot, *d_seg; uint8_t* d_fx; PgJob* d_jobs; int2* d_list; int* d_status;
+    const int nchi = (E + 255) / 256;
+    MYSLAM_HIP_CHECK(mem.alloc(&d_pose, (size_t)7 * n)); MYSLAM_HIP_CHECK(mem.alloc(&d_save, (size_t)7 * n));
+    MYSLAM_HIP_CHECK(mem.alloc(&d_meas, (size_t)7 * E)); MYSLAM_HIP_CHECK(mem.alloc(&d_minv, (size_t)7 * E));
+    MYSLAM_HIP_CHECK(mem.alloc(&d_J, (size_t)72 * E)); MYSLAM_HIP_CHECK(mem.alloc(&d_err, (size_t)6 * E));
+    MYSLAM_HIP_CHECK(mem.alloc(&d_D, (size_t)36 * std::max(nT, 1))); MYSLAM_HIP_CHECK(mem.alloc(&d_B, (size_t)36 * std::max(nT, 1)));
+    MYSLAM_HIP_CHECK(mem.alloc(&d_C, (size_t)rowsPad * ldz)); MYSLAM_HIP_CHECK(mem.alloc(&d_Z, (size_t)rowsPad * ldz));
+    MYSLAM_HIP_CHECK(mem.alloc(&d_Lw, (size_t)72 * nT)); MYSLAM_HIP_CHECK(mem.alloc(&d_Hss, (size_t)ldz * ldz));
+    MYSLAM_HIP_CHECK(mem.alloc(&d_bS, (size_t)ldz)); MYSLAM_HIP_CHECK(mem.alloc(&d_A, (size_t)ldz * ldz));
+    MYSLAM_HIP_CHECK(mem.alloc(&d_xS, (size_t)ldz)); MYSLAM_HIP_CHECK(mem.alloc(&d_xT, (size_t)rowsPad)); MYSLAM_HIP_CHECK(mem.alloc(&d_y, (size_t)rowsPad));
+    MYSLAM_HIP_CHECK(mem.alloc(&d_P, (size_t)PG_KS * ntile * 256)); MYSLAM_HIP_CHECK(mem.alloc(&d_diag, (size_t)6 * nF));
+    MYSLAM_HIP_CHECK(mem.alloc(&d_sc, (size_t)n)); MYSLAM_HIP_CHECK(mem.alloc(&d_part, (size_t)nchi)); MYSLAM_HIP_CHECK(mem.alloc(&d_res, 4));
+    MYSLAM_HIP_CHECK(mem.alloc(&d_e0, (size_t)E)); MYSLAM_HIP_CHECK(mem.alloc(&d_e1, (size_t)E)); MYSLAM_HIP_CHECK(mem.alloc(&d_slot, (size_t)n));
+    MYSLAM_HIP_CHECK(mem.alloc(&d_fx, (size_t)n)); MYSLAM_HIP_CHECK(mem.alloc(&d_jobs, jobs.size())); MYSLAM_HIP_CHECK(mem.alloc(&d_list, list.size()));
+    MYSLAM_HIP_CHECK(mem.alloc(&d_status, 1)); MYSLAM_HIP_CHECK(mem.alloc(&d_seg, seg.size()));
+    MYSLAM_HIP_CHECK(hipMemcpy(d_seg, seg.data(), sizeof(int32_t) * seg.size(), hipMemcpyHostToDevice));
+    MYSLAM_HIP_CHECK(hipMemcpy(d_pose, poses, sizeof(double) * 7 * n, hipMemcpyHostToDevice));
+    MYSLAM_HIP_CHECK(hipMemcpy(d_fx, fx.data(), n, hipMemcpyHostToDevice));
+    MYSLAM_HIP_CHECK(hipMemcpy(d_slot, slot.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    if (E) {
+        MYSLAM_HIP_CHECK(hipMemcpy(d_meas, meas, sizeof(double) * 7 * E, hipMemcpyHostToDevice));
+        MYSLAM_HIP_CHECK(hipMemcpy(d_e0, edge_v0, sizeof(int32_t) * E, hipMemcpyHostToDevice));
+        MYSLAM_HIP_CHECK(hipMemcpy(d_e1, edge_v1, sizeof(int32_t) * E, hipMemcpyHostToDevice));
+    }
+    if (!jobs.empty()) {
+        MYSLAM_HIP_CHECK(hipMemcpy(d_jobs, jobs.data(), sizeof(PgJob) * jobs.size(), hipMemcpyHostToDevice));
+        MYSLAM_HIP_CHECK(hipMemcpy(d_list, list.data(), sizeof(int2) * list.size(), hipMemcpyHostToDevice));
+    }
+    // blocks no job writes stay zero for the whole run (the sparsity pattern is fixed)
+    MYSLAM_HIP_CHECK(hipMemset(d_D, 0, sizeof(double) * 36 * std::max(nT, 1))); MYSLAM_HIP_CHECK(hipMemset(d_B, 0, sizeof(double) * 36 * std::max(nT, 1)));
+    MYSLAM_HIP_CHECK(hipMemset(d_C, 0, sizeof(double) * std::max<size_t>((size_t)rowsPad * ldz, 1)));
+    MYSLAM_HIP_CHECK(hipMemset(d_Z, 0, sizeof(double) * std::max<size_t>((size_t)rowsPad * ldz, 1)));
+    MYSLAM_HIP_CHECK(hipMemset(d_Hss, 0, sizeof(double) * ldz * ldz)); MYSLAM_HIP_CHECK(hipMemset(d_bS, 0, sizeof(double) * ldz));
+    MYSLAM_HIP_CHECK(hipMemset(d_diag, 0, sizeof(double) * std::max(6 * nF, 1)));
+    MYSLAM_HIP_CHECK(hipMemset(d_xS, 0, sizeof(double) * ldz)); MYSLAM_HIP_CHECK(hipMemset(d_xT, 0, sizeof(double) * std::max(rowsPad, 1)));
+
+    hipStream_t st = nullptr;
+    const int npe = std::max(n, E);
+    hipLaunchKernelGGL(k_pg_prepare, dim3((npe + 255) / 256), dim3(256), 0, st, d_pose, n, d_meas, d_minv, E);
+    auto chi2 = [&](double* out) -> int {               // d_res[0] <- sum of e^T e over all edges
+        if (E == 0) { *out = 0; return MYSLAM_OK; }
+        hipLaunchKernelGGL(k_pg_chi2, dim3(nchi), dim3(256), 0, st, d_pose, d_minv, d_e0, d_e1, E, d_part);
+        hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, st, d_part, nchi, d_res, 0);
+        MYSLAM_HIP_CHECK(hipMemcpy(out, d_res, sizeof(double), hipMemcpyDeviceToHost));
+        return MYSLAM_OK;
+    };
+    int it = 0, rc;
+    double currentChi = 0;
+    if ((rc = chi2(&currentChi)) != MYSLAM_OK) return rc;
+    if (nF > 0 && E > 0) {
+        double lambda = 0, ni = 2;
+        for (; it < max_iters; it++) {
+            double tempChi = currentChi;
+            hipLaunchKernelGGL(k_pg_linearize, dim3((12 * E + 127) / 128), dim3(128), 0, st, d_pose, d_minv, d_e0, d_e1, d_fx, E, d_J, d_err);
+            hipLaunchKernelGGL(k_pg_assemble, dim3((unsigned)jobs.size()), dim3(64), 0, st, d_jobs, d_list, d_J, d_err, d_D, d_B, d_C, d_Hss, d_bS, d_diag,
+                               ldz, mS, nT);
+            if (it == 0) {                              // computeLambdaInit: tau * max diagonal
+                double mx = 0;
+                hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, st, d_diag, 6 * nF, d_res, 1);
+                MYSLAM_HIP_CHECK(hipMemcpy(&mx, d_res, sizeof(double), hipMemcpyDeviceToHost));
+                lambda = 1e-5 * mx; ni = 2;
+            }
+            double rho = 0;
+            int qmax = 0;
+            do {
+                MYSLAM_HIP_CHECK(hipMemcpyAsync(d_save, d_pose, sizeof(double) * 7 * n, hipMemcpyDeviceToDevice, st));
+                MYSLAM_HIP_CHECK(hipMemsetAsync(d_status, 0, sizeof(int), st));
+                if (nT > 0) {
+                    hipLaunchKernelGGL(k_pg_sweep, dim3((ldz + 63) / 64, nseg), dim3(64), 0, st, d_D, d_B, d_C, d_Z, d_Lw, d_seg, ldz, lambda, d_status);
+                    hipLaunchKernelGGL(k_pg_syrk, dim3(ntile, PG_KS), dim3(64), 0, st, d_Z, d_P, ldz, k4, ntile);
+                }
+                if (mS > 0)
+                    hipLaunchKernelGGL(k_pg_schur, dim3(1), dim3(1024), 0, st, d_Hss, d_bS, d_P, d_A, d_xS, mS, ldz, ntile, nT > 0 ? 1 : 0, lambda, d_status);
+                if (nT > 0) {
+                    hipLaunchKernelGGL(k_pg_y, dim3((rows + 255) / 256), dim3(256), 0, st, d_Z, d_xS, d_y, rows, ldz, mS);
+                    hipLaunchKernelGGL(k_pg_back, dim3(nseg), dim3(64), 0, st, d_Lw, d_y, d_xT, d_seg);
+                }
+                hipLaunchKernelGGL(k_pg_update, dim3((n + 255) / 256), dim3(256), 0, st, d_pose, d_slot, n, nT, d_xT, d_xS, d_C, d_bS, ldz, mS, lambda, d_sc);
+                hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, st, d_sc, n, d_res + 1, 0);
+                hipLaunchKernelGGL(k_pg_chi2, dim3(nchi), dim3(256), 0, st, d_pose, d_minv, d_e0, d_e1, E, d_part);
+                hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, st, d_part, nchi, d_res, 0);
+                MYSLAM_HIP_CHECK(hipGetLastError());
+                double res[2]; int bad = 0;
+                MYSLAM_HIP_CHECK(hipMemcpy(res, d_res, sizeof(res), hipMemcpyDeviceToHost));
+                MYSLAM_HIP_CHECK(hipMemcpy(&bad, d_status, sizeof(int), hipMemcpyDeviceToHost));
+                const bool ok = !bad;
+                tempChi = ok ? res[0] : 1e300;
+                rho = currentChi - tempChi;
+                double scale = 1e-3;
+                if (ok) scale += res[1];
+                rho /= scale;
+                if (rho > 0 && std::isfinite(tempChi) && ok) {
+                    double alpha = 1. - pow(2 * rho - 1, 3);
+                    alpha = std::min(alpha, 2. / 3.);
+                    lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi;
+                } else {
+                    lambda *= ni; ni *= 2;
+                    MYSLAM_HIP_CHECK(hipMemcpyAsync(d_pose, d_save, sizeof(double) * 7 * n, hipMemcpyDeviceToDevice, st));
+                    if (!std::isfinite(lambda)) break;
+                }
+                qmax++;
+            } while (rho < 0 && qmax < 10);
+            if (qmax == 10 || rho == 0 || !std::isfinite(lambda)) { it++; break; }
+        }
+    }
+    MYSLAM_HIP_CHECK(hipMemcpy(poses, d_pose, sizeof(double) * 7 * n, hipMemcpyDeviceToHost));
+    if (final_chi2) *final_chi2 = currentChi;
+    if (iters) *iters = it;
+    return MYSLAM_OK;
+}
+
+int myslam_correct_map_points_device(const double* d_old_poses, const double* d_new_poses, int n_poses, const int32_t* d_first_kf,
+                                     double* d_points, int n_points, int32_t* d_status, void* hip_stream) {
+    if (n_points < 0 || n_poses < 0 || (n_points > 0 && (!d_old_poses || !d_new_poses || !d_first_kf || !d_points || !d_status))) return MYSLAM_ERR_INVALID;
+    if (n_points == 0) return MYSLAM_OK;
+    hipLaunchKernelGGL(k_correct_map_points, dim3((n_points + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, d_old_poses, d_new_poses, n_poses,
+                       d_first_kf, d_points, n_points, d_status);
+    MYSLAM_HIP_CHECK(hipGetLastError());
+    return MYSLAM_OK;
+}
+
+int myslam_correct_map_points(const double* old_poses, const double* new_poses, int n_poses, const int32_t* first_kf, double* points, int n_points) {
+    if (n_points < 0 || n_poses < 0 || (n_points > 0 && (!old_poses || !new_poses || !first_kf || !points))) return MYSLAM_ERR_INVALID;
+    if (n_points == 0) return MYSLAM_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MYSLAM_ERR_HIP;
+    DevBuf mem;
+    double *d_o, *d_n, *d_p; int32_t *d_k, *d_s;
+    MYSLAM_HIP_CHECK(mem.alloc(&d_o, (size_t)7 * n_poses)); MYSLAM_HIP_CHECK(mem.alloc(&d_n, (size_t)7 * n_poses));
+    MYSLAM_HIP_CHECK(mem.alloc(&d_p, (size_t)3 * n_points)); MYSLAM_HIP_CHECK(mem.alloc(&d_k, (size_t)n_points)); MYSLAM_HIP_CHECK(mem.alloc(&d_s, 1));
+    if (n_poses) {
+        MYSLAM_HIP_CHECK(hipMemcpy(d_o, old_poses, sizeof(double) * 7 * n_poses, hipMemcpyHostToDevice));
+        MYSLAM_HIP_CHECK(hipMemcpy(d_n, new_poses, sizeof(double) * 7 * n_poses, hipMemcpyHostToDevice));
+    }
+    MYSLAM_HIP_CHECK(hipMemcpy(d_p, points, sizeof(double) * 3 * n_points, hipMemcpyHostToDevice));
+    MYSLAM_HIP_CHECK(hipMemcpy(d_k, first_kf, sizeof(int32_t) * n_points, hipMemcpyHostToDevice));
+    MYSLAM_HIP_CHECK(hipMemset(d_s, 0, sizeof(int32_t)));
+    int rc = myslam_correct_map_points_device(d_o, d_n, n_poses, d_k, d_p, n_points, d_s, nullptr);
+    if (rc != MYSLAM_OK) return rc;
+    int32_t stt = 0;
+    MYSLAM_HIP_CHECK(hipMemcpy(&stt, d_s, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (stt != 0) return stt;
+    MYSLAM_HIP_CHECK(hipMemcpy(points, d_p, sizeof(double) * 3 * n_points, hipMemcpyDeviceToHost));
+    return MYSLAM_OK;
+}
+
+}  // extern "C"

@@ -179,3 +179,83 @@ def ba_problem(seed=0xBA, n_kf=10, n_mp=300, noise_px=0.5, outlier_frac=0.03, pe
         poses[:, 4:] += rng.normal(0, 0.02, size=(n_kf, 3))
     Kt = (K["fx"], K["fy"], K["cx"], K["cy"])
     return poses, pts, ep, el, obs, fixed, Kt
+
+
+# ---- loop correction: synthetic pose graphs ------------------------------------------------------------------------
+
+def _so3_exp(w):
+    th = float(np.linalg.norm(w))
+    W = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0.0]])
+    if th < 1e-12:
+        return np.eye(3) + W
+    return np.eye(3) + np.sin(th) / th * W + (1 - np.cos(th)) / th ** 2 * (W @ W)
+
+
+def _R_to_quat(R):
+    tr = np.trace(R)
+    if tr > 0:
+        s = np.sqrt(tr + 1.0) * 2; q = [(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s]
+    else:
+        i = int(np.argmax(np.diag(R))); j = (i + 1) % 3; k = (i + 2) % 3
+        s = np.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2
+        q = [0, 0, 0, (R[k, j] - R[j, k]) / s]
+        q[i] = 0.25 * s; q[j] = (R[j, i] + R[i, j]) / s; q[k] = (R[k, i] + R[i, k]) / s
+    q = np.array(q)
+    return q / np.linalg.norm(q)
+
+
+def _T_to_pose7(T):
+    return np.concatenate([_R_to_quat(T[:3, :3]), T[:3, 3]])
+
+
+def pose_graph(n_kf=200, n_loops=2, seed=0x9A, odo_noise=(0.002, 0.02), loop_noise=(0.0005, 0.005), n_active=10, laps=2.2):
+    """A key-frame pose graph as LoopClosing::PoseGraphOptimization builds it (src/loopclosing.cpp:546-601):
+    a car driving `laps` times round a circuit, key-frame poses Tcw integrated from noisy odometry (so they drift),
+    one edge per (KF, previous KF) with the odometry as measurement, `n_loops` loop edges (KF, much older KF at the same
+    place) with a near-true relative pose, and the reference's fixed set {KF 0, the last loop's loop-KF, the last n_active}.
+    Returns poses (n,7), fixed (n,), e0, e1 (E,), meas (E,7) with meas = T[e0] * T[e1]^-1, and the ground truth (n,7)."""
+    rng = _rng(seed)
+    per_lap = n_kf / laps
+    Tgt = []
+    for i in range(n_kf):
+        a = 2 * np.pi * i / per_lap
+        r = 40.0 + 6.0 * np.sin(3 * a)
+        twc = np.array([r * np.cos(a), 0.3 * np.sin(2 * a), r * np.sin(a)])
+        Rwc = _so3_exp(np.array([0.0, -(a + np.pi / 2), 0.0])) @ _so3_exp(np.array([0.02 * np.sin(5 * a), 0, 0.03 * np.cos(4 * a)]))
+        T = np.eye(4); T[:3, :3] = Rwc.T; T[:3, 3] = -Rwc.T @ twc
+        Tgt.append(T)
+
+    def noisy(T, s_rot, s_tr):
+        N = np.eye(4); N[:3, :3] = _so3_exp(rng.normal(0, s_rot, 3)); N[:3, 3] = rng.normal(0, s_tr, 3)
+        return N @ T
+
+    e0, e1, meas = [], [], []
+    Test = [Tgt[0]]
+    for i in range(1, n_kf):
+        M = noisy(Tgt[i] @ np.linalg.inv(Tgt[i - 1]), *odo_noise)
+        e0.append(i); e1.append(i - 1); meas.append(_T_to_pose7(M))
+        Test.append(M @ Test[-1])
+    fixed = np.zeros(n_kf, np.uint8)
+    fixed[0] = 1
+    fixed[max(0, n_kf - n_active):] = 1
+    lap = int(round(per_lap))
+    cand = [i for i in range(lap + 5, n_kf - n_active - 1)]
+    n_old = max(n_loops - 1, 0)
+    picks = sorted(rng.choice(cand, size=min(n_old, len(cand)), replace=False).tolist()) if n_old and cand else []
+    if n_loops:
+        picks.append(n_kf - 1)                                          # the loop being closed starts at the current key-frame
+    for k, i in enumerate(picks):
+        j = i - lap + int(rng.integers(-2, 3))
+        j = min(max(j, 1), i - 21)
+        M = noisy(Tgt[i] @ np.linalg.inv(Tgt[j]), *loop_noise)
+        e0.append(i); e1.append(j); meas.append(_T_to_pose7(M))
+        if k == len(picks) - 1:
+            # LoopLocalFusion (:466-533) has already moved the active window onto the corrected current pose
+            fixed[j] = 1
+            Tcorr = M @ Test[j]
+            rel = np.linalg.inv(Test[i]) @ Tcorr
+            for a in range(max(0, n_kf - n_active), n_kf):
+                Test[a] = Test[a] @ rel
+    poses = np.stack([_T_to_pose7(T) for T in Test])
+    gt = np.stack([_T_to_pose7(T) for T in Tgt])
+    return poses, fixed, np.array(e0, np.int32), np.array(e1, np.int32), np.array(meas).reshape(-1, 7), gt

@@ -276,6 +276,30 @@ int myslam_lk_track(myslam_lk* h, const uint8_t* prev, const uint8_t* next, int 
 int myslam_lk_track_batch(myslam_lk* h, const uint8_t* d_prev, const uint8_t* d_next, int batch, int rows, int cols, int step, size_t stride,
                           const float* d_prev_pts, float* d_next_pts, const int32_t* d_counts, int cap, uint8_t* d_status, float* d_err);
 
+/* ------------------------------------------------------------------------------------------
+ * Loop correction — replaces the g2o part of LoopClosing::PoseGraphOptimization (src/loopclosing.cpp:537-610) and the map-point
+ * write-back that follows it (:612-640).   [SURVEY.md §8(f) rank 3]
+ * poses: n x 7 (qx qy qz qw tx ty tz) Tcw of every key-frame, in/out (VertexPose, :548-565); fixed[i] != 0 for the key-frames the
+ * reference fixes (:557-562: active window, loop key-frame, key-frame 0); edge k = EdgePoseGraph between poses edge_v0[k] and
+ * edge_v1[k] with measurement meas[k] (7 doubles, = T[v0] * T[v1]^-1 when the edge is satisfied: mRelativePoseToLastKF :577-588,
+ * mRelativePoseToLoopKF :590-601), information I6, error log(meas^-1 * T[v0] * T[v1]^-1) (include/myslam/g2o_types.h:157-167),
+ * Jacobians by g2o's central differences (delta 1e-9; the analytic linearizeOplus is commented out at g2o_types.h:168-182).
+ * Runs g2o's Levenberg for max_iters (20, :606) iterations.  *final_chi2 = sum of e^T e at the returned poses, *iters = iterations
+ * done.  Host pointers; uploads, runs and downloads synchronously on the null stream.
+ * Solver structure: key-frames in index order form the chain; every edge that does not join neighbouring free key-frames adds
+ * one separator key-frame to a dense Schur block (at most 96 separators: MYSLAM_ERR_UNSUPPORTED beyond, i.e. graphs far from
+ * chain + loops); long chain runs are cut by further separators so that the serial block-tridiagonal sweeps run in parallel.
+ * ------------------------------------------------------------------------------------------ */
+int myslam_pose_graph_optimize(double* poses, int n, const uint8_t* fixed, const int32_t* edge_v0, const int32_t* edge_v1,
+                               const double* meas, int n_edges, int max_iters, double* final_chi2, int* iters);
+/* src/loopclosing.cpp:621-633: points[i] <- T_new[first_kf[i]]^-1 * (T_old[first_kf[i]] * points[i]) — each map point outside the
+ * active window keeps its camera-frame position in the key-frame that first observed it; first_kf[i] < 0 leaves the point alone
+ * (the :625-629 skip).  old_poses / new_poses: n_poses x 7 as above; points n_points x 3 in/out. */
+int myslam_correct_map_points(const double* old_poses, const double* new_poses, int n_poses, const int32_t* first_kf, double* points, int n_points);
+/* device pointers, asynchronous on hip_stream; *d_status (zeroed by the caller) receives MYSLAM_ERR_INVALID for an index >= n_poses */
+int myslam_correct_map_points_device(const double* d_old_poses, const double* d_new_poses, int n_poses, const int32_t* d_first_kf,
+                                     double* d_points, int n_points, int32_t* d_status, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -148,6 +148,15 @@ int orc_lk_track(const uint8_t* prev, const uint8_t* next, int rows, int cols, i
                  const float* prev_pts, float* next_pts, int n, int win, int max_level, int max_iters, float eps,
                  float min_eig_threshold, uint8_t* status, float* err);
 
+/* ---- loop correction (pgo_oracle.cpp): LoopClosing::PoseGraphOptimization, src/loopclosing.cpp:537-646 ---- */
+/* poses n x 7 (qx qy qz qw tx ty tz) Tcw in/out; edge k: error = log(meas_k^-1 * T[e0] * T[e1]^-1) (g2o_types.h:157-167) */
+int orc_pose_graph_optimize(double* poses, int n, const uint8_t* fixed, const int32_t* e0, const int32_t* e1,
+                            const double* meas, int E, int max_iters, double* final_chi2, int* iters);
+/* :621-633: p <- T_new[kf]^-1 * (T_old[kf] * p); kf < 0 leaves the point alone */
+int orc_correct_map_points(const double* old_poses, const double* new_poses, int nposes, const int32_t* kf, double* pts, int npts);
+int orc_se3_log(const double* q_t7, double* xi6);
+int orc_se3_compose(const double* a7, const double* b7, int invert_b, double* out7);
+
 #ifdef __cplusplus
 }
 #endif

@@ -366,3 +366,29 @@ class Oracle:
         xi = np.ascontiguousarray(xi, np.float64); out = np.zeros(7)
         self.lib.orc_se3_exp(_p(xi), _p(out))
         return out
+
+    # ---- loop correction: pose graph ----
+    def se3_log(self, pose7):
+        p = np.ascontiguousarray(pose7, np.float64); out = np.zeros(6)
+        self.lib.orc_se3_log(_p(p), _p(out))
+        return out
+
+    def se3_compose(self, a7, b7, invert_b=False):
+        a = np.ascontiguousarray(a7, np.float64); b = np.ascontiguousarray(b7, np.float64); out = np.zeros(7)
+        self.lib.orc_se3_compose(_p(a), _p(b), int(invert_b), _p(out))
+        return out
+
+    def pose_graph_optimize(self, poses, fixed, e0, e1, meas, iters=20):
+        poses = np.ascontiguousarray(poses, np.float64).copy(); fixed = np.ascontiguousarray(fixed, np.uint8)
+        e0 = np.ascontiguousarray(e0, np.int32); e1 = np.ascontiguousarray(e1, np.int32); meas = np.ascontiguousarray(meas, np.float64)
+        chi = C.c_double(); it = C.c_int()
+        rc = self.lib.orc_pose_graph_optimize(_p(poses), len(poses), _p(fixed), _p(e0), _p(e1), _p(meas), len(e0), iters, C.byref(chi), C.byref(it))
+        assert rc == 0, rc
+        return poses, chi.value, it.value
+
+    def correct_map_points(self, old_poses, new_poses, kf, pts):
+        old_poses = np.ascontiguousarray(old_poses, np.float64); new_poses = np.ascontiguousarray(new_poses, np.float64)
+        kf = np.ascontiguousarray(kf, np.int32); pts = np.ascontiguousarray(pts, np.float64).copy()
+        rc = self.lib.orc_correct_map_points(_p(old_poses), _p(new_poses), len(old_poses), _p(kf), _p(pts), len(pts))
+        assert rc == 0, rc
+        return pts

@@ -60,4 +60,10 @@ uv[::9] += 30.0
 T0 = np.array([0, 0, 0, 1, 0, 0, 0.0])
 po_pose, po_out, po_inl = o.pose_only_optimize(T0, P3, uv, Kt)
 np.savez_compressed(os.path.join(HERE, "pose_only_small.npz"), pose0=T0, pts3d=P3, obs=uv, K=np.array(Kt), pose=po_pose, outlier=po_out, inliers=po_inl)
+# loop correction: a 40 key-frame pose graph with one loop, optimised for 3 and for 20 iterations
+pg = synth.pose_graph(40, 1, seed=0x60)
+pg3 = o.pose_graph_optimize(*pg[:5], iters=3)
+pg20 = o.pose_graph_optimize(*pg[:5], iters=20)
+np.savez_compressed(os.path.join(HERE, "pgo_small.npz"), poses=pg[0], fixed=pg[1], e0=pg[2], e1=pg[3], meas=pg[4],
+                    poses3=pg3[0], chi3=pg3[1], poses20=pg20[0], chi20=pg20[1], its20=pg20[2])
 print("golden fixtures written to", HERE)

@@ -28,6 +28,18 @@ def test_oracle_reproduces_golden(oracle, synth):
     q = np.load(os.path.join(G, "pose_only_small.npz"))
     pose, outl, inl = oracle.pose_only_optimize(q["pose0"], q["pts3d"], q["obs"], tuple(q["K"]))
     assert np.allclose(pose, q["pose"], rtol=1e-12, atol=1e-12) and np.array_equal(outl, q["outlier"]) and inl == int(q["inliers"])
+    _check_pgo(oracle.pose_graph_optimize, synth, 1e-9)
+
+
+def _check_pgo(fn, synth, tol):
+    """tol: the numeric-Jacobian noise floor of the operator at 40 key-frames is ~1e-6 (tests/test_gpu_pgo.py); the oracle on the
+    same libm reproduces itself far below that."""
+    p = np.load(os.path.join(G, "pgo_small.npz"))
+    assert np.array_equal(p["poses"], synth.pose_graph(40, 1, seed=0x60)[0])
+    for its, key in ((3, "3"), (20, "20")):
+        poses, chi, done = fn(p["poses"], p["fixed"], p["e0"], p["e1"], p["meas"], iters=its)
+        assert np.abs(poses - p["poses" + key]).max() < tol and abs(chi - float(p["chi" + key])) <= 1e3 * tol * float(p["chi" + key])
+    assert done == int(p["its20"])
 
 
 @pytest.mark.gpu
@@ -51,3 +63,4 @@ def test_hip_reproduces_golden(api, synth):
     q = np.load(os.path.join(G, "pose_only_small.npz"))
     pose, outl, inl = api.pose_only_optimize(q["pose0"], q["pts3d"], q["obs"], tuple(q["K"]))
     assert np.allclose(pose, q["pose"], rtol=1e-8, atol=1e-9) and np.array_equal(outl, q["outlier"]) and inl == int(q["inliers"])
+    _check_pgo(api.pose_graph_optimize, synth, 2e-5)

@@ -1,0 +1,108 @@
+"""Loop correction on the GPU: pose-graph optimisation and the map-point write-back against the oracle's restatement of
+LoopClosing::PoseGraphOptimization (src/loopclosing.cpp:537-646).
+
+Tolerances.  g2o differentiates EdgePoseGraph numerically with delta = 1e-9 (the reference commented the analytic Jacobian out),
+so every Jacobian entry is a difference of two O(1..40) numbers divided by 2e-9: ~1e-6 of rounding noise that depends on the last
+bit of every operation.  A long chain is also soft along its bending modes (smallest Hessian eigenvalue ~ (pi / n)^2), so that
+noise moves the optimum itself.  Measured on the oracle alone (same source built with and without FMA contraction, or with one
+atan result moved by 1 ulp): 20 iterations end 4e-7 / 2.4e-5 / 9e-5 / 2e-3 / 3e-3 apart at n = 60 / 200 / 400 / 900 / 1500
+key-frames, a single iteration 5e-6 ... 7e-4, while the final chi2 agrees to 1e-6.  That is the reference's own noise floor;
+the parity bars here sit just above it:
+    chi2      1e-3 relative
+    poses     5e-4 * max(1, n / 200)^2  (metres, quaternion components)
+The error function itself is checked sharply: the oracle's chi2 at the device's poses equals the device's chi2 to 1e-9.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+def _cmp(got, ref, tol=None):
+    gp, gchi, git = got; rp, rchi, rit = ref
+    if tol is None:
+        tol = 5e-4 * max(1.0, len(gp) / 200.0) ** 2
+    s = np.sign(np.sum(gp[:, :4] * rp[:, :4], axis=1))[:, None]
+    assert np.abs(gp[:, :4] * s - rp[:, :4]).max() < tol
+    assert np.abs(gp[:, 4:] - rp[:, 4:]).max() < tol
+    assert abs(gchi - rchi) <= 1e-3 * abs(rchi) + 1e-12
+    assert git == rit
+
+
+@pytest.mark.parametrize("n_kf,n_loops,seed", [(60, 1, 1), (200, 2, 2), (400, 4, 3), (900, 7, 4)])
+def test_pose_graph_matches_oracle(api, oracle, synth, n_kf, n_loops, seed):
+    poses, fixed, e0, e1, meas, gt = synth.pose_graph(n_kf, n_loops, seed=seed)
+    ref = oracle.pose_graph_optimize(poses, fixed, e0, e1, meas)
+    got = api.pose_graph_optimize(poses, fixed, e0, e1, meas)
+    _cmp(got, ref)
+    chi0 = oracle.pose_graph_optimize(poses, fixed, e0, e1, meas, iters=0)[1]
+    assert got[1] < 0.05 * chi0                                     # the loop was actually closed
+    assert np.abs(got[0][fixed.astype(bool)] - ref[0][fixed.astype(bool)]).max() < 1e-15      # fixed key-frames untouched (up to normalisation)
+    # the error function, sharply: the oracle evaluates the device's poses to the device's chi2
+    chk = oracle.pose_graph_optimize(got[0], fixed, e0, e1, meas, iters=0)[1]
+    assert abs(chk - got[1]) <= 1e-9 * got[1]
+    # one and two iterations (before the soft modes have had time to drift)
+    for its in (1, 2):
+        _cmp(api.pose_graph_optimize(poses, fixed, e0, e1, meas, iters=its), oracle.pose_graph_optimize(poses, fixed, e0, e1, meas, iters=its))
+
+
+def test_pose_graph_iteration_zero_and_no_edges(api, oracle, synth):
+    poses, fixed, e0, e1, meas, _ = synth.pose_graph(50, 1, seed=5)
+    got = api.pose_graph_optimize(poses, fixed, e0, e1, meas, iters=0); ref = oracle.pose_graph_optimize(poses, fixed, e0, e1, meas, iters=0)
+    _cmp(got, ref, tol=1e-15)
+    assert abs(got[1] - ref[1]) <= 1e-12 * ref[1]
+    got = api.pose_graph_optimize(poses, fixed, e0[:0], e1[:0], meas[:0]); assert got[1] == 0 and got[2] == 0
+    allfixed = np.ones_like(fixed)
+    got = api.pose_graph_optimize(poses, allfixed, e0, e1, meas); ref = oracle.pose_graph_optimize(poses, allfixed, e0, e1, meas)
+    _cmp(got, ref, tol=1e-15)
+    assert got[2] == 0
+
+
+def test_pose_graph_general_structure(api, oracle, synth):
+    """Edges in either orientation, duplicate edges, edges skipping over fixed key-frames, two loops sharing a key-frame,
+    a free key-frame with no edge to its index neighbour."""
+    poses, fixed, e0, e1, meas, _ = synth.pose_graph(120, 3, seed=6)
+    rng = np.random.default_rng(0)
+    flip = rng.uniform(size=len(e0)) < 0.4
+    inv = np.stack([oracle.se3_compose(np.array([0, 0, 0, 1, 0, 0, 0.0]), m, invert_b=True) for m in meas])
+    e0f = np.where(flip, e1, e0); e1f = np.where(flip, e0, e1); mf = np.where(flip[:, None], inv, meas)
+    # duplicate a chain edge and add a second loop edge into the last loop's key-frame
+    e0f = np.concatenate([e0f, e0f[10:11], [e0f[-1] - 3]]); e1f = np.concatenate([e1f, e1f[10:11], [e1f[-1]]])
+    extra = oracle.se3_compose(poses[e0f[-1]], poses[e1f[-1]], invert_b=True)
+    mf = np.concatenate([mf, mf[10:11], extra[None]])
+    fixed = fixed.copy(); fixed[40] = 1; fixed[41] = 1
+    ref = oracle.pose_graph_optimize(poses, fixed, e0f, e1f, mf)
+    got = api.pose_graph_optimize(poses, fixed, e0f, e1f, mf)
+    _cmp(got, ref)
+
+
+def test_pose_graph_rejects_bad_input(api, synth):
+    poses, fixed, e0, e1, meas, _ = synth.pose_graph(30, 1, seed=7)
+    bad = e0.copy(); bad[3] = 30
+    with pytest.raises(Exception):
+        api.pose_graph_optimize(poses, fixed, bad, e1, meas)
+    with pytest.raises(Exception):
+        api.pose_graph_optimize(poses, fixed, e1, e1, meas)           # self edges
+    # a graph that is nowhere near a chain: half of the key-frames linked to up to 80 others -> more separators than supported
+    n = 240
+    p = np.tile(np.array([0, 0, 0, 1, 0, 0, 0.0]), (n, 1)); p[:, 4] = np.arange(n)
+    a, b = np.meshgrid(np.arange(n), np.arange(n)); m = (a - b) >= 120
+    ea, eb = a[m].astype(np.int32), b[m].astype(np.int32)
+    ms = np.tile(np.array([0, 0, 0, 1, 0, 0, 0.0]), (len(ea), 1)); ms[:, 4] = ea - eb
+    with pytest.raises(Exception):
+        api.pose_graph_optimize(p, np.zeros(n, np.uint8), ea, eb, ms)
+
+
+def test_correct_map_points(api, oracle, synth):
+    poses, fixed, e0, e1, meas, _ = synth.pose_graph(80, 1, seed=8)
+    new = api.pose_graph_optimize(poses, fixed, e0, e1, meas)[0]
+    rng = np.random.default_rng(1)
+    kf = rng.integers(-1, 80, 5000).astype(np.int32)
+    pts = rng.normal(0, 30, (5000, 3))
+    got = api.correct_map_points(poses, new, kf, pts); ref = oracle.correct_map_points(poses, new, kf, pts)
+    assert np.abs(got - ref).max() < 1e-10
+    assert np.array_equal(got[kf < 0], pts[kf < 0])
+    moved = np.linalg.norm(got - pts, axis=1)[kf >= 0]
+    assert moved.max() > 1e-3
+    with pytest.raises(Exception):
+        api.correct_map_points(poses, new, np.full(5000, 80, np.int32), pts)
+    assert api.correct_map_points(poses, new, kf[:0], pts[:0]).shape == (0, 3)

@@ -522,3 +522,70 @@ def test_pose_only_converges_and_flags_gross_outliers(oracle, synth):
     p, out, ni = oracle.pose_only_optimize(np.array([0, 0, 0, 1, 0, 0, 0.0]), pts, noisy, Kt)
     assert np.abs(p - T).max() < 1e-6                       # exact observations for the inliers -> exact pose
     assert set(np.where(out)[0]) == set(bad.tolist()) and ni == n - len(bad)
+
+
+# ---- loop correction (src/loopclosing.cpp:537-646) ----
+def _pose_apply(p7, X):
+    x, y, z, w = p7[:4] / np.linalg.norm(p7[:4])
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    return X @ R.T + p7[4:]
+
+
+def test_se3_log_exp_and_compose(oracle):
+    rng = np.random.default_rng(3)
+    I7 = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    for _ in range(50):
+        xi = np.concatenate([rng.normal(0, 2, 3), rng.normal(0, 0.8, 3)])
+        T = oracle.se3_exp(xi)
+        assert np.abs(oracle.se3_log(T) - xi).max() < 1e-12
+        assert np.abs(oracle.se3_log(oracle.se3_compose(T, T, invert_b=True))).max() < 1e-12          # T T^-1 = I
+        X = rng.normal(0, 5, (4, 3))
+        U = oracle.se3_exp(np.concatenate([rng.normal(0, 1, 3), rng.normal(0, 0.5, 3)]))
+        assert np.abs(_pose_apply(oracle.se3_compose(T, U), X) - _pose_apply(T, _pose_apply(U, X))).max() < 1e-12
+    assert np.abs(oracle.se3_log(I7)).max() == 0
+    # a pure translation has log = (t, 0); a pure rotation about z by 0.3 rad has log = (0, 0, 0, 0, 0, 0.3)
+    assert np.allclose(oracle.se3_log(np.array([0, 0, 0, 1, 1.5, -2, 0.25])), [1.5, -2, 0.25, 0, 0, 0], atol=1e-15)
+    assert np.allclose(oracle.se3_log(np.array([0, 0, np.sin(0.15), np.cos(0.15), 0, 0, 0])), [0, 0, 0, 0, 0, 0.3], atol=1e-15)
+
+
+def test_pose_graph_recovers_a_consistent_graph(oracle, synth):
+    """Measurements taken from the ground truth: the optimum is the ground truth itself (chi2 -> 0) wherever the anchors are true."""
+    _, fixed, e0, e1, _, gt = synth.pose_graph(60, 2, seed=11)
+    meas = np.stack([oracle.se3_compose(gt[a], gt[b], invert_b=True) for a, b in zip(e0, e1)])
+    rng = np.random.default_rng(0)
+    start = gt.copy()
+    free = ~fixed.astype(bool)
+    start[free, 4:] += rng.normal(0, 0.3, (free.sum(), 3))
+    start[free, :4] += rng.normal(0, 0.02, (free.sum(), 4))
+    chi0 = oracle.pose_graph_optimize(start, fixed, e0, e1, meas, iters=0)[1]
+    p, chi, its = oracle.pose_graph_optimize(start, fixed, e0, e1, meas)
+    assert chi0 > 1.0 and chi < 1e-12 * chi0
+    s = np.sign(np.sum(p[:, :4] * gt[:, :4], axis=1))[:, None]
+    assert np.abs(p[:, 4:] - gt[:, 4:]).max() < 1e-6 and np.abs(p[:, :4] * s - gt[:, :4]).max() < 1e-7
+    assert np.array_equal(p[~free, 4:], gt[~free, 4:])
+
+
+def test_pose_graph_error_definition(oracle):
+    """error = log(M^-1 T0 T1^-1) (g2o_types.h:161-167): chi2 of a single edge, read back through iters = 0."""
+    rng = np.random.default_rng(5)
+    T0 = oracle.se3_exp(rng.normal(0, 0.5, 6)); T1 = oracle.se3_exp(rng.normal(0, 0.5, 6)); M = oracle.se3_exp(rng.normal(0, 0.5, 6))
+    e = oracle.se3_log(oracle.se3_compose(oracle.se3_compose(np.array([0, 0, 0, 1, 0, 0, 0.0]), M, invert_b=True), oracle.se3_compose(T0, T1, invert_b=True)))
+    chi = oracle.pose_graph_optimize(np.stack([T0, T1]), np.array([1, 1], np.uint8), [0], [1], M[None], iters=0)[1]
+    assert abs(chi - e @ e) < 1e-13
+    # satisfied edge: M = T0 T1^-1
+    chi = oracle.pose_graph_optimize(np.stack([T0, T1]), np.array([1, 1], np.uint8), [0], [1], oracle.se3_compose(T0, T1, invert_b=True)[None], iters=0)[1]
+    assert chi < 1e-28
+
+
+def test_correct_map_points_keeps_camera_frame_position(oracle, synth):
+    poses, fixed, e0, e1, meas, _ = synth.pose_graph(40, 1, seed=12)
+    new = oracle.pose_graph_optimize(poses, fixed, e0, e1, meas)[0]
+    rng = np.random.default_rng(2)
+    kf = rng.integers(-1, 40, 300).astype(np.int32); pts = rng.normal(0, 20, (300, 3))
+    out = oracle.correct_map_points(poses, new, kf, pts)
+    assert np.array_equal(out[kf < 0], pts[kf < 0])
+    for i in np.flatnonzero(kf >= 0)[:60]:
+        assert np.abs(_pose_apply(new[kf[i]], out[i][None]) - _pose_apply(poses[kf[i]], pts[i][None])).max() < 1e-10     # :630-633
+    assert np.array_equal(oracle.correct_map_points(poses, poses, kf, pts)[kf < 0], pts[kf < 0])
+    assert np.abs(oracle.correct_map_points(poses, poses, kf, pts) - pts).max() < 1e-12
