@@ -222,6 +222,29 @@ struct LocalBA {               // flat-array form of the graph Backend::Optimize
     }
 };
 
+// flat-array form of the graph LoopClosing::PoseGraphOptimization builds (loopclosing.cpp:546-601) and of its write-back (:612-640)
+struct PoseGraph {
+    std::vector<double> poses;                       // nKF x 7 (qx qy qz qw tx ty tz) = KeyFrame::Pose() of every key-frame, index = position in the list
+    std::vector<uint8_t> fixed;                      // :557-562: active key-frames, the loop key-frame, key-frame 0
+    std::vector<int32_t> edge_v0, edge_v1;           // EdgePoseGraph vertices 0 / 1 (:581-582, :594-595)
+    std::vector<double> meas;                        // nedges x 7: mRelativePoseToLastKF / mRelativePoseToLoopKF (:583, :596)
+    void AddKeyFrame(const double pose7[7], bool isFixed) { poses.insert(poses.end(), pose7, pose7 + 7); fixed.push_back(isFixed); }
+    void AddEdge(int kf, int otherKf, const double relPose7[7]) { edge_v0.push_back(kf); edge_v1.push_back(otherKf); meas.insert(meas.end(), relPose7, relPose7 + 7); }
+    // optimizer.initializeOptimization(); optimizer.optimize(20) (:605-606); poses are replaced by the optimised estimates (:636-638)
+    int Optimize(int iterations = 20, double* final_chi2 = nullptr) {
+        int it = 0;
+        check(myslam_pose_graph_optimize(poses.data(), (int)(poses.size() / 7), fixed.data(), edge_v0.data(), edge_v1.data(), meas.data(),
+                                         (int)edge_v0.size(), iterations, final_chi2, &it), "myslam_pose_graph_optimize");
+        return it;
+    }
+    // :621-633: points (n x 3, in/out) keep their camera-frame position in first_kf[i] (index into poses; < 0 = skip)
+    static void CorrectMapPoints(const std::vector<double>& old_poses, const std::vector<double>& new_poses, const std::vector<int32_t>& first_kf,
+                                 std::vector<double>& points) {
+        check(myslam_correct_map_points(old_poses.data(), new_poses.data(), (int)(old_poses.size() / 7), first_kf.data(), points.data(),
+                                        (int)first_kf.size()), "myslam_correct_map_points");
+    }
+};
+
 // cv::calcOpticalFlowPyrLK(prev, next, prevPts, nextPts, status, err, Size(11,11), 3, TermCriteria(COUNT+EPS,30,0.01),
 // OPTFLOW_USE_INITIAL_FLOW) as Frontend::TrackLastFrame / FindFeaturesInRight call it (src/frontend.cpp:150-153, 358-361)
 struct Point2f { float x, y; };

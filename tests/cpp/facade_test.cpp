@@ -112,6 +112,53 @@ int main() {
         EXPECT(good > (int)p0.size() * 8 / 10);
     }
 
+    // loop correction: a 30 key-frame circle whose odometry drifts, closed by one loop edge
+    {
+        const int N = 30;
+        myslam::PoseGraph pg;
+        std::vector<double> gt((size_t)N * 7);
+        auto compose = [](const double* a, const double* b, bool invb, double* out) { orc_se3_compose(a, b, invb ? 1 : 0, out); };
+        for (int i = 0; i < N; i++) {
+            const double ang = 2 * M_PI * i / (N - 2), xi[6] = {0, 0, 0, 0, -ang, 0};
+            double R[7]; orc_se3_exp(xi, R);
+            const double twc[3] = {20 * std::cos(ang), 0, 20 * std::sin(ang)};
+            // Tcw = (Rwc^T, -Rwc^T twc) with Rwc = exp(+ang about y): here R already holds the inverse rotation
+            double T[7] = {R[0], R[1], R[2], R[3], 0, 0, 0}, neg[7] = {0, 0, 0, 1, -twc[0], -twc[1], -twc[2]};
+            compose(T, neg, false, &gt[(size_t)7 * i]);
+        }
+        std::uniform_real_distribution<double> U(-1, 1);
+        std::vector<double> est(gt.begin(), gt.begin() + 7);
+        for (int i = 1; i < N; i++) {
+            double M[7], noise[7], Mn[7], Ti[7];
+            compose(&gt[(size_t)7 * i], &gt[(size_t)7 * (i - 1)], true, M);
+            const double xi[6] = {0.02 * U(rng), 0.02 * U(rng), 0.02 * U(rng), 0.003 * U(rng), 0.003 * U(rng), 0.003 * U(rng)};
+            orc_se3_exp(xi, noise); compose(noise, M, false, Mn);
+            compose(Mn, &est[(size_t)7 * (i - 1)], false, Ti);
+            est.insert(est.end(), Ti, Ti + 7);
+            pg.AddEdge(i, i - 1, Mn);
+        }
+        for (int i = 0; i < N; i++) pg.AddKeyFrame(&est[(size_t)7 * i], i == 0 || i == 1);
+        double Ml0[7], Ml[7], nl[7]; compose(&gt[(size_t)7 * (N - 1)], &gt[7], true, Ml0);
+        const double xl[6] = {0.01, -0.02, 0.015, 0.002, -0.001, 0.0015};      // a noisy loop measurement: the optimum keeps a residual
+        orc_se3_exp(xl, nl); compose(nl, Ml0, false, Ml);
+        pg.AddEdge(N - 1, 1, Ml);
+        std::vector<double> rp = pg.poses; double rchi = 0, gchi = 0; int rit = 0;
+        EXPECT(orc_pose_graph_optimize(rp.data(), N, pg.fixed.data(), pg.edge_v0.data(), pg.edge_v1.data(), pg.meas.data(), (int)pg.edge_v0.size(), 20, &rchi, &rit) == 0);
+        const std::vector<double> before = pg.poses;
+        const int git = pg.Optimize(20, &gchi);
+        if (git != rit) printf("pose graph: device %d iterations chi2 %.12g, oracle %d iterations chi2 %.12g\n", git, gchi, rit, rchi);
+        EXPECT(git == rit || std::fabs(gchi - rchi) <= 1e-9 * rchi);      // at the rounding floor Levenberg gives up at a noise-dependent iteration
+        EXPECT(std::fabs(gchi - rchi) <= 1e-3 * rchi + 1e-12);
+        double dmax = 0;
+        for (size_t i = 0; i < rp.size(); i++) dmax = std::max(dmax, std::fabs(rp[i] - pg.poses[i]));
+        EXPECT(dmax < 5e-4);                 // the operator's numeric-Jacobian noise floor, see tests/test_gpu_pgo.py
+        std::vector<double> pts = {1, 2, 3, -4, 0.5, 9, 7, 7, 7}, rpts = pts; std::vector<int32_t> kf = {5, -1, 29};
+        myslam::PoseGraph::CorrectMapPoints(before, pg.poses, kf, pts);
+        EXPECT(orc_correct_map_points(before.data(), pg.poses.data(), N, kf.data(), rpts.data(), 3) == 0);
+        for (int i = 0; i < 9; i++) EXPECT(std::fabs(pts[i] - rpts[i]) < 1e-10);
+        EXPECT(pts[3] == -4 && pts[4] == 0.5 && pts[5] == 9);
+    }
+
     printf(fails ? "FACADE TEST FAILED (%d)\n" : "FACADE TEST OK (%d failures)\n", fails);
     return fails ? 1 : 0;
 }
