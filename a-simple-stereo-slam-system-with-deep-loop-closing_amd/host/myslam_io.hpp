@@ -4,7 +4,7 @@
 //   myslam::io::LoadImages      KITTI sequence listing: times.txt + image_0 / image_1 paths       app/run_kitti_stereo.cpp:114-144
 //   myslam::io::SaveTrajectory  "keyframe id, timestamp, tx ty tz qx qy qz qw" (std::fixed, setprecision(6))   src/system.cpp:153-180
 //   myslam::io::SaveLoopEdges   two such lines per loop edge (current, then loop key-frame)                    src/system.cpp:188-224
-// PNG decoding is not part of this header (the reference uses cv::imread; images reach the device path as raw u8 planes).
+// PNG decoding (cv::imread(file, IMREAD_GRAYSCALE) of the KITTI images) lives next door in myslam_png.hpp, equally dependency-free.
 #pragma once
 #include <fstream>
 #include <iomanip>

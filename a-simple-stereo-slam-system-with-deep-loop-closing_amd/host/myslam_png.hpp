@@ -1,0 +1,215 @@
+// myslam_png.hpp — dependency-free PNG reader for the KITTI grey images, header only.
+//   myslam::io::ReadPngGray(path, pixels, rows, cols)   what the reference gets from cv::imread(file, cv::IMREAD_GRAYSCALE) for the
+//                                                       8-bit single-channel PNGs of KITTI image_0 / image_1   app/run_kitti_stereo.cpp:66-67
+// Supported: non-interlaced PNG, colour type 0 (grey) with bit depth 8 or 16 (high byte kept), colour type 2 / 6 (RGB / RGBA, 8 bit;
+// grey = (R*4899 + G*9617 + B*1868 + 8192) >> 14, OpenCV's 8-bit BGR2GRAY fixed point).  Anything else returns false.
+// zlib stream: stored, fixed and dynamic Huffman blocks (RFC 1950 / 1951); CRC-32 of every chunk and the Adler-32 are verified.
+#pragma once
+#include <stdint.h>
+
+#include <fstream>
+#include <string>
+#include <vector>
+
+namespace myslam {
+namespace io {
+namespace png_detail {
+
+struct BitReader {
+    const uint8_t* p; size_t n, pos = 0; uint32_t buf = 0; int cnt = 0; bool bad = false;
+    BitReader(const uint8_t* p_, size_t n_) : p(p_), n(n_) {}
+    uint32_t bits(int k) {                                   // k <= 16, LSB first
+        while (cnt < k) { if (pos >= n) { bad = true; return 0; } buf |= (uint32_t)p[pos++] << cnt; cnt += 8; }
+        const uint32_t v = buf & ((1u << k) - 1);
+        buf >>= k; cnt -= k;
+        return v;
+    }
+    void align() { buf = 0; cnt = 0; }
+};
+
+struct Huffman {                                             // canonical code: counts per length + symbols sorted by (length, value)
+    uint16_t count[16] = {0}; std::vector<uint16_t> sym;
+    bool build(const uint8_t* len, int n) {
+        for (int i = 0; i < 16; i++) count[i] = 0;
+        for (int i = 0; i < n; i++) count[len[i]]++;
+        count[0] = 0;
+        int left = 1;
+        for (int l = 1; l < 16; l++) { left = (left << 1) - count[l]; if (left < 0) return false; }
+        uint16_t offs[16]; offs[1] = 0;
+        for (int l = 1; l < 15; l++) offs[l + 1] = offs[l] + count[l];
+        sym.assign(n, 0);
+        for (int i = 0; i < n; i++) if (len[i]) sym[offs[len[i]]++] = (uint16_t)i;
+        return true;
+    }
+    int decode(BitReader& br) const {
+        int code = 0, first = 0, index = 0;
+        for (int l = 1; l < 16; l++) {
+            code |= (int)br.bits(1);
+            const int c = count[l];
+            if (code - c < first) return sym[index + (code - first)];
+            index += c; first += c; first <<= 1; code <<= 1;
+            if (br.bad) return -1;
+        }
+        return -1;
+    }
+};
+
+inline bool inflate(const uint8_t* src, size_t n, std::vector<uint8_t>& out, size_t expect) {
+    if (n < 6 || (src[0] & 0x0f) != 8 || ((src[0] << 8) | src[1]) % 31 != 0 || (src[1] & 0x20)) return false;
+    BitReader br(src + 2, n - 2);
+    static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    out.clear(); out.reserve(expect);
+    for (bool last = false; !last;) {
+        last = br.bits(1) != 0;
+        const uint32_t type = br.bits(2);
+        if (br.bad) return false;
+        if (type == 0) {
+            br.align();
+            if (br.pos + 4 > br.n) return false;
+            const uint32_t len = br.p[br.pos] | (br.p[br.pos + 1] << 8), nlen = br.p[br.pos + 2] | (br.p[br.pos + 3] << 8);
+            br.pos += 4;
+            if ((len ^ 0xffffu) != nlen || br.pos + len > br.n) return false;
+            out.insert(out.end(), br.p + br.pos, br.p + br.pos + len);
+            br.pos += len;
+            continue;
+        }
+        if (type == 3) return false;
+        Huffman lit, dist;
+        uint8_t lens[320];
+        if (type == 1) {
+            for (int i = 0; i < 144; i++) lens[i] = 8;
+            for (int i = 144; i < 256; i++) lens[i] = 9;
+            for (int i = 256; i < 280; i++) lens[i] = 7;
+            for (int i = 280; i < 288; i++) lens[i] = 8;
+            lit.build(lens, 288);
+            for (int i = 0; i < 30; i++) lens[i] = 5;
+            dist.build(lens, 30);
+        } else {
+            const int nlen = (int)br.bits(5) + 257, ndist = (int)br.bits(5) + 1, ncode = (int)br.bits(4) + 4;
+            if (nlen > 286 || ndist > 30) return false;
+            static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            uint8_t cl[19] = {0};
+            for (int i = 0; i < ncode; i++) cl[order[i]] = (uint8_t)br.bits(3);
+            Huffman clen;
+            if (!clen.build(cl, 19)) return false;
+            for (int i = 0; i < nlen + ndist;) {
+                const int s = clen.decode(br);
+                if (s < 0) return false;
+                if (s < 16) { lens[i++] = (uint8_t)s; continue; }
+                int rep, val = 0;
+                if (s == 16) { if (i == 0) return false; val = lens[i - 1]; rep = 3 + (int)br.bits(2); }
+                else if (s == 17) rep = 3 + (int)br.bits(3);
+                else rep = 11 + (int)br.bits(7);
+                if (i + rep > nlen + ndist) return false;
+                while (rep--) lens[i++] = (uint8_t)val;
+            }
+            if (lens[256] == 0 || !lit.build(lens, nlen) || !dist.build(lens + nlen, ndist)) return false;
+        }
+        for (;;) {
+            const int s = lit.decode(br);
+            if (s < 0 || br.bad) return false;
+            if (s < 256) { out.push_back((uint8_t)s); continue; }
+            if (s == 256) break;
+            if (s > 285) return false;
+            const int len = lbase[s - 257] + (int)br.bits(lext[s - 257]);
+            const int ds = dist.decode(br);
+            if (ds < 0 || ds > 29) return false;
+            const size_t d = dbase[ds] + br.bits(dext[ds]);
+            if (br.bad || d > out.size()) return false;
+            const size_t from = out.size() - d;
+            for (int k = 0; k < len; k++) out.push_back(out[from + k]);
+        }
+    }
+    br.align();
+    if (br.pos + 4 > br.n) return false;
+    uint32_t a = 1, b = 0;                                   // Adler-32
+    for (size_t i = 0; i < out.size(); i++) { a = (a + out[i]) % 65521u; b = (b + a) % 65521u; }
+    const uint32_t want = ((uint32_t)br.p[br.pos] << 24) | (br.p[br.pos + 1] << 16) | (br.p[br.pos + 2] << 8) | br.p[br.pos + 3];
+    return ((b << 16) | a) == want;
+}
+
+inline uint32_t crc32(const uint8_t* p, size_t n) {
+    static uint32_t table[256]; static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1; table[i] = c; }
+        init = true;
+    }
+    uint32_t c = 0xffffffffu;
+    for (size_t i = 0; i < n; i++) c = table[(c ^ p[i]) & 0xff] ^ (c >> 8);
+    return c ^ 0xffffffffu;
+}
+
+inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | (p[1] << 16) | (p[2] << 8) | p[3]; }
+
+}  // namespace png_detail
+
+// Decodes PNG bytes into a tight rows x cols u8 grey plane.  false: not a PNG this reader supports, or a corrupt one.
+inline bool DecodePngGray(const uint8_t* data, size_t size, std::vector<uint8_t>& pixels, int& rows, int& cols) {
+    using namespace png_detail;
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (size < 8 + 25 || std::char_traits<char>::compare((const char*)data, (const char*)sig, 8) != 0) return false;
+    size_t pos = 8;
+    uint32_t w = 0, h = 0; int depth = 0, ctype = -1;
+    std::vector<uint8_t> z;
+    bool end = false;
+    while (!end && pos + 12 <= size) {
+        const uint32_t len = be32(data + pos);
+        if (pos + 12 + (size_t)len > size) return false;
+        const uint8_t* type = data + pos + 4;
+        const uint8_t* body = data + pos + 8;
+        if (crc32(type, 4 + (size_t)len) != be32(body + len)) return false;
+        const std::string t((const char*)type, 4);
+        if (t == "IHDR") {
+            if (len != 13) return false;
+            w = be32(body); h = be32(body + 4); depth = body[8]; ctype = body[9];
+            if (body[10] != 0 || body[11] != 0 || body[12] != 0) return false;          // compression, filter, no interlace
+        } else if (t == "IDAT") z.insert(z.end(), body, body + len);
+        else if (t == "IEND") end = true;
+        pos += 12 + (size_t)len;
+    }
+    if (!end || w == 0 || h == 0 || w > 65535 || h > 65535) return false;
+    int ch;
+    if (ctype == 0 && (depth == 8 || depth == 16)) ch = 1;
+    else if (ctype == 2 && depth == 8) ch = 3;
+    else if (ctype == 6 && depth == 8) ch = 4;
+    else return false;
+    const size_t bpp = (size_t)ch * (depth / 8), stride = bpp * w;
+    std::vector<uint8_t> raw;
+    if (!inflate(z.data(), z.size(), raw, (stride + 1) * h) || raw.size() != (stride + 1) * h) return false;
+    // undo the per-row filters in place (row r occupies raw[r*(stride+1)+1 ...])
+    std::vector<uint8_t> prev(stride, 0);
+    pixels.assign((size_t)w * h, 0);
+    for (uint32_t r = 0; r < h; r++) {
+        uint8_t* cur = &raw[(size_t)r * (stride + 1) + 1];
+        const int f = cur[-1];
+        if (f > 4) return false;
+        for (size_t i = 0; i < stride; i++) {
+            const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+            int pr = 0;
+            if (f == 1) pr = a;
+            else if (f == 2) pr = b;
+            else if (f == 3) pr = (a + b) >> 1;
+            else if (f == 4) { const int p = a + b - c, pa = p > a ? p - a : a - p, pb = p > b ? p - b : b - p, pc = p > c ? p - c : c - p; pr = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
+            cur[i] = (uint8_t)(cur[i] + pr);
+        }
+        uint8_t* dst = &pixels[(size_t)r * w];
+        if (ch == 1) for (uint32_t x = 0; x < w; x++) dst[x] = cur[x * bpp];                            // 16-bit: the high byte
+        else for (uint32_t x = 0; x < w; x++) { const uint8_t* q = cur + x * bpp; dst[x] = (uint8_t)((q[0] * 4899 + q[1] * 9617 + q[2] * 1868 + 8192) >> 14); }
+        prev.assign(cur, cur + stride);
+    }
+    rows = (int)h; cols = (int)w;
+    return true;
+}
+
+inline bool ReadPngGray(const std::string& path, std::vector<uint8_t>& pixels, int& rows, int& cols) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) return false;
+    std::vector<uint8_t> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    return DecodePngGray(buf.data(), buf.size(), pixels, rows, cols);
+}
+
+}  // namespace io
+}  // namespace myslam

@@ -10,3 +10,87 @@ def test_host_io_formats(tmp_path):
     subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "io_test.cpp"), "-o", exe])
     r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "IO TEST OK" in r.stdout, r.stdout + r.stderr
+
+
+def _png(img, level=6, filters=None, split=1 << 20, strategy=None):
+    """A PNG encoder for the test: img (H,W) u8/u16 grey or (H,W,3|4) u8; `filters` = per-row PNG filter types (default 0)."""
+    import struct
+    import zlib
+
+    import numpy as np
+    h, w = img.shape[:2]
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    depth = 16 if img.dtype == np.uint16 else 8
+    ctype = {1: 0, 3: 2, 4: 6}[ch]
+    rowsb = img.astype(">u2").tobytes() if depth == 16 else img.tobytes()
+    stride = w * ch * depth // 8; bpp = ch * depth // 8
+    rows = np.frombuffer(rowsb, np.uint8).reshape(h, stride).astype(np.int32)
+    out = bytearray()
+    prev = np.zeros(stride, np.int32)
+    for r in range(h):
+        f = 0 if filters is None else filters[r % len(filters)]
+        cur = rows[r]
+        a = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]]); b = prev; c = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]])
+        if f == 0: pr = 0
+        elif f == 1: pr = a
+        elif f == 2: pr = b
+        elif f == 3: pr = (a + b) >> 1
+        else:
+            p = a + b - c; pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+            pr = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, b, c))
+        out.append(f); out += ((cur - pr) & 255).astype(np.uint8).tobytes()
+        prev = cur
+    co = zlib.compressobj(level, zlib.DEFLATED, 15, 8, zlib.Z_DEFAULT_STRATEGY if strategy is None else strategy)
+    z = co.compress(bytes(out)) + co.flush()
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body) & 0xffffffff)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0)) + chunk(b"tEXt", b"k\0v")
+    for i in range(0, len(z), split):
+        png += chunk(b"IDAT", z[i:i + split])
+    return png + chunk(b"IEND", b"")
+
+
+def test_png_reader(tmp_path):
+    """host/myslam_png.hpp against PNGs written here with zlib: stored / fixed / dynamic blocks, every row filter, split IDATs,
+    8- and 16-bit grey, RGB(A) -> grey, corrupt files."""
+    import zlib
+
+    import numpy as np
+    exe = str(tmp_path / "png_test")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "png_test.cpp"), "-o", exe])
+    rng = np.random.default_rng(0)
+    yy, xx = np.mgrid[0:97, 0:331]
+    smooth = ((np.sin(xx / 9.0) + np.cos(yy / 7.0)) * 60 + 128 + rng.integers(-3, 4, xx.shape)).clip(0, 255).astype(np.uint8)
+    noise = rng.integers(0, 256, (64, 200), dtype=np.uint8)
+    kitti = (np.add.outer(np.arange(376), np.arange(1241)) % 251).astype(np.uint8)
+
+    def run(png, name):
+        p = tmp_path / (name + ".png"); p.write_bytes(png)
+        r = subprocess.run([exe, str(p), str(tmp_path / (name + ".raw"))], capture_output=True, text=True, timeout=60)
+        if r.returncode != 0:
+            return None
+        rows, cols = (int(v) for v in r.stdout.split())
+        return np.fromfile(tmp_path / (name + ".raw"), np.uint8).reshape(rows, cols)
+
+    cases = [("stored", _png(noise, level=0)), ("fixed", _png(smooth, level=6, strategy=zlib.Z_FIXED)), ("dynamic", _png(smooth, level=9)),
+             ("filters", _png(smooth, level=6, filters=[0, 1, 2, 3, 4])), ("paeth", _png(noise, level=1, filters=[4])),
+             ("split", _png(kitti, level=6, filters=[1, 4, 2], split=8192)), ("rle", _png(smooth, level=6, strategy=zlib.Z_RLE, filters=[2]))]
+    want = {"stored": noise, "fixed": smooth, "dynamic": smooth, "filters": smooth, "paeth": noise, "split": kitti, "rle": smooth}
+    for name, png in cases:
+        got = run(png, name)
+        assert got is not None and np.array_equal(got, want[name]), name
+    g16 = (smooth.astype(np.uint16) << 8) | rng.integers(0, 256, smooth.shape).astype(np.uint16)
+    assert np.array_equal(run(_png(g16, filters=[3, 4]), "g16"), smooth)
+    rgb = rng.integers(0, 256, (40, 77, 3), dtype=np.uint8)
+    r64 = rgb.astype(np.int64)
+    grey = ((r64[..., 0] * 4899 + r64[..., 1] * 9617 + r64[..., 2] * 1868 + 8192) >> 14).astype(np.uint8)
+    assert np.array_equal(run(_png(rgb, filters=[4, 1]), "rgb"), grey)
+    rgba = np.concatenate([rgb, rng.integers(0, 256, (40, 77, 1), dtype=np.uint8)], axis=2)
+    assert np.array_equal(run(_png(rgba, filters=[2, 3]), "rgba"), grey)
+    # corrupt: flipped payload byte (CRC), truncated file, not a PNG
+    good = bytearray(_png(smooth))
+    bad = bytearray(good); bad[len(bad) // 2] ^= 0x10
+    assert run(bytes(bad), "crc") is None
+    assert run(bytes(good[:len(good) // 2]), "trunc") is None
+    assert run(b"P5 4 4 255 " + bytes(16), "pgm") is None
