@@ -468,3 +468,14 @@ def correct_map_points(old_poses, new_poses, first_kf, points):
     assert old_poses.shape == new_poses.shape and len(first_kf) == len(points)
     _check(lib().myslam_correct_map_points(_p(old_poses), _p(new_poses), len(old_poses), _p(first_kf), _p(points), len(points)), "myslam_correct_map_points")
     return points
+
+
+def solve_pnp_ransac(pts3d, pts2d, K, iterations=100, reproj_error=5.991, confidence=0.99):
+    """cv::solvePnPRansac as LoopClosing::ComputeCorrectPose calls it (src/loopclosing.cpp:262-268).
+    Returns (pose7 Tcw, inlier flags, inlier count); raises MyslamError(UNSUPPORTED) when no model exists."""
+    p3 = np.ascontiguousarray(pts3d, np.float32).reshape(-1, 3); p2 = np.ascontiguousarray(pts2d, np.float32).reshape(-1, 2)
+    assert len(p3) == len(p2)
+    n = len(p3); pose = np.zeros(7); inl = np.zeros(max(n, 1), np.uint8); ni = C.c_int()
+    _check(lib().myslam_solve_pnp_ransac(_p(p3), _p(p2), n, C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]), int(iterations),
+                                         C.c_double(reproj_error), C.c_double(confidence), _p(pose), _p(inl), C.byref(ni)), "myslam_solve_pnp_ransac")
+    return pose, inl[:n].astype(bool), ni.value

@@ -27,6 +27,7 @@ UNITS = {
     "ba.hip": [],
     "lk.hip": EXACT,
     "pgo.hip": [],
+    "pnp.hip": EXACT,
     "prof.hip": [],
 }
 

@@ -282,4 +282,23 @@ inline int EstimateCurrentPose(double pose_qt[7], const std::vector<double>& map
     return inl;
 }
 
+// cv::solvePnPRansac(points3d, points2d, K, cv::Mat(), rvec, tvec, false, 100, 5.991, 0.99) + cv::Rodrigues as
+// LoopClosing::ComputeCorrectPose uses them (src/loopclosing.cpp:262-272).  pose7 = (qx qy qz qw tx ty tz) of SE3d(R, t).
+// false where OpenCV returns false (fewer than 5 matches, no model) — the reference wraps the call in try / catch and gives up.
+struct Point3f { float x, y, z; };
+inline bool solvePnPRansac(const std::vector<Point3f>& objectPoints, const std::vector<Point2f>& imagePoints, double fx, double fy, double cx,
+                           double cy, double pose7[7], std::vector<uint8_t>* inliers = nullptr, int iterationsCount = 100,
+                           float reprojectionError = 5.991f, double confidence = 0.99) {
+    if (objectPoints.size() != imagePoints.size()) throw std::runtime_error("solvePnPRansac: size mismatch");
+    const int n = (int)objectPoints.size();
+    std::vector<uint8_t> mask((size_t)std::max(n, 1));
+    int ninl = 0;
+    const int rc = myslam_solve_pnp_ransac(reinterpret_cast<const float*>(objectPoints.data()), reinterpret_cast<const float*>(imagePoints.data()), n,
+                                           fx, fy, cx, cy, iterationsCount, (double)reprojectionError, confidence, pose7, mask.data(), &ninl);
+    if (rc == MYSLAM_ERR_UNSUPPORTED) return false;
+    check(rc, "myslam_solve_pnp_ransac");
+    if (inliers) { mask.resize(n); *inliers = mask; }
+    return true;
+}
+
 }  // namespace myslam

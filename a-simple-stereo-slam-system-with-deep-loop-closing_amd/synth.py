@@ -259,3 +259,30 @@ def pose_graph(n_kf=200, n_loops=2, seed=0x9A, odo_noise=(0.002, 0.02), loop_noi
     poses = np.stack([_T_to_pose7(T) for T in Test])
     gt = np.stack([_T_to_pose7(T) for T in Tgt])
     return poses, fixed, np.array(e0, np.int32), np.array(e1, np.int32), np.array(meas).reshape(-1, 7), gt
+
+
+# ---- loop verification: 3D-2D matches between a loop key-frame's map points and the current key-frame --------------------------
+
+def pnp_problem(n=120, outlier_frac=0.3, noise_px=0.5, seed=0x919, K=KITTI00, w=IMG_W, h=IMG_H):
+    """Map points in front of a camera at a known pose (the loop-corrected pose LoopClosing::ComputeCorrectPose is after,
+    src/loopclosing.cpp:208-268), their pixels with Gaussian noise, and a fraction of gross mismatches.
+    Returns pts3d (n,3) f32, pts2d (n,2) f32, Kt, true pose7 (Tcw), inlier ground truth (n,) bool."""
+    rng = _rng(seed)
+    yaw = rng.uniform(-0.6, 0.6)
+    Rcw = _so3_exp(np.array([rng.uniform(-0.05, 0.05), yaw, rng.uniform(-0.05, 0.05)]))
+    tcw = np.array([rng.uniform(-3, 3), rng.uniform(-0.5, 0.5), rng.uniform(-3, 3)])
+    Kt = (K["fx"], K["fy"], K["cx"], K["cy"])
+    pc = np.stack([rng.uniform(-12, 12, n), rng.uniform(-3, 2, n), rng.uniform(4, 45, n)], 1)
+    u = Kt[0] * pc[:, 0] / pc[:, 2] + Kt[2]; v = Kt[1] * pc[:, 1] / pc[:, 2] + Kt[3]
+    u = np.clip(u, 0, w - 1); v = np.clip(v, 0, h - 1)                 # keep the pixels inside the image, move the points with them
+    pc[:, 0] = (u - Kt[2]) * pc[:, 2] / Kt[0]; pc[:, 1] = (v - Kt[3]) * pc[:, 2] / Kt[1]
+    pw = (pc - tcw) @ Rcw                                              # Rcw^T (pc - t)
+    uv = np.stack([u, v], 1) + rng.normal(0, noise_px, (n, 2))
+    good = np.ones(n, bool)
+    nout = int(round(outlier_frac * n))
+    if nout:
+        idx = rng.choice(n, nout, replace=False)
+        uv[idx] = np.stack([rng.uniform(0, w, nout), rng.uniform(0, h, nout)], 1)
+        good[idx] = False
+    T = np.eye(4); T[:3, :3] = Rcw; T[:3, 3] = tcw
+    return pw.astype(np.float32), uv.astype(np.float32), Kt, _T_to_pose7(T), good

@@ -300,6 +300,20 @@ int myslam_correct_map_points(const double* old_poses, const double* new_poses, 
 int myslam_correct_map_points_device(const double* d_old_poses, const double* d_new_poses, int n_poses, const int32_t* d_first_kf,
                                      double* d_points, int n_points, int32_t* d_status, void* hip_stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Loop verification — replaces cv::solvePnPRansac(vLoopPoints3d, vCurrentPoints2d, K, cv::Mat(), rvec, tvec, false, 100, 5.991, 0.99)
+ * followed by cv::Rodrigues in LoopClosing::ComputeCorrectPose (src/loopclosing.cpp:262-272).   [SURVEY.md §8(f) rank 3]
+ * pts3d n x 3 / pts2d n x 2 floats (cv::Point3f / cv::Point2f arrays as the reference builds them, :215-231); iterations = 100,
+ * reproj_error = 5.991 (pixels), confidence = 0.99 at the call site.  pose7 = (qx qy qz qw tx ty tz): Sophus::SE3d(R, t) of :270-272.
+ * inlier (optional, n flags) / *n_inliers: the RANSAC consensus set (the reference does not ask OpenCV for it).
+ * OpenCV 3.4 semantics kept: cv::RNG((uint64)-1) drives 5-point samples, EPnP per sample, squared reprojection error against
+ * threshold^2 in float, best-count bookkeeping with the shrinking iteration budget, then a least-squares refinement on the
+ * consensus set (Levenberg-Marquardt from the RANSAC model instead of OpenCV's DLT restart: the same minimiser).
+ * Returns MYSLAM_ERR_UNSUPPORTED when n < 5 or no model was found (OpenCV returns false there).  Host pointers, synchronous.
+ * ------------------------------------------------------------------------------------------ */
+int myslam_solve_pnp_ransac(const float* pts3d, const float* pts2d, int n, double fx, double fy, double cx, double cy, int iterations,
+                            double reproj_error, double confidence, double* pose7, uint8_t* inlier, int* n_inliers);
+
 #ifdef __cplusplus
 }
 #endif

@@ -157,6 +157,16 @@ int orc_correct_map_points(const double* old_poses, const double* new_poses, int
 int orc_se3_log(const double* q_t7, double* xi6);
 int orc_se3_compose(const double* a7, const double* b7, int invert_b, double* out7);
 
+/* ---- loop verification (pnp_oracle.cpp): cv::solvePnPRansac as called at src/loopclosing.cpp:262-268 ---- */
+/* pts3d n x 3, pts2d n x 2 (float, as the reference passes them); pose7 = (qx qy qz qw tx ty tz) world -> camera; inlier n flags.
+ * returns 0, -2 (fewer than 5 points), -3 (no model found) */
+int orc_solve_pnp_ransac(const float* pts3d, const float* pts2d, int n, double fx, double fy, double cx, double cy, int iterations,
+                         double reproj_error, double confidence, double* pose7, uint8_t* inlier, int* n_inliers);
+/* EPnP on n >= 4 correspondences (pw n x 3, uv n x 2): R (row-major 3x3), t */
+int orc_epnp(const double* pw, const double* uv, int n, double fx, double fy, double cx, double cy, double* R9, double* t3);
+/* `count` draws of cv::RNG(seed).uniform(a, b) */
+int orc_cv_rng_uniform(uint64_t seed, int a, int b, int count, int32_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -392,3 +392,22 @@ class Oracle:
         rc = self.lib.orc_correct_map_points(_p(old_poses), _p(new_poses), len(old_poses), _p(kf), _p(pts), len(pts))
         assert rc == 0, rc
         return pts
+
+    # ---- loop verification: PnP-RANSAC ----
+    def solve_pnp_ransac(self, pts3d, pts2d, K, iterations=100, reproj_error=5.991, confidence=0.99):
+        p3 = np.ascontiguousarray(pts3d, np.float32).reshape(-1, 3); p2 = np.ascontiguousarray(pts2d, np.float32).reshape(-1, 2)
+        n = len(p3); pose = np.zeros(7); inl = np.zeros(max(n, 1), np.uint8); ni = C.c_int()
+        rc = self.lib.orc_solve_pnp_ransac(_p(p3), _p(p2), n, C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]), iterations,
+                                           C.c_double(reproj_error), C.c_double(confidence), _p(pose), _p(inl), C.byref(ni))
+        return rc, pose, inl[:n].astype(bool), ni.value
+
+    def epnp(self, pw, uv, K):
+        pw = np.ascontiguousarray(pw, np.float64).reshape(-1, 3); uv = np.ascontiguousarray(uv, np.float64).reshape(-1, 2)
+        R = np.zeros(9); t = np.zeros(3)
+        rc = self.lib.orc_epnp(_p(pw), _p(uv), len(pw), C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]), _p(R), _p(t))
+        return rc, R.reshape(3, 3), t
+
+    def cv_rng_uniform(self, seed, a, b, count):
+        out = np.zeros(count, np.int32)
+        self.lib.orc_cv_rng_uniform(C.c_uint64(seed), a, b, count, _p(out))
+        return out

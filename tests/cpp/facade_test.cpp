@@ -159,6 +159,34 @@ int main() {
         EXPECT(pts[3] == -4 && pts[4] == 0.5 && pts[5] == 9);
     }
 
+    // loop verification: PnP-RANSAC on 80 map points seen from a known pose, every fifth match wrong
+    {
+        const double fx = 718.856, fy = 718.856, cx = 607.1928, cy = 185.2157;
+        const double xi[6] = {0.8, -0.1, 1.5, 0.02, 0.3, -0.01};
+        double T[7]; orc_se3_exp(xi, T);
+        const double qx = T[0], qy = T[1], qz = T[2], qw = T[3];
+        const double R[9] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw), 2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz),
+                             2 * (qy * qz - qx * qw), 2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)};
+        std::uniform_real_distribution<double> U(-1, 1);
+        std::vector<myslam::Point3f> p3; std::vector<myslam::Point2f> p2;
+        for (int i = 0; i < 80; i++) {
+            const double pc[3] = {10 * U(rng), 2.5 * U(rng), 22 + 16 * U(rng)}, d[3] = {pc[0] - T[4], pc[1] - T[5], pc[2] - T[6]};
+            p3.push_back({(float)(R[0] * d[0] + R[3] * d[1] + R[6] * d[2]), (float)(R[1] * d[0] + R[4] * d[1] + R[7] * d[2]), (float)(R[2] * d[0] + R[5] * d[1] + R[8] * d[2])});
+            double u = fx * pc[0] / pc[2] + cx + 0.4 * U(rng), v = fy * pc[1] / pc[2] + cy + 0.4 * U(rng);
+            if (i % 5 == 0) { u = 620 + 600 * U(rng); v = 188 + 180 * U(rng); }
+            p2.push_back({(float)u, (float)v});
+        }
+        double gp[7], rp[7]; std::vector<uint8_t> gin, rin(80); int rn = 0;
+        EXPECT(myslam::solvePnPRansac(p3, p2, fx, fy, cx, cy, gp, &gin));
+        EXPECT(orc_solve_pnp_ransac(reinterpret_cast<const float*>(p3.data()), reinterpret_cast<const float*>(p2.data()), 80, fx, fy, cx, cy, 100, (double)5.991f, 0.99,
+                                    rp, rin.data(), &rn) == 0);
+        EXPECT(gin == rin && rn >= 60);
+        for (int i = 0; i < 7; i++) EXPECT(std::fabs(gp[i] - rp[i]) < 1e-9);
+        for (int i = 0; i < 3; i++) EXPECT(std::fabs(gp[4 + i] - T[4 + i]) < 0.05);
+        std::vector<myslam::Point3f> few(p3.begin(), p3.begin() + 4); std::vector<myslam::Point2f> few2(p2.begin(), p2.begin() + 4);
+        EXPECT(!myslam::solvePnPRansac(few, few2, fx, fy, cx, cy, gp));
+    }
+
     printf(fails ? "FACADE TEST FAILED (%d)\n" : "FACADE TEST OK (%d failures)\n", fails);
     return fails ? 1 : 0;
 }

@@ -66,4 +66,9 @@ pg3 = o.pose_graph_optimize(*pg[:5], iters=3)
 pg20 = o.pose_graph_optimize(*pg[:5], iters=20)
 np.savez_compressed(os.path.join(HERE, "pgo_small.npz"), poses=pg[0], fixed=pg[1], e0=pg[2], e1=pg[3], meas=pg[4],
                     poses3=pg3[0], chi3=pg3[1], poses20=pg20[0], chi20=pg20[1], its20=pg20[2])
+# loop verification (rank 3): PnP-RANSAC on 90 matches with 30 % mismatches
+pn = synth.pnp_problem(90, 0.3, 0.5, seed=0x77)
+rc, pn_pose, pn_inl, pn_n = o.solve_pnp_ransac(pn[0], pn[1], pn[2])
+assert rc == 0
+np.savez_compressed(os.path.join(HERE, "pnp_small.npz"), pts3d=pn[0], pts2d=pn[1], K=np.array(pn[2]), pose=pn_pose, inlier=pn_inl, n_inliers=pn_n)
 print("golden fixtures written to", HERE)

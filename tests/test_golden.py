@@ -29,6 +29,9 @@ def test_oracle_reproduces_golden(oracle, synth):
     pose, outl, inl = oracle.pose_only_optimize(q["pose0"], q["pts3d"], q["obs"], tuple(q["K"]))
     assert np.allclose(pose, q["pose"], rtol=1e-12, atol=1e-12) and np.array_equal(outl, q["outlier"]) and inl == int(q["inliers"])
     _check_pgo(oracle.pose_graph_optimize, synth, 1e-9)
+    g = np.load(os.path.join(G, "pnp_small.npz"))
+    rc, pose, inl, ni = oracle.solve_pnp_ransac(g["pts3d"], g["pts2d"], tuple(g["K"]))
+    assert rc == 0 and np.array_equal(inl, g["inlier"]) and ni == int(g["n_inliers"]) and np.abs(pose - g["pose"]).max() < 1e-10
 
 
 def _check_pgo(fn, synth, tol):
@@ -64,3 +67,6 @@ def test_hip_reproduces_golden(api, synth):
     pose, outl, inl = api.pose_only_optimize(q["pose0"], q["pts3d"], q["obs"], tuple(q["K"]))
     assert np.allclose(pose, q["pose"], rtol=1e-8, atol=1e-9) and np.array_equal(outl, q["outlier"]) and inl == int(q["inliers"])
     _check_pgo(api.pose_graph_optimize, synth, 2e-5)
+    g = np.load(os.path.join(G, "pnp_small.npz"))
+    pose, inl, ni = api.solve_pnp_ransac(g["pts3d"], g["pts2d"], tuple(g["K"]))
+    assert np.array_equal(inl, g["inlier"]) and ni == int(g["n_inliers"]) and np.abs(pose - g["pose"]).max() < 1e-9

@@ -589,3 +589,53 @@ def test_correct_map_points_keeps_camera_frame_position(oracle, synth):
         assert np.abs(_pose_apply(new[kf[i]], out[i][None]) - _pose_apply(poses[kf[i]], pts[i][None])).max() < 1e-10     # :630-633
     assert np.array_equal(oracle.correct_map_points(poses, poses, kf, pts)[kf < 0], pts[kf < 0])
     assert np.abs(oracle.correct_map_points(poses, poses, kf, pts) - pts).max() < 1e-12
+
+
+# ---- loop verification: PnP-RANSAC (src/loopclosing.cpp:262-268) ----
+def test_cv_rng_is_the_multiply_with_carry_generator(oracle):
+    """cv::RNG: state <- (uint32)state * 4164903690 + (state >> 32), output = (uint32)state, uniform(a, b) = a + output % (b - a)."""
+    state = 2 ** 64 - 1
+    want = []
+    for _ in range(20):
+        state = ((state & 0xffffffff) * 4164903690 + (state >> 32)) & (2 ** 64 - 1)
+        want.append(7 + (state & 0xffffffff) % (1000 - 7))
+    assert oracle.cv_rng_uniform(2 ** 64 - 1, 7, 1000, 20).tolist() == want
+    assert oracle.cv_rng_uniform(0, 0, 10, 5).tolist() == oracle.cv_rng_uniform(0xffffffff, 0, 10, 5).tolist()      # RNG(0) -> 0xffffffff
+    assert oracle.cv_rng_uniform(1, 4, 4, 3).tolist() == [4, 4, 4]
+
+
+def test_epnp_is_exact_on_exact_data(oracle, synth):
+    for seed, n in ((1, 5), (2, 5), (3, 6), (4, 12), (5, 40)):
+        pw, uv, K, pose, _ = synth.pnp_problem(n, 0.0, 0.0, seed=seed)
+        pw = pw.astype(np.float64)
+        pc = _pose_apply(pose, pw)
+        uv = np.stack([K[0] * pc[:, 0] / pc[:, 2] + K[2], K[1] * pc[:, 1] / pc[:, 2] + K[3]], 1)     # exact pixels of the float32 points
+        rc, R, t = oracle.epnp(pw, uv, K)
+        assert rc == 0
+        assert np.abs(pw @ R.T + t - pc).max() < 1e-6 and abs(np.linalg.det(R) - 1) < 1e-9 and np.abs(R @ R.T - np.eye(3)).max() < 1e-9
+
+
+def test_pnp_ransac_consensus_and_least_squares_refinement(oracle, synth):
+    from scipy.optimize import least_squares
+    pw, uv, K, pose, good = synth.pnp_problem(160, 0.35, 0.5, seed=21)
+    rc, p, inl, ni = oracle.solve_pnp_ransac(pw, uv, K)
+    assert rc == 0 and ni == inl.sum() and (inl & good).sum() >= 0.95 * good.sum() and (inl & ~good).sum() <= 3
+    # every flagged match reprojects within the threshold under the RANSAC model's refinement (nearly all: the mask belongs to the
+    # unrefined model), nothing unflagged is close
+    pc = _pose_apply(p, pw.astype(np.float64))
+    e2 = (K[0] * pc[:, 0] / pc[:, 2] + K[2] - uv[:, 0]) ** 2 + (K[1] * pc[:, 1] / pc[:, 2] + K[3] - uv[:, 1]) ** 2
+    assert (e2[inl] <= 5.991 ** 2).mean() > 0.97 and (e2[~inl] > 5.991 ** 2).mean() > 0.97
+    # the refined pose is the least-squares optimum over the consensus set: an independent minimiser started there does not move
+    P = pw[inl].astype(np.float64); U = uv[inl].astype(np.float64)
+
+    def res(x):
+        q = p.copy(); T = oracle.se3_compose(oracle.se3_exp(x), q)
+        c = _pose_apply(T, P)
+        return np.concatenate([K[0] * c[:, 0] / c[:, 2] + K[2] - U[:, 0], K[1] * c[:, 1] / c[:, 2] + K[3] - U[:, 1]])
+    sol = least_squares(res, np.zeros(6), xtol=1e-15, ftol=1e-15, gtol=1e-15)
+    assert np.abs(sol.x).max() < 1e-6
+    # all-inlier data: the first successful hypothesis ends the search (RANSACUpdateNumIters -> 0) and everything is flagged
+    pw, uv, K, pose, good = synth.pnp_problem(50, 0.0, 0.1, seed=22)
+    rc, p, inl, ni = oracle.solve_pnp_ransac(pw, uv, K)
+    assert rc == 0 and ni == 50
+    assert oracle.solve_pnp_ransac(pw[:4], uv[:4], K)[0] == -2
