@@ -244,6 +244,7 @@ def pose_graph(n_kf=200, n_loops=2, seed=0x9A, odo_noise=(0.002, 0.02), loop_noi
     picks = sorted(rng.choice(cand, size=min(n_old, len(cand)), replace=False).tolist()) if n_old and cand else []
     if n_loops:
         picks.append(n_kf - 1)                                          # the loop being closed starts at the current key-frame
+    picks = [i for i in picks if i - 21 >= 1]                           # a loop needs a key-frame at least 21 back (cf. loopclosing.cpp:131)
     for k, i in enumerate(picks):
         j = i - lap + int(rng.integers(-2, 3))
         j = min(max(j, 1), i - 21)
