@@ -21,7 +21,7 @@ EXACT = ["-ffp-contract=off"]
 UNITS = {
     "orb_kernels.hip": EXACT,
     "orb_engine.hip": EXACT,
-    "match_tri.hip": EXACT,
+    "match_tri.hip": EXACT + ["-mllvm", "-amdgpu-mfma-vgpr-form"],     # MFMA accumulators in VGPRs: the arg-max reads them directly
     "calc.hip": [],
     "lcddb.hip": [],
     "ba.hip": [],

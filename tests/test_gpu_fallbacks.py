@@ -1,5 +1,5 @@
 """The alternative kernels kept behind developer switches (one cell per block FAST, LDS-tile blur, one-row resize, one wave per
-key-point describe, unfused conv1) must stay bit-compatible with the default path: run the extractor + CALC against the oracle in
+key-point describe, unfused conv1, xor / popcount Hamming) must stay bit-compatible with the default path: run the extractor + CALC against the oracle in
 child processes with the switches set (they are read once per process)."""
 import os
 import subprocess
@@ -30,12 +30,18 @@ wts = synth.calc_weights()
 d, _ = api.DeepLCD(wts).calcDescrOriginalImg(L, blur_in_place=False)
 x, _ = o.calc_preproc(L)
 assert np.abs(d - o.calc_forward(wts, x)).max() < 2e-5, "CALC differs"
+rng = np.random.default_rng(5)
+for nq, nt in ((700, 1033), (33, 2), (2000, 1999)):
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8); t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    t[nt // 2] = t[0]; q[0] = t[0]
+    gi, gd = api.hamming_match(q, t); ri, rd = o.hamming_match(q, t)
+    assert np.array_equal(gi, ri) and np.array_equal(gd, rd), "Hamming differs"
 print("FALLBACK OK")
 '''
 
 
 @pytest.mark.parametrize("env", [
-    {"MYSLAM_FAST_V": "3", "MYSLAM_BLUR_V": "2", "MYSLAM_RESIZE_V": "1", "MYSLAM_DESC_V": "1", "MYSLAM_CONV1_V": "1"},
+    {"MYSLAM_FAST_V": "3", "MYSLAM_BLUR_V": "2", "MYSLAM_RESIZE_V": "1", "MYSLAM_DESC_V": "1", "MYSLAM_CONV1_V": "1", "MYSLAM_HAMMING_V": "1"},
     {"MYSLAM_FAST_V": "2", "MYSLAM_BLUR_V": "1"},
     {"MYSLAM_FAST_V": "2", "MYSLAM_FAST_T": "64"},
 ])
