@@ -25,6 +25,8 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package  # noqa: E402
 
 H, W = 376, 1241
+# SQ_INSTS_VALU per image (wave-level instructions), rocprofv3 --pmc, profiles/r01_pmc_insts_orb_match_p64_v10.txt
+VALU_INSTS_PER_IMAGE = {"fast_cells": 238618128 / 128, "describe": 56505600 / 128, "octree": 13590512 / 128}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 PYR_PX = 1444097               # sum of the 8 level areas
 # algorithmic bytes per IMAGE of each ORB kernel (SURVEY.md §8(d) accounting)
@@ -305,6 +307,14 @@ def main():
                 "avg_launch_ms": busy["calc_conv2"][0] / busy["calc_conv2"][1],
                 "note": "fp32 MFMA implicit GEMM of CALC conv2; with --streams 2 it shares the CUs with the FAST kernel, so this duration "
                         "is stretched (107 TFLOP/s = 0.68 of peak when it runs alone, --streams 1)"},
+            # the issue-rate view of the same dominant kernel: wave-level VALU instructions per image from a separate
+            # `rocprofv3 --pmc SQ_INSTS_VALU` run (profiles/r01_pmc_insts_orb_match_p64_v10.txt), x 64 lanes, against 256 CUs x 4 SIMDs x
+            # 16 lanes per cycle at 2.4 GHz
+            "roofline_valu": None if dom not in VALU_INSTS_PER_IMAGE else {
+                "bound": "valu", "kernel": dom, "unit": "Tlane-op/s", "peak": 39.3,
+                "achieved": VALU_INSTS_PER_IMAGE[dom] * imgs_per_launch / launches_per_step * 64 / (per_launch_ms * 1e-3) / 1e12,
+                "frac": VALU_INSTS_PER_IMAGE[dom] * imgs_per_launch / launches_per_step * 64 / (per_launch_ms * 1e-3) / 1e12 / 39.3,
+                "valu_wave_insts_per_image": VALU_INSTS_PER_IMAGE[dom]},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in busy.items()},
             "ba_solve_ms_per_step": solve_ms,     # OptimizeActiveMap solve stage for the same windows, outside the timed region
         }
