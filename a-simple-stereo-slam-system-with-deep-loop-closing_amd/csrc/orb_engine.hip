@@ -86,6 +86,10 @@ struct myslam_orb {
     std::vector<int> nPerLevel;
     int umax[16];
     hipStream_t stream = nullptr;
+    // the Gaussian pyramid only depends on the image pyramid: it runs on an internal stream beside the latency-bound oct-tree
+    // kernel, fenced by events against the caller's stream (run_batch)
+    hipStream_t aux = nullptr;
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
 
     // plan for the current image size
     int rows = 0, cols = 0;
@@ -111,7 +115,7 @@ struct myslam_orb {
     int ensure(int batch, int r, int c, bool needMask);
     int ensure_stage(size_t imgBytes, size_t maskBytes, int cap);
     int build_pyramids(const uint8_t* d_imgs, int batch, int step, size_t stride, const uint8_t* d_masks, int nlev);
-    int blur_levels(int batch, int nlev);
+    int blur_levels(int batch, int nlev, hipStream_t s);
     int run_batch(const uint8_t* d_imgs, int batch, int r, int c, int step, size_t stride, const uint8_t* d_masks,
                   myslam_keypoint* d_kps, uint8_t* d_desc, int32_t* d_counts, int32_t* d_stat, int cap, bool detectOnly);
     void free_all();
@@ -286,7 +290,7 @@ int myslam_orb::build_pyramids(const uint8_t* d_imgs, int batch, int step, size_
     return MYSLAM_OK;
 }
 
-int myslam_orb::blur_levels(int batch, int nlev) {
+int myslam_orb::blur_levels(int batch, int nlev, hipStream_t stream) {
     const OrbPlan& P = full;
     for (int l = 0; l < nlev; l++) {                           // ORBextractor.cpp:965-966 / :1194-1199
         ScopedProf sp(P_BLUR, stream);
@@ -318,16 +322,34 @@ int myslam_orb::run_batch(const uint8_t* d_imgs, int batch, int r, int c, int st
     }
     if ((rc = build_pyramids(d_imgs, batch, step, stride, d_masks, P.nlevels))) return rc;
     if (stop == 2) return MYSLAM_OK;
+    static const int aux_mode = [] { const char* e = getenv("MYSLAM_ORB_AUX"); return e ? atoi(e) : 2; }();     // 0: one stream, 1: blur after FAST, 2: blur right after the pyramid (default)
+    const bool fork = aux_mode > 0 && !detectOnly && stop == 0;
+    if (fork && !aux) {
+        MYSLAM_HIP_CHECK(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+        MYSLAM_HIP_CHECK(hipEventCreateWithFlags(&evFork, hipEventDisableTiming));
+        MYSLAM_HIP_CHECK(hipEventCreateWithFlags(&evJoin, hipEventDisableTiming));
+    }
+    auto fork_blur = [&]() -> int {                          // blur on the internal stream, ordered after everything enqueued so far
+        MYSLAM_HIP_CHECK(hipEventRecord(evFork, stream));
+        MYSLAM_HIP_CHECK(hipStreamWaitEvent(aux, evFork, 0));
+        int rc2 = blur_levels(batch, P.nlevels, aux);
+        if (rc2) return rc2;
+        MYSLAM_HIP_CHECK(hipEventRecord(evJoin, aux));
+        return MYSLAM_OK;
+    };
+    if (fork && aux_mode == 2 && (rc = fork_blur())) return rc;
     {
         ScopedProf sp(P_FAST, stream);
         launch_fast(P, d_pyr, full.pyrBytes, d_masks ? d_mask : nullptr, d_cand, d_candCount, batch, stream);
     }
+    if (fork && aux_mode != 2 && (rc = fork_blur())) return rc;
     {
         ScopedProf sp(P_OCTREE, stream);
         launch_octree(P, d_cand, d_candCount, d_sort, d_octTab, d_sel, d_selCount, stat, batch, stream);
     }
     if (stop == 3) return MYSLAM_OK;
-    if (!detectOnly && (rc = blur_levels(batch, P.nlevels))) return rc;
+    if (fork) MYSLAM_HIP_CHECK(hipStreamWaitEvent(stream, evJoin, 0));
+    else if (!detectOnly && (rc = blur_levels(batch, P.nlevels, stream))) return rc;
     if (stop == 4) return MYSLAM_OK;
     {
         ScopedProf sp(P_DESC, stream);
@@ -357,6 +379,7 @@ void myslam_orb::free_all() {
     void* ptrs[] = {d_octTab, d_pyr, d_blur, d_mask, d_cand, d_sort, d_candCount, d_selCount, d_status, d_sel, d_stageImg, d_stageMask,
                     d_stageKps, d_stageKps2, d_stageDesc, d_stageKeep, d_stageCounts};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); (void)hipEventDestroy(evFork); (void)hipEventDestroy(evJoin); aux = nullptr; }
 }
 
 // =================================================================================================
@@ -522,7 +545,7 @@ int myslam_orb_calc_descriptors(myslam_orb* h, const uint8_t* img, int rows, int
     for (int i = 0; i < n; i++) if (kps[i].octave < 0 || kps[i].octave >= h->nlevels) return MYSLAM_ERR_INVALID;
     int rc = host_pyramid(h, img, rows, cols, step, n);
     if (rc) return rc;
-    if ((rc = h->blur_levels(1, h->nlevels))) return rc;
+    if ((rc = h->blur_levels(1, h->nlevels, h->stream))) return rc;
     MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_stageKps, kps, sizeof(myslam_keypoint) * n, hipMemcpyHostToDevice, h->stream));
     {
         ScopedProf sp(P_DESC, h->stream);
@@ -538,7 +561,7 @@ int myslam_orb_debug_pyramid(myslam_orb* h, const uint8_t* img, int rows, int co
     if (!h || !img || level < 0 || level >= h->nlevels) return MYSLAM_ERR_INVALID;
     int rc = host_pyramid(h, img, rows, cols, step, 16);
     if (rc) return rc;
-    if (blurred && (rc = h->blur_levels(1, h->nlevels))) return rc;
+    if (blurred && (rc = h->blur_levels(1, h->nlevels, h->stream))) return rc;
     const LevelGeom& g = h->full.lv[level];
     if (w) *w = g.w;
     if (hgt) *hgt = g.h;

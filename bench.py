@@ -281,7 +281,7 @@ def main():
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, P), "avg_launch_ms": per_launch_ms,
                     "algorithmic_bytes_per_launch": algo,
-                    "note": "packed-integer VALU bound in practice (~70 VALU instructions per pixel, DESIGN.md section 6); traffic = FETCH_SIZE+WRITE_SIZE of a separate rocprofv3 --pmc run (profiles/), uncorrected"}
+                    "note": "packed-integer VALU bound in practice (see roofline_valu and DESIGN.md section 6); avg_launch_ms is the event-timed duration on the ORB stream, which this kernel shares with the Gaussian-pyramid launches of the extractor's internal stream and with the LCD / DB / BA chain (3.28 ms when it runs alone: --streams 1 with MYSLAM_ORB_AUX=0); traffic = FETCH_SIZE+WRITE_SIZE of a separate rocprofv3 --pmc run (profiles/), uncorrected"}
         else:
             roof = {"bound": "hbm", "kernel": dom, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                     "traffic": None, "avg_launch_ms": per_launch_ms}

@@ -41,8 +41,8 @@ print("FALLBACK OK")
 
 
 @pytest.mark.parametrize("env", [
-    {"MYSLAM_FAST_V": "3", "MYSLAM_BLUR_V": "2", "MYSLAM_RESIZE_V": "1", "MYSLAM_DESC_V": "1", "MYSLAM_CONV1_V": "1", "MYSLAM_HAMMING_V": "1"},
-    {"MYSLAM_FAST_V": "2", "MYSLAM_BLUR_V": "1"},
+    {"MYSLAM_FAST_V": "3", "MYSLAM_BLUR_V": "2", "MYSLAM_RESIZE_V": "1", "MYSLAM_DESC_V": "1", "MYSLAM_CONV1_V": "1", "MYSLAM_HAMMING_V": "1", "MYSLAM_ORB_AUX": "0"},
+    {"MYSLAM_FAST_V": "2", "MYSLAM_BLUR_V": "1", "MYSLAM_ORB_AUX": "1"},
     {"MYSLAM_FAST_V": "2", "MYSLAM_FAST_T": "64"},
 ])
 def test_alternative_kernels_match_oracle(env):
