@@ -64,7 +64,9 @@ typedef struct myslam_orb myslam_orb;
 int myslam_orb_create(myslam_orb** out, int nfeatures, float scale_factor, int nlevels,
                       int ini_th_fast, int min_th_fast);
 int myslam_orb_destroy(myslam_orb* h);
-/* all work of this handle is issued on `hip_stream` (a hipStream_t; NULL = default stream) */
+/* all work of this handle is ordered on `hip_stream` (a hipStream_t; NULL = default stream).  The batched extractor may run its
+ * Gaussian-pyramid launches on an internal stream; they are fenced by events against `hip_stream` on both sides, so for the caller
+ * every call still starts after, and completes before, its neighbours on `hip_stream`. */
 int myslam_orb_set_stream(myslam_orb* h, void* hip_stream);
 /* getters ORBextractor.h:87-107 */
 int myslam_orb_get_tables(const myslam_orb* h, float* scale, float* inv_scale, int* features_per_level, int* umax16);
