@@ -57,6 +57,75 @@ __global__ __launch_bounds__(256) void k_lcd_input(const uint8_t* __restrict__ s
     out[(size_t)b * IN_PLANE + (dy + IN_PAD) * IN_PW + dx + IN_PAD] = (float)v * (float)(1.0 / 255.0);      // deeplcd.cpp:64 convertTo(CV_32F, 1/255.)
 }
 
+// ---- the same input WITHOUT materialising the blurred frame (blur_in_place = 0): the 160 x 120 resize reads four blurred pixels per
+// output, 77 k of the 467 k the full Gaussian would produce.  One thread per output pixel evaluates exactly those four 7 x 7
+// responses from an 8 x 8 source window — the blur is exact integer arithmetic ((sum_r q_r sum_c q_c p + 32768) >> 16, no
+// intermediate rounding), so the results equal the two-pass kernel's bit for bit.  REFLECT_101 rows by index; a window that leaves
+// the image sideways takes the byte-wise path.
+__device__ __forceinline__ int lcd_reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = (p < 0) ? -p : 2 * len - 2 - p;
+    return p;
+}
+struct LcdTaps { int q[7]; };
+__global__ __launch_bounds__(256) void k_lcd_input_fused(const uint8_t* __restrict__ src, int sw, int sh, int spitch, size_t sstride,
+                                                         const int32_t* __restrict__ xofs, const int16_t* __restrict__ xa,
+                                                         const int32_t* __restrict__ yofs, const int16_t* __restrict__ yb, LcdTaps tp,
+                                                         float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= IN_H * IN_W) return;
+    const int dy = i / IN_W, dx = i - dy * IN_W;
+    const int sy = yofs[dy];
+    const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
+    const int sx = xofs[dx], sx1 = min(sx + 1, sw - 1);
+    const uint8_t* img = src + (size_t)b * sstride;
+    const uint32_t qa = (uint32_t)tp.q[0] | ((uint32_t)tp.q[1] << 8) | ((uint32_t)tp.q[2] << 16) | ((uint32_t)tp.q[3] << 24);
+    const uint32_t qb = (uint32_t)tp.q[4] | ((uint32_t)tp.q[5] << 8) | ((uint32_t)tp.q[6] << 16);
+    // horizontal 7-tap sums at columns sx and sx1 for the rows sy0-3 .. sy0+4 (sy1 = sy0 + 1 except at the clamped bottom row)
+    uint32_t h0[8], h1[8];
+    if (sx >= 3 && sx + 4 < sw && sy0 >= 3 && sy0 + 4 < sh) {      // the whole 8 x 8 window lies inside the image: straight-line code
+        const uint8_t* row = img + (size_t)(sy0 - 3) * spitch + (sx - 3);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t lo, hi;
+            __builtin_memcpy(&lo, row + (size_t)j * spitch, 4); __builtin_memcpy(&hi, row + (size_t)j * spitch + 4, 4);     // bytes sx-3..sx, sx+1..sx+4
+            h0[j] = __builtin_amdgcn_udot4(lo, qa, __builtin_amdgcn_udot4(hi, qb, 0u, false), false);
+            const uint32_t lo1 = __builtin_amdgcn_alignbyte(hi, lo, 1u), hi1 = hi >> 8;             // the same window one pixel to the right
+            h1[j] = __builtin_amdgcn_udot4(lo1, qa, __builtin_amdgcn_udot4(hi1, qb, 0u, false), false);
+        }
+    } else {                                                       // border outputs: byte-wise with REFLECT_101 indices
+#pragma unroll 1
+        for (int j = 0; j < 8; j++) {
+            const uint8_t* row = img + (size_t)lcd_reflect101(sy0 - 3 + j, sh) * spitch;
+            uint32_t a = 0, c = 0;
+#pragma unroll 1
+            for (int k = 0; k < 7; k++) {
+                a += (uint32_t)tp.q[k] * row[lcd_reflect101(sx - 3 + k, sw)];
+                c += (uint32_t)tp.q[k] * row[lcd_reflect101(sx1 - 3 + k, sw)];
+            }
+            // (dynamic index into a register array: kept out of the fast path)
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) if (jj == j) { h0[jj] = a; h1[jj] = c; }
+        }
+    }
+    // vertical taps: the blurred row sy0 uses window rows 0..6, the blurred row sy1 rows (sy1 - sy0) .. (sy1 - sy0) + 6
+    const int o = sy1 - sy0;                                  // 0 or 1
+    uint32_t b00 = 32768u, b01 = 32768u, b10 = 32768u, b11 = 32768u;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        b00 += (uint32_t)tp.q[k] * h0[k]; b01 += (uint32_t)tp.q[k] * h1[k];
+        const uint32_t u0 = o ? h0[k + 1] : h0[k], u1 = o ? h1[k + 1] : h1[k];
+        b10 += (uint32_t)tp.q[k] * u0; b11 += (uint32_t)tp.q[k] * u1;
+    }
+    const int p00 = (int)(b00 >> 16), p01 = (int)(b01 >> 16), p10 = (int)(b10 >> 16), p11 = (int)(b11 >> 16);
+    const int a0 = xa[2 * dx], a1 = xa[2 * dx + 1], w0 = yb[2 * dy], w1 = yb[2 * dy + 1];
+    const int r0 = p00 * a0 + p01 * a1, r1 = p10 * a0 + p11 * a1;
+    int v = (((w0 * (r0 >> 4)) >> 16) + ((w1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    v = min(max(v, 0), 255);
+    out[(size_t)b * IN_PLANE + (dy + IN_PAD) * IN_PW + dx + IN_PAD] = (float)v * (float)(1.0 / 255.0);
+}
+
 // ---- conv1 + ReLU: lane = output channel, one wave walks 8 output pixels ----
 __global__ __launch_bounds__(256) void k_conv1(const float* __restrict__ in, const float* __restrict__ w1t /*[25][64]*/,
                                                const float* __restrict__ b1, float* __restrict__ out /*[H1*W1][64]*/) {
@@ -443,16 +512,24 @@ int myslam_lcd::describe(uint8_t* d_imgs, int batch, int r, int c, int step, siz
     if (rc) return rc;
     {
         ScopedProf sp(P_LCD_PRE, stream);
-        BlurArgs a;                                   // GaussianBlur(img, img, Size(7,7), 0)  deeplcd.cpp:46
-        a.src = d_imgs; a.dst = d_blur; a.w = c; a.h = r; a.spitch = step; a.dpitch = blurPitch; a.sstride = stride; a.dstride = blurBytes;
-        gauss_q8(1, a.q);
-        launch_blur(a, batch, stream);
-        if (blur_in_place)                            // the reference mutates the caller's pixels
-            for (int b = 0; b < batch; b++)
-                MYSLAM_HIP_CHECK(hipMemcpy2DAsync(d_imgs + (size_t)b * stride, step, d_blur + (size_t)b * blurBytes, blurPitch, c, r,
-                                                  hipMemcpyDeviceToDevice, stream));
-        hipLaunchKernelGGL(k_lcd_input, dim3((IN_H * IN_W + 255) / 256, batch), dim3(256), 0, stream, d_blur, c, r, blurPitch, blurBytes,
-                           d_xofs, d_xa, d_yofs, d_yb, d_in);       // cv::resize(.., Size(160,120))  deeplcd.cpp:48-50
+        static const int fused = [] { const char* e = getenv("MYSLAM_LCD_PRE_V"); return e ? atoi(e) != 1 : 1; }();     // tuning aid: 1 = two-pass blur + resize
+        if (!blur_in_place && fused) {
+            LcdTaps tp;
+            gauss_q8(1, tp.q);
+            hipLaunchKernelGGL(k_lcd_input_fused, dim3((IN_H * IN_W + 255) / 256, batch), dim3(256), 0, stream, d_imgs, c, r, step, stride,
+                               d_xofs, d_xa, d_yofs, d_yb, tp, d_in);
+        } else {
+            BlurArgs a;                                   // GaussianBlur(img, img, Size(7,7), 0)  deeplcd.cpp:46
+            a.src = d_imgs; a.dst = d_blur; a.w = c; a.h = r; a.spitch = step; a.dpitch = blurPitch; a.sstride = stride; a.dstride = blurBytes;
+            gauss_q8(1, a.q);
+            launch_blur(a, batch, stream);
+            if (blur_in_place)                            // the reference mutates the caller's pixels
+                for (int b = 0; b < batch; b++)
+                    MYSLAM_HIP_CHECK(hipMemcpy2DAsync(d_imgs + (size_t)b * stride, step, d_blur + (size_t)b * blurBytes, blurPitch, c, r,
+                                                      hipMemcpyDeviceToDevice, stream));
+            hipLaunchKernelGGL(k_lcd_input, dim3((IN_H * IN_W + 255) / 256, batch), dim3(256), 0, stream, d_blur, c, r, blurPitch, blurBytes,
+                               d_xofs, d_xa, d_yofs, d_yb, d_in);       // cv::resize(.., Size(160,120))  deeplcd.cpp:48-50
+        }
     }
     return lcd_forward(this, batch, d_out);
 }

@@ -166,3 +166,14 @@ def test_loop_database_many_queries_back_to_back(api, oracle, synth):
         for i in range(0, nq, 37):
             rb, rm, rc = oracle.lcddb_query(db, ids, q[i], int(cur[i]))
             assert int(dbest[i]) == rb and abs(float(dmax[i]) - rm) < SCORE_ATOL and int(dcnt[i]) == rc
+
+
+@pytest.mark.parametrize("h,w", [(376, 1241), (120, 160), (97, 131), (480, 640), (33, 41), (200, 9), (9, 300)])
+def test_fused_input_equals_two_pass_blur(api, synth, h, w):
+    """blur_in_place = False evaluates only the blurred pixels the 160 x 120 resize reads (k_lcd_input_fused); blur_in_place = True
+    runs the full Gaussian and the resize.  Both are exact integer arithmetic: identical network input, identical descriptor bits."""
+    lcd = api.DeepLCD(synth.calc_weights())
+    img = synth.random_image(h * 1000 + w, h, w)
+    d1, _ = lcd.calcDescrOriginalImg(img, blur_in_place=False)
+    d2, _ = lcd.calcDescrOriginalImg(img.copy(), blur_in_place=True)
+    assert np.array_equal(d1.view(np.uint32), d2.view(np.uint32))
