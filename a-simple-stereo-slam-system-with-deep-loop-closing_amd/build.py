@@ -22,7 +22,7 @@ UNITS = {
     "orb_kernels.hip": EXACT,
     "orb_engine.hip": EXACT,
     "match_tri.hip": EXACT + ["-mllvm", "-amdgpu-mfma-vgpr-form"],     # MFMA accumulators in VGPRs: the arg-max reads them directly
-    "calc.hip": [],
+    "calc.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
     "lcddb.hip": [],
     "ba.hip": [],
     "lk.hip": EXACT,

@@ -256,49 +256,180 @@ __device__ __forceinline__ float wave_sum_lane63_f32(float v) {
 
 // ---- conv2 + ReLU as an fp32 MFMA implicit GEMM ----
 // C[M = batch*1344][N = 128] = A[M][K = 1024] * Wt[K][N];  k = (ky*4+kx)*64 + ic  (channel runs contiguous in NHWC)
-// block tile 128(M) x 128(N), 4 waves as 2x2, each wave 64x64 = 2x2 MFMA 32x32 tiles; BK = 16 per stage (64 stages),
-// register-staged double buffering through LDS.
-constexpr int CV_BM = 128, CV_BN = 128, CV_BK = 16, CV_PA = CV_BM + 4, CV_PB = CV_BN + 4;
+// 4 waves as 2x2, each wave TI x TJ MFMA 32x32 tiles -> block tile (64 TI) x (64 TJ); BK k per stage, register-staged double
+// buffering through LDS.
+//   <2, 2, 16>  128 x 128 tile, 179 registers: the stand-alone configuration (68 % of the fp32-MFMA peak)
+//   <1, 1, 16>   64 x 64 tile, <= 80 registers and 17 KB of LDS: small enough to sit on a CU NEXT TO six waves per SIMD of the
+//               VALU-bound FAST kernel, so the matrix cores work while the vector ALUs are saturated
+constexpr int CV_BN = 128;
 
+template <int TI, int TJ, int BK>
 __global__ __launch_bounds__(256) void k_conv2_mfma(const float* __restrict__ in /*[B][31*41][64]*/,
                                                     const float* __restrict__ wt /*[1024][128]*/, const float* __restrict__ b2,
                                                     float* __restrict__ out /*[B*1344][128]*/, int Mtotal) {
-    __shared__ __attribute__((aligned(16))) float s_a[2][CV_BK * CV_PA];
-    __shared__ __attribute__((aligned(16))) float s_b[2][CV_BK * CV_PB];
+    constexpr int BM = 64 * TI, BN = 64 * TJ, PA = BM + 4, PB = BN + 4;
+    constexpr int AK = BM * BK / 256;                  // consecutive k per thread of the A slab (2, 4 or 8)
+    constexpr int BPT = BK * BN / 256;                 // consecutive n per thread of the B slab (4 or 8)
+    static_assert(CV_BN % BN == 0 && (AK == 2 || AK == 4 || AK == 8) && (BPT == 4 || BPT == 8) && 64 % BK == 0, "unsupported conv2 tiling");
+    __shared__ __attribute__((aligned(16))) float s_a[2][BK * PA];
+    __shared__ __attribute__((aligned(16))) float s_b[2][BK * PB];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    const int m0 = blockIdx.x * CV_BM;
+    const int wm = (wave >> 1) * (32 * TI), wn = (wave & 1) * (32 * TJ);
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
 
-    // A staging role: thread -> (row m = t>>1, 8 consecutive k at (t&1)*8)
-    const int am = t >> 1, ak = (t & 1) * 8;
+    // A staging role: thread -> (row m, AK consecutive k)
+    constexpr int ATPR = BK / AK;                      // threads per A row
+    const int am = t / ATPR, ak = (t % ATPR) * AK;
     const int gm = m0 + am;
     const bool mvalid = gm < Mtotal;
     const int img = mvalid ? gm / M2 : 0;
     const int pix = mvalid ? gm - img * M2 : 0;
     const int oy = pix / W2, ox = pix - oy * W2;
     const float* inb = in + (size_t)img * HP1 * WP1 * 64;
-    // B staging role: thread -> (k row = t>>4, 8 consecutive n at (t&15)*8)
-    const int bk = t >> 4, bn = (t & 15) * 8;
+    // B staging role: thread -> (k row, BPT consecutive n)
+    constexpr int BTPR = BN / BPT;
+    const int bk = t / BTPR, bn = (t % BTPR) * BPT;
 
-    float4 ra0, ra1, rb0, rb1;
+    float ra[AK], rb[BPT];
     auto load_stage = [&](int s) {
-        const int tap = s >> 2, ic0 = (s & 3) * 16;
+        constexpr int SPT = 64 / BK;                   // stages per filter tap
+        const int tap = s / SPT, ic0 = (s % SPT) * BK;
         const int iy = oy + (tap >> 2) - 2, ix = ox + (tap & 3) - 2;
         if (mvalid && iy >= 0 && iy < HP1 && ix >= 0 && ix < WP1) {
-            const float4* src = reinterpret_cast<const float4*>(inb + ((size_t)iy * WP1 + ix) * 64 + ic0 + ak);
-            ra0 = src[0]; ra1 = src[1];
+            const float* src = inb + ((size_t)iy * WP1 + ix) * 64 + ic0 + ak;
+            if constexpr (AK == 2) { const float2 v = *reinterpret_cast<const float2*>(src); ra[0] = v.x; ra[1] = v.y; }
+            else {
+#pragma unroll
+                for (int q = 0; q < AK / 4; q++) { const float4 v = reinterpret_cast<const float4*>(src)[q]; ra[4 * q] = v.x; ra[4 * q + 1] = v.y; ra[4 * q + 2] = v.z; ra[4 * q + 3] = v.w; }
+            }
         } else {
-            ra0 = make_float4(0, 0, 0, 0); ra1 = ra0;
+#pragma unroll
+            for (int q = 0; q < AK; q++) ra[q] = 0.f;
         }
-        const float4* wsrc = reinterpret_cast<const float4*>(wt + (size_t)(s * CV_BK + bk) * CV_BN + bn);
-        rb0 = wsrc[0]; rb1 = wsrc[1];
+        const float4* wsrc = reinterpret_cast<const float4*>(wt + (size_t)(s * BK + bk) * CV_BN + n0 + bn);
+#pragma unroll
+        for (int q = 0; q < BPT / 4; q++) { const float4 v = wsrc[q]; rb[4 * q] = v.x; rb[4 * q + 1] = v.y; rb[4 * q + 2] = v.z; rb[4 * q + 3] = v.w; }
     };
     auto store_stage = [&](int buf) {
         float* a = s_a[buf];
-        a[(ak + 0) * CV_PA + am] = ra0.x; a[(ak + 1) * CV_PA + am] = ra0.y; a[(ak + 2) * CV_PA + am] = ra0.z; a[(ak + 3) * CV_PA + am] = ra0.w;
-        a[(ak + 4) * CV_PA + am] = ra1.x; a[(ak + 5) * CV_PA + am] = ra1.y; a[(ak + 6) * CV_PA + am] = ra1.z; a[(ak + 7) * CV_PA + am] = ra1.w;
-        float4* bdst = reinterpret_cast<float4*>(&s_b[buf][bk * CV_PB + bn]);
-        bdst[0] = rb0; bdst[1] = rb1;
+#pragma unroll
+        for (int q = 0; q < AK; q++) a[(ak + q) * PA + am] = ra[q];
+        float4* bdst = reinterpret_cast<float4*>(&s_b[buf][bk * PB + bn]);
+#pragma unroll
+        for (int q = 0; q < BPT / 4; q++) bdst[q] = make_float4(rb[4 * q], rb[4 * q + 1], rb[4 * q + 2], rb[4 * q + 3]);
+    };
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+        for (int j = 0; j < TJ; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    constexpr int NSTAGE = K2 / BK;
+    const int lr = lane & 31, lk = lane >> 5;
+    for (int s = 0; s < NSTAGE; s++) {
+        const int buf = s & 1;
+        if (s + 1 < NSTAGE) load_stage(s + 1);
+        const float* a = s_a[buf];
+        const float* bb = s_b[buf];
+#pragma unroll
+        for (int kq = 0; kq < BK / 2; kq++) {
+            const int k = 2 * kq + lk;
+            float av[TI], bv[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; i++) av[i] = a[k * PA + wm + 32 * i + lr];
+#pragma unroll
+            for (int j = 0; j < TJ; j++) bv[j] = bb[k * PB + wn + 32 * j + lr];
+#pragma unroll
+            for (int i = 0; i < TI; i++)
+#pragma unroll
+                for (int j = 0; j < TJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < NSTAGE) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TJ; j++) {
+        const int n = n0 + wn + j * 32 + lr;
+        const float bias = b2[n];
+#pragma unroll
+        for (int i = 0; i < TI; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m < Mtotal) out[(size_t)m * CV_BN + n] = fmaxf(acc[i][j][r] + bias, 0.f);
+            }
+    }
+}
+
+// ---- conv2 on the bf16 matrix cores with fp32 accuracy ----
+// The fp32-input MFMA above runs at the f32 VECTOR rate — in practice it competes with the VALU-bound ORB kernels of the other
+// stream instead of running under them (measured: no gain from co-residency).  The bf16 matrix pipe is 16x
+// faster and separate.  Every f32 operand is split exactly into three bf16 pieces a = h + m + l (8 + 8 + 8 significand bits,
+// round-to-nearest conversions, exact residuals); of the nine partial products the six largest are kept:
+//     a b  ~  hh + hm + mh + hl + lh + mm        (dropped: ml, lm, ll <= 2^-23 |a b|, the rounding level of an f32 product)
+// accumulated in f32 by v_mfma_f32_32x32x16_bf16.  Weights are split once on the host ([stage][piece][n][16 k], so a stage's slab
+// is one contiguous 12 KB block); activations are split while they are staged into LDS (11 VALU per pair of elements).
+// Block tile 128 x 128, 4 waves x (2 x 2) tiles, BK = 16 = one MFMA K: 24 MFMAs of 32 cycles per wave and stage against
+// 32 x 64 cycles for the f32 form.
+typedef __bf16 cv_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void cv_split3(float a0, float a1, uint32_t& h, uint32_t& m, uint32_t& l) {    // two elements per dword, a0 low
+    const __bf16 h0 = (__bf16)a0, h1 = (__bf16)a1;
+    const float r0 = a0 - (float)h0, r1 = a1 - (float)h1;
+    const __bf16 m0 = (__bf16)r0, m1 = (__bf16)r1;
+    const float q0 = r0 - (float)m0, q1 = r1 - (float)m1;
+    const __bf16 l0 = (__bf16)q0, l1 = (__bf16)q1;
+    h = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
+    m = (uint32_t)__builtin_bit_cast(unsigned short, m0) | ((uint32_t)__builtin_bit_cast(unsigned short, m1) << 16);
+    l = (uint32_t)__builtin_bit_cast(unsigned short, l0) | ((uint32_t)__builtin_bit_cast(unsigned short, l1) << 16);
+}
+
+__global__ __launch_bounds__(256) void k_conv2_bf16x6(const float* __restrict__ in /*[B][31*41][64]*/,
+                                                      const uint4* __restrict__ wt3 /*[64 stages][3][128 n][2 k-halves] x 8 bf16*/,
+                                                      const float* __restrict__ b2, float* __restrict__ out /*[B*1344][128]*/, int Mtotal) {
+    constexpr int BM = 128, BN = 128;
+    __shared__ uint4 s_a[2][3][BM * 2];                // [piece][row m][k half]: 8 bf16 per uint4
+    __shared__ uint4 s_b[2][3][BN * 2];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int m0 = blockIdx.x * BM;
+    const int am = t >> 1, akh = t & 1;                // staging role: row m, k half (8 consecutive k)
+    const int gm = m0 + am;
+    const bool mvalid = gm < Mtotal;
+    const int img = mvalid ? gm / M2 : 0;
+    const int pix = mvalid ? gm - img * M2 : 0;
+    const int oy = pix / W2, ox = pix - oy * W2;
+    const float* inb = in + (size_t)img * HP1 * WP1 * 64;
+
+    // the prefetched slab of the next stage lives in registers across the MFMA block: unconditional loads from a clamped address
+    // plus a select at store time (a branch here sends the values through scratch and waits for the loads on the spot)
+    float4 ra0 = make_float4(0, 0, 0, 0), ra1 = ra0;
+    uint4 rb0 = make_uint4(0, 0, 0, 0), rb1 = rb0, rb2 = rb0;
+    bool rav = false;
+#define CV2_LOAD_STAGE(S)                                                                                                     \
+    {                                                                                                                         \
+        const int tap_ = (S) >> 2, ic0_ = ((S) & 3) * 16;                                                                     \
+        const int iy_ = oy + (tap_ >> 2) - 2, ix_ = ox + (tap_ & 3) - 2;                                                      \
+        rav = mvalid && iy_ >= 0 && iy_ < HP1 && ix_ >= 0 && ix_ < WP1;                                                       \
+        const float4* src_ = reinterpret_cast<const float4*>(inb + (rav ? ((size_t)iy_ * WP1 + ix_) * 64 : 0) + ic0_ + akh * 8); \
+        ra0 = src_[0]; ra1 = src_[1];                                                                                         \
+        const uint4* wsrc_ = wt3 + (size_t)(S) * (3 * BN * 2) + t;                                                            \
+        rb0 = wsrc_[0]; rb1 = wsrc_[BN * 2]; rb2 = wsrc_[2 * BN * 2];                                                         \
+    }
+    auto store_stage = [&](int buf) {
+        const float z = rav ? 1.f : 0.f;
+        uint4 h, m, l;
+        cv_split3(ra0.x * z, ra0.y * z, h.x, m.x, l.x); cv_split3(ra0.z * z, ra0.w * z, h.y, m.y, l.y);
+        cv_split3(ra1.x * z, ra1.y * z, h.z, m.z, l.z); cv_split3(ra1.z * z, ra1.w * z, h.w, m.w, l.w);
+        s_a[buf][0][t] = h; s_a[buf][1][t] = m; s_a[buf][2][t] = l;       // index (m * 2 + k half) == t
+        s_b[buf][0][t] = rb0; s_b[buf][1][t] = rb1; s_b[buf][2][t] = rb2;
     };
 
     f32x16 acc[2][2];
@@ -309,30 +440,39 @@ __global__ __launch_bounds__(256) void k_conv2_mfma(const float* __restrict__ in
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    load_stage(0);
+    CV2_LOAD_STAGE(0)
     store_stage(0);
     __syncthreads();
-    constexpr int NSTAGE = K2 / CV_BK;
+    constexpr int NSTAGE = K2 / 16;
     const int lr = lane & 31, lk = lane >> 5;
     for (int s = 0; s < NSTAGE; s++) {
         const int buf = s & 1;
-        if (s + 1 < NSTAGE) load_stage(s + 1);
-        const float* a = s_a[buf];
-        const float* bb = s_b[buf];
+        if (s + 1 < NSTAGE) CV2_LOAD_STAGE(s + 1)
+        cv_bf16x8 A[2][3], Bm[2][3];
 #pragma unroll
-        for (int kq = 0; kq < CV_BK / 2; kq++) {
-            const int k = 2 * kq + lk;
-            const float a0 = a[k * CV_PA + wm + lr], a1 = a[k * CV_PA + wm + 32 + lr];
-            const float b0 = bb[k * CV_PB + wn + lr], b1 = bb[k * CV_PB + wn + 32 + lr];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int p = 0; p < 3; p++) A[i][p] = __builtin_bit_cast(cv_bf16x8, s_a[buf][p][(wm + 32 * i + lr) * 2 + lk]);
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int p = 0; p < 3; p++) Bm[j][p] = __builtin_bit_cast(cv_bf16x8, s_b[buf][p][(wn + 32 * j + lr) * 2 + lk]);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][2], Bm[j][0], c, 0, 0, 0);       // l h
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], Bm[j][2], c, 0, 0, 0);       // h l
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][1], Bm[j][1], c, 0, 0, 0);       // m m
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][1], Bm[j][0], c, 0, 0, 0);       // m h
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], Bm[j][1], c, 0, 0, 0);       // h m
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], Bm[j][0], c, 0, 0, 0);       // h h
+                acc[i][j] = c;
+            }
         if (s + 1 < NSTAGE) store_stage(buf ^ 1);
         __syncthreads();
     }
-    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int n = wn + j * 32 + lr;
@@ -346,6 +486,8 @@ __global__ __launch_bounds__(256) void k_conv2_mfma(const float* __restrict__ in
             }
     }
 }
+
+#undef CV2_LOAD_STAGE
 
 // ---- conv3 + ReLU + flatten (NCHW order) + L2 normalise; one 1024-thread block per image ----
 // 16 waves share the 266 output pixels; each lane keeps its 18 weight quadruples (k = lane + 64 j) in registers.
@@ -419,6 +561,7 @@ using namespace myslam_hip;
 struct myslam_lcd {
     hipStream_t stream = nullptr;
     float *d_w1t = nullptr, *d_b1 = nullptr, *d_w2t = nullptr, *d_b2 = nullptr, *d_w3t = nullptr, *d_b3 = nullptr;
+    uint4* d_w2s = nullptr;            // conv2 weights split into three bf16 pieces, [stage][piece][n][k half] x 8 bf16
     int relu3 = 1;
     // resize tables for the current source size
     int rows = 0, cols = 0;
@@ -495,7 +638,15 @@ static int lcd_forward(myslam_lcd* h, int batch, float* d_out) {
     {
         ScopedProf sp(P_CONV2, s);
         const int Mtotal = batch * M2;
-        hipLaunchKernelGGL(k_conv2_mfma, dim3((Mtotal + CV_BM - 1) / CV_BM), dim3(256), 0, s, h->d_p1, h->d_w2t, h->d_b2, h->d_a2, Mtotal);
+        static const int lite = [] { const char* e = getenv("MYSLAM_CONV2_V"); return e ? atoi(e) : 3; }();     // 0/1/2: f32-input MFMA tilings
+        if (lite == 3)
+            hipLaunchKernelGGL(k_conv2_bf16x6, dim3((Mtotal + 127) / 128), dim3(256), 0, s, h->d_p1, h->d_w2s, h->d_b2, h->d_a2, Mtotal);
+        else if (lite == 1)
+            hipLaunchKernelGGL((k_conv2_mfma<1, 1, 16>), dim3((Mtotal + 63) / 64, 2), dim3(256), 0, s, h->d_p1, h->d_w2t, h->d_b2, h->d_a2, Mtotal);
+        else if (lite == 2)
+            hipLaunchKernelGGL((k_conv2_mfma<1, 2, 8>), dim3((Mtotal + 63) / 64), dim3(256), 0, s, h->d_p1, h->d_w2t, h->d_b2, h->d_a2, Mtotal);
+        else
+            hipLaunchKernelGGL((k_conv2_mfma<2, 2, 16>), dim3((Mtotal + 127) / 128), dim3(256), 0, s, h->d_p1, h->d_w2t, h->d_b2, h->d_a2, Mtotal);
     }
     {
         ScopedProf sp(P_CONV3, s);
@@ -553,6 +704,26 @@ int myslam_lcd_create(myslam_lcd** out, const float* weights, size_t nweights) {
     for (int oc = 0; oc < 4; oc++)
         for (int ic = 0; ic < 128; ic++)
             for (int t = 0; t < 9; t++) w3t[((size_t)t * 128 + ic) * 4 + oc] = w3[((size_t)oc * 128 + ic) * 9 + t];
+    // conv2 weights as three bf16 pieces (round to nearest even, exact residuals), stage-major so a stage's slab is contiguous
+    auto to_bf16 = [](float x) -> uint16_t {
+        uint32_t u; memcpy(&u, &x, 4);
+        if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (uint16_t)(u >> 16);
+    };
+    auto from_bf16 = [](uint16_t b) -> float { const uint32_t u = (uint32_t)b << 16; float x; memcpy(&x, &u, 4); return x; };
+    std::vector<uint16_t> w2s((size_t)64 * 3 * 128 * 16);
+    for (int k = 0; k < K2; k++) {
+        const int st = k >> 4, kk = k & 15;
+        for (int oc = 0; oc < 128; oc++) {
+            const float a = w2t[(size_t)k * 128 + oc];
+            const uint16_t hb = to_bf16(a); const float r = a - from_bf16(hb);
+            const uint16_t mb = to_bf16(r); const float q = r - from_bf16(mb);
+            const uint16_t lb = to_bf16(q);
+            const uint16_t pcs[3] = {hb, mb, lb};
+            for (int p = 0; p < 3; p++) w2s[(((size_t)st * 3 + p) * 128 + oc) * 16 + kk] = pcs[p];
+        }
+    }
     myslam_lcd* h = new myslam_lcd();
     auto up = [&](float*& d, const float* src, size_t n) -> int {
         MYSLAM_HIP_CHECK(hipMalloc((void**)&d, n * sizeof(float)));
@@ -565,6 +736,8 @@ int myslam_lcd_create(myslam_lcd** out, const float* weights, size_t nweights) {
         delete h;
         return rc;
     }
+    if (hipMalloc((void**)&h->d_w2s, w2s.size() * 2) != hipSuccess ||
+        hipMemcpy(h->d_w2s, w2s.data(), w2s.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { delete h; return MYSLAM_ERR_HIP; }
     *out = h;
     return MYSLAM_OK;
 }
@@ -586,7 +759,7 @@ int myslam_lcd_create_from_file(myslam_lcd** out, const char* path) {
 int myslam_lcd_destroy(myslam_lcd* h) {
     if (!h) return MYSLAM_ERR_INVALID;
     (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->d_w1t, h->d_b1, h->d_w2t, h->d_b2, h->d_w3t, h->d_b3, h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_blur,
+    void* ptrs[] = {h->d_w2s, h->d_w1t, h->d_b1, h->d_w2t, h->d_b2, h->d_w3t, h->d_b3, h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_blur,
                     h->d_in, h->d_a1, h->d_p1, h->d_a2, h->d_p2, h->d_stageImg, h->d_stageOut};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete h;

@@ -301,12 +301,15 @@ def main():
                        "parallelism": f"frame-sharded x{world}" + (", id-range sharded DB + all-gather of candidates" if world > 1 else "")},
             "roofline": roof,
             "roofline_mfma": None if "calc_conv2" not in busy else {
-                "bound": "mfma", "kernel": "calc_conv2", "peak": 157.3, "unit": "TFLOP/s",
-                "achieved": 2 * 176160768 * P / (busy["calc_conv2"][0] / busy["calc_conv2"][1] * 1e-3) / 1e12,
-                "frac": 2 * 176160768 * P / (busy["calc_conv2"][0] / busy["calc_conv2"][1] * 1e-3) / 1e12 / 157.3,
+                "bound": "mfma", "kernel": "calc_conv2", "peak": 2500.0, "unit": "TFLOP/s (bf16, dense)",
+                "achieved": 6 * 2 * 176160768 * P / (busy["calc_conv2"][0] / busy["calc_conv2"][1] * 1e-3) / 1e12,
+                "frac": 6 * 2 * 176160768 * P / (busy["calc_conv2"][0] / busy["calc_conv2"][1] * 1e-3) / 1e12 / 2500.0,
+                "effective_f32_tflops": 2 * 176160768 * P / (busy["calc_conv2"][0] / busy["calc_conv2"][1] * 1e-3) / 1e12,
                 "avg_launch_ms": busy["calc_conv2"][0] / busy["calc_conv2"][1],
-                "note": "fp32 MFMA implicit GEMM of CALC conv2; with --streams 2 it shares the CUs with the FAST kernel, so this duration "
-                        "is stretched (107 TFLOP/s = 0.68 of peak when it runs alone, --streams 1)"},
+                "note": "CALC conv2 as an implicit GEMM on the bf16 matrix cores with f32 accuracy: every f32 operand is split exactly into three "
+                        "bf16 pieces and the six largest partial products are accumulated in f32 (6 bf16 MFMA flops per f32 flop; error against an "
+                        "f64 reference 1.5e-6, the same as the f32-input MFMA it replaces); with --streams 2 it shares the CUs with the ORB "
+                        "kernels, so this duration is stretched (0.93 ms when it runs alone, --streams 1)"},
             # the issue-rate view of the same dominant kernel: wave-level VALU instructions per image from a separate
             # `rocprofv3 --pmc SQ_INSTS_VALU` run (profiles/r01_pmc_insts_orb_match_p64_v10.txt), x 64 lanes, against 256 CUs x 4 SIMDs x
             # 16 lanes per cycle at 2.4 GHz
