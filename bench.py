@@ -69,6 +69,7 @@ def parse():
     ap.add_argument("--orb-split", type=int, default=1, choices=[1, 2, 4, 8],
                     help="S > 1 = the 2P images go through S extractor handles on S streams (S equal groups; 2 is ~2-3 % faster, "
                          "but concurrent launches of the same kernel stretch each other, which blurs the per-launch roofline figure)")
+    ap.add_argument("--side-delay-ms", type=float, default=0.0, help="experiment: start the side chain this long after the step begins (spin kernel)")
     ap.add_argument("--no-join", action="store_true", help="do not join the side stream at the end of every step (streaming across steps)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = debugging aid: several ranks share GPU 0 and the collectives go through host memory")
@@ -206,6 +207,8 @@ def main():
         api.triangulate_stereo_batch(d_kps.data_ptr(), d_kps.data_ptr() + P * cap * 28, d_midx.data_ptr(), d_cnt.data_ptr(), P, cap,
                                      Kt, K["bf"] / K["fx"], d_xyz.data_ptr(), d_ok.data_ptr(), stream)
         with torch.cuda.stream(side_stream):
+            if args.side_delay_ms > 0 and side_stream is not main_stream:
+                torch.cuda._sleep(int(args.side_delay_ms * 1e-3 * 2.0e9))
             if use_lcd:
                 lcd.describe_batch(d_imgs.data_ptr(), P, H, W, W, H * W, d_descr.data_ptr(), blur_in_place=False)
                 if world > 1:       # every shard scores every rank's queries; candidates are merged after an all-gather
