@@ -23,7 +23,7 @@ UNITS = {
     "orb_engine.hip": EXACT,
     "match_tri.hip": EXACT + ["-mllvm", "-amdgpu-mfma-vgpr-form"],     # MFMA accumulators in VGPRs: the arg-max reads them directly
     "calc.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-    "lcddb.hip": [],
+    "lcddb.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
     "ba.hip": [],
     "lk.hip": EXACT,
     "pgo.hip": [],

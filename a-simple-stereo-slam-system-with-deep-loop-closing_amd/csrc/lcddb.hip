@@ -161,6 +161,128 @@ __global__ __launch_bounds__(256) void k_db_scan_mfma(const float* __restrict__ 
     }
 }
 
+// The same GEMM on the bf16 matrix cores with f32 accuracy (see k_conv2_bf16x6 in calc.hip): the f32-input MFMA runs at the f32
+// vector rate and competes with the VALU-bound ORB kernels of the other stream.  Database rows and queries are split exactly into
+// three bf16 pieces while they are staged into LDS; hh + hm + mh + hl + lh + mm are accumulated in f32.
+typedef __bf16 db_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void db_split3(float a0, float a1, uint32_t& h, uint32_t& m, uint32_t& l) {
+    const __bf16 h0 = (__bf16)a0, h1 = (__bf16)a1;
+    const float r0 = a0 - (float)h0, r1 = a1 - (float)h1;
+    const __bf16 m0 = (__bf16)r0, m1 = (__bf16)r1;
+    const float q0 = r0 - (float)m0, q1 = r1 - (float)m1;
+    const __bf16 l0 = (__bf16)q0, l1 = (__bf16)q1;
+    h = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
+    m = (uint32_t)__builtin_bit_cast(unsigned short, m0) | ((uint32_t)__builtin_bit_cast(unsigned short, m1) << 16);
+    l = (uint32_t)__builtin_bit_cast(unsigned short, l0) | ((uint32_t)__builtin_bit_cast(unsigned short, l1) << 16);
+}
+
+__global__ __launch_bounds__(256) void k_db_scan_bf16x6(const float* __restrict__ db, int rows_alloc, const float* __restrict__ q,
+                                                        int nq, const int32_t* __restrict__ nvalid, float thr_low,
+                                                        Partial* __restrict__ partials) {
+    __shared__ uint4 s_a[2][3][GM * 2];                // [piece][row][k half] x 8 bf16
+    __shared__ uint4 s_b[2][3][GN * 2];
+    __shared__ Partial s_p[2][GN];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int m0 = blockIdx.x * GM, n0 = blockIdx.y * GN;
+    const int row = t >> 1, kk = (t & 1) * 8;
+    const bool a_ok = (m0 + row) < rows_alloc, b_ok = (n0 + row) < nq;
+    // unconditional loads from clamped rows + a select at store time keep the prefetch in registers
+    const float* arow = db + (size_t)(a_ok ? m0 + row : 0) * DIM + kk;
+    const float* brow = q + (size_t)(b_ok ? n0 + row : 0) * DIM + kk;
+    float4 ra0, ra1, rb0, rb1;
+    bool kv = true;
+#define DB_LOAD_STAGE(ST)                                                                  \
+    {                                                                                      \
+        const int k0_ = (ST) * GK;                                                         \
+        kv = (k0_ + kk) < DIM;                                                             \
+        const int ko_ = kv ? k0_ : 0;                                                      \
+        const float4* pa_ = reinterpret_cast<const float4*>(arow + ko_); ra0 = pa_[0]; ra1 = pa_[1]; \
+        const float4* pb_ = reinterpret_cast<const float4*>(brow + ko_); rb0 = pb_[0]; rb1 = pb_[1]; \
+    }
+    auto store_stage = [&](int buf) {
+        const float za = (a_ok && kv) ? 1.f : 0.f, zb = (b_ok && kv) ? 1.f : 0.f;
+        uint4 h, m, l;
+        db_split3(ra0.x * za, ra0.y * za, h.x, m.x, l.x); db_split3(ra0.z * za, ra0.w * za, h.y, m.y, l.y);
+        db_split3(ra1.x * za, ra1.y * za, h.z, m.z, l.z); db_split3(ra1.z * za, ra1.w * za, h.w, m.w, l.w);
+        s_a[buf][0][t] = h; s_a[buf][1][t] = m; s_a[buf][2][t] = l;
+        db_split3(rb0.x * zb, rb0.y * zb, h.x, m.x, l.x); db_split3(rb0.z * zb, rb0.w * zb, h.y, m.y, l.y);
+        db_split3(rb1.x * zb, rb1.y * zb, h.z, m.z, l.z); db_split3(rb1.z * zb, rb1.w * zb, h.w, m.w, l.w);
+        s_b[buf][0][t] = h; s_b[buf][1][t] = m; s_b[buf][2][t] = l;
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    constexpr int NST = (DIM + GK - 1) / GK;                     // 67
+    DB_LOAD_STAGE(0)
+    store_stage(0);
+    __syncthreads();
+    const int lr = lane & 31, lk = lane >> 5;
+    for (int st = 0; st < NST; st++) {
+        const int buf = st & 1;
+        if (st + 1 < NST) DB_LOAD_STAGE(st + 1)
+        db_bf16x8 A[2][3], B[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int p = 0; p < 3; p++) A[i][p] = __builtin_bit_cast(db_bf16x8, s_a[buf][p][(wm + 32 * i + lr) * 2 + lk]);
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int p = 0; p < 3; p++) B[j][p] = __builtin_bit_cast(db_bf16x8, s_b[buf][p][(wn + 32 * j + lr) * 2 + lk]);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][2], B[j][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], B[j][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][1], B[j][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][1], B[j][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], B[j][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], B[j][0], c, 0, 0, 0);
+                acc[i][j] = c;
+            }
+        if (st + 1 < NST) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+#undef DB_LOAD_STAGE
+    // epilogue: identical to k_db_scan_mfma
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int n = n0 + wn + j * 32 + lr;
+        const int nv = (n < nq) ? nvalid[n] : 0;
+        float bs = 0.f; int bi = -1, cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const float sc = acc[i][j][r];
+                if (m < nv) {
+                    if (better(sc, m, bs, bi)) { bs = sc; bi = m; }
+                    cnt += (sc > thr_low);
+                }
+            }
+        const float os = __shfl_xor(bs, 32, 64); const int oi = __shfl_xor(bi, 32, 64); const int oc = __shfl_xor(cnt, 32, 64);
+        if (oi >= 0 && better(os, oi, bs, bi)) { bs = os; bi = oi; }
+        cnt += oc;
+        if (lk == 0 && (wave >> 1) == 1) s_p[0][wn + j * 32 + lr] = {bs, bi, cnt};
+        __syncthreads();
+        if (lk == 0 && (wave >> 1) == 0) {
+            const Partial o = s_p[0][wn + j * 32 + lr];
+            if (o.idx >= 0 && better(o.score, o.idx, bs, bi)) { bs = o.score; bi = o.idx; }
+            cnt += o.cnt;
+            if (n < nq) partials[(size_t)blockIdx.x * nq + n] = {bs, bi, cnt};
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void k_db_reduce(const Partial* __restrict__ partials, int nblocks, int nq,
                                                    const uint64_t* __restrict__ ids, uint64_t* __restrict__ best_id,
                                                    float* __restrict__ max_score, int32_t* __restrict__ cnt) {
@@ -296,10 +418,15 @@ static int db_query(myslam_lcddb* h, const float* d_q, const uint64_t* cur_ids_h
     {
         ScopedProf sp(P_DBSCAN, h->stream);
         int nparts = nblocks;
-        if (nq >= 32) {           // batched: fp32 MFMA GEMM with the per-query reduction fused into the epilogue
+        if (nq >= 32) {           // batched: GEMM on the matrix cores with the per-query reduction fused into the epilogue
             nparts = std::max(1, (maxv + GM - 1) / GM);
-            hipLaunchKernelGGL(k_db_scan_mfma, dim3(nparts, (nq + GN - 1) / GN), dim3(256), 0, h->stream, h->d_db, h->capacity, d_q, nq,
-                               h->d_nvalid, thr_low, h->d_partials);
+            static const int f32mfma = [] { const char* e = getenv("MYSLAM_DBSCAN_V"); return e ? atoi(e) == 1 : 0; }();      // tuning aid: 1 = f32-input MFMA
+            if (f32mfma)
+                hipLaunchKernelGGL(k_db_scan_mfma, dim3(nparts, (nq + GN - 1) / GN), dim3(256), 0, h->stream, h->d_db, h->capacity, d_q, nq,
+                                   h->d_nvalid, thr_low, h->d_partials);
+            else
+                hipLaunchKernelGGL(k_db_scan_bf16x6, dim3(nparts, (nq + GN - 1) / GN), dim3(256), 0, h->stream, h->d_db, h->capacity, d_q, nq,
+                                   h->d_nvalid, thr_low, h->d_partials);
         } else {                  // a few queries: bandwidth-bound GEMV, one wave per database row
             const size_t lds = sizeof(Partial) * DB_WAVES * nq;
             hipLaunchKernelGGL(k_db_scan, dim3(nblocks), dim3(256), lds, h->stream, h->d_db, d_q, nq, h->d_nvalid, thr_low, h->d_partials);

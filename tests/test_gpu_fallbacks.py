@@ -30,6 +30,17 @@ wts = synth.calc_weights()
 d, _ = api.DeepLCD(wts).calcDescrOriginalImg(L, blur_in_place=False)
 x, _ = o.calc_preproc(L)
 assert np.abs(d - o.calc_forward(wts, x)).max() < 2e-5, "CALC differs"
+db = synth.lcd_database(300); ids = np.arange(300, dtype=np.uint64)
+D = api.LoopDatabase(300)
+for i in range(300):
+    D.AddToDatabase(i, db[i])
+import torch as _t
+qs = _t.from_numpy(db[:64].copy()).cuda(); cur = np.full(64, 400, np.uint64)
+d_best = _t.zeros(64, dtype=_t.int64, device="cuda"); d_max = _t.zeros(64, device="cuda"); d_cnt = _t.zeros(64, dtype=_t.int32, device="cuda")
+D.query_batch(qs.data_ptr(), cur, 64, d_best.data_ptr(), d_max.data_ptr(), d_cnt.data_ptr()); _t.cuda.synchronize()
+for k in range(64):
+    ref = o.lcddb_query(db, ids, db[k], 400)
+    assert int(d_best[k]) == ref[0] and abs(float(d_max[k]) - ref[1]) < 2e-5 and int(d_cnt[k]) == ref[2], "DB scan differs"
 rng = np.random.default_rng(5)
 for nq, nt in ((700, 1033), (33, 2), (2000, 1999)):
     q = rng.integers(0, 256, (nq, 32), dtype=np.uint8); t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
@@ -41,7 +52,7 @@ print("FALLBACK OK")
 
 
 @pytest.mark.parametrize("env", [
-    {"MYSLAM_FAST_V": "3", "MYSLAM_BLUR_V": "2", "MYSLAM_RESIZE_V": "1", "MYSLAM_DESC_V": "1", "MYSLAM_CONV1_V": "1", "MYSLAM_HAMMING_V": "1", "MYSLAM_ORB_AUX": "0", "MYSLAM_CONV2_V": "0", "MYSLAM_LCD_PRE_V": "1"},
+    {"MYSLAM_FAST_V": "3", "MYSLAM_BLUR_V": "2", "MYSLAM_RESIZE_V": "1", "MYSLAM_DESC_V": "1", "MYSLAM_CONV1_V": "1", "MYSLAM_HAMMING_V": "1", "MYSLAM_ORB_AUX": "0", "MYSLAM_CONV2_V": "0", "MYSLAM_LCD_PRE_V": "1", "MYSLAM_DBSCAN_V": "1"},
     {"MYSLAM_FAST_V": "2", "MYSLAM_BLUR_V": "1", "MYSLAM_ORB_AUX": "1"},
     {"MYSLAM_FAST_V": "2", "MYSLAM_FAST_T": "64", "MYSLAM_CONV2_V": "1"},
 ])
