@@ -19,7 +19,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno
 # float-derived integers (BRIEF coordinates, fastAtan2, resize tables) must not see FMA contraction
 EXACT = ["-ffp-contract=off"]
 UNITS = {
-    "orb_kernels.hip": EXACT,
+    "orb_kernels.hip": EXACT + ["-mllvm", "-amdgpu-mfma-vgpr-form"],
     "orb_engine.hip": EXACT,
     "match_tri.hip": EXACT + ["-mllvm", "-amdgpu-mfma-vgpr-form"],     # MFMA accumulators in VGPRs: the arg-max reads them directly
     "calc.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],

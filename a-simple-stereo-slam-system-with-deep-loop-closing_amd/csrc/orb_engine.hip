@@ -104,6 +104,8 @@ struct myslam_orb {
     int32_t *d_candCount = nullptr, *d_selCount = nullptr, *d_status = nullptr;
     uint32_t* d_sel = nullptr;
     uint32_t* d_octTab = nullptr;      // per-level oct-tree path-code / cell-index tables (see make_plan)
+    uint4* d_blurTab = nullptr;        // operand tables of the matrix-core Gaussian, per level (see make_plan)
+    size_t blurH[MAXL] = {0}, blurV[MAXL] = {0}, blurI = 0; bool blurOk[MAXL] = {false};
 
     // staging for the host-buffer entry points
     uint8_t *d_stageImg = nullptr, *d_stageMask = nullptr; size_t stageImgBytes = 0, stageMaskBytes = 0;
@@ -225,6 +227,18 @@ int myslam_orb::make_plan(int r, int c) {
         if (rc) return rc;
         MYSLAM_HIP_CHECK(hipMemcpy(d_octTab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
+    static const bool want_mfma_blur = [] { const char* e = getenv("MYSLAM_BLUR_V"); return e && atoi(e) == 4; }();
+    for (int l = 0; l < nlevels; l++) blurOk[l] = false;
+    if (want_mfma_blur) {   // operand tables of k_blur7_mfma for every level (sigma = 2 taps); experimental kernel, see orb_kernels.hip
+        std::vector<uint4> bt;
+        int q[7];
+        gauss_q8(0, q);
+        blur_mfma_ident(bt, blurI);
+        for (int l = 0; l < nlevels; l++) blurOk[l] = blur_mfma_tables(P.lv[l].w, P.lv[l].h, P.lv[l].pitch, q, bt, blurH[l], blurV[l]);
+        if (d_blurTab) { (void)hipFree(d_blurTab); d_blurTab = nullptr; }
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&d_blurTab, bt.size() * sizeof(uint4)));
+        MYSLAM_HIP_CHECK(hipMemcpy(d_blurTab, bt.data(), bt.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    }
     full = P;
     // Detect(): level 0 only, budget = nfeatures (ORBextractor.cpp:1064-1065)
     det = P;
@@ -298,6 +312,7 @@ int myslam_orb::blur_levels(int batch, int nlev, hipStream_t stream) {
         a.src = d_pyr + P.lv[l].imgOff; a.dst = d_blur + P.lv[l].imgOff;
         a.w = P.lv[l].w; a.h = P.lv[l].h; a.spitch = a.dpitch = P.lv[l].pitch; a.sstride = a.dstride = P.pyrBytes;
         gauss_q8(0, a.q);
+        if (blurOk[l]) { a.tabH = d_blurTab + blurH[l]; a.tabV = d_blurTab + blurV[l]; a.ident = d_blurTab + blurI; }
         launch_blur(a, batch, stream);
     }
     return MYSLAM_OK;
@@ -376,7 +391,7 @@ int myslam_orb::ensure_stage(size_t imgBytes, size_t maskBytes, int cap) {
 }
 
 void myslam_orb::free_all() {
-    void* ptrs[] = {d_octTab, d_pyr, d_blur, d_mask, d_cand, d_sort, d_candCount, d_selCount, d_status, d_sel, d_stageImg, d_stageMask,
+    void* ptrs[] = {d_blurTab, d_octTab, d_pyr, d_blur, d_mask, d_cand, d_sort, d_candCount, d_selCount, d_status, d_sel, d_stageImg, d_stageMask,
                     d_stageKps, d_stageKps2, d_stageDesc, d_stageKeep, d_stageCounts};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); (void)hipEventDestroy(evFork); (void)hipEventDestroy(evJoin); aux = nullptr; }
