@@ -1,0 +1,38 @@
+"""bench.py prints exactly one JSON line with the driver's contract fields, the roofline and the CPU-baseline objects (small run)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("extra", [["--cpu-pairs", "2"], ["--no-cpu-baseline", "--workload", "orb_match", "--streams", "1"]])
+def test_bench_json_contract(extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--pairs", "16"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and d["value"] > 0
+    assert abs(d["value"] - 16 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    roof = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in roof, k
+    assert roof["bound"] in ("hbm", "mfma") and roof["peak"] > 0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    if "--no-cpu-baseline" in extra:
+        assert d["cpu_baseline"] is None
+    else:
+        cb = d["cpu_baseline"]
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in cb, k
+        assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1
