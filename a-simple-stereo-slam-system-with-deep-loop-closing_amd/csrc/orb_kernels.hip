@@ -2182,9 +2182,10 @@ void launch_resize(const ResizeArgs& a, int batch, hipStream_t s) {
 //                        per register group: dword stores.
 // 9 MFMAs (288 cycles) and ~160 VALU instructions per 1024 pixels against ~420 VALU instructions in k_blur7_strip; all coefficient
 // logic (bands, mirrored borders, partial tiles) lives in host-built operand tables, the kernel has no special cases.
-// STATUS: bit-exact, but NOT the default (MYSLAM_BLUR_V=4 selects it): a wave's loads and stores touch 32 rows x 32 bytes, and that
-// row-strided pattern — not the arithmetic — bounds it (1.2 ms per 512 pairs against 0.92 ms for the strip kernel; waves spend 55 %
-// of their cycles waiting on memory with the prefetch three tiles ahead).  The next step would be staging 256-column bands through LDS.
+// STATUS: bit-exact, but NOT the default (MYSLAM_BLUR_V=4 selects it): with the band staged through LDS it merely EQUALS the strip
+// kernel (0.92 ms per 512 pairs; 1.2 ms with per-wave 32-byte row accesses): the waves spend 58 % of their cycles waiting — two
+// barriers per tile row and a serial MFMA -> pack -> MFMA -> pack -> MFMA chain inside every wave — so the saved VALU work (160
+// against 420 instructions per 1024 pixels) does not show up as time yet.
 typedef int bl_v4i __attribute__((ext_vector_type(4)));
 typedef int bl_v16i __attribute__((ext_vector_type(16)));
 
@@ -2194,29 +2195,46 @@ __device__ __forceinline__ uint32_t bl_pack_byte(int r0, int r1, int r2, int r3,
     return __builtin_amdgcn_perm(t23, t01, 0x05040100u);
 }
 
+constexpr int BLM_INP = 176;          // LDS pitch of a staged input row: 160 window bytes + 16 (bank spread)
+constexpr int BLM_OUTP = 144;         // LDS pitch of an output row: 128 + 16
+
+// Block = 4 waves = a band of four adjacent 32-column strips walked downwards together: the 32 x 160-byte window of a tile row is
+// fetched once by the whole block with full-width coalesced loads into LDS (double buffered, requested one tile row ahead), the waves
+// read their A operands from there, and the finished 32 x 128 tile row goes back through LDS so that rows are stored 128 bytes wide.
 __global__ __launch_bounds__(256) void k_blur7_mfma(BlurArgs a, int nstrip, int ntile) {
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    if (wid >= nstrip) return;
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[2][32 * BLM_INP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[32 * BLM_OUTP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wid = blockIdx.x * 4 + wave;                     // strip of this wave
+    const bool live = wid < nstrip;
     const int b = blockIdx.z;
+    const int bx0 = 128 * blockIdx.x, bws = min(max(bx0 - 16, 0), a.spitch - 160);
     const int x0 = 32 * wid, ws = min(max(x0 - 16, 0), a.spitch - 64);
+    const int woff = live ? ws - bws : 0;                      // this strip's 64-column window inside the band window (0..96)
     const uint8_t* src = a.src + (size_t)b * a.sstride;
     uint8_t* dst = a.dst + (size_t)b * a.dstride;
     const int li = lane & 31, lh = lane >> 5;
-    const bl_v4i TH0 = __builtin_bit_cast(bl_v4i, a.tabH[(size_t)(wid * 2 + 0) * 64 + lane]);
-    const bl_v4i TH1 = __builtin_bit_cast(bl_v4i, a.tabH[(size_t)(wid * 2 + 1) * 64 + lane]);
+    const int sidx = live ? wid : 0;
+    const bl_v4i TH0 = __builtin_bit_cast(bl_v4i, a.tabH[(size_t)(sidx * 2 + 0) * 64 + lane]);
+    const bl_v4i TH1 = __builtin_bit_cast(bl_v4i, a.tabH[(size_t)(sidx * 2 + 1) * 64 + lane]);
     const bl_v4i ID = __builtin_bit_cast(bl_v4i, a.ident[lane]);
     const bl_v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const bl_v4i zero4 = {0, 0, 0, 0};
-    // Pixels and Tv blocks are requested one tile ahead of their use (every stage of a tile depends on the previous one, so the
-    // memory latency would otherwise be paid once per tile).
-    auto load_px = [&](int ty, uint4& p0, uint4& p1) {
-        const int y = min(32 * ty + li, a.h - 1);
-        const uint8_t* row = src + (size_t)y * a.spitch + ws + 16 * lh;
-        p0 = *reinterpret_cast<const uint4*>(row); p1 = *reinterpret_cast<const uint4*>(row + 32);
+    // staging roles: 32 rows x 10 uint4 = 320 pieces; thread tid takes piece tid and (tid < 64) piece 256 + tid
+    const int r1 = tid / 10, c1 = tid - 10 * r1, r2 = (256 + tid) / 10, c2 = (256 + tid) - 10 * r2;
+    uint4 g1 = make_uint4(0, 0, 0, 0), g2 = g1;
+    auto stage_load = [&](int ty) {
+        g1 = *reinterpret_cast<const uint4*>(src + (size_t)min(32 * ty + r1, a.h - 1) * a.spitch + bws + 16 * c1);
+        if (tid < 64) g2 = *reinterpret_cast<const uint4*>(src + (size_t)min(32 * ty + r2, a.h - 1) * a.spitch + bws + 16 * c2);
     };
-    // H tile as the two int8 planes (hi = H >> 8, lo = (H & 255) - 128), k slot b of a lane <-> tile row (b&3) + 8(b>>2) + 4 lh
-    auto htile = [&](uint4 p0, uint4 p1, bl_v4i& hi, bl_v4i& lo) {
+    auto stage_store = [&](int buf) {
+        *reinterpret_cast<uint4*>(&s_in[buf][r1 * BLM_INP + 16 * c1]) = g1;
+        if (tid < 64) *reinterpret_cast<uint4*>(&s_in[buf][r2 * BLM_INP + 16 * c2]) = g2;
+    };
+    // H tile from the staged window as the two int8 planes (hi = H >> 8, lo = (H & 255) - 128)
+    auto htile = [&](int buf, bl_v4i& hi, bl_v4i& lo) {
+        const uint8_t* row = &s_in[buf][li * BLM_INP + woff + 16 * lh];
+        uint4 p0 = *reinterpret_cast<const uint4*>(row), p1 = *reinterpret_cast<const uint4*>(row + 32);
         p0.x ^= 0x80808080u; p0.y ^= 0x80808080u; p0.z ^= 0x80808080u; p0.w ^= 0x80808080u;
         p1.x ^= 0x80808080u; p1.y ^= 0x80808080u; p1.z ^= 0x80808080u; p1.w ^= 0x80808080u;
         bl_v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(bl_v4i, p0), TH0, zero16, 0, 0, 0);
@@ -2229,18 +2247,25 @@ __global__ __launch_bounds__(256) void k_blur7_mfma(BlurArgs a, int nstrip, int 
     };
     bl_v4i Hh[3], Hl[3];                                       // tiles ty-1, ty, ty+1
     Hh[0] = zero4; Hl[0] = zero4;
-    // Pixel registers: three sets, set k holds a tile with index = k (mod 3).  Tile t+1 is consumed in step t and its set is refilled
-    // with tile t+4 right away, so a load has three steps to arrive.  The sets are addressed statically (the main loop is unrolled
-    // by three): rotating them through register copies would make every copy wait for its load.
-    uint4 P0a, P0b, P1a, P1b, P2a, P2b;
-    load_px(0, P0a, P0b);
-    load_px(min(1, ntile - 1), P1a, P1b);
-    load_px(min(2, ntile - 1), P2a, P2b);
-    htile(P0a, P0b, Hh[1], Hl[1]);
-    load_px(min(3, ntile - 1), P0a, P0b);
-    auto do_tile = [&](int ty, uint4& pa, uint4& pb, uint4 t0, uint4 t1, uint4 t2) {     // (pa, pb) = the set of tile ty + 1
-        if (ty + 1 < ntile) htile(pa, pb, Hh[2], Hl[2]); else { Hh[2] = zero4; Hl[2] = zero4; }
-        if (ty + 4 < ntile) load_px(ty + 4, pa, pb);
+    stage_load(0);
+    stage_store(0);
+    if (ntile > 1) stage_load(1);
+    __syncthreads();
+    htile(0, Hh[1], Hl[1]);
+    if (ntile > 1) stage_store(1);
+    // Tv blocks: the interior tiles share one set (registers); the first tile and the last two read theirs from the table
+    int tlast = ntile;
+    while (tlast > 1 && 32 * (tlast - 1) + 34 >= a.h) tlast--;
+    uint4 iv0 = make_uint4(0, 0, 0, 0), iv1 = iv0, iv2 = iv0;
+    if (tlast > 1) { iv0 = a.tabV[(size_t)(3 + 0) * 64 + lane]; iv1 = a.tabV[(size_t)(3 + 1) * 64 + lane]; iv2 = a.tabV[(size_t)(3 + 2) * 64 + lane]; }
+    for (int ty = 0; ty < ntile; ty++) {
+        uint4 t0 = iv0, t1 = iv1, t2 = iv2;
+        if (!(ty >= 1 && ty < tlast)) {
+            t0 = a.tabV[(size_t)(ty * 3 + 0) * 64 + lane]; t1 = a.tabV[(size_t)(ty * 3 + 1) * 64 + lane]; t2 = a.tabV[(size_t)(ty * 3 + 2) * 64 + lane];
+        }
+        if (ty + 2 < ntile) stage_load(ty + 2);               // lands in s_in[ty & 1] at the end of this step
+        __syncthreads();                                       // s_in[(ty + 1) & 1] complete; s_out free again
+        if (ty + 1 < ntile) htile((ty + 1) & 1, Hh[2], Hl[2]); else { Hh[2] = zero4; Hl[2] = zero4; }
         bl_v16i sh = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(bl_v4i, t0), Hh[0], zero16, 0, 0, 0);
         bl_v16i sl = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(bl_v4i, t0), Hl[0], zero16, 0, 0, 0);
         sh = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(bl_v4i, t1), Hh[1], sh, 0, 0, 0);
@@ -2257,41 +2282,20 @@ __global__ __launch_bounds__(256) void k_blur7_mfma(BlurArgs a, int nstrip, int 
             A3[w] = (int)(bl_pack_byte(v[0], v[1], v[2], v[3], 2) ^ 0x80808080u);
         }
         const bl_v16i T = __builtin_amdgcn_mfma_i32_32x32x32_i8(A3, ID, zero16, 0, 0, 0);      // lane (row li, half lh): x = (r&3) + 8(r>>2) + 4 lh
-        // the two half-waves hold interleaved 4-pixel groups of the same row: swap two dwords so that each lane owns 16 contiguous
-        // pixels (half 0: x 0..15, half 1: x 16..31) and stores them as one uint4
-        uint32_t d[4];
+        // lane (row li, half lh) holds the 4-pixel groups g at x = 8 g + 4 lh of its strip: into the output row in LDS
 #pragma unroll
-        for (int g = 0; g < 4; g++) d[g] = bl_pack_byte(T[4 * g], T[4 * g + 1], T[4 * g + 2], T[4 * g + 3], 0) ^ 0x80808080u;
-        const uint32_t r0 = (uint32_t)__shfl_xor((int)(lh ? d[0] : d[2]), 32, 64), r1 = (uint32_t)__shfl_xor((int)(lh ? d[1] : d[3]), 32, 64);
-        const uint4 o = lh ? make_uint4(r0, d[2], r1, d[3]) : make_uint4(d[0], r0, d[1], r1);
-        const int y = 32 * ty + li;
-        if (y < a.h) *reinterpret_cast<uint4*>(dst + (size_t)y * a.dpitch + x0 + 16 * lh) = o;
-        Hh[0] = Hh[1]; Hl[0] = Hl[1]; Hh[1] = Hh[2]; Hl[1] = Hl[2];
-    };
-    auto tv = [&](int ty, int o) { return a.tabV[(size_t)(ty * 3 + o) * 64 + lane]; };
-    auto do_tile_any = [&](int ty, uint4 t0, uint4 t1, uint4 t2) {          // set of tile ty + 1 chosen at run time (wave-uniform)
-        const int k = (ty + 1) % 3;
-        if (k == 0) do_tile(ty, P0a, P0b, t0, t1, t2); else if (k == 1) do_tile(ty, P1a, P1b, t0, t1, t2); else do_tile(ty, P2a, P2b, t0, t1, t2);
-    };
-    // Tv blocks: every tile whose 7-row windows stay inside the image uses the same three blocks; they stay in registers for the main
-    // loop, which therefore issues nothing but the pixel prefetch.  The first tile and the last two read theirs from the table.
-    int tlast = ntile;                                         // interior tiles are [1, tlast)
-    while (tlast > 1 && 32 * (tlast - 1) + 34 >= a.h) tlast--;
-    do_tile(0, P1a, P1b, tv(0, 0), tv(0, 1), tv(0, 2));
-    int ty = 1;
-    if (tlast > 1) {
-        const uint4 iv0 = tv(1, 0), iv1 = tv(1, 1), iv2 = tv(1, 2);
-        // a register use before the loop: the wait for these three loads lands here, not (as vmcnt(0)) in front of the loop's first MFMA
-        asm volatile("" ::"v"(iv0.x), "v"(iv0.y), "v"(iv0.z), "v"(iv0.w), "v"(iv1.x), "v"(iv1.y), "v"(iv1.z), "v"(iv1.w), "v"(iv2.x), "v"(iv2.y),
-                     "v"(iv2.z), "v"(iv2.w));
-        for (; ty + 3 <= tlast; ty += 3) {                     // ty = 1 (mod 3): tiles ty+1, ty+2, ty+3 live in sets 2, 0, 1
-            do_tile(ty, P2a, P2b, iv0, iv1, iv2);
-            do_tile(ty + 1, P0a, P0b, iv0, iv1, iv2);
-            do_tile(ty + 2, P1a, P1b, iv0, iv1, iv2);
+        for (int g = 0; g < 4; g++)
+            *reinterpret_cast<uint32_t*>(&s_out[li * BLM_OUTP + 32 * wave + 8 * g + 4 * lh]) =
+                bl_pack_byte(T[4 * g], T[4 * g + 1], T[4 * g + 2], T[4 * g + 3], 0) ^ 0x80808080u;
+        if (ty + 2 < ntile) stage_store(ty & 1);               // s_in[ty & 1] was read in the previous step (htile of tile ty)
+        __syncthreads();                                       // s_out complete
+        {   // 32 rows x 128 bytes, 8 threads per row
+            const int r = tid >> 3, c = tid & 7, y = 32 * ty + r;
+            if (y < a.h && bx0 + 16 * c + 16 <= a.dpitch)
+                *reinterpret_cast<uint4*>(dst + (size_t)y * a.dpitch + bx0 + 16 * c) = *reinterpret_cast<const uint4*>(&s_out[r * BLM_OUTP + 16 * c]);
         }
-        for (; ty < tlast; ty++) do_tile_any(ty, iv0, iv1, iv2);
+        Hh[0] = Hh[1]; Hl[0] = Hl[1]; Hh[1] = Hh[2]; Hl[1] = Hl[2];
     }
-    for (; ty < ntile; ty++) do_tile_any(ty, tv(ty, 0), tv(ty, 1), tv(ty, 2));
 }
 
 // ---- host: operand tables of k_blur7_mfma ----
@@ -2361,8 +2365,10 @@ void launch_blur(const BlurArgs& a, int batch, hipStream_t s) {
     if (a.tabH && a.tabV && a.ident && env && atoi(env) == 4 && (a.spitch & 15) == 0 && (a.dpitch & 15) == 0 &&
         ((reinterpret_cast<uintptr_t>(a.src) | a.sstride) & 15) == 0 && ((reinterpret_cast<uintptr_t>(a.dst) | a.dstride) & 15) == 0) {
         const int nstrip = (a.w + 31) / 32, ntile = (a.h + 31) / 32;
-        hipLaunchKernelGGL(k_blur7_mfma, dim3((nstrip + 3) / 4, 1, batch), dim3(256), 0, s, a, nstrip, ntile);
-        return;
+        if (a.spitch >= 160) {
+            hipLaunchKernelGGL(k_blur7_mfma, dim3((nstrip + 3) / 4, 1, batch), dim3(256), 0, s, a, nstrip, ntile);
+            return;
+        }
     }
     const int v = (env && atoi(env) != 4) ? atoi(env) : 3;
     if (small && v == 3 && a.w >= 8 && (a.spitch & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.src) | a.sstride) & 3) == 0) {
