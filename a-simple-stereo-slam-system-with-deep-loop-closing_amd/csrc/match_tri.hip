@@ -194,10 +194,114 @@ __global__ __launch_bounds__(256) void k_hamming_mfma(const uint8_t* __restrict_
     }
 }
 
-static inline bool hamming_use_mfma() {
-    static const int v = [] { const char* e = getenv("MYSLAM_HAMMING_V"); return e ? atoi(e) : 2; }();
-    return v != 1;
+// The same product on the FP4 path of the matrix cores (v_mfma_scale_f32_32x32x64_f8f6f4, K = 64 per instruction, twice the int8
+// rate): E2M1 represents +-1 exactly (0x2 / 0xA), the factor 32 of the query operand is its E8M0 block scale (2^5), sums of at most
+// 256 terms of +-32 plus the (31 - row) start value are exact in f32.  One descriptor dword (32 bits) expands to the 16 operand bytes
+// of a lane; 4 MFMAs per 32 x 32 tile instead of 8, 16 query registers per tile instead of 32, 4 KB of LDS per train chunk.
+typedef int hq_v8i __attribute__((ext_vector_type(8)));
+typedef float hq_v16f __attribute__((ext_vector_type(16)));
+constexpr int HF_ROWB = 144;                      // LDS bytes per expanded train row (128 + 16)
+
+__global__ __launch_bounds__(256) void k_hamming_fp4(const uint8_t* __restrict__ q, const int32_t* __restrict__ nqv,
+                                                     const uint8_t* __restrict__ tr, const int32_t* __restrict__ ntv,
+                                                     int cap, int nq_single, int nt_single,
+                                                     int32_t* __restrict__ out_idx, int32_t* __restrict__ out_dist) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_exp[2][32 * HF_ROWB];
+    __shared__ uint32_t s_lut[256];                // byte -> 8 FP4 codes (bit i -> nibble i): bit 1 -> -1.0 (0xA), bit 0 -> +1.0 (0x2)
+    const int p = blockIdx.y;
+    const int nq = nqv ? min(nqv[p], cap) : nq_single;
+    const int nt = ntv ? min(ntv[p], cap) : nt_single;
+    const int q0 = blockIdx.x * HQ_BLOCK;
+    if (q0 >= nq) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    {
+        uint32_t v = 0;
+        for (int i = 0; i < 8; i++) v |= (((tid >> i) & 1) ? 0xAu : 0x2u) << (4 * i);
+        s_lut[tid] = v;
+    }
+    __syncthreads();
+    const uint32_t* Q = reinterpret_cast<const uint32_t*>(q + (size_t)p * cap * 32);
+    const uint32_t* T = reinterpret_cast<const uint32_t*>(tr + (size_t)p * cap * 32);
+    auto expand32 = [&](uint32_t w) { return make_uint4(s_lut[w & 0xff], s_lut[(w >> 8) & 0xff], s_lut[(w >> 16) & 0xff], s_lut[w >> 24]); };
+    // query operands: k block m of tile t takes descriptor dword 2 m + (lane >> 5) of query qb + 32 t + (lane & 31)
+    const int qb = q0 + wv * (HQ_TILES * 32);
+    hq_v8i B[HQ_TILES][4];
+#pragma unroll
+    for (int t = 0; t < HQ_TILES; t++) {
+        const int qi = qb + 32 * t + (lane & 31);
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const uint4 e = expand32((qi < nq) ? Q[(size_t)qi * 8 + 2 * m + (lane >> 5)] : 0u);
+            B[t][m] = hq_v8i{(int)e.x, (int)e.y, (int)e.z, (int)e.w, 0, 0, 0, 0};
+        }
+    }
+    const int rbase = 4 * (lane >> 5);                       // row of accumulator register r: (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    hq_v16f cinit, ctail;
+    const int last0 = ((nt - 1) >> 5) << 5;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        cinit[r] = (float)(31 - row);
+        ctail[r] = (last0 + row < nt) ? (float)(31 - row) : -16777216.f;
+    }
+    int bestv[HQ_TILES], bestor[HQ_TILES], bestc[HQ_TILES];
+#pragma unroll
+    for (int t = 0; t < HQ_TILES; t++) { bestv[t] = -(1 << 30); bestor[t] = -(1 << 30); bestc[t] = 0; }
+    const int er = tid >> 3, ed = tid & 7;                   // expansion job: dword ed of chunk row er
+    auto expand = [&](int buf, uint32_t w) { *reinterpret_cast<uint4*>(&s_exp[buf][er * HF_ROWB + ed * 16]) = expand32(w); };
+    const int nchunk = (nt + 31) >> 5;
+    uint32_t wnext = (er < nt) ? T[(size_t)er * 8 + ed] : 0u;
+    if (nchunk > 0) expand(0, wnext);
+    for (int c = 0; c < nchunk; c++) {
+        const int t0 = c << 5;
+        if (c + 1 < nchunk) { const int row = t0 + 32 + er; wnext = (row < nt) ? T[(size_t)row * 8 + ed] : 0u; }
+        __syncthreads();
+        if (c + 1 < nchunk) expand((c + 1) & 1, wnext);
+        const uint8_t* sb = &s_exp[c & 1][(lane & 31) * HF_ROWB + (lane >> 5) * 16];
+        hq_v8i A[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const uint4 e = *reinterpret_cast<const uint4*>(sb + m * 32);
+            A[m] = hq_v8i{(int)e.x, (int)e.y, (int)e.z, (int)e.w, 0, 0, 0, 0};
+        }
+        const hq_v16f c0 = (c + 1 == nchunk) ? ctail : cinit;
+#pragma unroll
+        for (int t = 0; t < HQ_TILES; t++) {
+            // A: FP4, scale 2^0 (E8M0 127); B: FP4, scale 2^5 (132)
+            hq_v16f acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[0], B[t][0], c0, 4, 4, 0, 127, 0, 132);
+#pragma unroll
+            for (int m = 1; m < 4; m++) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[m], B[t][m], acc, 4, 4, 0, 127, 0, 132);
+            float vf = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) vf = fmaxf(fmaxf(vf, acc[r]), acc[r + 1]);
+            vf = fmaxf(vf, acc[15]);
+            const int v = (int)vf;
+            const bool better = v > bestor[t];
+            bestv[t] = better ? v : bestv[t];
+            bestor[t] = better ? (v | 31) : bestor[t];
+            bestc[t] = better ? c : bestc[t];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < HQ_TILES; t++) {
+        const int dot = bestv[t] >> 5, row = 31 - (bestv[t] & 31);
+        const uint32_t key = bestv[t] < -(1 << 20) ? 0u
+                                                     : ((uint32_t)(dot + 256) << 20) | (0xfffffu - (uint32_t)(bestc[t] * 32 + row));
+        const uint32_t b = max(key, (uint32_t)__shfl_xor((int)key, 32, 64));
+        const int qi = qb + 32 * t + lane;
+        if (lane < 32 && qi < nq) {
+            const bool any = nt > 0;
+            out_idx[(size_t)p * cap + qi] = any ? (int32_t)(0xfffffu - (b & 0xfffffu)) : -1;
+            out_dist[(size_t)p * cap + qi] = any ? (int32_t)((512u - (b >> 20)) >> 1) : -1;
+        }
+    }
 }
+
+static inline int hamming_variant() {         // 1: xor / popcount (VALU), 2: int8 MFMA, 3: FP4 MFMA
+    static const int v = [] { const char* e = getenv("MYSLAM_HAMMING_V"); return e ? atoi(e) : 3; }();
+    return v;
+}
+static inline bool hamming_use_mfma() { return hamming_variant() != 1; }
 
 // ------------------------------------------------------------------------------------------------
 // one-sided Jacobi SVD of the 4x4 DLT matrix (f64), fully unrolled pair loop (no runtime register indexing)
@@ -299,7 +403,10 @@ int myslam_hamming_match_batch(const uint8_t* d_q, const int32_t* d_nq, const ui
     if (cap >= (1 << 20)) return MYSLAM_ERR_UNSUPPORTED;          // the running minimum packs (distance, train index) into 32 bits
     hipStream_t s = (hipStream_t)hip_stream;
     ScopedProf sp(P_MATCH, s);
-    if (hamming_use_mfma())
+    if (hamming_variant() == 3)
+        hipLaunchKernelGGL(k_hamming_fp4, dim3((cap + HQ_BLOCK - 1) / HQ_BLOCK, batch), dim3(256), 0, s, d_q, d_nq, d_t, d_nt, cap, 0, 0,
+                           d_train_idx, d_dist);
+    else if (hamming_use_mfma())
         hipLaunchKernelGGL(k_hamming_mfma, dim3((cap + HQ_BLOCK - 1) / HQ_BLOCK, batch), dim3(256), 0, s, d_q, d_nq, d_t, d_nt, cap, 0, 0,
                            d_train_idx, d_dist);
     else
@@ -324,7 +431,10 @@ int myslam_hamming_match(const uint8_t* query, int nq, const uint8_t* train, int
     if (nt) MYSLAM_HIP_CHECK(hipMemcpy(dt, train, (size_t)nt * 32, hipMemcpyHostToDevice));
     {
         ScopedProf sp(P_MATCH, nullptr);
-        if (hamming_use_mfma())
+        if (hamming_variant() == 3)
+            hipLaunchKernelGGL(k_hamming_fp4, dim3((nq + HQ_BLOCK - 1) / HQ_BLOCK, 1), dim3(256), 0, nullptr, dq, (const int32_t*)nullptr, dt,
+                               (const int32_t*)nullptr, cap, nq, nt, di, dd);
+        else if (hamming_use_mfma())
             hipLaunchKernelGGL(k_hamming_mfma, dim3((nq + HQ_BLOCK - 1) / HQ_BLOCK, 1), dim3(256), 0, nullptr, dq, (const int32_t*)nullptr, dt,
                                (const int32_t*)nullptr, cap, nq, nt, di, dd);
         else

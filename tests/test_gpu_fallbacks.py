@@ -1,5 +1,5 @@
 """The alternative kernels kept behind developer switches (one cell per block FAST, LDS-tile blur, one-row resize, one wave per
-key-point describe, unfused conv1, f32-input MFMA conv2 tilings, two-pass DeepLCD input, xor / popcount Hamming; and the experimental int8 matrix-core Gaussian) must stay bit-compatible with the default path: run the extractor + CALC against the oracle in
+key-point describe, unfused conv1, f32-input MFMA conv2 tilings, two-pass DeepLCD input, xor / popcount and int8 matrix-core Hamming; and the experimental int8 matrix-core Gaussian) must stay bit-compatible with the default path: run the extractor + CALC against the oracle in
 child processes with the switches set (they are read once per process)."""
 import os
 import subprocess
@@ -53,7 +53,7 @@ print("FALLBACK OK")
 
 @pytest.mark.parametrize("env", [
     {"MYSLAM_FAST_V": "3", "MYSLAM_BLUR_V": "2", "MYSLAM_RESIZE_V": "1", "MYSLAM_DESC_V": "1", "MYSLAM_CONV1_V": "1", "MYSLAM_HAMMING_V": "1", "MYSLAM_ORB_AUX": "0", "MYSLAM_CONV2_V": "0", "MYSLAM_LCD_PRE_V": "1", "MYSLAM_DBSCAN_V": "1"},
-    {"MYSLAM_FAST_V": "2", "MYSLAM_BLUR_V": "1", "MYSLAM_ORB_AUX": "1"},
+    {"MYSLAM_FAST_V": "2", "MYSLAM_BLUR_V": "1", "MYSLAM_ORB_AUX": "1", "MYSLAM_HAMMING_V": "2"},
     {"MYSLAM_FAST_V": "2", "MYSLAM_FAST_T": "64", "MYSLAM_CONV2_V": "1"},
     {"MYSLAM_BLUR_V": "4"},
 ])
