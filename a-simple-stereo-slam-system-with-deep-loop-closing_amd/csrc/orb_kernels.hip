@@ -1347,17 +1347,35 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
     // ---- A: path codes + bucket histogram (LDS atomics) ----
     for (int i = t; i < NB; i += OT) s_cursor[i] = 0;
     __syncthreads();
+    // The low word of a sort entry is what phase D maximises per node.  With at most 1024 grid cells it is the complete selection
+    // key of the reference (:795-804: largest response, then first in the cell-major / row-major candidate order):
+    //     response << 22 | (0x3FFFFF - (cell << 12 | row in cell << 6 | column in cell))        (cells are at most 59 x 59)
+    // so phase D is ONE 32-bit maximum per node and the winner's pixel is decoded from the key; otherwise the entry keeps the FAST
+    // payload and phase D resolves the order with the cell tables in a second pass.
+    const bool rankkey = g.nCols * g.nRows <= 1024;
+    const float inv_ncols = 1.0f / (float)g.nCols;
     for (int i0 = t; i0 < n; i0 += 4 * OT) {                       // 4 keys in flight per thread: the pass is latency-bound
-        uint32_t pay[4], cx[4], cy[4];
+        uint32_t pay[4], cx[4], cy[4], qx[4], qy[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) pay[u] = (i0 + u * OT < n) ? keys[i0 + u * OT] : 0u;
 #pragma unroll
-        for (int u = 0; u < 4; u++) { cx[u] = xcode[(pay[u] >> 8) & 0xfff]; cy[u] = ycode[pay[u] >> 20]; }
+        for (int u = 0; u < 4; u++) {
+            const uint32_t px = (pay[u] >> 8) & 0xfff, py = pay[u] >> 20;
+            cx[u] = xcode[px]; cy[u] = ycode[py];
+            qx[u] = rankkey ? xcell[px] : 0u; qy[u] = rankkey ? ycell[py] : 0u;
+        }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             if (i0 + u * OT >= n) continue;
             const uint32_t code = cx[u] | cy[u];                    // == oct_code(px, py, g), tabulated per axis at plan time
-            bufA[i0 + u * OT] = ((uint64_t)code << 32) | pay[u];
+            uint32_t low = pay[u];
+            if (rankkey) {
+                const int px = (int)((pay[u] >> 8) & 0xfff), py = (int)(pay[u] >> 20);
+                const int ci = (int)(((float)qy[u] + 0.5f) * inv_ncols);                  // ycell = ci * nCols (exact: < 2^11)
+                const uint32_t pxc = (uint32_t)(px - 3 - (int)qx[u] * g.wCell), pyc = (uint32_t)(py - 3 - ci * g.hCell);
+                low = ((pay[u] & 0xffu) << 22) | (0x3fffffu - (((qy[u] + qx[u]) << 12) | (pyc << 6) | pxc));
+            }
+            bufA[i0 + u * OT] = ((uint64_t)code << 32) | low;
             atomicAdd(&s_cursor[code >> bsh], 1u);
         }
     }
@@ -1615,6 +1633,20 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
         for (int p0 = (t >> 4); p0 < ((mm + OT / 16 - 1) / (OT / 16)) * (OT / 16); p0 += OT / 16) {
             const bool live = p0 < mm;
             const int lo = live ? (int)L.lo(cur)[p0] : 0, hi = live ? (int)L.hi(cur)[p0] : 0;
+            if (rankkey) {                                               // block-uniform
+                uint32_t bk = 0;
+#pragma unroll 4
+                for (int i = lo + sub; i < hi; i += 16) bk = max(bk, (uint32_t)S[i]);
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) bk = max(bk, (uint32_t)__shfl_xor((int)bk, o, 64));
+                if (live && sub == 0) {
+                    const uint32_t rank = 0x3fffffu - (bk & 0x3fffffu), cell = rank >> 12;
+                    const int ci = (int)(((float)cell + 0.5f) * inv_ncols), cj = (int)cell - ci * g.nCols;
+                    const uint32_t px = (rank & 63u) + 3u + (uint32_t)(cj * g.wCell), py = ((rank >> 6) & 63u) + 3u + (uint32_t)(ci * g.hCell);
+                    out[p0] = (py << 20) | (px << 8) | (bk >> 22);
+                }
+                continue;
+            }
             uint32_t best = 0;
 #pragma unroll 2
             for (int i = lo + sub; i < hi; i += 16) best = max(best, (uint32_t)S[i] & 0xffu);

@@ -278,3 +278,12 @@ def test_wide_image_small_budget_capacity(api, oracle, synth):
     with pytest.raises(api.MyslamError) as e:                 # an undersized caller buffer is refused, never truncated
         ext.DetectAndCompute(img, cap=len(rk) - 1)
     assert e.value.code == api.ERR_CAPACITY
+
+
+def test_large_image_many_cells(api, oracle, synth):
+    """1500 x 1200: level 0 has more than 1024 FAST grid cells, so the oct-tree's best-key phase cannot pack the candidate order
+    into the sort entry and takes its two-pass form (k_octree, phase D)."""
+    img = synth.random_image(77, 1200, 1500)
+    gk, gd = api.ORBextractor(3000).DetectAndCompute(img)
+    rk, rd = oracle.detect_and_compute(oracle.params(3000), img)
+    assert gk.tobytes() == rk.tobytes() and np.array_equal(gd, rd)
