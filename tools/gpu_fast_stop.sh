@@ -1,9 +1,10 @@
 #!/bin/bash
-# developer aid: time the FAST strip kernel truncated after stage 1 (staging), 2 (score), 3 (NMS)
-export TMPDIR=/tmp
-for st in 1 2 3; do
-  MYSLAM_EXTRA_FLAGS=-DMYSLAM_FAST_STOP=$st python a-simple-stereo-slam-system-with-deep-loop-closing_amd/build.py --force > /dev/null 2>&1
-  echo -n "stop=$st "; python bench.py --steps 5 --warmup 1 --pairs 256 --workload orb_match --no-cpu-baseline 2>/dev/null | python -c "
+# developer aid: time the FAST strip kernel truncated after stage 1 (staging), 2 (score), 3 (NMS); one stream, no internal stream
+export TMPDIR=/tmp MYSLAM_ORB_AUX=0
+for st in 1 2 3 0; do
+  if [ $st = 0 ]; then MYSLAM_EXTRA_FLAGS= python a-simple-stereo-slam-system-with-deep-loop-closing_amd/build.py --force > /dev/null 2>&1
+  else MYSLAM_EXTRA_FLAGS=-DMYSLAM_FAST_STOP=$st python a-simple-stereo-slam-system-with-deep-loop-closing_amd/build.py --force > /dev/null 2>&1; fi
+  echo -n "stop=$st "; python bench.py --steps 5 --warmup 1 --pairs 512 --workload orb_match --streams 1 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print(round(d['kernel_ms_per_step']['fast_cells'],3))"
 done
