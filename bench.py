@@ -42,10 +42,15 @@ ALGO_BYTES = {
 def pmc_traffic(kernel, pairs):
     """HBM bytes per launch of `kernel` from the committed PMC run (separate rocprofv3 --pmc passes, tools/gpu_traffic.sh)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")))
+    import re
+    files = glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json"))
     if not files:
         return None
-    d = json.load(open(files[-1]))
+
+    def version(f):                                            # ..._v<N>.json: the highest build number is the current one
+        m = re.search(r"_v(\d+)\.json$", f)
+        return int(m.group(1)) if m else -1
+    d = json.load(open(max(files, key=version)))
     tag = {"fast_cells": "k_fast", "octree": "k_octree", "blur7": "k_blur7", "resize": "k_resize", "describe": "k_describe"}.get(kernel)
     for name, v in d["kernels"].items():
         if tag and name.startswith(tag):
