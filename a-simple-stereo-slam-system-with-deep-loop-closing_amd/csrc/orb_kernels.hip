@@ -1902,29 +1902,10 @@ __global__ __launch_bounds__(256) void k_describe(OrbPlan P, const uint8_t* __re
 
 // K5b: the same operator, phased per block of 64 keypoints so that nothing scalar runs 64-wide:
 //   0  thread per keypoint: slot -> (level, x, y, response)
-//   A  wave per keypoint  : intensity-centroid moments straight from global memory; lane = one aligned dword of the
-//                           31-row patch, the circular mask and the column weights u+16 come from a constant table
-//                           indexed by (alignment, dword): m10 = sum dot4(I, w) - 16 sum dot4(I, 1), m01 = sum v dot4(I, 1)
+//   A  16 keypoints / wave: intensity-centroid moments on the int8 matrix cores: [key-points x 64 k] x [64 k x {u, v weights}], the
+//                           patch as it lies in memory is the A operand (p - 128; the masked weights sum to zero), 16 MFMAs
 //   B  thread per keypoint: fastAtan2, deterministic sin/cos, cv::KeyPoint fields
 //   C  wave per keypoint  : blurred 37x37 window -> LDS, 4 steered BRIEF tests per lane
-struct IcwEntry { uint32_t w, o; };
-struct IcwTable { IcwEntry e[4 * DA_N]; };
-constexpr IcwTable make_icw_table() {
-    IcwTable t{};
-    constexpr int um[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};      // umax, ORBextractor.cpp:429-444
-    for (int off = 0; off < 4; off++)
-        for (int i = 0; i < DA_N; i++) {
-            const int r = i / DA_DW, c = i % DA_DW, v = r - HALF_PATCH, d = um[v < 0 ? -v : v];
-            uint32_t w = 0, o = 0;
-            for (int j = 0; j < 4; j++) {
-                const int u = 4 * c + j - off - HALF_PATCH;
-                if (u >= -d && u <= d) { w |= (uint32_t)(u + 16) << (8 * j); o |= 1u << (8 * j); }
-            }
-            t.e[off * DA_N + i].w = w; t.e[off * DA_N + i].o = o;
-        }
-    return t;
-}
-__device__ const IcwTable c_icw = make_icw_table();
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_add_i32(int v) { return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false); }
@@ -1944,7 +1925,8 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
     __shared__ __attribute__((aligned(16))) uint32_t s_b[4][DB_N];
     __shared__ int s_x[KD_KPB], s_y[KD_KPB], s_lv[KD_KPB], s_m10[KD_KPB], s_m01[KD_KPB];
     __shared__ float s_ca[KD_KPB], s_sb[KD_KPB];
-    __shared__ __attribute__((aligned(8))) IcwEntry s_icw[4 * DA_N];
+    __shared__ __attribute__((aligned(16))) uint4 s_bw[16 * 4 * 2];      // IC-angle weights as MFMA B operands: [row pair][k block][x | y]
+    __shared__ uint32_t s_pbase[KD_KPB], s_ppitch[KD_KPB];              // byte offset of patch(-15, -15) in the pyramid plane set, row pitch
     // XCD-aware block order: the dispatcher places block i on XCD i % 8, each XCD has a private L2, and the ~32 blocks of one
     // image read overlapping windows of the same two pyramids.  Logical block ids (image-major) are handed out so that every
     // XCD walks a contiguous range of images (bijective remap, any grid size): without it every XCD pulls every image
@@ -1954,7 +1936,17 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
     const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const int b = logical / nchunk, t = threadIdx.x;
     if (b >= batch) return;
-    for (int i = t; i < 4 * DA_N; i += 256) s_icw[i] = c_icw.e[i];
+    if (t < 128) {      // weights of patch row 2 rp + (kq >> 1), columns 16 (kq & 1) .. +15: u (x moment) or v (y moment) inside the circular mask
+        const int rp = t >> 3, kq = (t >> 1) & 3, jm = t & 1, row = 2 * rp + (kq >> 1), v = row - HALF_PATCH;
+        const int d = (row <= 30) ? c_umax[v < 0 ? -v : v] : -1;
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int bb = 0; bb < 16; bb++) {
+            const int u = 16 * (kq & 1) + bb - HALF_PATCH;
+            const int val = (u >= -d && u <= d) ? (jm ? v : u) : 0;
+            w[bb >> 2] |= (uint32_t)(val & 0xff) << (8 * (bb & 3));
+        }
+        s_bw[t] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;      // scalar: per-keypoint addressing goes to the SALU
     const int slot0 = (logical - b * nchunk) * KD_KPB;
     // ---- 0 ----
@@ -1976,41 +1968,49 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
         if (active) pay = selOut[(size_t)b * P.totalOut + P.lv[level].outBase + local];
         s_lv[t] = active ? level : -1;
         s_x[t] = (int)((pay >> 8) & 0xfff) + MIN_BORDER; s_y[t] = (int)(pay >> 20) + MIN_BORDER;      // :897-898
+        {   // keypoints keep >= 19 px from every border (ORBextractor.cpp:25): rows y-15 .. y+16 and columns x-15 .. x+16 exist
+            const LevelGeom& gl = P.lv[active ? level : 0];
+            s_ppitch[t] = (uint32_t)gl.pitch;
+            s_pbase[t] = active ? (uint32_t)(gl.imgOff + (size_t)(s_y[t] - HALF_PATCH) * gl.pitch + (s_x[t] - HALF_PATCH)) : 0u;
+        }
         resp = (float)(pay & 0xff);
     }
     __syncthreads();
-    // lane-constant patch coordinates of the dwords this lane fetches (hoisted out of the keypoint loops)
-    int ra_[DA_IT], ca_[DA_IT], rb_[DB_IT], cb_[DB_IT];
-#pragma unroll
-    for (int q = 0; q < DA_IT; q++) { const int i = lane + 64 * q; ra_[q] = i / DA_DW; ca_[q] = 4 * (i - ra_[q] * DA_DW); }
+    // lane-constant window coordinates of the dwords this lane fetches in phase C
+    int rb_[DB_IT], cb_[DB_IT];
 #pragma unroll
     for (int q = 0; q < DB_IT; q++) { const int i = lane + 64 * q; rb_[q] = i / DB_DW; cb_[q] = 4 * (i - rb_[q] * DB_DW); }
-    // ---- A ----
-    for (int j = 0; j < KD_KPB / 4; j++) {
-        const int k = wave * (KD_KPB / 4) + j;
-        const int level = __builtin_amdgcn_readfirstlane(s_lv[k]);
-        if (level < 0) continue;                                          // wave-uniform
-        const LevelGeom& g = P.lv[level];
-        const int x = __builtin_amdgcn_readfirstlane(s_x[k]), y = __builtin_amdgcn_readfirstlane(s_y[k]);
-        const uint8_t* img = pyr + (size_t)b * pyrStride + g.imgOff;
-        // keypoints keep >= 19 px from every border (ORBextractor.cpp:25), so all patch rows exist
-        const int xa0 = (x - HALF_PATCH) & ~3, offA = (x - HALF_PATCH) - xa0;
-        int A = 0, B = 0, Cn = 0;
+    // ---- A ----  intensity-centroid moments of 16 key-points per wave on the int8 matrix cores:
+    //   [16 key-points x 64 k] x [64 k x {u weights, v weights}],  k = two patch rows of 32 pixels, 16 MFMAs (v_mfma_i32_16x16x64_i8)
+    // A operand = the patch as it lies in memory (lane = key-point, 16 consecutive pixels per lane and k block, p - 128 as int8: the
+    // weights sum to zero over the symmetric mask, so the offset cancels exactly); B operand = the masked weights (s_bw).
+    {
+        typedef int kd_v4i __attribute__((ext_vector_type(4)));
+        const int kk = wave * 16 + (lane & 15), kq = lane >> 4;
+        const uint8_t* pl = pyr + (size_t)b * pyrStride + s_pbase[kk] + (size_t)(kq >> 1) * s_ppitch[kk] + 16 * (kq & 1);
+        const size_t step2 = 2 * (size_t)s_ppitch[kk];
+        const int jb = lane & 15;
+        kd_v4i acc = {0, 0, 0, 0};
 #pragma unroll
-        for (int q = 0; q < DA_IT; q++) {
-            const int i = lane + 64 * q;
-            if (i < DA_N) {
-                const int r = ra_[q];
-                const uint32_t I = *reinterpret_cast<const uint32_t*>(img + (size_t)(y - HALF_PATCH) * g.pitch + xa0 + (r * g.pitch + ca_[q]));
-                const IcwEntry e = s_icw[offA * DA_N + i];
-                const int sI = (int)__builtin_amdgcn_udot4(I, e.o, 0u, false);
-                A += (int)__builtin_amdgcn_udot4(I, e.w, 0u, false);
-                Cn += sI;
-                B += (r - HALF_PATCH) * sI;
+        for (int h8 = 0; h8 < 2; h8++) {                        // two batches of 8 row pairs: 8 window loads in flight
+            uint4 px[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) __builtin_memcpy(&px[q], pl + (size_t)(8 * h8 + q) * step2, 16);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int rp = 8 * h8 + q;
+                uint4 wv = (jb < 2) ? s_bw[(rp * 4 + kq) * 2 + jb] : make_uint4(0, 0, 0, 0);
+                uint4 pv = px[q];
+                pv.x ^= 0x80808080u; pv.y ^= 0x80808080u; pv.z ^= 0x80808080u; pv.w ^= 0x80808080u;
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(kd_v4i, pv), __builtin_bit_cast(kd_v4i, wv), acc, 0, 0, 0);
             }
         }
-        A = wave_sum_lane63_i32(A); B = wave_sum_lane63_i32(B); Cn = wave_sum_lane63_i32(Cn);
-        if (lane == 63) { s_m10[k] = A - 16 * Cn; s_m01[k] = B; }
+        // C/D: column = lane & 15 (0 -> m10, 1 -> m01), row (key-point) = 4 (lane >> 4) + register
+        if (jb < 2) {
+            int* dstm = jb ? s_m01 : s_m10;
+#pragma unroll
+            for (int r = 0; r < 4; r++) dstm[wave * 16 + 4 * kq + r] = acc[r];
+        }
     }
     __syncthreads();
     // ---- B ----
