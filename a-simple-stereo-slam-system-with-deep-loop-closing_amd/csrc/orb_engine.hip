@@ -266,7 +266,7 @@ int myslam_orb::ensure(int batch, int r, int c, bool needMask) {
     if (batch > batchCap) {
         MYSLAM_HIP_CHECK(hipStreamSynchronize(stream));
         int rc;
-        if ((rc = dev_alloc(d_pyr, (size_t)batch * full.pyrBytes))) return rc;
+        if ((rc = dev_alloc(d_pyr, (size_t)batch * full.pyrBytes + 64))) return rc;      // + 64: the resize kernel's 8-byte row loads may run 7 bytes past a row
         if ((rc = dev_alloc(d_blur, (size_t)batch * full.pyrBytes))) return rc;
         if ((rc = dev_alloc(d_cand, (size_t)batch * full.totalKeyCap))) return rc;
         if ((rc = dev_alloc(d_sort, (size_t)batch * full.totalKeyCap * 2))) return rc;
@@ -279,7 +279,7 @@ int myslam_orb::ensure(int batch, int r, int c, bool needMask) {
         batchCap = batch;
     }
     if (needMask && !maskAlloc) {
-        int rc = dev_alloc(d_mask, (size_t)batchCap * full.pyrBytes);
+        int rc = dev_alloc(d_mask, (size_t)batchCap * full.pyrBytes + 64);
         if (rc) return rc;
         maskAlloc = true;
     }

@@ -122,49 +122,51 @@ __global__ __launch_bounds__(256) void k_resize_strip(ResizeArgs a, int nstrips,
     const int rfirst = min(max(__builtin_amdgcn_readlane(ysy, 0), 0), a.sh - 1);
     const int rlast = min(max(__builtin_amdgcn_readlane(ysy, dy1 - 1 - dy0) + 1, 0), a.sh - 1);
     const int nrows = rlast - rfirst + 1;                        // <= RS_MAXR (checked by the launcher)
-    __shared__ __attribute__((aligned(8))) uint16_t s_t[4][RS_MAXR][256];
-    uint16_t (*T)[256] = s_t[threadIdx.x >> 6];
-    uint32_t raw[RS_MAXR][4];
+    // One unaligned 8-byte load per source row covers the byte pairs of all four destination columns (their source columns span at
+    // most 3 scale_x + 2 <= 7 bytes; the launcher checks scale_x): the kernel is bound by the ISSUE of its gather loads, so four
+    // 2-byte loads per row cost four times as much.  The pairs are picked with byte permutes whose selectors are lane constants.
+    uint32_t selk[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const uint32_t o = (uint32_t)(sx[k] - sx[0]); selk[k] = 0x0c000c00u | ((o + 1u) << 16) | o; }
+    uint2 raw8[RS_MAXR];
 #pragma unroll
     for (int rr = 0; rr < RS_MAXR; rr++) {
         const uint8_t* row = src + (size_t)(rfirst + min(rr, nrows - 1)) * a.spitch;
+        raw8[rr] = make_uint2(0u, 0u);
+        // at the right border sx = sw-1 and the weight of sx+1 is 0 (OpenCV clamps fx there): the bytes past the row are never weighted
+        if (has && rr < nrows) __builtin_memcpy(&raw8[rr], row + sx[0], 8);
+    }
+    // horizontal pass: raw[rr][k] <- the row-cache value (<= 32640) of source row rfirst + rr at this lane's 4 columns
+    uint32_t raw[RS_MAXR][4];
+#pragma unroll
+    for (int rr = 0; rr < RS_MAXR; rr++)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            uint16_t v = 0;
-            // at the right border sx = sw-1 and the weight of sx+1 is 0 (OpenCV clamps fx there): that byte's value is irrelevant
-            if (has && rr < nrows) __builtin_memcpy(&v, row + sx[k], 2);
-            raw[rr][k] = v;
+            const uint32_t pp = __builtin_amdgcn_perm(raw8[rr].y, raw8[rr].x, selk[k]);       // (p0, p1) as two u16
+            raw[rr][k] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pp), __builtin_bit_cast(u16x2, aw[k]), 0u, false) >> 4;
         }
-    }
+    // vertical pass: walk the source rows statically (the row cache stays in registers, no run-time register indexing) and emit the
+    // destination rows whose upper source row is the current one — at most one per source row for scale >= 1; the row coordinates
+    // are wave-uniform scalars
+    int dy = dy0;
+    int sy = __builtin_amdgcn_readlane(ysy, 0), b0 = __builtin_amdgcn_readlane(yb0, 0), b1 = __builtin_amdgcn_readlane(yb1, 0);
 #pragma unroll
     for (int rr = 0; rr < RS_MAXR; rr++) {
-        if (rr < nrows) {
-            uint32_t t[4];
+        while (dy < dy1 && min(max(sy, 0), a.sh - 1) - rfirst == rr) {          // uniform
+            const bool same = min(max(sy + 1, 0), a.sh - 1) - rfirst == rr;     // clamped at an image border: both taps on this row
+            uint32_t packed = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const uint32_t pp = __builtin_amdgcn_perm(0u, raw[rr][k], 0x0c010c00u);       // (p0, p1) as two u16
-                t[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pp), __builtin_bit_cast(u16x2, aw[k]), 0u, false) >> 4;   // <= 32640
+                const int tA = (int)raw[rr][k], tB = (int)(same ? raw[rr][k] : raw[rr + 1 < RS_MAXR ? rr + 1 : rr][k]);
+                const int v = (((b0 * tA) >> 16) + ((b1 * tB) >> 16) + 2) >> 2;     // in [0, 255]: the weights of each axis sum to 2048
+                packed |= (uint32_t)v << (8 * k);
             }
-            *reinterpret_cast<uint2*>(&T[rr][4 * lane]) = make_uint2(t[0] | (t[1] << 16), t[2] | (t[3] << 16));
+            if (has) *reinterpret_cast<uint32_t*>(dst + (size_t)dy * a.dpitch + dx4) = packed;
+            dy++;
+            if (dy < dy1) {
+                sy = __builtin_amdgcn_readlane(ysy, dy - dy0); b0 = __builtin_amdgcn_readlane(yb0, dy - dy0); b1 = __builtin_amdgcn_readlane(yb1, dy - dy0);
+            }
         }
-    }
-    // same lane reads what it wrote: no cross-lane dependency, program order suffices
-    for (int dy = dy0; dy < dy1; dy++) {
-        const int sy = __builtin_amdgcn_readlane(ysy, dy - dy0), b0 = __builtin_amdgcn_readlane(yb0, dy - dy0),
-                  b1 = __builtin_amdgcn_readlane(yb1, dy - dy0);
-        const int sy0 = min(max(sy, 0), a.sh - 1), sy1 = min(max(sy + 1, 0), a.sh - 1);
-        const uint2 ta = *reinterpret_cast<const uint2*>(&T[sy0 - rfirst][4 * lane]);
-        const uint2 tb = *reinterpret_cast<const uint2*>(&T[sy1 - rfirst][4 * lane]);
-        const int tA[4] = {(int)(ta.x & 0xffff), (int)(ta.x >> 16), (int)(ta.y & 0xffff), (int)(ta.y >> 16)};
-        const int tB[4] = {(int)(tb.x & 0xffff), (int)(tb.x >> 16), (int)(tb.y & 0xffff), (int)(tb.y >> 16)};
-        uint32_t packed = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int v = (((b0 * tA[k]) >> 16) + ((b1 * tB[k]) >> 16) + 2) >> 2;
-            v = min(max(v, 0), 255);
-            packed |= (uint32_t)v << (8 * k);
-        }
-        if (has) *reinterpret_cast<uint32_t*>(dst + (size_t)dy * a.dpitch + dx4) = packed;
     }
 }
 
@@ -2190,7 +2192,7 @@ void launch_ingest(const uint8_t* src, int rows, int cols, int step, size_t sstr
 // ------------------------------------------------------------------------------------------------
 void launch_resize(const ResizeArgs& a, int batch, hipStream_t s) {
     static const char* env = getenv("MYSLAM_RESIZE_V");           // tuning aid: 1 = one row per wave kernel
-    if (!(env && atoi(env) == 1) && (double)RS_R * a.scale_y + 2.0 <= (double)RS_MAXR) {
+    if (!(env && atoi(env) == 1) && (double)RS_R * a.scale_y + 2.0 <= (double)RS_MAXR && a.scale_x <= 1.6) {
         const int nstrips = (a.dw + 255) / 256, nbands = (a.dh + RS_R - 1) / RS_R;
         hipLaunchKernelGGL(k_resize_strip, dim3((nstrips * nbands + 3) / 4, 1, batch), dim3(256), 0, s, a, nstrips, nbands);
         return;
