@@ -1637,8 +1637,9 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
             const int lo = live ? (int)L.lo(cur)[p0] : 0, hi = live ? (int)L.hi(cur)[p0] : 0;
             if (rankkey) {                                               // block-uniform
                 uint32_t bk = 0;
+                const uint32_t* Slo = reinterpret_cast<const uint32_t*>(S);      // little endian: the selection key is the low word
 #pragma unroll 4
-                for (int i = lo + sub; i < hi; i += 16) bk = max(bk, (uint32_t)S[i]);
+                for (int i = lo + sub; i < hi; i += 16) bk = max(bk, Slo[2 * i]);
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) bk = max(bk, (uint32_t)__shfl_xor((int)bk, o, 64));
                 if (live && sub == 0) {
