@@ -36,3 +36,23 @@ def test_bench_json_contract(extra):
         for k in ("value", "unit", "cores", "kind", "sample"):
             assert k in cb, k
         assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """The N>1 path of bench.py (frame sharding, id-range sharded loop DB + all-gather, barrier, max over ranks, one JSON line from
+    rank 0) launched exactly as the driver launches it, with both ranks on the only GPU of the box and gloo carrying the collectives."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "16",
+           "--backend", "gloo"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None        # CPU baseline: rank 0 at N=1 only
+    assert abs(d["value"] - 2 * 16 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]       # whole-job rate: both ranks' pairs
+    assert "x2" in d["config"]["parallelism"]
