@@ -1021,7 +1021,11 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
             if (r < hr && k < nq) *reinterpret_cast<uint4*>(&s_tile[r * TP + 16 * k]) = v[u];
         }
     }
-    for (int i = threadIdx.x; i < G * ((SROWS * SP + 16) / 4); i += T) reinterpret_cast<uint32_t*>(&s_score[0][0])[i] = 0;
+    {   // zero the score maps (16-byte stores; the dword tail only exists when the array size is not a multiple of 16)
+        constexpr int NB = G * (SROWS * SP + 16), NV = NB / 16;
+        for (int i = threadIdx.x; i < NV; i += T) reinterpret_cast<uint4*>(&s_score[0][0])[i] = make_uint4(0, 0, 0, 0);
+        if (NB % 16 != 0 && threadIdx.x < (NB - 16 * NV) / 4) reinterpret_cast<uint32_t*>(&s_score[0][0])[4 * NV + threadIdx.x] = 0;
+    }
     if (threadIdx.x < G) s_ini[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_nlist = 0;
     __syncthreads();
