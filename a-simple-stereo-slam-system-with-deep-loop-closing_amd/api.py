@@ -99,6 +99,14 @@ class ORBextractor:
     def set_stream(self, stream_ptr):
         _check(lib().myslam_orb_set_stream(self._h, C.c_void_p(stream_ptr)), "myslam_orb_set_stream")
 
+    def set_fast_event(self, event_ptr):
+        """Record the hipEvent_t `event_ptr` (0 = off) on the handle's stream after the FAST stage of every following batched call."""
+        _check(lib().myslam_orb_set_fast_event(self._h, C.c_void_p(event_ptr or None)), "myslam_orb_set_fast_event")
+
+    def set_fast_gate(self, event_ptr):
+        """Make the handle's stream wait for the hipEvent_t `event_ptr` (0 = off) before the FAST stage of every following batched call."""
+        _check(lib().myslam_orb_set_fast_gate(self._h, C.c_void_p(event_ptr or None)), "myslam_orb_set_fast_gate")
+
     def tables(self):
         n = self.nlevels
         sc = np.zeros(n, np.float32); isc = np.zeros(n, np.float32); npl = np.zeros(n, np.int32); um = np.zeros(16, np.int32)

@@ -90,6 +90,8 @@ struct myslam_orb {
     // kernel, fenced by events against the caller's stream (run_batch)
     hipStream_t aux = nullptr;
     hipEvent_t evFork = nullptr, evJoin = nullptr;
+    hipEvent_t evUserFast = nullptr;     // caller's event, recorded after the FAST stage (myslam_orb_set_fast_event)
+    hipEvent_t evUserGate = nullptr;     // caller's event, waited for before the FAST stage (myslam_orb_set_fast_gate)
 
     // plan for the current image size
     int rows = 0, cols = 0;
@@ -353,10 +355,12 @@ int myslam_orb::run_batch(const uint8_t* d_imgs, int batch, int r, int c, int st
         return MYSLAM_OK;
     };
     if (fork && aux_mode == 2 && (rc = fork_blur())) return rc;
+    if (evUserGate) MYSLAM_HIP_CHECK(hipStreamWaitEvent(stream, evUserGate, 0));
     {
         ScopedProf sp(P_FAST, stream);
         launch_fast(P, d_pyr, full.pyrBytes, d_masks ? d_mask : nullptr, d_cand, d_candCount, batch, stream);
     }
+    if (evUserFast) MYSLAM_HIP_CHECK(hipEventRecord(evUserFast, stream));
     if (fork && aux_mode != 2 && (rc = fork_blur())) return rc;
     {
         ScopedProf sp(P_OCTREE, stream);
@@ -426,6 +430,18 @@ int myslam_orb_set_stream(myslam_orb* h, void* s) {
     if (!h) return MYSLAM_ERR_INVALID;
     (void)hipStreamSynchronize(h->stream);
     h->stream = (hipStream_t)s;
+    return MYSLAM_OK;
+}
+
+int myslam_orb_set_fast_event(myslam_orb* h, void* ev) {
+    if (!h) return MYSLAM_ERR_INVALID;
+    h->evUserFast = (hipEvent_t)ev;
+    return MYSLAM_OK;
+}
+
+int myslam_orb_set_fast_gate(myslam_orb* h, void* ev) {
+    if (!h) return MYSLAM_ERR_INVALID;
+    h->evUserGate = (hipEvent_t)ev;
     return MYSLAM_OK;
 }
 

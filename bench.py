@@ -71,14 +71,29 @@ def parse():
     ap.add_argument("--cpu-pairs", type=int, default=32)
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
                     help="2 = the DeepLCD / loop-DB / BA chain runs on a second HIP stream beside ORB + match + triangulation")
-    ap.add_argument("--orb-split", type=int, default=1, choices=[1, 2, 4, 8],
-                    help="S > 1 = the 2P images go through S extractor handles on S streams (S equal groups; 2 is ~2-3 % faster, "
-                         "but concurrent launches of the same kernel stretch each other, which blurs the per-launch roofline figure)")
+    ap.add_argument("--orb-split", type=int, default=0, choices=[0, 1, 2, 4, 8],
+                    help="S > 1 = the 2P images go through S extractor handles on S streams (S equal groups): the latency-bound oct-tree / "
+                         "describe launches of one group run under the VALU-bound FAST launch of the other (2 is ~3 % faster than 1; "
+                         "concurrent launches stretch each other, so per-launch durations are longer than when a kernel runs alone). "
+                         "0 (default) = 2 with --streams 2, 1 with --streams 1")
+    ap.add_argument("--pipeline", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
+                    help="1 = the left and the right images go through two extractor handles that take turns (myslam_orb_set_fast_event): "
+                         "one handle's VALU-bound FAST stage runs under the other's latency-bound oct-tree / descriptor stages, match + "
+                         "triangulation follow on a third stream, outputs are double-buffered and consecutive steps overlap (every step's "
+                         "work is complete at the closing barrier).  0 = every step is joined before the next starts.  "
+                         "-1 (default) = 1 with --streams 2, else 0")
     ap.add_argument("--side-delay-ms", type=float, default=0.0, help="experiment: start the side chain this long after the step begins (spin kernel)")
     ap.add_argument("--no-join", action="store_true", help="do not join the side stream at the end of every step (streaming across steps)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = debugging aid: several ranks share GPU 0 and the collectives go through host memory")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.pipeline < 0:
+        args.pipeline = 1 if (args.streams == 2 and args.orb_split in (0, 2)) else 0
+    if args.orb_split == 0:
+        args.orb_split = 2 if (args.streams == 2 or args.pipeline) else 1
+    if args.pipeline:
+        assert args.orb_split == 2, "--pipeline 1 runs the left / right images on two extractor handles (--orb-split 2)"
+    return args
 
 
 def cpu_baseline(synth, workload, n_pairs, db_np, gpu_frames):
@@ -148,10 +163,12 @@ def main():
     assert (2 * P) % S == 0
     orb_streams = [torch.cuda.Stream() for _ in range(S - 1)]
     orb_exts = [api.ORBextractor(2000, stream=st.cuda_stream) for st in orb_streams]
-    d_kps = torch.zeros(2 * P * cap * 28, dtype=torch.uint8, device=dev)
-    d_desc = torch.zeros(2 * P * cap * 32, dtype=torch.uint8, device=dev)
-    d_cnt = torch.zeros(2 * P, dtype=torch.int32, device=dev)
-    d_stat = torch.zeros(2 * P, dtype=torch.int32, device=dev)
+    NB = 2 if args.pipeline else 1          # pipeline: extractor outputs are double-buffered (step k+1 extracts while step k is matched)
+    d_kps_b = [torch.zeros(2 * P * cap * 28, dtype=torch.uint8, device=dev) for _ in range(NB)]
+    d_desc_b = [torch.zeros(2 * P * cap * 32, dtype=torch.uint8, device=dev) for _ in range(NB)]
+    d_cnt_b = [torch.zeros(2 * P, dtype=torch.int32, device=dev) for _ in range(NB)]
+    d_stat_b = [torch.zeros(2 * P, dtype=torch.int32, device=dev) for _ in range(NB)]
+    d_kps, d_desc, d_cnt, d_stat = d_kps_b[0], d_desc_b[0], d_cnt_b[0], d_stat_b[0]
     d_midx = torch.zeros(P * cap, dtype=torch.int32, device=dev)
     d_mdist = torch.zeros(P * cap, dtype=torch.int32, device=dev)
     d_xyz = torch.zeros(P * cap * 3, dtype=torch.float64, device=dev)
@@ -193,7 +210,73 @@ def main():
                                              5.991, 5.991, 5, 10, b_out[2].data_ptr(), s_echi.data_ptr(), s_out.data_ptr(), s_rd.data_ptr(),
                                              s_no.data_ptr(), s_st.data_ptr(), stream2)
 
-    def step():
+    def side_chain():
+        if args.side_delay_ms > 0 and side_stream is not main_stream:
+            torch.cuda._sleep(int(args.side_delay_ms * 1e-3 * 2.0e9))
+        if use_lcd:
+            lcd.describe_batch(d_imgs.data_ptr(), P, H, W, W, H * W, d_descr.data_ptr(), blur_in_place=False)
+            if world > 1:       # every shard scores every rank's queries; candidates are merged after an all-gather
+                if via_cpu:
+                    h_all = torch.empty(d_allq.shape, dtype=d_allq.dtype)
+                    dist.all_gather_into_tensor(h_all, d_descr.cpu())
+                    d_allq.copy_(h_all)
+                else:
+                    dist.all_gather_into_tensor(d_allq, d_descr)
+                D.query_batch(d_allq.data_ptr(), cur_ids, NQ, d_best.data_ptr(), d_max.data_ptr(), d_dbcnt.data_ptr())
+                pkg.sharded_db.merge_candidates(d_best, d_max, d_dbcnt, world, via_cpu=via_cpu)
+            else:
+                D.query_batch(d_descr.data_ptr(), cur_ids, NQ, d_best.data_ptr(), d_max.data_ptr(), d_dbcnt.data_ptr())
+        if use_ba:
+            api.ba_build_batch(*[t.data_ptr() for t in b_in], P, maxP, maxL, maxE, Kt, 5.991, *[t.data_ptr() for t in b_out], stream2)
+            if use_solve:
+                solve()
+
+    if args.pipeline:
+        # two extractor handles take turns: handle A (left images, main stream) and handle B (right images, its own stream) each wait
+        # for the other's FAST stage, so a FAST launch never runs beside the other FAST launch but under the other handle's oct-tree /
+        # descriptor launches; match + triangulation of step k run on a third stream once both handles are done with step k, while the
+        # handles already extract step k+1 into the other output buffer
+        extA, extB = ext, orb_exts[0]
+        sA, sB, sM = main_stream, orb_streams[0], torch.cuda.Stream()
+        ev_fast = [torch.cuda.Event(), torch.cuda.Event()]
+        ev_done = [[torch.cuda.Event(), torch.cuda.Event()] for _ in range(NB)]
+        ev_match = [torch.cuda.Event() for _ in range(NB)]
+        ev_start = torch.cuda.Event()
+        for e in ev_fast + [x for pr in ev_done for x in pr] + ev_match + [ev_start]:
+            e.record(main_stream)                       # creates the hipEvent_t behind the torch event
+        extA.set_fast_event(ev_fast[0].cuda_event); extB.set_fast_event(ev_fast[1].cuda_event)
+        if args.pipeline == 1:      # gate inside the call: only the FAST stages take turns, the pyramids are not held back
+            extA.set_fast_gate(ev_fast[1].cuda_event); extB.set_fast_gate(ev_fast[0].cuda_event)
+        step_no = [0]
+
+        def step():
+            p = step_no[0] % NB
+            step_no[0] += 1
+            kps, desc, cnt, stat = d_kps_b[p], d_desc_b[p], d_cnt_b[p], d_stat_b[p]
+            if args.pipeline == 2:
+                sA.wait_event(ev_fast[1])               # handle B's FAST of the previous step (whole call held back)
+            sA.wait_event(ev_match[p])                  # buffer p was last read by the match of step k - 2
+            ev_start.record(sA)
+            extA.detect_and_compute_batch(d_imgs.data_ptr(), P, H, W, W, H * W, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(),
+                                          stat.data_ptr(), cap)
+            ev_done[p][0].record(sA)
+            if args.pipeline == 2:
+                sB.wait_event(ev_fast[0])               # handle A's FAST of this step
+            sB.wait_event(ev_match[p])
+            extB.detect_and_compute_batch(d_imgs.data_ptr() + P * H * W, P, H, W, W, H * W, kps.data_ptr() + P * cap * 28,
+                                          desc.data_ptr() + P * cap * 32, cnt.data_ptr() + 4 * P, stat.data_ptr() + 4 * P, cap)
+            ev_done[p][1].record(sB)
+            sM.wait_event(ev_done[p][0]); sM.wait_event(ev_done[p][1])
+            api.hamming_match_batch(desc.data_ptr(), cnt.data_ptr(), desc.data_ptr() + P * cap * 32, cnt.data_ptr() + 4 * P,
+                                    P, cap, d_midx.data_ptr(), d_mdist.data_ptr(), sM.cuda_stream)
+            api.triangulate_stereo_batch(kps.data_ptr(), kps.data_ptr() + P * cap * 28, d_midx.data_ptr(), cnt.data_ptr(), P, cap,
+                                         Kt, K["bf"] / K["fx"], d_xyz.data_ptr(), d_ok.data_ptr(), sM.cuda_stream)
+            ev_match[p].record(sM)
+            side_stream.wait_event(ev_start)            # the LCD / DB / BA chain of step k starts with step k
+            with torch.cuda.stream(side_stream):
+                side_chain()
+
+    def step_joined():
         if S == 1:
             ext.detect_and_compute_batch(d_imgs.data_ptr(), 2 * P, H, W, W, H * W, d_kps.data_ptr(), d_desc.data_ptr(),
                                          d_cnt.data_ptr(), d_stat.data_ptr(), cap)
@@ -212,27 +295,12 @@ def main():
         api.triangulate_stereo_batch(d_kps.data_ptr(), d_kps.data_ptr() + P * cap * 28, d_midx.data_ptr(), d_cnt.data_ptr(), P, cap,
                                      Kt, K["bf"] / K["fx"], d_xyz.data_ptr(), d_ok.data_ptr(), stream)
         with torch.cuda.stream(side_stream):
-            if args.side_delay_ms > 0 and side_stream is not main_stream:
-                torch.cuda._sleep(int(args.side_delay_ms * 1e-3 * 2.0e9))
-            if use_lcd:
-                lcd.describe_batch(d_imgs.data_ptr(), P, H, W, W, H * W, d_descr.data_ptr(), blur_in_place=False)
-                if world > 1:       # every shard scores every rank's queries; candidates are merged after an all-gather
-                    if via_cpu:
-                        h_all = torch.empty(d_allq.shape, dtype=d_allq.dtype)
-                        dist.all_gather_into_tensor(h_all, d_descr.cpu())
-                        d_allq.copy_(h_all)
-                    else:
-                        dist.all_gather_into_tensor(d_allq, d_descr)
-                    D.query_batch(d_allq.data_ptr(), cur_ids, NQ, d_best.data_ptr(), d_max.data_ptr(), d_dbcnt.data_ptr())
-                    pkg.sharded_db.merge_candidates(d_best, d_max, d_dbcnt, world, via_cpu=via_cpu)
-                else:
-                    D.query_batch(d_descr.data_ptr(), cur_ids, NQ, d_best.data_ptr(), d_max.data_ptr(), d_dbcnt.data_ptr())
-            if use_ba:
-                api.ba_build_batch(*[t.data_ptr() for t in b_in], P, maxP, maxL, maxE, Kt, 5.991, *[t.data_ptr() for t in b_out], stream2)
-                if use_solve:
-                    solve()
+            side_chain()
         if side_stream is not main_stream and not args.no_join:
             main_stream.wait_stream(side_stream)            # a step is complete when both chains are
+
+    if not args.pipeline:
+        step = step_joined
 
     def barrier():
         if world > 1:
@@ -242,7 +310,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    assert int(d_stat.abs().sum()) == 0, "ORB capacity overflow"
+    assert all(int(t.abs().sum()) == 0 for t in d_stat_b), "ORB capacity overflow"
     n_kp = d_cnt.float().mean().item()
 
     api.prof_reset(); api.prof_enable(True)
@@ -278,7 +346,10 @@ def main():
         # the dominant kernel of the critical (ORB) stream; with --streams 2 the side chain's kernels run underneath it and their
         # event-timed durations are stretched by the sharing, so they are not candidates
         chain = [k for k in busy if k in ("resize", "fast_cells", "octree", "blur7", "describe", "hamming_match", "triangulate")]
-        dom = max(chain or busy, key=lambda k: busy[k][0])
+        # event-timed durations of overlapped launches say how long a kernel was resident, not how much of the chip it used (the
+        # latency-bound oct-tree runs under FAST for as long as FAST takes): the dominant kernel is the one with the largest
+        # instruction volume (PMC, VALU_INSTS_PER_IMAGE) among those that ran, by duration only if none of them is in that table
+        dom = max(chain or busy, key=lambda k: (VALU_INSTS_PER_IMAGE.get(k, 0), busy[k][0]))
         dom_ms, dom_n = busy[dom]
         per_launch_ms = dom_ms / dom_n
         imgs_per_launch = 2 * P
@@ -289,7 +360,7 @@ def main():
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, P), "avg_launch_ms": per_launch_ms,
                     "algorithmic_bytes_per_launch": algo,
-                    "note": "packed-integer VALU bound in practice (see roofline_valu and DESIGN.md section 6); avg_launch_ms is the event-timed duration on the ORB stream, which this kernel shares with the Gaussian-pyramid launches of the extractor's internal stream and with the LCD / DB / BA chain (3.28 ms when it runs alone: --streams 1 with MYSLAM_ORB_AUX=0); traffic = FETCH_SIZE+WRITE_SIZE of a separate rocprofv3 --pmc run (profiles/), uncorrected"}
+                    "note": "packed-integer VALU bound in practice (see roofline_valu and DESIGN.md section 6); avg_launch_ms is the event-timed duration of one launch (the left and the right images go through two extractor handles on two streams unless --orb-split 1, so a launch covers half of the step's images), which shares the chip with the other handle's launches, the Gaussian-pyramid launches of the extractors' internal streams and the LCD / DB / BA chain (3.28 ms for all 1024 images when it runs alone: --streams 1 with MYSLAM_ORB_AUX=0); traffic = FETCH_SIZE+WRITE_SIZE of a separate rocprofv3 --pmc run (profiles/), uncorrected"}
         else:
             roof = {"bound": "hbm", "kernel": dom, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                     "traffic": None, "avg_launch_ms": per_launch_ms}
@@ -305,7 +376,7 @@ def main():
                                     "orb_match": "configs[1]: ORB extract L+R (2000 feats) + L/R Hamming match + triangulation",
                                     "orb_match_lcd": f"configs[2]: configs[1] + DeepLCD descriptor + {n_db_local * world}-KF cosine DB scan"}[args.workload],
                        "pairs_per_step_per_gpu": P, "image": "1241x376 u8", "keypoints_per_image": n_kp,
-                       "hip_streams": args.streams,
+                       "hip_streams": args.streams, "orb_extractor_handles": S,
                        "parallelism": f"frame-sharded x{world}" + (", id-range sharded DB + all-gather of candidates" if world > 1 else "")},
             "roofline": roof,
             "roofline_mfma": None if "calc_conv2" not in busy else {

@@ -68,6 +68,16 @@ int myslam_orb_destroy(myslam_orb* h);
  * Gaussian-pyramid launches on an internal stream; they are fenced by events against `hip_stream` on both sides, so for the caller
  * every call still starts after, and completes before, its neighbours on `hip_stream`. */
 int myslam_orb_set_stream(myslam_orb* h, void* hip_stream);
+/* pipelining aid for callers that run several extractor handles on several streams (e.g. the left and the right images of a
+ * stereo rig, which the reference extracts one after the other, frontend.cpp:86-94): `hip_event` (a hipEvent_t, NULL = off) is
+ * recorded on the handle's stream right after the grid-FAST stage of every following batched call.  FAST is the VALU-bound
+ * stage, the oct-tree / descriptor stages after it are latency-bound: a second handle whose stream waits for this event runs its
+ * own FAST under them instead of beside the first handle's FAST.  No reference counterpart (scheduling only). */
+int myslam_orb_set_fast_event(myslam_orb* h, void* hip_event);
+/* the matching gate: before the grid-FAST stage of every following batched call the handle's stream waits for `hip_event`
+ * (a hipEvent_t, NULL = off) as it was last recorded when the call is made; the pyramid stages before FAST are not held back.
+ * Two handles that gate each other with their fast events take turns on the VALU-bound stage. */
+int myslam_orb_set_fast_gate(myslam_orb* h, void* hip_event);
 /* getters ORBextractor.h:87-107 */
 int myslam_orb_get_tables(const myslam_orb* h, float* scale, float* inv_scale, int* features_per_level, int* umax16);
 /* upper bound of keypoints DetectAndCompute / Detect can return for one image: sum over levels of

@@ -287,3 +287,50 @@ def test_large_image_many_cells(api, oracle, synth):
     gk, gd = api.ORBextractor(3000).DetectAndCompute(img)
     rk, rd = oracle.detect_and_compute(oracle.params(3000), img)
     assert gk.tobytes() == rk.tobytes() and np.array_equal(gd, rd)
+
+
+def test_two_handles_taking_turns_on_fast(api, oracle, synth):
+    """myslam_orb_set_fast_event / _set_fast_gate: two handles on two streams that gate each other's FAST stage (bench.py's
+    left / right pipeline) return exactly what a plain call returns, over several rounds with buffer reuse."""
+    import torch
+    B, H, W = 4, 260, 400
+    imgs = [np.stack([synth.random_image(7000 + 10 * s + i, H, W) for i in range(B)]) for s in range(2)]
+    ref = [[oracle.detect_and_compute(oracle.params(600), im) for im in side] for side in imgs]
+    exts = [api.ORBextractor(600), api.ORBextractor(600)]
+    cap = exts[0].max_keypoints()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    evs = [torch.cuda.Event(), torch.cuda.Event()]
+    for e in evs:
+        e.record(torch.cuda.current_stream())
+    d_imgs = [torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in imgs]
+    d_kps = [torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    d_desc = [torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    d_cnt = [torch.zeros(B, dtype=torch.int32, device="cuda") for _ in range(2)]
+    d_st = [torch.ones(B, dtype=torch.int32, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    for s in range(2):
+        exts[s].set_stream(streams[s].cuda_stream)
+        exts[s].set_fast_event(evs[s].cuda_event)
+        exts[s].set_fast_gate(evs[1 - s].cuda_event)
+    for rep in range(3):
+        for s in range(2):
+            exts[s].detect_and_compute_batch(d_imgs[s].data_ptr(), B, H, W, W, H * W, d_kps[s].data_ptr(), d_desc[s].data_ptr(),
+                                             d_cnt[s].data_ptr(), d_st[s].data_ptr(), cap)
+        torch.cuda.synchronize()
+        for s in range(2):
+            assert evs[s].query()
+            cnt = d_cnt[s].cpu().numpy(); assert (d_st[s].cpu().numpy() == 0).all()
+            kps = d_kps[s].cpu().numpy().view(api.KP_DTYPE).reshape(B, cap)
+            desc = d_desc[s].cpu().numpy().reshape(B, cap, 32)
+            for b in range(B):
+                rk, rd = ref[s][b]
+                assert _kp_equal(kps[b, :cnt[b]], rk), (rep, s, b, _explain(kps[b, :cnt[b]], rk))
+                assert np.array_equal(desc[b, :cnt[b]], rd)
+            d_kps[s].zero_(); d_desc[s].zero_()
+        torch.cuda.synchronize()
+    for s in range(2):                     # gates off again: plain calls
+        exts[s].set_fast_event(0); exts[s].set_fast_gate(0)
+    exts[0].detect_and_compute_batch(d_imgs[0].data_ptr(), B, H, W, W, H * W, d_kps[0].data_ptr(), d_desc[0].data_ptr(),
+                                     d_cnt[0].data_ptr(), d_st[0].data_ptr(), cap)
+    torch.cuda.synchronize()
+    assert (d_st[0].cpu().numpy() == 0).all() and d_cnt[0].cpu().numpy().tolist() == [len(r[0]) for r in ref[0]]
