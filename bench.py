@@ -88,11 +88,11 @@ def parse():
                     help="gloo = debugging aid: several ranks share GPU 0 and the collectives go through host memory")
     args = ap.parse_args()
     if args.pipeline < 0:
-        args.pipeline = 1 if (args.streams == 2 and args.orb_split in (0, 2)) else 0
+        args.pipeline = 1 if (args.streams == 2 and args.orb_split != 1) else 0
     if args.orb_split == 0:
         args.orb_split = 2 if (args.streams == 2 or args.pipeline) else 1
     if args.pipeline:
-        assert args.orb_split == 2, "--pipeline 1 runs the left / right images on two extractor handles (--orb-split 2)"
+        assert args.orb_split >= 2, "--pipeline runs the images on two or more extractor handles (--orb-split >= 2)"
     return args
 
 
@@ -236,37 +236,37 @@ def main():
         # for the other's FAST stage, so a FAST launch never runs beside the other FAST launch but under the other handle's oct-tree /
         # descriptor launches; match + triangulation of step k run on a third stream once both handles are done with step k, while the
         # handles already extract step k+1 into the other output buffer
-        extA, extB = ext, orb_exts[0]
-        sA, sB, sM = main_stream, orb_streams[0], torch.cuda.Stream()
-        ev_fast = [torch.cuda.Event(), torch.cuda.Event()]
-        ev_done = [[torch.cuda.Event(), torch.cuda.Event()] for _ in range(NB)]
+        exts = [ext] + orb_exts
+        sX, sM = [main_stream] + orb_streams, torch.cuda.Stream()
+        G = 2 * P // S
+        ev_fast = [torch.cuda.Event() for _ in range(S)]
+        ev_done = [[torch.cuda.Event() for _ in range(S)] for _ in range(NB)]
         ev_match = [torch.cuda.Event() for _ in range(NB)]
         ev_start = torch.cuda.Event()
         for e in ev_fast + [x for pr in ev_done for x in pr] + ev_match + [ev_start]:
             e.record(main_stream)                       # creates the hipEvent_t behind the torch event
-        extA.set_fast_event(ev_fast[0].cuda_event); extB.set_fast_event(ev_fast[1].cuda_event)
-        if args.pipeline == 1:      # gate inside the call: only the FAST stages take turns, the pyramids are not held back
-            extA.set_fast_gate(ev_fast[1].cuda_event); extB.set_fast_gate(ev_fast[0].cuda_event)
+        for i, e in enumerate(exts):
+            e.set_fast_event(ev_fast[i].cuda_event)
+            if args.pipeline == 1:      # gate inside the call: only the FAST stages take turns (ring), the pyramids are not held back
+                e.set_fast_gate(ev_fast[(i - 1) % S].cuda_event)
         step_no = [0]
 
         def step():
             p = step_no[0] % NB
             step_no[0] += 1
             kps, desc, cnt, stat = d_kps_b[p], d_desc_b[p], d_cnt_b[p], d_stat_b[p]
-            if args.pipeline == 2:
-                sA.wait_event(ev_fast[1])               # handle B's FAST of the previous step (whole call held back)
-            sA.wait_event(ev_match[p])                  # buffer p was last read by the match of step k - 2
-            ev_start.record(sA)
-            extA.detect_and_compute_batch(d_imgs.data_ptr(), P, H, W, W, H * W, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(),
-                                          stat.data_ptr(), cap)
-            ev_done[p][0].record(sA)
-            if args.pipeline == 2:
-                sB.wait_event(ev_fast[0])               # handle A's FAST of this step
-            sB.wait_event(ev_match[p])
-            extB.detect_and_compute_batch(d_imgs.data_ptr() + P * H * W, P, H, W, W, H * W, kps.data_ptr() + P * cap * 28,
-                                          desc.data_ptr() + P * cap * 32, cnt.data_ptr() + 4 * P, stat.data_ptr() + 4 * P, cap)
-            ev_done[p][1].record(sB)
-            sM.wait_event(ev_done[p][0]); sM.wait_event(ev_done[p][1])
+            for i, e in enumerate(exts):
+                if args.pipeline == 2:
+                    sX[i].wait_event(ev_fast[(i - 1) % S])      # the previous handle's FAST (whole call held back)
+                sX[i].wait_event(ev_match[p])                   # buffer p was last read by the match of step k - 2
+                if i == 0:
+                    ev_start.record(sX[0])
+                o = i * G
+                e.detect_and_compute_batch(d_imgs.data_ptr() + o * H * W, G, H, W, W, H * W, kps.data_ptr() + o * cap * 28,
+                                           desc.data_ptr() + o * cap * 32, cnt.data_ptr() + 4 * o, stat.data_ptr() + 4 * o, cap)
+                ev_done[p][i].record(sX[i])
+            for i in range(S):
+                sM.wait_event(ev_done[p][i])
             api.hamming_match_batch(desc.data_ptr(), cnt.data_ptr(), desc.data_ptr() + P * cap * 32, cnt.data_ptr() + 4 * P,
                                     P, cap, d_midx.data_ptr(), d_mdist.data_ptr(), sM.cuda_stream)
             api.triangulate_stereo_batch(kps.data_ptr(), kps.data_ptr() + P * cap * 28, d_midx.data_ptr(), cnt.data_ptr(), P, cap,
