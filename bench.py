@@ -39,7 +39,7 @@ ALGO_BYTES = {
 }
 
 
-def pmc_traffic(kernel, pairs):
+def pmc_traffic(kernel, imgs_per_launch):
     """HBM bytes per launch of `kernel` from the committed PMC run (separate rocprofv3 --pmc passes, tools/gpu_traffic.sh)."""
     import glob
     import re
@@ -55,7 +55,10 @@ def pmc_traffic(kernel, pairs):
     for name, v in d["kernels"].items():
         if tag and name.startswith(tag):
             kb = v.get("FETCH_SIZE_KB_per_launch", 0) + v.get("WRITE_SIZE_KB_per_launch", 0)
-            return kb * 1024.0 * pairs / d["pairs_per_step"]
+            # the PMC run counted `launches` launches of this kernel over 3 steps (tools/gpu_traffic.sh: --steps 2 --warmup 1) of
+            # 2 * pairs_per_step images each: bytes per image, times the images one launch of THIS run covers
+            per_image = kb * 1024.0 * v.get("launches", 3) / (d.get("steps_total", 3) * 2.0 * d["pairs_per_step"])
+            return per_image * imgs_per_launch
     return None
 
 
@@ -358,7 +361,7 @@ def main():
             algo = ALGO_BYTES[dom] * imgs_per_launch / launches_per_step        # bytes per launch
             achieved = algo / (per_launch_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, P), "avg_launch_ms": per_launch_ms,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, imgs_per_launch / launches_per_step), "avg_launch_ms": per_launch_ms,
                     "algorithmic_bytes_per_launch": algo,
                     "note": "packed-integer VALU bound in practice (see roofline_valu and DESIGN.md section 6); avg_launch_ms is the event-timed duration of one launch (the left and the right images go through two extractor handles on two streams unless --orb-split 1, so a launch covers half of the step's images), which shares the chip with the other handle's launches, the Gaussian-pyramid launches of the extractors' internal streams and the LCD / DB / BA chain (3.28 ms for all 1024 images when it runs alone: --streams 1 with MYSLAM_ORB_AUX=0); traffic = FETCH_SIZE+WRITE_SIZE of a separate rocprofv3 --pmc run (profiles/), uncorrected"}
         else:

@@ -68,8 +68,8 @@ int myslam_orb_destroy(myslam_orb* h);
  * Gaussian-pyramid launches on an internal stream; they are fenced by events against `hip_stream` on both sides, so for the caller
  * every call still starts after, and completes before, its neighbours on `hip_stream`. */
 int myslam_orb_set_stream(myslam_orb* h, void* hip_stream);
-/* pipelining aid for callers that run several extractor handles on several streams (e.g. the left and the right images of a
- * stereo rig, which the reference extracts one after the other, frontend.cpp:86-94): `hip_event` (a hipEvent_t, NULL = off) is
+/* pipelining aid for callers that run several extractor handles on several streams (two cameras, or the left and the right images
+ * of a batch of stereo pairs): `hip_event` (a hipEvent_t, NULL = off) is
  * recorded on the handle's stream right after the grid-FAST stage of every following batched call.  FAST is the VALU-bound
  * stage, the oct-tree / descriptor stages after it are latency-bound: a second handle whose stream waits for this event runs its
  * own FAST under them instead of beside the first handle's FAST.  No reference counterpart (scheduling only). */

@@ -18,6 +18,6 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
         k = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("myslam_hip::", "")
         agg[k] += float(row["Counter_Value"]); n[k] += 1
     for k in agg: out.setdefault(k, {})[C + "_KB_per_launch"] = agg[k] / n[k]; out[k]["launches"] = n[k]
-print(json.dumps({"pairs_per_step": $P, "note": "raw rocprofv3 counter values (KB) averaged per launch; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md)", "kernels": out}, indent=1))
+print(json.dumps({"pairs_per_step": $P, "steps_total": 3, "note": "raw rocprofv3 counter values (KB) averaged per launch; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md)", "kernels": out}, indent=1))
 PY
 rm -rf gpurun_out/tr_FETCH_SIZE gpurun_out/tr_WRITE_SIZE
