@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void k_blur7_dot(BlurArgs a) {
 // columns 4l..4l+3, loads ONE aligned dword per input row (a fully coalesced 256-byte row segment per wave), gets its
 // neighbours' dwords over the DPP network (wave_shr/shl), keeps the last four vertical pairs of horizontal sums in
 // registers and emits two output rows per two input rows.  No LDS, no barriers.  Needs w >= 8 and taps <= 255.
-constexpr int B3_R = 16;                       // output rows per wave
+constexpr int B3_R = 32;                       // output rows per wave
 
 __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ uint32_t dpp_wave_shl1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
@@ -383,7 +383,6 @@ __global__ __launch_bounds__(256) void k_blur7_strip(BlurArgs a, int nstrips, in
     // column roles
     const bool has = x0 < a.w;                                   // owns at least one image column
     const bool lastq = has && x0 + 4 >= a.w;                     // owns column w-1
-    const bool needL = lane == 0 && x0 > 0;                      // left neighbour lives in another wave
     const bool needR = lane == 63 && x0 + 4 < a.w;
     const int m = a.w - x0;                                      // valid bytes in the last dword (1..4) when lastq
     uint32_t sel1 = 0x07060504u, sel2 = 0;
@@ -411,12 +410,19 @@ __global__ __launch_bounds__(256) void k_blur7_strip(BlurArgs a, int nstrips, in
     const uint32_t t_0 = (uint32_t)a.q[0] << 16, t12 = (uint32_t)a.q[1] | ((uint32_t)a.q[2] << 16);
     const uint32_t t34 = (uint32_t)a.q[3] | ((uint32_t)a.q[4] << 16), t56 = (uint32_t)a.q[5] | ((uint32_t)a.q[6] << 16);
 
-    // the three dwords of one input row this lane needs: own, left neighbour, right neighbour (loads only)
-    auto load_row = [&](int j, uint32_t& c, uint32_t& l, uint32_t& r) {
-        const uint8_t* row = src + (size_t)reflect101(y0 - 3 + j, a.h) * a.spitch;
-        c = has ? *reinterpret_cast<const uint32_t*>(row + x0) : 0u;
-        l = needL ? *reinterpret_cast<const uint32_t*>(row + x0 - 4) : 0u;
-        r = needR ? *reinterpret_cast<const uint32_t*>(row + x0 + 4) : 0u;
+    // the two dwords of one input row this lane loads: its own and — lanes 0 / 63 only — the neighbour strip's adjacent dword (the
+    // other lanes get their neighbours over DPP and re-read their own dword).  Both loads are unconditional from clamped
+    // addresses (rows are mirrored at most once: the launcher guarantees h >= 8; every row holds `spitch` readable bytes): no
+    // branch sits between a load and its use, so the prefetch of the next row pair stays in flight behind a counted s_waitcnt.
+    const int xo = min(x0, a.spitch - 4);
+    const int xe = lane == 0 ? max(x0 - 4, 0) : lane == 63 ? min(x0 + 4, a.spitch - 4) : xo;
+    auto load_row = [&](int j, uint32_t& c, uint32_t& e) {
+        int y = y0 - 3 + j;
+        y = y < 0 ? -y : y;
+        y = y >= a.h ? 2 * a.h - 2 - y : y;
+        const uint8_t* row = src + (size_t)y * a.spitch;
+        c = *reinterpret_cast<const uint32_t*>(row + xo);
+        e = *reinterpret_cast<const uint32_t*>(row + xe);
     };
     // horizontal pass of one row: 4 sums (<= 65280).  The neighbours' dwords arrive over DPP; lanes 0 / 63 have no DPP source and
     // keep the `old` operand = the dword loaded from the adjacent strip.  Waves that touch an image border (edge_tag = true)
@@ -450,17 +456,17 @@ __global__ __launch_bounds__(256) void k_blur7_strip(BlurArgs a, int nstrips, in
         for (int u = 0; u < 4; u++)
 #pragma unroll
             for (int k = 0; k < 4; k++) D[u][k] = 0;
-        uint32_t c0, l0, r0, c1, l1, r1;
-        load_row(0, c0, l0, r0); load_row(1, c1, l1, r1);
+        uint32_t c0, e0, c1, e1;
+        load_row(0, c0, e0); load_row(1, c1, e1);
         for (int base = 0; base < npair; base += 4) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int pi = base + u;
                 if (pi < npair) {
-                    uint32_t nc0 = 0, nl0 = 0, nr0 = 0, nc1 = 0, nl1 = 0, nr1 = 0;
-                    if (pi + 1 < npair) { load_row(2 * pi + 2, nc0, nl0, nr0); load_row(2 * pi + 3, nc1, nl1, nr1); }     // prefetch
+                    uint32_t nc0, ne0, nc1, ne1;
+                    load_row(2 * pi + 2, nc0, ne0); load_row(2 * pi + 3, nc1, ne1);      // prefetch (rows past the band are mirrored / unused)
                     uint32_t he[4], ho[4];
-                    hrow(edge_tag, c0, l0, r0, he); hrow(edge_tag, c1, l1, r1, ho);
+                    hrow(edge_tag, c0, e0, e0, he); hrow(edge_tag, c1, e1, e1, ho);
 #pragma unroll
                     for (int k = 0; k < 4; k++) D[u][k] = he[k] | (ho[k] << 16);
                     if (pi >= 3) {
@@ -482,7 +488,7 @@ __global__ __launch_bounds__(256) void k_blur7_strip(BlurArgs a, int nstrips, in
                             if (oy + 1 < a.h) *reinterpret_cast<uint32_t*>(dst + (size_t)(oy + 1) * a.dpitch + x0) = hi;
                         }
                     }
-                    c0 = nc0; l0 = nl0; r0 = nr0; c1 = nc1; l1 = nl1; r1 = nr1;
+                    c0 = nc0; e0 = ne0; c1 = nc1; e1 = ne1;
                 }
             }
         }
@@ -2410,7 +2416,7 @@ void launch_blur(const BlurArgs& a, int batch, hipStream_t s) {
         }
     }
     const int v = (env && atoi(env) != 4) ? atoi(env) : 3;
-    if (small && v == 3 && a.w >= 8 && (a.spitch & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.src) | a.sstride) & 3) == 0) {
+    if (small && v == 3 && a.w >= 8 && a.h >= 8 && (a.spitch & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.src) | a.sstride) & 3) == 0) {
         const int nstrips = (a.w + 255) / 256, nbands = (a.h + B3_R - 1) / B3_R;
         hipLaunchKernelGGL(k_blur7_strip, dim3((nstrips * nbands + 3) / 4, 1, batch), dim3(256), 0, s, a, nstrips, nbands);
         return;

@@ -74,7 +74,7 @@ def parse():
     ap.add_argument("--cpu-pairs", type=int, default=32)
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
                     help="2 = the DeepLCD / loop-DB / BA chain runs on a second HIP stream beside ORB + match + triangulation")
-    ap.add_argument("--orb-split", type=int, default=0, choices=[0, 1, 2, 4, 8],
+    ap.add_argument("--orb-split", type=int, default=0, choices=[0, 1, 2, 3, 4, 8],
                     help="S > 1 = the 2P images go through S extractor handles on S streams (S equal groups): the latency-bound oct-tree / "
                          "describe launches of one group run under the VALU-bound FAST launch of the other (2 is ~3 % faster than 1; "
                          "concurrent launches stretch each other, so per-launch durations are longer than when a kernel runs alone). "
