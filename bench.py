@@ -85,6 +85,8 @@ def parse():
                          "triangulation follow on a third stream, outputs are double-buffered and consecutive steps overlap (every step's "
                          "work is complete at the closing barrier).  0 = every step is joined before the next starts.  "
                          "-1 (default) = 1 with --streams 2, else 0")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed region: run one joined, un-gated step and check that it reproduces the pipeline's last outputs bit for bit")
     ap.add_argument("--side-delay-ms", type=float, default=0.0, help="experiment: start the side chain this long after the step begins (spin kernel)")
     ap.add_argument("--no-join", action="store_true", help="do not join the side stream at the end of every step (streaming across steps)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -325,6 +327,28 @@ def main():
     dt = time.perf_counter() - t0
     api.prof_enable(False)
     prof = api.prof_read()
+    if args.verify and args.pipeline:
+        # the overlapped schedule must not change a single output: one plain step (handles un-gated, joined) against the last pipelined one
+        p_last = (step_no[0] - 1) % NB
+        outs = lambda p: [d_kps_b[p], d_desc_b[p], d_cnt_b[p], d_stat_b[p], d_midx, d_mdist, d_xyz, d_ok] + \
+            ([d_descr, d_best, d_max, d_dbcnt] if use_lcd else []) + (list(b_out) if use_ba else [])
+        ref = [t.clone() for t in outs(p_last)]
+        for e in exts:
+            e.set_fast_event(0); e.set_fast_gate(0)
+        for t in outs(0):
+            t.zero_()
+        step_joined()
+        torch.cuda.synchronize()
+        n_exact = len(ref) - (len(b_out) if use_ba else 0)        # the BA blocks are f64 atomic sums: equal up to the order of the additions
+        for i, (a, r) in enumerate(zip(outs(0), ref)):
+            if i < n_exact:
+                assert torch.equal(a.view(torch.uint8), r.view(torch.uint8)), f"pipeline output {i} differs from the joined step"
+            else:
+                assert torch.allclose(a, r, rtol=1e-10, atol=1e-10 * float(r.abs().max())), f"pipeline BA output {i} differs from the joined step"
+        for i, e in enumerate(exts):
+            e.set_fast_event(ev_fast[i].cuda_event)
+            if args.pipeline == 1:
+                e.set_fast_gate(ev_fast[(i - 1) % S].cuda_event)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if via_cpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

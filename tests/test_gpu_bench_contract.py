@@ -11,7 +11,7 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("extra", [["--cpu-pairs", "2"], ["--no-cpu-baseline", "--workload", "orb_match", "--streams", "1"]])
+@pytest.mark.parametrize("extra", [["--cpu-pairs", "2", "--verify"], ["--no-cpu-baseline", "--workload", "orb_match", "--streams", "1"]])
 def test_bench_json_contract(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--pairs", "16"] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
@@ -47,7 +47,7 @@ def test_bench_two_ranks_on_one_gpu():
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "16",
-           "--backend", "gloo"]
+           "--backend", "gloo", "--verify"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
