@@ -199,11 +199,58 @@ __global__ __launch_bounds__(256) void k_pool_lrn(const float* __restrict__ in, 
     }
 }
 
+// ---- the same operator for the 128-channel conv2 map, 2 x 2 pooled pixels per wave ----
+// Lane l owns channels (2l, 2l+1): one 8-byte load per input pixel and lane (a coalesced 512-byte row per wave), all 25 loads of the
+// 5 x 5 input block issued before the first use (coordinates clamped instead of clipped: a duplicate does not change a maximum),
+// every input pixel read 1.56 instead of 2.25 times, the LRN neighbours over lane shuffles instead of LDS.  Same maxima, same
+// LRN summation order (channels c-2 .. c+2) as k_pool_lrn<128>: identical results.
+__global__ __launch_bounds__(256) void k_pool_lrn128_2x2(const float* __restrict__ in, int H, int W, int OH, int OW, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int TW = (OW + 1) >> 1, TH = (OH + 1) >> 1;
+    const int tile = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (tile >= TW * TH) return;
+    const int ty = tile / TW, tx = tile - ty * TW;
+    const int oy = 2 * ty, ox = 2 * tx, y0 = 2 * oy, x0 = 2 * ox;
+    const float2* I = reinterpret_cast<const float2*>(in + (size_t)b * H * W * 128) + lane;
+    float2 v[5][5];
+#pragma unroll
+    for (int r = 0; r < 5; r++)
+#pragma unroll
+        for (int c = 0; c < 5; c++) v[r][c] = I[((size_t)min(y0 + r, H - 1) * W + min(x0 + c, W - 1)) * 64];
+    auto pmax = [&](int r0, int c0) {
+        float2 m = v[r0][c0];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) { m.x = fmaxf(m.x, v[r0 + r][c0 + c].x); m.y = fmaxf(m.y, v[r0 + r][c0 + c].y); }
+        return m;
+    };
+    auto lrn_store = [&](float2 m, int py, int px) {
+        float2 pv, nx;
+        pv.x = __shfl_up(m.x, 1, 64); pv.y = __shfl_up(m.y, 1, 64); nx.x = __shfl_down(m.x, 1, 64); nx.y = __shfl_down(m.y, 1, 64);
+        if (lane == 0) pv = make_float2(0.f, 0.f);
+        if (lane == 63) nx = make_float2(0.f, 0.f);
+        float sa = 0.f, sb = 0.f;       // channel 2l: c-2 .. c+2 = pv.x pv.y m.x m.y nx.x; channel 2l+1: pv.y m.x m.y nx.x nx.y
+        sa += pv.x * pv.x; sa += pv.y * pv.y; sa += m.x * m.x; sa += m.y * m.y; sa += nx.x * nx.x;
+        sb += pv.y * pv.y; sb += m.x * m.x; sb += m.y * m.y; sb += nx.x * nx.x; sb += nx.y * nx.y;
+        float2 o;
+        o.x = m.x * lrn_pow_m075(1.f + (1e-4f / 5.f) * sa);
+        o.y = m.y * lrn_pow_m075(1.f + (1e-4f / 5.f) * sb);
+        reinterpret_cast<float2*>(out + ((size_t)b * OH * OW + (size_t)py * OW + px) * 128)[lane] = o;
+    };
+    const bool row1 = oy + 1 < OH, col1 = ox + 1 < OW;           // wave-uniform
+    lrn_store(pmax(0, 0), oy, ox);
+    if (col1) lrn_store(pmax(0, 2), oy, ox + 1);
+    if (row1) lrn_store(pmax(2, 0), oy + 1, ox);
+    if (row1 && col1) lrn_store(pmax(2, 2), oy + 1, ox + 1);
+}
+
 // ---- conv1 + ReLU + max-pool + LRN fused: one wave per POOLED pixel, lane = channel ----
 // The 3x3 (clipped) pool window needs 9 conv1 outputs = a 9x9 input window, which is wave-uniform: it is fetched with
 // scalar loads and fed to v_fmac as SGPR operands, so the conv1 activation map (1.3 MB per image) never exists in HBM.
-// Same operation order per output as k_conv1 + k_pool_lrn (tap order ky,kx; LRN sum over c-2..c+2), so the results are
-// identical to the unfused pair; the LRN neighbours come over lane shuffles instead of LDS.
+// Same operation order per output as k_conv1 + k_pool_lrn (tap order ky,kx; LRN sum over c-2..c+2): the results agree with
+// the unfused pair to the last bit or two (multiply-add contraction); the LRN neighbours come over lane shuffles instead of LDS.
 __global__ __launch_bounds__(256) void k_conv1_pool_lrn(const float* __restrict__ in, const float* __restrict__ w1t /*[25][64]*/,
                                                         const float* __restrict__ b1, float* __restrict__ out /*[HP1*WP1][64]*/) {
     const int b = blockIdx.y;
@@ -248,7 +295,8 @@ __global__ __launch_bounds__(256) void k_conv1_pool_lrn(const float* __restrict_
 // conv1 output 2.25 times.  Here a wave owns a 2 x 2 block of pooled pixels = 5 x 5 conv1 outputs (1.56 per pooled pixel
 // instead of 2.25: -31 % FMAs), walks the conv rows top to bottom (5 input rows x 13 columns of wave-uniform scalars per conv
 // row) and folds each output into the maxima of the pooled pixels it belongs to.  Per output the tap order (ky, kx), bias,
-// ReLU, clipping and the LRN are those of k_conv1_pool_lrn: identical results.
+// ReLU, clipping and the LRN are those of k_conv1_pool_lrn (results agree to the last bit or two: the compiler contracts the
+// multiply-add chains of the two kernels differently).
 constexpr int HT1 = (HP1 + 1) / 2, WT1 = (WP1 + 1) / 2;           // 2 x 2 tiles of the pooled map
 __global__ __launch_bounds__(256) void k_conv1_pool_lrn2(const float* __restrict__ in, const float* __restrict__ w1t /*[25][64]*/,
                                                          const float* __restrict__ b1, float* __restrict__ out /*[HP1*WP1][64]*/) {
@@ -711,7 +759,11 @@ static int lcd_forward(myslam_lcd* h, int batch, float* d_out) {
     }
     {
         ScopedProf sp(P_CONV3, s);
-        hipLaunchKernelGGL((k_pool_lrn<C2>), dim3((HP2 * WP2 + 3) / 4, batch), dim3(256), 0, s, h->d_a2, H2, W2, HP2, WP2, h->d_p2);
+        static const char* envp = getenv("MYSLAM_POOL2_V");         // tuning aid: 1 = one wave per pooled pixel, LRN through LDS
+        if (envp && atoi(envp) == 1)
+            hipLaunchKernelGGL((k_pool_lrn<C2>), dim3((HP2 * WP2 + 3) / 4, batch), dim3(256), 0, s, h->d_a2, H2, W2, HP2, WP2, h->d_p2);
+        else
+            hipLaunchKernelGGL(k_pool_lrn128_2x2, dim3((((HP2 + 1) / 2) * ((WP2 + 1) / 2) + 3) / 4, batch), dim3(256), 0, s, h->d_a2, H2, W2, HP2, WP2, h->d_p2);
         hipLaunchKernelGGL(k_conv3_norm, dim3(batch), dim3(CV3_T), 0, s, h->d_p2, h->d_w3t, h->d_b3, d_out, h->relu3);
     }
     MYSLAM_HIP_CHECK(hipGetLastError());

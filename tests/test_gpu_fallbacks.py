@@ -53,7 +53,7 @@ print("FALLBACK OK")
 
 @pytest.mark.parametrize("env", [
     {"MYSLAM_FAST_V": "3", "MYSLAM_BLUR_V": "2", "MYSLAM_RESIZE_V": "1", "MYSLAM_DESC_V": "1", "MYSLAM_CONV1_V": "1", "MYSLAM_HAMMING_V": "1", "MYSLAM_ORB_AUX": "0", "MYSLAM_CONV2_V": "0", "MYSLAM_LCD_PRE_V": "1", "MYSLAM_DBSCAN_V": "1"},
-    {"MYSLAM_FAST_V": "2", "MYSLAM_BLUR_V": "1", "MYSLAM_ORB_AUX": "1", "MYSLAM_HAMMING_V": "2", "MYSLAM_CONV1_V": "2"},
+    {"MYSLAM_FAST_V": "2", "MYSLAM_BLUR_V": "1", "MYSLAM_ORB_AUX": "1", "MYSLAM_HAMMING_V": "2", "MYSLAM_CONV1_V": "2", "MYSLAM_POOL2_V": "1"},
     {"MYSLAM_FAST_V": "2", "MYSLAM_FAST_T": "64", "MYSLAM_CONV2_V": "1"},
     {"MYSLAM_BLUR_V": "4"},
 ])

@@ -177,3 +177,30 @@ def test_fused_input_equals_two_pass_blur(api, synth, h, w):
     d1, _ = lcd.calcDescrOriginalImg(img, blur_in_place=False)
     d2, _ = lcd.calcDescrOriginalImg(img.copy(), blur_in_place=True)
     assert np.array_equal(d1.view(np.uint32), d2.view(np.uint32))
+
+
+def test_tiled_conv1_and_pool_kernels_against_the_simple_ones():
+    """k_pool_lrn128_2x2 (2 x 2 pooled pixels per wave, LRN over shuffles) returns the bits of k_pool_lrn<128> (MYSLAM_POOL2_V=1);
+    k_conv1_pool_lrn2 agrees with the one-pooled-pixel kernel (MYSLAM_CONV1_V=2) and the unfused conv1 -> pool pair (=1) to a few
+    1e-8 on unit-norm descriptors (same tap order; the compiler contracts the multiply-adds of the three kernels differently)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    child = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+import torch, __graft_entry__ as g
+pkg = g.load_package(); api, synth = pkg.api, pkg.synth
+lcd = api.DeepLCD(synth.calc_weights())
+out = [lcd.calcDescrOriginalImg(synth.random_image(4100 + i, 240, 320))[0] for i in range(4)]
+sys.stdout.buffer.write(np.stack(out).astype(np.float32).tobytes())
+''' % ROOT
+    res = []
+    for env in ({}, {"MYSLAM_POOL2_V": "1"}, {"MYSLAM_CONV1_V": "2"}, {"MYSLAM_CONV1_V": "1"}):
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", child], env=e, capture_output=True, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        res.append(np.frombuffer(r.stdout[-4 * 1064 * 4:], np.float32))
+    assert res[0].size == 4 * 1064 and np.array_equal(res[0].view(np.uint32), res[1].view(np.uint32))
+    assert np.abs(res[2] - res[0]).max() < 2e-7 and np.abs(res[3] - res[0]).max() < 2e-7
