@@ -8,6 +8,7 @@ There is no CPU fallback: a missing library or GPU raises.
 """
 import ctypes as C
 import os
+import re
 
 import numpy as np
 
@@ -29,19 +30,48 @@ class MyslamError(RuntimeError):
         self.code = code
 
 
+HEADER_PATH = os.path.join(_HERE, "..", "include", "myslam_hip.h")
+CAND_DTYPE = np.dtype([("best_id", "<u8"), ("max_score", "<f4"), ("cnt", "<i4")])      # myslam_lcd_candidate
+assert CAND_DTYPE.itemsize == 16
+
 _lib = None
+_SCALARS = {"int": C.c_int, "float": C.c_float, "double": C.c_double, "size_t": C.c_size_t, "uint64_t": C.c_uint64, "long": C.c_long,
+            "int32_t": C.c_int32, "uint8_t": C.c_uint8}
+
+
+def header_prototypes(path=HEADER_PATH):
+    """{function name: (return type, [parameter types])} parsed from include/myslam_hip.h — every pointer is 'ptr'."""
+    txt = open(path).read()
+    txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
+    txt = re.sub(r"//[^\n]*", " ", txt)
+    out = {}
+    for m in re.finditer(r"\b(int|float|size_t|const char\s*\*)\s+(myslam_\w+)\s*\(([^()]*)\)\s*;", txt):
+        ret, name, params = m.group(1), m.group(2), m.group(3).strip()
+        types = []
+        if params and params != "void":
+            for prm in params.split(","):
+                prm = prm.strip()
+                if "*" in prm:
+                    types.append("ptr")
+                else:
+                    toks = [t for t in prm.split() if t != "const"]
+                    types.append(toks[0])
+        out[name] = ("char*" if "char" in ret else ret, types)
+    return out
 
 
 def lib():
-    """Load libmyslam_hip.so (fails loudly when it has not been built)."""
+    """Load libmyslam_hip.so (fails loudly when it has not been built) and declare every prototype of the header, so that 64-bit
+    pointers, size_t and floating-point arguments never depend on how a call site wraps them."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() / build.py first (no CPU fallback)")
         L = C.CDLL(LIB_PATH)
-        L.myslam_hip_version.restype = C.c_char_p
-        L.myslam_lcd_score.restype = C.c_float
-        L.myslam_lcd_nweights.restype = C.c_size_t
+        for name, (ret, types) in header_prototypes().items():
+            fn = getattr(L, name)              # AttributeError = the library does not export what the header declares
+            fn.restype = {"int": C.c_int, "float": C.c_float, "size_t": C.c_size_t, "char*": C.c_char_p}[ret]
+            fn.argtypes = [C.c_void_p if t == "ptr" else _SCALARS[t] for t in types]
         _lib = L
     return _lib
 
@@ -328,6 +358,27 @@ class LoopDatabase:
         cur = np.ascontiguousarray(cur_ids, np.uint64)
         _check(lib().myslam_lcddb_query_batch(self._h, C.c_void_p(d_q), _p(cur), nq, C.c_float(thr_low), C.c_void_p(d_best),
                                               C.c_void_p(d_max), C.c_void_p(d_cnt)), "myslam_lcddb_query_batch")
+
+
+    def query_batch_sharded(self, d_q, cur_ids, nq, d_cand, thr_low=0.92):
+        """per-shard records (myslam_lcd_candidate, 16 bytes each, device memory) for the multi-GPU exchange"""
+        cur = np.ascontiguousarray(cur_ids, np.uint64)
+        _check(lib().myslam_lcddb_query_batch_sharded(self._h, d_q, _p(cur), nq, thr_low, d_cand), "myslam_lcddb_query_batch_sharded")
+
+
+def lcd_merge_candidates(gathered):
+    """gathered: [nshards, nq] CAND_DTYPE records in ascending id-range order (host) -> (best_id u64, max_score f32, cnt i32)"""
+    g = np.ascontiguousarray(gathered, CAND_DTYPE)
+    assert g.ndim == 2
+    ns, nq = g.shape
+    best = np.zeros(nq, np.uint64); mx = np.zeros(nq, np.float32); cnt = np.zeros(nq, np.int32)
+    _check(lib().myslam_lcd_merge_candidates(_p(g), ns, nq, _p(best), _p(mx), _p(cnt)), "myslam_lcd_merge_candidates")
+    return best, mx, cnt
+
+
+def lcd_merge_candidates_device(d_gathered, nshards, nq, d_best, d_max, d_cnt, stream=0):
+    _check(lib().myslam_lcd_merge_candidates_device(d_gathered, nshards, nq, d_best, d_max, d_cnt, stream or None),
+           "myslam_lcd_merge_candidates_device")
 
 
 # ---------------------------------------------------------------------------------- BA

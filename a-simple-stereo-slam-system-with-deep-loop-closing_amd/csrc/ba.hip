@@ -23,9 +23,12 @@ struct BaArgs {
 __global__ __launch_bounds__(256) void k_ba_build(BaArgs a) {
     extern __shared__ __attribute__((aligned(16))) double s_d[];
     const int w = blockIdx.x, t = threadIdx.x;
-    const int P = a.sizes ? a.sizes[3 * w] : a.nposes;
-    const int L = a.sizes ? a.sizes[3 * w + 1] : a.npts;
-    const int E = a.sizes ? a.sizes[3 * w + 2] : a.nedges;
+    int P = a.sizes ? a.sizes[3 * w] : a.nposes;
+    int L = a.sizes ? a.sizes[3 * w + 1] : a.npts;
+    int E = a.sizes ? a.sizes[3 * w + 2] : a.nedges;
+    // a window whose sizes do not fit the common capacities would overrun LDS: it is skipped (outputs zero, chi2[0] = -1)
+    const bool oversize = P < 0 || L < 0 || E < 0 || P > a.maxP || L > a.maxL || E > a.maxE;
+    if (oversize) { P = 0; L = 0; E = 0; if (t == 0) a.chi2[(size_t)w * a.maxE] = -1.0; }
     double* sR = s_d;                        // maxP x 12 (R row-major, t)
     double* sHpp = sR + a.maxP * 12;         // maxP x 21 (upper triangle, row-major)
     double* sbp = sHpp + a.maxP * 21;        // maxP x 6
@@ -810,11 +813,9 @@ static int ba_opt_launch(const BaOptArgs& a, int nwin, hipStream_t s) {
     if (a.maxP > 10) return MYSLAM_ERR_CAPACITY;          // substitution runs on one wave: 6P <= 64; 55 pose pairs x 8 slices <= 512 threads
     const size_t lds = ba_opt_lds(a.maxP, a.maxL);
     if (lds > 160 * 1024 - 512) return MYSLAM_ERR_CAPACITY;
-    static size_t attr = 0;
-    if (lds > 48 * 1024 && lds > attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_optimize), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = lds;
-    }
+    // the attribute is per device and per process: set it on every launch that needs it (cheap, re-entrant, multi-GPU safe)
+    if (lds > 48 * 1024)
+        MYSLAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_optimize), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ScopedProf sp(P_BA, s);
     hipLaunchKernelGGL(k_ba_optimize, dim3(nwin), dim3(BA_NT), lds, s, a);
     MYSLAM_HIP_CHECK(hipGetLastError());
@@ -1030,11 +1031,8 @@ static size_t ba_lds(int maxP, int maxL) { return sizeof(double) * ((size_t)maxP
 static int ba_launch(const BaArgs& a, int nwin, hipStream_t s) {
     const size_t lds = ba_lds(a.maxP, a.maxL);
     if (lds > 150 * 1024) return MYSLAM_ERR_CAPACITY;
-    static size_t attr = 0;
-    if (lds > 48 * 1024 && lds > attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = lds;
-    }
+    if (lds > 48 * 1024)
+        MYSLAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ScopedProf sp(P_BA, s);
     hipLaunchKernelGGL(k_ba_build, dim3(nwin), dim3(256), lds, s, a);
     MYSLAM_HIP_CHECK(hipGetLastError());
@@ -1069,37 +1067,19 @@ int myslam_ba_build(const double* poses, int nposes, const double* points, int n
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MYSLAM_ERR_HIP;
     const int E = nedges > 0 ? nedges : 1;
-    const size_t nd = (size_t)nposes * 7 + (size_t)npts * 3 + (size_t)E * 2 + (size_t)nposes * 36 + (size_t)npts * 9 +
-                      (size_t)E * 18 + (size_t)nposes * 6 + (size_t)npts * 3 + (size_t)E;
-    double* d = nullptr; int32_t* di = nullptr; uint8_t* df = nullptr;
-    MYSLAM_HIP_CHECK(hipMalloc((void**)&d, nd * sizeof(double)));
-    MYSLAM_HIP_CHECK(hipMalloc((void**)&di, (size_t)E * 2 * sizeof(int32_t)));
-    MYSLAM_HIP_CHECK(hipMalloc((void**)&df, (size_t)npts));
-    double* d_poses = d; double* d_pts = d_poses + (size_t)nposes * 7; double* d_obs = d_pts + (size_t)npts * 3;
-    double* d_Hpp = d_obs + (size_t)E * 2; double* d_Hll = d_Hpp + (size_t)nposes * 36; double* d_Hpl = d_Hll + (size_t)npts * 9;
-    double* d_bp = d_Hpl + (size_t)E * 18; double* d_bl = d_bp + (size_t)nposes * 6; double* d_chi = d_bl + (size_t)npts * 3;
-    MYSLAM_HIP_CHECK(hipMemcpy(d_poses, poses, sizeof(double) * nposes * 7, hipMemcpyHostToDevice));
-    MYSLAM_HIP_CHECK(hipMemcpy(d_pts, points, sizeof(double) * npts * 3, hipMemcpyHostToDevice));
-    if (nedges) {
-        MYSLAM_HIP_CHECK(hipMemcpy(d_obs, obs, sizeof(double) * nedges * 2, hipMemcpyHostToDevice));
-        MYSLAM_HIP_CHECK(hipMemcpy(di, edge_pose, sizeof(int32_t) * nedges, hipMemcpyHostToDevice));
-        MYSLAM_HIP_CHECK(hipMemcpy(di + E, edge_pt, sizeof(int32_t) * nedges, hipMemcpyHostToDevice));
-    }
-    if (fixed_pt) MYSLAM_HIP_CHECK(hipMemcpy(df, fixed_pt, npts, hipMemcpyHostToDevice));
-    BaArgs a{d_poses, d_pts, di, di + E, d_obs, fixed_pt ? df : nullptr, nullptr, nposes, npts, nedges, nposes, npts, E,
-             fx, fy, cx, cy, huber_delta, d_Hpp, d_Hll, d_Hpl, d_bp, d_bl, d_chi};
-    int rc = ba_launch(a, 1, nullptr);
+    HostCall hc;
+    const int i_p = hc.in(poses, (size_t)nposes * 7), i_x = hc.in(points, (size_t)npts * 3), i_o = hc.in(obs, (size_t)nedges * 2);
+    const int i_ep = hc.in(edge_pose, (size_t)nedges), i_el = hc.in(edge_pt, (size_t)nedges), i_f = hc.in(fixed_pt, fixed_pt ? (size_t)npts : 0);
+    const int o_pp = hc.out(Hpp, (size_t)nposes * 36), o_ll = hc.out(Hll, (size_t)npts * 9), o_pl = hc.out(Hpl, (size_t)nedges * 18);
+    const int o_bp = hc.out(bp, (size_t)nposes * 6), o_bl = hc.out(bl, (size_t)npts * 3), o_c = hc.out(chi2, (size_t)nedges);
+    int rc = hc.upload();
     if (rc) return rc;
-    MYSLAM_HIP_CHECK(hipMemcpy(Hpp, d_Hpp, sizeof(double) * nposes * 36, hipMemcpyDeviceToHost));
-    MYSLAM_HIP_CHECK(hipMemcpy(Hll, d_Hll, sizeof(double) * npts * 9, hipMemcpyDeviceToHost));
-    MYSLAM_HIP_CHECK(hipMemcpy(bp, d_bp, sizeof(double) * nposes * 6, hipMemcpyDeviceToHost));
-    MYSLAM_HIP_CHECK(hipMemcpy(bl, d_bl, sizeof(double) * npts * 3, hipMemcpyDeviceToHost));
-    if (nedges) {
-        MYSLAM_HIP_CHECK(hipMemcpy(Hpl, d_Hpl, sizeof(double) * nedges * 18, hipMemcpyDeviceToHost));
-        MYSLAM_HIP_CHECK(hipMemcpy(chi2, d_chi, sizeof(double) * nedges, hipMemcpyDeviceToHost));
-    }
-    (void)hipFree(d); (void)hipFree(di); (void)hipFree(df);
-    return MYSLAM_OK;
+    BaArgs a{hc.dev<double>(i_p), hc.dev<double>(i_x), hc.dev<int32_t>(i_ep), hc.dev<int32_t>(i_el), hc.dev<double>(i_o),
+             fixed_pt ? hc.dev<uint8_t>(i_f) : nullptr, nullptr, nposes, npts, nedges, nposes, npts, E,
+             fx, fy, cx, cy, huber_delta, hc.dev<double>(o_pp), hc.dev<double>(o_ll), hc.dev<double>(o_pl), hc.dev<double>(o_bp),
+             hc.dev<double>(o_bl), hc.dev<double>(o_c)};
+    if ((rc = ba_launch(a, 1, hc.stream()))) return rc;
+    return hc.download();
 }
 
 int myslam_ba_optimize_batch(double* d_poses, double* d_points, const int32_t* d_edge_pose, const int32_t* d_edge_pt, const double* d_obs,
@@ -1120,27 +1100,19 @@ int myslam_ba_optimize(double* poses, int nposes, double* points, int npts, cons
     if (!poses || !points || nposes < 1 || npts < 1 || nedges < 1 || !edge_pose || !edge_pt || !obs || max_iters < 1) return MYSLAM_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MYSLAM_ERR_HIP;
-    double *d_p = nullptr, *d_x = nullptr, *d_o = nullptr, *d_w = nullptr, *d_chi = nullptr; int32_t *d_i = nullptr, *d_st = nullptr; uint8_t* d_f = nullptr;
-    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_p, sizeof(double) * nposes * 7)); MYSLAM_HIP_CHECK(hipMalloc((void**)&d_x, sizeof(double) * npts * 3));
-    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_o, sizeof(double) * nedges * 2)); MYSLAM_HIP_CHECK(hipMalloc((void**)&d_w, sizeof(double) * nedges * 18));
-    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_chi, sizeof(double))); MYSLAM_HIP_CHECK(hipMalloc((void**)&d_i, sizeof(int32_t) * (2 * nedges + 2)));
-    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_f, npts)); d_st = d_i + 2 * nedges;
-    MYSLAM_HIP_CHECK(hipMemcpy(d_p, poses, sizeof(double) * nposes * 7, hipMemcpyHostToDevice));
-    MYSLAM_HIP_CHECK(hipMemcpy(d_x, points, sizeof(double) * npts * 3, hipMemcpyHostToDevice));
-    MYSLAM_HIP_CHECK(hipMemcpy(d_o, obs, sizeof(double) * nedges * 2, hipMemcpyHostToDevice));
-    MYSLAM_HIP_CHECK(hipMemcpy(d_i, edge_pose, sizeof(int32_t) * nedges, hipMemcpyHostToDevice));
-    MYSLAM_HIP_CHECK(hipMemcpy(d_i + nedges, edge_pt, sizeof(int32_t) * nedges, hipMemcpyHostToDevice));
-    if (fixed_pt) MYSLAM_HIP_CHECK(hipMemcpy(d_f, fixed_pt, npts, hipMemcpyHostToDevice));
-    BaOptArgs a{d_p, d_x, d_i, d_i + nedges, d_o, fixed_pt ? d_f : nullptr, nullptr, nposes, npts, nedges, nposes, npts, nedges,
-                fx, fy, cx, cy, huber_delta, max_iters, d_w, d_chi, d_st + 1, d_st, 1, 0.0, nullptr, nullptr, nullptr, nullptr};
-    int rc = ba_opt_launch(a, 1, nullptr);
+    HostCall hc;
+    int32_t st[2] = {0, 0}; double chi = 0;
+    const int i_p = hc.inout(poses, (size_t)nposes * 7), i_x = hc.inout(points, (size_t)npts * 3), i_o = hc.in(obs, (size_t)nedges * 2);
+    const int i_ep = hc.in(edge_pose, (size_t)nedges), i_el = hc.in(edge_pt, (size_t)nedges), i_f = hc.in(fixed_pt, fixed_pt ? (size_t)npts : 0);
+    const int o_st = hc.out(st, 2), o_chi = hc.out(&chi, 1), t_w = hc.tmp<double>((size_t)nedges * 18);
+    int rc = hc.upload();
     if (rc) return rc;
-    int32_t st[2]; double chi;
-    MYSLAM_HIP_CHECK(hipMemcpy(st, d_st, sizeof(st), hipMemcpyDeviceToHost));
-    MYSLAM_HIP_CHECK(hipMemcpy(&chi, d_chi, sizeof(double), hipMemcpyDeviceToHost));
-    MYSLAM_HIP_CHECK(hipMemcpy(poses, d_p, sizeof(double) * nposes * 7, hipMemcpyDeviceToHost));
-    MYSLAM_HIP_CHECK(hipMemcpy(points, d_x, sizeof(double) * npts * 3, hipMemcpyDeviceToHost));
-    (void)hipFree(d_p); (void)hipFree(d_x); (void)hipFree(d_o); (void)hipFree(d_w); (void)hipFree(d_chi); (void)hipFree(d_i); (void)hipFree(d_f);
+    int32_t* d_st = hc.dev<int32_t>(o_st);
+    BaOptArgs a{hc.dev<double>(i_p), hc.dev<double>(i_x), hc.dev<int32_t>(i_ep), hc.dev<int32_t>(i_el), hc.dev<double>(i_o),
+                fixed_pt ? hc.dev<uint8_t>(i_f) : nullptr, nullptr, nposes, npts, nedges, nposes, npts, nedges,
+                fx, fy, cx, cy, huber_delta, max_iters, hc.dev<double>(t_w), hc.dev<double>(o_chi), d_st + 1, d_st, 1, 0.0, nullptr, nullptr, nullptr, nullptr};
+    if ((rc = ba_opt_launch(a, 1, hc.stream()))) return rc;
+    if ((rc = hc.download())) return rc;
     if (final_chi2) *final_chi2 = chi;
     if (iters) *iters = st[1];
     return st[0];
@@ -1169,28 +1141,21 @@ int myslam_ba_optimize_active_map(double* poses, int nposes, double* points, int
         return MYSLAM_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MYSLAM_ERR_HIP;
-    double *d_p = nullptr, *d_x = nullptr, *d_o = nullptr, *d_w = nullptr, *d_chi = nullptr; int32_t *d_i = nullptr, *d_st = nullptr; uint8_t *d_f = nullptr, *d_out = nullptr;
-    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_p, sizeof(double) * nposes * 7)); MYSLAM_HIP_CHECK(hipMalloc((void**)&d_x, sizeof(double) * npts * 3));
-    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_o, sizeof(double) * nedges * 2)); MYSLAM_HIP_CHECK(hipMalloc((void**)&d_w, sizeof(double) * nedges * 18));
-    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_chi, sizeof(double) * nedges)); MYSLAM_HIP_CHECK(hipMalloc((void**)&d_i, sizeof(int32_t) * (2 * nedges + 3)));
-    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_f, npts)); MYSLAM_HIP_CHECK(hipMalloc((void**)&d_out, nedges)); d_st = d_i + 2 * nedges;
-    MYSLAM_HIP_CHECK(hipMemcpy(d_p, poses, sizeof(double) * nposes * 7, hipMemcpyHostToDevice));
-    MYSLAM_HIP_CHECK(hipMemcpy(d_x, points, sizeof(double) * npts * 3, hipMemcpyHostToDevice));
-    MYSLAM_HIP_CHECK(hipMemcpy(d_o, obs, sizeof(double) * nedges * 2, hipMemcpyHostToDevice));
-    MYSLAM_HIP_CHECK(hipMemcpy(d_i, edge_pose, sizeof(int32_t) * nedges, hipMemcpyHostToDevice));
-    MYSLAM_HIP_CHECK(hipMemcpy(d_i + nedges, edge_pt, sizeof(int32_t) * nedges, hipMemcpyHostToDevice));
-    if (fixed_pt) MYSLAM_HIP_CHECK(hipMemcpy(d_f, fixed_pt, npts, hipMemcpyHostToDevice));
-    BaOptArgs a{d_p, d_x, d_i, d_i + nedges, d_o, fixed_pt ? d_f : nullptr, nullptr, nposes, npts, nedges, nposes, npts, nedges,
-                fx, fy, cx, cy, huber_delta, iters_per_round, d_w, nullptr, nullptr, d_st, max_rounds, chi2_th, d_chi, d_out, d_st + 1, d_st + 2};
-    int rc = ba_opt_launch(a, 1, nullptr);
+    HostCall hc;
+    int32_t st[3] = {0, 0, 0};
+    const int i_p = hc.inout(poses, (size_t)nposes * 7), i_x = hc.inout(points, (size_t)npts * 3), i_o = hc.in(obs, (size_t)nedges * 2);
+    const int i_ep = hc.in(edge_pose, (size_t)nedges), i_el = hc.in(edge_pt, (size_t)nedges), i_f = hc.in(fixed_pt, fixed_pt ? (size_t)npts : 0);
+    const int o_st = hc.out(st, 3), o_chi = hc.out(edge_chi2, (size_t)nedges), o_out = hc.out(outlier, (size_t)nedges);
+    const int t_w = hc.tmp<double>((size_t)nedges * 18);
+    int rc = hc.upload();
     if (rc) return rc;
-    int32_t st[3];
-    MYSLAM_HIP_CHECK(hipMemcpy(st, d_st, sizeof(st), hipMemcpyDeviceToHost));
-    MYSLAM_HIP_CHECK(hipMemcpy(edge_chi2, d_chi, sizeof(double) * nedges, hipMemcpyDeviceToHost));
-    MYSLAM_HIP_CHECK(hipMemcpy(outlier, d_out, nedges, hipMemcpyDeviceToHost));
-    MYSLAM_HIP_CHECK(hipMemcpy(poses, d_p, sizeof(double) * nposes * 7, hipMemcpyDeviceToHost));
-    MYSLAM_HIP_CHECK(hipMemcpy(points, d_x, sizeof(double) * npts * 3, hipMemcpyDeviceToHost));
-    (void)hipFree(d_p); (void)hipFree(d_x); (void)hipFree(d_o); (void)hipFree(d_w); (void)hipFree(d_chi); (void)hipFree(d_i); (void)hipFree(d_f); (void)hipFree(d_out);
+    int32_t* d_st = hc.dev<int32_t>(o_st);
+    BaOptArgs a{hc.dev<double>(i_p), hc.dev<double>(i_x), hc.dev<int32_t>(i_ep), hc.dev<int32_t>(i_el), hc.dev<double>(i_o),
+                fixed_pt ? hc.dev<uint8_t>(i_f) : nullptr, nullptr, nposes, npts, nedges, nposes, npts, nedges,
+                fx, fy, cx, cy, huber_delta, iters_per_round, hc.dev<double>(t_w), nullptr, nullptr, d_st, max_rounds, chi2_th,
+                hc.dev<double>(o_chi), hc.dev<uint8_t>(o_out), d_st + 1, d_st + 2};
+    if ((rc = ba_opt_launch(a, 1, hc.stream()))) return rc;
+    if ((rc = hc.download())) return rc;
     if (rounds) *rounds = st[1];
     if (n_outliers) *n_outliers = st[2];
     return st[0];
@@ -1215,23 +1180,18 @@ int myslam_pose_only_optimize(double* pose7, const double* pts3d, const double* 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MYSLAM_ERR_HIP;
     const int m = n > 0 ? n : 1;
-    double *d_p = nullptr, *d_x = nullptr, *d_o = nullptr; uint8_t* d_out = nullptr; int32_t* d_i = nullptr;
-    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_p, sizeof(double) * 7)); MYSLAM_HIP_CHECK(hipMalloc((void**)&d_x, sizeof(double) * 3 * m));
-    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_o, sizeof(double) * 2 * m)); MYSLAM_HIP_CHECK(hipMalloc((void**)&d_out, m));
-    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_i, sizeof(int32_t) * 2));
-    MYSLAM_HIP_CHECK(hipMemcpy(d_p, pose7, sizeof(double) * 7, hipMemcpyHostToDevice));
-    if (n) {
-        MYSLAM_HIP_CHECK(hipMemcpy(d_x, pts3d, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
-        MYSLAM_HIP_CHECK(hipMemcpy(d_o, obs, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
-    }
-    PoseOnlyArgs a{d_p, d_x, d_o, nullptr, n, m, fx, fy, cx, cy, chi2_th, rounds, iters, pre_optimize, d_out, d_i, d_i + 1};
-    hipLaunchKernelGGL(k_pose_only, dim3(1), dim3(BA_NT), 0, nullptr, a);
+    HostCall hc;
+    int32_t st[2] = {0, 0};
+    const int i_p = hc.inout(pose7, 7), i_x = hc.in(pts3d, (size_t)3 * n), i_o = hc.in(obs, (size_t)2 * n);
+    const int o_st = hc.out(st, 2), o_out = hc.out(outlier, (size_t)n);
+    int rc = hc.upload();
+    if (rc) return rc;
+    int32_t* d_i = hc.dev<int32_t>(o_st);
+    PoseOnlyArgs a{hc.dev<double>(i_p), hc.dev<double>(i_x), hc.dev<double>(i_o), nullptr, n, m, fx, fy, cx, cy, chi2_th, rounds, iters, pre_optimize,
+                   hc.dev<uint8_t>(o_out), d_i, d_i + 1};
+    hipLaunchKernelGGL(k_pose_only, dim3(1), dim3(BA_NT), 0, hc.stream(), a);
     MYSLAM_HIP_CHECK(hipGetLastError());
-    int32_t st[2];
-    MYSLAM_HIP_CHECK(hipMemcpy(st, d_i, sizeof(st), hipMemcpyDeviceToHost));
-    MYSLAM_HIP_CHECK(hipMemcpy(pose7, d_p, sizeof(double) * 7, hipMemcpyDeviceToHost));
-    if (n) MYSLAM_HIP_CHECK(hipMemcpy(outlier, d_out, n, hipMemcpyDeviceToHost));
-    (void)hipFree(d_p); (void)hipFree(d_x); (void)hipFree(d_o); (void)hipFree(d_out); (void)hipFree(d_i);
+    if ((rc = hc.download())) return rc;
     if (n_inliers) *n_inliers = st[0];
     return st[1];
 }

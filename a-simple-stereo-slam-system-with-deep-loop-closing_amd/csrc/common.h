@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "../../include/myslam_hip.h"
 
@@ -33,6 +34,44 @@ struct ScopedProf {
     int id; hipStream_t s;
     ScopedProf(int id_, hipStream_t s_) : id(id_), s(s_) { prof_begin(id, s); }
     ~ScopedProf() { prof_end(id, s); }
+};
+
+// ---- staging of the host-pointer ("drop-in", B = 1) entry points --------------------------------------------------------------
+// One grow-only device block, one pinned host block and one stream per calling THREAD, carved into 256-byte aligned pieces per
+// call: no hipMalloc / hipFree per call, one host->device and one device->host copy per call, and nothing to free on an error
+// return (the arena owns the memory).  Pieces are laid out [in][inout][out][tmp]; `upload()` copies in + inout, `download()` copies
+// inout + out back and synchronises.  Usage: register pieces, upload(), launch on stream() with dev<T>(piece), download().
+struct HostArena {
+    uint8_t* d = nullptr; uint8_t* h = nullptr; size_t cap = 0; hipStream_t s = nullptr;
+    ~HostArena();
+    int ensure(size_t bytes);
+};
+HostArena& host_arena();
+
+class HostCall {
+  public:
+    enum Kind { IN = 0, INOUT = 1, OUT = 2, TMP = 3 };
+    HostCall() : A(host_arena()) {}
+    template <class T> int in(const T* p, size_t n) { return add(IN, p, nullptr, n * sizeof(T)); }
+    template <class T> int inout(T* p, size_t n) { return add(INOUT, p, p, n * sizeof(T)); }
+    template <class T> int out(T* p, size_t n) { return add(OUT, nullptr, p, n * sizeof(T)); }
+    template <class T> int tmp(size_t n) { return add(TMP, nullptr, nullptr, n * sizeof(T)); }
+    int upload();
+    int download();
+    template <class T> T* dev(int piece) const { return reinterpret_cast<T*>(A.d + pc[piece].off); }
+    hipStream_t stream() const { return A.s; }
+
+  private:
+    struct Piece { Kind kind; const void* src; void* dst; size_t bytes, off; };
+    int add(Kind k, const void* src, void* dst, size_t bytes) {
+        if (npc >= MAXP) return -1;
+        pc[npc] = {k, src, dst, bytes, 0};
+        return npc++;
+    }
+    static constexpr int MAXP = 24;
+    HostArena& A;
+    Piece pc[MAXP]; int npc = 0;
+    size_t endIn = 0, begOut = 0, endOut = 0;
 };
 
 template <typename T>

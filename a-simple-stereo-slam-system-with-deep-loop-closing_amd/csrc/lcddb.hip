@@ -298,6 +298,40 @@ __global__ __launch_bounds__(256) void k_db_reduce(const Partial* __restrict__ p
     max_score[qi] = ms; cnt[qi] = c;
 }
 
+// per-shard result of a query in the layout that travels between ranks: cnt bit 31 = this shard's scan hit the break (:133)
+__global__ __launch_bounds__(256) void k_db_pack_candidates(const uint64_t* __restrict__ best_id, const float* __restrict__ max_score,
+                                                            const int32_t* __restrict__ cnt, const int32_t* __restrict__ nvalid, int nrows,
+                                                            int nq, myslam_lcd_candidate* __restrict__ out) {
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    myslam_lcd_candidate c;
+    c.best_id = best_id[qi]; c.max_score = max_score[qi];
+    c.cnt = (cnt[qi] & 0x7fffffff) | (nvalid[qi] < nrows ? (int32_t)0x80000000 : 0);
+    out[qi] = c;
+}
+
+// The reference's ONE ascending scan (loopclosing.cpp:124-161) over shards that own ascending id ranges: strict '>' keeps the
+// first (= lowest-id) maximum, counts add up, and the first shard whose own scan hit the break ends the whole scan.
+__host__ __device__ inline void merge_one(const myslam_lcd_candidate* g, int nshards, int nq, int qi, uint64_t& best, float& ms, int32_t& cnt) {
+    best = 0; ms = 0.f; cnt = 0;
+    for (int s = 0; s < nshards; s++) {
+        const myslam_lcd_candidate c = g[(size_t)s * nq + qi];
+        if (c.max_score > ms) { ms = c.max_score; best = c.best_id; }
+        cnt += c.cnt & 0x7fffffff;
+        if (c.cnt < 0) break;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_db_merge_candidates(const myslam_lcd_candidate* __restrict__ g, int nshards, int nq,
+                                                             uint64_t* __restrict__ best_id, float* __restrict__ max_score,
+                                                             int32_t* __restrict__ cnt) {
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    uint64_t b; float m; int32_t c;
+    merge_one(g, nshards, nq, qi, b, m, c);
+    best_id[qi] = b; max_score[qi] = m; cnt[qi] = c;
+}
+
 }  // namespace myslam_hip
 
 using namespace myslam_hip;
@@ -312,6 +346,7 @@ struct myslam_lcddb {
     int32_t* d_nvalid = nullptr; int nvalidCap = 0;
     int32_t* h_nvalid = nullptr; hipEvent_t nvEvent = nullptr;      // pinned staging of the per-query row limits + "copy done" event
     float* d_q1 = nullptr; uint64_t* d_best1 = nullptr; float* d_max1 = nullptr; int32_t* d_cnt1 = nullptr;
+    uint64_t* d_bestS = nullptr; float* d_maxS = nullptr; int32_t* d_cntS = nullptr; int shardCap = 0;     // scratch of the sharded query
 
     // index of the first row the reference's scan does NOT look at: it breaks at the first id with
     // (cur - id) < 20 in unsigned arithmetic (loopclosing.cpp:133), i.e. id in [cur-19, cur] mod 2^64
@@ -348,7 +383,7 @@ int myslam_lcddb_create(myslam_lcddb** out, int capacity) {
 int myslam_lcddb_destroy(myslam_lcddb* h) {
     if (!h) return MYSLAM_ERR_INVALID;
     (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->d_db, h->d_ids, h->d_partials, h->d_nvalid, h->d_q1, h->d_best1, h->d_max1, h->d_cnt1};
+    void* ptrs[] = {h->d_db, h->d_ids, h->d_partials, h->d_nvalid, h->d_q1, h->d_best1, h->d_max1, h->d_cnt1, h->d_bestS, h->d_maxS, h->d_cntS};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_nvalid) (void)hipHostFree(h->h_nvalid);
     if (h->nvEvent) (void)hipEventDestroy(h->nvEvent);
@@ -442,6 +477,42 @@ int myslam_lcddb_query_batch(myslam_lcddb* h, const float* d_q, const uint64_t* 
                              uint64_t* d_best_id, float* d_max_score, int32_t* d_cnt) {
     if (!h || !d_q || !cur_ids || nq < 1 || nq > 65536 || !d_best_id || !d_max_score || !d_cnt) return MYSLAM_ERR_INVALID;
     return db_query(h, d_q, cur_ids, nq, thr_low, d_best_id, d_max_score, d_cnt);
+}
+
+int myslam_lcddb_query_batch_sharded(myslam_lcddb* h, const float* d_q, const uint64_t* cur_ids, int nq, float thr_low,
+                                     myslam_lcd_candidate* d_cand) {
+    if (!h || !d_q || !cur_ids || nq < 1 || nq > 65536 || !d_cand) return MYSLAM_ERR_INVALID;
+    if (nq > h->shardCap) {
+        MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+        void* old[] = {h->d_bestS, h->d_maxS, h->d_cntS};
+        for (void* p : old) if (p) (void)hipFree(p);
+        h->d_bestS = nullptr; h->d_maxS = nullptr; h->d_cntS = nullptr; h->shardCap = 0;
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_bestS, sizeof(uint64_t) * nq));
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_maxS, sizeof(float) * nq));
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_cntS, sizeof(int32_t) * nq));
+        h->shardCap = nq;
+    }
+    int rc = db_query(h, d_q, cur_ids, nq, thr_low, h->d_bestS, h->d_maxS, h->d_cntS);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_db_pack_candidates, dim3((nq + 255) / 256), dim3(256), 0, h->stream, h->d_bestS, h->d_maxS, h->d_cntS, h->d_nvalid,
+                       h->n, nq, d_cand);
+    MYSLAM_HIP_CHECK(hipGetLastError());
+    return MYSLAM_OK;
+}
+
+int myslam_lcd_merge_candidates(const myslam_lcd_candidate* gathered, int nshards, int nq, uint64_t* best_id, float* max_score, int32_t* cnt) {
+    if (!gathered || nshards < 1 || nq < 0 || !best_id || !max_score || !cnt) return MYSLAM_ERR_INVALID;
+    for (int qi = 0; qi < nq; qi++) merge_one(gathered, nshards, nq, qi, best_id[qi], max_score[qi], cnt[qi]);
+    return MYSLAM_OK;
+}
+
+int myslam_lcd_merge_candidates_device(const myslam_lcd_candidate* d_gathered, int nshards, int nq, uint64_t* d_best_id, float* d_max_score,
+                                       int32_t* d_cnt, void* hip_stream) {
+    if (!d_gathered || nshards < 1 || nq < 1 || !d_best_id || !d_max_score || !d_cnt) return MYSLAM_ERR_INVALID;
+    hipLaunchKernelGGL(k_db_merge_candidates, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, d_gathered, nshards, nq, d_best_id,
+                       d_max_score, d_cnt);
+    MYSLAM_HIP_CHECK(hipGetLastError());
+    return MYSLAM_OK;
 }
 
 int myslam_lcddb_query(myslam_lcddb* h, const float* descr, uint64_t cur_id, float thr_low, uint64_t* best_id, float* max_score,

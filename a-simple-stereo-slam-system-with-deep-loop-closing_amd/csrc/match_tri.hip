@@ -377,7 +377,8 @@ __global__ __launch_bounds__(256) void k_triangulate(const float* __restrict__ x
     double ul, vl, ur, vr;
     if (kl) {
         const int j = match[o];
-        if (j < 0) { ok[o] = 0; xyz[3 * o] = xyz[3 * o + 1] = xyz[3 * o + 2] = 0; return; }
+        if (j < 0 || j >= cap) { ok[o] = 0;      // no match (or an index outside the pair's slots: treated as none)
+            xyz[3 * o] = xyz[3 * o + 1] = xyz[3 * o + 2] = 0; return; }
         ul = kl[o].x; vl = kl[o].y;
         const myslam_keypoint r = kr[(size_t)p * cap + j];
         ur = r.x; vr = r.y;
@@ -423,29 +424,28 @@ int myslam_hamming_match(const uint8_t* query, int nq, const uint8_t* train, int
     if (nt >= (1 << 20)) return MYSLAM_ERR_UNSUPPORTED;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MYSLAM_ERR_HIP;
-    uint8_t *dq = nullptr, *dt = nullptr; int32_t *di = nullptr, *dd = nullptr;
     const int cap = std::max(nq, std::max(nt, 1));
-    MYSLAM_HIP_CHECK(hipMalloc((void**)&dq, (size_t)cap * 32)); MYSLAM_HIP_CHECK(hipMalloc((void**)&dt, (size_t)cap * 32));
-    MYSLAM_HIP_CHECK(hipMalloc((void**)&di, (size_t)cap * 4)); MYSLAM_HIP_CHECK(hipMalloc((void**)&dd, (size_t)cap * 4));
-    MYSLAM_HIP_CHECK(hipMemcpy(dq, query, (size_t)nq * 32, hipMemcpyHostToDevice));
-    if (nt) MYSLAM_HIP_CHECK(hipMemcpy(dt, train, (size_t)nt * 32, hipMemcpyHostToDevice));
+    HostCall hc;                                               // thread-local staging: no allocation, one copy each way
+    const int pq = hc.in(query, (size_t)nq * 32), pt = hc.in(train, (size_t)nt * 32);
+    const int pi = hc.out(train_idx, (size_t)nq), pd = hc.out(dist, (size_t)nq);
+    int rc = hc.upload();
+    if (rc) return rc;
+    const uint8_t* dq = hc.dev<uint8_t>(pq); const uint8_t* dt = hc.dev<uint8_t>(pt);
+    int32_t* di = hc.dev<int32_t>(pi); int32_t* dd = hc.dev<int32_t>(pd);
     {
-        ScopedProf sp(P_MATCH, nullptr);
+        ScopedProf sp(P_MATCH, hc.stream());
         if (hamming_variant() == 3)
-            hipLaunchKernelGGL(k_hamming_fp4, dim3((nq + HQ_BLOCK - 1) / HQ_BLOCK, 1), dim3(256), 0, nullptr, dq, (const int32_t*)nullptr, dt,
+            hipLaunchKernelGGL(k_hamming_fp4, dim3((nq + HQ_BLOCK - 1) / HQ_BLOCK, 1), dim3(256), 0, hc.stream(), dq, (const int32_t*)nullptr, dt,
                                (const int32_t*)nullptr, cap, nq, nt, di, dd);
         else if (hamming_use_mfma())
-            hipLaunchKernelGGL(k_hamming_mfma, dim3((nq + HQ_BLOCK - 1) / HQ_BLOCK, 1), dim3(256), 0, nullptr, dq, (const int32_t*)nullptr, dt,
+            hipLaunchKernelGGL(k_hamming_mfma, dim3((nq + HQ_BLOCK - 1) / HQ_BLOCK, 1), dim3(256), 0, hc.stream(), dq, (const int32_t*)nullptr, dt,
                                (const int32_t*)nullptr, cap, nq, nt, di, dd);
         else
-            hipLaunchKernelGGL(k_hamming, dim3((nq + HM_T - 1) / HM_T, 1), dim3(HM_T), 0, nullptr, dq, (const int32_t*)nullptr, dt,
+            hipLaunchKernelGGL(k_hamming, dim3((nq + HM_T - 1) / HM_T, 1), dim3(HM_T), 0, hc.stream(), dq, (const int32_t*)nullptr, dt,
                                (const int32_t*)nullptr, cap, nq, nt, di, dd);
     }
     MYSLAM_HIP_CHECK(hipGetLastError());
-    MYSLAM_HIP_CHECK(hipMemcpy(train_idx, di, (size_t)nq * 4, hipMemcpyDeviceToHost));
-    MYSLAM_HIP_CHECK(hipMemcpy(dist, dd, (size_t)nq * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(dq); (void)hipFree(dt); (void)hipFree(di); (void)hipFree(dd);
-    return MYSLAM_OK;
+    return hc.download();
 }
 
 // src/loopclosing.cpp:175-186 — host bookkeeping (a handful of compares)
@@ -480,24 +480,19 @@ int myslam_triangulate_stereo(const float* xl, const float* yl, const float* xr,
     if (!xl || !yl || !xr || !yr || !xyz || !ok) return MYSLAM_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MYSLAM_ERR_HIP;
-    float* d_in = nullptr; double* d_xyz = nullptr; uint8_t* d_ok = nullptr;
-    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_in, (size_t)n * 16)); MYSLAM_HIP_CHECK(hipMalloc((void**)&d_xyz, (size_t)n * 24));
-    MYSLAM_HIP_CHECK(hipMalloc((void**)&d_ok, (size_t)n));
-    MYSLAM_HIP_CHECK(hipMemcpy(d_in, xl, (size_t)n * 4, hipMemcpyHostToDevice));
-    MYSLAM_HIP_CHECK(hipMemcpy(d_in + n, yl, (size_t)n * 4, hipMemcpyHostToDevice));
-    MYSLAM_HIP_CHECK(hipMemcpy(d_in + 2 * n, xr, (size_t)n * 4, hipMemcpyHostToDevice));
-    MYSLAM_HIP_CHECK(hipMemcpy(d_in + 3 * n, yr, (size_t)n * 4, hipMemcpyHostToDevice));
+    HostCall hc;
+    const int p0 = hc.in(xl, (size_t)n), p1 = hc.in(yl, (size_t)n), p2 = hc.in(xr, (size_t)n), p3 = hc.in(yr, (size_t)n);
+    const int px = hc.out(xyz, (size_t)n * 3), po = hc.out(ok, (size_t)n);
+    int rc = hc.upload();
+    if (rc) return rc;
     {
-        ScopedProf sp(P_TRI, nullptr);
-        hipLaunchKernelGGL(k_triangulate, dim3((n + 255) / 256, 1), dim3(256), 0, nullptr, d_in, d_in + n, d_in + 2 * n, d_in + 3 * n,
-                           (const myslam_keypoint*)nullptr, (const myslam_keypoint*)nullptr, (const int32_t*)nullptr,
-                           (const int32_t*)nullptr, n, n, fx, fy, cx, cy, baseline, d_xyz, d_ok);
+        ScopedProf sp(P_TRI, hc.stream());
+        hipLaunchKernelGGL(k_triangulate, dim3((n + 255) / 256, 1), dim3(256), 0, hc.stream(), hc.dev<float>(p0), hc.dev<float>(p1),
+                           hc.dev<float>(p2), hc.dev<float>(p3), (const myslam_keypoint*)nullptr, (const myslam_keypoint*)nullptr,
+                           (const int32_t*)nullptr, (const int32_t*)nullptr, n, n, fx, fy, cx, cy, baseline, hc.dev<double>(px), hc.dev<uint8_t>(po));
     }
     MYSLAM_HIP_CHECK(hipGetLastError());
-    MYSLAM_HIP_CHECK(hipMemcpy(xyz, d_xyz, (size_t)n * 24, hipMemcpyDeviceToHost));
-    MYSLAM_HIP_CHECK(hipMemcpy(ok, d_ok, (size_t)n, hipMemcpyDeviceToHost));
-    (void)hipFree(d_in); (void)hipFree(d_xyz); (void)hipFree(d_ok);
-    return MYSLAM_OK;
+    return hc.download();
 }
 
 }  // extern "C"

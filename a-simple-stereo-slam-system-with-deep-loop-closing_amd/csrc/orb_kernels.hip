@@ -2467,11 +2467,8 @@ void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCo
     int ncmax = 0;
     for (int l = 0; l < P.nlevels; l++) ncmax = max(ncmax, P.lv[l].nodeCap);
     const size_t lds = octree_lds_bytes(ncmax);
-    static size_t lds_attr = 0;
-    if (lds > 48 * 1024 && lds > lds_attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_attr = lds;
-    }
+    // per device and per process: set on every launch that needs it (cheap, re-entrant, multi-GPU safe)
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_octree, dim3(P.nlevels, batch), dim3(OT), lds, s, P, cand, candCount, sortbuf, octTab, selOut, selCount, status, ncmax);
 }
 

@@ -1,4 +1,5 @@
 // prof.hip — per-kernel HIP-event timing + library-wide entry points.
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -6,10 +7,10 @@
 
 namespace myslam_hip {
 
-static const char* kNames[P_COUNT] = {"resize", "fast_cells", "octree", "blur7", "describe", "hamming_match", "triangulate",
+static const char* kNames[P_COUNT] = {"resize", "fast", "octree", "blur7", "describe", "hamming_match", "triangulate",
                                       "lcd_preproc", "calc_conv1", "calc_conv2", "calc_conv3", "lcddb_scan", "ba_build", "screen"};
 struct Pending { int id; hipEvent_t a, b; };
-static bool g_on = false;
+static std::atomic<bool> g_on{false};
 static std::mutex g_mu;
 static std::vector<Pending> g_pending;
 static std::vector<hipEvent_t> g_pool;
@@ -25,18 +26,71 @@ static hipEvent_t get_event() {
 }
 
 void prof_begin(int id, hipStream_t s) {
-    if (!g_on) return;
+    if (!g_on.load(std::memory_order_relaxed)) return;
     std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_on.load(std::memory_order_relaxed)) return;
     t_start[id] = get_event();
     (void)hipEventRecord(t_start[id], s);
 }
 
 void prof_end(int id, hipStream_t s) {
-    if (!g_on) return;
+    if (!t_start[id]) return;                 // profiling was off (or switched on mid-call) when the launch began: nothing to pair
     std::lock_guard<std::mutex> lk(g_mu);
     hipEvent_t e = get_event();
     (void)hipEventRecord(e, s);
     g_pending.push_back({id, t_start[id], e});
+    t_start[id] = nullptr;
+}
+
+// ---- thread-local staging of the host-pointer entry points (common.h) ----
+HostArena::~HostArena() {
+    if (d) (void)hipFree(d);
+    if (h) (void)hipHostFree(h);
+    if (s) (void)hipStreamDestroy(s);
+}
+
+int HostArena::ensure(size_t bytes) {
+    if (!s) MYSLAM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    if (bytes <= cap) return MYSLAM_OK;
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    if (d) { (void)hipFree(d); d = nullptr; }
+    if (h) { (void)hipHostFree(h); h = nullptr; }
+    cap = 0;
+    const size_t want = (bytes + (bytes >> 2) + 65535) & ~(size_t)65535;
+    MYSLAM_HIP_CHECK(hipMalloc((void**)&d, want));
+    MYSLAM_HIP_CHECK(hipHostMalloc((void**)&h, want));
+    cap = want;
+    return MYSLAM_OK;
+}
+
+HostArena& host_arena() {
+    static thread_local HostArena a;
+    return a;
+}
+
+int HostCall::upload() {
+    size_t off = 0;
+    for (int k = IN; k <= TMP; k++) {
+        if (k == INOUT) begOut = off;
+        for (int i = 0; i < npc; i++)
+            if (pc[i].kind == k) { pc[i].off = off; off += (pc[i].bytes + 255) & ~(size_t)255; }
+        if (k == INOUT) endIn = off;
+        if (k == OUT) endOut = off;
+    }
+    int rc = A.ensure(off ? off : 256);
+    if (rc) return rc;
+    for (int i = 0; i < npc; i++)
+        if (pc[i].kind <= INOUT && pc[i].bytes) memcpy(A.h + pc[i].off, pc[i].src, pc[i].bytes);
+    if (endIn) MYSLAM_HIP_CHECK(hipMemcpyAsync(A.d, A.h, endIn, hipMemcpyHostToDevice, A.s));
+    return MYSLAM_OK;
+}
+
+int HostCall::download() {
+    if (endOut > begOut) MYSLAM_HIP_CHECK(hipMemcpyAsync(A.h + begOut, A.d + begOut, endOut - begOut, hipMemcpyDeviceToHost, A.s));
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(A.s));
+    for (int i = 0; i < npc; i++)
+        if ((pc[i].kind == INOUT || pc[i].kind == OUT) && pc[i].bytes && pc[i].dst) memcpy(pc[i].dst, A.h + pc[i].off, pc[i].bytes);
+    return MYSLAM_OK;
 }
 
 static void drain() {
@@ -66,7 +120,7 @@ const char* myslam_hip_version(void) { return "myslam_hip 0.1 (gfx950)"; }
 int myslam_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!on) drain();
-    g_on = on != 0;
+    g_on.store(on != 0);
     return MYSLAM_OK;
 }
 

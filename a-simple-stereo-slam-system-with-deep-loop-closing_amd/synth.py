@@ -75,9 +75,10 @@ def stereo_pair(stream_id=0, t=0, h=IMG_H, w=IMG_W, scene=None, bf=KITTI00["bf"]
     return to_u8(left), to_u8(right)
 
 
-def stereo_batch(n_pairs, stream_id=0, t0=0, h=IMG_H, w=IMG_W):
-    """[n_pairs, 2, h, w] uint8: frames t0.. of one stream (left=[:,0], right=[:,1])."""
-    scene = make_scene(stream_id, h, w)
+def stereo_batch(n_pairs, stream_id=0, t0=0, h=IMG_H, w=IMG_W, n_rect=6000):
+    """[n_pairs, 2, h, w] uint8: frames t0.. of one stream (left=[:,0], right=[:,1]).  n_rect = 6000 is the BASELINE stream
+    (SURVEY.md §8(d)); fewer rectangles give a sparser scene (a few % FAST corners, closer to real imagery)."""
+    scene = make_scene(stream_id, h, w, n_rect)
     out = np.empty((n_pairs, 2, h, w), np.uint8)
     for i in range(n_pairs):
         out[i, 0], out[i, 1] = stereo_pair(stream_id, t0 + i, h, w, scene)
@@ -156,17 +157,15 @@ def ba_problem(seed=0xBA, n_kf=10, n_mp=300, noise_px=0.5, outlier_frac=0.03, pe
         poses[i, :4] = [-q[0], -q[1], -q[2], q[3]]
         poses[i, 4:] = tcw
     pts = np.stack([rng.uniform(-10, 10, n_mp), rng.uniform(-3, 3, n_mp), rng.uniform(5, 40, n_mp) + n_kf], axis=1)
-    ep, el, obs = [], [], []
-    for j in range(n_mp):
-        for i in range(n_kf):
-            R = _quat_to_R(poses[i, :4]); pc = R @ pts[j] + poses[i, 4:]
-            if pc[2] < 0.5:
-                continue
-            u = K["fx"] * pc[0] / pc[2] + K["cx"]; v = K["fy"] * pc[1] / pc[2] + K["cy"]
-            if not (0 <= u < w and 0 <= v < h):
-                continue
-            ep.append(i); el.append(j); obs.append([u, v])
-    ep = np.array(ep, np.int32); el = np.array(el, np.int32); obs = np.array(obs, np.float64).reshape(-1, 2)
+    # every landmark is observed by every key-frame it projects into; edges grouped by landmark (as backend.cpp:161-205 builds them)
+    Rs = np.stack([_quat_to_R(poses[i, :4]) for i in range(n_kf)])
+    pc = np.einsum("iab,jb->jia", Rs, pts) + poses[None, :, 4:]                 # [n_mp, n_kf, 3]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        u = K["fx"] * pc[..., 0] / pc[..., 2] + K["cx"]; v = K["fy"] * pc[..., 1] / pc[..., 2] + K["cy"]
+    vis = (pc[..., 2] >= 0.5) & (u >= 0) & (u < w) & (v >= 0) & (v < h)
+    el, ep = np.nonzero(vis)
+    ep = ep.astype(np.int32); el = el.astype(np.int32)
+    obs = np.stack([u[vis], v[vis]], axis=1).astype(np.float64).reshape(-1, 2)
     obs += rng.normal(0, noise_px, size=obs.shape)
     nout = int(outlier_frac * len(ep))
     if nout:
@@ -179,6 +178,21 @@ def ba_problem(seed=0xBA, n_kf=10, n_mp=300, noise_px=0.5, outlier_frac=0.03, pe
         poses[:, 4:] += rng.normal(0, 0.02, size=(n_kf, 3))
     Kt = (K["fx"], K["fy"], K["cx"], K["cy"])
     return poses, pts, ep, el, obs, fixed, Kt
+
+
+def ba_windows(n, seed0=0xBA, **kw):
+    """n DISTINCT sliding-window BA instances (seeds seed0, seed0 + 1, ...) padded to common capacities, in the layout of the
+    *_batch entry points: (poses [n,maxP,7], points [n,maxL,3], edge_pose [n,maxE], edge_pt [n,maxE], obs [n,maxE,2],
+    fixed [n,maxL], sizes [n,3] = (nposes, npts, nedges)), plus the camera tuple."""
+    probs = [ba_problem(seed=seed0 + i, **kw) for i in range(n)]
+    maxP = max(len(p[0]) for p in probs); maxL = max(len(p[1]) for p in probs); maxE = max(len(p[2]) for p in probs)
+    poses = np.zeros((n, maxP, 7)); poses[:, :, 3] = 1.0
+    pts = np.zeros((n, maxL, 3)); ep = np.zeros((n, maxE), np.int32); el = np.zeros((n, maxE), np.int32)
+    obs = np.zeros((n, maxE, 2)); fixed = np.zeros((n, maxL), np.uint8); sizes = np.zeros((n, 3), np.int32)
+    for i, (po, pt, e0, e1, ob, fx, _) in enumerate(probs):
+        poses[i, :len(po)] = po; pts[i, :len(pt)] = pt; ep[i, :len(e0)] = e0; el[i, :len(e1)] = e1; obs[i, :len(ob)] = ob
+        fixed[i, :len(fx)] = fx; sizes[i] = (len(po), len(pt), len(e0))
+    return (poses, pts, ep, el, obs, fixed, sizes), probs[0][6]
 
 
 # ---- loop correction: synthetic pose graphs ------------------------------------------------------------------------

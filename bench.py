@@ -4,17 +4,26 @@
 A "step" = one pass of the hot path over one batch (default 512) of synthetic 1241x376 stereo pairs resident in HBM:
   ORB DetectAndCompute (2000 features) on left+right -> L/R 256-bit Hamming match -> stereo triangulation
   -> DeepLCD descriptor of the left image -> cosine scan of the key-frame database -> local-BA block build
-  (one 10 KF x 300 landmark window per frame).           [BASELINE.json configs[3]; --workload orb_match = configs[1]]
+  (one DISTINCT 10 KF x 300 landmark window per frame).  [BASELINE.json configs[3]; --workload orb_match = configs[1]]
 
-One process per GPU (launched by torch.distributed.run for --gpus N > 1).  Frames shard across ranks
-(stream r on rank r, no data-path collective); the loop database is sharded by key-frame id range and the only
-exchange is an all-gather of the query descriptors and of the per-shard (score, id, count) candidates (RCCL).
+One process per GPU.  `python bench.py --gpus N` launches its N ranks itself when it is not already running under
+torch.distributed.run (which works as before: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).  Frames shard
+across ranks (stream r on rank r, no data-path collective); the loop database is sharded by key-frame id range and the only
+exchange is an all-gather of the query descriptors and of the 16-byte per-shard candidate records (RCCL).
 
+Passes (all after the warm-up, each bracketed by barrier + synchronize):
+  1. the TIMED region: K steps, per-kernel event profiling OFF            -> value, ms_per_step
+  2. a profiled pass: the same K steps with a HIP event pair around every launch (on the launch's stream) -> roofline
+  3. (full workload) K steps with the OptimizeActiveMap solve on 1 frame in 6 (the reference's key-frame cadence) -> full_solve_cadence6
 Prints ONE JSON line (rank 0).  PyTorch is used for device memory, streams and torch.distributed only.
 """
 import argparse
+import glob
 import json
 import os
+import re
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,61 +34,72 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package  # noqa: E402
 
 H, W = 376, 1241
-# SQ_INSTS_VALU per image (wave-level instructions), rocprofv3 --pmc, profiles/r01_pmc_insts_orb_match_p64_v10.txt
-VALU_INSTS_PER_IMAGE = {"fast_cells": 238618128 / 128, "describe": 56505600 / 128, "octree": 13590512 / 128}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_PEAK_TLANEOPS = 39.3      # 256 CUs x 4 SIMDs x 16 lanes per cycle x 2.4 GHz
 PYR_PX = 1444097               # sum of the 8 level areas
-# algorithmic bytes per IMAGE of each ORB kernel (SURVEY.md §8(d) accounting)
+# algorithmic bytes per IMAGE of each ORB stage (SURVEY.md §8(d) accounting)
 ALGO_BYTES = {
     "resize": 1407767 + 977481,            # read levels 0-6, write levels 1-7
-    "fast_cells": PYR_PX + 4 * 20000,      # read every level once + candidate list
+    "fast": PYR_PX + 4 * 20000,            # read every level once + candidate list
     "blur7": 2 * PYR_PX,                   # read + write every level
     "describe": 2000 * (749 + 512 + 60),   # IC patch + BRIEF samples + outputs
     "octree": 2 * 4 * 56000,               # candidates in, selected out (latency bound in practice)
 }
+# profiling slot (csrc/prof.hip) -> kernel symbol prefix as rocprofv3 prints it
+SYMBOL = {"resize": "k_resize_strip", "fast": "k_fast_strip", "octree": "k_octree", "blur7": "k_blur7_strip", "describe": "k_describe2",
+          "hamming_match": "k_hamming_fp4", "triangulate": "k_triangulate", "lcd_preproc": "k_lcd_input_fused",
+          "calc_conv1": "k_conv1_pool_lrn2", "calc_conv2": "k_conv2_bf16x6", "calc_conv3": "k_pool_lrn128_2x2", "lcddb_scan": "k_db_scan_bf16x6",
+          "ba_build": "k_ba_build", "screen": "k_screen"}
 
 
-def pmc_traffic(kernel, imgs_per_launch):
-    """HBM bytes per launch of `kernel` from the committed PMC run (separate rocprofv3 --pmc passes, tools/gpu_traffic.sh)."""
-    import glob
-    import re
-    files = glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json"))
+def pmc_file():
+    """The newest committed counter summary of this build family (tools/pmc_collect.py writes it): profiles/r<NN>_pmc_<tag>.json."""
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json")) if re.search(r"r(\d+)_pmc_[^/]*\.json$", f) and "traffic" not in f and "mfma" not in f]
     if not files:
-        return None
+        return None, None
 
-    def version(f):                                            # ..._v<N>.json: the highest build number is the current one
-        m = re.search(r"_v(\d+)\.json$", f)
-        return int(m.group(1)) if m else -1
-    d = json.load(open(max(files, key=version)))
-    tag = {"fast_cells": "k_fast", "octree": "k_octree", "blur7": "k_blur7", "resize": "k_resize", "describe": "k_describe"}.get(kernel)
-    for name, v in d["kernels"].items():
-        if tag and name.startswith(tag):
-            kb = v.get("FETCH_SIZE_KB_per_launch", 0) + v.get("WRITE_SIZE_KB_per_launch", 0)
-            # the PMC run counted `launches` launches of this kernel over 3 steps (tools/gpu_traffic.sh: --steps 2 --warmup 1) of
-            # 2 * pairs_per_step images each: bytes per image, times the images one launch of THIS run covers
-            per_image = kb * 1024.0 * v.get("launches", 3) / (d.get("steps_total", 3) * 2.0 * d["pairs_per_step"])
-            return per_image * imgs_per_launch
-    return None
+    def key(f):
+        m = re.search(r"r(\d+)_pmc_.*?(\d+)\.json$", f)
+        return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
+    f = max(files, key=key)
+    try:
+        d = json.load(open(f))
+    except Exception:
+        return None, None
+    return (d, os.path.relpath(f, ROOT)) if "kernels" in d and "calibration" in d else (None, None)
+
+
+def pmc_lookup(pmc, slot):
+    """(full kernel symbol, per-image record) of the profiling slot's kernel in the counter summary"""
+    if not pmc:
+        return None, None
+    pre = SYMBOL.get(slot)
+    for name, rec in pmc["kernels"].items():
+        if pre and name.startswith(pre):
+            return name, rec
+    return None, None
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=512, help="stereo pairs per step per GPU")
-    ap.add_argument("--workload", default="full", choices=["full", "orb_match", "orb_match_lcd", "full_solve"])
+    ap.add_argument("--workload", default="full", choices=["full", "orb_match", "orb_match_lcd", "full_solve", "latency"])
     ap.add_argument("--db", type=int, default=0, help="key-frame database size (default 10000, or 6250 per GPU when sharded)")
+    ap.add_argument("--scene-rects", type=int, default=6000,
+                    help="rectangles of the synthetic scene (SURVEY.md §8(d): 6000 = the corner-dense BASELINE stream; 300 = a sparse stream "
+                         "closer to real imagery, on which the two-phase FAST path pays most)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=32)
+    ap.add_argument("--cpu-pairs", type=int, default=200, help="upper bound of the frames the all-cores CPU baseline times (after its warm-up)")
+    ap.add_argument("--no-extra-passes", action="store_true", help="skip the profiled and the solve-cadence passes (timed region only)")
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
-                    help="2 = the DeepLCD / loop-DB / BA chain runs on a second HIP stream beside ORB + match + triangulation")
+                    help="2 = the DeepLCD / loop-DB / BA chain runs on its own HIP stream beside ORB + match + triangulation")
     ap.add_argument("--orb-split", type=int, default=0, choices=[0, 1, 2, 3, 4, 8],
-                    help="S > 1 = the 2P images go through S extractor handles on S streams (S equal groups): the latency-bound oct-tree / "
-                         "describe launches of one group run under the VALU-bound FAST launch of the other (2 is ~3 % faster than 1; "
-                         "concurrent launches stretch each other, so per-launch durations are longer than when a kernel runs alone). "
-                         "0 (default) = 2 with --streams 2, 1 with --streams 1")
-    ap.add_argument("--pipeline", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
+                    help="S > 1 = the 2P images go through S extractor handles on S streams (S equal groups).  0 (default) = 2 with "
+                         "--streams 2, 1 with --streams 1")
+    ap.add_argument("--pipeline", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="1 = the left and the right images go through two extractor handles that take turns (myslam_orb_set_fast_event): "
                          "one handle's VALU-bound FAST stage runs under the other's latency-bound oct-tree / descriptor stages, match + "
                          "triangulation follow on a third stream, outputs are double-buffered and consecutive steps overlap (every step's "
@@ -87,8 +107,6 @@ def parse():
                          "-1 (default) = 1 with --streams 2, else 0")
     ap.add_argument("--verify", action="store_true",
                     help="after the timed region: run one joined, un-gated step and check that it reproduces the pipeline's last outputs bit for bit")
-    ap.add_argument("--side-delay-ms", type=float, default=0.0, help="experiment: start the side chain this long after the step begins (spin kernel)")
-    ap.add_argument("--no-join", action="store_true", help="do not join the side stream at the end of every step (streaming across steps)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = debugging aid: several ranks share GPU 0 and the collectives go through host memory")
     args = ap.parse_args()
@@ -101,29 +119,57 @@ def parse():
     return args
 
 
-def cpu_baseline(synth, workload, n_pairs, db_np, gpu_frames):
-    """The oracle (a plain C++ port of the reference arithmetic, oracle/) timed on this host over a bounded sample of the same
-    frames and stages: frame-parallel over all host cores (std::thread pool, one frame per task, oracle/bench_oracle.cpp), plus
-    a single-thread figure (the reference runs every stage single-threaded inside its std::thread)."""
+def self_launch(n):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks (one per GPU) ourselves and pass rank 0's output on."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
+
+
+def cpu_baseline(synth, workload, max_pairs, db_np, gpu_frames, ba_w):
+    """The oracle (a plain C++ port of the reference arithmetic, oracle/) timed on this host over a bounded sample of the same frames
+    and stages, SURVEY.md §8(d) protocol: (i) one thread — the reference runs every stage single-threaded inside its std::thread —
+    and (ii) frame-parallel over all host cores (std::thread pool, one frame per task, oracle/bench_oracle.cpp); warm-up frames first,
+    wall clock over the rest, per-stage medians.  Bounded to roughly 10-30 s of CPU work."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from pyoracle import Oracle
     o = Oracle()
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    n_pairs = min(len(gpu_frames), max(n_pairs, 2 * cores))            # the same frames the GPU processed
     stages = {"orb_match": 1, "orb_match_lcd": 2, "full": 3, "full_solve": 4}[workload]
     ids = np.arange(len(db_np), dtype=np.uint64)
-    args = (synth.KITTI00, synth.calc_weights(), db_np, ids, synth.ba_problem())
-    n1 = min(6, n_pairs)
-    dt1 = o.bench_frames(gpu_frames[:n1], *args, stages=stages, threads=1)
-    dt = o.bench_frames(gpu_frames[:n_pairs], *args, stages=stages, threads=cores)
-    return {"value": n_pairs / dt, "unit": "stereo frames/s", "cores": cores, "kind": "port",
-            "value_1thread": n1 / dt1,
-            "sample": f"{n_pairs} of the GPU run's synthetic 1241x376 stereo pairs, same stages, oracle frame-parallel on {cores} "
-                      f"host threads in {dt:.1f} s (single thread: {n1} pairs in {dt1:.1f} s)"}
+    args = (synth.KITTI00, synth.calc_weights(), db_np, ids, ba_w)
+    names = ["orb_extract_LR", "match_triangulate", "deeplcd_dbscan", "ba_build", "ba_solve"][:max(2, stages + 1)]
+    # (i) one thread: 2 warm-up + up to 10 frames (~0.3 s per frame)
+    n1 = min(len(gpu_frames), 12); w1 = min(2, n1 - 1)
+    dt1, st1 = o.bench_frames(gpu_frames[:n1], *args, stages=stages, threads=1, n_warmup=w1)
+    fps1 = (n1 - w1) / dt1
+    # (ii) all cores: 20 warm-up frames + as many frames as ~15 s of this host allow, at most max_pairs (200 on the GPU box's 256 threads)
+    wn = min(20, max(0, len(gpu_frames) - 2))
+    est = fps1 * min(cores, 64)
+    n = int(min(len(gpu_frames) - wn, max_pairs, max(min(2 * cores, 64), 15 * est)))
+    n = max(n, 2)
+    dt, st = o.bench_frames(gpu_frames[:wn + n], *args, stages=stages, threads=cores, n_warmup=wn)
+    med = lambda a, k0: {nm: float(np.median(a[k0:, i]) * 1e3) for i, nm in enumerate(names)}
+    return {"value": n / dt, "unit": "stereo frames/s", "cores": cores, "kind": "port", "value_1thread": fps1,
+            "stage_median_ms_1thread": med(st1, w1), "stage_median_ms_allcores": med(st, wn),
+            "sample": f"{n} of the GPU run's synthetic 1241x376 stereo pairs after {wn} warm-up frames, same stages, oracle frame-parallel on "
+                      f"{cores} host threads in {dt:.1f} s; single thread: {n1 - w1} pairs after {w1} warm-up in {dt1:.1f} s"}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)
     import torch
     import torch.distributed as dist
 
@@ -133,25 +179,36 @@ def main():
     via_cpu = args.backend == "gloo"
     if via_cpu:
         local_rank = 0
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE {world} (under torch.distributed.run pass --gpus = --nproc-per-node)"
+    rccl_ranks = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        assert via_cpu or torch.cuda.device_count() > local_rank, \
+            f"rank {rank}: {torch.cuda.device_count()} visible GPU(s) but LOCAL_RANK {local_rank} (one GPU per rank; --backend gloo shares GPU 0)"
         torch.cuda.set_device(local_rank)
         if via_cpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        one = torch.ones(1, dtype=torch.int32, device="cpu" if via_cpu else torch.device("cuda", local_rank))
+        dist.all_reduce(one)                                     # the ranks the collective library actually connected
+        rccl_ranks = int(one.item())
+        assert rccl_ranks == world
     else:
         torch.cuda.set_device(0)
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
     pkg = load_package()
     api, synth = pkg.api, pkg.synth
     assert api.device_count() >= 1
+    if args.workload == "latency":
+        assert world == 1
+        from tools import latency_b1
+        print(json.dumps(latency_b1.run(api, synth, with_oracle=not args.no_cpu_baseline)))
+        return
     main_stream = torch.cuda.current_stream()
     stream = main_stream.cuda_stream
-    # the LCD -> DB -> BA chain only reads the input images: it runs beside the ORB chain on its own stream (MFMA conv2 under the
-    # VALU-bound FAST kernel, the latency-bound small kernels under each other) and is joined at the end of every step
+    # the LCD -> DB -> BA chain only reads the input images: it runs beside the ORB chain on its own stream
     side_stream = torch.cuda.Stream() if args.streams == 2 else main_stream
     stream2 = side_stream.cuda_stream
     P = args.pairs
@@ -159,7 +216,7 @@ def main():
     Kt = (K["fx"], K["fy"], K["cx"], K["cy"])
 
     # ---- inputs resident in HBM before the timed region ----
-    frames = synth.stereo_batch(P, stream_id=rank)                      # [P, 2, H, W]
+    frames = synth.stereo_batch(P, stream_id=rank, n_rect=args.scene_rects)   # [P, 2, H, W]
     imgs = np.concatenate([frames[:, 0], frames[:, 1]], axis=0)         # all left images, then all right images
     d_imgs = torch.from_numpy(imgs).to(dev)
     ext = api.ORBextractor(2000, stream=stream)
@@ -196,45 +253,46 @@ def main():
         d_allq = torch.zeros(NQ, 1064, device=dev)
         d_best = torch.zeros(NQ, dtype=torch.int64, device=dev)
         d_max = torch.zeros(NQ, device=dev); d_dbcnt = torch.zeros(NQ, dtype=torch.int32, device=dev)
+        d_cand = torch.zeros(NQ * 16, dtype=torch.uint8, device=dev)
+        if world > 1:
+            pkg.sharded_db.check_shard_order(int(ids[0]), int(ids[-1]), world, via_cpu=via_cpu, device=dev)
+    ba_w = None
     if use_ba:
-        poses, pts, ep, el, obs, fixed, _ = synth.ba_problem()
-        maxP, maxL, maxE = len(poses), len(pts), len(ep)
-        rep = lambda a: torch.from_numpy(np.ascontiguousarray(np.broadcast_to(a, (P,) + a.shape))).to(dev)
-        b_in = [rep(poses), rep(pts), rep(ep), rep(el), rep(obs), rep(fixed),
-                torch.tensor([[maxP, maxL, maxE]] * P, dtype=torch.int32, device=dev)]
+        ba_w, _ = synth.ba_windows(P, seed0=0xBA + 100000 * rank)        # P DISTINCT windows (10 KF x 300 MP, ~2950 edges each)
+        maxP, maxL, maxE = ba_w[0].shape[1], ba_w[1].shape[1], ba_w[2].shape[1]
+        b_in = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in ba_w]
         b_out = [torch.zeros(P, n, dtype=torch.float64, device=dev) for n in (maxP * 36, maxL * 9, maxE * 18, maxP * 6, maxL * 3, maxE)]
-        # the solve updates poses/points in place: every step starts from the pristine window
+        # the solve updates poses/points in place: every step starts from the pristine windows
         s_poses, s_pts = b_in[0].clone(), b_in[1].clone()
         s_echi = torch.zeros(P, maxE, dtype=torch.float64, device=dev); s_out = torch.zeros(P, maxE, dtype=torch.uint8, device=dev)
         s_rd = torch.zeros(P, dtype=torch.int32, device=dev); s_no = torch.zeros(P, dtype=torch.int32, device=dev)
         s_st = torch.zeros(P, dtype=torch.int32, device=dev)
 
-        def solve():        # Backend::OptimizeActiveMap solve stage: rounds of optimize(10) + outlier flags (backend.cpp:208-243)
-            s_poses.copy_(b_in[0]); s_pts.copy_(b_in[1])
-            api.ba_optimize_active_map_batch(s_poses.data_ptr(), s_pts.data_ptr(), *[t.data_ptr() for t in b_in[2:]], P, maxP, maxL, maxE, Kt,
+        def solve(nwin=P):   # Backend::OptimizeActiveMap solve stage: rounds of optimize(10) + outlier flags (backend.cpp:208-243)
+            s_poses[:nwin].copy_(b_in[0][:nwin]); s_pts[:nwin].copy_(b_in[1][:nwin])
+            api.ba_optimize_active_map_batch(s_poses.data_ptr(), s_pts.data_ptr(), *[t.data_ptr() for t in b_in[2:]], nwin, maxP, maxL, maxE, Kt,
                                              5.991, 5.991, 5, 10, b_out[2].data_ptr(), s_echi.data_ptr(), s_out.data_ptr(), s_rd.data_ptr(),
                                              s_no.data_ptr(), s_st.data_ptr(), stream2)
+    solve_windows = [P if use_solve else 0]          # windows the side chain also SOLVES per step (pass 3 sets ceil(P / 6))
 
     def side_chain():
-        if args.side_delay_ms > 0 and side_stream is not main_stream:
-            torch.cuda._sleep(int(args.side_delay_ms * 1e-3 * 2.0e9))
         if use_lcd:
             lcd.describe_batch(d_imgs.data_ptr(), P, H, W, W, H * W, d_descr.data_ptr(), blur_in_place=False)
-            if world > 1:       # every shard scores every rank's queries; candidates are merged after an all-gather
+            if world > 1:       # every shard scores every rank's queries; the 16-byte candidate records are merged after an all-gather
                 if via_cpu:
                     h_all = torch.empty(d_allq.shape, dtype=d_allq.dtype)
                     dist.all_gather_into_tensor(h_all, d_descr.cpu())
                     d_allq.copy_(h_all)
                 else:
                     dist.all_gather_into_tensor(d_allq, d_descr)
-                D.query_batch(d_allq.data_ptr(), cur_ids, NQ, d_best.data_ptr(), d_max.data_ptr(), d_dbcnt.data_ptr())
-                pkg.sharded_db.merge_candidates(d_best, d_max, d_dbcnt, world, via_cpu=via_cpu)
+                D.query_batch_sharded(d_allq.data_ptr(), cur_ids, NQ, d_cand.data_ptr())
+                pkg.sharded_db.exchange_and_merge(d_cand, world, d_best, d_max, d_dbcnt, via_cpu=via_cpu)
             else:
                 D.query_batch(d_descr.data_ptr(), cur_ids, NQ, d_best.data_ptr(), d_max.data_ptr(), d_dbcnt.data_ptr())
         if use_ba:
             api.ba_build_batch(*[t.data_ptr() for t in b_in], P, maxP, maxL, maxE, Kt, 5.991, *[t.data_ptr() for t in b_out], stream2)
-            if use_solve:
-                solve()
+            if solve_windows[0]:
+                solve(solve_windows[0])
 
     if args.pipeline:
         # two extractor handles take turns: handle A (left images, main stream) and handle B (right images, its own stream) each wait
@@ -301,7 +359,7 @@ def main():
                                      Kt, K["bf"] / K["fx"], d_xyz.data_ptr(), d_ok.data_ptr(), stream)
         with torch.cuda.stream(side_stream):
             side_chain()
-        if side_stream is not main_stream and not args.no_join:
+        if side_stream is not main_stream:
             main_stream.wait_stream(side_stream)            # a step is complete when both chains are
 
     if not args.pipeline:
@@ -312,23 +370,54 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n):
+        """n steps bracketed by barrier + synchronize on both sides; the slowest rank's wall time"""
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if via_cpu else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     for _ in range(args.warmup):
         step()
     barrier()
     assert all(int(t.abs().sum()) == 0 for t in d_stat_b), "ORB capacity overflow"
     n_kp = d_cnt.float().mean().item()
 
-    api.prof_reset(); api.prof_enable(True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    # ---- pass 1: the timed region (no per-kernel events) ----
     api.prof_enable(False)
-    prof = api.prof_read()
+    dt = timed(args.steps)
+
+    # ---- pass 2: the same steps with a HIP event pair around every launch, on the launch's own stream ----
+    prof, dt_prof = {}, None
+    if not args.no_extra_passes:
+        api.prof_reset(); api.prof_enable(True)
+        dt_prof = timed(args.steps)
+        api.prof_enable(False)
+        prof = api.prof_read()
+
+    # ---- pass 3: configs[3] at the reference's cadence: the solve runs per KEY-FRAME, about 1 frame in 6 ----
+    cadence = None
+    if use_ba and not use_solve and not args.no_extra_passes:
+        solve_windows[0] = (P + 5) // 6
+        step(); barrier()
+        dt_c = timed(args.steps)
+        solve_windows[0] = 0
+        assert int(s_st.abs().sum()) == 0
+        cadence = {"value": world * P * args.steps / dt_c, "unit": "stereo frames/s", "ms_per_step": dt_c / args.steps * 1e3,
+                   "solved_windows_per_step": (P + 5) // 6,
+                   "note": "as the timed region, plus Backend::OptimizeActiveMap's solve stage (rounds of Levenberg-Marquardt optimize(10), Schur + "
+                           "Cholesky, outlier flags) on every 6th frame's window — the reference solves per key-frame, about 1 frame in 6"}
+
     if args.verify and args.pipeline:
         # the overlapped schedule must not change a single output: one plain step (handles un-gated, joined) against the last pipelined one
+        step(); torch.cuda.synchronize()
         p_last = (step_no[0] - 1) % NB
         outs = lambda p: [d_kps_b[p], d_desc_b[p], d_cnt_b[p], d_stat_b[p], d_midx, d_mdist, d_xyz, d_ok] + \
             ([d_descr, d_best, d_max, d_dbcnt] if use_lcd else []) + (list(b_out) if use_ba else [])
@@ -349,86 +438,96 @@ def main():
             e.set_fast_event(ev_fast[i].cuda_event)
             if args.pipeline == 1:
                 e.set_fast_gate(ev_fast[(i - 1) % S].cuda_event)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if via_cpu else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
     solve_ms = None
-    if use_ba and not use_solve:        # the "g2o solve" half of configs[3], timed on its own (not part of `value`)
+    if use_ba and not use_solve and not args.no_extra_passes:        # the solve of ALL P windows, timed on its own (not part of `value`)
         with torch.cuda.stream(side_stream):
             solve(); torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(5):
                 solve()
             torch.cuda.synchronize()
-        solve_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        solve_ms = (time.perf_counter() - t1) / 5 * 1e3
         assert int(s_st.abs().sum()) == 0
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = world * P * args.steps / dt
-        # dominant kernel and its roofline position (HIP events on the launch stream, over the timed region)
+        pmc, pmc_path = pmc_file()
         busy = {k: v for k, v in prof.items() if v[1] > 0}
-        # the dominant kernel of the critical (ORB) stream; with --streams 2 the side chain's kernels run underneath it and their
-        # event-timed durations are stretched by the sharing, so they are not candidates
-        chain = [k for k in busy if k in ("resize", "fast_cells", "octree", "blur7", "describe", "hamming_match", "triangulate")]
-        # event-timed durations of overlapped launches say how long a kernel was resident, not how much of the chip it used (the
-        # latency-bound oct-tree runs under FAST for as long as FAST takes): the dominant kernel is the one with the largest
-        # instruction volume (PMC, VALU_INSTS_PER_IMAGE) among those that ran, by duration only if none of them is in that table
-        dom = max(chain or busy, key=lambda k: (VALU_INSTS_PER_IMAGE.get(k, 0), busy[k][0]))
-        dom_ms, dom_n = busy[dom]
-        per_launch_ms = dom_ms / dom_n
-        imgs_per_launch = 2 * P
-        launches_per_step = dom_n / args.steps
-        if dom in ALGO_BYTES:
-            algo = ALGO_BYTES[dom] * imgs_per_launch / launches_per_step        # bytes per launch
-            achieved = algo / (per_launch_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, imgs_per_launch / launches_per_step), "avg_launch_ms": per_launch_ms,
-                    "algorithmic_bytes_per_launch": algo,
-                    "note": "packed-integer VALU bound in practice (see roofline_valu and DESIGN.md section 6); avg_launch_ms is the event-timed duration of one launch (the left and the right images go through two extractor handles on two streams unless --orb-split 1, so a launch covers half of the step's images), which shares the chip with the other handle's launches, the Gaussian-pyramid launches of the extractors' internal streams and the LCD / DB / BA chain (3.28 ms for all 1024 images when it runs alone: --streams 1 with MYSLAM_ORB_AUX=0); traffic = FETCH_SIZE+WRITE_SIZE of a separate rocprofv3 --pmc run (profiles/), uncorrected"}
-        else:
-            roof = {"bound": "hbm", "kernel": dom, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-                    "traffic": None, "avg_launch_ms": per_launch_ms}
+        roof = {"bound": "hbm", "kernel": None, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+        roof_valu = None
+        if busy:
+            # the dominant kernel of the critical (ORB) chain: the one with the largest event-timed total among the chain's stages
+            chain = [k for k in busy if k in ("resize", "fast", "octree", "blur7", "describe", "hamming_match", "triangulate")]
+            # event-timed durations of overlapped launches say how long a kernel was resident, not how much of the chip it used (the
+            # latency-bound oct-tree runs under FAST for as long as FAST takes): among the chain's stages the dominant kernel is the
+            # one with the largest VALU instruction volume (counter summary) when that is known, else the largest duration
+            def volume(k):
+                _, rec = pmc_lookup(pmc, k)
+                return ((rec or {}).get("valu_wave_insts_per_image", 0.0), busy[k][0])
+            dom = max(chain or busy, key=volume)
+            dom_ms, dom_n = busy[dom]
+            per_launch_ms = dom_ms / dom_n
+            launches_per_step = dom_n / args.steps
+            imgs_per_launch = 2 * P / launches_per_step
+            sym, rec = pmc_lookup(pmc, dom)
+            roof.update({"kernel": sym or SYMBOL.get(dom, dom), "stage": dom, "avg_launch_ms": per_launch_ms, "images_per_launch": imgs_per_launch})
+            if dom in ALGO_BYTES:
+                algo = ALGO_BYTES[dom] * imgs_per_launch                        # bytes per launch
+                achieved = algo / (per_launch_ms * 1e-3) / 1e9
+                roof.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo})
+            if rec:
+                # HBM bytes per launch from the counter summary: FETCH_SIZE scaled by the factor that makes k_ingest's FETCH_SIZE equal
+                # the bytes it provably reads (MI355X_MICROARCH.md: gfx950 tallies 128-byte requests at 64 bytes), + WRITE_SIZE
+                roof["traffic"] = (rec["fetch_bytes_per_image_corrected"] + rec["write_bytes_per_image"]) * imgs_per_launch
+                roof["traffic_detail"] = {"source": pmc_path, "fetch_scale": pmc["calibration"]["fetch_scale"],
+                                          "fetch_bytes_per_image_corrected": rec["fetch_bytes_per_image_corrected"],
+                                          "write_bytes_per_image": rec["write_bytes_per_image"]}
+                v = rec.get("valu_wave_insts_per_image")
+                if v:
+                    ach = v * imgs_per_launch * 64 / (per_launch_ms * 1e-3) / 1e12
+                    roof_valu = {"bound": "valu", "kernel": roof["kernel"], "unit": "Tlane-op/s", "peak": VALU_PEAK_TLANEOPS, "achieved": ach,
+                                 "frac": ach / VALU_PEAK_TLANEOPS, "valu_wave_insts_per_image": v, "source": pmc_path}
+            roof["note"] = ("avg_launch_ms = HIP-event duration of one launch on its own stream in the profiled pass (same schedule as the timed "
+                            "region); a launch covers images_per_launch images and shares the chip with the other streams' launches; the kernel "
+                            "is packed-integer VALU bound in practice (roofline_valu, DESIGN.md section 6)")
+        mf = None
+        if "calc_conv2" in busy:
+            c2 = busy["calc_conv2"][0] / busy["calc_conv2"][1]
+            f32eq = 2 * 176160768 * P / (c2 * 1e-3) / 1e12
+            mf = {"bound": "mfma", "kernel": SYMBOL["calc_conv2"], "peak": 157.3, "unit": "TFLOP/s (f32-equivalent, against the f32 matrix peak)",
+                  "achieved": f32eq, "frac": f32eq / 157.3, "bf16_tflops": 6 * f32eq, "bf16_frac_of_2500": 6 * f32eq / 2500.0, "avg_launch_ms": c2,
+                  "note": "CALC conv2 as an implicit GEMM on the bf16 matrix cores with f32 accuracy (3-way exact operand split, 6 partial products "
+                          "per useful f32 flop): `achieved` counts USEFUL f32 flops; bf16_tflops counts the partial products"}
+        n_internal = S            # every extractor handle runs its Gaussian pyramid on an internal stream (orb_engine.hip run_batch)
         out = {
             "metric": "stereo frames/sec (ORB+match+LCD+BA-build) @1241x376",
             "value": value, "unit": "stereo frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/int32 (ORB, Hamming), f32 (CALC, DB scan), f64 (triangulation, BA)", "data": "synthetic",
             "config": {"workload": {"full": "configs[3]: ORB extract L+R (2000 feats) + L/R Hamming match + triangulation + DeepLCD descriptor + "
-                                            f"{n_db_local * world}-KF cosine DB scan + local-BA (10 KF x 300 MP) block build per frame",
-                                    "full_solve": "configs[3] incl. solve: as 'full' + the Backend::OptimizeActiveMap solve stage (rounds of Levenberg-Marquardt "
-                                                  "optimize(10) with Schur + Cholesky, outlier flags) of the 10 KF x 300 MP window per frame",
+                                            f"{n_db_local * world}-KF cosine DB scan + local-BA (10 KF x 300 MP, one distinct window per frame) block build",
+                                    "full_solve": "configs[3] incl. solve on EVERY frame: as 'full' + the Backend::OptimizeActiveMap solve stage (rounds of "
+                                                  "Levenberg-Marquardt optimize(10) with Schur + Cholesky, outlier flags) of the 10 KF x 300 MP window",
                                     "orb_match": "configs[1]: ORB extract L+R (2000 feats) + L/R Hamming match + triangulation",
                                     "orb_match_lcd": f"configs[2]: configs[1] + DeepLCD descriptor + {n_db_local * world}-KF cosine DB scan"}[args.workload],
-                       "pairs_per_step_per_gpu": P, "image": "1241x376 u8", "keypoints_per_image": n_kp,
-                       "hip_streams": args.streams, "orb_extractor_handles": S,
-                       "parallelism": f"frame-sharded x{world}" + (", id-range sharded DB + all-gather of candidates" if world > 1 else "")},
-            "roofline": roof,
-            "roofline_mfma": None if "calc_conv2" not in busy else {
-                "bound": "mfma", "kernel": "calc_conv2", "peak": 2500.0, "unit": "TFLOP/s (bf16, dense)",
-                "achieved": 6 * 2 * 176160768 * P / (busy["calc_conv2"][0] / busy["calc_conv2"][1] * 1e-3) / 1e12,
-                "frac": 6 * 2 * 176160768 * P / (busy["calc_conv2"][0] / busy["calc_conv2"][1] * 1e-3) / 1e12 / 2500.0,
-                "effective_f32_tflops": 2 * 176160768 * P / (busy["calc_conv2"][0] / busy["calc_conv2"][1] * 1e-3) / 1e12,
-                "avg_launch_ms": busy["calc_conv2"][0] / busy["calc_conv2"][1],
-                "note": "CALC conv2 as an implicit GEMM on the bf16 matrix cores with f32 accuracy: every f32 operand is split exactly into three "
-                        "bf16 pieces and the six largest partial products are accumulated in f32 (6 bf16 MFMA flops per f32 flop; error against an "
-                        "f64 reference 1.5e-6, the same as the f32-input MFMA it replaces); with --streams 2 it shares the CUs with the ORB "
-                        "kernels, so this duration is stretched (0.93 ms when it runs alone, --streams 1)"},
-            # the issue-rate view of the same dominant kernel: wave-level VALU instructions per image from a separate
-            # `rocprofv3 --pmc SQ_INSTS_VALU` run (profiles/r01_pmc_insts_orb_match_p64_v10.txt), x 64 lanes, against 256 CUs x 4 SIMDs x
-            # 16 lanes per cycle at 2.4 GHz
-            "roofline_valu": None if dom not in VALU_INSTS_PER_IMAGE else {
-                "bound": "valu", "kernel": dom, "unit": "Tlane-op/s", "peak": 39.3,
-                "achieved": VALU_INSTS_PER_IMAGE[dom] * imgs_per_launch / launches_per_step * 64 / (per_launch_ms * 1e-3) / 1e12,
-                "frac": VALU_INSTS_PER_IMAGE[dom] * imgs_per_launch / launches_per_step * 64 / (per_launch_ms * 1e-3) / 1e12 / 39.3,
-                "valu_wave_insts_per_image": VALU_INSTS_PER_IMAGE[dom]},
-            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in busy.items()},
-            "ba_solve_ms_per_step": solve_ms,     # OptimizeActiveMap solve stage for the same windows, outside the timed region
+                       "pairs_per_step_per_gpu": P, "image": "1241x376 u8", "scene_rects": args.scene_rects, "keypoints_per_image": n_kp,
+                       "hip_streams": {"caller": len({stream, stream2} | {s.cuda_stream for s in orb_streams}) + (1 if args.pipeline else 0),
+                                       "extractor_internal": n_internal},
+                       "orb_extractor_handles": S, "pipelined_steps": bool(args.pipeline),
+                       "parallelism": f"frame-sharded x{world}" + (", id-range sharded DB + all-gather of 16-byte candidate records" if world > 1 else "")},
+            "rccl_ranks": rccl_ranks if not via_cpu else None, "collective_backend": (args.backend if world > 1 else None),
+            "collective_ranks": rccl_ranks,
+            "roofline": roof, "roofline_valu": roof_valu, "roofline_mfma": mf,
+            "profiled_pass": None if dt_prof is None else {"ms_per_step": dt_prof / args.steps * 1e3,
+                                                           "kernel_ms_per_step": {SYMBOL.get(k, k): v[0] / args.steps for k, v in busy.items()}},
+            "full_solve_cadence6": cadence,
+            "ba_solve_all_windows_ms": solve_ms,     # OptimizeActiveMap solve stage for all P windows, outside the timed region
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(synth, args.workload, args.cpu_pairs, db_np if db_np is not None else synth.lcd_database(16), frames)
+            out["cpu_baseline"] = cpu_baseline(synth, args.workload, args.cpu_pairs, db_np if db_np is not None else synth.lcd_database(16), frames,
+                                               ba_w if ba_w is not None else synth.ba_windows(2)[0])
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -200,6 +200,25 @@ int myslam_lcddb_query(myslam_lcddb* h, const float* descr1064, uint64_t cur_id,
 int myslam_lcddb_query_batch(myslam_lcddb* h, const float* d_q, const uint64_t* cur_ids /*host*/, int nq, float thr_low,
                              uint64_t* d_best_id, float* d_max_score, int32_t* d_cnt);
 
+/* Multi-GPU form: the database is sharded by contiguous key-frame id range, shard r on rank r, every shard scores
+ * every query.  A shard's answer travels as one 16-byte record; the records of all shards (rank order = id order) are reduced to what
+ * ONE scan of src/loopclosing.cpp:124-161 over the whole std::map returns: strict '>' keeps the first (lowest-id) maximum, counts
+ * add up, and the first shard whose own scan hit the `cur - id < 20` break (:133) ends the scan for all shards behind it.
+ * The all-gather between the two calls is the caller's (RCCL ncclAllGather on the raw bytes). */
+typedef struct myslam_lcd_candidate {
+    uint64_t best_id;      /* 0 when nothing scored above 0 (loopclosing.cpp:129) */
+    float max_score;
+    int32_t cnt;           /* bits 0..30: #{score > thr_low} in this shard; bit 31: this shard's scan stopped at the break */
+} myslam_lcd_candidate;
+/* as myslam_lcddb_query_batch, one record per query (device memory, asynchronous on the handle's stream) */
+int myslam_lcddb_query_batch_sharded(myslam_lcddb* h, const float* d_q, const uint64_t* cur_ids /*host*/, int nq, float thr_low,
+                                     myslam_lcd_candidate* d_cand);
+/* gathered: [nshards][nq] records, shard-major in ascending id-range order.  Host pointers (plain C++, no device needed). */
+int myslam_lcd_merge_candidates(const myslam_lcd_candidate* gathered, int nshards, int nq, uint64_t* best_id, float* max_score, int32_t* cnt);
+/* the same reduce on device pointers, asynchronous on hip_stream */
+int myslam_lcd_merge_candidates_device(const myslam_lcd_candidate* d_gathered, int nshards, int nq, uint64_t* d_best_id,
+                                       float* d_max_score, int32_t* d_cnt, void* hip_stream);
+
 /* ------------------------------------------------------------------------------------------
  * Local BA linear-system build — replaces the per-edge work g2o does for
  * Backend::OptimizeActiveMap (src/backend.cpp:126-232): EdgeProjection::computeError /
@@ -213,7 +232,8 @@ int myslam_ba_build(const double* poses, int nposes, const double* points, int n
                     const uint8_t* fixed_pt, double fx, double fy, double cx, double cy, double huber_delta,
                     double* Hpp, double* Hll, double* Hpl, double* bp, double* bl, double* chi2);
 /* batch of `nwin` windows with identical capacities (max_poses, max_pts, max_edges); window w's arrays
- * start at base + w*capacity*elemsize; d_sizes = nwin x 3 (nposes, npts, nedges) */
+ * start at base + w*capacity*elemsize; d_sizes = nwin x 3 (nposes, npts, nedges).  A window whose sizes exceed the capacities is
+ * skipped: its blocks are zero and its chi2[0] = -1. */
 int myslam_ba_build_batch(const double* d_poses, const double* d_points, const int32_t* d_edge_pose,
                           const int32_t* d_edge_pt, const double* d_obs, const uint8_t* d_fixed,
                           const int32_t* d_sizes, int nwin, int max_poses, int max_pts, int max_edges,

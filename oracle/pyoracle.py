@@ -318,24 +318,29 @@ class Oracle:
         assert rc == 0, rc
         return poses, points, chi, out, r.value, no.value
 
-    def bench_frames(self, frames, K, weights, db, ids, ba, stages=3, threads=1, nfeatures=2000):
+    def bench_frames(self, frames, K, weights, db, ids, ba_windows, stages=3, threads=1, nfeatures=2000, n_warmup=0):
         """CPU-baseline driver (bench_oracle.cpp): frames [n,2,H,W] u8 through the whole per-frame pipeline on `threads` threads.
-        Returns wall seconds."""
+        ba_windows = (poses [nw,maxP,7], points [nw,maxL,3], ep [nw,maxE], el [nw,maxE], obs [nw,maxE,2], fixed [nw,maxL],
+        sizes [nw,3]); frame i uses window i % nw.  The first n_warmup frames run untimed.
+        Returns (wall seconds over the frames after the warm-up, per-frame stage seconds [n,5]: orb, match+tri, lcd+db, ba build, ba solve)."""
         frames = np.ascontiguousarray(frames, np.uint8)
         n, _, H, W = frames.shape
         weights = np.ascontiguousarray(weights, np.float32); db = np.ascontiguousarray(db, np.float32)
         ids = np.ascontiguousarray(ids, np.uint64)
-        poses, pts, ep, el, obs, fixed, _ = ba
+        poses, pts, ep, el, obs, fixed, sizes = ba_windows
         poses = np.ascontiguousarray(poses, np.float64); pts = np.ascontiguousarray(pts, np.float64)
         ep = np.ascontiguousarray(ep, np.int32); el = np.ascontiguousarray(el, np.int32)
         obs = np.ascontiguousarray(obs, np.float64); fixed = np.ascontiguousarray(fixed, np.uint8)
-        sec = C.c_double()
+        sizes = np.ascontiguousarray(sizes, np.int32).reshape(-1, 3)
+        nw, maxP, maxL, maxE = len(sizes), poses.shape[1], pts.shape[1], ep.shape[1]
+        assert poses.shape == (nw, maxP, 7) and pts.shape == (nw, maxL, 3) and el.shape == (nw, maxE) and obs.shape == (nw, maxE, 2)
+        sec = C.c_double(); st = np.zeros((n, 5))
         rc = self.lib.orc_bench_frames(_p(frames), n, H, W, nfeatures, C.c_double(K["fx"]), C.c_double(K["fy"]), C.c_double(K["cx"]),
                                        C.c_double(K["cy"]), C.c_double(K["bf"] / K["fx"]), _p(weights), C.c_size_t(weights.size),
-                                       _p(db), _p(ids), len(ids), _p(poses), len(poses), _p(pts), len(pts), _p(ep), _p(el), _p(obs),
-                                       len(ep), _p(fixed), int(stages), int(threads), C.byref(sec))
+                                       _p(db), _p(ids), len(ids), _p(poses), _p(pts), _p(ep), _p(el), _p(obs), _p(fixed), _p(sizes),
+                                       nw, maxP, maxL, maxE, int(stages), int(threads), int(n_warmup), C.byref(sec), _p(st))
         assert rc == 0, rc
-        return sec.value
+        return sec.value, st
 
     def pose_only_optimize(self, pose, pts3d, obs, K, chi2_th=5.991, rounds=4, iters=10, pre_optimize=0):
         pose = np.ascontiguousarray(pose, np.float64).copy(); pts3d = np.ascontiguousarray(pts3d, np.float64); obs = np.ascontiguousarray(obs, np.float64)

@@ -20,8 +20,10 @@ def test_bench_json_contract(extra):
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-              "config", "roofline", "cpu_baseline"):
+              "config", "roofline", "cpu_baseline", "profiled_pass", "rccl_ranks"):
         assert k in d, k
+    assert d["roofline"]["kernel"].startswith("k_")               # the profiled kernel by its symbol
+    assert d["config"]["hip_streams"]["caller"] >= 1
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and d["value"] > 0
     assert abs(d["value"] - 16 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
@@ -55,4 +57,18 @@ def test_bench_two_ranks_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None        # CPU baseline: rank 0 at N=1 only
     assert abs(d["value"] - 2 * 16 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]       # whole-job rate: both ranks' pairs
-    assert "x2" in d["config"]["parallelism"]
+    assert "x2" in d["config"]["parallelism"] and d["collective_ranks"] == 2
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` without torch.distributed.run: bench.py starts its ranks itself (gloo here: both ranks share the
+    box's only GPU; with the default nccl backend each rank takes its own GPU and the JSON carries rccl_ranks)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "16", "--backend", "gloo",
+           "--no-extra-passes"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["collective_ranks"] == 2 and d["collective_backend"] == "gloo" and d["value"] > 0

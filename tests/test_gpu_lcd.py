@@ -168,6 +168,112 @@ def test_loop_database_many_queries_back_to_back(api, oracle, synth):
             assert int(dbest[i]) == rb and abs(float(dmax[i]) - rm) < SCORE_ATOL and int(dcnt[i]) == rc
 
 
+def _db_check(oracle, db, ids, q, cur, dbest, dmax, dcnt, rows):
+    """device results of queries `rows` against the oracle's scan (the oracle scan costs ~n x 1064 flops per query on one core)"""
+    for i in rows:
+        rb, rm, rc = oracle.lcddb_query(db, ids, q[i], int(cur[i]))
+        scores = db @ q[i]
+        near = int((np.abs(scores - 0.92) < 1e-5).sum())                 # counts may only differ for scores within float noise of the threshold
+        assert int(dbest[i]) == rb and abs(float(dmax[i]) - rm) < SCORE_ATOL and abs(int(dcnt[i]) - rc) <= near, i
+
+
+def test_loop_database_configs4_shard_shape(api, oracle, synth):
+    """BASELINE configs[4] per GPU: a 6 250-row shard of the 50 000-KF database scored against 4 096 queries per call (512 frames x
+    8 ranks), through the sharded entry point; 128 of the queries are checked against the oracle's scan, all of them against an f64
+    matrix product; the break flag of every record against the id rule."""
+    import torch
+    n, nq, shard = 6250, 4096, 3
+    db = synth.lcd_database(n, seed=0xDB + shard); ids = np.arange(shard * n, (shard + 1) * n, dtype=np.uint64)
+    D = api.LoopDatabase(n)
+    t = torch.from_numpy(db).cuda(); D.append_batch(ids, t.data_ptr(), n)
+    rng = np.random.default_rng(44)
+    q = db[rng.integers(0, n, nq)] * 0.85 + 0.15 * synth.lcd_database(nq, seed=79)
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    cur = np.full(nq, 8 * n + 20, np.uint64)
+    cur[::5] = rng.integers(shard * n - 50, (shard + 1) * n + 50, len(cur[::5])).astype(np.uint64)      # some scans stop inside / before / after this shard
+    dq = torch.from_numpy(q).cuda()
+    cand = torch.zeros(nq * 16, dtype=torch.uint8, device="cuda")
+    D.query_batch_sharded(dq.data_ptr(), cur, nq, cand.data_ptr())
+    torch.cuda.synchronize()
+    rec = cand.cpu().numpy().view(api.CAND_DTYPE)
+    broke = rec["cnt"] < 0
+    assert np.array_equal(broke, pkg_breaks(ids, cur))
+    cnt = rec["cnt"] & 0x7fffffff
+    _db_check(oracle, db, ids, q, cur, rec["best_id"], rec["max_score"], cnt, range(0, nq, 32))
+    # every query: scores of the rows the scan may see, in f64
+    S = db.astype(np.float64) @ q.astype(np.float64).T                  # [n, nq]
+    for i in range(nq):
+        lim = int(np.searchsorted(ids, np.uint64(max(int(cur[i]) - 19, 0)), side="left")) if broke[i] else n
+        lim = min(lim, n)
+        col = S[:lim, i]
+        if lim == 0 or col.max() <= 0:
+            assert rec["best_id"][i] == 0 and rec["max_score"][i] == 0
+            continue
+        assert abs(float(rec["max_score"][i]) - col.max()) < SCORE_ATOL
+        assert abs(col[int(rec["best_id"][i] - ids[0])] - col.max()) < 2 * SCORE_ATOL
+
+
+def pkg_breaks(ids, cur):
+    from conftest import load_package
+    return load_package().sharded_db.shard_breaks(ids, cur)
+
+
+def test_loop_database_50k_rows(api, oracle, synth):
+    """configs[4]'s whole database on ONE GPU: 50 000 key-frames (212.8 MB of descriptors), 512 queries per call."""
+    import torch
+    n, nq = 50000, 512
+    db = synth.lcd_database(n, seed=0x50); ids = np.arange(n, dtype=np.uint64) * 3 + 7
+    D = api.LoopDatabase(n)
+    t = torch.from_numpy(db).cuda(); D.append_batch(ids, t.data_ptr(), n)
+    rng = np.random.default_rng(45)
+    q = db[rng.integers(0, n, nq)] * 0.9 + 0.1 * synth.lcd_database(nq, seed=80)
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    cur = np.full(nq, int(ids[-1]) + 20, np.uint64)
+    cur[::7] = rng.integers(100, int(ids[-1]) + 40, len(cur[::7])).astype(np.uint64)
+    dq = torch.from_numpy(q).cuda()
+    dbest = torch.zeros(nq, dtype=torch.int64, device="cuda"); dmax = torch.zeros(nq, device="cuda"); dcnt = torch.zeros(nq, dtype=torch.int32, device="cuda")
+    D.query_batch(dq.data_ptr(), cur, nq, dbest.data_ptr(), dmax.data_ptr(), dcnt.data_ptr())
+    torch.cuda.synchronize()
+    _db_check(oracle, db, ids, q, cur, dbest.cpu().numpy(), dmax.cpu().numpy(), dcnt.cpu().numpy(), list(range(0, nq, 16)))
+    one = D.query(q[3], int(cur[3]))                                     # the B = 1 entry point on the same database
+    assert one[0] == int(dbest[3]) and abs(one[1] - float(dmax[3])) < SCORE_ATOL
+
+
+def test_sharded_records_merge_on_device_equals_one_scan(api, oracle, synth):
+    """8 id-range shards on one GPU: per-shard records from myslam_lcddb_query_batch_sharded, reduced by
+    myslam_lcd_merge_candidates_device, equal ONE scan of the whole database — including queries whose scan breaks inside shard 3
+    (everything behind it must be ignored) and a duplicate row in a later shard (the lowest id wins)."""
+    import torch
+    S, per, nq = 8, 300, 96
+    n = S * per
+    db = synth.lcd_database(n, seed=0x51); ids = np.arange(n, dtype=np.uint64) * 2
+    db[5 * per + 11] = db[17]
+    rng = np.random.default_rng(46)
+    q = db[rng.integers(0, n, nq)] * 0.9 + 0.1 * synth.lcd_database(nq, seed=81)
+    q[0] = db[17]; q[1] = db[5 * per + 7]
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    cur = rng.integers(30, 2 * n + 40, nq).astype(np.uint64)
+    cur[0] = 2 * n + 20
+    cur[1] = ids[3 * per + per // 2] + 9                                 # best match in shard 5, break inside shard 3
+    cur[2] = ids[3 * per] + 19                                           # break at the first row of shard 3
+    dq = torch.from_numpy(q).cuda()
+    gathered = torch.zeros(S * nq * 16, dtype=torch.uint8, device="cuda")
+    shards = []
+    for s in range(S):
+        D = api.LoopDatabase(per)
+        t = torch.from_numpy(db[s * per:(s + 1) * per].copy()).cuda(); D.append_batch(ids[s * per:(s + 1) * per], t.data_ptr(), per)
+        D.query_batch_sharded(dq.data_ptr(), cur, nq, gathered.data_ptr() + s * nq * 16)
+        shards.append((D, t))
+    dbest = torch.zeros(nq, dtype=torch.int64, device="cuda"); dmax = torch.zeros(nq, device="cuda"); dcnt = torch.zeros(nq, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    api.lcd_merge_candidates_device(gathered.data_ptr(), S, nq, dbest.data_ptr(), dmax.data_ptr(), dcnt.data_ptr())
+    torch.cuda.synchronize()
+    hb, hm, hc = api.lcd_merge_candidates(gathered.cpu().numpy().view(api.CAND_DTYPE).reshape(S, nq))      # the host entry point agrees
+    assert np.array_equal(hb.view(np.int64), dbest.cpu().numpy()) and np.array_equal(hm, dmax.cpu().numpy()) and np.array_equal(hc, dcnt.cpu().numpy())
+    _db_check(oracle, db, ids, q, cur, dbest.cpu().numpy(), dmax.cpu().numpy(), dcnt.cpu().numpy(), range(nq))
+    assert int(dbest[0]) == 34 and int(dbest[1]) < int(ids[3 * per + per // 2])
+
+
 @pytest.mark.parametrize("h,w", [(376, 1241), (120, 160), (97, 131), (480, 640), (33, 41), (200, 9), (9, 300)])
 def test_fused_input_equals_two_pass_blur(api, synth, h, w):
     """blur_in_place = False evaluates only the blurred pixels the 160 x 120 resize reads (k_lcd_input_fused); blur_in_place = True
