@@ -31,6 +31,10 @@ class MyslamError(RuntimeError):
 
 
 HEADER_PATH = os.path.join(_HERE, "..", "include", "myslam_hip.h")
+CALC_LAYER_DTYPE = np.dtype([("type", "<i4"), ("num_output", "<i4"), ("kernel", "<i4"), ("stride", "<i4"), ("pad", "<i4"),
+                             ("local_size", "<i4"), ("alpha", "<f4"), ("beta", "<f4"), ("k", "<f4")])     # myslam_calc_layer
+assert CALC_LAYER_DTYPE.itemsize == 36
+CALC_CONV, CALC_RELU, CALC_POOL_MAX, CALC_LRN = 1, 2, 3, 4
 CAND_DTYPE = np.dtype([("best_id", "<u8"), ("max_score", "<f4"), ("cnt", "<i4")])      # myslam_lcd_candidate
 assert CAND_DTYPE.itemsize == 16
 
@@ -136,6 +140,12 @@ class ORBextractor:
     def set_fast_gate(self, event_ptr):
         """Make the handle's stream wait for the hipEvent_t `event_ptr` (0 = off) before the FAST stage of every following batched call."""
         _check(lib().myslam_orb_set_fast_gate(self._h, C.c_void_p(event_ptr or None)), "myslam_orb_set_fast_gate")
+
+    OPT_FAST_MODE, OPT_INTERNAL_STREAM, OPT_STOP_AFTER = 1, 2, 3
+
+    def set_option(self, option, value):
+        """scheduling / debugging knobs (myslam_orb_set_option): none of them changes a result"""
+        _check(lib().myslam_orb_set_option(self._h, int(option), int(value)), "myslam_orb_set_option")
 
     def tables(self):
         n = self.nlevels
@@ -268,15 +278,55 @@ def triangulate_stereo_batch(d_kl, d_kr, d_match, d_nl, batch, cap, K, baseline,
 
 
 # ---------------------------------------------------------------------------------- DeepLCD
-class DeepLCD:
-    """DeepLCD(weights) — include/myslam/deeplcd.h:33 (the Caffe prototxt/caffemodel pair becomes one flat f32 blob)."""
+def calc_default_layers():
+    """the SURVEY A.6 layer list as CALC_LAYER_DTYPE records"""
+    n = lib().myslam_lcd_default_layers(None, 0)
+    L = np.zeros(n, CALC_LAYER_DTYPE)
+    assert lib().myslam_lcd_default_layers(_p(L), n) == n
+    return L
 
-    def __init__(self, weights, stream=None):
-        w = np.ascontiguousarray(weights, np.float32).ravel()
+
+def calc_parse_caffe(prototxt_path, caffemodel_path):
+    """(layer records, flat weights) of a deploy.prototxt + .caffemodel pair — host only, no device needed"""
+    nl = C.c_int(); nw = C.c_size_t()
+    _check(lib().myslam_calc_parse_caffe(prototxt_path.encode(), caffemodel_path.encode(), None, 0, C.byref(nl), None, 0, C.byref(nw)),
+           "myslam_calc_parse_caffe")
+    L = np.zeros(nl.value, CALC_LAYER_DTYPE); w = np.zeros(nw.value, np.float32)
+    _check(lib().myslam_calc_parse_caffe(prototxt_path.encode(), caffemodel_path.encode(), _p(L), len(L), C.byref(nl), _p(w), w.size, C.byref(nw)),
+           "myslam_calc_parse_caffe")
+    return L, w
+
+
+class DeepLCD:
+    """DeepLCD(weights) — include/myslam/deeplcd.h:33.  `weights` = flat f32 blob of the SURVEY A.6 layer list; `layers` = explicit
+    CALC_LAYER_DTYPE records; DeepLCD.from_caffe(prototxt, caffemodel) = the reference's constructor arguments."""
+    OPT_GENERIC_KERNELS = 1
+
+    def __init__(self, weights=None, stream=None, layers=None, caffe=None, path=None):
         self._h = C.c_void_p()
-        _check(lib().myslam_lcd_create(C.byref(self._h), _p(w), C.c_size_t(w.size)), "myslam_lcd_create")
+        if caffe is not None:
+            _check(lib().myslam_lcd_create_from_caffe(C.byref(self._h), caffe[0].encode(), caffe[1].encode()), "myslam_lcd_create_from_caffe")
+        elif path is not None:
+            _check(lib().myslam_lcd_create_from_file(C.byref(self._h), path.encode()), "myslam_lcd_create_from_file")
+        else:
+            w = np.ascontiguousarray(weights, np.float32).ravel()
+            if layers is not None:
+                L = np.ascontiguousarray(layers, CALC_LAYER_DTYPE)
+                _check(lib().myslam_lcd_create_from_layers(C.byref(self._h), _p(L), len(L), _p(w), w.size), "myslam_lcd_create_from_layers")
+            else:
+                _check(lib().myslam_lcd_create(C.byref(self._h), _p(w), w.size), "myslam_lcd_create")
         if stream is not None:
             _check(lib().myslam_lcd_set_stream(self._h, C.c_void_p(stream)), "myslam_lcd_set_stream")
+
+    @classmethod
+    def from_caffe(cls, prototxt_path="calc_model/deploy.prototxt", caffemodel_path="calc_model/calc.caffemodel", stream=None):
+        return cls(caffe=(prototxt_path, caffemodel_path), stream=stream)
+
+    def set_option(self, option, value):
+        _check(lib().myslam_lcd_set_option(self._h, int(option), int(value)), "myslam_lcd_set_option")
+
+    def uses_fused_kernels(self):
+        return lib().myslam_lcd_uses_fused_kernels(self._h) == 1
 
     def __del__(self):
         if getattr(self, "_h", None) and self._h.value and _lib is not None:

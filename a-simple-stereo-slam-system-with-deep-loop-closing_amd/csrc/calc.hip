@@ -3,12 +3,17 @@
 //
 //   u8 image --blur 7x7 (sigma<=0 table, optionally in place: reference quirk)--> resize 160x120 --> /255
 //   conv1 64@5x5 s2 p4 + ReLU -> maxpool 3x3 s2 (ceil) -> LRN(5,1e-4,.75)        [VALU, lane = channel]
-//   conv2 128@4x4 s1 p2 + ReLU                                                   [fp32 MFMA implicit GEMM]
+//   conv2 128@4x4 s1 p2 + ReLU                                                   [bf16 matrix cores, f32 accuracy]
 //   maxpool -> LRN -> conv3 4@3x3 + ReLU -> flatten (Caffe NCHW order) -> L2 normalise
 //
+// The layer list is DATA (myslam_calc_layer records: from deploy.prototxt through host/myslam_caffe.hpp, from the CALCW2 model file, or
+// the SURVEY A.6 default).  A list with the geometry above runs on the fused kernels, which take the LRN constants and the ReLU flags
+// as arguments; any other list of Convolution / ReLU / max-Pooling / LRN layers runs on the generic layer-by-layer kernels at the
+// end of this file (so a differing pad or LRN window in the real prototxt needs no new kernel); everything else is refused with
+// MYSLAM_ERR_UNSUPPORTED.
 // Activations are NHWC (channel-last) in HBM so that a wave's 64 lanes map to 64 channels (coalesced
-// 256-byte rows) and conv2's im2col rows are contiguous 64-byte channel runs.  All arithmetic is f32
-// (the reference runs Caffe in f32); conv2 uses v_mfma_f32_32x32x2_f32, which is an exact f32 FMA chain.
+// 256-byte rows) and conv2's im2col rows are contiguous 64-byte channel runs.  All arithmetic is f32-accurate
+// (the reference runs Caffe in f32).
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -18,6 +23,7 @@
 
 #include "common.h"
 #include "orb_plan.h"
+#include "../host/myslam_caffe.hpp"
 
 namespace myslam_hip {
 
@@ -126,85 +132,26 @@ __global__ __launch_bounds__(256) void k_lcd_input_fused(const uint8_t* __restri
     out[(size_t)b * IN_PLANE + (dy + IN_PAD) * IN_PW + dx + IN_PAD] = (float)v * (float)(1.0 / 255.0);
 }
 
-// ---- conv1 + ReLU: lane = output channel, one wave walks 8 output pixels ----
-__global__ __launch_bounds__(256) void k_conv1(const float* __restrict__ in, const float* __restrict__ w1t /*[25][64]*/,
-                                               const float* __restrict__ b1, float* __restrict__ out /*[H1*W1][64]*/) {
-    const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float w[25];
-#pragma unroll
-    for (int k = 0; k < 25; k++) w[k] = w1t[k * 64 + lane];
-    const float bias = b1[lane];
-    const float* I = in + (size_t)b * IN_PLANE;
-    const int p0 = (blockIdx.x * 4 + wave) * 8;
-    for (int p = p0; p < min(p0 + 8, H1 * W1); p++) {
-        const int oy = p / W1, ox = p - oy * W1;
-        float acc = 0.f;
-#pragma unroll
-        for (int ky = 0; ky < 5; ky++) {
-            const int iy = oy * 2 + ky - 4;
-#pragma unroll
-            for (int kx = 0; kx < 5; kx++) {
-                const int ix = ox * 2 + kx - 4;
-                const float v = I[(iy + IN_PAD) * IN_PW + ix + IN_PAD];
-                acc += w[ky * 5 + kx] * v;
-            }
-        }
-        out[((size_t)b * H1 * W1 + p) * 64 + lane] = fmaxf(acc + bias, 0.f);
-    }
-}
-
 // LRN denominator scale^-0.75 = rsqrt(scale) * sqrt(rsqrt(scale)) on the hardware rsq / sqrt units (scale >= 1; within 3 ulp of
 // powf, two orders of magnitude inside the descriptor tolerance) instead of the ~150-instruction powf expansion
 __device__ __forceinline__ float lrn_pow_m075(float scale) {
     const float r = __builtin_amdgcn_rsqf(scale);
     return r * __builtin_amdgcn_sqrtf(r);
 }
-
-// ---- max-pool 3x3 s2 (Caffe ceil mode, clipped windows) + LRN across channels; one wave per output pixel ----
-template <int C>
-__global__ __launch_bounds__(256) void k_pool_lrn(const float* __restrict__ in, int H, int W, int OH, int OW,
-                                                  float* __restrict__ out) {
-    constexpr int PER = C / 64;
-    __shared__ float s_v[4][C + 4];
-    const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int p = blockIdx.x * 4 + wave;
-    if (p < OH * OW) {
-        const int oy = p / OW, ox = p - oy * OW;
-        const int y0 = oy * 2, x0 = ox * 2, y1 = min(y0 + 3, H), x1 = min(x0 + 3, W);
-        const float* I = in + (size_t)b * H * W * C;
-#pragma unroll
-        for (int q = 0; q < PER; q++) {
-            const int c = lane + 64 * q;
-            float m = -INFINITY;
-            for (int y = y0; y < y1; y++)
-                for (int x = x0; x < x1; x++) m = fmaxf(m, I[((size_t)y * W + x) * C + c]);
-            s_v[wave][c + 2] = m;
-        }
-        if (lane < 2) { s_v[wave][lane] = 0.f; s_v[wave][C + 2 + lane] = 0.f; }
-    }
-    __syncthreads();
-    if (p < OH * OW) {
-#pragma unroll
-        for (int q = 0; q < PER; q++) {
-            const int c = lane + 64 * q;
-            const float* v = &s_v[wave][c];          // v[0..4] = channels c-2..c+2 (zero padded)
-            float ss = 0.f;
-#pragma unroll
-            for (int j = 0; j < 5; j++) ss += v[j] * v[j];
-            const float scale = 1.f + (1e-4f / 5.f) * ss;
-            out[((size_t)b * OH * OW + p) * C + c] = v[2] * lrn_pow_m075(scale);
-        }
-    }
+// LRN constants of one layer (lrn_param of the prototxt): y = x * (k + alpha / n * sum x^2)^-beta; aon = alpha / n evaluated in f32 on
+// the host exactly as Caffe does; fast = beta is 0.75 (the hardware rsq / sqrt form above), otherwise powf
+struct LrnP { float aon, beta, k; int fast; };
+__device__ __forceinline__ float lrn_factor(float ss, const LrnP& p) {
+    const float scale = p.k + p.aon * ss;
+    return p.fast ? lrn_pow_m075(scale) : powf(scale, -p.beta);
 }
 
-// ---- the same operator for the 128-channel conv2 map, 2 x 2 pooled pixels per wave ----
+// ---- max-pool 3x3 s2 (Caffe ceil mode, clipped windows) + LRN(5) across the 128 channels of the conv2 map, 2 x 2 pooled pixels per wave ----
 // Lane l owns channels (2l, 2l+1): one 8-byte load per input pixel and lane (a coalesced 512-byte row per wave), all 25 loads of the
 // 5 x 5 input block issued before the first use (coordinates clamped instead of clipped: a duplicate does not change a maximum),
-// every input pixel read 1.56 instead of 2.25 times, the LRN neighbours over lane shuffles instead of LDS.  Same maxima, same
-// LRN summation order (channels c-2 .. c+2) as k_pool_lrn<128>: identical results.
-__global__ __launch_bounds__(256) void k_pool_lrn128_2x2(const float* __restrict__ in, int H, int W, int OH, int OW, float* __restrict__ out) {
+// every input pixel read 1.56 instead of 2.25 times, the LRN neighbours over lane shuffles instead of LDS; LRN summation order
+// channels c-2 .. c+2.
+__global__ __launch_bounds__(256) void k_pool_lrn128_2x2(const float* __restrict__ in, int H, int W, int OH, int OW, LrnP lp, float* __restrict__ out) {
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int TW = (OW + 1) >> 1, TH = (OH + 1) >> 1;
@@ -235,8 +182,8 @@ __global__ __launch_bounds__(256) void k_pool_lrn128_2x2(const float* __restrict
         sa += pv.x * pv.x; sa += pv.y * pv.y; sa += m.x * m.x; sa += m.y * m.y; sa += nx.x * nx.x;
         sb += pv.y * pv.y; sb += m.x * m.x; sb += m.y * m.y; sb += nx.x * nx.x; sb += nx.y * nx.y;
         float2 o;
-        o.x = m.x * lrn_pow_m075(1.f + (1e-4f / 5.f) * sa);
-        o.y = m.y * lrn_pow_m075(1.f + (1e-4f / 5.f) * sb);
+        o.x = m.x * lrn_factor(sa, lp);
+        o.y = m.y * lrn_factor(sb, lp);
         reinterpret_cast<float2*>(out + ((size_t)b * OH * OW + (size_t)py * OW + px) * 128)[lane] = o;
     };
     const bool row1 = oy + 1 < OH, col1 = ox + 1 < OW;           // wave-uniform
@@ -246,60 +193,16 @@ __global__ __launch_bounds__(256) void k_pool_lrn128_2x2(const float* __restrict
     if (row1 && col1) lrn_store(pmax(2, 2), oy + 1, ox + 1);
 }
 
-// ---- conv1 + ReLU + max-pool + LRN fused: one wave per POOLED pixel, lane = channel ----
-// The 3x3 (clipped) pool window needs 9 conv1 outputs = a 9x9 input window, which is wave-uniform: it is fetched with
-// scalar loads and fed to v_fmac as SGPR operands, so the conv1 activation map (1.3 MB per image) never exists in HBM.
-// Same operation order per output as k_conv1 + k_pool_lrn (tap order ky,kx; LRN sum over c-2..c+2): the results agree with
-// the unfused pair to the last bit or two (multiply-add contraction); the LRN neighbours come over lane shuffles instead of LDS.
-__global__ __launch_bounds__(256) void k_conv1_pool_lrn(const float* __restrict__ in, const float* __restrict__ w1t /*[25][64]*/,
-                                                        const float* __restrict__ b1, float* __restrict__ out /*[HP1*WP1][64]*/) {
-    const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int p = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    if (p >= HP1 * WP1) return;
-    float w[25];
-#pragma unroll
-    for (int k = 0; k < 25; k++) w[k] = w1t[k * 64 + lane];
-    const float bias = b1[lane];
-    const int oy = p / WP1, ox = p - oy * WP1;
-    const float* I = in + (size_t)b * IN_PLANE + (4 * oy) * IN_PW + 4 * ox;      // window origin (input row 4 oy - 4, col 4 ox - 4)
-    float win[9][9];
-#pragma unroll
-    for (int r = 0; r < 9; r++)
-#pragma unroll
-        for (int c = 0; c < 9; c++) win[r][c] = I[r * IN_PW + c];
-    float m = -INFINITY;
-#pragma unroll
-    for (int dy = 0; dy < 3; dy++)
-#pragma unroll
-        for (int dx = 0; dx < 3; dx++) {
-            float acc = 0.f;
-#pragma unroll
-            for (int ky = 0; ky < 5; ky++)
-#pragma unroll
-                for (int kx = 0; kx < 5; kx++) acc += w[ky * 5 + kx] * win[2 * dy + ky][2 * dx + kx];
-            const bool inside = 2 * oy + dy < H1 && 2 * ox + dx < W1;      // Caffe ceil-mode pooling: clipped window
-            m = fmaxf(m, inside ? fmaxf(acc + bias, 0.f) : -INFINITY);
-        }
-    // LRN(5, 1e-4, 0.75) across the 64 channels (zero padded)
-    const float um1 = __shfl_up(m, 1, 64), um2 = __shfl_up(m, 2, 64), dp1 = __shfl_down(m, 1, 64), dp2 = __shfl_down(m, 2, 64);
-    const float v0 = lane >= 2 ? um2 : 0.f, v1 = lane >= 1 ? um1 : 0.f, v3 = lane <= 62 ? dp1 : 0.f, v4 = lane <= 61 ? dp2 : 0.f;
-    float ss = 0.f;
-    ss += v0 * v0; ss += v1 * v1; ss += m * m; ss += v3 * v3; ss += v4 * v4;
-    const float scale = 1.f + (1e-4f / 5.f) * ss;
-    out[((size_t)b * HP1 * WP1 + p) * 64 + lane] = m * lrn_pow_m075(scale);
-}
-
-// ---- the same fused operator, 2 x 2 POOLED pixels per wave ----
-// Neighbouring 3x3 / stride-2 pool windows share a row and a column of conv1 outputs: one wave per pooled pixel computes every
-// conv1 output 2.25 times.  Here a wave owns a 2 x 2 block of pooled pixels = 5 x 5 conv1 outputs (1.56 per pooled pixel
+// ---- conv1 + ReLU + max-pool + LRN fused, 2 x 2 POOLED pixels per wave, lane = channel ----
+// The input window of a pool window is wave-uniform: it is fetched with scalar loads and fed to v_fmac as SGPR operands, so the conv1
+// activation map (1.3 MB per image) never exists in HBM.  Neighbouring 3x3 / stride-2 pool windows share a row and a column of conv1
+// outputs: one wave per pooled pixel would compute every conv1 output 2.25 times.  Here a wave owns a 2 x 2 block of pooled pixels = 5 x 5 conv1 outputs (1.56 per pooled pixel
 // instead of 2.25: -31 % FMAs), walks the conv rows top to bottom (5 input rows x 13 columns of wave-uniform scalars per conv
-// row) and folds each output into the maxima of the pooled pixels it belongs to.  Per output the tap order (ky, kx), bias,
-// ReLU, clipping and the LRN are those of k_conv1_pool_lrn (results agree to the last bit or two: the compiler contracts the
-// multiply-add chains of the two kernels differently).
+// row) and folds each output into the maxima of the pooled pixels it belongs to.  Per output: tap order (ky, kx), bias, ReLU,
+// Caffe's clipped ceil-mode windows, LRN over channels c-2 .. c+2 (zero padded) across lane shuffles.
 constexpr int HT1 = (HP1 + 1) / 2, WT1 = (WP1 + 1) / 2;           // 2 x 2 tiles of the pooled map
 __global__ __launch_bounds__(256) void k_conv1_pool_lrn2(const float* __restrict__ in, const float* __restrict__ w1t /*[25][64]*/,
-                                                         const float* __restrict__ b1, float* __restrict__ out /*[HP1*WP1][64]*/) {
+                                                         const float* __restrict__ b1, int relu, LrnP lp, float* __restrict__ out /*[HP1*WP1][64]*/) {
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int tile = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
@@ -329,20 +232,20 @@ __global__ __launch_bounds__(256) void k_conv1_pool_lrn2(const float* __restrict
 #pragma unroll
                 for (int kx = 0; kx < 5; kx++) acc += w[ky * 5 + kx] * win[ky][2 * cx + kx];
             const bool inside = 2 * oy + cy < H1 && 2 * ox + cx < W1;      // Caffe ceil-mode pooling: clipped windows
-            const float v = inside ? fmaxf(acc + bias, 0.f) : -INFINITY;
+            const float pre = acc + bias;
+            const float v = inside ? (relu ? fmaxf(pre, 0.f) : pre) : -INFINITY;
             if (cy <= 2 && cx <= 2) m00 = fmaxf(m00, v);
             if (cy <= 2 && cx >= 2) m01 = fmaxf(m01, v);
             if (cy >= 2 && cx <= 2) m10 = fmaxf(m10, v);
             if (cy >= 2 && cx >= 2) m11 = fmaxf(m11, v);
         }
     }
-    auto lrn_store = [&](float m, int py, int px) {              // LRN(5, 1e-4, 0.75) across the 64 channels (zero padded)
+    auto lrn_store = [&](float m, int py, int px) {              // LRN(5) across the 64 channels (zero padded)
         const float um1 = __shfl_up(m, 1, 64), um2 = __shfl_up(m, 2, 64), dp1 = __shfl_down(m, 1, 64), dp2 = __shfl_down(m, 2, 64);
         const float v0 = lane >= 2 ? um2 : 0.f, v1 = lane >= 1 ? um1 : 0.f, v3 = lane <= 62 ? dp1 : 0.f, v4 = lane <= 61 ? dp2 : 0.f;
         float ss = 0.f;
         ss += v0 * v0; ss += v1 * v1; ss += m * m; ss += v3 * v3; ss += v4 * v4;
-        const float scale = 1.f + (1e-4f / 5.f) * ss;
-        out[((size_t)b * HP1 * WP1 + py * WP1 + px) * 64 + lane] = m * lrn_pow_m075(scale);
+        out[((size_t)b * HP1 * WP1 + py * WP1 + px) * 64 + lane] = m * lrn_factor(ss, lp);
     };
     lrn_store(m00, oy, ox);
     if (col1) lrn_store(m01, oy, ox + 1);
@@ -361,124 +264,13 @@ __device__ __forceinline__ float wave_sum_lane63_f32(float v) {
     return v;
 }
 
-// ---- conv2 + ReLU as an fp32 MFMA implicit GEMM ----
-// C[M = batch*1344][N = 128] = A[M][K = 1024] * Wt[K][N];  k = (ky*4+kx)*64 + ic  (channel runs contiguous in NHWC)
-// 4 waves as 2x2, each wave TI x TJ MFMA 32x32 tiles -> block tile (64 TI) x (64 TJ); BK k per stage, register-staged double
-// buffering through LDS.
-//   <2, 2, 16>  128 x 128 tile, 179 registers: the stand-alone configuration (68 % of the fp32-MFMA peak)
-//   <1, 1, 16>   64 x 64 tile, <= 80 registers and 17 KB of LDS: small enough to sit on a CU NEXT TO six waves per SIMD of the
-//               VALU-bound FAST kernel, so the matrix cores work while the vector ALUs are saturated
 constexpr int CV_BN = 128;
 
-template <int TI, int TJ, int BK>
-__global__ __launch_bounds__(256) void k_conv2_mfma(const float* __restrict__ in /*[B][31*41][64]*/,
-                                                    const float* __restrict__ wt /*[1024][128]*/, const float* __restrict__ b2,
-                                                    float* __restrict__ out /*[B*1344][128]*/, int Mtotal) {
-    constexpr int BM = 64 * TI, BN = 64 * TJ, PA = BM + 4, PB = BN + 4;
-    constexpr int AK = BM * BK / 256;                  // consecutive k per thread of the A slab (2, 4 or 8)
-    constexpr int BPT = BK * BN / 256;                 // consecutive n per thread of the B slab (4 or 8)
-    static_assert(CV_BN % BN == 0 && (AK == 2 || AK == 4 || AK == 8) && (BPT == 4 || BPT == 8) && 64 % BK == 0, "unsupported conv2 tiling");
-    __shared__ __attribute__((aligned(16))) float s_a[2][BK * PA];
-    __shared__ __attribute__((aligned(16))) float s_b[2][BK * PB];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = (wave >> 1) * (32 * TI), wn = (wave & 1) * (32 * TJ);
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-
-    // A staging role: thread -> (row m, AK consecutive k)
-    constexpr int ATPR = BK / AK;                      // threads per A row
-    const int am = t / ATPR, ak = (t % ATPR) * AK;
-    const int gm = m0 + am;
-    const bool mvalid = gm < Mtotal;
-    const int img = mvalid ? gm / M2 : 0;
-    const int pix = mvalid ? gm - img * M2 : 0;
-    const int oy = pix / W2, ox = pix - oy * W2;
-    const float* inb = in + (size_t)img * HP1 * WP1 * 64;
-    // B staging role: thread -> (k row, BPT consecutive n)
-    constexpr int BTPR = BN / BPT;
-    const int bk = t / BTPR, bn = (t % BTPR) * BPT;
-
-    float ra[AK], rb[BPT];
-    auto load_stage = [&](int s) {
-        constexpr int SPT = 64 / BK;                   // stages per filter tap
-        const int tap = s / SPT, ic0 = (s % SPT) * BK;
-        const int iy = oy + (tap >> 2) - 2, ix = ox + (tap & 3) - 2;
-        if (mvalid && iy >= 0 && iy < HP1 && ix >= 0 && ix < WP1) {
-            const float* src = inb + ((size_t)iy * WP1 + ix) * 64 + ic0 + ak;
-            if constexpr (AK == 2) { const float2 v = *reinterpret_cast<const float2*>(src); ra[0] = v.x; ra[1] = v.y; }
-            else {
-#pragma unroll
-                for (int q = 0; q < AK / 4; q++) { const float4 v = reinterpret_cast<const float4*>(src)[q]; ra[4 * q] = v.x; ra[4 * q + 1] = v.y; ra[4 * q + 2] = v.z; ra[4 * q + 3] = v.w; }
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < AK; q++) ra[q] = 0.f;
-        }
-        const float4* wsrc = reinterpret_cast<const float4*>(wt + (size_t)(s * BK + bk) * CV_BN + n0 + bn);
-#pragma unroll
-        for (int q = 0; q < BPT / 4; q++) { const float4 v = wsrc[q]; rb[4 * q] = v.x; rb[4 * q + 1] = v.y; rb[4 * q + 2] = v.z; rb[4 * q + 3] = v.w; }
-    };
-    auto store_stage = [&](int buf) {
-        float* a = s_a[buf];
-#pragma unroll
-        for (int q = 0; q < AK; q++) a[(ak + q) * PA + am] = ra[q];
-        float4* bdst = reinterpret_cast<float4*>(&s_b[buf][bk * PB + bn]);
-#pragma unroll
-        for (int q = 0; q < BPT / 4; q++) bdst[q] = make_float4(rb[4 * q], rb[4 * q + 1], rb[4 * q + 2], rb[4 * q + 3]);
-    };
-
-    f32x16 acc[TI][TJ];
-#pragma unroll
-    for (int i = 0; i < TI; i++)
-#pragma unroll
-        for (int j = 0; j < TJ; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-    load_stage(0);
-    store_stage(0);
-    __syncthreads();
-    constexpr int NSTAGE = K2 / BK;
-    const int lr = lane & 31, lk = lane >> 5;
-    for (int s = 0; s < NSTAGE; s++) {
-        const int buf = s & 1;
-        if (s + 1 < NSTAGE) load_stage(s + 1);
-        const float* a = s_a[buf];
-        const float* bb = s_b[buf];
-#pragma unroll
-        for (int kq = 0; kq < BK / 2; kq++) {
-            const int k = 2 * kq + lk;
-            float av[TI], bv[TJ];
-#pragma unroll
-            for (int i = 0; i < TI; i++) av[i] = a[k * PA + wm + 32 * i + lr];
-#pragma unroll
-            for (int j = 0; j < TJ; j++) bv[j] = bb[k * PB + wn + 32 * j + lr];
-#pragma unroll
-            for (int i = 0; i < TI; i++)
-#pragma unroll
-                for (int j = 0; j < TJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
-        if (s + 1 < NSTAGE) store_stage(buf ^ 1);
-        __syncthreads();
-    }
-    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-#pragma unroll
-    for (int j = 0; j < TJ; j++) {
-        const int n = n0 + wn + j * 32 + lr;
-        const float bias = b2[n];
-#pragma unroll
-        for (int i = 0; i < TI; i++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (m < Mtotal) out[(size_t)m * CV_BN + n] = fmaxf(acc[i][j][r] + bias, 0.f);
-            }
-    }
-}
-
-// ---- conv2 on the bf16 matrix cores with fp32 accuracy ----
-// The fp32-input MFMA above runs at the f32 VECTOR rate — in practice it competes with the VALU-bound ORB kernels of the other
-// stream instead of running under them (measured: no gain from co-residency).  The bf16 matrix pipe is 16x
-// faster and separate.  Every f32 operand is split exactly into three bf16 pieces a = h + m + l (8 + 8 + 8 significand bits,
+// ---- conv2 + ReLU as an implicit GEMM on the bf16 matrix cores with fp32 accuracy ----
+// C[M = batch*1344][N = 128] = A[M][K = 1024] * Wt[K][N];  k = (ky*4+kx)*64 + ic  (channel runs contiguous in NHWC).
+// An fp32-input MFMA (v_mfma_f32_32x32x2_f32) runs at the f32 VECTOR rate — in practice it competes with the VALU-bound ORB kernels of
+// the other stream instead of running under them (measured: 1.48 against 0.93 ms per 512 frames, no gain from co-residency,
+// DESIGN.md section 4).  The bf16 matrix pipe is 16x faster and separate.  Every f32 operand is split exactly into three bf16 pieces a = h + m + l (8 + 8 + 8 significand bits,
 // round-to-nearest conversions, exact residuals); of the nine partial products the six largest are kept:
 //     a b  ~  hh + hm + mh + hl + lh + mm        (dropped: ml, lm, ll <= 2^-23 |a b|, the rounding level of an f32 product)
 // accumulated in f32 by v_mfma_f32_32x32x16_bf16.  Weights are split once on the host ([stage][piece][n][16 k], so a stage's slab
@@ -500,7 +292,7 @@ __device__ __forceinline__ void cv_split3(float a0, float a1, uint32_t& h, uint3
 
 __global__ __launch_bounds__(256) void k_conv2_bf16x6(const float* __restrict__ in /*[B][31*41][64]*/,
                                                       const uint4* __restrict__ wt3 /*[64 stages][3][128 n][2 k-halves] x 8 bf16*/,
-                                                      const float* __restrict__ b2, float* __restrict__ out /*[B*1344][128]*/, int Mtotal) {
+                                                      const float* __restrict__ b2, float* __restrict__ out /*[B*1344][128]*/, int Mtotal, int relu) {
     constexpr int BM = 128, BN = 128;
     __shared__ uint4 s_a[2][3][BM * 2];                // [piece][row m][k half]: 8 bf16 per uint4
     __shared__ uint4 s_b[2][3][BN * 2];
@@ -589,7 +381,8 @@ __global__ __launch_bounds__(256) void k_conv2_bf16x6(const float* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (m < Mtotal) out[(size_t)m * CV_BN + n] = fmaxf(acc[i][j][r] + bias, 0.f);
+                const float v = acc[i][j][r] + bias;
+                if (m < Mtotal) out[(size_t)m * CV_BN + n] = relu ? fmaxf(v, 0.f) : v;
             }
     }
 }
@@ -643,6 +436,87 @@ __global__ __launch_bounds__(CV3_T) void k_conv3_norm(const float* __restrict__ 
     for (int i = threadIdx.x; i < MYSLAM_LCD_DIM; i += CV3_T) out[(size_t)b * MYSLAM_LCD_DIM + i] = s_o[i] / nrm;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Generic layer kernels (NHWC f32): any list of Convolution / ReLU / max-Pooling (Caffe ceil mode) / LRN (across channels) layers.
+// Slower than the fused kernels (no fusion, no matrix cores) — they exist so that a layer list that differs from SURVEY A.6
+// (pad, LRN window, an extra layer ...) still runs, and they serve the stage taps of the parity tests.
+// ------------------------------------------------------------------------------------------------
+// one wave per output pixel, lane -> output channels lane, lane + 64, ...; the input value of a tap is wave-uniform
+__global__ __launch_bounds__(256) void k_conv_generic(const float* __restrict__ in, size_t in_stride, int in_pitch /*floats per row*/, int H, int W, int IC,
+                                                      const float* __restrict__ wt /*[K*K*IC][OC]*/, const float* __restrict__ bias, int OC, int K, int S,
+                                                      int P, int relu, float* __restrict__ out /*[OH*OW][OC]*/, int OH, int OW) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int p = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (p >= OH * OW) return;
+    const int oy = p / OW, ox = p - oy * OW;
+    const float* I = in + (size_t)b * in_stride;
+    for (int oc0 = 0; oc0 < OC; oc0 += 64) {
+        const int oc = oc0 + lane;
+        float acc = 0.f;
+        for (int ky = 0; ky < K; ky++) {
+            const int iy = oy * S + ky - P;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < K; kx++) {
+                const int ix = ox * S + kx - P;
+                if (ix < 0 || ix >= W) continue;
+                const float* src = I + (size_t)iy * in_pitch + (size_t)ix * IC;
+                const float* wk = wt + (size_t)((ky * K + kx) * IC) * OC + oc;
+                if (oc < OC)
+                    for (int ic = 0; ic < IC; ic++) acc += wk[(size_t)ic * OC] * src[ic];
+            }
+        }
+        if (oc < OC) {
+            const float v = acc + bias[oc];
+            out[((size_t)b * OH * OW + p) * OC + oc] = relu ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_relu_generic(float* __restrict__ x, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] = fmaxf(x[i], 0.f);
+}
+
+// Caffe max pooling, ceil mode, windows clipped to the input (pad 0); thread per output element
+__global__ __launch_bounds__(256) void k_pool_generic(const float* __restrict__ in, int H, int W, int C, int K, int S, float* __restrict__ out, int OH, int OW) {
+    const int b = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)OH * OW * C) return;
+    const int c = (int)(i % C), p = (int)(i / C), oy = p / OW, ox = p - oy * OW;
+    const int y0 = oy * S, x0 = ox * S, y1 = min(y0 + K, H), x1 = min(x0 + K, W);
+    const float* I = in + (size_t)b * H * W * C;
+    float m = -INFINITY;
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++) m = fmaxf(m, I[((size_t)y * W + x) * C + c]);
+    out[(size_t)b * OH * OW * C + i] = m;
+}
+
+// Caffe LRN across channels: y = x * (k + alpha / n * sum_{|j - c| <= n/2} x_j^2)^-beta
+__global__ __launch_bounds__(256) void k_lrn_generic(const float* __restrict__ in, int HW, int C, int n, LrnP lp, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)HW * C) return;
+    const int c = (int)(i % C);
+    const float* v = in + (size_t)b * HW * C + i - c;
+    float ss = 0.f;
+    for (int j = max(0, c - n / 2); j <= min(C - 1, c + n / 2); j++) ss += v[j] * v[j];
+    out[(size_t)b * HW * C + i] = v[c] * lrn_factor(ss, lp);
+}
+
+// flatten in Caffe's NCHW order + L2 normalise (deeplcd.cpp:80-88); one block per image, N = C * HW = 1064
+__global__ __launch_bounds__(256) void k_flatten_norm_generic(const float* __restrict__ in /*[HW][C]*/, int HW, int C, float* __restrict__ out) {
+    __shared__ float s_red[4];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* I = in + (size_t)b * HW * C;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < HW * C; i += 256) ss += I[i] * I[i];
+    ss = wave_sum_lane63_f32(ss);
+    if (lane == 63) s_red[wave] = ss;
+    __syncthreads();
+    const float nrm = sqrtf(s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+    for (int i = threadIdx.x; i < HW * C; i += 256) { const int c = i % C, p = i / C; out[(size_t)b * HW * C + (size_t)c * HW + p] = I[i] / nrm; }
+}
+
 static void lcd_resize_tables(int ssize, int dsize, bool is_x, std::vector<int32_t>& ofs, std::vector<int16_t>& coef) {
     const double inv_scale = (double)dsize / ssize;
     const double scale = 1. / inv_scale;
@@ -661,29 +535,105 @@ static void lcd_resize_tables(int ssize, int dsize, bool is_x, std::vector<int32
     }
 }
 
+// the SURVEY A.6 layer list (the defaults of the flat CALCW1 blob)
+static const myslam_calc_layer kDefaultLayers[10] = {
+    {MYSLAM_CALC_CONV, 64, 5, 2, 4, 0, 0.f, 0.f, 0.f},  {MYSLAM_CALC_RELU, 0, 0, 0, 0, 0, 0.f, 0.f, 0.f},
+    {MYSLAM_CALC_POOL_MAX, 0, 3, 2, 0, 0, 0.f, 0.f, 0.f}, {MYSLAM_CALC_LRN, 0, 0, 0, 0, 5, 1e-4f, 0.75f, 1.f},
+    {MYSLAM_CALC_CONV, 128, 4, 1, 2, 0, 0.f, 0.f, 0.f}, {MYSLAM_CALC_RELU, 0, 0, 0, 0, 0, 0.f, 0.f, 0.f},
+    {MYSLAM_CALC_POOL_MAX, 0, 3, 2, 0, 0, 0.f, 0.f, 0.f}, {MYSLAM_CALC_LRN, 0, 0, 0, 0, 5, 1e-4f, 0.75f, 1.f},
+    {MYSLAM_CALC_CONV, 4, 3, 1, 0, 0, 0.f, 0.f, 0.f},   {MYSLAM_CALC_RELU, 0, 0, 0, 0, 0, 0.f, 0.f, 0.f}};
+
+// shape walk of a layer list from 1 x IN_H x IN_W: validates it, counts the weights, returns the output size
+struct LayerShape { int C, H, W; };
+static int walk_layers(const myslam_calc_layer* L, int n, std::vector<LayerShape>& shapes, size_t& nweights) {
+    LayerShape s{1, IN_H, IN_W};
+    nweights = 0; shapes.clear();
+    if (!L || n < 1 || n > 64) return MYSLAM_ERR_INVALID;
+    for (int i = 0; i < n; i++) {
+        const myslam_calc_layer& l = L[i];
+        switch (l.type) {
+            case MYSLAM_CALC_CONV:
+                if (l.num_output < 1 || l.num_output > 1024 || l.kernel < 1 || l.kernel > 15 || l.stride < 1 || l.pad < 0 || l.pad >= l.kernel) return MYSLAM_ERR_INVALID;
+                if (s.H + 2 * l.pad < l.kernel || s.W + 2 * l.pad < l.kernel) return MYSLAM_ERR_INVALID;
+                nweights += (size_t)l.num_output * s.C * l.kernel * l.kernel + (size_t)l.num_output;
+                s = {l.num_output, (s.H + 2 * l.pad - l.kernel) / l.stride + 1, (s.W + 2 * l.pad - l.kernel) / l.stride + 1};
+                break;
+            case MYSLAM_CALC_RELU: break;
+            case MYSLAM_CALC_POOL_MAX: {
+                if (l.kernel < 1 || l.stride < 1 || l.kernel > s.H || l.kernel > s.W) return MYSLAM_ERR_INVALID;
+                if (l.pad != 0) return MYSLAM_ERR_UNSUPPORTED;
+                int oh = (int)ceilf((float)(s.H - l.kernel) / l.stride) + 1, ow = (int)ceilf((float)(s.W - l.kernel) / l.stride) + 1;      // Caffe ceil mode
+                if ((oh - 1) * l.stride >= s.H) oh--;
+                if ((ow - 1) * l.stride >= s.W) ow--;
+                s = {s.C, oh, ow};
+                break;
+            }
+            case MYSLAM_CALC_LRN:
+                if (l.local_size < 1 || !(l.local_size & 1) || !(l.k > 0.f) || !(l.alpha >= 0.f)) return MYSLAM_ERR_INVALID;
+                break;
+            default: return MYSLAM_ERR_UNSUPPORTED;
+        }
+        shapes.push_back(s);
+    }
+    if ((size_t)s.C * s.H * s.W != MYSLAM_LCD_DIM) return MYSLAM_ERR_UNSUPPORTED;          // deeplcd.cpp:80 asserts 1064 outputs
+    return MYSLAM_OK;
+}
+
+// does the list have the geometry the fused kernels are written for?  (optional ReLUs; a missing LRN = the identity LRN)
+struct FusedPlan { bool ok; int relu[3]; LrnP lrn[2]; };
+static FusedPlan match_fused(const myslam_calc_layer* L, int n) {
+    FusedPlan f{false, {0, 0, 0}, {{0.f, 0.75f, 1.f, 1}, {0.f, 0.75f, 1.f, 1}}};
+    const int geo[3][4] = {{C1, 5, 2, 4}, {C2, 4, 1, 2}, {C3, 3, 1, 0}};
+    int i = 0;
+    for (int blk = 0; blk < 3; blk++) {
+        if (i >= n || L[i].type != MYSLAM_CALC_CONV || L[i].num_output != geo[blk][0] || L[i].kernel != geo[blk][1] || L[i].stride != geo[blk][2] ||
+            L[i].pad != geo[blk][3])
+            return f;
+        i++;
+        if (i < n && L[i].type == MYSLAM_CALC_RELU) { f.relu[blk] = 1; i++; }
+        if (blk == 2) break;
+        if (i >= n || L[i].type != MYSLAM_CALC_POOL_MAX || L[i].kernel != 3 || L[i].stride != 2 || L[i].pad != 0) return f;
+        i++;
+        if (i < n && L[i].type == MYSLAM_CALC_LRN) {
+            if (L[i].local_size != 5) return f;
+            f.lrn[blk] = {L[i].alpha / (float)L[i].local_size, L[i].beta, L[i].k, L[i].beta == 0.75f ? 1 : 0};
+            i++;
+        }
+    }
+    f.ok = (i == n);
+    return f;
+}
+
 }  // namespace myslam_hip
 
 using namespace myslam_hip;
 
 struct myslam_lcd {
     hipStream_t stream = nullptr;
-    float *d_w1t = nullptr, *d_b1 = nullptr, *d_w2t = nullptr, *d_b2 = nullptr, *d_w3t = nullptr, *d_b3 = nullptr;
-    uint4* d_w2s = nullptr;            // conv2 weights split into three bf16 pieces, [stage][piece][n][k half] x 8 bf16
-    int relu3 = 1;
+    // the model
+    std::vector<myslam_calc_layer> layers; std::vector<LayerShape> shapes;
+    FusedPlan fused{};                 // fused.ok: the layer list has the geometry of the fused kernels
+    int forceGeneric = 0;              // myslam_lcd_set_option(GENERIC_KERNELS)
+    std::vector<float*> d_wt, d_b;     // per convolution: weights re-laid out as [K*K*IC][OC], bias
+    uint4* d_w2s = nullptr;            // fused path: conv2 weights split into three bf16 pieces, [stage][piece][n][k half] x 8 bf16
+    size_t actMax = 0;                 // largest activation (floats per image) of the generic path
     // resize tables for the current source size
     int rows = 0, cols = 0;
     int32_t *d_xofs = nullptr, *d_yofs = nullptr; int16_t *d_xa = nullptr, *d_yb = nullptr;
     // batch buffers
     int batchCap = 0; size_t blurBytes = 0; int blurPitch = 0;
     uint8_t* d_blur = nullptr;
-    float *d_in = nullptr, *d_a1 = nullptr, *d_p1 = nullptr, *d_a2 = nullptr, *d_p2 = nullptr;
+    float *d_in = nullptr, *d_p1 = nullptr, *d_a2 = nullptr, *d_p2 = nullptr;      // fused path activations
+    float *d_g0 = nullptr, *d_g1 = nullptr; int genericCap = 0;                    // generic path ping-pong (allocated on first use)
     // host-entry staging
-    uint8_t* d_stageImg = nullptr; size_t stageBytes = 0; float* d_stageOut = nullptr;
+    uint8_t* d_stageImg = nullptr; size_t stageBytes = 0; float* d_stageOut = nullptr; float* h_stageOut = nullptr;
 
     int ensure_tables(int r, int c);
     int ensure_batch(int batch, int r, int c);
-    int forward(int batch);     // d_in -> d_out
+    int ensure_generic(int batch);
+    int forward_generic(int batch, float* d_out, int stop_after, float** tap);
     int describe(uint8_t* d_imgs, int batch, int r, int c, int step, size_t stride, int blur_in_place, float* d_out);
+    void free_all();
 };
 
 template <typename T>
@@ -692,6 +642,14 @@ static int lcd_alloc(T*& p, size_t n) {
     if (!n) return MYSLAM_OK;
     MYSLAM_HIP_CHECK(hipMalloc((void**)&p, n * sizeof(T)));
     return MYSLAM_OK;
+}
+
+void myslam_lcd::free_all() {
+    void* ptrs[] = {d_w2s, d_xofs, d_yofs, d_xa, d_yb, d_blur, d_in, d_p1, d_a2, d_p2, d_g0, d_g1, d_stageImg, d_stageOut};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (float* p : d_wt) if (p) (void)hipFree(p);
+    for (float* p : d_b) if (p) (void)hipFree(p);
+    if (h_stageOut) (void)hipHostFree(h_stageOut);
 }
 
 int myslam_lcd::ensure_tables(int r, int c) {
@@ -722,49 +680,83 @@ int myslam_lcd::ensure_batch(int batch, int r, int c) {
     if ((rc = lcd_alloc(d_blur, blurBytes * batch))) return rc;
     if ((rc = lcd_alloc(d_in, (size_t)batch * IN_PLANE))) return rc;
     MYSLAM_HIP_CHECK(hipMemsetAsync(d_in, 0, (size_t)batch * IN_PLANE * sizeof(float), stream));     // the padding stays zero: writers touch the interior only
-    if ((rc = lcd_alloc(d_a1, (size_t)batch * H1 * W1 * C1))) return rc;
-    if ((rc = lcd_alloc(d_p1, (size_t)batch * HP1 * WP1 * C1))) return rc;
-    if ((rc = lcd_alloc(d_a2, (size_t)batch * H2 * W2 * C2))) return rc;
-    if ((rc = lcd_alloc(d_p2, (size_t)batch * HP2 * WP2 * C2))) return rc;
-    batchCap = batch;
+    if (fused.ok) {
+        if ((rc = lcd_alloc(d_p1, (size_t)batch * HP1 * WP1 * C1))) return rc;
+        if ((rc = lcd_alloc(d_a2, (size_t)batch * H2 * W2 * C2))) return rc;
+        if ((rc = lcd_alloc(d_p2, (size_t)batch * HP2 * WP2 * C2))) return rc;
+    }
+    batchCap = batch; genericCap = 0;
+    return MYSLAM_OK;
+}
+
+int myslam_lcd::ensure_generic(int batch) {
+    if (batch <= genericCap) return MYSLAM_OK;
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(stream));
+    int rc;
+    if ((rc = lcd_alloc(d_g0, (size_t)batch * actMax)) || (rc = lcd_alloc(d_g1, (size_t)batch * actMax))) return rc;
+    genericCap = batch;
+    return MYSLAM_OK;
+}
+
+// layer by layer on the generic kernels.  stop_after >= 0: stop after that layer index and return its activation in *tap.
+int myslam_lcd::forward_generic(int batch, float* d_out, int stop_after, float** tap) {
+    int rc = ensure_generic(batch);
+    if (rc) return rc;
+    hipStream_t s = stream;
+    const float* cur = d_in + IN_PAD * IN_PW + IN_PAD; size_t curStride = IN_PLANE; int curPitch = IN_PW;      // the interior of the padded input plane
+    LayerShape sh{1, IN_H, IN_W};
+    float* bufs[2] = {d_g0, d_g1}; int nb = 0, conv = 0;
+    ScopedProf sp(P_CONV2, s);
+    for (size_t i = 0; i < layers.size(); i++) {
+        const myslam_calc_layer& l = layers[i];
+        const LayerShape o = shapes[i];
+        if (l.type == MYSLAM_CALC_RELU) {
+            if (cur == d_in + IN_PAD * IN_PW + IN_PAD) return MYSLAM_ERR_UNSUPPORTED;                       // a ReLU on the raw input (never in a CALC net)
+            const size_t n = (size_t)batch * o.C * o.H * o.W;
+            hipLaunchKernelGGL(k_relu_generic, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, const_cast<float*>(cur), n);
+        } else {
+            float* dst = bufs[nb]; nb ^= 1;
+            if (l.type == MYSLAM_CALC_CONV) {
+                hipLaunchKernelGGL(k_conv_generic, dim3((o.H * o.W + 3) / 4, batch), dim3(256), 0, s, cur, curStride, curPitch, sh.H, sh.W, sh.C,
+                                   d_wt[conv], d_b[conv], o.C, l.kernel, l.stride, l.pad, 0, dst, o.H, o.W);
+                conv++;
+            } else if (l.type == MYSLAM_CALC_POOL_MAX) {
+                if (curPitch != sh.W * sh.C) return MYSLAM_ERR_UNSUPPORTED;
+                const size_t n = (size_t)o.C * o.H * o.W;
+                hipLaunchKernelGGL(k_pool_generic, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, s, cur, sh.H, sh.W, sh.C, l.kernel, l.stride, dst, o.H, o.W);
+            } else {
+                if (curPitch != sh.W * sh.C) return MYSLAM_ERR_UNSUPPORTED;
+                const size_t n = (size_t)o.C * o.H * o.W;
+                const LrnP lp{l.alpha / (float)l.local_size, l.beta, l.k, l.beta == 0.75f ? 1 : 0};
+                hipLaunchKernelGGL(k_lrn_generic, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, s, cur, o.H * o.W, o.C, l.local_size, lp, dst);
+            }
+            cur = dst; curStride = (size_t)o.C * o.H * o.W; curPitch = o.W * o.C;
+        }
+        sh = o;
+        if ((int)i == stop_after) { if (tap) *tap = const_cast<float*>(cur); MYSLAM_HIP_CHECK(hipGetLastError()); return MYSLAM_OK; }
+    }
+    hipLaunchKernelGGL(k_flatten_norm_generic, dim3(batch), dim3(256), 0, s, cur, sh.H * sh.W, sh.C, d_out);
+    MYSLAM_HIP_CHECK(hipGetLastError());
     return MYSLAM_OK;
 }
 
 static int lcd_forward(myslam_lcd* h, int batch, float* d_out) {
+    if (!h->fused.ok || h->forceGeneric) return h->forward_generic(batch, d_out, -1, nullptr);
     hipStream_t s = h->stream;
+    const FusedPlan& f = h->fused;
     {
         ScopedProf sp(P_CONV1, s);
-        static const char* env = getenv("MYSLAM_CONV1_V");        // tuning aid: 1 = unfused conv1 -> pool/LRN pair
-        if (env && atoi(env) == 1) {
-            hipLaunchKernelGGL(k_conv1, dim3((H1 * W1 + 31) / 32, batch), dim3(256), 0, s, h->d_in, h->d_w1t, h->d_b1, h->d_a1);
-            hipLaunchKernelGGL((k_pool_lrn<C1>), dim3((HP1 * WP1 + 3) / 4, batch), dim3(256), 0, s, h->d_a1, H1, W1, HP1, WP1, h->d_p1);
-        } else if (env && atoi(env) == 2) {                       // one wave per pooled pixel
-            hipLaunchKernelGGL(k_conv1_pool_lrn, dim3((HP1 * WP1 + 3) / 4, batch), dim3(256), 0, s, h->d_in, h->d_w1t, h->d_b1, h->d_p1);
-        } else {
-            hipLaunchKernelGGL(k_conv1_pool_lrn2, dim3((HT1 * WT1 + 3) / 4, batch), dim3(256), 0, s, h->d_in, h->d_w1t, h->d_b1, h->d_p1);
-        }
+        hipLaunchKernelGGL(k_conv1_pool_lrn2, dim3((HT1 * WT1 + 3) / 4, batch), dim3(256), 0, s, h->d_in, h->d_wt[0], h->d_b[0], f.relu[0], f.lrn[0], h->d_p1);
     }
     {
         ScopedProf sp(P_CONV2, s);
         const int Mtotal = batch * M2;
-        static const int lite = [] { const char* e = getenv("MYSLAM_CONV2_V"); return e ? atoi(e) : 3; }();     // 0/1/2: f32-input MFMA tilings
-        if (lite == 3)
-            hipLaunchKernelGGL(k_conv2_bf16x6, dim3((Mtotal + 127) / 128), dim3(256), 0, s, h->d_p1, h->d_w2s, h->d_b2, h->d_a2, Mtotal);
-        else if (lite == 1)
-            hipLaunchKernelGGL((k_conv2_mfma<1, 1, 16>), dim3((Mtotal + 63) / 64, 2), dim3(256), 0, s, h->d_p1, h->d_w2t, h->d_b2, h->d_a2, Mtotal);
-        else if (lite == 2)
-            hipLaunchKernelGGL((k_conv2_mfma<1, 2, 8>), dim3((Mtotal + 63) / 64), dim3(256), 0, s, h->d_p1, h->d_w2t, h->d_b2, h->d_a2, Mtotal);
-        else
-            hipLaunchKernelGGL((k_conv2_mfma<2, 2, 16>), dim3((Mtotal + 127) / 128), dim3(256), 0, s, h->d_p1, h->d_w2t, h->d_b2, h->d_a2, Mtotal);
+        hipLaunchKernelGGL(k_conv2_bf16x6, dim3((Mtotal + 127) / 128), dim3(256), 0, s, h->d_p1, h->d_w2s, h->d_b[1], h->d_a2, Mtotal, f.relu[1]);
     }
     {
         ScopedProf sp(P_CONV3, s);
-        static const char* envp = getenv("MYSLAM_POOL2_V");         // tuning aid: 1 = one wave per pooled pixel, LRN through LDS
-        if (envp && atoi(envp) == 1)
-            hipLaunchKernelGGL((k_pool_lrn<C2>), dim3((HP2 * WP2 + 3) / 4, batch), dim3(256), 0, s, h->d_a2, H2, W2, HP2, WP2, h->d_p2);
-        else
-            hipLaunchKernelGGL(k_pool_lrn128_2x2, dim3((((HP2 + 1) / 2) * ((WP2 + 1) / 2) + 3) / 4, batch), dim3(256), 0, s, h->d_a2, H2, W2, HP2, WP2, h->d_p2);
-        hipLaunchKernelGGL(k_conv3_norm, dim3(batch), dim3(CV3_T), 0, s, h->d_p2, h->d_w3t, h->d_b3, d_out, h->relu3);
+        hipLaunchKernelGGL(k_pool_lrn128_2x2, dim3((((HP2 + 1) / 2) * ((WP2 + 1) / 2) + 3) / 4, batch), dim3(256), 0, s, h->d_a2, H2, W2, HP2, WP2, f.lrn[1], h->d_p2);
+        hipLaunchKernelGGL(k_conv3_norm, dim3(batch), dim3(CV3_T), 0, s, h->d_p2, h->d_wt[2], h->d_b[2], d_out, f.relu[2]);
     }
     MYSLAM_HIP_CHECK(hipGetLastError());
     return MYSLAM_OK;
@@ -776,8 +768,7 @@ int myslam_lcd::describe(uint8_t* d_imgs, int batch, int r, int c, int step, siz
     if (rc) return rc;
     {
         ScopedProf sp(P_LCD_PRE, stream);
-        static const int fused = [] { const char* e = getenv("MYSLAM_LCD_PRE_V"); return e ? atoi(e) != 1 : 1; }();     // tuning aid: 1 = two-pass blur + resize
-        if (!blur_in_place && fused) {
+        if (!blur_in_place) {
             LcdTaps tp;
             gauss_q8(1, tp.q);
             hipLaunchKernelGGL(k_lcd_input_fused, dim3((IN_H * IN_W + 255) / 256, batch), dim3(256), 0, stream, d_imgs, c, r, step, stride,
@@ -787,10 +778,9 @@ int myslam_lcd::describe(uint8_t* d_imgs, int batch, int r, int c, int step, siz
             a.src = d_imgs; a.dst = d_blur; a.w = c; a.h = r; a.spitch = step; a.dpitch = blurPitch; a.sstride = stride; a.dstride = blurBytes;
             gauss_q8(1, a.q);
             launch_blur(a, batch, stream);
-            if (blur_in_place)                            // the reference mutates the caller's pixels
-                for (int b = 0; b < batch; b++)
-                    MYSLAM_HIP_CHECK(hipMemcpy2DAsync(d_imgs + (size_t)b * stride, step, d_blur + (size_t)b * blurBytes, blurPitch, c, r,
-                                                      hipMemcpyDeviceToDevice, stream));
+            for (int b = 0; b < batch; b++)               // the reference mutates the caller's pixels
+                MYSLAM_HIP_CHECK(hipMemcpy2DAsync(d_imgs + (size_t)b * stride, step, d_blur + (size_t)b * blurBytes, blurPitch, c, r,
+                                                  hipMemcpyDeviceToDevice, stream));
             hipLaunchKernelGGL(k_lcd_input, dim3((IN_H * IN_W + 255) / 256, batch), dim3(256), 0, stream, d_blur, c, r, blurPitch, blurBytes,
                                d_xofs, d_xa, d_yofs, d_yb, d_in);       // cv::resize(.., Size(160,120))  deeplcd.cpp:48-50
         }
@@ -798,83 +788,141 @@ int myslam_lcd::describe(uint8_t* d_imgs, int batch, int r, int c, int step, siz
     return lcd_forward(this, batch, d_out);
 }
 
-extern "C" {
-
-size_t myslam_lcd_nweights(void) { return NWEIGHTS; }
-
-int myslam_lcd_create(myslam_lcd** out, const float* weights, size_t nweights) {
-    if (!out || !weights || nweights != NWEIGHTS) return MYSLAM_ERR_INVALID;
+static int lcd_create(myslam_lcd** out, const myslam_calc_layer* layers, int nlayers, const float* weights, size_t nweights) {
+    if (!out || !weights) return MYSLAM_ERR_INVALID;
+    std::vector<LayerShape> shapes; size_t need = 0;
+    int rc = walk_layers(layers, nlayers, shapes, need);
+    if (rc) return rc;
+    if (nweights != need) return MYSLAM_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MYSLAM_ERR_HIP;
-    const float* w1 = weights;            const float* b1 = w1 + 64 * 25;
-    const float* w2 = b1 + 64;            const float* b2 = w2 + 128 * 64 * 16;
-    const float* w3 = b2 + 128;           const float* b3 = w3 + 4 * 128 * 9;
-    std::vector<float> w1t(25 * 64), w2t((size_t)K2 * 128), w3t(1152 * 4);
-    for (int oc = 0; oc < 64; oc++) for (int k = 0; k < 25; k++) w1t[k * 64 + oc] = w1[oc * 25 + k];
-    for (int oc = 0; oc < 128; oc++)
-        for (int ic = 0; ic < 64; ic++)
-            for (int t = 0; t < 16; t++) w2t[((size_t)t * 64 + ic) * 128 + oc] = w2[((size_t)oc * 64 + ic) * 16 + t];
-    for (int oc = 0; oc < 4; oc++)
-        for (int ic = 0; ic < 128; ic++)
-            for (int t = 0; t < 9; t++) w3t[((size_t)t * 128 + ic) * 4 + oc] = w3[((size_t)oc * 128 + ic) * 9 + t];
-    // conv2 weights as three bf16 pieces (round to nearest even, exact residuals), stage-major so a stage's slab is contiguous
-    auto to_bf16 = [](float x) -> uint16_t {
-        uint32_t u; memcpy(&u, &x, 4);
-        if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);
-        u += 0x7fffu + ((u >> 16) & 1u);
-        return (uint16_t)(u >> 16);
-    };
-    auto from_bf16 = [](uint16_t b) -> float { const uint32_t u = (uint32_t)b << 16; float x; memcpy(&x, &u, 4); return x; };
-    std::vector<uint16_t> w2s((size_t)64 * 3 * 128 * 16);
-    for (int k = 0; k < K2; k++) {
-        const int st = k >> 4, kk = k & 15;
-        for (int oc = 0; oc < 128; oc++) {
-            const float a = w2t[(size_t)k * 128 + oc];
-            const uint16_t hb = to_bf16(a); const float r = a - from_bf16(hb);
-            const uint16_t mb = to_bf16(r); const float q = r - from_bf16(mb);
-            const uint16_t lb = to_bf16(q);
-            const uint16_t pcs[3] = {hb, mb, lb};
-            for (int p = 0; p < 3; p++) w2s[(((size_t)st * 3 + p) * 128 + oc) * 16 + kk] = pcs[p];
-        }
-    }
     myslam_lcd* h = new myslam_lcd();
-    auto up = [&](float*& d, const float* src, size_t n) -> int {
-        MYSLAM_HIP_CHECK(hipMalloc((void**)&d, n * sizeof(float)));
-        MYSLAM_HIP_CHECK(hipMemcpy(d, src, n * sizeof(float), hipMemcpyHostToDevice));
-        return MYSLAM_OK;
-    };
-    int rc;
-    if ((rc = up(h->d_w1t, w1t.data(), w1t.size())) || (rc = up(h->d_b1, b1, 64)) || (rc = up(h->d_w2t, w2t.data(), w2t.size())) ||
-        (rc = up(h->d_b2, b2, 128)) || (rc = up(h->d_w3t, w3t.data(), w3t.size())) || (rc = up(h->d_b3, b3, 4))) {
-        delete h;
-        return rc;
+    h->layers.assign(layers, layers + nlayers); h->shapes = shapes;
+    h->fused = match_fused(layers, nlayers);
+    for (auto& s : shapes) h->actMax = std::max(h->actMax, (size_t)s.C * s.H * s.W);
+    auto fail = [&](int code) { h->free_all(); delete h; return code; };
+    // convolution weights: [OC][IC][K][K] -> [K*K*IC][OC] (k = (ky*K + kx)*IC + ic: channel runs contiguous, one coalesced row per k)
+    const float* w = weights; int ic = 1;
+    std::vector<float> w2t;
+    for (int i = 0, conv = 0; i < nlayers; i++) {
+        if (layers[i].type != MYSLAM_CALC_CONV) continue;
+        const int OC = layers[i].num_output, K = layers[i].kernel, KK = K * K;
+        std::vector<float> wt((size_t)KK * ic * OC);
+        for (int oc = 0; oc < OC; oc++)
+            for (int c = 0; c < ic; c++)
+                for (int t = 0; t < KK; t++) wt[((size_t)t * ic + c) * OC + oc] = w[((size_t)oc * ic + c) * KK + t];
+        float *dw = nullptr, *db = nullptr;
+        if (hipMalloc((void**)&dw, wt.size() * sizeof(float)) != hipSuccess) return fail(MYSLAM_ERR_HIP);
+        h->d_wt.push_back(dw);
+        if (hipMalloc((void**)&db, (size_t)OC * sizeof(float)) != hipSuccess) return fail(MYSLAM_ERR_HIP);
+        h->d_b.push_back(db);
+        if (hipMemcpy(dw, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(db, w + (size_t)OC * ic * KK, (size_t)OC * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            return fail(MYSLAM_ERR_HIP);
+        if (conv == 1) w2t.swap(wt);
+        w += (size_t)OC * ic * KK + OC; ic = OC; conv++;
     }
-    if (hipMalloc((void**)&h->d_w2s, w2s.size() * 2) != hipSuccess ||
-        hipMemcpy(h->d_w2s, w2s.data(), w2s.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { delete h; return MYSLAM_ERR_HIP; }
+    if (h->fused.ok) {
+        // conv2 weights as three bf16 pieces (round to nearest even, exact residuals), stage-major so a stage's slab is contiguous
+        auto to_bf16 = [](float x) -> uint16_t {
+            uint32_t u; memcpy(&u, &x, 4);
+            if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);
+            u += 0x7fffu + ((u >> 16) & 1u);
+            return (uint16_t)(u >> 16);
+        };
+        auto from_bf16 = [](uint16_t b) -> float { const uint32_t u = (uint32_t)b << 16; float x; memcpy(&x, &u, 4); return x; };
+        std::vector<uint16_t> w2s((size_t)64 * 3 * 128 * 16);
+        for (int k = 0; k < K2; k++) {
+            const int st = k >> 4, kk = k & 15;
+            for (int oc = 0; oc < 128; oc++) {
+                const float a = w2t[(size_t)k * 128 + oc];
+                const uint16_t hb = to_bf16(a); const float r = a - from_bf16(hb);
+                const uint16_t mb = to_bf16(r); const float q = r - from_bf16(mb);
+                const uint16_t lb = to_bf16(q);
+                const uint16_t pcs[3] = {hb, mb, lb};
+                for (int p = 0; p < 3; p++) w2s[(((size_t)st * 3 + p) * 128 + oc) * 16 + kk] = pcs[p];
+            }
+        }
+        if (hipMalloc((void**)&h->d_w2s, w2s.size() * 2) != hipSuccess ||
+            hipMemcpy(h->d_w2s, w2s.data(), w2s.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
+            return fail(MYSLAM_ERR_HIP);
+    }
     *out = h;
     return MYSLAM_OK;
 }
 
-// own flat model file: magic "CALCW1\0\0", uint64 count, then count f32 (little endian)
+extern "C" {
+
+size_t myslam_lcd_nweights(void) { return NWEIGHTS; }
+
+int myslam_lcd_default_layers(myslam_calc_layer* layers, int cap) {
+    if (layers) { if (cap < 10) return MYSLAM_ERR_CAPACITY; memcpy(layers, kDefaultLayers, sizeof(kDefaultLayers)); }
+    return 10;
+}
+
+int myslam_lcd_create(myslam_lcd** out, const float* weights, size_t nweights) {
+    return lcd_create(out, kDefaultLayers, 10, weights, nweights);
+}
+
+int myslam_lcd_create_from_layers(myslam_lcd** out, const myslam_calc_layer* layers, int nlayers, const float* weights, size_t nweights) {
+    return lcd_create(out, layers, nlayers, weights, nweights);
+}
+
+// host only: what myslam_lcd_create_from_caffe would load (parse + validate, no device needed)
+int myslam_calc_parse_caffe(const char* prototxt_path, const char* caffemodel_path, myslam_calc_layer* layers, int cap, int* nlayers,
+                            float* weights, size_t wcap, size_t* nweights) {
+    myslam_caffe::Model m;
+    int rc = myslam_caffe::load(prototxt_path, caffemodel_path, m);
+    if (rc) return rc;
+    if (m.in_c != 1 || m.in_h != IN_H || m.in_w != IN_W) return MYSLAM_ERR_UNSUPPORTED;      // the reference resizes every frame to 160 x 120 grey (deeplcd.cpp:50)
+    std::vector<LayerShape> shapes; size_t need = 0;
+    if ((rc = walk_layers(m.layers.data(), (int)m.layers.size(), shapes, need))) return rc;
+    if (need != m.weights.size()) return MYSLAM_ERR_INVALID;
+    if (nlayers) *nlayers = (int)m.layers.size();
+    if (nweights) *nweights = m.weights.size();
+    if (layers) { if (cap < (int)m.layers.size()) return MYSLAM_ERR_CAPACITY; memcpy(layers, m.layers.data(), m.layers.size() * sizeof(myslam_calc_layer)); }
+    if (weights) { if (wcap < m.weights.size()) return MYSLAM_ERR_CAPACITY; memcpy(weights, m.weights.data(), m.weights.size() * sizeof(float)); }
+    return MYSLAM_OK;
+}
+
+// DeepLCD::DeepLCD(prototxt, caffemodel)  deeplcd.cpp:10-31
+int myslam_lcd_create_from_caffe(myslam_lcd** out, const char* prototxt_path, const char* caffemodel_path) {
+    if (!out) return MYSLAM_ERR_INVALID;
+    myslam_caffe::Model m;
+    int rc = myslam_caffe::load(prototxt_path, caffemodel_path, m);
+    if (rc) return rc;
+    if (m.in_c != 1 || m.in_h != IN_H || m.in_w != IN_W) return MYSLAM_ERR_UNSUPPORTED;
+    return lcd_create(out, m.layers.data(), (int)m.layers.size(), m.weights.data(), m.weights.size());
+}
+
+// own model files (little endian):
+//   "CALCW1\0\0", u64 count, count f32                                                  — weights of the SURVEY A.6 layer list
+//   "CALCW2\0\0", u32 nlayers, nlayers x myslam_calc_layer (36 bytes), u64 count, count f32 — layer list + weights
 int myslam_lcd_create_from_file(myslam_lcd** out, const char* path) {
     if (!out || !path) return MYSLAM_ERR_INVALID;
     FILE* f = fopen(path, "rb");
     if (!f) return MYSLAM_ERR_INVALID;
-    char magic[8]; uint64_t n = 0;
-    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "CALCW1\0\0", 8) != 0 || fread(&n, 8, 1, f) != 1 || n != NWEIGHTS) { fclose(f); return MYSLAM_ERR_INVALID; }
-    std::vector<float> w(n);
-    const size_t got = fread(w.data(), sizeof(float), n, f);
+    char magic[8]; uint64_t n = 0; uint32_t nl = 0;
+    std::vector<myslam_calc_layer> L(kDefaultLayers, kDefaultLayers + 10);
+    bool ok = fread(magic, 1, 8, f) == 8;
+    if (ok && memcmp(magic, "CALCW2\0\0", 8) == 0) {
+        ok = fread(&nl, 4, 1, f) == 1 && nl >= 1 && nl <= 64;
+        if (ok) { L.resize(nl); ok = fread(L.data(), sizeof(myslam_calc_layer), nl, f) == nl; }
+    } else if (!ok || memcmp(magic, "CALCW1\0\0", 8) != 0) {
+        ok = false;
+    }
+    ok = ok && fread(&n, 8, 1, f) == 1 && n > 0 && n < (1u << 28);
+    std::vector<float> w;
+    if (ok) { w.resize(n); ok = fread(w.data(), sizeof(float), n, f) == n; }
     fclose(f);
-    if (got != n) return MYSLAM_ERR_INVALID;
-    return myslam_lcd_create(out, w.data(), n);
+    if (!ok) return MYSLAM_ERR_INVALID;
+    return lcd_create(out, L.data(), (int)L.size(), w.data(), n);
 }
 
 int myslam_lcd_destroy(myslam_lcd* h) {
     if (!h) return MYSLAM_ERR_INVALID;
     (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->d_w2s, h->d_w1t, h->d_b1, h->d_w2t, h->d_b2, h->d_w3t, h->d_b3, h->d_xofs, h->d_yofs, h->d_xa, h->d_yb, h->d_blur,
-                    h->d_in, h->d_a1, h->d_p1, h->d_a2, h->d_p2, h->d_stageImg, h->d_stageOut};
-    for (void* p : ptrs) if (p) (void)hipFree(p);
+    h->free_all();
     delete h;
     return MYSLAM_OK;
 }
@@ -885,6 +933,14 @@ int myslam_lcd_set_stream(myslam_lcd* h, void* s) {
     h->stream = (hipStream_t)s;
     return MYSLAM_OK;
 }
+
+int myslam_lcd_set_option(myslam_lcd* h, int option, int value) {
+    if (!h) return MYSLAM_ERR_INVALID;
+    if (option == MYSLAM_LCD_OPT_GENERIC_KERNELS) { h->forceGeneric = value != 0; return MYSLAM_OK; }
+    return MYSLAM_ERR_INVALID;
+}
+
+int myslam_lcd_uses_fused_kernels(const myslam_lcd* h) { return h ? (h->fused.ok && !h->forceGeneric ? 1 : 0) : MYSLAM_ERR_INVALID; }
 
 float myslam_lcd_score(const float* d1, const float* d2) {      // deeplcd.cpp:35-39 (host: 1064 FMAs)
     float s = 0;
@@ -901,6 +957,7 @@ int myslam_lcd_describe_batch(myslam_lcd* h, uint8_t* d_imgs, int batch, int row
 static int lcd_stage(myslam_lcd* h, size_t bytes) {
     if (bytes > h->stageBytes) { int rc = lcd_alloc(h->d_stageImg, bytes); if (rc) return rc; h->stageBytes = bytes; }
     if (!h->d_stageOut) { int rc = lcd_alloc(h->d_stageOut, (size_t)MYSLAM_LCD_DIM); if (rc) return rc; }
+    if (!h->h_stageOut) MYSLAM_HIP_CHECK(hipHostMalloc((void**)&h->h_stageOut, sizeof(float) * MYSLAM_LCD_DIM));
     return MYSLAM_OK;
 }
 
@@ -911,8 +968,9 @@ int myslam_lcd_calc_descr_original_img(myslam_lcd* h, uint8_t* img, int rows, in
     MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_stageImg, img, (size_t)rows * step, hipMemcpyHostToDevice, h->stream));
     if ((rc = h->describe(h->d_stageImg, 1, rows, cols, step, (size_t)rows * step, blur_in_place, h->d_stageOut))) return rc;
     if (blur_in_place) MYSLAM_HIP_CHECK(hipMemcpyAsync(img, h->d_stageImg, (size_t)rows * step, hipMemcpyDeviceToHost, h->stream));
-    MYSLAM_HIP_CHECK(hipMemcpyAsync(descr, h->d_stageOut, sizeof(float) * MYSLAM_LCD_DIM, hipMemcpyDeviceToHost, h->stream));
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(h->h_stageOut, h->d_stageOut, sizeof(float) * MYSLAM_LCD_DIM, hipMemcpyDeviceToHost, h->stream));
     MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    memcpy(descr, h->h_stageOut, sizeof(float) * MYSLAM_LCD_DIM);
     return MYSLAM_OK;
 }
 
@@ -926,13 +984,15 @@ int myslam_lcd_calc_descr(myslam_lcd* h, const uint8_t* img, int step, float* de
     hipLaunchKernelGGL(k_lcd_input, dim3((IN_H * IN_W + 255) / 256, 1), dim3(256), 0, h->stream, h->d_stageImg, IN_W, IN_H, step,
                        (size_t)IN_H * step, h->d_xofs, h->d_xa, h->d_yofs, h->d_yb, h->d_in);
     if ((rc = lcd_forward(h, 1, h->d_stageOut))) return rc;
-    MYSLAM_HIP_CHECK(hipMemcpyAsync(descr, h->d_stageOut, sizeof(float) * MYSLAM_LCD_DIM, hipMemcpyDeviceToHost, h->stream));
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(h->h_stageOut, h->d_stageOut, sizeof(float) * MYSLAM_LCD_DIM, hipMemcpyDeviceToHost, h->stream));
     MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    memcpy(descr, h->h_stageOut, sizeof(float) * MYSLAM_LCD_DIM);
     return MYSLAM_OK;
 }
 
-// stage taps: 0 = conv1+relu [62*82][64], 1 = pool1+lrn [31*41][64], 2 = conv2+relu [32*42][128],
-//             3 = pool2+lrn [16*21][128], 4 = descriptor [1064]
+// stage taps of the SURVEY A.6 list (whatever kernels run it): 0 = conv1+relu [62*82][64], 1 = pool1+lrn [31*41][64],
+// 2 = conv2+relu [32*42][128], 3 = pool2+lrn [16*21][128], 4 = descriptor [1064].  Taps 1-3 come from the fused kernels' buffers when the
+// fused path is active; tap 0 (never materialised there) and every tap of a generic-path handle come from the generic layer kernels.
 int myslam_lcd_debug_forward(myslam_lcd* h, const float* in, float* out_stage, int stage, size_t cap_floats) {
     if (!h || !in || !out_stage || stage < 0 || stage > 4) return MYSLAM_ERR_INVALID;
     int rc = h->ensure_batch(1, h->rows ? h->rows : IN_H, h->cols ? h->cols : IN_W);
@@ -940,13 +1000,32 @@ int myslam_lcd_debug_forward(myslam_lcd* h, const float* in, float* out_stage, i
     if ((rc = lcd_stage(h, 16))) return rc;
     MYSLAM_HIP_CHECK(hipMemcpy2DAsync(h->d_in + IN_PAD * IN_PW + IN_PAD, IN_PW * sizeof(float), in, IN_W * sizeof(float), IN_W * sizeof(float), IN_H,
                                       hipMemcpyHostToDevice, h->stream));
-    if ((rc = lcd_forward(h, 1, h->d_stageOut))) return rc;
-    if (stage == 0)      // the conv1 activation map is not materialised by the fused kernel: produce the tap on request
-        hipLaunchKernelGGL(k_conv1, dim3((H1 * W1 + 31) / 32, 1), dim3(256), 0, h->stream, h->d_in, h->d_w1t, h->d_b1, h->d_a1);
-    const float* src[5] = {h->d_a1, h->d_p1, h->d_a2, h->d_p2, h->d_stageOut};
-    const size_t n[5] = {(size_t)H1 * W1 * C1, (size_t)HP1 * WP1 * C1, (size_t)H2 * W2 * C2, (size_t)HP2 * WP2 * C2, MYSLAM_LCD_DIM};
-    if (cap_floats < n[stage]) return MYSLAM_ERR_CAPACITY;
-    MYSLAM_HIP_CHECK(hipMemcpyAsync(out_stage, src[stage], n[stage] * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    const bool fusedNow = h->fused.ok && !h->forceGeneric;
+    const float* src = nullptr; size_t n = 0;
+    if (stage == 4) {
+        if ((rc = lcd_forward(h, 1, h->d_stageOut))) return rc;
+        src = h->d_stageOut; n = MYSLAM_LCD_DIM;
+    } else if (fusedNow && stage >= 1) {
+        if ((rc = lcd_forward(h, 1, h->d_stageOut))) return rc;
+        const float* bufs[4] = {nullptr, h->d_p1, h->d_a2, h->d_p2};
+        const size_t sizes[4] = {0, (size_t)HP1 * WP1 * C1, (size_t)H2 * W2 * C2, (size_t)HP2 * WP2 * C2};
+        src = bufs[stage]; n = sizes[stage];
+    } else {
+        // layer index whose output is the tap: the stage-th "block end" (a conv followed by its ReLU / a pool followed by its LRN)
+        int idx = -1, seen = -1;
+        for (size_t i = 0; i < h->layers.size(); i++) {
+            const int t = h->layers[i].type;
+            if (t == MYSLAM_CALC_CONV || t == MYSLAM_CALC_POOL_MAX) seen++;
+            if (seen == stage) idx = (int)i;
+            if (seen > stage) break;
+        }
+        if (idx < 0) return MYSLAM_ERR_INVALID;
+        float* tap = nullptr;
+        if ((rc = h->forward_generic(1, h->d_stageOut, idx, &tap))) return rc;
+        src = tap; n = (size_t)h->shapes[idx].C * h->shapes[idx].H * h->shapes[idx].W;
+    }
+    if (cap_floats < n) return MYSLAM_ERR_CAPACITY;
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(out_stage, src, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
     return MYSLAM_OK;
 }

@@ -61,108 +61,18 @@ __global__ __launch_bounds__(256) void k_db_scan(const float* __restrict__ db, c
     }
 }
 
-// ---- batched scan as an fp32 MFMA GEMM: scores[rows x queries] = DB[rows x 1064] * Q^T, reduced per query in the
-// epilogue.  Block tile 128 rows x 128 queries, 4 waves as 2x2 of 64x64 (2x2 v_mfma_f32_32x32x2_f32), BK = 16,
-// register-staged LDS double buffering.  The database streams from HBM once per 128 queries.
+// ---- batched scan as a matrix-core GEMM: scores[rows x queries] = DB[rows x 1064] * Q^T, reduced per query in the
+// epilogue.  Block tile 128 rows x 128 queries, 4 waves as 2x2 of 64x64, BK = 16, register-staged LDS double buffering.
+// The database streams from HBM once per 128 queries.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int GM = 128, GN = 128, GK = 16, GP = GM + 4;
+constexpr int GM = 128, GN = 128, GK = 16;
 
 __device__ __forceinline__ bool better(float s, int row, float bs, int brow) {
     return s > bs || (s == bs && brow >= 0 && row < brow);       // strict '>' scan: on equal scores the lower row came first
 }
 
-__global__ __launch_bounds__(256) void k_db_scan_mfma(const float* __restrict__ db, int rows_alloc, const float* __restrict__ q,
-                                                      int nq, const int32_t* __restrict__ nvalid, float thr_low,
-                                                      Partial* __restrict__ partials) {
-    __shared__ __attribute__((aligned(16))) float s_a[2][GK * GP];
-    __shared__ __attribute__((aligned(16))) float s_b[2][GK * GP];
-    __shared__ Partial s_p[2][GN];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    const int m0 = blockIdx.x * GM, n0 = blockIdx.y * GN;
-    const int row = t >> 1, kk = (t & 1) * 8;
-    const bool a_ok = (m0 + row) < rows_alloc, b_ok = (n0 + row) < nq;
-    const float* arow = db + (size_t)(m0 + row) * DIM + kk;
-    const float* brow = q + (size_t)(n0 + row) * DIM + kk;
-    float4 ra0, ra1, rb0, rb1;
-    const float4 z4 = make_float4(0, 0, 0, 0);
-    auto load_stage = [&](int st) {
-        const int k0 = st * GK;
-        const bool kv = (k0 + kk) < DIM;                         // 1064 = 66*16 + 8: only the last half-chunk is padding
-        if (a_ok && kv) { const float4* p = reinterpret_cast<const float4*>(arow + k0); ra0 = p[0]; ra1 = p[1]; } else { ra0 = z4; ra1 = z4; }
-        if (b_ok && kv) { const float4* p = reinterpret_cast<const float4*>(brow + k0); rb0 = p[0]; rb1 = p[1]; } else { rb0 = z4; rb1 = z4; }
-    };
-    auto store_stage = [&](int buf) {
-        float* a = s_a[buf]; float* b = s_b[buf];
-        a[(kk + 0) * GP + row] = ra0.x; a[(kk + 1) * GP + row] = ra0.y; a[(kk + 2) * GP + row] = ra0.z; a[(kk + 3) * GP + row] = ra0.w;
-        a[(kk + 4) * GP + row] = ra1.x; a[(kk + 5) * GP + row] = ra1.y; a[(kk + 6) * GP + row] = ra1.z; a[(kk + 7) * GP + row] = ra1.w;
-        b[(kk + 0) * GP + row] = rb0.x; b[(kk + 1) * GP + row] = rb0.y; b[(kk + 2) * GP + row] = rb0.z; b[(kk + 3) * GP + row] = rb0.w;
-        b[(kk + 4) * GP + row] = rb1.x; b[(kk + 5) * GP + row] = rb1.y; b[(kk + 6) * GP + row] = rb1.z; b[(kk + 7) * GP + row] = rb1.w;
-    };
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    constexpr int NST = (DIM + GK - 1) / GK;                     // 67
-    load_stage(0);
-    store_stage(0);
-    __syncthreads();
-    const int lr = lane & 31, lk = lane >> 5;
-    for (int st = 0; st < NST; st++) {
-        const int buf = st & 1;
-        if (st + 1 < NST) load_stage(st + 1);
-        const float* a = s_a[buf]; const float* b = s_b[buf];
-#pragma unroll
-        for (int kq = 0; kq < GK / 2; kq++) {
-            const int k = 2 * kq + lk;
-            const float a0 = a[k * GP + wm + lr], a1 = a[k * GP + wm + 32 + lr];
-            const float b0 = b[k * GP + wn + lr], b1 = b[k * GP + wn + 32 + lr];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        if (st + 1 < NST) store_stage(buf ^ 1);
-        __syncthreads();
-    }
-    // epilogue: per query column reduce over this block's 128 rows.  C/D layout: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int n = n0 + wn + j * 32 + lr;
-        const int nv = (n < nq) ? nvalid[n] : 0;
-        float bs = 0.f; int bi = -1, cnt = 0;
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                const float sc = acc[i][j][r];
-                if (m < nv) {
-                    if (better(sc, m, bs, bi)) { bs = sc; bi = m; }
-                    cnt += (sc > thr_low);
-                }
-            }
-        // lanes l and l^32 hold the same query column
-        const float os = __shfl_xor(bs, 32, 64); const int oi = __shfl_xor(bi, 32, 64); const int oc = __shfl_xor(cnt, 32, 64);
-        if (oi >= 0 && better(os, oi, bs, bi)) { bs = os; bi = oi; }
-        cnt += oc;
-        if (lk == 0 && (wave >> 1) == 1) s_p[0][wn + j * 32 + lr] = {bs, bi, cnt};      // upper row half parks its result
-        __syncthreads();
-        if (lk == 0 && (wave >> 1) == 0) {
-            const Partial o = s_p[0][wn + j * 32 + lr];
-            if (o.idx >= 0 && better(o.score, o.idx, bs, bi)) { bs = o.score; bi = o.idx; }
-            cnt += o.cnt;
-            if (n < nq) partials[(size_t)blockIdx.x * nq + n] = {bs, bi, cnt};
-        }
-        __syncthreads();
-    }
-}
-
-// The same GEMM on the bf16 matrix cores with f32 accuracy (see k_conv2_bf16x6 in calc.hip): the f32-input MFMA runs at the f32
-// vector rate and competes with the VALU-bound ORB kernels of the other stream.  Database rows and queries are split exactly into
+// The GEMM runs on the bf16 matrix cores with f32 accuracy (see k_conv2_bf16x6 in calc.hip): an f32-input MFMA runs at the f32
+// vector rate and competes with the VALU-bound ORB kernels of the other stream (0.28 against 0.15 ms per 512 queries x 10 k rows).  Database rows and queries are split exactly into
 // three bf16 pieces while they are staged into LDS; hh + hm + mh + hl + lh + mm are accumulated in f32.
 typedef __bf16 db_bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void db_split3(float a0, float a1, uint32_t& h, uint32_t& m, uint32_t& l) {
@@ -455,13 +365,8 @@ static int db_query(myslam_lcddb* h, const float* d_q, const uint64_t* cur_ids_h
         int nparts = nblocks;
         if (nq >= 32) {           // batched: GEMM on the matrix cores with the per-query reduction fused into the epilogue
             nparts = std::max(1, (maxv + GM - 1) / GM);
-            static const int f32mfma = [] { const char* e = getenv("MYSLAM_DBSCAN_V"); return e ? atoi(e) == 1 : 0; }();      // tuning aid: 1 = f32-input MFMA
-            if (f32mfma)
-                hipLaunchKernelGGL(k_db_scan_mfma, dim3(nparts, (nq + GN - 1) / GN), dim3(256), 0, h->stream, h->d_db, h->capacity, d_q, nq,
-                                   h->d_nvalid, thr_low, h->d_partials);
-            else
-                hipLaunchKernelGGL(k_db_scan_bf16x6, dim3(nparts, (nq + GN - 1) / GN), dim3(256), 0, h->stream, h->d_db, h->capacity, d_q, nq,
-                                   h->d_nvalid, thr_low, h->d_partials);
+            hipLaunchKernelGGL(k_db_scan_bf16x6, dim3(nparts, (nq + GN - 1) / GN), dim3(256), 0, h->stream, h->d_db, h->capacity, d_q, nq,
+                               h->d_nvalid, thr_low, h->d_partials);
         } else {                  // a few queries: bandwidth-bound GEMV, one wave per database row
             const size_t lds = sizeof(Partial) * DB_WAVES * nq;
             hipLaunchKernelGGL(k_db_scan, dim3(nblocks), dim3(256), lds, h->stream, h->d_db, d_q, nq, h->d_nvalid, thr_low, h->d_partials);

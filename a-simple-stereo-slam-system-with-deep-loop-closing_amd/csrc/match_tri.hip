@@ -1,8 +1,7 @@
 // match_tri.hip — 256-bit Hamming brute-force matcher and stereo triangulation for gfx950.
 //
 // Hamming: replaces cv::BFMatcher(NORM_HAMMING)::match (reference src/loopclosing.cpp:33,172): one
-// best train row per query row, ties -> lowest train index.  Integer ALU bound (xor + v_bcnt), the
-// train set of a frame (<= ~2000 x 32 B) is staged through LDS and broadcast-read by all lanes.
+// best train row per query row, ties -> lowest train index: a +-1 product on the FP4 matrix cores.
 //
 // Triangulation: replaces triangulation() (reference include/myslam/algorithm.h:16-33) for the
 // stereo rig (src/system.cpp:108-116,141-145): DLT 4x4, smallest right singular vector by one-sided
@@ -13,188 +12,23 @@
 
 namespace myslam_hip {
 
-constexpr int HM_T = 256;        // queries per block
-constexpr int HM_CHUNK = 512;    // train rows staged per LDS chunk (16 KiB)
-
-__global__ __launch_bounds__(HM_T) void k_hamming(const uint8_t* __restrict__ q, const int32_t* __restrict__ nqv,
-                                                  const uint8_t* __restrict__ tr, const int32_t* __restrict__ ntv,
-                                                  int cap, int nq_single, int nt_single,
-                                                  int32_t* __restrict__ out_idx, int32_t* __restrict__ out_dist) {
-    __shared__ __attribute__((aligned(16))) uint4 s_t[HM_CHUNK * 2];
-    const int p = blockIdx.y;
-    const int nq = nqv ? min(nqv[p], cap) : nq_single;
-    const int nt = ntv ? min(ntv[p], cap) : nt_single;
-    const int qi = blockIdx.x * HM_T + threadIdx.x;
-    if (blockIdx.x * HM_T >= nq) return;
-    const uint4* Q = reinterpret_cast<const uint4*>(q + (size_t)p * cap * 32);
-    const uint4* T = reinterpret_cast<const uint4*>(tr + (size_t)p * cap * 32);
-    uint4 a = make_uint4(0, 0, 0, 0), b = a;
-    if (qi < nq) { a = Q[2 * qi]; b = Q[2 * qi + 1]; }
-    // running minimum of the key (distance << 20 | train index): one v_min_u32 keeps the smallest distance and, among equal
-    // distances, the lowest train index (BFMatcher keeps the first minimum).  nt < 2^20.
-    uint32_t bestKey = 0xffffffffu;
-    for (int j0 = 0; j0 < nt; j0 += HM_CHUNK) {
-        const int m = min(HM_CHUNK, nt - j0);
-        __syncthreads();
-        for (int i = threadIdx.x; i < 2 * m; i += HM_T) s_t[i] = T[2 * j0 + i];
-        __syncthreads();
-        auto row = [&](int j) {
-            const uint4 c = s_t[2 * j], d = s_t[2 * j + 1];          // broadcast reads
-            // v_bcnt_u32_b32 adds its second operand: one accumulate chain per row (four rows are in flight), no separate adds
-            uint32_t h;
-            asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(h) : "v"(a.x ^ c.x));
-            asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(h) : "v"(a.y ^ c.y), "v"(h));
-            asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(h) : "v"(a.z ^ c.z), "v"(h));
-            asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(h) : "v"(a.w ^ c.w), "v"(h));
-            asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(h) : "v"(b.x ^ d.x), "v"(h));
-            asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(h) : "v"(b.y ^ d.y), "v"(h));
-            asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(h) : "v"(b.z ^ d.z), "v"(h));
-            asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(h) : "v"(b.w ^ d.w), "v"(h));
-            bestKey = min(bestKey, (h << 20) | (uint32_t)(j0 + j));
-        };
-        int j = 0;
-        for (; j + 4 <= m; j += 4) { row(j); row(j + 1); row(j + 2); row(j + 3); }
-        for (; j < m; j++) row(j);
-    }
-    if (qi < nq) {
-        const bool any = nt > 0;
-        out_idx[(size_t)p * cap + qi] = any ? (int32_t)(bestKey & 0xfffffu) : -1;
-        out_dist[(size_t)p * cap + qi] = any ? (int32_t)(bestKey >> 20) : -1;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// Hamming brute force on the integer matrix cores.  With every descriptor bit b encoded as the int8 s = 1 - 2b,
+// Hamming brute force on the matrix cores.  With every descriptor bit b encoded as s = 1 - 2b,
 //     sum_k s_q[k] s_t[k] = 256 - 2 * hamming(q, t),
-// so the 2000 x 2000 distance matrix of a stereo pair is a [nt x 256] x [256 x nq] i8 GEMM: v_mfma_i32_32x32x32_i8, 8 per
-// 32 train x 32 query tile (the plain kernel above already runs at the VALU issue peak: 8 xor + 8 bcnt + min per distance).
-//   * block = 4 waves x HQ_TILES query tiles of 32; the query operand (B) is expanded to +-1 bytes ONCE into registers
-//     (32 VGPRs per tile) and reused against every train chunk
-//   * train descriptors stay bit-packed in HBM; each chunk of 32 is expanded into LDS by the whole block through a
-//     256-entry byte -> 8 x int8 table (4 ds_read_b64 + 2 ds_write_b128 per thread), double buffered, one barrier per chunk
+// so the 2000 x 2000 distance matrix of a stereo pair is a [nt x 256] x [256 x nq] product.
+//   * block = 4 waves x HQ_TILES query tiles of 32; the query operand (B) is expanded ONCE into registers and reused against
+//     every train chunk
+//   * train descriptors stay bit-packed in HBM; each chunk of 32 is expanded into LDS by the whole block through a 256-entry
+//     byte table, double buffered, one barrier per chunk
 //   * A (train) and B (query) use the same (lane, byte) -> k map, so the hardware's k order inside an operand is irrelevant
 //   * the 32x32 result puts ONE query column in every lane (16 train rows in its registers): the running best is a single
 //     register per tile, key = (dot + 256) << 20 | (0xFFFFF - train index), maximised with v_max3 — highest dot = smallest
 //     distance, ties to the lowest train index (BFMatcher keeps the first minimum); the two half-waves merge at the end.
+// (History: xor / popcount on the VALU ran at its issue peak, 1.00 ms per 512 pairs; int8 MFMA 0.40 ms; this FP4 form 0.23 ms.)
 constexpr int HQ_TILES = 4;                       // query tiles of 32 per wave -> 512 queries per block
 constexpr int HQ_BLOCK = 4 * HQ_TILES * 32;
-constexpr int HQ_ROWB = 272;                      // LDS bytes per expanded train row (256 + 16: conflict-free ds_read_b128)
-typedef int hq_v4i __attribute__((ext_vector_type(4)));
-typedef int hq_v16i __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256) void k_hamming_mfma(const uint8_t* __restrict__ q, const int32_t* __restrict__ nqv,
-                                                      const uint8_t* __restrict__ tr, const int32_t* __restrict__ ntv,
-                                                      int cap, int nq_single, int nt_single,
-                                                      int32_t* __restrict__ out_idx, int32_t* __restrict__ out_dist) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_exp[2][32 * HQ_ROWB];
-    __shared__ __attribute__((aligned(8))) uint2 s_lut[256];
-    const int p = blockIdx.y;
-    const int nq = nqv ? min(nqv[p], cap) : nq_single;
-    const int nt = ntv ? min(ntv[p], cap) : nt_single;
-    const int q0 = blockIdx.x * HQ_BLOCK;
-    if (q0 >= nq) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    {   // byte -> 8 int8 (bit i -> byte i): bit 1 -> -1, bit 0 -> +1
-        uint32_t lo = 0, hi = 0;
-        for (int i = 0; i < 4; i++) {
-            lo |= (((tid >> i) & 1) ? 0xffu : 0x01u) << (8 * i);
-            hi |= (((tid >> (4 + i)) & 1) ? 0xffu : 0x01u) << (8 * i);
-        }
-        s_lut[tid] = make_uint2(lo, hi);
-    }
-    __syncthreads();
-    const uint32_t* Q = reinterpret_cast<const uint32_t*>(q + (size_t)p * cap * 32);
-    const uint32_t* T = reinterpret_cast<const uint32_t*>(tr + (size_t)p * cap * 32);
-    // query operands: tile t of this wave covers queries qb + 32 t + (lane & 31); k-block m takes the 16-bit half (lane >> 5)
-    // of dword m
-    const int qb = q0 + wv * (HQ_TILES * 32);
-    hq_v4i B[HQ_TILES][8];
-#pragma unroll
-    for (int t = 0; t < HQ_TILES; t++) {
-        const int qi = qb + 32 * t + (lane & 31);
-#pragma unroll
-        for (int m = 0; m < 8; m++) {
-            const uint32_t w = (qi < nq) ? Q[(size_t)qi * 8 + m] : 0u;
-            const uint32_t h = (lane >> 5) ? (w >> 16) : (w & 0xffffu);
-            const uint2 e0 = s_lut[h & 0xff], e1 = s_lut[h >> 8];
-            B[t][m] = hq_v4i{(int)e0.x, (int)e0.y, (int)e1.x, (int)e1.y};
-        }
-    }
-    // Query bytes are scaled to +-32 and the accumulator starts at (31 - row): a tile then yields 32 * dot + (31 - train row in the
-    // chunk) directly — the within-chunk arg-max (highest dot, then lowest row) is a plain integer maximum over the 16 registers
-    // of a lane, with no per-element VALU work; across chunks a candidate must beat the best dot strictly (earlier chunk = lower
-    // index wins ties).
-#pragma unroll
-    for (int t = 0; t < HQ_TILES; t++)
-#pragma unroll
-        for (int m = 0; m < 8; m++)
-#pragma unroll
-            for (int k = 0; k < 4; k++) B[t][m][k] = (int)(((uint32_t)B[t][m][k] << 5) & 0xe0e0e0e0u);
-    const int rbase = 4 * (lane >> 5);                       // row of accumulator register r: (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    hq_v16i cinit, ctail;
-    const int last0 = ((nt - 1) >> 5) << 5;
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int row = rbase + (r & 3) + 8 * (r >> 2);
-        cinit[r] = 31 - row;
-        ctail[r] = (last0 + row < nt) ? 31 - row : -(1 << 24);
-    }
-    int bestv[HQ_TILES], bestor[HQ_TILES], bestc[HQ_TILES];
-#pragma unroll
-    for (int t = 0; t < HQ_TILES; t++) { bestv[t] = -(1 << 30); bestor[t] = -(1 << 30); bestc[t] = 0; }
-    // the expansion job of this thread: dword (tid & 7) of chunk row (tid >> 3)
-    const int er = tid >> 3, ed = tid & 7;
-    auto expand = [&](int buf, uint32_t w) {
-        const uint2 a = s_lut[w & 0xff], b = s_lut[(w >> 8) & 0xff], c = s_lut[(w >> 16) & 0xff], d = s_lut[w >> 24];
-        uint4* dst = reinterpret_cast<uint4*>(&s_exp[buf][er * HQ_ROWB + ed * 32]);
-        dst[0] = make_uint4(a.x, a.y, b.x, b.y);
-        dst[1] = make_uint4(c.x, c.y, d.x, d.y);
-    };
-    const int nchunk = (nt + 31) >> 5;
-    uint32_t wnext = (er < nt) ? T[(size_t)er * 8 + ed] : 0u;
-    if (nchunk > 0) expand(0, wnext);
-    for (int c = 0; c < nchunk; c++) {
-        const int t0 = c << 5;
-        if (c + 1 < nchunk) { const int row = t0 + 32 + er; wnext = (row < nt) ? T[(size_t)row * 8 + ed] : 0u; }
-        __syncthreads();                                    // chunk c expanded by everyone; buffer (c + 1) & 1 free again
-        if (c + 1 < nchunk) expand((c + 1) & 1, wnext);
-        const uint8_t* sb = &s_exp[c & 1][(lane & 31) * HQ_ROWB + (lane >> 5) * 16];
-        hq_v4i A[8];
-#pragma unroll
-        for (int m = 0; m < 8; m++) A[m] = *reinterpret_cast<const hq_v4i*>(sb + m * 32);
-        const hq_v16i c0 = (c + 1 == nchunk) ? ctail : cinit;
-#pragma unroll
-        for (int t = 0; t < HQ_TILES; t++) {
-            hq_v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[0], B[t][0], c0, 0, 0, 0);
-#pragma unroll
-            for (int m = 1; m < 8; m++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[m], B[t][m], acc, 0, 0, 0);
-            int v = max(max(acc[0], acc[1]), acc[2]);
-#pragma unroll
-            for (int r = 3; r < 15; r += 2) v = max(max(v, acc[r]), acc[r + 1]);
-            v = max(v, acc[15]);
-            const bool better = v > bestor[t];
-            bestv[t] = better ? v : bestv[t];
-            bestor[t] = better ? (v | 31) : bestor[t];
-            bestc[t] = better ? c : bestc[t];
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < HQ_TILES; t++) {
-        // full key = (dot + 256) << 20 | (0xFFFFF - train index); the two half-waves hold different rows of the same query
-        const int dot = bestv[t] >> 5, row = 31 - (bestv[t] & 31);
-        const uint32_t key = bestv[t] < -(1 << 20) ? 0u          // this half-wave saw no valid train row
-                                                     : ((uint32_t)(dot + 256) << 20) | (0xfffffu - (uint32_t)(bestc[t] * 32 + row));
-        const uint32_t b = max(key, (uint32_t)__shfl_xor((int)key, 32, 64));
-        const int qi = qb + 32 * t + lane;
-        if (lane < 32 && qi < nq) {
-            const bool any = nt > 0;
-            out_idx[(size_t)p * cap + qi] = any ? (int32_t)(0xfffffu - (b & 0xfffffu)) : -1;
-            out_dist[(size_t)p * cap + qi] = any ? (int32_t)((512u - (b >> 20)) >> 1) : -1;
-        }
-    }
-}
-
-// The same product on the FP4 path of the matrix cores (v_mfma_scale_f32_32x32x64_f8f6f4, K = 64 per instruction, twice the int8
+// The product runs on the FP4 path of the matrix cores (v_mfma_scale_f32_32x32x64_f8f6f4, K = 64 per instruction, twice the int8
 // rate): E2M1 represents +-1 exactly (0x2 / 0xA), the factor 32 of the query operand is its E8M0 block scale (2^5), sums of at most
 // 256 terms of +-32 plus the (31 - row) start value are exact in f32.  One descriptor dword (32 bits) expands to the 16 operand bytes
 // of a lane; 4 MFMAs per 32 x 32 tile instead of 8, 16 query registers per tile instead of 32, 4 KB of LDS per train chunk.
@@ -297,12 +131,6 @@ __global__ __launch_bounds__(256) void k_hamming_fp4(const uint8_t* __restrict__
     }
 }
 
-static inline int hamming_variant() {         // 1: xor / popcount (VALU), 2: int8 MFMA, 3: FP4 MFMA
-    static const int v = [] { const char* e = getenv("MYSLAM_HAMMING_V"); return e ? atoi(e) : 3; }();
-    return v;
-}
-static inline bool hamming_use_mfma() { return hamming_variant() != 1; }
-
 // ------------------------------------------------------------------------------------------------
 // one-sided Jacobi SVD of the 4x4 DLT matrix (f64), fully unrolled pair loop (no runtime register indexing)
 __device__ __forceinline__ void tri_solve(const double (&P)[2][12], const double (&pt)[2][2], double* xyz, double& ratio) {
@@ -404,15 +232,8 @@ int myslam_hamming_match_batch(const uint8_t* d_q, const int32_t* d_nq, const ui
     if (cap >= (1 << 20)) return MYSLAM_ERR_UNSUPPORTED;          // the running minimum packs (distance, train index) into 32 bits
     hipStream_t s = (hipStream_t)hip_stream;
     ScopedProf sp(P_MATCH, s);
-    if (hamming_variant() == 3)
-        hipLaunchKernelGGL(k_hamming_fp4, dim3((cap + HQ_BLOCK - 1) / HQ_BLOCK, batch), dim3(256), 0, s, d_q, d_nq, d_t, d_nt, cap, 0, 0,
-                           d_train_idx, d_dist);
-    else if (hamming_use_mfma())
-        hipLaunchKernelGGL(k_hamming_mfma, dim3((cap + HQ_BLOCK - 1) / HQ_BLOCK, batch), dim3(256), 0, s, d_q, d_nq, d_t, d_nt, cap, 0, 0,
-                           d_train_idx, d_dist);
-    else
-        hipLaunchKernelGGL(k_hamming, dim3((cap + HM_T - 1) / HM_T, batch), dim3(HM_T), 0, s, d_q, d_nq, d_t, d_nt, cap, 0, 0,
-                           d_train_idx, d_dist);
+    hipLaunchKernelGGL(k_hamming_fp4, dim3((cap + HQ_BLOCK - 1) / HQ_BLOCK, batch), dim3(256), 0, s, d_q, d_nq, d_t, d_nt, cap, 0, 0,
+                       d_train_idx, d_dist);
     MYSLAM_HIP_CHECK(hipGetLastError());
     return MYSLAM_OK;
 }
@@ -434,15 +255,8 @@ int myslam_hamming_match(const uint8_t* query, int nq, const uint8_t* train, int
     int32_t* di = hc.dev<int32_t>(pi); int32_t* dd = hc.dev<int32_t>(pd);
     {
         ScopedProf sp(P_MATCH, hc.stream());
-        if (hamming_variant() == 3)
-            hipLaunchKernelGGL(k_hamming_fp4, dim3((nq + HQ_BLOCK - 1) / HQ_BLOCK, 1), dim3(256), 0, hc.stream(), dq, (const int32_t*)nullptr, dt,
-                               (const int32_t*)nullptr, cap, nq, nt, di, dd);
-        else if (hamming_use_mfma())
-            hipLaunchKernelGGL(k_hamming_mfma, dim3((nq + HQ_BLOCK - 1) / HQ_BLOCK, 1), dim3(256), 0, hc.stream(), dq, (const int32_t*)nullptr, dt,
-                               (const int32_t*)nullptr, cap, nq, nt, di, dd);
-        else
-            hipLaunchKernelGGL(k_hamming, dim3((nq + HM_T - 1) / HM_T, 1), dim3(HM_T), 0, hc.stream(), dq, (const int32_t*)nullptr, dt,
-                               (const int32_t*)nullptr, cap, nq, nt, di, dd);
+        hipLaunchKernelGGL(k_hamming_fp4, dim3((nq + HQ_BLOCK - 1) / HQ_BLOCK, 1), dim3(256), 0, hc.stream(), dq, (const int32_t*)nullptr, dt,
+                           (const int32_t*)nullptr, cap, nq, nt, di, dd);
     }
     MYSLAM_HIP_CHECK(hipGetLastError());
     return hc.download();

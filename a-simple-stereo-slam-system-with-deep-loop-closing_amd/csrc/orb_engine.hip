@@ -21,7 +21,7 @@ namespace myslam_hip {
 void launch_resize(const ResizeArgs& a, int batch, hipStream_t s);
 void launch_blur(const BlurArgs& a, int batch, hipStream_t s);
 void launch_fast(const OrbPlan& P, const uint8_t* pyr, size_t pyrStride, const uint8_t* maskPyr, uint32_t* cand,
-                 int32_t* candCount, int batch, hipStream_t s);
+                 int32_t* candCount, const uint32_t* statPrev, uint32_t* statCur, int forceMode, int batch, hipStream_t s);
 void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCount, uint64_t* sortbuf, const uint32_t* octTab, uint32_t* selOut,
                    int32_t* selCount, int32_t* status, int batch, hipStream_t s);
 void launch_describe(const OrbPlan& P, const uint8_t* pyr, const uint8_t* blur, size_t pyrStride, const uint32_t* selOut,
@@ -106,8 +106,12 @@ struct myslam_orb {
     int32_t *d_candCount = nullptr, *d_selCount = nullptr, *d_status = nullptr;
     uint32_t* d_sel = nullptr;
     uint32_t* d_octTab = nullptr;      // per-level oct-tree path-code / cell-index tables (see make_plan)
-    uint4* d_blurTab = nullptr;        // operand tables of the matrix-core Gaussian, per level (see make_plan)
-    size_t blurH[MAXL] = {0}, blurV[MAXL] = {0}, blurI = 0; bool blurOk[MAXL] = {false};
+    // FAST path selection (orb_kernels.hip FastCtl): two [MAXL][4] counter blocks, the launch accumulates into one and reads the other
+    uint32_t* d_fastStat = nullptr; int fastFlip = 0;
+    // options (myslam_orb_set_option)
+    int optFastMode = -1;              // -1 = chosen per level from the previous launch's statistics, 0 = two-phase, 1 = dense
+    int optInternalStream = 2;         // 0 = everything on the caller's stream, 1 = Gaussian pyramid forked after FAST, 2 = after the image pyramid
+    int optStopAfter = 0;              // debug: stop a batched call after stage 1 ingest / 2 pyramid / 3 oct-tree / 4 blur (0 = run all)
 
     // staging for the host-buffer entry points
     uint8_t *d_stageImg = nullptr, *d_stageMask = nullptr; size_t stageImgBytes = 0, stageMaskBytes = 0;
@@ -120,6 +124,7 @@ struct myslam_orb {
     int ensure_stage(size_t imgBytes, size_t maskBytes, int cap);
     int build_pyramids(const uint8_t* d_imgs, int batch, int step, size_t stride, const uint8_t* d_masks, int nlev);
     int blur_levels(int batch, int nlev, hipStream_t s);
+    int run_fast(const OrbPlan& P, const uint8_t* maskPyr, int batch);
     int run_batch(const uint8_t* d_imgs, int batch, int r, int c, int step, size_t stride, const uint8_t* d_masks,
                   myslam_keypoint* d_kps, uint8_t* d_desc, int32_t* d_counts, int32_t* d_stat, int cap, bool detectOnly);
     void free_all();
@@ -229,18 +234,6 @@ int myslam_orb::make_plan(int r, int c) {
         if (rc) return rc;
         MYSLAM_HIP_CHECK(hipMemcpy(d_octTab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
-    static const bool want_mfma_blur = [] { const char* e = getenv("MYSLAM_BLUR_V"); return e && atoi(e) == 4; }();
-    for (int l = 0; l < nlevels; l++) blurOk[l] = false;
-    if (want_mfma_blur) {   // operand tables of k_blur7_mfma for every level (sigma = 2 taps); experimental kernel, see orb_kernels.hip
-        std::vector<uint4> bt;
-        int q[7];
-        gauss_q8(0, q);
-        blur_mfma_ident(bt, blurI);
-        for (int l = 0; l < nlevels; l++) blurOk[l] = blur_mfma_tables(P.lv[l].w, P.lv[l].h, P.lv[l].pitch, q, bt, blurH[l], blurV[l]);
-        if (d_blurTab) { (void)hipFree(d_blurTab); d_blurTab = nullptr; }
-        MYSLAM_HIP_CHECK(hipMalloc((void**)&d_blurTab, bt.size() * sizeof(uint4)));
-        MYSLAM_HIP_CHECK(hipMemcpy(d_blurTab, bt.data(), bt.size() * sizeof(uint4), hipMemcpyHostToDevice));
-    }
     full = P;
     // Detect(): level 0 only, budget = nfeatures (ORBextractor.cpp:1064-1065)
     det = P;
@@ -314,7 +307,6 @@ int myslam_orb::blur_levels(int batch, int nlev, hipStream_t stream) {
         a.src = d_pyr + P.lv[l].imgOff; a.dst = d_blur + P.lv[l].imgOff;
         a.w = P.lv[l].w; a.h = P.lv[l].h; a.spitch = a.dpitch = P.lv[l].pitch; a.sstride = a.dstride = P.pyrBytes;
         gauss_q8(0, a.q);
-        if (blurOk[l]) { a.tabH = d_blurTab + blurH[l]; a.tabV = d_blurTab + blurV[l]; a.ident = d_blurTab + blurI; }
         launch_blur(a, batch, stream);
     }
     return MYSLAM_OK;
@@ -331,15 +323,14 @@ int myslam_orb::run_batch(const uint8_t* d_imgs, int batch, int r, int c, int st
     MYSLAM_HIP_CHECK(hipMemsetAsync(d_candCount, 0, sizeof(int32_t) * (size_t)batch * MAXL, stream));
     MYSLAM_HIP_CHECK(hipMemsetAsync(d_selCount, 0, sizeof(int32_t) * (size_t)batch * MAXL, stream));
     MYSLAM_HIP_CHECK(hipMemsetAsync(stat, 0, sizeof(int32_t) * (size_t)batch, stream));
-    const char* dbg_stop = getenv("MYSLAM_DEBUG_STOP");      // stage-isolation aid for the parity tests
-    const int stop = dbg_stop ? atoi(dbg_stop) : 0;
+    const int stop = optStopAfter;
     if (stop == 1) {
         launch_ingest(d_imgs, full.rows, full.cols, step, stride, d_pyr + full.lv[0].imgOff, full.lv[0].pitch, full.pyrBytes, batch, stream);
         return MYSLAM_OK;
     }
     if ((rc = build_pyramids(d_imgs, batch, step, stride, d_masks, P.nlevels))) return rc;
     if (stop == 2) return MYSLAM_OK;
-    static const int aux_mode = [] { const char* e = getenv("MYSLAM_ORB_AUX"); return e ? atoi(e) : 2; }();     // 0: one stream, 1: blur after FAST, 2: blur right after the pyramid (default)
+    const int aux_mode = optInternalStream;
     const bool fork = aux_mode > 0 && !detectOnly && stop == 0;
     if (fork && !aux) {
         MYSLAM_HIP_CHECK(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
@@ -356,10 +347,7 @@ int myslam_orb::run_batch(const uint8_t* d_imgs, int batch, int r, int c, int st
     };
     if (fork && aux_mode == 2 && (rc = fork_blur())) return rc;
     if (evUserGate) MYSLAM_HIP_CHECK(hipStreamWaitEvent(stream, evUserGate, 0));
-    {
-        ScopedProf sp(P_FAST, stream);
-        launch_fast(P, d_pyr, full.pyrBytes, d_masks ? d_mask : nullptr, d_cand, d_candCount, batch, stream);
-    }
+    if ((rc = run_fast(P, d_masks ? d_mask : nullptr, batch))) return rc;
     if (evUserFast) MYSLAM_HIP_CHECK(hipEventRecord(evUserFast, stream));
     if (fork && aux_mode != 2 && (rc = fork_blur())) return rc;
     {
@@ -379,6 +367,21 @@ int myslam_orb::run_batch(const uint8_t* d_imgs, int batch, int r, int c, int st
     return MYSLAM_OK;
 }
 
+// grid FAST on the handle's stream; the launch reads the statistics block of the previous launch and fills the other one
+int myslam_orb::run_fast(const OrbPlan& P, const uint8_t* maskPyr, int batch) {
+    if (!d_fastStat) {
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&d_fastStat, sizeof(uint32_t) * 2 * MAXL * 4));
+        MYSLAM_HIP_CHECK(hipMemsetAsync(d_fastStat, 0, sizeof(uint32_t) * 2 * MAXL * 4, stream));
+    }
+    uint32_t* cur = d_fastStat + (size_t)fastFlip * MAXL * 4;
+    const uint32_t* prev = d_fastStat + (size_t)(fastFlip ^ 1) * MAXL * 4;
+    fastFlip ^= 1;
+    MYSLAM_HIP_CHECK(hipMemsetAsync(cur, 0, sizeof(uint32_t) * MAXL * 4, stream));
+    ScopedProf sp(P_FAST, stream);
+    launch_fast(P, d_pyr, full.pyrBytes, maskPyr, d_cand, d_candCount, prev, cur, optFastMode, batch, stream);
+    return MYSLAM_OK;
+}
+
 int myslam_orb::ensure_stage(size_t imgBytes, size_t maskBytes, int cap) {
     if (imgBytes > stageImgBytes) { int rc = dev_alloc(d_stageImg, imgBytes); if (rc) return rc; stageImgBytes = imgBytes; }
     if (maskBytes > stageMaskBytes) { int rc = dev_alloc(d_stageMask, maskBytes); if (rc) return rc; stageMaskBytes = maskBytes; }
@@ -395,7 +398,7 @@ int myslam_orb::ensure_stage(size_t imgBytes, size_t maskBytes, int cap) {
 }
 
 void myslam_orb::free_all() {
-    void* ptrs[] = {d_blurTab, d_octTab, d_pyr, d_blur, d_mask, d_cand, d_sort, d_candCount, d_selCount, d_status, d_sel, d_stageImg, d_stageMask,
+    void* ptrs[] = {d_fastStat, d_octTab, d_pyr, d_blur, d_mask, d_cand, d_sort, d_candCount, d_selCount, d_status, d_sel, d_stageImg, d_stageMask,
                     d_stageKps, d_stageKps2, d_stageDesc, d_stageKeep, d_stageCounts};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); (void)hipEventDestroy(evFork); (void)hipEventDestroy(evJoin); aux = nullptr; }
@@ -443,6 +446,16 @@ int myslam_orb_set_fast_gate(myslam_orb* h, void* ev) {
     if (!h) return MYSLAM_ERR_INVALID;
     h->evUserGate = (hipEvent_t)ev;
     return MYSLAM_OK;
+}
+
+int myslam_orb_set_option(myslam_orb* h, int option, int value) {
+    if (!h) return MYSLAM_ERR_INVALID;
+    switch (option) {
+        case MYSLAM_ORB_OPT_FAST_MODE: if (value < -1 || value > 1) return MYSLAM_ERR_INVALID; h->optFastMode = value; return MYSLAM_OK;
+        case MYSLAM_ORB_OPT_INTERNAL_STREAM: if (value < 0 || value > 2) return MYSLAM_ERR_INVALID; h->optInternalStream = value; return MYSLAM_OK;
+        case MYSLAM_ORB_OPT_STOP_AFTER: if (value < 0 || value > 4) return MYSLAM_ERR_INVALID; h->optStopAfter = value; return MYSLAM_OK;
+    }
+    return MYSLAM_ERR_INVALID;
 }
 
 int myslam_orb_get_tables(const myslam_orb* h, float* scale, float* inv_scale, int* fpl, int* umax16) {
@@ -616,7 +629,7 @@ int myslam_orb_debug_candidates(myslam_orb* h, const uint8_t* img, int rows, int
     if (mask) MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_stageMask, mask, (size_t)rows * step, hipMemcpyHostToDevice, h->stream));
     MYSLAM_HIP_CHECK(hipMemsetAsync(h->d_candCount, 0, sizeof(int32_t) * MAXL, h->stream));
     if ((rc = h->build_pyramids(h->d_stageImg, 1, step, (size_t)rows * step, mask ? h->d_stageMask : nullptr, h->nlevels))) return rc;
-    launch_fast(h->full, h->d_pyr, h->full.pyrBytes, mask ? h->d_mask : nullptr, h->d_cand, h->d_candCount, 1, h->stream);
+    if ((rc = h->run_fast(h->full, mask ? h->d_mask : nullptr, 1))) return rc;
     int32_t counts[MAXL];
     MYSLAM_HIP_CHECK(hipMemcpyAsync(counts, h->d_candCount, sizeof(counts), hipMemcpyDeviceToHost, h->stream));
     MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void k_resize_strip(ResizeArgs a, int nstrips,
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: 7x7 separable Gaussian, Q8 coefficients, REFLECT_101.  128x32 outputs per 256-thread block, dword I/O.
+// K2: 7x7 separable Gaussian, Q8 coefficients (<= 255 each, sum 256), REFLECT_101.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int reflect101(int p, int len) {
     if (len == 1) return 0;
@@ -179,87 +179,7 @@ __device__ __forceinline__ int reflect101(int p, int len) {
     return p;
 }
 
-// tile: 128 x 32 outputs per block; input tile covers columns x0-4 .. x0+131 (dword aligned), rows y0-3 .. y0+34
-constexpr int BT_W = 128, BT_H = 32, BI_H = BT_H + 6, BI_P = BT_W + 8, BI_DW = BI_P / 4;
-
-__global__ __launch_bounds__(256) void k_blur7(BlurArgs a) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[BI_H * BI_P];
-    __shared__ __attribute__((aligned(16))) uint16_t s_h[BI_H * BT_W];
-    const int t = threadIdx.x;
-    const int b = blockIdx.z;
-    const int x0 = blockIdx.x * BT_W, y0 = blockIdx.y * BT_H;
-    const uint8_t* src = a.src + (size_t)b * a.sstride;
-    const bool aligned = ((a.spitch & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 3) == 0);
-    // 1. stage the input tile (rows reflected; columns outside [0,w) are fixed up in step 2)
-    for (int i = t; i < BI_H * BI_DW; i += 256) {
-        const int r = i / BI_DW, k = i - r * BI_DW;
-        const int gy = reflect101(y0 + r - 3, a.h);
-        const int gx = x0 - 4 + 4 * k;
-        const uint8_t* row = src + (size_t)gy * a.spitch;
-        uint32_t v;
-        if (aligned && gx >= 0 && gx + 4 <= a.spitch) {
-            v = *reinterpret_cast<const uint32_t*>(row + gx);
-        } else {
-            v = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) v |= (uint32_t)row[min(max(gx + j, 0), a.spitch - 1)] << (8 * j);
-        }
-        *reinterpret_cast<uint32_t*>(&s_in[r * BI_P + 4 * k]) = v;
-    }
-    __syncthreads();
-    // 2. BORDER_REFLECT_101 columns: x in [-3,-1] and [w, w+2]; their mirror images are inside this tile
-    for (int i = t; i < BI_H * 6; i += 256) {
-        const int r = i / 6, j = i - r * 6;
-        const int x = (j < 3) ? j - 3 : a.w + (j - 3);
-        const int c = x - (x0 - 4);
-        if (c >= 0 && c < BI_P) {
-            const int cr = reflect101(x, a.w) - (x0 - 4);
-            if (cr >= 0 && cr < BI_P) s_in[r * BI_P + c] = s_in[r * BI_P + cr];
-        }
-    }
-    __syncthreads();
-    // 3. horizontal pass: 4 outputs per iteration from 3 aligned dwords
-    for (int i = t; i < BI_H * (BT_W / 4); i += 256) {
-        const int r = i >> 5, qd = i & 31;
-        const uint32_t* p = reinterpret_cast<const uint32_t*>(&s_in[r * BI_P + 4 * qd]);
-        const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
-        int px[12];
-#pragma unroll
-        for (int k = 0; k < 4; k++) { px[k] = (w0 >> (8 * k)) & 0xff; px[4 + k] = (w1 >> (8 * k)) & 0xff; px[8 + k] = (w2 >> (8 * k)) & 0xff; }
-        uint32_t o[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {                         // output x0+4qd+j uses tile columns 4qd+1+j .. 4qd+7+j
-            int acc = 0;
-#pragma unroll
-            for (int k = 0; k < 7; k++) acc += a.q[k] * px[1 + j + k];
-            o[j] = (uint32_t)acc;
-        }
-        uint2 pk = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
-        *reinterpret_cast<uint2*>(&s_h[r * BT_W + 4 * qd]) = pk;
-    }
-    __syncthreads();
-    // 4. vertical pass + rounding, one dword store per 4 outputs
-    uint8_t* dst = a.dst + (size_t)b * a.dstride;
-    for (int i = t; i < BT_H * (BT_W / 4); i += 256) {
-        const int y = i >> 5, qd = i & 31;
-        const int oy = y0 + y, ox = x0 + 4 * qd;
-        if (oy >= a.h || ox >= a.w) continue;
-        uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
-#pragma unroll
-        for (int j = 0; j < 7; j++) {
-            const uint2 v = *reinterpret_cast<const uint2*>(&s_h[(y + j) * BT_W + 4 * qd]);
-            const uint32_t qj = (uint32_t)a.q[j];
-            acc0 += qj * (v.x & 0xffff); acc1 += qj * (v.x >> 16);
-            acc2 += qj * (v.y & 0xffff); acc3 += qj * (v.y >> 16);
-        }
-        const uint32_t r0 = min((acc0 + 32768u) >> 16, 255u), r1 = min((acc1 + 32768u) >> 16, 255u);
-        const uint32_t r2 = min((acc2 + 32768u) >> 16, 255u), r3 = min((acc3 + 32768u) >> 16, 255u);
-        // destination pitch is a multiple of 64: the 4-byte store never leaves the row; bytes past w are padding
-        *reinterpret_cast<uint32_t*>(dst + (size_t)oy * a.dpitch + ox) = r0 | (r1 << 8) | (r2 << 16) | (r3 << 24);
-    }
-}
-
-// K2b: the same filter on the dot-product units.  Taps <= 255 (true for every kernel this library builds):
+// K2b: LDS-tiled form on the dot-product units (any alignment, any size: the in-place DeepLCD blur and tiny images):
 // horizontal pass = 2 x v_dot4_u32_u8 per pixel on byte-aligned windows (v_alignbyte), two rows at a time so that the
 // u16 results are stored as vertical pairs (h[2j][x], h[2j+1][x]); vertical pass = 4 x v_dot2_u32_u16 per pixel on
 // those pairs with the rounding constant as accumulator seed.  128 x 64 outputs per block.
@@ -499,259 +419,29 @@ __global__ __launch_bounds__(256) void k_blur7_strip(BlurArgs a, int nstrips, in
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3: grid FAST.  One 256-thread block per 30-px grid cell: the cell's ROI (+3 px ring) is staged in
-// LDS, every interior pixel gets its FAST-9 score (largest threshold at which it is still a corner),
-// 3x3 strict-maximum NMS runs inside the cell only (as cv::FAST on the sub-Mat does), the 20 -> 7
-// threshold fallback is decided per cell, survivors are appended to the level's candidate list.
+// K3: grid FAST.  One 256-thread block per strip of 4 horizontally adjacent 30-px grid cells: the strip's ROI rows (+3 px ring)
+// are staged once in LDS (shared halos), every interior pixel gets its FAST-9 score (largest threshold at which it is still a
+// corner), 3x3 strict-maximum NMS runs inside each cell only (as cv::FAST on the sub-Mat does), the 20 -> 7 threshold
+// fallback is decided per cell, survivors are appended to the level's candidate list.
 // Candidate payload: py<<20 | px<<8 | score   (px,py border-relative as in ORBextractor.cpp:871-872).
 // ------------------------------------------------------------------------------------------------
 // ring order = reference makeOffsets(), ORBextractor.cpp:365-369
 #define FAST_RING_X {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1}
 #define FAST_RING_Y {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3}
 
-// necessary condition for a FAST-9 corner at threshold th: any arc of 9 contains one pixel of every opposite
-// pair (k, k+8) — the reference's pre-tests (:466-478).  "every pair has a member darker than v-th" is
-// max_k min(p_k, p_k+8) < v-th (and symmetrically for brighter): 30 two-cycle min/max ops instead of 32
-// four-cycle compares into lane masks.
-template <int TP>
-__device__ __forceinline__ bool fast9_pretest(const uint8_t* p, int th) {
-    constexpr int RX[16] = FAST_RING_X;
-    constexpr int RY[16] = FAST_RING_Y;
-    const int v = p[0];
-    int mx_of_min = 0, mn_of_max = 255;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int a = p[RX[k] + RY[k] * TP], b = p[RX[k + 8] + RY[k + 8] * TP];
-        mx_of_min = max(mx_of_min, min(a, b));
-        mn_of_max = min(mn_of_max, max(a, b));
-    }
-    return (mx_of_min < v - th) || (mn_of_max > v + th);
-}
-
-// FAST-9 score = largest threshold at which the pixel is still a corner (cv::cornerScore<16> without the
-// threshold seed): max over the 16 arcs of 9 of min(v - p) and of min(p - v), minus 1; 0 if below minTh.
-// Packed 16-bit evaluation: register j holds (d[j], d[j+8]); the sliding minima/maxima over windows of
-// 2, 4, 8, 9 ring positions are v_pk_min/max_i16 on those pairs (the wrap-around is a half swap).
 typedef short s16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ s16x2 hswap(s16x2 x) { return __builtin_shufflevector(x, x, 1, 0); }
 __device__ __forceinline__ s16x2 pmin(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ s16x2 pmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
 
-template <int TP>
-__device__ __forceinline__ int fast9_score(const uint8_t* p, int minTh) {
-    constexpr int RX[16] = FAST_RING_X;
-    constexpr int RY[16] = FAST_RING_Y;
-    const int v = p[0];
-    const s16x2 vv = {(short)v, (short)v};
-    s16x2 P[8], Ps[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const s16x2 q = {(short)p[RX[j] + RY[j] * TP], (short)p[RX[j + 8] + RY[j + 8] * TP]};
-        P[j] = vv - q;                       // (d[j], d[j+8])
-        Ps[j] = hswap(P[j]);                 // (d[j+8], d[j])
-    }
-    s16x2 A[8], B[8], C[8], Am[8], Bm[8], Cm[8];
-#pragma unroll
-    for (int j = 0; j < 7; j++) { A[j] = pmin(P[j], P[j + 1]); Am[j] = pmax(P[j], P[j + 1]); }
-    A[7] = pmin(P[7], Ps[0]); Am[7] = pmax(P[7], Ps[0]);
-#pragma unroll
-    for (int j = 0; j < 6; j++) { B[j] = pmin(A[j], A[j + 2]); Bm[j] = pmax(Am[j], Am[j + 2]); }
-    B[6] = pmin(A[6], hswap(A[0])); B[7] = pmin(A[7], hswap(A[1]));
-    Bm[6] = pmax(Am[6], hswap(Am[0])); Bm[7] = pmax(Am[7], hswap(Am[1]));
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        C[j] = pmin(B[j], B[j + 4]); Cm[j] = pmax(Bm[j], Bm[j + 4]);
-        C[j + 4] = pmin(B[j + 4], hswap(B[j])); Cm[j + 4] = pmax(Bm[j + 4], hswap(Bm[j]));
-    }
-    s16x2 dark = {-1000, -1000}, brt = {1000, 1000};
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        dark = pmax(dark, pmin(C[j], Ps[j]));        // min over arc k..k+8 for k = j and k = j+8
-        brt = pmin(brt, pmax(Cm[j], Ps[j]));         // max over the same arcs
-    }
-    const int best_dark = max((int)dark.x, (int)dark.y);
-    const int best_bright = -min((int)brt.x, (int)brt.y);
-    const int s = max(best_dark, best_bright) - 1;
-    return s >= minTh ? s : 0;
-}
-
-// T threads per cell (64 = one wave per cell: no inter-wave barriers, every wave runs its cell independently);
-// CW = largest cell interior edge the instantiation supports (LDS is sized by it).
-template <int T, int CW>
-__global__ __launch_bounds__(T) void k_fast_cells(OrbPlan P, const uint8_t* __restrict__ pyr, size_t pyrStride,
-                                                  const uint8_t* __restrict__ maskPyr,
-                                                  uint32_t* __restrict__ cand, int32_t* __restrict__ candCount) {
-    constexpr int TP = (CW + 15) & ~3;            // ROI tile pitch: 3 (align) + CW + 6 (+3 dword slack)
-    constexpr int TROWS = CW + 6;
-    constexpr int SP = (CW + 2 + 3) & ~3;         // score tile pitch (1-px zero border)
-    constexpr int SROWS = CW + 2;
-    constexpr int NLOC = ((CW + 1) / 2) * ((CW + 1) / 2);   // strict 8-neighbour maxima a cell can hold
-    __shared__ __attribute__((aligned(16))) uint8_t s_tile[TROWS * TP];
-    __shared__ __attribute__((aligned(16))) uint8_t s_score[SROWS * SP];
-    __shared__ uint32_t s_list[NLOC];
-    __shared__ uint16_t s_cl[CW * CW + 8];
-    __shared__ int s_cnt, s_base, s_npass, s_wr, s_ncl;
-
-    const int b = blockIdx.y;
-    int level = 0;
-    for (int l = 1; l < P.nlevels; l++) if ((int)blockIdx.x >= P.lv[l].cellBase) level = l;
-    const LevelGeom& g = P.lv[level];
-    const int cell = blockIdx.x - g.cellBase;
-    const int ci = cell / g.nCols, cj = cell - ci * g.nCols;
-    const int iniY = MIN_BORDER + ci * g.hCell, iniX = MIN_BORDER + cj * g.wCell;
-    if (iniY >= g.maxBY - 3 || iniX >= g.maxBX - 6) return;            // :843, :852
-    const int maxY = min(iniY + g.hCell + 6, g.maxBY), maxX = min(iniX + g.wCell + 6, g.maxBX);
-    const int wr = maxX - iniX, hr = maxY - iniY;                      // ROI
-    const int wc = wr - 6, hc = hr - 6;                                // detection interior
-    if (wc <= 0 || hc <= 0) return;
-
-    const uint8_t* img = pyr + (size_t)b * pyrStride + g.imgOff;
-    // stage ROI with aligned 4-byte loads (internal planes: 64-byte pitch, 256-byte base)
-    const int x0a = iniX & ~3, off = iniX - x0a;
-    const int ndw = (off + wr + 3) >> 2;
-    for (int r = threadIdx.x / 32; r < hr; r += T / 32) {             // ndw <= 18 dwords per ROI row
-        const int k = threadIdx.x & 31;
-        if (k < ndw) {
-            const uint32_t v = *reinterpret_cast<const uint32_t*>(img + (size_t)(iniY + r) * g.pitch + x0a + 4 * k);
-            *reinterpret_cast<uint32_t*>(&s_tile[r * TP + 4 * k]) = v;
-        }
-    }
-    for (int i = threadIdx.x; i < (SROWS * SP) / 4; i += T) reinterpret_cast<uint32_t*>(s_score)[i] = 0;
-    if (threadIdx.x == 0) { s_cnt = 0; s_ncl = 0; }
-    __syncthreads();
-
-    // thread -> pixel mapping without integer division: lane x = t & 31 (+32), rows t >> 5 (+T/32)
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int lane = threadIdx.x & 63;
-    // phase 1: cheap necessary test on every pixel; survivors are compacted into an LDS work list (cy<<8 | cx)
-    for (int cy0 = 0; cy0 < hc; cy0 += T / 32) {
-        for (int cx0 = 0; cx0 < wc; cx0 += 32) {
-            const int cy = cy0 + ty, cx = cx0 + tx;
-            bool pass = false;
-            if (cy < hc && cx < wc) pass = fast9_pretest<TP>(&s_tile[(cy + 3) * TP + off + cx + 3], P.minTh);
-            const unsigned long long m = __ballot(pass);
-            if (m) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&s_ncl, __popcll(m));
-                base = __shfl(base, 0, 64);
-                if (pass) s_cl[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((cy << 8) | cx);
-            }
-        }
-    }
-    __syncthreads();
-    // phase 2: full score only for the survivors (dense lanes)
-    const int ncl = s_ncl;
-    for (int q = threadIdx.x; q < ncl; q += T) {
-        const int i = s_cl[q];
-        const int cy = i >> 8, cx = i & 0xff;
-        const int s = fast9_score<TP>(&s_tile[(cy + 3) * TP + off + cx + 3], P.minTh);
-        if (s) s_score[(cy + 1) * SP + cx + 1] = (uint8_t)s;
-    }
-    __syncthreads();
-
-    // NMS (strict > all 8 neighbours, zeros outside the cell interior): only phase-2 survivors can be maxima
-    int any_ini = 0;
-    for (int q = threadIdx.x; q < ncl; q += T) {
-        const int i = s_cl[q];
-        const int cy = i >> 8, cx = i & 0xff;
-        const uint8_t* sp = &s_score[(cy + 1) * SP + cx + 1];
-        const int s = sp[0];
-        if (s) {
-            const bool mx = s > sp[-1] && s > sp[1] && s > sp[-SP - 1] && s > sp[-SP] && s > sp[-SP + 1] &&
-                            s > sp[SP - 1] && s > sp[SP] && s > sp[SP + 1];
-            if (mx) {
-                const int px = cx + 3 + cj * g.wCell, py = cy + 3 + ci * g.hCell;     // border-relative
-                const int pos = atomicAdd(&s_cnt, 1);
-                if (pos < NLOC) s_list[pos] = ((uint32_t)py << 20) | ((uint32_t)px << 8) | (uint32_t)s;
-                any_ini |= (s >= P.iniTh);
-            }
-        }
-    }
-    // does the cell have a corner at iniTh?  else fall back to minTh (:858-865)
-    const int cell_has_ini = __syncthreads_or(any_ini);
-    const int nloc = min(s_cnt, NLOC);
-    const uint8_t* mimg = maskPyr ? maskPyr + (size_t)b * pyrStride + g.imgOff : nullptr;
-    auto passes = [&](uint32_t kp) -> bool {
-        if (cell_has_ini && (int)(kp & 0xff) < P.iniTh) return false;
-        if (mimg) {                                                                   // :873-877 (no +16: reference quirk)
-            const int px = (kp >> 8) & 0xfff, py = kp >> 20;
-            if (mimg[(size_t)py * g.pitch + px] == 0) return false;
-        }
-        return true;
-    };
-    int npass = 0;
-    for (int i = threadIdx.x; i < nloc; i += T) npass += passes(s_list[i]) ? 1 : 0;
-    if (threadIdx.x == 0) { s_npass = 0; s_wr = 0; }
-    __syncthreads();
-    if (npass) atomicAdd(&s_npass, npass);
-    __syncthreads();
-    const int n = s_npass;
-    if (n == 0) return;
-    if (threadIdx.x == 0) s_base = atomicAdd(&candCount[b * MAXL + level], n);
-    __syncthreads();
-    uint32_t* out = cand + (size_t)b * P.totalKeyCap + g.keyOff;
-    for (int i = threadIdx.x; i < nloc; i += T) {
-        const uint32_t kp = s_list[i];
-        if (!passes(kp)) continue;
-        const int dst = s_base + atomicAdd(&s_wr, 1);
-        if (dst < g.keyCap) out[dst] = kp;
-    }
-}
-
-// ---- register-tile variant -------------------------------------------------------------------------
-// Each lane owns 4 horizontally adjacent pixels: it pulls the 7 x 16-byte window they share out of LDS with
-// dword reads (3.5 LDS instructions per pixel instead of 17 byte reads), shifts it into place with
-// v_alignbyte, and builds the packed (d[j], d[j+8]) operands of the score tree straight from registers with
-// v_perm_b32 (compile-time byte selectors).  NMS works the same way on the score tile.
-template <int C>
-__device__ __forceinline__ int fast9_score_regs(const uint32_t (&r)[7][3], int minTh) {
-    constexpr int RX[16] = FAST_RING_X;
-    constexpr int RY[16] = FAST_RING_Y;
-    constexpr int xc = 3 + C;
-    const uint32_t cw = r[3][xc >> 2];
-    const uint32_t vv_u = __builtin_amdgcn_perm(cw, cw, 0x0c000c00u | ((4u + (xc & 3)) << 16) | (uint32_t)(xc & 3));
-    s16x2 vv; __builtin_memcpy(&vv, &vv_u, 4);
-    s16x2 P[8], Ps[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int xa = xc + RX[j], ya = 3 + RY[j], xb = xc + RX[j + 8], yb = 3 + RY[j + 8];
-        const uint32_t qu = __builtin_amdgcn_perm(r[yb][xb >> 2], r[ya][xa >> 2],
-                                                  0x0c000c00u | ((4u + (uint32_t)(xb & 3)) << 16) | (uint32_t)(xa & 3));
-        s16x2 q; __builtin_memcpy(&q, &qu, 4);
-        P[j] = vv - q;                       // (d[j], d[j+8])
-        Ps[j] = hswap(P[j]);
-    }
-    s16x2 A[8], B[8], Cn[8], Am[8], Bm[8], Cm[8];
-#pragma unroll
-    for (int j = 0; j < 7; j++) { A[j] = pmin(P[j], P[j + 1]); Am[j] = pmax(P[j], P[j + 1]); }
-    A[7] = pmin(P[7], Ps[0]); Am[7] = pmax(P[7], Ps[0]);
-#pragma unroll
-    for (int j = 0; j < 6; j++) { B[j] = pmin(A[j], A[j + 2]); Bm[j] = pmax(Am[j], Am[j + 2]); }
-    B[6] = pmin(A[6], hswap(A[0])); B[7] = pmin(A[7], hswap(A[1]));
-    Bm[6] = pmax(Am[6], hswap(Am[0])); Bm[7] = pmax(Am[7], hswap(Am[1]));
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        Cn[j] = pmin(B[j], B[j + 4]); Cm[j] = pmax(Bm[j], Bm[j + 4]);
-        Cn[j + 4] = pmin(B[j + 4], hswap(B[j])); Cm[j + 4] = pmax(Bm[j + 4], hswap(Bm[j]));
-    }
-    s16x2 dark = {-1000, -1000}, brt = {1000, 1000};
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        dark = pmax(dark, pmin(Cn[j], Ps[j]));
-        brt = pmin(brt, pmax(Cm[j], Ps[j]));
-    }
-    const int s = max(max((int)dark.x, (int)dark.y), -min((int)brt.x, (int)brt.y)) - 1;
-    return s >= minTh ? s : 0;
-}
-
-// Two-pixel packing of the same score: register i holds ring position i of two horizontally adjacent pixels (raw u8
-// values in 16-bit lanes), so no difference to the centre is taken until the end:
+// FAST-9 score = largest threshold at which the pixel is still a corner (cv::cornerScore<16> without the threshold seed):
+// max over the 16 arcs of 9 of min(v - p) and of min(p - v), minus 1.
+// Two-pixel packing: register i holds ring position i of two horizontally adjacent pixels (raw u8 values in 16-bit lanes), so no
+// difference to the centre is taken until the end:
 //   bright = max over arcs (min over the arc of p) - v,   dark = v - min over arcs (max over the arc of p).
 // The 16 arcs of 9 are covered from the 8 even-aligned windows of 8: arc [2k, 2k+8] = m8[k] + p[2k+8] and
-// arc [2k-1, 2k+7] = p[2k-1] + m8[k], and max(min(m, a), min(m, b)) = min(m, max(a, b)) — 47 packed ops per polarity
+// arc [2k-1, 2k+7] = p[2k-1] + m8[k], and max(min(m, a), min(m, b)) = min(m, max(a, b)) — 36 packed ops per polarity
 // for two pixels.  Returns z = score - (minTh - 1) for corners at minTh, 0 otherwise (an order-preserving shift: the
-// NMS compares z, the append adds minTh - 1 back).  PAIR selects pixels (2 PAIR, 2 PAIR + 1) of the lane's four.
+// NMS compares z, the append adds minTh - 1 back).  PAIR selects pixels (2 PAIR, 2 PAIR + 1) of the window's four.
 // gfx950 has three-input packed minimum / maximum only for f16.  Ring values are carried as 0x6400 | p in each 16-bit lane:
 // that is the f16 number 1024 + p (exact, normal), whose bit patterns order exactly like the integers, so the two-input steps
 // stay v_pk_min/max_i16, the three-input steps are v_pk_minimum3/maximum3_f16 on the same registers, and differences of two
@@ -795,131 +485,28 @@ __device__ __forceinline__ s16x2 fast9_score_pair(const uint32_t (&r)[NR][3], s1
     return pmax(sraw, thv) - thv;
 }
 
-template <int C>
-__device__ __forceinline__ bool nms_regs(const uint32_t (&m)[3][3], int& s_out) {
-    auto by = [&](int row, int x) -> int { return (int)((m[row][x >> 2] >> (8 * (x & 3))) & 0xff); };
-    constexpr int x = 4 + C;
-    const int s = by(1, x);
-    s_out = s;
-    if (!s) return false;
-    return s > by(0, x - 1) && s > by(0, x) && s > by(0, x + 1) && s > by(1, x - 1) && s > by(1, x + 1) &&
-           s > by(2, x - 1) && s > by(2, x) && s > by(2, x + 1);
+// bytes A, A+1 (A = 0..3) of the dword pair (lo, hi) as two zero-extended 16-bit lanes
+template <int A>
+__device__ __forceinline__ s16x2 pick16(uint32_t lo, uint32_t hi) {
+    const uint32_t u = __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | ((uint32_t)(A + 1) << 16) | (uint32_t)A);
+    s16x2 q; __builtin_memcpy(&q, &u, 4);
+    return q;
 }
 
-template <int T, int CW>
-__global__ __launch_bounds__(T) void k_fast_cells_v3(OrbPlan P, const uint8_t* __restrict__ pyr, size_t pyrStride,
-                                                     const uint8_t* __restrict__ maskPyr,
-                                                     uint32_t* __restrict__ cand, int32_t* __restrict__ candCount) {
-    constexpr int TP = (CW + 18) & ~3;            // ROI tile pitch: lanes read 16 bytes from column 4*gi <= CW-1
-    constexpr int TROWS = CW + 6;
-    constexpr int SP = (CW + 4 + 8 + 3) & ~3;     // score tile: interior starts at column 4 (dword aligned), row 1
-    constexpr int SROWS = CW + 2;
-    constexpr int NLOC = ((CW + 1) / 2) * ((CW + 1) / 2);
-    __shared__ __attribute__((aligned(16))) uint8_t s_tile[TROWS * TP + 16];
-    __shared__ __attribute__((aligned(16))) uint8_t s_score[SROWS * SP + 16];
-    __shared__ uint32_t s_list[NLOC];
-    __shared__ int s_cnt, s_base, s_npass, s_wr;
-
-    const int b = blockIdx.y;
-    int level = 0;
-    for (int l = 1; l < P.nlevels; l++) if ((int)blockIdx.x >= P.lv[l].cellBase) level = l;
-    const LevelGeom& g = P.lv[level];
-    const int cell = blockIdx.x - g.cellBase;
-    const int ci = cell / g.nCols, cj = cell - ci * g.nCols;
-    const int iniY = MIN_BORDER + ci * g.hCell, iniX = MIN_BORDER + cj * g.wCell;
-    if (iniY >= g.maxBY - 3 || iniX >= g.maxBX - 6) return;            // :843, :852
-    const int maxY = min(iniY + g.hCell + 6, g.maxBY), maxX = min(iniX + g.wCell + 6, g.maxBX);
-    const int wr = maxX - iniX, hr = maxY - iniY;                      // ROI
-    const int wc = wr - 6, hc = hr - 6;                                // detection interior
-    if (wc <= 0 || hc <= 0) return;
-
-    const uint8_t* img = pyr + (size_t)b * pyrStride + g.imgOff;
-    const int x0a = iniX & ~3, off = iniX - x0a;
-    const int ndw = (off + wr + 3) >> 2;
-    for (int r = threadIdx.x / 32; r < hr; r += T / 32) {             // ndw <= 18 dwords per ROI row
-        const int k = threadIdx.x & 31;
-        if (k < ndw) {
-            const uint32_t v = *reinterpret_cast<const uint32_t*>(img + (size_t)(iniY + r) * g.pitch + x0a + 4 * k);
-            *reinterpret_cast<uint32_t*>(&s_tile[r * TP + 4 * k]) = v;
-        }
-    }
-    for (int i = threadIdx.x; i < (SROWS * SP) / 4; i += T) reinterpret_cast<uint32_t*>(s_score)[i] = 0;
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
-
-    const int ngr = (wc + 3) >> 2, ngroups = ngr * hc;
-    // scores: 4 pixels per lane from a 7 x 12-byte register window
-    for (int q = threadIdx.x; q < ngroups; q += T) {
-        const int cy = q / ngr, gi = q - cy * ngr;
-        uint32_t r[7][3];
-#pragma unroll
-        for (int j = 0; j < 7; j++) {
-            const uint32_t* rp = reinterpret_cast<const uint32_t*>(&s_tile[(cy + j) * TP + 4 * gi]);
-            const uint32_t w0 = rp[0], w1 = rp[1], w2 = rp[2], w3 = rp[3];
-            r[j][0] = __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)off);
-            r[j][1] = __builtin_amdgcn_alignbyte(w2, w1, (uint32_t)off);
-            r[j][2] = __builtin_amdgcn_alignbyte(w3, w2, (uint32_t)off);
-        }
-        const int cx = 4 * gi;
-        uint32_t s0 = fast9_score_regs<0>(r, P.minTh), s1 = fast9_score_regs<1>(r, P.minTh);
-        uint32_t s2 = fast9_score_regs<2>(r, P.minTh), s3 = fast9_score_regs<3>(r, P.minTh);
-        if (cx + 1 >= wc) s1 = 0;
-        if (cx + 2 >= wc) s2 = 0;
-        if (cx + 3 >= wc) s3 = 0;
-        *reinterpret_cast<uint32_t*>(&s_score[(cy + 1) * SP + 4 + cx]) = s0 | (s1 << 8) | (s2 << 16) | (s3 << 24);
-    }
-    __syncthreads();
-
-    // NMS (strict > all 8 neighbours, zeros outside the cell interior)
-    int any_ini = 0;
-    for (int q = threadIdx.x; q < ngroups; q += T) {
-        const int cy = q / ngr, gi = q - cy * ngr;
-        uint32_t m[3][3];
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const uint32_t* rp = reinterpret_cast<const uint32_t*>(&s_score[(cy + j) * SP + 4 * gi]);
-            m[j][0] = rp[0]; m[j][1] = rp[1]; m[j][2] = rp[2];
-        }
-        int sc[4]; bool mx[4];
-        mx[0] = nms_regs<0>(m, sc[0]); mx[1] = nms_regs<1>(m, sc[1]); mx[2] = nms_regs<2>(m, sc[2]); mx[3] = nms_regs<3>(m, sc[3]);
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            if (mx[c]) {
-                const int px = 4 * gi + c + 3 + cj * g.wCell, py = cy + 3 + ci * g.hCell;     // border-relative
-                const int pos = atomicAdd(&s_cnt, 1);
-                if (pos < NLOC) s_list[pos] = ((uint32_t)py << 20) | ((uint32_t)px << 8) | (uint32_t)sc[c];
-                any_ini |= (sc[c] >= P.iniTh);
-            }
-        }
-    }
-    const int cell_has_ini = __syncthreads_or(any_ini);
-    const int nloc = min(s_cnt, NLOC);
-    const uint8_t* mimg = maskPyr ? maskPyr + (size_t)b * pyrStride + g.imgOff : nullptr;
-    auto passes = [&](uint32_t kp) -> bool {
-        if (cell_has_ini && (int)(kp & 0xff) < P.iniTh) return false;
-        if (mimg) {                                                                   // :873-877 (no +16: reference quirk)
-            const int px = (kp >> 8) & 0xfff, py = kp >> 20;
-            if (mimg[(size_t)py * g.pitch + px] == 0) return false;
-        }
-        return true;
-    };
-    int npass = 0;
-    for (int i = threadIdx.x; i < nloc; i += T) npass += passes(s_list[i]) ? 1 : 0;
-    if (threadIdx.x == 0) { s_npass = 0; s_wr = 0; }
-    __syncthreads();
-    if (npass) atomicAdd(&s_npass, npass);
-    __syncthreads();
-    const int n = s_npass;
-    if (n == 0) return;
-    if (threadIdx.x == 0) s_base = atomicAdd(&candCount[b * MAXL + level], n);
-    __syncthreads();
-    uint32_t* out = cand + (size_t)b * P.totalKeyCap + g.keyOff;
-    for (int i = threadIdx.x; i < nloc; i += T) {
-        const uint32_t kp = s_list[i];
-        if (!passes(kp)) continue;
-        const int dst = s_base + atomicAdd(&s_wr, 1);
-        if (dst < g.keyCap) out[dst] = kp;
-    }
+// Necessary condition for a FAST-9 corner at threshold th, on two pixels at once: every arc of 9 contains two CYCLICALLY ADJACENT
+// compass points of the ring (positions 0, 4, 8, 12 = (0,3), (3,0), (0,-3), (-3,0)), so a corner has an adjacent compass pair whose
+// two pixels are both darker than v - th or both brighter than v + th (the in-tree isFastCorner pre-tests, ORBextractor.cpp:464-478,
+// are the same idea on opposite pairs).  19 packed ops and 5 byte-pair picks against 77 + 17 for the score.  Returns true when either
+// pixel of the pair passes.
+__device__ __forceinline__ bool fast9_compass_pair(s16x2 v, s16x2 p0, s16x2 p4, s16x2 p8, s16x2 p12, s16x2 thv) {
+    const s16x2 dmin = pmin(pmin(pmax(p0, p4), pmax(p4, p8)), pmin(pmax(p8, p12), pmax(p12, p0)));
+    const s16x2 bmax = pmax(pmax(pmin(p0, p4), pmin(p4, p8)), pmax(pmin(p8, p12), pmin(p12, p0)));
+    const s16x2 t1 = (v - thv) - dmin;                       // > 0  <=>  some adjacent compass pair is darker than v - th
+    const s16x2 t2 = bmax - (v + thv);                       // > 0  <=>  some adjacent compass pair is brighter than v + th
+    const s16x2 zero = {0, 0};
+    const s16x2 m = pmax(pmax(t1, t2), zero);
+    uint32_t u; __builtin_memcpy(&u, &m, 4);
+    return u != 0;
 }
 
 // 3x3 strict-maximum test for pixels (2 PAIR, 2 PAIR + 1) of the lane's four, on 16-bit lanes: 9 byte-pair picks,
@@ -957,14 +544,26 @@ __device__ __forceinline__ int wave_incl_scan_dpp(int v) {
     return v;
 }
 
-// ---- strip variant: one block scores G horizontally adjacent cells -----------------------------------
-// Same arithmetic as k_fast_cells_v3 per cell (NMS and the 20 -> 7 fallback never cross a cell border), but the
-// ROI rows of G cells are staged once (shared 6-px halos), block dispatch / barriers / the global append are
-// amortised over G cells.
+// Path selection of the strip kernel (per level): `prev` = what the previous launch of this extractor handle measured,
+// `cur` = what this launch accumulates (zeroed by the host): [level][4] = {pairs that survived the pre-test (two-phase path) or
+// pairs holding a corner (dense path), pixel pairs looked at, path used, -}.  force: -1 = choose, 0 = two-phase, 1 = dense.
+// Both paths produce the same candidate SET, so the choice only moves time: on imagery with a few % of corners the two-phase
+// path scores a tenth of the pixels; when most pixel pairs survive the pre-test (noise-like texture) compaction cannot pay.
+struct FastCtl { const uint32_t* prev; uint32_t* cur; int force; };
+
+// ---- strip kernel: one block scores G horizontally adjacent cells -----------------------------------
+// NMS and the 20 -> 7 fallback never cross a cell border; the ROI rows of G cells are staged once (shared 6-px halos), block
+// dispatch / barriers / the global append are amortised over G cells.
+//   two-phase path:  1. compass pre-test on every pixel (work item = 4 pixels x 2 rows from a 6-row x 12-byte register window),
+//                       surviving pixel PAIRS are ballot-compacted into an LDS list (one LDS atomic per wave and iteration);
+//                    2. one lane per listed pair: 7 x 8-byte window, packed score, 16-bit store into the score map;
+//                    3. one lane per listed pair: 3x3 strict-maximum test on the score map.
+//   dense path:      every pixel is scored (work item = 4 pixels x 2 rows: the two 7-row windows share 6 rows), NMS per item.
+// Blocks are handed out XCD-aware: consecutive strips (which share halo rows and columns) go to the same XCD's L2.
 template <int CW, int G>
 __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __restrict__ pyr, size_t pyrStride,
                                                     const uint8_t* __restrict__ maskPyr,
-                                                    uint32_t* __restrict__ cand, int32_t* __restrict__ candCount) {
+                                                    uint32_t* __restrict__ cand, int32_t* __restrict__ candCount, FastCtl ctl, int batch) {
     constexpr int T = 256;
     constexpr int TP = (15 + G * CW + 6 + 16 + 15) & ~15;              // row pitch of the staged tile (16-byte aligned rows)
     constexpr int NQ = TP / 16;                                        // 16-byte groups per row
@@ -972,21 +571,31 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
     constexpr int SP = (CW + 4 + 8 + 3) & ~3;
     constexpr int SROWS = CW + 2 + 1;
     constexpr int NLIST = G * ((CW + 1) / 2) * ((CW + 1) / 2);         // a cell of a x b pixels holds at most ceil(a/2) ceil(b/2) strict maxima
+    constexpr int NPAIR = G * CW * ((CW + 1) / 2);                     // pixel pairs of a strip
+    static_assert(CW <= 63 && G <= 4, "pair list entry = cell << 11 | row << 5 | pair index");
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[TROWS * TP + 16];
     __shared__ __attribute__((aligned(16))) uint8_t s_score[G][SROWS * SP + 16];
+    __shared__ uint16_t s_pairs[NPAIR];
     // strict maxima of the strip (py<<20 | px<<8 | z) and their cells: the list lives in the tile's LDS, which is dead once the
     // scores are computed (5 bytes per entry, NLIST entries always fit: checked below)
     static_assert(NLIST * 5 <= TROWS * TP, "maxima list must fit into the staged tile");
     uint32_t* const s_list = reinterpret_cast<uint32_t*>(s_tile);
     uint8_t* const s_listc = s_tile + 4 * NLIST;
-    __shared__ int s_ini[G], s_nlist;
+    __shared__ int s_ini[G], s_wc[G], s_nlist, s_npair, s_ncorner;
 
-    const int b = blockIdx.y;
+    // XCD-aware block order (bijective remap of the 1-D grid): the dispatcher places block i on XCD i % 8 and every XCD has a private
+    // L2; logical ids (image-major, strips row by row) are handed out so that each XCD walks a contiguous range of strips, whose
+    // shared halo rows / columns then hit in that L2 instead of being fetched once per XCD
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+    const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int b = logical / P.nstrips, sidx = logical - b * P.nstrips;
+    if (b >= batch) return;
     int level = 0;
-    for (int l = 1; l < P.nlevels; l++) if ((int)blockIdx.x >= P.lv[l].stripBase) level = l;
+    for (int l = 1; l < P.nlevels; l++) if (sidx >= P.lv[l].stripBase) level = l;
     const LevelGeom& g = P.lv[level];
     const int spr = (g.nCols + G - 1) / G;                             // strips per cell row
-    const int strip = blockIdx.x - g.stripBase;
+    const int strip = sidx - g.stripBase;
     const int ci = strip / spr, cj0 = (strip - ci * spr) * G;
     const int iniY = MIN_BORDER + ci * g.hCell;
     if (iniY >= g.maxBY - 3) return;                                   // :843
@@ -994,20 +603,21 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
     const int hr = maxY - iniY, hc = hr - 6;
     if (hc <= 0) return;
     // cells of this strip: interior widths (0 = cell skipped, :852)
-    int wcs[G];
-    int ncell = 0;
+    int ncell = 0, wlast = 0, pairs_total = 0;
 #pragma unroll
     for (int c = 0; c < G; c++) {
         const int cj = cj0 + c;
         const int iniX = MIN_BORDER + cj * g.wCell;
         int wc = 0;
         if (cj < g.nCols && iniX < g.maxBX - 6) wc = max(0, min(iniX + g.wCell + 6, g.maxBX) - iniX - 6);
-        wcs[c] = wc;
-        if (wc > 0) ncell = c + 1;
+        if ((int)threadIdx.x == c) s_wc[c] = wc;                       // per-cell widths are looked up from LDS (a register array would be indexed dynamically)
+        if (wc > 0) { ncell = c + 1; wlast = wc; }
+        pairs_total += ((wc + 1) >> 1) * hc;
     }
     if (ncell == 0) return;
+    auto wc_of = [&](int c) __attribute__((always_inline)) -> int { return s_wc[c]; };
     const int iniX0 = MIN_BORDER + cj0 * g.wCell;
-    const int endX = MIN_BORDER + (cj0 + ncell - 1) * g.wCell + wcs[ncell - 1] + 6;     // exclusive right edge of the last ROI
+    const int endX = MIN_BORDER + (cj0 + ncell - 1) * g.wCell + wlast + 6;             // exclusive right edge of the last ROI
     const uint8_t* img = pyr + (size_t)b * pyrStride + g.imgOff;
     const int x0a = iniX0 & ~15, off = iniX0 - x0a;                    // level planes are 256-byte aligned with 64-byte pitch
     const int nq = min((endX - x0a + 15) >> 4, NQ);
@@ -1033,20 +643,24 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
         if (NB % 16 != 0 && threadIdx.x < (NB - 16 * NV) / 4) reinterpret_cast<uint32_t*>(&s_score[0][0])[4 * NV + threadIdx.x] = 0;
     }
     if (threadIdx.x < G) s_ini[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_nlist = 0;
+    if (threadIdx.x == 0) { s_nlist = 0; s_npair = 0; s_ncorner = 0; }
+    // path of this launch: what the previous launch of the handle saw on this level decides (block-uniform)
+    bool dense;
+    {
+        const float ps = (float)ctl.prev[level * 4], pt = (float)ctl.prev[level * 4 + 1];
+        const bool was_dense = ctl.prev[level * 4 + 2] != 0;
+        dense = ctl.force >= 0 ? ctl.force != 0 : (pt > 0.f && (was_dense ? ps > 0.45f * pt : ps > 0.72f * pt));
+    }
     __syncthreads();
-#if defined(MYSLAM_FAST_STOP) && MYSLAM_FAST_STOP == 1
-    return;
-#endif
 
     const s16x2 thv = {(short)P.minTh, (short)P.minTh};
     const int zoff = P.minTh - 1;                                      // the score map holds z = score - zoff
-    // work item = 4 pixels x 2 rows: the two 7-row windows share 6 rows (8 rows x 16 bytes from LDS instead of 14)
+    // work item = 4 pixels x 2 rows
     const int hc2 = (hc + 1) >> 1;
     const int ngr = (g.wCell + 3) >> 2, per_cell = ngr * hc2, nitems = ncell * per_cell;
     // q -> (cell c, row pair cy2, 4-pixel group gi) without integer division: q < 2^12, so a float reciprocal + one fix-up is exact
     const float inv_pc = 1.0f / (float)per_cell, inv_ngr = 1.0f / (float)ngr;
-    auto split = [&](int q, int& c, int& cy, int& gi) {
+    auto split = [&](int q, int& c, int& cy, int& gi) __attribute__((always_inline)) {
         c = (int)(((float)q + 0.5f) * inv_pc);
         int rem = q - c * per_cell;
         if (rem < 0) { c--; rem += per_cell; } else if (rem >= per_cell) { c++; rem -= per_cell; }
@@ -1054,96 +668,217 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
         gi = rem - cy * ngr;
         if (gi < 0) { cy--; gi += ngr; } else if (gi >= ngr) { cy++; gi -= ngr; }
     };
-    for (int q = threadIdx.x; q < nitems; q += T) {
-        int c, cy2, gi;
-        split(q, c, cy2, gi);
-        const int wc = (c == 0) ? wcs[0] : (c == 1) ? wcs[1 % G] : (c == 2) ? wcs[2 % G] : wcs[3 % G];
-        const int cx = 4 * gi, cy = 2 * cy2;
-        if (cx >= wc) continue;
-        const int col = off + c * g.wCell + cx;                        // tile byte of ROI column cx of cell c
-        const uint32_t sh = (uint32_t)(col & 3);
-        uint32_t r[8][3];                                              // tile rows cy .. cy+7 (row cy+7 may lie below the ROI: staged as zeros / unused)
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint32_t* rp = reinterpret_cast<const uint32_t*>(&s_tile[(cy + j) * TP + (col & ~3)]);
-            const uint32_t w0 = rp[0], w1 = rp[1], w2 = rp[2], w3 = rp[3];
-            r[j][0] = __builtin_amdgcn_alignbyte(w1, w0, sh);
-            r[j][1] = __builtin_amdgcn_alignbyte(w2, w1, sh);
-            r[j][2] = __builtin_amdgcn_alignbyte(w3, w2, sh);
-        }
-        const uint32_t keepm = (wc - cx < 4) ? (1u << (8 * (wc - cx))) - 1u : 0xffffffffu;
-        {
-            const s16x2 za = fast9_score_pair<0, 0, 8>(r, thv), zb = fast9_score_pair<1, 0, 8>(r, thv);
-            uint32_t ua, ub;
-            __builtin_memcpy(&ua, &za, 4); __builtin_memcpy(&ub, &zb, 4);
-            *reinterpret_cast<uint32_t*>(&s_score[c][(cy + 1) * SP + 4 + cx]) = __builtin_amdgcn_perm(ub, ua, 0x06040200u) & keepm;   // the four z bytes
-        }
-        if (cy + 1 < hc) {
-            const s16x2 za = fast9_score_pair<0, 1, 8>(r, thv), zb = fast9_score_pair<1, 1, 8>(r, thv);
-            uint32_t ua, ub;
-            __builtin_memcpy(&ua, &za, 4); __builtin_memcpy(&ub, &zb, 4);
-            *reinterpret_cast<uint32_t*>(&s_score[c][(cy + 2) * SP + 4 + cx]) = __builtin_amdgcn_perm(ub, ua, 0x06040200u) & keepm;
-        }
-    }
-    __syncthreads();
-#if defined(MYSLAM_FAST_STOP) && MYSLAM_FAST_STOP == 2
-    return;
-#endif
-    // NMS: every 4-pixel work item reports its strict maxima; they are appended to an LDS list with ONE returning LDS atomic
-    // per wave and iteration (DPP prefix sum over the lanes' counts), so the filter / append phase below runs on dense lanes.
     const int lane = threadIdx.x & 63;
-    for (int q0 = 0; q0 < nitems; q0 += T) {                           // uniform trip count: the wave-wide scan needs every lane
-        const int q = q0 + threadIdx.x;
-        int mk = 0, c = 0, cy = 0, gi = 0;              // mk: bits 0-3 row cy, bits 4-7 row cy+1
-        uint32_t zc0 = 0, zc1 = 0;
-        if (q < nitems) {
-            int cy2;
-            split(q, c, cy2, gi);
-            cy = 2 * cy2;
-            const int wc = (c == 0) ? wcs[0] : (c == 1) ? wcs[1 % G] : (c == 2) ? wcs[2 % G] : wcs[3 % G];
-            if (4 * gi < wc) {
-                uint32_t m[4][3];                                      // score-map rows cy-1 .. cy+2 (the map has a zero border row)
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t* rp = reinterpret_cast<const uint32_t*>(&s_score[c][(cy + j) * SP + 4 * gi]);
-                    m[j][0] = rp[0]; m[j][1] = rp[1]; m[j][2] = rp[2];
-                }
-                uint32_t za, zb;
-                if (m[1][1] != 0) {                                    // else none of the four pixels of this row is a corner
-                    const int ma = nms_pair<0, 0, 4>(m, za), mb = nms_pair<1, 0, 4>(m, zb);
-                    mk = ma | (mb << 2);
-                    zc0 = m[1][1];
-                }
-                if (cy + 1 < hc && m[2][1] != 0) {
-                    const int ma = nms_pair<0, 1, 4>(m, za), mb = nms_pair<1, 1, 4>(m, zb);
-                    mk |= (ma | (mb << 2)) << 4;
-                    zc1 = m[2][1];
-                }
-            }
-        }
+    // append the strict maxima a lane found (bit k of mk = pixel k of its group, z of pixel k at bits [8 sh k, 8 sh k + 8) of zc) to the
+    // strip's LDS list: ONE returning LDS atomic per wave and call (DPP prefix sum over the lanes' counts).  Wave-uniform call sites only.
+    auto push_maxima = [&](int mk, uint32_t zc0, uint32_t zc1, int zshift, int c, int px0, int py0) __attribute__((always_inline)) {
         int incl = __popc(mk);
         const int cnt = incl;
         incl = wave_incl_scan_dpp(incl);
         const int total = __builtin_amdgcn_readlane(incl, 63);
-        if (total == 0) continue;                                      // wave-uniform
+        if (total == 0) return;                                        // wave-uniform
         int base = 0;
         if (lane == 63) base = atomicAdd(&s_nlist, total);
         base = __builtin_amdgcn_readlane(base, 63);
         if (mk) {
-            const int px = 4 * gi + 3 + (cj0 + c) * g.wCell, py = cy + 3 + ci * g.hCell;     // border-relative, of pixel 0 of the first row
             int dst = base + incl - cnt, zmax = 0, bits = mk;
             while (bits) {
                 const int k2 = __ffs(bits) - 1;
                 bits &= bits - 1;
-                const uint32_t z = (((k2 & 4) ? zc1 : zc0) >> (8 * (k2 & 3))) & 0xff;
-                if (dst < NLIST) { s_list[dst] = ((uint32_t)(py + (k2 >> 2)) << 20) | ((uint32_t)(px + (k2 & 3)) << 8) | z; s_listc[dst] = (uint8_t)c; }
+                const uint32_t z = (((k2 & 4) ? zc1 : zc0) >> (zshift * (k2 & 3))) & 0xff;
+                if (dst < NLIST) { s_list[dst] = ((uint32_t)(py0 + (k2 >> 2)) << 20) | ((uint32_t)(px0 + (k2 & 3)) << 8) | z; s_listc[dst] = (uint8_t)c; }
                 dst++;
                 zmax = max(zmax, (int)z);
             }
             if (zmax + zoff >= P.iniTh) s_ini[c] = 1;
         }
+    };
+
+    if (!dense) {
+        // ---- 1. compass pre-test, surviving pixel pairs -> s_pairs ----
+        for (int q0 = 0; q0 < nitems; q0 += T) {                       // uniform trip count: the wave-wide scan needs every lane
+            const int q = q0 + threadIdx.x;
+            int pm = 0, c = 0, cy = 0, cx = 0;                         // pm bit 2 r + k: pair k of row cy + r survives
+            if (q < nitems) {
+                int cy2, gi;
+                split(q, c, cy2, gi);
+                cx = 4 * gi; cy = 2 * cy2;
+                const int wc = wc_of(c);
+                if (cx < wc) {
+                    const int col = off + c * g.wCell + cx;            // tile byte of ROI column cx of cell c
+                    const uint32_t sh = (uint32_t)(col & 3);
+                    const uint8_t* base = &s_tile[cy * TP + (col & ~3)];
+                    uint32_t rc[2][3], ru[2][2], rd[2][2];             // centre rows (12 bytes), rows above / below the centres (8 bytes)
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        const uint32_t* pu = reinterpret_cast<const uint32_t*>(base + (r + 0) * TP);
+                        const uint32_t* pc = reinterpret_cast<const uint32_t*>(base + (r + 3) * TP);
+                        const uint32_t* pd = reinterpret_cast<const uint32_t*>(base + (r + 6) * TP);
+                        const uint32_t u0 = pu[0], u1 = pu[1], u2 = pu[2], c0 = pc[0], c1 = pc[1], c2 = pc[2], c3 = pc[3], d0 = pd[0], d1 = pd[1], d2 = pd[2];
+                        ru[r][0] = __builtin_amdgcn_alignbyte(u1, u0, sh); ru[r][1] = __builtin_amdgcn_alignbyte(u2, u1, sh);
+                        rc[r][0] = __builtin_amdgcn_alignbyte(c1, c0, sh); rc[r][1] = __builtin_amdgcn_alignbyte(c2, c1, sh);
+                        rc[r][2] = __builtin_amdgcn_alignbyte(c3, c2, sh);
+                        rd[r][0] = __builtin_amdgcn_alignbyte(d1, d0, sh); rd[r][1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                    }
+                    // pixel i of the group sits at window byte 3 + i: ring position 0 = (0, +3) in row + 6, 8 = (0, -3) in row + 0,
+                    // 4 = (+3, 0) and 12 = (-3, 0) in the centre row.  Pair 0 = bytes (3, 4), pair 1 = bytes (5, 6).
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        const uint32_t c0 = rc[r][0], c1 = rc[r][1], c2 = rc[r][2];
+                        const bool a = fast9_compass_pair(pick16<3>(c0, c1), pick16<3>(rd[r][0], rd[r][1]), pick16<2>(c1, c1), pick16<3>(ru[r][0], ru[r][1]),
+                                                          pick16<0>(c0, c0), thv);
+                        const bool bb = fast9_compass_pair(pick16<1>(c1, c1), pick16<1>(rd[r][1], rd[r][1]), pick16<0>(c2, c2), pick16<1>(ru[r][1], ru[r][1]),
+                                                           pick16<2>(c0, c0), thv);
+                        pm |= (a ? 1 : 0) << (2 * r);
+                        pm |= (bb ? 2 : 0) << (2 * r);
+                    }
+                    if (cx + 2 >= wc) pm &= 5;                         // second pair outside the cell interior
+                    if (cy + 1 >= hc) pm &= 3;                         // second row outside
+                }
+            }
+            int incl = __popc(pm);
+            const int cnt = incl;
+            incl = wave_incl_scan_dpp(incl);
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            if (total == 0) continue;                                  // wave-uniform
+            int base = 0;
+            if (lane == 63) base = atomicAdd(&s_npair, total);
+            base = __builtin_amdgcn_readlane(base, 63);
+            int dst = base + incl - cnt;
+#pragma unroll
+            for (int k2 = 0; k2 < 4; k2++)
+                if (pm & (1 << k2)) s_pairs[dst++] = (uint16_t)((c << 11) | ((cy + (k2 >> 1)) << 5) | ((cx >> 1) + (k2 & 1)));
+        }
+        __syncthreads();
+        const int np = min(s_npair, NPAIR);
+        // ---- 2. score of the listed pairs ----
+        for (int q = threadIdx.x; q < np; q += T) {
+            const uint32_t e = s_pairs[q];
+            const int c = (int)(e >> 11), row = (int)((e >> 5) & 63), cx = 2 * (int)(e & 31);
+            const int col = off + c * g.wCell + cx;
+            const uint32_t sh = (uint32_t)(col & 3);
+            uint32_t r[7][3];
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                const uint32_t* rp = reinterpret_cast<const uint32_t*>(&s_tile[(row + j) * TP + (col & ~3)]);
+                const uint32_t w0 = rp[0], w1 = rp[1], w2 = rp[2];
+                r[j][0] = __builtin_amdgcn_alignbyte(w1, w0, sh);
+                r[j][1] = __builtin_amdgcn_alignbyte(w2, w1, sh);
+                r[j][2] = 0u;
+            }
+            const s16x2 z = fast9_score_pair<0, 0, 7>(r, thv);
+            uint32_t u;
+            __builtin_memcpy(&u, &z, 4);
+            uint32_t zb = __builtin_amdgcn_perm(u, u, 0x0c0c0200u);      // the two z bytes
+            if (cx + 1 >= wc_of(c)) zb &= 0xffu;
+            if (zb) *reinterpret_cast<uint16_t*>(&s_score[c][(row + 1) * SP + 4 + cx]) = (uint16_t)zb;
+        }
+        __syncthreads();
+        // ---- 3. NMS of the listed pairs ----
+        for (int q0 = 0; q0 < np; q0 += T) {                           // uniform trip count
+            const int q = q0 + threadIdx.x;
+            int mk = 0, c = 0, row = 0, cx = 0;
+            uint32_t zc = 0;
+            if (q < np) {
+                const uint32_t e = s_pairs[q];
+                c = (int)(e >> 11); row = (int)((e >> 5) & 63); cx = 2 * (int)(e & 31);
+                if (*reinterpret_cast<const uint16_t*>(&s_score[c][(row + 1) * SP + 4 + cx]) != 0) {
+                    const uint32_t sh2 = (uint32_t)(cx & 2);
+                    uint32_t m[3][3];                                  // score-map rows row-1 .. row+1, the pair at bytes 4, 5
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        const uint32_t* rp = reinterpret_cast<const uint32_t*>(&s_score[c][(row + j) * SP + (cx & ~3)]);
+                        const uint32_t w0 = rp[0], w1 = rp[1], w2 = rp[2];
+                        m[j][0] = __builtin_amdgcn_alignbyte(w1, w0, sh2);
+                        m[j][1] = __builtin_amdgcn_alignbyte(w2, w1, sh2);
+                        m[j][2] = 0u;
+                    }
+                    uint32_t z16;
+                    mk = nms_pair<0, 0, 3>(m, z16);
+                    zc = z16;
+                }
+            }
+            push_maxima(mk, zc, 0u, 16, c, cx + 3 + (cj0 + c) * g.wCell, row + 3 + ci * g.hCell);
+        }
+    } else {
+        // ---- dense path: score every pixel ----
+        int ncorner = 0;
+        for (int q = threadIdx.x; q < nitems; q += T) {
+            int c, cy2, gi;
+            split(q, c, cy2, gi);
+            const int wc = wc_of(c);
+            const int cx = 4 * gi, cy = 2 * cy2;
+            if (cx >= wc) continue;
+            const int col = off + c * g.wCell + cx;                        // tile byte of ROI column cx of cell c
+            const uint32_t sh = (uint32_t)(col & 3);
+            uint32_t r[8][3];                                              // tile rows cy .. cy+7 (row cy+7 may lie below the ROI: staged as zeros / unused)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t* rp = reinterpret_cast<const uint32_t*>(&s_tile[(cy + j) * TP + (col & ~3)]);
+                const uint32_t w0 = rp[0], w1 = rp[1], w2 = rp[2], w3 = rp[3];
+                r[j][0] = __builtin_amdgcn_alignbyte(w1, w0, sh);
+                r[j][1] = __builtin_amdgcn_alignbyte(w2, w1, sh);
+                r[j][2] = __builtin_amdgcn_alignbyte(w3, w2, sh);
+            }
+            const uint32_t keepm = (wc - cx < 4) ? (1u << (8 * (wc - cx))) - 1u : 0xffffffffu;
+            {
+                const s16x2 za = fast9_score_pair<0, 0, 8>(r, thv), zb = fast9_score_pair<1, 0, 8>(r, thv);
+                uint32_t ua, ub;
+                __builtin_memcpy(&ua, &za, 4); __builtin_memcpy(&ub, &zb, 4);
+                const uint32_t z4 = __builtin_amdgcn_perm(ub, ua, 0x06040200u) & keepm;   // the four z bytes
+                *reinterpret_cast<uint32_t*>(&s_score[c][(cy + 1) * SP + 4 + cx]) = z4;
+                ncorner += ((z4 & 0xffffu) != 0) + ((z4 >> 16) != 0);
+            }
+            if (cy + 1 < hc) {
+                const s16x2 za = fast9_score_pair<0, 1, 8>(r, thv), zb = fast9_score_pair<1, 1, 8>(r, thv);
+                uint32_t ua, ub;
+                __builtin_memcpy(&ua, &za, 4); __builtin_memcpy(&ub, &zb, 4);
+                const uint32_t z4 = __builtin_amdgcn_perm(ub, ua, 0x06040200u) & keepm;
+                *reinterpret_cast<uint32_t*>(&s_score[c][(cy + 2) * SP + 4 + cx]) = z4;
+                ncorner += ((z4 & 0xffffu) != 0) + ((z4 >> 16) != 0);
+            }
+        }
+        ncorner = wave_reduce_sum(ncorner);
+        if (lane == 0 && ncorner) atomicAdd(&s_ncorner, ncorner);
+        __syncthreads();
+        // NMS: every 4-pixel x 2-row work item reports its strict maxima
+        for (int q0 = 0; q0 < nitems; q0 += T) {                           // uniform trip count: the wave-wide scan needs every lane
+            const int q = q0 + threadIdx.x;
+            int mk = 0, c = 0, cy = 0, gi = 0;              // mk: bits 0-3 row cy, bits 4-7 row cy+1
+            uint32_t zc0 = 0, zc1 = 0;
+            if (q < nitems) {
+                int cy2;
+                split(q, c, cy2, gi);
+                cy = 2 * cy2;
+                if (4 * gi < wc_of(c)) {
+                    uint32_t m[4][3];                                      // score-map rows cy-1 .. cy+2 (the map has a zero border row)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t* rp = reinterpret_cast<const uint32_t*>(&s_score[c][(cy + j) * SP + 4 * gi]);
+                        m[j][0] = rp[0]; m[j][1] = rp[1]; m[j][2] = rp[2];
+                    }
+                    uint32_t za, zb;
+                    if (m[1][1] != 0) {                                    // else none of the four pixels of this row is a corner
+                        const int ma = nms_pair<0, 0, 4>(m, za), mb = nms_pair<1, 0, 4>(m, zb);
+                        mk = ma | (mb << 2);
+                        zc0 = m[1][1];
+                    }
+                    if (cy + 1 < hc && m[2][1] != 0) {
+                        const int ma = nms_pair<0, 1, 4>(m, za), mb = nms_pair<1, 1, 4>(m, zb);
+                        mk |= (ma | (mb << 2)) << 4;
+                        zc1 = m[2][1];
+                    }
+                }
+            }
+            push_maxima(mk, zc0, zc1, 8, c, 4 * gi + 3 + (cj0 + c) * g.wCell, cy + 3 + ci * g.hCell);
+        }
     }
     __syncthreads();
+    if (threadIdx.x == 0) {             // what the next launch of this handle decides on
+        atomicAdd(&ctl.cur[level * 4], (uint32_t)(dense ? s_ncorner : min(s_npair, NPAIR)));
+        atomicAdd(&ctl.cur[level * 4 + 1], (uint32_t)pairs_total);
+        ctl.cur[level * 4 + 2] = dense ? 1u : 0u;
+    }
     // filter (:858-865: th 20 if the cell has any such corner, else th 7; mask :873-877) and append: one global atomic per wave
     const uint8_t* mimg = maskPyr ? maskPyr + (size_t)b * pyrStride + g.imgOff : nullptr;
     const int nl = min(s_nlist, NLIST);
@@ -1351,9 +1086,6 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
     const int NB = g.nIni << (2 * D);
     const int bsh = ROOT_SHIFT - 2 * D;
 
-#ifdef MYSLAM_OCT_TIMING
-    long long tk0 = (long long)__builtin_readcyclecounter(), tkA = 0, tkB = 0, tkC = 0; int nrounds = 0;
-#endif
     const uint32_t* xcode = octTab + g.tabOff; const uint32_t* ycode = xcode + g.tabX;
     const uint32_t* xcell = ycode + g.tabY; const uint32_t* ycell = xcell + g.tabX;
     // ---- A: path codes + bucket histogram (LDS atomics) ----
@@ -1392,9 +1124,6 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
         }
     }
     __syncthreads();
-#ifdef MYSLAM_OCT_TIMING
-    tkA = (long long)__builtin_readcyclecounter();
-#endif
     // ---- B: exclusive offsets, then scatter (order inside a bucket is irrelevant) ----
     {
         const int c = (NB + OT - 1) / OT;
@@ -1425,9 +1154,6 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
     }
     __syncthreads();
 
-#ifdef MYSLAM_OCT_TIMING
-    tkB = (long long)__builtin_readcyclecounter();
-#endif
     // ---- C: node list simulation ----
     // roots (:599-632): non-empty roots in index order
     if (t == 0) {
@@ -1445,9 +1171,6 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
     for (int round = 0; round < 96; round++) {
         const int m = s_i[0];
         const int prevSize = m;
-#ifdef MYSLAM_OCT_TIMING
-        nrounds++;
-#endif
         int newM;
         if (mode == 0) {
             // ---------- full round (:645-712): every node with >1 key is split ----------
@@ -1631,9 +1354,6 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
         }
     }
 
-#ifdef MYSLAM_OCT_TIMING
-    tkC = (long long)__builtin_readcyclecounter();
-#endif
     // ---- D: best key per node (:788-807), list order.  16 lanes per node.  Pass 1 finds the node's largest response;
     // pass 2 breaks ties by the reference's candidate order (cell-major, row-major inside a cell), so the cell tables
     // are only read for keys that carry that response. ----
@@ -1678,11 +1398,6 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
         }
     }
     if (t == 0) *myCount = min(m, g.nodeCap);
-#ifdef MYSLAM_OCT_TIMING
-    __syncthreads();
-    if (b == 0 && t == 0) printf("oct L%d n=%d m=%d rounds=%d  A=%lld B=%lld C=%lld D=%lld ticks\n", level, n, m, nrounds, tkA - tk0, tkB - tkA, tkC - tkB,
-                                 (long long)__builtin_readcyclecounter() - tkC);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1792,128 +1507,13 @@ __device__ __forceinline__ uint32_t wave_brief(const uint8_t* __restrict__ img, 
     return w;
 }
 
-// LDS patches of one keypoint (one wave): the 31x31 intensity-centroid patch of the level image and the
-// 37x37 window of the blurred level that the steered 31x31 BRIEF pattern can reach (|rotated coord| <= 18).
-// Both are fetched with aligned dword loads issued back to back (one HBM/L2 round trip per keypoint).
-constexpr int DA_ROWS = 31, DA_DW = 9, DA_P = DA_DW * 4;      // x-15.. : 3 (align) + 31 -> 9 dwords
+// LDS window of one keypoint (one wave): the 37x37 window of the blurred level that the steered 31x31 BRIEF pattern can reach
+// (|rotated coord| <= 18), fetched with aligned dword loads issued back to back.
 constexpr int DB_R = 18, DB_ROWS = 2 * DB_R + 1, DB_DW = 11, DB_P = DB_DW * 4;   // 3 + 37 -> 11 dwords
-constexpr int DA_N = DA_ROWS * DA_DW, DB_N = DB_ROWS * DB_DW;              // 279, 407 dwords
-constexpr int DA_IT = (DA_N + 63) / 64, DB_IT = (DB_N + 63) / 64;          // 5, 7 loads per lane
+constexpr int DB_N = DB_ROWS * DB_DW;                                           // 407 dwords
+constexpr int DB_IT = (DB_N + 63) / 64;                                         // 7 loads per lane
 
-__global__ __launch_bounds__(256) void k_describe(OrbPlan P, const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
-                                                  size_t pyrStride, const uint32_t* __restrict__ selOut,
-                                                  const int32_t* __restrict__ selCount, myslam_keypoint* __restrict__ kps,
-                                                  uint8_t* __restrict__ desc, int32_t* __restrict__ counts,
-                                                  int32_t* __restrict__ status, int cap, int detectOnly) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_a[4][DA_N];
-    __shared__ __attribute__((aligned(16))) uint32_t s_b[4][DB_N];
-    const int b = blockIdx.y;
-    const int wave = threadIdx.x >> 6;
-    const int slot = blockIdx.x * 4 + wave;
-    const int lane = threadIdx.x & 63;
-    int level = -1, local = 0, total = 0;
-    for (int l = 0; l < P.nlevels; l++) {
-        const int c = selCount[b * MAXL + l];
-        if (level < 0 && slot < total + c) { level = l; local = slot - total; }
-        total += c;
-    }
-    if (slot == 0 && lane == 0) {
-        counts[b] = min(total, cap);
-        if (total > cap && status) status[b] = MYSLAM_ERR_CAPACITY;
-    }
-    const bool active = (level >= 0 && slot < cap);
-    const LevelGeom& g = P.lv[active ? level : 0];
-    uint32_t pay = 0;
-    if (active) pay = selOut[(size_t)b * P.totalOut + g.outBase + local];
-    const int x = (int)((pay >> 8) & 0xfff) + MIN_BORDER, y = (int)(pay >> 20) + MIN_BORDER;    // :897-898
-    myslam_keypoint kp;
-    kp.response = (float)(pay & 0xff);
-    kp.class_id = -1;
-    if (detectOnly) {                         // ORBextractor::Detect: raw cv::FAST keypoints
-        kp.x = (float)x; kp.y = (float)y; kp.size = 7.f; kp.angle = -1.f; kp.octave = 0;
-        if (active && lane == 0) kps[(size_t)b * cap + slot] = kp;
-        return;
-    }
-    const uint8_t* img = pyr + (size_t)b * pyrStride + g.imgOff;
-    const uint8_t* bl = blur + (size_t)b * pyrStride + g.imgOff;
-    // --- fetch both patches (keypoints keep >= 19 px from every border, ORBextractor.cpp:25, so all rows exist) ---
-    const int xa0 = (x - HALF_PATCH) & ~3, offA = (x - HALF_PATCH) - xa0;
-    const int xb0 = (x - DB_R) & ~3, offB = (x - DB_R) - xb0;
-    uint32_t ra[DA_IT], rb[DB_IT];
-    if (active) {
-#pragma unroll
-        for (int k = 0; k < DA_IT; k++) {
-            const int i = lane + 64 * k;
-            const int r = i / DA_DW, c = i - r * DA_DW;
-            ra[k] = (i < DA_N) ? *reinterpret_cast<const uint32_t*>(img + (size_t)(y - HALF_PATCH + r) * g.pitch + xa0 + 4 * c) : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < DB_IT; k++) {
-            const int i = lane + 64 * k;
-            const int r = i / DB_DW, c = i - r * DB_DW;
-            rb[k] = (i < DB_N) ? *reinterpret_cast<const uint32_t*>(bl + (size_t)(y - DB_R + r) * g.pitch + xb0 + 4 * c) : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < DA_IT; k++) { const int i = lane + 64 * k; if (i < DA_N) s_a[wave][i] = ra[k]; }
-#pragma unroll
-        for (int k = 0; k < DB_IT; k++) { const int i = lane + 64 * k; if (i < DB_N) s_b[wave][i] = rb[k]; }
-    }
-    __syncthreads();
-    if (!active) return;
-    // --- IC_Angle (:27-55): lanes 2r / 2r+1 take the left (incl. centre) / right half of patch row r ---
-    const uint8_t* pa = reinterpret_cast<const uint8_t*>(s_a[wave]);
-    int m10 = 0, m01 = 0;
-    {
-        const int r = lane >> 1;
-        if (r < DA_ROWS) {
-            const int v = r - HALF_PATCH;
-            const int d = c_umax[v < 0 ? -v : v];
-            const uint8_t* row = pa + r * DA_P + offA + HALF_PATCH;        // &patch(row v, u = 0)
-            const int right = lane & 1;
-            int sI = 0;
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int u = right ? (j + 1) : -j;
-                const bool ok = right ? (j + 1 <= d) : (j <= d);
-                const int I = ok ? (int)row[u] : 0;
-                m10 += u * I; sI += I;
-            }
-            m01 = v * sI;
-        }
-    }
-    m10 = wave_reduce_sum(m10);
-    m01 = wave_reduce_sum(m01);
-    const float angle = fast_atan2_deg((float)m01, (float)m10);                                    // :54
-    // --- steered BRIEF (:58-98) from the blurred window ---
-    const float factorPI = (float)(3.14159265358979323846 / 180.f);
-    float ca, sb;
-    det_sincos(__fmul_rn(angle, factorPI), sb, ca);
-    const uint8_t* center = reinterpret_cast<const uint8_t*>(s_b[wave]) + DB_R * DB_P + offB + DB_R;
-    uint32_t nib = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int8_t* pp = &c_pattern[(lane * 4 + j) * 4];
-        const float x0 = (float)pp[0], y0 = (float)pp[1], x1 = (float)pp[2], y1 = (float)pp[3];
-        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, sb), __fmul_rn(y0, ca)));
-        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sb)));
-        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sb), __fmul_rn(y1, ca)));
-        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sb)));
-        const int t0 = center[r0 * DB_P + c0], t1 = center[r1 * DB_P + c1];
-        nib |= (uint32_t)(t0 < t1) << j;
-    }
-    const uint32_t byte = nib | (__shfl_down(nib, 1, 64) << 4);            // valid on even lanes
-    uint32_t w = byte | (__shfl_down(byte, 2, 64) << 8);
-    w |= (__shfl_down(byte, 4, 64) << 16) | (__shfl_down(byte, 6, 64) << 24);   // valid on lanes % 8 == 0
-    if ((lane & 7) == 0) reinterpret_cast<uint32_t*>(desc + ((size_t)b * cap + slot) * 32)[lane >> 3] = w;
-    if (lane == 0) {
-        kp.x = (level != 0) ? __fmul_rn((float)x, g.scale) : (float)x;                            // :975-981
-        kp.y = (level != 0) ? __fmul_rn((float)y, g.scale) : (float)y;
-        kp.size = g.scaledPatch; kp.angle = angle; kp.octave = level;
-        kps[(size_t)b * cap + slot] = kp;
-    }
-}
-
-// K5b: the same operator, phased per block of 64 keypoints so that nothing scalar runs 64-wide:
+// K5: orientation + steered BRIEF, phased per block of 64 keypoints so that nothing scalar runs 64-wide:
 //   0  thread per keypoint: slot -> (level, x, y, response)
 //   A  16 keypoints / wave: intensity-centroid moments on the int8 matrix cores: [key-points x 64 k] x [64 k x {u, v weights}], the
 //                           patch as it lies in memory is the A operand (p - 128; the masked weights sum to zero), 16 MFMAs
@@ -1934,7 +1534,7 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
                                                    size_t pyrStride, const uint32_t* __restrict__ selOut,
                                                    const int32_t* __restrict__ selCount, myslam_keypoint* __restrict__ kps,
                                                    uint8_t* __restrict__ desc, int32_t* __restrict__ counts,
-                                                   int32_t* __restrict__ status, int cap, int nchunk, int batch) {
+                                                   int32_t* __restrict__ status, int cap, int nchunk, int batch, int detectOnly) {
     __shared__ __attribute__((aligned(16))) uint32_t s_b[4][DB_N];
     __shared__ int s_x[KD_KPB], s_y[KD_KPB], s_lv[KD_KPB], s_m10[KD_KPB], s_m01[KD_KPB];
     __shared__ float s_ca[KD_KPB], s_sb[KD_KPB];
@@ -1987,7 +1587,13 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
             s_pbase[t] = active ? (uint32_t)(gl.imgOff + (size_t)(s_y[t] - HALF_PATCH) * gl.pitch + (s_x[t] - HALF_PATCH)) : 0u;
         }
         resp = (float)(pay & 0xff);
+        if (detectOnly && active) {                // ORBextractor::Detect (:1067-1073): raw cv::FAST keypoints of level 0, no angle / descriptor
+            myslam_keypoint kp;
+            kp.x = (float)s_x[t]; kp.y = (float)s_y[t]; kp.size = 7.f; kp.angle = -1.f; kp.response = resp; kp.octave = 0; kp.class_id = -1;
+            kps[(size_t)b * cap + slot] = kp;
+        }
     }
+    if (detectOnly) return;                        // block-uniform
     __syncthreads();
     // lane-constant window coordinates of the dwords this lane fetches in phase C
     int rb_[DB_IT], cb_[DB_IT];
@@ -2202,8 +1808,8 @@ void launch_ingest(const uint8_t* src, int rows, int cols, int step, size_t sstr
 // launch helpers (called from orb_engine.hip)
 // ------------------------------------------------------------------------------------------------
 void launch_resize(const ResizeArgs& a, int batch, hipStream_t s) {
-    static const char* env = getenv("MYSLAM_RESIZE_V");           // tuning aid: 1 = one row per wave kernel
-    if (!(env && atoi(env) == 1) && (double)RS_R * a.scale_y + 2.0 <= (double)RS_MAXR && a.scale_x <= 1.6) {
+    // register strips cover pyramid scale factors up to 1.25 (rows) / 1.6 (columns); larger steps take the generic kernel
+    if ((double)RS_R * a.scale_y + 2.0 <= (double)RS_MAXR && a.scale_x <= 1.6) {
         const int nstrips = (a.dw + 255) / 256, nbands = (a.dh + RS_R - 1) / RS_R;
         hipLaunchKernelGGL(k_resize_strip, dim3((nstrips * nbands + 3) / 4, 1, batch), dim3(256), 0, s, a, nstrips, nbands);
         return;
@@ -2212,251 +1818,25 @@ void launch_resize(const ResizeArgs& a, int batch, hipStream_t s) {
     hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, a);
 }
 
-// ------------------------------------------------------------------------------------------------
-// 7x7 Gaussian on the int8 matrix cores.  The blur is exact integer arithmetic — out = (sum_r q_r (sum_c q_c p) + 32768) >> 16 —
-// i.e. two banded (Toeplitz) matrix products, Th over the columns and Tv over the rows, with REFLECT_101 folded into the bands.
-// One wave walks a 32-column strip downwards in 32 x 32 tiles:
-//   1. H = P x Th^T     A = the image tile as it lies in memory (lane = row, 16 consecutive pixels per lane and k block, p - 128
-//                        as int8), B = Th for this strip (table), K = the 64 columns around the strip: 2 MFMAs.  The result leaves
-//                        every lane with ONE column and 16 rows of H — exactly the shape of a B operand whose k slots are rows —
-//   2. V = Tv x H        so the vertical pass needs no data movement: H (16-bit) is split into its high and low byte planes, each is
-//                        multiplied by the Tv blocks of the tile above, this tile and the tile below (table): 6 MFMAs,
-//                        out = (256 S_hi + S_lo + const) >> 16.
-//   3. transpose         the result is again one column per lane, the worst shape for a row-major store; one more MFMA against a
-//                        0/1 selection matrix with the operand roles swapped returns it with one ROW per lane, 4 consecutive pixels
-//                        per register group: dword stores.
-// 9 MFMAs (288 cycles) and ~160 VALU instructions per 1024 pixels against ~420 VALU instructions in k_blur7_strip; all coefficient
-// logic (bands, mirrored borders, partial tiles) lives in host-built operand tables, the kernel has no special cases.
-// STATUS: bit-exact, but NOT the default (MYSLAM_BLUR_V=4 selects it): with the band staged through LDS it merely EQUALS the strip
-// kernel (0.92 ms per 512 pairs; 1.2 ms with per-wave 32-byte row accesses): the waves spend 58 % of their cycles waiting — two
-// barriers per tile row and a serial MFMA -> pack -> MFMA -> pack -> MFMA chain inside every wave — so the saved VALU work (160
-// against 420 instructions per 1024 pixels) does not show up as time yet.
-typedef int bl_v4i __attribute__((ext_vector_type(4)));
-typedef int bl_v16i __attribute__((ext_vector_type(16)));
-
-__device__ __forceinline__ uint32_t bl_pack_byte(int r0, int r1, int r2, int r3, int which) {     // byte `which` (0..2) of four registers
-    const uint32_t s2 = 0x0c0c0400u + 0x0101u * (uint32_t)which;          // (b.byte, a.byte) -> bytes 0, 1
-    const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)r1, (uint32_t)r0, s2), t23 = __builtin_amdgcn_perm((uint32_t)r3, (uint32_t)r2, s2);
-    return __builtin_amdgcn_perm(t23, t01, 0x05040100u);
-}
-
-constexpr int BLM_INP = 176;          // LDS pitch of a staged input row: 160 window bytes + 16 (bank spread)
-constexpr int BLM_OUTP = 144;         // LDS pitch of an output row: 128 + 16
-
-// Block = 4 waves = a band of four adjacent 32-column strips walked downwards together: the 32 x 160-byte window of a tile row is
-// fetched once by the whole block with full-width coalesced loads into LDS (double buffered, requested one tile row ahead), the waves
-// read their A operands from there, and the finished 32 x 128 tile row goes back through LDS so that rows are stored 128 bytes wide.
-__global__ __launch_bounds__(256) void k_blur7_mfma(BlurArgs a, int nstrip, int ntile) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[2][32 * BLM_INP];
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[32 * BLM_OUTP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wid = blockIdx.x * 4 + wave;                     // strip of this wave
-    const bool live = wid < nstrip;
-    const int b = blockIdx.z;
-    const int bx0 = 128 * blockIdx.x, bws = min(max(bx0 - 16, 0), a.spitch - 160);
-    const int x0 = 32 * wid, ws = min(max(x0 - 16, 0), a.spitch - 64);
-    const int woff = live ? ws - bws : 0;                      // this strip's 64-column window inside the band window (0..96)
-    const uint8_t* src = a.src + (size_t)b * a.sstride;
-    uint8_t* dst = a.dst + (size_t)b * a.dstride;
-    const int li = lane & 31, lh = lane >> 5;
-    const int sidx = live ? wid : 0;
-    const bl_v4i TH0 = __builtin_bit_cast(bl_v4i, a.tabH[(size_t)(sidx * 2 + 0) * 64 + lane]);
-    const bl_v4i TH1 = __builtin_bit_cast(bl_v4i, a.tabH[(size_t)(sidx * 2 + 1) * 64 + lane]);
-    const bl_v4i ID = __builtin_bit_cast(bl_v4i, a.ident[lane]);
-    const bl_v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const bl_v4i zero4 = {0, 0, 0, 0};
-    // staging roles: 32 rows x 10 uint4 = 320 pieces; thread tid takes piece tid and (tid < 64) piece 256 + tid
-    const int r1 = tid / 10, c1 = tid - 10 * r1, r2 = (256 + tid) / 10, c2 = (256 + tid) - 10 * r2;
-    uint4 g1 = make_uint4(0, 0, 0, 0), g2 = g1;
-    auto stage_load = [&](int ty) {
-        g1 = *reinterpret_cast<const uint4*>(src + (size_t)min(32 * ty + r1, a.h - 1) * a.spitch + bws + 16 * c1);
-        if (tid < 64) g2 = *reinterpret_cast<const uint4*>(src + (size_t)min(32 * ty + r2, a.h - 1) * a.spitch + bws + 16 * c2);
-    };
-    auto stage_store = [&](int buf) {
-        *reinterpret_cast<uint4*>(&s_in[buf][r1 * BLM_INP + 16 * c1]) = g1;
-        if (tid < 64) *reinterpret_cast<uint4*>(&s_in[buf][r2 * BLM_INP + 16 * c2]) = g2;
-    };
-    // H tile from the staged window as the two int8 planes (hi = H >> 8, lo = (H & 255) - 128)
-    auto htile = [&](int buf, bl_v4i& hi, bl_v4i& lo) {
-        const uint8_t* row = &s_in[buf][li * BLM_INP + woff + 16 * lh];
-        uint4 p0 = *reinterpret_cast<const uint4*>(row), p1 = *reinterpret_cast<const uint4*>(row + 32);
-        p0.x ^= 0x80808080u; p0.y ^= 0x80808080u; p0.z ^= 0x80808080u; p0.w ^= 0x80808080u;
-        p1.x ^= 0x80808080u; p1.y ^= 0x80808080u; p1.z ^= 0x80808080u; p1.w ^= 0x80808080u;
-        bl_v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(bl_v4i, p0), TH0, zero16, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(bl_v4i, p1), TH1, acc, 0, 0, 0);
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            lo[w] = (int)(bl_pack_byte(acc[4 * w], acc[4 * w + 1], acc[4 * w + 2], acc[4 * w + 3], 0) ^ 0x80808080u);
-            hi[w] = (int)bl_pack_byte(acc[4 * w], acc[4 * w + 1], acc[4 * w + 2], acc[4 * w + 3], 1);
-        }
-    };
-    bl_v4i Hh[3], Hl[3];                                       // tiles ty-1, ty, ty+1
-    Hh[0] = zero4; Hl[0] = zero4;
-    stage_load(0);
-    stage_store(0);
-    if (ntile > 1) stage_load(1);
-    __syncthreads();
-    htile(0, Hh[1], Hl[1]);
-    if (ntile > 1) stage_store(1);
-    // Tv blocks: the interior tiles share one set (registers); the first tile and the last two read theirs from the table
-    int tlast = ntile;
-    while (tlast > 1 && 32 * (tlast - 1) + 34 >= a.h) tlast--;
-    uint4 iv0 = make_uint4(0, 0, 0, 0), iv1 = iv0, iv2 = iv0;
-    if (tlast > 1) { iv0 = a.tabV[(size_t)(3 + 0) * 64 + lane]; iv1 = a.tabV[(size_t)(3 + 1) * 64 + lane]; iv2 = a.tabV[(size_t)(3 + 2) * 64 + lane]; }
-    for (int ty = 0; ty < ntile; ty++) {
-        uint4 t0 = iv0, t1 = iv1, t2 = iv2;
-        if (!(ty >= 1 && ty < tlast)) {
-            t0 = a.tabV[(size_t)(ty * 3 + 0) * 64 + lane]; t1 = a.tabV[(size_t)(ty * 3 + 1) * 64 + lane]; t2 = a.tabV[(size_t)(ty * 3 + 2) * 64 + lane];
-        }
-        if (ty + 2 < ntile) stage_load(ty + 2);               // lands in s_in[ty & 1] at the end of this step
-        __syncthreads();                                       // s_in[(ty + 1) & 1] complete; s_out free again
-        if (ty + 1 < ntile) htile((ty + 1) & 1, Hh[2], Hl[2]); else { Hh[2] = zero4; Hl[2] = zero4; }
-        bl_v16i sh = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(bl_v4i, t0), Hh[0], zero16, 0, 0, 0);
-        bl_v16i sl = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(bl_v4i, t0), Hl[0], zero16, 0, 0, 0);
-        sh = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(bl_v4i, t1), Hh[1], sh, 0, 0, 0);
-        sl = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(bl_v4i, t1), Hl[1], sl, 0, 0, 0);
-        sh = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(bl_v4i, t2), Hh[2], sh, 0, 0, 0);
-        sl = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(bl_v4i, t2), Hl[2], sl, 0, 0, 0);
-        // out = (256 S_hi + S_lo + 32768 + 256 (128 + 32768)) >> 16 = byte 2 of the sum; out - 128 as the transpose's A operand
-        bl_v4i A3;
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            int v[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = (sh[4 * w + k] << 8) + sl[4 * w + k] + 8454144;
-            A3[w] = (int)(bl_pack_byte(v[0], v[1], v[2], v[3], 2) ^ 0x80808080u);
-        }
-        const bl_v16i T = __builtin_amdgcn_mfma_i32_32x32x32_i8(A3, ID, zero16, 0, 0, 0);      // lane (row li, half lh): x = (r&3) + 8(r>>2) + 4 lh
-        // lane (row li, half lh) holds the 4-pixel groups g at x = 8 g + 4 lh of its strip: into the output row in LDS
-#pragma unroll
-        for (int g = 0; g < 4; g++)
-            *reinterpret_cast<uint32_t*>(&s_out[li * BLM_OUTP + 32 * wave + 8 * g + 4 * lh]) =
-                bl_pack_byte(T[4 * g], T[4 * g + 1], T[4 * g + 2], T[4 * g + 3], 0) ^ 0x80808080u;
-        if (ty + 2 < ntile) stage_store(ty & 1);               // s_in[ty & 1] was read in the previous step (htile of tile ty)
-        __syncthreads();                                       // s_out complete
-        {   // 32 rows x 128 bytes, 8 threads per row
-            const int r = tid >> 3, c = tid & 7, y = 32 * ty + r;
-            if (y < a.h && bx0 + 16 * c + 16 <= a.dpitch)
-                *reinterpret_cast<uint4*>(dst + (size_t)y * a.dpitch + bx0 + 16 * c) = *reinterpret_cast<const uint4*>(&s_out[r * BLM_OUTP + 16 * c]);
-        }
-        Hh[0] = Hh[1]; Hl[0] = Hl[1]; Hh[1] = Hh[2]; Hl[1] = Hl[2];
-    }
-}
-
-// ---- host: operand tables of k_blur7_mfma ----
-static int bl_reflect101(int p, int len) {
-    if (len == 1) return 0;
-    while (p < 0 || p >= len) p = (p < 0) ? -p : 2 * len - 2 - p;
-    return p;
-}
-static int bl_coef(const int q[7], int out, int in, int len) {          // weight of input position `in` in output position `out`
-    if (out < 0 || out >= len || in < 0 || in >= len) return 0;
-    int c = 0;
-    for (int t = 0; t < 7; t++) if (bl_reflect101(out + t - 3, len) == in) c += q[t];
-    return c;
-}
-static inline int bl_slot_row(int b, int half) { return (b & 3) + 8 * (b >> 2) + 4 * half; }
-static uint4 bl_pack16(const int c[16]) {
-    uint32_t w[4] = {0, 0, 0, 0};
-    for (int i = 0; i < 16; i++) w[i >> 2] |= (uint32_t)(c[i] & 0xff) << (8 * (i & 3));
-    return make_uint4(w[0], w[1], w[2], w[3]);
-}
-bool blur_mfma_tables(int w, int h, int spitch, const int q[7], std::vector<uint4>& tab, size_t& offH, size_t& offV) {
-    if (w < 8 || h < 8 || spitch < 64 || (spitch & 15)) return false;
-    for (int t = 0; t < 7; t++) if (q[t] < 0 || q[t] > 127) return false;
-    const int nstrip = (w + 31) / 32, ntile = (h + 31) / 32;
-    offH = tab.size();
-    for (int s = 0; s < nstrip; s++) {
-        const int x0 = 32 * s, ws = std::min(std::max(x0 - 16, 0), spitch - 64);
-        for (int kb = 0; kb < 2; kb++)
-            for (int l = 0; l < 64; l++) {
-                int c[16];
-                for (int bb = 0; bb < 16; bb++) {
-                    c[bb] = bl_coef(q, x0 + (l & 31), ws + 32 * kb + 16 * (l >> 5) + bb, w);
-                    if (c[bb] > 127) return false;
-                }
-                tab.push_back(bl_pack16(c));
-            }
-        // every input column an output column of this strip needs must lie inside the 64-column window
-        for (int j = 0; j < 32 && x0 + j < w; j++)
-            for (int t = 0; t < 7; t++) { const int in = bl_reflect101(x0 + j + t - 3, w); if (in < ws || in >= ws + 64) return false; }
-    }
-    offV = tab.size();
-    for (int ty = 0; ty < ntile; ty++)
-        for (int o = 0; o < 3; o++)
-            for (int l = 0; l < 64; l++) {
-                int c[16];
-                for (int bb = 0; bb < 16; bb++) {
-                    c[bb] = bl_coef(q, 32 * ty + (l & 31), 32 * (ty + o - 1) + bl_slot_row(bb, l >> 5), h);
-                    if (c[bb] > 127) return false;
-                }
-                tab.push_back(bl_pack16(c));
-            }
-    return true;
-}
-void blur_mfma_ident(std::vector<uint4>& tab, size_t& offI) {
-    offI = tab.size();
-    for (int l = 0; l < 64; l++) {
-        int c[16];
-        for (int bb = 0; bb < 16; bb++) c[bb] = bl_slot_row(bb, l >> 5) == (l & 31) ? 1 : 0;
-        tab.push_back(bl_pack16(c));
-    }
-}
-
 void launch_blur(const BlurArgs& a, int batch, hipStream_t s) {
-    bool small = true;
-    for (int j = 0; j < 7; j++) small = small && a.q[j] >= 0 && a.q[j] <= 255;
-    static const char* env = getenv("MYSLAM_BLUR_V");             // tuning aid: 1 = multiply-add kernel, 2 = LDS dot kernel, 3 = register strips
-    if (a.tabH && a.tabV && a.ident && env && atoi(env) == 4 && (a.spitch & 15) == 0 && (a.dpitch & 15) == 0 &&
-        ((reinterpret_cast<uintptr_t>(a.src) | a.sstride) & 15) == 0 && ((reinterpret_cast<uintptr_t>(a.dst) | a.dstride) & 15) == 0) {
-        const int nstrip = (a.w + 31) / 32, ntile = (a.h + 31) / 32;
-        if (a.spitch >= 160) {
-            hipLaunchKernelGGL(k_blur7_mfma, dim3((nstrip + 3) / 4, 1, batch), dim3(256), 0, s, a, nstrip, ntile);
-            return;
-        }
-    }
-    const int v = (env && atoi(env) != 4) ? atoi(env) : 3;
-    if (small && v == 3 && a.w >= 8 && a.h >= 8 && (a.spitch & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.src) | a.sstride) & 3) == 0) {
+    // register strips need dword-aligned rows and at least 8 x 8 pixels; everything else goes through the LDS-tiled kernel
+    if (a.w >= 8 && a.h >= 8 && (a.spitch & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.src) | a.sstride) & 3) == 0) {
         const int nstrips = (a.w + 255) / 256, nbands = (a.h + B3_R - 1) / B3_R;
         hipLaunchKernelGGL(k_blur7_strip, dim3((nstrips * nbands + 3) / 4, 1, batch), dim3(256), 0, s, a, nstrips, nbands);
         return;
     }
-    if (small && v != 1) {
-        dim3 grid((a.w + B2_W - 1) / B2_W, (a.h + B2_H - 1) / B2_H, batch);
-        hipLaunchKernelGGL(k_blur7_dot, grid, dim3(256), 0, s, a);
-        return;
-    }
-    dim3 grid((a.w + BT_W - 1) / BT_W, (a.h + BT_H - 1) / BT_H, batch);
-    hipLaunchKernelGGL(k_blur7, grid, dim3(256), 0, s, a);
+    dim3 grid((a.w + B2_W - 1) / B2_W, (a.h + B2_H - 1) / B2_H, batch);
+    hipLaunchKernelGGL(k_blur7_dot, grid, dim3(256), 0, s, a);
 }
 
 void launch_fast(const OrbPlan& P, const uint8_t* pyr, size_t pyrStride, const uint8_t* maskPyr, uint32_t* cand,
-                 int32_t* candCount, int batch, hipStream_t s) {
+                 int32_t* candCount, const uint32_t* statPrev, uint32_t* statCur, int forceMode, int batch, hipStream_t s) {
     int cw = 0;
     for (int l = 0; l < P.nlevels; l++) cw = max(cw, max(P.lv[l].wCell, P.lv[l].hCell));
-    static const char* env = getenv("MYSLAM_FAST_T");           // tuning aid: threads per cell (64 | 256)
-    const int T = env ? atoi(env) : 256;
-    static const char* envv = getenv("MYSLAM_FAST_V");          // tuning aid: 2 = LDS byte-read two-phase kernel, 3 = register tiles
-    const int V = envv ? atoi(envv) : 4;
-    if (V == 4) {      // strips of 4 cells per block
-        static const char* envl = getenv("MYSLAM_FAST_LDS_PAD");      // tuning aid: extra dynamic LDS bytes (caps resident blocks per CU)
-        const size_t pad = envl ? (size_t)atoi(envl) : 0;
-        if (cw <= 40) hipLaunchKernelGGL((k_fast_strip<40, 4>), dim3(P.nstrips, batch), dim3(256), pad, s, P, pyr, pyrStride, maskPyr, cand, candCount);
-        else hipLaunchKernelGGL((k_fast_strip<MAX_CELL, 4>), dim3(P.nstrips, batch), dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount);
-        return;
-    }
-    if (V == 3) {
-        if (cw <= 40) hipLaunchKernelGGL((k_fast_cells_v3<256, 40>), dim3(P.ncells, batch), dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount);
-        else hipLaunchKernelGGL((k_fast_cells_v3<256, MAX_CELL>), dim3(P.ncells, batch), dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount);
-        return;
-    }
-    if (cw <= 40) {
-        if (T == 64) hipLaunchKernelGGL((k_fast_cells<64, 40>), dim3(P.ncells, batch), dim3(64), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount);
-        else hipLaunchKernelGGL((k_fast_cells<256, 40>), dim3(P.ncells, batch), dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount);
-    } else {
-        if (T == 64) hipLaunchKernelGGL((k_fast_cells<64, MAX_CELL>), dim3(P.ncells, batch), dim3(64), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount);
-        else hipLaunchKernelGGL((k_fast_cells<256, MAX_CELL>), dim3(P.ncells, batch), dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount);
-    }
+    const FastCtl ctl{statPrev, statCur, forceMode};
+    const dim3 grid((unsigned)P.nstrips * (unsigned)batch);
+    if (cw <= 40) hipLaunchKernelGGL((k_fast_strip<40, 4>), grid, dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount, ctl, batch);
+    else hipLaunchKernelGGL((k_fast_strip<MAX_CELL, 4>), grid, dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount, ctl, batch);
 }
 
 size_t octree_lds_bytes(int nodeCap) { return 192 + 4 * (size_t)OT_MAXB + 4 * (size_t)(OT_MAXB + 2) + (size_t)nodeCap * 54 + 16; }
@@ -2476,15 +1856,9 @@ void launch_describe(const OrbPlan& P, const uint8_t* pyr, const uint8_t* blur, 
                      const int32_t* selCount, myslam_keypoint* kps, uint8_t* desc, int32_t* counts, int32_t* status,
                      int cap, int detectOnly, int batch, hipStream_t s) {
     const int slots = min(cap, P.totalOut);
-    static const char* env = getenv("MYSLAM_DESC_V");             // tuning aid: 1 = one wave per keypoint end to end
-    if (!detectOnly && !(env && atoi(env) == 1)) {
-        const int nchunk = (slots + KD_KPB - 1) / KD_KPB;
-        hipLaunchKernelGGL(k_describe2, dim3(nchunk * batch), dim3(256), 0, s, P, pyr, blur, pyrStride, selOut, selCount,
-                           kps, desc, counts, status, cap, nchunk, batch);
-        return;
-    }
-    hipLaunchKernelGGL(k_describe, dim3((slots + 3) / 4, batch), dim3(256), 0, s, P, pyr, blur, pyrStride, selOut, selCount,
-                       kps, desc, counts, status, cap, detectOnly);
+    const int nchunk = (slots + KD_KPB - 1) / KD_KPB;
+    hipLaunchKernelGGL(k_describe2, dim3(nchunk * batch), dim3(256), 0, s, P, pyr, blur, pyrStride, selOut, selCount,
+                       kps, desc, counts, status, cap, nchunk, batch, detectOnly);
 }
 
 void launch_screen(const OrbPlan& P, const uint8_t* pyr, myslam_keypoint* kin, int n, myslam_keypoint* kout, uint8_t* keep,

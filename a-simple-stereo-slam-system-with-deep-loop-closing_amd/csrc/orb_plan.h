@@ -1,7 +1,6 @@
 // orb_plan.h — geometry of one ORB extraction configuration (image size x extractor params).
 // Host computes it once per (rows, cols); kernels receive it by value.
 #pragma once
-#include <vector>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -58,12 +57,6 @@ struct ResizeArgs {
 struct BlurArgs {
     const uint8_t* src; uint8_t* dst; int w, h, spitch, dpitch; size_t sstride, dstride;
     int q[7];                                    // Q8 taps, sum 256
-    // optional operand tables of the matrix-core kernel (k_blur7_mfma; built by blur_mfma_tables for this w, h, spitch, q):
-    // tabH[strip][k block 2][lane 64], tabV[tile][neighbour 3][lane 64], ident[lane 64]; null -> the VALU kernels
-    const uint4* tabH = nullptr; const uint4* tabV = nullptr; const uint4* ident = nullptr;
 };
-// host side: appends the tables to `tab` (uint4 units) and returns false when the geometry / taps cannot use the matrix-core kernel
-bool blur_mfma_tables(int w, int h, int spitch, const int q[7], std::vector<uint4>& tab, size_t& offH, size_t& offV);
-void blur_mfma_ident(std::vector<uint4>& tab, size_t& offI);
 
 }  // namespace myslam_hip

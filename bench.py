@@ -107,6 +107,10 @@ def parse():
                          "-1 (default) = 1 with --streams 2, else 0")
     ap.add_argument("--verify", action="store_true",
                     help="after the timed region: run one joined, un-gated step and check that it reproduces the pipeline's last outputs bit for bit")
+    ap.add_argument("--orb-internal-stream", type=int, default=2, choices=[0, 1, 2],
+                    help="myslam_orb_set_option(INTERNAL_STREAM): 2 = Gaussian pyramid on the extractor's internal stream (default), 0 = one stream")
+    ap.add_argument("--fast-mode", type=int, default=-1, choices=[-1, 0, 1],
+                    help="myslam_orb_set_option(FAST_MODE): -1 = the FAST kernel picks its path per level (default), 0 = two-phase, 1 = dense")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = debugging aid: several ranks share GPU 0 and the collectives go through host memory")
     args = ap.parse_args()
@@ -225,6 +229,9 @@ def main():
     assert (2 * P) % S == 0
     orb_streams = [torch.cuda.Stream() for _ in range(S - 1)]
     orb_exts = [api.ORBextractor(2000, stream=st.cuda_stream) for st in orb_streams]
+    for e in [ext] + orb_exts:
+        e.set_option(e.OPT_INTERNAL_STREAM, args.orb_internal_stream)
+        e.set_option(e.OPT_FAST_MODE, args.fast_mode)
     NB = 2 if args.pipeline else 1          # pipeline: extractor outputs are double-buffered (step k+1 extracts while step k is matched)
     d_kps_b = [torch.zeros(2 * P * cap * 28, dtype=torch.uint8, device=dev) for _ in range(NB)]
     d_desc_b = [torch.zeros(2 * P * cap * 32, dtype=torch.uint8, device=dev) for _ in range(NB)]
@@ -500,7 +507,7 @@ def main():
                   "achieved": f32eq, "frac": f32eq / 157.3, "bf16_tflops": 6 * f32eq, "bf16_frac_of_2500": 6 * f32eq / 2500.0, "avg_launch_ms": c2,
                   "note": "CALC conv2 as an implicit GEMM on the bf16 matrix cores with f32 accuracy (3-way exact operand split, 6 partial products "
                           "per useful f32 flop): `achieved` counts USEFUL f32 flops; bf16_tflops counts the partial products"}
-        n_internal = S            # every extractor handle runs its Gaussian pyramid on an internal stream (orb_engine.hip run_batch)
+        n_internal = S if args.orb_internal_stream else 0        # every extractor handle runs its Gaussian pyramid on an internal stream
         out = {
             "metric": "stereo frames/sec (ORB+match+LCD+BA-build) @1241x376",
             "value": value, "unit": "stereo frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -78,6 +78,18 @@ int myslam_orb_set_fast_event(myslam_orb* h, void* hip_event);
  * (a hipEvent_t, NULL = off) as it was last recorded when the call is made; the pyramid stages before FAST are not held back.
  * Two handles that gate each other with their fast events take turns on the VALU-bound stage. */
 int myslam_orb_set_fast_gate(myslam_orb* h, void* hip_event);
+/* scheduling / debugging knobs of a handle (no reference counterpart; none of them changes a result):
+ *   FAST_MODE        -1 (default) = the grid-FAST kernel picks its path per pyramid level from what the handle's previous launch measured:
+ *                    a compass pre-test + compaction of the surviving pixel pairs (imagery with a few % of corners: a tenth of the pixels
+ *                    is scored) or full scoring of every pixel (noise-like texture where most pairs survive the pre-test);
+ *                    0 / 1 force the two-phase / the dense path
+ *   INTERNAL_STREAM  2 (default) = the Gaussian pyramid runs on an internal stream right after the image pyramid, 1 = forked after FAST,
+ *                    0 = everything on the handle's stream
+ *   STOP_AFTER       debug: a batched call returns after stage 1 ingest / 2 pyramid / 3 oct-tree / 4 blur (0 = complete call) */
+#define MYSLAM_ORB_OPT_FAST_MODE 1
+#define MYSLAM_ORB_OPT_INTERNAL_STREAM 2
+#define MYSLAM_ORB_OPT_STOP_AFTER 3
+int myslam_orb_set_option(myslam_orb* h, int option, int value);
 /* getters ORBextractor.h:87-107 */
 int myslam_orb_get_tables(const myslam_orb* h, float* scale, float* inv_scale, int* features_per_level, int* umax16);
 /* upper bound of keypoints DetectAndCompute / Detect can return for one image: sum over levels of
@@ -158,12 +170,45 @@ int myslam_triangulate_stereo_batch(const myslam_keypoint* d_kps_l, const myslam
 
 /* ------------------------------------------------------------------------------------------
  * DeepLCD — replaces class DeepLCD (include/myslam/deeplcd.h:21-48, src/deeplcd.cpp:10-91)
- * weights: flat f32 blob conv1.w[64][1][5][5] conv1.b[64] conv2.w[128][64][4][4] conv2.b[128]
- *          conv3.w[4][128][3][3] conv3.b[4]  (137476 floats; the Caffe model is not redistributable)
+ *
+ * The model is DATA: a list of layer records (what calc_model/deploy.prototxt says) + the convolution weights (what
+ * calc_model/calc.caffemodel holds).  Three sources:
+ *   myslam_lcd_create_from_caffe  the reference's two files, read by a dependency-free parser (host/myslam_caffe.hpp)
+ *   myslam_lcd_create_from_layers records + flat weights from the caller
+ *   myslam_lcd_create / _from_file the SURVEY A.6 layer list (myslam_lcd_default_layers) + a flat blob / the CALCW1 / CALCW2 files
+ * weights: flat f32, per Convolution layer in order: w[OC][IC][K][K] then b[OC] (Caffe's blob order).  For the default list:
+ *          conv1.w[64][1][5][5] conv1.b[64] conv2.w[128][64][4][4] conv2.b[128] conv3.w[4][128][3][3] conv3.b[4] (137476 floats).
+ * Supported layers: Convolution (square kernel, group 1, with bias), ReLU, Pooling MAX (Caffe ceil mode, pad 0), LRN ACROSS_CHANNELS;
+ * input 1 x 120 x 160 (the reference resizes every frame to that, deeplcd.cpp:50); 1064 outputs (deeplcd.cpp:80 asserts it).
+ * Anything else: MYSLAM_ERR_UNSUPPORTED.  A list with the SURVEY A.6 geometry (any LRN alpha / beta / k, ReLUs present or not) runs
+ * on fused kernels; other lists run layer by layer on generic kernels (myslam_lcd_uses_fused_kernels tells which).
  * ------------------------------------------------------------------------------------------ */
+#define MYSLAM_CALC_CONV 1
+#define MYSLAM_CALC_RELU 2
+#define MYSLAM_CALC_POOL_MAX 3
+#define MYSLAM_CALC_LRN 4
+typedef struct myslam_calc_layer {
+    int32_t type;                              /* MYSLAM_CALC_* */
+    int32_t num_output, kernel, stride, pad;   /* Convolution (convolution_param); Pooling uses kernel / stride / pad (pooling_param) */
+    int32_t local_size;                        /* LRN (lrn_param): y = x * (k + alpha / local_size * sum x^2)^-beta */
+    float alpha, beta, k;
+} myslam_calc_layer;
 typedef struct myslam_lcd myslam_lcd;
+/* the SURVEY A.6 list (10 records); layers == NULL returns the count only */
+int myslam_lcd_default_layers(myslam_calc_layer* layers, int cap);
 int myslam_lcd_create(myslam_lcd** out, const float* weights, size_t nweights);
+int myslam_lcd_create_from_layers(myslam_lcd** out, const myslam_calc_layer* layers, int nlayers, const float* weights, size_t nweights);
+/* DeepLCD::DeepLCD(prototxt_path, caffemodel_path, gpu_id)  deeplcd.h:33, deeplcd.cpp:10-31 */
+int myslam_lcd_create_from_caffe(myslam_lcd** out, const char* prototxt_path, const char* caffemodel_path);
+/* host only (no device needed): parse + validate the two Caffe files into records and the flat weight blob; NULL outputs are skipped */
+int myslam_calc_parse_caffe(const char* prototxt_path, const char* caffemodel_path, myslam_calc_layer* layers, int cap, int* nlayers,
+                            float* weights, size_t wcap, size_t* nweights);
+/* own files: "CALCW1" (weights of the default list) or "CALCW2" (records + weights), see csrc/calc.hip */
 int myslam_lcd_create_from_file(myslam_lcd** out, const char* path);
+/* 1 = the layer list runs on the fused kernels, 0 = on the generic layer kernels */
+int myslam_lcd_uses_fused_kernels(const myslam_lcd* h);
+#define MYSLAM_LCD_OPT_GENERIC_KERNELS 1       /* value != 0: run even a fusable list on the generic kernels (tests, diagnosis) */
+int myslam_lcd_set_option(myslam_lcd* h, int option, int value);
 int myslam_lcd_destroy(myslam_lcd* h);
 int myslam_lcd_set_stream(myslam_lcd* h, void* hip_stream);
 size_t myslam_lcd_nweights(void);

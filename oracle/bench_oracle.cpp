@@ -88,15 +88,15 @@ extern "C" int orc_bench_frames(const uint8_t* frames /*n_pairs x 2 x rows x col
             if (st) st[4] = now_s() - t0;
         }
     };
-    auto run_pool = [&](int upto) {
-        limit = upto;
+    auto run_pool = [&](int from, int upto) {
+        next.store(from); limit = upto;
         std::vector<std::thread> pool;
         for (int t = 0; t < threads; t++) pool.emplace_back(worker);
         for (auto& th : pool) th.join();
     };
-    if (n_warmup > 0) run_pool(n_warmup);          // frames [0, n_warmup): untimed
+    if (n_warmup > 0) run_pool(0, n_warmup);       // frames [0, n_warmup): untimed
     const auto t0 = std::chrono::steady_clock::now();
-    run_pool(n_pairs);                             // frames [n_warmup, n_pairs)
+    run_pool(n_warmup, n_pairs);                   // frames [n_warmup, n_pairs)
     *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return fail.load() ? -2 : 0;
 }

@@ -123,27 +123,48 @@ int orc_calc_preproc(uint8_t* img, int rows, int cols, int step, int blur_in_pla
     return 0;
 }
 
-int orc_calc_forward(const float* weights, size_t nweights, const float* in, float* out1064) {
-    if (nweights != NW) return -1;
-    const float* w1 = weights;            const float* b1 = w1 + 64 * 25;
-    const float* w2 = b1 + 64;            const float* b2 = w2 + 128 * 64 * 16;
-    const float* w3 = b2 + 128;           const float* b3 = w3 + 4 * 128 * 9;
-    std::vector<float> a, p;
-    int H, W, PH, PW;
-    conv2d(in, 1, IN_H, IN_W, w1, b1, 64, 5, 2, 4, true, a, H, W);          // 62x82
-    maxpool(a, 64, H, W, 3, 2, p, PH, PW);                                   // 31x41
-    lrn(p, 64, PH, PW, 5, 1e-4f, 0.75f, 1.f);
-    conv2d(p.data(), 64, PH, PW, w2, b2, 128, 4, 1, 2, true, a, H, W);      // 32x42
-    maxpool(a, 128, H, W, 3, 2, p, PH, PW);                                  // 16x21
-    lrn(p, 128, PH, PW, 5, 1e-4f, 0.75f, 1.f);
-    conv2d(p.data(), 128, PH, PW, w3, b3, 4, 3, 1, 0, true, a, H, W);       // 14x19
-    if ((size_t)4 * H * W != 1064) return -2;                                // deeplcd.cpp:80 assert
+// The layer list as data (what deploy.prototxt says): Caffe semantics per layer, NCHW f32.
+int orc_calc_forward_net(const orc_calc_layer* L, int nlayers, const float* weights, size_t nweights, const float* in, float* out1064) {
+    std::vector<float> a(in, in + (size_t)IN_H * IN_W), t;
+    int C = 1, H = IN_H, W = IN_W;
+    const float* w = weights; size_t used = 0;
+    for (int i = 0; i < nlayers; i++) {
+        const orc_calc_layer& l = L[i];
+        int OH, OW;
+        if (l.type == 1) {                                                     // Convolution
+            const size_t nw = (size_t)l.num_output * C * l.kernel * l.kernel;
+            if (used + nw + l.num_output > nweights) return -1;
+            conv2d(a.data(), C, H, W, w, w + nw, l.num_output, l.kernel, l.stride, l.pad, false, t, OH, OW);
+            w += nw + l.num_output; used += nw + l.num_output;
+            a.swap(t); C = l.num_output; H = OH; W = OW;
+        } else if (l.type == 2) {                                              // ReLU
+            for (auto& v : a) v = std::max(v, 0.f);
+        } else if (l.type == 3) {                                              // Pooling MAX (ceil mode)
+            maxpool(a, C, H, W, l.kernel, l.stride, t, OH, OW);
+            a.swap(t); H = OH; W = OW;
+        } else if (l.type == 4) {                                              // LRN across channels
+            lrn(a, C, H, W, l.local_size, l.alpha, l.beta, l.k);
+        } else {
+            return -3;
+        }
+    }
+    if (used != nweights) return -1;
+    if ((size_t)C * H * W != 1064) return -2;                                 // deeplcd.cpp:80 assert
     // deeplcd.cpp:88 descriptor /= descriptor.norm()   (f32)
     float ss = 0;
     for (int i = 0; i < 1064; i++) ss += a[i] * a[i];
     float nrm = sqrtf(ss);
     for (int i = 0; i < 1064; i++) out1064[i] = a[i] / nrm;
     return 0;
+}
+
+// the SURVEY A.6 list
+int orc_calc_forward(const float* weights, size_t nweights, const float* in, float* out1064) {
+    if (nweights != NW) return -1;
+    const orc_calc_layer L[10] = {{1, 64, 5, 2, 4, 0, 0, 0, 0},  {2, 0, 0, 0, 0, 0, 0, 0, 0}, {3, 0, 3, 2, 0, 0, 0, 0, 0}, {4, 0, 0, 0, 0, 5, 1e-4f, 0.75f, 1.f},
+                                  {1, 128, 4, 1, 2, 0, 0, 0, 0}, {2, 0, 0, 0, 0, 0, 0, 0, 0}, {3, 0, 3, 2, 0, 0, 0, 0, 0}, {4, 0, 0, 0, 0, 5, 1e-4f, 0.75f, 1.f},
+                                  {1, 4, 3, 1, 0, 0, 0, 0, 0},   {2, 0, 0, 0, 0, 0, 0, 0, 0}};
+    return orc_calc_forward_net(L, 10, weights, nweights, in, out1064);
 }
 
 float orc_lcd_score(const float* a, const float* b) {      // deeplcd.cpp:35-39

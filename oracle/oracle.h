@@ -112,6 +112,9 @@ int orc_triangulate_stereo(const float* xl, const float* yl, const float* xr, co
 /* weights blob layout: see calc_oracle.cpp header. */
 int orc_calc_preproc(uint8_t* img, int rows, int cols, int step, int blur_in_place, float* out /*120*160*/);
 int orc_calc_forward(const float* weights, size_t nweights, const float* in /*120*160*/, float* out1064);
+/* one layer as deploy.prototxt describes it: type 1 Convolution / 2 ReLU / 3 Pooling MAX / 4 LRN (across channels) */
+typedef struct orc_calc_layer { int32_t type, num_output, kernel, stride, pad, local_size; float alpha, beta, k; } orc_calc_layer;
+int orc_calc_forward_net(const orc_calc_layer* layers, int nlayers, const float* weights, size_t nweights, const float* in, float* out1064);
 size_t orc_calc_nweights(void);
 float orc_lcd_score(const float* a, const float* b);
 /* DetectLoop scan (loopclosing.cpp:124-161): ids ascending */

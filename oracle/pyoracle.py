@@ -41,6 +41,10 @@ def _p(a, t=C.c_void_p):
     return a.ctypes.data_as(t)
 
 
+CALC_LAYER_DTYPE = np.dtype([("type", "<i4"), ("num_output", "<i4"), ("kernel", "<i4"), ("stride", "<i4"), ("pad", "<i4"),
+                             ("local_size", "<i4"), ("alpha", "<f4"), ("beta", "<f4"), ("k", "<f4")])
+
+
 class Oracle:
     def __init__(self):
         self.lib = C.CDLL(build())
@@ -264,6 +268,15 @@ class Oracle:
         weights = np.ascontiguousarray(weights, np.float32); x = np.ascontiguousarray(x, np.float32)
         out = np.zeros(1064, np.float32)
         rc = self.lib.orc_calc_forward(_p(weights), C.c_size_t(weights.size), _p(x), _p(out))
+        assert rc == 0, rc
+        return out
+
+    def calc_forward_net(self, layers, weights, x):
+        """layers: structured array / list of (type, num_output, kernel, stride, pad, local_size, alpha, beta, k) records"""
+        L = np.ascontiguousarray(layers, CALC_LAYER_DTYPE)
+        w = np.ascontiguousarray(weights, np.float32).ravel(); x = np.ascontiguousarray(x, np.float32)
+        out = np.zeros(1064, np.float32)
+        rc = self.lib.orc_calc_forward_net(_p(L), len(L), _p(w), C.c_size_t(w.size), _p(x), _p(out))
         assert rc == 0, rc
         return out
 

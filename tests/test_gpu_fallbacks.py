@@ -1,63 +1,75 @@
-"""The alternative kernels kept behind developer switches (one cell per block FAST, LDS-tile blur, one-row resize, one wave per
-key-point describe, unfused conv1, f32-input MFMA conv2 tilings, two-pass DeepLCD input, xor / popcount and int8 matrix-core Hamming; and the experimental int8 matrix-core Gaussian) must stay bit-compatible with the default path: run the extractor + CALC against the oracle in
-child processes with the switches set (they are read once per process)."""
-import os
-import subprocess
-import sys
-
+"""Paths a run does not necessarily take must stay bit-compatible with the oracle:
+  * the two paths of the grid-FAST kernel (compass pre-test + compaction / dense scoring) and its own choice between them,
+  * the extractor with and without its internal Gaussian-pyramid stream,
+  * the capability fallbacks (generic resize for scale factors above 1.25, the LDS-tiled Gaussian for unaligned / tiny images).
+(The generic CALC layer kernels against the fused ones: tests/test_gpu_lcd.py.)"""
+import numpy as np
 import pytest
-
-from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
-CHILD = r'''
-import sys, numpy as np
-sys.path.insert(0, %(root)r)
-import torch
-import __graft_entry__ as g
-pkg = g.load_package(); api, synth = pkg.api, pkg.synth
-sys.path.insert(0, %(root)r + "/oracle")
-from pyoracle import Oracle
-o = Oracle()
-for (h, w, nf) in ((240, 320, 500), (301, 517, 1200)):
-    img = synth.random_image(1000 + h, h, w)
-    gk, gd = api.ORBextractor(nf).DetectAndCompute(img)
-    rk, rd = o.detect_and_compute(o.params(nf), img)
-    assert gk.tobytes() == rk.tobytes() and np.array_equal(gd, rd), "ORB differs"
-L, _ = synth.stereo_pair(0, 1)
-wts = synth.calc_weights()
-d, _ = api.DeepLCD(wts).calcDescrOriginalImg(L, blur_in_place=False)
-x, _ = o.calc_preproc(L)
-assert np.abs(d - o.calc_forward(wts, x)).max() < 2e-5, "CALC differs"
-db = synth.lcd_database(300); ids = np.arange(300, dtype=np.uint64)
-D = api.LoopDatabase(300)
-for i in range(300):
-    D.AddToDatabase(i, db[i])
-import torch as _t
-qs = _t.from_numpy(db[:64].copy()).cuda(); cur = np.full(64, 400, np.uint64)
-d_best = _t.zeros(64, dtype=_t.int64, device="cuda"); d_max = _t.zeros(64, device="cuda"); d_cnt = _t.zeros(64, dtype=_t.int32, device="cuda")
-D.query_batch(qs.data_ptr(), cur, 64, d_best.data_ptr(), d_max.data_ptr(), d_cnt.data_ptr()); _t.cuda.synchronize()
-for k in range(64):
-    ref = o.lcddb_query(db, ids, db[k], 400)
-    assert int(d_best[k]) == ref[0] and abs(float(d_max[k]) - ref[1]) < 2e-5 and int(d_cnt[k]) == ref[2], "DB scan differs"
-rng = np.random.default_rng(5)
-for nq, nt in ((700, 1033), (33, 2), (2000, 1999)):
-    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8); t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
-    t[nt // 2] = t[0]; q[0] = t[0]
-    gi, gd = api.hamming_match(q, t); ri, rd = o.hamming_match(q, t)
-    assert np.array_equal(gi, ri) and np.array_equal(gd, rd), "Hamming differs"
-print("FALLBACK OK")
-'''
+
+@pytest.mark.parametrize("mode", [0, 1, -1])
+@pytest.mark.parametrize("kind,nrect", [("texture", 0), ("noise", 0), ("scene", 300), ("scene", 6000)])
+def test_fast_paths_bitexact(api, oracle, synth, mode, kind, nrect):
+    """FAST_MODE 0 (two-phase), 1 (dense) and -1 (chosen from the previous launch's statistics; called three times so that the choice
+    is exercised) on corner-dense texture, pure noise, a sparse scene (a few % of corners) and the BASELINE scene."""
+    if kind == "scene":
+        img = synth.stereo_batch(1, stream_id=3, n_rect=nrect, h=200, w=420)[0, 0]
+    else:
+        img = synth.random_image(77, 200, 420, kind)
+    rk, rd = oracle.detect_and_compute(oracle.params(800), img)
+    ext = api.ORBextractor(800)
+    ext.set_option(ext.OPT_FAST_MODE, mode)
+    for rep in range(3 if mode < 0 else 1):
+        gk, gd = ext.DetectAndCompute(img)
+        assert gk.tobytes() == rk.tobytes() and np.array_equal(gd, rd), (mode, kind, rep)
+    for lvl in (0, 3, 7):                                           # candidate sets before the oct-tree
+        xs, ys, sc = ext.debug_candidates(img, lvl)
+        rx, ry, rs = oracle.grid_fast(oracle.pyramid(oracle.params(800), img)[lvl])
+        assert sorted(zip(ys.tolist(), xs.tolist(), sc.tolist())) == sorted(zip(ry.tolist(), rx.tolist(), rs.tolist())), (mode, kind, lvl)
 
 
-@pytest.mark.parametrize("env", [
-    {"MYSLAM_FAST_V": "3", "MYSLAM_BLUR_V": "2", "MYSLAM_RESIZE_V": "1", "MYSLAM_DESC_V": "1", "MYSLAM_CONV1_V": "1", "MYSLAM_HAMMING_V": "1", "MYSLAM_ORB_AUX": "0", "MYSLAM_CONV2_V": "0", "MYSLAM_LCD_PRE_V": "1", "MYSLAM_DBSCAN_V": "1"},
-    {"MYSLAM_FAST_V": "2", "MYSLAM_BLUR_V": "1", "MYSLAM_ORB_AUX": "1", "MYSLAM_HAMMING_V": "2", "MYSLAM_CONV1_V": "2", "MYSLAM_POOL2_V": "1"},
-    {"MYSLAM_FAST_V": "2", "MYSLAM_FAST_T": "64", "MYSLAM_CONV2_V": "1"},
-    {"MYSLAM_BLUR_V": "4"},
-])
-def test_alternative_kernels_match_oracle(env):
-    e = dict(os.environ); e.update(env)
-    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=e, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "FALLBACK OK" in r.stdout, (env, r.stdout[-2000:], r.stderr[-2000:])
+def test_fast_mode_switches_between_batches(api, oracle, synth):
+    """One handle, alternating noise and sparse images: whatever path the statistics select, every result equals the oracle's."""
+    ext = api.ORBextractor(500)
+    imgs = [synth.random_image(5, 180, 400, "noise"), synth.stereo_batch(1, stream_id=2, n_rect=200, h=180, w=400)[0, 0]]
+    refs = [oracle.detect_and_compute(oracle.params(500), im) for im in imgs]
+    for i in (0, 0, 1, 1, 1, 0, 1, 0, 0):
+        gk, gd = ext.DetectAndCompute(imgs[i])
+        assert gk.tobytes() == refs[i][0].tobytes() and np.array_equal(gd, refs[i][1])
+
+
+@pytest.mark.parametrize("aux", [0, 1, 2])
+def test_internal_stream_modes(api, oracle, synth, aux):
+    import torch
+    imgs = np.stack([synth.random_image(900 + i, 240, 320) for i in range(4)])
+    ext = api.ORBextractor(600)
+    ext.set_option(ext.OPT_INTERNAL_STREAM, aux)
+    cap = ext.max_keypoints(240, 320)
+    d = torch.from_numpy(imgs).cuda()
+    kps = torch.zeros(4 * cap * 28, dtype=torch.uint8, device="cuda"); desc = torch.zeros(4 * cap * 32, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(4, dtype=torch.int32, device="cuda"); st = torch.zeros(4, dtype=torch.int32, device="cuda")
+    for _ in range(2):
+        ext.detect_and_compute_batch(d.data_ptr(), 4, 240, 320, 320, 240 * 320, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), st.data_ptr(), cap)
+    torch.cuda.synchronize()
+    assert int(st.abs().sum()) == 0
+    k = kps.cpu().numpy().view(api.KP_DTYPE).reshape(4, cap); dd = desc.cpu().numpy().reshape(4, cap, 32)
+    for i in range(4):
+        rk, rd = oracle.detect_and_compute(oracle.params(600), imgs[i])
+        n = int(cnt[i])
+        assert k[i, :n].tobytes() == rk.tobytes() and np.array_equal(dd[i, :n], rd)
+
+
+def test_capability_fallbacks(api, oracle, synth):
+    """scale factor 1.5 -> the generic resize kernel (the register strips cover factors up to 1.25); a 7-pixel-high LCD input ->
+    the LDS-tiled Gaussian."""
+    img = synth.random_image(31, 300, 500)
+    p = oracle.params(700, scale=1.5, nlevels=5)
+    gk, gd = api.ORBextractor(700, scaleFactor=1.5, nlevels=5).DetectAndCompute(img)
+    rk, rd = oracle.detect_and_compute(p, img)
+    assert gk.tobytes() == rk.tobytes() and np.array_equal(gd, rd)
+    small = synth.random_image(32, 7, 301)
+    lcd = api.DeepLCD(synth.calc_weights())
+    _, blurred = lcd.calcDescrOriginalImg(small, blur_in_place=True)
+    assert np.array_equal(blurred, oracle.calc_preproc(small, blur_in_place=True)[1])

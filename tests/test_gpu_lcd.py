@@ -285,28 +285,88 @@ def test_fused_input_equals_two_pass_blur(api, synth, h, w):
     assert np.array_equal(d1.view(np.uint32), d2.view(np.uint32))
 
 
-def test_tiled_conv1_and_pool_kernels_against_the_simple_ones():
-    """k_pool_lrn128_2x2 (2 x 2 pooled pixels per wave, LRN over shuffles) returns the bits of k_pool_lrn<128> (MYSLAM_POOL2_V=1);
-    k_conv1_pool_lrn2 agrees with the one-pooled-pixel kernel (MYSLAM_CONV1_V=2) and the unfused conv1 -> pool pair (=1) to a few
-    1e-8 on unit-norm descriptors (same tap order; the compiler contracts the multiply-adds of the three kernels differently)."""
-    import os
-    import subprocess
-    import sys
-    from conftest import ROOT
-    child = r'''
-import sys, numpy as np
-sys.path.insert(0, %r)
-import torch, __graft_entry__ as g
-pkg = g.load_package(); api, synth = pkg.api, pkg.synth
-lcd = api.DeepLCD(synth.calc_weights())
-out = [lcd.calcDescrOriginalImg(synth.random_image(4100 + i, 240, 320))[0] for i in range(4)]
-sys.stdout.buffer.write(np.stack(out).astype(np.float32).tobytes())
-''' % ROOT
-    res = []
-    for env in ({}, {"MYSLAM_POOL2_V": "1"}, {"MYSLAM_CONV1_V": "2"}, {"MYSLAM_CONV1_V": "1"}):
-        e = dict(os.environ); e.update(env)
-        r = subprocess.run([sys.executable, "-c", child], env=e, capture_output=True, timeout=600)
-        assert r.returncode == 0, r.stderr.decode()[-2000:]
-        res.append(np.frombuffer(r.stdout[-4 * 1064 * 4:], np.float32))
-    assert res[0].size == 4 * 1064 and np.array_equal(res[0].view(np.uint32), res[1].view(np.uint32))
-    assert np.abs(res[2] - res[0]).max() < 2e-7 and np.abs(res[3] - res[0]).max() < 2e-7
+def test_fused_kernels_against_the_generic_layer_kernels(api, oracle, synth):
+    """The fused kernels (conv1 + pool + LRN, bf16x6 conv2, pool + LRN, conv3 + norm) and the generic layer-by-layer kernels run the
+    same layer list: descriptors agree to float noise, and both sit within the tolerance of the oracle."""
+    w = synth.calc_weights()
+    fused, generic = api.DeepLCD(w), api.DeepLCD(w)
+    generic.set_option(generic.OPT_GENERIC_KERNELS, 1)
+    assert fused.uses_fused_kernels() and not generic.uses_fused_kernels()
+    for i in range(3):
+        img = synth.random_image(4100 + i, 240, 320)
+        a, _ = fused.calcDescrOriginalImg(img); b, _ = generic.calcDescrOriginalImg(img)
+        ref = oracle.calc_forward(w, oracle.calc_preproc(img, blur_in_place=True)[0])
+        assert np.abs(a - b).max() < 5e-6 and np.abs(a - ref).max() < DESC_ATOL and np.abs(b - ref).max() < DESC_ATOL
+    x = np.random.default_rng(3).random((120, 160), dtype=np.float32)
+    for stage in range(5):                                          # the stage taps agree between the two kernel families
+        ta, tb = fused.debug_forward(x, stage), generic.debug_forward(x, stage)
+        assert np.abs(ta - tb).max() <= 2e-5 * max(1.0, float(np.abs(tb).max())), stage
+
+
+def test_create_from_caffe_files(api, oracle, synth, tmp_path):
+    """DeepLCD(prototxt, caffemodel) as the reference constructs it (deeplcd.cpp:10-31): a hand-encoded deploy.prototxt + .caffemodel
+    pair (tests/caffe_files.py, no Caffe) gives the flat-blob handle's descriptor bit for bit."""
+    import caffe_files
+    w = synth.calc_weights()
+    pp, mp = caffe_files.write_pair(tmp_path, api.calc_default_layers(), w)
+    a, b = api.DeepLCD.from_caffe(pp, mp), api.DeepLCD(w)
+    assert a.uses_fused_kernels()
+    img = synth.random_image(77, 376, 1241)
+    da, _ = a.calcDescrOriginalImg(img); db, _ = b.calcDescrOriginalImg(img)
+    assert np.array_equal(da.view(np.uint32), db.view(np.uint32))
+    # the CALCW2 model file (records + weights) loads to the same handle
+    L = api.calc_default_layers()
+    path = str(tmp_path / "calc.w2")
+    with open(path, "wb") as f:
+        f.write(b"CALCW2\0\0"); f.write(np.uint32(len(L)).tobytes()); f.write(L.tobytes())
+        f.write(np.uint64(w.size).tobytes()); f.write(np.asarray(w, np.float32).tobytes())
+    dc, _ = api.DeepLCD(path=path).calcDescrOriginalImg(img)
+    assert np.array_equal(dc.view(np.uint32), db.view(np.uint32))
+
+
+@pytest.mark.parametrize("change", ["alpha", "beta_k", "no_relu3", "lrn3", "no_lrn"])
+def test_layer_list_is_data(api, oracle, synth, tmp_path, change):
+    """A changed hyper-parameter in the prototxt changes the output exactly as the oracle's layer-list forward predicts: LRN alpha
+    (fused kernels, fast pow), beta / k (fused kernels, powf), a dropped ReLU (flag), an LRN window of 3 and a net without LRN layers
+    (generic layer kernels)."""
+    import caffe_files
+    w = synth.calc_weights()
+    L = api.calc_default_layers()
+    if change == "alpha":
+        L["alpha"][3] = 0.5; L["alpha"][7] = 2.0
+    elif change == "beta_k":
+        L["beta"][3] = 0.5; L["k"][3] = 2.0; L["beta"][7] = 1.25; L["alpha"][7] = 1.0
+    elif change == "no_relu3":
+        L = L[:-1]
+    elif change == "lrn3":
+        L["local_size"][3] = 3; L["alpha"][3] = 0.3
+    else:
+        L = L[[0, 1, 2, 4, 5, 6, 8, 9]]
+    pp, mp = caffe_files.write_pair(tmp_path, L, w)
+    lcd = api.DeepLCD.from_caffe(pp, mp)
+    assert lcd.uses_fused_kernels() == (change != "lrn3")
+    base = api.DeepLCD(w)
+    for i in range(2):
+        img = synth.random_image(500 + i, 200, 300)
+        x, _ = oracle.calc_preproc(img, blur_in_place=True)
+        got, _ = lcd.calcDescrOriginalImg(img)
+        ref = oracle.calc_forward_net(L, w, x)
+        assert np.abs(got - ref).max() < DESC_ATOL, change
+        if change != "no_relu3" or (oracle.calc_forward(w, x) != ref).any():
+            assert np.abs(got - base.calcDescrOriginalImg(img)[0]).max() > 10 * DESC_ATOL or change == "no_lrn", change
+
+
+def test_unsupported_models_are_refused(api, synth):
+    w = synth.calc_weights()
+    L = api.calc_default_layers()
+    bad = L.copy(); bad["type"][2] = 9
+    with pytest.raises(api.MyslamError) as e:
+        api.DeepLCD(w, layers=bad)
+    assert e.value.code == api.ERR_UNSUPPORTED
+    bad = L.copy(); bad["pad"][8] = 1                               # 4 x 16 x 21 outputs instead of 1064
+    with pytest.raises(api.MyslamError) as e:
+        api.DeepLCD(w, layers=bad)
+    assert e.value.code == api.ERR_UNSUPPORTED
+    with pytest.raises(api.MyslamError) as e:                       # weights that do not fit the list
+        api.DeepLCD(w[:-1], layers=L)
+    assert e.value.code == api.ERR_INVALID

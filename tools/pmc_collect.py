@@ -40,8 +40,8 @@ def run_pass(counters, pairs, workload, outdir, scene_rects):
         shutil.rmtree(outdir)
     cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", outdir, "-o", "a", "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--pairs", str(pairs), "--workload", workload,
-           "--streams", "1", "--no-cpu-baseline", "--no-extra-passes", "--scene-rects", str(scene_rects)]
-    env = dict(os.environ, TMPDIR="/tmp", MYSLAM_ORB_AUX="0")
+           "--streams", "1", "--orb-internal-stream", "0", "--no-cpu-baseline", "--no-extra-passes", "--scene-rects", str(scene_rects)]
+    env = dict(os.environ, TMPDIR="/tmp")
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
     files = glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True)
     if r.returncode != 0 or not files:
@@ -114,7 +114,7 @@ def main():
     out = {
         "build": args.tag, "round": args.round,
         "command": f"rocprofv3 --kernel-trace --pmc <set> -- python bench.py --steps 2 --warmup 1 --pairs {P} --workload {args.workload} --streams 1 "
-                   f"--no-cpu-baseline --no-extra-passes --scene-rects {args.scene_rects}   (MYSLAM_ORB_AUX=0; one pass per counter set)",
+                   f"--orb-internal-stream 0 --no-cpu-baseline --no-extra-passes --scene-rects {args.scene_rects}   (one pass per counter set)",
         "counter_sets": PASSES, "pairs_per_step": P, "steps_total": steps_total,
         "calibration": {"kernel": "k_ingest", "known_read_bytes_per_image": known_r, "counted_read_bytes_per_image": ing["fetch_bytes_per_image_raw"],
                         "fetch_scale": fetch_scale, "known_write_bytes_per_image": known_w, "counted_write_over_known": write_check,
