@@ -5,7 +5,7 @@
 //   pyramid block  : levels 0..L-1 back to back (level 0 is ingested from the caller's buffer)
 //   blurred block  : same geometry, 7x7 sigma=2 Gaussian of every level
 //   candidates     : per level a u32 list  py<<20 | px<<8 | score   (+ count)
-//   sort buffers   : per level 2 x u64 (path code<<32 | payload)
+//   sort buffer    : per level the candidates' u32 selection keys in quad-tree bucket order
 //   selected keys  : per level <= N+3 payloads in oct-tree list order (+ count)
 #include <math.h>
 #include <stdlib.h>
@@ -22,7 +22,7 @@ void launch_resize(const ResizeArgs& a, int batch, hipStream_t s);
 void launch_blur(const BlurArgs& a, int batch, hipStream_t s);
 void launch_fast(const OrbPlan& P, const uint8_t* pyr, size_t pyrStride, const uint8_t* maskPyr, uint32_t* cand,
                  int32_t* candCount, const uint32_t* statPrev, uint32_t* statCur, int forceMode, int batch, hipStream_t s);
-void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCount, uint64_t* sortbuf, const uint32_t* octTab, uint32_t* selOut,
+void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCount, uint32_t* sortbuf, const uint32_t* octTab, uint32_t* selOut,
                    int32_t* selCount, int32_t* status, int batch, hipStream_t s);
 void launch_describe(const OrbPlan& P, const uint8_t* pyr, const uint8_t* blur, size_t pyrStride, const uint32_t* selOut,
                      const int32_t* selCount, myslam_keypoint* kps, uint8_t* desc, int32_t* counts, int32_t* status,
@@ -102,7 +102,7 @@ struct myslam_orb {
     bool maskAlloc = false;
     uint8_t *d_pyr = nullptr, *d_blur = nullptr, *d_mask = nullptr;
     uint32_t* d_cand = nullptr;
-    uint64_t* d_sort = nullptr;
+    uint32_t* d_sort = nullptr;        // per level the candidates' 32-bit sort entries in bucket order + their path codes
     int32_t *d_candCount = nullptr, *d_selCount = nullptr, *d_status = nullptr;
     uint32_t* d_sel = nullptr;
     uint32_t* d_octTab = nullptr;      // per-level oct-tree path-code / cell-index tables (see make_plan)

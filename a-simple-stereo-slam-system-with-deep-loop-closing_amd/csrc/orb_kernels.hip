@@ -547,8 +547,10 @@ __device__ __forceinline__ int wave_incl_scan_dpp(int v) {
 // Path selection of the strip kernel (per level): `prev` = what the previous launch of this extractor handle measured,
 // `cur` = what this launch accumulates (zeroed by the host): [level][4] = {pairs that survived the pre-test (two-phase path) or
 // pairs holding a corner (dense path), pixel pairs looked at, path used, -}.  force: -1 = choose, 0 = two-phase, 1 = dense.
-// Both paths produce the same candidate SET, so the choice only moves time: on imagery with a few % of corners the two-phase
-// path scores a tenth of the pixels; when most pixel pairs survive the pre-test (noise-like texture) compaction cannot pay.
+// Both paths produce the same candidate SET, so the choice only moves time.  Measured on MI355X (ms per 512 images, two-phase / dense,
+// against the fraction of pixel pairs that survive the pre-test): 0.09: 1.01 / 1.54, 0.18: 1.26 / 1.60, 0.30: 1.53 / 1.61,
+// 0.46: 1.81 / 1.64, 0.63: 2.04 / 1.63 — break-even near 0.41.  The switch goes to dense above 0.38 surviving pairs and back
+// below 0.22 corner-holding pairs (the dense path's own statistic; about 0.25 at the break-even).
 struct FastCtl { const uint32_t* prev; uint32_t* cur; int force; };
 
 // ---- strip kernel: one block scores G horizontally adjacent cells -----------------------------------
@@ -649,7 +651,7 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
     {
         const float ps = (float)ctl.prev[level * 4], pt = (float)ctl.prev[level * 4 + 1];
         const bool was_dense = ctl.prev[level * 4 + 2] != 0;
-        dense = ctl.force >= 0 ? ctl.force != 0 : (pt > 0.f && (was_dense ? ps > 0.45f * pt : ps > 0.72f * pt));
+        dense = ctl.force >= 0 ? ctl.force != 0 : (pt > 0.f && (was_dense ? ps > 0.22f * pt : ps > 0.38f * pt));
     }
     __syncthreads();
 
@@ -874,7 +876,10 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {             // what the next launch of this handle decides on
+    // what the next launch of this handle decides on: a SAMPLE of the strips reports (a ratio of sums needs no more, and a few
+    // thousand same-address atomics per launch cost nothing where 300 k of them serialise into milliseconds)
+    const int sample_stride = max(1, nwg >> 12);
+    if (threadIdx.x == 0 && logical % sample_stride == 0) {
         atomicAdd(&ctl.cur[level * 4], (uint32_t)(dense ? s_ncorner : min(s_npair, NPAIR)));
         atomicAdd(&ctl.cur[level * 4 + 1], (uint32_t)pairs_total);
         ctl.cur[level * 4 + 2] = dense ? 1u : 0u;
@@ -968,11 +973,13 @@ __device__ __forceinline__ uint32_t oct_code(int px, int py, const LevelGeom& g)
     return code;
 }
 
-// in-place 4-way partition of S[lo,hi) on the 2-bit digit at bit position sh (deep nodes only; one thread)
-__device__ __noinline__ void partition4(uint64_t* __restrict__ S, int lo, int hi, int sh, int& b1, int& b2, int& b3) {
+// The sorted entries are 32-bit (the selection key, or the FAST payload on grids of more than 1024 cells); their quad-tree path codes
+// live in a parallel array that only nodes deeper than the counting sort's depth ever read (many keys crowding into one ~10-px cell).
+// in-place 4-way partition of (S, Cd)[lo,hi) on the 2-bit path-code digit at bit position sh (deep nodes only; one thread)
+__device__ __noinline__ void partition4(uint32_t* __restrict__ S, uint32_t* __restrict__ Cd, int lo, int hi, int sh, int& b1, int& b2, int& b3) {
     int c0 = 0, c1 = 0, c2 = 0;
     for (int i = lo; i < hi; i++) {
-        const int d = (int)((S[i] >> sh) & 3);
+        const int d = (int)((Cd[i] >> sh) & 3);
         c0 += (d == 0); c1 += (d == 1); c2 += (d == 2);
     }
     b1 = lo + c0; b2 = b1 + c1; b3 = b2 + c2;
@@ -983,16 +990,15 @@ __device__ __noinline__ void partition4(uint64_t* __restrict__ S, int lo, int hi
     for (int k = 0; k < 3; k++) {                            // bucket 3 is in place once 0..2 are
         int i = (k == 0) ? p0 : (k == 1) ? p1 : p2;
         while (i < ends[k]) {
-            uint64_t v = S[i];
-            int d = (int)((v >> sh) & 3);
+            uint32_t v = S[i], cv = Cd[i];
+            int d = (int)((cv >> sh) & 3);
             while (d != k) {                                 // cycle the element into its bucket
                 const int j = take(d);
-                const uint64_t w = S[j];
-                S[j] = v; v = w;
-                d = (int)((v >> sh) & 3);
-                // skip slots of bucket d that already hold a d-element is unnecessary: take() hands out fresh slots
+                const uint32_t w = S[j], cw = Cd[j];
+                S[j] = v; Cd[j] = cv; v = w; cv = cw;
+                d = (int)((cv >> sh) & 3);
             }
-            S[i] = v;
+            S[i] = v; Cd[i] = cv;
             i++;
             if (k == 0) p0 = i; else if (k == 1) p1 = i; else p2 = i;
         }
@@ -1020,19 +1026,19 @@ struct OctLds {
 };
 
 // boundaries of the 4 children of node (depth d, prefix pfx, [lo,hi))
-__device__ __forceinline__ void child_bounds(const OctLds& L, uint64_t* __restrict__ S, int D, int lo, int hi, int d, int pfx,
+__device__ __forceinline__ void child_bounds(const OctLds& L, uint32_t* __restrict__ S, uint32_t* __restrict__ Cd, int D, int lo, int hi, int d, int pfx,
                                              int& b1, int& b2, int& b3) {
     if (d < D) {
         const int sb = 2 * (D - d - 1);
         const int base = pfx << 2;
         b1 = L.offs[(base + 1) << sb]; b2 = L.offs[(base + 2) << sb]; b3 = L.offs[(base + 3) << sb];
     } else {
-        partition4(S, lo, hi, 32 + ROOT_SHIFT - 2 * (d + 1), b1, b2, b3);
+        partition4(S, Cd, lo, hi, ROOT_SHIFT - 2 * (d + 1), b1, b2, b3);
     }
 }
 
 __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __restrict__ cand,
-                                               const int32_t* __restrict__ candCount, uint64_t* __restrict__ sortbuf,
+                                               const int32_t* __restrict__ candCount, uint32_t* __restrict__ sortbuf,
                                                const uint32_t* __restrict__ octTab,
                                                uint32_t* __restrict__ selOut, int32_t* __restrict__ selCount,
                                                int32_t* __restrict__ status, int NCmax) {
@@ -1080,8 +1086,8 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
     if (n == 0) { if (t == 0) *myCount = 0; return; }
 
     const uint32_t* keys = cand + (size_t)b * P.totalKeyCap + g.keyOff;
-    uint64_t* bufA = sortbuf + ((size_t)b * P.totalKeyCap + g.keyOff) * 2;
-    uint64_t* S = bufA + g.keyCap;
+    uint32_t* S = sortbuf + ((size_t)b * P.totalKeyCap + g.keyOff) * 2;    // the level's entries in bucket order (32 bits each) ...
+    uint32_t* Cd = S + g.keyCap;                                           // ... and their path codes
     const int D = g.sortDepth;                                   // bucket = code >> (ROOT_SHIFT - 2D)
     const int NB = g.nIni << (2 * D);
     const int bsh = ROOT_SHIFT - 2 * D;
@@ -1091,37 +1097,25 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
     // ---- A: path codes + bucket histogram (LDS atomics) ----
     for (int i = t; i < NB; i += OT) s_cursor[i] = 0;
     __syncthreads();
-    // The low word of a sort entry is what phase D maximises per node.  With at most 1024 grid cells it is the complete selection
-    // key of the reference (:795-804: largest response, then first in the cell-major / row-major candidate order):
+    // A sort entry is what phase D maximises per node.  With at most 1024 grid cells it is the complete selection key of the
+    // reference (:795-804: largest response, then first in the cell-major / row-major candidate order):
     //     response << 22 | (0x3FFFFF - (cell << 12 | row in cell << 6 | column in cell))        (cells are at most 59 x 59)
-    // so phase D is ONE 32-bit maximum per node and the winner's pixel is decoded from the key; otherwise the entry keeps the FAST
+    // so phase D is ONE 32-bit maximum per node and the winner's pixel is decoded from the key; otherwise the entry is the FAST
     // payload and phase D resolves the order with the cell tables in a second pass.
+    // The candidate list is walked twice (histogram, then scatter: the second walk hits in L2) instead of parking 64-bit
+    // (code, key) pairs in HBM between the passes, and phase D streams the 32-bit keys alone: 12-16 bytes of sort traffic per
+    // candidate instead of 32.
     const bool rankkey = g.nCols * g.nRows <= 1024;
     const float inv_ncols = 1.0f / (float)g.nCols;
     for (int i0 = t; i0 < n; i0 += 4 * OT) {                       // 4 keys in flight per thread: the pass is latency-bound
-        uint32_t pay[4], cx[4], cy[4], qx[4], qy[4];
+        uint32_t pay[4], cx[4], cy[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) pay[u] = (i0 + u * OT < n) ? keys[i0 + u * OT] : 0u;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t px = (pay[u] >> 8) & 0xfff, py = pay[u] >> 20;
-            cx[u] = xcode[px]; cy[u] = ycode[py];
-            qx[u] = rankkey ? xcell[px] : 0u; qy[u] = rankkey ? ycell[py] : 0u;
-        }
+        for (int u = 0; u < 4; u++) { cx[u] = xcode[(pay[u] >> 8) & 0xfff]; cy[u] = ycode[pay[u] >> 20]; }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (i0 + u * OT >= n) continue;
-            const uint32_t code = cx[u] | cy[u];                    // == oct_code(px, py, g), tabulated per axis at plan time
-            uint32_t low = pay[u];
-            if (rankkey) {
-                const int px = (int)((pay[u] >> 8) & 0xfff), py = (int)(pay[u] >> 20);
-                const int ci = (int)(((float)qy[u] + 0.5f) * inv_ncols);                  // ycell = ci * nCols (exact: < 2^11)
-                const uint32_t pxc = (uint32_t)(px - 3 - (int)qx[u] * g.wCell), pyc = (uint32_t)(py - 3 - ci * g.hCell);
-                low = ((pay[u] & 0xffu) << 22) | (0x3fffffu - (((qy[u] + qx[u]) << 12) | (pyc << 6) | pxc));
-            }
-            bufA[i0 + u * OT] = ((uint64_t)code << 32) | low;
-            atomicAdd(&s_cursor[code >> bsh], 1u);
-        }
+        for (int u = 0; u < 4; u++)
+            if (i0 + u * OT < n) atomicAdd(&s_cursor[(cx[u] | cy[u]) >> bsh], 1u);     // code == oct_code(px, py, g), tabulated per axis at plan time
     }
     __syncthreads();
     // ---- B: exclusive offsets, then scatter (order inside a bucket is irrelevant) ----
@@ -1142,14 +1136,28 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
     }
     __syncthreads();
     for (int i0 = t; i0 < n; i0 += 4 * OT) {
-        uint64_t v[4];
+        uint32_t pay[4], cx[4], cy[4], qx[4], qy[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = (i0 + u * OT < n) ? bufA[i0 + u * OT] : 0ull;
+        for (int u = 0; u < 4; u++) pay[u] = (i0 + u * OT < n) ? keys[i0 + u * OT] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t px = (pay[u] >> 8) & 0xfff, py = pay[u] >> 20;
+            cx[u] = xcode[px]; cy[u] = ycode[py];
+            qx[u] = rankkey ? xcell[px] : 0u; qy[u] = rankkey ? ycell[py] : 0u;
+        }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             if (i0 + u * OT >= n) continue;
-            const uint32_t pos = atomicAdd(&s_cursor[(uint32_t)(v[u] >> 32) >> bsh], 1u);
-            S[pos] = v[u];
+            uint32_t low = pay[u];
+            if (rankkey) {
+                const int px = (int)((pay[u] >> 8) & 0xfff), py = (int)(pay[u] >> 20);
+                const int ci = (int)(((float)qy[u] + 0.5f) * inv_ncols);                  // ycell = ci * nCols (exact: < 2^11)
+                const uint32_t pxc = (uint32_t)(px - 3 - (int)qx[u] * g.wCell), pyc = (uint32_t)(py - 3 - ci * g.hCell);
+                low = ((pay[u] & 0xffu) << 22) | (0x3fffffu - (((qy[u] + qx[u]) << 12) | (pyc << 6) | pxc));
+            }
+            const uint32_t code = cx[u] | cy[u];
+            const uint32_t pos = atomicAdd(&s_cursor[code >> bsh], 1u);
+            S[pos] = low; Cd[pos] = code;
         }
     }
     __syncthreads();
@@ -1182,7 +1190,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
                 int k = 0;
                 if (hi - lo > 1 && d < g.ndepth) {
                     int b1, b2, b3;
-                    child_bounds(L, S, D, lo, hi, d, L.pfx(cur)[p], b1, b2, b3);
+                    child_bounds(L, S, Cd, D, lo, hi, d, L.pfx(cur)[p], b1, b2, b3);
                     L.nb1[p] = (uint32_t)b1; L.nb2[p] = (uint32_t)b2; L.nb3[p] = (uint32_t)b3;
                     const int c0 = b1 - lo, c1 = b2 - b1, c2 = b3 - b2, c3 = hi - b3;
                     k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
@@ -1265,7 +1273,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
                 const int lo = (int)L.lo(cur)[p], hi = (int)L.hi(cur)[p], d = L.dep(cur)[p];
                 int k = 1, big = 1, b1 = hi, b2 = hi, b3 = hi;           // depth-exhausted node: one "child" = itself
                 if (d < g.ndepth) {
-                    child_bounds(L, S, D, lo, hi, d, L.pfx(cur)[p], b1, b2, b3);
+                    child_bounds(L, S, Cd, D, lo, hi, d, L.pfx(cur)[p], b1, b2, b3);
                     const int c0 = b1 - lo, c1 = b2 - b1, c2 = b3 - b2, c3 = hi - b3;
                     k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
                     big = (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1);
@@ -1367,9 +1375,8 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
             const int lo = live ? (int)L.lo(cur)[p0] : 0, hi = live ? (int)L.hi(cur)[p0] : 0;
             if (rankkey) {                                               // block-uniform
                 uint32_t bk = 0;
-                const uint32_t* Slo = reinterpret_cast<const uint32_t*>(S);      // little endian: the selection key is the low word
 #pragma unroll 4
-                for (int i = lo + sub; i < hi; i += 16) bk = max(bk, Slo[2 * i]);
+                for (int i = lo + sub; i < hi; i += 16) bk = max(bk, S[i]);
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) bk = max(bk, (uint32_t)__shfl_xor((int)bk, o, 64));
                 if (live && sub == 0) {
@@ -1382,12 +1389,12 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
             }
             uint32_t best = 0;
 #pragma unroll 2
-            for (int i = lo + sub; i < hi; i += 16) best = max(best, (uint32_t)S[i] & 0xffu);
+            for (int i = lo + sub; i < hi; i += 16) best = max(best, S[i] & 0xffu);
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) best = max(best, (uint32_t)__shfl_xor((int)best, o, 64));
             uint64_t bo = ~0ull;
             for (int i = lo + sub; i < hi; i += 16) {
-                const uint32_t pay = (uint32_t)S[i];
+                const uint32_t pay = S[i];
                 if ((pay & 0xffu) != best) continue;
                 const uint32_t px = (pay >> 8) & 0xfff, py = pay >> 20;
                 bo = min(bo, ((uint64_t)(ycell[py] + xcell[px]) << 24) | ((uint64_t)py << 12) | (uint64_t)px);
@@ -1841,7 +1848,7 @@ void launch_fast(const OrbPlan& P, const uint8_t* pyr, size_t pyrStride, const u
 
 size_t octree_lds_bytes(int nodeCap) { return 192 + 4 * (size_t)OT_MAXB + 4 * (size_t)(OT_MAXB + 2) + (size_t)nodeCap * 54 + 16; }
 
-void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCount, uint64_t* sortbuf, const uint32_t* octTab, uint32_t* selOut,
+void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCount, uint32_t* sortbuf, const uint32_t* octTab, uint32_t* selOut,
                    int32_t* selCount, int32_t* status, int batch, hipStream_t s) {
     // one launch for all levels: the small levels fill the gaps the large ones leave
     int ncmax = 0;

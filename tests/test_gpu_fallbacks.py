@@ -15,9 +15,9 @@ def test_fast_paths_bitexact(api, oracle, synth, mode, kind, nrect):
     """FAST_MODE 0 (two-phase), 1 (dense) and -1 (chosen from the previous launch's statistics; called three times so that the choice
     is exercised) on corner-dense texture, pure noise, a sparse scene (a few % of corners) and the BASELINE scene."""
     if kind == "scene":
-        img = synth.stereo_batch(1, stream_id=3, n_rect=nrect, h=200, w=420)[0, 0]
+        img = synth.stereo_batch(1, stream_id=3, n_rect=nrect, h=240, w=420)[0, 0]
     else:
-        img = synth.random_image(77, 200, 420, kind)
+        img = synth.random_image(77, 240, 420, kind)
     rk, rd = oracle.detect_and_compute(oracle.params(800), img)
     ext = api.ORBextractor(800)
     ext.set_option(ext.OPT_FAST_MODE, mode)
@@ -33,7 +33,7 @@ def test_fast_paths_bitexact(api, oracle, synth, mode, kind, nrect):
 def test_fast_mode_switches_between_batches(api, oracle, synth):
     """One handle, alternating noise and sparse images: whatever path the statistics select, every result equals the oracle's."""
     ext = api.ORBextractor(500)
-    imgs = [synth.random_image(5, 180, 400, "noise"), synth.stereo_batch(1, stream_id=2, n_rect=200, h=180, w=400)[0, 0]]
+    imgs = [synth.random_image(5, 240, 400, "noise"), synth.stereo_batch(1, stream_id=2, n_rect=200, h=240, w=400)[0, 0]]
     refs = [oracle.detect_and_compute(oracle.params(500), im) for im in imgs]
     for i in (0, 0, 1, 1, 1, 0, 1, 0, 0):
         gk, gd = ext.DetectAndCompute(imgs[i])
@@ -65,8 +65,8 @@ def test_capability_fallbacks(api, oracle, synth):
     """scale factor 1.5 -> the generic resize kernel (the register strips cover factors up to 1.25); a 7-pixel-high LCD input ->
     the LDS-tiled Gaussian."""
     img = synth.random_image(31, 300, 500)
-    p = oracle.params(700, scale=1.5, nlevels=5)
-    gk, gd = api.ORBextractor(700, scaleFactor=1.5, nlevels=5).DetectAndCompute(img)
+    p = oracle.params(700, scale=1.5, nlevels=4)
+    gk, gd = api.ORBextractor(700, scaleFactor=1.5, nlevels=4).DetectAndCompute(img)
     rk, rd = oracle.detect_and_compute(p, img)
     assert gk.tobytes() == rk.tobytes() and np.array_equal(gd, rd)
     small = synth.random_image(32, 7, 301)

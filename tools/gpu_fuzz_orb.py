@@ -13,13 +13,24 @@ bad = 0
 for it in range(N):
     h = int(rng.integers(110, 520)); w = int(rng.integers(140, 1300))
     nf = int(rng.choice([60, 200, 500, 1000, 2000])); nl = int(rng.choice([1, 3, 5, 8])); sf = float(rng.choice([1.1, 1.2, 1.2, 1.3]))
-    kind = "noise" if rng.random() < 0.2 else "texture"
-    img = np.ascontiguousarray(synth.random_image(int(rng.integers(1 << 30)), h, w, kind))
+    u = rng.random()
+    kind = "noise" if u < 0.2 else ("texture" if u < 0.55 else "sparse")
+    if kind == "sparse":      # a scene with few rectangles: a few % of FAST corners, the regime of the two-phase FAST path
+        img = np.ascontiguousarray(synth.stereo_batch(1, stream_id=int(rng.integers(1000)), n_rect=int(rng.integers(20, 1500)), h=h, w=w)[0, 0])
+    else:
+        img = np.ascontiguousarray(synth.random_image(int(rng.integers(1 << 30)), h, w, kind))
     try:
         ext = api.ORBextractor(nf, sf, nl)
     except Exception as e:
         print("create failed", h, w, nf, nl, sf, e); continue
     p = o.params(nf); p.scale_factor = sf; p.nlevels = nl
+    mode = int(rng.choice([-1, -1, 0, 1]))
+    ext.set_option(ext.OPT_FAST_MODE, mode)
+    if mode < 0 and rng.random() < 0.5:
+        try:
+            ext.DetectAndCompute(np.ascontiguousarray(synth.random_image(int(rng.integers(1 << 30)), h, w, "noise")))     # primes the path statistics
+        except api.MyslamError:
+            pass
     try:
         gk, gd = ext.DetectAndCompute(img)
     except api.MyslamError as e:
