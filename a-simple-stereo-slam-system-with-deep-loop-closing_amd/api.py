@@ -147,6 +147,10 @@ class ORBextractor:
         """scheduling / debugging knobs (myslam_orb_set_option): none of them changes a result"""
         _check(lib().myslam_orb_set_option(self._h, int(option), int(value)), "myslam_orb_set_option")
 
+    def set_gauss_taps(self, q7=None):
+        q = None if q7 is None else np.ascontiguousarray(q7, np.int32)
+        _check(lib().myslam_orb_set_gauss_taps(self._h, _p(q) if q is not None else None), "myslam_orb_set_gauss_taps")
+
     def tables(self):
         n = self.nlevels
         sc = np.zeros(n, np.float32); isc = np.zeros(n, np.float32); npl = np.zeros(n, np.int32); um = np.zeros(16, np.int32)

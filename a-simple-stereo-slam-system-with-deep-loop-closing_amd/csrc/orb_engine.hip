@@ -112,6 +112,7 @@ struct myslam_orb {
     int optFastMode = -1;              // -1 = chosen per level from the previous launch's statistics, 0 = two-phase, 1 = dense
     int optInternalStream = 2;         // 0 = everything on the caller's stream, 1 = Gaussian pyramid forked after FAST, 2 = after the image pyramid
     int optStopAfter = 0;              // debug: stop a batched call after stage 1 ingest / 2 pyramid / 3 oct-tree / 4 blur (0 = run all)
+    int tapsSet = 0, taps[7] = {0};    // myslam_orb_set_gauss_taps: replacement of the sigma = 2 Q8 taps
 
     // staging for the host-buffer entry points
     uint8_t *d_stageImg = nullptr, *d_stageMask = nullptr; size_t stageImgBytes = 0, stageMaskBytes = 0;
@@ -306,7 +307,7 @@ int myslam_orb::blur_levels(int batch, int nlev, hipStream_t stream) {
         BlurArgs a;
         a.src = d_pyr + P.lv[l].imgOff; a.dst = d_blur + P.lv[l].imgOff;
         a.w = P.lv[l].w; a.h = P.lv[l].h; a.spitch = a.dpitch = P.lv[l].pitch; a.sstride = a.dstride = P.pyrBytes;
-        gauss_q8(0, a.q);
+        if (tapsSet) memcpy(a.q, taps, sizeof(taps)); else gauss_q8(0, a.q);
         launch_blur(a, batch, stream);
     }
     return MYSLAM_OK;
@@ -456,6 +457,17 @@ int myslam_orb_set_option(myslam_orb* h, int option, int value) {
         case MYSLAM_ORB_OPT_STOP_AFTER: if (value < 0 || value > 4) return MYSLAM_ERR_INVALID; h->optStopAfter = value; return MYSLAM_OK;
     }
     return MYSLAM_ERR_INVALID;
+}
+
+int myslam_orb_set_gauss_taps(myslam_orb* h, const int32_t* q7) {
+    if (!h) return MYSLAM_ERR_INVALID;
+    if (!q7) { h->tapsSet = 0; return MYSLAM_OK; }
+    int sum = 0;
+    for (int i = 0; i < 7; i++) { if (q7[i] < 0 || q7[i] > 255) return MYSLAM_ERR_INVALID; sum += q7[i]; }
+    if (sum != 256) return MYSLAM_ERR_INVALID;
+    for (int i = 0; i < 7; i++) h->taps[i] = q7[i];
+    h->tapsSet = 1;
+    return MYSLAM_OK;
 }
 
 int myslam_orb_get_tables(const myslam_orb* h, float* scale, float* inv_scale, int* fpl, int* umax16) {

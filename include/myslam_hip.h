@@ -90,6 +90,11 @@ int myslam_orb_set_fast_gate(myslam_orb* h, void* hip_event);
 #define MYSLAM_ORB_OPT_INTERNAL_STREAM 2
 #define MYSLAM_ORB_OPT_STOP_AFTER 3
 int myslam_orb_set_option(myslam_orb* h, int option, int value);
+/* The 7 x 7 sigma = 2 Gaussian before rBRIEF (ORBextractor.cpp:966, :1197) runs in OpenCV's 8-bit fixed-point form; how OpenCV 3.4.8
+ * rounds the taps to Q8 could not be checked in the build environment (parity unpinned).  Default
+ * [18,34,49,54,49,34,18] (round to nearest, residue on the centre tap).  A maintainer who measures another table with
+ * tools/dump_opencv_goldens.py sets it here (7 ints, 0..255, sum 256; NULL restores the default). */
+int myslam_orb_set_gauss_taps(myslam_orb* h, const int32_t* q7);
 /* getters ORBextractor.h:87-107 */
 int myslam_orb_get_tables(const myslam_orb* h, float* scale, float* inv_scale, int* features_per_level, int* umax16);
 /* upper bound of keypoints DetectAndCompute / Detect can return for one image: sum over levels of

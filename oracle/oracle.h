@@ -60,6 +60,11 @@ int orc_build_pyramid(const orc_orb_params* p, const uint8_t* img, int rows, int
 
 /* ---- FAST (cv::FAST restated, Appendix A.1; predicate mirrored at ORBextractor.cpp:449-511) ---- */
 /* score map of a whole ROI at threshold th: out[y*w+x] = score (>=th) or 0; no NMS. */
+/* replace the sigma = 2 Q8 taps (7 ints, 0..255, sum 256; NULL restores the default [18,34,49,54,49,34,18]) — process global */
+int orc_set_gauss_taps(const int* q7);
+/* FAST score of one pixel: the oracle's definition, and OpenCV's cornerScore<16> including its threshold seed */
+int orc_fast_score_px(const uint8_t* img, int step, int x, int y);
+int orc_fast_score_seeded(const uint8_t* img, int step, int x, int y, int threshold);
 int orc_fast_score_map(const uint8_t* img, int w, int h, int step, int th, uint8_t* out);
 /* cv::FAST(img, th, nonmax=true): row-major list of (x,y,score) */
 int orc_fast_detect(const uint8_t* img, int w, int h, int step, int th,

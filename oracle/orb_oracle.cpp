@@ -136,7 +136,13 @@ int resize_linear(const uint8_t* src, int sw, int sh, int sstep, uint8_t* dst, i
 // ---------------------------------------------------------------------------------------
 // cv::GaussianBlur 8U 7x7 fixed point, Appendix A.3
 // ---------------------------------------------------------------------------------------
+// The sigma = 2 taps are one of the definitions that could not be pinned against OpenCV here (the 8U fixed-point kernel construction
+// is version specific): they can be replaced at run time (orc_set_gauss_taps) so that a maintainer who finds another rounding with
+// tools/dump_opencv_goldens.py changes ONE table on each side.  g_taps_set == 0: the default below.
+int g_taps[7]; int g_taps_set = 0;
+
 void gauss_coeffs(int kind, int q[7]) {
+    if (kind == 0 && g_taps_set) { for (int i = 0; i < 7; i++) q[i] = g_taps[i]; return; }
     if (kind == 1) {   // sigma<=0, ksize 7: OpenCV small_gaussian_tab[3] = {1,3.5,7,9,7,3.5,1}/32
         const int t[7] = {8, 28, 56, 72, 56, 28, 8};
         for (int i = 0; i < 7; i++) q[i] = t[i];
@@ -204,6 +210,34 @@ inline int fast_score_px(const uint8_t* p, int step) {
         best_bright = std::max(best_bright, -mx);  // all 9 have -d > t
     }
     return std::max(best_dark, best_bright) - 1;
+}
+
+// cv::cornerScore<16> as OpenCV 3.4 writes it (fast_score.cpp, scalar path), INCLUDING the threshold seed of the running maxima
+// that the oracle's definition above leaves out.  Used only to show that the seed never matters where the score is used: for a
+// pixel that is a corner at `threshold` both return the same value (tests/test_oracle_kat.py).
+inline int fast_score_px_seeded(const uint8_t* p, int step, int threshold) {
+    const int K = 8, N = K * 3 + 1;
+    int v = p[0], d[N];
+    for (int k = 0; k < N; k++) d[k] = v - p[kRing[k % 16][0] + kRing[k % 16][1] * step];
+    int a0 = threshold;
+    for (int k = 0; k < 16; k += 2) {
+        int a = std::min(d[k + 1], d[k + 2]);
+        a = std::min(a, d[k + 3]);
+        if (a <= a0) continue;
+        a = std::min(a, d[k + 4]); a = std::min(a, d[k + 5]); a = std::min(a, d[k + 6]); a = std::min(a, d[k + 7]); a = std::min(a, d[k + 8]);
+        a0 = std::max(a0, std::min(a, d[k]));
+        a0 = std::max(a0, std::min(a, d[k + 9]));
+    }
+    int b0 = -a0;
+    for (int k = 0; k < 16; k += 2) {
+        int b = std::max(d[k + 1], d[k + 2]);
+        b = std::max(b, d[k + 3]); b = std::max(b, d[k + 4]); b = std::max(b, d[k + 5]);
+        if (b >= b0) continue;
+        b = std::max(b, d[k + 6]); b = std::max(b, d[k + 7]); b = std::max(b, d[k + 8]);
+        b0 = std::min(b0, std::max(b, d[k]));
+        b0 = std::min(b0, std::max(b, d[k + 9]));
+    }
+    return -b0 - 1;
 }
 
 // scores of the detection interior [3,w-3)x[3,h-3) of a ROI; zero elsewhere (OpenCV row buffers)
@@ -619,6 +653,19 @@ const int8_t* orc_orb_pattern(void) { return kPattern; }
 int orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstep, uint8_t* dst, int dw, int dh, int dstep) {
     return resize_linear(src, sw, sh, sstep, dst, dw, dh, dstep);
 }
+
+int orc_set_gauss_taps(const int* q7) {           // NULL = back to the default; taps must be 0..255 and sum to 256
+    if (!q7) { g_taps_set = 0; return 0; }
+    int sum = 0;
+    for (int i = 0; i < 7; i++) { if (q7[i] < 0 || q7[i] > 255) return -1; sum += q7[i]; }
+    if (sum != 256) return -1;
+    for (int i = 0; i < 7; i++) g_taps[i] = q7[i];
+    g_taps_set = 1;
+    return 0;
+}
+
+int orc_fast_score_seeded(const uint8_t* img, int step, int x, int y, int threshold) { return fast_score_px_seeded(img + (size_t)y * step + x, step, threshold); }
+int orc_fast_score_px(const uint8_t* img, int step, int x, int y) { return fast_score_px(img + (size_t)y * step + x, step); }
 
 int orc_gaussian_blur7_u8(const uint8_t* src, int w, int h, int sstep, uint8_t* dst, int dstep, int kind) {
     return gaussian_blur7(src, w, h, sstep, dst, dstep, kind);

@@ -108,6 +108,19 @@ class Oracle:
         return lv
 
     # ---- FAST ----
+    def set_gauss_taps(self, q7=None):
+        """sigma = 2 taps of the ORB blur (process global; None restores the default)"""
+        q = None if q7 is None else np.ascontiguousarray(q7, np.int32)
+        assert self.lib.orc_set_gauss_taps(_p(q) if q is not None else None) == 0
+
+    def fast_score_px(self, img, x, y):
+        img = np.ascontiguousarray(img, np.uint8)
+        return self.lib.orc_fast_score_px(_p(img), img.strides[0], int(x), int(y))
+
+    def fast_score_seeded(self, img, x, y, th):
+        img = np.ascontiguousarray(img, np.uint8)
+        return self.lib.orc_fast_score_seeded(_p(img), img.strides[0], int(x), int(y), int(th))
+
     def fast_score_map(self, img, th):
         img = np.ascontiguousarray(img, np.uint8)
         out = np.zeros_like(img)

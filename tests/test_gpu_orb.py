@@ -334,3 +334,39 @@ def test_two_handles_taking_turns_on_fast(api, oracle, synth):
                                      d_cnt[0].data_ptr(), d_st[0].data_ptr(), cap)
     torch.cuda.synchronize()
     assert (d_st[0].cpu().numpy() == 0).all() and d_cnt[0].cpu().numpy().tolist() == [len(r[0]) for r in ref[0]]
+
+
+def test_gauss_taps_option_matches_oracle(api, oracle, synth):
+    """myslam_orb_set_gauss_taps / orc_set_gauss_taps: the one-table change a maintainer makes when OpenCV's fixed-point Gaussian turns
+    out to round differently (tools/dump_opencv_goldens.py): blurred levels and descriptors follow on both sides, key-points do not move."""
+    img = synth.random_image(321, 240, 320)
+    taps = [18, 34, 48, 56, 48, 34, 18]
+    ext = api.ORBextractor(500)
+    k0, d0 = ext.DetectAndCompute(img)
+    ext.set_gauss_taps(taps)
+    k1, d1 = ext.DetectAndCompute(img)
+    try:
+        oracle.set_gauss_taps(taps)
+        rk, rd = oracle.detect_and_compute(oracle.params(500), img)
+        for l in (0, 5):
+            assert np.array_equal(ext.debug_pyramid(img, l, blurred=True), oracle.blur7(oracle.pyramid(oracle.params(500), img)[l], 0))
+    finally:
+        oracle.set_gauss_taps(None)
+    assert k1.tobytes() == rk.tobytes() and np.array_equal(d1, rd)
+    assert k1.tobytes() == k0.tobytes() and not np.array_equal(d1, d0)
+    ext.set_gauss_taps(None)
+    k2, d2 = ext.DetectAndCompute(img)
+    assert np.array_equal(d2, d0)
+    with pytest.raises(api.MyslamError):
+        ext.set_gauss_taps([18, 34, 49, 55, 49, 34, 18])             # sum 257
+
+
+def test_get_tables(api, oracle):
+    """a1: the constructor tables (ORBextractor.cpp:384-445) through myslam_orb_get_tables"""
+    for nf, sf, nl in ((2000, 1.2, 8), (300, 1.2, 8), (100, 1.2, 8), (1000, 1.5, 4)):
+        sc, isc, npl, um = api.ORBextractor(nf, sf, nl).tables()
+        r = oracle.orb_tables(oracle.params(nf, scale=sf, nlevels=nl))
+        assert np.array_equal(sc.view(np.uint32), np.asarray(r[0], np.float32).view(np.uint32)) and np.array_equal(isc.view(np.uint32), np.asarray(r[1], np.float32).view(np.uint32))
+        assert np.array_equal(npl, r[2]) and np.array_equal(um, r[3])
+    assert api.ORBextractor(2000).tables()[2].tolist() == [434, 362, 302, 251, 209, 175, 145, 122]
+    assert api.ORBextractor(2000).tables()[3].tolist() == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]

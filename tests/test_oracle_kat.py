@@ -639,3 +639,36 @@ def test_pnp_ransac_consensus_and_least_squares_refinement(oracle, synth):
     rc, p, inl, ni = oracle.solve_pnp_ransac(pw, uv, K)
     assert rc == 0 and ni == 50
     assert oracle.solve_pnp_ransac(pw[:4], uv[:4], K)[0] == -2
+
+
+def test_fast_score_threshold_seed_is_irrelevant(oracle, synth):
+    """cv::cornerScore<16> seeds its running maxima with the threshold; the oracle's score leaves the seed out (SURVEY A.1).  For every
+    pixel that IS a corner at the threshold (the only pixels whose score is ever used: cv::FAST scores detections) both give the same
+    value, for both thresholds of the extractor; for non-corners the seeded form returns threshold - 1 and the oracle's map stores 0."""
+    rng = np.random.default_rng(11)
+    for img in (synth.random_image(3, 64, 96), synth.random_image(4, 64, 96, "noise"), synth.stereo_batch(1, n_rect=150, h=64, w=96)[0, 0]):
+        n_corner = 0
+        for _ in range(1500):
+            x = int(rng.integers(3, img.shape[1] - 3)); y = int(rng.integers(3, img.shape[0] - 3))
+            s = oracle.fast_score_px(img, x, y)
+            for th in (7, 20):
+                seeded = oracle.fast_score_seeded(img, x, y, th)
+                if oracle.is_fast_corner(img, x, y, th):
+                    assert s >= th and seeded == s, (x, y, th, s, seeded)
+                    n_corner += 1
+                else:
+                    assert s < th and seeded == th - 1, (x, y, th, s, seeded)
+        assert n_corner > 0
+
+
+def test_gauss_taps_option(oracle, synth):
+    """The sigma = 2 taps are a run-time table on the oracle side as on the device side (myslam_orb_set_gauss_taps): default
+    [18,34,49,54,49,34,18]; e.g. an error-diffusion rounding [18,34,48,56,48,34,18] changes the blurred image."""
+    img = synth.random_image(9, 60, 80)
+    a = oracle.blur7(img, 0)
+    try:
+        oracle.set_gauss_taps([18, 34, 48, 56, 48, 34, 18])
+        b = oracle.blur7(img, 0)
+    finally:
+        oracle.set_gauss_taps(None)
+    assert np.array_equal(oracle.blur7(img, 0), a) and not np.array_equal(a, b) and np.abs(a.astype(int) - b.astype(int)).max() <= 2
