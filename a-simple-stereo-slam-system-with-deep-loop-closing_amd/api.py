@@ -265,6 +265,24 @@ def hamming_filter(dist):
     return keep.astype(bool), mn.value
 
 
+def expand_pyramid_keypoints(feats, nlevels=8):
+    """LoopClosing::ProcessNewKF (loopclosing.cpp:94-105): nlevels pyramid key-points per feature, class_id = feature index"""
+    f = np.ascontiguousarray(feats, KP_DTYPE)
+    out = np.zeros(len(f) * nlevels, KP_DTYPE)
+    _check(lib().myslam_expand_pyramid_keypoints(_p(f), len(f), nlevels, _p(out)), "myslam_expand_pyramid_keypoints")
+    return out
+
+
+def match_feature_pairs(train_idx, dist, loop_pyr_kps, cur_pyr_kps):
+    """LoopClosing::MatchFeatures (loopclosing.cpp:175-194): (current feature id, loop feature id) pairs, std::set order"""
+    ti = np.ascontiguousarray(train_idx, np.int32); d = np.ascontiguousarray(dist, np.int32)
+    lk = np.ascontiguousarray(loop_pyr_kps, KP_DTYPE); ck = np.ascontiguousarray(cur_pyr_kps, KP_DTYPE)
+    assert len(ti) == len(d) == len(lk)
+    pairs = np.zeros((max(len(ti), 1), 2), np.int32); n = C.c_int()
+    _check(lib().myslam_match_feature_pairs(_p(ti), _p(d), len(ti), _p(lk), _p(ck), len(ck), _p(pairs), C.byref(n)), "myslam_match_feature_pairs")
+    return pairs[:n.value].copy()
+
+
 def triangulate_stereo(xl, yl, xr, yr, fx, fy, cx, cy, baseline):
     xl, yl, xr, yr = [np.ascontiguousarray(a, np.float32) for a in (xl, yl, xr, yr)]
     n = len(xl)

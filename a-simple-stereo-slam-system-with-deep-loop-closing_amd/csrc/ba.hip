@@ -244,12 +244,11 @@ __device__ void pose_oplus(double* T, const double* d) {
 //             chunks and adds it to S once at the end (8 partial sums per entry).
 //   Cholesky  6x6-blocked right-looking factorisation of the 6P x 6P lower triangle (3 barriers per block column).
 //   solve     one wave, lane = row, shuffles; landmark back-substitution one thread per landmark.
-#ifdef MYSLAM_BA_TIMING           // developer aid: per-phase s_memtime ticks of window 0 go to the tail of its scratch
-#define BA_TICK(i) do { if (w == 0 && t == 0) { const long long now_ = (long long)__builtin_readcyclecounter(); tk[i] += now_ - tlast; tlast = now_; } } while (0)
-#else
-#define BA_TICK(i) do { } while (0)
-#endif
 
+// GL = false: the whole state lives in LDS (windows of up to ~700 landmarks at 7 key-frames).  GL = true: the per-landmark arrays
+// (points, backups, Hll, bl, G, edge ranges: 22 doubles per landmark) live in the window's HBM scratch behind the pose-sorted edge list
+// instead — slower, but a window of the reference's size (7 key-frames x ~150 new features each, backend.cpp:134-135) still fits.
+template <bool GL>
 __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
     extern __shared__ __attribute__((aligned(16))) double s_d[];
     __shared__ double s_red[BA_NW];
@@ -265,18 +264,19 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
     double* sRb = sR + a.maxP * 12;
     double* sHpp = sRb + a.maxP * 12;         // maxP x 21
     double* sbp = sHpp + a.maxP * 21;         // maxP x 6
-    double* sPt = sbp + a.maxP * 6;           // maxL x 3
+    double* const lmBase = GL ? a.W + (size_t)w * a.maxE * 18 + ((size_t)a.maxE + 1) / 2 + 8 : sbp + a.maxP * 6;      // behind plist / in LDS
+    double* sPt = lmBase;                     // maxL x 3
     double* sPtb = sPt + a.maxL * 3;
     double* sHll = sPtb + a.maxL * 3;         // maxL x 6
     double* sbl = sHll + a.maxL * 6;          // maxL x 3
     double* sG = sbl + a.maxL * 3;            // maxL x 6   upper-triangular G (g00 g01 g02 g11 g12 g22)
-    double* sS = sG + a.maxL * 6;             // (6 maxP)^2
+    double* sS = GL ? sbp + a.maxP * 6 : sG + a.maxL * 6;             // (6 maxP)^2
     double* srhs = sS + 36 * a.maxP * a.maxP; // 6 maxP
     double* sLinv = srhs + 6 * a.maxP;        // maxP x 21  inverses of the diagonal blocks of chol(S)
     double* sy = sLinv + 21 * a.maxP;         // 3 BA_CL    G^T bl of the chunk's landmarks
     double* sV = sy + 3 * BA_CL;              // vrows x BA_VS: V of the chunk, row = 6 pose + r, column = 3 landmark + c
     const int vrows = 16 * ((6 * a.maxP + 15) / 16);
-    int* lbeg = reinterpret_cast<int*>(sV + vrows * BA_VS);   // maxL
+    int* lbeg = reinterpret_cast<int*>(GL ? sG + a.maxL * 6 : sV + vrows * BA_VS);   // maxL
     int* lend = lbeg + a.maxL;
     double* poses = a.poses + (size_t)w * a.maxP * 7;
     double* pts = a.points + (size_t)w * a.maxL * 3;
@@ -286,9 +286,6 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
     const uint8_t* fixed = a.fixed ? a.fixed + (size_t)w * a.maxL : nullptr;
     int* plist = reinterpret_cast<int*>(a.W + (size_t)w * a.maxE * 18);     // edges sorted by pose (stable)
     const double d2 = a.delta * a.delta;
-#ifdef MYSLAM_BA_TIMING
-    long long tk[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = (long long)__builtin_readcyclecounter();
-#endif
 
     // ---- load state, landmark -> edge range ----
     for (int p = t; p < P; p += BA_NT) {
@@ -364,7 +361,6 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
         return block_sum(acc, s_red);
     };
 
-    BA_TICK(0);
     const int nb = (n + 15) / 16;                       // 16-row blocks of the reduced system
 
     int it = 0, rnd = 0, cntOut = 0;
@@ -445,7 +441,6 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
         }
         if (t == 0) s_sc[2] = curChi0;
         __syncthreads();
-        BA_TICK(1);
 
         int qmax = 0;
         double rho = 0;
@@ -481,7 +476,6 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
                 g[0] = m00; g[1] = m10; g[2] = m20; g[3] = m11; g[4] = m21; g[5] = m22;
             }
             __syncthreads();
-            BA_TICK(2);
             // ---- Schur complement S -= V V^T, rhs -= V y on the f64 matrix cores, chunk by chunk ----
             // 16x16 tiles of the lower triangle, q -> (ti,tj): 0:(0,0) 1:(1,0) 2:(1,1) 3:(2,0) 4:(2,1) 5:(2,2) 6:(3,0) 7:(3,1) 8:(3,2) 9:(3,3).
             // wave wv owns tile wv for all k; tiles 8 and 9 (only when nb == 4) are split over k between the 8 waves, which
@@ -537,7 +531,6 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
                     }
                 }
                 __syncthreads();
-                BA_TICK(3);
                 if (own) {
                     const double* pa = sV + (size_t)(16 * ti + (lane & 15)) * BA_VS + (lane >> 4);
                     const double* pb = sV + (size_t)(16 * tj + (lane & 15)) * BA_VS + (lane >> 4);
@@ -560,7 +553,6 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
                     }
                 }
                 __syncthreads();
-                BA_TICK(4);
             }
             // flush: D row = (lane>>4) + 4 v, col = lane & 15.  Owned tiles subtract directly; the split tiles go through LDS.
             if (own) {
@@ -593,7 +585,6 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
                 }
             }
             __syncthreads();
-            BA_TICK(5);
             // ---- blocked Cholesky of S (lower triangle), 6x6 blocks.  Every panel thread factors the diagonal block
             // redundantly in registers (same latency as one thread doing it, one barrier less per block column) ----
             for (int jb = 0; jb < P; jb++) {
@@ -668,7 +659,6 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
                 }
                 __syncthreads();
             }
-            BA_TICK(6);
             // block forward / backward substitution by one wave (lane = row); values move over readlane
             if (t < 64) {
                 double y = (t < n) ? srhs[t] : 0.0;
@@ -716,7 +706,6 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
                 if (t < n) srhs[t] = y;               // xp
             }
             __syncthreads();
-            BA_TICK(7);
             const bool ok = s_sc[5] != 0.0;
             // xl = Hinv (bl - W^T xp); scale = x^T (lambda x + b); oplus on the landmarks
             double sc = 0;
@@ -761,7 +750,6 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
                 for (int i = t; i < L * 3; i += BA_NT) sPt[i] = sPtb[i];
             }
             __syncthreads();
-            BA_TICK(8);
             qmax++;
         } while (rho < 0 && qmax < 10 && isfinite(s_sc[0]));
         if (qmax == 10 || rho == 0 || !isfinite(s_sc[0])) { it++; break; }
@@ -796,28 +784,31 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
     }
     for (int i = t; i < 3 * L; i += BA_NT) pts[i] = sPt[i];
     if (t == 0) { if (a.final_chi2) a.final_chi2[w] = fin; if (a.iters) a.iters[w] = it; a.status[w] = MYSLAM_OK; }
-#ifdef MYSLAM_BA_TIMING
-    BA_TICK(9);
-    if (w == 0 && t == 0) for (int i = 0; i < 10; i++) a.W[(size_t)a.maxE * 18 - 10 + i] = (double)tk[i];
-#endif
 }
 
-static size_t ba_opt_lds(int maxP, int maxL) {
+static size_t ba_opt_lds(int maxP, int maxL, bool gl) {
     const size_t vrows = 16 * (((size_t)6 * maxP + 15) / 16);
-    return sizeof(double) * ((size_t)maxP * (12 + 12 + 21 + 6) + (size_t)maxL * (3 + 3 + 6 + 3 + 6) + 36 * (size_t)maxP * maxP + (6 + 21) * (size_t)maxP +
+    const size_t lm = gl ? 0 : (size_t)maxL;           // per-landmark arrays in HBM scratch instead
+    return sizeof(double) * ((size_t)maxP * (12 + 12 + 21 + 6) + lm * (3 + 3 + 6 + 3 + 6) + 36 * (size_t)maxP * maxP + (6 + 21) * (size_t)maxP +
                              3 * BA_CL + vrows * BA_VS) +
-           sizeof(int) * (2 * (size_t)maxL);
+           sizeof(int) * (2 * lm);
 }
 
 static int ba_opt_launch(const BaOptArgs& a, int nwin, hipStream_t s) {
     if (a.maxP > 10) return MYSLAM_ERR_CAPACITY;          // substitution runs on one wave: 6P <= 64; 55 pose pairs x 8 slices <= 512 threads
-    const size_t lds = ba_opt_lds(a.maxP, a.maxL);
-    if (lds > 160 * 1024 - 512) return MYSLAM_ERR_CAPACITY;
+    size_t lds = ba_opt_lds(a.maxP, a.maxL, false);
+    const bool gl = lds > 160 * 1024 - 512;                // large window: per-landmark state goes to the HBM scratch
+    if (gl) {
+        lds = ba_opt_lds(a.maxP, a.maxL, true);
+        // the scratch (maxE x 18 doubles per window) must hold the pose-sorted edge list + 22 doubles per landmark
+        if (((size_t)a.maxE + 1) / 2 + 8 + 22 * (size_t)a.maxL + 2 > (size_t)a.maxE * 18 || lds > 160 * 1024 - 512) return MYSLAM_ERR_CAPACITY;
+    }
+    const void* fn = gl ? reinterpret_cast<const void*>(k_ba_optimize<true>) : reinterpret_cast<const void*>(k_ba_optimize<false>);
     // the attribute is per device and per process: set it on every launch that needs it (cheap, re-entrant, multi-GPU safe)
-    if (lds > 48 * 1024)
-        MYSLAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_optimize), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 48 * 1024) MYSLAM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ScopedProf sp(P_BA, s);
-    hipLaunchKernelGGL(k_ba_optimize, dim3(nwin), dim3(BA_NT), lds, s, a);
+    if (gl) hipLaunchKernelGGL(k_ba_optimize<true>, dim3(nwin), dim3(BA_NT), lds, s, a);
+    else hipLaunchKernelGGL(k_ba_optimize<false>, dim3(nwin), dim3(BA_NT), lds, s, a);
     MYSLAM_HIP_CHECK(hipGetLastError());
     return MYSLAM_OK;
 }

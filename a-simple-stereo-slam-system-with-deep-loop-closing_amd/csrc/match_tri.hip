@@ -7,6 +7,8 @@
 // stereo rig (src/system.cpp:108-116,141-145): DLT 4x4, smallest right singular vector by one-sided
 // Jacobi in f64, accept iff sigma3/sigma2 < 1e-2 and z > 0 (src/frontend.cpp:400,471).
 #include <algorithm>
+#include <utility>
+#include <vector>
 
 #include "common.h"
 
@@ -271,6 +273,43 @@ int myslam_hamming_filter(const int32_t* dist, int n, uint8_t* keep, int* min_di
     const double lim = std::max(2.0 * (double)mn, 30.0);
     for (int i = 0; i < n; i++) keep[i] = ((double)dist[i] <= lim) ? 1 : 0;
     if (min_dist) *min_dist = mn;
+    return MYSLAM_OK;
+}
+
+// LoopClosing::ProcessNewKF, src/loopclosing.cpp:94-105: every single-layer feature of the key-frame becomes nlevels pyramid key-points
+// (octave = level, response = -1, class_id = index of the feature) — the input of ScreenAndComputeKPsParams.  Host bookkeeping.
+int myslam_expand_pyramid_keypoints(const myslam_keypoint* feats, int n, int nlevels, myslam_keypoint* out /* n * nlevels */) {
+    if (n < 0 || nlevels < 1 || (n > 0 && (!feats || !out))) return MYSLAM_ERR_INVALID;
+    for (int i = 0; i < n; i++)
+        for (int l = 0; l < nlevels; l++) {
+            myslam_keypoint kp = feats[i];
+            kp.octave = l; kp.response = -1.f; kp.class_id = i;
+            out[(size_t)i * nlevels + l] = kp;
+        }
+    return MYSLAM_OK;
+}
+
+// LoopClosing::MatchFeatures, src/loopclosing.cpp:172-203, after the matcher: keep matches with distance <= max(2 * min_dist, 30),
+// map both sides to their FEATURE ids through class_id and insert (current, loop) into a std::set — one entry per feature pair, in the
+// set's order (ascending current id, then loop id), which is the order ComputeCorrectPose walks (:215-238).  query = loop key-frame's
+// pyramid key-points, train = current key-frame's.  Returns MYSLAM_OK; the caller applies the `< 10 matches` rule (:196).
+int myslam_match_feature_pairs(const int32_t* train_idx, const int32_t* dist, int n_query, const myslam_keypoint* loop_pyr_kps,
+                               const myslam_keypoint* cur_pyr_kps, int n_train, int32_t* pairs /* n_query x 2: (current, loop) */, int* n_pairs) {
+    if (n_query < 0 || !n_pairs || (n_query > 0 && (!train_idx || !dist || !loop_pyr_kps || !cur_pyr_kps || !pairs))) return MYSLAM_ERR_INVALID;
+    *n_pairs = 0;
+    if (n_query == 0) return MYSLAM_OK;
+    int mn = dist[0];
+    for (int i = 1; i < n_query; i++) mn = std::min(mn, dist[i]);
+    const double lim = std::max(2.0 * (double)mn, 30.0);
+    std::vector<std::pair<int, int>> v;
+    for (int i = 0; i < n_query; i++) {
+        if (train_idx[i] < 0 || train_idx[i] >= n_train) return MYSLAM_ERR_INVALID;
+        if ((double)dist[i] <= lim) v.emplace_back(cur_pyr_kps[train_idx[i]].class_id, loop_pyr_kps[i].class_id);
+    }
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+    for (size_t k = 0; k < v.size(); k++) { pairs[2 * k] = v[k].first; pairs[2 * k + 1] = v[k].second; }
+    *n_pairs = (int)v.size();
     return MYSLAM_OK;
 }
 

@@ -301,3 +301,90 @@ def pnp_problem(n=120, outlier_frac=0.3, noise_px=0.5, seed=0x919, K=KITTI00, w=
         good[idx] = False
     T = np.eye(4); T[:3, :3] = Rcw; T[:3, 3] = tcw
     return pw.astype(np.float32), uv.astype(np.float32), Kt, _T_to_pose7(T), good
+
+
+# ---- a geometrically consistent stereo SEQUENCE with ground truth (the stand-in for BASELINE configs[0], KITTI-00) ----------------------
+# World: ONE continuous textured wall whose depth zig-zags along x (a piecewise-linear profile Z(X): no occlusion edges, every pixel
+# has a well-defined depth).  The rig (left camera + right camera `baseline` to its right) moves out along the wall and back to its
+# start, with a small yaw.  Every pixel is the bilinear sample of the wall point its viewing ray hits, so LK tracks, stereo
+# disparities, triangulated landmarks and camera poses are mutually consistent and the true poses are known.
+
+SEQ_K = {"fx": 420.0, "fy": 420.0, "cx": 359.5, "cy": 119.5, "bf": 420.0 * 0.54}       # a 720 x 240 camera, 0.54 m baseline
+
+
+def sequence_scene(seed=0x5E0, tex_w=4096, tex_h=1024, texels_per_m=40.0):
+    rng = _rng(seed)
+    xs = [-45.0]
+    while xs[-1] < 55.0:
+        xs.append(xs[-1] + rng.uniform(3.0, 7.0))
+    xs = np.array(xs)
+    zs = np.empty(len(xs)); zs[0] = 14.0
+    for i in range(1, len(xs)):                       # depth between 8 and 24 m, slope at most 1.0
+        lo = max(8.0, zs[i - 1] - (xs[i] - xs[i - 1])); hi = min(24.0, zs[i - 1] + (xs[i] - xs[i - 1]))
+        zs[i] = rng.uniform(lo, hi)
+    seg = np.sqrt(np.diff(xs) ** 2 + np.diff(zs) ** 2)
+    arc = np.concatenate([[0.0], np.cumsum(seg)])     # arc length of the wall at every knot: the texture is not stretched by the slant
+    t = 128.0 + 50.0 * (_value_noise(rng, tex_h, tex_w, 64) + 0.5 * _value_noise(rng, tex_h, tex_w, 16) + 0.25 * _value_noise(rng, tex_h, tex_w, 4)) / 1.75
+    nr = 9000
+    rx = rng.integers(0, tex_w, nr); ry = rng.integers(0, tex_h, nr); sw = rng.integers(4, 36, nr); sh = rng.integers(4, 36, nr)
+    val = rng.uniform(-80.0, 80.0, nr)
+    diff = np.zeros((tex_h + 1, tex_w + 1))
+    np.add.at(diff, (ry, rx), val); np.add.at(diff, (ry, np.minimum(rx + sw, tex_w)), -val)
+    np.add.at(diff, (np.minimum(ry + sh, tex_h), rx), -val); np.add.at(diff, (np.minimum(ry + sh, tex_h), np.minimum(rx + sw, tex_w)), val)
+    t += np.cumsum(np.cumsum(diff, axis=0), axis=1)[:tex_h, :tex_w]
+    return {"x": xs, "z": zs, "arc": arc, "tex": t, "texels_per_m": texels_per_m}
+
+
+def sequence_poses(n=200):
+    """camera position [x, y, z] and yaw of frame t: out to the right along the wall and back on the same track, ending where it started"""
+    t = np.arange(n) / (n - 1)
+    x = 6.0 * (0.5 - 0.5 * np.cos(2 * np.pi * t))                                      # 0 -> 6 m -> 0
+    zc = 0.8 * np.sin(2 * np.pi * t)
+    yaw = np.deg2rad(2.0) * np.sin(4 * np.pi * t)
+    return np.stack([x, np.zeros(n), zc], 1), yaw
+
+
+def pose7_from_twc(c, yaw):
+    """(qx qy qz qw tx ty tz) of Tcw for a camera at position c with yaw (rotation about the camera's y axis)"""
+    Rwc = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]])
+    Rcw = Rwc.T
+    return np.concatenate([_R_to_quat(Rcw), -Rcw @ np.asarray(c, float)])
+
+
+def sequence_depth(scene, c, yaw, u, K=SEQ_K):
+    """(lambda, arc-length coordinate) of the wall point seen at image column(s) u: the ray c + lambda * (dx, yn, dz) meets Z(X)"""
+    xn = (np.asarray(u, float) - K["cx"]) / K["fx"]
+    dx = np.cos(yaw) * xn + np.sin(yaw); dz = -np.sin(yaw) * xn + np.cos(yaw)
+    xs, zs, arc = scene["x"], scene["z"], scene["arc"]
+    best = np.full(xn.shape, np.inf); sarc = np.zeros(xn.shape)
+    for k in range(len(xs) - 1):
+        m = (zs[k + 1] - zs[k]) / (xs[k + 1] - xs[k])
+        den = dz - m * dx
+        lam = (zs[k] + m * (c[0] - xs[k]) - c[2]) / np.where(np.abs(den) < 1e-9, 1e-9, den)
+        X = c[0] + lam * dx
+        hit = (lam > 0.5) & (X >= xs[k]) & (X <= xs[k + 1]) & (lam < best)
+        best = np.where(hit, lam, best)
+        sarc = np.where(hit, arc[k] + (X - xs[k]) * np.sqrt(1 + m * m), sarc)
+    return best, sarc
+
+
+def render_camera(scene, c, yaw, h=240, w=720, K=SEQ_K, noise_seed=None):
+    lam, sarc = sequence_depth(scene, c, yaw, np.arange(w), K)
+    yn = (np.arange(h) - K["cy"]) / K["fy"]
+    tex = scene["tex"]; TH, TW = tex.shape
+    s = scene["texels_per_m"]
+    tu = np.mod(sarc * s, TW - 1)[None, :].repeat(h, 0)
+    tv = np.mod((c[1] + lam[None, :] * yn[:, None]) * s + TH / 2, TH - 1)
+    u0 = np.floor(tu).astype(int); v0 = np.floor(tv).astype(int); fu = tu - u0; fv = tv - v0
+    img = (tex[v0, u0] * (1 - fu) + tex[v0, u0 + 1] * fu) * (1 - fv) + (tex[v0 + 1, u0] * (1 - fu) + tex[v0 + 1, u0 + 1] * fu) * fv
+    if noise_seed is not None:
+        img = img + _rng(noise_seed).uniform(-1.5, 1.5, size=img.shape)
+    return np.ascontiguousarray(np.clip(np.rint(img), 0, 255).astype(np.uint8))
+
+
+def render_stereo(scene, c, yaw, t=0, **kw):
+    """(left, right) of the rig at position c / yaw; the right camera sits `baseline` along the rig's x axis"""
+    K = kw.get("K", SEQ_K)
+    bl = K["bf"] / K["fx"]
+    cr = np.asarray(c, float) + bl * np.array([np.cos(yaw), 0.0, -np.sin(yaw)])
+    return render_camera(scene, c, yaw, noise_seed=1000 + 2 * t, **kw), render_camera(scene, cr, yaw, noise_seed=1001 + 2 * t, **kw)

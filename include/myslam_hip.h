@@ -159,6 +159,16 @@ int myslam_hamming_match_batch(const uint8_t* d_q, const int32_t* d_nq, const ui
 /* keep[i] = dist[i] <= max(2*min_dist, 30.0)   (loopclosing.cpp:175-186); host-side bookkeeping */
 int myslam_hamming_filter(const int32_t* dist, int n, uint8_t* keep, int* min_dist);
 
+/* Key-frame / feature bookkeeping of the loop closer around the two calls above (KeyFrame::mvPyramidKeyPoints,
+ * cv::KeyPoint::class_id as the feature index).  Host functions, no device work.
+ * expand: LoopClosing::ProcessNewKF src/loopclosing.cpp:94-105 — out[i * nlevels + l] = feats[i] with octave = l, response = -1,
+ *         class_id = i (the input of myslam_orb_screen_and_compute_params).
+ * pairs : LoopClosing::MatchFeatures :175-194 — matches with distance <= max(2 * min_dist, 30) mapped to (current feature id, loop
+ *         feature id) through class_id, de-duplicated and ordered as the reference's std::set<std::pair<int,int>> iterates. */
+int myslam_expand_pyramid_keypoints(const myslam_keypoint* feats, int n, int nlevels, myslam_keypoint* out);
+int myslam_match_feature_pairs(const int32_t* train_idx, const int32_t* dist, int n_query, const myslam_keypoint* loop_pyr_kps,
+                               const myslam_keypoint* cur_pyr_kps, int n_train, int32_t* pairs, int* n_pairs);
+
 /* ------------------------------------------------------------------------------------------
  * Triangulation — replaces triangulation() include/myslam/algorithm.h:16-33 with the stereo rig
  * of src/system.cpp:108-116,141-145 and Camera::pixel2camera src/camera.cpp:22-26.

@@ -183,3 +183,14 @@ def test_ba_duplicate_edges_and_degenerate_landmarks(api, oracle, synth):
     p1 = api.ba_optimize(poses[:1], pts, np.zeros_like(ep[el < 30]), el[el < 30], obs[el < 30], fixed, K, iters=5)      # one pose
     r1 = oracle.ba_optimize(poses[:1], pts, np.zeros_like(ep[el < 30]), el[el < 30], obs[el < 30], fixed, K, iters=5)
     assert p1[3] == r1[3] and np.allclose(p1[0], r1[0], rtol=1e-6, atol=1e-7)
+
+
+def test_large_window_uses_hbm_scratch(api, oracle, synth):
+    """A window of the reference's own size (7 key-frames, ~1000 active map points: 7 x ~150 new features per key-frame,
+    backend.cpp:134-135) does not fit the all-in-LDS solver: the per-landmark state moves to the HBM scratch, same results."""
+    poses, pts, ep, el, obs, fixed, Kt = synth.ba_problem(seed=0xB16, n_kf=7, n_mp=1100)
+    gp, gx, gchi, gout, gr, gn = api.ba_optimize_active_map(poses, pts, ep, el, obs, fixed, Kt)
+    rp, rx, rchi, rout, rr, rn = oracle.ba_optimize_active_map(poses, pts, ep, el, obs, fixed, Kt)
+    assert gr == rr and np.allclose(gp, rp, rtol=1e-7, atol=1e-9) and np.allclose(gx, rx, rtol=1e-7, atol=1e-8)
+    far = np.abs(rchi - 5.991) > 1e-6
+    assert np.array_equal(gout[far], rout[far]) and abs(gn - rn) <= int((~far).sum())

@@ -1,0 +1,68 @@
+"""Composition parity (the stand-in for BASELINE configs[0], KITTI-00 first 200 pairs — neither the data set nor a reference build
+exists here): a synthetic 200-frame stereo sequence with known camera poses is tracked, mapped and loop-closed through the whole
+operator chain (tests/sequence_chain.py) twice — through the HIP library and through the CPU oracle — and the two logs must agree
+entry by entry: key-points, LK tracks, outlier flags, descriptors, matches and consensus sets identically; landmarks and SE3 poses
+within 1e-6; the pose graph within the bars of its operator test.  The estimated trajectory is also compared with the ground truth."""
+import numpy as np
+import pytest
+
+import sequence_chain as sc
+
+pytestmark = pytest.mark.gpu
+
+N_FRAMES = 200
+EXACT = {"detect", "lk_right", "lk_track", "loop_match"}
+
+
+def _frames(synth, n):
+    scene = synth.sequence_scene()
+    C, yaw = synth.sequence_poses(n)
+    return [synth.render_stereo(scene, C[t], yaw[t], t) for t in range(n)], C, yaw
+
+
+def _ate(poses7, C, yaw, synth):
+    """RMSE of the camera centres against the ground truth, both expressed in the frame of camera 0"""
+    T0 = sc.T_of(synth.pose7_from_twc(C[0], yaw[0]))
+    est = np.array([np.linalg.inv(sc.T_of(p))[:3, 3] for p in poses7])
+    gt = np.array([np.linalg.inv(sc.T_of(synth.pose7_from_twc(C[t], yaw[t])) @ np.linalg.inv(T0))[:3, 3] for t in range(len(poses7))])
+    return float(np.sqrt(np.mean(np.sum((est - gt) ** 2, axis=1)))), float(np.abs(est - gt).max())
+
+
+def test_sequence_chain_hip_equals_oracle(api, oracle, synth, pkg):
+    frames, C, yaw = _frames(synth, N_FRAMES)
+    w = synth.calc_weights()
+    K = synth.SEQ_K
+    a = sc.Chain(sc.HipBackend(api, w), pkg.api, K, frames).run()
+    b = sc.Chain(sc.OracleBackend(oracle, w), pkg.api, K, frames).run()
+    assert len(a.log) == len(b.log) and len(a.kfs) == len(b.kfs) == (N_FRAMES - 1) // 6 + 1
+    counts = {}
+    for (ta, xa), (tb, xb) in zip(a.log, b.log):
+        assert ta == tb and len(xa) == len(xb), (ta, tb)
+        counts[ta] = counts.get(ta, 0) + 1
+        for i, (u, v) in enumerate(zip(xa, xb)):
+            assert u.shape == v.shape, (ta, counts[ta], i, u.shape, v.shape)
+            if ta == "pgo" and i == 2:
+                continue        # iterations done: at the rounding floor of chi2 Levenberg gives up at a noise-dependent iteration
+            if ta in EXACT or u.dtype.kind in "biuV" or u.dtype.names:
+                assert u.tobytes() == v.tobytes(), f"{ta} #{counts[ta]} output {i} differs"
+            elif ta == "lcd":
+                assert np.abs(u - v).max() < 2e-5, (ta, counts[ta], i)
+            elif ta == "pgo":
+                tol = 5e-4 if i == 0 else max(1e-9, 1e-3 * abs(float(v.ravel()[0])))
+                assert np.abs(u - v).max() <= tol, (ta, i, np.abs(u - v).max())
+            elif ta == "correct_points":
+                assert np.abs(u - v).max() < 5e-3, (ta, np.abs(u - v).max())
+            else:                                                   # poses, landmarks, chi2 values
+                assert np.allclose(u, v, rtol=1e-6, atol=1e-6), (ta, counts[ta], i, np.abs(u - v).max())
+    assert counts["pose_only"] == N_FRAMES - 1 and counts["ba"] == len(a.kfs) - 1 and counts["lcd"] == len(a.kfs)
+    assert a.n_loop_matches >= 10                                   # loopclosing.cpp:245: the loop is only closed with >= 10 3D-2D matches
+    for pa, pb in zip(a.poses, b.poses):
+        assert np.allclose(pa, pb, rtol=1e-6, atol=1e-6)
+    rmse, worst = _ate(a.poses, C, yaw, synth)
+    rmse_o, _ = _ate(b.poses, C, yaw, synth)
+    print(f"sequence: {N_FRAMES} frames, {len(a.kfs)} key-frames, {len(a.points)} landmarks, {a.n_loop_matches} loop matches; "
+          f"ATE rmse {rmse:.4f} m (oracle chain {rmse_o:.4f} m), worst {worst:.4f} m over a {float(np.abs(C).max()):.1f} m excursion")
+    # the reference's local BA optimises left-camera reprojections only and fixes no key-frame (backend.cpp:137-177): until the window
+    # slides past the first key-frames its similarity gauge is free, which shows as a scale drift of the whole track — a property of
+    # the reference algorithm on this sequence that both chains share; the bar here is only "tracking did not break"
+    assert rmse < 1.5 and abs(rmse - rmse_o) < 1e-5
