@@ -601,6 +601,15 @@ def correct_map_points(old_poses, new_poses, first_kf, points):
     return points
 
 
+def loop_local_fusion(active_poses, cur, corrected_cur, first_active_kf, points):
+    """LoopClosing::LoopLocalFusion (src/loopclosing.cpp:466-507), arithmetic part: returns (corrected active poses, corrected points)"""
+    poses = np.ascontiguousarray(active_poses, np.float64).reshape(-1, 7).copy(); cc = np.ascontiguousarray(corrected_cur, np.float64)
+    kf = np.ascontiguousarray(first_active_kf, np.int32); pts = np.ascontiguousarray(points, np.float64).reshape(-1, 3).copy()
+    assert len(kf) == len(pts)
+    _check(lib().myslam_loop_local_fusion(_p(poses), len(poses), int(cur), _p(cc), _p(kf), _p(pts), len(pts)), "myslam_loop_local_fusion")
+    return poses, pts
+
+
 def solve_pnp_ransac(pts3d, pts2d, K, iterations=100, reproj_error=5.991, confidence=0.99):
     """cv::solvePnPRansac as LoopClosing::ComputeCorrectPose calls it (src/loopclosing.cpp:262-268).
     Returns (pose7 Tcw, inlier flags, inlier count); raises MyslamError(UNSUPPORTED) when no model exists."""

@@ -361,13 +361,17 @@ int myslam_lk_track(myslam_lk* h, const uint8_t* prev, const uint8_t* next, int 
     if (!h || n < 0 || (n > 0 && (!prev_pts || !next_pts || !status))) return MYSLAM_ERR_INVALID;
     if (n == 0) return MYSLAM_OK;
     if (!prev || !next || rows < 1 || cols < 1 || prev_step < cols || next_step < cols) return MYSLAM_ERR_INVALID;
-    const size_t ib = (size_t)rows * cols;
-    if (2 * ib > h->imgBytes) {
+    // both images travel as ONE contiguous copy each with their own row pitch (a 2-D copy from pageable memory goes row by row: 5 ms
+    // for a 1241 x 376 pair against 0.1 ms), the kernels read them with that pitch
+    const size_t pb = ((size_t)rows * prev_step + 255) & ~(size_t)255, nb = (size_t)rows * next_step;
+    if (pb + nb > h->imgBytes) {
+        MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
         if (h->d_img) (void)hipFree(h->d_img);
         h->d_img = nullptr; h->imgBytes = 0;
-        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_img, 2 * ib)); h->imgBytes = 2 * ib;
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_img, pb + nb)); h->imgBytes = pb + nb;
     }
     if (n > h->ptsCap) {
+        MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
         if (h->d_pts) (void)hipFree(h->d_pts);
         if (h->d_st) (void)hipFree(h->d_st);
         h->d_pts = nullptr; h->d_st = nullptr; h->ptsCap = 0;
@@ -375,12 +379,12 @@ int myslam_lk_track(myslam_lk* h, const uint8_t* prev, const uint8_t* next, int 
         h->ptsCap = n;
     }
     hipStream_t s = h->stream;
-    MYSLAM_HIP_CHECK(hipMemcpy2DAsync(h->d_img, cols, prev, prev_step, cols, rows, hipMemcpyHostToDevice, s));
-    MYSLAM_HIP_CHECK(hipMemcpy2DAsync(h->d_img + ib, cols, next, next_step, cols, rows, hipMemcpyHostToDevice, s));
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_img, prev, (size_t)rows * prev_step - (size_t)(prev_step - cols), hipMemcpyHostToDevice, s));      // the last row ends at its last pixel
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_img + pb, next, (size_t)rows * next_step - (size_t)(next_step - cols), hipMemcpyHostToDevice, s));
     float* d_pp = h->d_pts; float* d_np = d_pp + 2 * (size_t)h->ptsCap; float* d_err = d_np + 2 * (size_t)h->ptsCap;
     MYSLAM_HIP_CHECK(hipMemcpyAsync(d_pp, prev_pts, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
     MYSLAM_HIP_CHECK(hipMemcpyAsync(d_np, next_pts, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
-    int rc = lk_run(h, h->d_img, h->d_img + ib, 1, rows, cols, cols, cols, ib, ib, d_pp, d_np, nullptr, n, n, h->d_st, d_err);
+    int rc = lk_run(h, h->d_img, h->d_img + pb, 1, rows, cols, prev_step, next_step, pb, nb, d_pp, d_np, nullptr, n, n, h->d_st, d_err);
     if (rc) return rc;
     MYSLAM_HIP_CHECK(hipMemcpyAsync(next_pts, d_np, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, s));
     MYSLAM_HIP_CHECK(hipMemcpyAsync(status, h->d_st, n, hipMemcpyDeviceToHost, s));

@@ -864,6 +864,68 @@ int myslam_pose_graph_optimize(double* poses, int n, const uint8_t* fixed, const
     return MYSLAM_OK;
 }
 
+// LoopClosing::LoopLocalFusion, src/loopclosing.cpp:466-507 (the arithmetic; the re-linking of observations :509-532 is Map bookkeeping
+// and stays with the integrator).  A handful of SE3 products on the host (unit quaternion + translation, renormalised after every
+// product as Sophus does), the map points on the device.
+namespace {
+struct HostSE3 { double q[4], t[3]; };
+inline void h_rot(const double* q, const double* v, double* out) {
+    double uv[3] = {q[1] * v[2] - q[2] * v[1], q[2] * v[0] - q[0] * v[2], q[0] * v[1] - q[1] * v[0]};
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+    out[0] = v[0] + q[3] * uv[0] + (q[1] * uv[2] - q[2] * uv[1]);
+    out[1] = v[1] + q[3] * uv[1] + (q[2] * uv[0] - q[0] * uv[2]);
+    out[2] = v[2] + q[3] * uv[2] + (q[0] * uv[1] - q[1] * uv[0]);
+}
+inline HostSE3 h_load(const double* p) {
+    HostSE3 r;
+    const double n = sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2] + p[3] * p[3]);
+    for (int k = 0; k < 4; k++) r.q[k] = p[k] / n;
+    for (int k = 0; k < 3; k++) r.t[k] = p[4 + k];
+    return r;
+}
+inline HostSE3 h_mul(const HostSE3& a, const HostSE3& b) {
+    HostSE3 r;
+    r.q[3] = a.q[3] * b.q[3] - a.q[0] * b.q[0] - a.q[1] * b.q[1] - a.q[2] * b.q[2];
+    r.q[0] = a.q[3] * b.q[0] + a.q[0] * b.q[3] + a.q[1] * b.q[2] - a.q[2] * b.q[1];
+    r.q[1] = a.q[3] * b.q[1] - a.q[0] * b.q[2] + a.q[1] * b.q[3] + a.q[2] * b.q[0];
+    r.q[2] = a.q[3] * b.q[2] + a.q[0] * b.q[1] - a.q[1] * b.q[0] + a.q[2] * b.q[3];
+    const double n = sqrt(r.q[0] * r.q[0] + r.q[1] * r.q[1] + r.q[2] * r.q[2] + r.q[3] * r.q[3]);
+    for (int k = 0; k < 4; k++) r.q[k] /= n;
+    double rt[3];
+    h_rot(a.q, b.t, rt);
+    for (int k = 0; k < 3; k++) r.t[k] = a.t[k] + rt[k];
+    return r;
+}
+inline HostSE3 h_inv(const HostSE3& a) {
+    HostSE3 r;
+    r.q[0] = -a.q[0]; r.q[1] = -a.q[1]; r.q[2] = -a.q[2]; r.q[3] = a.q[3];
+    double rt[3];
+    h_rot(r.q, a.t, rt);
+    for (int k = 0; k < 3; k++) r.t[k] = -rt[k];
+    return r;
+}
+}  // namespace
+
+int myslam_loop_local_fusion(double* active_poses, int n_active, int cur, const double* corrected_cur_pose7, const int32_t* first_active_kf,
+                             double* points, int n_points) {
+    if (!active_poses || n_active < 1 || n_active > 64 || cur < 0 || cur >= n_active || !corrected_cur_pose7 || n_points < 0 ||
+        (n_points > 0 && (!first_active_kf || !points)))
+        return MYSLAM_ERR_INVALID;
+    std::vector<double> oldp(active_poses, active_poses + (size_t)7 * n_active), newp((size_t)7 * n_active);
+    const HostSE3 Tc_inv = h_inv(h_load(active_poses + 7 * cur)), Tcc = h_load(corrected_cur_pose7);
+    for (int a = 0; a < n_active; a++) {
+        const HostSE3 T = (a == cur) ? Tcc : h_mul(h_mul(h_load(active_poses + 7 * a), Tc_inv), Tcc);       // :480-482
+        for (int k = 0; k < 4; k++) newp[7 * a + k] = T.q[k];
+        for (int k = 0; k < 3; k++) newp[7 * a + 4 + k] = T.t[k];
+    }
+    if (n_points > 0) {
+        int rc = myslam_correct_map_points(oldp.data(), newp.data(), n_active, first_active_kf, points, n_points);     // :486-502
+        if (rc) return rc;
+    }
+    for (size_t k = 0; k < newp.size(); k++) active_poses[k] = newp[k];                                       // :505-507
+    return MYSLAM_OK;
+}
+
 int myslam_correct_map_points_device(const double* d_old_poses, const double* d_new_poses, int n_poses, const int32_t* d_first_kf,
                                      double* d_points, int n_points, int32_t* d_status, void* hip_stream) {
     if (n_points < 0 || n_poses < 0 || (n_points > 0 && (!d_old_poses || !d_new_poses || !d_first_kf || !d_points || !d_status))) return MYSLAM_ERR_INVALID;

@@ -388,6 +388,13 @@ int myslam_pose_graph_optimize(double* poses, int n, const uint8_t* fixed, const
  * active window keeps its camera-frame position in the key-frame that first observed it; first_kf[i] < 0 leaves the point alone
  * (the :625-629 skip).  old_poses / new_poses: n_poses x 7 as above; points n_points x 3 in/out. */
 int myslam_correct_map_points(const double* old_poses, const double* new_poses, int n_poses, const int32_t* first_kf, double* points, int n_points);
+/* LoopClosing::LoopLocalFusion, src/loopclosing.cpp:466-507 — the arithmetic of it (re-linking the current key-frame's observations to the
+ * loop key-frame's map points, :509-532, is Map bookkeeping and stays with the caller).  active_poses: n_active x 7 Tcw of the active
+ * key-frames, in/out; cur = index of the current key-frame among them; corrected_cur_pose7 = _mseCorrectedCurrentPose.
+ * Every active key-frame moves rigidly with the current one (Ta' = Ta * Tc^-1 * Tc'); every map point i keeps its camera-frame position
+ * in the active key-frame first_active_kf[i] that first observes it (< 0: left alone).  Host pointers. */
+int myslam_loop_local_fusion(double* active_poses, int n_active, int cur, const double* corrected_cur_pose7, const int32_t* first_active_kf,
+                             double* points, int n_points);
 /* device pointers, asynchronous on hip_stream; *d_status (zeroed by the caller) receives MYSLAM_ERR_INVALID for an index >= n_poses */
 int myslam_correct_map_points_device(const double* d_old_poses, const double* d_new_poses, int n_poses, const int32_t* d_first_kf,
                                      double* d_points, int n_points, int32_t* d_status, void* hip_stream);

@@ -158,6 +158,8 @@ int orc_lk_track(const uint8_t* prev, const uint8_t* next, int rows, int cols, i
 
 /* ---- loop correction (pgo_oracle.cpp): LoopClosing::PoseGraphOptimization, src/loopclosing.cpp:537-646 ---- */
 /* poses n x 7 (qx qy qz qw tx ty tz) Tcw in/out; edge k: error = log(meas_k^-1 * T[e0] * T[e1]^-1) (g2o_types.h:157-167) */
+int orc_loop_local_fusion(double* active_poses, int n_active, int cur, const double* corrected_cur, const int32_t* first_active_kf,
+                          double* points, int n_points);
 int orc_pose_graph_optimize(double* poses, int n, const uint8_t* fixed, const int32_t* e0, const int32_t* e1,
                             const double* meas, int E, int max_iters, double* final_chi2, int* iters);
 /* :621-633: p <- T_new[kf]^-1 * (T_old[kf] * p); kf < 0 leaves the point alone */

@@ -188,6 +188,31 @@ int orc_se3_compose(const double* a7, const double* b7, int invert_b, double* ou
     return 0;
 }
 
+// LoopClosing::LoopLocalFusion, src/loopclosing.cpp:466-507 (arithmetic part): the active key-frames move rigidly with the corrected
+// current key-frame (Ta' = Ta * Tc^-1 * Tc'), every active map point keeps its camera-frame position in the active key-frame that
+// first observes it (p' = Ta'^-1 * (Ta * p)).
+int orc_loop_local_fusion(double* active_poses, int n_active, int cur, const double* corrected_cur, const int32_t* first_active_kf,
+                          double* points, int n_points) {
+    if (n_active < 1 || cur < 0 || cur >= n_active || !active_poses || !corrected_cur || n_points < 0) return -1;
+    std::vector<SE3q> oldp(n_active), newp(n_active);
+    for (int a = 0; a < n_active; a++) oldp[a] = load7(active_poses + 7 * a);
+    const SE3q Tc_inv = inv(oldp[cur]), Tcc = load7(corrected_cur);
+    for (int a = 0; a < n_active; a++) newp[a] = (a == cur) ? Tcc : mul(mul(oldp[a], Tc_inv), Tcc);          // :480-482
+    for (int i = 0; i < n_points; i++) {
+        const int a = first_active_kf[i];
+        if (a < 0) continue;
+        if (a >= n_active) return -1;
+        double pc[3], pw[3];
+        rot(oldp[a].q, points + 3 * i, pc);
+        for (int k = 0; k < 3; k++) pc[k] += oldp[a].t[k];                                                     // :499
+        const SE3q Ti = inv(newp[a]);
+        rot(Ti.q, pc, pw);
+        for (int k = 0; k < 3; k++) points[3 * i + k] = pw[k] + Ti.t[k];                                       // :501
+    }
+    for (int a = 0; a < n_active; a++) store7(newp[a], active_poses + 7 * a);                                  // :505-507
+    return 0;
+}
+
 int orc_pose_graph_optimize(double* poses, int n, const uint8_t* fixed, const int32_t* e0, const int32_t* e1,
                             const double* meas, int E, int max_iters, double* final_chi2, int* iters) {
     if (n < 0 || E < 0 || max_iters < 0 || (n > 0 && !poses) || (E > 0 && (!e0 || !e1 || !meas))) return -1;

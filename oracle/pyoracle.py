@@ -417,6 +417,13 @@ class Oracle:
         assert rc == 0, rc
         return poses, chi.value, it.value
 
+    def loop_local_fusion(self, active_poses, cur, corrected_cur, first_active_kf, pts):
+        poses = np.ascontiguousarray(active_poses, np.float64).reshape(-1, 7).copy(); cc = np.ascontiguousarray(corrected_cur, np.float64)
+        kf = np.ascontiguousarray(first_active_kf, np.int32); pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3).copy()
+        rc = self.lib.orc_loop_local_fusion(_p(poses), len(poses), int(cur), _p(cc), _p(kf), _p(pts), len(pts))
+        assert rc == 0, rc
+        return poses, pts
+
     def correct_map_points(self, old_poses, new_poses, kf, pts):
         old_poses = np.ascontiguousarray(old_poses, np.float64); new_poses = np.ascontiguousarray(new_poses, np.float64)
         kf = np.ascontiguousarray(kf, np.int32); pts = np.ascontiguousarray(pts, np.float64).copy()

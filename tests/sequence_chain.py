@@ -100,6 +100,9 @@ class HipBackend:
     def correct_points(self, old, new, first, pts):
         return self.api.correct_map_points(old, new, first, pts)
 
+    def local_fusion(self, poses, cur, corrected, first, pts):
+        return self.api.loop_local_fusion(poses, cur, corrected, first, pts)
+
 
 class OracleBackend:
     name = "oracle"
@@ -154,6 +157,9 @@ class OracleBackend:
 
     def correct_points(self, old, new, first, pts):
         return self.o.correct_map_points(old, new, first, pts)
+
+    def local_fusion(self, poses, cur, corrected, first, pts):
+        return self.o.loop_local_fusion(poses, cur, corrected, first, pts)
 
 
 # ---- the chain -----------------------------------------------------------------------------------------------------------------------
@@ -305,17 +311,31 @@ class Chain:
         self.rec("pnp", inl, np.array([n]), pose)
         pose2, outl, ninl = self.be.pose_only(pose, p3.astype(np.float64), p2.astype(np.float64), self.Kt, pre=1)     # OptimizeCurrentPose :339-433
         self.rec("loop_pose", pose2, outl, np.array([ninl]))
-        # PoseGraphOptimization (:537-610): chain edges mRelativePoseToLastKF, one loop edge, the loop key-frame fixed
+        # LoopLocalFusion (:466-507): the active window moves rigidly with the corrected current key-frame, active map points follow the
+        # active key-frame that first observes them
         n_kf = len(self.kfs)
+        act = list(range(max(0, n_kf - self.window), n_kf))
+        aidx = {k: i for i, k in enumerate(act)}
+        ids = sorted(self.points)
+        first_act = np.array([min((aidx[k] for k in self.obs[m] if k in aidx), default=-1) for m in ids], np.int32)
+        pts = np.stack([self.points[m] for m in ids])
+        loop_edge = p7_of(T_of(pose2) @ np.linalg.inv(T_of(loop["pose"])))                        # mRelativePoseToLoopKF (:441-446)
+        aposes, pts = self.be.local_fusion(np.stack([self.kfs[k]["pose"] for k in act]), aidx[cur_i], pose2, first_act, pts)
+        self.rec("local_fusion", aposes, pts)
+        for i, k in enumerate(act):
+            self.kfs[k]["pose"] = aposes[i].copy()
+        for j, m in enumerate(ids):
+            self.points[m] = pts[j].copy()
+        # PoseGraphOptimization (:537-610): chain edges mRelativePoseToLastKF, one loop edge; active key-frames, the loop key-frame and
+        # key-frame 0 are fixed (:557-562)
         poses = np.stack([k["pose"] for k in self.kfs])
-        fixed = np.zeros(n_kf, np.uint8); fixed[loop_i] = 1
+        fixed = np.zeros(n_kf, np.uint8); fixed[act] = 1; fixed[loop_i] = 1; fixed[0] = 1
         e0 = list(range(1, n_kf)) + [cur_i]; e1 = list(range(0, n_kf - 1)) + [loop_i]
-        meas = [self.kfs[i]["rel"] for i in range(1, n_kf)] + [p7_of(T_of(pose2) @ np.linalg.inv(T_of(loop["pose"])))]
+        meas = [self.kfs[i]["rel"] for i in range(1, n_kf)] + [loop_edge]
         new_poses, chi2, iters = self.be.pgo(poses, fixed, np.array(e0, np.int32), np.array(e1, np.int32), np.stack(meas))
         self.rec("pgo", new_poses, np.array([chi2]), np.array([iters]))
-        ids = sorted(self.points)
-        pts = np.stack([self.points[m] for m in ids])
-        first = np.array([self.first_kf[m] for m in ids], np.int32)
+        # map points outside the active map follow the key-frame that first observed them (:612-633)
+        first = np.array([-1 if first_act[j] >= 0 else self.first_kf[m] for j, m in enumerate(ids)], np.int32)
         pts2 = self.be.correct_points(poses, new_poses, first, pts)                             # :612-640
         self.rec("correct_points", pts2)
         self.final_poses = new_poses

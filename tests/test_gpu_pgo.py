@@ -115,3 +115,18 @@ def test_correct_map_points(api, oracle, synth):
     with pytest.raises(Exception):
         api.correct_map_points(poses, new, np.full(5000, 80, np.int32), pts)
     assert api.correct_map_points(poses, new, kf[:0], pts[:0]).shape == (0, 3)
+
+
+def test_loop_local_fusion(api, oracle, synth):
+    """LoopClosing::LoopLocalFusion (loopclosing.cpp:466-507), arithmetic part: active key-frames move rigidly with the corrected
+    current key-frame, active map points keep their camera-frame position in their first active observer."""
+    rng = np.random.default_rng(5)
+    pg = synth.pose_graph(40, 1, seed=9)
+    poses = pg[0][-7:].copy()
+    corrected = oracle.se3_compose(poses[6], oracle.se3_exp(np.array([0.3, -0.1, 0.2, 0.02, -0.01, 0.03])))
+    pts = rng.uniform(-5, 5, (500, 3)) + np.array([0, 0, 15.0])
+    first = rng.integers(-1, 7, 500).astype(np.int32)
+    gp, gx = api.loop_local_fusion(poses, 6, corrected, first, pts)
+    rp, rx = oracle.loop_local_fusion(poses, 6, corrected, first, pts)
+    assert np.allclose(gp, rp, rtol=0, atol=1e-12) and np.allclose(gx, rx, rtol=1e-12, atol=1e-11)
+    assert np.array_equal(gx[first < 0], pts[first < 0]) and np.allclose(gp[6], corrected / np.r_[np.full(4, np.linalg.norm(corrected[:4])), 1, 1, 1])

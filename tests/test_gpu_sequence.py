@@ -50,11 +50,11 @@ def test_sequence_chain_hip_equals_oracle(api, oracle, synth, pkg):
             elif ta == "pgo":
                 tol = 5e-4 if i == 0 else max(1e-9, 1e-3 * abs(float(v.ravel()[0])))
                 assert np.abs(u - v).max() <= tol, (ta, i, np.abs(u - v).max())
-            elif ta == "correct_points":
+            elif ta in ("correct_points", "local_fusion"):
                 assert np.abs(u - v).max() < 5e-3, (ta, np.abs(u - v).max())
             else:                                                   # poses, landmarks, chi2 values
                 assert np.allclose(u, v, rtol=1e-6, atol=1e-6), (ta, counts[ta], i, np.abs(u - v).max())
-    assert counts["pose_only"] == N_FRAMES - 1 and counts["ba"] == len(a.kfs) - 1 and counts["lcd"] == len(a.kfs)
+    assert counts["pose_only"] == N_FRAMES - 1 and counts["ba"] == len(a.kfs) - 1 and counts["lcd"] == len(a.kfs) and counts["local_fusion"] == 1
     assert a.n_loop_matches >= 10                                   # loopclosing.cpp:245: the loop is only closed with >= 10 3D-2D matches
     for pa, pb in zip(a.poses, b.poses):
         assert np.allclose(pa, pb, rtol=1e-6, atol=1e-6)
