@@ -10,6 +10,9 @@
 //   myslam::LocalBA::{Build,Optimize,OptimizeActiveMap}  Backend::OptimizeActiveMap  src/backend.cpp:126-243
 //   myslam::PyrLKTracker::calcOpticalFlowPyrLK        cv::calcOpticalFlowPyrLK call sites        src/frontend.cpp:150-153, 358-361
 //   myslam::EstimateCurrentPose                       g2o stage of Frontend::EstimateCurrentPose src/frontend.cpp:176-276
+//   myslam::KeyFrameFeatures / MatchFeatures          KeyFrame::{mvPyramidKeyPoints, mORBDescriptors} + LoopClosing::ProcessNewKF /
+//                                                     MatchFeatures bookkeeping                   src/loopclosing.cpp:83-121, 163-203
+//   myslam::LoopLocalFusion                           arithmetic of LoopClosing::LoopLocalFusion  src/loopclosing.cpp:466-507
 //
 // No OpenCV / Eigen / g2o: images are (data, rows, cols, step) views, cv::KeyPoint is the layout-compatible
 // myslam_keypoint, DescrVector is std::array<float,1064>.  Errors the reference reports by logging + return keep
@@ -95,6 +98,9 @@ class ORBextractor {
         check(myslam_orb_calc_descriptors(h_, image.data, image.rows, image.cols, image.step, keypoints.data(), (int)keypoints.size(),
                                           descriptors.data()), "myslam_orb_calc_descriptors");
     }
+    // scheduling / parity knobs (no reference counterpart; see include/myslam_hip.h)
+    void SetOption(int option, int value) { check(myslam_orb_set_option(h_, option, value), "myslam_orb_set_option"); }
+    void SetGaussTaps(const int32_t* q7) { check(myslam_orb_set_gauss_taps(h_, q7), "myslam_orb_set_gauss_taps"); }
     // getters, ORBextractor.h:87-107
     int GetLevels() const { return nlevels_; }
     float GetScaleFactor() const { return mvScaleFactor.size() > 1 ? mvScaleFactor[1] : 1.f; }
@@ -115,8 +121,13 @@ class ORBextractor {
 class DeepLCD {
    public:
     using DescrVector = std::array<float, MYSLAM_LCD_DIM>;     // Eigen::Matrix<float,1064,1>, deeplcd.h:25
-    // the Caffe prototxt + caffemodel pair becomes one flat weight file
+    // DeepLCD(network_definition_file, pre_trained_model_file, gpu_id) deeplcd.h:33: the reference's own two files, read without Caffe
+    DeepLCD(const std::string& network_definition_file, const std::string& pre_trained_model_file, int /*gpu_id*/ = -1) {
+        check(myslam_lcd_create_from_caffe(&h_, network_definition_file.c_str(), pre_trained_model_file.c_str()), "myslam_lcd_create_from_caffe");
+    }
+    // own model file (CALCW1 / CALCW2, csrc/calc.hip)
     explicit DeepLCD(const std::string& weights_file) { check(myslam_lcd_create_from_file(&h_, weights_file.c_str()), "myslam_lcd_create_from_file"); }
+    bool UsesFusedKernels() const { return myslam_lcd_uses_fused_kernels(h_) == 1; }
     DeepLCD(const float* weights, size_t n) { check(myslam_lcd_create(&h_, weights, n), "myslam_lcd_create"); }
     ~DeepLCD() { if (h_) myslam_lcd_destroy(h_); }
     DeepLCD(const DeepLCD&) = delete;
@@ -148,6 +159,45 @@ struct BFMatcherHamming {      // cv::DescriptorMatcher::create("BruteForce-Hamm
         for (int i = 0; i < nq; i++) matches[i] = DMatch{i, idx[i], 0, (float)dist[i]};
     }
 };
+
+// What LoopClosing keeps per key-frame for loop verification (include/myslam/keyframe.h:44-52): the pyramid key-points that survived
+// ScreenAndComputeKPsParams (class_id = index of the feature they belong to) and their descriptors.
+struct KeyFrameFeatures {
+    std::vector<KeyPoint> mvPyramidKeyPoints;
+    Descriptors mORBDescriptors;
+    // LoopClosing::ProcessNewKF, src/loopclosing.cpp:94-112.  `image` is the key-frame's left image AFTER DeepLCD::calcDescrOriginalImg
+    // blurred it in place (the reference's order of calls); featureKeyPoints = mvpFeaturesLeft[i]->mkpPosition.
+    void Compute(ORBextractor& extractor, const ImageView& image, const std::vector<KeyPoint>& featureKeyPoints) {
+        const int nl = extractor.GetLevels();
+        std::vector<KeyPoint> pyr(featureKeyPoints.size() * (size_t)nl);
+        check(myslam_expand_pyramid_keypoints(featureKeyPoints.data(), (int)featureKeyPoints.size(), nl, pyr.data()), "myslam_expand_pyramid_keypoints");
+        extractor.ScreenAndComputeKPsParams(image, pyr, mvPyramidKeyPoints);
+        extractor.CalcDescriptors(image, mvPyramidKeyPoints, mORBDescriptors);
+    }
+};
+
+// LoopClosing::MatchFeatures, src/loopclosing.cpp:163-203: BFMatcher(loop -> current), distance filter, (current feature, loop feature)
+// pairs in the order of the reference's std::set.  false when fewer than 10 pairs survive (:196).
+inline bool MatchFeatures(const KeyFrameFeatures& loopKF, const KeyFrameFeatures& currentKF, std::vector<std::pair<int, int>>& validFeatureMatches) {
+    validFeatureMatches.clear();
+    const int nq = (int)loopKF.mvPyramidKeyPoints.size(), nt = (int)currentKF.mvPyramidKeyPoints.size();
+    if (nq == 0 || nt == 0) return false;
+    std::vector<int32_t> idx(nq), dist(nq), pairs((size_t)nq * 2);
+    check(myslam_hamming_match(loopKF.mORBDescriptors.data(), nq, currentKF.mORBDescriptors.data(), nt, idx.data(), dist.data()), "myslam_hamming_match");
+    int np = 0;
+    check(myslam_match_feature_pairs(idx.data(), dist.data(), nq, loopKF.mvPyramidKeyPoints.data(), currentKF.mvPyramidKeyPoints.data(), nt,
+                                     pairs.data(), &np), "myslam_match_feature_pairs");
+    for (int k = 0; k < np; k++) validFeatureMatches.emplace_back(pairs[2 * k], pairs[2 * k + 1]);
+    return np >= 10;
+}
+
+// LoopClosing::LoopLocalFusion, src/loopclosing.cpp:466-507 (the arithmetic; re-linking observations :509-532 stays with the Map):
+// activePoses (n x 7, in/out) move rigidly with the corrected current key-frame, points (n x 3, in/out) follow firstActiveKF[i] (< 0 = skip)
+inline void LoopLocalFusion(std::vector<double>& activePoses, int currentIndex, const double correctedCurrentPose[7],
+                            const std::vector<int32_t>& firstActiveKF, std::vector<double>& points) {
+    check(myslam_loop_local_fusion(activePoses.data(), (int)(activePoses.size() / 7), currentIndex, correctedCurrentPose, firstActiveKF.data(),
+                                   points.data(), (int)firstActiveKF.size()), "myslam_loop_local_fusion");
+}
 
 // triangulation() of algorithm.h:16-33 for the stereo rig (left ext = I, right ext t = (-baseline,0,0)); ok = success && z > 0
 inline void triangulation(const std::vector<float>& xl, const std::vector<float>& yl, const std::vector<float>& xr,

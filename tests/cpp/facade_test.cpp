@@ -1,4 +1,5 @@
 // C++ parity test of the facade (product) against the oracle (checker).  Built and run by tests/test_gpu_facade.py.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -185,6 +186,62 @@ int main() {
         for (int i = 0; i < 3; i++) EXPECT(std::fabs(gp[4 + i] - T[4 + i]) < 0.05);
         std::vector<myslam::Point3f> few(p3.begin(), p3.begin() + 4); std::vector<myslam::Point2f> few2(p2.begin(), p2.begin() + 4);
         EXPECT(!myslam::solvePnPRansac(few, few2, fx, fy, cx, cy, gp));
+    }
+
+    // loop closer bookkeeping (a26): KeyFrame::{mvPyramidKeyPoints, mORBDescriptors} of two key-frames of the same scene, MatchFeatures,
+    // LoopLocalFusion — the reference's own call order (ProcessNewKF blurs the image in place first)
+    {
+        std::vector<uint8_t> imgB = img;                                  // "current" key-frame: the scene shifted by 3 px
+        for (int y = 0; y < H; y++) for (int x = 0; x < W - 3; x++) imgB[(size_t)y * W + x] = img[(size_t)y * W + x + 3];
+        myslam::ORBextractor det(150, 1.2f, 8, 20, 7);
+        std::vector<uint8_t> imgs[2] = {img, imgB};
+        myslam::KeyFrameFeatures kf[2];
+        std::vector<std::vector<orc_keypoint>> rpyr(2); std::vector<std::vector<uint8_t>> rdesc(2);
+        std::vector<float> w(myslam_lcd_nweights());
+        std::mt19937 wr(3); std::normal_distribution<float> N01(0.f, 0.05f);
+        for (auto& v : w) v = N01(wr);
+        myslam::DeepLCD lcd(w.data(), w.size());
+        for (int k = 0; k < 2; k++) {
+            myslam::ImageView v{imgs[k].data(), H, W, W};
+            std::vector<myslam::KeyPoint> feats; det.Detect(v, nomask, feats);
+            std::vector<uint8_t> ref = imgs[k];
+            (void)lcd.calcDescrOriginalImg(v);                           // blurs imgs[k] in place (reference quirk)
+            std::vector<float> net(120 * 160);
+            EXPECT(orc_calc_preproc(ref.data(), H, W, W, 1, net.data()) == 0);
+            EXPECT(ref == imgs[k]);
+            kf[k].Compute(ext, v, feats);
+            // the oracle's chain: expand by hand, screen, describe
+            orc_orb_params p8{600, 1.2f, 8, 20, 7};
+            std::vector<orc_keypoint> pyr(feats.size() * 8), out(feats.size() * 8 + 1);
+            for (size_t i = 0; i < feats.size(); i++)
+                for (int l = 0; l < 8; l++) { orc_keypoint q; std::memcpy(&q, &feats[i], sizeof(q)); q.octave = l; q.response = -1; q.class_id = (int)i; pyr[i * 8 + l] = q; }
+            int no = 0;
+            EXPECT(orc_screen(&p8, ref.data(), H, W, W, pyr.data(), (int)pyr.size(), out.data(), (int)out.size(), &no) == 0);
+            out.resize(no); rpyr[k] = out; rdesc[k].resize((size_t)no * 32);
+            EXPECT(orc_calc_descriptors(&p8, ref.data(), H, W, W, out.data(), no, rdesc[k].data()) == 0);
+            EXPECT((int)kf[k].mvPyramidKeyPoints.size() == no && no > 100);
+            EXPECT(std::memcmp(kf[k].mvPyramidKeyPoints.data(), out.data(), sizeof(orc_keypoint) * no) == 0);
+            EXPECT(kf[k].mORBDescriptors == rdesc[k]);
+        }
+        std::vector<std::pair<int, int>> pairs;
+        const bool enough = myslam::MatchFeatures(kf[0], kf[1], pairs);
+        // reference restatement of :172-194 on the oracle's matcher output
+        const int nq = (int)rpyr[0].size(), nt = (int)rpyr[1].size();
+        std::vector<int32_t> ri(nq), rdst(nq);
+        EXPECT(orc_hamming_match(rdesc[0].data(), nq, rdesc[1].data(), nt, ri.data(), rdst.data()) == 0);
+        int mn = rdst[0]; for (int i = 1; i < nq; i++) mn = std::min(mn, rdst[i]);
+        std::vector<std::pair<int, int>> want;
+        for (int i = 0; i < nq; i++) if ((double)rdst[i] <= std::max(2.0 * mn, 30.0)) want.emplace_back(rpyr[1][ri[i]].class_id, rpyr[0][i].class_id);
+        std::sort(want.begin(), want.end()); want.erase(std::unique(want.begin(), want.end()), want.end());
+        EXPECT(pairs == want && enough == (want.size() >= 10) && want.size() >= 10);
+        // LoopLocalFusion on three active key-frames
+        std::vector<double> act = {0, 0, 0, 1, 0, 0, 0,  0, 0.01, 0, 1, 0.5, 0, 0.1,  0.01, 0, 0, 1, 1.0, 0.02, 0.2}, ract = act;
+        const double corr[7] = {0.0, 0.02, 0.0, 1.0, 1.1, 0.0, 0.25};
+        std::vector<double> pts = {1, 2, 13, -4, 0.5, 9, 7, 1, 17}, rpts = pts; std::vector<int32_t> first = {0, -1, 2};
+        myslam::LoopLocalFusion(act, 2, corr, first, pts);
+        EXPECT(orc_loop_local_fusion(ract.data(), 3, 2, corr, first.data(), rpts.data(), 3) == 0);
+        for (size_t i = 0; i < act.size(); i++) EXPECT(std::fabs(act[i] - ract[i]) < 1e-12);
+        for (size_t i = 0; i < pts.size(); i++) EXPECT(std::fabs(pts[i] - rpts[i]) < 1e-10);
     }
 
     printf(fails ? "FACADE TEST FAILED (%d)\n" : "FACADE TEST OK (%d failures)\n", fails);
