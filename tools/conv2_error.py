@@ -1,4 +1,4 @@
-"""conv2 output error against an f64 torch reference for the selected MYSLAM_CONV2_V (GPU box)."""
+"""conv2 (bf16 x 6 matrix-core kernel) output error against an f64 torch reference (GPU box)."""
 import sys, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,4 +19,4 @@ for seed in range(4):
     a2 = F.relu(F.conv2d(torch.from_numpy(p1.copy())[None].double(), w2, b2, stride=1, padding=2))[0].numpy()
     got = lcd.debug_forward(x, 2).reshape(32, 42, 128).transpose(2, 0, 1)
     errs.append((np.abs(got - a2).max() / np.abs(a2).max(), np.abs(got - a2).mean() / np.abs(a2).mean()))
-print("MYSLAM_CONV2_V", os.environ.get("MYSLAM_CONV2_V", "default"), "max-normalised error %.3e, mean relative error %.3e" % tuple(np.max(errs, axis=0)))
+print("k_conv2_bf16x6: max-normalised error %.3e, mean relative error %.3e" % tuple(np.max(errs, axis=0)))
