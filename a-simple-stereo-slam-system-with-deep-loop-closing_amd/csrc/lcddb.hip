@@ -280,12 +280,17 @@ int myslam_lcddb_create(myslam_lcddb** out, int capacity) {
     myslam_lcddb* h = new myslam_lcddb();
     const int rowsPerBlock = DB_WAVES * DB_ROWS_PER_WAVE;
     h->capacity = (capacity + rowsPerBlock - 1) / rowsPerBlock * rowsPerBlock;      // scan reads whole blocks of rows
-    MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_db, (size_t)h->capacity * DIM * sizeof(float)));
-    MYSLAM_HIP_CHECK(hipMemset(h->d_db, 0, (size_t)h->capacity * DIM * sizeof(float)));
-    MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_ids, (size_t)h->capacity * sizeof(uint64_t)));
-    MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_q1, DIM * sizeof(float)));
-    MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_best1, 8)); MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_max1, 4));
-    MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_cnt1, 4));
+    auto alloc_all = [&]() -> int {
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_db, (size_t)h->capacity * DIM * sizeof(float)));
+        MYSLAM_HIP_CHECK(hipMemset(h->d_db, 0, (size_t)h->capacity * DIM * sizeof(float)));
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_ids, (size_t)h->capacity * sizeof(uint64_t)));
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_q1, DIM * sizeof(float)));
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_best1, 8)); MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_max1, 4));
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_cnt1, 4));
+        return MYSLAM_OK;
+    };
+    const int rc = alloc_all();
+    if (rc) { (void)myslam_lcddb_destroy(h); return rc; }      // nothing half-built survives an allocation failure
     *out = h;
     return MYSLAM_OK;
 }
