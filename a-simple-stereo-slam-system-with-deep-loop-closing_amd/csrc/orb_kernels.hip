@@ -545,12 +545,13 @@ __device__ __forceinline__ int wave_incl_scan_dpp(int v) {
 }
 
 // Path selection of the strip kernel (per level): `prev` = what the previous launch of this extractor handle measured,
-// `cur` = what this launch accumulates (zeroed by the host): [level][4] = {pairs that survived the pre-test (two-phase path) or
-// pairs holding a corner (dense path), pixel pairs looked at, path used, -}.  force: -1 = choose, 0 = two-phase, 1 = dense.
+// `cur` = what this launch accumulates (zeroed by the host): [level][4] = {pixel pairs that survived the pre-test (two-phase path) or
+// 4-pixel rows holding a corner (dense path), pixel pairs looked at, path used, -}.  force: -1 = choose, 0 = two-phase, 1 = dense.
 // Both paths produce the same candidate SET, so the choice only moves time.  Measured on MI355X (ms per 512 images, two-phase / dense,
 // against the fraction of pixel pairs that survive the pre-test): 0.09: 1.01 / 1.54, 0.18: 1.26 / 1.60, 0.30: 1.53 / 1.61,
-// 0.46: 1.81 / 1.64, 0.63: 2.04 / 1.63 — break-even near 0.41.  The switch goes to dense above 0.38 surviving pairs and back
-// below 0.22 corner-holding pairs (the dense path's own statistic; about 0.25 at the break-even).
+// 0.46: 1.81 / 1.64, 0.63: 2.04 / 1.63 — break-even near 0.41.  The switch goes to dense above 0.41 surviving pairs and back when
+// fewer than 0.33 of the 4-pixel rows hold a corner (the dense path's own statistic, free on the scalar unit; about 0.37 at the
+// break-even; there are half as many 4-pixel rows as pixel pairs, hence the 0.165 below).
 struct FastCtl { const uint32_t* prev; uint32_t* cur; int force; };
 
 // ---- strip kernel: one block scores G horizontally adjacent cells -----------------------------------
@@ -651,7 +652,7 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
     {
         const float ps = (float)ctl.prev[level * 4], pt = (float)ctl.prev[level * 4 + 1];
         const bool was_dense = ctl.prev[level * 4 + 2] != 0;
-        dense = ctl.force >= 0 ? ctl.force != 0 : (pt > 0.f && (was_dense ? ps > 0.22f * pt : ps > 0.38f * pt));
+        dense = ctl.force >= 0 ? ctl.force != 0 : (pt > 0.f && (was_dense ? ps > 0.165f * pt : ps > 0.41f * pt));
     }
     __syncthreads();
 
@@ -804,7 +805,6 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
         }
     } else {
         // ---- dense path: score every pixel ----
-        int ncorner = 0;
         for (int q = threadIdx.x; q < nitems; q += T) {
             int c, cy2, gi;
             split(q, c, cy2, gi);
@@ -829,7 +829,6 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
                 __builtin_memcpy(&ua, &za, 4); __builtin_memcpy(&ub, &zb, 4);
                 const uint32_t z4 = __builtin_amdgcn_perm(ub, ua, 0x06040200u) & keepm;   // the four z bytes
                 *reinterpret_cast<uint32_t*>(&s_score[c][(cy + 1) * SP + 4 + cx]) = z4;
-                ncorner += ((z4 & 0xffffu) != 0) + ((z4 >> 16) != 0);
             }
             if (cy + 1 < hc) {
                 const s16x2 za = fast9_score_pair<0, 1, 8>(r, thv), zb = fast9_score_pair<1, 1, 8>(r, thv);
@@ -837,12 +836,10 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
                 __builtin_memcpy(&ua, &za, 4); __builtin_memcpy(&ub, &zb, 4);
                 const uint32_t z4 = __builtin_amdgcn_perm(ub, ua, 0x06040200u) & keepm;
                 *reinterpret_cast<uint32_t*>(&s_score[c][(cy + 2) * SP + 4 + cx]) = z4;
-                ncorner += ((z4 & 0xffffu) != 0) + ((z4 >> 16) != 0);
             }
         }
-        ncorner = wave_reduce_sum(ncorner);
-        if (lane == 0 && ncorner) atomicAdd(&s_ncorner, ncorner);
         __syncthreads();
+        int nquad = 0;                     // 4-pixel rows that hold a corner: counted on the scalar unit (ballot + s_bcnt1), the statistic of this path
         // NMS: every 4-pixel x 2-row work item reports its strict maxima
         for (int q0 = 0; q0 < nitems; q0 += T) {                           // uniform trip count: the wave-wide scan needs every lane
             const int q = q0 + threadIdx.x;
@@ -860,6 +857,7 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
                         m[j][0] = rp[0]; m[j][1] = rp[1]; m[j][2] = rp[2];
                     }
                     uint32_t za, zb;
+                    nquad += __popcll(__ballot(m[1][1] != 0)) + __popcll(__ballot(cy + 1 < hc && m[2][1] != 0));
                     if (m[1][1] != 0) {                                    // else none of the four pixels of this row is a corner
                         const int ma = nms_pair<0, 0, 4>(m, za), mb = nms_pair<1, 0, 4>(m, zb);
                         mk = ma | (mb << 2);
@@ -874,6 +872,7 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
             }
             push_maxima(mk, zc0, zc1, 8, c, 4 * gi + 3 + (cj0 + c) * g.wCell, cy + 3 + ci * g.hCell);
         }
+        if (lane == 0 && nquad) atomicAdd(&s_ncorner, nquad);
     }
     __syncthreads();
     // what the next launch of this handle decides on: a SAMPLE of the strips reports (a ratio of sums needs no more, and a few

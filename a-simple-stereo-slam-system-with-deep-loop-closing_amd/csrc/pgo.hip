@@ -688,8 +688,7 @@ int myslam_pose_graph_optimize(double* poses, int n, const uint8_t* fixed, const
     {
         std::vector<int> tvert(nT);
         for (int i = 0; i < n; i++) if (tpos[i] >= 0) tvert[tpos[i]] = i;
-        const char* lenv = getenv("MYSLAM_PGO_RUN");
-        int lmax = lenv ? atoi(lenv) : std::max(16, (int)std::ceil(std::sqrt(11.0 * nT)));
+        int lmax = std::max(16, (int)std::ceil(std::sqrt(11.0 * nT)));
         for (;; lmax *= 2) {
             std::vector<int> cuts;
             for (int s0 = 0; s0 < nT;) {

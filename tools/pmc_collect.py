@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 H, W = 376, 1241
 PASSES = [["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_INSTS_VALU_MFMA_MOPS_I8"],
           ["FETCH_SIZE"], ["WRITE_SIZE"]]
+STEPS_TOTAL = 4          # bench --warmup 2 --steps 2
 ORB_KERNELS = ("k_ingest", "k_resize", "k_fast", "k_octree", "k_blur7", "k_describe")      # unit = image; everything else: unit = stereo pair
 
 
@@ -39,7 +40,7 @@ def run_pass(counters, pairs, workload, outdir, scene_rects):
     if os.path.isdir(outdir):
         shutil.rmtree(outdir)
     cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", outdir, "-o", "a", "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--pairs", str(pairs), "--workload", workload,
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "2", "--pairs", str(pairs), "--workload", workload,
            "--streams", "1", "--orb-internal-stream", "0", "--no-cpu-baseline", "--no-extra-passes", "--scene-rects", str(scene_rects)]
     env = dict(os.environ, TMPDIR="/tmp")
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
@@ -47,16 +48,24 @@ def run_pass(counters, pairs, workload, outdir, scene_rects):
     if r.returncode != 0 or not files:
         sys.stderr.write(r.stdout[-2000:] + r.stderr[-4000:])
         raise SystemExit(f"rocprofv3 pass {counters} failed (rc {r.returncode})")
-    agg = collections.defaultdict(lambda: collections.defaultdict(float))
-    disp = collections.defaultdict(set)
+    # per kernel: dispatch id -> {counter: value}; only the LAST step's dispatches are summed (the first launches of a run carry one-off
+    # behaviour: e.g. the FAST kernel takes its two-phase path until its statistics say "dense")
+    per = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
     for row in csv.DictReader(open(files[0])):
         k = short(row["Kernel_Name"])
         if not k.startswith("k_"):
             continue
-        agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
-        disp[k].add(row.get("Dispatch_Id", row.get("Correlation_Id", "")))
+        per[k][int(row.get("Dispatch_Id", row.get("Correlation_Id", "0")))][row["Counter_Name"]] += float(row["Counter_Value"])
     shutil.rmtree(outdir, ignore_errors=True)
-    return agg, {k: len(v) for k, v in disp.items()}
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); nd = {}
+    for k, d in per.items():
+        ids = sorted(d)
+        per_step = max(1, len(ids) // STEPS_TOTAL)
+        for i in ids[-per_step:]:
+            for c, v in d[i].items():
+                agg[k][c] += v
+        nd[k] = per_step
+    return agg, nd
 
 
 def main():
@@ -67,7 +76,7 @@ def main():
     ap.add_argument("--workload", default="full")
     ap.add_argument("--scene-rects", type=int, default=6000)
     args = ap.parse_args()
-    P, steps_total = args.pairs, 3
+    P, steps_total = args.pairs, 1          # run_pass() keeps the last step only
     out_root = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_root, exist_ok=True)
     kernels = collections.defaultdict(dict)
@@ -88,7 +97,7 @@ def main():
         unit = "image" if k.startswith(ORB_KERNELS) else "pair"
         nunits = steps_total * (2 * P if unit == "image" else P)
         rec["unit"] = unit
-        rec["launches_per_step"] = rec["dispatches"] / steps_total
+        rec["launches_per_step"] = rec["dispatches"]
         if "SQ_INSTS_VALU_total" in rec:
             rec["valu_wave_insts_per_" + unit] = rec["SQ_INSTS_VALU_total"] / nunits
         if "FETCH_SIZE_total" in rec:
@@ -113,8 +122,8 @@ def main():
             cross[k] = {"corrected_fetch_over_pyramid_bytes": rec["fetch_bytes_per_image_corrected"] / pyr_px}
     out = {
         "build": args.tag, "round": args.round,
-        "command": f"rocprofv3 --kernel-trace --pmc <set> -- python bench.py --steps 2 --warmup 1 --pairs {P} --workload {args.workload} --streams 1 "
-                   f"--orb-internal-stream 0 --no-cpu-baseline --no-extra-passes --scene-rects {args.scene_rects}   (one pass per counter set)",
+        "command": f"rocprofv3 --kernel-trace --pmc <set> -- python bench.py --steps 2 --warmup 2 --pairs {P} --workload {args.workload} --streams 1 "
+                   f"--orb-internal-stream 0 --no-cpu-baseline --no-extra-passes --scene-rects {args.scene_rects}   (one pass per counter set; counters of the LAST step)",
         "counter_sets": PASSES, "pairs_per_step": P, "steps_total": steps_total,
         "calibration": {"kernel": "k_ingest", "known_read_bytes_per_image": known_r, "counted_read_bytes_per_image": ing["fetch_bytes_per_image_raw"],
                         "fetch_scale": fetch_scale, "known_write_bytes_per_image": known_w, "counted_write_over_known": write_check,
