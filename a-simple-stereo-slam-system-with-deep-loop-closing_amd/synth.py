@@ -336,10 +336,11 @@ def sequence_scene(seed=0x5E0, tex_w=4096, tex_h=1024, texels_per_m=40.0):
 
 
 def sequence_poses(n=200):
-    """camera position [x, y, z] and yaw of frame t: out to the right along the wall and back on the same track, ending where it started"""
+    """camera position [x, y, z] and yaw of frame t: a flat figure along the wall that starts in full sideways motion (a vehicle that
+    is already driving: the first key-frames see parallax), swings 3 m to either side and ends where it started"""
     t = np.arange(n) / (n - 1)
-    x = 6.0 * (0.5 - 0.5 * np.cos(2 * np.pi * t))                                      # 0 -> 6 m -> 0
-    zc = 0.8 * np.sin(2 * np.pi * t)
+    x = 3.0 * np.sin(2 * np.pi * t)                                                    # 0 -> 3 m -> -3 m -> 0
+    zc = 0.8 * (1.0 - np.cos(2 * np.pi * t))
     yaw = np.deg2rad(2.0) * np.sin(4 * np.pi * t)
     return np.stack([x, np.zeros(n), zc], 1), yaw
 

@@ -164,9 +164,12 @@ class OracleBackend:
 
 # ---- the chain -----------------------------------------------------------------------------------------------------------------------
 class Chain:
-    def __init__(self, be, api, K, frames, kf_every=6, window=7):
-        """frames: list of (left, right) uint8 images; api: the product's host helpers (pyramid expansion, match -> feature pairs)"""
+    def __init__(self, be, api, K, frames, kf_every=6, window=7, anchor_gauge=False):
+        """frames: list of (left, right) uint8 images; api: the product's host helpers (pyramid expansion, match -> feature pairs).
+        anchor_gauge: DIAGNOSTIC, not the reference's behaviour — after every local BA the window (poses + the landmarks it moved) is
+        put back rigidly so that its oldest key-frame keeps the pose it had (the reference's graph fixes no pose, backend.cpp:139-150)"""
         self.be, self.api, self.K, self.frames = be, api, K, frames
+        self.anchor_gauge = anchor_gauge
         self.Kt = (K["fx"], K["fy"], K["cx"], K["cy"])
         self.kf_every, self.window = kf_every, window
         self.log = []
@@ -238,6 +241,11 @@ class Chain:
         fixed = np.array([0 if self.first_kf[m] in idx else 1 for m in mps], np.uint8)          # backend.cpp:175-177
         p2, x2, chi, out, rounds, nout = self.be.ba(poses, pts, np.array(ep, np.int32), np.array(el, np.int32), np.array(ob), fixed, self.Kt)
         self.rec("ba", p2, x2, out, np.array([rounds, nout]), chi)
+        if self.anchor_gauge:
+            G = np.linalg.inv(T_of(poses[0])) @ T_of(p2[0])                   # world motion of the oldest key-frame: Twc_old * Tcw_new
+            Gi = np.linalg.inv(G)
+            p2 = np.stack([p7_of(T_of(q) @ Gi) for q in p2])
+            x2 = np.where(fixed[:, None] != 0, x2, x2 @ G[:3, :3].T + G[:3, 3])
         for i, k in enumerate(win):
             self.kfs[k]["pose"] = p2[i].copy()
         for j, m in enumerate(mps):

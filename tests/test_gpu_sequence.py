@@ -62,7 +62,19 @@ def test_sequence_chain_hip_equals_oracle(api, oracle, synth, pkg):
     rmse_o, _ = _ate(b.poses, C, yaw, synth)
     print(f"sequence: {N_FRAMES} frames, {len(a.kfs)} key-frames, {len(a.points)} landmarks, {a.n_loop_matches} loop matches; "
           f"ATE rmse {rmse:.4f} m (oracle chain {rmse_o:.4f} m), worst {worst:.4f} m over a {float(np.abs(C).max()):.1f} m excursion")
-    # the reference's local BA optimises left-camera reprojections only and fixes no key-frame (backend.cpp:137-177): until the window
-    # slides past the first key-frames its similarity gauge is free, which shows as a scale drift of the whole track — a property of
-    # the reference algorithm on this sequence that both chains share; the bar here is only "tracking did not break"
-    assert rmse < 1.5 and abs(rmse - rmse_o) < 1e-5
+    # the reference's local BA optimises left-camera reprojections only and fixes no key-frame (backend.cpp:139-177): until the window
+    # slides past the first key-frames the rigid gauge of every solve is free, and each of the first six solves moves the whole window
+    # (key-frame 0 included) by 5-13 cm — a property of the reference algorithm that both chains share; the bar here is "tracking did
+    # not break" + equality of the chains.  test_sequence_gauge_anchored shows what is left once that motion is taken out.
+    assert rmse < 1.0 and abs(rmse - rmse_o) < 1e-5
+
+
+def test_sequence_gauge_anchored(api, synth, pkg):
+    """The same chain through the HIP library with the DIAGNOSTIC gauge anchor (sequence_chain.Chain(anchor_gauge=True): after every
+    local BA the window is moved back rigidly so that its oldest key-frame keeps its pose): the trajectory error that remains is the
+    composition's own — centimetres on a 13 m track —, which is what says that the operators compose into a working tracker."""
+    frames, C, yaw = _frames(synth, N_FRAMES)
+    a = sc.Chain(sc.HipBackend(api, synth.calc_weights()), pkg.api, synth.SEQ_K, frames, anchor_gauge=True).run()
+    rmse, worst = _ate(a.poses, C, yaw, synth)
+    print(f"sequence, gauge anchored: ATE rmse {rmse:.4f} m, worst {worst:.4f} m; {len(a.kfs)} key-frames, {a.n_loop_matches} loop matches")
+    assert rmse < 0.12 and worst < 0.25 and a.n_loop_matches >= 10
