@@ -533,6 +533,36 @@ __device__ __forceinline__ int nms_pair(const uint32_t (&m)[NR][3], uint32_t& zc
     return ((int)d.x > 0 ? 1 : 0) | ((int)d.y > 0 ? 2 : 0);
 }
 
+// Dense-path NMS, separable form.  One score-map row of a lane = 3 dwords (pixels -4..-1 | 0..3 | 4..7, the lane's four in the middle).
+// With the five pairs of adjacent pixels P(-1) .. P3 (zero-extended bytes in 16-bit lanes), pixel pair A = (0, 1) has left = P(-1),
+// centre = P0, right = P1 and pair B = (2, 3) has P1, P2, P3:  lr = max(left, right), h = max(lr, centre).  The largest of the 8
+// neighbours of a pixel in row M is then max(h[M-1], h[M+1], lr[M]): 5 picks + 4 packed max per row and 4 per output row,
+// against 9 picks + 7 max per pixel pair when every pair gathers its own neighbourhood.
+struct NmsRow { s16x2 hA, hB, lrA, lrB, cA, cB; };
+__device__ __forceinline__ NmsRow nms_row(uint32_t d0, uint32_t d1, uint32_t d2) {
+    const s16x2 pm1 = pick16<3>(d0, d1), p0 = pick16<0>(d1, d1), p1 = pick16<1>(d1, d1), p2 = pick16<2>(d1, d1), p3 = pick16<3>(d1, d2);
+    NmsRow r;
+    r.lrA = pmax(pm1, p1); r.hA = pmax(r.lrA, p0);
+    r.lrB = pmax(p1, p3);  r.hB = pmax(r.lrB, p2);
+    r.cA = p0; r.cB = p2;
+    return r;
+}
+// the four z bytes of row M with everything that is not a STRICT 3x3 maximum set to zero: t = sat(c - neighbours) is non-zero exactly
+// at strict maxima and t << 8 >= 256 > c there, so min(c, t << 8) keeps c at maxima and gives 0 elsewhere.  zacc collects the largest
+// surviving z of the caller's rows (two 16-bit lanes).
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t nms_strict4(const NmsRow& U, const NmsRow& M, const NmsRow& D, u16x2& zacc) {
+    auto keep = [](s16x2 c, s16x2 nb) -> u16x2 {
+        u16x2 cu, nu; __builtin_memcpy(&cu, &c, 4); __builtin_memcpy(&nu, &nb, 4);
+        const u16x2 t = __builtin_elementwise_sub_sat(cu, nu);
+        return __builtin_elementwise_min(cu, (u16x2)(t << (unsigned short)8));
+    };
+    const u16x2 ka = keep(M.cA, pmax(pmax(U.hA, D.hA), M.lrA)), kb = keep(M.cB, pmax(pmax(U.hB, D.hB), M.lrB));
+    zacc = __builtin_elementwise_max(zacc, __builtin_elementwise_max(ka, kb));
+    uint32_t za, zb; __builtin_memcpy(&za, &ka, 4); __builtin_memcpy(&zb, &kb, 4);
+    return __builtin_amdgcn_perm(zb, za, 0x06040200u);
+}
+
 // inclusive prefix sum over the 64 lanes on the DPP network (row_shr 1/2/4/8, then the two row broadcasts)
 __device__ __forceinline__ int wave_incl_scan_dpp(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);        // row_shr:1
@@ -563,8 +593,11 @@ struct FastCtl { const uint32_t* prev; uint32_t* cur; int force; };
 //                    3. one lane per listed pair: 3x3 strict-maximum test on the score map.
 //   dense path:      every pixel is scored (work item = 4 pixels x 2 rows: the two 7-row windows share 6 rows), NMS per item.
 // Blocks are handed out XCD-aware: consecutive strips (which share halo rows and columns) go to the same XCD's L2.
+#ifndef FAST_DBG
+#define FAST_DBG 0
+#endif
 template <int CW, int G>
-__global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __restrict__ pyr, size_t pyrStride,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 6 : 3))) void k_fast_strip(OrbPlan P, const uint8_t* __restrict__ pyr, size_t pyrStride,
                                                     const uint8_t* __restrict__ maskPyr,
                                                     uint32_t* __restrict__ cand, int32_t* __restrict__ candCount, FastCtl ctl, int batch) {
     constexpr int T = 256;
@@ -572,7 +605,7 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
     constexpr int NQ = TP / 16;                                        // 16-byte groups per row
     constexpr int TROWS = CW + 6 + 1;                                  // + 1: the second row of a work item reads one row further
     constexpr int SP = (CW + 4 + 8 + 3) & ~3;
-    constexpr int SROWS = CW + 2 + 1;
+    constexpr int SROWS = CW + 2 + 4;                                  // + 4: the dense path's NMS reads whole 4-row blocks (rows past the cell stay zero)
     constexpr int NLIST = G * ((CW + 1) / 2) * ((CW + 1) / 2);         // a cell of a x b pixels holds at most ceil(a/2) ceil(b/2) strict maxima
     constexpr int NPAIR = G * CW * ((CW + 1) / 2);                     // pixel pairs of a strip
     static_assert(CW <= 63 && G <= 4, "pair list entry = cell << 11 | row << 5 | pair index");
@@ -584,6 +617,11 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
     static_assert(NLIST * 5 <= TROWS * TP, "maxima list must fit into the staged tile");
     uint32_t* const s_list = reinterpret_cast<uint32_t*>(s_tile);
     uint8_t* const s_listc = s_tile + 4 * NLIST;
+    // dense path: one record per 4-pixel ROW that holds a strict maximum = its NMS-filtered z dword (s_recz, in the dead tile) + the
+    // row's (cell << 10 | row << 4 | group) (s_pairs, which only the two-phase path uses otherwise).  A cell of a x b pixels has at
+    // most ceil(a/2) ceil(b/2) strict maxima, hence at most NLIST such rows.
+    static_assert(NLIST * 4 <= TROWS * TP && NLIST <= NPAIR, "row records must fit");
+    uint32_t* const s_recz = reinterpret_cast<uint32_t*>(s_tile);
     __shared__ int s_ini[G], s_wc[G], s_nlist, s_npair, s_ncorner;
 
     // XCD-aware block order (bijective remap of the 1-D grid): the dispatcher places block i on XCD i % 8 and every XCD has a private
@@ -805,9 +843,19 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
         }
     } else {
         // ---- dense path: score every pixel ----
-        for (int q = threadIdx.x; q < nitems; q += T) {
-            int c, cy2, gi;
-            split(q, c, cy2, gi);
+        // a lane's work items are q = tid, tid + T, ...: (cell, row pair, group) is split once and then advanced by the split of T
+        int c, cy2, gi;
+        split((int)threadIdx.x, c, cy2, gi);
+        const int dc = T / per_cell, drem = T - dc * per_cell, dcy = drem / ngr, dgi = drem - dcy * ngr;       // block-uniform
+        auto advance = [&](int& c_, int& cy2_, int& gi_) __attribute__((always_inline)) {
+            gi_ += dgi; cy2_ += dcy; c_ += dc;
+            if (gi_ >= ngr) { gi_ -= ngr; cy2_++; }
+            if (cy2_ >= hc2) { cy2_ -= hc2; c_++; }
+        };
+#if FAST_DBG == 2
+        return;
+#endif
+        for (int q = threadIdx.x; q < nitems; q += T, advance(c, cy2, gi)) {
             const int wc = wc_of(c);
             const int cx = 4 * gi, cy = 2 * cy2;
             if (cx >= wc) continue;
@@ -839,38 +887,69 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
             }
         }
         __syncthreads();
+#if FAST_DBG == 1
+        return;
+#endif
         int nquad = 0;                     // 4-pixel rows that hold a corner: counted on the scalar unit (ballot + s_bcnt1), the statistic of this path
-        // NMS: every 4-pixel x 2-row work item reports its strict maxima
-        for (int q0 = 0; q0 < nitems; q0 += T) {                           // uniform trip count: the wave-wide scan needs every lane
+        // NMS on 4 x 4 pixel blocks (6 score-map rows x 3 dwords per lane, separable 3x3 maximum).  Every 4-pixel row that holds a strict
+        // maximum leaves ONE record (its filtered z dword) in the strip's list — four ballots and one LDS atomic per wave and
+        // iteration; the records are expanded into candidates by the append phase below, where every lane has work.
+        const int hc4 = (hc + 3) >> 2, per_cell4 = ngr * hc4, nitems4 = ncell * per_cell4;
+        int cy4;
+        {   // q -> (cell, row block, group) as split() does for the scoring items
+            const int q = (int)threadIdx.x;
+            c = (int)(((float)q + 0.5f) * (1.0f / (float)per_cell4));
+            int rem = q - c * per_cell4;
+            if (rem < 0) { c--; rem += per_cell4; } else if (rem >= per_cell4) { c++; rem -= per_cell4; }
+            cy4 = (int)(((float)rem + 0.5f) * inv_ngr);
+            gi = rem - cy4 * ngr;
+            if (gi < 0) { cy4--; gi += ngr; } else if (gi >= ngr) { cy4++; gi -= ngr; }
+        }
+        const int ec = T / per_cell4, erem = T - ec * per_cell4, ecy = erem / ngr, egi = erem - ecy * ngr;     // block-uniform
+        const int zini = P.iniTh - zoff;                                   // z of a corner at the initial threshold
+        for (int q0 = 0; q0 < nitems4; q0 += T) {                          // uniform trip count: the ballot needs every lane
             const int q = q0 + threadIdx.x;
-            int mk = 0, c = 0, cy = 0, gi = 0;              // mk: bits 0-3 row cy, bits 4-7 row cy+1
-            uint32_t zc0 = 0, zc1 = 0;
-            if (q < nitems) {
-                int cy2;
-                split(q, c, cy2, gi);
-                cy = 2 * cy2;
-                if (4 * gi < wc_of(c)) {
-                    uint32_t m[4][3];                                      // score-map rows cy-1 .. cy+2 (the map has a zero border row)
+            uint32_t zm[4] = {0u, 0u, 0u, 0u};                             // rows 4 cy4 .. + 3: z where the pixel is a strict maximum, else 0
+            u16x2 zacc = {0, 0};
+            if (q < nitems4 && 4 * gi < wc_of(c)) {
+                uint32_t m[6][3];                                          // score-map rows 4 cy4 - 1 .. 4 cy4 + 4 (zero border rows around the cell)
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t* rp = reinterpret_cast<const uint32_t*>(&s_score[c][(cy + j) * SP + 4 * gi]);
-                        m[j][0] = rp[0]; m[j][1] = rp[1]; m[j][2] = rp[2];
-                    }
-                    uint32_t za, zb;
-                    nquad += __popcll(__ballot(m[1][1] != 0)) + __popcll(__ballot(cy + 1 < hc && m[2][1] != 0));
-                    if (m[1][1] != 0) {                                    // else none of the four pixels of this row is a corner
-                        const int ma = nms_pair<0, 0, 4>(m, za), mb = nms_pair<1, 0, 4>(m, zb);
-                        mk = ma | (mb << 2);
-                        zc0 = m[1][1];
-                    }
-                    if (cy + 1 < hc && m[2][1] != 0) {
-                        const int ma = nms_pair<0, 1, 4>(m, za), mb = nms_pair<1, 1, 4>(m, zb);
-                        mk |= (ma | (mb << 2)) << 4;
-                        zc1 = m[2][1];
-                    }
+                for (int j = 0; j < 6; j++) {
+                    const uint32_t* rp = reinterpret_cast<const uint32_t*>(&s_score[c][(4 * cy4 + j) * SP + 4 * gi]);
+                    m[j][0] = rp[0]; m[j][1] = rp[1]; m[j][2] = rp[2];
+                }
+                const bool h0 = m[1][1] != 0, h1 = m[2][1] != 0, h2 = m[3][1] != 0, h3 = m[4][1] != 0;    // rows past the cell hold zeros
+                nquad += __popcll(__ballot(h0)) + __popcll(__ballot(h1)) + __popcll(__ballot(h2)) + __popcll(__ballot(h3));
+                if (h0 || h1 || h2 || h3) {                                // else none of the 16 pixels is a corner
+                    NmsRow R[6];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) R[j] = nms_row(m[j][0], m[j][1], m[j][2]);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) zm[j] = nms_strict4(R[j], R[j + 1], R[j + 2], zacc);
                 }
             }
-            push_maxima(mk, zc0, zc1, 8, c, 4 * gi + 3 + (cj0 + c) * g.wCell, cy + 3 + ci * g.hCell);
+            const unsigned long long b0 = __ballot(zm[0] != 0), b1 = __ballot(zm[1] != 0), b2 = __ballot(zm[2] != 0), b3 = __ballot(zm[3] != 0);
+            const int total = (int)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+            if (total != 0) {                                              // wave-uniform
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_nlist, total);
+                base = __builtin_amdgcn_readfirstlane(base);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const int code = (c << 10) | (cy4 << 6) | gi;              // row = 4 cy4 + j
+                // lane-major order (a lane's rows stay together, lanes = blocks adjacent in x): the oct-tree kernel that consumes the
+                // candidate list is measurably faster on spatially coherent input (table lookups, scatter coalescing)
+                int pos = base + (int)__popcll(b0 & below) + (int)__popcll(b1 & below) + (int)__popcll(b2 & below) + (int)__popcll(b3 & below);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (zm[j] != 0) {
+                        if (pos < NLIST) { s_recz[pos] = zm[j]; s_pairs[pos] = (uint16_t)(code | (j << 4)); }
+                        pos++;
+                    }
+                if (max((int)zacc.x, (int)zacc.y) >= zini) s_ini[c] = 1;
+            }
+            gi += egi; cy4 += ecy; c += ec;
+            if (gi >= ngr) { gi -= ngr; cy4++; }
+            if (cy4 >= hc4) { cy4 -= hc4; c++; }
         }
         if (lane == 0 && nquad) atomicAdd(&s_ncorner, nquad);
     }
@@ -885,8 +964,53 @@ __global__ __launch_bounds__(256) void k_fast_strip(OrbPlan P, const uint8_t* __
     }
     // filter (:858-865: th 20 if the cell has any such corner, else th 7; mask :873-877) and append: one global atomic per wave
     const uint8_t* mimg = maskPyr ? maskPyr + (size_t)b * pyrStride + g.imgOff : nullptr;
-    const int nl = min(s_nlist, NLIST);
     uint32_t* out = cand + (size_t)b * P.totalKeyCap + g.keyOff;
+    if (dense) {
+        // every record = a 4-pixel row: two halves, at most one strict maximum each; all passes of a wave are appended with one global atomic
+        const int nrec = min(s_nlist, NLIST);
+        for (int i0 = 0; i0 < nrec; i0 += T) {
+            if (i0 + (int)(threadIdx.x & ~63u) >= nrec) continue;          // this wave has no record in this round (no barrier in the loop)
+            const int i = i0 + threadIdx.x;
+            uint32_t z = 0;
+            int px0 = 0, py = 0, ini = 0;
+            if (i < nrec) {
+                const int code = s_pairs[i], c = code >> 10;
+                z = s_recz[i];
+                px0 = 4 * (code & 15) + 3 + (cj0 + c) * g.wCell;
+                py = ((code >> 4) & 63) + 3 + ci * g.hCell;
+                ini = s_ini[c];
+            }
+            uint32_t kp[2];
+            unsigned long long bm[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const uint32_t h = k ? z >> 16 : z & 0xffffu;
+                const uint32_t second = h >> 8;                            // non-zero: the maximum is the half's second pixel
+                const int sc = (int)(second ? second : h) + zoff;
+                const int px = px0 + 2 * k + (second ? 1 : 0);
+                bool pass = h != 0 && !(ini && sc < P.iniTh);
+                if (pass && mimg) pass = mimg[(size_t)py * g.pitch + px] != 0;         // (no +16: reference quirk)
+                kp[k] = ((uint32_t)py << 20) | ((uint32_t)px << 8) | (uint32_t)sc;
+                bm[k] = __ballot(pass);
+            }
+            const int total = (int)(__popcll(bm[0]) + __popcll(bm[1]));
+            if (total == 0) continue;                                      // wave-uniform
+            int gbase = 0;
+            if (lane == 0) gbase = atomicAdd(&candCount[b * MAXL + level], total);
+            gbase = __builtin_amdgcn_readfirstlane(gbase);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            int dst = gbase + (int)__popcll(bm[0] & below) + (int)__popcll(bm[1] & below);     // lane-major, as above
+            if ((bm[0] >> lane) & 1ull) {
+                if (dst < g.keyCap) out[dst] = kp[0];
+                dst++;
+            }
+            if ((bm[1] >> lane) & 1ull) {
+                if (dst < g.keyCap) out[dst] = kp[1];
+            }
+        }
+        return;
+    }
+    const int nl = min(s_nlist, NLIST);
     for (int i0 = 0; i0 < nl; i0 += T) {
         const int i = i0 + threadIdx.x;
         bool pass = false;
