@@ -442,10 +442,12 @@ __device__ __forceinline__ s16x2 pmax(s16x2 a, s16x2 b) { return __builtin_eleme
 // arc [2k-1, 2k+7] = p[2k-1] + m8[k], and max(min(m, a), min(m, b)) = min(m, max(a, b)) — 36 packed ops per polarity
 // for two pixels.  Returns z = score - (minTh - 1) for corners at minTh, 0 otherwise (an order-preserving shift: the
 // NMS compares z, the append adds minTh - 1 back).  PAIR selects pixels (2 PAIR, 2 PAIR + 1) of the window's four.
-// gfx950 has three-input packed minimum / maximum only for f16.  Ring values are carried as 0x6400 | p in each 16-bit lane:
-// that is the f16 number 1024 + p (exact, normal), whose bit patterns order exactly like the integers, so the two-input steps
-// stay v_pk_min/max_i16, the three-input steps are v_pk_minimum3/maximum3_f16 on the same registers, and differences of two
-// such values are plain 16-bit integer subtractions.
+// gfx950 has three-input packed minimum / maximum only for f16.  Ring values are zero-extended bytes in 16-bit lanes, i.e. the f16
+// bit patterns of +0 and the positive denormals 1 .. 255, which order exactly like the integers; the kernels run with f16 denormals
+// preserved (the AMDGPU default, amdhsa_float_denorm_mode_16_64 = 3) and a minimum / maximum only selects one of its operands, so the
+// two-input steps stay v_pk_min/max_i16, the three-input steps are v_pk_minimum3/maximum3_f16 on the same registers, and differences
+// are plain 16-bit integer subtractions.  (Round 1 carried 0x6400 | p — the normal numbers 1024 + p — which cost an extra OR on every
+// byte pair that straddles two dwords.)
 __device__ __forceinline__ s16x2 pmin3(s16x2 a, s16x2 b, s16x2 c) { s16x2 d; asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 __device__ __forceinline__ s16x2 pmax3(s16x2 a, s16x2 b, s16x2 c) { s16x2 d; asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 
@@ -454,13 +456,10 @@ __device__ __forceinline__ s16x2 fast9_score_pair(const uint32_t (&r)[NR][3], s1
     constexpr int RX[16] = FAST_RING_X;
     constexpr int RY[16] = FAST_RING_Y;
     constexpr int xc = 3 + 2 * PAIR;
-    constexpr uint32_t K64 = 0x64646464u;
-    auto pick = [&](int row, int a) -> s16x2 {          // bytes a, a+1 of window row `row` as (0x6400 | byte) in two 16-bit lanes
-        uint32_t u;
-        if ((a & 3) == 3)                               // the pair straddles two dwords: no room for the constant in the same v_perm
-            u = __builtin_amdgcn_perm(r[row][(a >> 2) + 1], r[row][a >> 2], 0x0c040c03u) | 0x64006400u;
-        else
-            u = __builtin_amdgcn_perm(K64, r[row][a >> 2], 0x04000400u | ((uint32_t)(a & 3) + 1u) << 16 | (uint32_t)(a & 3));
+    auto pick = [&](int row, int a) -> s16x2 {          // bytes a, a+1 of window row `row`, zero-extended into two 16-bit lanes
+        const int d0 = a >> 2, d1 = ((a & 3) == 3) ? d0 + 1 : d0;
+        const uint32_t u = __builtin_amdgcn_perm(r[row][d1], r[row][d0],
+                                                 0x0c000c00u | ((((a & 3) == 3) ? 4u : (uint32_t)(a & 3) + 1u) << 16) | (uint32_t)(a & 3));
         s16x2 q; __builtin_memcpy(&q, &u, 4);
         return q;
     };
@@ -481,7 +480,7 @@ __device__ __forceinline__ s16x2 fast9_score_pair(const uint32_t (&r)[NR][3], s1
     }
     const s16x2 brt = pmax(pmax3(pmax3(ub[0], ub[1], ub[2]), pmax3(ub[3], ub[4], ub[5]), ub[6]), ub[7]);
     const s16x2 drk = pmin(pmin3(pmin3(ud[0], ud[1], ud[2]), pmin3(ud[3], ud[4], ud[5]), ud[6]), ud[7]);
-    const s16x2 sraw = pmax(brt - vv, vv - drk);             // score + 1 (the 0x6400 offsets cancel)
+    const s16x2 sraw = pmax(brt - vv, vv - drk);             // score + 1
     return pmax(sraw, thv) - thv;
 }
 
@@ -585,24 +584,24 @@ __device__ __forceinline__ int wave_incl_scan_dpp(int v) {
 struct FastCtl { const uint32_t* prev; uint32_t* cur; int force; };
 
 // ---- strip kernel: one block scores G horizontally adjacent cells -----------------------------------
-// NMS and the 20 -> 7 fallback never cross a cell border; the ROI rows of G cells are staged once (shared 6-px halos), block
-// dispatch / barriers / the global append are amortised over G cells.
+// NMS and the 20 -> 7 fallback never cross a cell border; the ROI rows of the G cells are staged once, every cell at its own 16-byte
+// aligned LDS offset (unaligned 16-byte global loads), so that a lane's register windows are dword-aligned; block dispatch, barriers
+// and the global append are amortised over G cells.
 //   two-phase path:  1. compass pre-test on every pixel (work item = 4 pixels x 2 rows from a 6-row x 12-byte register window),
 //                       surviving pixel PAIRS are ballot-compacted into an LDS list (one LDS atomic per wave and iteration);
 //                    2. one lane per listed pair: 7 x 8-byte window, packed score, 16-bit store into the score map;
 //                    3. one lane per listed pair: 3x3 strict-maximum test on the score map.
-//   dense path:      every pixel is scored (work item = 4 pixels x 2 rows: the two 7-row windows share 6 rows), NMS per item.
+//   dense path:      every pixel is scored (work item = 4 pixels x 2 rows: the two 7-row windows share 6 rows); NMS on 4 x 4 blocks in
+//                    separable form; every 4-pixel row with a strict maximum leaves one list record, expanded by the append phase.
 // Blocks are handed out XCD-aware: consecutive strips (which share halo rows and columns) go to the same XCD's L2.
-#ifndef FAST_DBG
-#define FAST_DBG 0
-#endif
 template <int CW, int G>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 6 : 3))) void k_fast_strip(OrbPlan P, const uint8_t* __restrict__ pyr, size_t pyrStride,
                                                     const uint8_t* __restrict__ maskPyr,
                                                     uint32_t* __restrict__ cand, int32_t* __restrict__ candCount, FastCtl ctl, int batch) {
     constexpr int T = 256;
-    constexpr int TP = (15 + G * CW + 6 + 16 + 15) & ~15;              // row pitch of the staged tile (16-byte aligned rows)
-    constexpr int NQ = TP / 16;                                        // 16-byte groups per row
+    constexpr int CP = (CW + 6 + 15) & ~15;                            // every cell's ROI (cell + 6 halo columns) is staged at its own 16-byte aligned offset:
+    constexpr int TP = G * CP;                                         //   a lane's 12-byte windows are then dword-aligned and need no byte alignment
+    constexpr int NQC = CP / 16;                                       // 16-byte groups per cell row
     constexpr int TROWS = CW + 6 + 1;                                  // + 1: the second row of a work item reads one row further
     constexpr int SP = (CW + 4 + 8 + 3) & ~3;
     constexpr int SROWS = CW + 2 + 4;                                  // + 4: the dense path's NMS reads whole 4-row blocks (rows past the cell stay zero)
@@ -644,7 +643,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
     const int hr = maxY - iniY, hc = hr - 6;
     if (hc <= 0) return;
     // cells of this strip: interior widths (0 = cell skipped, :852)
-    int ncell = 0, wlast = 0, pairs_total = 0;
+    int ncell = 0, pairs_total = 0;
 #pragma unroll
     for (int c = 0; c < G; c++) {
         const int cj = cj0 + c;
@@ -652,30 +651,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
         int wc = 0;
         if (cj < g.nCols && iniX < g.maxBX - 6) wc = max(0, min(iniX + g.wCell + 6, g.maxBX) - iniX - 6);
         if ((int)threadIdx.x == c) s_wc[c] = wc;                       // per-cell widths are looked up from LDS (a register array would be indexed dynamically)
-        if (wc > 0) { ncell = c + 1; wlast = wc; }
+        if (wc > 0) ncell = c + 1;
         pairs_total += ((wc + 1) >> 1) * hc;
     }
     if (ncell == 0) return;
     auto wc_of = [&](int c) __attribute__((always_inline)) -> int { return s_wc[c]; };
     const int iniX0 = MIN_BORDER + cj0 * g.wCell;
-    const int endX = MIN_BORDER + (cj0 + ncell - 1) * g.wCell + wlast + 6;             // exclusive right edge of the last ROI
     const uint8_t* img = pyr + (size_t)b * pyrStride + g.imgOff;
-    const int x0a = iniX0 & ~15, off = iniX0 - x0a;                    // level planes are 256-byte aligned with 64-byte pitch
-    const int nq = min((endX - x0a + 15) >> 4, NQ);
-    {   // all loads of a thread are issued before its LDS stores
-        constexpr int NIT = (TROWS * NQ + T - 1) / T;
+    {   // all loads of a thread are issued before its LDS stores.  Unaligned 16-byte loads (a cell starts at any column); a load may run up
+        // to 15 bytes past its row or, in the last row of the last plane, into the slack behind the pyramid block — those bytes are never used
+        constexpr int NIT = (TROWS * G * NQC + T - 1) / T;
         uint4 v[NIT];
 #pragma unroll
         for (int u = 0; u < NIT; u++) {
-            const int i = threadIdx.x + u * T, r = i / NQ, k = i - r * NQ;
-            if (r < hr && k < nq && x0a + 16 * k < g.pitch)
-                v[u] = *reinterpret_cast<const uint4*>(img + (size_t)(iniY + r) * g.pitch + x0a + 16 * k);
-            else v[u] = make_uint4(0, 0, 0, 0);
+            const int i = threadIdx.x + u * T, r = i / (G * NQC), rem = i - r * (G * NQC), c = rem / NQC, k = rem - c * NQC;
+            const int x = iniX0 + c * g.wCell + 16 * k;
+            if (r < hr && c < ncell && x < g.pitch) {
+                const uint8_t* src = img + (size_t)(iniY + r) * g.pitch + x;
+                uint4 t;
+                __builtin_memcpy(&t, src, 16);
+                v[u] = t;
+            } else v[u] = make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int u = 0; u < NIT; u++) {
-            const int i = threadIdx.x + u * T, r = i / NQ, k = i - r * NQ;
-            if (r < hr && k < nq) *reinterpret_cast<uint4*>(&s_tile[r * TP + 16 * k]) = v[u];
+            const int i = threadIdx.x + u * T, r = i / (G * NQC), rem = i - r * (G * NQC), c = rem / NQC, k = rem - c * NQC;
+            if (r < hr && c < ncell) *reinterpret_cast<uint4*>(&s_tile[r * TP + c * CP + 16 * k]) = v[u];
         }
     }
     {   // zero the score maps (16-byte stores; the dword tail only exists when the array size is not a multiple of 16)
@@ -746,20 +747,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
                 cx = 4 * gi; cy = 2 * cy2;
                 const int wc = wc_of(c);
                 if (cx < wc) {
-                    const int col = off + c * g.wCell + cx;            // tile byte of ROI column cx of cell c
-                    const uint32_t sh = (uint32_t)(col & 3);
-                    const uint8_t* base = &s_tile[cy * TP + (col & ~3)];
+                    const uint8_t* base = &s_tile[cy * TP + c * CP + cx];     // ROI column cx of cell c: dword-aligned
                     uint32_t rc[2][3], ru[2][2], rd[2][2];             // centre rows (12 bytes), rows above / below the centres (8 bytes)
 #pragma unroll
                     for (int r = 0; r < 2; r++) {
                         const uint32_t* pu = reinterpret_cast<const uint32_t*>(base + (r + 0) * TP);
                         const uint32_t* pc = reinterpret_cast<const uint32_t*>(base + (r + 3) * TP);
                         const uint32_t* pd = reinterpret_cast<const uint32_t*>(base + (r + 6) * TP);
-                        const uint32_t u0 = pu[0], u1 = pu[1], u2 = pu[2], c0 = pc[0], c1 = pc[1], c2 = pc[2], c3 = pc[3], d0 = pd[0], d1 = pd[1], d2 = pd[2];
-                        ru[r][0] = __builtin_amdgcn_alignbyte(u1, u0, sh); ru[r][1] = __builtin_amdgcn_alignbyte(u2, u1, sh);
-                        rc[r][0] = __builtin_amdgcn_alignbyte(c1, c0, sh); rc[r][1] = __builtin_amdgcn_alignbyte(c2, c1, sh);
-                        rc[r][2] = __builtin_amdgcn_alignbyte(c3, c2, sh);
-                        rd[r][0] = __builtin_amdgcn_alignbyte(d1, d0, sh); rd[r][1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                        ru[r][0] = pu[0]; ru[r][1] = pu[1];
+                        rc[r][0] = pc[0]; rc[r][1] = pc[1]; rc[r][2] = pc[2];
+                        rd[r][0] = pd[0]; rd[r][1] = pd[1];
                     }
                     // pixel i of the group sits at window byte 3 + i: ring position 0 = (0, +3) in row + 6, 8 = (0, -3) in row + 0,
                     // 4 = (+3, 0) and 12 = (-3, 0) in the centre row.  Pair 0 = bytes (3, 4), pair 1 = bytes (5, 6).
@@ -796,7 +793,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
         for (int q = threadIdx.x; q < np; q += T) {
             const uint32_t e = s_pairs[q];
             const int c = (int)(e >> 11), row = (int)((e >> 5) & 63), cx = 2 * (int)(e & 31);
-            const int col = off + c * g.wCell + cx;
+            const int col = c * CP + cx;
             const uint32_t sh = (uint32_t)(col & 3);
             uint32_t r[7][3];
 #pragma unroll
@@ -852,23 +849,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
             if (gi_ >= ngr) { gi_ -= ngr; cy2_++; }
             if (cy2_ >= hc2) { cy2_ -= hc2; c_++; }
         };
-#if FAST_DBG == 2
-        return;
-#endif
         for (int q = threadIdx.x; q < nitems; q += T, advance(c, cy2, gi)) {
             const int wc = wc_of(c);
             const int cx = 4 * gi, cy = 2 * cy2;
             if (cx >= wc) continue;
-            const int col = off + c * g.wCell + cx;                        // tile byte of ROI column cx of cell c
-            const uint32_t sh = (uint32_t)(col & 3);
             uint32_t r[8][3];                                              // tile rows cy .. cy+7 (row cy+7 may lie below the ROI: staged as zeros / unused)
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint32_t* rp = reinterpret_cast<const uint32_t*>(&s_tile[(cy + j) * TP + (col & ~3)]);
-                const uint32_t w0 = rp[0], w1 = rp[1], w2 = rp[2], w3 = rp[3];
-                r[j][0] = __builtin_amdgcn_alignbyte(w1, w0, sh);
-                r[j][1] = __builtin_amdgcn_alignbyte(w2, w1, sh);
-                r[j][2] = __builtin_amdgcn_alignbyte(w3, w2, sh);
+            for (int j = 0; j < 8; j++) {                                  // ROI column cx of cell c: dword-aligned
+                const uint32_t* rp = reinterpret_cast<const uint32_t*>(&s_tile[(cy + j) * TP + c * CP + cx]);
+                r[j][0] = rp[0]; r[j][1] = rp[1]; r[j][2] = rp[2];
             }
             const uint32_t keepm = (wc - cx < 4) ? (1u << (8 * (wc - cx))) - 1u : 0xffffffffu;
             {
@@ -887,9 +876,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
             }
         }
         __syncthreads();
-#if FAST_DBG == 1
-        return;
-#endif
         int nquad = 0;                     // 4-pixel rows that hold a corner: counted on the scalar unit (ballot + s_bcnt1), the statistic of this path
         // NMS on 4 x 4 pixel blocks (6 score-map rows x 3 dwords per lane, separable 3x3 maximum).  Every 4-pixel row that holds a strict
         // maximum leaves ONE record (its filtered z dword) in the strip's list — four ballots and one LDS atomic per wave and

@@ -36,12 +36,12 @@ def short(name):
     return n
 
 
-def run_pass(counters, pairs, workload, outdir, scene_rects):
+def run_pass(counters, pairs, workload, outdir, scene_rects, extra=()):
     if os.path.isdir(outdir):
         shutil.rmtree(outdir)
     cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", outdir, "-o", "a", "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "2", "--pairs", str(pairs), "--workload", workload,
-           "--streams", "1", "--orb-internal-stream", "0", "--no-cpu-baseline", "--no-extra-passes", "--scene-rects", str(scene_rects)]
+           "--streams", "1", "--orb-internal-stream", "0", "--no-cpu-baseline", "--no-extra-passes", "--scene-rects", str(scene_rects)] + list(extra)
     env = dict(os.environ, TMPDIR="/tmp")
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
     files = glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True)
@@ -75,17 +75,19 @@ def main():
     ap.add_argument("--pairs", type=int, default=64)
     ap.add_argument("--workload", default="full")
     ap.add_argument("--scene-rects", type=int, default=6000)
+    ap.add_argument("--bench-arg", action="append", default=[], help="extra argument passed to bench.py (repeatable), e.g. --bench-arg=--fast-mode --bench-arg=1")
+    ap.add_argument("--sq-only", action="store_true", help="instruction counters only (one pass, no traffic calibration)")
     args = ap.parse_args()
     P, steps_total = args.pairs, 1          # run_pass() keeps the last step only
     out_root = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_root, exist_ok=True)
     kernels = collections.defaultdict(dict)
-    for counters in PASSES:
+    for counters in (PASSES[:1] if args.sq_only else PASSES):
         try:
-            agg, nd = run_pass(counters, P, args.workload, os.path.join(out_root, "pmc_tmp"), args.scene_rects)
+            agg, nd = run_pass(counters, P, args.workload, os.path.join(out_root, "pmc_tmp"), args.scene_rects, args.bench_arg)
         except SystemExit:
             if len(counters) > 5:          # an optional counter this rocprofv3 does not know: retry with the basic SQ set
-                agg, nd = run_pass(counters[:5], P, args.workload, os.path.join(out_root, "pmc_tmp"), args.scene_rects)
+                agg, nd = run_pass(counters[:5], P, args.workload, os.path.join(out_root, "pmc_tmp"), args.scene_rects, args.bench_arg)
             else:
                 raise
         for k, v in agg.items():
@@ -104,6 +106,12 @@ def main():
             rec["fetch_bytes_per_" + unit + "_raw"] = rec["FETCH_SIZE_total"] * 1024.0 / nunits
         if "WRITE_SIZE_total" in rec:
             rec["write_bytes_per_" + unit] = rec["WRITE_SIZE_total"] * 1024.0 / nunits
+    if args.sq_only:
+        for k, rec in sorted(kernels.items()):
+            u = rec["unit"]
+            print(f"{k:28s} VALU/{u} {rec.get('valu_wave_insts_per_' + u, 0):12.0f}  SALU {rec.get('SQ_INSTS_SALU_total', 0) / (2 * P if u == 'image' else P):12.0f}  "
+                  f"LDS {rec.get('SQ_INSTS_LDS_total', 0) / (2 * P if u == 'image' else P):10.0f}  busy cycles {rec.get('SQ_BUSY_CYCLES_total', 0):14.0f}")
+        return
     ing = kernels.get("k_ingest")
     if not ing or "fetch_bytes_per_image_raw" not in ing:
         raise SystemExit("k_ingest missing from the FETCH_SIZE pass: cannot calibrate")
