@@ -26,7 +26,7 @@ void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCo
                    int32_t* selCount, int32_t* status, int batch, hipStream_t s);
 void launch_describe(const OrbPlan& P, const uint8_t* pyr, const uint8_t* blur, size_t pyrStride, const uint32_t* selOut,
                      const int32_t* selCount, myslam_keypoint* kps, uint8_t* desc, int32_t* counts, int32_t* status,
-                     int cap, int detectOnly, int batch, hipStream_t s);
+                     int cap, int detectOnly, int batch, uint16_t* order, hipStream_t s);
 void launch_screen(const OrbPlan& P, const uint8_t* pyr, myslam_keypoint* kin, int n, myslam_keypoint* kout, uint8_t* keep,
                    hipStream_t s);
 void launch_calc_desc(const OrbPlan& P, const uint8_t* blur, const myslam_keypoint* kps, int n, uint8_t* desc, hipStream_t s);
@@ -105,6 +105,7 @@ struct myslam_orb {
     uint32_t* d_sort = nullptr;        // per level the candidates' 32-bit sort entries in bucket order + their path codes
     int32_t *d_candCount = nullptr, *d_selCount = nullptr, *d_status = nullptr;
     uint32_t* d_sel = nullptr;
+    uint16_t* d_order = nullptr;       // processing order of the descriptor kernel (tile order of the selected keys, orb_kernels.hip k_sel_order)
     uint32_t* d_octTab = nullptr;      // per-level oct-tree path-code / cell-index tables (see make_plan)
     // FAST path selection (orb_kernels.hip FastCtl): two [MAXL][4] counter blocks, the launch accumulates into one and reads the other
     uint32_t* d_fastStat = nullptr; int fastFlip = 0;
@@ -270,6 +271,7 @@ int myslam_orb::ensure(int batch, int r, int c, bool needMask) {
         if ((rc = dev_alloc(d_selCount, (size_t)batch * MAXL))) return rc;
         if ((rc = dev_alloc(d_status, (size_t)batch))) return rc;
         if ((rc = dev_alloc(d_sel, (size_t)batch * selPer))) return rc;
+        if ((rc = dev_alloc(d_order, (size_t)batch * selPer))) return rc;
         if ((rc = dev_alloc(d_mask, 0))) return rc;
         maskAlloc = false;
         batchCap = batch;
@@ -362,7 +364,7 @@ int myslam_orb::run_batch(const uint8_t* d_imgs, int batch, int r, int c, int st
     {
         ScopedProf sp(P_DESC, stream);
         launch_describe(P, d_pyr, d_blur, full.pyrBytes, d_sel, d_selCount, d_kps, d_desc, d_counts, stat, cap,
-                        detectOnly ? 1 : 0, batch, stream);
+                        detectOnly ? 1 : 0, batch, d_order, stream);
     }
     MYSLAM_HIP_CHECK(hipGetLastError());
     return MYSLAM_OK;
@@ -399,7 +401,7 @@ int myslam_orb::ensure_stage(size_t imgBytes, size_t maskBytes, int cap) {
 }
 
 void myslam_orb::free_all() {
-    void* ptrs[] = {d_fastStat, d_octTab, d_pyr, d_blur, d_mask, d_cand, d_sort, d_candCount, d_selCount, d_status, d_sel, d_stageImg, d_stageMask,
+    void* ptrs[] = {d_fastStat, d_octTab, d_pyr, d_blur, d_mask, d_cand, d_sort, d_candCount, d_selCount, d_status, d_sel, d_order, d_stageImg, d_stageMask,
                     d_stageKps, d_stageKps2, d_stageDesc, d_stageKeep, d_stageCounts};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); (void)hipEventDestroy(evFork); (void)hipEventDestroy(evJoin); aux = nullptr; }

@@ -1646,13 +1646,56 @@ __device__ __forceinline__ int wave_sum_lane63_i32(int v) {
 
 constexpr int KD_KPB = 64;                                       // keypoints per block
 
+// Processing order of the descriptor kernel: the selected keys of a level in Z-order of small pixel tiles (a counting sort over
+// <= 1024 tile bins per (image, level); 32 x 32 pixels at 1241 x 376).  The oct-tree's list order scatters consecutive key-points all over the level; in tile order
+// the 64 key-points of a block sit in a compact region, their 37 x 37 / 32 x 32 windows overlap and are fetched once per block
+// instead of once per key-point.  Only the ORDER OF WORK changes: results go to the slots the list order prescribes.
+__global__ __launch_bounds__(256) void k_sel_order(OrbPlan P, const uint32_t* __restrict__ selOut, const int32_t* __restrict__ selCount,
+                                                   uint16_t* __restrict__ order, int batch) {
+    constexpr int NB = 1024;                                           // tile bins: columns < 64, rows < 16
+    __shared__ int s_hist[NB], s_wsum[4];
+    const int level = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    const LevelGeom& g = P.lv[level];
+    const int n = min(selCount[b * MAXL + level], g.nodeCap);
+    int ts = 4;                                                        // tile shift (bin = column high bits | Z-order of the low 4 + 4 bits)
+    while ((g.w >> ts) >= 64 || (g.h >> ts) >= 16) ts++;
+    const uint32_t* sel = selOut + (size_t)b * P.totalOut + g.outBase;
+    uint16_t* out = order + (size_t)b * P.totalOut + g.outBase;
+    for (int i = t; i < NB; i += 256) s_hist[i] = 0;
+    __syncthreads();
+    auto bin_of = [&](uint32_t pay) -> int {
+        const int tx = (int)((pay >> 8) & 0xfff) >> ts, ty = (int)(pay >> 20) >> ts;
+        int z = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) z |= (((tx >> k) & 1) << (2 * k)) | (((ty >> k) & 1) << (2 * k + 1));
+        return ((tx >> 4) << 8) | z;
+    };
+    for (int i = t; i < n; i += 256) atomicAdd(&s_hist[bin_of(sel[i])], 1);
+    __syncthreads();
+    {   // exclusive scan of the bins: 4 consecutive bins per thread, wave scans, 4 wave totals
+        const int v0 = s_hist[4 * t], v1 = s_hist[4 * t + 1], v2 = s_hist[4 * t + 2], v3 = s_hist[4 * t + 3];
+        const int v = v0 + v1 + v2 + v3;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int nb = __shfl_up(incl, o, 64); if ((t & 63) >= o) incl += nb; }
+        if ((t & 63) == 63) s_wsum[t >> 6] = incl;
+        __syncthreads();
+        int base = incl - v;
+        for (int w = 0; w < (t >> 6); w++) base += s_wsum[w];
+        s_hist[4 * t] = base; s_hist[4 * t + 1] = base + v0; s_hist[4 * t + 2] = base + v0 + v1; s_hist[4 * t + 3] = base + v0 + v1 + v2;
+    }
+    __syncthreads();
+    for (int i = t; i < n; i += 256) out[atomicAdd(&s_hist[bin_of(sel[i])], 1)] = (uint16_t)i;
+}
+
 __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                                    size_t pyrStride, const uint32_t* __restrict__ selOut,
                                                    const int32_t* __restrict__ selCount, myslam_keypoint* __restrict__ kps,
                                                    uint8_t* __restrict__ desc, int32_t* __restrict__ counts,
-                                                   int32_t* __restrict__ status, int cap, int nchunk, int batch, int detectOnly) {
+                                                   int32_t* __restrict__ status, int cap, int nchunk, int batch, int detectOnly,
+                                                   const uint16_t* __restrict__ order) {
     __shared__ __attribute__((aligned(16))) uint32_t s_b[4][DB_N];
-    __shared__ int s_x[KD_KPB], s_y[KD_KPB], s_lv[KD_KPB], s_m10[KD_KPB], s_m01[KD_KPB];
+    __shared__ int s_x[KD_KPB], s_y[KD_KPB], s_lv[KD_KPB], s_m10[KD_KPB], s_m01[KD_KPB], s_out[KD_KPB];
     __shared__ float s_ca[KD_KPB], s_sb[KD_KPB];
     __shared__ __attribute__((aligned(16))) uint4 s_bw[16 * 4 * 2];      // IC-angle weights as MFMA B operands: [row pair][k block][x | y]
     __shared__ uint32_t s_pbase[KD_KPB], s_ppitch[KD_KPB];              // byte offset of patch(-15, -15) in the pyramid plane set, row pitch
@@ -1692,7 +1735,15 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
             counts[b] = min(total, cap);
             if (total > cap && status) status[b] = MYSLAM_ERR_CAPACITY;
         }
-        const bool active = (level >= 0 && slot < cap);
+        // work item `slot` = the local-th key of its level in PROCESSING order; it is written where the oct-tree's list order puts it
+        int oslot = slot;
+        if (level >= 0 && order) {
+            const int orig = order[(size_t)b * P.totalOut + P.lv[level].outBase + local];
+            oslot = slot - local + orig;
+            local = orig;
+        }
+        const bool active = (level >= 0 && oslot < cap);
+        s_out[t] = oslot;
         uint32_t pay = 0;
         if (active) pay = selOut[(size_t)b * P.totalOut + P.lv[level].outBase + local];
         s_lv[t] = active ? level : -1;
@@ -1706,7 +1757,7 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
         if (detectOnly && active) {                // ORBextractor::Detect (:1067-1073): raw cv::FAST keypoints of level 0, no angle / descriptor
             myslam_keypoint kp;
             kp.x = (float)s_x[t]; kp.y = (float)s_y[t]; kp.size = 7.f; kp.angle = -1.f; kp.response = resp; kp.octave = 0; kp.class_id = -1;
-            kps[(size_t)b * cap + slot] = kp;
+            kps[(size_t)b * cap + oslot] = kp;
         }
     }
     if (detectOnly) return;                        // block-uniform
@@ -1762,7 +1813,7 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
         kp.x = (level != 0) ? __fmul_rn((float)x, g.scale) : (float)x;                            // :975-981
         kp.y = (level != 0) ? __fmul_rn((float)y, g.scale) : (float)y;
         kp.size = g.scaledPatch; kp.angle = angle; kp.response = resp; kp.octave = level; kp.class_id = -1;
-        kps[(size_t)b * cap + slot0 + t] = kp;
+        kps[(size_t)b * cap + s_out[t]] = kp;
     }
     __syncthreads();
     // ---- C ----
@@ -1770,7 +1821,7 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
 #pragma unroll
     for (int q = 0; q < 16; q++) pat[q] = (float)c_pattern[lane * 16 + q];
     for (int j = 0; j < KD_KPB / 4; j++) {
-        const int k = wave * (KD_KPB / 4) + j;
+        const int k = 4 * j + wave;                                   // the four waves work on neighbouring key-points of the tile order: their windows overlap in L1
         const int level = __builtin_amdgcn_readfirstlane(s_lv[k]);
         if (level < 0) continue;
         const LevelGeom& g = P.lv[level];
@@ -1805,7 +1856,7 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
         const uint32_t byte = nib | (__shfl_down(nib, 1, 64) << 4);            // valid on even lanes
         uint32_t w = byte | (__shfl_down(byte, 2, 64) << 8);
         w |= (__shfl_down(byte, 4, 64) << 16) | (__shfl_down(byte, 6, 64) << 24);   // valid on lanes % 8 == 0
-        if ((lane & 7) == 0) reinterpret_cast<uint32_t*>(desc + ((size_t)b * cap + slot0 + k) * 32)[lane >> 3] = w;
+        if ((lane & 7) == 0) reinterpret_cast<uint32_t*>(desc + ((size_t)b * cap + s_out[k]) * 32)[lane >> 3] = w;
     }
 }
 
@@ -1970,11 +2021,12 @@ void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCo
 
 void launch_describe(const OrbPlan& P, const uint8_t* pyr, const uint8_t* blur, size_t pyrStride, const uint32_t* selOut,
                      const int32_t* selCount, myslam_keypoint* kps, uint8_t* desc, int32_t* counts, int32_t* status,
-                     int cap, int detectOnly, int batch, hipStream_t s) {
+                     int cap, int detectOnly, int batch, uint16_t* order, hipStream_t s) {
     const int slots = min(cap, P.totalOut);
     const int nchunk = (slots + KD_KPB - 1) / KD_KPB;
+    if (order && !detectOnly) hipLaunchKernelGGL(k_sel_order, dim3(P.nlevels, batch), dim3(256), 0, s, P, selOut, selCount, order, batch);
     hipLaunchKernelGGL(k_describe2, dim3(nchunk * batch), dim3(256), 0, s, P, pyr, blur, pyrStride, selOut, selCount,
-                       kps, desc, counts, status, cap, nchunk, batch, detectOnly);
+                       kps, desc, counts, status, cap, nchunk, batch, detectOnly, detectOnly ? nullptr : order);
 }
 
 void launch_screen(const OrbPlan& P, const uint8_t* pyr, myslam_keypoint* kin, int n, myslam_keypoint* kout, uint8_t* keep,
