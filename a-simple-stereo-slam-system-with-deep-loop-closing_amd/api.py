@@ -242,6 +242,12 @@ class ORBextractor:
                                                  _p(xs), _p(ys), _p(sc), cap, C.byref(n)), "debug_candidates")
         return xs[:n.value].copy(), ys[:n.value].copy(), sc[:n.value].copy()
 
+    def fast_statistics(self, level):
+        """what the last grid-FAST launch measured on `level`: (statistic, pixel pairs, path) — myslam_orb_debug_readback(what = 6)"""
+        out = np.zeros(4, np.uint32)
+        _check(lib().myslam_orb_debug_readback(self._h, 6, 0, level, _p(out), out.nbytes, 0), "debug_readback")
+        return int(out[0]), int(out[1]), int(out[2])
+
 
 # ---------------------------------------------------------------------------------- Hamming / triangulation
 def hamming_match(query, train):

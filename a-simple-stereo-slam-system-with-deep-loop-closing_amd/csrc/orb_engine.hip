@@ -111,7 +111,7 @@ struct myslam_orb {
     uint32_t* d_fastStat = nullptr; int fastFlip = 0;
     // options (myslam_orb_set_option)
     int optFastMode = -1;              // -1 = chosen per level from the previous launch's statistics, 0 = two-phase, 1 = dense
-    int optInternalStream = 2;         // 0 = everything on the caller's stream, 1 = Gaussian pyramid forked after FAST, 2 = after the image pyramid
+    int optInternalStream = 1;         // 0 = everything on the caller's stream, 1 = Gaussian pyramid forked after FAST (default), 2 = after the image pyramid
     int optStopAfter = 0;              // debug: stop a batched call after stage 1 ingest / 2 pyramid / 3 oct-tree / 4 blur (0 = run all)
     int tapsSet = 0, taps[7] = {0};    // myslam_orb_set_gauss_taps: replacement of the sigma = 2 Q8 taps
 
@@ -687,6 +687,12 @@ int myslam_orb_debug_readback(myslam_orb* h, int what, int b, int level, void* o
         case 3: {
             if (cap_bytes < (size_t)g.keyCap * 4) return MYSLAM_ERR_CAPACITY;
             MYSLAM_HIP_CHECK(hipMemcpy(out, h->d_cand + (size_t)b * P.totalKeyCap + g.keyOff, (size_t)g.keyCap * 4, hipMemcpyDeviceToHost));
+            return MYSLAM_OK;
+        }
+        case 6: {     // what the last grid-FAST launch measured on this level (FastCtl, orb_kernels.hip): {statistic, pixel pairs, path, 0}
+            if (cap_bytes < 16) return MYSLAM_ERR_CAPACITY;
+            if (!h->d_fastStat) return MYSLAM_ERR_INVALID;
+            MYSLAM_HIP_CHECK(hipMemcpy(out, h->d_fastStat + ((size_t)(h->fastFlip ^ 1) * MAXL + level) * 4, 16, hipMemcpyDeviceToHost));
             return MYSLAM_OK;
         }
         case 5: {

@@ -576,11 +576,12 @@ __device__ __forceinline__ int wave_incl_scan_dpp(int v) {
 // Path selection of the strip kernel (per level): `prev` = what the previous launch of this extractor handle measured,
 // `cur` = what this launch accumulates (zeroed by the host): [level][4] = {pixel pairs that survived the pre-test (two-phase path) or
 // 4-pixel rows holding a corner (dense path), pixel pairs looked at, path used, -}.  force: -1 = choose, 0 = two-phase, 1 = dense.
-// Both paths produce the same candidate SET, so the choice only moves time.  Measured on MI355X (ms per 512 images, two-phase / dense,
-// against the fraction of pixel pairs that survive the pre-test): 0.09: 1.01 / 1.54, 0.18: 1.26 / 1.60, 0.30: 1.53 / 1.61,
-// 0.46: 1.81 / 1.64, 0.63: 2.04 / 1.63 — break-even near 0.41.  The switch goes to dense above 0.41 surviving pairs and back when
-// fewer than 0.33 of the 4-pixel rows hold a corner (the dense path's own statistic, free on the scalar unit; about 0.37 at the
-// break-even; there are half as many 4-pixel rows as pixel pairs, hence the 0.165 below).
+// Both paths produce the same candidate SET, so the choice only moves time.  Measured on MI355X (ms per 512 images of 1241 x 376,
+// two-phase / dense, against the fraction of the pixel pairs that survive the pre-test; tools/fast_path_table.py prints the fractions,
+// bench.py --fast-mode the times): 0.14: 1.00 / 1.41, 0.29: 1.26 / 1.42, 0.45: 1.53 / 1.44, 0.54: 1.68 / 1.45, 0.62: 1.80 / 1.46,
+// 0.76: 2.02 / 1.48 — the two-phase path costs 0.78 + 1.63 s, break-even at s = 0.40.  The switch goes to dense above 0.41 surviving
+// pairs and back when fewer than 0.165 corner rows per pixel pair are seen (the dense path's own statistic, free on the scalar unit:
+// 0.174 at the break-even).
 struct FastCtl { const uint32_t* prev; uint32_t* cur; int force; };
 
 // ---- strip kernel: one block scores G horizontally adjacent cells -----------------------------------

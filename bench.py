@@ -107,8 +107,9 @@ def parse():
                          "-1 (default) = 1 with --streams 2, else 0")
     ap.add_argument("--verify", action="store_true",
                     help="after the timed region: run one joined, un-gated step and check that it reproduces the pipeline's last outputs bit for bit")
-    ap.add_argument("--orb-internal-stream", type=int, default=2, choices=[0, 1, 2],
-                    help="myslam_orb_set_option(INTERNAL_STREAM): 2 = Gaussian pyramid on the extractor's internal stream (default), 0 = one stream")
+    ap.add_argument("--orb-internal-stream", type=int, default=1, choices=[0, 1, 2],
+                    help="myslam_orb_set_option(INTERNAL_STREAM): 1 = Gaussian pyramid on the extractor's internal stream beside the oct-tree kernel "
+                         "(the library's default), 2 = beside FAST, 0 = one stream")
     ap.add_argument("--fast-mode", type=int, default=-1, choices=[-1, 0, 1],
                     help="myslam_orb_set_option(FAST_MODE): -1 = the FAST kernel picks its path per level (default), 0 = two-phase, 1 = dense")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],

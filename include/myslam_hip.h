@@ -83,8 +83,8 @@ int myslam_orb_set_fast_gate(myslam_orb* h, void* hip_event);
  *                    a compass pre-test + compaction of the surviving pixel pairs (imagery with a few % of corners: a tenth of the pixels
  *                    is scored) or full scoring of every pixel (noise-like texture where most pairs survive the pre-test);
  *                    0 / 1 force the two-phase / the dense path
- *   INTERNAL_STREAM  2 (default) = the Gaussian pyramid runs on an internal stream right after the image pyramid, 1 = forked after FAST,
- *                    0 = everything on the handle's stream
+ *   INTERNAL_STREAM  1 (default) = the Gaussian pyramid runs on an internal stream beside the oct-tree kernel (forked after FAST),
+ *                    2 = forked right after the image pyramid (beside FAST), 0 = everything on the handle's stream
  *   STOP_AFTER       debug: a batched call returns after stage 1 ingest / 2 pyramid / 3 oct-tree / 4 blur (0 = complete call) */
 #define MYSLAM_ORB_OPT_FAST_MODE 1
 #define MYSLAM_ORB_OPT_INTERNAL_STREAM 2
@@ -143,7 +143,9 @@ int myslam_orb_debug_candidates(myslam_orb* h, const uint8_t* img, int rows, int
                                 int32_t* xs, int32_t* ys, int32_t* scores, int cap, int* n);
 
 /* raw readback of the engine's HBM buffers after a *_batch call: what = 0 pyramid plane (w*h, tight), 1 blurred
- * plane, 2 candidate count (i32), 3 candidate payloads (u32 py<<20|px<<8|score), 4 selected count, 5 selected payloads */
+ * plane, 2 candidate count (i32), 3 candidate payloads (u32 py<<20|px<<8|score), 4 selected count, 5 selected payloads,
+ * 6 the grid-FAST statistics of the last launch on `level`: 4 x u32 {pixel pairs that survived the pre-test (two-phase path) or 4-pixel
+ * rows holding a corner (dense path), pixel pairs looked at — both over the sampled strips —, path used (0 two-phase, 1 dense), 0} */
 int myslam_orb_debug_readback(myslam_orb* h, int what, int b, int level, void* out, size_t cap_bytes, int detect_plan);
 
 /* ------------------------------------------------------------------------------------------
