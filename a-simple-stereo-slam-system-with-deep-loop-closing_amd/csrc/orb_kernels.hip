@@ -93,14 +93,16 @@ __global__ __launch_bounds__(256) void k_resize(ResizeArgs a) {
 // and walks RS_R destination rows: x coordinates / weights are computed once, every needed source row is sampled once
 // (one unaligned 2-byte load per pixel = the two horizontal taps, v_perm + v_dot2_u32_u16 = the 11-bit interpolation) and
 // reused by the destination rows that share it (the OpenCV row cache), all row decisions are wave-uniform.
-constexpr int RS_R = 8;                      // destination rows per wave (power of two)
+constexpr int RS_R = 8;                      // destination rows per band (power of two)
+constexpr int RS_NB = 2;                     // bands a wave walks with one set of column coordinates (RS_NB * RS_R <= 64)
 constexpr int RS_MAXR = 12;                  // source rows a band may span: RS_R * scale_y + 2 (scale factors up to 1.25)
 
 __global__ __launch_bounds__(256) void k_resize_strip(ResizeArgs a, int nstrips, int nbands) {
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // scalar: row addressing goes to the SALU
-    if (wid >= nstrips * nbands) return;
-    const int strip = wid % nstrips, band = wid / nstrips;
+    const int ngroups = (nbands + RS_NB - 1) / RS_NB;                                              // a wave walks RS_NB consecutive bands of its strip
+    if (wid >= nstrips * ngroups) return;
+    const int strip = wid % nstrips, group = wid / nstrips;
     const int b = blockIdx.z;
     const int dx4 = strip * 256 + 4 * lane;
     const bool has = dx4 < a.dw;
@@ -113,58 +115,68 @@ __global__ __launch_bounds__(256) void k_resize_strip(ResizeArgs a, int nstrips,
         resize_coord(min(dx4 + k, a.dw - 1), a.scale_x, a.sw, true, sx[k], c0, c1);
         aw[k] = (uint32_t)c0 | ((uint32_t)c1 << 16);
     }
-    const int dy0 = band * RS_R, dy1 = min(dy0 + RS_R, a.dh);
-    // the band's row coordinates: lane k computes row dy0 + k once, the loop reads them back as scalars
-    int ysy, yb0, yb1;
-    resize_coord(min(dy0 + (lane & (RS_R - 1)), a.dh - 1), a.scale_y, a.sh, false, ysy, yb0, yb1);
-    // every source row the band needs, fetched in ONE batch of loads (the kernel is latency-bound otherwise), interpolated
-    // horizontally once (the OpenCV row cache) and parked in LDS as 16-bit values for the vertical step
-    const int rfirst = min(max(__builtin_amdgcn_readlane(ysy, 0), 0), a.sh - 1);
-    const int rlast = min(max(__builtin_amdgcn_readlane(ysy, dy1 - 1 - dy0) + 1, 0), a.sh - 1);
-    const int nrows = rlast - rfirst + 1;                        // <= RS_MAXR (checked by the launcher)
     // One unaligned 8-byte load per source row covers the byte pairs of all four destination columns (their source columns span at
     // most 3 scale_x + 2 <= 7 bytes; the launcher checks scale_x): the kernel is bound by the ISSUE of its gather loads, so four
     // 2-byte loads per row cost four times as much.  The pairs are picked with byte permutes whose selectors are lane constants.
     uint32_t selk[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) { const uint32_t o = (uint32_t)(sx[k] - sx[0]); selk[k] = 0x0c000c00u | ((o + 1u) << 16) | o; }
-    uint2 raw8[RS_MAXR];
+    // the row coordinates of all RS_NB bands: lane k computes row dy0 + k once (RS_NB * RS_R <= 64), the loops read them back as scalars
+    const int gy0 = group * RS_NB * RS_R;
+    int ysy, yb0, yb1;
+    resize_coord(min(gy0 + (lane & (RS_NB * RS_R - 1)), a.dh - 1), a.scale_y, a.sh, false, ysy, yb0, yb1);
+    for (int bi = 0; bi < RS_NB; bi++) {
+        const int dy0 = gy0 + bi * RS_R, dy1 = min(dy0 + RS_R, a.dh), l0 = bi * RS_R;
+        if (dy0 >= a.dh) break;                                      // uniform
+        // every source row the band needs, fetched in ONE batch of loads (the kernel is latency-bound otherwise) and interpolated
+        // horizontally once (the OpenCV row cache, kept in registers)
+        const int rfirst = min(max(__builtin_amdgcn_readlane(ysy, l0), 0), a.sh - 1);
+        const int rlast = min(max(__builtin_amdgcn_readlane(ysy, l0 + dy1 - 1 - dy0) + 1, 0), a.sh - 1);
+        const int nrows = rlast - rfirst + 1;                        // <= RS_MAXR (checked by the launcher)
+        uint2 raw8[RS_MAXR];
 #pragma unroll
-    for (int rr = 0; rr < RS_MAXR; rr++) {
-        const uint8_t* row = src + (size_t)(rfirst + min(rr, nrows - 1)) * a.spitch;
-        raw8[rr] = make_uint2(0u, 0u);
-        // at the right border sx = sw-1 and the weight of sx+1 is 0 (OpenCV clamps fx there): the bytes past the row are never weighted
-        if (has && rr < nrows) __builtin_memcpy(&raw8[rr], row + sx[0], 8);
-    }
-    // horizontal pass: raw[rr][k] <- the row-cache value (<= 32640) of source row rfirst + rr at this lane's 4 columns
-    uint32_t raw[RS_MAXR][4];
-#pragma unroll
-    for (int rr = 0; rr < RS_MAXR; rr++)
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t pp = __builtin_amdgcn_perm(raw8[rr].y, raw8[rr].x, selk[k]);       // (p0, p1) as two u16
-            raw[rr][k] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pp), __builtin_bit_cast(u16x2, aw[k]), 0u, false) >> 4;
+        for (int rr = 0; rr < RS_MAXR; rr++) {
+            const uint8_t* row = src + (size_t)(rfirst + min(rr, nrows - 1)) * a.spitch;
+            raw8[rr] = make_uint2(0u, 0u);
+            // at the right border sx = sw-1 and the weight of sx+1 is 0 (OpenCV clamps fx there): the bytes past the row are never weighted
+            if (has && rr < nrows) __builtin_memcpy(&raw8[rr], row + sx[0], 8);
         }
-    // vertical pass: walk the source rows statically (the row cache stays in registers, no run-time register indexing) and emit the
-    // destination rows whose upper source row is the current one — at most one per source row for scale >= 1; the row coordinates
-    // are wave-uniform scalars
-    int dy = dy0;
-    int sy = __builtin_amdgcn_readlane(ysy, 0), b0 = __builtin_amdgcn_readlane(yb0, 0), b1 = __builtin_amdgcn_readlane(yb1, 0);
+        // horizontal pass: raw[rr][k] <- 16 x the row-cache value (<= 32640) of source row rfirst + rr at this lane's 4 columns
+        // (the low four bits are cleared instead of shifted out: the vertical step multiplies 24-bit operands and keeps bits 32..)
+        uint32_t raw[RS_MAXR][4];
 #pragma unroll
-    for (int rr = 0; rr < RS_MAXR; rr++) {
-        while (dy < dy1 && min(max(sy, 0), a.sh - 1) - rfirst == rr) {          // uniform
-            const bool same = min(max(sy + 1, 0), a.sh - 1) - rfirst == rr;     // clamped at an image border: both taps on this row
-            uint32_t packed = 0;
+        for (int rr = 0; rr < RS_MAXR; rr++)
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int tA = (int)raw[rr][k], tB = (int)(same ? raw[rr][k] : raw[rr + 1 < RS_MAXR ? rr + 1 : rr][k]);
-                const int v = (((b0 * tA) >> 16) + ((b1 * tB) >> 16) + 2) >> 2;     // in [0, 255]: the weights of each axis sum to 2048
-                packed |= (uint32_t)v << (8 * k);
+                const uint32_t pp = __builtin_amdgcn_perm(raw8[rr].y, raw8[rr].x, selk[k]);       // (p0, p1) as two u16
+                raw[rr][k] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pp), __builtin_bit_cast(u16x2, aw[k]), 0u, false) & ~15u;
             }
-            if (has) *reinterpret_cast<uint32_t*>(dst + (size_t)dy * a.dpitch + dx4) = packed;
-            dy++;
-            if (dy < dy1) {
-                sy = __builtin_amdgcn_readlane(ysy, dy - dy0); b0 = __builtin_amdgcn_readlane(yb0, dy - dy0); b1 = __builtin_amdgcn_readlane(yb1, dy - dy0);
+        // vertical pass: walk the source rows statically (the row cache stays in registers, no run-time register indexing) and emit the
+        // destination rows whose upper source row is the current one — at most one per source row for scale >= 1; the row coordinates
+        // are wave-uniform scalars.  (b * t) >> 16 with b <= 2048 and t <= 32640 is the high word of (b << 12) * (16 t): both factors
+        // fit 24 bits, so it is ONE full-rate v_mul_hi_u32_u24 (a 32-bit v_mul_lo_u32 runs at quarter rate).
+        int dy = dy0;
+        int sy = __builtin_amdgcn_readlane(ysy, l0);
+        uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane(yb0, l0) << 12, b1 = (uint32_t)__builtin_amdgcn_readlane(yb1, l0) << 12;
+#pragma unroll
+        for (int rr = 0; rr < RS_MAXR; rr++) {
+            while (dy < dy1 && min(max(sy, 0), a.sh - 1) - rfirst == rr) {          // uniform
+                const bool same = min(max(sy + 1, 0), a.sh - 1) - rfirst == rr;     // clamped at an image border: both taps on this row
+                uint32_t packed = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t tA = raw[rr][k], tB = same ? raw[rr][k] : raw[rr + 1 < RS_MAXR ? rr + 1 : rr][k];
+                    const uint32_t hA = (uint32_t)(((uint64_t)(b0 & 0xffffffu) * (uint64_t)(tA & 0xffffffu)) >> 32);
+                    const uint32_t hB = (uint32_t)(((uint64_t)(b1 & 0xffffffu) * (uint64_t)(tB & 0xffffffu)) >> 32);
+                    const uint32_t v = (hA + hB + 2u) >> 2;                         // in [0, 255]: the weights of each axis sum to 2048
+                    packed |= v << (8 * k);
+                }
+                if (has) *reinterpret_cast<uint32_t*>(dst + (size_t)dy * a.dpitch + dx4) = packed;
+                dy++;
+                if (dy < dy1) {
+                    sy = __builtin_amdgcn_readlane(ysy, l0 + dy - dy0);
+                    b0 = (uint32_t)__builtin_amdgcn_readlane(yb0, l0 + dy - dy0) << 12; b1 = (uint32_t)__builtin_amdgcn_readlane(yb1, l0 + dy - dy0) << 12;
+                }
             }
         }
     }
@@ -1979,7 +1991,8 @@ void launch_resize(const ResizeArgs& a, int batch, hipStream_t s) {
     // register strips cover pyramid scale factors up to 1.25 (rows) / 1.6 (columns); larger steps take the generic kernel
     if ((double)RS_R * a.scale_y + 2.0 <= (double)RS_MAXR && a.scale_x <= 1.6) {
         const int nstrips = (a.dw + 255) / 256, nbands = (a.dh + RS_R - 1) / RS_R;
-        hipLaunchKernelGGL(k_resize_strip, dim3((nstrips * nbands + 3) / 4, 1, batch), dim3(256), 0, s, a, nstrips, nbands);
+        const int ngroups = (nbands + RS_NB - 1) / RS_NB;
+        hipLaunchKernelGGL(k_resize_strip, dim3((nstrips * ngroups + 3) / 4, 1, batch), dim3(256), 0, s, a, nstrips, nbands);
         return;
     }
     dim3 grid((a.dw + 255) / 256, (a.dh + 3) / 4, batch);
