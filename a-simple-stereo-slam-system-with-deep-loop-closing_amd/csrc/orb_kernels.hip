@@ -1840,13 +1840,15 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
         const LevelGeom& g = P.lv[level];
         const int x = __builtin_amdgcn_readfirstlane(s_x[k]), y = __builtin_amdgcn_readfirstlane(s_y[k]);
         const float ca = s_ca[k], sb = s_sb[k];
-        const uint8_t* bl = blur + (size_t)b * pyrStride + g.imgOff;
         const int xb0 = (x - DB_R) & ~3, offB = (x - DB_R) - xb0;
+        // window origin: wave-uniform 64-bit base + a 32-bit lane offset from full-rate 24-bit multiplies (32-bit and 64-bit integer
+        // multiplies run at quarter rate)
+        const uint8_t* bl = blur + (size_t)b * pyrStride + g.imgOff + (size_t)(y - DB_R) * g.pitch + xb0;
         uint32_t rb[DB_IT];
 #pragma unroll
         for (int q = 0; q < DB_IT; q++) {
             const int i = lane + 64 * q;
-            rb[q] = (i < DB_N) ? *reinterpret_cast<const uint32_t*>(bl + (size_t)(y - DB_R) * g.pitch + xb0 + (rb_[q] * g.pitch + cb_[q])) : 0u;
+            rb[q] = (i < DB_N) ? *reinterpret_cast<const uint32_t*>(bl + (uint32_t)(__mul24(rb_[q], g.pitch) + cb_[q])) : 0u;
         }
         __builtin_amdgcn_wave_barrier();                                  // previous keypoint's window reads are done (same wave)
 #pragma unroll
@@ -1863,7 +1865,7 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
             const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sb)));
             const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sb), __fmul_rn(y1, ca)));
             const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sb)));
-            const int t0 = center[r0 * DB_P + c0], t1 = center[r1 * DB_P + c1];
+            const int t0 = center[__mul24(r0, DB_P) + c0], t1 = center[__mul24(r1, DB_P) + c1];
             nib |= (uint32_t)(t0 < t1) << q;
         }
         const uint32_t byte = nib | (__shfl_down(nib, 1, 64) << 4);            // valid on even lanes
