@@ -30,6 +30,34 @@ def test_fast_paths_bitexact(api, oracle, synth, mode, kind, nrect):
         assert sorted(zip(ys.tolist(), xs.tolist(), sc.tolist())) == sorted(zip(ry.tolist(), rx.tolist(), rs.tolist())), (mode, kind, lvl)
 
 
+def test_fast_statistics_readback(api, synth):
+    """myslam_orb_debug_readback(what = 6): the numbers the path choice is made from — forced modes report their own path, the
+    surviving-pair fraction of noise is far above that of a sparse scene, and the automatic mode follows them"""
+    noise = synth.random_image(11, 240, 420, "noise")
+    sparse = synth.stereo_batch(1, stream_id=4, n_rect=150, h=240, w=420)[0, 0]
+    frac = {}
+    for name, img in (("noise", noise), ("sparse", sparse)):
+        ext = api.ORBextractor(500)
+        ext.set_option(ext.OPT_FAST_MODE, 0)
+        ext.DetectAndCompute(img)
+        stat, pairs, path = ext.fast_statistics(0)
+        assert path == 0 and 0 < pairs and stat <= pairs
+        frac[name] = stat / pairs
+        ext.set_option(ext.OPT_FAST_MODE, 1)
+        ext.DetectAndCompute(img)
+        stat1, pairs1, path1 = ext.fast_statistics(0)
+        assert path1 == 1 and pairs1 == pairs and stat1 <= pairs1
+    assert frac["noise"] > 0.6 and frac["sparse"] < 0.3
+    ext = api.ORBextractor(500)                               # automatic: first launch two-phase (no history), then what the history says
+    ext.DetectAndCompute(noise)
+    assert ext.fast_statistics(0)[2] == 0
+    ext.DetectAndCompute(noise)
+    assert ext.fast_statistics(0)[2] == 1
+    ext.DetectAndCompute(sparse)                              # still decided by the noise image's statistics
+    ext.DetectAndCompute(sparse)
+    assert ext.fast_statistics(0)[2] == 0
+
+
 def test_fast_mode_switches_between_batches(api, oracle, synth):
     """One handle, alternating noise and sparse images: whatever path the statistics select, every result equals the oracle's."""
     ext = api.ORBextractor(500)

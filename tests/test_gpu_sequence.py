@@ -56,6 +56,14 @@ def test_sequence_chain_hip_equals_oracle(api, oracle, synth, pkg):
                 assert np.allclose(u, v, rtol=1e-6, atol=1e-6), (ta, counts[ta], i, np.abs(u - v).max())
     assert counts["pose_only"] == N_FRAMES - 1 and counts["ba"] == len(a.kfs) - 1 and counts["lcd"] == len(a.kfs) and counts["local_fusion"] == 1
     assert a.n_loop_matches >= 10                                   # loopclosing.cpp:245: the loop is only closed with >= 10 3D-2D matches
+    # DetectLoop's ranking (the 0.94 / 0.92 score thresholds need the trained model; the ORDER does not): when the camera comes back
+    # to its starting place — half-way, 1.6 m closer to the wall, and at the end — the database scan returns key-frame 0, with
+    # a score above every query that looks at a new place
+    lcd = [x for t, x in a.log if t == "lcd"]
+    best = [int(x[3][0]) for x in lcd]; score = [float(x[4][0]) for x in lcd]
+    half = (len(lcd) - 1) // 2
+    assert best[-1] == 0 and best[half] == 0 and best[half + 1] == 0
+    assert score[-1] > max(score[half + 6:len(lcd) - 6])
     for pa, pb in zip(a.poses, b.poses):
         assert np.allclose(pa, pb, rtol=1e-6, atol=1e-6)
     rmse, worst = _ate(a.poses, C, yaw, synth)
