@@ -1637,10 +1637,13 @@ __device__ __forceinline__ uint32_t wave_brief(const uint8_t* __restrict__ img, 
 }
 
 // LDS window of one keypoint (one wave): the 37x37 window of the blurred level that the steered 31x31 BRIEF pattern can reach
-// (|rotated coord| <= 18), fetched with aligned dword loads issued back to back.
-constexpr int DB_R = 18, DB_ROWS = 2 * DB_R + 1, DB_DW = 11, DB_P = DB_DW * 4;   // 3 + 37 -> 11 dwords
-constexpr int DB_N = DB_ROWS * DB_DW;                                           // 407 dwords
-constexpr int DB_IT = (DB_N + 63) / 64;                                         // 7 loads per lane
+// (|rotated coord| <= 18), fetched as four ALIGNED 16-byte pieces per row (15 + 37 <= 64 bytes), lane = (row, piece).  The kernel is
+// bound by the texture addresser (TA_BUSY 72-78 % of its run time), which works off about one L1 access per cycle and merges the lanes
+// of a load only when they fall into aligned groups: dword-per-lane loads over 44-byte rows went out as ~55 accesses per instruction
+// (PMC: 486 L1 accesses per key-point), aligned 16-byte pieces are 3 instead of 7 instructions and one access per lane (315).
+constexpr int DB_R = 18, DB_ROWS = 2 * DB_R + 1, DB_P = 64;                       // row pitch of the LDS window (bytes)
+constexpr int DB_N = DB_ROWS * 4;                                               // 148 pieces of 16 bytes
+constexpr int DB_IT = (DB_N + 63) / 64;                                         // 3 loads per lane
 
 // K5: orientation + steered BRIEF, phased per block of 64 keypoints so that nothing scalar runs 64-wide:
 //   0  thread per keypoint: slot -> (level, x, y, response)
@@ -1707,7 +1710,7 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
                                                    uint8_t* __restrict__ desc, int32_t* __restrict__ counts,
                                                    int32_t* __restrict__ status, int cap, int nchunk, int batch, int detectOnly,
                                                    const uint16_t* __restrict__ order) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_b[4][DB_N];
+    __shared__ __attribute__((aligned(16))) uint4 s_b[4][DB_N];
     __shared__ int s_x[KD_KPB], s_y[KD_KPB], s_lv[KD_KPB], s_m10[KD_KPB], s_m01[KD_KPB], s_out[KD_KPB];
     __shared__ float s_ca[KD_KPB], s_sb[KD_KPB];
     __shared__ __attribute__((aligned(16))) uint4 s_bw[16 * 4 * 2];      // IC-angle weights as MFMA B operands: [row pair][k block][x | y]
@@ -1775,10 +1778,6 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
     }
     if (detectOnly) return;                        // block-uniform
     __syncthreads();
-    // lane-constant window coordinates of the dwords this lane fetches in phase C
-    int rb_[DB_IT], cb_[DB_IT];
-#pragma unroll
-    for (int q = 0; q < DB_IT; q++) { const int i = lane + 64 * q; rb_[q] = i / DB_DW; cb_[q] = 4 * (i - rb_[q] * DB_DW); }
     // ---- A ----  intensity-centroid moments of 16 key-points per wave on the int8 matrix cores:
     //   [16 key-points x 64 k] x [64 k x {u weights, v weights}],  k = two patch rows of 32 pixels, 16 MFMAs (v_mfma_i32_16x16x64_i8)
     // A operand = the patch as it lies in memory (lane = key-point, 16 consecutive pixels per lane and k block, p - 128 as int8: the
@@ -1840,15 +1839,15 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
         const LevelGeom& g = P.lv[level];
         const int x = __builtin_amdgcn_readfirstlane(s_x[k]), y = __builtin_amdgcn_readfirstlane(s_y[k]);
         const float ca = s_ca[k], sb = s_sb[k];
-        const int xb0 = (x - DB_R) & ~3, offB = (x - DB_R) - xb0;
-        // window origin: wave-uniform 64-bit base + a 32-bit lane offset from full-rate 24-bit multiplies (32-bit and 64-bit integer
-        // multiplies run at quarter rate)
+        const int xb0 = (x - DB_R) & ~15, offB = (x - DB_R) - xb0;
+        // window origin: wave-uniform 64-bit base + a 32-bit lane offset (piece i = lane + 64 q: row i >> 2, 16-byte piece i & 3).
+        // The last piece of a row may reach past the image width into the row's padding or the next row: never read by a test point.
         const uint8_t* bl = blur + (size_t)b * pyrStride + g.imgOff + (size_t)(y - DB_R) * g.pitch + xb0;
-        uint32_t rb[DB_IT];
+        uint4 rb[DB_IT];
 #pragma unroll
         for (int q = 0; q < DB_IT; q++) {
             const int i = lane + 64 * q;
-            rb[q] = (i < DB_N) ? *reinterpret_cast<const uint32_t*>(bl + (uint32_t)(__mul24(rb_[q], g.pitch) + cb_[q])) : 0u;
+            rb[q] = (i < DB_N) ? *reinterpret_cast<const uint4*>(bl + (uint32_t)(__mul24(i >> 2, g.pitch) + 16 * (i & 3))) : make_uint4(0, 0, 0, 0);
         }
         __builtin_amdgcn_wave_barrier();                                  // previous keypoint's window reads are done (same wave)
 #pragma unroll
