@@ -792,7 +792,7 @@ int myslam_lcd::describe(uint8_t* d_imgs, int batch, int r, int c, int step, siz
             hipLaunchKernelGGL(k_lcd_input_fused, dim3((IN_H * IN_W + 255) / 256, batch), dim3(256), 0, stream, d_imgs, c, r, step, stride,
                                d_xofs, d_xa, d_yofs, d_yb, tp, d_in);
         } else {
-            BlurArgs a;                                   // GaussianBlur(img, img, Size(7,7), 0)  deeplcd.cpp:46
+            BlurArgs a{};                                 // GaussianBlur(img, img, Size(7,7), 0)  deeplcd.cpp:46  (src0 / n0 = 0: no in-place images)
             a.src = d_imgs; a.dst = d_blur; a.w = c; a.h = r; a.spitch = step; a.dpitch = blurPitch; a.sstride = stride; a.dstride = blurBytes;
             gauss_q8(1, a.q);
             launch_blur(a, batch, stream);

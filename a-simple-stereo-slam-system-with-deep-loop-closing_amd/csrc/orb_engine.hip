@@ -20,6 +20,8 @@ namespace myslam_hip {
 
 void launch_resize(const ResizeArgs& a, int batch, hipStream_t s);
 void launch_blur(const BlurArgs& a, int batch, hipStream_t s);
+bool blur_uses_strips(const BlurArgs& a);
+bool resize_uses_strips(const ResizeArgs& a);
 void launch_fast(const OrbPlan& P, const uint8_t* pyr, size_t pyrStride, const uint8_t* maskPyr, uint32_t* cand,
                  int32_t* candCount, const uint32_t* statPrev, uint32_t* statCur, int forceMode, int batch, hipStream_t s);
 void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCount, uint32_t* sortbuf, const uint32_t* octTab, uint32_t* selOut,
@@ -112,6 +114,7 @@ struct myslam_orb {
     // options (myslam_orb_set_option)
     int optFastMode = -1;              // -1 = chosen per level from the previous launch's statistics, 0 = two-phase, 1 = dense
     int optInternalStream = 1;         // 0 = everything on the caller's stream, 1 = Gaussian pyramid forked after FAST (default), 2 = after the image pyramid
+    int optCopyInput = 0;              // 1 = copy every input image into the pyramid block (default 0: level 0 is read in place, see run_batch)
     int optStopAfter = 0;              // debug: stop a batched call after stage 1 ingest / 2 pyramid / 3 oct-tree / 4 blur (0 = run all)
     int tapsSet = 0, taps[7] = {0};    // myslam_orb_set_gauss_taps: replacement of the sigma = 2 Q8 taps
 
@@ -125,6 +128,8 @@ struct myslam_orb {
     int ensure(int batch, int r, int c, bool needMask);
     int ensure_stage(size_t imgBytes, size_t maskBytes, int cap);
     int build_pyramids(const uint8_t* d_imgs, int batch, int step, size_t stride, const uint8_t* d_masks, int nlev);
+    ResizeArgs level_resize_args(uint8_t* base, int l) const;
+    BlurArgs level_blur_args(int l) const;
     int blur_levels(int batch, int nlev, hipStream_t s);
     int run_fast(const OrbPlan& P, const uint8_t* maskPyr, int batch);
     int run_batch(const uint8_t* d_imgs, int batch, int r, int c, int step, size_t stride, const uint8_t* d_masks,
@@ -289,27 +294,43 @@ int myslam_orb::build_pyramids(const uint8_t* d_imgs, int batch, int step, size_
     for (int pass = 0; pass < (d_masks ? 2 : 1); pass++) {
         uint8_t* base = pass ? d_mask : d_pyr;
         const uint8_t* src = pass ? d_masks : d_imgs;
-        launch_ingest(src, P.rows, P.cols, step, stride, base + P.lv[0].imgOff, P.lv[0].pitch, P.pyrBytes, batch, stream);
+        const int n0 = pass ? 0 : P.ext0N;                     // images read in place have no level-0 copy (masks are always copied)
+        if (batch > n0)
+            launch_ingest(src + (size_t)n0 * stride, P.rows, P.cols, step, stride, base + (size_t)n0 * P.pyrBytes + P.lv[0].imgOff, P.lv[0].pitch,
+                          P.pyrBytes, batch - n0, stream);
         for (int l = 1; l < nlev; l++) {                       // ComputePyramid, ORBextractor.cpp:1235-1246
             ScopedProf sp(P_RESIZE, stream);
-            ResizeArgs a;
-            a.src = base + P.lv[l - 1].imgOff; a.sw = P.lv[l - 1].w; a.sh = P.lv[l - 1].h; a.spitch = P.lv[l - 1].pitch; a.sstride = P.pyrBytes;
-            a.dst = base + P.lv[l].imgOff; a.dw = P.lv[l].w; a.dh = P.lv[l].h; a.dpitch = P.lv[l].pitch; a.dstride = P.pyrBytes;
-            a.scale_x = 1. / ((double)a.dw / a.sw); a.scale_y = 1. / ((double)a.dh / a.sh);
+            ResizeArgs a = level_resize_args(base, l);
+            if (l == 1 && n0 > 0) { a.src0 = d_imgs; a.spitch0 = step; a.sstride0 = stride; a.n0 = n0; }
             launch_resize(a, batch, stream);
         }
     }
     return MYSLAM_OK;
 }
-
+ResizeArgs myslam_orb::level_resize_args(uint8_t* base, int l) const {
+    const OrbPlan& P = full;
+    ResizeArgs a;
+    a.src = base + P.lv[l - 1].imgOff; a.sw = P.lv[l - 1].w; a.sh = P.lv[l - 1].h; a.spitch = P.lv[l - 1].pitch; a.sstride = P.pyrBytes;
+    a.src0 = nullptr; a.spitch0 = 0; a.n0 = 0; a.sstride0 = 0;
+    a.dst = base + P.lv[l].imgOff; a.dw = P.lv[l].w; a.dh = P.lv[l].h; a.dpitch = P.lv[l].pitch; a.dstride = P.pyrBytes;
+    a.scale_x = 1. / ((double)a.dw / a.sw); a.scale_y = 1. / ((double)a.dh / a.sh);
+    return a;
+}
+BlurArgs myslam_orb::level_blur_args(int l) const {
+    const OrbPlan& P = full;
+    BlurArgs a;
+    a.src = d_pyr + P.lv[l].imgOff; a.dst = d_blur + P.lv[l].imgOff;
+    a.w = P.lv[l].w; a.h = P.lv[l].h; a.spitch = a.dpitch = P.lv[l].pitch; a.sstride = a.dstride = P.pyrBytes;
+    a.src0 = nullptr; a.spitch0 = 0; a.n0 = 0; a.sstride0 = 0;
+    if (tapsSet) memcpy(a.q, taps, sizeof(taps)); else gauss_q8(0, a.q);
+    return a;
+}
 int myslam_orb::blur_levels(int batch, int nlev, hipStream_t stream) {
     const OrbPlan& P = full;
     for (int l = 0; l < nlev; l++) {                           // ORBextractor.cpp:965-966 / :1194-1199
         ScopedProf sp(P_BLUR, stream);
-        BlurArgs a;
-        a.src = d_pyr + P.lv[l].imgOff; a.dst = d_blur + P.lv[l].imgOff;
-        a.w = P.lv[l].w; a.h = P.lv[l].h; a.spitch = a.dpitch = P.lv[l].pitch; a.sstride = a.dstride = P.pyrBytes;
-        if (tapsSet) memcpy(a.q, taps, sizeof(taps)); else gauss_q8(0, a.q);
+        BlurArgs a = level_blur_args(l);
+        if (l == 0 && P.ext0N > 0) { a.src0 = P.ext0; a.spitch0 = P.ext0Pitch; a.sstride0 = P.ext0Stride; a.n0 = P.ext0N; }
         launch_blur(a, batch, stream);
     }
     return MYSLAM_OK;
@@ -327,6 +348,19 @@ int myslam_orb::run_batch(const uint8_t* d_imgs, int batch, int r, int c, int st
     MYSLAM_HIP_CHECK(hipMemsetAsync(d_selCount, 0, sizeof(int32_t) * (size_t)batch * MAXL, stream));
     MYSLAM_HIP_CHECK(hipMemsetAsync(stat, 0, sizeof(int32_t) * (size_t)batch, stream));
     const int stop = optStopAfter;
+    // Level 0 in place: every image but the last of the batch is read where the caller put it (no copy into the pyramid block: 0.94 MB
+    // of HBM traffic per 1241 x 376 image saved).  The gather kernels' unaligned loads may run a few bytes past a row, which stays
+    // inside the caller's batch for all images but the last — that one is copied.  Needs the register-strip forms of the level-1
+    // resize and the level-0 blur (the fallbacks want aligned rows) and a complete call (the debug stops read the copy).
+    {
+        int n0 = 0;
+        if (!optCopyInput && stop == 0 && batch > 1 && full.nlevels >= 1) {
+            bool ok = blur_uses_strips(level_blur_args(0));
+            if (full.nlevels > 1) ok = ok && resize_uses_strips(level_resize_args(d_pyr, 1));
+            if (ok) n0 = batch - 1;
+        }
+        full.ext0 = det.ext0 = d_imgs; full.ext0Stride = det.ext0Stride = stride; full.ext0Pitch = det.ext0Pitch = step; full.ext0N = det.ext0N = n0;
+    }
     if (stop == 1) {
         launch_ingest(d_imgs, full.rows, full.cols, step, stride, d_pyr + full.lv[0].imgOff, full.lv[0].pitch, full.pyrBytes, batch, stream);
         return MYSLAM_OK;
@@ -456,6 +490,7 @@ int myslam_orb_set_option(myslam_orb* h, int option, int value) {
     switch (option) {
         case MYSLAM_ORB_OPT_FAST_MODE: if (value < -1 || value > 1) return MYSLAM_ERR_INVALID; h->optFastMode = value; return MYSLAM_OK;
         case MYSLAM_ORB_OPT_INTERNAL_STREAM: if (value < 0 || value > 2) return MYSLAM_ERR_INVALID; h->optInternalStream = value; return MYSLAM_OK;
+        case MYSLAM_ORB_OPT_COPY_INPUT: if (value < 0 || value > 1) return MYSLAM_ERR_INVALID; h->optCopyInput = value; return MYSLAM_OK;
         case MYSLAM_ORB_OPT_STOP_AFTER: if (value < 0 || value > 4) return MYSLAM_ERR_INVALID; h->optStopAfter = value; return MYSLAM_OK;
     }
     return MYSLAM_ERR_INVALID;

@@ -106,7 +106,9 @@ __global__ __launch_bounds__(256) void k_resize_strip(ResizeArgs a, int nstrips,
     const int b = blockIdx.z;
     const int dx4 = strip * 256 + 4 * lane;
     const bool has = dx4 < a.dw;
-    const uint8_t* src = a.src + (size_t)b * a.sstride;
+    const bool ext = b < a.n0;                                   // block-uniform: level 0 read in place
+    const uint8_t* src = ext ? a.src0 + (size_t)b * a.sstride0 : a.src + (size_t)b * a.sstride;
+    const int spitch = ext ? a.spitch0 : a.spitch;
     uint8_t* dst = a.dst + (size_t)b * a.dstride;
     int sx[4]; uint32_t aw[4];
 #pragma unroll
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256) void k_resize_strip(ResizeArgs a, int nstrips,
         uint2 raw8[RS_MAXR];
 #pragma unroll
         for (int rr = 0; rr < RS_MAXR; rr++) {
-            const uint8_t* row = src + (size_t)(rfirst + min(rr, nrows - 1)) * a.spitch;
+            const uint8_t* row = src + (size_t)(rfirst + min(rr, nrows - 1)) * spitch;
             raw8[rr] = make_uint2(0u, 0u);
             // at the right border sx = sw-1 and the weight of sx+1 is 0 (OpenCV clamps fx there): the bytes past the row are never weighted
             if (has && rr < nrows) __builtin_memcpy(&raw8[rr], row + sx[0], 8);
@@ -308,7 +310,10 @@ __global__ __launch_bounds__(256) void k_blur7_strip(BlurArgs a, int nstrips, in
     const int strip = wid % nstrips, band = wid / nstrips;
     const int b = blockIdx.z;
     const int x0 = strip * 256 + 4 * lane, y0 = band * B3_R;
-    const uint8_t* src = a.src + (size_t)b * a.sstride;
+    const bool ext = b < a.n0;                                   // block-uniform: level 0 read in place (rows of any alignment; the dword
+    const uint8_t* src = ext ? a.src0 + (size_t)b * a.sstride0 : a.src + (size_t)b * a.sstride;      // that holds column w-1 may reach into
+    const int spitch = ext ? a.spitch0 : a.spitch;                                                   // the next row: never the last image)
+    const int sread = ext ? ((a.w + 3) & ~3) : a.spitch;         // bytes of a row that may be read
     uint8_t* dst = a.dst + (size_t)b * a.dstride;
     const int nout = min(B3_R, a.h - y0);
     const int npair = (nout + 6 + 1) >> 1;                       // input row pairs to walk
@@ -346,15 +351,15 @@ __global__ __launch_bounds__(256) void k_blur7_strip(BlurArgs a, int nstrips, in
     // other lanes get their neighbours over DPP and re-read their own dword).  Both loads are unconditional from clamped
     // addresses (rows are mirrored at most once: the launcher guarantees h >= 8; every row holds `spitch` readable bytes): no
     // branch sits between a load and its use, so the prefetch of the next row pair stays in flight behind a counted s_waitcnt.
-    const int xo = min(x0, a.spitch - 4);
-    const int xe = lane == 0 ? max(x0 - 4, 0) : lane == 63 ? min(x0 + 4, a.spitch - 4) : xo;
+    const int xo = min(x0, sread - 4);
+    const int xe = lane == 0 ? max(x0 - 4, 0) : lane == 63 ? min(x0 + 4, sread - 4) : xo;
     auto load_row = [&](int j, uint32_t& c, uint32_t& e) {
         int y = y0 - 3 + j;
         y = y < 0 ? -y : y;
         y = y >= a.h ? 2 * a.h - 2 - y : y;
-        const uint8_t* row = src + (size_t)y * a.spitch;
-        c = *reinterpret_cast<const uint32_t*>(row + xo);
-        e = *reinterpret_cast<const uint32_t*>(row + xe);
+        const uint8_t* row = src + (size_t)y * spitch;
+        __builtin_memcpy(&c, row + xo, 4);                       // (a caller's rows need not be dword-aligned)
+        __builtin_memcpy(&e, row + xe, 4);
     };
     // horizontal pass of one row: 4 sums (<= 65280).  The neighbours' dwords arrive over DPP; lanes 0 / 63 have no DPP source and
     // keep the `old` operand = the dword loaded from the adjacent strip.  Waves that touch an image border (edge_tag = true)
@@ -670,7 +675,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
     if (ncell == 0) return;
     auto wc_of = [&](int c) __attribute__((always_inline)) -> int { return s_wc[c]; };
     const int iniX0 = MIN_BORDER + cj0 * g.wCell;
-    const uint8_t* img = pyr + (size_t)b * pyrStride + g.imgOff;
+    const bool ext = level == 0 && b < P.ext0N;                      // level 0 read in place (block-uniform)
+    const uint8_t* img = ext ? P.ext0 + (size_t)b * P.ext0Stride : pyr + (size_t)b * pyrStride + g.imgOff;
+    const int ipitch = ext ? P.ext0Pitch : g.pitch;
     {   // all loads of a thread are issued before its LDS stores.  Unaligned 16-byte loads (a cell starts at any column); a load may run up
         // to 15 bytes past its row or, in the last row of the last plane, into the slack behind the pyramid block — those bytes are never used
         constexpr int NIT = (TROWS * G * NQC + T - 1) / T;
@@ -679,8 +686,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
         for (int u = 0; u < NIT; u++) {
             const int i = threadIdx.x + u * T, r = i / (G * NQC), rem = i - r * (G * NQC), c = rem / NQC, k = rem - c * NQC;
             const int x = iniX0 + c * g.wCell + 16 * k;
-            if (r < hr && c < ncell && x < g.pitch) {
-                const uint8_t* src = img + (size_t)(iniY + r) * g.pitch + x;
+            if (r < hr && c < ncell && x < ipitch) {
+                const uint8_t* src = img + (size_t)(iniY + r) * ipitch + x;
                 uint4 t;
                 __builtin_memcpy(&t, src, 16);
                 v[u] = t;
@@ -1714,7 +1721,7 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
     __shared__ int s_x[KD_KPB], s_y[KD_KPB], s_lv[KD_KPB], s_m10[KD_KPB], s_m01[KD_KPB], s_out[KD_KPB];
     __shared__ float s_ca[KD_KPB], s_sb[KD_KPB];
     __shared__ __attribute__((aligned(16))) uint4 s_bw[16 * 4 * 2];      // IC-angle weights as MFMA B operands: [row pair][k block][x | y]
-    __shared__ uint32_t s_pbase[KD_KPB], s_ppitch[KD_KPB];              // byte offset of patch(-15, -15) in the pyramid plane set, row pitch
+    __shared__ uint32_t s_pbase[KD_KPB], s_ppitch[KD_KPB];              // byte offset of patch(-15, -15) in the image's plane set (level 0 read in place: in the caller's image), row pitch
     // XCD-aware block order: the dispatcher places block i on XCD i % 8, each XCD has a private L2, and the ~32 blocks of one
     // image read overlapping windows of the same two pyramids.  Logical block ids (image-major) are handed out so that every
     // XCD walks a contiguous range of images (bijective remap, any grid size): without it every XCD pulls every image
@@ -1766,8 +1773,10 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
         s_x[t] = (int)((pay >> 8) & 0xfff) + MIN_BORDER; s_y[t] = (int)(pay >> 20) + MIN_BORDER;      // :897-898
         {   // keypoints keep >= 19 px from every border (ORBextractor.cpp:25): rows y-15 .. y+16 and columns x-15 .. x+16 exist
             const LevelGeom& gl = P.lv[active ? level : 0];
-            s_ppitch[t] = (uint32_t)gl.pitch;
-            s_pbase[t] = active ? (uint32_t)(gl.imgOff + (size_t)(s_y[t] - HALF_PATCH) * gl.pitch + (s_x[t] - HALF_PATCH)) : 0u;
+            const bool ext = active && level == 0 && b < P.ext0N;
+            const uint32_t pp = ext ? (uint32_t)P.ext0Pitch : (uint32_t)gl.pitch;
+            s_ppitch[t] = pp | (ext ? 0x80000000u : 0u);                  // bit 31: the patch lies in the caller's image
+            s_pbase[t] = active ? (uint32_t)((ext ? 0 : gl.imgOff) + (size_t)(s_y[t] - HALF_PATCH) * pp + (s_x[t] - HALF_PATCH)) : 0u;
         }
         resp = (float)(pay & 0xff);
         if (detectOnly && active) {                // ORBextractor::Detect (:1067-1073): raw cv::FAST keypoints of level 0, no angle / descriptor
@@ -1785,8 +1794,10 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
     {
         typedef int kd_v4i __attribute__((ext_vector_type(4)));
         const int kk = wave * 16 + (lane & 15), kq = lane >> 4;
-        const uint8_t* pl = pyr + (size_t)b * pyrStride + s_pbase[kk] + (size_t)(kq >> 1) * s_ppitch[kk] + 16 * (kq & 1);
-        const size_t step2 = 2 * (size_t)s_ppitch[kk];
+        const uint32_t ppk = s_ppitch[kk], ppitch = ppk & 0x7fffffffu;
+        const uint8_t* pl = ((ppk >> 31) ? P.ext0 + (size_t)b * P.ext0Stride : pyr + (size_t)b * pyrStride) + s_pbase[kk] + (size_t)(kq >> 1) * ppitch +
+                            16 * (kq & 1);
+        const size_t step2 = 2 * (size_t)ppitch;
         const int jb = lane & 15;
         kd_v4i acc = {0, 0, 0, 0};
 #pragma unroll
@@ -1988,9 +1999,11 @@ void launch_ingest(const uint8_t* src, int rows, int cols, int step, size_t sstr
 // ------------------------------------------------------------------------------------------------
 // launch helpers (called from orb_engine.hip)
 // ------------------------------------------------------------------------------------------------
+bool resize_uses_strips(const ResizeArgs& a) { return (double)RS_R * a.scale_y + 2.0 <= (double)RS_MAXR && a.scale_x <= 1.6; }
+
 void launch_resize(const ResizeArgs& a, int batch, hipStream_t s) {
     // register strips cover pyramid scale factors up to 1.25 (rows) / 1.6 (columns); larger steps take the generic kernel
-    if ((double)RS_R * a.scale_y + 2.0 <= (double)RS_MAXR && a.scale_x <= 1.6) {
+    if (resize_uses_strips(a)) {
         const int nstrips = (a.dw + 255) / 256, nbands = (a.dh + RS_R - 1) / RS_R;
         const int ngroups = (nbands + RS_NB - 1) / RS_NB;
         hipLaunchKernelGGL(k_resize_strip, dim3((nstrips * ngroups + 3) / 4, 1, batch), dim3(256), 0, s, a, nstrips, nbands);
@@ -2000,9 +2013,13 @@ void launch_resize(const ResizeArgs& a, int batch, hipStream_t s) {
     hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, s, a);
 }
 
+bool blur_uses_strips(const BlurArgs& a) {
+    return a.w >= 8 && a.h >= 8 && (a.spitch & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.src) | a.sstride) & 3) == 0;
+}
+
 void launch_blur(const BlurArgs& a, int batch, hipStream_t s) {
     // register strips need dword-aligned rows and at least 8 x 8 pixels; everything else goes through the LDS-tiled kernel
-    if (a.w >= 8 && a.h >= 8 && (a.spitch & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.src) | a.sstride) & 3) == 0) {
+    if (blur_uses_strips(a)) {
         const int nstrips = (a.w + 255) / 256, nbands = (a.h + B3_R - 1) / B3_R;
         hipLaunchKernelGGL(k_blur7_strip, dim3((nstrips * nbands + 3) / 4, 1, batch), dim3(256), 0, s, a, nstrips, nbands);
         return;

@@ -45,17 +45,23 @@ struct OrbPlan {
     int totalKeyCap;                  // sum keyCap
     int totalOut;                     // sum nodeCap
     size_t pyrBytes;                  // bytes of one image's pyramid block
+    // level 0 read in place: images b < ext0N take their level-0 plane from the caller's buffer (ext0 + b * ext0Stride, row pitch
+    // ext0Pitch) instead of a copy inside the pyramid block.  The kernels' unaligned 8 / 16-byte loads may run a few bytes past a row:
+    // harmless inside the caller's batch, which is why the LAST image of a batch is always copied (ext0N <= batch - 1).
+    const uint8_t* ext0; size_t ext0Stride; int ext0Pitch, ext0N;
     LevelGeom lv[MAXL];
 };
 
 struct ResizeArgs {
     const uint8_t* src; int sw, sh, spitch; size_t sstride;
+    const uint8_t* src0 = nullptr; int spitch0 = 0, n0 = 0; size_t sstride0 = 0;      // images b < n0 read their source plane here (level 0 in place)
     uint8_t* dst; int dw, dh, dpitch; size_t dstride;
     double scale_x, scale_y;                     // 1 / ((double)dsize / ssize), as cv::resize computes it
 };
 
 struct BlurArgs {
     const uint8_t* src; uint8_t* dst; int w, h, spitch, dpitch; size_t sstride, dstride;
+    const uint8_t* src0 = nullptr; int spitch0 = 0, n0 = 0; size_t sstride0 = 0;      // images b < n0 read their source plane here (level 0 in place; any alignment)
     int q[7];                                    // Q8 taps, sum 256
 };
 

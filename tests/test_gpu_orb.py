@@ -370,3 +370,52 @@ def test_get_tables(api, oracle):
         assert np.array_equal(npl, r[2]) and np.array_equal(um, r[3])
     assert api.ORBextractor(2000).tables()[2].tolist() == [434, 362, 302, 251, 209, 175, 145, 122]
     assert api.ORBextractor(2000).tables()[3].tolist() == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+
+
+@pytest.mark.parametrize("copy_input", [0, 1])
+@pytest.mark.parametrize("cols,step,gap", [(423, 423, 0), (423, 431, 17), (640, 640, 0), (257, 300, 5)])
+def test_level0_read_in_place(api, oracle, synth, copy_input, cols, step, gap):
+    """A *_batch call reads the full-resolution level of every image but the last in place (MYSLAM_ORB_OPT_COPY_INPUT 0, the default):
+    odd widths, row pitches that are not multiples of 4 and gaps between the images must give the bytes the copying path gives — the
+    oracle's — for every image of the batch, the in-place ones and the copied last one, with and without a mask, and for Detect."""
+    import torch
+    B, rows = 5, 240
+    imgs = [synth.random_image(4200 + i, rows, cols, "texture" if i % 2 else "noise") for i in range(B)]
+    stride = rows * step + gap
+    buf = np.full(B * stride + 64, 0xA5, np.uint8)                      # pitch padding and gaps hold garbage, not zeros
+    for i, im in enumerate(imgs):
+        v = buf[i * stride:i * stride + rows * step].reshape(rows, step)
+        v[:, :cols] = im
+    d = torch.from_numpy(buf).cuda()
+    mask = np.full((rows, cols), 255, np.uint8); mask[60:140, 100:220] = 0
+    mbuf = np.zeros(B * stride + 64, np.uint8)
+    for i in range(B):
+        mbuf[i * stride:i * stride + rows * step].reshape(rows, step)[:, :cols] = mask
+    dm = torch.from_numpy(mbuf).cuda()
+    ext = api.ORBextractor(600)
+    ext.set_option(ext.OPT_COPY_INPUT, copy_input)
+    cap = ext.max_keypoints(rows, cols)
+    kps = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda"); desc = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(B, dtype=torch.int32, device="cuda"); st = torch.zeros(B, dtype=torch.int32, device="cuda")
+    for use_mask in (False, True):
+        for _ in range(2):                                               # second call: the FAST path chosen from statistics
+            ext.detect_and_compute_batch(d.data_ptr(), B, rows, cols, step, stride, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), st.data_ptr(), cap,
+                                         d_masks=dm.data_ptr() if use_mask else 0)
+        torch.cuda.synchronize()
+        assert int(st.abs().sum()) == 0
+        k = kps.cpu().numpy().view(api.KP_DTYPE).reshape(B, cap); dd = desc.cpu().numpy().reshape(B, cap, 32)
+        for i in range(B):
+            rk, rd = oracle.detect_and_compute(oracle.params(600), imgs[i], mask if use_mask else None)
+            n = int(cnt[i])
+            assert n == len(rk) and k[i, :n].tobytes() == rk.tobytes() and np.array_equal(dd[i, :n], rd), (copy_input, use_mask, i)
+    det = api.ORBextractor(300)
+    det.set_option(det.OPT_COPY_INPUT, copy_input)
+    dcap = det.max_keypoints(rows, cols)
+    dk = torch.zeros(B * dcap * 28, dtype=torch.uint8, device="cuda")
+    det.detect_batch(d.data_ptr(), B, rows, cols, step, stride, dk.data_ptr(), cnt.data_ptr(), st.data_ptr(), dcap)
+    torch.cuda.synchronize()
+    k = dk.cpu().numpy().view(api.KP_DTYPE).reshape(B, dcap)
+    for i in range(B):
+        rk = oracle.detect(oracle.params(300), imgs[i])
+        n = int(cnt[i])
+        assert n == len(rk) and k[i, :n].tobytes() == rk.tobytes(), (copy_input, "detect", i)
