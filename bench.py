@@ -110,6 +110,8 @@ def parse():
     ap.add_argument("--orb-internal-stream", type=int, default=1, choices=[0, 1, 2],
                     help="myslam_orb_set_option(INTERNAL_STREAM): 1 = Gaussian pyramid on the extractor's internal stream beside the oct-tree kernel "
                          "(the library's default), 2 = beside FAST, 0 = one stream")
+    ap.add_argument("--orb-copy-input", type=int, default=0, choices=[0, 1],
+                    help="myslam_orb_set_option(COPY_INPUT): 0 = level 0 read in place (the library's default), 1 = every image copied into the pyramid block")
     ap.add_argument("--fast-mode", type=int, default=-1, choices=[-1, 0, 1],
                     help="myslam_orb_set_option(FAST_MODE): -1 = the FAST kernel picks its path per level (default), 0 = two-phase, 1 = dense")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -233,6 +235,7 @@ def main():
     for e in [ext] + orb_exts:
         e.set_option(e.OPT_INTERNAL_STREAM, args.orb_internal_stream)
         e.set_option(e.OPT_FAST_MODE, args.fast_mode)
+        e.set_option(e.OPT_COPY_INPUT, args.orb_copy_input)
     NB = 2 if args.pipeline else 1          # pipeline: extractor outputs are double-buffered (step k+1 extracts while step k is matched)
     d_kps_b = [torch.zeros(2 * P * cap * 28, dtype=torch.uint8, device=dev) for _ in range(NB)]
     d_desc_b = [torch.zeros(2 * P * cap * 32, dtype=torch.uint8, device=dev) for _ in range(NB)]
@@ -524,6 +527,8 @@ def main():
                        "hip_streams": {"caller": len({stream, stream2} | {s.cuda_stream for s in orb_streams}) + (1 if args.pipeline else 0),
                                        "extractor_internal": n_internal},
                        "orb_extractor_handles": S, "pipelined_steps": bool(args.pipeline),
+                       "input_level0": "read in place (resident input images; the last image of each extractor call is copied)" if not args.orb_copy_input
+                                       else "copied into the pyramid block",
                        "parallelism": f"frame-sharded x{world}" + (", id-range sharded DB + all-gather of 16-byte candidate records" if world > 1 else "")},
             "rccl_ranks": rccl_ranks if not via_cpu else None, "collective_backend": (args.backend if world > 1 else None),
             "collective_ranks": rccl_ranks,

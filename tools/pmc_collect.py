@@ -6,7 +6,8 @@ gpurun_out/r<round>_pmc_<tag>.json (copy it to profiles/ and commit it: bench.py
 
 Three separate rocprofv3 passes of the same bench command (kernel trace + counters only, as MI355X_MICROARCH.md prescribes:
 FETCH_SIZE and WRITE_SIZE do not fit into one pass): SQ instruction counts, FETCH_SIZE, WRITE_SIZE.  The bench runs joined on one
-stream (--streams 1) so that every ORB launch covers all 2P images and nothing overlaps.
+stream (--streams 1) so that every ORB launch covers all 2P images and nothing overlaps, and with MYSLAM_ORB_OPT_COPY_INPUT 1 so that the
+calibration kernel below sees every image (by default the extractor reads level 0 in place and copies only the last image of a batch).
 
 FETCH_SIZE calibration: on gfx950 the counter tallies 128-byte requests at 64 bytes.  k_ingest reads every byte of the 1241x376
 input exactly once (466 616 B per image, known from the algorithm), so fetch_scale = known bytes / counted bytes of k_ingest is
@@ -41,7 +42,7 @@ def run_pass(counters, pairs, workload, outdir, scene_rects, extra=()):
         shutil.rmtree(outdir)
     cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", outdir, "-o", "a", "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "2", "--pairs", str(pairs), "--workload", workload,
-           "--streams", "1", "--orb-internal-stream", "0", "--no-cpu-baseline", "--no-extra-passes", "--scene-rects", str(scene_rects)] + list(extra)
+           "--streams", "1", "--orb-internal-stream", "0", "--orb-copy-input", "1", "--no-cpu-baseline", "--no-extra-passes", "--scene-rects", str(scene_rects)] + list(extra)
     env = dict(os.environ, TMPDIR="/tmp")
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
     files = glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True)
@@ -131,7 +132,8 @@ def main():
     out = {
         "build": args.tag, "round": args.round,
         "command": f"rocprofv3 --kernel-trace --pmc <set> -- python bench.py --steps 2 --warmup 2 --pairs {P} --workload {args.workload} --streams 1 "
-                   f"--orb-internal-stream 0 --no-cpu-baseline --no-extra-passes --scene-rects {args.scene_rects}   (one pass per counter set; counters of the LAST step)",
+                   f"--orb-internal-stream 0 --orb-copy-input 1 --no-cpu-baseline --no-extra-passes --scene-rects {args.scene_rects}   (one pass per counter set; counters of the LAST "
+                   f"step; COPY_INPUT 1 so that the calibration kernel k_ingest sees every image — by default it copies only the last image of a batch)",
         "counter_sets": PASSES, "pairs_per_step": P, "steps_total": steps_total,
         "calibration": {"kernel": "k_ingest", "known_read_bytes_per_image": known_r, "counted_read_bytes_per_image": ing["fetch_bytes_per_image_raw"],
                         "fetch_scale": fetch_scale, "known_write_bytes_per_image": known_w, "counted_write_over_known": write_check,
