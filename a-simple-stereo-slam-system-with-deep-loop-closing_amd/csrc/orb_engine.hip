@@ -600,6 +600,7 @@ static int host_pyramid(myslam_orb* h, const uint8_t* img, int rows, int cols, i
     if (rc) return rc;
     if ((rc = h->ensure_stage((size_t)rows * step, 0, ncap))) return rc;
     MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_stageImg, img, (size_t)rows * step, hipMemcpyHostToDevice, h->stream));
+    h->full.ext0N = h->det.ext0N = 0;                          // single staged image: nothing is read in place
     return h->build_pyramids(h->d_stageImg, 1, step, (size_t)rows * step, nullptr, h->nlevels);
 }
 
@@ -677,6 +678,7 @@ int myslam_orb_debug_candidates(myslam_orb* h, const uint8_t* img, int rows, int
     MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_stageImg, img, (size_t)rows * step, hipMemcpyHostToDevice, h->stream));
     if (mask) MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_stageMask, mask, (size_t)rows * step, hipMemcpyHostToDevice, h->stream));
     MYSLAM_HIP_CHECK(hipMemsetAsync(h->d_candCount, 0, sizeof(int32_t) * MAXL, h->stream));
+    h->full.ext0N = h->det.ext0N = 0;                          // single staged image: nothing is read in place
     if ((rc = h->build_pyramids(h->d_stageImg, 1, step, (size_t)rows * step, mask ? h->d_stageMask : nullptr, h->nlevels))) return rc;
     if ((rc = h->run_fast(h->full, mask ? h->d_mask : nullptr, 1))) return rc;
     int32_t counts[MAXL];

@@ -408,6 +408,17 @@ def test_level0_read_in_place(api, oracle, synth, copy_input, cols, step, gap):
             rk, rd = oracle.detect_and_compute(oracle.params(600), imgs[i], mask if use_mask else None)
             n = int(cnt[i])
             assert n == len(rk) and k[i, :n].tobytes() == rk.tobytes() and np.array_equal(dd[i, :n], rd), (copy_input, use_mask, i)
+    # single-image entry points on the handle that has just read a batch in place: they stage and copy their own image
+    other = synth.random_image(977, rows, cols, "texture")
+    pyr = oracle.pyramid(oracle.params(600), other)
+    for lvl in (0, 1, 3):
+        assert np.array_equal(ext.debug_pyramid(other, lvl), pyr[lvl]), (copy_input, "debug_pyramid", lvl)
+    xs, ys, sc = ext.debug_candidates(other, 0)
+    rx, ry, rs = oracle.grid_fast(pyr[0])
+    assert sorted(zip(ys.tolist(), xs.tolist(), sc.tolist())) == sorted(zip(ry.tolist(), rx.tolist(), rs.tolist()))
+    gk, gd = ext.DetectAndCompute(other)
+    rk, rd = oracle.detect_and_compute(oracle.params(600), other)
+    assert gk.tobytes() == rk.tobytes() and np.array_equal(gd, rd)
     det = api.ORBextractor(300)
     det.set_option(det.OPT_COPY_INPUT, copy_input)
     dcap = det.max_keypoints(rows, cols)
