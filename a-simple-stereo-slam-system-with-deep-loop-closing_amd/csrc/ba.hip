@@ -3,10 +3,9 @@
 //   EdgeProjection::computeError / linearizeOplus      include/myslam/g2o_types.h:115-144
 //   RobustKernelHuber (delta = 5.991, backend.cpp:198-200) and the weighted block quadratic form
 //   (SURVEY.md Appendix A.7):  Hpp += w Jx^T Jx, Hll += w Jp^T Jp, Hpl = w Jx^T Jp, bp -= w Jx^T e, bl -= w Jp^T e.
-// f64 throughout (g2o is f64).  One 256-thread block per window; the window's pose blocks (6x6 upper
-// triangle + 6) and landmark blocks (3x3 upper + 3) are accumulated in LDS with ds_add_f64, the per-edge
-// 6x3 Hpl blocks stream straight to HBM.  Summation order is not fixed -> results agree with the oracle to
-// ~1e-12 relative, not bit-exactly (stated in the tests).
+// f64 throughout (g2o is f64).  One 256-thread block per window; pose and landmark blocks are summed in a fixed order (two runs
+// give the same bits, see k_ba_build), the per-edge 6x3 Hpl blocks stream straight to HBM.  The order differs
+// from the oracle's plain edge loop -> agreement to ~1e-12 relative, not bit-exactly (stated in the tests).
 #include "common.h"
 
 namespace myslam_hip {
@@ -19,112 +18,6 @@ struct BaArgs {
     double fx, fy, cx, cy, delta;
     double *Hpp, *Hll, *Hpl, *bp, *bl, *chi2;
 };
-
-__global__ __launch_bounds__(256) void k_ba_build(BaArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double s_d[];
-    const int w = blockIdx.x, t = threadIdx.x;
-    int P = a.sizes ? a.sizes[3 * w] : a.nposes;
-    int L = a.sizes ? a.sizes[3 * w + 1] : a.npts;
-    int E = a.sizes ? a.sizes[3 * w + 2] : a.nedges;
-    // a window whose sizes do not fit the common capacities would overrun LDS: it is skipped (outputs zero, chi2[0] = -1)
-    const bool oversize = P < 0 || L < 0 || E < 0 || P > a.maxP || L > a.maxL || E > a.maxE;
-    if (oversize) { P = 0; L = 0; E = 0; if (t == 0) a.chi2[(size_t)w * a.maxE] = -1.0; }
-    double* sR = s_d;                        // maxP x 12 (R row-major, t)
-    double* sHpp = sR + a.maxP * 12;         // maxP x 21 (upper triangle, row-major)
-    double* sbp = sHpp + a.maxP * 21;        // maxP x 6
-    double* sHll = sbp + a.maxP * 6;         // maxL x 6
-    double* sbl = sHll + a.maxL * 6;         // maxL x 3
-    const double* poses = a.poses + (size_t)w * a.maxP * 7;
-    const double* pts = a.points + (size_t)w * a.maxL * 3;
-    const int32_t* ep = a.ep + (size_t)w * a.maxE;
-    const int32_t* el = a.el + (size_t)w * a.maxE;
-    const double* obs = a.obs + (size_t)w * a.maxE * 2;
-    const uint8_t* fixed = a.fixed ? a.fixed + (size_t)w * a.maxL : nullptr;
-
-    for (int i = t; i < a.maxP * 27 + a.maxL * 9; i += 256) sHpp[i] = 0.0;
-    for (int p = t; p < P; p += 256) {
-        double x = poses[7 * p], y = poses[7 * p + 1], z = poses[7 * p + 2], q = poses[7 * p + 3];
-        const double n = sqrt(x * x + y * y + z * z + q * q);
-        x /= n; y /= n; z /= n; q /= n;
-        double* R = sR + 12 * p;
-        R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * q);     R[2] = 2 * (x * z + y * q);
-        R[3] = 2 * (x * y + z * q);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * q);
-        R[6] = 2 * (x * z - y * q);     R[7] = 2 * (y * z + x * q);     R[8] = 1 - 2 * (x * x + y * y);
-        R[9] = poses[7 * p + 4]; R[10] = poses[7 * p + 5]; R[11] = poses[7 * p + 6];
-    }
-    __syncthreads();
-
-    for (int k = t; k < E; k += 256) {
-        const int ip = ep[k], il = el[k];
-        double* hpl = a.Hpl + ((size_t)w * a.maxE + k) * 18;
-        if (ip < 0 || ip >= P || il < 0 || il >= L) {             // malformed edge: contributes nothing
-            a.chi2[(size_t)w * a.maxE + k] = 0.0;
-#pragma unroll
-            for (int i = 0; i < 18; i++) hpl[i] = 0.0;
-            continue;
-        }
-        const double* R = sR + 12 * ip;
-        const double pw0 = pts[3 * il], pw1 = pts[3 * il + 1], pw2 = pts[3 * il + 2];
-        const double X = R[0] * pw0 + R[1] * pw1 + R[2] * pw2 + R[9];
-        const double Y = R[3] * pw0 + R[4] * pw1 + R[5] * pw2 + R[10];
-        const double Z = R[6] * pw0 + R[7] * pw1 + R[8] * pw2 + R[11];
-        const double e0 = obs[2 * k] - (a.fx * X / Z + a.cx);      // g2o_types.h:119-121
-        const double e1 = obs[2 * k + 1] - (a.fy * Y / Z + a.cy);
-        const double Zinv = 1.0 / (Z + 1e-18), Zinv2 = Zinv * Zinv;   // :133-134
-        double J[12];
-        J[0] = -a.fx * Zinv; J[1] = 0; J[2] = a.fx * X * Zinv2; J[3] = a.fx * X * Y * Zinv2;
-        J[4] = -a.fx - a.fx * X * X * Zinv2; J[5] = a.fx * Y * Zinv;
-        J[6] = 0; J[7] = -a.fy * Zinv; J[8] = a.fy * Y * Zinv2; J[9] = a.fy + a.fy * Y * Y * Zinv2;
-        J[10] = -a.fy * X * Y * Zinv2; J[11] = -a.fy * X * Zinv;
-        double Jp[6];
-#pragma unroll
-        for (int r = 0; r < 2; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) Jp[r * 3 + c] = J[r * 6] * R[c] + J[r * 6 + 1] * R[3 + c] + J[r * 6 + 2] * R[6 + c];   // :140-141
-        const double e2 = e0 * e0 + e1 * e1;
-        a.chi2[(size_t)w * a.maxE + k] = e2;
-        const double wgt = (e2 <= a.delta * a.delta) ? 1.0 : a.delta / sqrt(e2);   // Huber rho'
-        double* hp = sHpp + 21 * ip;
-        int u = 0;
-#pragma unroll
-        for (int r = 0; r < 6; r++) {
-#pragma unroll
-            for (int c = r; c < 6; c++) atomicAdd(&hp[u++], wgt * (J[r] * J[c] + J[6 + r] * J[6 + c]));
-            atomicAdd(&sbp[6 * ip + r], -wgt * (J[r] * e0 + J[6 + r] * e1));
-        }
-        const bool fx_pt = fixed && fixed[il];
-        if (!fx_pt) {
-            double* hl = sHll + 6 * il;
-            int v = 0;
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-#pragma unroll
-                for (int c = r; c < 3; c++) atomicAdd(&hl[v++], wgt * (Jp[r] * Jp[c] + Jp[3 + r] * Jp[3 + c]));
-                atomicAdd(&sbl[3 * il + r], -wgt * (Jp[r] * e0 + Jp[3 + r] * e1));
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 6; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) hpl[r * 3 + c] = fx_pt ? 0.0 : wgt * (J[r] * Jp[c] + J[6 + r] * Jp[3 + c]);
-    }
-    __syncthreads();
-
-    for (int i = t; i < P * 36; i += 256) {
-        const int p = i / 36, r = (i % 36) / 6, c = i % 6;
-        const int rr = min(r, c), cc = max(r, c);
-        const int u = rr * 6 - rr * (rr - 1) / 2 + (cc - rr);       // index in the row-major upper triangle
-        a.Hpp[((size_t)w * a.maxP + p) * 36 + r * 6 + c] = sHpp[21 * p + u];
-    }
-    for (int i = t; i < P * 6; i += 256) a.bp[(size_t)w * a.maxP * 6 + i] = sbp[i];
-    for (int i = t; i < L * 9; i += 256) {
-        const int l = i / 9, r = (i % 9) / 3, c = i % 3;
-        const int rr = min(r, c), cc = max(r, c);
-        const int u = rr * 3 - rr * (rr - 1) / 2 + (cc - rr);
-        a.Hll[((size_t)w * a.maxL + l) * 9 + r * 3 + c] = sHll[6 * l + u];
-    }
-    for (int i = t; i < L * 3; i += 256) a.bl[(size_t)w * a.maxL * 3 + i] = sbl[i];
-}
 
 // ------------------------------------------------------------------------------------------------
 // Levenberg-Marquardt on device: what g2o's OptimizationAlgorithmLevenberg + BlockSolver_6_3 do for
@@ -184,6 +77,171 @@ __device__ __forceinline__ double wave_sum_lane63(double v) {
 }
 __device__ __forceinline__ double bcast_lane(double v, int srcLane) {       // srcLane must be wave-uniform
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), srcLane), __builtin_amdgcn_readlane(__double2loint(v), srcLane));
+}
+
+// Block build of one window with ONE evaluation per edge and a fixed summation order (two runs give the same bits):
+//   landmark blocks  the edges of a landmark normally form one contiguous run (the order Backend::OptimizeActiveMap emits them,
+//                    backend.cpp:166-206): a lane pair walks the run (one half each), sums Hll / bl in registers and writes the
+//                    edges' chi2 and Hpl;
+//   pose blocks      the same lanes add each edge's 27 pose terms into ITS WAVE's private copy of the pose blocks in LDS
+//                    (ds_add_f64: lanes of one instruction that hit the same address are served in lane order, instructions in
+//                    program order — nothing depends on how the four waves interleave); the four copies are added in wave order.
+//   A landmark whose edges are scattered over several runs takes the slow road: its edges are evaluated one per thread (pose terms
+//   as above) and its block is summed by one thread scanning the edge list in order.
+__global__ __launch_bounds__(256) void k_ba_build(BaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double s_d[];
+    const int w = blockIdx.x, t = threadIdx.x, wv = t >> 6;
+    int P = a.sizes ? a.sizes[3 * w] : a.nposes;
+    int L = a.sizes ? a.sizes[3 * w + 1] : a.npts;
+    int E = a.sizes ? a.sizes[3 * w + 2] : a.nedges;
+    // a window whose sizes do not fit the common capacities would overrun LDS: it is skipped (outputs zero, chi2[0] = -1)
+    const bool oversize = P < 0 || L < 0 || E < 0 || P > a.maxP || L > a.maxL || E > a.maxE;
+    if (oversize) { P = 0; L = 0; E = 0; if (t == 0) a.chi2[(size_t)w * a.maxE] = -1.0; }
+    double* sR = s_d;                                           // maxP x 12 (R row-major, t)
+    double* sAcc = sR + a.maxP * 12;                            // 4 waves x maxP x 27 (6x6 upper triangle row-major, then b)
+    int* s_runs = reinterpret_cast<int*>(sAcc + 4 * a.maxP * 27);      // maxL: contiguous runs of each landmark in the edge list
+    int* s_start = s_runs + a.maxL;                             // maxL: first edge of the landmark's run (meaningful when it has exactly one)
+    int* s_len = s_start + a.maxL;                              // maxL: length of that run
+    const double* poses = a.poses + (size_t)w * a.maxP * 7;
+    const double* pts = a.points + (size_t)w * a.maxL * 3;
+    const int32_t* ep = a.ep + (size_t)w * a.maxE;
+    const int32_t* el = a.el + (size_t)w * a.maxE;
+    const double* obs = a.obs + (size_t)w * a.maxE * 2;
+    const uint8_t* fixed = a.fixed ? a.fixed + (size_t)w * a.maxL : nullptr;
+    const double d2 = a.delta * a.delta;
+    double* myAcc = sAcc + (size_t)wv * a.maxP * 27;
+
+    for (int i = t; i < 4 * a.maxP * 27; i += 256) sAcc[i] = 0.0;
+    for (int l = t; l < L; l += 256) s_runs[l] = 0;
+    for (int p = t; p < P; p += 256) {
+        double x = poses[7 * p], y = poses[7 * p + 1], z = poses[7 * p + 2], q = poses[7 * p + 3];
+        const double n = sqrt(x * x + y * y + z * z + q * q);
+        x /= n; y /= n; z /= n; q /= n;
+        double* R = sR + 12 * p;
+        R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * q);     R[2] = 2 * (x * z + y * q);
+        R[3] = 2 * (x * y + z * q);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * q);
+        R[6] = 2 * (x * z - y * q);     R[7] = 2 * (y * z + x * q);     R[8] = 1 - 2 * (x * x + y * y);
+        R[9] = poses[7 * p + 4]; R[10] = poses[7 * p + 5]; R[11] = poses[7 * p + 6];
+    }
+    __syncthreads();
+    // runs of every landmark: a run starts where the landmark index changes (integer counts: the order of the adds does not matter)
+    for (int k = t; k < E; k += 256) {
+        const int il = el[k];
+        if (il >= 0 && il < L && (k == 0 || el[k - 1] != il)) {
+            atomicAdd(&s_runs[il], 1);
+            int n = 1;
+            while (k + n < E && el[k + n] == il) n++;
+            s_start[il] = k; s_len[il] = n;                     // (several runs: any of them; such a landmark does not use these)
+        }
+    }
+    __syncthreads();
+    // one edge: chi2, Hpl, the pose terms into this wave's copy; hl (may be null) collects the landmark terms
+    auto edge = [&](int k, int il, double* hl) {
+        double* hpl = a.Hpl + ((size_t)w * a.maxE + k) * 18;
+        const int ip = ep[k];
+        if (ip < 0 || ip >= P) {                                // malformed edge: contributes nothing
+            a.chi2[(size_t)w * a.maxE + k] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 18; i++) hpl[i] = 0.0;
+            return;
+        }
+        double e0, e1, J[12], Jp[6];
+        ba_edge(sR + 12 * ip, pts + 3 * il, obs + 2 * k, a.fx, a.fy, a.cx, a.cy, e0, e1, J, Jp);
+        const double e2 = e0 * e0 + e1 * e1;
+        a.chi2[(size_t)w * a.maxE + k] = e2;
+        const double wgt = (e2 <= d2) ? 1.0 : a.delta / sqrt(e2);   // Huber rho'
+        double* hp = myAcc + 27 * ip;
+        int u = 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+#pragma unroll
+            for (int c = r; c < 6; c++) atomicAdd(&hp[u++], wgt * (J[r] * J[c] + J[6 + r] * J[6 + c]));
+        }
+#pragma unroll
+        for (int r = 0; r < 6; r++) atomicAdd(&hp[21 + r], -wgt * (J[r] * e0 + J[6 + r] * e1));
+        const bool fx_pt = fixed && fixed[il];
+        if (hl && !fx_pt) {
+            int v = 0;
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+#pragma unroll
+                for (int c = r; c < 3; c++) hl[v++] += wgt * (Jp[r] * Jp[c] + Jp[3 + r] * Jp[3 + c]);
+            }
+#pragma unroll
+            for (int r = 0; r < 3; r++) hl[6 + r] += -wgt * (Jp[r] * e0 + Jp[3 + r] * e1);
+        }
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) hpl[r * 3 + c] = fx_pt ? 0.0 : wgt * (J[r] * Jp[c] + J[6 + r] * Jp[3 + c]);
+    };
+    auto lm_store = [&](int il, const double* hl) {
+        double* Hl = a.Hll + ((size_t)w * a.maxL + il) * 9;
+        Hl[0] = hl[0]; Hl[1] = hl[1]; Hl[2] = hl[2]; Hl[3] = hl[1]; Hl[4] = hl[3]; Hl[5] = hl[4]; Hl[6] = hl[2]; Hl[7] = hl[4]; Hl[8] = hl[5];
+        double* bl = a.bl + ((size_t)w * a.maxL + il) * 3;
+        bl[0] = hl[6]; bl[1] = hl[7]; bl[2] = hl[8];
+    };
+    for (int k = t; k < E; k += 256) {                          // edges outside single-run landmarks: one per thread
+        const int il = el[k];
+        if (il < 0 || il >= L) {                                // malformed edge: contributes nothing
+            a.chi2[(size_t)w * a.maxE + k] = 0.0;
+            double* hpl = a.Hpl + ((size_t)w * a.maxE + k) * 18;
+#pragma unroll
+            for (int i = 0; i < 18; i++) hpl[i] = 0.0;
+        } else if (s_runs[il] != 1) edge(k, il, nullptr);       // scattered landmark: its block is summed below
+    }
+    // single-run landmarks: a lane PAIR per landmark, each lane walks one half of the run (every lane of the wave has work; a thread
+    // per run start would leave nine lanes in ten idle); the two halves are added first + second
+    for (int i0 = 0; i0 < 2 * L; i0 += 256) {                   // uniform trip count: the pair exchange needs both lanes
+        const int idx = i0 + t, il = idx >> 1, half = idx & 1;
+        double hl[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const bool own = il < L && s_runs[il] == 1;
+        if (own) {
+            const int k0 = s_start[il], n = s_len[il], n0 = (n + 1) >> 1;
+            const int kb = half ? k0 + n0 : k0, ke = half ? k0 + n : k0 + n0;
+            for (int kk = kb; kk < ke; kk++) edge(kk, il, hl);
+        }
+#pragma unroll
+        for (int u = 0; u < 9; u++) hl[u] += __shfl_down(hl[u], 1, 64);       // even lane: first half + second half
+        if (own && half == 0) lm_store(il, hl);
+    }
+    for (int il = t; il < L; il += 256) {                       // landmarks without edges (zeros) or with scattered edges (full scan, edge order)
+        const int nr = s_runs[il];
+        if (nr == 1) continue;
+        double hl[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (nr > 1 && !(fixed && fixed[il]))
+            for (int kk = 0; kk < E; kk++) {
+                const int ip = ep[kk];
+                if (el[kk] != il || ip < 0 || ip >= P) continue;
+                double e0, e1, J[12], Jp[6];
+                ba_edge(sR + 12 * ip, pts + 3 * il, obs + 2 * kk, a.fx, a.fy, a.cx, a.cy, e0, e1, J, Jp);
+                const double e2 = e0 * e0 + e1 * e1;
+                const double wgt = (e2 <= d2) ? 1.0 : a.delta / sqrt(e2);
+                int v = 0;
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+#pragma unroll
+                    for (int c = r; c < 3; c++) hl[v++] += wgt * (Jp[r] * Jp[c] + Jp[3 + r] * Jp[3 + c]);
+                }
+#pragma unroll
+                for (int r = 0; r < 3; r++) hl[6 + r] += -wgt * (Jp[r] * e0 + Jp[3 + r] * e1);
+            }
+        lm_store(il, hl);
+    }
+    __syncthreads();
+    // pose blocks: the four wave copies in wave order
+    for (int i = t; i < P * 36; i += 256) {
+        const int p = i / 36, r = (i % 36) / 6, c = i % 6;
+        const int rr = min(r, c), cc = max(r, c);
+        const int u = rr * 6 - rr * (rr - 1) / 2 + (cc - rr);       // index in the row-major upper triangle
+        const size_t o = (size_t)27 * p + u, ws = (size_t)a.maxP * 27;
+        a.Hpp[((size_t)w * a.maxP + p) * 36 + r * 6 + c] = ((sAcc[o] + sAcc[ws + o]) + sAcc[2 * ws + o]) + sAcc[3 * ws + o];
+    }
+    for (int i = t; i < P * 6; i += 256) {
+        const int p = i / 6, r = i % 6;
+        const size_t o = (size_t)27 * p + 21 + r, ws = (size_t)a.maxP * 27;
+        a.bp[(size_t)w * a.maxP * 6 + i] = ((sAcc[o] + sAcc[ws + o]) + sAcc[2 * ws + o]) + sAcc[3 * ws + o];
+    }
 }
 
 constexpr int BA_NT = 512;             // threads per window
@@ -1017,7 +1075,7 @@ __global__ __launch_bounds__(BA_NT) void k_pose_only(PoseOnlyArgs a) {
     }
 }
 
-static size_t ba_lds(int maxP, int maxL) { return sizeof(double) * ((size_t)maxP * 39 + (size_t)maxL * 9); }
+static size_t ba_lds(int maxP, int maxL) { return sizeof(double) * ((size_t)maxP * (12 + 4 * 27)) + sizeof(int) * 3 * (size_t)maxL; }
 
 static int ba_launch(const BaArgs& a, int nwin, hipStream_t s) {
     const size_t lds = ba_lds(a.maxP, a.maxL);
