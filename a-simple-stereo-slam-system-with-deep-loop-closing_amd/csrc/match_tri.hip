@@ -148,8 +148,12 @@ __device__ __forceinline__ void tri_solve(const double (&P)[2][12], const double
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) V[i][j] = (i == j) ? 1.0 : 0.0;
+    // Per column pair: one sqrt, one division and one reciprocal square root (f64 sqrt / division cost ~25 instructions each on this
+    // hardware; the textbook form zeta -> t -> c needs two of each, plus two more for a normalised convergence measure).  The rotation
+    // angle is the same: tan(theta) = 2 gamma / (d + sign(d) hypot(d, 2 gamma)) with d = beta - alpha; convergence is tested on squares.
     for (int sweep = 0; sweep < 60; sweep++) {
-        double off = 0;
+        double off2 = 0;                                     // largest gamma^2 / (alpha beta) of the sweep, kept as a pair of products
+        bool rotated = false;
 #pragma unroll
         for (int p = 0; p < 3; p++)
 #pragma unroll
@@ -157,12 +161,15 @@ __device__ __forceinline__ void tri_solve(const double (&P)[2][12], const double
                 double alpha = 0, beta = 0, gamma = 0;
 #pragma unroll
                 for (int i = 0; i < 4; i++) { alpha += A[i][p] * A[i][p]; beta += A[i][q] * A[i][q]; gamma += A[i][p] * A[i][q]; }
-                const double lim = 1e-30 + 1e-17 * sqrt(alpha * beta);
-                if (gamma != 0.0 && fabs(gamma) > lim) {
-                    off = fmax(off, fabs(gamma) / sqrt(alpha * beta + 1e-300));
-                    const double zeta = (beta - alpha) / (2.0 * gamma);
-                    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                const double ab = alpha * beta, g2 = gamma * gamma;
+                // |gamma| > 1e-30 + 1e-17 sqrt(alpha beta)  (the pair is numerically orthogonal otherwise), on squares
+                if (g2 > 1e-60 && g2 > 1e-34 * ab) {
+                    rotated = true;
+                    if (g2 > off2 * ab) off2 = g2 / (ab + 1e-300);
+                    const double d = beta - alpha, tg = 2.0 * gamma;
+                    const double hyp = sqrt(d * d + tg * tg);
+                    const double t = tg / (d + (d >= 0 ? hyp : -hyp));
+                    const double c = rsqrt(1.0 + t * t), s = c * t;
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const double ap = A[i][p], aq = A[i][q];
@@ -172,7 +179,7 @@ __device__ __forceinline__ void tri_solve(const double (&P)[2][12], const double
                     }
                 }
             }
-        if (off < 1e-15) break;
+        if (!rotated || off2 < 1e-30) break;                 // off = sqrt(off2) < 1e-15
     }
     double sv[4];
 #pragma unroll
