@@ -1183,6 +1183,8 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
     uint8_t* pcur = smem + 192;
     uint32_t* s_cursor = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * OT_MAXB;
     OctLds L;
+    L.offs = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * (OT_MAXB + 2);
+    uint32_t* const s_tab = reinterpret_cast<uint32_t*>(pcur);      // phases A / B: the level's lookup tables, in the space of the node arrays (54 NC bytes)
     L.lo0 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
     L.lo1 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
     L.hi0 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
@@ -1190,7 +1192,6 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
     L.nb1 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
     L.nb2 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
     L.nb3 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
-    L.offs = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * (OT_MAXB + 2);
     L.ckey0 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
     L.ckey1 = reinterpret_cast<uint32_t*>(pcur); pcur += 4 * NC;
     L.pfx0 = reinterpret_cast<uint16_t*>(pcur); pcur += 2 * NC;
@@ -1223,8 +1224,14 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
 
     const uint32_t* xcode = octTab + g.tabOff; const uint32_t* ycode = xcode + g.tabX;
     const uint32_t* xcell = ycode + g.tabY; const uint32_t* ycell = xcell + g.tabX;
+    // The passes over the candidates are bound by the texture addresser: per candidate four table gathers (one L1 access per lane
+    // each) and two scattered stores.  The level's four tables (2 (w + h) dwords, 13 KB at 1241 x 376) are therefore staged in LDS —
+    // in the space of the node arrays, which phase C initialises — whenever they fit; the gathers become LDS reads.
+    const int ntab = 2 * (g.tabX + g.tabY);
+    const bool tabLds = (size_t)ntab * 4 <= (size_t)54 * NC;            // block-uniform
     // ---- A: path codes + bucket histogram (LDS atomics) ----
     for (int i = t; i < NB; i += OT) s_cursor[i] = 0;
+    if (tabLds) for (int i = t; i < ntab; i += OT) s_tab[i] = xcode[i];
     __syncthreads();
     // A sort entry is what phase D maximises per node.  With at most 1024 grid cells it is the complete selection key of the
     // reference (:795-804: largest response, then first in the cell-major / row-major candidate order):
@@ -1236,60 +1243,69 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
     // candidate instead of 32.
     const bool rankkey = g.nCols * g.nRows <= 1024;
     const float inv_ncols = 1.0f / (float)g.nCols;
-    for (int i0 = t; i0 < n; i0 += 4 * OT) {                       // 4 keys in flight per thread: the pass is latency-bound
-        uint32_t pay[4], cx[4], cy[4];
+    auto passes = [&](auto in_lds) __attribute__((always_inline)) {
+        constexpr bool LDS = decltype(in_lds)::value;
+        const int oyc = g.tabX, oxl = g.tabX + g.tabY, oyl = 2 * g.tabX + g.tabY;
+        auto XC = [&](uint32_t i) -> uint32_t { if constexpr (LDS) return s_tab[i]; else return xcode[i]; };
+        auto YC = [&](uint32_t i) -> uint32_t { if constexpr (LDS) return s_tab[oyc + i]; else return ycode[i]; };
+        auto XL = [&](uint32_t i) -> uint32_t { if constexpr (LDS) return s_tab[oxl + i]; else return xcell[i]; };
+        auto YL = [&](uint32_t i) -> uint32_t { if constexpr (LDS) return s_tab[oyl + i]; else return ycell[i]; };
+        for (int i0 = t; i0 < n; i0 += 4 * OT) {                       // 4 keys in flight per thread: the pass is latency-bound
+            uint32_t pay[4], cx[4], cy[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) pay[u] = (i0 + u * OT < n) ? keys[i0 + u * OT] : 0u;
+            for (int u = 0; u < 4; u++) pay[u] = (i0 + u * OT < n) ? keys[i0 + u * OT] : 0u;
 #pragma unroll
-        for (int u = 0; u < 4; u++) { cx[u] = xcode[(pay[u] >> 8) & 0xfff]; cy[u] = ycode[pay[u] >> 20]; }
+            for (int u = 0; u < 4; u++) { cx[u] = XC((pay[u] >> 8) & 0xfff); cy[u] = YC(pay[u] >> 20); }
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (i0 + u * OT < n) atomicAdd(&s_cursor[(cx[u] | cy[u]) >> bsh], 1u);     // code == oct_code(px, py, g), tabulated per axis at plan time
-    }
-    __syncthreads();
-    // ---- B: exclusive offsets, then scatter (order inside a bucket is irrelevant) ----
-    {
-        const int c = (NB + OT - 1) / OT;
-        const int beg = min(NB, t * c), end = min(NB, beg + c);
-        uint64_t sum = 0;
-        for (int i = beg; i < end; i++) sum += s_cursor[i];
-        uint64_t total;
-        uint64_t run = block_excl_scan64(sum, s_w, total);
-        for (int i = beg; i < end; i++) {
-            const uint32_t h = s_cursor[i];
-            L.offs[i] = (uint32_t)run;
-            s_cursor[i] = (uint32_t)run;
-            run += h;
+            for (int u = 0; u < 4; u++)
+                if (i0 + u * OT < n) atomicAdd(&s_cursor[(cx[u] | cy[u]) >> bsh], 1u);     // code == oct_code(px, py, g), tabulated per axis at plan time
         }
-        if (t == 0) L.offs[NB] = (uint32_t)n;
-    }
-    __syncthreads();
-    for (int i0 = t; i0 < n; i0 += 4 * OT) {
-        uint32_t pay[4], cx[4], cy[4], qx[4], qy[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) pay[u] = (i0 + u * OT < n) ? keys[i0 + u * OT] : 0u;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t px = (pay[u] >> 8) & 0xfff, py = pay[u] >> 20;
-            cx[u] = xcode[px]; cy[u] = ycode[py];
-            qx[u] = rankkey ? xcell[px] : 0u; qy[u] = rankkey ? ycell[py] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (i0 + u * OT >= n) continue;
-            uint32_t low = pay[u];
-            if (rankkey) {
-                const int px = (int)((pay[u] >> 8) & 0xfff), py = (int)(pay[u] >> 20);
-                const int ci = (int)(((float)qy[u] + 0.5f) * inv_ncols);                  // ycell = ci * nCols (exact: < 2^11)
-                const uint32_t pxc = (uint32_t)(px - 3 - (int)qx[u] * g.wCell), pyc = (uint32_t)(py - 3 - ci * g.hCell);
-                low = ((pay[u] & 0xffu) << 22) | (0x3fffffu - (((qy[u] + qx[u]) << 12) | (pyc << 6) | pxc));
+        __syncthreads();
+        // ---- B: exclusive offsets, then scatter (order inside a bucket is irrelevant) ----
+        {
+            const int c = (NB + OT - 1) / OT;
+            const int beg = min(NB, t * c), end = min(NB, beg + c);
+            uint64_t sum = 0;
+            for (int i = beg; i < end; i++) sum += s_cursor[i];
+            uint64_t total;
+            uint64_t run = block_excl_scan64(sum, s_w, total);
+            for (int i = beg; i < end; i++) {
+                const uint32_t h = s_cursor[i];
+                L.offs[i] = (uint32_t)run;
+                s_cursor[i] = (uint32_t)run;
+                run += h;
             }
-            const uint32_t code = cx[u] | cy[u];
-            const uint32_t pos = atomicAdd(&s_cursor[code >> bsh], 1u);
-            S[pos] = low; Cd[pos] = code;
+            if (t == 0) L.offs[NB] = (uint32_t)n;
         }
-    }
-    __syncthreads();
+        __syncthreads();
+        for (int i0 = t; i0 < n; i0 += 4 * OT) {
+            uint32_t pay[4], cx[4], cy[4], qx[4], qy[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) pay[u] = (i0 + u * OT < n) ? keys[i0 + u * OT] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t px = (pay[u] >> 8) & 0xfff, py = pay[u] >> 20;
+                cx[u] = XC(px); cy[u] = YC(py);
+                qx[u] = rankkey ? XL(px) : 0u; qy[u] = rankkey ? YL(py) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (i0 + u * OT >= n) continue;
+                uint32_t low = pay[u];
+                if (rankkey) {
+                    const int px = (int)((pay[u] >> 8) & 0xfff), py = (int)(pay[u] >> 20);
+                    const int ci = (int)(((float)qy[u] + 0.5f) * inv_ncols);                  // ycell = ci * nCols (exact: < 2^11)
+                    const uint32_t pxc = (uint32_t)(px - 3 - (int)qx[u] * g.wCell), pyc = (uint32_t)(py - 3 - ci * g.hCell);
+                    low = ((pay[u] & 0xffu) << 22) | (0x3fffffu - (((qy[u] + qx[u]) << 12) | (pyc << 6) | pxc));
+                }
+                const uint32_t code = cx[u] | cy[u];
+                const uint32_t pos = atomicAdd(&s_cursor[code >> bsh], 1u);
+                S[pos] = low; Cd[pos] = code;
+            }
+        }
+        __syncthreads();
+    };
+    if (tabLds) passes(std::true_type{}); else passes(std::false_type{});
 
     // ---- C: node list simulation ----
     // roots (:599-632): non-empty roots in index order
