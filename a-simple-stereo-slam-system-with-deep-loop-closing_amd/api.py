@@ -506,6 +506,25 @@ def ba_optimize_batch(d_poses, d_points, d_ep, d_el, d_obs, d_fixed, d_sizes, nw
                                           C.c_void_p(d_status), C.c_void_p(stream or None)), "myslam_ba_optimize_batch")
 
 
+def ba_flatten_window(active_kf_ids, mp_ids, mp_outlier, mp_first_observer_kf, obs_mp_id, obs_kf_id, obs_uv, obs_feat_outlier):
+    """The graph-build rules of Backend::OptimizeActiveMap (src/backend.cpp:139-206) on the Map's tables (host only).
+    Returns dict(pose_src, pt_src, edge_pose, edge_pt, edge_obs, edge_src, fixed): slots -> input rows, edges grouped by landmark."""
+    kf = np.ascontiguousarray(active_kf_ids, np.uint64); mp = np.ascontiguousarray(mp_ids, np.uint64)
+    mo = np.ascontiguousarray(mp_outlier, np.uint8); mf = np.ascontiguousarray(mp_first_observer_kf, np.uint64)
+    om = np.ascontiguousarray(obs_mp_id, np.uint64); ok = np.ascontiguousarray(obs_kf_id, np.uint64)
+    uv = np.ascontiguousarray(obs_uv, np.float32).reshape(-1, 2); fo = np.ascontiguousarray(obs_feat_outlier, np.uint8)
+    assert len(mp) == len(mo) == len(mf) and len(om) == len(ok) == len(uv) == len(fo)
+    pose_src = np.zeros(max(len(kf), 1), np.int32); pt_src = np.zeros(max(len(mp), 1), np.int32); fixed = np.zeros(max(len(mp), 1), np.uint8)
+    n = max(len(om), 1)
+    ep = np.zeros(n, np.int32); el = np.zeros(n, np.int32); eo = np.zeros((n, 2), np.float64); es = np.zeros(n, np.int32)
+    npt = C.c_int32(); ne = C.c_int32()
+    _check(lib().myslam_ba_flatten_window(_p(kf), len(kf), _p(mp), _p(mo), _p(mf), len(mp), _p(om), _p(ok), _p(uv), _p(fo), len(om),
+                                          _p(pose_src), _p(pt_src), C.byref(npt), _p(ep), _p(el), _p(eo), _p(es), C.byref(ne), _p(fixed)),
+           "myslam_ba_flatten_window")
+    L, E = npt.value, ne.value
+    return dict(pose_src=pose_src[:len(kf)], pt_src=pt_src[:L], fixed=fixed[:L], edge_pose=ep[:E], edge_pt=el[:E], edge_obs=eo[:E], edge_src=es[:E])
+
+
 def ba_optimize_active_map(poses, points, edge_pose, edge_pt, obs, fixed, K, delta=5.991, chi2_th=5.991, rounds=5, iters=10):
     """The solve stage of Backend::OptimizeActiveMap (src/backend.cpp:208-243).
     Returns (poses, points, edge_chi2, outlier flags, failed rounds, outlier count)."""

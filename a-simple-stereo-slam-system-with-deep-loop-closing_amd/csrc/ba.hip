@@ -6,6 +6,9 @@
 // f64 throughout (g2o is f64).  One 256-thread block per window; pose and landmark blocks are summed in a fixed order (two runs
 // give the same bits, see k_ba_build), the per-edge 6x3 Hpl blocks stream straight to HBM.  The order differs
 // from the oracle's plain edge loop -> agreement to ~1e-12 relative, not bit-exactly (stated in the tests).
+#include <algorithm>
+#include <unordered_map>
+#include <vector>
 #include "common.h"
 
 namespace myslam_hip {
@@ -853,7 +856,7 @@ static size_t ba_opt_lds(int maxP, int maxL, bool gl) {
 }
 
 static int ba_opt_launch(const BaOptArgs& a, int nwin, hipStream_t s) {
-    if (a.maxP > 10) return MYSLAM_ERR_CAPACITY;          // substitution runs on one wave: 6P <= 64; 55 pose pairs x 8 slices <= 512 threads
+    if (a.maxP > MYSLAM_BA_MAX_WINDOW_POSES) return MYSLAM_ERR_UNSUPPORTED;          // substitution runs on one wave: 6P <= 64; 55 pose pairs x 8 slices <= 512 threads
     size_t lds = ba_opt_lds(a.maxP, a.maxL, false);
     const bool gl = lds > 160 * 1024 - 512;                // large window: per-landmark state goes to the HBM scratch
     if (gl) {
@@ -1243,6 +1246,70 @@ int myslam_pose_only_optimize(double* pose7, const double* pts3d, const double* 
     if ((rc = hc.download())) return rc;
     if (n_inliers) *n_inliers = st[0];
     return st[1];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Map -> flat arrays (host): the graph-build rules of Backend::OptimizeActiveMap, src/backend.cpp:139-206.  See myslam_hip.h.
+// ------------------------------------------------------------------------------------------------
+int myslam_ba_flatten_window(const uint64_t* active_kf_ids, int n_kf, const uint64_t* mp_ids, const uint8_t* mp_outlier,
+                             const uint64_t* mp_first_observer_kf, int n_mp, const uint64_t* obs_mp_id, const uint64_t* obs_kf_id,
+                             const float* obs_uv, const uint8_t* obs_feat_outlier, int n_obs, int32_t* pose_src, int32_t* pt_src,
+                             int32_t* n_pts, int32_t* edge_pose, int32_t* edge_pt, double* edge_obs, int32_t* edge_src, int32_t* n_edges,
+                             uint8_t* fixed_pt) {
+    if (n_kf < 0 || n_mp < 0 || n_obs < 0 || !n_pts || !n_edges) return MYSLAM_ERR_INVALID;
+    if ((n_kf && (!active_kf_ids || !pose_src)) || (n_mp && (!mp_ids || !mp_first_observer_kf || !pt_src || !fixed_pt)) ||
+        (n_obs && (!obs_mp_id || !obs_kf_id || !obs_uv || !edge_pose || !edge_pt || !edge_obs || !edge_src)))
+        return MYSLAM_ERR_INVALID;
+    *n_pts = 0; *n_edges = 0;
+    // pose slots: ascending key-frame id (g2o sorts its active vertices by id; ids are unique map keys)
+    std::vector<int32_t> korder(n_kf);
+    for (int i = 0; i < n_kf; i++) korder[i] = i;
+    std::sort(korder.begin(), korder.end(), [&](int a, int b) { return active_kf_ids[a] < active_kf_ids[b]; });
+    for (int i = 1; i < n_kf; i++)
+        if (active_kf_ids[korder[i]] == active_kf_ids[korder[i - 1]]) return MYSLAM_ERR_INVALID;
+    std::unordered_map<uint64_t, int32_t> kslot, mrow;
+    kslot.reserve(n_kf * 2); mrow.reserve(n_mp * 2);
+    for (int i = 0; i < n_kf; i++) { pose_src[i] = korder[i]; kslot[active_kf_ids[korder[i]]] = i; }
+    for (int i = 0; i < n_mp; i++)
+        if (!mrow.emplace(mp_ids[i], i).second) return MYSLAM_ERR_INVALID;
+    // observations per map point, list order kept (a stable bucket pass over the rows)
+    std::vector<int32_t> cnt(n_mp + 1, 0), rows(n_obs);
+    std::vector<int32_t> orow(n_obs);
+    for (int k = 0; k < n_obs; k++) {
+        auto it = mrow.find(obs_mp_id[k]);
+        if (it == mrow.end()) return MYSLAM_ERR_INVALID;                                   // an observation of a map point that is not active
+        if (kslot.find(obs_kf_id[k]) == kslot.end()) return MYSLAM_ERR_INVALID;            // backend.cpp:187 assert
+        orow[k] = it->second; cnt[it->second + 1]++;
+    }
+    for (int i = 0; i < n_mp; i++) cnt[i + 1] += cnt[i];
+    {
+        std::vector<int32_t> fill(cnt.begin(), cnt.end() - 1);
+        for (int k = 0; k < n_obs; k++) rows[fill[orow[k]]++] = k;
+    }
+    // landmark slots: ascending map-point id
+    std::vector<int32_t> morder(n_mp);
+    for (int i = 0; i < n_mp; i++) morder[i] = i;
+    std::sort(morder.begin(), morder.end(), [&](int a, int b) { return mp_ids[a] < mp_ids[b]; });
+    int L = 0, E = 0;
+    for (int oi = 0; oi < n_mp; oi++) {
+        const int i = morder[oi];
+        if (mp_outlier && mp_outlier[i]) continue;                                         // :163
+        const int e0 = E;
+        for (int r = cnt[i]; r < cnt[i + 1]; r++) {
+            const int k = rows[r];
+            if (obs_feat_outlier && obs_feat_outlier[k]) continue;                         // :189
+            edge_pose[E] = kslot[obs_kf_id[k]]; edge_pt[E] = L;
+            edge_obs[2 * E] = (double)obs_uv[2 * k]; edge_obs[2 * E + 1] = (double)obs_uv[2 * k + 1];      // toVec2(feat->mkpPosition.pt), :194
+            edge_src[E] = k;
+            E++;
+        }
+        if (E == e0) continue;                                                             // no edge: g2o never activates the vertex
+        pt_src[L] = i;
+        fixed_pt[L] = kslot.find(mp_first_observer_kf[i]) == kslot.end() ? 1 : 0;          // :175-177
+        L++;
+    }
+    *n_pts = L; *n_edges = E;
+    return MYSLAM_OK;
 }
 
 }  // extern "C"

@@ -777,8 +777,11 @@ static int lcd_forward(myslam_lcd* h, int batch, float* d_out) {
         hipLaunchKernelGGL(k_conv2_bf16x6, dim3((Mtotal + 127) / 128), dim3(256), 0, s, h->d_p1, h->d_w2s, h->d_b[1], h->d_a2, Mtotal, f.relu[1]);
     }
     {
-        ScopedProf sp(P_CONV3, s);
+        ScopedProf sp(P_POOL2, s);
         hipLaunchKernelGGL(k_pool_lrn128_2x2, dim3((((HP2 + 1) / 2) * ((WP2 + 1) / 2) + 3) / 4, batch), dim3(256), 0, s, h->d_a2, H2, W2, HP2, WP2, f.lrn[1], h->d_p2);
+    }
+    {
+        ScopedProf sp(P_CONV3, s);
         hipLaunchKernelGGL(k_conv3_norm, dim3(batch), dim3(CV3_T), 0, s, h->d_p2, h->d_wt[2], h->d_b[2], d_out, f.relu[2]);
     }
     MYSLAM_HIP_CHECK(hipGetLastError());

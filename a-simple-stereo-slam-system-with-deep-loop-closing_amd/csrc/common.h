@@ -27,7 +27,7 @@ void prof_begin(int id, hipStream_t s);
 void prof_end(int id, hipStream_t s);
 enum ProfId {
     P_RESIZE = 0, P_FAST, P_OCTREE, P_BLUR, P_DESC, P_MATCH, P_TRI, P_LCD_PRE, P_CONV1, P_CONV2,
-    P_CONV3, P_DBSCAN, P_BA, P_SCREEN, P_COUNT
+    P_CONV3, P_DBSCAN, P_BA, P_SCREEN, P_POOL2, P_COUNT
 };
 
 struct ScopedProf {

@@ -39,15 +39,15 @@ void launch_ingest(const uint8_t* src, int rows, int cols, int step, size_t sstr
 static inline int cv_round(float v) { return (int)lrintf(v); }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// Gaussian taps in Q8 (sum 256).  kind 0: sigma = 2 (ORBextractor.cpp:966); kind 1: OpenCV's fixed
-// 7-tap table used when sigma <= 0 (deeplcd.cpp:46).
+// Gaussian taps in Q8.  kind 0: sigma = 2 (ORBextractor.cpp:966) as OpenCV 3.4.8's getFixedpointGaussianKernel builds it: every
+// normalised tap rounded to Q8 on its own (ufixedpoint16(softdouble) = cvRound(v * 256)) -> [18,34,49,55,49,34,18], sum 257 — the
+// error-diffusion construction that forces the sum to 256 came with later releases.  kind 1: OpenCV's fixed 7-tap table used when
+// sigma <= 0 (deeplcd.cpp:46), sum 256.
 void gauss_q8(int kind, int q[7]) {
     if (kind == 1) { const int t[7] = {8, 28, 56, 72, 56, 28, 8}; memcpy(q, t, sizeof(t)); return; }
     double g[7], sum = 0;
     for (int i = 0; i < 7; i++) { double x = i - 3; g[i] = exp(-(x * x) / 8.0); sum += g[i]; }
-    int qs = 0;
-    for (int i = 0; i < 7; i++) { q[i] = (int)lrint(g[i] / sum * 256.0); qs += q[i]; }
-    q[3] += 256 - qs;
+    for (int i = 0; i < 7; i++) q[i] = (int)lrint(g[i] / sum * 256.0);
 }
 
 // cv::resize INTER_LINEAR coefficient tables (OpenCV 3.4 resize.cpp: fx = (dx+0.5)*scale-0.5, 11-bit weights)
@@ -499,9 +499,10 @@ int myslam_orb_set_option(myslam_orb* h, int option, int value) {
 int myslam_orb_set_gauss_taps(myslam_orb* h, const int32_t* q7) {
     if (!h) return MYSLAM_ERR_INVALID;
     if (!q7) { h->tapsSet = 0; return MYSLAM_OK; }
+    // any table whose Q8.8 row sums fit the 16-bit horizontal accumulator (255 * sum <= 65535); the u8 result saturates
     int sum = 0;
     for (int i = 0; i < 7; i++) { if (q7[i] < 0 || q7[i] > 255) return MYSLAM_ERR_INVALID; sum += q7[i]; }
-    if (sum != 256) return MYSLAM_ERR_INVALID;
+    if (sum < 1 || sum > 257) return MYSLAM_ERR_INVALID;
     for (int i = 0; i < 7; i++) h->taps[i] = q7[i];
     h->tapsSet = 1;
     return MYSLAM_OK;

@@ -185,12 +185,22 @@ __global__ __launch_bounds__(256) void k_resize_strip(ResizeArgs a, int nstrips,
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: 7x7 separable Gaussian, Q8 coefficients (<= 255 each, sum 256), REFLECT_101.
+// K2: 7x7 separable Gaussian, Q8 coefficients (<= 255 each, sum <= 257: the Q8.8 row sums fit 16 bits), REFLECT_101, u8 saturation.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int reflect101(int p, int len) {
     if (len == 1) return 0;
     while (p < 0 || p >= len) p = (p < 0) ? -p : 2 * len - 2 - p;
     return p;
+}
+
+// Four vertical sums (Q16.16 + rounding seed, each < 2^25) -> four u8 in one dword, SATURATED as OpenCV's ufixedpoint32 -> uint8_t
+// conversion does: taps that sum to 257 (OpenCV 3.4.8's independently rounded sigma = 2 table) reach 257 on saturated image regions.
+// v_perm picks the two high halves, v_sat_pk_u8_i16 clamps both to 0..255: 5 instructions per 4 pixels.
+__device__ __forceinline__ uint32_t pack4_sat_hi16(uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3) {
+    uint32_t p01 = __builtin_amdgcn_perm(s1, s0, 0x07060302u), p23 = __builtin_amdgcn_perm(s3, s2, 0x07060302u), u01, u23;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(u01) : "v"(p01));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(u23) : "v"(p23));
+    return (u01 & 0xffffu) | (u23 << 16);
 }
 
 // K2b: LDS-tiled form on the dot-product units (any alignment, any size: the in-place DeepLCD blur and tiny images):
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(256) void k_blur7_dot(BlurArgs a) {
         uint4 D[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) D[j] = *reinterpret_cast<const uint4*>(&s_hp[(yp + j) * B2_W + 4 * qd]);
-        uint32_t lo = 0, hi = 0;
+        uint32_t S0[4], S1[4];
 #pragma unroll
         for (int xi = 0; xi < 4; xi++) {
             const uint32_t d0 = xi == 0 ? D[0].x : xi == 1 ? D[0].y : xi == 2 ? D[0].z : D[0].w;
@@ -285,9 +295,9 @@ __global__ __launch_bounds__(256) void k_blur7_dot(BlurArgs a) {
             s0 = DOT2(d0, t01, s0); s0 = DOT2(d1, t23, s0); s0 = DOT2(d2, t45, s0); s0 = DOT2(d3, t6_, s0);
             s1 = DOT2(d0, t_0, s1); s1 = DOT2(d1, t12, s1); s1 = DOT2(d2, t34, s1); s1 = DOT2(d3, t56, s1);
 #undef DOT2
-            lo |= (s0 >> 16) << (8 * xi);
-            hi |= (s1 >> 16) << (8 * xi);
+            S0[xi] = s0; S1[xi] = s1;
         }
+        const uint32_t lo = pack4_sat_hi16(S0[0], S0[1], S0[2], S0[3]), hi = pack4_sat_hi16(S1[0], S1[1], S1[2], S1[3]);
         // destination pitch is a multiple of 64: the 4-byte store never leaves the row; bytes past w are padding
         *reinterpret_cast<uint32_t*>(dst + (size_t)oy * a.dpitch + ox) = lo;
         if (oy + 1 < a.h) *reinterpret_cast<uint32_t*>(dst + (size_t)(oy + 1) * a.dpitch + ox) = hi;
@@ -408,7 +418,7 @@ __global__ __launch_bounds__(256) void k_blur7_strip(BlurArgs a, int nstrips, in
                     for (int k = 0; k < 4; k++) D[u][k] = he[k] | (ho[k] << 16);
                     if (pi >= 3) {
                         const int oy = y0 + 2 * (pi - 3);
-                        uint32_t lo = 0, hi = 0;
+                        uint32_t S0[4], S1[4];
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
                             const uint32_t d0 = D[(u + 1) & 3][k], d1 = D[(u + 2) & 3][k], d2 = D[(u + 3) & 3][k], d3 = D[u][k];
@@ -417,9 +427,9 @@ __global__ __launch_bounds__(256) void k_blur7_strip(BlurArgs a, int nstrips, in
                             s0 = DOT2(d0, t01, s0); s0 = DOT2(d1, t23, s0); s0 = DOT2(d2, t45, s0); s0 = DOT2(d3, t6_, s0);
                             s1 = DOT2(d0, t_0, s1); s1 = DOT2(d1, t12, s1); s1 = DOT2(d2, t34, s1); s1 = DOT2(d3, t56, s1);
 #undef DOT2
-                            lo |= (s0 >> 16) << (8 * k);
-                            hi |= (s1 >> 16) << (8 * k);
+                            S0[k] = s0; S1[k] = s1;
                         }
+                        const uint32_t lo = pack4_sat_hi16(S0[0], S0[1], S0[2], S0[3]), hi = pack4_sat_hi16(S1[0], S1[1], S1[2], S1[3]);
                         if (has) {      // destination pitch is a multiple of 64: the dword never leaves the row; bytes past w are padding
                             *reinterpret_cast<uint32_t*>(dst + (size_t)oy * a.dpitch + x0) = lo;
                             if (oy + 1 < a.h) *reinterpret_cast<uint32_t*>(dst + (size_t)(oy + 1) * a.dpitch + x0) = hi;

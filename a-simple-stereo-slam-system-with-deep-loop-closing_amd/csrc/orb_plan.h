@@ -62,7 +62,7 @@ struct ResizeArgs {
 struct BlurArgs {
     const uint8_t* src; uint8_t* dst; int w, h, spitch, dpitch; size_t sstride, dstride;
     const uint8_t* src0 = nullptr; int spitch0 = 0, n0 = 0; size_t sstride0 = 0;      // images b < n0 read their source plane here (level 0 in place; any alignment)
-    int q[7];                                    // Q8 taps, sum 256
+    int q[7];                                    // Q8 taps, sum <= 257
 };
 
 }  // namespace myslam_hip

@@ -8,7 +8,7 @@
 namespace myslam_hip {
 
 static const char* kNames[P_COUNT] = {"resize", "fast", "octree", "blur7", "describe", "hamming_match", "triangulate",
-                                      "lcd_preproc", "calc_conv1", "calc_conv2", "calc_conv3", "lcddb_scan", "ba_build", "screen"};
+                                      "lcd_preproc", "calc_conv1", "calc_conv2", "calc_conv3", "lcddb_scan", "ba_build", "screen", "calc_pool2"};
 struct Pending { int id; hipEvent_t a, b; };
 static std::atomic<bool> g_on{false};
 static std::mutex g_mu;

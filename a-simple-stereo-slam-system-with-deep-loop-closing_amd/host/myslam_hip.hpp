@@ -23,6 +23,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/myslam_hip.h"
@@ -240,6 +241,33 @@ struct LocalBA {               // flat-array form of the graph Backend::Optimize
     std::vector<uint8_t> fixed;                      // setFixed rule of backend.cpp:175-177
     double fx = 0, fy = 0, cx = 0, cy = 0, huber_delta = 5.991;   // backend.cpp:155,199
     std::vector<double> Hpp, Hll, Hpl, bp, bl, chi2;
+    // --- Map -> flat arrays (backend.cpp:139-206): copy the Map's tables into the *Table members, call Flatten(), and the arrays above
+    // are filled; after OptimizeActiveMap() pose slot p belongs to key-frame kf_ids[pose_src[p]], landmark slot j to map point
+    // mp_ids[pt_src[j]] and edge k to observation row edge_src[k] (outlier[k] -> that feature's mbIsOutlier, :234-250)
+    std::vector<uint64_t> kf_ids; std::vector<double> kf_pose7;                                       // Map::GetActiveKeyFrames(): mnKFId, Pose()
+    std::vector<uint64_t> mp_ids, mp_first_observer_kf; std::vector<uint8_t> mp_outlier; std::vector<double> mp_pos;   // GetActiveMapPoints()
+    std::vector<uint64_t> obs_mp_id, obs_kf_id; std::vector<float> obs_uv; std::vector<uint8_t> obs_feat_outlier;    // GetActiveObservations()
+    std::vector<int32_t> pose_src, pt_src, edge_src;
+    void AddKeyFrame(uint64_t kfId, const double pose7[7]) { kf_ids.push_back(kfId); kf_pose7.insert(kf_pose7.end(), pose7, pose7 + 7); }
+    void AddMapPoint(uint64_t id, const double pos[3], bool isOutlier, uint64_t firstObserverKFId) {
+        mp_ids.push_back(id); mp_pos.insert(mp_pos.end(), pos, pos + 3); mp_outlier.push_back(isOutlier); mp_first_observer_kf.push_back(firstObserverKFId);
+    }
+    void AddObservation(uint64_t mpId, uint64_t kfId, float u, float v, bool featureIsOutlier) {
+        obs_mp_id.push_back(mpId); obs_kf_id.push_back(kfId); obs_uv.push_back(u); obs_uv.push_back(v); obs_feat_outlier.push_back(featureIsOutlier);
+    }
+    void Flatten() {
+        const int nk = (int)kf_ids.size(), nm = (int)mp_ids.size(), no = (int)obs_mp_id.size();
+        pose_src.assign(nk, 0); pt_src.assign(nm, 0); fixed.assign(nm, 0);
+        edge_pose.assign(no, 0); edge_pt.assign(no, 0); edge_src.assign(no, 0); obs.assign((size_t)no * 2, 0);
+        int32_t L = 0, E = 0;
+        check(myslam_ba_flatten_window(kf_ids.data(), nk, mp_ids.data(), mp_outlier.data(), mp_first_observer_kf.data(), nm, obs_mp_id.data(),
+                                       obs_kf_id.data(), obs_uv.data(), obs_feat_outlier.data(), no, pose_src.data(), pt_src.data(), &L,
+                                       edge_pose.data(), edge_pt.data(), obs.data(), edge_src.data(), &E, fixed.data()), "myslam_ba_flatten_window");
+        pt_src.resize(L); fixed.resize(L); edge_pose.resize(E); edge_pt.resize(E); edge_src.resize(E); obs.resize((size_t)E * 2);
+        poses.resize((size_t)nk * 7); points.resize((size_t)L * 3);
+        for (int p = 0; p < nk; p++) std::copy(kf_pose7.begin() + 7 * pose_src[p], kf_pose7.begin() + 7 * pose_src[p] + 7, poses.begin() + 7 * p);
+        for (int j = 0; j < L; j++) std::copy(mp_pos.begin() + 3 * pt_src[j], mp_pos.begin() + 3 * pt_src[j] + 3, points.begin() + 3 * j);
+    }
     void Build() {
         const int P = (int)(poses.size() / 7), L = (int)(points.size() / 3), E = (int)edge_pose.size();
         Hpp.assign((size_t)P * 36, 0); Hll.assign((size_t)L * 9, 0); Hpl.assign((size_t)E * 18, 0);

@@ -8,6 +8,8 @@ the CPU oracle and the HIP path always see identical bytes.
   * loop database  |N(0,1)|^1064 rows, L2-normalised, seed 0xDB
   * BA window      10 key-frames x 300 landmarks, K = KITTI00, seed 0xBA
 """
+import os
+
 import numpy as np
 
 KITTI00 = dict(fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, bf=386.1448)   # config/stereo/gray/KITTI00-02.yaml
@@ -80,8 +82,17 @@ def stereo_batch(n_pairs, stream_id=0, t0=0, h=IMG_H, w=IMG_W, n_rect=6000):
     (SURVEY.md §8(d)); fewer rectangles give a sparser scene (a few % FAST corners, closer to real imagery)."""
     scene = make_scene(stream_id, h, w, n_rect)
     out = np.empty((n_pairs, 2, h, w), np.uint8)
-    for i in range(n_pairs):
+
+    def one(i):
         out[i, 0], out[i, 1] = stereo_pair(stream_id, t0 + i, h, w, scene)
+    workers = min(32, n_pairs, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    if workers <= 1:
+        for i in range(n_pairs):
+            one(i)
+    else:           # frames are independent (own PRNG each): rendered on a thread pool, same bytes as the serial loop
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(workers) as ex:
+            list(ex.map(one, range(n_pairs)))
     return out
 
 

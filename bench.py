@@ -29,13 +29,24 @@ import time
 
 import numpy as np
 
+# The ROCm runtime multiplexes HIP streams onto GPU_MAX_HW_QUEUES (default 4) HSA hardware queues, and streams that share a queue
+# serialise — a host->device copy on one of them stalls the kernels of the other (measured: the streamed pass ran at copy + compute
+# instead of max(copy, compute)).  The default schedule uses 5 streams (two extractor handles, match, LCD / BA chain, input copies):
+# one hardware queue each.  A runtime setting of the application, stated in the JSON (config.hip_hw_queues); the library reads no
+# environment variable.  Must be set before the HIP runtime initialises (i.e. before `import torch`).
+HW_QUEUES = os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package  # noqa: E402
 
 H, W = 376, 1241
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-VALU_PEAK_TLANEOPS = 39.3      # 256 CUs x 4 SIMDs x 16 lanes per cycle x 2.4 GHz
+VALU_PEAK_TLANEOPS = 39.3      # spec-derived: 256 CUs x 4 SIMDs x 16 lanes per cycle x 2.4 GHz (packed-16 / VOP3 integer classes: 4 cycles per wave64)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense
+# The MEASURED peaks of the same machine class live in profiles/r<NN>_peaks.json (tools/peaks.hip via tools/peaks.py): HBM copy rate,
+# issue rate of the instruction classes the FAST kernel is made of, bf16 MFMA rate.  The roofline objects carry both: `peak` is the
+# vendor figure the contract names (HBM) or the measured ceiling (VALU: no vendor figure exists), the other one sits beside it.
 PYR_PX = 1444097               # sum of the 8 level areas
 # algorithmic bytes per IMAGE of each ORB stage (SURVEY.md §8(d) accounting)
 ALGO_BYTES = {
@@ -48,7 +59,7 @@ ALGO_BYTES = {
 # profiling slot (csrc/prof.hip) -> kernel symbol prefix as rocprofv3 prints it
 SYMBOL = {"resize": "k_resize_strip", "fast": "k_fast_strip", "octree": "k_octree", "blur7": "k_blur7_strip", "describe": "k_describe2",
           "hamming_match": "k_hamming_fp4", "triangulate": "k_triangulate", "lcd_preproc": "k_lcd_input_fused",
-          "calc_conv1": "k_conv1_pool_lrn2", "calc_conv2": "k_conv2_bf16x6", "calc_conv3": "k_pool_lrn128_2x2", "lcddb_scan": "k_db_scan_bf16x6",
+          "calc_conv1": "k_conv1_pool_lrn2", "calc_conv2": "k_conv2_bf16x6", "calc_pool2": "k_pool_lrn128_2x2", "calc_conv3": "k_conv3_norm", "lcddb_scan": "k_db_scan_bf16x6",
           "ba_build": "k_ba_build", "screen": "k_screen"}
 
 
@@ -67,6 +78,22 @@ def pmc_file():
     except Exception:
         return None, None
     return (d, os.path.relpath(f, ROOT)) if "kernels" in d and "calibration" in d else (None, None)
+
+
+def peaks_file():
+    """The newest committed machine-peak measurement (tools/peaks.py): profiles/r<NN>_peaks.json -> (summary dict, relative path)."""
+    files = glob.glob(os.path.join(ROOT, "profiles", "r*_peaks.json"))
+    best = (None, None, -1)
+    for f in files:
+        m = re.search(r"r(\d+)_peaks\.json$", f)
+        if not m or int(m.group(1)) <= best[2]:
+            continue
+        try:
+            d = json.load(open(f))
+            best = (d["summary"], os.path.relpath(f, ROOT), int(m.group(1)))
+        except Exception:
+            pass
+    return best[0], best[1]
 
 
 def pmc_lookup(pmc, slot):
@@ -93,7 +120,11 @@ def parse():
                          "closer to real imagery, on which the two-phase FAST path pays most)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=200, help="upper bound of the frames the all-cores CPU baseline times (after its warm-up)")
-    ap.add_argument("--no-extra-passes", action="store_true", help="skip the profiled and the solve-cadence passes (timed region only)")
+    ap.add_argument("--no-extra-passes", action="store_true", help="skip the profiled, the solve-cadence and the streamed-input passes (timed region only)")
+    ap.add_argument("--stream-input", type=int, default=4,
+                    help="B > 0 (default 4): after the timed region, K more steps in which every step's images arrive over PCIe — B distinct batches "
+                         "(consecutive frames of the synthetic stream) in pinned host memory, host->device copies on a copy stream, double-buffered "
+                         "device input; reported as `streamed` beside the resident `value`.  0 = skip")
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
                     help="2 = the DeepLCD / loop-DB / BA chain runs on its own HIP stream beside ORB + match + triangulation")
     ap.add_argument("--orb-split", type=int, default=0, choices=[0, 1, 2, 3, 4, 8],
@@ -107,9 +138,10 @@ def parse():
                          "-1 (default) = 1 with --streams 2, else 0")
     ap.add_argument("--verify", action="store_true",
                     help="after the timed region: run one joined, un-gated step and check that it reproduces the pipeline's last outputs bit for bit")
-    ap.add_argument("--orb-internal-stream", type=int, default=1, choices=[0, 1, 2],
+    ap.add_argument("--orb-internal-stream", type=int, default=0, choices=[0, 1, 2],
                     help="myslam_orb_set_option(INTERNAL_STREAM): 1 = Gaussian pyramid on the extractor's internal stream beside the oct-tree kernel "
-                         "(the library's default), 2 = beside FAST, 0 = one stream")
+                         "(the library's default), 2 = beside FAST, 0 = one stream per extractor handle (default here: with one HSA hardware queue "
+                         "per HIP stream — see HW_QUEUES — the internal streams gain nothing, measured)")
     ap.add_argument("--orb-copy-input", type=int, default=0, choices=[0, 1],
                     help="myslam_orb_set_option(COPY_INPUT): 0 = level 0 read in place (the library's default), 1 = every image copied into the pyramid block")
     ap.add_argument("--fast-mode", type=int, default=-1, choices=[-1, 0, 1],
@@ -226,6 +258,7 @@ def main():
     frames = synth.stereo_batch(P, stream_id=rank, n_rect=args.scene_rects)   # [P, 2, H, W]
     imgs = np.concatenate([frames[:, 0], frames[:, 1]], axis=0)         # all left images, then all right images
     d_imgs = torch.from_numpy(imgs).to(dev)
+    cur = {"imgs": d_imgs}              # the device buffer the steps read their images from (the streamed pass swaps it per step)
     ext = api.ORBextractor(2000, stream=stream)
     cap = ext.max_keypoints()
     S = args.orb_split
@@ -288,7 +321,7 @@ def main():
 
     def side_chain():
         if use_lcd:
-            lcd.describe_batch(d_imgs.data_ptr(), P, H, W, W, H * W, d_descr.data_ptr(), blur_in_place=False)
+            lcd.describe_batch(cur["imgs"].data_ptr(), P, H, W, W, H * W, d_descr.data_ptr(), blur_in_place=False)
             if world > 1:       # every shard scores every rank's queries; the 16-byte candidate records are merged after an all-gather
                 if via_cpu:
                     h_all = torch.empty(d_allq.shape, dtype=d_allq.dtype)
@@ -336,7 +369,7 @@ def main():
                 if i == 0:
                     ev_start.record(sX[0])
                 o = i * G
-                e.detect_and_compute_batch(d_imgs.data_ptr() + o * H * W, G, H, W, W, H * W, kps.data_ptr() + o * cap * 28,
+                e.detect_and_compute_batch(cur["imgs"].data_ptr() + o * H * W, G, H, W, W, H * W, kps.data_ptr() + o * cap * 28,
                                            desc.data_ptr() + o * cap * 32, cnt.data_ptr() + 4 * o, stat.data_ptr() + 4 * o, cap)
                 ev_done[p][i].record(sX[i])
             for i in range(S):
@@ -352,7 +385,7 @@ def main():
 
     def step_joined():
         if S == 1:
-            ext.detect_and_compute_batch(d_imgs.data_ptr(), 2 * P, H, W, W, H * W, d_kps.data_ptr(), d_desc.data_ptr(),
+            ext.detect_and_compute_batch(cur["imgs"].data_ptr(), 2 * P, H, W, W, H * W, d_kps.data_ptr(), d_desc.data_ptr(),
                                          d_cnt.data_ptr(), d_stat.data_ptr(), cap)
         else:               # S equal groups of images, group 0 on the main stream
             G = 2 * P // S
@@ -360,7 +393,7 @@ def main():
                 st.wait_stream(main_stream)
             for gi, e in enumerate([ext] + orb_exts):
                 o = gi * G
-                e.detect_and_compute_batch(d_imgs.data_ptr() + o * H * W, G, H, W, W, H * W, d_kps.data_ptr() + o * cap * 28,
+                e.detect_and_compute_batch(cur["imgs"].data_ptr() + o * H * W, G, H, W, W, H * W, d_kps.data_ptr() + o * cap * 28,
                                            d_desc.data_ptr() + o * cap * 32, d_cnt.data_ptr() + 4 * o, d_stat.data_ptr() + 4 * o, cap)
             for st in orb_streams:
                 main_stream.wait_stream(st)
@@ -426,6 +459,76 @@ def main():
                    "note": "as the timed region, plus Backend::OptimizeActiveMap's solve stage (rounds of Levenberg-Marquardt optimize(10), Schur + "
                            "Cholesky, outlier flags) on every 6th frame's window — the reference solves per key-frame, about 1 frame in 6"}
 
+    # ---- pass 4: streamed input — every step's images cross PCIe (app/run_kitti_stereo.cpp:61-90 reads two images per step) ----
+    streamed = None
+    if args.stream_input > 0 and not args.no_extra_passes:
+        NBAT = args.stream_input
+        t_gen = time.perf_counter()
+        h_bat = []
+        for j in range(NBAT):           # consecutive frames of the same synthetic stream: batch j = frames j*P .. (j+1)*P - 1
+            f = frames if j == 0 else synth.stereo_batch(P, stream_id=rank, t0=j * P, n_rect=args.scene_rects)
+            h_bat.append(torch.from_numpy(np.concatenate([f[:, 0], f[:, 1]], axis=0)).pin_memory())
+        t_gen = time.perf_counter() - t_gen
+        NBUF = 3        # device input buffers: the copy of step k + 1 only needs step k - 2 to have finished
+        d_in = [torch.empty_like(d_imgs) for _ in range(NBUF)]
+        sC = torch.cuda.Stream()
+        readers = [main_stream] + orb_streams + ([side_stream] if side_stream is not main_stream else [])
+        ev_ready = [torch.cuda.Event() for _ in range(NBUF)]
+        ev_read = [[torch.cuda.Event() for _ in readers] for _ in range(NBUF)]
+        bytes_step = h_bat[0].numel()
+        k_stream = [0]
+        copy_ev = []
+
+        def step_streamed():
+            k = k_stream[0]; k_stream[0] += 1
+            b = k % NBUF
+            for e in ev_read[b]:
+                sC.wait_event(e)                    # the readers of step k - NBUF (same buffer) have finished: level 0 is read in place
+            ec = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ec[0].record(sC)
+            with torch.cuda.stream(sC):
+                d_in[b].copy_(h_bat[k % NBAT], non_blocking=True)
+            ec[1].record(sC); copy_ev.append(ec)
+            ev_ready[b].record(sC)
+            for st in readers:
+                st.wait_event(ev_ready[b])
+            cur["imgs"] = d_in[b]
+            step()
+            for e, st in zip(ev_read[b], readers):
+                e.record(st)
+
+        for _ in range(NBUF):
+            step_streamed()
+        barrier()
+        def signature():            # the valid descriptors of the step's first image (slots past the count hold stale bytes)
+            p = (step_no[0] - 1) % NB if args.pipeline else 0
+            n0 = int(d_cnt_b[p][0].item())
+            return d_desc_b[p][:32 * n0].clone()
+        sig_first = signature()         # of the last warm-up step
+        barrier()
+        copy_ev.clear()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_streamed()
+        barrier()
+        dt_s = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt_s], dtype=torch.float64, device="cpu" if via_cpu else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_s = float(t.item())
+        cur["imgs"] = d_imgs
+        assert all(int(t.abs().sum()) == 0 for t in d_stat_b), "ORB capacity overflow (streamed pass)"
+        sig_last = signature()
+        same_batch = (args.steps % NBAT) == 0          # the last timed step and the last warm-up step saw the same host batch
+        assert NBAT == 1 or (sig_first.shape == sig_last.shape and torch.equal(sig_first, sig_last)) == same_batch, "streamed pass: the steps did not see the batches they were sent"
+        del d_in, sig_first
+        streamed = {"value": world * P * args.steps / dt_s, "unit": "stereo frames/s", "ms_per_step": dt_s / args.steps * 1e3,
+                    "h2d_GBps": bytes_step * args.steps / dt_s / 1e9, "h2d_bytes_per_step": bytes_step, "distinct_batches": NBAT,
+                    "host_render_s": t_gen, "h2d_copy_ms_avg": float(np.mean([a.elapsed_time(b) for a, b in copy_ev])),
+                    "note": "every step extracts images that crossed PCIe for that step: consecutive frames of the synthetic stream in pinned host "
+                            "memory, one host->device copy per step on a copy stream, two device input buffers (a buffer is overwritten only after "
+                            "every reader of the step that used it has finished — level 0 is read in place)"}
+
     if args.verify and args.pipeline:
         # the overlapped schedule must not change a single output: one plain step (handles un-gated, joined) against the last pipelined one
         step(); torch.cuda.synchronize()
@@ -461,8 +564,11 @@ def main():
         ms_step = dt / args.steps * 1e3
         value = world * P * args.steps / dt
         pmc, pmc_path = pmc_file()
+        peaks, peaks_path = peaks_file()
+        valu_peak = (peaks or {}).get("valu_packed16_tlaneops") or VALU_PEAK_TLANEOPS
         busy = {k: v for k, v in prof.items() if v[1] > 0}
-        roof = {"bound": "hbm", "kernel": None, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+        roof = {"bound": "hbm", "kernel": None, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                "peak_measured": (peaks or {}).get("hbm_copy_GBps"), "peaks_source": peaks_path}
         roof_valu = None
         if busy:
             # the dominant kernel of the critical (ORB) chain: the one with the largest event-timed total among the chain's stages
@@ -484,6 +590,8 @@ def main():
                 algo = ALGO_BYTES[dom] * imgs_per_launch                        # bytes per launch
                 achieved = algo / (per_launch_ms * 1e-3) / 1e9
                 roof.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo})
+                if roof["peak_measured"]:
+                    roof["frac_of_measured"] = achieved / roof["peak_measured"]
             if rec:
                 # HBM bytes per launch from the counter summary: FETCH_SIZE scaled by the factor that makes k_ingest's FETCH_SIZE equal
                 # the bytes it provably reads (MI355X_MICROARCH.md: gfx950 tallies 128-byte requests at 64 bytes), + WRITE_SIZE
@@ -494,8 +602,13 @@ def main():
                 v = rec.get("valu_wave_insts_per_image")
                 if v:
                     ach = v * imgs_per_launch * 64 / (per_launch_ms * 1e-3) / 1e12
-                    roof_valu = {"bound": "valu", "kernel": roof["kernel"], "unit": "Tlane-op/s", "peak": VALU_PEAK_TLANEOPS, "achieved": ach,
-                                 "frac": ach / VALU_PEAK_TLANEOPS, "valu_wave_insts_per_image": v, "source": pmc_path}
+                    roof_valu = {"bound": "valu", "kernel": roof["kernel"], "unit": "Tlane-op/s", "peak": valu_peak, "achieved": ach,
+                                 "frac": ach / valu_peak, "peak_spec_16_lanes_per_cycle": VALU_PEAK_TLANEOPS, "peaks_source": peaks_path,
+                                 "valu_wave_insts_per_image": v, "source": pmc_path,
+                                 "note": "peak = measured issue rate of v_pk_max_i16 / v_pk_min_i16 / v_pk_maximum3_f16 / v_pk_minimum3_f16 (4 cycles "
+                                         "per wave64 instruction per SIMD; v_perm_b32, v_dot4, v_alignbyte and every VOP3 integer class measure the same; "
+                                         "only VOP2 add / and / or / lshr / 16-bit min-max and f32 add / mul / fma issue in 2 cycles) — the classes "
+                                         "k_fast_strip's scoring network consists of"}
             roof["note"] = ("avg_launch_ms = HIP-event duration of one launch on its own stream in the profiled pass (same schedule as the timed "
                             "region); a launch covers images_per_launch images and shares the chip with the other streams' launches; the kernel "
                             "is packed-integer VALU bound in practice (roofline_valu, DESIGN.md section 6)")
@@ -503,10 +616,12 @@ def main():
         if "calc_conv2" in busy:
             c2 = busy["calc_conv2"][0] / busy["calc_conv2"][1]
             f32eq = 2 * 176160768 * P / (c2 * 1e-3) / 1e12
-            mf = {"bound": "mfma", "kernel": SYMBOL["calc_conv2"], "peak": 157.3, "unit": "TFLOP/s (f32-equivalent, against the f32 matrix peak)",
-                  "achieved": f32eq, "frac": f32eq / 157.3, "bf16_tflops": 6 * f32eq, "bf16_frac_of_2500": 6 * f32eq / 2500.0, "avg_launch_ms": c2,
-                  "note": "CALC conv2 as an implicit GEMM on the bf16 matrix cores with f32 accuracy (3-way exact operand split, 6 partial products "
-                          "per useful f32 flop): `achieved` counts USEFUL f32 flops; bf16_tflops counts the partial products"}
+            mf = {"bound": "mfma", "kernel": SYMBOL["calc_conv2"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s (bf16 dense)",
+                  "achieved": 6 * f32eq, "frac": 6 * f32eq / MFMA_BF16_PEAK_TFLOPS, "peak_measured": (peaks or {}).get("mfma_bf16_tflops"),
+                  "peaks_source": peaks_path, "f32_equivalent_tflops": f32eq, "avg_launch_ms": c2,
+                  "note": "CALC conv2 as an implicit GEMM on the bf16 matrix cores with f32 accuracy (3-way exact operand split, 6 bf16 partial "
+                          "products per useful f32 multiply-add): `achieved` counts the bf16 flops the matrix pipe executes, priced against the "
+                          "bf16 dense peak; f32_equivalent_tflops counts the USEFUL f32 flops (the f32-input MFMA peak would be 157.3)"}
         n_internal = S if args.orb_internal_stream else 0        # every extractor handle runs its Gaussian pyramid on an internal stream
         out = {
             "metric": "stereo frames/sec (ORB+match+LCD+BA-build) @1241x376",
@@ -522,7 +637,7 @@ def main():
                        "pairs_per_step_per_gpu": P, "image": "1241x376 u8", "scene_rects": args.scene_rects, "keypoints_per_image": n_kp,
                        "hip_streams": {"caller": len({stream, stream2} | {s.cuda_stream for s in orb_streams}) + (1 if args.pipeline else 0),
                                        "extractor_internal": n_internal},
-                       "orb_extractor_handles": S, "pipelined_steps": bool(args.pipeline),
+                       "hip_hw_queues": int(HW_QUEUES), "orb_extractor_handles": S, "pipelined_steps": bool(args.pipeline),
                        "input_level0": "read in place (resident input images; the last image of each extractor call is copied)" if not args.orb_copy_input
                                        else "copied into the pyramid block",
                        "parallelism": f"frame-sharded x{world}" + (", id-range sharded DB + all-gather of 16-byte candidate records" if world > 1 else "")},
@@ -531,6 +646,10 @@ def main():
             "roofline": roof, "roofline_valu": roof_valu, "roofline_mfma": mf,
             "profiled_pass": None if dt_prof is None else {"ms_per_step": dt_prof / args.steps * 1e3,
                                                            "kernel_ms_per_step": {SYMBOL.get(k, k): v[0] / args.steps for k, v in busy.items()}},
+            "streamed": None if streamed is None else dict(streamed, ratio_to_resident=streamed["value"] / value,
+                                                           pcie_h2d_measured_GBps=(peaks or {}).get("h2d_GBps"),
+                                                           pcie_bound_frames_per_s=None if not (peaks or {}).get("h2d_GBps") else
+                                                           world * (peaks["h2d_GBps"] * 1e9) / (2 * H * W)),
             "full_solve_cadence6": cadence,
             "ba_solve_all_windows_ms": solve_ms,     # OptimizeActiveMap solve stage for all P windows, outside the timed region
         }

@@ -96,8 +96,10 @@ int myslam_orb_set_fast_gate(myslam_orb* h, void* hip_event);
 int myslam_orb_set_option(myslam_orb* h, int option, int value);
 /* The 7 x 7 sigma = 2 Gaussian before rBRIEF (ORBextractor.cpp:966, :1197) runs in OpenCV's 8-bit fixed-point form; how OpenCV 3.4.8
  * rounds the taps to Q8 could not be checked in the build environment (parity unpinned).  Default
- * [18,34,49,54,49,34,18] (round to nearest, residue on the centre tap).  A maintainer who measures another table with
- * tools/dump_opencv_goldens.py sets it here (7 ints, 0..255, sum 256; NULL restores the default). */
+ * [18,34,49,55,49,34,18]: every normalised tap rounded to nearest on its own, as getFixedpointGaussianKernel of the 3.4.8 era does —
+ * the sum is 257 and the u8 result saturates as ufixedpoint32 -> uint8_t does.  A maintainer who measures another table with
+ * tools/dump_opencv_goldens.py sets it here (7 ints, 0..255, sum 1..257 so that the Q8.8 row sums fit 16 bits; NULL restores the
+ * default; [18,34,49,54,49,34,18] is the sum-256 table rounds 1-2 of this library used). */
 int myslam_orb_set_gauss_taps(myslam_orb* h, const int32_t* q7);
 /* getters ORBextractor.h:87-107 */
 int myslam_orb_get_tables(const myslam_orb* h, float* scale, float* inv_scale, int* features_per_level, int* umax16);
@@ -307,10 +309,37 @@ int myslam_ba_build_batch(const double* d_poses, const double* d_points, const i
                           double* d_Hpp, double* d_Hll, double* d_Hpl, double* d_bp, double* d_bl, double* d_chi2,
                           void* hip_stream);
 
+/* Map -> flat arrays: the graph-build rules of Backend::OptimizeActiveMap (src/backend.cpp:139-206) as a host function (plain C++,
+ * no device needed), so that a maintainer's OptimizeActiveMap body is { copy the Map's tables; flatten; optimize_active_map; write back }.
+ * Inputs (host pointers), one row per object of the reference's containers:
+ *   active_kf_ids[n_kf]                 Map::GetActiveKeyFrames() keys (any order; :136,139-150)
+ *   mp_ids / mp_outlier / mp_first_observer_kf [n_mp]   Map::GetActiveMapPoints(): mnId, mbIsOutlier, and the key-frame id of
+ *                                       GetObservations().front() (:163-177)
+ *   obs_mp_id / obs_kf_id / obs_uv / obs_feat_outlier [n_obs]   every MapPoint::GetActiveObservations() entry (list order within a map
+ *                                       point): the map point's id, feature->mpKF->mnKFId, feature->mkpPosition.pt, feature->mbIsOutlier (:181-189)
+ * Rules reproduced: outlier map points get no vertex and no edges (:163); outlier features get no edge (:189); a map point whose FIRST
+ * observer is not an active key-frame is fixed (:175-177); an observation from a key-frame outside the active set is the reference's
+ * assert (:187) -> MYSLAM_ERR_INVALID, as is an observation of an unknown map point.  Orders (the reference iterates unordered_maps, g2o
+ * then sorts vertices by id): pose slots by ascending key-frame id, landmark slots by ascending map-point id, edges grouped by landmark
+ * (what myslam_ba_optimize* need) in observation-list order.  Map points left without an edge are dropped (g2o never activates them).
+ * Outputs: pose_src[n_kf] / pt_src[*n_pts] = index of the INPUT row each slot was taken from (to gather poses / positions and to write
+ * results back: :252-258), edge_pose / edge_pt / edge_obs (double, as toVec2) / edge_src (index of the observation row, for the outlier
+ * write-back :234-250) [*n_edges <= n_obs], fixed_pt[*n_pts]. */
+int myslam_ba_flatten_window(const uint64_t* active_kf_ids, int n_kf, const uint64_t* mp_ids, const uint8_t* mp_outlier,
+                             const uint64_t* mp_first_observer_kf, int n_mp, const uint64_t* obs_mp_id, const uint64_t* obs_kf_id,
+                             const float* obs_uv, const uint8_t* obs_feat_outlier, int n_obs, int32_t* pose_src, int32_t* pt_src,
+                             int32_t* n_pts, int32_t* edge_pose, int32_t* edge_pt, double* edge_obs, int32_t* edge_src, int32_t* n_edges,
+                             uint8_t* fixed_pt);
+
+/* The solve kernels keep a window's pose system on one wavefront: at most MYSLAM_BA_MAX_WINDOW_POSES key-frames per window
+ * (Map.activeMap.size is 7 in every config the reference ships, config/stereo/gray/KITTI00-02.yaml:73); a larger window returns
+ * MYSLAM_ERR_UNSUPPORTED from myslam_ba_optimize* (myslam_ba_build* has no such limit). */
+#define MYSLAM_BA_MAX_WINDOW_POSES 10
+
 /* Levenberg-Marquardt with Schur complement on device — replaces optimizer.optimize(n) of
  * Backend::OptimizeActiveMap (src/backend.cpp:212-214: g2o OptimizationAlgorithmLevenberg + BlockSolver_6_3 +
  * CSparse).  poses/points are updated in place.  Edges must be grouped by landmark
- * (backend.cpp:161-205 builds them that way); max_poses <= 10.  d_scratch: nwin x max_edges x 18 doubles. */
+ * (backend.cpp:161-205 builds them that way; myslam_ba_flatten_window does); max_poses <= MYSLAM_BA_MAX_WINDOW_POSES.  d_scratch: nwin x max_edges x 18 doubles. */
 int myslam_ba_optimize(double* poses, int nposes, double* points, int npts, const int32_t* edge_pose, const int32_t* edge_pt,
                        const double* obs, int nedges, const uint8_t* fixed_pt, double fx, double fy, double cx, double cy,
                        double huber_delta, int max_iters, double* final_chi2, int* iters);
@@ -324,7 +353,7 @@ int myslam_ba_optimize_batch(double* d_poses, double* d_points, const int32_t* d
  * { initializeOptimization(); optimize(iters_per_round = 10) }, stopping as soon as more than half of the edges have
  * chi2() <= chi2_th (5.991); then the outlier flags of :232-249.  edge_chi2[k] is what edge->chi2() returns there: e^T e of
  * the last error evaluation (the last Levenberg trial, accepted or not — a g2o property the reference inherits).
- * *rounds = the reference's `iteration` counter (rounds that failed the inlier test).  Edges grouped by landmark, max_poses <= 10. */
+ * *rounds = the reference's `iteration` counter (rounds that failed the inlier test).  Edges grouped by landmark, max_poses <= MYSLAM_BA_MAX_WINDOW_POSES. */
 int myslam_ba_optimize_active_map(double* poses, int nposes, double* points, int npts, const int32_t* edge_pose, const int32_t* edge_pt,
                                   const double* obs, int nedges, const uint8_t* fixed_pt, double fx, double fy, double cx, double cy,
                                   double huber_delta, double chi2_th, int max_rounds, int iters_per_round,

@@ -60,7 +60,7 @@ int orc_build_pyramid(const orc_orb_params* p, const uint8_t* img, int rows, int
 
 /* ---- FAST (cv::FAST restated, Appendix A.1; predicate mirrored at ORBextractor.cpp:449-511) ---- */
 /* score map of a whole ROI at threshold th: out[y*w+x] = score (>=th) or 0; no NMS. */
-/* replace the sigma = 2 Q8 taps (7 ints, 0..255, sum 256; NULL restores the default [18,34,49,54,49,34,18]) — process global */
+/* replace the sigma = 2 Q8 taps (7 ints, 0..255, sum 1..257; NULL restores the default [18,34,49,55,49,34,18] = OpenCV 3.4.8's per-tap rounding) — process global */
 int orc_set_gauss_taps(const int* q7);
 /* FAST score of one pixel: the oracle's definition, and OpenCV's cornerScore<16> including its threshold seed */
 int orc_fast_score_px(const uint8_t* img, int step, int x, int y);

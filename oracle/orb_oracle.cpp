@@ -151,9 +151,10 @@ void gauss_coeffs(int kind, int q[7]) {
     const double sigma = 2.0;
     double g[7], sum = 0;
     for (int i = 0; i < 7; i++) { double x = i - 3; g[i] = exp(-(x * x) / (2 * sigma * sigma)); sum += g[i]; }
-    int qs = 0;
-    for (int i = 0; i < 7; i++) { q[i] = (int)lrint(g[i] / sum * 256.0); qs += q[i]; }
-    q[3] += 256 - qs;   // Appendix A.3: centre tap absorbs the rounding residue -> [18,34,49,54,49,34,18]
+    // OpenCV 3.4.8 getFixedpointGaussianKernel: kernel[i] = ufixedpoint16(values[i] / sum) = cvRound(v * 256) per tap, no fix-up of the
+    // sum -> [18,34,49,55,49,34,18] (sum 257); the error-diffusion construction with sum 256 belongs to later releases.  (SURVEY
+    // Appendix A.3 chose "residue on the centre tap", [..,54,..]; orc_set_gauss_taps still accepts that table.)
+    for (int i = 0; i < 7; i++) q[i] = (int)lrint(g[i] / sum * 256.0);
 }
 
 inline int reflect101(int p, int len) {
@@ -175,7 +176,7 @@ int gaussian_blur7(const uint8_t* src, int w, int h, int sstep, uint8_t* dst, in
         for (int x = 0; x < w; x++) {
             int acc = 0;
             for (int i = 0; i < 7; i++) acc += q[i] * S[reflect101(x + i - 3, w)];
-            hbuf[(size_t)y * w + x] = (uint16_t)acc;   // Q8.8, max 255*256
+            hbuf[(size_t)y * w + x] = (uint16_t)std::min(acc, 65535);   // Q8.8 ufixedpoint16 (saturating; 255 * 257 = 65535 still fits)
         }
     }
     for (int y = 0; y < h; y++) {
@@ -654,11 +655,11 @@ int orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstep, uint8_t*
     return resize_linear(src, sw, sh, sstep, dst, dw, dh, dstep);
 }
 
-int orc_set_gauss_taps(const int* q7) {           // NULL = back to the default; taps must be 0..255 and sum to 256
+int orc_set_gauss_taps(const int* q7) {           // NULL = back to the default; taps must be 0..255 and sum to 1..257 (Q8.8 row sums fit 16 bits)
     if (!q7) { g_taps_set = 0; return 0; }
     int sum = 0;
     for (int i = 0; i < 7; i++) { if (q7[i] < 0 || q7[i] > 255) return -1; sum += q7[i]; }
-    if (sum != 256) return -1;
+    if (sum < 1 || sum > 257) return -1;
     for (int i = 0; i < 7; i++) g_taps[i] = q7[i];
     g_taps_set = 1;
     return 0;

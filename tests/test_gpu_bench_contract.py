@@ -31,6 +31,20 @@ def test_bench_json_contract(extra):
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in roof, k
     assert roof["bound"] in ("hbm", "mfma") and roof["peak"] > 0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    # the streamed-input pass: every step's images cross PCIe; three distinct host batches here
+    st = d["streamed"]
+    assert st and st["value"] > 0 and st["distinct_batches"] == 4 and st["h2d_bytes_per_step"] == 2 * 16 * 376 * 1241
+    assert abs(st["h2d_GBps"] - st["h2d_bytes_per_step"] / (st["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * st["h2d_GBps"]
+    # normalisations: every frac is achieved / peak, and the matrix-core one is priced against the bf16 dense peak (cannot exceed 1)
+    if d.get("roofline_mfma"):
+        mf = d["roofline_mfma"]
+        assert mf["peak"] == 2500.0 and abs(mf["frac"] - mf["achieved"] / mf["peak"]) < 1e-9 and mf["frac"] < 1.0
+    if d.get("roofline_valu"):
+        rv = d["roofline_valu"]
+        assert abs(rv["frac"] - rv["achieved"] / rv["peak"]) < 1e-9 and 30.0 < rv["peak"] < 45.0
+    km = d["profiled_pass"]["kernel_ms_per_step"]
+    if "lcd" in d["config"]["workload"].lower():
+        assert "k_conv3_norm" in km and "k_pool_lrn128_2x2" in km and "k_conv2_bf16x6" in km
     if "--no-cpu-baseline" in extra:
         assert d["cpu_baseline"] is None
     else:
@@ -72,3 +86,21 @@ def test_bench_self_launch_two_ranks():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["collective_ranks"] == 2 and d["collective_backend"] == "gloo" and d["value"] > 0
+
+
+def test_bench_self_launch_eight_ranks():
+    """BASELINE configs[4]'s rank count on one GPU: `python bench.py --gpus 8 --backend gloo --pairs 8` — the 8-rank code path (8 id-range
+    shards, check_shard_order, NQ = 8 P queries per shard scan, two all-gathers per step, the 8-way candidate merge) so that the first real
+    8-GPU run cannot fail on something two ranks never exercised."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--pairs", "8", "--backend", "gloo",
+           "--db", "640", "--stream-input", "2"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["collective_ranks"] == 8 and d["collective_backend"] == "gloo" and d["scaling"] == "weak"
+    assert abs(d["value"] - 8 * 8 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]        # whole-job rate over all 8 ranks
+    assert "x8" in d["config"]["parallelism"] and "5120-KF" in d["config"]["workload"]
+    assert d["streamed"]["value"] > 0 and d["full_solve_cadence6"]["value"] > 0

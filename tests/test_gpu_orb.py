@@ -358,7 +358,26 @@ def test_gauss_taps_option_matches_oracle(api, oracle, synth):
     k2, d2 = ext.DetectAndCompute(img)
     assert np.array_equal(d2, d0)
     with pytest.raises(api.MyslamError):
-        ext.set_gauss_taps([18, 34, 49, 55, 49, 34, 18])             # sum 257
+        ext.set_gauss_taps([18, 34, 49, 56, 49, 34, 18])             # sum 258: the Q8.8 row sums would not fit 16 bits
+    ext.set_gauss_taps([18, 34, 49, 54, 49, 34, 18])                 # the sum-256 table of rounds 1-2 stays selectable
+    ext.set_gauss_taps(None)
+
+
+def test_blur_saturates_like_ufixedpoint(api, oracle, synth):
+    """The default sigma = 2 taps sum to 257 (OpenCV 3.4.8 rounds every tap on its own), so saturated image regions reach 257 before the
+    u8 conversion: strip kernel (wide, aligned levels) and LDS kernel (narrow levels) both clamp like ufixedpoint32 -> uint8_t."""
+    for h, w in ((376, 1241), (120, 200)):
+        img = synth.random_image(5, h, w)
+        img[20:90, 30:170] = 255; img[5:40, w - 60:] = 254; img[h - 30:, :80] = 255
+        ext = api.ORBextractor(500)
+        P = oracle.pyramid(oracle.params(500), img)
+        for l in (0, 1, 4, 7):
+            got = ext.debug_pyramid(img, l, blurred=True); ref = oracle.blur7(P[l], 0)
+            assert np.array_equal(got, ref), (h, w, l)
+            if l == 0:
+                assert ref.max() == 255 and (ref[30:80, 40:160] == 255).all()
+        k, d = ext.DetectAndCompute(img); rk, rd = oracle.detect_and_compute(oracle.params(500), img)
+        assert k.tobytes() == rk.tobytes() and np.array_equal(d, rd)
 
 
 def test_get_tables(api, oracle):

@@ -64,15 +64,20 @@ def test_resize_close_to_float_bilinear(oracle, synth):
 
 
 def test_blur_coefficients_and_impulse(oracle):
-    for kind, q in ((0, [18, 34, 49, 54, 49, 34, 18]), (1, [8, 28, 56, 72, 56, 28, 8])):
-        assert sum(q) == 256
+    # kind 0 (sigma = 2): every normalised tap rounded to Q8 on its own, as OpenCV 3.4.8's getFixedpointGaussianKernel does -> sum 257;
+    # kind 1 (sigma <= 0): OpenCV's fixed 7-tap table, sum 256
+    g = np.exp(-(np.arange(7) - 3.0) ** 2 / 8.0)
+    assert np.rint(g / g.sum() * 256).astype(int).tolist() == [18, 34, 49, 55, 49, 34, 18]
+    for kind, q in ((0, [18, 34, 49, 55, 49, 34, 18]), (1, [8, 28, 56, 72, 56, 28, 8])):
+        assert sum(q) == (257 if kind == 0 else 256)
         img = np.zeros((21, 21), np.uint8); img[10, 10] = 255
         out = oracle.blur7(img, kind)
         qq = np.array(q, np.int64)
         expect = ((np.outer(qq, qq) * 255 + 32768) >> 16).astype(np.uint8)
         assert np.array_equal(out[7:14, 7:14], expect)
-        const = np.full((16, 40), 201, np.uint8)
-        assert np.all(oracle.blur7(const, kind) == 201)
+        for c in (0, 1, 100, 201, 254, 255):          # constant images: (c * sum^2 + 2^15) >> 16, saturated to 255 (ufixedpoint32 -> u8)
+            const = np.full((16, 40), c, np.uint8)
+            assert np.all(oracle.blur7(const, kind) == min(255, (c * sum(q) ** 2 + 32768) >> 16)), (kind, c)
 
 
 def test_blur_reflect101(oracle):
@@ -663,7 +668,8 @@ def test_fast_score_threshold_seed_is_irrelevant(oracle, synth):
 
 def test_gauss_taps_option(oracle, synth):
     """The sigma = 2 taps are a run-time table on the oracle side as on the device side (myslam_orb_set_gauss_taps): default
-    [18,34,49,54,49,34,18]; e.g. an error-diffusion rounding [18,34,48,56,48,34,18] changes the blurred image."""
+    [18,34,49,55,49,34,18] (sum 257, OpenCV 3.4.8's per-tap rounding); e.g. an error-diffusion rounding [18,34,48,56,48,34,18] or the
+    residue-on-the-centre table [18,34,49,54,49,34,18] of rounds 1-2 changes the blurred image."""
     img = synth.random_image(9, 60, 80)
     a = oracle.blur7(img, 0)
     try:
@@ -671,4 +677,12 @@ def test_gauss_taps_option(oracle, synth):
         b = oracle.blur7(img, 0)
     finally:
         oracle.set_gauss_taps(None)
-    assert np.array_equal(oracle.blur7(img, 0), a) and not np.array_equal(a, b) and np.abs(a.astype(int) - b.astype(int)).max() <= 2
+    assert np.array_equal(oracle.blur7(img, 0), a) and not np.array_equal(a, b) and np.abs(a.astype(int) - b.astype(int)).max() <= 3
+    try:
+        oracle.set_gauss_taps([18, 34, 49, 54, 49, 34, 18])
+        c = oracle.blur7(img, 0)
+    finally:
+        oracle.set_gauss_taps(None)
+    assert not np.array_equal(a, c) and np.abs(a.astype(int) - c.astype(int)).max() <= 2
+    with pytest.raises(AssertionError):
+        oracle.set_gauss_taps([18, 34, 49, 56, 49, 34, 18])      # sum 258: 255 * 258 overflows the Q8.8 row sum
