@@ -92,6 +92,58 @@ int main() {
         int flagdiff = 0;
         for (int k = 0; k < E; k++) flagdiff += (ba.outlier[k] != rout[k]) && std::fabs(rchi[k] - 5.991) > 1e-6;
         EXPECT(flagdiff == 0);
+
+        // the same window entered through the Map tables (Backend::OptimizeActiveMap's graph build, backend.cpp:139-206): key-frames and map
+        // points in scrambled container order with arbitrary ids, plus an outlier map point, an outlier feature and a landmark whose
+        // first observer left the window; Flatten() must reproduce the flat arrays above (minus the skipped rows) and the solve must agree
+        myslam::LocalBA fb;
+        fb.fx = ba.fx; fb.fy = ba.fy; fb.cx = ba.cx; fb.cy = ba.cy;
+        std::vector<double> p0v(7 * P), x0v(3 * L);
+        for (int pp = 0; pp < P; pp++) { const double q[7] = {0, 0, 0, 1, -tx[pp], 0, 0}; std::copy(q, q + 7, p0v.begin() + 7 * pp); }
+        const int korder[6] = {3, 0, 5, 1, 4, 2};
+        for (int i = 0; i < P; i++) fb.AddKeyFrame(100 + 10 * korder[i], &p0v[7 * korder[i]]);            // ids 100, 110, ... ascending with the slot
+        std::vector<int> lorder(L);
+        for (int l = 0; l < L; l++) lorder[l] = (l * 37) % L;                                                // 37 is coprime to 80
+        // (landmark positions: `ba`'s optimised points serve as the second problem's initial estimate)
+        for (int i = 0; i < L; i++) {
+            const int l = lorder[i];
+            fb.AddMapPoint(1000 + l, &ba.points[3 * l], /*isOutlier=*/l == 5, /*firstObserverKFId=*/(l % 9 == 0) ? 7 : 100);
+        }
+        for (int i = 0; i < L; i++) {
+            const int l = lorder[i];
+            for (int pp = 0; pp < P; pp++)
+                fb.AddObservation(1000 + l, 100 + 10 * pp, (float)ba.obs[2 * (l * P + pp)], (float)ba.obs[2 * (l * P + pp) + 1], /*featureIsOutlier=*/l == 8 && pp == 3);
+        }
+        fb.Flatten();
+        EXPECT((int)fb.poses.size() == 7 * P && (int)fb.points.size() == 3 * (L - 1) && (int)fb.edge_pose.size() == E - P - 1);
+        bool ok = true;
+        for (int pp = 0; pp < P; pp++) ok = ok && fb.kf_ids[fb.pose_src[pp]] == (uint64_t)(100 + 10 * pp);
+        for (size_t j = 0; j < fb.pt_src.size(); j++) {
+            const int l = (int)fb.mp_ids[fb.pt_src[j]] - 1000;
+            ok = ok && l != 5 && (j == 0 || fb.mp_ids[fb.pt_src[j]] > fb.mp_ids[fb.pt_src[j - 1]]) && fb.fixed[j] == (l % 9 == 0 ? 1 : 0);
+        }
+        for (size_t k = 0; k < fb.edge_pose.size(); k++) {
+            const int row = fb.edge_src[k], l = (int)fb.obs_mp_id[row] - 1000, pp = (int)(fb.obs_kf_id[row] - 100) / 10;
+            ok = ok && fb.edge_pose[k] == pp && (int)fb.mp_ids[fb.pt_src[fb.edge_pt[k]]] - 1000 == l && !(l == 8 && pp == 3) && l != 5;
+            ok = ok && fb.obs[2 * k] == (double)(float)ba.obs[2 * (l * P + pp)] && (k == 0 || fb.edge_pt[k] >= fb.edge_pt[k - 1]);
+        }
+        EXPECT(ok);
+        // solve through the facade and through the oracle on the flattened arrays
+        std::vector<double> fp = fb.poses, fx2 = fb.points, fchi(fb.edge_pose.size()); std::vector<uint8_t> fout(fb.edge_pose.size()); int fr = 0, fn = 0;
+        EXPECT(orc_ba_optimize_active_map(fp.data(), P, fx2.data(), (int)fb.points.size() / 3, fb.edge_pose.data(), fb.edge_pt.data(), fb.obs.data(),
+                                          (int)fb.edge_pose.size(), fb.fixed.data(), fb.fx, fb.fy, fb.cx, fb.cy, 5.991, 5.991, 5, 10, fchi.data(), fout.data(), &fr, &fn) == 0);
+        const int fnout = fb.OptimizeActiveMap();
+        EXPECT(fnout == fn);
+        double fd = 0;
+        for (size_t i = 0; i < fp.size(); i++) fd = std::max(fd, std::fabs(fp[i] - fb.poses[i]));
+        for (size_t i = 0; i < fx2.size(); i++) fd = std::max(fd, std::fabs(fx2[i] - fb.points[i]));
+        EXPECT(fd < 1e-7);
+        // a window beyond the solve kernels' pose limit is refused with a status, not truncated
+        myslam::LocalBA big = fb;
+        for (int extra = 0; extra < 6; extra++) big.poses.insert(big.poses.end(), p0v.begin(), p0v.begin() + 7);
+        bool threw = false;
+        try { big.OptimizeActiveMap(); } catch (const std::exception&) { threw = true; }
+        EXPECT(threw && (int)big.poses.size() / 7 > MYSLAM_BA_MAX_WINDOW_POSES);
     }
 
     // LK tracker: the image against itself shifted by 2 px

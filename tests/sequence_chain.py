@@ -228,18 +228,20 @@ class Chain:
 
     # Backend::OptimizeActiveMap (backend.cpp:126-266): the last `window` key-frames, every map point they observe
     def local_ba(self):
-        win = list(range(max(0, len(self.kfs) - self.window), len(self.kfs)))
-        idx = {k: i for i, k in enumerate(win)}
-        mps = sorted(m for m, o in self.obs.items() if any(k in idx for k in o))
+        win = list(range(max(0, len(self.kfs) - self.window), len(self.kfs)))            # Map::GetActiveKeyFrames
+        idx = set(win)
+        act = [m for m, o in self.obs.items() if any(k in idx for k in o)]               # Map::GetActiveMapPoints (container order is arbitrary)
+        rows = [(m, k) for m in act for k in sorted(self.obs[m]) if k in idx]            # MapPoint::GetActiveObservations, list order = insertion order
+        # the graph-build rules of backend.cpp:139-206 live behind the C ABI (myslam_ba_flatten_window): skip outliers, fix landmarks whose
+        # first observer left the window, vertices by id, edges grouped by landmark
+        fl = self.api.ba_flatten_window(win, act, np.zeros(len(act), np.uint8), [self.first_kf[m] for m in act],
+                                        [m for m, _ in rows], [k for _, k in rows], np.array([self.obs[m][k] for m, k in rows], np.float32).reshape(-1, 2),
+                                        np.zeros(len(rows), np.uint8))
+        win = [win[i] for i in fl["pose_src"]]; mps = [act[i] for i in fl["pt_src"]]
+        edge_ref = [rows[i] for i in fl["edge_src"]]; fixed = fl["fixed"]
         poses = np.stack([self.kfs[k]["pose"] for k in win])
         pts = np.stack([self.points[m] for m in mps])
-        ep, el, ob, edge_ref = [], [], [], []
-        for j, m in enumerate(mps):                                  # edges grouped by landmark
-            for k in sorted(self.obs[m]):
-                if k in idx:
-                    ep.append(idx[k]); el.append(j); ob.append(self.obs[m][k]); edge_ref.append((m, k))
-        fixed = np.array([0 if self.first_kf[m] in idx else 1 for m in mps], np.uint8)          # backend.cpp:175-177
-        p2, x2, chi, out, rounds, nout = self.be.ba(poses, pts, np.array(ep, np.int32), np.array(el, np.int32), np.array(ob), fixed, self.Kt)
+        p2, x2, chi, out, rounds, nout = self.be.ba(poses, pts, fl["edge_pose"], fl["edge_pt"], fl["edge_obs"], fixed, self.Kt)
         self.rec("ba", p2, x2, out, np.array([rounds, nout]), chi)
         if self.anchor_gauge:
             G = np.linalg.inv(T_of(poses[0])) @ T_of(p2[0])                   # world motion of the oldest key-frame: Twc_old * Tcw_new

@@ -366,7 +366,7 @@ def test_gauss_taps_option_matches_oracle(api, oracle, synth):
 def test_blur_saturates_like_ufixedpoint(api, oracle, synth):
     """The default sigma = 2 taps sum to 257 (OpenCV 3.4.8 rounds every tap on its own), so saturated image regions reach 257 before the
     u8 conversion: strip kernel (wide, aligned levels) and LDS kernel (narrow levels) both clamp like ufixedpoint32 -> uint8_t."""
-    for h, w in ((376, 1241), (120, 200)):
+    for h, w in ((376, 1241), (240, 320)):
         img = synth.random_image(5, h, w)
         img[20:90, 30:170] = 255; img[5:40, w - 60:] = 254; img[h - 30:, :80] = 255
         ext = api.ORBextractor(500)
