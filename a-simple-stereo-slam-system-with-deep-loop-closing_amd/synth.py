@@ -133,6 +133,61 @@ def calc_weights(seed=0xCA1C):
     return np.concatenate(parts)
 
 
+def _gauss2(n, sigma):
+    c = (n - 1) / 2
+    y, x = np.mgrid[0:n, 0:n]
+    g = np.exp(-((x - c) ** 2 + (y - c) ** 2) / (2 * sigma ** 2))
+    return g / g.sum()
+
+
+def calc_weights_handcrafted(c3_gain=6.0, c3_bias=0.05):
+    """A deterministic, NON-degenerate weight set of the CALC architecture, built by hand (the trained calc.caffemodel is a download the
+    build environment cannot make; N(0, 1/fan_in) weights give cosine scores of 0.99 between ANY two frames, so the loop rule of
+    src/loopclosing.cpp:124-161 can never be exercised with them).  CALC is trained to reproduce HOG-like appearance; this bank is the
+    classical hand-made analogue:
+      conv1 (64 @ 5x5 / 2): smoothed intensity and its complement at two scales (ON / OFF pathways), 16 signed gradient directions x 2
+                            scales, 7 ridge / valley orientations x 2 polarities x 2 scales;
+      conv2 (128 @ 4x4):    Gaussian pooling of every conv1 channel, and the same sharpened against its neighbours in the bank;
+      conv3 (4 @ 3x3):      centre-minus-surround of the pooled ON / OFF maps at cell scale (an 8 x 8 input-pixel cell per output), biased
+                            down so that the ReLU leaves a sparse blob map, plus a little oriented-energy so the whole bank matters.
+    The descriptor is a 14 x 19 x 4 map of bright / dark blob dominance: the same place seen again scores >= 0.97 against itself, a
+    key-frame 0.4 m to the side <= 0.85, unrelated places ~0.6 (tests/test_gpu_sequence.py measures it on the rendered sequence).
+    Same flat layout as calc_weights()."""
+    w1 = np.zeros((64, 1, 5, 5), np.float32); b1 = np.zeros(64, np.float32)
+    w1[0, 0] = _gauss2(5, 1.2); w1[1, 0] = -_gauss2(5, 1.2); b1[1] = 1.0          # input in [0, 1]: both pathways stay in [0, 1]
+    w1[2, 0] = _gauss2(5, 2.0); w1[3, 0] = -_gauss2(5, 2.0); b1[3] = 1.0
+    y, x = np.mgrid[-2:3, -2:3].astype(float)
+    k = 4
+    for sig in (0.9, 1.5):
+        g = np.exp(-(x * x + y * y) / (2 * sig * sig)); gx = -x * g; gy = -y * g; nrm = np.abs(gx).sum()
+        for d in range(16):
+            th = 2 * np.pi * d / 16
+            w1[k, 0] = 2 * (np.cos(th) * gx + np.sin(th) * gy) / nrm; k += 1
+    for sig in (1.0, 1.6):
+        for d in range(7):
+            th = np.pi * d / 7
+            u = x * np.cos(th) + y * np.sin(th); v = -x * np.sin(th) + y * np.cos(th)
+            f = (1 - u * u / (sig * sig)) * np.exp(-(u * u) / (2 * sig * sig) - (v * v) / (2 * (1.5 * sig) ** 2)); f -= f.mean(); f /= np.abs(f).sum()
+            w1[k, 0] = 2 * f; w1[k + 1, 0] = -2 * f; k += 2
+    assert k == 64
+    w2 = np.zeros((128, 64, 4, 4), np.float32); b2 = np.zeros(128, np.float32)
+    p4 = _gauss2(4, 1.2)
+    for c in range(64):
+        w2[c, c] = p4
+        w2[64 + c, c] = 1.5 * p4
+        for o in (c - 1, c + 1):
+            if 0 <= o < 64:
+                w2[64 + c, o] -= 0.5 * p4
+    w3 = np.zeros((4, 128, 3, 3), np.float32); b3 = np.full(4, -c3_bias, np.float32)
+    cs = -np.ones((3, 3)) / 8; cs[1, 1] = 1.0
+    for j in range(4):
+        w3[j, j] = c3_gain * cs
+    for d in range(16):
+        th = 2 * np.pi * d / 16
+        w3[0, 4 + d] += 0.05 * abs(np.cos(th)) * _gauss2(3, 1.0); w3[1, 4 + d] += 0.05 * abs(np.sin(th)) * _gauss2(3, 1.0)
+    return np.concatenate([w1.ravel(), b1, w2.ravel(), b2, w3.ravel(), b3]).astype(np.float32)
+
+
 def lcd_database(n, seed=0xDB, dim=1064):
     rng = _rng(seed)
     db = np.abs(rng.standard_normal(size=(n, dim))).astype(np.float32)

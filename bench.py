@@ -119,7 +119,7 @@ def parse():
                     help="rectangles of the synthetic scene (SURVEY.md §8(d): 6000 = the corner-dense BASELINE stream; 300 = a sparse stream "
                          "closer to real imagery, on which the two-phase FAST path pays most)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=200, help="upper bound of the frames the all-cores CPU baseline times (after its warm-up)")
+    ap.add_argument("--cpu-pairs", type=int, default=4, help="timed frames PER THREAD of the all-cores CPU baseline (after one warm-up frame per thread)")
     ap.add_argument("--no-extra-passes", action="store_true", help="skip the profiled, the solve-cadence and the streamed-input passes (timed region only)")
     ap.add_argument("--stream-input", type=int, default=4,
                     help="B > 0 (default 4): after the timed region, K more steps in which every step's images arrive over PCIe — B distinct batches "
@@ -175,15 +175,30 @@ def self_launch(n):
     sys.exit(rc)
 
 
-def cpu_baseline(synth, workload, max_pairs, db_np, gpu_frames, ba_w):
+def physical_cores():
+    """(hardware threads this process may run on, physical cores among them): SMT siblings counted once"""
+    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    cores = set()
+    for c in cpus:
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+        except OSError:
+            sib = str(c)
+        cores.add(sib)
+    return len(cpus), max(1, len(cores))
+
+
+def cpu_baseline(synth, workload, frames_per_thread, db_np, gpu_frames, ba_w):
     """The oracle (a plain C++ port of the reference arithmetic, oracle/) timed on this host over a bounded sample of the same frames
     and stages, SURVEY.md §8(d) protocol: (i) one thread — the reference runs every stage single-threaded inside its std::thread —
-    and (ii) frame-parallel over all host cores (std::thread pool, one frame per task, oracle/bench_oracle.cpp); warm-up frames first,
-    wall clock over the rest, per-stage medians.  Bounded to roughly 10-30 s of CPU work."""
+    and (ii) frame-parallel on every PHYSICAL core (std::thread pool, one frame per task, oracle/bench_oracle.cpp; SMT siblings add
+    nothing to this integer / f32 code): one warm-up frame per thread, then `frames_per_thread` (>= 4) timed frames per thread, the
+    GPU run's frames in a cycle; wall clock over the timed frames, per-stage medians, parallel efficiency = all-cores rate /
+    (threads x one-thread rate).  Bounded to roughly 10-30 s of CPU work."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from pyoracle import Oracle
     o = Oracle()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    hw_threads, cores = physical_cores()
     stages = {"orb_match": 1, "orb_match_lcd": 2, "full": 3, "full_solve": 4}[workload]
     ids = np.arange(len(db_np), dtype=np.uint64)
     args = (synth.KITTI00, synth.calc_weights(), db_np, ids, ba_w)
@@ -192,17 +207,17 @@ def cpu_baseline(synth, workload, max_pairs, db_np, gpu_frames, ba_w):
     n1 = min(len(gpu_frames), 12); w1 = min(2, n1 - 1)
     dt1, st1 = o.bench_frames(gpu_frames[:n1], *args, stages=stages, threads=1, n_warmup=w1)
     fps1 = (n1 - w1) / dt1
-    # (ii) all cores: 20 warm-up frames + as many frames as ~15 s of this host allow, at most max_pairs (200 on the GPU box's 256 threads)
-    wn = min(20, max(0, len(gpu_frames) - 2))
-    est = fps1 * min(cores, 64)
-    n = int(min(len(gpu_frames) - wn, max_pairs, max(min(2 * cores, 64), 15 * est)))
-    n = max(n, 2)
-    dt, st = o.bench_frames(gpu_frames[:wn + n], *args, stages=stages, threads=cores, n_warmup=wn)
+    # (ii) every physical core: 1 warm-up + frames_per_thread timed frames per thread
+    fpt = max(1, int(frames_per_thread))
+    wn, n = cores, cores * fpt
+    dt, st = o.bench_frames(gpu_frames, *args, stages=stages, threads=cores, n_warmup=wn, n_tasks=wn + n)
     med = lambda a, k0: {nm: float(np.median(a[k0:, i]) * 1e3) for i, nm in enumerate(names)}
-    return {"value": n / dt, "unit": "stereo frames/s", "cores": cores, "kind": "port", "value_1thread": fps1,
+    return {"value": n / dt, "unit": "stereo frames/s", "cores": cores, "hardware_threads": hw_threads, "kind": "port", "value_1thread": fps1,
+            "parallel_efficiency": (n / dt) / (cores * fps1),
             "stage_median_ms_1thread": med(st1, w1), "stage_median_ms_allcores": med(st, wn),
-            "sample": f"{n} of the GPU run's synthetic 1241x376 stereo pairs after {wn} warm-up frames, same stages, oracle frame-parallel on "
-                      f"{cores} host threads in {dt:.1f} s; single thread: {n1 - w1} pairs after {w1} warm-up in {dt1:.1f} s"}
+            "sample": f"{n} stereo pairs ({fpt} per thread, the GPU run's synthetic 1241x376 frames in a cycle) after {wn} warm-up frames, same stages, "
+                      f"oracle frame-parallel on {cores} threads (one per physical core of {hw_threads} hardware threads) in {dt:.1f} s; "
+                      f"single thread: {n1 - w1} pairs after {w1} warm-up in {dt1:.1f} s"}
 
 
 def main():

@@ -4,6 +4,8 @@
 // triangulation, CALC descriptor of the left image + loop-database scan, local-BA block build (and, optionally, the
 // OptimizeActiveMap solve stage).  Protocol of SURVEY.md §8(d): the first `n_warmup` frames are processed untimed, the wall
 // clock covers the remaining frames, per-stage medians are taken by the caller from `stage_seconds`.
+#include <malloc.h>
+
 #include <atomic>
 #include <chrono>
 #include <thread>
@@ -19,14 +21,20 @@ struct BaWindows {        // nwin windows with common capacities; frame i uses w
 inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }  // namespace
 
-extern "C" int orc_bench_frames(const uint8_t* frames /*n_pairs x 2 x rows x cols*/, int n_pairs, int rows, int cols, int nfeatures,
+// n_tasks frames are processed (task i uses stereo pair i % n_pairs), the first n_warmup of them untimed.
+extern "C" int orc_bench_frames(const uint8_t* frames /*n_pairs x 2 x rows x cols*/, int n_pairs, int n_tasks, int rows, int cols, int nfeatures,
                                 double fx, double fy, double cx, double cy, double baseline,
                                 const float* weights, size_t nweights, const float* db, const uint64_t* ids, int n_db,
                                 const double* ba_poses, const double* ba_points, const int32_t* ep, const int32_t* el, const double* obs,
                                 const uint8_t* fixed, const int32_t* ba_sizes /*nwin x 3*/, int nwin, int maxP, int maxL, int maxE,
                                 int stages /*1 orb+match+tri, 2 +lcd, 3 +ba build, 4 +ba solve*/, int threads, int n_warmup,
-                                double* seconds, double* stage_seconds /*n_pairs x 5 or NULL*/) {
-    if (!frames || n_pairs < 1 || threads < 1 || !seconds || n_warmup < 0 || n_warmup >= n_pairs) return -1;
+                                double* seconds, double* stage_seconds /*n_tasks x 5 or NULL*/) {
+    if (!frames || n_pairs < 1 || n_tasks < 1 || threads < 1 || !seconds || n_warmup < 0 || n_warmup >= n_tasks) return -1;
+    // every frame allocates a few MB of pyramid / blurred planes: above glibc's mmap threshold each of them is an mmap + page faults +
+    // munmap under the process-wide mm lock, which serialises a frame-parallel run (measured: 18x longer per frame on 256 threads).
+    // Keep those blocks in the per-thread arenas instead — a frame's planes are then reused by the thread's next frame.
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
     if (stages >= 3 && (nwin < 1 || !ba_sizes)) return -1;
     const BaWindows W{ba_poses, ba_points, ep, el, obs, fixed, ba_sizes, nwin, maxP, maxL, maxE};
     std::atomic<int> next{0}, fail{0};
@@ -46,7 +54,7 @@ extern "C" int orc_bench_frames(const uint8_t* frames /*n_pairs x 2 x rows x col
             const int i = next.fetch_add(1);
             if (i >= limit) break;
             double* st = stage_seconds ? stage_seconds + (size_t)i * 5 : nullptr;
-            const uint8_t* L = frames + (size_t)i * 2 * img; const uint8_t* R = L + img;
+            const uint8_t* L = frames + (size_t)(i % n_pairs) * 2 * img; const uint8_t* R = L + img;
             int nl = 0, nr = 0;
             double t0 = now_s();
             if (orc_detect_and_compute(&p, L, rows, cols, cols, nullptr, 0, kl.data(), dl.data(), cap, &nl) ||
@@ -96,7 +104,7 @@ extern "C" int orc_bench_frames(const uint8_t* frames /*n_pairs x 2 x rows x col
     };
     if (n_warmup > 0) run_pool(0, n_warmup);       // frames [0, n_warmup): untimed
     const auto t0 = std::chrono::steady_clock::now();
-    run_pool(n_warmup, n_pairs);                   // frames [n_warmup, n_pairs)
+    run_pool(n_warmup, n_tasks);                   // tasks [n_warmup, n_tasks)
     *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return fail.load() ? -2 : 0;
 }

@@ -344,11 +344,11 @@ class Oracle:
         assert rc == 0, rc
         return poses, points, chi, out, r.value, no.value
 
-    def bench_frames(self, frames, K, weights, db, ids, ba_windows, stages=3, threads=1, nfeatures=2000, n_warmup=0):
+    def bench_frames(self, frames, K, weights, db, ids, ba_windows, stages=3, threads=1, nfeatures=2000, n_warmup=0, n_tasks=None):
         """CPU-baseline driver (bench_oracle.cpp): frames [n,2,H,W] u8 through the whole per-frame pipeline on `threads` threads.
         ba_windows = (poses [nw,maxP,7], points [nw,maxL,3], ep [nw,maxE], el [nw,maxE], obs [nw,maxE,2], fixed [nw,maxL],
-        sizes [nw,3]); frame i uses window i % nw.  The first n_warmup frames run untimed.
-        Returns (wall seconds over the frames after the warm-up, per-frame stage seconds [n,5]: orb, match+tri, lcd+db, ba build, ba solve)."""
+        sizes [nw,3]); task i uses frame i % n and window i % nw; n_tasks (default n) tasks run, the first n_warmup of them untimed.
+        Returns (wall seconds over the tasks after the warm-up, per-task stage seconds [n_tasks,5]: orb, match+tri, lcd+db, ba build, ba solve)."""
         frames = np.ascontiguousarray(frames, np.uint8)
         n, _, H, W = frames.shape
         weights = np.ascontiguousarray(weights, np.float32); db = np.ascontiguousarray(db, np.float32)
@@ -360,8 +360,9 @@ class Oracle:
         sizes = np.ascontiguousarray(sizes, np.int32).reshape(-1, 3)
         nw, maxP, maxL, maxE = len(sizes), poses.shape[1], pts.shape[1], ep.shape[1]
         assert poses.shape == (nw, maxP, 7) and pts.shape == (nw, maxL, 3) and el.shape == (nw, maxE) and obs.shape == (nw, maxE, 2)
-        sec = C.c_double(); st = np.zeros((n, 5))
-        rc = self.lib.orc_bench_frames(_p(frames), n, H, W, nfeatures, C.c_double(K["fx"]), C.c_double(K["fy"]), C.c_double(K["cx"]),
+        n_tasks = n if n_tasks is None else int(n_tasks)
+        sec = C.c_double(); st = np.zeros((n_tasks, 5))
+        rc = self.lib.orc_bench_frames(_p(frames), n, n_tasks, H, W, nfeatures, C.c_double(K["fx"]), C.c_double(K["fy"]), C.c_double(K["cx"]),
                                        C.c_double(K["cy"]), C.c_double(K["bf"] / K["fx"]), _p(weights), C.c_size_t(weights.size),
                                        _p(db), _p(ids), len(ids), _p(poses), _p(pts), _p(ep), _p(el), _p(obs), _p(fixed), _p(sizes),
                                        nw, maxP, maxL, maxE, int(stages), int(threads), int(n_warmup), C.byref(sec), _p(st))

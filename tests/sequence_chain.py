@@ -164,12 +164,16 @@ class OracleBackend:
 
 # ---- the chain -----------------------------------------------------------------------------------------------------------------------
 class Chain:
-    def __init__(self, be, api, K, frames, kf_every=6, window=7, anchor_gauge=False):
+    def __init__(self, be, api, K, frames, kf_every=6, window=7, anchor_gauge=False, lcd_min_db=25, lcd_thr_high=0.94, lcd_thr_low=0.92):
         """frames: list of (left, right) uint8 images; api: the product's host helpers (pyramid expansion, match -> feature pairs).
         anchor_gauge: DIAGNOSTIC, not the reference's behaviour — after every local BA the window (poses + the landmarks it moved) is
         put back rigidly so that its oldest key-frame keeps the pose it had (the reference's graph fixes no pose, backend.cpp:139-150)"""
         self.be, self.api, self.K, self.frames = be, api, K, frames
         self.anchor_gauge = anchor_gauge
+        # the loop detector's configuration values (config/*.yaml: LCD.nDatabaseMinSize, LCD.similarityScoreThreshold.high / .low; the KITTI
+        # files say 50 / 0.94 / 0.92 — a 200-frame sequence makes 34 key-frames, so the gate is lowered, the thresholds are KITTI's)
+        self.lcd_min_db, self.lcd_thr_high, self.lcd_thr_low = lcd_min_db, lcd_thr_high, lcd_thr_low
+        self.detected = []          # (current key-frame index, loop key-frame index) pairs DetectLoop accepted
         self.Kt = (K["fx"], K["fy"], K["cx"], K["cy"])
         self.kf_every, self.window = kf_every, window
         self.log = []
@@ -274,6 +278,10 @@ class Chain:
         kf_id = len(self.kfs) - 1
         q = self.be.db_query(d, 3 * kf_id + 5)                       # key-frame ids spaced by 3: the `cur - id < 20` cut-off hides the last five
         self.rec("lcd", d, kf["pyr"], kf["desc"], np.array([q[0], q[2]]), np.array([q[1]]))
+        # LoopClosingRun (loopclosing.cpp:62-75): the detector runs once the database holds more than nDatabaseMinSize key-frames (the current
+        # key-frame is added afterwards, :78); DetectLoop's decision (:140-148): maxScore >= high and at most 3 scores above low
+        if kf_id > self.lcd_min_db and q[1] >= self.lcd_thr_high and q[2] <= 3:
+            self.detected.append((kf_id, int(q[0]) // 3))
         self.be.db_add(3 * kf_id, d)
 
     def run(self):
@@ -301,10 +309,12 @@ class Chain:
                 pose, px, mp = self.insert_keyframe(t, pose, px, mp, False)
                 last_pose = pose.copy()
             self.poses.append(pose.copy())
-        self.close_loop(len(self.kfs) - 1, 0)
+        # the loop-closing thread works asynchronously in the reference; here the loops DetectLoop accepted are closed after the last frame
+        for cur_i, loop_i in self.detected:
+            self.close_loop(cur_i, loop_i)
         return self
 
-    # the loop closer on a forced candidate: MatchFeatures, ComputeCorrectPose, OptimizeCurrentPose, PoseGraphOptimization
+    # the loop closer on a candidate DetectLoop accepted: MatchFeatures, ComputeCorrectPose, OptimizeCurrentPose, PoseGraphOptimization
     def close_loop(self, cur_i, loop_i):
         cur, loop = self.kfs[cur_i], self.kfs[loop_i]
         ti, dist = self.be.hamming(loop["desc"], cur["desc"])                                   # query = loop KF, train = current KF (:172)

@@ -30,7 +30,7 @@ def _ate(poses7, C, yaw, synth):
 
 def test_sequence_chain_hip_equals_oracle(api, oracle, synth, pkg):
     frames, C, yaw = _frames(synth, N_FRAMES)
-    w = synth.calc_weights()
+    w = synth.calc_weights_handcrafted()         # a non-degenerate CALC-shaped model: the loop must be DETECTED by the rule, not forced
     K = synth.SEQ_K
     a = sc.Chain(sc.HipBackend(api, w), pkg.api, K, frames).run()
     b = sc.Chain(sc.OracleBackend(oracle, w), pkg.api, K, frames).run()
@@ -56,14 +56,18 @@ def test_sequence_chain_hip_equals_oracle(api, oracle, synth, pkg):
                 assert np.allclose(u, v, rtol=1e-6, atol=1e-6), (ta, counts[ta], i, np.abs(u - v).max())
     assert counts["pose_only"] == N_FRAMES - 1 and counts["ba"] == len(a.kfs) - 1 and counts["lcd"] == len(a.kfs) and counts["local_fusion"] == 1
     assert a.n_loop_matches >= 10                                   # loopclosing.cpp:245: the loop is only closed with >= 10 3D-2D matches
-    # DetectLoop's ranking (the 0.94 / 0.92 score thresholds need the trained model; the ORDER does not): when the camera comes back
-    # to its starting place — half-way, 1.6 m closer to the wall, and at the end — the database scan returns key-frame 0, with
-    # a score above every query that looks at a new place
+    # DetectLoop by its own rule (src/loopclosing.cpp:124-161 + the database gate of :62): the only accepted candidate of the whole
+    # sequence is (last key-frame, key-frame 0) — the camera is back at its start — and it is what closed the loop above
+    assert a.detected == b.detected == [(len(a.kfs) - 1, 0)], (a.detected, b.detected)
     lcd = [x for t, x in a.log if t == "lcd"]
-    best = [int(x[3][0]) for x in lcd]; score = [float(x[4][0]) for x in lcd]
-    half = (len(lcd) - 1) // 2
-    assert best[-1] == 0 and best[half] == 0 and best[half + 1] == 0
-    assert score[-1] > max(score[half + 6:len(lcd) - 6])
+    best = [int(x[3][0]) for x in lcd]; cnt = [int(x[3][1]) for x in lcd]; score = [float(x[4][0]) for x in lcd]
+    assert best[-1] == 0 and score[-1] >= 0.97 and cnt[-1] <= 3                     # the revisit: far above the 0.94 threshold
+    gate = a.lcd_min_db
+    assert max(score[gate + 1:-1]) < 0.94                                           # no other key-frame behind the gate is accepted ...
+    assert any(0.92 < s_ < 0.94 for s_ in score[gate + 1:-1])                       # ... although some are "suspected" (> 0.92): both thresholds act
+    assert np.median(score[8:gate]) < 0.90                                          # unrelated places score low (N(0, 1/fan_in) weights: 0.99 everywhere)
+    # the scan's cut-off: the five youngest key-frames (ids spaced by 3, cur - id < 20) are never candidates, although they look most alike
+    assert all(b_ // 3 <= i - 5 for i, b_ in enumerate(best) if score[i] > 0)
     for pa, pb in zip(a.poses, b.poses):
         assert np.allclose(pa, pb, rtol=1e-6, atol=1e-6)
     rmse, worst = _ate(a.poses, C, yaw, synth)
@@ -82,7 +86,7 @@ def test_sequence_gauge_anchored(api, synth, pkg):
     local BA the window is moved back rigidly so that its oldest key-frame keeps its pose): the trajectory error that remains is the
     composition's own — centimetres on a 13 m track —, which is what says that the operators compose into a working tracker."""
     frames, C, yaw = _frames(synth, N_FRAMES)
-    a = sc.Chain(sc.HipBackend(api, synth.calc_weights()), pkg.api, synth.SEQ_K, frames, anchor_gauge=True).run()
+    a = sc.Chain(sc.HipBackend(api, synth.calc_weights_handcrafted()), pkg.api, synth.SEQ_K, frames, anchor_gauge=True).run()
     rmse, worst = _ate(a.poses, C, yaw, synth)
     print(f"sequence, gauge anchored: ATE rmse {rmse:.4f} m, worst {worst:.4f} m; {len(a.kfs)} key-frames, {a.n_loop_matches} loop matches")
     assert rmse < 0.12 and worst < 0.25 and a.n_loop_matches >= 10
