@@ -176,7 +176,8 @@ def self_launch(n):
 
 
 def physical_cores():
-    """(hardware threads this process may run on, physical cores among them): SMT siblings counted once"""
+    """(hardware threads this process may run on, physical cores among them — SMT siblings counted once —, CPU quota of the container's
+    cgroup in CPUs or None)"""
     cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
     cores = set()
     for c in cpus:
@@ -185,20 +186,36 @@ def physical_cores():
         except OSError:
             sib = str(c)
         cores.add(sib)
-    return len(cpus), max(1, len(cores))
+    n_cores = max(1, len(cores))
+    # a container's CPU-time quota (cgroup) can be far below its CPU affinity: threads beyond it only time-slice
+    quota = None
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else float(t.split()[0]) / float(t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: None if int(t) <= 0 else int(t) / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()))):
+        try:
+            quota = parse(open(path).read().strip())
+            break
+        except (OSError, ValueError, IndexError, ZeroDivisionError):
+            continue
+    return len(cpus), n_cores, quota
 
 
 def cpu_baseline(synth, workload, frames_per_thread, db_np, gpu_frames, ba_w):
     """The oracle (a plain C++ port of the reference arithmetic, oracle/) timed on this host over a bounded sample of the same frames
     and stages, SURVEY.md §8(d) protocol: (i) one thread — the reference runs every stage single-threaded inside its std::thread —
-    and (ii) frame-parallel on every PHYSICAL core (std::thread pool, one frame per task, oracle/bench_oracle.cpp; SMT siblings add
+    and (ii) frame-parallel on every PHYSICAL core the host really grants (affinity mask, cgroup quota and a measured spin test) (std::thread pool, one frame per task, oracle/bench_oracle.cpp; SMT siblings add
     nothing to this integer / f32 code): one warm-up frame per thread, then `frames_per_thread` (>= 4) timed frames per thread, the
     GPU run's frames in a cycle; wall clock over the timed frames, per-stage medians, parallel efficiency = all-cores rate /
     (threads x one-thread rate).  Bounded to roughly 10-30 s of CPU work."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from pyoracle import Oracle
     o = Oracle()
-    hw_threads, cores = physical_cores()
+    hw_threads, phys, quota = physical_cores()
+    cores = phys if not quota else max(1, min(phys, int(quota + 0.5)))          # threads the host will actually run at the same time
+    # ... as far as the container can see.  Measured: `cores` spinning threads against one (the GPU boxes of this pool show 256
+    # hardware threads and deliver about 12 CPUs' worth of time)
+    capacity = o.cpu_capacity(cores, 250)
+    if capacity < 0.75 * cores:
+        cores = max(1, int(capacity + 0.5))
     stages = {"orb_match": 1, "orb_match_lcd": 2, "full": 3, "full_solve": 4}[workload]
     ids = np.arange(len(db_np), dtype=np.uint64)
     args = (synth.KITTI00, synth.calc_weights(), db_np, ids, ba_w)
@@ -212,11 +229,13 @@ def cpu_baseline(synth, workload, frames_per_thread, db_np, gpu_frames, ba_w):
     wn, n = cores, cores * fpt
     dt, st = o.bench_frames(gpu_frames, *args, stages=stages, threads=cores, n_warmup=wn, n_tasks=wn + n)
     med = lambda a, k0: {nm: float(np.median(a[k0:, i]) * 1e3) for i, nm in enumerate(names)}
-    return {"value": n / dt, "unit": "stereo frames/s", "cores": cores, "hardware_threads": hw_threads, "kind": "port", "value_1thread": fps1,
+    return {"value": n / dt, "unit": "stereo frames/s", "cores": cores, "hardware_threads": hw_threads, "physical_cores": phys,
+            "cgroup_cpu_quota": quota, "measured_concurrent_threads": capacity, "kind": "port", "value_1thread": fps1,
             "parallel_efficiency": (n / dt) / (cores * fps1),
             "stage_median_ms_1thread": med(st1, w1), "stage_median_ms_allcores": med(st, wn),
             "sample": f"{n} stereo pairs ({fpt} per thread, the GPU run's synthetic 1241x376 frames in a cycle) after {wn} warm-up frames, same stages, "
-                      f"oracle frame-parallel on {cores} threads (one per physical core of {hw_threads} hardware threads) in {dt:.1f} s; "
+                      f"oracle frame-parallel on {cores} threads ({phys} physical cores / {hw_threads} hardware threads visible, cgroup CPU quota "
+                      f"{'none' if not quota else round(quota, 1)}) in {dt:.1f} s; "
                       f"single thread: {n1 - w1} pairs after {w1} warm-up in {dt1:.1f} s"}
 
 

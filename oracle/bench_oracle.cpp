@@ -108,3 +108,25 @@ extern "C" int orc_bench_frames(const uint8_t* frames /*n_pairs x 2 x rows x col
     *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return fail.load() ? -2 : 0;
 }
+
+// How many threads does this host really run at the same time?  Containers often see every CPU of the machine in their affinity mask
+// while a CPU-time quota (or the neighbours) grants them a fraction: `threads` workers each do the same fixed amount of register-only
+// integer work; the result is threads x (one worker's time alone) / (wall time of all of them together).
+extern "C" double orc_cpu_capacity(int threads, int work_ms) {
+    if (threads < 1) return 0;
+    auto spin = [](uint64_t iters) { uint64_t x = 88172645463325252ull; for (uint64_t i = 0; i < iters; i++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; } return x; };
+    // calibrate: iterations for ~work_ms on one thread
+    uint64_t iters = 1 << 22; double t1 = 0; volatile uint64_t sink = 0;
+    for (int rep = 0; rep < 8; rep++) {
+        const double t0 = now_s(); sink = sink + spin(iters); t1 = now_s() - t0;
+        if (t1 * 1e3 >= 0.5 * work_ms) break;
+        iters *= 2;
+    }
+    const double t0 = now_s();
+    std::vector<std::thread> pool;
+    std::atomic<uint64_t> acc{0};
+    for (int t = 0; t < threads; t++) pool.emplace_back([&]() { acc += spin(iters); });
+    for (auto& th : pool) th.join();
+    const double tw = now_s() - t0;
+    return tw > 0 ? threads * t1 / tw : 0;
+}

@@ -369,6 +369,11 @@ class Oracle:
         assert rc == 0, rc
         return sec.value, st
 
+    def cpu_capacity(self, threads, work_ms=60):
+        """threads the host really runs concurrently (affinity masks overstate it under a CPU quota): bench_oracle.cpp"""
+        self.lib.orc_cpu_capacity.restype = C.c_double
+        return float(self.lib.orc_cpu_capacity(int(threads), int(work_ms)))
+
     def pose_only_optimize(self, pose, pts3d, obs, K, chi2_th=5.991, rounds=4, iters=10, pre_optimize=0):
         pose = np.ascontiguousarray(pose, np.float64).copy(); pts3d = np.ascontiguousarray(pts3d, np.float64); obs = np.ascontiguousarray(obs, np.float64)
         n = len(pts3d); out = np.zeros(max(n, 1), np.uint8); ni = C.c_int()
