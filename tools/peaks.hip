@@ -274,6 +274,25 @@ __global__ __launch_bounds__(256) void k_mfma_f64(double* out, int iters) {
     if (s == 1.2345) out[0] = s;
 }
 
+// dependent accumulate chains: NACC accumulators, RUN back-to-back MFMAs on one accumulator before moving to the next (what a GEMM
+// inner loop that finishes one output tile's K step before the next tile's looks like)
+template <int NACC, int RUN>
+__global__ __launch_bounds__(256) void k_mfma_chain(float* out, int iters) {
+    bf16x8 a, b;
+    for (int i = 0; i < 8; i++) { a[i] = (__bf16)(float)(threadIdx.x + i); b[i] = (__bf16)(float)(i + 1); }
+    f32x16 c[NACC];
+    for (int k = 0; k < NACC; k++) for (int i = 0; i < 16; i++) c[k][i] = 0;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int k = 0; k < NACC; k++)
+#pragma unroll
+            for (int r = 0; r < RUN; r++) c[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c[k], 0, 0, 0);
+    }
+    float s = 0;
+    for (int k = 0; k < NACC; k++) for (int i = 0; i < 16; i++) s += c[k][i];
+    if (s == 1.2345f) out[0] = s;
+}
+
 template <class F>
 static double time_launch(F launch) {
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -425,6 +444,13 @@ int main(int argc, char** argv) {
             t = time_launch([&] { hipLaunchKernelGGL(k_mfma_f64, dim3(grid), dim3(256), 0, 0, (double*)d_out, iters); });
             m[nm++] = {"mfma_f64_16x16x4_f64", 2.0 * 16 * 16 * 4, t, w};
         }
+        // dependent chains (bf16 32x32x16): accumulators per wave x back-to-back run length x waves per SIMD
+        std::string chain = " \"mfma_bf16_dependent_chains\": {\"unit\": \"TFLOP/s\", \"note\": \"NACC accumulators per wave, RUN back-to-back MFMAs on one accumulator before the next\"";
+#define CHAIN(NACC, RUN) for (int w : {1, 2, 4}) { \
+            double t = time_launch([&] { hipLaunchKernelGGL((k_mfma_chain<NACC, RUN>), dim3(256 * w), dim3(256), 0, 0, (float*)d_out, iters / RUN); }); \
+            char buf[160]; snprintf(buf, sizeof buf, ", \"nacc%d_run%d@%dwave_per_simd\": %.1f", NACC, RUN, w, 2.0 * 32 * 32 * 16 * NACC * RUN * (iters / RUN) * (256.0 * w * 4) / (t * 1e-3) / 1e12); chain += buf; }
+        CHAIN(1, 1) CHAIN(2, 1) CHAIN(2, 6) CHAIN(4, 1) CHAIN(4, 6) CHAIN(8, 1)
+        printf("%s},\n", chain.c_str());
         printf(" \"mfma\": {\"unit\": \"T(FL)OP/s dense\", \"spec\": {\"bf16\": 2500.0, \"i8\": 5000.0, \"fp4\": 10000.0, \"f64\": 78.6}, \"instructions\": {\n");
         for (int i = 0; i < nm; i++) {
             double total = m[i].flop * 4.0 * iters * (256.0 * m[i].w * 4);
