@@ -14,8 +14,7 @@ OUT = os.path.join(HERE, "libmyslam_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
-COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"] + \
-    os.environ.get("MYSLAM_HIPCC_EXTRA", "").split()          # build-time only (kernel experiments: -DCV2_MODE=...); the library reads no environment
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 # float-derived integers (BRIEF coordinates, fastAtan2, resize tables) must not see FMA contraction
 EXACT = ["-ffp-contract=off"]
 UNITS = {

@@ -131,10 +131,10 @@ __global__ __launch_bounds__(256) void k_ba_build(BaArgs a) {
     for (int k = t; k < E; k += 256) {
         const int il = el[k];
         if (il >= 0 && il < L && (k == 0 || el[k - 1] != il)) {
-            atomicAdd(&s_runs[il], 1);
+            const int earlier = atomicAdd(&s_runs[il], 1);
             int n = 1;
             while (k + n < E && el[k + n] == il) n++;
-            s_start[il] = k; s_len[il] = n;                     // (several runs: any of them; such a landmark does not use these)
+            if (earlier == 0) { s_start[il] = k; s_len[il] = n; }      // one writer per landmark (a landmark with several runs does not use these)
         }
     }
     __syncthreads();
@@ -865,8 +865,9 @@ static int ba_opt_launch(const BaOptArgs& a, int nwin, hipStream_t s) {
         if (((size_t)a.maxE + 1) / 2 + 8 + 22 * (size_t)a.maxL + 2 > (size_t)a.maxE * 18 || lds > 160 * 1024 - 512) return MYSLAM_ERR_CAPACITY;
     }
     const void* fn = gl ? reinterpret_cast<const void*>(k_ba_optimize<true>) : reinterpret_cast<const void*>(k_ba_optimize<false>);
-    // the attribute is per device and per process: set it on every launch that needs it (cheap, re-entrant, multi-GPU safe)
-    if (lds > 48 * 1024) MYSLAM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // the limit belongs to the function (per device and process), not to a launch: always the device's whole LDS minus the kernel's static
+    // part, so that concurrent callers with windows of different sizes cannot lower it under each other's launches
+    MYSLAM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
     ScopedProf sp(P_BA, s);
     if (gl) hipLaunchKernelGGL(k_ba_optimize<true>, dim3(nwin), dim3(BA_NT), lds, s, a);
     else hipLaunchKernelGGL(k_ba_optimize<false>, dim3(nwin), dim3(BA_NT), lds, s, a);

@@ -202,8 +202,7 @@ __global__ __launch_bounds__(256) void k_pool_lrn128_2x2(const float* __restrict
 // Caffe's clipped ceil-mode windows, LRN over channels c-2 .. c+2 (zero padded) across lane shuffles.
 constexpr int HT1 = (HP1 + 1) / 2, WT1 = (WP1 + 1) / 2;           // 2 x 2 tiles of the pooled map
 __global__ __launch_bounds__(256) void k_conv1_pool_lrn2(const float* __restrict__ in, const float* __restrict__ w1t /*[25][64]*/,
-                                                         const float* __restrict__ b1, int relu, LrnP lp,
-                                                         uint16_t* __restrict__ out3 /*[B][3 pieces][HP1*WP1][64] bf16: v = h + m + l exactly*/) {
+                                                         const float* __restrict__ b1, int relu, LrnP lp, float* __restrict__ out /*[HP1*WP1][64]*/) {
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int tile = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
@@ -264,15 +263,7 @@ __global__ __launch_bounds__(256) void k_conv1_pool_lrn2(const float* __restrict
         const float v0 = lane >= 2 ? um2 : 0.f, v1 = lane >= 1 ? um1 : 0.f, v3 = lane <= 62 ? dp1 : 0.f, v4 = lane <= 61 ? dp2 : 0.f;
         float ss = 0.f;
         ss += v0 * v0; ss += v1 * v1; ss += m * m; ss += v3 * v3; ss += v4 * v4;
-        // conv2 multiplies on the bf16 matrix cores with f32 accuracy: its operand is split HERE, once per element, into three bf16
-        // pieces (round-to-nearest conversions, exact residuals: h + m + l == v bit for bit) instead of once per tap inside conv2
-        const float v = m * lrn_factor(ss, lp);
-        const __bf16 h = (__bf16)v; const float r = v - (float)h;
-        const __bf16 mm = (__bf16)r; const float q = r - (float)mm;
-        const __bf16 l = (__bf16)q;
-        uint16_t* o = out3 + ((size_t)b * 3 * HP1 * WP1 + py * WP1 + px) * 64 + lane;
-        o[0] = __builtin_bit_cast(uint16_t, h); o[(size_t)HP1 * WP1 * 64] = __builtin_bit_cast(uint16_t, mm);
-        o[(size_t)2 * HP1 * WP1 * 64] = __builtin_bit_cast(uint16_t, l);
+        out[((size_t)b * HP1 * WP1 + py * WP1 + px) * 64 + lane] = m * lrn_factor(ss, lp);
     };
     lrn_store(m00, oy, ox);
     if (col1) lrn_store(m01, oy, ox + 1);
@@ -295,203 +286,131 @@ constexpr int CV_BN = 128;
 
 // ---- conv2 + ReLU as an implicit GEMM on the bf16 matrix cores with fp32 accuracy ----
 // C[M = batch*1344][N = 128] = A[M][K = 1024] * Wt[K][N];  k = (ky*4+kx)*64 + ic  (channel runs contiguous in NHWC).
-// An fp32-input MFMA (v_mfma_f32_32x32x2_f32) runs at the f32 VECTOR rate; the bf16 matrix pipe is 16x faster and separate.  Every f32
-// operand is split exactly into three bf16 pieces a = h + m + l (8 + 8 + 8 significand bits, round-to-nearest conversions, exact
-// residuals); of the nine partial products the six largest are kept:
+// An fp32-input MFMA (v_mfma_f32_32x32x2_f32) runs at the f32 VECTOR rate — in practice it competes with the VALU-bound ORB kernels of
+// the other stream instead of running under them (measured: 1.48 against 0.93 ms per 512 frames, no gain from co-residency,
+// DESIGN.md section 4).  The bf16 matrix pipe is 16x faster and separate.  Every f32 operand is split exactly into three bf16 pieces a = h + m + l (8 + 8 + 8 significand bits,
+// round-to-nearest conversions, exact residuals); of the nine partial products the six largest are kept:
 //     a b  ~  hh + hm + mh + hl + lh + mm        (dropped: ml, lm, ll <= 2^-23 |a b|, the rounding level of an f32 product)
-// accumulated in f32 by v_mfma_f32_32x32x16_bf16.  Weights are split once on the host, activations once by their producer
-// (k_conv1_pool_lrn2 writes three bf16 planes).
-//
-// Round 3 structure (round 2: a 128 x 128 tile whose A slab was re-fetched, re-split and re-written to LDS for each of the 16 taps —
-// 7 GB through L1 per launch, staging and MFMA halves of a K step barely overlapping: 0.93 ms per 512 frames against 0.43 ms of MFMA):
-//   * a block owns THREE OUTPUT ROWS of one image (126 pixels = four 32-row MFMA tiles) and keeps the input patch those rows see —
-//     6 rows x 45 columns (2 zero columns either side) x 64 channels x 3 pieces, 102 KB — resident in LDS for the whole K loop: every
-//     tap's A operand is an LDS read at a fixed offset from the lane's pixel (im2col by address arithmetic, nothing is re-staged);
-//   * the patch and the weight slabs arrive by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write, no VALU); pixels
-//     outside the image are DMA'd from a block of zeros;
-//   * pixel pitch 128 bytes with the eight 16-byte chunks of a pixel XOR-swizzled by the pixel index: bank-conflict-free ds_read_b128;
-//   * 8 waves: wave (mi, nh) owns the 32 x 64 output block (rows 32 mi.., channels 64 nh..): 9 ds_read_b128 feed 12 MFMAs per K
-//     step of 16; the weight slabs travel through a ring of four 12 KB buffers, three K steps ahead of the multiplication (an LDS-DMA
-//     takes about a microsecond to land, a K step 0.3 us), with hand-counted s_waitcnt vmcnt and one barrier per step.
+// accumulated in f32 by v_mfma_f32_32x32x16_bf16.  Weights are split once on the host ([stage][piece][n][16 k], so a stage's slab
+// is one contiguous 12 KB block); activations are split while they are staged into LDS (11 VALU per pair of elements).
+// Block tile 128 x 128, 4 waves x (2 x 2) tiles, BK = 16 = one MFMA K: 24 MFMAs of 32 cycles per wave and stage against
+// 32 x 64 cycles for the f32 form.
 typedef __bf16 cv_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __attribute__((address_space(3))) void* cv_lds_ptr;
-typedef const __attribute__((address_space(1))) void* cv_glb_ptr;
 
-constexpr int P2_ROWS = 3;                                   // output rows per block
-constexpr int P2_NT = (H2 + P2_ROWS - 1) / P2_ROWS;          // 11 row groups per image (the last one holds 2 rows)
-constexpr int P2_PW = WP1 + 4, P2_PH = P2_ROWS + 3;          // patch: 45 x 6 pixels
-constexpr int P2_PIX = P2_PW * P2_PH;                        // 270
-constexpr int P2_PITCH = 128;                                // bytes per patch pixel and piece: 8 chunks of 16 bytes, XOR-swizzled (below)
-constexpr int P2_PIECE = (P2_PIX * P2_PITCH + 1023) / 1024 * 1024;      // 34 816: whole 1 KB DMA instructions
-constexpr int P2_CHUNKS = P2_PIECE / 1024;                   // 34 per piece
-constexpr int P2_BSLAB = 3 * 2 * 128 * 16;                   // 12 288: [piece][k half][n] x 8 bf16
-constexpr int P2_NBUF = 4;                                   // weight slabs: one being multiplied, three in flight
-constexpr int P2_LDS = 3 * P2_PIECE + P2_NBUF * P2_BSLAB;    // 153 600 bytes
-constexpr int P2_T = 512;
-#ifndef CV2_MODE
-#define CV2_MODE 0           // kernel-timing experiments (tools/conv2_time.sh): 1 no MFMAs, 2 no operand reads, 3 no waits / barriers, 4 no slab DMA
-#endif
-
-// LDS-DMA: 16 bytes per lane from the lane's own global address to lds_dst + 16 lane (lds_dst wave-uniform).  Inline assembly so that
-// the compiler's wait-count bookkeeping does not see it: hipcc drains every outstanding DMA (vmcnt(0)) in front of a barrier or of an
-// LDS read it cannot tell apart from the DMA's target, which would serialise the ring below; the waits are counted by hand instead.
-__device__ __forceinline__ void cv_dma16(const void* gsrc, uint32_t lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+__device__ __forceinline__ void cv_split3(float a0, float a1, uint32_t& h, uint32_t& m, uint32_t& l) {    // two elements per dword, a0 low
+    const __bf16 h0 = (__bf16)a0, h1 = (__bf16)a1;
+    const float r0 = a0 - (float)h0, r1 = a1 - (float)h1;
+    const __bf16 m0 = (__bf16)r0, m1 = (__bf16)r1;
+    const float q0 = r0 - (float)m0, q1 = r1 - (float)m1;
+    const __bf16 l0 = (__bf16)q0, l1 = (__bf16)q1;
+    h = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
+    m = (uint32_t)__builtin_bit_cast(unsigned short, m0) | ((uint32_t)__builtin_bit_cast(unsigned short, m1) << 16);
+    l = (uint32_t)__builtin_bit_cast(unsigned short, l0) | ((uint32_t)__builtin_bit_cast(unsigned short, l1) << 16);
 }
 
-__global__ __launch_bounds__(P2_T) void k_conv2_patch_bf16x6(const uint16_t* __restrict__ in3 /*[B][3][31*41][64] bf16*/,
-                                                             const uint4* __restrict__ wt3 /*[64 stages][3][128 n][2 k-halves] x 8 bf16*/,
-                                                             const float* __restrict__ b2, float* __restrict__ out /*[B*1344][128]*/,
-                                                             const uint4* __restrict__ zeros /*>= 16 zero bytes*/, int relu) {
-    extern __shared__ __attribute__((aligned(1024))) uint8_t s_mem[];
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)s_mem;      // LDS byte address of the block's window
-    const uint32_t lds_b = lds0 + 3 * P2_PIECE;
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int img = blockIdx.y, oy0 = blockIdx.x * P2_ROWS;
-    const int nrows = min(P2_ROWS, H2 - oy0);
+__global__ __launch_bounds__(256) void k_conv2_bf16x6(const float* __restrict__ in /*[B][31*41][64]*/,
+                                                      const uint4* __restrict__ wt3 /*[64 stages][3][128 n][2 k-halves] x 8 bf16*/,
+                                                      const float* __restrict__ b2, float* __restrict__ out /*[B*1344][128]*/, int Mtotal, int relu) {
+    constexpr int BM = 128, BN = 128;
+    // [piece][k half][row]: 8 bf16 per uint4.  K-half major, the second half shifted by 128 bytes: the 16 lanes a ds_read_b128 / ds_write_b128
+    // serves per cycle then touch 64 distinct banks (row-major [row][k half] put lanes i and i + 8 on the same banks); the waves' LDS wait
+    // fell by a third (PMC SQ_WAIT_INST_LDS 19.9 M -> 13.2 M per 64 frames), the kernel by 1-2 %
+    constexpr int KH = BM + 8;
+    __shared__ uint4 s_a[2][3][2 * KH];
+    __shared__ uint4 s_b[2][3][2 * KH];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int m0 = blockIdx.x * BM;
+    const int am = t >> 1, akh = t & 1;                // staging role: row m, k half (8 consecutive k)
+    const int gm = m0 + am;
+    const bool mvalid = gm < Mtotal;
+    const int img = mvalid ? gm / M2 : 0;
+    const int pix = mvalid ? gm - img * M2 : 0;
+    const int oy = pix / W2, ox = pix - oy * W2;
+    const float* inb = in + (size_t)img * HP1 * WP1 * 64;
 
-    // ---- the input patch: rows oy0 - 2 .. oy0 + 3, columns -2 .. 42 of the three planes.  Pixel pitch 128 bytes; the 16-byte chunk q
-    // (8 channels) of pixel `pix` sits in slot q ^ ((pix >> 1) & 7): the 16 lanes a ds_read_b128 serves per cycle hold 16 pixels that are
-    // distinct mod 16 and ask for the same q, so (pix & 1, slot) — the 64-bank position — is different for each of them.  The DMA
-    // writes LDS linearly, so the swizzle goes into the SOURCE address (cdna_hip_programming.md rule 21).
-    for (int id = wave; id < 3 * P2_CHUNKS; id += P2_T / 64) {
-        const int p = id / P2_CHUNKS, ch = id - p * P2_CHUNKS;
-        const int off = ch * 1024 + lane * 16;
-        const int pix = off >> 7, slot = (off >> 4) & 7, q = slot ^ ((pix >> 1) & 7);
-        const int pr = pix / P2_PW, pc = pix - pr * P2_PW;
-        const int iy = oy0 - 2 + pr, ix = pc - 2;
-        const bool inside = pix < P2_PIX && iy >= 0 && iy < HP1 && ix >= 0 && ix < WP1;
-        const void* src = inside ? (const void*)(in3 + (((size_t)img * 3 + p) * HP1 * WP1 + iy * WP1 + ix) * 64 + q * 8) : (const void*)zeros;
-        cv_dma16(src, lds0 + p * P2_PIECE + ch * 1024);
+    // the prefetched slab of the next stage lives in registers across the MFMA block: unconditional loads from a clamped address
+    // plus a select at store time (a branch here sends the values through scratch and waits for the loads on the spot)
+    float4 ra0 = make_float4(0, 0, 0, 0), ra1 = ra0;
+    uint4 rb0 = make_uint4(0, 0, 0, 0), rb1 = rb0, rb2 = rb0;
+    bool rav = false;
+#define CV2_LOAD_STAGE(S)                                                                                                     \
+    {                                                                                                                         \
+        const int tap_ = (S) >> 2, ic0_ = ((S) & 3) * 16;                                                                     \
+        const int iy_ = oy + (tap_ >> 2) - 2, ix_ = ox + (tap_ & 3) - 2;                                                      \
+        rav = mvalid && iy_ >= 0 && iy_ < HP1 && ix_ >= 0 && ix_ < WP1;                                                       \
+        const float4* src_ = reinterpret_cast<const float4*>(inb + (rav ? ((size_t)iy_ * WP1 + ix_) * 64 : 0) + ic0_ + akh * 8); \
+        ra0 = src_[0]; ra1 = src_[1];                                                                                         \
+        const uint4* wsrc_ = wt3 + (size_t)(S) * (3 * BN * 2) + t;                                                            \
+        rb0 = wsrc_[0]; rb1 = wsrc_[BN * 2]; rb2 = wsrc_[2 * BN * 2];                                                         \
     }
-    const int nper = wave < 4 ? 2 : 1;                         // DMA instructions this wave issues per weight slab
-    auto load_slab = [&](int s, int buf) {                     // 12 DMA instructions of 1 KB: (piece, k half, n half)
-        for (int c = wave; c < 12; c += P2_T / 64) {
-            const int piece = c >> 2, kh = (c >> 1) & 1, nh = c & 1;
-            cv_dma16(wt3 + (((size_t)s * 3 + piece) * 128 + nh * 64 + lane) * 2 + kh, lds_b + buf * P2_BSLAB + ((piece * 2 + kh) * 128 + nh * 64) * 16);
-        }
+    auto store_stage = [&](int buf) {
+        const float z = rav ? 1.f : 0.f;
+        uint4 h, m, l;
+        cv_split3(ra0.x * z, ra0.y * z, h.x, m.x, l.x); cv_split3(ra0.z * z, ra0.w * z, h.y, m.y, l.y);
+        cv_split3(ra1.x * z, ra1.y * z, h.z, m.z, l.z); cv_split3(ra1.z * z, ra1.w * z, h.w, m.w, l.w);
+        const int si = akh * KH + am;                                     // (row, k half) of this thread's slab piece
+        s_a[buf][0][si] = h; s_a[buf][1][si] = m; s_a[buf][2][si] = l;
+        s_b[buf][0][si] = rb0; s_b[buf][1][si] = rb1; s_b[buf][2][si] = rb2;
     };
-    load_slab(0, 0); load_slab(1, 1); load_slab(2, 2);
 
-    const int mi = wave >> 1, nh = wave & 1;
-    const int lr = lane & 31, lk = lane >> 5;
-    // this lane's output pixel (row of the A operand): its patch pixel at tap (0, 0)
-    const int mloc = min(32 * mi + lr, nrows * W2 - 1);                                  // rows past the block's pixels repeat its last one (never stored)
-    const int r0 = mloc / W2, c0 = mloc - r0 * W2;
-    const int pix0 = r0 * P2_PW + c0;
-    const uint8_t* const b_base = s_mem + 3 * P2_PIECE + (lk * 128 + nh * 64 + lr) * 16;
-
-    f32x16 acc[2];
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
-    // Operands travel LDS -> registers one K step AHEAD of the MFMAs that use them (two register sets): a step's nine ds_read_b128 are in
-    // flight while the previous step multiplies, so no MFMA waits on LDS latency (measured before this: 4 exposed LDS waits per step,
-    // the matrix pipe 43 % busy).
-    cv_bf16x8 A[2][3], Bm[2][2][3];
-    auto read_ops = [&](int set, int sn) {                     // operands of K step sn (tap sn / 4, channels 16 (sn % 4) ..) into register set `set`
-        const int tp = sn >> 2, iq = sn & 3;
-        const int pix = pix0 + (tp >> 2) * P2_PW + (tp & 3);
-        const uint8_t* const ap = s_mem + pix * P2_PITCH + (((2 * iq + lk) ^ ((pix >> 1) & 7)) << 4);
-#pragma unroll
-        for (int p = 0; p < 3; p++) A[set][p] = *reinterpret_cast<const cv_bf16x8*>(ap + p * P2_PIECE);
+    for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int p = 0; p < 3; p++) Bm[set][j][p] = *reinterpret_cast<const cv_bf16x8*>(b_base + (sn & 3) * P2_BSLAB + (p * 2 * 128 + j * 32) * 16);
-    };
-    // the patch and slab 0 have landed once at most the DMAs of slabs 1 and 2 are outstanding; the barrier publishes them
-    if (nper == 2) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
-    read_ops(0, 0);
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
+    CV2_LOAD_STAGE(0)
+    store_stage(0);
+    __syncthreads();
     constexpr int NSTAGE = K2 / 16;
-#pragma unroll 1
-    for (int tap = 0; tap < 16; tap++) {
+    const int lr = lane & 31, lk = lane >> 5;
+    for (int s = 0; s < NSTAGE; s++) {
+        const int buf = s & 1;
+        if (s + 1 < NSTAGE) CV2_LOAD_STAGE(s + 1)
+        cv_bf16x8 A[2][3], Bm[2][3];
 #pragma unroll
-        for (int icq = 0; icq < 4; icq++) {
-            const int s = tap * 4 + icq;
-            constexpr int dummy = 0; (void)dummy;
-            // slab s + 1 must have landed before its operands are read below (slab s + 2 may stay in flight); the barrier publishes it and
-            // says that every wave is done with K step s - 1, i.e. with its reads of slab s - 1 — whose buffer the next DMA overwrites
-#if CV2_MODE != 3
-            if (tap < 15) {
-                if (nper == 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            }
-#endif
-            // Issue order of a K step, pinned with sched_barrier: the operands of THIS step are already in registers, so the first MFMAs
-            // go out right behind the barrier and the matrix pipe works while this wave issues the DMA (60-180 cycles apiece) and the
-            // next step's LDS reads; left to itself the compiler puts DMA + reads first and the pipe idles behind every barrier
-            const int cur = icq & 1, nxt = cur ^ 1;              // static after unrolling
-            const bool more = tap < 15 || icq < 3;
-            const int sn = s + 1, tp = sn >> 2, iq = sn & 3;
-            const int pixn = pix0 + (tp >> 2) * P2_PW + (tp & 3);
-            const uint8_t* const ap = s_mem + pixn * P2_PITCH + (((2 * iq + lk) ^ ((pixn >> 1) & 7)) << 4);
-            const uint8_t* const bp = b_base + iq * P2_BSLAB;
-#define CV2_MF(j, pa, pb) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cur][pa], Bm[cur][j][pb], acc[j], 0, 0, 0)
-            CV2_MF(0, 2, 0); CV2_MF(1, 2, 0);                                                      // l h
-            __builtin_amdgcn_sched_barrier(0);
-#if CV2_MODE != 4
-            if (tap < 15 || icq == 0) load_slab(s + 3, (icq + 3) & 3);                   // slab s + 3 into the buffer of slab s - 1
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            CV2_MF(0, 0, 2); CV2_MF(1, 0, 2);                                                      // h l
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) {
+        for (int i = 0; i < 2; i++)
 #pragma unroll
-                for (int p = 0; p < 3; p++) A[nxt][p] = *reinterpret_cast<const cv_bf16x8*>(ap + p * P2_PIECE);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            CV2_MF(0, 1, 1); CV2_MF(1, 1, 1);                                                      // m m
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) {
+            for (int p = 0; p < 3; p++) A[i][p] = __builtin_bit_cast(cv_bf16x8, s_a[buf][p][lk * KH + wm + 32 * i + lr]);
 #pragma unroll
-                for (int p = 0; p < 3; p++) Bm[nxt][0][p] = *reinterpret_cast<const cv_bf16x8*>(bp + (p * 2 * 128) * 16);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            CV2_MF(0, 1, 0); CV2_MF(1, 1, 0);                                                      // m h
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) {
+        for (int j = 0; j < 2; j++)
 #pragma unroll
-                for (int p = 0; p < 3; p++) Bm[nxt][1][p] = *reinterpret_cast<const cv_bf16x8*>(bp + (p * 2 * 128 + 32) * 16);
+            for (int p = 0; p < 3; p++) Bm[j][p] = __builtin_bit_cast(cv_bf16x8, s_b[buf][p][lk * KH + wn + 32 * j + lr]);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][2], Bm[j][0], c, 0, 0, 0);       // l h
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], Bm[j][2], c, 0, 0, 0);       // h l
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][1], Bm[j][1], c, 0, 0, 0);       // m m
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][1], Bm[j][0], c, 0, 0, 0);       // m h
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], Bm[j][1], c, 0, 0, 0);       // h m
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][0], Bm[j][0], c, 0, 0, 0);       // h h
+                acc[i][j] = c;
             }
-            __builtin_amdgcn_sched_barrier(0);
-            CV2_MF(0, 0, 1); CV2_MF(1, 0, 1);                                                      // h m
-            CV2_MF(0, 0, 0); CV2_MF(1, 0, 0);                                                      // h h
-            __builtin_amdgcn_sched_barrier(0);
-#undef CV2_MF
-        }
+        if (s + 1 < NSTAGE) store_stage(buf ^ 1);
+        __syncthreads();
     }
-    const size_t mrow0 = (size_t)img * M2 + (size_t)oy0 * W2;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-        const int n = nh * 64 + j * 32 + lr;
+        const int n = wn + j * 32 + lr;
         const float bias = b2[n];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int m = 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            const float v = acc[j][r] + bias;
-            if (m < nrows * W2) out[(mrow0 + m) * CV_BN + n] = relu ? fmaxf(v, 0.f) : v;
-        }
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const float v = acc[i][j][r] + bias;
+                if (m < Mtotal) out[(size_t)m * CV_BN + n] = relu ? fmaxf(v, 0.f) : v;
+            }
     }
 }
 
-// the f32 view of the three bf16 planes k_conv1_pool_lrn2 writes (stage taps of the parity tests only): h + m + l is exact
-__global__ __launch_bounds__(256) void k_join3(const uint16_t* __restrict__ in3, float* __restrict__ out, int n_per_img, int batch) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)n_per_img * batch) return;
-    const size_t b = i / n_per_img, e = i - b * n_per_img;
-    const uint16_t* p = in3 + b * 3 * n_per_img + e;
-    auto f = [](uint16_t u) { return __uint_as_float((uint32_t)u << 16); };
-    out[i] = (f(p[0]) + f(p[n_per_img])) + f(p[2 * (size_t)n_per_img]);
-}
+#undef CV2_LOAD_STAGE
 
 // ---- conv3 + ReLU + flatten (NCHW order) + L2 normalise; one 1024-thread block per image ----
 // 16 waves share the 266 output pixels; each lane keeps its 18 weight quadruples (k = lane + 64 j) in registers.
@@ -667,8 +586,9 @@ static int walk_layers(const myslam_calc_layer* L, int n, std::vector<LayerShape
                 if (l.kernel < 1 || l.stride < 1 || l.kernel > s.H || l.kernel > s.W) return MYSLAM_ERR_INVALID;
                 if (l.pad != 0) return MYSLAM_ERR_UNSUPPORTED;
                 int oh = (int)ceilf((float)(s.H - l.kernel) / l.stride) + 1, ow = (int)ceilf((float)(s.W - l.kernel) / l.stride) + 1;      // Caffe ceil mode
-                if ((oh - 1) * l.stride >= s.H) oh--;
-                if ((ow - 1) * l.stride >= s.W) ow--;
+                // Caffe clips the last window only when pad > 0 (pooling_layer.cpp); with pad = 0 a stride larger than the kernel can leave a
+                // last window that starts outside the map (Caffe emits -FLT_MAX there): no CALC-like net does that — refused
+                if ((oh - 1) * l.stride >= s.H || (ow - 1) * l.stride >= s.W) return MYSLAM_ERR_UNSUPPORTED;
                 s = {s.C, oh, ow};
                 break;
             }
@@ -719,7 +639,6 @@ struct myslam_lcd {
     FusedPlan fused{};                 // fused.ok: the layer list has the geometry of the fused kernels
     int forceGeneric = 0;              // myslam_lcd_set_option(GENERIC_KERNELS)
     std::vector<float*> d_wt, d_b;     // per convolution: weights re-laid out as [K*K*IC][OC], bias
-    uint4* d_zero = nullptr;           // fused path: 256 zero bytes (the source of the conv2 patch's out-of-image pixels)
     uint4* d_w2s = nullptr;            // fused path: conv2 weights split into three bf16 pieces, [stage][piece][n][k half] x 8 bf16
     size_t actMax = 0;                 // largest activation (floats per image) of the generic path
     // resize tables for the current source size
@@ -750,7 +669,7 @@ static int lcd_alloc(T*& p, size_t n) {
 }
 
 void myslam_lcd::free_all() {
-    void* ptrs[] = {d_zero, d_w2s, d_xofs, d_yofs, d_xa, d_yb, d_blur, d_in, d_p1, d_a2, d_p2, d_g0, d_g1, d_stageImg, d_stageOut};
+    void* ptrs[] = {d_w2s, d_xofs, d_yofs, d_xa, d_yb, d_blur, d_in, d_p1, d_a2, d_p2, d_g0, d_g1, d_stageImg, d_stageOut};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (float* p : d_wt) if (p) (void)hipFree(p);
     for (float* p : d_b) if (p) (void)hipFree(p);
@@ -786,7 +705,7 @@ int myslam_lcd::ensure_batch(int batch, int r, int c) {
     if ((rc = lcd_alloc(d_in, (size_t)batch * IN_PLANE))) return rc;
     MYSLAM_HIP_CHECK(hipMemsetAsync(d_in, 0, (size_t)batch * IN_PLANE * sizeof(float), stream));     // the padding stays zero: writers touch the interior only
     if (fused.ok) {
-        if ((rc = lcd_alloc(d_p1, (size_t)batch * HP1 * WP1 * C1 * 3 / 2))) return rc;            // three bf16 planes (6 bytes per element)
+        if ((rc = lcd_alloc(d_p1, (size_t)batch * HP1 * WP1 * C1))) return rc;
         if ((rc = lcd_alloc(d_a2, (size_t)batch * H2 * W2 * C2))) return rc;
         if ((rc = lcd_alloc(d_p2, (size_t)batch * HP2 * WP2 * C2))) return rc;
     }
@@ -851,15 +770,12 @@ static int lcd_forward(myslam_lcd* h, int batch, float* d_out) {
     const FusedPlan& f = h->fused;
     {
         ScopedProf sp(P_CONV1, s);
-        hipLaunchKernelGGL(k_conv1_pool_lrn2, dim3((HT1 * WT1 + 3) / 4, batch), dim3(256), 0, s, h->d_in, h->d_wt[0], h->d_b[0], f.relu[0], f.lrn[0],
-                           reinterpret_cast<uint16_t*>(h->d_p1));
+        hipLaunchKernelGGL(k_conv1_pool_lrn2, dim3((HT1 * WT1 + 3) / 4, batch), dim3(256), 0, s, h->d_in, h->d_wt[0], h->d_b[0], f.relu[0], f.lrn[0], h->d_p1);
     }
     {
         ScopedProf sp(P_CONV2, s);
-        // the attribute is per device and per process: set it on every launch (cheap, re-entrant, multi-GPU safe)
-        MYSLAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv2_patch_bf16x6), hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS));
-        hipLaunchKernelGGL(k_conv2_patch_bf16x6, dim3(P2_NT, batch), dim3(P2_T), P2_LDS, s, reinterpret_cast<const uint16_t*>(h->d_p1), h->d_w2s,
-                           h->d_b[1], h->d_a2, h->d_zero, f.relu[1]);
+        const int Mtotal = batch * M2;
+        hipLaunchKernelGGL(k_conv2_bf16x6, dim3((Mtotal + 127) / 128), dim3(256), 0, s, h->d_p1, h->d_w2s, h->d_b[1], h->d_a2, Mtotal, f.relu[1]);
     }
     {
         ScopedProf sp(P_POOL2, s);
@@ -955,8 +871,7 @@ static int lcd_create(myslam_lcd** out, const myslam_calc_layer* layers, int nla
             }
         }
         if (hipMalloc((void**)&h->d_w2s, w2s.size() * 2) != hipSuccess ||
-            hipMemcpy(h->d_w2s, w2s.data(), w2s.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMalloc((void**)&h->d_zero, 256) != hipSuccess || hipMemset(h->d_zero, 0, 256) != hipSuccess)
+            hipMemcpy(h->d_w2s, w2s.data(), w2s.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
             return fail(MYSLAM_ERR_HIP);
     }
     *out = h;
@@ -1122,11 +1037,6 @@ int myslam_lcd_debug_forward(myslam_lcd* h, const float* in, float* out_stage, i
         const float* bufs[4] = {nullptr, h->d_p1, h->d_a2, h->d_p2};
         const size_t sizes[4] = {0, (size_t)HP1 * WP1 * C1, (size_t)H2 * W2 * C2, (size_t)HP2 * WP2 * C2};
         src = bufs[stage]; n = sizes[stage];
-        if (stage == 1) {               // the pooled conv1 map lives as three bf16 planes: join them (exact) for the tap; the forward pass is
-            hipLaunchKernelGGL(k_join3, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, reinterpret_cast<const uint16_t*>(h->d_p1),
-                               h->d_a2, (int)n, 1);                       // over, so conv2's output buffer serves as scratch
-            src = h->d_a2;
-        }
     } else {
         // layer index whose output is the tap: the stage-th "block end" (a conv followed by its ReLU / a pool followed by its LRN)
         int idx = -1, seen = -1;

@@ -23,6 +23,7 @@ constexpr int WAVE = 64;
 
 // ---- per-kernel event timing (bench.py's roofline leg reads it through the C ABI) ----
 struct ProfSlot { const char* name; double ms; long calls; };
+bool prof_is_on();
 void prof_begin(int id, hipStream_t s);
 void prof_end(int id, hipStream_t s);
 enum ProfId {
@@ -43,7 +44,9 @@ struct ScopedProf {
 // inout + out back and synchronises.  Usage: register pieces, upload(), launch on stream() with dev<T>(piece), download().
 struct HostArena {
     uint8_t* d = nullptr; uint8_t* h = nullptr; size_t cap = 0; hipStream_t s = nullptr;
+    int dev = -1;               // the device block, stream and pinned block belong to: a thread that switches devices gets a fresh arena
     ~HostArena();
+    void release();
     int ensure(size_t bytes);
 };
 HostArena& host_arena();
@@ -64,13 +67,13 @@ class HostCall {
   private:
     struct Piece { Kind kind; const void* src; void* dst; size_t bytes, off; };
     int add(Kind k, const void* src, void* dst, size_t bytes) {
-        if (npc >= MAXP) return -1;
+        if (npc >= MAXP) { overflow = true; return 0; }           // upload() refuses the call; piece 0 keeps dev<T>() in bounds until then
         pc[npc] = {k, src, dst, bytes, 0};
         return npc++;
     }
     static constexpr int MAXP = 24;
     HostArena& A;
-    Piece pc[MAXP]; int npc = 0;
+    Piece pc[MAXP]; int npc = 0; bool overflow = false;
     size_t endIn = 0, begOut = 0, endOut = 0;
 };
 

@@ -33,6 +33,8 @@ void launch_screen(const OrbPlan& P, const uint8_t* pyr, myslam_keypoint* kin, i
                    hipStream_t s);
 void launch_calc_desc(const OrbPlan& P, const uint8_t* blur, const myslam_keypoint* kps, int n, uint8_t* desc, hipStream_t s);
 void launch_unpack_cands(const uint32_t* cand, int n, int32_t* xs, int32_t* ys, int32_t* sc, hipStream_t s);
+void launch_blur_levels(const BlurArgs* lv, int n, int batch, hipStream_t s);
+void launch_zero_u32(uint32_t* p0, int n0, uint32_t* p1, int n1, uint32_t* p2, int n2, uint32_t* p3, int n3, hipStream_t s);
 void launch_ingest(const uint8_t* src, int rows, int cols, int step, size_t sstride, uint8_t* dst, int dpitch,
                    size_t dstride, int batch, hipStream_t s);
 
@@ -118,6 +120,18 @@ struct myslam_orb {
     int optStopAfter = 0;              // debug: stop a batched call after stage 1 ingest / 2 pyramid / 3 oct-tree / 4 blur (0 = run all)
     int tapsSet = 0, taps[7] = {0};    // myslam_orb_set_gauss_taps: replacement of the sigma = 2 Q8 taps
 
+    // Host-pointer calls (one frame per call: the drop-ins) replay a HIP graph: the ~35 launches, memsets and the copies of a call are
+    // captured once per (image shape, mask, Detect / DetectAndCompute, FAST statistics parity) and replayed with ONE hipGraphLaunch.
+    // `gen` changes whenever something a captured graph depends on does (buffers, plan, options, taps, streams): stale graphs are dropped.
+    // (the captured hipGraph_t is kept alive beside its executable: on ROCm 7.2 an executable whose source graph has been destroyed reads
+    // freed kernel-argument memory as soon as the heap reuses it — found as pixel bytes landing in the candidate counters)
+    struct HostGraph { hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; uint64_t gen = 0; int rows = 0, cols = 0, step = 0, dcap = 0, calls = 0; bool mask = false; };
+    HostGraph hostGraph[2][2];           // [detectOnly][fastFlip]
+    uint64_t gen = 1;
+    hipStream_t hostStream = nullptr;    // the host-pointer calls' stream when the handle has none (the legacy NULL stream cannot be captured)
+    uint8_t* h_pin = nullptr; size_t pinBytes = 0;      // pinned staging: image, mask, counts, key-points, descriptors
+    int ensure_pin(size_t bytes);
+    void drop_host_graphs();
     // staging for the host-buffer entry points
     uint8_t *d_stageImg = nullptr, *d_stageMask = nullptr; size_t stageImgBytes = 0, stageMaskBytes = 0;
     myslam_keypoint *d_stageKps = nullptr, *d_stageKps2 = nullptr; uint8_t* d_stageDesc = nullptr; uint8_t* d_stageKeep = nullptr;
@@ -261,12 +275,13 @@ int myslam_orb::ensure(int batch, int r, int c, bool needMask) {
         MYSLAM_HIP_CHECK(hipStreamSynchronize(stream));
         int rc = make_plan(r, c);
         if (rc) { rows = cols = 0; return rc; }
-        batchCap = 0;
+        batchCap = 0; gen++;
     }
     const int detOut = det.totalOut;
     const size_t selPer = (size_t)std::max(full.totalOut, detOut);
     if (batch > batchCap) {
         MYSLAM_HIP_CHECK(hipStreamSynchronize(stream));
+        gen++;
         int rc;
         if ((rc = dev_alloc(d_pyr, (size_t)batch * full.pyrBytes + 64))) return rc;      // + 64: the resize kernel's 8-byte row loads may run 7 bytes past a row
         if ((rc = dev_alloc(d_blur, (size_t)batch * full.pyrBytes))) return rc;
@@ -327,12 +342,13 @@ BlurArgs myslam_orb::level_blur_args(int l) const {
 }
 int myslam_orb::blur_levels(int batch, int nlev, hipStream_t stream) {
     const OrbPlan& P = full;
+    BlurArgs lv[MAXL];
     for (int l = 0; l < nlev; l++) {                           // ORBextractor.cpp:965-966 / :1194-1199
-        ScopedProf sp(P_BLUR, stream);
-        BlurArgs a = level_blur_args(l);
-        if (l == 0 && P.ext0N > 0) { a.src0 = P.ext0; a.spitch0 = P.ext0Pitch; a.sstride0 = P.ext0Stride; a.n0 = P.ext0N; }
-        launch_blur(a, batch, stream);
+        lv[l] = level_blur_args(l);
+        if (l == 0 && P.ext0N > 0) { lv[l].src0 = P.ext0; lv[l].spitch0 = P.ext0Pitch; lv[l].sstride0 = P.ext0Stride; lv[l].n0 = P.ext0N; }
     }
+    ScopedProf sp(P_BLUR, stream);
+    launch_blur_levels(lv, nlev, batch, stream);               // every level in one launch
     return MYSLAM_OK;
 }
 
@@ -344,9 +360,13 @@ int myslam_orb::run_batch(const uint8_t* d_imgs, int batch, int r, int c, int st
     if (rc) return rc;
     const OrbPlan& P = detectOnly ? det : full;
     int32_t* stat = d_stat ? d_stat : d_status;
-    MYSLAM_HIP_CHECK(hipMemsetAsync(d_candCount, 0, sizeof(int32_t) * (size_t)batch * MAXL, stream));
-    MYSLAM_HIP_CHECK(hipMemsetAsync(d_selCount, 0, sizeof(int32_t) * (size_t)batch * MAXL, stream));
-    MYSLAM_HIP_CHECK(hipMemsetAsync(stat, 0, sizeof(int32_t) * (size_t)batch, stream));
+    if (!d_fastStat) {
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&d_fastStat, sizeof(uint32_t) * 2 * MAXL * 4));
+        MYSLAM_HIP_CHECK(hipMemsetAsync(d_fastStat, 0, sizeof(uint32_t) * 2 * MAXL * 4, stream));
+    }
+    // candidate / selection counters, status words and the FAST statistics block this call accumulates into (run_fast): one launch
+    launch_zero_u32(reinterpret_cast<uint32_t*>(d_candCount), batch * MAXL, reinterpret_cast<uint32_t*>(d_selCount), batch * MAXL,
+                    reinterpret_cast<uint32_t*>(stat), batch, d_fastStat + (size_t)fastFlip * MAXL * 4, MAXL * 4, stream);
     const int stop = optStopAfter;
     // Level 0 in place: every image but the last of the batch is read where the caller put it (no copy into the pyramid block: 0.94 MB
     // of HBM traffic per 1241 x 376 image saved).  The gather kernels' unaligned loads may run a few bytes past a row, which stays
@@ -354,7 +374,9 @@ int myslam_orb::run_batch(const uint8_t* d_imgs, int batch, int r, int c, int st
     // resize and the level-0 blur (the fallbacks want aligned rows) and a complete call (the debug stops read the copy).
     {
         int n0 = 0;
-        if (!optCopyInput && stop == 0 && batch > 1 && full.nlevels >= 1) {
+        // ... and only when the images do not overlap (stride >= rows x pitch): the over-reads of an in-place image then land in the next
+        // image or in the gap before it; any other layout (stride 0 = one image repeated, interleaved images) is copied as before
+        if (!optCopyInput && stop == 0 && batch > 1 && full.nlevels >= 1 && stride >= (size_t)r * (size_t)step) {
             bool ok = blur_uses_strips(level_blur_args(0));
             if (full.nlevels > 1) ok = ok && resize_uses_strips(level_resize_args(d_pyr, 1));
             if (ok) n0 = batch - 1;
@@ -406,23 +428,34 @@ int myslam_orb::run_batch(const uint8_t* d_imgs, int batch, int r, int c, int st
 
 // grid FAST on the handle's stream; the launch reads the statistics block of the previous launch and fills the other one
 int myslam_orb::run_fast(const OrbPlan& P, const uint8_t* maskPyr, int batch) {
-    if (!d_fastStat) {
-        MYSLAM_HIP_CHECK(hipMalloc((void**)&d_fastStat, sizeof(uint32_t) * 2 * MAXL * 4));
-        MYSLAM_HIP_CHECK(hipMemsetAsync(d_fastStat, 0, sizeof(uint32_t) * 2 * MAXL * 4, stream));
-    }
-    uint32_t* cur = d_fastStat + (size_t)fastFlip * MAXL * 4;
+    uint32_t* cur = d_fastStat + (size_t)fastFlip * MAXL * 4;             // cleared by run_batch's counter launch
     const uint32_t* prev = d_fastStat + (size_t)(fastFlip ^ 1) * MAXL * 4;
     fastFlip ^= 1;
-    MYSLAM_HIP_CHECK(hipMemsetAsync(cur, 0, sizeof(uint32_t) * MAXL * 4, stream));
     ScopedProf sp(P_FAST, stream);
     launch_fast(P, d_pyr, full.pyrBytes, maskPyr, d_cand, d_candCount, prev, cur, optFastMode, batch, stream);
     return MYSLAM_OK;
 }
 
+int myslam_orb::ensure_pin(size_t bytes) {
+    if (bytes <= pinBytes) return MYSLAM_OK;
+    if (h_pin) { (void)hipHostFree(h_pin); h_pin = nullptr; pinBytes = 0; }
+    gen++;
+    const size_t want = (bytes + (bytes >> 2) + 4095) & ~(size_t)4095;
+    MYSLAM_HIP_CHECK(hipHostMalloc((void**)&h_pin, want));
+    pinBytes = want;
+    return MYSLAM_OK;
+}
+
+void myslam_orb::drop_host_graphs() {
+    for (auto& row : hostGraph)
+        for (auto& g : row) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); g = HostGraph(); }
+}
+
 int myslam_orb::ensure_stage(size_t imgBytes, size_t maskBytes, int cap) {
-    if (imgBytes > stageImgBytes) { int rc = dev_alloc(d_stageImg, imgBytes); if (rc) return rc; stageImgBytes = imgBytes; }
-    if (maskBytes > stageMaskBytes) { int rc = dev_alloc(d_stageMask, maskBytes); if (rc) return rc; stageMaskBytes = maskBytes; }
+    if (imgBytes > stageImgBytes) { gen++; int rc = dev_alloc(d_stageImg, imgBytes); if (rc) return rc; stageImgBytes = imgBytes; }
+    if (maskBytes > stageMaskBytes) { gen++; int rc = dev_alloc(d_stageMask, maskBytes); if (rc) return rc; stageMaskBytes = maskBytes; }
     if (cap > stageCap) {
+        gen++;
         int rc;
         if ((rc = dev_alloc(d_stageKps, (size_t)cap))) return rc;
         if ((rc = dev_alloc(d_stageKps2, (size_t)cap))) return rc;
@@ -439,6 +472,9 @@ void myslam_orb::free_all() {
                     d_stageKps, d_stageKps2, d_stageDesc, d_stageKeep, d_stageCounts};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); (void)hipEventDestroy(evFork); (void)hipEventDestroy(evJoin); aux = nullptr; }
+    drop_host_graphs();
+    if (hostStream) { (void)hipStreamSynchronize(hostStream); (void)hipStreamDestroy(hostStream); hostStream = nullptr; }
+    if (h_pin) { (void)hipHostFree(h_pin); h_pin = nullptr; pinBytes = 0; }
 }
 
 // =================================================================================================
@@ -469,24 +505,25 @@ int myslam_orb_destroy(myslam_orb* h) {
 int myslam_orb_set_stream(myslam_orb* h, void* s) {
     if (!h) return MYSLAM_ERR_INVALID;
     (void)hipStreamSynchronize(h->stream);
-    h->stream = (hipStream_t)s;
+    h->stream = (hipStream_t)s; h->gen++;
     return MYSLAM_OK;
 }
 
 int myslam_orb_set_fast_event(myslam_orb* h, void* ev) {
     if (!h) return MYSLAM_ERR_INVALID;
-    h->evUserFast = (hipEvent_t)ev;
+    h->evUserFast = (hipEvent_t)ev; h->gen++;
     return MYSLAM_OK;
 }
 
 int myslam_orb_set_fast_gate(myslam_orb* h, void* ev) {
     if (!h) return MYSLAM_ERR_INVALID;
-    h->evUserGate = (hipEvent_t)ev;
+    h->evUserGate = (hipEvent_t)ev; h->gen++;
     return MYSLAM_OK;
 }
 
 int myslam_orb_set_option(myslam_orb* h, int option, int value) {
     if (!h) return MYSLAM_ERR_INVALID;
+    h->gen++;
     switch (option) {
         case MYSLAM_ORB_OPT_FAST_MODE: if (value < -1 || value > 1) return MYSLAM_ERR_INVALID; h->optFastMode = value; return MYSLAM_OK;
         case MYSLAM_ORB_OPT_INTERNAL_STREAM: if (value < 0 || value > 2) return MYSLAM_ERR_INVALID; h->optInternalStream = value; return MYSLAM_OK;
@@ -498,13 +535,13 @@ int myslam_orb_set_option(myslam_orb* h, int option, int value) {
 
 int myslam_orb_set_gauss_taps(myslam_orb* h, const int32_t* q7) {
     if (!h) return MYSLAM_ERR_INVALID;
-    if (!q7) { h->tapsSet = 0; return MYSLAM_OK; }
+    if (!q7) { h->tapsSet = 0; h->gen++; return MYSLAM_OK; }
     // any table whose Q8.8 row sums fit the 16-bit horizontal accumulator (255 * sum <= 65535); the u8 result saturates
     int sum = 0;
     for (int i = 0; i < 7; i++) { if (q7[i] < 0 || q7[i] > 255) return MYSLAM_ERR_INVALID; sum += q7[i]; }
     if (sum < 1 || sum > 257) return MYSLAM_ERR_INVALID;
     for (int i = 0; i < 7; i++) h->taps[i] = q7[i];
-    h->tapsSet = 1;
+    h->tapsSet = 1; h->gen++;
     return MYSLAM_OK;
 }
 
@@ -565,22 +602,74 @@ static int host_extract(myslam_orb* h, const uint8_t* img, int rows, int cols, i
     if (mask && mask_step < cols) return MYSLAM_ERR_INVALID;
     int rc = h->ensure(1, rows, cols, mask != nullptr);          // plan first: the exact slot count depends on the image shape
     if (rc) return rc;
+    if (mask && mask_step != step) return MYSLAM_ERR_INVALID;    // masks share the image's pitch inside the engine
     const int dcap = std::max(cap, std::max(h->full.totalOut, h->det.totalOut));
-    if ((rc = h->ensure_stage((size_t)rows * step, mask ? (size_t)rows * mask_step : 0, dcap))) return rc;
-    MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_stageImg, img, (size_t)rows * step, hipMemcpyHostToDevice, h->stream));
-    if (mask) MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_stageMask, mask, (size_t)rows * mask_step, hipMemcpyHostToDevice, h->stream));
-    // masks share the image's pitch inside the engine: re-pitch on ingest through the same kernel (step may differ)
-    if (mask && mask_step != step) return MYSLAM_ERR_INVALID;
-    rc = h->run_batch(h->d_stageImg, 1, rows, cols, step, (size_t)rows * step, mask ? h->d_stageMask : nullptr,
-                      h->d_stageKps, h->d_stageDesc, h->d_stageCounts, h->d_stageCounts + 1, dcap, detectOnly);
-    if (rc) return rc;
+    const size_t imgBytes = (size_t)rows * step, maskBytes = mask ? imgBytes : 0;
+    if ((rc = h->ensure_stage(imgBytes, maskBytes, dcap))) return rc;
+    // pinned staging: [image][mask][counts (8 bytes, 256 reserved)][key-points dcap][descriptors dcap]
+    const size_t oCnt = (imgBytes + maskBytes + 255) & ~(size_t)255, oKps = oCnt + 256, oDesc = oKps + (((size_t)dcap * sizeof(myslam_keypoint) + 255) & ~(size_t)255);
+    if ((rc = h->ensure_pin(oDesc + (size_t)dcap * 32))) return rc;
+    // the caller's stream, or a private one: host-pointer calls complete before they return, so the stream they run on is invisible —
+    // work the caller queued on the handle's own stream that uses the handle's buffers (a _batch call) is waited for first
+    hipStream_t caller = h->stream;
+    if (!caller) {
+        if (!h->hostStream) { MYSLAM_HIP_CHECK(hipStreamCreateWithFlags(&h->hostStream, hipStreamNonBlocking)); h->gen++; }
+        MYSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
+    }
+    hipStream_t hs = caller ? caller : h->hostStream;
+    struct Swap { myslam_orb* h; hipStream_t keep; ~Swap() { h->stream = keep; } } swap{h, caller};
+    h->stream = hs;
+    memcpy(h->h_pin, img, imgBytes);
+    if (mask) memcpy(h->h_pin + imgBytes, mask, maskBytes);
+    auto enqueue = [&]() -> int {                               // everything a call puts on the stream (what a graph captures)
+        MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_stageImg, h->h_pin, imgBytes, hipMemcpyHostToDevice, hs));
+        if (mask) MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_stageMask, h->h_pin + imgBytes, maskBytes, hipMemcpyHostToDevice, hs));
+        int r2 = h->run_batch(h->d_stageImg, 1, rows, cols, step, imgBytes, mask ? h->d_stageMask : nullptr,
+                              h->d_stageKps, h->d_stageDesc, h->d_stageCounts, h->d_stageCounts + 1, dcap, detectOnly);
+        if (r2) return r2;
+        MYSLAM_HIP_CHECK(hipMemcpyAsync(h->h_pin + oCnt, h->d_stageCounts, 8, hipMemcpyDeviceToHost, hs));
+        MYSLAM_HIP_CHECK(hipMemcpyAsync(h->h_pin + oKps, h->d_stageKps, sizeof(myslam_keypoint) * (size_t)dcap, hipMemcpyDeviceToHost, hs));
+        if (!detectOnly) MYSLAM_HIP_CHECK(hipMemcpyAsync(h->h_pin + oDesc, h->d_stageDesc, (size_t)32 * dcap, hipMemcpyDeviceToHost, hs));
+        return MYSLAM_OK;
+    };
+    // a graph is replayable when nothing outside the capture takes part: no profiling events, no caller events, a complete call
+    const bool graphable = !prof_is_on() && !h->evUserGate && !h->evUserFast && h->optStopAfter == 0;
+    myslam_orb::HostGraph& G = h->hostGraph[detectOnly ? 1 : 0][h->fastFlip & 1];
+    const bool same = G.gen == h->gen && G.rows == rows && G.cols == cols && G.step == step && G.dcap == dcap && G.mask == (mask != nullptr);
+    if (!same) { if (G.exec) (void)hipGraphExecDestroy(G.exec); if (G.graph) (void)hipGraphDestroy(G.graph); G = myslam_orb::HostGraph(); G.gen = h->gen; G.rows = rows; G.cols = cols; G.step = step; G.dcap = dcap; G.mask = mask != nullptr; }
+    bool done = false;
+    if (graphable && G.exec) {
+        if (hipGraphLaunch(G.exec, hs) == hipSuccess) { h->fastFlip ^= 1; done = true; }        // the replay stands for run_fast's ping-pong step too
+        else { (void)hipGetLastError(); (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; if (G.graph) { (void)hipGraphDestroy(G.graph); G.graph = nullptr; } G.calls = -1000000; }
+    } else if (graphable && G.calls >= 1) {
+        // second call with this key (the first ran eagerly: lazy allocations, stream / event creation): capture, instantiate, launch
+        const int flip0 = h->fastFlip;
+        if (hipStreamBeginCapture(hs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const int r2 = enqueue();
+            hipGraph_t graph = nullptr;
+            const hipError_t e = hipStreamEndCapture(hs, &graph);
+            if (r2 == MYSLAM_OK && e == hipSuccess && graph && hipGraphInstantiate(&G.exec, graph, nullptr, nullptr, 0) == hipSuccess &&
+                hipGraphLaunch(G.exec, hs) == hipSuccess) {
+                done = true; G.graph = graph;
+            } else {                       // not capturable here: stay eager for this key
+                (void)hipGetLastError();
+                if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
+                if (graph) (void)hipGraphDestroy(graph);
+                G.calls = -1000000; h->fastFlip = flip0;
+            }
+        } else {
+            (void)hipGetLastError(); G.calls = -1000000;
+        }
+    }
+    if (!done && (rc = enqueue())) return rc;
+    G.calls++;
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(hs));
     int32_t res[2];
-    MYSLAM_HIP_CHECK(hipMemcpyAsync(res, h->d_stageCounts, sizeof(res), hipMemcpyDeviceToHost, h->stream));
-    MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    memcpy(res, h->h_pin + oCnt, sizeof(res));
     if (res[1] != 0) return res[1];
     if (res[0] > cap) { *n = res[0]; return MYSLAM_ERR_CAPACITY; }
-    MYSLAM_HIP_CHECK(hipMemcpy(kps, h->d_stageKps, sizeof(myslam_keypoint) * res[0], hipMemcpyDeviceToHost));
-    if (!detectOnly) MYSLAM_HIP_CHECK(hipMemcpy(desc, h->d_stageDesc, (size_t)32 * res[0], hipMemcpyDeviceToHost));
+    memcpy(kps, h->h_pin + oKps, sizeof(myslam_keypoint) * (size_t)res[0]);
+    if (!detectOnly) memcpy(desc, h->h_pin + oDesc, (size_t)32 * res[0]);
     *n = res[0];
     return MYSLAM_OK;
 }
@@ -678,7 +767,11 @@ int myslam_orb_debug_candidates(myslam_orb* h, const uint8_t* img, int rows, int
     if ((rc = h->ensure_stage((size_t)rows * step, mask ? (size_t)rows * step : 0, 16))) return rc;
     MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_stageImg, img, (size_t)rows * step, hipMemcpyHostToDevice, h->stream));
     if (mask) MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_stageMask, mask, (size_t)rows * step, hipMemcpyHostToDevice, h->stream));
-    MYSLAM_HIP_CHECK(hipMemsetAsync(h->d_candCount, 0, sizeof(int32_t) * MAXL, h->stream));
+    if (!h->d_fastStat) {
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_fastStat, sizeof(uint32_t) * 2 * MAXL * 4));
+        MYSLAM_HIP_CHECK(hipMemsetAsync(h->d_fastStat, 0, sizeof(uint32_t) * 2 * MAXL * 4, h->stream));
+    }
+    launch_zero_u32(reinterpret_cast<uint32_t*>(h->d_candCount), MAXL, h->d_fastStat + (size_t)h->fastFlip * MAXL * 4, MAXL * 4, nullptr, 0, nullptr, 0, h->stream);
     h->full.ext0N = h->det.ext0N = 0;                          // single staged image: nothing is read in place
     if ((rc = h->build_pyramids(h->d_stageImg, 1, step, (size_t)rows * step, mask ? h->d_stageMask : nullptr, h->nlevels))) return rc;
     if ((rc = h->run_fast(h->full, mask ? h->d_mask : nullptr, 1))) return rc;

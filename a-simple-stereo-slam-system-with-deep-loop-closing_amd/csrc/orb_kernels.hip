@@ -313,10 +313,17 @@ constexpr int B3_R = 32;                       // output rows per wave
 __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ uint32_t dpp_wave_shl1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
 
-__global__ __launch_bounds__(256) void k_blur7_strip(BlurArgs a, int nstrips, int nbands) {
+// All strip-capable levels of a pyramid in ONE launch (one wave per 256-column x 32-row band of some level): a one-frame call spends
+// more time between its launches than inside them (8 blur launches -> 1), and the small levels fill the gaps of the large ones.
+struct BlurMulti { BlurArgs a[MAXL]; int wave0[MAXL + 1]; int nstrips[MAXL]; int n; };
+__global__ __launch_bounds__(256) void k_blur7_strip(BlurMulti M) {
     const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // wave id -> (band, strip); scalar: row addressing goes to the SALU
-    if (wid >= nstrips * nbands) return;
+    const int gw = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));    // wave id over all levels; scalar: row addressing goes to the SALU
+    if (gw >= M.wave0[M.n]) return;
+    int lvl = 0;
+    while (lvl + 1 < M.n && gw >= M.wave0[lvl + 1]) lvl++;
+    const BlurArgs& a = M.a[lvl];
+    const int wid = gw - M.wave0[lvl], nstrips = M.nstrips[lvl];                                  // wave id -> (band, strip) of its level
     const int strip = wid % nstrips, band = wid / nstrips;
     const int b = blockIdx.z;
     const int x0 = strip * 256 + 4 * lane, y0 = band * B3_R;
@@ -2030,6 +2037,22 @@ __global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ src,
     else { uint32_t w[4] = {o.x, o.y, o.z, o.w}; for (int j = 0; j < 4 && x16 + 4 * j < dpitch; j++) reinterpret_cast<uint32_t*>(q)[j] = w[j]; }
 }
 
+// the per-call counters (candidate / selection counts, status words, FAST statistics) are cleared by ONE small kernel instead of four
+// hipMemsetAsync calls: three launches fewer per call, and kernel nodes are the part of a captured HIP graph that replays reliably
+// (memset nodes of a replayed graph left garbage in the counters on ROCm 7.2)
+struct ZeroArgs { uint32_t* p[4]; int n[4]; };
+__global__ __launch_bounds__(256) void k_zero_u32(ZeroArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (a.p[k] && i < a.n[k]) a.p[k][i] = 0u;
+}
+void launch_zero_u32(uint32_t* p0, int n0, uint32_t* p1, int n1, uint32_t* p2, int n2, uint32_t* p3, int n3, hipStream_t s) {
+    ZeroArgs a{{p0, p1, p2, p3}, {n0, n1, n2, n3}};
+    const int n = max(max(n0, n1), max(n2, n3));
+    if (n > 0) hipLaunchKernelGGL(k_zero_u32, dim3((n + 255) / 256), dim3(256), 0, s, a);
+}
+
 void launch_ingest(const uint8_t* src, int rows, int cols, int step, size_t sstride, uint8_t* dst, int dpitch,
                    size_t dstride, int batch, hipStream_t s) {
     const int t = (cols + 15) / 16;
@@ -2059,16 +2082,23 @@ bool blur_uses_strips(const BlurArgs& a) {
     return a.w >= 8 && a.h >= 8 && (a.spitch & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.src) | a.sstride) & 3) == 0;
 }
 
-void launch_blur(const BlurArgs& a, int batch, hipStream_t s) {
-    // register strips need dword-aligned rows and at least 8 x 8 pixels; everything else goes through the LDS-tiled kernel
-    if (blur_uses_strips(a)) {
-        const int nstrips = (a.w + 255) / 256, nbands = (a.h + B3_R - 1) / B3_R;
-        hipLaunchKernelGGL(k_blur7_strip, dim3((nstrips * nbands + 3) / 4, 1, batch), dim3(256), 0, s, a, nstrips, nbands);
-        return;
+// n levels (n <= MAXL): the ones the register-strip kernel can take share one launch, the others (unaligned rows, images narrower
+// than 8 pixels) go through the LDS-tiled kernel one by one
+void launch_blur_levels(const BlurArgs* lv, int n, int batch, hipStream_t s) {
+    BlurMulti M; M.n = 0; M.wave0[0] = 0;
+    for (int i = 0; i < n; i++) {
+        const BlurArgs& a = lv[i];
+        if (blur_uses_strips(a)) {
+            const int nstrips = (a.w + 255) / 256, nbands = (a.h + B3_R - 1) / B3_R;
+            M.a[M.n] = a; M.nstrips[M.n] = nstrips; M.wave0[M.n + 1] = M.wave0[M.n] + nstrips * nbands; M.n++;
+        } else {
+            dim3 grid((a.w + B2_W - 1) / B2_W, (a.h + B2_H - 1) / B2_H, batch);
+            hipLaunchKernelGGL(k_blur7_dot, grid, dim3(256), 0, s, a);
+        }
     }
-    dim3 grid((a.w + B2_W - 1) / B2_W, (a.h + B2_H - 1) / B2_H, batch);
-    hipLaunchKernelGGL(k_blur7_dot, grid, dim3(256), 0, s, a);
+    if (M.n) hipLaunchKernelGGL(k_blur7_strip, dim3((M.wave0[M.n] + 3) / 4, 1, batch), dim3(256), 0, s, M);
 }
+void launch_blur(const BlurArgs& a, int batch, hipStream_t s) { launch_blur_levels(&a, 1, batch, s); }
 
 void launch_fast(const OrbPlan& P, const uint8_t* pyr, size_t pyrStride, const uint8_t* maskPyr, uint32_t* cand,
                  int32_t* candCount, const uint32_t* statPrev, uint32_t* statCur, int forceMode, int batch, hipStream_t s) {
@@ -2088,8 +2118,10 @@ void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCo
     int ncmax = 0;
     for (int l = 0; l < P.nlevels; l++) ncmax = max(ncmax, P.lv[l].nodeCap);
     const size_t lds = octree_lds_bytes(ncmax);
-    // per device and per process: set on every launch that needs it (cheap, re-entrant, multi-GPU safe)
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // The limit is state of the FUNCTION (per device and process), not of a launch: it is always raised to the device's whole LDS, never
+    // to this launch's own size — a handle with a smaller plan (or another thread) would otherwise lower it under a launch that is still
+    // to come, e.g. the replay of a captured HIP graph (a memory fault, found with two extractor handles of different budgets).
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(k_octree, dim3(P.nlevels, batch), dim3(OT), lds, s, P, cand, candCount, sortbuf, octTab, selOut, selCount, status, ncmax);
 }
 

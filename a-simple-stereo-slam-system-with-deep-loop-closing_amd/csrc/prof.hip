@@ -25,6 +25,8 @@ static hipEvent_t get_event() {
     return e;
 }
 
+bool prof_is_on() { return g_on.load(std::memory_order_relaxed); }
+
 void prof_begin(int id, hipStream_t s) {
     if (!g_on.load(std::memory_order_relaxed)) return;
     std::lock_guard<std::mutex> lk(g_mu);
@@ -43,13 +45,20 @@ void prof_end(int id, hipStream_t s) {
 }
 
 // ---- thread-local staging of the host-pointer entry points (common.h) ----
-HostArena::~HostArena() {
+void HostArena::release() {
+    if (s) (void)hipStreamSynchronize(s);
     if (d) (void)hipFree(d);
     if (h) (void)hipHostFree(h);
     if (s) (void)hipStreamDestroy(s);
+    d = nullptr; h = nullptr; s = nullptr; cap = 0;
 }
 
+HostArena::~HostArena() { release(); }
+
 int HostArena::ensure(size_t bytes) {
+    int cur = 0;
+    MYSLAM_HIP_CHECK(hipGetDevice(&cur));
+    if (cur != dev) { release(); dev = cur; }          // the calling thread selected another device since its last call
     if (!s) MYSLAM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     if (bytes <= cap) return MYSLAM_OK;
     MYSLAM_HIP_CHECK(hipStreamSynchronize(s));
@@ -69,6 +78,7 @@ HostArena& host_arena() {
 }
 
 int HostCall::upload() {
+    if (overflow) return MYSLAM_ERR_CAPACITY;          // more pieces than a call may register
     size_t off = 0;
     for (int k = IN; k <= TMP; k++) {
         if (k == INOUT) begOut = off;

@@ -43,7 +43,7 @@ struct TextNode {
 class TextParser {
   public:
     explicit TextParser(const std::string& s) : t(s) {}
-    bool parse(TextNode& root) { return body(root, false) && (skip(), p >= t.size()); }
+    bool parse(TextNode& root) { return body(root, false, 0) && (skip(), p >= t.size()); }
 
   private:
     const std::string& t; size_t p = 0;
@@ -76,7 +76,9 @@ class TextParser {
         out = t.substr(b, p - b);
         return p > b;
     }
-    bool body(TextNode& n, bool braced) {
+    static constexpr int kMaxDepth = 64;          // a prototxt nests 3-4 levels; user-supplied files must not be able to exhaust the stack
+    bool body(TextNode& n, bool braced, int depth) {
+        if (depth > kMaxDepth) return false;
         for (;;) {
             skip();
             if (p >= t.size()) return !braced;
@@ -86,13 +88,13 @@ class TextParser {
             skip();
             if (p < t.size() && t[p] == ':') {
                 p++; skip();
-                if (p < t.size() && t[p] == '{') { p++; TextNode c; if (!body(c, true)) return false; n.children.emplace_back(key, std::move(c)); continue; }
+                if (p < t.size() && t[p] == '{') { p++; TextNode c; if (!body(c, true, depth + 1)) return false; n.children.emplace_back(key, std::move(c)); continue; }
                 std::string v;
                 if (!value(v)) return false;
                 n.scalars.emplace_back(key, v);
             } else if (p < t.size() && t[p] == '{') {
                 p++; TextNode c;
-                if (!body(c, true)) return false;
+                if (!body(c, true, depth + 1)) return false;
                 n.children.emplace_back(key, std::move(c));
             } else {
                 return false;
@@ -243,12 +245,21 @@ inline int parse_prototxt(const std::string& text, Model& m) {
     for (auto& s : root.all("input_dim")) dims.push_back(atoi(s.c_str()));
     if (const TextNode* sh = root.child("input_shape")) for (auto& s : sh->all("dim")) dims.push_back(atoi(s.c_str()));
     int in_ch = 0;
+    // the net is run as a CHAIN: every layer must consume exactly the blob the previous layer produced (in-place layers included); a
+    // prototxt with branches, skips or several inputs is refused instead of being silently flattened
+    std::string cur_top = root.get("input") ? *root.get("input") : "";
     for (auto& c : root.children) {
         if (c.first != "layer" && c.first != "layers") continue;
         const TextNode& L = c.second;
         std::string type = L.get("type") ? *L.get("type") : "";
         const std::string name = L.get("name") ? *L.get("name") : "";
         for (auto& ch : type) ch = (char)tolower((unsigned char)ch);
+        {
+            const std::vector<std::string> bottoms = L.all("bottom"), tops = L.all("top");
+            if (bottoms.size() > 1 || tops.size() > 1) return MYSLAM_ERR_UNSUPPORTED;
+            if (type != "input" && !bottoms.empty() && !cur_top.empty() && bottoms[0] != cur_top) return MYSLAM_ERR_UNSUPPORTED;
+            if (!tops.empty()) cur_top = tops[0];
+        }
         myslam_calc_layer rec;
         memset(&rec, 0, sizeof(rec));
         if (type == "input") {

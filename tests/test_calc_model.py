@@ -71,3 +71,35 @@ def test_parse_rejects_what_it_cannot_run(pkg, synth, tmp_path):
     with pytest.raises(api.MyslamError) as e:
         api.calc_parse_caffe(pp, mp)
     assert e.value.code == api.ERR_UNSUPPORTED
+
+
+def test_parse_refuses_non_chains_and_deep_nesting(pkg, synth, tmp_path):
+    """The reader runs the net as a chain: a layer whose `bottom` is not the previous layer's `top` (a skip connection, a second
+    branch) is refused instead of being flattened silently; and a prototxt cannot exhaust the parser's stack with nested braces."""
+    api = pkg.api
+    L = api.calc_default_layers()
+    w = synth.calc_weights()
+    pp, mp = caffe_files.write_pair(tmp_path, L, w)
+    text = open(pp).read()
+    # re-wire the second convolution to the network input: a branch, not a chain
+    import re
+    hits = [m for m in re.finditer(r'type: "Convolution" bottom: "([^"]+)"', text)]
+    assert len(hits) == 3
+    broken = text[:hits[1].start(1)] + "data" + text[hits[1].end(1):]
+    open(pp, "w").write(broken)
+    with pytest.raises(api.MyslamError) as e:
+        api.calc_parse_caffe(pp, mp)
+    assert e.value.code == api.ERR_UNSUPPORTED
+    # two bottoms (an Eltwise-style join) -> UNSUPPORTED
+    open(pp, "w").write(text.replace('type: "LRN" bottom:', 'type: "LRN" bottom: "data" bottom:', 1))
+    with pytest.raises(api.MyslamError) as e:
+        api.calc_parse_caffe(pp, mp)
+    assert e.value.code == api.ERR_UNSUPPORTED
+    # 100 000 nested blocks: INVALID, not a stack overflow
+    open(pp, "w").write(text + "\n" + "x { " * 100000 + "}" * 100000)
+    with pytest.raises(api.MyslamError) as e:
+        api.calc_parse_caffe(pp, mp)
+    assert e.value.code == api.ERR_INVALID
+    open(pp, "w").write(text)                      # and the untouched file still parses
+    L2, _ = api.calc_parse_caffe(pp, mp)
+    assert len(L2) == len(L)

@@ -449,3 +449,29 @@ def test_level0_read_in_place(api, oracle, synth, copy_input, cols, step, gap):
         rk = oracle.detect(oracle.params(300), imgs[i])
         n = int(cnt[i])
         assert n == len(rk) and k[i, :n].tobytes() == rk.tobytes(), (copy_input, "detect", i)
+
+
+def test_batch_of_overlapping_images_is_copied(api, oracle, synth):
+    """img_stride < rows * step (here 0: the SAME image five times, and rows * step / 2: every image shares half its rows with the next
+    one): the in-place path would rely on over-reads landing in the next image — such layouts take the copying path and give the
+    oracle's bytes."""
+    import torch
+    rows, cols, step = 240, 333, 336
+    img = synth.random_image(4300, rows + rows // 2 * 4, cols)
+    buf = np.full(img.shape[0] * step + 64, 0xA5, np.uint8)
+    buf[:img.shape[0] * step].reshape(-1, step)[:, :cols] = img
+    d = torch.from_numpy(buf).cuda()
+    ext = api.ORBextractor(400)
+    cap = ext.max_keypoints(rows, cols)
+    for B, stride in ((5, 0), (5, rows // 2 * step)):
+        kps = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda"); desc = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+        cnt = torch.zeros(B, dtype=torch.int32, device="cuda"); st = torch.zeros(B, dtype=torch.int32, device="cuda")
+        ext.detect_and_compute_batch(d.data_ptr(), B, rows, cols, step, stride, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), st.data_ptr(), cap)
+        torch.cuda.synchronize()
+        assert int(st.abs().sum()) == 0
+        k = kps.cpu().numpy().view(api.KP_DTYPE).reshape(B, cap); dd = desc.cpu().numpy().reshape(B, cap, 32)
+        for i in range(B):
+            r0 = i * stride // step
+            rk, rd = oracle.detect_and_compute(oracle.params(400), img[r0:r0 + rows])
+            n = int(cnt[i])
+            assert n == len(rk) and k[i, :n].tobytes() == rk.tobytes() and np.array_equal(dd[i, :n], rd), (stride, i)
