@@ -560,7 +560,7 @@ def main():
                     "h2d_GBps": bytes_step * args.steps / dt_s / 1e9, "h2d_bytes_per_step": bytes_step, "distinct_batches": NBAT,
                     "host_render_s": t_gen, "h2d_copy_ms_avg": float(np.mean([a.elapsed_time(b) for a, b in copy_ev])),
                     "note": "every step extracts images that crossed PCIe for that step: consecutive frames of the synthetic stream in pinned host "
-                            "memory, one host->device copy per step on a copy stream, two device input buffers (a buffer is overwritten only after "
+                            "memory, one host->device copy per step on a copy stream, three device input buffers (a buffer is overwritten only after "
                             "every reader of the step that used it has finished — level 0 is read in place)"}
 
     if args.verify and args.pipeline:
