@@ -496,7 +496,7 @@ def main():
     # ---- pass 4: streamed input — every step's images cross PCIe (app/run_kitti_stereo.cpp:61-90 reads two images per step) ----
     streamed = None
     if args.stream_input > 0 and not args.no_extra_passes:
-        NBAT = args.stream_input
+        NBAT = args.stream_input if world == 1 else min(args.stream_input, 2)      # N ranks render on one host: two batches per rank there
         t_gen = time.perf_counter()
         h_bat = []
         for j in range(NBAT):           # consecutive frames of the same synthetic stream: batch j = frames j*P .. (j+1)*P - 1

@@ -94,6 +94,8 @@ constexpr int INSTS_PER_BLOCK = 32, BLOCKS_PER_ITER = 4;
 #define I_CND_E64(d) "v_cndmask_b32_e64 %" #d ", %" #d ", %9, s[20:21]\n"
 #define I_CND_NODEP(d) "v_cndmask_b32 %" #d ", %8, %9, vcc\n"
 #define I_ADDC(d) "v_addc_co_u32 %" #d ", vcc, %" #d ", %8, vcc\n"
+#define I_CMPCND64(d) "v_cmp_gt_u32_e64 s[20:21], %" #d ", %8\nv_cndmask_b32_e64 %" #d ", %" #d ", %9, s[20:21]\n"
+#define I_CNDADD(d) "v_cndmask_b32 %" #d ", %" #d ", %9, vcc\nv_add_u32 %" #d ", %" #d ", %8\nv_add_u32 %" #d ", %" #d ", %8\nv_add_u32 %" #d ", %" #d ", %8\n"
 #define I_PKMULLO(d) "v_pk_mul_lo_u16 %" #d ", %" #d ", %8\n"
 #define I_PKMAD(d) "v_pk_mad_u16 %" #d ", %" #d ", %8, %9\n"
 #define I_CVTUB(d) "v_cvt_f32_ubyte0 %" #d ", %" #d "\n"
@@ -155,6 +157,8 @@ VALU_KERNEL(cndmask_b32_vcc_set, uint32_t, I_CND)
 VALU_KERNEL(cndmask_b32_e64_sgpr_mask, uint32_t, I_CND_E64)
 VALU_KERNEL(cndmask_b32_no_dependency, uint32_t, I_CND_NODEP)
 VALU_KERNEL(addc_co_u32, uint32_t, I_ADDC)
+VALU_KERNEL(cmp_e64_sgpr_plus_cndmask_e64, uint32_t, I_CMPCND64)
+VALU_KERNEL(cndmask_vcc_plus_3_add_u32, uint32_t, I_CNDADD)
 VALU_KERNEL(pk_mul_lo_u16, uint32_t, I_PKMULLO)
 VALU_KERNEL(pk_mad_u16, uint32_t, I_PKMAD)
 VALU_KERNEL(cvt_f32_ubyte0, uint32_t, I_CVTUB)
@@ -411,6 +415,7 @@ int main(int argc, char** argv) {
     RUNU(sub_u32, 1); RUNU(bfe_u32, 1); RUNU(add3_u32, 1); RUNU(or3_b32, 1); RUNU(lshl_add_u32, 1); RUNU(med3_u32, 1); RUNU(max3_u16, 1); RUNU(min3_f16, 1);
     RUNU(max_u16_sdwa, 1); RUNU(mov_b32_dpp, 1); RUNU(add_u32_dpp, 1); RUNU(cmp_gt_u32_plus_cndmask, 1); RUNU(cmp_gt_u32, 1); RUNU(cndmask_b32_vcc_set, 1);
     RUNU(cndmask_b32_e64_sgpr_mask, 1); RUNU(cndmask_b32_no_dependency, 1); RUNU(addc_co_u32, 1);
+    RUNU(cmp_e64_sgpr_plus_cndmask_e64, 1); RUNU(cndmask_vcc_plus_3_add_u32, 1);
     RUNU(pk_mul_lo_u16, 2); RUNU(pk_mad_u16, 2); RUNU(cvt_f32_ubyte0, 1); RUNU(sad_u8, 1); RUNU(mov_b32, 1); RUNU(readlane_b32, 1);
 #define RUNF(NAME) rows.push_back(run_valu<float>(#NAME, k_##NAME, 1.0f, 0.999f, 0.001f, d_out, 1))
 #define RUND(NAME, ops) rows.push_back(run_valu<double>(#NAME, k_##NAME, 1.0, 0.999, 0.001, d_out, ops))
