@@ -644,3 +644,41 @@ def solve_pnp_ransac(pts3d, pts2d, K, iterations=100, reproj_error=5.991, confid
     _check(lib().myslam_solve_pnp_ransac(_p(p3), _p(p2), n, C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]), C.c_double(K[3]), int(iterations),
                                          C.c_double(reproj_error), C.c_double(confidence), _p(pose), _p(inl), C.byref(ni)), "myslam_solve_pnp_ransac")
     return pose, inl[:n].astype(bool), ni.value
+
+
+# ---------------------------------------------------------------------------------- host-side formats (no device needed)
+def read_png_gray(path):
+    """cv::imread(path, IMREAD_GRAYSCALE) for the KITTI grey PNGs (app/run_kitti_stereo.cpp:66-67) -> uint8 [rows, cols]"""
+    r = C.c_int(); c = C.c_int(); b = path.encode()
+    _check(lib().myslam_io_read_png_gray(b, None, 0, C.byref(r), C.byref(c)), "myslam_io_read_png_gray")
+    out = np.zeros((r.value, c.value), np.uint8)
+    _check(lib().myslam_io_read_png_gray(b, _p(out), out.size, C.byref(r), C.byref(c)), "myslam_io_read_png_gray")
+    return out
+
+
+def load_images(sequence_path):
+    """LoadImages (app/run_kitti_stereo.cpp:114-144) -> (left paths, right paths, timestamps)"""
+    n = C.c_int(); b = sequence_path.encode()
+    _check(lib().myslam_io_load_images(b, None, 0, C.byref(n)), "myslam_io_load_images")
+    ts = np.zeros(max(n.value, 1), np.float64)
+    _check(lib().myslam_io_load_images(b, _p(ts), len(ts), C.byref(n)), "myslam_io_load_images")
+    buf = C.create_string_buffer(len(b) + 64)
+
+    def path(i, right):
+        _check(lib().myslam_io_image_path(b, i, right, buf, len(buf)), "myslam_io_image_path")
+        return buf.value.decode()
+    return [path(i, 0) for i in range(n.value)], [path(i, 1) for i in range(n.value)], ts[:n.value]
+
+
+def save_trajectory(path, ids, timestamps, poses7_cw):
+    """System::SaveTrajectory (src/system.cpp:153-180); poses are Tcw (KeyFrame::Pose()) as qx qy qz qw tx ty tz"""
+    ids = np.ascontiguousarray(ids, np.uint64); ts = np.ascontiguousarray(timestamps, np.float64); ps = np.ascontiguousarray(poses7_cw, np.float64).reshape(-1, 7)
+    assert len(ids) == len(ts) == len(ps)
+    _check(lib().myslam_io_save_trajectory(path.encode(), _p(ids), _p(ts), _p(ps), len(ids)), "myslam_io_save_trajectory")
+
+
+def save_loop_edges(path, cur_ids, cur_ts, cur_poses, loop_ids, loop_ts, loop_poses):
+    """System::SaveLoopEdges (src/system.cpp:188-224)"""
+    a = [np.ascontiguousarray(cur_ids, np.uint64), np.ascontiguousarray(cur_ts, np.float64), np.ascontiguousarray(cur_poses, np.float64).reshape(-1, 7),
+         np.ascontiguousarray(loop_ids, np.uint64), np.ascontiguousarray(loop_ts, np.float64), np.ascontiguousarray(loop_poses, np.float64).reshape(-1, 7)]
+    _check(lib().myslam_io_save_loop_edges(path.encode(), *[_p(x) for x in a], len(a[0])), "myslam_io_save_loop_edges")

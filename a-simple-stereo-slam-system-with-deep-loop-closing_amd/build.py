@@ -28,6 +28,7 @@ UNITS = {
     "pgo.hip": [],
     "pnp.hip": EXACT,
     "prof.hip": [],
+    "io.hip": [],
 }
 
 

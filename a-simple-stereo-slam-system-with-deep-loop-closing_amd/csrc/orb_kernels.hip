@@ -2067,8 +2067,12 @@ void launch_ingest(const uint8_t* src, int rows, int cols, int step, size_t sstr
 bool resize_uses_strips(const ResizeArgs& a) { return (double)RS_R * a.scale_y + 2.0 <= (double)RS_MAXR && a.scale_x <= 1.6; }
 
 void launch_resize(const ResizeArgs& a, int batch, hipStream_t s) {
-    // register strips cover pyramid scale factors up to 1.25 (rows) / 1.6 (columns); larger steps take the generic kernel
-    if (resize_uses_strips(a)) {
+    // register strips cover pyramid scale factors up to 1.25 (rows) / 1.6 (columns); larger steps take the generic kernel — and so do
+    // launches with little work (a one-frame call: a level is ~100 strip waves that each walk their band serially, 8.5 us per level and
+    // seven dependent levels; one thread per four destination pixels finishes a level in a third of that).  Same arithmetic, bit for bit
+    // (tests/test_gpu_fallbacks.py); images read in place (n0 > 0: batched calls only) need the strip form.
+    const bool little = a.n0 == 0 && (size_t)batch * a.dw * a.dh < (size_t)1500000;
+    if (resize_uses_strips(a) && !little) {
         const int nstrips = (a.dw + 255) / 256, nbands = (a.dh + RS_R - 1) / RS_R;
         const int ngroups = (nbands + RS_NB - 1) / RS_NB;
         hipLaunchKernelGGL(k_resize_strip, dim3((nstrips * ngroups + 3) / 4, 1, batch), dim3(256), 0, s, a, nstrips, nbands);

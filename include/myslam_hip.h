@@ -448,6 +448,25 @@ int myslam_correct_map_points_device(const double* d_old_poses, const double* d_
 int myslam_solve_pnp_ransac(const float* pts3d, const float* pts2d, int n, double fx, double fy, double cx, double cy, int iterations,
                             double reproj_error, double confidence, double* pose7, uint8_t* inlier, int* n_inliers);
 
+/* ------------------------------------------------------------------------------------------
+ * Host-side formats of the reference's runner — plain host code, no device needed; the C++ forms live in
+ * host/myslam_io.hpp and host/myslam_png.hpp.
+ * ------------------------------------------------------------------------------------------ */
+/* cv::imread(file, cv::IMREAD_GRAYSCALE) for the 8-bit single-channel PNGs of KITTI image_0 / image_1 (app/run_kitti_stereo.cpp:66-67).
+ * out == NULL: size query (rows, cols only).  Non-interlaced grey 8 / 16 bit, RGB / RGBA 8 bit (BGR2GRAY fixed point); else INVALID. */
+int myslam_io_read_png_gray(const char* path, uint8_t* out, size_t cap_bytes, int* rows, int* cols);
+/* LoadImages (app/run_kitti_stereo.cpp:114-144): *n = number of frames listed in <sequence>/times.txt; timestamps may be NULL */
+int myslam_io_load_images(const char* sequence_path, double* timestamps, int cap, int* n);
+/* "<sequence>/image_0/000123.png" (right != 0: image_1), :135-141 */
+int myslam_io_image_path(const char* sequence_path, int index, int right, char* buf, size_t cap);
+/* System::SaveTrajectory (src/system.cpp:153-180): one line "id timestamp tx ty tz qx qy qz qw" per key-frame in ascending id order,
+ * std::fixed / setprecision(6), pose = KeyFrame::Pose().inverse().  poses7_cw = Tcw as qx qy qz qw tx ty tz (what every entry point
+ * of this library calls a pose). */
+int myslam_io_save_trajectory(const char* path, const uint64_t* ids, const double* timestamps, const double* poses7_cw, int n);
+/* System::SaveLoopEdges (src/system.cpp:188-224): two lines per loop (current key-frame, loop key-frame), ordered by the current id */
+int myslam_io_save_loop_edges(const char* path, const uint64_t* cur_ids, const double* cur_ts, const double* cur_poses7_cw,
+                              const uint64_t* loop_ids, const double* loop_ts, const double* loop_poses7_cw, int n);
+
 #ifdef __cplusplus
 }
 #endif

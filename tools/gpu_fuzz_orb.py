@@ -45,6 +45,17 @@ for it in range(N):
     if ok:
         for l in range(nl):
             ok = ok and np.array_equal(ext.debug_pyramid(img, l, blurred=True), o.blur7(o.pyramid(p, img)[l], 0))
+    if ok and rng.random() < 0.5:
+        # the same handle on more frames of the same shape: the second call captures a HIP graph, the later ones replay it (both FAST
+        # statistics parities); masks on and off alternate the graph key
+        for rep in range(4):
+            img2 = np.ascontiguousarray(synth.random_image(int(rng.integers(1 << 30)), h, w, "texture" if rep % 2 else "noise"))
+            mask = None
+            if rng.random() < 0.3:
+                mask = np.full((h, w), 255, np.uint8); y0, x0 = int(rng.integers(0, h - 20)), int(rng.integers(0, w - 20)); mask[y0:y0 + h // 3, x0:x0 + w // 3] = 0
+            g2, d2 = ext.DetectAndCompute(img2, mask)
+            r2, e2 = o.detect_and_compute(p, img2, mask, cap=ext.max_keypoints(h, w) + 8)
+            ok = ok and g2.tobytes() == r2.tobytes() and np.array_equal(d2, e2)
     if not ok:
         bad += 1
         print("MISMATCH", dict(h=h, w=w, nf=nf, nl=nl, sf=sf, kind=kind, n_gpu=len(gk), n_ref=len(rk)))
