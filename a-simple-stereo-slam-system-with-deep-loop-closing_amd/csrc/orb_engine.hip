@@ -35,6 +35,8 @@ void launch_calc_desc(const OrbPlan& P, const uint8_t* blur, const myslam_keypoi
 void launch_unpack_cands(const uint32_t* cand, int n, int32_t* xs, int32_t* ys, int32_t* sc, hipStream_t s);
 void launch_blur_levels(const BlurArgs* lv, int n, int batch, hipStream_t s);
 void launch_zero_u32(uint32_t* p0, int n0, uint32_t* p1, int n1, uint32_t* p2, int n2, uint32_t* p3, int n3, hipStream_t s);
+void launch_ingest_clear(const uint8_t* src, int rows, int cols, int step, size_t sstride, uint8_t* dst, int dpitch, size_t dstride, int batch,
+                         uint32_t* p0, int n0, uint32_t* p1, int n1, uint32_t* p2, int n2, uint32_t* p3, int n3, hipStream_t s);
 void launch_ingest(const uint8_t* src, int rows, int cols, int step, size_t sstride, uint8_t* dst, int dpitch,
                    size_t dstride, int batch, hipStream_t s);
 
@@ -128,6 +130,7 @@ struct myslam_orb {
     struct HostGraph { hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; uint64_t gen = 0; int rows = 0, cols = 0, step = 0, dcap = 0, calls = 0; bool mask = false; };
     HostGraph hostGraph[2][2];           // [detectOnly][fastFlip]
     uint64_t gen = 1;
+    struct Clear { uint32_t* p[4]; int n[4]; } clr{{nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}};      // counters the next level-0 ingest clears (run_batch -> build_pyramids)
     hipStream_t hostStream = nullptr;    // the host-pointer calls' stream when the handle has none (the legacy NULL stream cannot be captured)
     uint8_t* h_pin = nullptr; size_t pinBytes = 0;      // pinned staging: image, mask, counts, key-points, descriptors
     int ensure_pin(size_t bytes);
@@ -136,6 +139,7 @@ struct myslam_orb {
     uint8_t *d_stageImg = nullptr, *d_stageMask = nullptr; size_t stageImgBytes = 0, stageMaskBytes = 0;
     myslam_keypoint *d_stageKps = nullptr, *d_stageKps2 = nullptr; uint8_t* d_stageDesc = nullptr; uint8_t* d_stageKeep = nullptr;
     int32_t* d_stageCounts = nullptr; int stageCap = 0;
+    uint8_t* d_stageOut = nullptr; size_t stageOutBytes = 0, stageDescOff = 0;      // the block d_stageCounts / d_stageKps / d_stageDesc point into
 
     int make_tables();
     int make_plan(int r, int c);
@@ -310,9 +314,16 @@ int myslam_orb::build_pyramids(const uint8_t* d_imgs, int batch, int step, size_
         uint8_t* base = pass ? d_mask : d_pyr;
         const uint8_t* src = pass ? d_masks : d_imgs;
         const int n0 = pass ? 0 : P.ext0N;                     // images read in place have no level-0 copy (masks are always copied)
-        if (batch > n0)
-            launch_ingest(src + (size_t)n0 * stride, P.rows, P.cols, step, stride, base + (size_t)n0 * P.pyrBytes + P.lv[0].imgOff, P.lv[0].pitch,
-                          P.pyrBytes, batch - n0, stream);
+        if (batch > n0) {
+            uint8_t* dst0 = base + (size_t)n0 * P.pyrBytes + P.lv[0].imgOff;
+            if (pass == 0 && clr.n[0] > 0) {       // the call's first launch also clears the per-call counters (run_batch)
+                launch_ingest_clear(src + (size_t)n0 * stride, P.rows, P.cols, step, stride, dst0, P.lv[0].pitch, P.pyrBytes, batch - n0,
+                                    clr.p[0], clr.n[0], clr.p[1], clr.n[1], clr.p[2], clr.n[2], clr.p[3], clr.n[3], stream);
+                clr.n[0] = 0;
+            } else {
+                launch_ingest(src + (size_t)n0 * stride, P.rows, P.cols, step, stride, dst0, P.lv[0].pitch, P.pyrBytes, batch - n0, stream);
+            }
+        }
         for (int l = 1; l < nlev; l++) {                       // ComputePyramid, ORBextractor.cpp:1235-1246
             ScopedProf sp(P_RESIZE, stream);
             ResizeArgs a = level_resize_args(base, l);
@@ -364,9 +375,10 @@ int myslam_orb::run_batch(const uint8_t* d_imgs, int batch, int r, int c, int st
         MYSLAM_HIP_CHECK(hipMalloc((void**)&d_fastStat, sizeof(uint32_t) * 2 * MAXL * 4));
         MYSLAM_HIP_CHECK(hipMemsetAsync(d_fastStat, 0, sizeof(uint32_t) * 2 * MAXL * 4, stream));
     }
-    // candidate / selection counters, status words and the FAST statistics block this call accumulates into (run_fast): one launch
-    launch_zero_u32(reinterpret_cast<uint32_t*>(d_candCount), batch * MAXL, reinterpret_cast<uint32_t*>(d_selCount), batch * MAXL,
-                    reinterpret_cast<uint32_t*>(stat), batch, d_fastStat + (size_t)fastFlip * MAXL * 4, MAXL * 4, stream);
+    // candidate / selection counters, status words and the FAST statistics block this call accumulates into (run_fast) are cleared by the
+    // call's first launch, the level-0 ingest (build_pyramids)
+    clr = {{reinterpret_cast<uint32_t*>(d_candCount), reinterpret_cast<uint32_t*>(d_selCount), reinterpret_cast<uint32_t*>(stat), d_fastStat + (size_t)fastFlip * MAXL * 4},
+           {batch * MAXL, batch * MAXL, batch, MAXL * 4}};
     const int stop = optStopAfter;
     // Level 0 in place: every image but the last of the batch is read where the caller put it (no copy into the pyramid block: 0.94 MB
     // of HBM traffic per 1241 x 376 image saved).  The gather kernels' unaligned loads may run a few bytes past a row, which stays
@@ -384,7 +396,8 @@ int myslam_orb::run_batch(const uint8_t* d_imgs, int batch, int r, int c, int st
         full.ext0 = det.ext0 = d_imgs; full.ext0Stride = det.ext0Stride = stride; full.ext0Pitch = det.ext0Pitch = step; full.ext0N = det.ext0N = n0;
     }
     if (stop == 1) {
-        launch_ingest(d_imgs, full.rows, full.cols, step, stride, d_pyr + full.lv[0].imgOff, full.lv[0].pitch, full.pyrBytes, batch, stream);
+        launch_ingest_clear(d_imgs, full.rows, full.cols, step, stride, d_pyr + full.lv[0].imgOff, full.lv[0].pitch, full.pyrBytes, batch,
+                            clr.p[0], clr.n[0], clr.p[1], clr.n[1], clr.p[2], clr.n[2], clr.p[3], clr.n[3], stream);
         return MYSLAM_OK;
     }
     if ((rc = build_pyramids(d_imgs, batch, step, stride, d_masks, P.nlevels))) return rc;
@@ -457,11 +470,16 @@ int myslam_orb::ensure_stage(size_t imgBytes, size_t maskBytes, int cap) {
     if (cap > stageCap) {
         gen++;
         int rc;
-        if ((rc = dev_alloc(d_stageKps, (size_t)cap))) return rc;
+        // counts, key-points and descriptors of a one-frame call share ONE block ([256 bytes][cap key-points][cap descriptors]): the
+        // call brings all of it back in one device -> host copy
+        const size_t oK = 256, oD = oK + (((size_t)cap * sizeof(myslam_keypoint) + 255) & ~(size_t)255), total = oD + (size_t)cap * 32;
+        if ((rc = dev_alloc(d_stageOut, total))) return rc;
+        stageOutBytes = total; stageDescOff = oD;
+        d_stageCounts = reinterpret_cast<int32_t*>(d_stageOut);
+        d_stageKps = reinterpret_cast<myslam_keypoint*>(d_stageOut + oK);
+        d_stageDesc = d_stageOut + oD;
         if ((rc = dev_alloc(d_stageKps2, (size_t)cap))) return rc;
-        if ((rc = dev_alloc(d_stageDesc, (size_t)cap * 32))) return rc;
         if ((rc = dev_alloc(d_stageKeep, (size_t)cap))) return rc;
-        if (!d_stageCounts && (rc = dev_alloc(d_stageCounts, 4))) return rc;
         stageCap = cap;
     }
     return MYSLAM_OK;
@@ -469,7 +487,7 @@ int myslam_orb::ensure_stage(size_t imgBytes, size_t maskBytes, int cap) {
 
 void myslam_orb::free_all() {
     void* ptrs[] = {d_fastStat, d_octTab, d_pyr, d_blur, d_mask, d_cand, d_sort, d_candCount, d_selCount, d_status, d_sel, d_order, d_stageImg, d_stageMask,
-                    d_stageKps, d_stageKps2, d_stageDesc, d_stageKeep, d_stageCounts};
+                    d_stageOut, d_stageKps2, d_stageKeep};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); (void)hipEventDestroy(evFork); (void)hipEventDestroy(evJoin); aux = nullptr; }
     drop_host_graphs();
@@ -606,9 +624,11 @@ static int host_extract(myslam_orb* h, const uint8_t* img, int rows, int cols, i
     const int dcap = std::max(cap, std::max(h->full.totalOut, h->det.totalOut));
     const size_t imgBytes = (size_t)rows * step, maskBytes = mask ? imgBytes : 0;
     if ((rc = h->ensure_stage(imgBytes, maskBytes, dcap))) return rc;
-    // pinned staging: [image][mask][counts (8 bytes, 256 reserved)][key-points dcap][descriptors dcap]
-    const size_t oCnt = (imgBytes + maskBytes + 255) & ~(size_t)255, oKps = oCnt + 256, oDesc = oKps + (((size_t)dcap * sizeof(myslam_keypoint) + 255) & ~(size_t)255);
-    if ((rc = h->ensure_pin(oDesc + (size_t)dcap * 32))) return rc;
+    // pinned staging: [image][mask][a mirror of the device output block: counts (256 bytes) | key-points | descriptors]
+    const size_t oOut = (imgBytes + maskBytes + 255) & ~(size_t)255, oCnt = oOut, oKps = oOut + 256, oDesc = oOut + h->stageDescOff;
+    // what a call copies back: everything up to the last slot it can fill (Detect: no descriptors)
+    const size_t outBytes = detectOnly ? 256 + sizeof(myslam_keypoint) * (size_t)dcap : h->stageDescOff + (size_t)32 * dcap;
+    if ((rc = h->ensure_pin(oOut + h->stageOutBytes))) return rc;
     // the caller's stream, or a private one: host-pointer calls complete before they return, so the stream they run on is invisible —
     // work the caller queued on the handle's own stream that uses the handle's buffers (a _batch call) is waited for first
     hipStream_t caller = h->stream;
@@ -627,9 +647,7 @@ static int host_extract(myslam_orb* h, const uint8_t* img, int rows, int cols, i
         int r2 = h->run_batch(h->d_stageImg, 1, rows, cols, step, imgBytes, mask ? h->d_stageMask : nullptr,
                               h->d_stageKps, h->d_stageDesc, h->d_stageCounts, h->d_stageCounts + 1, dcap, detectOnly);
         if (r2) return r2;
-        MYSLAM_HIP_CHECK(hipMemcpyAsync(h->h_pin + oCnt, h->d_stageCounts, 8, hipMemcpyDeviceToHost, hs));
-        MYSLAM_HIP_CHECK(hipMemcpyAsync(h->h_pin + oKps, h->d_stageKps, sizeof(myslam_keypoint) * (size_t)dcap, hipMemcpyDeviceToHost, hs));
-        if (!detectOnly) MYSLAM_HIP_CHECK(hipMemcpyAsync(h->h_pin + oDesc, h->d_stageDesc, (size_t)32 * dcap, hipMemcpyDeviceToHost, hs));
+        MYSLAM_HIP_CHECK(hipMemcpyAsync(h->h_pin + oOut, h->d_stageOut, outBytes, hipMemcpyDeviceToHost, hs));      // counts + key-points (+ descriptors): one copy
         return MYSLAM_OK;
     };
     // a graph is replayable when nothing outside the capture takes part: no profiling events, no caller events, a complete call

@@ -2015,8 +2015,19 @@ __global__ void k_unpack_cands(const uint32_t* __restrict__ cand, int n, int32_t
 // ------------------------------------------------------------------------------------------------
 // K0: ingest level 0 from the caller's buffer (any pitch/alignment) into the 64-byte pitched plane
 // ------------------------------------------------------------------------------------------------
+// The per-call counters (candidate / selection counts, status words, FAST statistics) are cleared by the FIRST kernel of a call — this
+// one — instead of by hipMemsetAsync: no launch of their own (a one-frame call is a chain of short dependent launches), and kernel nodes
+// are the part of a captured HIP graph that replays reliably (memset nodes of a replayed graph left garbage in the counters on ROCm 7.2).
+struct ZeroArgs { uint32_t* p[4]; int n[4]; };
 __global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ src, int rows, int cols, int step, size_t sstride,
-                                                uint8_t* __restrict__ dst, int dpitch, size_t dstride, int tpr, int rpb) {
+                                                uint8_t* __restrict__ dst, int dpitch, size_t dstride, int tpr, int rpb, ZeroArgs z) {
+    {
+        const int T = (int)(gridDim.x * gridDim.y * gridDim.z) * 256;
+        const int tid = (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256 + (int)threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            for (int i = tid; i < z.n[k]; i += T) z.p[k][i] = 0u;
+    }
     // 16 destination bytes per thread (one aligned 16-byte store) from 5 aligned source dwords + v_alignbyte; tpr threads per row
     const int b = blockIdx.z;
     const int y = blockIdx.y * rpb + (int)threadIdx.x / tpr;
@@ -2037,11 +2048,7 @@ __global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ src,
     else { uint32_t w[4] = {o.x, o.y, o.z, o.w}; for (int j = 0; j < 4 && x16 + 4 * j < dpitch; j++) reinterpret_cast<uint32_t*>(q)[j] = w[j]; }
 }
 
-// the per-call counters (candidate / selection counts, status words, FAST statistics) are cleared by ONE small kernel instead of four
-// hipMemsetAsync calls: three launches fewer per call, and kernel nodes are the part of a captured HIP graph that replays reliably
-// (memset nodes of a replayed graph left garbage in the counters on ROCm 7.2)
-struct ZeroArgs { uint32_t* p[4]; int n[4]; };
-__global__ __launch_bounds__(256) void k_zero_u32(ZeroArgs a) {
+__global__ __launch_bounds__(256) void k_zero_u32(ZeroArgs a) {             // the same clearing on its own (debug entry points)
     const int i = blockIdx.x * 256 + threadIdx.x;
 #pragma unroll
     for (int k = 0; k < 4; k++)
@@ -2053,12 +2060,21 @@ void launch_zero_u32(uint32_t* p0, int n0, uint32_t* p1, int n1, uint32_t* p2, i
     if (n > 0) hipLaunchKernelGGL(k_zero_u32, dim3((n + 255) / 256), dim3(256), 0, s, a);
 }
 
-void launch_ingest(const uint8_t* src, int rows, int cols, int step, size_t sstride, uint8_t* dst, int dpitch,
-                   size_t dstride, int batch, hipStream_t s) {
+static void ingest_launch(const uint8_t* src, int rows, int cols, int step, size_t sstride, uint8_t* dst, int dpitch,
+                          size_t dstride, int batch, const ZeroArgs& z, hipStream_t s) {
     const int t = (cols + 15) / 16;
     const int tpr = t < 256 ? t : 256, rpb = t < 256 ? 256 / t : 1;
     dim3 grid((t + 255) / 256, (rows + rpb - 1) / rpb, batch);
-    hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, s, src, rows, cols, step, sstride, dst, dpitch, dstride, tpr, rpb);
+    hipLaunchKernelGGL(k_ingest, grid, dim3(256), 0, s, src, rows, cols, step, sstride, dst, dpitch, dstride, tpr, rpb, z);
+}
+void launch_ingest(const uint8_t* src, int rows, int cols, int step, size_t sstride, uint8_t* dst, int dpitch,
+                   size_t dstride, int batch, hipStream_t s) {
+    ingest_launch(src, rows, cols, step, sstride, dst, dpitch, dstride, batch, ZeroArgs{{nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}}, s);
+}
+// the call's first launch: level-0 ingest + the per-call counters
+void launch_ingest_clear(const uint8_t* src, int rows, int cols, int step, size_t sstride, uint8_t* dst, int dpitch, size_t dstride, int batch,
+                         uint32_t* p0, int n0, uint32_t* p1, int n1, uint32_t* p2, int n2, uint32_t* p3, int n3, hipStream_t s) {
+    ingest_launch(src, rows, cols, step, sstride, dst, dpitch, dstride, batch, ZeroArgs{{p0, p1, p2, p3}, {n0, n1, n2, n3}}, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2134,9 +2150,11 @@ void launch_describe(const OrbPlan& P, const uint8_t* pyr, const uint8_t* blur, 
                      int cap, int detectOnly, int batch, uint16_t* order, hipStream_t s) {
     const int slots = min(cap, P.totalOut);
     const int nchunk = (slots + KD_KPB - 1) / KD_KPB;
-    if (order && !detectOnly) hipLaunchKernelGGL(k_sel_order, dim3(P.nlevels, batch), dim3(256), 0, s, P, selOut, selCount, order, batch);
+    // the tile-order permutation pays when thousands of windows compete for L1 / L2; a handful of images is a few dozen blocks: list order
+    const bool tiled = order && !detectOnly && batch >= 8;
+    if (tiled) hipLaunchKernelGGL(k_sel_order, dim3(P.nlevels, batch), dim3(256), 0, s, P, selOut, selCount, order, batch);
     hipLaunchKernelGGL(k_describe2, dim3(nchunk * batch), dim3(256), 0, s, P, pyr, blur, pyrStride, selOut, selCount,
-                       kps, desc, counts, status, cap, nchunk, batch, detectOnly, detectOnly ? nullptr : order);
+                       kps, desc, counts, status, cap, nchunk, batch, detectOnly, tiled ? order : nullptr);
 }
 
 void launch_screen(const OrbPlan& P, const uint8_t* pyr, myslam_keypoint* kin, int n, myslam_keypoint* kout, uint8_t* keep,
