@@ -1183,6 +1183,7 @@ __device__ __forceinline__ void child_bounds(const OctLds& L, uint32_t* __restri
     }
 }
 
+constexpr int OCT_FL = 4;              // candidates in flight per thread in the two candidate passes (8: same time, batched and one-frame)
 __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __restrict__ cand,
                                                const int32_t* __restrict__ candCount, uint32_t* __restrict__ sortbuf,
                                                const uint32_t* __restrict__ octTab,
@@ -1267,14 +1268,14 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
         auto YC = [&](uint32_t i) -> uint32_t { if constexpr (LDS) return s_tab[oyc + i]; else return ycode[i]; };
         auto XL = [&](uint32_t i) -> uint32_t { if constexpr (LDS) return s_tab[oxl + i]; else return xcell[i]; };
         auto YL = [&](uint32_t i) -> uint32_t { if constexpr (LDS) return s_tab[oyl + i]; else return ycell[i]; };
-        for (int i0 = t; i0 < n; i0 += 4 * OT) {                       // 4 keys in flight per thread: the pass is latency-bound
-            uint32_t pay[4], cx[4], cy[4];
+        for (int i0 = t; i0 < n; i0 += OCT_FL * OT) {                  // OCT_FL keys in flight per thread: the pass is latency-bound
+            uint32_t pay[OCT_FL], cx[OCT_FL], cy[OCT_FL];
 #pragma unroll
-            for (int u = 0; u < 4; u++) pay[u] = (i0 + u * OT < n) ? keys[i0 + u * OT] : 0u;
+            for (int u = 0; u < OCT_FL; u++) pay[u] = (i0 + u * OT < n) ? keys[i0 + u * OT] : 0u;
 #pragma unroll
-            for (int u = 0; u < 4; u++) { cx[u] = XC((pay[u] >> 8) & 0xfff); cy[u] = YC(pay[u] >> 20); }
+            for (int u = 0; u < OCT_FL; u++) { cx[u] = XC((pay[u] >> 8) & 0xfff); cy[u] = YC(pay[u] >> 20); }
 #pragma unroll
-            for (int u = 0; u < 4; u++)
+            for (int u = 0; u < OCT_FL; u++)
                 if (i0 + u * OT < n) atomicAdd(&s_cursor[(cx[u] | cy[u]) >> bsh], 1u);     // code == oct_code(px, py, g), tabulated per axis at plan time
         }
         __syncthreads();
@@ -1295,18 +1296,18 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
             if (t == 0) L.offs[NB] = (uint32_t)n;
         }
         __syncthreads();
-        for (int i0 = t; i0 < n; i0 += 4 * OT) {
-            uint32_t pay[4], cx[4], cy[4], qx[4], qy[4];
+        for (int i0 = t; i0 < n; i0 += OCT_FL * OT) {
+            uint32_t pay[OCT_FL], cx[OCT_FL], cy[OCT_FL], qx[OCT_FL], qy[OCT_FL];
 #pragma unroll
-            for (int u = 0; u < 4; u++) pay[u] = (i0 + u * OT < n) ? keys[i0 + u * OT] : 0u;
+            for (int u = 0; u < OCT_FL; u++) pay[u] = (i0 + u * OT < n) ? keys[i0 + u * OT] : 0u;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < OCT_FL; u++) {
                 const uint32_t px = (pay[u] >> 8) & 0xfff, py = pay[u] >> 20;
                 cx[u] = XC(px); cy[u] = YC(py);
                 qx[u] = rankkey ? XL(px) : 0u; qy[u] = rankkey ? YL(py) : 0u;
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < OCT_FL; u++) {
                 if (i0 + u * OT >= n) continue;
                 uint32_t low = pay[u];
                 if (rankkey) {
