@@ -1075,20 +1075,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
 // Tie-break of the size sort (:731 sorts pair<int,Node*>, i.e. by heap address) = creation order, the
 // same deterministic choice the oracle makes.
 // ------------------------------------------------------------------------------------------------
-constexpr int OT = 512;       // threads per (image, level) block: the key passes (codes, scatter, best key) are latency-bound at 4 waves
+// threads per (image, level) block (template parameter OT of k_octree): the passes are separated by block barriers, so a block's time is
+// its slowest wave's.  Batches run 256-thread blocks (five instead of four blocks per CU by LDS, +0.8 % frames/s under the pipeline
+// although the kernel alone is slower, 0.87 against 0.78 ms per 1024 images); a lone frame has only nlevels blocks in flight and runs
+// them 512 wide (53 us instead of 75)
 constexpr int OT_MAXB = 1024;        // buckets of the counting sort
 
+// inclusive prefix sum of a 64-bit value over the 64 lanes on the DPP network (both halves moved, one 64-bit add per step; lanes
+// without a source add zero): 24 VALU operations instead of 12 dependent trips through the LDS crossbar
 __device__ __forceinline__ uint64_t wave_incl_scan64(uint64_t v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint64_t n = __shfl_up(v, o, 64);
-        if (lane >= o) v += n;
+#define MYSLAM_SCAN64_STEP(CTRL, ROWS)                                                                                   \
+    {                                                                                                                    \
+        const uint32_t l2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROWS, 0xf, false);          \
+        const uint32_t h2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROWS, 0xf, false);  \
+        v += ((uint64_t)h2 << 32) | l2;                                                                                  \
     }
+    MYSLAM_SCAN64_STEP(0x111, 0xf)          // row_shr:1
+    MYSLAM_SCAN64_STEP(0x112, 0xf)          // row_shr:2
+    MYSLAM_SCAN64_STEP(0x114, 0xf)          // row_shr:4
+    MYSLAM_SCAN64_STEP(0x118, 0xf)          // row_shr:8
+    MYSLAM_SCAN64_STEP(0x142, 0xa)          // row_bcast15 -> rows 1, 3
+    MYSLAM_SCAN64_STEP(0x143, 0xc)          // row_bcast31 -> rows 2, 3
+#undef MYSLAM_SCAN64_STEP
     return v;
 }
 
 // exclusive block scan of a packed 64-bit counter; s_w = OT/64 uint64 of LDS scratch
+template <int OT>
 __device__ __forceinline__ uint64_t block_excl_scan64(uint64_t v, uint64_t* s_w, uint64_t& total) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const uint64_t incl = wave_incl_scan64(v);
@@ -1183,7 +1196,17 @@ __device__ __forceinline__ void child_bounds(const OctLds& L, uint32_t* __restri
     }
 }
 
+// maximum over aligned groups of 8 lanes (a half row of the DPP network: mirror, then the two quad exchanges), in every lane of the group
+__device__ __forceinline__ uint32_t half_row_max_u32(uint32_t v) {
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false));      // row_half_mirror: lane i <- lane 7 - i
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false));       // quad_perm [1, 0, 3, 2]
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, false));       // quad_perm [2, 3, 0, 1]
+    return v;
+}
+
+constexpr int OCT_WIDE_BELOW = 64;      // batches smaller than this run 512-thread blocks
 constexpr int OCT_FL = 4;              // candidates in flight per thread in the two candidate passes (8: same time, batched and one-frame)
+template <int OT>
 __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __restrict__ cand,
                                                const int32_t* __restrict__ candCount, uint32_t* __restrict__ sortbuf,
                                                const uint32_t* __restrict__ octTab,
@@ -1286,7 +1309,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
             uint64_t sum = 0;
             for (int i = beg; i < end; i++) sum += s_cursor[i];
             uint64_t total;
-            uint64_t run = block_excl_scan64(sum, s_w, total);
+            uint64_t run = block_excl_scan64<OT>(sum, s_w, total);
             for (int i = beg; i < end; i++) {
                 const uint32_t h = s_cursor[i];
                 L.offs[i] = (uint32_t)run;
@@ -1365,7 +1388,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
                 L.kk[p] = (uint8_t)k;
             }
             uint64_t total;
-            uint64_t run = block_excl_scan64(packed, s_w, total);
+            uint64_t run = block_excl_scan64<OT>(packed, s_w, total);
             const int Ktot = (int)(total & 0x1fffff), Ntot = (int)((total >> 21) & 0x1fffff), Btot = (int)(total >> 42);
             const int nxt = cur ^ 1, cnxt = ccur ^ 1;
             for (int p = beg; p < end; p++) {
@@ -1446,7 +1469,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
                 packed += (uint64_t)k | ((uint64_t)big << 32);
             }
             uint64_t total;
-            uint64_t run = block_excl_scan64(packed, s_w, total);
+            uint64_t run = block_excl_scan64<OT>(packed, s_w, total);
             for (int j = beg; j < end; j++) {
                 const int k = L.kk[j] & 15, big = L.kk[j] >> 4;
                 run += (uint64_t)k | ((uint64_t)big << 32);
@@ -1505,7 +1528,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
                 uint64_t un = 0;
                 for (int p = pb; p < pe; p++) un += (L.mark[p] == 0);
                 uint64_t tot2;
-                uint64_t ex = block_excl_scan64(un, s_w, tot2);
+                uint64_t ex = block_excl_scan64<OT>(un, s_w, tot2);
                 for (int p = pb; p < pe; p++) {
                     if (L.mark[p] == 0) {
                         L.lo(nxt)[Kc + (int)ex] = L.lo(cur)[p]; L.hi(nxt)[Kc + (int)ex] = L.hi(cur)[p];
@@ -1525,23 +1548,35 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
         }
     }
 
-    // ---- D: best key per node (:788-807), list order.  16 lanes per node.  Pass 1 finds the node's largest response;
+    // ---- D: best key per node (:788-807), list order.  8 or 16 lanes per node.  Payload levels: pass 1 finds the node's largest response;
     // pass 2 breaks ties by the reference's candidate order (cell-major, row-major inside a cell), so the cell tables
     // are only read for keys that carry that response. ----
     const int m = s_i[0];
     uint32_t* out = selOut + (size_t)b * P.totalOut + g.outBase;
     {
-        const int sub = t & 15;
+        // rank-key levels: 8 lanes per node; otherwise 16
+        const int GLN = rankkey ? 8 : 16;
+        const int sub = t & (GLN - 1);
         const int mm = min(m, g.nodeCap);
-        for (int p0 = (t >> 4); p0 < ((mm + OT / 16 - 1) / (OT / 16)) * (OT / 16); p0 += OT / 16) {
+        const int ngrp = OT / GLN;
+        for (int p0 = t / GLN; p0 < ((mm + ngrp - 1) / ngrp) * ngrp; p0 += ngrp) {
             const bool live = p0 < mm;
             const int lo = live ? (int)L.lo(cur)[p0] : 0, hi = live ? (int)L.hi(cur)[p0] : 0;
             if (rankkey) {                                               // block-uniform
+                // four consecutive keys per lane and load (16-byte loads at 4-byte alignment; a load may run up to 3 entries past the node,
+                // into the next node's keys or the code array behind S: masked), four loads in flight: 128 keys per round trip and group
                 uint32_t bk = 0;
 #pragma unroll 4
-                for (int i = lo + sub; i < hi; i += 16) bk = max(bk, S[i]);
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) bk = max(bk, (uint32_t)__shfl_xor((int)bk, o, 64));
+                for (int i = lo + 4 * sub; i < hi; i += 32) {
+                    uint4 k4;
+                    __builtin_memcpy(&k4, S + i, 16);
+                    const int left = hi - i;                             // >= 1
+                    bk = max(bk, k4.x);
+                    bk = max(bk, left > 1 ? k4.y : 0u);
+                    bk = max(bk, left > 2 ? k4.z : 0u);
+                    bk = max(bk, left > 3 ? k4.w : 0u);
+                }
+                bk = half_row_max_u32(bk);
                 if (live && sub == 0) {
                     const uint32_t rank = 0x3fffffu - (bk & 0x3fffffu), cell = rank >> 12;
                     const int ci = (int)(((float)cell + 0.5f) * inv_ncols), cj = (int)cell - ci * g.nCols;
@@ -2142,8 +2177,12 @@ void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCo
     // The limit is state of the FUNCTION (per device and process), not of a launch: it is always raised to the device's whole LDS, never
     // to this launch's own size — a handle with a smaller plan (or another thread) would otherwise lower it under a launch that is still
     // to come, e.g. the replay of a captured HIP graph (a memory fault, found with two extractor handles of different budgets).
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(k_octree, dim3(P.nlevels, batch), dim3(OT), lds, s, P, cand, candCount, sortbuf, octTab, selOut, selCount, status, ncmax);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (batch >= OCT_WIDE_BELOW)
+        hipLaunchKernelGGL(k_octree<256>, dim3(P.nlevels, batch), dim3(256), lds, s, P, cand, candCount, sortbuf, octTab, selOut, selCount, status, ncmax);
+    else
+        hipLaunchKernelGGL(k_octree<512>, dim3(P.nlevels, batch), dim3(512), lds, s, P, cand, candCount, sortbuf, octTab, selOut, selCount, status, ncmax);
 }
 
 void launch_describe(const OrbPlan& P, const uint8_t* pyr, const uint8_t* blur, size_t pyrStride, const uint32_t* selOut,
