@@ -212,7 +212,7 @@ int myslam_orb::make_plan(int r, int c) {
         g.outBase = outBase; outBase += g.nodeCap;
         g.scale = scale[l];
         g.scaledPatch = (float)(int)(PATCH_SIZE * scale[l]);                            // :891
-        g.imgOff = imgOff; imgOff += align_up((size_t)g.pitch * g.h, 256);
+        g.imgOff = imgOff; imgOff += align_up((size_t)g.pitch * align_up((size_t)g.h, 8), 256);      // whole 8-row tiles: the blurred planes are tiled (orb_plan.h)
         g.keyOff = keyOff; keyOff += g.keyCap;
     }
     P.ncells = cellBase; P.nstrips = stripBase; P.totalKeyCap = (int)keyOff; P.totalOut = outBase; P.pyrBytes = imgOff;
@@ -288,7 +288,7 @@ int myslam_orb::ensure(int batch, int r, int c, bool needMask) {
         gen++;
         int rc;
         if ((rc = dev_alloc(d_pyr, (size_t)batch * full.pyrBytes + 64))) return rc;      // + 64: the resize kernel's 8-byte row loads may run 7 bytes past a row
-        if ((rc = dev_alloc(d_blur, (size_t)batch * full.pyrBytes))) return rc;
+        if ((rc = dev_alloc(d_blur, (size_t)batch * full.pyrBytes + 4096))) return rc;     // + 4096: a descriptor window's fourth tile column may lie past the last plane
         if ((rc = dev_alloc(d_cand, (size_t)batch * full.totalKeyCap))) return rc;
         if ((rc = dev_alloc(d_sort, (size_t)batch * full.totalKeyCap * 2))) return rc;
         if ((rc = dev_alloc(d_candCount, (size_t)batch * MAXL))) return rc;
@@ -348,6 +348,7 @@ BlurArgs myslam_orb::level_blur_args(int l) const {
     a.src = d_pyr + P.lv[l].imgOff; a.dst = d_blur + P.lv[l].imgOff;
     a.w = P.lv[l].w; a.h = P.lv[l].h; a.spitch = a.dpitch = P.lv[l].pitch; a.sstride = a.dstride = P.pyrBytes;
     a.src0 = nullptr; a.spitch0 = 0; a.n0 = 0; a.sstride0 = 0;
+    a.dtiled = 1;
     if (tapsSet) memcpy(a.q, taps, sizeof(taps)); else gauss_q8(0, a.q);
     return a;
 }
@@ -758,6 +759,16 @@ int myslam_orb_calc_descriptors(myslam_orb* h, const uint8_t* img, int rows, int
     return MYSLAM_OK;
 }
 
+// debug taps: a blurred plane (16 x 8-pixel tiles on the device, orb_plan.h) as rows of out_step bytes
+static int download_tiled_plane(const uint8_t* d_plane, const LevelGeom& g, uint8_t* out, int out_step, hipStream_t stream) {
+    std::vector<uint8_t> tmp((size_t)g.pitch * align_up((size_t)g.h, 8));
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(tmp.data(), d_plane, tmp.size(), hipMemcpyDeviceToHost, stream));
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(stream));
+    for (int y = 0; y < g.h; y++)
+        for (int x = 0; x < g.w; x++) out[(size_t)y * out_step + x] = tmp[tiled_off(x, y, g.pitch)];
+    return MYSLAM_OK;
+}
+
 int myslam_orb_debug_pyramid(myslam_orb* h, const uint8_t* img, int rows, int cols, int step, int level, int blurred,
                              uint8_t* out, int out_step, int* w, int* hgt) {
     if (!h || !img || level < 0 || level >= h->nlevels) return MYSLAM_ERR_INVALID;
@@ -769,8 +780,8 @@ int myslam_orb_debug_pyramid(myslam_orb* h, const uint8_t* img, int rows, int co
     if (hgt) *hgt = g.h;
     if (out) {
         if (out_step < g.w) return MYSLAM_ERR_INVALID;
-        MYSLAM_HIP_CHECK(hipMemcpy2DAsync(out, out_step, (blurred ? h->d_blur : h->d_pyr) + g.imgOff, g.pitch, g.w, g.h,
-                                          hipMemcpyDeviceToHost, h->stream));
+        if (blurred) return download_tiled_plane(h->d_blur + g.imgOff, g, out, out_step, h->stream);
+        MYSLAM_HIP_CHECK(hipMemcpy2DAsync(out, out_step, h->d_pyr + g.imgOff, g.pitch, g.w, g.h, hipMemcpyDeviceToHost, h->stream));
     }
     MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
     return MYSLAM_OK;
@@ -825,6 +836,7 @@ int myslam_orb_debug_readback(myslam_orb* h, int what, int b, int level, void* o
         case 0: case 1: {
             if (cap_bytes < (size_t)g.w * g.h) return MYSLAM_ERR_CAPACITY;
             const uint8_t* base = (what ? h->d_blur : h->d_pyr) + (size_t)b * h->full.pyrBytes + g.imgOff;
+            if (what) return download_tiled_plane(base, g, static_cast<uint8_t*>(out), g.w, h->stream);
             MYSLAM_HIP_CHECK(hipMemcpy2D(out, g.w, base, g.pitch, g.w, g.h, hipMemcpyDeviceToHost));
             return MYSLAM_OK;
         }

@@ -299,6 +299,12 @@ __global__ __launch_bounds__(256) void k_blur7_dot(BlurArgs a) {
         }
         const uint32_t lo = pack4_sat_hi16(S0[0], S0[1], S0[2], S0[3]), hi = pack4_sat_hi16(S1[0], S1[1], S1[2], S1[3]);
         // destination pitch is a multiple of 64: the 4-byte store never leaves the row; bytes past w are padding
+        if (a.dtiled) {                                                  // oy is even: both rows lie in the same tile
+            uint8_t* o = dst + tiled_off(ox, oy, a.dpitch);
+            *reinterpret_cast<uint32_t*>(o) = lo;
+            if (oy + 1 < a.h) *reinterpret_cast<uint32_t*>(o + 16) = hi;
+            continue;
+        }
         *reinterpret_cast<uint32_t*>(dst + (size_t)oy * a.dpitch + ox) = lo;
         if (oy + 1 < a.h) *reinterpret_cast<uint32_t*>(dst + (size_t)(oy + 1) * a.dpitch + ox) = hi;
     }
@@ -316,7 +322,11 @@ __device__ __forceinline__ uint32_t dpp_wave_shl1(uint32_t v) { return (uint32_t
 // All strip-capable levels of a pyramid in ONE launch (one wave per 256-column x 32-row band of some level): a one-frame call spends
 // more time between its launches than inside them (8 blur launches -> 1), and the small levels fill the gaps of the large ones.
 struct BlurMulti { BlurArgs a[MAXL]; int wave0[MAXL + 1]; int nstrips[MAXL]; int n; };
+constexpr int B3_TS = 144;                     // LDS bytes per staged tile (128 + 16: the dword writes of a wave then spread over all banks)
 __global__ __launch_bounds__(256) void k_blur7_strip(BlurMulti M) {
+    // tiled destinations: a wave parks 8 output rows of its 256 columns (16 tiles) here and writes them out as 2 KB of whole cache
+    // lines — two 16-byte stores per lane instead of eight dword stores that each touch 16 lines
+    __shared__ __attribute__((aligned(16))) uint8_t s_tl[4][16 * B3_TS];
     const int lane = threadIdx.x & 63;
     const int gw = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));    // wave id over all levels; scalar: row addressing goes to the SALU
     if (gw >= M.wave0[M.n]) return;
@@ -404,7 +414,24 @@ __global__ __launch_bounds__(256) void k_blur7_strip(BlurMulti M) {
         h[2] = __builtin_amdgcn_udot4(A2, qa, __builtin_amdgcn_udot4(B2, qb, 0u, false), false);
         h[3] = __builtin_amdgcn_udot4(A3, qa, __builtin_amdgcn_udot4(B3, qb, 0u, false), false);
     };
+    uint8_t* const tl = s_tl[threadIdx.x >> 6];
+    // the parked tile row -> memory: chunk c = lane + 64 j of the 128 (tile, row) chunks in memory order; tiles past the row pitch do not exist
+    auto flush_tiles = [&](int ty) __attribute__((always_inline)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint8_t* o = dst + (size_t)ty * a.dpitch * 8 + (size_t)strip * 2048;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int c = lane + 64 * j;
+            const uint4 v = *reinterpret_cast<const uint4*>(tl + (c >> 3) * B3_TS + ((c & 7) << 4));
+            if (strip * 256 + 16 * (c >> 3) < a.dpitch) *reinterpret_cast<uint4*>(o + 16 * c) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
     auto run = [&](auto edge_tag) {
+        int dirty_ty = -1;                                     // tile row with parked rows that are not written out yet (wave-uniform)
         uint32_t D[4][4];
 #pragma unroll
         for (int u = 0; u < 4; u++)
@@ -437,7 +464,13 @@ __global__ __launch_bounds__(256) void k_blur7_strip(BlurMulti M) {
                             S0[k] = s0; S1[k] = s1;
                         }
                         const uint32_t lo = pack4_sat_hi16(S0[0], S0[1], S0[2], S0[3]), hi = pack4_sat_hi16(S1[0], S1[1], S1[2], S1[3]);
-                        if (has) {      // destination pitch is a multiple of 64: the dword never leaves the row; bytes past w are padding
+                        if (a.dtiled) {                                  // wave-uniform.  Rows oy, oy + 1 of the tile row: oy & 7 = 2 ((u + 1) & 3)
+                            uint8_t* w = tl + (lane >> 2) * B3_TS + ((lane & 3) << 2) + 32 * ((u + 1) & 3);
+                            *reinterpret_cast<uint32_t*>(w) = lo;
+                            *reinterpret_cast<uint32_t*>(w + 16) = hi;       // (row h of a plane whose height is odd: inside the padded tile, never read)
+                            dirty_ty = oy >> 3;
+                            if (u == 2) { flush_tiles(dirty_ty); dirty_ty = -1; }
+                        } else if (has) {      // destination pitch is a multiple of 64: the dword never leaves the row; bytes past w are padding
                             *reinterpret_cast<uint32_t*>(dst + (size_t)oy * a.dpitch + x0) = lo;
                             if (oy + 1 < a.h) *reinterpret_cast<uint32_t*>(dst + (size_t)(oy + 1) * a.dpitch + x0) = hi;
                         }
@@ -446,6 +479,7 @@ __global__ __launch_bounds__(256) void k_blur7_strip(BlurMulti M) {
                 }
             }
         }
+        if (dirty_ty >= 0) flush_tiles(dirty_ty);              // the band's last tile row (fewer than 8 rows: the others are padding)
     };
     // interior strips: no lane sees an image border, the neighbour dwords of lanes 0 / 63 are plain loads
     const bool interior = strip > 0 && (strip + 1) * 256 + 4 <= a.w;
@@ -1687,6 +1721,8 @@ __device__ __forceinline__ float wave_ic_angle(const uint8_t* __restrict__ img, 
 }
 
 // 256-bit rBRIEF; lane l produces bits 4l..4l+3; result bytes assembled with shuffles; lanes 0,8,..,56 hold a u32
+// TILED: img is a blurred plane of the extractor (16 x 8-pixel tiles, tiled_off)
+template <bool TILED = false>
 __device__ __forceinline__ uint32_t wave_brief(const uint8_t* __restrict__ img, int pitch, int x, int y, float angle_deg) {
     const int lane = threadIdx.x & 63;
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
@@ -1703,7 +1739,8 @@ __device__ __forceinline__ uint32_t wave_brief(const uint8_t* __restrict__ img, 
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
         const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = center[r0 * pitch + c0], t1 = center[r1 * pitch + c1];
+        const int t0 = TILED ? img[tiled_off(x + c0, y + r0, pitch)] : center[r0 * pitch + c0];
+        const int t1 = TILED ? img[tiled_off(x + c1, y + r1, pitch)] : center[r1 * pitch + c1];
         nib |= (uint32_t)(t0 < t1) << j;
     }
     uint32_t byte = nib | (__shfl_down(nib, 1, 64) << 4);            // valid on even lanes
@@ -1713,13 +1750,14 @@ __device__ __forceinline__ uint32_t wave_brief(const uint8_t* __restrict__ img, 
 }
 
 // LDS window of one keypoint (one wave): the 37x37 window of the blurred level that the steered 31x31 BRIEF pattern can reach
-// (|rotated coord| <= 18), fetched as four ALIGNED 16-byte pieces per row (15 + 37 <= 64 bytes), lane = (row, piece).  The kernel is
-// bound by the texture addresser (TA_BUSY 72-78 % of its run time), which works off about one L1 access per cycle and merges the lanes
-// of a load only when they fall into aligned groups: dword-per-lane loads over 44-byte rows went out as ~55 accesses per instruction
-// (PMC: 486 L1 accesses per key-point), aligned 16-byte pieces are 3 instead of 7 instructions and one access per lane (315).
+// (|rotated coord| <= 18), 64 bytes per row from a 16-byte aligned column (15 + 37 <= 64).  The kernel waits for L1 line fills and the
+// texture addresser (TA_BUSY 72-78 % of its run time; tools/ta_probe.hip: a vector load costs max(16, ~1.25 x lines) cycles of a CU when
+// the lines are in L1 and ~2.6-3 per line when they come from L2).  Round 2 fetched four aligned 16-byte pieces per row, lane = (row, piece):
+// 3 instead of 7 instructions, ~55 lines per key-point; the blurred planes are now TILED (16 x 8 pixels per cache line, orb_plan.h), a
+// window is 20-24 lines fetched as 512-byte runs (1.31 -> 1.16 ms per 1024 images).
 constexpr int DB_R = 18, DB_ROWS = 2 * DB_R + 1, DB_P = 64;                       // row pitch of the LDS window (bytes)
 constexpr int DB_N = DB_ROWS * 4;                                               // 148 pieces of 16 bytes
-constexpr int DB_IT = (DB_N + 63) / 64;                                         // 3 loads per lane
+constexpr int DB_IT = 3;                                                        // 6 tile rows x 4 tile columns x 8 rows = 192 chunks of 16 bytes: 3 loads per lane
 
 // K5: orientation + steered BRIEF, phased per block of 64 keypoints so that nothing scalar runs 64-wide:
 //   0  thread per keypoint: slot -> (level, x, y, response)
@@ -1936,18 +1974,27 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
         const int x = __builtin_amdgcn_readfirstlane(s_x[k]), y = __builtin_amdgcn_readfirstlane(s_y[k]);
         const float ca = s_ca[k], sb = s_sb[k];
         const int xb0 = (x - DB_R) & ~15, offB = (x - DB_R) - xb0;
-        // window origin: wave-uniform 64-bit base + a 32-bit lane offset (piece i = lane + 64 q: row i >> 2, 16-byte piece i & 3).
-        // The last piece of a row may reach past the image width into the row's padding or the next row: never read by a test point.
-        const uint8_t* bl = blur + (size_t)b * pyrStride + g.imgOff + (size_t)(y - DB_R) * g.pitch + xb0;
+        // The window in the TILED blurred plane: 4 tile columns (64 bytes at a 16-byte aligned column) x the 5 or 6 tile rows that hold
+        // image rows y - 18 .. y + 18; chunk i = lane + 64 q in memory order (tile row i >> 5, tile column (i >> 3) & 3, row of the tile
+        // i & 7): lanes 0-31 and 32-63 of a load each read 512 contiguous bytes = 4 whole cache lines; chunks of rows outside the window
+        // are not requested.  The fourth tile column may lie past the image width (row padding or the next tile row): never read by a
+        // test point.  The chunks land in LDS in row-major order (DB_P bytes per window row), where the test points address them.
+        const int y0 = y - DB_R;
+        const uint8_t* bl = blur + (size_t)b * pyrStride + g.imgOff + (size_t)(y0 >> 3) * g.pitch * 8 + (size_t)(xb0 >> 4) * 128;
         uint4 rb[DB_IT];
 #pragma unroll
         for (int q = 0; q < DB_IT; q++) {
             const int i = lane + 64 * q;
-            rb[q] = (i < DB_N) ? *reinterpret_cast<const uint4*>(bl + (uint32_t)(__mul24(i >> 2, g.pitch) + 16 * (i & 3))) : make_uint4(0, 0, 0, 0);
+            const int wr = ((i >> 5) << 3) + (i & 7) - (y0 & 7);              // window row of the chunk
+            rb[q] = (wr >= 0 && wr < DB_ROWS) ? *reinterpret_cast<const uint4*>(bl + (uint32_t)(__mul24(i >> 5, g.pitch * 8) + 16 * (i & 31))) : make_uint4(0, 0, 0, 0);
         }
         __builtin_amdgcn_wave_barrier();                                  // previous keypoint's window reads are done (same wave)
 #pragma unroll
-        for (int q = 0; q < DB_IT; q++) { const int i = lane + 64 * q; if (i < DB_N) s_b[wave][i] = rb[q]; }
+        for (int q = 0; q < DB_IT; q++) {
+            const int i = lane + 64 * q;
+            const int wr = ((i >> 5) << 3) + (i & 7) - (y0 & 7);
+            if (wr >= 0 && wr < DB_ROWS) s_b[wave][wr * 4 + ((i >> 3) & 3)] = rb[q];
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -2036,7 +2083,7 @@ __global__ __launch_bounds__(256) void k_calc_desc(OrbPlan P, const uint8_t* __r
     const int level = min(max(k.octave, 0), P.nlevels - 1);
     const LevelGeom& g = P.lv[level];
     const int px = __float2int_rn(__fdiv_rn(k.x, g.scale)), py = __float2int_rn(__fdiv_rn(k.y, g.scale));
-    const uint32_t w = wave_brief(blur + g.imgOff, g.pitch, px, py, k.angle);
+    const uint32_t w = wave_brief<true>(blur + g.imgOff, g.pitch, px, py, k.angle);
     if ((lane & 7) == 0) reinterpret_cast<uint32_t*>(desc + (size_t)i * 32)[lane >> 3] = w;
 }
 

@@ -63,6 +63,15 @@ struct BlurArgs {
     const uint8_t* src; uint8_t* dst; int w, h, spitch, dpitch; size_t sstride, dstride;
     const uint8_t* src0 = nullptr; int spitch0 = 0, n0 = 0; size_t sstride0 = 0;      // images b < n0 read their source plane here (level 0 in place; any alignment)
     int q[7];                                    // Q8 taps, sum <= 257
+    int dtiled = 0;                              // destination in 16 x 8-pixel tiles (tiled_off): the extractor's blurred planes
 };
+
+// The blurred planes of the extractor are stored in tiles of 16 x 8 pixels = one 128-byte cache line each (tile rows of pitch / 16 tiles,
+// pitch a multiple of 64; plane heights rounded up to 8 rows): their only reader is the descriptor kernel, which fetches a 37 x 37
+// window per key-point — 20-24 lines as tiles against ~55 (37 rows x 1.5) in row-major order, and the L1 line fills are what that
+// kernel waits for (tools/ta_probe.hip).  Byte offset of pixel (x, y) in a plane:
+__host__ __device__ inline size_t tiled_off(int x, int y, int pitch) {
+    return (size_t)(y >> 3) * (size_t)pitch * 8 + (size_t)((x >> 4) << 7) + (size_t)(((y & 7) << 4) | (x & 15));
+}
 
 }  // namespace myslam_hip
