@@ -136,12 +136,28 @@ __global__ __launch_bounds__(256) void k_resize_strip(ResizeArgs a, int nstrips,
         const int rlast = min(max(__builtin_amdgcn_readlane(ysy, l0 + dy1 - 1 - dy0) + 1, 0), a.sh - 1);
         const int nrows = rlast - rfirst + 1;                        // <= RS_MAXR (checked by the launcher)
         uint2 raw8[RS_MAXR];
+        if (ext) {                                                   // block-uniform: a caller's rows may start at any byte
 #pragma unroll
-        for (int rr = 0; rr < RS_MAXR; rr++) {
-            const uint8_t* row = src + (size_t)(rfirst + min(rr, nrows - 1)) * spitch;
-            raw8[rr] = make_uint2(0u, 0u);
-            // at the right border sx = sw-1 and the weight of sx+1 is 0 (OpenCV clamps fx there): the bytes past the row are never weighted
-            if (has && rr < nrows) __builtin_memcpy(&raw8[rr], row + sx[0], 8);
+            for (int rr = 0; rr < RS_MAXR; rr++) {
+                const uint8_t* row = src + (size_t)(rfirst + min(rr, nrows - 1)) * spitch;
+                raw8[rr] = make_uint2(0u, 0u);
+                // at the right border sx = sw-1 and the weight of sx+1 is 0 (OpenCV clamps fx there): the bytes past the row are never weighted
+                if (has && rr < nrows) __builtin_memcpy(&raw8[rr], row + sx[0], 8);
+            }
+        } else {
+            // pyramid planes: 12 bytes from the dword-aligned address below sx[0], shifted into place with two v_alignbyte — an 8-byte load
+            // at BYTE alignment costs the texture addresser 32 cycles per wave instruction, the aligned 12-byte one 17.7 (tools/ta_probe.hip)
+            uint32_t raw12[RS_MAXR][3];
+            const uint32_t xal = (uint32_t)sx[0] & ~3u, sh = (uint32_t)sx[0] & 3u;
+#pragma unroll
+            for (int rr = 0; rr < RS_MAXR; rr++) {
+                const uint8_t* row = src + (size_t)(rfirst + min(rr, nrows - 1)) * spitch;
+                raw12[rr][0] = raw12[rr][1] = raw12[rr][2] = 0u;
+                if (has && rr < nrows) __builtin_memcpy(raw12[rr], __builtin_assume_aligned(row + xal, 4), 12);
+            }
+#pragma unroll
+            for (int rr = 0; rr < RS_MAXR; rr++)
+                raw8[rr] = make_uint2(__builtin_amdgcn_alignbyte(raw12[rr][1], raw12[rr][0], sh), __builtin_amdgcn_alignbyte(raw12[rr][2], raw12[rr][1], sh));
         }
         // horizontal pass: raw[rr][k] <- 16 x the row-cache value (<= 32640) of source row rfirst + rr at this lane's 4 columns
         // (the low four bits are cleared instead of shifted out: the vertical step multiplies 24-bit operands and keeps bits 32..)

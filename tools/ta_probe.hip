@@ -27,12 +27,14 @@ enum Shape {
     X4_ROWPAIR_A4,       // as x4_rowpair with the column at 4 (mod 16)
     X4_ROWPAIR_A8,       // ... at 8 (mod 16)
     X4_ROWPAIR_A16,      // ... at 0 (mod 16)
+    X2_GATHER_BYTE,      // the resize gather as the kernel issued it until round 3: 8 B per lane at BYTE alignment (x = 4.75 lane)
+    X3_GATHER,           // 12 B per lane, 4-byte aligned, same stride (the aligned replacement)
     X2_GATHER,           // 8 B per lane at x = 5 lane / 4-ish (the resize kernel's horizontal gather: stride 1.2 pixels x 4)
     NSHAPES
 };
 static const char* NAMES[NSHAPES] = {"x4_rowquad16", "x4_rowquad_aligned64", "x4_rowpair_anycol", "x4_linear_1KB", "x2_row8", "x1_row16", "x1_row11_44B",
-                                     "x1_linear_256B", "u8_window_scatter", "x4_rowquad16_3of4_lanes", "x4_rowpair_col4mod16", "x4_rowpair_col8mod16", "x4_rowpair_col0mod16", "x2_stride_gather"};
-static const int USEFUL[NSHAPES] = {1024, 1024, 1024, 1024, 512, 256, 256, 256, 64, 768, 1024, 1024, 1024, 512};
+                                     "x1_linear_256B", "u8_window_scatter", "x4_rowquad16_3of4_lanes", "x4_rowpair_col4mod16", "x4_rowpair_col8mod16", "x4_rowpair_col0mod16", "x2_stride_gather_bytealigned", "x3_stride_gather_dwordaligned", "x2_stride_gather"};
+static const int USEFUL[NSHAPES] = {1024, 1024, 1024, 1024, 512, 256, 256, 256, 64, 768, 1024, 1024, 1024, 512, 768, 512};
 
 __device__ __forceinline__ uint32_t hash32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
 
@@ -51,6 +53,7 @@ __global__ __launch_bounds__(256) void k_probe(const uint8_t* __restrict__ plane
     else if (SHAPE == X1_ROW11) off = (lane / 11) * PITCH + 4 * (lane % 11);
     else if (SHAPE == X1_LINEAR) off = 4 * lane;
     else if (SHAPE == U8_SCATTER) off = (hash32(lane * 7919u + 13u) % 37u) * PITCH + (hash32(lane * 104729u + 7u) % 37u);
+    else if (SHAPE == X2_GATHER_BYTE) off = (lane * 19) >> 2;
     else off = ((lane * 19) >> 4) * 4;                      // X2_GATHER: ~4.75 bytes per lane step, 4-byte aligned 8-byte loads
     for (int it = 0; it < iters; it += 8) {
         uint32_t v[8][4];
@@ -65,11 +68,12 @@ __global__ __launch_bounds__(256) void k_probe(const uint8_t* __restrict__ plane
             if (SHAPE == X4_ROWPAIR_A8) col = (col & ~15u) | 8u;
             if (SHAPE == X4_ROWPAIR_A16) col &= ~15u;
             if (SHAPE == X2_ROW8) col &= ~7u;
-            if (SHAPE == X1_ROW16 || SHAPE == X1_ROW11 || SHAPE == X1_LINEAR || SHAPE == X2_GATHER) col &= ~3u;
+            if (SHAPE == X1_ROW16 || SHAPE == X1_ROW11 || SHAPE == X1_LINEAR || SHAPE == X2_GATHER || SHAPE == X3_GATHER || SHAPE == X2_GATHER_BYTE) col &= ~3u;
             const uint8_t* p = plane + (size_t)row * PITCH + col + off;
             if (SHAPE == X4_ROWQUAD_3OF4) { uint4 t = make_uint4(0, 0, 0, 0); if ((lane & 3) != 3) __builtin_memcpy(&t, p, 16); v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w; }
             else if (SHAPE <= X4_LINEAR || SHAPE == X4_ROWPAIR_A4 || SHAPE == X4_ROWPAIR_A8 || SHAPE == X4_ROWPAIR_A16) { uint4 t; __builtin_memcpy(&t, p, 16); v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w; }
-            else if (SHAPE == X2_ROW8 || SHAPE == X2_GATHER) { uint2 t; __builtin_memcpy(&t, p, 8); v[u][0] = t.x; v[u][1] = t.y; v[u][2] = 0; v[u][3] = 0; }
+            else if (SHAPE == X3_GATHER) { uint32_t t[3]; __builtin_memcpy(t, __builtin_assume_aligned(p, 4), 12); v[u][0] = t[0]; v[u][1] = t[1]; v[u][2] = t[2]; v[u][3] = 0; }
+            else if (SHAPE == X2_ROW8 || SHAPE == X2_GATHER || SHAPE == X2_GATHER_BYTE) { uint2 t; __builtin_memcpy(&t, p, 8); v[u][0] = t.x; v[u][1] = t.y; v[u][2] = 0; v[u][3] = 0; }
             else if (SHAPE == U8_SCATTER) { v[u][0] = *p; v[u][1] = v[u][2] = v[u][3] = 0; }
             else { uint32_t t; __builtin_memcpy(&t, p, 4); v[u][0] = t; v[u][1] = v[u][2] = v[u][3] = 0; }
         }
@@ -124,6 +128,8 @@ int main() {
         run<X4_ROWPAIR_A4>(plane, rowsets[s] - 1, d_out, cus, ghz, setn[s], false);
         run<X4_ROWPAIR_A8>(plane, rowsets[s] - 1, d_out, cus, ghz, setn[s], false);
         run<X4_ROWPAIR_A16>(plane, rowsets[s] - 1, d_out, cus, ghz, setn[s], false);
+        run<X2_GATHER_BYTE>(plane, rowsets[s] - 1, d_out, cus, ghz, setn[s], false);
+        run<X3_GATHER>(plane, rowsets[s] - 1, d_out, cus, ghz, setn[s], false);
         run<X2_GATHER>(plane, rowsets[s] - 1, d_out, cus, ghz, setn[s], true);
         printf(" }%s\n", s == 2 ? "" : ",");
         CHECK(hipFree(plane));
