@@ -214,6 +214,32 @@ def test_batch_equals_single_and_oracle(api, oracle, synth):
             assert np.array_equal(desc[b, :cnt[b]], rd)
 
 
+def test_large_batch_takes_the_batch_kernels(api, oracle, synth):
+    """72 different images in one call: batches of 64 and more run the 256-thread oct-tree blocks (`k_octree<256>`; smaller ones the 512-thread
+    form) and the tile-ordered descriptor pass — every image must still equal the oracle's single-image result."""
+    import torch
+    B, h, w, nf = 72, 240, 328, 300
+    kinds = ("texture", "noise", "texture")
+    imgs = np.stack([synth.random_image(7100 + i, h, w, kinds[i % 3]) for i in range(B)])
+    imgs[5] = synth.stereo_batch(1, stream_id=3, n_rect=40, h=h, w=w)[0, 0]          # a sparse scene and a flat image among them
+    imgs[9] = 128
+    ext = api.ORBextractor(nf)
+    cap = ext.max_keypoints(h, w)
+    d_imgs = torch.from_numpy(np.ascontiguousarray(imgs)).cuda()
+    d_kps = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda"); d_desc = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros(B, dtype=torch.int32, device="cuda"); d_st = torch.ones(B, dtype=torch.int32, device="cuda")
+    ext.set_stream(torch.cuda.current_stream().cuda_stream)
+    for rep in range(2):
+        ext.detect_and_compute_batch(d_imgs.data_ptr(), B, h, w, w, h * w, d_kps.data_ptr(), d_desc.data_ptr(), d_cnt.data_ptr(), d_st.data_ptr(), cap)
+        torch.cuda.synchronize()
+        cnt = d_cnt.cpu().numpy(); assert (d_st.cpu().numpy() == 0).all()
+        kps = d_kps.cpu().numpy().view(api.KP_DTYPE).reshape(B, cap); desc = d_desc.cpu().numpy().reshape(B, cap, 32)
+        for b in range(B):
+            rk, rd = oracle.detect_and_compute(oracle.params(nf), imgs[b])
+            assert _kp_equal(kps[b, :cnt[b]], rk), (rep, b, _explain(kps[b, :cnt[b]], rk))
+            assert np.array_equal(desc[b, :cnt[b]], rd), (rep, b)
+
+
 def test_golden_fixture(api):
     """Committed oracle outputs (tests/golden/orb_small.npz): the HIP path must reproduce them byte for byte."""
     import os

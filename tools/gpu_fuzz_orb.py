@@ -56,6 +56,25 @@ for it in range(N):
             g2, d2 = ext.DetectAndCompute(img2, mask)
             r2, e2 = o.detect_and_compute(p, img2, mask, cap=ext.max_keypoints(h, w) + 8)
             ok = ok and g2.tobytes() == r2.tobytes() and np.array_equal(d2, e2)
+    if ok and h * w < 160 * 1024 and rng.random() < 0.15:
+        # the image as entry 17 of a batch of 64 + different frames: the batch forms of the kernels (256-thread oct-tree blocks, tile-ordered
+        # descriptor pass, level 0 read in place) must give the single-image bytes
+        import torch
+        B = 64 + int(rng.integers(0, 9))
+        batch = np.stack([img if i == 17 else synth.random_image(int(rng.integers(1 << 30)), h, w, "texture") for i in range(B)])
+        cap = ext.max_keypoints(h, w)
+        d_imgs = torch.from_numpy(np.ascontiguousarray(batch)).cuda()
+        d_k = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda"); d_d = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+        d_c = torch.zeros(B, dtype=torch.int32, device="cuda"); d_s = torch.ones(B, dtype=torch.int32, device="cuda")
+        ext.set_stream(torch.cuda.current_stream().cuda_stream)
+        ext.detect_and_compute_batch(d_imgs.data_ptr(), B, h, w, w, h * w, d_k.data_ptr(), d_d.data_ptr(), d_c.data_ptr(), d_s.data_ptr(), cap)
+        torch.cuda.synchronize()
+        c = d_c.cpu().numpy(); kk = d_k.cpu().numpy().view(api.KP_DTYPE).reshape(B, cap); dd = d_d.cpu().numpy().reshape(B, cap, 32)
+        ok = ok and int(d_s.abs().sum()) == 0 and kk[17, :c[17]].tobytes() == rk.tobytes() and np.array_equal(dd[17, :c[17]], rd)
+        for b2 in (0, B - 1):
+            r2, e2 = o.detect_and_compute(p, batch[b2], cap=cap + 8)
+            ok = ok and kk[b2, :c[b2]].tobytes() == r2.tobytes() and np.array_equal(dd[b2, :c[b2]], e2)
+        ext.set_stream(0)
     if not ok:
         bad += 1
         print("MISMATCH", dict(h=h, w=w, nf=nf, nl=nl, sf=sf, kind=kind, n_gpu=len(gk), n_ref=len(rk)))
