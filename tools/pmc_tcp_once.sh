@@ -10,7 +10,7 @@ else:
     for r in csv.DictReader(open(f[0])):
         k=r['Kernel_Name'].split('(')[0].replace('void ','').replace('myslam_hip::','')
         agg[k][r['Counter_Name']]+=float(r['Counter_Value'])
-    for k in ('k_describe2','k_fast_strip<40, 4>','k_octree','k_blur7_strip','k_resize_strip'):
+    for k in ('k_describe2','k_fast_strip<40, 4>','k_octree<256>','k_blur7_strip','k_resize_strip'):
         print(k, {c: round(v/4/128) for c,v in agg[k].items()}, "(per image)")
 PY
 done
