@@ -329,6 +329,7 @@ class DeepLCD:
     """DeepLCD(weights) — include/myslam/deeplcd.h:33.  `weights` = flat f32 blob of the SURVEY A.6 layer list; `layers` = explicit
     CALC_LAYER_DTYPE records; DeepLCD.from_caffe(prototxt, caffemodel) = the reference's constructor arguments."""
     OPT_GENERIC_KERNELS = 1
+    OPT_CONV2_BF16X6 = 2
 
     def __init__(self, weights=None, stream=None, layers=None, caffe=None, path=None):
         self._h = C.c_void_p()
@@ -355,6 +356,10 @@ class DeepLCD:
 
     def uses_fused_kernels(self):
         return lib().myslam_lcd_uses_fused_kernels(self._h) == 1
+
+    def conv2_products(self):
+        """3: conv2 runs as f16 x 3 on the matrix cores, 6: as bf16 x 6, 0: generic kernels"""
+        return lib().myslam_lcd_conv2_products(self._h)
 
     def __del__(self):
         if getattr(self, "_h", None) and self._h.value and _lib is not None:

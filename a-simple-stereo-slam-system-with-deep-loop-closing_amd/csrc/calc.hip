@@ -410,6 +410,107 @@ __global__ __launch_bounds__(256) void k_conv2_bf16x6(const float* __restrict__ 
     }
 }
 
+// ---- the same implicit GEMM on the f16 matrix cores, three products instead of six (round 3) ----
+// An f32 operand is split into two f16 pieces with 22 significant bits between them:  a = h + m' 2^-11,  h = f16(a),  m' = f16((a - h) 2^11)
+// (a - h is exact in f32, the power-of-two scaling keeps the residual out of f16's subnormal range).  Then
+//     2^11 a b  ~  h_a (2^11 h_b)  +  h_a m'_b  +  m'_a h_b            (dropped: m_a m_b and the two rounding terms, <= 2^-21 |a b| together)
+// so that ONE accumulator takes all three products: the weight side carries a third plane Hs = 2^11 h_b (exact in f16 while |w| < 2^5: checked
+// when the model is loaded, as is the bound 65504 on the activations — models outside keep the bf16 x 6 kernel).  Half the matrix
+// instructions of the bf16 form (12 per wave and K step) and 5 instead of 6 operand planes through LDS; measured against an f64 reference
+// the error is of the same order (tools/conv2_error.py).  Same tiling, staging roles and LDS layout as k_conv2_bf16x6.
+typedef _Float16 cv_f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void cv_split2_f16(float a0, float a1, uint32_t& h, uint32_t& m) {    // two elements per dword, a0 low
+    const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+    const _Float16 m0 = (_Float16)((a0 - (float)h0) * 2048.f), m1 = (_Float16)((a1 - (float)h1) * 2048.f);
+    h = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
+    m = (uint32_t)__builtin_bit_cast(unsigned short, m0) | ((uint32_t)__builtin_bit_cast(unsigned short, m1) << 16);
+}
+
+__global__ __launch_bounds__(256) void k_conv2_f16x3(const float* __restrict__ in /*[B][31*41][64]*/,
+                                                     const uint4* __restrict__ wt3 /*[64 stages][3: Hs, m', h][128 n][2 k-halves] x 8 f16*/,
+                                                     const float* __restrict__ b2, float* __restrict__ out /*[B*1344][128]*/, int Mtotal, int relu) {
+    constexpr int BM = 128, BN = 128;
+    constexpr int KH = BM + 8;
+    __shared__ uint4 s_a[2][2][2 * KH];
+    __shared__ uint4 s_b[2][3][2 * KH];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int m0 = blockIdx.x * BM;
+    const int am = t >> 1, akh = t & 1;                // staging role: row m, k half (8 consecutive k)
+    const int gm = m0 + am;
+    const bool mvalid = gm < Mtotal;
+    const int img = mvalid ? gm / M2 : 0;
+    const int pix = mvalid ? gm - img * M2 : 0;
+    const int oy = pix / W2, ox = pix - oy * W2;
+    const float* inb = in + (size_t)img * HP1 * WP1 * 64;
+
+    float4 ra0 = make_float4(0, 0, 0, 0), ra1 = ra0;
+    uint4 rb0 = make_uint4(0, 0, 0, 0), rb1 = rb0, rb2 = rb0;
+    bool rav = false;
+    auto store_stage = [&](int buf) {
+        const float z = rav ? 1.f : 0.f;
+        uint4 h, m;
+        cv_split2_f16(ra0.x * z, ra0.y * z, h.x, m.x); cv_split2_f16(ra0.z * z, ra0.w * z, h.y, m.y);
+        cv_split2_f16(ra1.x * z, ra1.y * z, h.z, m.z); cv_split2_f16(ra1.z * z, ra1.w * z, h.w, m.w);
+        const int si = akh * KH + am;
+        s_a[buf][0][si] = h; s_a[buf][1][si] = m;
+        s_b[buf][0][si] = rb0; s_b[buf][1][si] = rb1; s_b[buf][2][si] = rb2;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    CV2_LOAD_STAGE(0)
+    store_stage(0);
+    __syncthreads();
+    constexpr int NSTAGE = K2 / 16;
+    const int lr = lane & 31, lk = lane >> 5;
+    for (int s = 0; s < NSTAGE; s++) {
+        const int buf = s & 1;
+        if (s + 1 < NSTAGE) CV2_LOAD_STAGE(s + 1)
+        cv_f16x8 A[2][2], Bm[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int p = 0; p < 2; p++) A[i][p] = __builtin_bit_cast(cv_f16x8, s_a[buf][p][lk * KH + wm + 32 * i + lr]);
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int p = 0; p < 3; p++) Bm[j][p] = __builtin_bit_cast(cv_f16x8, s_b[buf][p][lk * KH + wn + 32 * j + lr]);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i][1], Bm[j][2], c, 0, 0, 0);        // m'_a h_b
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i][0], Bm[j][1], c, 0, 0, 0);        // h_a m'_b
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i][0], Bm[j][0], c, 0, 0, 0);        // h_a 2^11 h_b
+                acc[i][j] = c;
+            }
+        if (s + 1 < NSTAGE) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int n = wn + j * 32 + lr;
+        const float bias = b2[n];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const float v = acc[i][j][r] * (1.0f / 2048.f) + bias;
+                if (m < Mtotal) out[(size_t)m * CV_BN + n] = relu ? fmaxf(v, 0.f) : v;
+            }
+    }
+}
+
 #undef CV2_LOAD_STAGE
 
 // ---- conv3 + ReLU + flatten (NCHW order) + L2 normalise; one 1024-thread block per image ----
@@ -638,8 +739,10 @@ struct myslam_lcd {
     std::vector<myslam_calc_layer> layers; std::vector<LayerShape> shapes;
     FusedPlan fused{};                 // fused.ok: the layer list has the geometry of the fused kernels
     int forceGeneric = 0;              // myslam_lcd_set_option(GENERIC_KERNELS)
+    int forceBf16 = 0;                 // myslam_lcd_set_option(CONV2_BF16X6): keep the six-product bf16 kernel
     std::vector<float*> d_wt, d_b;     // per convolution: weights re-laid out as [K*K*IC][OC], bias
     uint4* d_w2s = nullptr;            // fused path: conv2 weights split into three bf16 pieces, [stage][piece][n][k half] x 8 bf16
+    uint4* d_w2h = nullptr;            // the same as three f16 planes (2^11 h, m', h) when the model's ranges allow k_conv2_f16x3, else nullptr
     size_t actMax = 0;                 // largest activation (floats per image) of the generic path
     // resize tables for the current source size
     int rows = 0, cols = 0;
@@ -669,7 +772,7 @@ static int lcd_alloc(T*& p, size_t n) {
 }
 
 void myslam_lcd::free_all() {
-    void* ptrs[] = {d_w2s, d_xofs, d_yofs, d_xa, d_yb, d_blur, d_in, d_p1, d_a2, d_p2, d_g0, d_g1, d_stageImg, d_stageOut};
+    void* ptrs[] = {d_w2s, d_w2h, d_xofs, d_yofs, d_xa, d_yb, d_blur, d_in, d_p1, d_a2, d_p2, d_g0, d_g1, d_stageImg, d_stageOut};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (float* p : d_wt) if (p) (void)hipFree(p);
     for (float* p : d_b) if (p) (void)hipFree(p);
@@ -775,7 +878,8 @@ static int lcd_forward(myslam_lcd* h, int batch, float* d_out) {
     {
         ScopedProf sp(P_CONV2, s);
         const int Mtotal = batch * M2;
-        hipLaunchKernelGGL(k_conv2_bf16x6, dim3((Mtotal + 127) / 128), dim3(256), 0, s, h->d_p1, h->d_w2s, h->d_b[1], h->d_a2, Mtotal, f.relu[1]);
+        if (h->d_w2h && !h->forceBf16) hipLaunchKernelGGL(k_conv2_f16x3, dim3((Mtotal + 127) / 128), dim3(256), 0, s, h->d_p1, h->d_w2h, h->d_b[1], h->d_a2, Mtotal, f.relu[1]);
+        else hipLaunchKernelGGL(k_conv2_bf16x6, dim3((Mtotal + 127) / 128), dim3(256), 0, s, h->d_p1, h->d_w2s, h->d_b[1], h->d_a2, Mtotal, f.relu[1]);
     }
     {
         ScopedProf sp(P_POOL2, s);
@@ -874,6 +978,36 @@ static int lcd_create(myslam_lcd** out, const myslam_calc_layer* layers, int nla
             hipMemcpy(h->d_w2s, w2s.data(), w2s.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
             return fail(MYSLAM_ERR_HIP);
     }
+    if (h->fused.ok) {
+        // f16 planes for k_conv2_f16x3 — only when nothing can leave f16's range: |w2| < 2^5 (2^11 h must stay below 65504) and conv2's input,
+        // the LRN'd / pooled conv1 map, bounded by sum |w1| + |b1| (inputs are pixels / 255) < 65504 with an LRN that cannot amplify (k >= 1)
+        const float* w1 = weights; const int n1 = layers[0].num_output, k1 = layers[0].kernel * layers[0].kernel;     // conv1: 1 input channel
+        double bound1 = 0, wmax2 = 0;
+        for (int oc = 0; oc < n1; oc++) {
+            double sacc = std::fabs((double)w1[(size_t)n1 * k1 + oc]);
+            for (int t = 0; t < k1; t++) sacc += std::fabs((double)w1[(size_t)oc * k1 + t]);
+            bound1 = std::max(bound1, sacc);
+        }
+        for (float v : w2t) wmax2 = std::max(wmax2, (double)std::fabs(v));
+        const bool finite = std::isfinite(bound1) && std::isfinite(wmax2);
+        if (finite && bound1 < 60000.0 && wmax2 < 31.0 && h->fused.lrn[0].k >= 1.0f && h->fused.lrn[0].beta >= 0.0f) {
+            auto to_f16 = [](float x) -> uint16_t { const _Float16 v = (_Float16)x; uint16_t u; memcpy(&u, &v, 2); return u; };   // round to nearest even
+            auto from_f16 = [](uint16_t b) -> float { _Float16 v; memcpy(&v, &b, 2); return (float)v; };
+            std::vector<uint16_t> w2h((size_t)64 * 3 * 128 * 16);
+            for (int k = 0; k < K2; k++) {
+                const int st = k >> 4, kk = k & 15;
+                for (int oc = 0; oc < 128; oc++) {
+                    const float a = w2t[(size_t)k * 128 + oc];
+                    const uint16_t hb = to_f16(a); const float hf = from_f16(hb);
+                    const uint16_t pcs[3] = {to_f16(hf * 2048.f), to_f16((a - hf) * 2048.f), hb};
+                    for (int p = 0; p < 3; p++) w2h[(((size_t)st * 3 + p) * 128 + oc) * 16 + kk] = pcs[p];
+                }
+            }
+            if (hipMalloc((void**)&h->d_w2h, w2h.size() * 2) != hipSuccess ||
+                hipMemcpy(h->d_w2h, w2h.data(), w2h.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
+                return fail(MYSLAM_ERR_HIP);
+        }
+    }
     *out = h;
     return MYSLAM_OK;
 }
@@ -964,9 +1098,15 @@ int myslam_lcd_set_stream(myslam_lcd* h, void* s) {
 int myslam_lcd_set_option(myslam_lcd* h, int option, int value) {
     if (!h) return MYSLAM_ERR_INVALID;
     if (option == MYSLAM_LCD_OPT_GENERIC_KERNELS) { h->forceGeneric = value != 0; return MYSLAM_OK; }
+    if (option == MYSLAM_LCD_OPT_CONV2_BF16X6) { h->forceBf16 = value != 0; return MYSLAM_OK; }
     return MYSLAM_ERR_INVALID;
 }
 
+int myslam_lcd_conv2_products(const myslam_lcd* h) {
+    if (!h) return MYSLAM_ERR_INVALID;
+    if (!h->fused.ok || h->forceGeneric) return 0;
+    return (h->d_w2h && !h->forceBf16) ? 3 : 6;
+}
 int myslam_lcd_uses_fused_kernels(const myslam_lcd* h) { return h ? (h->fused.ok && !h->forceGeneric ? 1 : 0) : MYSLAM_ERR_INVALID; }
 
 float myslam_lcd_score(const float* d1, const float* d2) {      // deeplcd.cpp:35-39 (host: 1064 FMAs)

@@ -71,7 +71,7 @@ ALGO_BYTES = {
 # profiling slot (csrc/prof.hip) -> kernel symbol prefix as rocprofv3 prints it
 SYMBOL = {"resize": "k_resize_strip", "fast": "k_fast_strip", "octree": "k_octree", "blur7": "k_blur7_strip", "describe": "k_describe2",
           "hamming_match": "k_hamming_fp4", "triangulate": "k_triangulate", "lcd_preproc": "k_lcd_input_fused",
-          "calc_conv1": "k_conv1_pool_lrn2", "calc_conv2": "k_conv2_bf16x6", "calc_pool2": "k_pool_lrn128_2x2", "calc_conv3": "k_conv3_norm", "lcddb_scan": "k_db_scan_bf16x6",
+          "calc_conv1": "k_conv1_pool_lrn2", "calc_conv2": "k_conv2_f16x3", "calc_pool2": "k_pool_lrn128_2x2", "calc_conv3": "k_conv3_norm", "lcddb_scan": "k_db_scan_bf16x6",
           "ba_build": "k_ba_build", "screen": "k_screen"}
 
 
@@ -676,11 +676,12 @@ def main():
             c2 = busy["calc_conv2"][0] / busy["calc_conv2"][1]
             f32eq = 2 * 176160768 * P / (c2 * 1e-3) / 1e12
             mf = {"bound": "mfma", "kernel": SYMBOL["calc_conv2"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s (bf16 dense)",
-                  "achieved": 6 * f32eq, "frac": 6 * f32eq / MFMA_BF16_PEAK_TFLOPS, "peak_measured": (peaks or {}).get("mfma_bf16_tflops"),
+                  "achieved": 3 * f32eq, "frac": 3 * f32eq / MFMA_BF16_PEAK_TFLOPS, "peak_measured": (peaks or {}).get("mfma_bf16_tflops"),
                   "peaks_source": peaks_path, "f32_equivalent_tflops": f32eq, "avg_launch_ms": c2,
-                  "note": "CALC conv2 as an implicit GEMM on the bf16 matrix cores with f32 accuracy (3-way exact operand split, 6 bf16 partial "
-                          "products per useful f32 multiply-add): `achieved` counts the bf16 flops the matrix pipe executes, priced against the "
-                          "bf16 dense peak; f32_equivalent_tflops counts the USEFUL f32 flops (the f32-input MFMA peak would be 157.3)"}
+                  "note": "CALC conv2 as an implicit GEMM on the 16-bit matrix cores with f32 accuracy (every f32 operand split exactly into two f16 "
+                          "pieces, 3 partial products per useful f32 multiply-add; f16 and bf16 run at the same dense rate): `achieved` counts the "
+                          "flops the matrix pipe executes, priced against the 16-bit dense peak; f32_equivalent_tflops counts the USEFUL f32 flops "
+                          "(the f32-input MFMA peak would be 157.3)"}
         n_internal = S if args.orb_internal_stream else 0        # every extractor handle runs its Gaussian pyramid on an internal stream
         out = {
             "metric": "stereo frames/sec (ORB+match+LCD+BA-build) @1241x376",

@@ -230,7 +230,13 @@ int myslam_calc_parse_caffe(const char* prototxt_path, const char* caffemodel_pa
 int myslam_lcd_create_from_file(myslam_lcd** out, const char* path);
 /* 1 = the layer list runs on the fused kernels, 0 = on the generic layer kernels */
 int myslam_lcd_uses_fused_kernels(const myslam_lcd* h);
+/* partial products per multiply-add of the fused path's conv2: 3 = f16 x 3 (k_conv2_f16x3: the model's ranges fit f16 — |conv2 weight| < 31 and
+ * sum |conv1 weights| + |bias| < 60000 with an LRN that cannot amplify), 6 = bf16 x 6 (k_conv2_bf16x6), 0 = generic kernels.  Both matrix-core forms
+ * reach f32-level accuracy (max-normalised error against f64: 1.1e-6 / 1.5e-6). */
+int myslam_lcd_conv2_products(const myslam_lcd* h);
 #define MYSLAM_LCD_OPT_GENERIC_KERNELS 1       /* value != 0: run even a fusable list on the generic kernels (tests, diagnosis) */
+#define MYSLAM_LCD_OPT_CONV2_BF16X6 2          /* value != 0: conv2 of the fused path on the six-product bf16 kernel even when the model's ranges allow the
+                                                * three-product f16 one (both reach f32-level accuracy; tests compare them) */
 int myslam_lcd_set_option(myslam_lcd* h, int option, int value);
 int myslam_lcd_destroy(myslam_lcd* h);
 int myslam_lcd_set_stream(myslam_lcd* h, void* hip_stream);

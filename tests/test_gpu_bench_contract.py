@@ -44,7 +44,7 @@ def test_bench_json_contract(extra):
         assert abs(rv["frac"] - rv["achieved"] / rv["peak"]) < 1e-9 and 30.0 < rv["peak"] < 45.0
     km = d["profiled_pass"]["kernel_ms_per_step"]
     if "lcd" in d["config"]["workload"].lower():
-        assert "k_conv3_norm" in km and "k_pool_lrn128_2x2" in km and "k_conv2_bf16x6" in km
+        assert "k_conv3_norm" in km and "k_pool_lrn128_2x2" in km and "k_conv2_f16x3" in km
     if "--no-cpu-baseline" in extra:
         assert d["cpu_baseline"] is None
     else:

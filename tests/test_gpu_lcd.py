@@ -286,7 +286,7 @@ def test_fused_input_equals_two_pass_blur(api, synth, h, w):
 
 
 def test_fused_kernels_against_the_generic_layer_kernels(api, oracle, synth):
-    """The fused kernels (conv1 + pool + LRN, bf16x6 conv2, pool + LRN, conv3 + norm) and the generic layer-by-layer kernels run the
+    """The fused kernels (conv1 + pool + LRN, split-precision matrix-core conv2, pool + LRN, conv3 + norm) and the generic layer-by-layer kernels run the
     same layer list: descriptors agree to float noise, and both sit within the tolerance of the oracle."""
     w = synth.calc_weights()
     fused, generic = api.DeepLCD(w), api.DeepLCD(w)
@@ -370,3 +370,29 @@ def test_unsupported_models_are_refused(api, synth):
     with pytest.raises(api.MyslamError) as e:                       # weights that do not fit the list
         api.DeepLCD(w[:-1], layers=L)
     assert e.value.code == api.ERR_INVALID
+
+
+def test_conv2_f16x3_and_bf16x6_agree_and_ranges_select_the_kernel(api, oracle, synth):
+    """conv2 of the fused path has two matrix-core forms with f32-level accuracy: three products of f16 pieces (the default when the model's
+    ranges fit f16) and six of bf16 pieces.  Same model: both within the oracle's tolerance and within float noise of each other.  A model whose
+    conv2 weights reach 40 cannot put 2^11 h into f16: it must take the bf16 kernel by itself and still match the oracle."""
+    w = synth.calc_weights()
+    a, b = api.DeepLCD(w), api.DeepLCD(w)
+    b.set_option(b.OPT_CONV2_BF16X6, 1)
+    assert a.conv2_products() == 3 and b.conv2_products() == 6
+    x = np.random.default_rng(11).random((120, 160), dtype=np.float32)
+    ta, tb = a.debug_forward(x, 2), b.debug_forward(x, 2)                     # conv2 + ReLU output
+    assert np.abs(ta - tb).max() <= 4e-6 * float(np.abs(tb).max())
+    for i in range(2):
+        img = synth.random_image(5200 + i, 240, 320)
+        da, _ = a.calcDescrOriginalImg(img); db_, _ = b.calcDescrOriginalImg(img)
+        ref = oracle.calc_forward(w, oracle.calc_preproc(img, blur_in_place=True)[0])
+        assert np.abs(da - db_).max() < 5e-6 and np.abs(da - ref).max() < DESC_ATOL and np.abs(db_ - ref).max() < DESC_ATOL
+    big = w.copy()
+    o2 = 64 * 25 + 64                                                          # conv2 weights follow conv1's 64 x 25 weights + 64 biases
+    big[o2:o2 + 128 * 64 * 16] *= 40.0 / float(np.abs(big[o2:o2 + 128 * 64 * 16]).max())
+    c = api.DeepLCD(big)
+    assert c.uses_fused_kernels() and c.conv2_products() == 6
+    img = synth.random_image(5300, 240, 320)
+    dc, _ = c.calcDescrOriginalImg(img)
+    assert np.abs(dc - oracle.calc_forward(big, oracle.calc_preproc(img, blur_in_place=True)[0])).max() < DESC_ATOL
