@@ -513,22 +513,24 @@ __global__ __launch_bounds__(256) void k_conv2_f16x3(const float* __restrict__ i
 
 #undef CV2_LOAD_STAGE
 
-// ---- conv3 + ReLU + flatten (NCHW order) + L2 normalise; one 1024-thread block per image ----
-// 16 waves share the 266 output pixels; each lane keeps its 18 weight quadruples (k = lane + 64 j) in registers.
-constexpr int CV3_T = 1024, CV3_NW = CV3_T / 64;
+// ---- conv3 + ReLU + flatten (NCHW order) + L2 normalise ----
+// CV3_NB blocks of 256 threads per image: 16 waves share the 266 output pixels (wave g takes pixels g, g + 16, ...), each lane keeps its 18
+// weight quadruples (k = lane + 64 j) in registers; k_l2norm_1064 follows.  Round 2 ran ONE 1024-thread block per image: 16 waves x 101 registers need a nearly empty CU, so under the pipeline the
+// kernel waited for whole CUs to drain (1.7 ms resident for 0.05 ms of work) — and the LCD chain it sits in is as long as the step.  A
+// 256-thread block moves in as soon as one FAST block retires (+2.7 % frames/s).
+constexpr int CV3_T = 256, CV3_NB = 4, CV3_NW = CV3_NB * CV3_T / 64;
 __global__ __launch_bounds__(CV3_T) void k_conv3_norm(const float* __restrict__ in /*[B][16*21][128]*/,
                                                       const float* __restrict__ w3t /*[1152][4]*/, const float* __restrict__ b3,
-                                                      float* __restrict__ out /*[B][1064]*/, int relu) {
-    __shared__ float s_o[C3 * H3 * W3];
-    __shared__ float s_red[CV3_NW];
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                                      float* __restrict__ out /*[B][1064], not yet normalised*/, int relu) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gw = blockIdx.x * (CV3_T / 64) + wave;
     const float* I = in + (size_t)b * HP2 * WP2 * 128;
     const float4* Wt = reinterpret_cast<const float4*>(w3t);
+    float* O = out + (size_t)b * MYSLAM_LCD_DIM;
     float4 w[18];
 #pragma unroll
     for (int j = 0; j < 18; j++) w[j] = Wt[lane + 64 * j];
-    for (int p = wave; p < H3 * W3; p += CV3_NW) {
+    for (int p = gw; p < H3 * W3; p += CV3_NW) {
         const int oy = p / W3, ox = p - oy * W3;
         float v[18];
 #pragma unroll
@@ -544,20 +546,34 @@ __global__ __launch_bounds__(CV3_T) void k_conv3_norm(const float* __restrict__ 
         if (lane == 63) {
             float r[4] = {acc.x + b3[0], acc.y + b3[1], acc.z + b3[2], acc.w + b3[3]};
 #pragma unroll
-            for (int c = 0; c < 4; c++) s_o[c * H3 * W3 + p] = relu ? fmaxf(r[c], 0.f) : r[c];
+            for (int c = 0; c < 4; c++) O[c * H3 * W3 + p] = relu ? fmaxf(r[c], 0.f) : r[c];
         }
     }
-    __syncthreads();
+}
+
+// L2 normalisation of the 1064 values of an image (deeplcd.cpp:84-90), one wave per image, in place.  A kernel of its own: the blocks of an
+// image run on different XCDs, and making their values visible to a "last block" inside k_conv3 takes an agent-scope release — an L2
+// write-back per block on this chip (measured: 0.05 -> 0.51 ms per 512 images).
+__global__ __launch_bounds__(256) void k_l2norm_1064(float* __restrict__ out, int batch) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= batch) return;
+    float* O = out + (size_t)b * MYSLAM_LCD_DIM;
+    constexpr int NV = (MYSLAM_LCD_DIM + 63) / 64;
+    float vv[NV];
     float ss = 0.f;
-    for (int i = threadIdx.x; i < MYSLAM_LCD_DIM; i += CV3_T) ss += s_o[i] * s_o[i];
-    ss = wave_sum_lane63_f32(ss);
-    if (lane == 63) s_red[wave] = ss;
-    __syncthreads();
-    float tot = 0.f;
 #pragma unroll
-    for (int i = 0; i < CV3_NW; i++) tot += s_red[i];
-    const float nrm = sqrtf(tot);                                             // deeplcd.cpp:88
-    for (int i = threadIdx.x; i < MYSLAM_LCD_DIM; i += CV3_T) out[(size_t)b * MYSLAM_LCD_DIM + i] = s_o[i] / nrm;
+    for (int u = 0; u < NV; u++) {
+        const int i = lane + 64 * u;
+        vv[u] = i < MYSLAM_LCD_DIM ? O[i] : 0.f;
+        ss += vv[u] * vv[u];
+    }
+    ss = wave_sum_lane63_f32(ss);
+    const float nrm = sqrtf(__shfl(ss, 63, 64));                              // deeplcd.cpp:88
+#pragma unroll
+    for (int u = 0; u < NV; u++) {
+        const int i = lane + 64 * u;
+        if (i < MYSLAM_LCD_DIM) O[i] = vv[u] / nrm;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -887,7 +903,8 @@ static int lcd_forward(myslam_lcd* h, int batch, float* d_out) {
     }
     {
         ScopedProf sp(P_CONV3, s);
-        hipLaunchKernelGGL(k_conv3_norm, dim3(batch), dim3(CV3_T), 0, s, h->d_p2, h->d_wt[2], h->d_b[2], d_out, f.relu[2]);
+        hipLaunchKernelGGL(k_conv3_norm, dim3(CV3_NB, batch), dim3(CV3_T), 0, s, h->d_p2, h->d_wt[2], h->d_b[2], d_out, f.relu[2]);
+        hipLaunchKernelGGL(k_l2norm_1064, dim3((batch + 3) / 4), dim3(256), 0, s, d_out, batch);
     }
     MYSLAM_HIP_CHECK(hipGetLastError());
     return MYSLAM_OK;
