@@ -679,7 +679,8 @@ struct FastCtl { const uint32_t* prev; uint32_t* cur; int force; };
 //   dense path:      every pixel is scored (work item = 4 pixels x 2 rows: the two 7-row windows share 6 rows); NMS on 4 x 4 blocks in
 //                    separable form; every 4-pixel row with a strict maximum leaves one list record, expanded by the append phase.
 // Blocks are handed out XCD-aware: consecutive strips (which share halo rows and columns) go to the same XCD's L2.
-template <int CW, int G>
+// CW / CH = the widest / tallest grid cell of the plan (columns cost LDS in 16-byte steps, rows one by one)
+template <int CW, int G, int CH = CW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 6 : 3))) void k_fast_strip(OrbPlan P, const uint8_t* __restrict__ pyr, size_t pyrStride,
                                                     const uint8_t* __restrict__ maskPyr,
                                                     uint32_t* __restrict__ cand, int32_t* __restrict__ candCount, FastCtl ctl, int batch) {
@@ -687,12 +688,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
     constexpr int CP = (CW + 6 + 15) & ~15;                            // every cell's ROI (cell + 6 halo columns) is staged at its own 16-byte aligned offset:
     constexpr int TP = G * CP;                                         //   a lane's 12-byte windows are then dword-aligned and need no byte alignment
     constexpr int NQC = CP / 16;                                       // 16-byte groups per cell row
-    constexpr int TROWS = CW + 6 + 1;                                  // + 1: the second row of a work item reads one row further
+    constexpr int TROWS = CH + 6 + 1;                                  // + 1: the second row of a work item reads one row further
     constexpr int SP = (CW + 4 + 8 + 3) & ~3;
-    constexpr int SROWS = CW + 2 + 4;                                  // + 4: the dense path's NMS reads whole 4-row blocks (rows past the cell stay zero)
-    constexpr int NLIST = G * ((CW + 1) / 2) * ((CW + 1) / 2);         // a cell of a x b pixels holds at most ceil(a/2) ceil(b/2) strict maxima
-    constexpr int NPAIR = G * CW * ((CW + 1) / 2);                     // pixel pairs of a strip
-    static_assert(CW <= 63 && G <= 4, "pair list entry = cell << 11 | row << 5 | pair index");
+    constexpr int SROWS = CH + 2 + 4;                                  // + 4: the dense path's NMS reads whole 4-row blocks (rows past the cell stay zero)
+    constexpr int NLIST = G * ((CW + 1) / 2) * ((CH + 1) / 2);         // a cell of a x b pixels holds at most ceil(a/2) ceil(b/2) strict maxima
+    constexpr int NPAIR = G * CH * ((CW + 1) / 2);                     // pixel pairs of a strip
+    static_assert(CW <= 63 && CH <= 63 && G <= 4, "pair list entry = cell << 11 | row << 5 | pair index");
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[TROWS * TP + 16];
     __shared__ __attribute__((aligned(16))) uint8_t s_score[G][SROWS * SP + 16];
     __shared__ uint16_t s_pairs[NPAIR];
@@ -707,6 +708,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
     static_assert(NLIST * 4 <= TROWS * TP && NLIST <= NPAIR, "row records must fit");
     uint32_t* const s_recz = reinterpret_cast<uint32_t*>(s_tile);
     __shared__ int s_ini[G], s_wc[G], s_nlist, s_npair, s_ncorner;
+    // LDS footprint on purpose (1241 x 376: cells of at most 32 x 40 pixels): a block of this instance needs 22.4 KB, seven would fit a CU — and
+    // with seven waves per SIMD FAST holds 504 of the 512 registers per lane, nothing of the other streams can move in (measured: FAST alone 3 %
+    // faster, the pipelined step 1 % slower).  Padded to just over 160 KB / 7 it stays at six blocks, which leaves 22 KB of LDS and 80 registers per
+    // lane free: together with what ONE retiring FAST block frees, a conv2 block (43.5 KB) or a descriptor / oct-tree block fits at once
+    // instead of waiting for the launch to drain (+1.5 % frames/s; the 25.1 KB instance left 9 KB: only blur / resize blocks fitted).
+    constexpr int LDS_EST = TROWS * TP + 16 + G * (SROWS * SP + 16) + 2 * NPAIR + 64;
+    constexpr int LDS_PAD = (CW <= 32 && LDS_EST < 163840 / 7) ? 163840 / 7 + 256 - LDS_EST : 4;
+    static_assert(CW > 32 || 6 * (LDS_EST + LDS_PAD) + 21504 <= 163840, "six blocks + one descriptor block per CU");
+    __shared__ volatile uint8_t s_padx[LDS_PAD]; s_padx[threadIdx.x & 1] = 0;
 
     // XCD-aware block order (bijective remap of the 1-D grid): the dispatcher places block i on XCD i % 8 and every XCD has a private
     // L2; logical ids (image-major, strips row by row) are handed out so that each XCD walks a contiguous range of strips, whose
@@ -2221,11 +2231,12 @@ void launch_blur(const BlurArgs& a, int batch, hipStream_t s) { launch_blur_leve
 
 void launch_fast(const OrbPlan& P, const uint8_t* pyr, size_t pyrStride, const uint8_t* maskPyr, uint32_t* cand,
                  int32_t* candCount, const uint32_t* statPrev, uint32_t* statCur, int forceMode, int batch, hipStream_t s) {
-    int cw = 0;
-    for (int l = 0; l < P.nlevels; l++) cw = max(cw, max(P.lv[l].wCell, P.lv[l].hCell));
+    int cw = 0, ch = 0;
+    for (int l = 0; l < P.nlevels; l++) { cw = max(cw, P.lv[l].wCell); ch = max(ch, P.lv[l].hCell); }
     const FastCtl ctl{statPrev, statCur, forceMode};
     const dim3 grid((unsigned)P.nstrips * (unsigned)batch);
-    if (cw <= 40) hipLaunchKernelGGL((k_fast_strip<40, 4>), grid, dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount, ctl, batch);
+    if (cw <= 32 && ch <= 40) hipLaunchKernelGGL((k_fast_strip<32, 4, 40>), grid, dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount, ctl, batch);
+    else if (max(cw, ch) <= 40) hipLaunchKernelGGL((k_fast_strip<40, 4>), grid, dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount, ctl, batch);
     else hipLaunchKernelGGL((k_fast_strip<MAX_CELL, 4>), grid, dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount, ctl, batch);
 }
 
