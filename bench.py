@@ -588,6 +588,21 @@ def main():
                  "note": "as the timed region, plus the OptimizeActiveMap solve stage on EVERY frame's window (configs[3] read as 'every frame is a "
                          "key-frame'; = --workload full_solve)"}
 
+    # ---- pass 6: the extractor ALONE on an otherwise idle chip (three calls of one handle, event pair around every launch): what a launch
+    # of each ORB kernel takes when nothing shares its CUs — under the pipeline a launch is resident for longer BY DESIGN (blocks of the
+    # other streams move in beside FAST's), so the per-launch durations of pass 2 price the schedule, these price the kernel ----
+    alone = {}
+    if not args.no_extra_passes:
+        barrier()
+        api.prof_reset(); api.prof_enable(True)
+        n_alone = 2 * P // S
+        for _ in range(3):
+            ext.detect_and_compute_batch(cur["imgs"].data_ptr(), n_alone, H, W, W, H * W, d_kps_b[0].data_ptr(), d_desc_b[0].data_ptr(),
+                                         d_cnt_b[0].data_ptr(), d_stat_b[0].data_ptr(), cap)
+        torch.cuda.synchronize()
+        api.prof_enable(False)
+        alone = {k: v for k, v in api.prof_read().items() if v[1] > 0}
+
     if args.verify and args.pipeline:
         # the overlapped schedule must not change a single output: one plain step (handles un-gated, joined) against the last pipelined one
         step(); torch.cuda.synchronize()
@@ -645,12 +660,17 @@ def main():
             imgs_per_launch = 2 * P / launches_per_step
             sym, rec = pmc_lookup(pmc, dom)
             roof.update({"kernel": sym or SYMBOL.get(dom, dom), "stage": dom, "avg_launch_ms": per_launch_ms, "images_per_launch": imgs_per_launch})
+            alone_ms = alone[dom][0] / alone[dom][1] if dom in alone else None      # the same launch (same images per launch) on an idle chip
             if dom in ALGO_BYTES:
                 algo = ALGO_BYTES[dom] * imgs_per_launch                        # bytes per launch
                 achieved = algo / (per_launch_ms * 1e-3) / 1e9
                 roof.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo})
                 if roof["peak_measured"]:
                     roof["frac_of_measured"] = achieved / roof["peak_measured"]
+                if alone_ms:
+                    roof["alone"] = {"avg_launch_ms": alone_ms, "achieved": algo / (alone_ms * 1e-3) / 1e9,
+                                     "frac": algo / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "note": "the same launch with nothing else on the chip (pass 6)"}
             if rec:
                 # HBM bytes per launch from the counter summary: FETCH_SIZE scaled by the factor that makes k_ingest's FETCH_SIZE equal
                 # the bytes it provably reads (MI355X_MICROARCH.md: gfx950 tallies 128-byte requests at 64 bytes), + WRITE_SIZE
@@ -662,7 +682,8 @@ def main():
                 if v:
                     ach = v * imgs_per_launch * 64 / (per_launch_ms * 1e-3) / 1e12
                     roof_valu = {"bound": "valu", "kernel": roof["kernel"], "unit": "Tlane-op/s", "peak": valu_peak, "achieved": ach,
-                                 "frac": ach / valu_peak, "peak_spec_16_lanes_per_cycle": VALU_PEAK_TLANEOPS, "peaks_source": peaks_path,
+                                 "frac": ach / valu_peak, "frac_alone": (v * imgs_per_launch * 64 / (alone_ms * 1e-3) / 1e12 / valu_peak) if alone_ms else None,
+                                 "peak_spec_16_lanes_per_cycle": VALU_PEAK_TLANEOPS, "peaks_source": peaks_path,
                                  "valu_wave_insts_per_image": v, "source": pmc_path,
                                  "note": "peak = measured issue rate of v_pk_max_i16 / v_pk_min_i16 / v_pk_maximum3_f16 / v_pk_minimum3_f16 (4 cycles "
                                          "per wave64 instruction per SIMD; v_perm_b32, v_dot4, v_alignbyte and every VOP3 integer class measure the same; "
@@ -706,6 +727,9 @@ def main():
             "roofline": roof, "roofline_valu": roof_valu, "roofline_mfma": mf,
             "profiled_pass": None if dt_prof is None else {"ms_per_step": dt_prof / args.steps * 1e3,
                                                            "kernel_ms_per_step": {SYMBOL.get(k, k): v[0] / args.steps for k, v in busy.items()}},
+            "extractor_alone": None if not alone else {"images_per_call": 2 * P // S, "calls": 3,
+                                                       "kernel_ms_per_call": {SYMBOL.get(k, k): v[0] / 3 for k, v in alone.items()},
+                                                       "note": "pass 6: one extractor handle on an otherwise idle chip; event-timed launches"},
             "streamed": None if streamed is None else dict(streamed, ratio_to_resident=streamed["value"] / value,
                                                            pcie_h2d_measured_GBps=(peaks or {}).get("h2d_GBps"),
                                                            pcie_bound_frames_per_s=None if not (peaks or {}).get("h2d_GBps") else
