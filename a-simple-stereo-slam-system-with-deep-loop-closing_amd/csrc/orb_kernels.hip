@@ -184,8 +184,9 @@ __global__ __launch_bounds__(256) void k_resize_strip(ResizeArgs a, int nstrips,
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const uint32_t tA = raw[rr][k], tB = same ? raw[rr][k] : raw[rr + 1 < RS_MAXR ? rr + 1 : rr][k];
-                    const uint32_t hA = (uint32_t)(((uint64_t)(b0 & 0xffffffu) * (uint64_t)(tA & 0xffffffu)) >> 32);
-                    const uint32_t hB = (uint32_t)(((uint64_t)(b1 & 0xffffffu) * (uint64_t)(tB & 0xffffffu)) >> 32);
+                    uint32_t hA, hB;        // both factors < 2^24 by construction: the instruction itself, without the masks C++ needs to say so
+                    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(hA) : "s"(b0), "v"(tA));
+                    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(hB) : "s"(b1), "v"(tB));
                     const uint32_t v = (hA + hB + 2u) >> 2;                         // in [0, 255]: the weights of each axis sum to 2048
                     packed |= v << (8 * k);
                 }
