@@ -1993,6 +1993,8 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
     float pat[16];                                                    // this lane's 4 test pairs (x0 y0 x1 y1), ORBextractor.cpp:101-359
 #pragma unroll
     for (int q = 0; q < 16; q++) pat[q] = (float)c_pattern[lane * 16 + q];
+#pragma unroll
+    for (int q = 0; q < 16; q++) asm volatile("" : "+v"(pat[q]));      // kept as floats: the compiler otherwise re-converts the packed int8 pattern for every key-point
     for (int j = 0; j < KD_KPB / 4; j++) {
         const int k = 4 * j + wave;                                   // the four waves work on neighbouring key-points of the tile order: their windows overlap in L1
         const int level = __builtin_amdgcn_readfirstlane(s_lv[k]);
@@ -2030,11 +2032,15 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const float x0 = pat[4 * q], y0 = pat[4 * q + 1], x1 = pat[4 * q + 2], y1 = pat[4 * q + 3];
-            const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, sb), __fmul_rn(y0, ca)));
-            const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sb)));
-            const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sb), __fmul_rn(y1, ca)));
-            const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sb)));
-            const int t0 = center[__mul24(r0, DB_P) + c0], t1 = center[__mul24(r1, DB_P) + c1];
+            // cvRound = round to nearest even: for |s| < 2^22, s + 1.5 * 2^23 has ulp 1, so its low mantissa bits ARE the rounded integer
+            // (offset by the constant's bit pattern, folded into the address): one add instead of v_rndne + v_cvt per coordinate
+            constexpr float RM = 12582912.f; constexpr uint32_t RK = 0x4B400000u;
+            const uint32_t r0 = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(x0, sb), __fmul_rn(y0, ca)), RM));
+            const uint32_t c0 = __float_as_uint(__fadd_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sb)), RM));
+            const uint32_t r1 = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(x1, sb), __fmul_rn(y1, ca)), RM));
+            const uint32_t c1 = __float_as_uint(__fadd_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sb)), RM));
+            static_assert(DB_P == 64, "row pitch of the LDS window as a shift");
+            const int t0 = center[(int)((r0 << 6) + c0 - 65u * RK)], t1 = center[(int)((r1 << 6) + c1 - 65u * RK)];
             nib |= (uint32_t)(t0 < t1) << q;
         }
         const uint32_t byte = nib | (__shfl_down(nib, 1, 64) << 4);            // valid on even lanes
