@@ -513,6 +513,121 @@ __global__ __launch_bounds__(256) void k_conv2_f16x3(const float* __restrict__ i
 
 #undef CV2_LOAD_STAGE
 
+// ---- conv1 + ReLU + max-pool + LRN on the f16 matrix cores (round 3) ----
+// The VALU form above spends 234 wave instructions per pooled pixel (scalar-window bookkeeping, 15 multiply-adds per conv output, every conv output
+// computed 1.56 times) — and VALU issue is what the whole pipeline is short of.  Here a block owns 2 x 4 pooled pixels = 5 x 9 conv outputs (18 KB of LDS and 70 registers: it fits into what six FAST blocks leave of a CU —
+// the 2 x 8 tile was 20 % faster alone and 2.5 % slower under the pipeline):
+//   1. its 13 x 21 input patch goes to LDS as two f16 planes (a = h + m' 2^-11, as k_conv2_f16x3 splits its operands);
+//   2. the conv outputs are a [64 x 32] x [32 x 64] product (K = 5 rows x 6 slots, the sixth and two more with zero weights; stride-2 im2col = 4 dword
+//      LDS reads per lane, plane and K step at constant offsets from the lane's window origin), three partial products into one accumulator;
+//   3. bias and ReLU go into an LDS conv map [64][64]; 4. lane = channel: 3 x 3 maximum over the map (Caffe's clipped ceil-mode windows), LRN over
+//      lane shuffles, one 256-byte row per pooled pixel out.
+// ~80 instead of 234 wave instructions per pooled pixel, no conv output computed twice inside a block.  Same range conditions as k_conv2_f16x3.
+constexpr int C1T_PH = 2, C1T_PW = 4, C1T_CH = 2 * C1T_PH + 1, C1T_CW = 2 * C1T_PW + 1;       // pooled tile, conv outputs it needs
+constexpr int C1T_IH = 2 * (C1T_CH - 1) + 5, C1T_IW = 2 * (C1T_CW - 1) + 5, C1T_IP = 24;       // input patch 13 x 21, 24 halfs per LDS row
+constexpr int C1T_NCP = C1T_CH * C1T_CW, C1T_NM = (C1T_NCP + 31) / 32, C1T_CP = 66;             // 45 conv pixels, 2 M tiles, conv map pitch (floats)
+constexpr int C1T_TX = (WP1 + C1T_PW - 1) / C1T_PW, C1T_TY = (HP1 + C1T_PH - 1) / C1T_PH;
+static_assert(C1T_NM <= 4, "one M tile per wave");
+
+__global__ __launch_bounds__(256) void k_conv1_f16x3_pool_lrn(const float* __restrict__ in, const uint4* __restrict__ w1h /*[2 n tiles][2 k steps][3: Hs, m', h][64 lanes]*/,
+                                                              const float* __restrict__ b1, int relu, LrnP lp, float* __restrict__ out /*[HP1*WP1][64]*/) {
+    __shared__ __attribute__((aligned(8))) _Float16 s_h[C1T_IH * C1T_IP + 4], s_m[C1T_IH * C1T_IP + 4];
+    static_assert(C1T_IP % 2 == 0, "dword reads of pixel pairs");
+    __shared__ float s_conv[32 * C1T_NM * C1T_CP];
+    const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int ty = blockIdx.x / C1T_TX, tx = blockIdx.x - ty * C1T_TX;
+    const int py0 = ty * C1T_PH, px0 = tx * C1T_PW;
+    // 1. input patch: padded-plane rows 4 py0 .., columns 4 px0 .. (rows / columns past the plane only feed conv outputs outside the map: zeros)
+    const float* I = in + (size_t)b * IN_PLANE;
+    static_assert(C1T_IP % 4 == 0 && C1T_IH * (C1T_IP / 4) <= 256 && (4 * C1T_PW) % 4 == 0, "one float4 of the patch per thread");
+    if (t < C1T_IH * (C1T_IP / 4)) {                                   // whole LDS rows (the zero-weight K slots still need finite operands), 4 pixels per thread
+        const int r = t / (C1T_IP / 4), c4 = 4 * (t - r * (C1T_IP / 4));
+        const int iy = 4 * py0 + r, ix = 4 * px0 + c4;                  // 16-byte aligned: 4 px0 and the plane pitch are multiples of 4
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (iy < IN_PH && ix + 4 <= IN_PW) a = *reinterpret_cast<const float4*>(I + iy * IN_PW + ix);
+        if (c4 + 3 >= C1T_IW) { if (c4 + 1 >= C1T_IW) a.y = 0.f; if (c4 + 2 >= C1T_IW) a.z = 0.f; a.w = 0.f; if (c4 >= C1T_IW) a.x = 0.f; }
+        const _Float16 h0 = (_Float16)a.x, h1 = (_Float16)a.y, h2 = (_Float16)a.z, h3 = (_Float16)a.w;
+        typedef _Float16 c1_h4 __attribute__((ext_vector_type(4)));
+        const c1_h4 hv = {h0, h1, h2, h3};
+        const c1_h4 mv = {(_Float16)((a.x - (float)h0) * 2048.f), (_Float16)((a.y - (float)h1) * 2048.f), (_Float16)((a.z - (float)h2) * 2048.f),
+                          (_Float16)((a.w - (float)h3) * 2048.f)};
+        *reinterpret_cast<c1_h4*>(&s_h[r * C1T_IP + c4]) = hv;
+        *reinterpret_cast<c1_h4*>(&s_m[r * C1T_IP + c4]) = mv;
+    }
+    __syncthreads();
+    // 2. conv outputs of M tile `wave`.  K slot k = 6 ky + kx' with kx' = 0..5 (kx' = 5 and slots 30, 31 carry zero weights): a lane's 8 slots are
+    //    4 aligned dwords of the patch (two horizontally adjacent pixels each) at constant offsets from its window origin — 4 ds_read_b32 per
+    //    plane and K step instead of 8 two-byte reads + packing
+    if (wave < C1T_NM) {
+        const int mrow = lane & 31, kh = lane >> 5;
+        const int cp = min(32 * wave + mrow, C1T_NCP - 1);             // rows past the conv pixels of the tile repeat the last one (their results are never read)
+        const int cy = cp / C1T_CW, cx = cp - cy * C1T_CW;
+        const uint32_t* ph = reinterpret_cast<const uint32_t*>(s_h) + (2 * cy * C1T_IP + 2 * cx) / 2;      // window origin: an even half index
+        const uint32_t* pm = reinterpret_cast<const uint32_t*>(s_m) + (2 * cy * C1T_IP + 2 * cx) / 2;
+        cv_f16x8 Ah[2], Am[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            uint32_t dh[4], dm[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                // dword d of the 16 (d = 8 ks + 4 kh + j): patch row d / 3, pixel pair d % 3; d = 15 is padding (zero weights): dword 14 again
+                const int d0 = min(8 * ks + j, 14), d1 = min(8 * ks + 4 + j, 14);
+                const int o0 = (d0 / 3) * (C1T_IP / 2) + d0 % 3, o1 = (d1 / 3) * (C1T_IP / 2) + d1 % 3;      // compile-time constants
+                const int o = kh ? o1 : o0;
+                dh[j] = ph[o]; dm[j] = pm[o];
+            }
+            Ah[ks] = __builtin_bit_cast(cv_f16x8, make_uint4(dh[0], dh[1], dh[2], dh[3]));
+            Am[ks] = __builtin_bit_cast(cv_f16x8, make_uint4(dm[0], dm[1], dm[2], dm[3]));
+        }
+        const float lo = relu ? 0.f : -INFINITY;
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const uint4* wp = w1h + ((nt * 2 + ks) * 3) * 64 + lane;               // L2-resident, 12 KB
+                const cv_f16x8 B0 = __builtin_bit_cast(cv_f16x8, wp[0]), B1 = __builtin_bit_cast(cv_f16x8, wp[64]), B2 = __builtin_bit_cast(cv_f16x8, wp[128]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Am[ks], B2, acc, 0, 0, 0);          // m'_a h_w
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[ks], B1, acc, 0, 0, 0);          // h_a m'_w
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[ks], B0, acc, 0, 0, 0);          // h_a 2^11 h_w
+            }
+            const int n = 32 * nt + (lane & 31);
+            const float bias = b1[n];
+            float* o = s_conv + (32 * wave + 4 * kh) * C1T_CP + n;                                // accumulator row r -> conv pixel 32 wave + (r & 3) + 8 (r >> 2) + 4 kh
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[((r & 3) + 8 * (r >> 2)) * C1T_CP] = fmaxf(acc[r] * (1.0f / 2048.f) + bias, lo);      // all rows of the M tile; validity is the pool's business
+        }
+    }
+    __syncthreads();
+    // 3. lane = channel: pooled maximum + LRN(5) across the 64 channels (zero padded), as k_conv1_pool_lrn2
+    for (int pp = wave; pp < C1T_PH * C1T_PW; pp += 4) {
+        const int qy = pp / C1T_PW, qx = pp - qy * C1T_PW;
+        const int py = py0 + qy, px = px0 + qx;
+        if (py >= HP1 || px >= WP1) continue;                           // wave-uniform
+        float m = -INFINITY;
+        const float* cm = s_conv + ((2 * qy) * C1T_CW + 2 * qx) * C1T_CP + lane;
+        if (2 * py + 2 < H1 && 2 * px + 2 < W1) {                       // wave-uniform: the whole 3 x 3 window lies inside the conv map
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+                for (int dx = 0; dx < 3; dx++) m = fmaxf(m, cm[(dy * C1T_CW + dx) * C1T_CP]);
+        } else {                                                        // Caffe ceil-mode pooling: clipped windows at the map's last row / column
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+                for (int dx = 0; dx < 3; dx++)
+                    if (2 * py + dy < H1 && 2 * px + dx < W1) m = fmaxf(m, cm[(dy * C1T_CW + dx) * C1T_CP]);
+        }
+        const float um1 = __shfl_up(m, 1, 64), um2 = __shfl_up(m, 2, 64), dp1 = __shfl_down(m, 1, 64), dp2 = __shfl_down(m, 2, 64);
+        const float v0 = lane >= 2 ? um2 : 0.f, v1 = lane >= 1 ? um1 : 0.f, v3 = lane <= 62 ? dp1 : 0.f, v4 = lane <= 61 ? dp2 : 0.f;
+        float ss = 0.f;
+        ss += v0 * v0; ss += v1 * v1; ss += m * m; ss += v3 * v3; ss += v4 * v4;
+        out[((size_t)b * HP1 * WP1 + py * WP1 + px) * 64 + lane] = m * lrn_factor(ss, lp);
+    }
+}
+
 // ---- conv3 + ReLU + flatten (NCHW order) + L2 normalise ----
 // CV3_NB blocks of 256 threads per image: 16 waves share the 266 output pixels (wave g takes pixels g, g + 16, ...), each lane keeps its 18
 // weight quadruples (k = lane + 64 j) in registers; k_l2norm_1064 follows.  Round 2 ran ONE 1024-thread block per image: 16 waves x 101 registers need a nearly empty CU, so under the pipeline the
@@ -758,6 +873,7 @@ struct myslam_lcd {
     int forceBf16 = 0;                 // myslam_lcd_set_option(CONV2_BF16X6): keep the six-product bf16 kernel
     std::vector<float*> d_wt, d_b;     // per convolution: weights re-laid out as [K*K*IC][OC], bias
     uint4* d_w2s = nullptr;            // fused path: conv2 weights split into three bf16 pieces, [stage][piece][n][k half] x 8 bf16
+    uint4* d_w1h = nullptr;            // conv1 weights as MFMA operands of k_conv1_f16x3_pool_lrn ([n tile][k step][2^11 h, m', h][lane]), same condition as d_w2h
     uint4* d_w2h = nullptr;            // the same as three f16 planes (2^11 h, m', h) when the model's ranges allow k_conv2_f16x3, else nullptr
     size_t actMax = 0;                 // largest activation (floats per image) of the generic path
     // resize tables for the current source size
@@ -788,7 +904,7 @@ static int lcd_alloc(T*& p, size_t n) {
 }
 
 void myslam_lcd::free_all() {
-    void* ptrs[] = {d_w2s, d_w2h, d_xofs, d_yofs, d_xa, d_yb, d_blur, d_in, d_p1, d_a2, d_p2, d_g0, d_g1, d_stageImg, d_stageOut};
+    void* ptrs[] = {d_w2s, d_w2h, d_w1h, d_xofs, d_yofs, d_xa, d_yb, d_blur, d_in, d_p1, d_a2, d_p2, d_g0, d_g1, d_stageImg, d_stageOut};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (float* p : d_wt) if (p) (void)hipFree(p);
     for (float* p : d_b) if (p) (void)hipFree(p);
@@ -889,7 +1005,8 @@ static int lcd_forward(myslam_lcd* h, int batch, float* d_out) {
     const FusedPlan& f = h->fused;
     {
         ScopedProf sp(P_CONV1, s);
-        hipLaunchKernelGGL(k_conv1_pool_lrn2, dim3((HT1 * WT1 + 3) / 4, batch), dim3(256), 0, s, h->d_in, h->d_wt[0], h->d_b[0], f.relu[0], f.lrn[0], h->d_p1);
+        if (h->d_w1h && !h->forceBf16) hipLaunchKernelGGL(k_conv1_f16x3_pool_lrn, dim3(C1T_TX * C1T_TY, batch), dim3(256), 0, s, h->d_in, h->d_w1h, h->d_b[0], f.relu[0], f.lrn[0], h->d_p1);
+        else hipLaunchKernelGGL(k_conv1_pool_lrn2, dim3((HT1 * WT1 + 3) / 4, batch), dim3(256), 0, s, h->d_in, h->d_wt[0], h->d_b[0], f.relu[0], f.lrn[0], h->d_p1);
     }
     {
         ScopedProf sp(P_CONV2, s);
@@ -1023,6 +1140,26 @@ static int lcd_create(myslam_lcd** out, const myslam_calc_layer* layers, int nla
             if (hipMalloc((void**)&h->d_w2h, w2h.size() * 2) != hipSuccess ||
                 hipMemcpy(h->d_w2h, w2h.data(), w2h.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
                 return fail(MYSLAM_ERR_HIP);
+            double wmax1 = 0;
+            for (int i = 0; i < n1 * k1; i++) wmax1 = std::max(wmax1, (double)std::fabs(w1[i]));
+            if (wmax1 < 31.0 && k1 == 25 && n1 == 64) {
+                // conv1 weights in the B-operand layout of v_mfma_f32_32x32x16_f16: lane (n = lane & 31, k half = lane >> 5) holds k = 16 ks + 8 kh + j
+                std::vector<uint16_t> w1h((size_t)2 * 2 * 3 * 64 * 8);
+                for (int nt = 0; nt < 2; nt++)
+                    for (int ks = 0; ks < 2; ks++)
+                        for (int ln = 0; ln < 64; ln++)
+                            for (int j = 0; j < 8; j++) {
+                                const int n = 32 * nt + (ln & 31), k = 16 * ks + 8 * (ln >> 5) + j;
+                                const int ky = k / 6, kx = k % 6;                                   // K slot -> tap (kx = 5 and slots 30, 31: zero)
+                                const float a = (ky < 5 && kx < 5) ? w1[(size_t)n * 25 + ky * 5 + kx] : 0.f;
+                                const uint16_t hb = to_f16(a); const float hf = from_f16(hb);
+                                const uint16_t pcs[3] = {to_f16(hf * 2048.f), to_f16((a - hf) * 2048.f), hb};
+                                for (int pc = 0; pc < 3; pc++) w1h[((((size_t)(nt * 2 + ks) * 3 + pc) * 64 + ln) * 8) + j] = pcs[pc];
+                            }
+                if (hipMalloc((void**)&h->d_w1h, w1h.size() * 2) != hipSuccess ||
+                    hipMemcpy(h->d_w1h, w1h.data(), w1h.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
+                    return fail(MYSLAM_ERR_HIP);
+            }
         }
     }
     *out = h;

@@ -71,7 +71,7 @@ ALGO_BYTES = {
 # profiling slot (csrc/prof.hip) -> kernel symbol prefix as rocprofv3 prints it
 SYMBOL = {"resize": "k_resize_strip", "fast": "k_fast_strip", "octree": "k_octree", "blur7": "k_blur7_strip", "describe": "k_describe2",
           "hamming_match": "k_hamming_fp4", "triangulate": "k_triangulate", "lcd_preproc": "k_lcd_input_fused",
-          "calc_conv1": "k_conv1_pool_lrn2", "calc_conv2": "k_conv2_f16x3", "calc_pool2": "k_pool_lrn128_2x2", "calc_conv3": "k_conv3_norm", "lcddb_scan": "k_db_scan_bf16x6",
+          "calc_conv1": "k_conv1_f16x3_pool_lrn", "calc_conv2": "k_conv2_f16x3", "calc_pool2": "k_pool_lrn128_2x2", "calc_conv3": "k_conv3_norm", "lcddb_scan": "k_db_scan_bf16x6",
           "ba_build": "k_ba_build", "screen": "k_screen"}
 
 

@@ -13,7 +13,7 @@ for f in $D/lib*.so; do
 import json
 try:
     d = json.load(open("gpurun_out/ab_${n}_$rep.json"))
-    print("$n", $rep, round(d["value"]), round(d["ms_per_step"], 3), {k: round(v, 3) for k, v in ((d.get("profiled_pass") or {}).get("kernel_ms_per_step") or {}).items() if k in ("k_fast_strip", "k_octree", "k_describe2", "k_resize_strip", "k_blur7_strip", "k_conv1_pool_lrn2", "k_conv2_f16x3", "k_ba_build", "k_triangulate", "k_hamming_fp4")})
+    print("$n", $rep, round(d["value"]), round(d["ms_per_step"], 3), {k: round(v, 3) for k, v in ((d.get("profiled_pass") or {}).get("kernel_ms_per_step") or {}).items() if k in ("k_fast_strip", "k_octree", "k_describe2", "k_resize_strip", "k_blur7_strip", "k_conv1_f16x3_pool_lrn", "k_conv2_f16x3", "k_ba_build", "k_triangulate", "k_hamming_fp4")})
 except Exception as e:
     print("$n failed", e)
 PY

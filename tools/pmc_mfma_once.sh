@@ -10,7 +10,7 @@ else:
     for r in csv.DictReader(open(f[0])):
         k=r['Kernel_Name'].split('(')[0].replace('void ','').replace('myslam_hip::','')
         agg[k][r['Counter_Name']]+=float(r['Counter_Value'])
-    for k in ('k_conv2_f16x3','k_conv1_pool_lrn2','k_hamming_fp4'):
+    for k in ('k_conv2_f16x3','k_conv1_f16x3_pool_lrn','k_hamming_fp4'):
         print(k, {c: round(v/4) for c,v in agg[k].items()}, "(per launch of 64 frames)")
 PY
 done
