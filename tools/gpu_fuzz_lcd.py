@@ -1,0 +1,43 @@
+"""GPU fuzz of the DeepLCD path: random CALC weights (scaled per layer so that the value ranges move through and past what the f16 matrix-core
+kernels accept), random image sizes, the descriptor against the oracle (2e-5), the two conv2 / conv1 kernel families against each other, the
+batch call against the single-frame call, and scores.   python tools/gpu_fuzz_lcd.py [seed] [cases]"""
+import sys, numpy as np
+sys.path.insert(0, ".")
+import torch  # noqa: F401
+import __graft_entry__ as g
+pkg = g.load_package(); api, synth = pkg.api, pkg.synth
+sys.path.insert(0, "oracle")
+from pyoracle import Oracle
+o = Oracle()
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+bad = 0; kinds = {3: 0, 6: 0}
+O1, O2 = 64 * 25 + 64, 64 * 25 + 64 + 128 * 64 * 16 + 128            # offsets of conv2's and conv3's blocks in the flat weight blob
+for it in range(N):
+    w = synth.calc_weights(int(rng.integers(1 << 30))).copy()
+    s1, s2, s3 = (float(np.exp(rng.uniform(np.log(0.2), np.log(8.0)))) for _ in range(3))
+    w[:64 * 25] *= s1; w[O1:O1 + 128 * 64 * 16] *= s2; w[O2:O2 + 4 * 128 * 9] *= s3
+    if rng.random() < 0.15:       # a model whose conv2 weights leave the f16 form's range: must fall back by itself
+        w[O1:O1 + 128 * 64 * 16] *= 35.0 / float(np.abs(w[O1:O1 + 128 * 64 * 16]).max())
+    h = int(rng.integers(120, 420)); wd = int(rng.integers(160, 1300))
+    img = np.ascontiguousarray(synth.random_image(int(rng.integers(1 << 30)), h, wd, "texture" if rng.random() < 0.7 else "noise"))
+    a = api.DeepLCD(w); b = api.DeepLCD(w); b.set_option(b.OPT_CONV2_BF16X6, 1)
+    kinds[a.conv2_products()] = kinds.get(a.conv2_products(), 0) + 1
+    da, _ = a.calcDescrOriginalImg(img, blur_in_place=False); db_, _ = b.calcDescrOriginalImg(img, blur_in_place=False)
+    ref = o.calc_forward(w, o.calc_preproc(img, blur_in_place=False)[0])
+    ok = np.isfinite(da).all() and np.abs(da - ref).max() < 2e-5 and np.abs(db_ - ref).max() < 2e-5 and np.abs(da - db_).max() < 5e-6
+    # the batch entry point on three copies + one other frame: entry 0 equals the single-frame call bit for bit
+    B = 4
+    imgs = np.stack([img, img, synth.random_image(int(rng.integers(1 << 30)), h, wd, "texture"), img])
+    d_imgs = torch.from_numpy(np.ascontiguousarray(imgs)).cuda(); d_out = torch.zeros(B, 1064, dtype=torch.float32, device="cuda")
+    a.describe_batch(d_imgs.data_ptr(), B, h, wd, wd, h * wd, d_out.data_ptr(), blur_in_place=False)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    ok = ok and np.array_equal(got[0].view(np.uint32), da.view(np.uint32)) and np.array_equal(got[0], got[3])
+    ok = ok and abs(api.DeepLCD.score(got[0], got[2]) - o.lcd_score(got[0], got[2])) < 1e-6
+    if not ok:
+        bad += 1
+        print("LCD MISMATCH", dict(h=h, w=wd, s=(round(s1, 2), round(s2, 2), round(s3, 2)), products=a.conv2_products(),
+                                   err_a=float(np.abs(da - ref).max()), err_b=float(np.abs(db_ - ref).max()), ab=float(np.abs(da - db_).max())))
+print(f"fuzz done: {N} cases, {bad} mismatches; conv2 kernel chosen: {kinds}")
+sys.exit(1 if bad else 0)
