@@ -235,8 +235,9 @@ int myslam_lcd_uses_fused_kernels(const myslam_lcd* h);
  * reach f32-level accuracy (max-normalised error against f64: 1.1e-6 / 1.5e-6). */
 int myslam_lcd_conv2_products(const myslam_lcd* h);
 #define MYSLAM_LCD_OPT_GENERIC_KERNELS 1       /* value != 0: run even a fusable list on the generic kernels (tests, diagnosis) */
-#define MYSLAM_LCD_OPT_CONV2_BF16X6 2          /* value != 0: conv2 of the fused path on the six-product bf16 kernel even when the model's ranges allow the
-                                                * three-product f16 one (both reach f32-level accuracy; tests compare them) */
+#define MYSLAM_LCD_OPT_CONV2_BF16X6 2          /* value != 0: conv2 of the fused path on the six-product bf16 kernel and conv1 on its f32 vector kernel even when
+                                                * the model's ranges allow the three-product f16 matrix-core kernels (all reach f32-level accuracy; tests and
+                                                * tools/gpu_fuzz_lcd.py compare the two families) */
 int myslam_lcd_set_option(myslam_lcd* h, int option, int value);
 int myslam_lcd_destroy(myslam_lcd* h);
 int myslam_lcd_set_stream(myslam_lcd* h, void* hip_stream);
