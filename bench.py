@@ -605,10 +605,14 @@ def main():
 
     if args.verify and args.pipeline:
         # the overlapped schedule must not change a single output: one plain step (handles un-gated, joined) against the last pipelined one
-        step(); torch.cuda.synchronize()
-        p_last = (step_no[0] - 1) % NB
         outs = lambda p: [d_kps_b[p], d_desc_b[p], d_cnt_b[p], d_stat_b[p], d_midx, d_mdist, d_xyz, d_ok] + \
             ([d_descr, d_best, d_max, d_dbcnt] if use_lcd else []) + (list(b_out) if use_ba else [])
+        torch.cuda.synchronize()
+        for p in range(NB):             # both sides start from cleared buffers: slots behind an image's count keep whatever an earlier pass
+            for t in outs(p):           # (the streamed one extracts other frames) left there, and whole buffers are compared
+                t.zero_()
+        step(); torch.cuda.synchronize()
+        p_last = (step_no[0] - 1) % NB
         ref = [t.clone() for t in outs(p_last)]
         for e in exts:
             e.set_fast_event(0); e.set_fast_gate(0)
