@@ -415,6 +415,12 @@ class LoopDatabase:
     def __len__(self):
         return lib().myslam_lcddb_size(self._h)
 
+    def capacity(self):
+        return lib().myslam_lcddb_capacity(self._h)
+
+    def reserve(self, rows):
+        _check(lib().myslam_lcddb_reserve(self._h, int(rows)), "myslam_lcddb_reserve")
+
     def AddToDatabase(self, kf_id, descr):
         d = np.ascontiguousarray(descr, np.float32)
         _check(lib().myslam_lcddb_append(self._h, C.c_uint64(kf_id), _p(d)), "myslam_lcddb_append")

@@ -1279,7 +1279,6 @@ int myslam_ba_flatten_window(const uint64_t* active_kf_ids, int n_kf, const uint
     for (int k = 0; k < n_obs; k++) {
         auto it = mrow.find(obs_mp_id[k]);
         if (it == mrow.end()) return MYSLAM_ERR_INVALID;                                   // an observation of a map point that is not active
-        if (kslot.find(obs_kf_id[k]) == kslot.end()) return MYSLAM_ERR_INVALID;            // backend.cpp:187 assert
         orow[k] = it->second; cnt[it->second + 1]++;
     }
     for (int i = 0; i < n_mp; i++) cnt[i + 1] += cnt[i];
@@ -1298,8 +1297,10 @@ int myslam_ba_flatten_window(const uint64_t* active_kf_ids, int n_kf, const uint
         const int e0 = E;
         for (int r = cnt[i]; r < cnt[i + 1]; r++) {
             const int k = rows[r];
+            const auto ks = kslot.find(obs_kf_id[k]);
+            if (ks == kslot.end()) return MYSLAM_ERR_INVALID;                              // :187 assert — behind the outlier skip of :163, as there
             if (obs_feat_outlier && obs_feat_outlier[k]) continue;                         // :189
-            edge_pose[E] = kslot[obs_kf_id[k]]; edge_pt[E] = L;
+            edge_pose[E] = ks->second; edge_pt[E] = L;
             edge_obs[2 * E] = (double)obs_uv[2 * k]; edge_obs[2 * E + 1] = (double)obs_uv[2 * k + 1];      // toVec2(feat->mkpPosition.pt), :194
             edge_src[E] = k;
             E++;

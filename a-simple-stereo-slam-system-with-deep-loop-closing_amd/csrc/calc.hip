@@ -1124,7 +1124,8 @@ static int lcd_create(myslam_lcd** out, const myslam_calc_layer* layers, int nla
         }
         for (float v : w2t) wmax2 = std::max(wmax2, (double)std::fabs(v));
         const bool finite = std::isfinite(bound1) && std::isfinite(wmax2);
-        if (finite && bound1 < 60000.0 && wmax2 < 31.0 && h->fused.lrn[0].k >= 1.0f && h->fused.lrn[0].beta >= 0.0f) {
+        if (finite && bound1 < 60000.0 && wmax2 < 31.0 && h->fused.lrn[0].k >= 1.0f && h->fused.lrn[0].beta >= 0.0f &&
+            h->fused.lrn[0].aon >= 0.0f && std::isfinite(h->fused.lrn[0].aon) && std::isfinite(h->fused.lrn[0].beta)) {      // alpha < 0 would make (k + alpha/n ss)^-beta exceed 1 (walk_layers rejects it already)
             auto to_f16 = [](float x) -> uint16_t { const _Float16 v = (_Float16)x; uint16_t u; memcpy(&u, &v, 2); return u; };   // round to nearest even
             auto from_f16 = [](uint16_t b) -> float { _Float16 v; memcpy(&v, &b, 2); return (float)v; };
             std::vector<uint16_t> w2h((size_t)64 * 3 * 128 * 16);

@@ -315,9 +315,39 @@ int myslam_lcddb_set_stream(myslam_lcddb* h, void* s) {
 
 int myslam_lcddb_size(const myslam_lcddb* h) { return h ? h->n : MYSLAM_ERR_INVALID; }
 
+// LoopClosing::_mvDatabase is an unbounded std::map (loopclosing.h:120, loopclosing.cpp:651-659): the device matrix grows with it.
+// New storage, one device-to-device copy of the rows held so far, zeroed tail (the scan kernels read whole blocks of rows).
+static int db_reserve(myslam_lcddb* h, long long rows) {
+    const int rowsPerBlock = DB_WAVES * DB_ROWS_PER_WAVE;
+    if (rows <= h->capacity) return MYSLAM_OK;
+    if (rows > (long long)INT32_MAX - rowsPerBlock) return MYSLAM_ERR_CAPACITY;
+    const int cap = (int)((rows + rowsPerBlock - 1) / rowsPerBlock * rowsPerBlock);
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));                    // nothing in flight reads the old matrix
+    float* nd = nullptr; uint64_t* ni = nullptr;
+    if (hipMalloc((void**)&nd, (size_t)cap * DIM * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return MYSLAM_ERR_CAPACITY; }
+    if (hipMalloc((void**)&ni, (size_t)cap * sizeof(uint64_t)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(nd); return MYSLAM_ERR_CAPACITY; }
+    auto move_rows = [&]() -> int {
+        if (h->n) {
+            MYSLAM_HIP_CHECK(hipMemcpyAsync(nd, h->d_db, (size_t)h->n * DIM * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+            MYSLAM_HIP_CHECK(hipMemcpyAsync(ni, h->d_ids, (size_t)h->n * sizeof(uint64_t), hipMemcpyDeviceToDevice, h->stream));
+        }
+        MYSLAM_HIP_CHECK(hipMemsetAsync(nd + (size_t)h->n * DIM, 0, (size_t)(cap - h->n) * DIM * sizeof(float), h->stream));
+        MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+        return MYSLAM_OK;
+    };
+    const int rc = move_rows();
+    if (rc) { (void)hipFree(nd); (void)hipFree(ni); return rc; }
+    (void)hipFree(h->d_db); (void)hipFree(h->d_ids);
+    h->d_db = nd; h->d_ids = ni; h->capacity = cap;
+    return MYSLAM_OK;
+}
+
 static int db_append(myslam_lcddb* h, const uint64_t* ids, const float* src, int n, hipMemcpyKind kind) {
     if (!h || !ids || !src || n < 0) return MYSLAM_ERR_INVALID;
-    if (h->n + n > h->capacity) return MYSLAM_ERR_CAPACITY;
+    if ((long long)h->n + n > h->capacity) {                              // geometric growth: AddToDatabase never fails for lack of room
+        const int rc = db_reserve(h, std::max<long long>((long long)h->n + n, 2LL * h->capacity));
+        if (rc) return rc;
+    }
     for (int i = 0; i < n; i++) {
         const uint64_t prev = (i == 0) ? (h->ids.empty() ? 0 : h->ids.back()) : ids[i - 1];
         const bool first = (i == 0 && h->ids.empty());
@@ -329,6 +359,13 @@ static int db_append(myslam_lcddb* h, const uint64_t* ids, const float* src, int
     h->ids.insert(h->ids.end(), ids, ids + n);
     h->n += n;
     return MYSLAM_OK;
+}
+
+int myslam_lcddb_capacity(const myslam_lcddb* h) { return h ? h->capacity : MYSLAM_ERR_INVALID; }
+
+int myslam_lcddb_reserve(myslam_lcddb* h, int rows) {
+    if (!h || rows < 0) return MYSLAM_ERR_INVALID;
+    return db_reserve(h, rows);
 }
 
 int myslam_lcddb_append(myslam_lcddb* h, uint64_t id, const float* descr) { return db_append(h, &id, descr, 1, hipMemcpyHostToDevice); }

@@ -399,6 +399,7 @@ int myslam_orb::run_batch(const uint8_t* d_imgs, int batch, int r, int c, int st
     if (stop == 1) {
         launch_ingest_clear(d_imgs, full.rows, full.cols, step, stride, d_pyr + full.lv[0].imgOff, full.lv[0].pitch, full.pyrBytes, batch,
                             clr.p[0], clr.n[0], clr.p[1], clr.n[1], clr.p[2], clr.n[2], clr.p[3], clr.n[3], stream);
+        clr.n[0] = 0;                      // the list holds the caller's d_stat pointer: it must not outlive the call (build_pyramids resets it too)
         return MYSLAM_OK;
     }
     if ((rc = build_pyramids(d_imgs, batch, step, stride, d_masks, P.nlevels))) return rc;

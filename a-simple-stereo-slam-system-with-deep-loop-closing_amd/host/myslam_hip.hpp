@@ -220,6 +220,8 @@ class LoopDatabase {           // LoopClosing::_mvDatabase + DetectLoop + AddToD
     LoopDatabase& operator=(const LoopDatabase&) = delete;
     void AddToDatabase(unsigned long kfId, const DeepLCD::DescrVector& d) { check(myslam_lcddb_append(h_, kfId, d.data()), "myslam_lcddb_append"); }
     size_t size() const { return (size_t)myslam_lcddb_size(h_); }
+    size_t capacity() const { return (size_t)myslam_lcddb_capacity(h_); }          // grows by itself (std::map has no bound); reserve() avoids the moves
+    void reserve(int rows) { check(myslam_lcddb_reserve(h_, rows), "myslam_lcddb_reserve"); }
     // loopclosing.cpp:124-161: true + loop KF id when maxScore >= high threshold and at most 3 scores exceed the low one
     bool DetectLoop(unsigned long curKFId, const DeepLCD::DescrVector& d, unsigned long& loopKFId, float* maxScore = nullptr) {
         uint64_t best = 0; float mx = 0; int cnt = 0;

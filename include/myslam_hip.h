@@ -267,6 +267,12 @@ int myslam_lcddb_create(myslam_lcddb** out, int capacity);
 int myslam_lcddb_destroy(myslam_lcddb* h);
 int myslam_lcddb_set_stream(myslam_lcddb* h, void* hip_stream);
 int myslam_lcddb_size(const myslam_lcddb* h);
+/* `capacity` of myslam_lcddb_create is the first allocation only: _mvDatabase is an unbounded std::map (loopclosing.h:120), so append
+ * grows the device matrix geometrically (x2, one device-to-device copy of the rows held so far; the handle's stream is synchronised
+ * while it moves) and fails with MYSLAM_ERR_CAPACITY only when the device has no memory left.  myslam_lcddb_reserve makes room for
+ * `rows` key-frames ahead of time (never shrinks); myslam_lcddb_capacity = rows the current allocation holds. */
+int myslam_lcddb_capacity(const myslam_lcddb* h);
+int myslam_lcddb_reserve(myslam_lcddb* h, int rows);
 int myslam_lcddb_append(myslam_lcddb* h, uint64_t id, const float* descr1064);
 int myslam_lcddb_append_batch(myslam_lcddb* h, const uint64_t* ids /*host*/, const float* d_descr, int n);
 int myslam_lcddb_query(myslam_lcddb* h, const float* descr1064, uint64_t cur_id, float thr_low,

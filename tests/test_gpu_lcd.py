@@ -108,6 +108,40 @@ def test_loop_database_scan(api, oracle, synth, n):
         D.AddToDatabase(int(ids[-1]), db[0])                         # ids must ascend (std::map order)
 
 
+def test_loop_database_grows_like_the_std_map(api, oracle, synth):
+    """LoopClosing::_mvDatabase is an unbounded std::map (loopclosing.h:120, loopclosing.cpp:651-659): AddToDatabase must never fail for
+    lack of room.  A handle created for 8 key-frames takes 700 one by one and a 2 000-row device batch; every scan equals the oracle's."""
+    import torch
+    n1, n2 = 700, 2000
+    db = synth.lcd_database(n1 + n2); ids = np.arange(n1 + n2, dtype=np.uint64) * 2 + 1
+    D = api.LoopDatabase(8)
+    cap0 = D.capacity()
+    grown = 0
+    for i in range(n1):
+        D.AddToDatabase(int(ids[i]), db[i])
+        if D.capacity() != cap0:
+            grown += 1; cap0 = D.capacity()
+        if i in (7, 8, 63, 64, 65, 300, n1 - 1):                      # straight after a move and between moves
+            got = D.query(db[i // 2], int(ids[i]) + 20); ref = oracle.lcddb_query(db[:i + 1], ids[:i + 1], db[i // 2], int(ids[i]) + 20)
+            assert got[0] == ref[0] and abs(got[1] - ref[1]) < SCORE_ATOL and got[2] == ref[2], i
+    assert len(D) == n1 and grown >= 3 and D.capacity() >= n1
+    t = torch.from_numpy(db[n1:]).cuda()
+    D.append_batch(ids[n1:], t.data_ptr(), n2)                        # one batch larger than twice the capacity
+    assert len(D) == n1 + n2 and D.capacity() >= n1 + n2
+    D.reserve(10000); c = D.capacity(); assert c >= 10000
+    D.reserve(100); assert D.capacity() == c                          # never shrinks
+    nq = 64
+    qs = db[np.random.default_rng(5).integers(0, n1 + n2, nq)].copy()
+    cur = np.full(nq, int(ids[-1]) + 20, np.uint64); cur[::3] = ids[n1 + 5]
+    d_q = torch.from_numpy(qs).cuda()
+    d_best = torch.zeros(nq, dtype=torch.int64, device="cuda"); d_max = torch.zeros(nq, device="cuda"); d_cnt = torch.zeros(nq, dtype=torch.int32, device="cuda")
+    D.query_batch(d_q.data_ptr(), cur, nq, d_best.data_ptr(), d_max.data_ptr(), d_cnt.data_ptr())
+    torch.cuda.synchronize()
+    for i in range(nq):
+        ref = oracle.lcddb_query(db, ids, qs[i], int(cur[i]))
+        assert int(d_best[i]) == ref[0] and abs(float(d_max[i]) - ref[1]) < SCORE_ATOL and int(d_cnt[i]) == ref[2], i
+
+
 def test_loop_database_rules(api, oracle, synth):
     db = synth.lcd_database(100); ids = np.arange(100, dtype=np.uint64) * 2
     D = api.LoopDatabase(100)
