@@ -15,6 +15,7 @@ the parity tests and bench.py; it never falls back to a CPU path.
 from . import build as _build          # noqa: F401
 from . import synth                    # noqa: F401
 from . import api                      # noqa: F401
+from . import chain                    # noqa: F401  (Frontend / Backend / LoopClosing of the reference over the operators: configs[0]'s host side)
 
 
 def __getattr__(name):

@@ -378,10 +378,10 @@ def pnp_problem(n=120, outlier_frac=0.3, noise_px=0.5, seed=0x919, K=KITTI00, w=
 SEQ_K = {"fx": 420.0, "fy": 420.0, "cx": 359.5, "cy": 119.5, "bf": 420.0 * 0.54}       # a 720 x 240 camera, 0.54 m baseline
 
 
-def sequence_scene(seed=0x5E0, tex_w=4096, tex_h=1024, texels_per_m=40.0):
+def sequence_scene(seed=0x5E0, tex_w=4096, tex_h=1024, texels_per_m=40.0, x_min=-45.0, x_max=55.0):
     rng = _rng(seed)
-    xs = [-45.0]
-    while xs[-1] < 55.0:
+    xs = [x_min]
+    while xs[-1] < x_max:
         xs.append(xs[-1] + rng.uniform(3.0, 7.0))
     xs = np.array(xs)
     zs = np.empty(len(xs)); zs[0] = 14.0
@@ -401,10 +401,17 @@ def sequence_scene(seed=0x5E0, tex_w=4096, tex_h=1024, texels_per_m=40.0):
     return {"x": xs, "z": zs, "arc": arc, "tex": t, "texels_per_m": texels_per_m}
 
 
-def sequence_poses(n=200):
-    """camera position [x, y, z] and yaw of frame t: a flat figure along the wall that starts in full sideways motion (a vehicle that
-    is already driving: the first key-frames see parallax), swings 3 m to either side and ends where it started"""
+def sequence_poses(n=200, kind="figure", reach=25.0):
+    """camera position [x, y, z] and yaw of frame t.  "figure": a flat figure along the wall that starts in full sideways motion (a
+    vehicle that is already driving: the first key-frames see parallax), swings 3 m to either side and ends where it started.
+    "outback": a drive of `reach` metres along the wall and back to the start (up to reach * pi / n metres per frame: tens of pixels of
+    flow per frame at KITTI resolution, features leave the view for good, the way back revisits every place)"""
     t = np.arange(n) / (n - 1)
+    if kind == "outback":
+        x = reach * np.sin(np.pi * t)
+        zc = 1.0 * np.sin(2 * np.pi * t) ** 2
+        yaw = np.deg2rad(3.0) * np.sin(6 * np.pi * t)
+        return np.stack([x, np.zeros(n), zc], 1), yaw
     x = 3.0 * np.sin(2 * np.pi * t)                                                    # 0 -> 3 m -> -3 m -> 0
     zc = 0.8 * (1.0 - np.cos(2 * np.pi * t))
     yaw = np.deg2rad(2.0) * np.sin(4 * np.pi * t)

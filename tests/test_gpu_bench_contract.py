@@ -51,6 +51,14 @@ def test_bench_json_contract(extra):
     km = d["profiled_pass"]["kernel_ms_per_step"]
     if "lcd" in d["config"]["workload"].lower():
         assert "k_conv3_norm" in km and "k_pool_lrn128_2x2" in km and "k_conv2_f16x3" in km
+    # the oracle parity sample of the timed workload (frames of one more step of the same step function, pulled after the timed region)
+    ps = d["parity_sample"]
+    assert ps and ps["ok"] is True and ps["mismatches"] == [] and ps["frames"] == 8 and ps["pairs_per_step"] == 16
+    assert ps["orb"] == "bit-exact" and ps["match"] == "bit-exact" and ps["keypoints_compared"] > 8 * 2 * 1500 and ps["triangulation_max_rel"] <= 1e-9
+    if "lcd" in d["config"]["workload"].lower():
+        assert ps["lcd_max_abs"] < 2e-5 and ps["db_score_max_abs"] < 2e-5 and ps["ba_max_rel"] <= 1e-11
+    else:
+        assert ps["lcd_max_abs"] is None and ps["ba_max_rel"] is None
     if "--no-cpu-baseline" in extra:
         assert d["cpu_baseline"] is None
     else:
