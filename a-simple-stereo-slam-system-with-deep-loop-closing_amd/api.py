@@ -449,10 +449,53 @@ class LoopDatabase:
                                               C.c_void_p(d_max), C.c_void_p(d_cnt)), "myslam_lcddb_query_batch")
 
 
+    def update_query_limits(self, cur_ids):
+        """new cur_ids (or appended rows) for a query that was recorded into a HIP graph (StepGraph); MyslamError(CAPACITY) = record again"""
+        cur = np.ascontiguousarray(cur_ids, np.uint64)
+        _check(lib().myslam_lcddb_update_query_limits(self._h, _p(cur), len(cur)), "myslam_lcddb_update_query_limits")
+
     def query_batch_sharded(self, d_q, cur_ids, nq, d_cand, thr_low=0.92):
         """per-shard records (myslam_lcd_candidate, 16 bytes each, device memory) for the multi-GPU exchange"""
         cur = np.ascontiguousarray(cur_ids, np.uint64)
         _check(lib().myslam_lcddb_query_batch_sharded(self._h, d_q, _p(cur), nq, thr_low, d_cand), "myslam_lcddb_query_batch_sharded")
+
+
+class StepGraph:
+    """One batched step recorded into a HIP graph (myslam_graph_begin / _end) and replayed with one launch.
+        g = StepGraph.record(origin_stream, [side streams...], body)      # body() issues the step's *_batch calls on those streams
+        g.launch(origin_stream)"""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def record(cls, origin, sides, body):
+        arr = (C.c_void_p * max(1, len(sides)))(*[C.c_void_p(s) for s in sides])
+        _check(lib().myslam_graph_begin(C.c_void_p(origin), arr, len(sides)), "myslam_graph_begin")
+        err = None
+        try:
+            body()
+        except BaseException as e:          # the capture must be closed whatever the body did
+            err = e
+        h = C.c_void_p()
+        rc = lib().myslam_graph_end(C.c_void_p(origin), arr, len(sides), C.byref(h))
+        if err is not None:
+            if rc == OK:
+                lib().myslam_graph_destroy(h)
+            raise err
+        _check(rc, "myslam_graph_end")
+        return cls(h)
+
+    def launch(self, stream):
+        _check(lib().myslam_graph_launch(self._h, C.c_void_p(stream)), "myslam_graph_launch")
+
+    def node_count(self):
+        return lib().myslam_graph_node_count(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value and _lib is not None:
+            _lib.myslam_graph_destroy(self._h)
+            self._h = C.c_void_p()
 
 
 def lcd_merge_candidates(gathered):

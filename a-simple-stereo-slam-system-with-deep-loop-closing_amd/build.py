@@ -29,6 +29,7 @@ UNITS = {
     "pnp.hip": EXACT,
     "prof.hip": [],
     "io.hip": [],
+    "graph.hip": [],
 }
 
 

@@ -257,6 +257,9 @@ struct myslam_lcddb {
     int32_t* h_nvalid = nullptr; hipEvent_t nvEvent = nullptr;      // pinned staging of the per-query row limits + "copy done" event
     float* d_q1 = nullptr; uint64_t* d_best1 = nullptr; float* d_max1 = nullptr; int32_t* d_cnt1 = nullptr;
     uint64_t* d_bestS = nullptr; float* d_maxS = nullptr; int32_t* d_cntS = nullptr; int shardCap = 0;     // scratch of the sharded query
+    int graphRows = 0, graphQueries = 0;      // > 0: a query of this handle was recorded into a HIP graph covering this many rows / queries
+    std::vector<int32_t> lastLimits, scratchLimits; bool nvFresh = false, nvPending = false;      // what d_nvalid holds (skip identical uploads)
+    bool graphStale = false;                  // the matrix moved (db_reserve) after a query was recorded: the recorded step reads freed memory
 
     // index of the first row the reference's scan does NOT look at: it breaks at the first id with
     // (cur - id) < 20 in unsigned arithmetic (loopclosing.cpp:133), i.e. id in [cur-19, cur] mod 2^64
@@ -339,6 +342,7 @@ static int db_reserve(myslam_lcddb* h, long long rows) {
     if (rc) { (void)hipFree(nd); (void)hipFree(ni); return rc; }
     (void)hipFree(h->d_db); (void)hipFree(h->d_ids);
     h->d_db = nd; h->d_ids = ni; h->capacity = cap;
+    if (h->graphRows) h->graphStale = true;
     return MYSLAM_OK;
 }
 
@@ -374,10 +378,21 @@ int myslam_lcddb_append_batch(myslam_lcddb* h, const uint64_t* ids, const float*
     return db_append(h, ids, d_descr, n, hipMemcpyDeviceToDevice);
 }
 
+static bool stream_is_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st == hipStreamCaptureStatusActive;
+}
+
 static int db_query(myslam_lcddb* h, const float* d_q, const uint64_t* cur_ids_host, int nq, float thr_low, uint64_t* d_best,
                     float* d_max, int32_t* d_cnt) {
     const int rowsPerBlock = DB_WAVES * DB_ROWS_PER_WAVE;
+    // Recorded into a HIP graph (graph.hip)?  Then nothing here may synchronise or allocate, the copy node of the row limits reads the
+    // pinned buffer at EVERY replay (myslam_lcddb_update_query_limits rewrites it), and the launch covers every row the database holds
+    // (not only the rows today's limits reach), so that later limits stay inside the captured grid.
+    const bool cap = stream_is_capturing(h->stream);
     if (nq > h->nvalidCap) {
+        if (cap) return MYSLAM_ERR_UNSUPPORTED;                          // first call with this many queries: run it once outside the capture
         MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
         if (h->d_nvalid) (void)hipFree(h->d_nvalid);
         if (h->h_nvalid) (void)hipHostFree(h->h_nvalid);
@@ -385,23 +400,38 @@ static int db_query(myslam_lcddb* h, const float* d_q, const uint64_t* cur_ids_h
         MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_nvalid, sizeof(int32_t) * nq));
         MYSLAM_HIP_CHECK(hipHostMalloc((void**)&h->h_nvalid, sizeof(int32_t) * nq));
         if (!h->nvEvent) MYSLAM_HIP_CHECK(hipEventCreateWithFlags(&h->nvEvent, hipEventDisableTiming));
-        h->nvalidCap = nq;
-    } else {
-        MYSLAM_HIP_CHECK(hipEventSynchronize(h->nvEvent));               // the previous call's upload has left the pinned buffer
+        h->nvalidCap = nq; h->nvFresh = false;
     }
-    int32_t* nv = h->h_nvalid;
+    // the row limits of this call; when they equal what the device buffer already holds (the same cur_ids against the same rows, the
+    // usual case of a batch of queries per step) nothing is uploaded and the host never waits for the device
     int maxv = 0;
-    for (int i = 0; i < nq; i++) { nv[i] = h->n_valid(cur_ids_host[i]); maxv = std::max(maxv, nv[i]); }
+    bool same = h->nvFresh && !cap && (int)h->lastLimits.size() == nq;
+    h->scratchLimits.resize(nq);
+    for (int i = 0; i < nq; i++) {
+        const int v = h->n_valid(cur_ids_host[i]);
+        h->scratchLimits[i] = v; maxv = std::max(maxv, v);
+        if (same && h->lastLimits[i] != v) same = false;
+    }
+    if (cap) { maxv = std::max(maxv, h->n); h->graphRows = maxv; h->graphQueries = nq; h->graphStale = false; }
     const int nblocks = std::max(1, (maxv + rowsPerBlock - 1) / rowsPerBlock);
-    const size_t need = (size_t)nblocks * nq;
+    const size_t need = (size_t)std::max(nblocks, std::max(1, (maxv + GM - 1) / GM)) * nq;
     if (need > h->partialsCap) {
+        if (cap) return MYSLAM_ERR_UNSUPPORTED;
         MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
         if (h->d_partials) (void)hipFree(h->d_partials);
         MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_partials, need * sizeof(Partial)));
         h->partialsCap = need;
     }
-    MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_nvalid, nv, sizeof(int32_t) * nq, hipMemcpyHostToDevice, h->stream));      // pinned -> no host sync
-    MYSLAM_HIP_CHECK(hipEventRecord(h->nvEvent, h->stream));
+    if (!same) {
+        if (!cap) {
+            if (h->graphRows) MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));      // a recorded step also reads the pinned buffer: wait for its replays
+            else if (h->nvPending) MYSLAM_HIP_CHECK(hipEventSynchronize(h->nvEvent));   // the previous upload has left the pinned buffer
+        }
+        memcpy(h->h_nvalid, h->scratchLimits.data(), sizeof(int32_t) * nq);
+        MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_nvalid, h->h_nvalid, sizeof(int32_t) * nq, hipMemcpyHostToDevice, h->stream));      // pinned -> no host sync
+        if (!cap) { MYSLAM_HIP_CHECK(hipEventRecord(h->nvEvent, h->stream)); h->nvPending = true; }
+        h->lastLimits = h->scratchLimits; h->nvFresh = !cap;             // (a recorded copy re-runs at every replay with whatever the pinned buffer holds then)
+    }
     {
         ScopedProf sp(P_DBSCAN, h->stream);
         int nparts = nblocks;
@@ -424,6 +454,16 @@ int myslam_lcddb_query_batch(myslam_lcddb* h, const float* d_q, const uint64_t* 
                              uint64_t* d_best_id, float* d_max_score, int32_t* d_cnt) {
     if (!h || !d_q || !cur_ids || nq < 1 || nq > 65536 || !d_best_id || !d_max_score || !d_cnt) return MYSLAM_ERR_INVALID;
     return db_query(h, d_q, cur_ids, nq, thr_low, d_best_id, d_max_score, d_cnt);
+}
+
+int myslam_lcddb_update_query_limits(myslam_lcddb* h, const uint64_t* cur_ids, int nq) {
+    if (!h || !cur_ids || nq < 1) return MYSLAM_ERR_INVALID;
+    if (!h->graphRows || nq > h->graphQueries || nq > h->nvalidCap) return MYSLAM_ERR_INVALID;      // no recorded query to feed
+    if (h->graphStale || h->n > h->graphRows) return MYSLAM_ERR_CAPACITY;      // the database moved or outgrew the recorded launch: record the step again
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));               // no replay is reading the pinned buffer
+    for (int i = 0; i < nq; i++) h->h_nvalid[i] = h->n_valid(cur_ids[i]);
+    h->nvFresh = false;                                              // the next replay rewrites d_nvalid behind the eager path's back
+    return MYSLAM_OK;
 }
 
 int myslam_lcddb_query_batch_sharded(myslam_lcddb* h, const float* d_q, const uint64_t* cur_ids, int nq, float thr_low,

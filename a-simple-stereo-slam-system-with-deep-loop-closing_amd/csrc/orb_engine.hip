@@ -404,7 +404,11 @@ int myslam_orb::run_batch(const uint8_t* d_imgs, int batch, int r, int c, int st
     }
     if ((rc = build_pyramids(d_imgs, batch, step, stride, d_masks, P.nlevels))) return rc;
     if (stop == 2) return MYSLAM_OK;
-    const int aux_mode = optInternalStream;
+    // (a call that is being recorded into a HIP graph stays on its stream: on ROCm 7.2 a fork onto the internal stream from a stream that
+    // itself joined the capture as a side stream crashes hipStreamEndCapture — found with two handles recorded into one graph)
+    hipStreamCaptureStatus capst = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(stream, &capst) != hipSuccess) { (void)hipGetLastError(); capst = hipStreamCaptureStatusNone; }
+    const int aux_mode = capst == hipStreamCaptureStatusActive ? 0 : optInternalStream;
     const bool fork = aux_mode > 0 && !detectOnly && stop == 0;
     if (fork && !aux) {
         MYSLAM_HIP_CHECK(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));

@@ -1,8 +1,14 @@
 // myslam_png.hpp — dependency-free PNG reader for the KITTI grey images, header only.
 //   myslam::io::ReadPngGray(path, pixels, rows, cols)   what the reference gets from cv::imread(file, cv::IMREAD_GRAYSCALE) for the
 //                                                       8-bit single-channel PNGs of KITTI image_0 / image_1   app/run_kitti_stereo.cpp:66-67
-// Supported: non-interlaced PNG, colour type 0 (grey) with bit depth 8 or 16 (high byte kept), colour type 2 / 6 (RGB / RGBA, 8 bit;
-// grey = (R*4899 + G*9617 + B*1868 + 8192) >> 14, OpenCV's 8-bit BGR2GRAY fixed point).  Anything else returns false.
+// Supported: every non-interlaced PNG — grey (1 / 2 / 4 / 8 / 16 bit), grey + alpha, RGB, RGBA (8 / 16 bit), palette (1 / 2 / 4 / 8 bit) —
+// reduced to 8-bit grey the way cv::imread(..., IMREAD_GRAYSCALE) of OpenCV 3.4.8 asks libpng 1.6 to (modules/imgcodecs/src/grfmt_png.cpp:
+// png_set_strip_16, png_set_strip_alpha, png_set_palette_to_rgb, png_set_expand_gray_1_2_4_to_8, png_set_rgb_to_gray(1, 0.299, 0.587)):
+//   low-bit grey is scaled to 0..255, a palette index becomes its PLTE colour, alpha (and tRNS) is dropped, colour becomes
+//   grey = (9797 R + 19234 G + 3737 B) >> 15 for 8-bit samples (libpng's coefficients 0.299 / 0.587 * 32768 TRUNCATED, blue = the rest, the
+//   "historical approach which simply truncates"; R = G = B passes through) and (… + 16384) >> 15 for 16-bit samples, and 16-bit results
+//   keep their high byte.  These colour rules are a recollection of libpng's pngrtran.c (not checkable here: parity unpinned); KITTI's
+//   image_0 / image_1 are 8-bit grey, where none of them applies.  Interlaced (Adam7) files return false.
 // zlib stream: stored, fixed and dynamic Huffman blocks (RFC 1950 / 1951); CRC-32 of every chunk and the Adler-32 are verified.
 #pragma once
 #include <stdint.h>
@@ -153,7 +159,7 @@ inline bool DecodePngGray(const uint8_t* data, size_t size, std::vector<uint8_t>
     if (size < 8 + 25 || std::char_traits<char>::compare((const char*)data, (const char*)sig, 8) != 0) return false;
     size_t pos = 8;
     uint32_t w = 0, h = 0; int depth = 0, ctype = -1;
-    std::vector<uint8_t> z;
+    std::vector<uint8_t> z, plte;
     bool end = false;
     while (!end && pos + 12 <= size) {
         const uint32_t len = be32(data + pos);
@@ -166,19 +172,24 @@ inline bool DecodePngGray(const uint8_t* data, size_t size, std::vector<uint8_t>
             if (len != 13) return false;
             w = be32(body); h = be32(body + 4); depth = body[8]; ctype = body[9];
             if (body[10] != 0 || body[11] != 0 || body[12] != 0) return false;          // compression, filter, no interlace
-        } else if (t == "IDAT") z.insert(z.end(), body, body + len);
+        } else if (t == "PLTE") { if (len % 3 != 0 || len > 768) return false; plte.assign(body, body + len); }
+        else if (t == "IDAT") z.insert(z.end(), body, body + len);
         else if (t == "IEND") end = true;
         pos += 12 + (size_t)len;
     }
     if (!end || w == 0 || h == 0 || w > 65535 || h > 65535) return false;
     int ch;
-    if (ctype == 0 && (depth == 8 || depth == 16)) ch = 1;
-    else if (ctype == 2 && depth == 8) ch = 3;
-    else if (ctype == 6 && depth == 8) ch = 4;
+    const bool d816 = depth == 8 || depth == 16, dlow = depth == 1 || depth == 2 || depth == 4;
+    if (ctype == 0 && (d816 || dlow)) ch = 1;
+    else if (ctype == 2 && d816) ch = 3;
+    else if (ctype == 3 && (dlow || depth == 8) && !plte.empty()) ch = 1;
+    else if (ctype == 4 && d816) ch = 2;
+    else if (ctype == 6 && d816) ch = 4;
     else return false;
-    const size_t bpp = (size_t)ch * (depth / 8), stride = bpp * w;
+    const size_t bits = (size_t)ch * depth, bpp = bits >= 8 ? bits / 8 : 1, stride = (bits * w + 7) / 8;
     std::vector<uint8_t> raw;
     if (!inflate(z.data(), z.size(), raw, (stride + 1) * h) || raw.size() != (stride + 1) * h) return false;
+    auto grey8 = [](uint32_t r, uint32_t g, uint32_t b) -> uint8_t { return (r == g && r == b) ? (uint8_t)r : (uint8_t)((9797u * r + 19234u * g + 3737u * b) >> 15); };
     // undo the per-row filters in place (row r occupies raw[r*(stride+1)+1 ...])
     std::vector<uint8_t> prev(stride, 0);
     pixels.assign((size_t)w * h, 0);
@@ -196,8 +207,28 @@ inline bool DecodePngGray(const uint8_t* data, size_t size, std::vector<uint8_t>
             cur[i] = (uint8_t)(cur[i] + pr);
         }
         uint8_t* dst = &pixels[(size_t)r * w];
-        if (ch == 1) for (uint32_t x = 0; x < w; x++) dst[x] = cur[x * bpp];                            // 16-bit: the high byte
-        else for (uint32_t x = 0; x < w; x++) { const uint8_t* q = cur + x * bpp; dst[x] = (uint8_t)((q[0] * 4899 + q[1] * 9617 + q[2] * 1868 + 8192) >> 14); }
+        if (depth < 8) {                                                     // packed samples, most significant bits first
+            const int mask = (1 << depth) - 1, scale = 255 / mask;
+            for (uint32_t x = 0; x < w; x++) {
+                const size_t bit = (size_t)x * depth;
+                const int v = (cur[bit >> 3] >> (8 - depth - (int)(bit & 7))) & mask;
+                if (ctype == 3) { if ((size_t)v * 3 + 2 >= plte.size()) return false; dst[x] = grey8(plte[v * 3], plte[v * 3 + 1], plte[v * 3 + 2]); }
+                else dst[x] = (uint8_t)(v * scale);
+            }
+        } else if (ctype == 3) {
+            for (uint32_t x = 0; x < w; x++) { const size_t v = cur[x]; if (v * 3 + 2 >= plte.size()) return false; dst[x] = grey8(plte[v * 3], plte[v * 3 + 1], plte[v * 3 + 2]); }
+        } else if (ch <= 2) {
+            for (uint32_t x = 0; x < w; x++) dst[x] = cur[x * bpp];                                        // grey (+ alpha): 16-bit keeps the high byte
+        } else if (depth == 8) {
+            for (uint32_t x = 0; x < w; x++) { const uint8_t* q = cur + x * bpp; dst[x] = grey8(q[0], q[1], q[2]); }
+        } else {                                                             // 16-bit colour: converted at 16 bits (with rounding), then the high byte
+            for (uint32_t x = 0; x < w; x++) {
+                const uint8_t* q = cur + x * bpp;
+                const uint32_t R = (q[0] << 8) | q[1], G = (q[2] << 8) | q[3], B = (q[4] << 8) | q[5];
+                const uint32_t g16 = (R == G && R == B) ? R : ((9797u * R + 19234u * G + 3737u * B + 16384u) >> 15);
+                dst[x] = (uint8_t)(g16 >> 8);
+            }
+        }
         prev.assign(cur, cur + stride);
     }
     rows = (int)h; cols = (int)w;

@@ -46,7 +46,16 @@ def _ranks_wanted():
 
 
 # N > 1: torch's process group brings one more stream (the collectives' own) — one more queue
-HW_QUEUES = os.environ.setdefault("GPU_MAX_HW_QUEUES", "5" if _ranks_wanted() == 1 else "6")
+def _small_batch():
+    for i, a in enumerate(sys.argv):
+        if a == "--pairs" and i + 1 < len(sys.argv) and sys.argv[i + 1].isdigit():
+            return int(sys.argv[i + 1]) <= 64
+    return False
+
+
+# N > 1: torch's process group brings one more stream (the collectives' own) — one more queue; small batches run on up to 16 lanes, and
+# lanes that share a hardware queue serialise (8 pairs per step, 16 lanes: 17.1 k frames/s on 8 queues, 19.0 k on 16, 26.5 k on 24)
+HW_QUEUES = os.environ.setdefault("GPU_MAX_HW_QUEUES", ("24" if _small_batch() else "5") if _ranks_wanted() == 1 else "6")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -153,6 +162,14 @@ def parse():
                          "triangulation follow on a third stream, outputs are double-buffered and consecutive steps overlap (every step's "
                          "work is complete at the closing barrier).  0 = every step is joined before the next starts.  "
                          "-1 (default) = 1 with --streams 2, else 0")
+    ap.add_argument("--graph", type=int, default=-1, choices=[-1, 0, 1],
+                    help="1 = the timed region replays recorded steps: the whole step (extractor for the 2P images, match, triangulation, DeepLCD, "
+                         "database scan, BA build) is recorded per LANE on one stream (myslam_graph_begin / _end) and --lanes lanes (own handles and "
+                         "buffers each) replay their graphs concurrently, step k on lane k mod L — for small batches, where a step is launch- and "
+                         "latency-bound; 0 = eager launches on the four-stream schedule; -1 (default) = 1 when --pairs <= 64 on one GPU, else 0.  The "
+                         "other mode is timed in an extra pass (`step_graph` / `step_eager`)")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes of --graph 1 (0 = 16 for <= 16 pairs per step, 8 up to 64, else 4)")
+    ap.add_argument("--created-main-stream", action="store_true", help="debug: the four-stream schedule's main chain on a created stream instead of the legacy NULL stream")
     ap.add_argument("--verify", action="store_true",
                     help="after the timed region: run one joined, un-gated step and check that it reproduces the pipeline's last outputs bit for bit")
     ap.add_argument("--orb-internal-stream", type=int, default=0, choices=[0, 1, 2],
@@ -291,7 +308,11 @@ def parity_sample(api, synth, frames, sample, cap, Kt, K, bufs, db_np, db_ids, c
         rxyz, rok = o.triangulate_stereo(kl["x"], kl["y"], kr["x"][ridx], kr["y"][ridx], K["fx"], K["fy"], K["cx"], K["cy"], K["bf"] / K["fx"])
         ok = bufs["ok"][i * cap:i * cap + nl].astype(bool); xyz = bufs["xyz"].reshape(-1, 3)[i * cap:i * cap + nl]
         n_ok += int(rok.sum())
-        if not np.array_equal(ok, rok):
+        # a match of exactly zero disparity is a point at infinity: the DLT's homogeneous coordinate is rounding noise and so is the sign of z
+        # (1e17 m here, 1e17 m behind the camera in the oracle; Eigen's bdcSvd in the reference is no different) — such points are not compared
+        finite = (np.abs(rxyz[:, 2]) < 1e9) & (np.abs(xyz[:, 2]) < 1e9)
+        rok = rok & finite
+        if not np.array_equal(ok[finite], rok[finite]):
             bad(f"frame {i}: triangulation flags")
         elif rok.any():
             d = float(np.max(np.abs(xyz[rok] - rxyz[rok]) / np.maximum(1.0, np.abs(rxyz[rok]))))
@@ -372,6 +393,10 @@ def main():
         from tools import latency_b1
         print(json.dumps(latency_b1.run(api, synth, with_oracle=not args.no_cpu_baseline)))
         return
+    # the four-stream schedule keeps its main chain on the legacy NULL stream: measured, its launches cost the host 0.63 ms per step there and
+    # 1.02 ms on a created stream (8 pairs per step; tools/ab_streams.sh) — the lanes of the small-batch mode bring their own streams
+    if args.created_main_stream:
+        torch.cuda.set_stream(torch.cuda.Stream())
     main_stream = torch.cuda.current_stream()
     stream = main_stream.cuda_stream
     # the LCD -> DB -> BA chain only reads the input images: it runs beside the ORB chain on its own stream
@@ -465,6 +490,7 @@ def main():
             if solve_windows[0]:
                 solve(solve_windows[0])
 
+    step_no = [0]           # steps issued so far: step k writes extractor output buffer k % NB
     if args.pipeline:
         # two extractor handles take turns: handle A (left images, main stream) and handle B (right images, its own stream) each wait
         # for the other's FAST stage, so a FAST launch never runs beside the other FAST launch but under the other handle's oct-tree /
@@ -483,7 +509,6 @@ def main():
             e.set_fast_event(ev_fast[i].cuda_event)
             if args.pipeline == 1:      # gate inside the call: only the FAST stages take turns (ring), the pyramids are not held back
                 e.set_fast_gate(ev_fast[(i - 1) % S].cuda_event)
-        step_no = [0]
 
         def step():
             p = step_no[0] % NB
@@ -541,12 +566,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(n):
-        """n steps bracketed by barrier + synchronize on both sides; the slowest rank's wall time"""
+    host_ms = [0.0]
+
+    def timed(n, fn=None):
+        """n steps bracketed by barrier + synchronize on both sides; the slowest rank's wall time.  host_ms[0] = CPU time the launches of
+        one step took (the loop that enqueues the n steps, before the closing barrier waits for the device)"""
+        fn = fn or step
         barrier()
         t0 = time.perf_counter()
         for _ in range(n):
-            step()
+            fn()
+        host_ms[0] = (time.perf_counter() - t0) / n * 1e3
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -561,12 +591,103 @@ def main():
     assert all(int(t.abs().sum()) == 0 for t in d_stat_b), "ORB capacity overflow"
     n_kp = d_cnt.float().mean().item()
 
+    # ---- small batches: LANES.  A step of a few frames is a latency-bound chain of ~38 dependent launches (0.86 ms at 8 pairs on one
+    # stream, 0.53 ms host-bound on four).  Measured on ROCm 7.2: a HIP graph recorded from ONE stream replays for ~0.03 ms of host time,
+    # one recorded across streams for 0.36-0.75 ms (no better than launching eagerly).  So the step is recorded per lane on a single
+    # stream — one extractor handle for the 2P images, match, triangulation, DeepLCD, database scan, BA build — and L lanes (own handles,
+    # buffers and stream each: the analogue of L cameras) replay their graphs concurrently: step k runs on lane k % L.
+    step_eager = step
+    lanes = []
+    can_graph = world == 1
+    use_graph = can_graph and (args.graph == 1 or (args.graph < 0 and P <= 64))
+    n_lanes = args.lanes if args.lanes > 0 else (16 if P <= 16 else 8 if P <= 64 else 4)
+
+    def build_lane():
+        st = torch.cuda.Stream(); s_ = st.cuda_stream
+        ln = {"stream": st, "ext": api.ORBextractor(2000, stream=s_)}
+        ln["ext"].set_option(ln["ext"].OPT_INTERNAL_STREAM, 0); ln["ext"].set_option(ln["ext"].OPT_FAST_MODE, args.fast_mode)
+        ln["ext"].set_option(ln["ext"].OPT_COPY_INPUT, args.orb_copy_input)
+        z = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)
+        o = {"kps": z(2 * P * cap * 28, torch.uint8), "desc": z(2 * P * cap * 32, torch.uint8), "cnt": z(2 * P, torch.int32), "stat": z(2 * P, torch.int32),
+             "midx": z(P * cap, torch.int32), "mdist": z(P * cap, torch.int32), "xyz": z(P * cap * 3, torch.float64), "ok": z(P * cap, torch.uint8)}
+        if use_lcd:
+            ln["lcd"] = api.DeepLCD(synth.calc_weights(), stream=s_)
+            ln["D"] = api.LoopDatabase(n_db_local, stream=s_)             # (every lane holds its own copy of the database: the handle owns the scan's scratch)
+            ln["D"].append_batch(ids, t_db.data_ptr(), n_db_local)
+            o.update({"descr": torch.zeros(P, 1064, device=dev), "best": z(P, torch.int64), "max": z(P, torch.float32), "dbcnt": z(P, torch.int32)})
+        if use_ba:
+            o["ba"] = [torch.zeros(P, n, dtype=torch.float64, device=dev) for n in (maxP * 36, maxL * 9, maxE * 18, maxP * 6, maxL * 3, maxE)]
+        ln["o"] = o
+
+        def body():
+            ln["ext"].detect_and_compute_batch(d_imgs.data_ptr(), 2 * P, H, W, W, H * W, o["kps"].data_ptr(), o["desc"].data_ptr(), o["cnt"].data_ptr(),
+                                               o["stat"].data_ptr(), cap)
+            api.hamming_match_batch(o["desc"].data_ptr(), o["cnt"].data_ptr(), o["desc"].data_ptr() + P * cap * 32, o["cnt"].data_ptr() + 4 * P,
+                                    P, cap, o["midx"].data_ptr(), o["mdist"].data_ptr(), s_)
+            api.triangulate_stereo_batch(o["kps"].data_ptr(), o["kps"].data_ptr() + P * cap * 28, o["midx"].data_ptr(), o["cnt"].data_ptr(), P, cap,
+                                         Kt, K["bf"] / K["fx"], o["xyz"].data_ptr(), o["ok"].data_ptr(), s_)
+            if use_lcd:
+                ln["lcd"].describe_batch(d_imgs.data_ptr(), P, H, W, W, H * W, o["descr"].data_ptr(), blur_in_place=False)
+                ln["D"].query_batch(o["descr"].data_ptr(), cur_ids[:P], P, o["best"].data_ptr(), o["max"].data_ptr(), o["dbcnt"].data_ptr())
+            if use_ba:
+                api.ba_build_batch(*[t.data_ptr() for t in b_in], P, maxP, maxL, maxE, Kt, 5.991, *[t.data_ptr() for t in o["ba"]], s_)
+        ln["body"] = body
+        for _ in range(2):                               # eager first: lazy allocations, both FAST-statistics parities
+            body()
+        st.synchronize()
+        ln["graphs"] = [api.StepGraph.record(s_, [], body) for _ in range(2)]     # two consecutive steps, replayed alternately
+        ln["k"] = 0
+        return ln
+
+    def step_lanes():
+        ln = lanes[step_no[0] % len(lanes)]; step_no[0] += 1
+        ln["graphs"][ln["k"] & 1].launch(ln["stream"].cuda_stream); ln["k"] += 1
+
+    def step_lanes_eager():                              # the same lanes without the recording: what the graphs save
+        ln = lanes[step_no[0] % len(lanes)]; step_no[0] += 1
+        ln["body"]()
+
+    if use_graph:
+        api.prof_enable(False)
+        lanes = [build_lane() for _ in range(n_lanes)]
+        step = step_lanes
+        for _ in range(2 * n_lanes):
+            step()
+        barrier()
+
     # ---- pass 1: the timed region (no per-kernel events) ----
     api.prof_enable(False)
     dt = timed(args.steps)
+    host_launch_ms = host_ms[0]
+    # the other launch mode over the same steps (eager when the timed region replayed graphs, graphs when it launched eagerly)
+    other_mode = None
+    lanes_eager = None
+    if can_graph and not args.no_extra_passes:
+        if not use_graph:
+            api.prof_enable(False)
+            lanes = [build_lane() for _ in range(n_lanes)]
+        fn_o = step_eager if use_graph else step_lanes
+        for _ in range(2 * n_lanes):
+            fn_o()
+        barrier()
+        dt_o = timed(args.steps, fn_o)
+        other_mode = {"mode": "eager launches, two extractor handles + match + side chain on four streams, consecutive steps overlap" if use_graph else
+                              f"HIP graph replay on {n_lanes} single-stream lanes",
+                      "value": world * P * args.steps / dt_o, "unit": "stereo frames/s", "ms_per_step": dt_o / args.steps * 1e3,
+                      "host_launch_ms_per_step": host_ms[0], "graph_nodes": lanes[0]["graphs"][0].node_count()}
+        for _ in range(2 * n_lanes):
+            step_lanes_eager()
+        barrier()
+        dt_l = timed(args.steps, step_lanes_eager)
+        lanes_eager = {"mode": f"the same {n_lanes} lanes launched eagerly (no recording)", "value": world * P * args.steps / dt_l,
+                       "ms_per_step": dt_l / args.steps * 1e3, "host_launch_ms_per_step": host_ms[0]}
+    if not use_graph:
+        step = step_eager
 
     # ---- pass 2: the same steps with a HIP event pair around every launch, on the launch's own stream ----
     prof, dt_prof = {}, None
+    step_timed = step
+    step = step_eager                  # every pass below launches eagerly: the profiling events, the solve cadence and the streamed input change per step
     if not args.no_extra_passes:
         api.prof_reset(); api.prof_enable(True)
         dt_prof = timed(args.steps)
@@ -707,20 +828,49 @@ def main():
             e.set_fast_event(ev_fast[i].cuda_event)
             if args.pipeline == 1:
                 e.set_fast_gate(ev_fast[(i - 1) % S].cuda_event)
+    if args.verify and lanes:           # a recorded step on a lane against the joined eager step: every output bit for bit
+        torch.cuda.synchronize()
+        step_joined(); torch.cuda.synchronize()
+        refs = {"kps": d_kps, "desc": d_desc, "cnt": d_cnt, "midx": d_midx, "mdist": d_mdist, "xyz": d_xyz, "ok": d_ok}
+        if use_lcd:
+            refs.update({"descr": d_descr, "best": d_best, "max": d_max, "dbcnt": d_dbcnt})
+        n0 = [int(v) for v in d_cnt.cpu()]
+        for ln in lanes[:2]:
+            for rep in range(2):
+                ln["graphs"][rep].launch(ln["stream"].cuda_stream); ln["stream"].synchronize()
+                lo = ln["o"]
+                assert torch.equal(lo["cnt"], d_cnt) and int(lo["stat"].abs().sum()) == 0
+                kl = lo["kps"].view(2 * P, cap * 28); kr = d_kps.view(2 * P, cap * 28); dl = lo["desc"].view(2 * P, cap * 32); dr = d_desc.view(2 * P, cap * 32)
+                for b_ in range(2 * P):             # slots behind an image's count are never written
+                    assert torch.equal(kl[b_, :28 * n0[b_]], kr[b_, :28 * n0[b_]]) and torch.equal(dl[b_, :32 * n0[b_]], dr[b_, :32 * n0[b_]]), f"lane key-points / descriptors, image {b_}"
+                for b_ in range(P):
+                    sl = slice(b_ * cap, b_ * cap + n0[b_])
+                    assert torch.equal(lo["midx"][sl], d_midx[sl]) and torch.equal(lo["mdist"][sl], d_mdist[sl]) and torch.equal(lo["ok"][sl], d_ok[sl])
+                    assert torch.equal(lo["xyz"].view(-1, 3)[sl].view(torch.uint8), d_xyz.view(-1, 3)[sl].view(torch.uint8))
+                for k_ in ("descr", "best", "max", "dbcnt"):
+                    if k_ in lo:
+                        assert torch.equal(lo[k_].view(torch.uint8), refs[k_].view(torch.uint8)), f"lane output {k_}"
+                if use_ba:
+                    for a_, r_ in zip(lo["ba"], b_out):
+                        assert torch.equal(a_.view(torch.uint8), r_.view(torch.uint8)), "lane BA blocks"
 
     # ---- parity sample: K frames of one more step of the timed workload against the oracle (untimed; beside cpu_baseline) ----
     parity = None
     if rank == 0 and args.parity_frames > 0 and world == 1:
         barrier()
-        step(); barrier()
-        p_last = (step_no[0] - 1) % NB if args.pipeline else 0
+        step_timed(); barrier()                         # the launch mode of the timed region (a graph replay on a lane for small batches)
         host = lambda t: t.cpu().numpy()
-        bufs = {"kps": host(d_kps_b[p_last]), "desc": host(d_desc_b[p_last]), "cnt": host(d_cnt_b[p_last]), "midx": host(d_midx), "mdist": host(d_mdist),
-                "xyz": host(d_xyz), "ok": host(d_ok)}
-        if use_lcd:
-            bufs.update({"descr": host(d_descr), "best": host(d_best), "max": host(d_max), "dbcnt": host(d_dbcnt)})
-        if use_ba:
-            bufs["ba"] = [host(t) for t in b_out]
+        if use_graph:
+            lo = lanes[(step_no[0] - 1) % len(lanes)]["o"]
+            bufs = {k: (host(v) if k != "ba" else [host(t) for t in v]) for k, v in lo.items() if k != "stat"}
+        else:
+            p_last = (step_no[0] - 1) % NB
+            bufs = {"kps": host(d_kps_b[p_last]), "desc": host(d_desc_b[p_last]), "cnt": host(d_cnt_b[p_last]), "midx": host(d_midx), "mdist": host(d_mdist),
+                    "xyz": host(d_xyz), "ok": host(d_ok)}
+            if use_lcd:
+                bufs.update({"descr": host(d_descr), "best": host(d_best), "max": host(d_max), "dbcnt": host(d_dbcnt)})
+            if use_ba:
+                bufs["ba"] = [host(t) for t in b_out]
         kf = min(args.parity_frames, P)
         sample = sorted({int(round(j * (P - 1) / max(1, kf - 1))) for j in range(kf)})
         parity = parity_sample(api, synth, frames, sample, cap, Kt, K, bufs, db_np, ids if use_lcd else None, int(cur_ids[0]) if use_lcd else 0,
@@ -841,6 +991,11 @@ def main():
                                                            pcie_bound_frames_per_s=None if not (peaks or {}).get("h2d_GBps") else
                                                            world * (peaks["h2d_GBps"] * 1e9) / (2 * H * W)),
             "full_solve_cadence6": cadence, "full_solve_every_frame": every,
+            "launch_mode": f"HIP graph replay on {n_lanes} single-stream lanes (step k on lane k mod {n_lanes})" if use_graph else
+                           "eager launches (two extractor handles + match + side chain on four streams, consecutive steps overlap)",
+            "host_launch_ms_per_step": host_launch_ms,      # CPU time of enqueuing one step of the timed region
+            "graph_nodes": lanes[0]["graphs"][0].node_count() if (use_graph and lanes) else None,
+            ("step_eager" if use_graph else "step_graph"): other_mode, "step_lanes_eager": lanes_eager,
             "ba_solve_all_windows_ms": solve_ms,     # OptimizeActiveMap solve stage for all P windows, outside the timed region
             "parity_sample": parity,
         }

@@ -281,6 +281,12 @@ int myslam_lcddb_query(myslam_lcddb* h, const float* descr1064, uint64_t cur_id,
 int myslam_lcddb_query_batch(myslam_lcddb* h, const float* d_q, const uint64_t* cur_ids /*host*/, int nq, float thr_low,
                              uint64_t* d_best_id, float* d_max_score, int32_t* d_cnt);
 
+/* For a query recorded into a HIP graph (myslam_graph_begin / _end below): the per-query row limits (the `cur - id < 20` cut-off of
+ * loopclosing.cpp:133 for each cur_id) sit in a pinned host buffer that the recorded copy reads at EVERY replay.  This call rewrites them
+ * for new cur_ids or after appends; it waits for the handle's stream first.  MYSLAM_ERR_CAPACITY = the database moved (it grew beyond its
+ * allocation) or holds more rows than the recorded launch covers: record the step again.  nq <= the recorded query count. */
+int myslam_lcddb_update_query_limits(myslam_lcddb* h, const uint64_t* cur_ids /*host*/, int nq);
+
 /* Multi-GPU form: the database is sharded by contiguous key-frame id range, shard r on rank r, every shard scores
  * every query.  A shard's answer travels as one 16-byte record; the records of all shards (rank order = id order) are reduced to what
  * ONE scan of src/loopclosing.cpp:124-161 over the whole std::map returns: strict '>' keeps the first (lowest-id) maximum, counts
@@ -479,6 +485,26 @@ int myslam_io_save_trajectory(const char* path, const uint64_t* ids, const doubl
 /* System::SaveLoopEdges (src/system.cpp:188-224): two lines per loop (current key-frame, loop key-frame), ordered by the current id */
 int myslam_io_save_loop_edges(const char* path, const uint64_t* cur_ids, const double* cur_ts, const double* cur_poses7_cw,
                               const uint64_t* loop_ids, const double* loop_ts, const double* loop_poses7_cw, int n);
+
+/* ------------------------------------------------------------------------------------------
+ * A whole batched step as ONE HIP graph — the per-frame call pattern of the reference (one frame at a time: src/frontend.cpp:302-328,
+ * src/loopclosing.cpp:83-121) is launch-bound on a GPU: ~90 launches on 4-5 streams cost the host ~0.6 ms however few frames they carry.
+ * Every *_batch entry point is asynchronous and allocation-free after its first call with a given shape, so a caller records one step
+ * between begin and end — the calls it would make anyway, on the streams it would use — and replays it with one launch per step.
+ *   begin: starts a thread-local capture on origin_stream and forks the side streams into it (they must be distinct from the origin);
+ *   end:   joins the side streams back, ends the capture and instantiates the graph.
+ * Rules: run the step once eagerly first (lazy allocations); profiling must be off (MYSLAM_ERR_UNSUPPORTED); events passed to
+ * myslam_orb_set_fast_gate must be recorded INSIDE the capture (the first handle of a ring takes no gate); buffers, handles, options and
+ * streams the step uses must stay as they were; host code is not replayed — record TWO consecutive steps and replay them alternately so
+ * that the extractor's FAST statistics keep ping-ponging, and feed the loop database's row limits through
+ * myslam_lcddb_update_query_limits.  Results are bit-identical to the eager step (tests/test_gpu_graph.py).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct myslam_step_graph myslam_step_graph;
+int myslam_graph_begin(void* origin_stream, void* const* side_streams, int n_side);
+int myslam_graph_end(void* origin_stream, void* const* side_streams, int n_side, myslam_step_graph** out);
+int myslam_graph_launch(myslam_step_graph* g, void* hip_stream);
+int myslam_graph_node_count(const myslam_step_graph* g);
+int myslam_graph_destroy(myslam_step_graph* g);
 
 #ifdef __cplusplus
 }

@@ -84,7 +84,8 @@ def test_png_reader(tmp_path):
     assert np.array_equal(run(_png(g16, filters=[3, 4]), "g16"), smooth)
     rgb = rng.integers(0, 256, (40, 77, 3), dtype=np.uint8)
     r64 = rgb.astype(np.int64)
-    grey = ((r64[..., 0] * 4899 + r64[..., 1] * 9617 + r64[..., 2] * 1868 + 8192) >> 14).astype(np.uint8)
+    grey = ((r64[..., 0] * 9797 + r64[..., 1] * 19234 + r64[..., 2] * 3737) >> 15).astype(np.uint8)      # libpng rgb_to_gray as cv::imread sets it up (myslam_png.hpp)
+    same = (rgb[..., 0] == rgb[..., 1]) & (rgb[..., 0] == rgb[..., 2]); grey[same] = rgb[..., 0][same]
     assert np.array_equal(run(_png(rgb, filters=[4, 1]), "rgb"), grey)
     rgba = np.concatenate([rgb, rng.integers(0, 256, (40, 77, 1), dtype=np.uint8)], axis=2)
     assert np.array_equal(run(_png(rgba, filters=[2, 3]), "rgba"), grey)
