@@ -34,8 +34,9 @@ UNITS = {
 
 
 def _deps():
+    host = os.path.join(HERE, "host")          # header-only host code (formats, the Caffe readers) that csrc/io.hip and csrc/calc.hip include
     return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))] + \
-           [os.path.join(HERE, "..", "include", "myslam_hip.h")]
+           [os.path.join(host, f) for f in os.listdir(host) if f.endswith(".hpp")] + [os.path.join(HERE, "..", "include", "myslam_hip.h")]
 
 
 def _stale(target, sources):

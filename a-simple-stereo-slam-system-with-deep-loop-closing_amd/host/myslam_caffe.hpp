@@ -72,7 +72,7 @@ class TextParser {
             return true;
         }
         const size_t b = p;
-        while (p < t.size() && !isspace((unsigned char)t[p]) && t[p] != '}' && t[p] != '{' && t[p] != ',' && t[p] != ';' && t[p] != '#') p++;
+        while (p < t.size() && !isspace((unsigned char)t[p]) && t[p] != '}' && t[p] != '{' && t[p] != ',' && t[p] != ';' && t[p] != '#' && t[p] != ']' && t[p] != '[') p++;
         out = t.substr(b, p - b);
         return p > b;
     }
@@ -89,6 +89,19 @@ class TextParser {
             if (p < t.size() && t[p] == ':') {
                 p++; skip();
                 if (p < t.size() && t[p] == '{') { p++; TextNode c; if (!body(c, true, depth + 1)) return false; n.children.emplace_back(key, std::move(c)); continue; }
+                if (p < t.size() && t[p] == '[') {                  // the short form of a repeated field: `dim: [1, 1, 120, 160]` = four `dim:` entries
+                    p++;                                            // (protobuf's TextFormat prints it with use_short_repeated_primitives and always parses it)
+                    for (;;) {
+                        skip();                                     // (skip() also passes the separating commas)
+                        if (p >= t.size()) return false;
+                        if (t[p] == ']') { p++; break; }
+                        if (t[p] == '{') { p++; TextNode c; if (!body(c, true, depth + 1)) return false; n.children.emplace_back(key, std::move(c)); continue; }
+                        std::string v;
+                        if (!value(v)) return false;
+                        n.scalars.emplace_back(key, v);
+                    }
+                    continue;
+                }
                 std::string v;
                 if (!value(v)) return false;
                 n.scalars.emplace_back(key, v);
