@@ -1,0 +1,154 @@
+// sharded_db_rccl.cpp — the multi-GPU loop-database exchange with NO Python in the loop: plain C++, the HIP runtime, librccl and the C ABI.
+// One process per GPU (WORLD_SIZE / RANK / LOCAL_RANK from the environment, as torch.distributed.run or mpirun set them); the reference's
+// side would be LoopClosing::DetectLoop, /root/reference/src/loopclosing.cpp:124-161, over a std::map that no longer fits one device.
+//   1. every rank holds the contiguous id range [r n/W, (r+1) n/W) of the key-frame descriptors in a myslam_lcddb and P query descriptors
+//   2. ncclAllGather of the queries (W x P x 1064 f32)
+//   3. myslam_lcddb_query_batch_sharded: every shard scores every query -> one 16-byte myslam_lcd_candidate per query (device memory)
+//   4. ncclAllGather of the raw candidate bytes (W x NQ x 16)
+//   5. myslam_lcd_merge_candidates_device -> (best id, max score, count) of ONE ascending scan over the whole database
+// Rank 0 also holds the whole database in one handle and checks 5. against its single scan.
+//   usage: sharded_db_rccl <db.f32> <queries.f32> <cur_ids.u64> <n_db> <nq>      (nq divisible by WORLD_SIZE)
+//   the ncclUniqueId travels through the file $MYSLAM_NCCL_ID_FILE (rank 0 writes it; a launcher with MPI would broadcast it instead)
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "myslam_hip.h"
+
+#define HIPOK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "rank %d: %s -> %s\n", g_rank, #x, hipGetErrorString(e_)); return 2; } } while (0)
+#define NCCLOK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { fprintf(stderr, "rank %d: %s -> %s\n", g_rank, #x, ncclGetErrorString(r_)); return 3; } } while (0)
+#define MYOK(x) do { int c_ = (x); if (c_ != MYSLAM_OK) { fprintf(stderr, "rank %d: %s -> %d\n", g_rank, #x, c_); return 4; } } while (0)
+static int g_rank = 0;
+
+template <class T>
+static bool read_all(const char* path, std::vector<T>& v, size_t n) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    v.resize(n);
+    const size_t got = fread(v.data(), sizeof(T), n, f);
+    fclose(f);
+    return got == n;
+}
+
+static int env_int(const char* k, int def) { const char* s = getenv(k); return s ? atoi(s) : def; }
+
+int main(int argc, char** argv) {
+    if (argc < 6) { fprintf(stderr, "usage: %s db.f32 queries.f32 cur_ids.u64 n_db nq\n", argv[0]); return 1; }
+    const int world = env_int("WORLD_SIZE", 1), rank = env_int("RANK", 0), local = env_int("LOCAL_RANK", rank);
+    g_rank = rank;
+    const int n_db = atoi(argv[4]), nq = atoi(argv[5]);
+    if (world < 1 || rank < 0 || rank >= world || nq % world != 0 || n_db < world) { fprintf(stderr, "bad sizes\n"); return 1; }
+    const int P = nq / world, D = MYSLAM_LCD_DIM;
+    std::vector<float> db, q; std::vector<uint64_t> cur;
+    if (!read_all(argv[1], db, (size_t)n_db * D) || !read_all(argv[2], q, (size_t)nq * D) || !read_all(argv[3], cur, (size_t)nq)) { fprintf(stderr, "cannot read the inputs\n"); return 1; }
+    int ndev = 0;
+    HIPOK(hipGetDeviceCount(&ndev));
+    if (local >= ndev) { fprintf(stderr, "rank %d: LOCAL_RANK %d but %d device(s)\n", rank, local, ndev); return 1; }
+    HIPOK(hipSetDevice(local));
+
+    // ---- communicator -----------------------------------------------------------------------------------------------------------
+    ncclUniqueId id;
+    const char* idfile = getenv("MYSLAM_NCCL_ID_FILE");
+    if (world > 1 && !idfile) { fprintf(stderr, "MYSLAM_NCCL_ID_FILE is not set\n"); return 1; }
+    if (rank == 0) {
+        NCCLOK(ncclGetUniqueId(&id));
+        if (world > 1) {
+            const std::string tmp = std::string(idfile) + ".tmp";
+            FILE* f = fopen(tmp.c_str(), "wb");
+            if (!f || fwrite(&id, sizeof(id), 1, f) != 1) return 1;
+            fclose(f);
+            if (rename(tmp.c_str(), idfile) != 0) return 1;
+        }
+    } else {
+        FILE* f = nullptr;
+        for (int t = 0; t < 600 && !(f = fopen(idfile, "rb")); t++) usleep(100000);
+        if (!f || fread(&id, sizeof(id), 1, f) != 1) { fprintf(stderr, "rank %d: no unique id\n", rank); return 1; }
+        fclose(f);
+    }
+    ncclComm_t comm;
+    NCCLOK(ncclCommInitRank(&comm, world, id, rank));
+    hipStream_t s;
+    HIPOK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+
+    // ---- this rank's shard: ids lo .. hi-1 (key-frame id = row index) ----------------------------------------------------------------
+    const int lo = (int)((long long)n_db * rank / world), hi = (int)((long long)n_db * (rank + 1) / world);
+    myslam_lcddb* shard = nullptr;
+    MYOK(myslam_lcddb_create(&shard, 16));                          // grows as the reference's std::map does
+    MYOK(myslam_lcddb_set_stream(shard, s));
+    for (int i = lo; i < hi; i++) MYOK(myslam_lcddb_append(shard, (uint64_t)i, db.data() + (size_t)i * D));     // LoopClosing::AddToDatabase, one key-frame at a time
+    if (myslam_lcddb_size(shard) != hi - lo) return 5;
+
+    float *d_myq = nullptr, *d_allq = nullptr; myslam_lcd_candidate *d_cand = nullptr, *d_gath = nullptr;
+    uint64_t* d_best = nullptr; float* d_max = nullptr; int32_t* d_cnt = nullptr;
+    HIPOK(hipMalloc((void**)&d_myq, sizeof(float) * P * D)); HIPOK(hipMalloc((void**)&d_allq, sizeof(float) * nq * D));
+    HIPOK(hipMalloc((void**)&d_cand, sizeof(myslam_lcd_candidate) * nq)); HIPOK(hipMalloc((void**)&d_gath, sizeof(myslam_lcd_candidate) * nq * world));
+    HIPOK(hipMalloc((void**)&d_best, 8 * nq)); HIPOK(hipMalloc((void**)&d_max, 4 * nq)); HIPOK(hipMalloc((void**)&d_cnt, 4 * nq));
+    HIPOK(hipMemcpyAsync(d_myq, q.data() + (size_t)rank * P * D, sizeof(float) * P * D, hipMemcpyHostToDevice, s));      // this rank's own P queries
+
+    // ---- the exchange: two all-gathers around the two C-ABI calls, everything on one stream, no host synchronisation in between ---------
+    const float thr_low = 0.92f;
+    NCCLOK(ncclAllGather(d_myq, d_allq, (size_t)P * D, ncclFloat, comm, s));
+    MYOK(myslam_lcddb_query_batch_sharded(shard, d_allq, cur.data(), nq, thr_low, d_cand));
+    NCCLOK(ncclAllGather(d_cand, d_gath, sizeof(myslam_lcd_candidate) * (size_t)nq, ncclChar, comm, s));
+    MYOK(myslam_lcd_merge_candidates_device(d_gath, world, nq, d_best, d_max, d_cnt, s));
+    std::vector<uint64_t> best(nq); std::vector<float> mx(nq); std::vector<int32_t> cnt(nq);
+    HIPOK(hipMemcpyAsync(best.data(), d_best, 8 * nq, hipMemcpyDeviceToHost, s));
+    HIPOK(hipMemcpyAsync(mx.data(), d_max, 4 * nq, hipMemcpyDeviceToHost, s));
+    HIPOK(hipMemcpyAsync(cnt.data(), d_cnt, 4 * nq, hipMemcpyDeviceToHost, s));
+    HIPOK(hipStreamSynchronize(s));
+
+    // ---- rank 0: the same queries against ONE scan of the whole database -------------------------------------------------------------
+    int bad = 0;
+    if (rank == 0) {
+        myslam_lcddb* whole = nullptr;
+        MYOK(myslam_lcddb_create(&whole, n_db));
+        MYOK(myslam_lcddb_set_stream(whole, s));
+        std::vector<uint64_t> ids(n_db);
+        for (int i = 0; i < n_db; i++) ids[i] = (uint64_t)i;
+        float* d_db = nullptr;
+        HIPOK(hipMalloc((void**)&d_db, sizeof(float) * (size_t)n_db * D));
+        HIPOK(hipMemcpy(d_db, db.data(), sizeof(float) * (size_t)n_db * D, hipMemcpyHostToDevice));
+        MYOK(myslam_lcddb_append_batch(whole, ids.data(), d_db, n_db));
+        uint64_t* d_b1 = nullptr; float* d_m1 = nullptr; int32_t* d_c1 = nullptr;
+        HIPOK(hipMalloc((void**)&d_b1, 8 * nq)); HIPOK(hipMalloc((void**)&d_m1, 4 * nq)); HIPOK(hipMalloc((void**)&d_c1, 4 * nq));
+        MYOK(myslam_lcddb_query_batch(whole, d_allq, cur.data(), nq, thr_low, d_b1, d_m1, d_c1));
+        std::vector<uint64_t> b1(nq); std::vector<float> m1(nq); std::vector<int32_t> c1(nq);
+        HIPOK(hipMemcpyAsync(b1.data(), d_b1, 8 * nq, hipMemcpyDeviceToHost, s));
+        HIPOK(hipMemcpyAsync(m1.data(), d_m1, 4 * nq, hipMemcpyDeviceToHost, s));
+        HIPOK(hipMemcpyAsync(c1.data(), d_c1, 4 * nq, hipMemcpyDeviceToHost, s));
+        HIPOK(hipStreamSynchronize(s));
+        int loops = 0, breaks = 0;
+        for (int i = 0; i < nq; i++) {
+            if (best[i] != b1[i] || cnt[i] != c1[i] || memcmp(&mx[i], &m1[i], 4) != 0) {
+                if (bad++ < 5) fprintf(stderr, "query %d: sharded (%llu, %.9g, %d) vs one scan (%llu, %.9g, %d)\n", i, (unsigned long long)best[i], mx[i], cnt[i],
+                                       (unsigned long long)b1[i], m1[i], c1[i]);
+            }
+            loops += (mx[i] >= 0.94f && cnt[i] <= 3);               // DetectLoop's decision, loopclosing.cpp:147
+            breaks += cur[i] < (uint64_t)n_db + 19;
+        }
+        // the host form of the merge on the gathered bytes (a CPU-side consumer needs no device)
+        std::vector<myslam_lcd_candidate> hg((size_t)nq * world);
+        HIPOK(hipMemcpy(hg.data(), d_gath, sizeof(myslam_lcd_candidate) * hg.size(), hipMemcpyDeviceToHost));
+        std::vector<uint64_t> b2(nq); std::vector<float> m2(nq); std::vector<int32_t> c2(nq);
+        MYOK(myslam_lcd_merge_candidates(hg.data(), world, nq, b2.data(), m2.data(), c2.data()));
+        for (int i = 0; i < nq; i++) bad += (b2[i] != best[i] || c2[i] != cnt[i] || memcmp(&m2[i], &mx[i], 4) != 0);
+        printf("%s ranks=%d n_db=%d queries=%d (P=%d per rank) accepted_loops=%d queries_hitting_the_cut_off=%d mismatches=%d\n",
+               bad ? "SHARDED DB RCCL FAILED" : "SHARDED DB RCCL OK", world, n_db, nq, P, loops, breaks, bad);
+        (void)myslam_lcddb_destroy(whole);
+        (void)hipFree(d_db); (void)hipFree(d_b1); (void)hipFree(d_m1); (void)hipFree(d_c1);
+    }
+    (void)myslam_lcddb_destroy(shard);
+    void* fr[] = {d_myq, d_allq, d_cand, d_gath, d_best, d_max, d_cnt};
+    for (void* p : fr) (void)hipFree(p);
+    NCCLOK(ncclCommDestroy(comm));
+    (void)hipStreamDestroy(s);
+    return bad ? 6 : 0;
+}

@@ -28,3 +28,33 @@ def test_c_abi_gated_handles(tmp_path):
     subprocess.check_call(cmd)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "PIPELINE TEST OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_cpp_sharded_db_over_rccl(synth, tmp_path):
+    """The multi-GPU loop-database exchange as a compiled program (tests/cpp/sharded_db_rccl.cpp): C++ + librccl + the C ABI, no Python in
+    the loop — ncclCommInitRank, ncclAllGather of the queries, myslam_lcddb_query_batch_sharded, ncclAllGather of the 16-byte records,
+    myslam_lcd_merge_candidates_device, checked against one scan of the whole database.  One rank per visible GPU (1 on this pool's boxes)."""
+    import numpy as np
+    import torch
+    exe = str(tmp_path / "sharded_db_rccl")
+    cmd = ["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "sharded_db_rccl.cpp"), "-o", exe, "-L" + PKG_DIR, "-lmyslam_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lrccl",
+           "-Wl,-rpath," + PKG_DIR, "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    n_db, nq = 3000, 64
+    db = synth.lcd_database(n_db)
+    rng = np.random.default_rng(11)
+    q = db[rng.integers(0, n_db, nq)] * 0.98 + 0.02 * synth.lcd_database(nq, seed=5)
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    cur = np.full(nq, n_db + 20, np.uint64); cur[::3] = rng.integers(30, n_db, len(cur[::3]))       # a third of the scans stop at the `cur - id < 20` cut-off
+    (tmp_path / "db.f32").write_bytes(db.astype(np.float32).tobytes()); (tmp_path / "q.f32").write_bytes(q.tobytes()); (tmp_path / "cur.u64").write_bytes(cur.tobytes())
+    world = max(1, torch.cuda.device_count())
+    while nq % world:
+        world -= 1
+    env = dict(os.environ, WORLD_SIZE=str(world), MYSLAM_NCCL_ID_FILE=str(tmp_path / "nccl_id"), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    args = [exe, str(tmp_path / "db.f32"), str(tmp_path / "q.f32"), str(tmp_path / "cur.u64"), str(n_db), str(nq)]
+    procs = [subprocess.Popen(args, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [(p.returncode, o[1][-1500:]) for p, o in zip(procs, outs)]
+    assert f"SHARDED DB RCCL OK ranks={world}" in outs[0][0] and "mismatches=0" in outs[0][0], outs[0][0]
+    print(outs[0][0].strip())
