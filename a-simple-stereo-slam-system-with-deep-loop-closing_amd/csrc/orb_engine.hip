@@ -34,6 +34,8 @@ void launch_screen(const OrbPlan& P, const uint8_t* pyr, myslam_keypoint* kin, i
 void launch_calc_desc(const OrbPlan& P, const uint8_t* blur, const myslam_keypoint* kps, int n, uint8_t* desc, hipStream_t s);
 void launch_unpack_cands(const uint32_t* cand, int n, int32_t* xs, int32_t* ys, int32_t* sc, hipStream_t s);
 void launch_blur_levels(const BlurArgs* lv, int n, int batch, hipStream_t s);
+bool blur_mfma_tables(int w, int h, const int q[7], std::vector<uint4>& tab, size_t& offH, size_t& offV);
+void blur_mfma_ident(std::vector<uint4>& tab, size_t& offI);
 void launch_zero_u32(uint32_t* p0, int n0, uint32_t* p1, int n1, uint32_t* p2, int n2, uint32_t* p3, int n3, hipStream_t s);
 void launch_ingest_clear(const uint8_t* src, int rows, int cols, int step, size_t sstride, uint8_t* dst, int dpitch, size_t dstride, int batch,
                          uint32_t* p0, int n0, uint32_t* p1, int n1, uint32_t* p2, int n2, uint32_t* p3, int n3, hipStream_t s);
@@ -121,6 +123,9 @@ struct myslam_orb {
     int optCopyInput = 0;              // 1 = copy every input image into the pyramid block (default 0: level 0 is read in place, see run_batch)
     int optStopAfter = 0;              // debug: stop a batched call after stage 1 ingest / 2 pyramid / 3 oct-tree / 4 blur (0 = run all)
     int tapsSet = 0, taps[7] = {0};    // myslam_orb_set_gauss_taps: replacement of the sigma = 2 Q8 taps
+    int optBlurMfma = 0;               // 1 = the Gaussian pyramid on the int8 matrix cores (k_blur7_mfma) for every level that can take it
+    uint4* d_blurTab = nullptr; bool blurTabValid = false; size_t blurOffI = 0, blurOffH[MAXL] = {0}, blurOffV[MAXL] = {0}; bool blurLvOk[MAXL] = {false}; int blurVconst = 0;
+    int ensure_blur_tables();
 
     // Host-pointer calls (one frame per call: the drop-ins) replay a HIP graph: the ~35 launches, memsets and the copies of a call are
     // captured once per (image shape, mask, Detect / DetectAndCompute, FAST statistics parity) and replayed with ONE hipGraphLaunch.
@@ -279,7 +284,7 @@ int myslam_orb::ensure(int batch, int r, int c, bool needMask) {
         MYSLAM_HIP_CHECK(hipStreamSynchronize(stream));
         int rc = make_plan(r, c);
         if (rc) { rows = cols = 0; return rc; }
-        batchCap = 0; gen++;
+        batchCap = 0; gen++; blurTabValid = false;
     }
     const int detOut = det.totalOut;
     const size_t selPer = (size_t)std::max(full.totalOut, detOut);
@@ -342,6 +347,25 @@ ResizeArgs myslam_orb::level_resize_args(uint8_t* base, int l) const {
     a.scale_x = 1. / ((double)a.dw / a.sw); a.scale_y = 1. / ((double)a.dh / a.sh);
     return a;
 }
+// operand tables of the matrix-core Gaussian: per level of the current plan and tap table (rebuilt when either changes)
+int myslam_orb::ensure_blur_tables() {
+    if (blurTabValid) return MYSLAM_OK;
+    std::vector<uint4> tab;
+    int q[7];
+    if (tapsSet) memcpy(q, taps, sizeof(q)); else gauss_q8(0, q);
+    int sum = 0;
+    for (int t = 0; t < 7; t++) sum += q[t];
+    blurVconst = sum * 128 * sum + 32768;          // H = 256 hi + lo + 128 sum(q)  (H' = H - 128 sum + 128, lo carries another -128): vertical sum of that constant + the rounding half
+    blur_mfma_ident(tab, blurOffI);
+    for (int l = 0; l < full.nlevels; l++) blurLvOk[l] = blur_mfma_tables(full.lv[l].w, full.lv[l].h, q, tab, blurOffH[l], blurOffV[l]);
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(stream));
+    int rc = dev_alloc(d_blurTab, tab.size());
+    if (rc) return rc;
+    MYSLAM_HIP_CHECK(hipMemcpy(d_blurTab, tab.data(), tab.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    blurTabValid = true; gen++;
+    return MYSLAM_OK;
+}
+
 BlurArgs myslam_orb::level_blur_args(int l) const {
     const OrbPlan& P = full;
     BlurArgs a;
@@ -350,6 +374,7 @@ BlurArgs myslam_orb::level_blur_args(int l) const {
     a.src0 = nullptr; a.spitch0 = 0; a.n0 = 0; a.sstride0 = 0;
     a.dtiled = 1;
     if (tapsSet) memcpy(a.q, taps, sizeof(taps)); else gauss_q8(0, a.q);
+    if (optBlurMfma && blurTabValid && blurLvOk[l]) { a.tabH = d_blurTab + blurOffH[l]; a.tabV = d_blurTab + blurOffV[l]; a.ident = d_blurTab + blurOffI; a.vconst = blurVconst; }
     return a;
 }
 int myslam_orb::blur_levels(int batch, int nlev, hipStream_t stream) {
@@ -370,6 +395,7 @@ int myslam_orb::run_batch(const uint8_t* d_imgs, int batch, int r, int c, int st
     if (!detectOnly && !d_desc) return MYSLAM_ERR_INVALID;
     int rc = ensure(batch, r, c, d_masks != nullptr);
     if (rc) return rc;
+    if (optBlurMfma && !detectOnly && (rc = ensure_blur_tables())) return rc;
     const OrbPlan& P = detectOnly ? det : full;
     int32_t* stat = d_stat ? d_stat : d_status;
     if (!d_fastStat) {
@@ -492,7 +518,7 @@ int myslam_orb::ensure_stage(size_t imgBytes, size_t maskBytes, int cap) {
 }
 
 void myslam_orb::free_all() {
-    void* ptrs[] = {d_fastStat, d_octTab, d_pyr, d_blur, d_mask, d_cand, d_sort, d_candCount, d_selCount, d_status, d_sel, d_order, d_stageImg, d_stageMask,
+    void* ptrs[] = {d_blurTab, d_fastStat, d_octTab, d_pyr, d_blur, d_mask, d_cand, d_sort, d_candCount, d_selCount, d_status, d_sel, d_order, d_stageImg, d_stageMask,
                     d_stageOut, d_stageKps2, d_stageKeep};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); (void)hipEventDestroy(evFork); (void)hipEventDestroy(evJoin); aux = nullptr; }
@@ -553,12 +579,14 @@ int myslam_orb_set_option(myslam_orb* h, int option, int value) {
         case MYSLAM_ORB_OPT_INTERNAL_STREAM: if (value < 0 || value > 2) return MYSLAM_ERR_INVALID; h->optInternalStream = value; return MYSLAM_OK;
         case MYSLAM_ORB_OPT_COPY_INPUT: if (value < 0 || value > 1) return MYSLAM_ERR_INVALID; h->optCopyInput = value; return MYSLAM_OK;
         case MYSLAM_ORB_OPT_STOP_AFTER: if (value < 0 || value > 4) return MYSLAM_ERR_INVALID; h->optStopAfter = value; return MYSLAM_OK;
+        case MYSLAM_ORB_OPT_BLUR_MFMA: if (value < 0 || value > 1) return MYSLAM_ERR_INVALID; h->optBlurMfma = value; return MYSLAM_OK;
     }
     return MYSLAM_ERR_INVALID;
 }
 
 int myslam_orb_set_gauss_taps(myslam_orb* h, const int32_t* q7) {
     if (!h) return MYSLAM_ERR_INVALID;
+    h->blurTabValid = false;
     if (!q7) { h->tapsSet = 0; h->gen++; return MYSLAM_OK; }
     // any table whose Q8.8 row sums fit the 16-bit horizontal accumulator (255 * sum <= 65535); the u8 result saturates
     int sum = 0;

@@ -504,6 +504,210 @@ __global__ __launch_bounds__(256) void k_blur7_strip(BlurMulti M) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// K2d: the 7 x 7 Gaussian on the int8 matrix cores (MYSLAM_ORB_OPT_BLUR_MFMA).  The blur is exact integer arithmetic —
+// out = sat8((sum_r q_r (sum_c q_c p) + 32768) >> 16) — i.e. two banded (Toeplitz) matrix products, Th over the columns and Tv over the
+// rows, with REFLECT_101 folded into the bands.  Why: the step is bound by VALU issue while the matrix pipe idles;
+// this form needs ~180 VALU instructions per 1024 pixels against ~420 in k_blur7_strip.  One wave walks a 32-column strip of one level
+// downwards in 32 x 32 tiles:
+//   1. H' = (P - 128) x Th^T + 128   A = the image tile as it lies in memory (lane = row, 16 consecutive pixels per lane and k block),
+//                                    B = Th of this strip (table), K = the 64 columns around the strip: 2 MFMAs.  With the accumulator
+//                                    seeded with 128, H' = H - 128 sum(q) + 128 is a signed 16-bit number for any tap table of sum <= 257.
+//                                    The result leaves every lane with ONE column and 16 rows of H' — the shape of a B operand whose k
+//                                    slots are rows —
+//   2. V = Tv x H                    so the vertical pass needs no data movement: H' is split into its high and low byte planes, each is
+//                                    multiplied by the Tv blocks of the tile above, this tile and the tile below (table): 6 MFMAs,
+//                                    out = min(255, (256 S_hi + S_lo + vconst) >> 16).
+//   3. transpose                     the result is again one column per lane; one more MFMA against a 0/1 selection matrix with the operand
+//                                    roles swapped returns it with one ROW per lane: lane (row, half) holds 16 consecutive pixels = one
+//                                    16-byte row of a 16 x 8 destination tile, so a wave's store is 8 whole 128-byte cache lines.
+// All coefficient logic (bands, mirrored borders, partial tiles) lives in host-built operand tables; the kernel has no special cases.
+// (Round 1 had this kernel with row-major output, where its 32-row x 32-byte stores bounded it; the tiled planes of round 3 remove that.)
+typedef int bl_v4i __attribute__((ext_vector_type(4)));
+typedef int bl_v16i __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ uint32_t bl_pack_byte(int r0, int r1, int r2, int r3, int which) {     // byte `which` (0..2) of four registers
+    const uint32_t s2 = 0x0c0c0400u + 0x0101u * (uint32_t)which;          // (b.byte, a.byte) -> bytes 0, 1
+    const uint32_t t01 = __builtin_amdgcn_perm((uint32_t)r1, (uint32_t)r0, s2), t23 = __builtin_amdgcn_perm((uint32_t)r3, (uint32_t)r2, s2);
+    return __builtin_amdgcn_perm(t23, t01, 0x05040100u);
+}
+
+struct BlurMfmaMulti { BlurArgs a[MAXL]; int wave0[MAXL + 1]; int tabHOff[MAXL], tabVOff[MAXL]; int n; };
+
+__global__ __launch_bounds__(256) void k_blur7_mfma(BlurMfmaMulti M) {
+    const int lane = threadIdx.x & 63;
+    const int gw = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (gw >= M.wave0[M.n]) return;
+    int lvl = 0;
+    while (lvl + 1 < M.n && gw >= M.wave0[lvl + 1]) lvl++;
+    const BlurArgs& a = M.a[lvl];
+    const int wid = gw - M.wave0[lvl];                              // 32-column strip of the level
+    const int ntile = (a.h + 31) >> 5;
+    const int b = blockIdx.z;
+    const int x0 = 32 * wid, ws = min(max(x0 - 16, 0), a.w - 64);   // the 64 source columns of the strip (inside the image for any pitch)
+    const bool ext = b < a.n0;                                      // block-uniform: level 0 read in place (rows of any alignment)
+    const uint8_t* src = ext ? a.src0 + (size_t)b * a.sstride0 : a.src + (size_t)b * a.sstride;
+    const int spitch = ext ? a.spitch0 : a.spitch;
+    uint8_t* dst = a.dst + (size_t)b * a.dstride;
+    const int li = lane & 31, lh = lane >> 5;
+    const uint4* tabH = a.tabH + M.tabHOff[lvl];
+    const uint4* tabV = a.tabV + M.tabVOff[lvl];
+    const bl_v4i TH0 = __builtin_bit_cast(bl_v4i, tabH[(size_t)(wid * 2 + 0) * 64 + lane]);
+    const bl_v4i TH1 = __builtin_bit_cast(bl_v4i, tabH[(size_t)(wid * 2 + 1) * 64 + lane]);
+    const bl_v4i ID = __builtin_bit_cast(bl_v4i, a.ident[lane]);
+    const bl_v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const bl_v16i seed16 = {128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128};
+    const bl_v4i zero4 = {0, 0, 0, 0};
+    const int vconst = a.vconst;
+    // pixels are requested ahead of their use (every stage of a tile depends on the previous one)
+    auto load_px = [&](int ty, uint4& p0, uint4& p1) __attribute__((always_inline)) {
+        const int y = min(32 * ty + li, a.h - 1);
+        const uint8_t* row = src + (size_t)y * spitch + ws + 16 * lh;
+        __builtin_memcpy(&p0, row, 16); __builtin_memcpy(&p1, row + 32, 16);
+    };
+    // H' tile as two int8 planes (hi = H' >> 8, lo = (H' & 255) - 128), k slot b of a lane <-> tile row (b&3) + 8(b>>2) + 4 lh
+    auto htile = [&](uint4 p0, uint4 p1, bl_v4i& hi, bl_v4i& lo) __attribute__((always_inline)) {
+        p0.x ^= 0x80808080u; p0.y ^= 0x80808080u; p0.z ^= 0x80808080u; p0.w ^= 0x80808080u;
+        p1.x ^= 0x80808080u; p1.y ^= 0x80808080u; p1.z ^= 0x80808080u; p1.w ^= 0x80808080u;
+        bl_v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(bl_v4i, p0), TH0, seed16, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(bl_v4i, p1), TH1, acc, 0, 0, 0);
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            lo[w] = (int)(bl_pack_byte(acc[4 * w], acc[4 * w + 1], acc[4 * w + 2], acc[4 * w + 3], 0) ^ 0x80808080u);
+            hi[w] = (int)bl_pack_byte(acc[4 * w], acc[4 * w + 1], acc[4 * w + 2], acc[4 * w + 3], 1);
+        }
+    };
+    bl_v4i Hh[3], Hl[3];                                       // tiles ty-1, ty, ty+1
+    Hh[0] = zero4; Hl[0] = zero4;
+    // Pixel registers: three sets, set k holds a tile with index = k (mod 3).  Tile t+1 is consumed in step t and its set is refilled
+    // with tile t+4 right away, so a load has three steps to arrive; the sets are addressed statically (the main loop is unrolled by three)
+    uint4 P0a, P0b, P1a, P1b, P2a, P2b;
+    load_px(0, P0a, P0b);
+    load_px(min(1, ntile - 1), P1a, P1b);
+    load_px(min(2, ntile - 1), P2a, P2b);
+    htile(P0a, P0b, Hh[1], Hl[1]);
+    load_px(min(3, ntile - 1), P0a, P0b);
+    const int hpad = (a.h + 7) & ~7;                            // tiled planes are whole 8-row tile rows
+    auto do_tile = [&](int ty, uint4& pa, uint4& pb, uint4 t0, uint4 t1, uint4 t2) __attribute__((always_inline)) {     // (pa, pb) = the set of tile ty + 1
+        if (ty + 1 < ntile) htile(pa, pb, Hh[2], Hl[2]); else { Hh[2] = zero4; Hl[2] = zero4; }
+        if (ty + 4 < ntile) load_px(ty + 4, pa, pb);
+        bl_v16i sh = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(bl_v4i, t0), Hh[0], zero16, 0, 0, 0);
+        bl_v16i sl = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(bl_v4i, t0), Hl[0], zero16, 0, 0, 0);
+        sh = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(bl_v4i, t1), Hh[1], sh, 0, 0, 0);
+        sl = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(bl_v4i, t1), Hl[1], sl, 0, 0, 0);
+        sh = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(bl_v4i, t2), Hh[2], sh, 0, 0, 0);
+        sl = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(bl_v4i, t2), Hl[2], sl, 0, 0, 0);
+        // out = min(255, (256 S_hi + S_lo + vconst) >> 16) = byte 2 of the clamped sum; out - 128 as the transpose's A operand
+        bl_v4i A3;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            int v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = min((sh[4 * w + k] << 8) + sl[4 * w + k] + vconst, 0x00ffffff);
+            A3[w] = (int)(bl_pack_byte(v[0], v[1], v[2], v[3], 2) ^ 0x80808080u);
+        }
+        const bl_v16i T = __builtin_amdgcn_mfma_i32_32x32x32_i8(A3, ID, zero16, 0, 0, 0);      // lane (row li, half lh): x = (r&3) + 8(r>>2) + 4 lh
+        // the two half-waves hold interleaved 4-pixel groups of the same row: swap two dwords so that each lane owns 16 contiguous
+        // pixels (half 0: x 0..15, half 1: x 16..31) — one 16-byte row of a destination tile
+        uint32_t d[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) d[g] = bl_pack_byte(T[4 * g], T[4 * g + 1], T[4 * g + 2], T[4 * g + 3], 0) ^ 0x80808080u;
+        const uint32_t r0 = (uint32_t)__shfl_xor((int)(lh ? d[0] : d[2]), 32, 64), r1 = (uint32_t)__shfl_xor((int)(lh ? d[1] : d[3]), 32, 64);
+        const uint4 o = lh ? make_uint4(r0, d[2], r1, d[3]) : make_uint4(d[0], r0, d[1], r1);
+        const int y = 32 * ty + li, x = x0 + 16 * lh;
+        if (y < hpad && x < a.dpitch) *reinterpret_cast<uint4*>(dst + tiled_off(x, y, a.dpitch)) = o;
+        Hh[0] = Hh[1]; Hl[0] = Hl[1]; Hh[1] = Hh[2]; Hl[1] = Hl[2];
+    };
+    auto tv = [&](int ty, int o) __attribute__((always_inline)) { return tabV[(size_t)(ty * 3 + o) * 64 + lane]; };
+    auto do_tile_any = [&](int ty, uint4 t0, uint4 t1, uint4 t2) __attribute__((always_inline)) {          // set of tile ty + 1 chosen at run time (wave-uniform)
+        const int k = (ty + 1) % 3;
+        if (k == 0) do_tile(ty, P0a, P0b, t0, t1, t2); else if (k == 1) do_tile(ty, P1a, P1b, t0, t1, t2); else do_tile(ty, P2a, P2b, t0, t1, t2);
+    };
+    // Tv blocks: every tile whose 7-row windows stay inside the image uses the same three blocks; they stay in registers for the main
+    // loop.  The first tile and the last two read theirs from the table.
+    int tlast = ntile;                                         // interior tiles are [1, tlast)
+    while (tlast > 1 && 32 * (tlast - 1) + 34 >= a.h) tlast--;
+    do_tile(0, P1a, P1b, tv(0, 0), tv(0, 1), tv(0, 2));
+    int ty = 1;
+    if (tlast > 1) {
+        const uint4 iv0 = tv(1, 0), iv1 = tv(1, 1), iv2 = tv(1, 2);
+        asm volatile("" ::"v"(iv0.x), "v"(iv0.y), "v"(iv0.z), "v"(iv0.w), "v"(iv1.x), "v"(iv1.y), "v"(iv1.z), "v"(iv1.w), "v"(iv2.x), "v"(iv2.y),
+                     "v"(iv2.z), "v"(iv2.w));
+        for (; ty + 3 <= tlast; ty += 3) {                     // ty = 1 (mod 3): tiles ty+1, ty+2, ty+3 live in sets 2, 0, 1
+            do_tile(ty, P2a, P2b, iv0, iv1, iv2);
+            do_tile(ty + 1, P0a, P0b, iv0, iv1, iv2);
+            do_tile(ty + 2, P1a, P1b, iv0, iv1, iv2);
+        }
+        for (; ty < tlast; ty++) do_tile_any(ty, iv0, iv1, iv2);
+    }
+    for (; ty < ntile; ty++) do_tile_any(ty, tv(ty, 0), tv(ty, 1), tv(ty, 2));
+}
+
+// ---- host: operand tables of k_blur7_mfma ----
+static int bl_reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = (p < 0) ? -p : 2 * len - 2 - p;
+    return p;
+}
+static int bl_coef(const int q[7], int out, int in, int len) {          // weight of input position `in` in output position `out`
+    if (out < 0 || out >= len || in < 0 || in >= len) return 0;
+    int c = 0;
+    for (int t = 0; t < 7; t++) if (bl_reflect101(out + t - 3, len) == in) c += q[t];
+    return c;
+}
+static inline int bl_slot_row(int b, int half) { return (b & 3) + 8 * (b >> 2) + 4 * half; }
+static uint4 bl_pack16(const int c[16]) {
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 16; i++) w[i >> 2] |= (uint32_t)(c[i] & 0xff) << (8 * (i & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+// appends the level's Th blocks (2 per 32-column strip) and Tv blocks (3 per 32-row tile) to `tab`; false = this level cannot take the
+// matrix-core form (narrower than 64 columns, a folded coefficient above 127, a window that does not hold its mirrored columns)
+bool blur_mfma_tables(int w, int h, const int q[7], std::vector<uint4>& tab, size_t& offH, size_t& offV) {
+    if (w < 64 || h < 8) return false;
+    int sum = 0;
+    for (int t = 0; t < 7; t++) { if (q[t] < 0 || q[t] > 127) return false; sum += q[t]; }
+    if (sum < 1 || sum > 257) return false;
+    const int nstrip = (w + 31) / 32, ntile = (h + 31) / 32;
+    const size_t keep = tab.size();
+    offH = tab.size();
+    for (int s = 0; s < nstrip; s++) {
+        const int x0 = 32 * s, ws = std::min(std::max(x0 - 16, 0), w - 64);
+        for (int kb = 0; kb < 2; kb++)
+            for (int l = 0; l < 64; l++) {
+                int c[16];
+                for (int bb = 0; bb < 16; bb++) {
+                    c[bb] = bl_coef(q, x0 + (l & 31), ws + 32 * kb + 16 * (l >> 5) + bb, w);
+                    if (c[bb] > 127) { tab.resize(keep); return false; }
+                }
+                tab.push_back(bl_pack16(c));
+            }
+        // every input column an output column of this strip needs must lie inside the 64-column window
+        for (int j = 0; j < 32 && x0 + j < w; j++)
+            for (int t = 0; t < 7; t++) { const int in = bl_reflect101(x0 + j + t - 3, w); if (in < ws || in >= ws + 64) { tab.resize(keep); return false; } }
+    }
+    offV = tab.size();
+    for (int ty = 0; ty < ntile; ty++)
+        for (int o = 0; o < 3; o++)
+            for (int l = 0; l < 64; l++) {
+                int c[16];
+                for (int bb = 0; bb < 16; bb++) {
+                    c[bb] = bl_coef(q, 32 * ty + (l & 31), 32 * (ty + o - 1) + bl_slot_row(bb, l >> 5), h);
+                    if (c[bb] > 127) { tab.resize(keep); return false; }
+                }
+                tab.push_back(bl_pack16(c));
+            }
+    return true;
+}
+void blur_mfma_ident(std::vector<uint4>& tab, size_t& offI) {
+    offI = tab.size();
+    for (int l = 0; l < 64; l++) {
+        int c[16];
+        for (int bb = 0; bb < 16; bb++) c[bb] = bl_slot_row(bb, l >> 5) == (l & 31) ? 1 : 0;
+        tab.push_back(bl_pack16(c));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K3: grid FAST.  One 256-thread block per strip of 4 horizontally adjacent 30-px grid cells: the strip's ROI rows (+3 px ring)
 // are staged once in LDS (shared halos), every interior pixel gets its FAST-9 score (largest threshold at which it is still a
 // corner), 3x3 strict-maximum NMS runs inside each cell only (as cv::FAST on the sub-Mat does), the 20 -> 7 threshold
@@ -2222,9 +2426,14 @@ bool blur_uses_strips(const BlurArgs& a) {
 // than 8 pixels) go through the LDS-tiled kernel one by one
 void launch_blur_levels(const BlurArgs* lv, int n, int batch, hipStream_t s) {
     BlurMulti M; M.n = 0; M.wave0[0] = 0;
+    BlurMfmaMulti X; X.n = 0; X.wave0[0] = 0;
     for (int i = 0; i < n; i++) {
         const BlurArgs& a = lv[i];
-        if (blur_uses_strips(a)) {
+        if (a.tabH && a.tabV && a.ident && a.dtiled && (a.dpitch & 15) == 0 && ((reinterpret_cast<uintptr_t>(a.dst) | a.dstride) & 15) == 0) {
+            // matrix-core form: one wave per 32-column strip of the level, all such levels in one launch.  (tabH / tabV already point at
+            // the level's blocks: the per-level offsets of the multi-launch stay 0)
+            X.a[X.n] = a; X.tabHOff[X.n] = 0; X.tabVOff[X.n] = 0; X.wave0[X.n + 1] = X.wave0[X.n] + (a.w + 31) / 32; X.n++;
+        } else if (blur_uses_strips(a)) {
             const int nstrips = (a.w + 255) / 256, nbands = (a.h + B3_R - 1) / B3_R;
             M.a[M.n] = a; M.nstrips[M.n] = nstrips; M.wave0[M.n + 1] = M.wave0[M.n] + nstrips * nbands; M.n++;
         } else {
@@ -2233,6 +2442,7 @@ void launch_blur_levels(const BlurArgs* lv, int n, int batch, hipStream_t s) {
         }
     }
     if (M.n) hipLaunchKernelGGL(k_blur7_strip, dim3((M.wave0[M.n] + 3) / 4, 1, batch), dim3(256), 0, s, M);
+    if (X.n) hipLaunchKernelGGL(k_blur7_mfma, dim3((X.wave0[X.n] + 3) / 4, 1, batch), dim3(256), 0, s, X);
 }
 void launch_blur(const BlurArgs& a, int batch, hipStream_t s) { launch_blur_levels(&a, 1, batch, s); }
 

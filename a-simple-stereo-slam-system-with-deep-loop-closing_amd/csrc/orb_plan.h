@@ -64,6 +64,10 @@ struct BlurArgs {
     const uint8_t* src0 = nullptr; int spitch0 = 0, n0 = 0; size_t sstride0 = 0;      // images b < n0 read their source plane here (level 0 in place; any alignment)
     int q[7];                                    // Q8 taps, sum <= 257
     int dtiled = 0;                              // destination in 16 x 8-pixel tiles (tiled_off): the extractor's blurred planes
+    // operand tables of the matrix-core form (k_blur7_mfma; orb_kernels.hip blur_mfma_tables): banded Toeplitz blocks of the horizontal pass
+    // per 32-column strip, of the vertical pass per 32-row tile, the 0/1 transposition matrix; vconst = 128 sum(q)^2 + 32768.  Null =
+    // the register-strip kernel
+    const uint4* tabH = nullptr; const uint4* tabV = nullptr; const uint4* ident = nullptr; int vconst = 0;
 };
 
 // The blurred planes of the extractor are stored in tiles of 16 x 8 pixels = one 128-byte cache line each (tile rows of pitch / 16 tiles,

@@ -78,7 +78,7 @@ ALGO_BYTES = {
     "octree": 2 * 4 * 56000,               # candidates in, selected out (latency bound in practice)
 }
 # profiling slot (csrc/prof.hip) -> kernel symbol prefix as rocprofv3 prints it
-SYMBOL = {"resize": "k_resize_strip", "fast": "k_fast_strip", "octree": "k_octree", "blur7": "k_blur7_strip", "describe": "k_describe2",
+SYMBOL = {"resize": "k_resize_strip", "fast": "k_fast_strip", "octree": "k_octree", "blur7": "k_blur7", "describe": "k_describe2",
           "hamming_match": "k_hamming_fp4", "triangulate": "k_triangulate", "lcd_preproc": "k_lcd_input_fused",
           "calc_conv1": "k_conv1_f16x3_pool_lrn", "calc_conv2": "k_conv2_f16x3", "calc_pool2": "k_pool_lrn128_2x2", "calc_conv3": "k_conv3_norm", "lcddb_scan": "k_db_scan_bf16x6",
           "ba_build": "k_ba_build", "screen": "k_screen"}
@@ -180,6 +180,8 @@ def parse():
                     help="myslam_orb_set_option(COPY_INPUT): 0 = level 0 read in place (the library's default), 1 = every image copied into the pyramid block")
     ap.add_argument("--fast-mode", type=int, default=-1, choices=[-1, 0, 1],
                     help="myslam_orb_set_option(FAST_MODE): -1 = the FAST kernel picks its path per level (default), 0 = two-phase, 1 = dense")
+    ap.add_argument("--blur-mfma", type=int, default=0, choices=[0, 1],
+                    help="myslam_orb_set_option(BLUR_MFMA): 1 = the Gaussian pyramid on the int8 matrix cores (k_blur7_mfma), 0 = register-strip kernel")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = debugging aid: several ranks share GPU 0 and the collectives go through host memory")
     args = ap.parse_args()
@@ -421,6 +423,7 @@ def main():
         e.set_option(e.OPT_INTERNAL_STREAM, args.orb_internal_stream)
         e.set_option(e.OPT_FAST_MODE, args.fast_mode)
         e.set_option(e.OPT_COPY_INPUT, args.orb_copy_input)
+        e.set_option(e.OPT_BLUR_MFMA, args.blur_mfma)
     NB = 2 if args.pipeline else 1          # pipeline: extractor outputs are double-buffered (step k+1 extracts while step k is matched)
     d_kps_b = [torch.zeros(2 * P * cap * 28, dtype=torch.uint8, device=dev) for _ in range(NB)]
     d_desc_b = [torch.zeros(2 * P * cap * 32, dtype=torch.uint8, device=dev) for _ in range(NB)]
@@ -606,7 +609,7 @@ def main():
         st = torch.cuda.Stream(); s_ = st.cuda_stream
         ln = {"stream": st, "ext": api.ORBextractor(2000, stream=s_)}
         ln["ext"].set_option(ln["ext"].OPT_INTERNAL_STREAM, 0); ln["ext"].set_option(ln["ext"].OPT_FAST_MODE, args.fast_mode)
-        ln["ext"].set_option(ln["ext"].OPT_COPY_INPUT, args.orb_copy_input)
+        ln["ext"].set_option(ln["ext"].OPT_COPY_INPUT, args.orb_copy_input); ln["ext"].set_option(ln["ext"].OPT_BLUR_MFMA, args.blur_mfma)
         z = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)
         o = {"kps": z(2 * P * cap * 28, torch.uint8), "desc": z(2 * P * cap * 32, torch.uint8), "cnt": z(2 * P, torch.int32), "stat": z(2 * P, torch.int32),
              "midx": z(P * cap, torch.int32), "mdist": z(P * cap, torch.int32), "xyz": z(P * cap * 3, torch.float64), "ok": z(P * cap, torch.uint8)}

@@ -88,11 +88,15 @@ int myslam_orb_set_fast_gate(myslam_orb* h, void* hip_event);
  *   COPY_INPUT       0 (default) = a *_batch call reads the full-resolution level of every image but the last IN PLACE (no copy into the
  *                    pyramid block): the input buffer must then stay unchanged until the call has completed on the handle's stream;
  *                    1 = every image is copied first, the input may be overwritten as soon as the copy kernel has run
- *   STOP_AFTER       debug: a batched call returns after stage 1 ingest / 2 pyramid / 3 oct-tree / 4 blur (0 = complete call) */
+ *   STOP_AFTER       debug: a batched call returns after stage 1 ingest / 2 pyramid / 3 oct-tree / 4 blur (0 = complete call)
+ *   BLUR_MFMA        1 = the 7 x 7 Gaussian pyramid runs on the int8 matrix cores (two banded Toeplitz products per 32 x 32 tile, bit-identical
+ *                    to the register-strip kernel; levels narrower than 64 columns or tap tables with a folded coefficient above 127 keep
+ *                    the strip kernel), 0 = register-strip kernel on the vector units.  The step is VALU-issue bound: see DESIGN.md section 6 */
 #define MYSLAM_ORB_OPT_FAST_MODE 1
 #define MYSLAM_ORB_OPT_INTERNAL_STREAM 2
 #define MYSLAM_ORB_OPT_STOP_AFTER 3
 #define MYSLAM_ORB_OPT_COPY_INPUT 4
+#define MYSLAM_ORB_OPT_BLUR_MFMA 5
 int myslam_orb_set_option(myslam_orb* h, int option, int value);
 /* The 7 x 7 sigma = 2 Gaussian before rBRIEF (ORBextractor.cpp:966, :1197) runs in OpenCV's 8-bit fixed-point form; how OpenCV 3.4.8
  * rounds the taps to Q8 could not be checked in the build environment (parity unpinned).  Default

@@ -101,3 +101,50 @@ def test_capability_fallbacks(api, oracle, synth):
     lcd = api.DeepLCD(synth.calc_weights())
     _, blurred = lcd.calcDescrOriginalImg(small, blur_in_place=True)
     assert np.array_equal(blurred, oracle.calc_preproc(small, blur_in_place=True)[1])
+
+
+@pytest.mark.parametrize("shape", [(376, 1241), (240, 420), (97, 333), (96, 96), (100, 90)])
+def test_matrix_core_gaussian_bitexact(api, oracle, synth, shape):
+    """MYSLAM_ORB_OPT_BLUR_MFMA: the Gaussian pyramid as banded int8 matrix products (k_blur7_mfma) — every blurred level and the whole
+    extraction must equal the oracle bit for bit: saturated flat-white areas (the default tap table sums to 257), borders, partial tiles,
+    levels too narrow for the matrix-core form (they keep the strip kernel inside the same call), single frames and a batch whose level 0
+    is read in place; another tap table through the same path."""
+    import torch
+    h, w = shape
+    img = synth.random_image(41 + h, h, w, "texture")
+    img[: h // 3, : w // 2] = 255; img[h // 2:, w // 3:] = 0                      # saturation: 255 * 257 * 257 needs the clamp
+    nlev = 8 if min(h, w) >= 200 else 3 if w == 90 else 2      # (100, 90): level 2 is 62 columns wide — below the matrix-core form's 64: strip kernel
+    par = oracle.params(600, nlevels=nlev)
+    ext = api.ORBextractor(600, nlevels=nlev); ext.set_option(ext.OPT_BLUR_MFMA, 1)
+    rk, rd = oracle.detect_and_compute(par, img)
+    for rep in range(2):                                                            # second call = the replayed graph of the host-pointer path
+        gk, gd = ext.DetectAndCompute(img)
+        assert gk.tobytes() == rk.tobytes() and np.array_equal(gd, rd), (shape, rep)
+    pyr = oracle.pyramid(par, img)
+    for lvl in range(nlev):
+        assert np.array_equal(ext.debug_pyramid(img, lvl, blurred=True), oracle.blur7(pyr[lvl], 0)), (shape, lvl)
+    # batch: level 0 of every image but the last is read where the caller put it (pitch = cols: rows of any alignment)
+    B = 5
+    imgs = np.stack([np.roll(img, 7 * i, axis=1) for i in range(B)])
+    d = torch.from_numpy(np.ascontiguousarray(imgs)).cuda()
+    cap = ext.max_keypoints(h, w)
+    kps = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda"); desc = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(B, dtype=torch.int32, device="cuda"); st = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ext.set_stream(torch.cuda.current_stream().cuda_stream)
+    ext.detect_and_compute_batch(d.data_ptr(), B, h, w, w, h * w, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), st.data_ptr(), cap)
+    torch.cuda.synchronize()
+    assert int(st.abs().sum()) == 0
+    k = kps.cpu().numpy().view(api.KP_DTYPE).reshape(B, cap); dd = desc.cpu().numpy().reshape(B, cap, 32)
+    for i in range(B):
+        rki, rdi = oracle.detect_and_compute(par, imgs[i])
+        n = int(cnt[i])
+        assert k[i, :n].tobytes() == rki.tobytes() and np.array_equal(dd[i, :n], rdi), (shape, i)
+    # another tap table (the sum-256 one of rounds 1-2) through the same kernels
+    q = [18, 34, 49, 54, 49, 34, 18]
+    ext.set_gauss_taps(q); oracle.set_gauss_taps(q)
+    try:
+        rk2, rd2 = oracle.detect_and_compute(par, img)
+        gk2, gd2 = ext.DetectAndCompute(img)
+        assert gk2.tobytes() == rk2.tobytes() and np.array_equal(gd2, rd2)
+    finally:
+        oracle.set_gauss_taps(None)

@@ -52,7 +52,17 @@ def test_layer_taps_against_torch(api, synth):
         got = _nhwc_to_nchw(lcd.debug_forward(x, stage), h, ww, c)
         ref = r[0].numpy()
         err = np.abs(got - ref).max() / max(1e-6, np.abs(ref).max())
-        assert err < 2e-5, (stage, err)                              # asymmetric weights: a transposed tile would fail here
+        # f32-level accuracy is what the f16 x 3 / bf16 x 6 split products on the 16-bit matrix cores claim (measured 1.1e-6 against this
+        # f64 net, tools/conv2_error.py): the bar is 5e-6 max-normalised, not the 2e-5 ABSOLUTE bar against the f32 oracle (an asymmetric
+        # weight bank: a transposed tile would fail here by orders of magnitude)
+        assert err < 5e-6, (stage, err)
+    # the bf16 x 6 fallback kernels hold the same bar
+    lcd2 = api.DeepLCD(w); lcd2.set_option(lcd2.OPT_CONV2_BF16X6, 1)
+    for stage, (r, h, ww, c) in enumerate(refs):
+        got = _nhwc_to_nchw(lcd2.debug_forward(x, stage), h, ww, c)
+        ref = r[0].numpy()
+        err = np.abs(got - ref).max() / max(1e-6, np.abs(ref).max())
+        assert err < 5e-6, ("bf16x6", stage, err)
 
 
 def test_describe_batch(api, oracle, synth):
