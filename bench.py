@@ -662,28 +662,6 @@ def main():
     api.prof_enable(False)
     dt = timed(args.steps)
     host_launch_ms = host_ms[0]
-    # the other launch mode over the same steps (eager when the timed region replayed graphs, graphs when it launched eagerly)
-    other_mode = None
-    lanes_eager = None
-    if can_graph and not args.no_extra_passes:
-        if not use_graph:
-            api.prof_enable(False)
-            lanes = [build_lane() for _ in range(n_lanes)]
-        fn_o = step_eager if use_graph else step_lanes
-        for _ in range(2 * n_lanes):
-            fn_o()
-        barrier()
-        dt_o = timed(args.steps, fn_o)
-        other_mode = {"mode": "eager launches, two extractor handles + match + side chain on four streams, consecutive steps overlap" if use_graph else
-                              f"HIP graph replay on {n_lanes} single-stream lanes",
-                      "value": world * P * args.steps / dt_o, "unit": "stereo frames/s", "ms_per_step": dt_o / args.steps * 1e3,
-                      "host_launch_ms_per_step": host_ms[0], "graph_nodes": lanes[0]["graphs"][0].node_count()}
-        for _ in range(2 * n_lanes):
-            step_lanes_eager()
-        barrier()
-        dt_l = timed(args.steps, step_lanes_eager)
-        lanes_eager = {"mode": f"the same {n_lanes} lanes launched eagerly (no recording)", "value": world * P * args.steps / dt_l,
-                       "ms_per_step": dt_l / args.steps * 1e3, "host_launch_ms_per_step": host_ms[0]}
     if not use_graph:
         step = step_eager
 
@@ -808,6 +786,30 @@ def main():
         api.prof_enable(False)
         alone = {k: v for k, v in api.prof_read().items() if v[1] > 0}
 
+    # (this pass comes last of the timed ones: the lanes bring their own streams, and on this runtime streams beyond GPU_MAX_HW_QUEUES share
+    # hardware queues — created before the streamed-input pass they cost it a third of its rate, 38.5 k instead of 57 k frames/s)
+    # the other launch mode over the same steps (eager when the timed region replayed graphs, graphs when it launched eagerly)
+    other_mode = None
+    lanes_eager = None
+    if can_graph and not args.no_extra_passes:
+        if not use_graph:
+            api.prof_enable(False)
+            lanes = [build_lane() for _ in range(n_lanes)]
+        fn_o = step_eager if use_graph else step_lanes
+        for _ in range(2 * n_lanes):
+            fn_o()
+        barrier()
+        dt_o = timed(args.steps, fn_o)
+        other_mode = {"mode": "eager launches, two extractor handles + match + side chain on four streams, consecutive steps overlap" if use_graph else
+                              f"HIP graph replay on {n_lanes} single-stream lanes",
+                      "value": world * P * args.steps / dt_o, "unit": "stereo frames/s", "ms_per_step": dt_o / args.steps * 1e3,
+                      "host_launch_ms_per_step": host_ms[0], "graph_nodes": lanes[0]["graphs"][0].node_count()}
+        for _ in range(2 * n_lanes):
+            step_lanes_eager()
+        barrier()
+        dt_l = timed(args.steps, step_lanes_eager)
+        lanes_eager = {"mode": f"the same {n_lanes} lanes launched eagerly (no recording)", "value": world * P * args.steps / dt_l,
+                       "ms_per_step": dt_l / args.steps * 1e3, "host_launch_ms_per_step": host_ms[0]}
     if args.verify and args.pipeline:
         # the overlapped schedule must not change a single output: one plain step (handles un-gated, joined) against the last pipelined one
         outs = lambda p: [d_kps_b[p], d_desc_b[p], d_cnt_b[p], d_stat_b[p], d_midx, d_mdist, d_xyz, d_ok] + \
