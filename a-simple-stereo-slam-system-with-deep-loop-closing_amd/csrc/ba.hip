@@ -92,6 +92,7 @@ __device__ __forceinline__ double bcast_lane(double v, int srcLane) {       // s
 //   A landmark whose edges are scattered over several runs takes the slow road: its edges are evaluated one per thread (pose terms
 //   as above) and its block is summed by one thread scanning the edge list in order.
 __global__ __launch_bounds__(256) void k_ba_build(BaArgs a) {
+    MYSLAM_SIDE_PRIO();
     extern __shared__ __attribute__((aligned(16))) double s_d[];
     const int w = blockIdx.x, t = threadIdx.x, wv = t >> 6;
     int P = a.sizes ? a.sizes[3 * w] : a.nposes;

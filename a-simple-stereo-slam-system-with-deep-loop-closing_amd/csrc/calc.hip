@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void k_lcd_input_fused(const uint8_t* __restri
                                                          const int32_t* __restrict__ xofs, const int16_t* __restrict__ xa,
                                                          const int32_t* __restrict__ yofs, const int16_t* __restrict__ yb, LcdTaps tp,
                                                          float* __restrict__ out) {
+    MYSLAM_SIDE_PRIO();
     const int b = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= IN_H * IN_W) return;
@@ -152,6 +153,7 @@ __device__ __forceinline__ float lrn_factor(float ss, const LrnP& p) {
 // every input pixel read 1.56 instead of 2.25 times, the LRN neighbours over lane shuffles instead of LDS; LRN summation order
 // channels c-2 .. c+2.
 __global__ __launch_bounds__(256) void k_pool_lrn128_2x2(const float* __restrict__ in, int H, int W, int OH, int OW, LrnP lp, float* __restrict__ out) {
+    MYSLAM_SIDE_PRIO();
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int TW = (OW + 1) >> 1, TH = (OH + 1) >> 1;
@@ -430,6 +432,7 @@ __device__ __forceinline__ void cv_split2_f16(float a0, float a1, uint32_t& h, u
 __global__ __launch_bounds__(256) void k_conv2_f16x3(const float* __restrict__ in /*[B][31*41][64]*/,
                                                      const uint4* __restrict__ wt3 /*[64 stages][3: Hs, m', h][128 n][2 k-halves] x 8 f16*/,
                                                      const float* __restrict__ b2, float* __restrict__ out /*[B*1344][128]*/, int Mtotal, int relu) {
+    MYSLAM_SIDE_PRIO();
     constexpr int BM = 128, BN = 128;
     constexpr int KH = BM + 8;
     __shared__ uint4 s_a[2][2][2 * KH];
@@ -531,6 +534,7 @@ static_assert(C1T_NM <= 4, "one M tile per wave");
 
 __global__ __launch_bounds__(256) void k_conv1_f16x3_pool_lrn(const float* __restrict__ in, const uint4* __restrict__ w1h /*[2 n tiles][2 k steps][3: Hs, m', h][64 lanes]*/,
                                                               const float* __restrict__ b1, int relu, LrnP lp, float* __restrict__ out /*[HP1*WP1][64]*/) {
+    MYSLAM_SIDE_PRIO();
     __shared__ __attribute__((aligned(8))) _Float16 s_h[C1T_IH * C1T_IP + 4], s_m[C1T_IH * C1T_IP + 4];
     static_assert(C1T_IP % 2 == 0, "dword reads of pixel pairs");
     __shared__ float s_conv[32 * C1T_NM * C1T_CP];
@@ -637,6 +641,7 @@ constexpr int CV3_T = 256, CV3_NB = 4, CV3_NW = CV3_NB * CV3_T / 64;
 __global__ __launch_bounds__(CV3_T) void k_conv3_norm(const float* __restrict__ in /*[B][16*21][128]*/,
                                                       const float* __restrict__ w3t /*[1152][4]*/, const float* __restrict__ b3,
                                                       float* __restrict__ out /*[B][1064], not yet normalised*/, int relu) {
+    MYSLAM_SIDE_PRIO();
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gw = blockIdx.x * (CV3_T / 64) + wave;
     const float* I = in + (size_t)b * HP2 * WP2 * 128;

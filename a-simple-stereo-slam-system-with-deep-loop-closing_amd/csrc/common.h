@@ -17,6 +17,18 @@
         }                                                                                   \
     } while (0)
 
+// Wave priority of everything that is NOT the grid-FAST kernel (experiment of round 4): FAST is the VALU-issue
+// bound kernel and is resident during the whole step; the kernels that run under it are latency / texture-addresser / matrix-pipe bound.
+// With a raised priority their (few) ready instructions issue ahead of FAST's, so they leave the CU sooner and FAST fills what is left.
+#ifndef MYSLAM_SIDE_PRIO_LEVEL
+#define MYSLAM_SIDE_PRIO_LEVEL 0
+#endif
+#if MYSLAM_SIDE_PRIO_LEVEL > 0
+#define MYSLAM_SIDE_PRIO() __builtin_amdgcn_s_setprio(MYSLAM_SIDE_PRIO_LEVEL)
+#else
+#define MYSLAM_SIDE_PRIO() ((void)0)
+#endif
+
 namespace myslam_hip {
 
 constexpr int WAVE = 64;

@@ -89,6 +89,7 @@ __device__ __forceinline__ void db_split3(float a0, float a1, uint32_t& h, uint3
 __global__ __launch_bounds__(256) void k_db_scan_bf16x6(const float* __restrict__ db, int rows_alloc, const float* __restrict__ q,
                                                         int nq, const int32_t* __restrict__ nvalid, float thr_low,
                                                         Partial* __restrict__ partials) {
+    MYSLAM_SIDE_PRIO();
     __shared__ uint4 s_a[2][3][GM * 2];                // [piece][row][k half] x 8 bf16
     __shared__ uint4 s_b[2][3][GN * 2];
     __shared__ Partial s_p[2][GN];

@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void k_hamming_fp4(const uint8_t* __restrict__
                                                      const uint8_t* __restrict__ tr, const int32_t* __restrict__ ntv,
                                                      int cap, int nq_single, int nt_single,
                                                      int32_t* __restrict__ out_idx, int32_t* __restrict__ out_dist) {
+    MYSLAM_SIDE_PRIO();
     __shared__ __attribute__((aligned(16))) uint8_t s_exp[2][32 * HF_ROWB];
     __shared__ uint32_t s_lut[256];                // byte -> 8 FP4 codes (bit i -> nibble i): bit 1 -> -1.0 (0xA), bit 0 -> +1.0 (0x2)
     const int p = blockIdx.y;
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(256) void k_triangulate(const float* __restrict__ x
                                                      const int32_t* __restrict__ match, const int32_t* __restrict__ nlv,
                                                      int cap, int n_single, double fx, double fy, double cx, double cy,
                                                      double baseline, double* __restrict__ xyz, uint8_t* __restrict__ ok) {
+    MYSLAM_SIDE_PRIO();
     const int p = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int n = nlv ? min(nlv[p], cap) : n_single;

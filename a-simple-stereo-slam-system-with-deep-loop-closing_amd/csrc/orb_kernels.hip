@@ -98,6 +98,7 @@ constexpr int RS_NB = 2;                     // bands a wave walks with one set 
 constexpr int RS_MAXR = 12;                  // source rows a band may span: RS_R * scale_y + 2 (scale factors up to 1.25)
 
 __global__ __launch_bounds__(256) void k_resize_strip(ResizeArgs a, int nstrips, int nbands) {
+    MYSLAM_SIDE_PRIO();
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // scalar: row addressing goes to the SALU
     const int ngroups = (nbands + RS_NB - 1) / RS_NB;                                              // a wave walks RS_NB consecutive bands of its strip
@@ -341,6 +342,7 @@ __device__ __forceinline__ uint32_t dpp_wave_shl1(uint32_t v) { return (uint32_t
 struct BlurMulti { BlurArgs a[MAXL]; int wave0[MAXL + 1]; int nstrips[MAXL]; int n; };
 constexpr int B3_TS = 144;                     // LDS bytes per staged tile (128 + 16: the dword writes of a wave then spread over all banks)
 __global__ __launch_bounds__(256) void k_blur7_strip(BlurMulti M) {
+    MYSLAM_SIDE_PRIO();
     // tiled destinations: a wave parks 8 output rows of its 256 columns (16 tiles) here and writes them out as 2 KB of whole cache
     // lines — two 16-byte stores per lane instead of eight dword stores that each touch 16 lines
     __shared__ __attribute__((aligned(16))) uint8_t s_tl[4][16 * B3_TS];
@@ -1477,6 +1479,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
                                                const uint32_t* __restrict__ octTab,
                                                uint32_t* __restrict__ selOut, int32_t* __restrict__ selCount,
                                                int32_t* __restrict__ status, int NCmax) {
+    MYSLAM_SIDE_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int t = threadIdx.x;
     const int level = blockIdx.x, b = blockIdx.y;
@@ -2055,6 +2058,7 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
                                                    uint8_t* __restrict__ desc, int32_t* __restrict__ counts,
                                                    int32_t* __restrict__ status, int cap, int nchunk, int batch, int detectOnly,
                                                    const uint16_t* __restrict__ order) {
+    MYSLAM_SIDE_PRIO();
     // per wave: phase A parks the 32 x 32 patches of four key-points here (4 x 64 pieces of 16 bytes), phase C the 37-row BRIEF window
     __shared__ __attribute__((aligned(16))) uint4 s_b[4][256];
     static_assert(DB_N <= 256, "the BRIEF window must fit the per-wave buffer");

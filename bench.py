@@ -180,6 +180,7 @@ def parse():
                     help="myslam_orb_set_option(COPY_INPUT): 0 = level 0 read in place (the library's default), 1 = every image copied into the pyramid block")
     ap.add_argument("--fast-mode", type=int, default=-1, choices=[-1, 0, 1],
                     help="myslam_orb_set_option(FAST_MODE): -1 = the FAST kernel picks its path per level (default), 0 = two-phase, 1 = dense")
+    ap.add_argument("--side-skip", default="", help="diagnostic: comma list of side-chain parts to leave out (lcd, db, ba) — measures what each part costs the step")
     ap.add_argument("--blur-mfma", type=int, default=0, choices=[0, 1],
                     help="myslam_orb_set_option(BLUR_MFMA): 1 = the Gaussian pyramid on the int8 matrix cores (k_blur7_mfma), 0 = register-strip kernel")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -474,9 +475,12 @@ def main():
                                              s_no.data_ptr(), s_st.data_ptr(), stream2)
     solve_windows = [P if use_solve else 0]          # windows the side chain also SOLVES per step (pass 3 sets ceil(P / 6))
 
+    skip = set(args.side_skip.split(",")) if args.side_skip else set()      # diagnostic: the marginal cost of the side chain's parts
+
     def side_chain():
-        if use_lcd:
+        if use_lcd and "lcd" not in skip:
             lcd.describe_batch(cur["imgs"].data_ptr(), P, H, W, W, H * W, d_descr.data_ptr(), blur_in_place=False)
+        if use_lcd and "db" not in skip:
             if world > 1:       # every shard scores every rank's queries; the 16-byte candidate records are merged after an all-gather
                 if via_cpu:
                     h_all = torch.empty(d_allq.shape, dtype=d_allq.dtype)
@@ -488,7 +492,7 @@ def main():
                 pkg.sharded_db.exchange_and_merge(d_cand, world, d_best, d_max, d_dbcnt, via_cpu=via_cpu)
             else:
                 D.query_batch(d_descr.data_ptr(), cur_ids, NQ, d_best.data_ptr(), d_max.data_ptr(), d_dbcnt.data_ptr())
-        if use_ba:
+        if use_ba and "ba" not in skip:
             api.ba_build_batch(*[t.data_ptr() for t in b_in], P, maxP, maxL, maxE, Kt, 5.991, *[t.data_ptr() for t in b_out], stream2)
             if solve_windows[0]:
                 solve(solve_windows[0])
