@@ -141,7 +141,7 @@ class ORBextractor:
         """Make the handle's stream wait for the hipEvent_t `event_ptr` (0 = off) before the FAST stage of every following batched call."""
         _check(lib().myslam_orb_set_fast_gate(self._h, C.c_void_p(event_ptr or None)), "myslam_orb_set_fast_gate")
 
-    OPT_FAST_MODE, OPT_INTERNAL_STREAM, OPT_STOP_AFTER, OPT_COPY_INPUT, OPT_BLUR_MFMA = 1, 2, 3, 4, 5
+    OPT_FAST_MODE, OPT_INTERNAL_STREAM, OPT_STOP_AFTER, OPT_COPY_INPUT, OPT_BLUR_MFMA, OPT_SIDE_BLOCKS_PER_CU = 1, 2, 3, 4, 5, 6
 
     def set_option(self, option, value):
         """scheduling / debugging knobs (myslam_orb_set_option): none of them changes a result"""
@@ -330,6 +330,7 @@ class DeepLCD:
     CALC_LAYER_DTYPE records; DeepLCD.from_caffe(prototxt, caffemodel) = the reference's constructor arguments."""
     OPT_GENERIC_KERNELS = 1
     OPT_CONV2_BF16X6 = 2
+    OPT_SKIP_KERNELS = 3
 
     def __init__(self, weights=None, stream=None, layers=None, caffe=None, path=None):
         self._h = C.c_void_p()

@@ -429,89 +429,123 @@ __device__ __forceinline__ void cv_split2_f16(float a0, float a1, uint32_t& h, u
     m = (uint32_t)__builtin_bit_cast(unsigned short, m0) | ((uint32_t)__builtin_bit_cast(unsigned short, m1) << 16);
 }
 
-__global__ __launch_bounds__(256) void k_conv2_f16x3(const float* __restrict__ in /*[B][31*41][64]*/,
-                                                     const uint4* __restrict__ wt3 /*[64 stages][3: Hs, m', h][128 n][2 k-halves] x 8 f16*/,
-                                                     const float* __restrict__ b2, float* __restrict__ out /*[B*1344][128]*/, int Mtotal, int relu) {
+// Round 4: the kernel no longer stages anything per K step.
+//   * A block owns THREE OUTPUT ROWS of one image (126 pixels = one 128-row M tile, 11 blocks per image).  Its input is a 6 x 45-pixel patch of
+//     the conv1 map, which arrives already split (conv1's epilogue writes a = h + m' 2^-11 as f16 pairs).  The patch of ONE channel group (16
+//     channels: 64 bytes per pixel, [h k-half 0][h k-half 1][m' 0][m' 1], padded to 80 bytes so that the 16-byte operand reads of 16 lanes spread
+//     over all banks) is 21.6 KB of LDS; the 16 taps of that group are im2col'ed by ADDRESS: a lane's A operand of tap (ky, kx) is the same
+//     LDS read at a constant offset.  Four patches per block (the next one is fetched into registers under the current one's 192 MFMAs).
+//   * A wave owns 32 of the 128 output channels for all 128 rows: its B operands (three f16 planes per K step) come straight from the
+//     L2-resident weight slab in operand layout (one coalesced 1 KB read per plane), two K steps ahead; nothing of B passes through LDS.
+//   * 8 block barriers in total (the staging form had 128), 21.6 KB of LDS (was 43.5: it now fits beside six FAST blocks), every activation
+//     fetched once per block and channel group (was once per tap: 16 x), no split arithmetic.
+// K order: channel group outer, tap inner (the staging form ran tap-major): the f32 accumulation order differs in the last bits, the
+// error against f64 is unchanged (tools/conv2_error.py).
+constexpr int C2R = 3, C2PW = WP1 + 4, C2PH = C2R + 3, C2PIX = C2PH * C2PW, C2PS = 5;        // patch 6 x 45 pixels, 5 uint4 (80 bytes) per pixel
+constexpr int C2NB = (H2 + C2R - 1) / C2R;                                                   // blocks per image
+static_assert(C2R * W2 <= 128, "three output rows are one 128-row M tile");
+
+__global__ __launch_bounds__(256) void k_conv2_f16x3(const float* __restrict__ in /*[B][31*41] x 256 bytes: per group of 16 channels 16 f16 h, then 16 f16 m'*/,
+                                                     const uint4* __restrict__ wt3 /*[64 stages = tap * 4 + group][3: Hs, m', h][128 n][2 k-halves] x 8 f16*/,
+                                                     const float* __restrict__ b2, float* __restrict__ out /*[B*1344][128]*/, int batch, int relu) {
     MYSLAM_SIDE_PRIO();
-    constexpr int BM = 128, BN = 128;
-    constexpr int KH = BM + 8;
-    __shared__ uint4 s_a[2][2][2 * KH];
-    __shared__ uint4 s_b[2][3][2 * KH];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    const int m0 = blockIdx.x * BM;
-    const int am = t >> 1, akh = t & 1;                // staging role: row m, k half (8 consecutive k)
-    const int gm = m0 + am;
-    const bool mvalid = gm < Mtotal;
-    const int img = mvalid ? gm / M2 : 0;
-    const int pix = mvalid ? gm - img * M2 : 0;
-    const int oy = pix / W2, ox = pix - oy * W2;
-    const float* inb = in + (size_t)img * HP1 * WP1 * 64;
-
-    float4 ra0 = make_float4(0, 0, 0, 0), ra1 = ra0;
-    uint4 rb0 = make_uint4(0, 0, 0, 0), rb1 = rb0, rb2 = rb0;
-    bool rav = false;
-    auto store_stage = [&](int buf) {
-        const float z = rav ? 1.f : 0.f;
-        uint4 h, m;
-        cv_split2_f16(ra0.x * z, ra0.y * z, h.x, m.x); cv_split2_f16(ra0.z * z, ra0.w * z, h.y, m.y);
-        cv_split2_f16(ra1.x * z, ra1.y * z, h.z, m.z); cv_split2_f16(ra1.z * z, ra1.w * z, h.w, m.w);
-        const int si = akh * KH + am;
-        s_a[buf][0][si] = h; s_a[buf][1][si] = m;
-        s_b[buf][0][si] = rb0; s_b[buf][1][si] = rb1; s_b[buf][2][si] = rb2;
-    };
-
-    f32x16 acc[2][2];
+    __shared__ uint4 s_patch[C2PIX * C2PS];
+    // (a limited grid — blocks walking several work items, as k_describe2 does — was measured for this kernel too, round 4: 1 .. 4 blocks per CU
+    // gave 7.03-7.11 ms per step against 7.03-7.08 unlimited: nothing, not built in)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 31, lk = lane >> 5;
+    const int img = blockIdx.y, row0 = C2R * blockIdx.x;
+    const int nvalid = min(C2R, H2 - row0) * W2;                  // output pixels of this block
+    const uint4* inq = reinterpret_cast<const uint4*>(in + (size_t)img * HP1 * WP1 * 64);        // 16 uint4 per pixel, 4 per channel group
+    // patch staging roles: item = (patch pixel, 16-byte piece); 1080 items, up to 5 per thread
+    constexpr int NIT = (C2PIX * 4 + 255) / 256;
+    int psrc[NIT], pdst[NIT];                                      // source uint4 index inside the image (-1: zero padding), LDS index (-1: no item)
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int u = 0; u < NIT; u++) {
+        const int idx = t + 256 * u, pix = idx >> 2, piece = idx & 3;
+        const int prow = pix / C2PW, pcol = pix - prow * C2PW;
+        const int iy = row0 - 2 + prow, ix = pcol - 2;
+        const bool item = idx < C2PIX * 4, inside = item && iy >= 0 && iy < HP1 && ix >= 0 && ix < WP1;
+        psrc[u] = inside ? (iy * WP1 + ix) * 16 + piece : -1;
+        pdst[u] = item ? pix * C2PS + piece : -1;
+    }
+    uint4 pr[NIT];
+#define C2_PLOAD(CG)                                                                                          \
+    _Pragma("unroll") for (int u = 0; u < NIT; u++) {                                                           \
+        const uint4 v_ = inq[max(psrc[u], 0) + 4 * (CG)];                                                       \
+        const uint32_t k_ = psrc[u] >= 0 ? 0xffffffffu : 0u;                                                    \
+        pr[u] = make_uint4(v_.x & k_, v_.y & k_, v_.z & k_, v_.w & k_);                                         \
+    }
+#define C2_PSTORE()                                                                                           \
+    _Pragma("unroll") for (int u = 0; u < NIT; u++) if (pdst[u] >= 0) s_patch[pdst[u]] = pr[u];
+    // A operand bases of the wave's four 32-row tiles: row m -> output pixel (m / 42, m % 42) -> patch pixel of tap (0, 0)
+    int abase[4];
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+    for (int i = 0; i < 4; i++) {
+        const int m = min(32 * i + lr, C2R * W2 - 1);             // rows past the block's pixels repeat the last one (never stored)
+        const int orow = m / W2, ocol = m - orow * W2;
+        abase[i] = (orow * C2PW + ocol) * C2PS + lk;
+    }
+    const int wbase = (32 * wave + lr) * 2 + lk;                   // this lane's uint4 inside a (stage, plane) block of 256
+    uint4 Bq[4][3];
+#define C2_BLOAD(SET, SPRIME)                                                                                 \
+    {                                                                                                         \
+        const int sp_ = min((SPRIME), 63), S_ = (sp_ & 15) * 4 + (sp_ >> 4);      /* stage index of the weight slab: tap * 4 + group */ \
+        const uint4* w_ = wt3 + (size_t)S_ * 768 + wbase;                                                     \
+        Bq[SET][0] = w_[0]; Bq[SET][1] = w_[256]; Bq[SET][2] = w_[512];                                       \
+    }
+    f32x16 acc[4];
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
 
-    CV2_LOAD_STAGE(0)
-    store_stage(0);
+    C2_PLOAD(0)
+    C2_BLOAD(0, 0)
+    C2_BLOAD(1, 1)
+    C2_PSTORE()
     __syncthreads();
-    constexpr int NSTAGE = K2 / 16;
-    const int lr = lane & 31, lk = lane >> 5;
-    for (int s = 0; s < NSTAGE; s++) {
-        const int buf = s & 1;
-        if (s + 1 < NSTAGE) CV2_LOAD_STAGE(s + 1)
-        cv_f16x8 A[2][2], Bm[2][3];
+    for (int cg = 0; cg < 4; cg++) {
+        C2_PLOAD(min(cg + 1, 3))                                   // next group's patch: in flight under this group's 16 taps (branch-free)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int tap = 0; tap < 16; tap++) {
+            C2_BLOAD((tap + 2) & 3, cg * 16 + tap + 2)             // two K steps ahead (past the end: the last one again)
+            __builtin_amdgcn_sched_barrier(0);                     // ... and issued HERE: left alone, the scheduler sinks every load to its first use (vmcnt(0) in front of each MFMA group)
+            const int toff = ((tap >> 2) * C2PW + (tap & 3)) * C2PS;
+            cv_f16x8 Ah[4], Am[4];
 #pragma unroll
-            for (int p = 0; p < 2; p++) A[i][p] = __builtin_bit_cast(cv_f16x8, s_a[buf][p][lk * KH + wm + 32 * i + lr]);
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int p = 0; p < 3; p++) Bm[j][p] = __builtin_bit_cast(cv_f16x8, s_b[buf][p][lk * KH + wn + 32 * j + lr]);
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                f32x16 c = acc[i][j];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i][1], Bm[j][2], c, 0, 0, 0);        // m'_a h_b
-                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i][0], Bm[j][1], c, 0, 0, 0);        // h_a m'_b
-                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i][0], Bm[j][0], c, 0, 0, 0);        // h_a 2^11 h_b
-                acc[i][j] = c;
+            for (int i = 0; i < 4; i++) {
+                Ah[i] = __builtin_bit_cast(cv_f16x8, s_patch[abase[i] + toff]);
+                Am[i] = __builtin_bit_cast(cv_f16x8, s_patch[abase[i] + toff + 2]);
             }
-        if (s + 1 < NSTAGE) store_stage(buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);                     // all eight operand reads are issued before the first MFMA waits for one
+            const cv_f16x8 B0 = __builtin_bit_cast(cv_f16x8, Bq[tap & 3][0]), B1 = __builtin_bit_cast(cv_f16x8, Bq[tap & 3][1]),
+                           B2 = __builtin_bit_cast(cv_f16x8, Bq[tap & 3][2]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Am[i], B2, acc[i], 0, 0, 0);        // m'_a h_b
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i], B1, acc[i], 0, 0, 0);        // h_a m'_b
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i], B0, acc[i], 0, 0, 0);        // h_a 2^11 h_b
+        }
+        __syncthreads();                                           // every wave has read the patch
+        if (cg < 3) C2_PSTORE()
         __syncthreads();
     }
+#undef C2_PLOAD
+#undef C2_PSTORE
+#undef C2_BLOAD
+    const int n = 32 * wave + lr;
+    const float bias = b2[n];
+    float* ob = out + ((size_t)img * M2 + (size_t)row0 * W2) * CV_BN + n;
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int n = wn + j * 32 + lr;
-        const float bias = b2[n];
+    for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                const float v = acc[i][j][r] * (1.0f / 2048.f) + bias;
-                if (m < Mtotal) out[(size_t)m * CV_BN + n] = relu ? fmaxf(v, 0.f) : v;
-            }
-    }
+        for (int r = 0; r < 16; r++) {
+            const int m = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const float v = acc[i][r] * (1.0f / 2048.f) + bias;
+            if (m < nvalid) ob[(size_t)m * CV_BN] = relu ? fmaxf(v, 0.f) : v;
+        }
 }
 
 #undef CV2_LOAD_STAGE
@@ -628,7 +662,14 @@ __global__ __launch_bounds__(256) void k_conv1_f16x3_pool_lrn(const float* __res
         const float v0 = lane >= 2 ? um2 : 0.f, v1 = lane >= 1 ? um1 : 0.f, v3 = lane <= 62 ? dp1 : 0.f, v4 = lane <= 61 ? dp2 : 0.f;
         float ss = 0.f;
         ss += v0 * v0; ss += v1 * v1; ss += m * m; ss += v3 * v3; ss += v4 * v4;
-        out[((size_t)b * HP1 * WP1 + py * WP1 + px) * 64 + lane] = m * lrn_factor(ss, lp);
+        // the pooled / normalised map leaves as two f16 planes, a = h + m' 2^-11 — what k_conv2_f16x3 multiplies with (it used to split the f32
+        // map itself, every value 16 times)
+        const float y = m * lrn_factor(ss, lp);
+        const _Float16 yh = (_Float16)y, ym = (_Float16)((y - (float)yh) * 2048.f);
+        unsigned short* oh = reinterpret_cast<unsigned short*>(out + ((size_t)b * HP1 * WP1 + py * WP1 + px) * 64);      // 256 bytes per pixel
+        const int oi = (lane >> 4) * 32 + (lane & 15);              // group of 16 channels: its 16 h halves, then its 16 m' halves
+        oh[oi] = __builtin_bit_cast(unsigned short, yh);
+        oh[oi + 16] = __builtin_bit_cast(unsigned short, ym);
     }
 }
 
@@ -876,6 +917,9 @@ struct myslam_lcd {
     FusedPlan fused{};                 // fused.ok: the layer list has the geometry of the fused kernels
     int forceGeneric = 0;              // myslam_lcd_set_option(GENERIC_KERNELS)
     int forceBf16 = 0;                 // myslam_lcd_set_option(CONV2_BF16X6): keep the six-product bf16 kernel
+    // the two f16 matrix-core kernels go together: conv1 hands conv2 its input as two f16 planes (h, m'); the bf16 / f32 pair keeps an f32 map
+    bool f16_family() const { return d_w1h && d_w2h && !forceBf16; }
+    int skipMask = 0;                  // myslam_lcd_set_option(SKIP_KERNELS): TIMING ONLY — bit 0 input, 1 conv1, 2 conv2, 3 pool2, 4 conv3 + norm are not launched
     std::vector<float*> d_wt, d_b;     // per convolution: weights re-laid out as [K*K*IC][OC], bias
     uint4* d_w2s = nullptr;            // fused path: conv2 weights split into three bf16 pieces, [stage][piece][n][k half] x 8 bf16
     uint4* d_w1h = nullptr;            // conv1 weights as MFMA operands of k_conv1_f16x3_pool_lrn ([n tile][k step][2^11 h, m', h][lane]), same condition as d_w2h
@@ -1008,22 +1052,22 @@ static int lcd_forward(myslam_lcd* h, int batch, float* d_out) {
     if (!h->fused.ok || h->forceGeneric) return h->forward_generic(batch, d_out, -1, nullptr);
     hipStream_t s = h->stream;
     const FusedPlan& f = h->fused;
-    {
+    if (!(h->skipMask & 2)) {
         ScopedProf sp(P_CONV1, s);
-        if (h->d_w1h && !h->forceBf16) hipLaunchKernelGGL(k_conv1_f16x3_pool_lrn, dim3(C1T_TX * C1T_TY, batch), dim3(256), 0, s, h->d_in, h->d_w1h, h->d_b[0], f.relu[0], f.lrn[0], h->d_p1);
+        if (h->f16_family()) hipLaunchKernelGGL(k_conv1_f16x3_pool_lrn, dim3(C1T_TX * C1T_TY, batch), dim3(256), 0, s, h->d_in, h->d_w1h, h->d_b[0], f.relu[0], f.lrn[0], h->d_p1);
         else hipLaunchKernelGGL(k_conv1_pool_lrn2, dim3((HT1 * WT1 + 3) / 4, batch), dim3(256), 0, s, h->d_in, h->d_wt[0], h->d_b[0], f.relu[0], f.lrn[0], h->d_p1);
     }
-    {
+    if (!(h->skipMask & 4)) {
         ScopedProf sp(P_CONV2, s);
         const int Mtotal = batch * M2;
-        if (h->d_w2h && !h->forceBf16) hipLaunchKernelGGL(k_conv2_f16x3, dim3((Mtotal + 127) / 128), dim3(256), 0, s, h->d_p1, h->d_w2h, h->d_b[1], h->d_a2, Mtotal, f.relu[1]);
+        if (h->f16_family()) hipLaunchKernelGGL(k_conv2_f16x3, dim3(C2NB, batch), dim3(256), 0, s, h->d_p1, h->d_w2h, h->d_b[1], h->d_a2, batch, f.relu[1]);
         else hipLaunchKernelGGL(k_conv2_bf16x6, dim3((Mtotal + 127) / 128), dim3(256), 0, s, h->d_p1, h->d_w2s, h->d_b[1], h->d_a2, Mtotal, f.relu[1]);
     }
-    {
+    if (!(h->skipMask & 8)) {
         ScopedProf sp(P_POOL2, s);
         hipLaunchKernelGGL(k_pool_lrn128_2x2, dim3((((HP2 + 1) / 2) * ((WP2 + 1) / 2) + 3) / 4, batch), dim3(256), 0, s, h->d_a2, H2, W2, HP2, WP2, f.lrn[1], h->d_p2);
     }
-    {
+    if (!(h->skipMask & 16)) {
         ScopedProf sp(P_CONV3, s);
         hipLaunchKernelGGL(k_conv3_norm, dim3(CV3_NB, batch), dim3(CV3_T), 0, s, h->d_p2, h->d_wt[2], h->d_b[2], d_out, f.relu[2]);
         hipLaunchKernelGGL(k_l2norm_1064, dim3((batch + 3) / 4), dim3(256), 0, s, d_out, batch);
@@ -1036,7 +1080,7 @@ int myslam_lcd::describe(uint8_t* d_imgs, int batch, int r, int c, int step, siz
     if (!d_imgs || batch <= 0 || r <= 0 || c <= 0 || step < c || !d_out) return MYSLAM_ERR_INVALID;
     int rc = ensure_batch(batch, r, c);
     if (rc) return rc;
-    {
+    if (!(skipMask & 1)) {
         ScopedProf sp(P_LCD_PRE, stream);
         if (!blur_in_place) {
             LcdTaps tp;
@@ -1259,13 +1303,14 @@ int myslam_lcd_set_option(myslam_lcd* h, int option, int value) {
     if (!h) return MYSLAM_ERR_INVALID;
     if (option == MYSLAM_LCD_OPT_GENERIC_KERNELS) { h->forceGeneric = value != 0; return MYSLAM_OK; }
     if (option == MYSLAM_LCD_OPT_CONV2_BF16X6) { h->forceBf16 = value != 0; return MYSLAM_OK; }
+    if (option == MYSLAM_LCD_OPT_SKIP_KERNELS) { h->skipMask = value & 31; return MYSLAM_OK; }
     return MYSLAM_ERR_INVALID;
 }
 
 int myslam_lcd_conv2_products(const myslam_lcd* h) {
     if (!h) return MYSLAM_ERR_INVALID;
     if (!h->fused.ok || h->forceGeneric) return 0;
-    return (h->d_w2h && !h->forceBf16) ? 3 : 6;
+    return h->f16_family() ? 3 : 6;
 }
 int myslam_lcd_uses_fused_kernels(const myslam_lcd* h) { return h ? (h->fused.ok && !h->forceGeneric ? 1 : 0) : MYSLAM_ERR_INVALID; }
 
@@ -1354,6 +1399,16 @@ int myslam_lcd_debug_forward(myslam_lcd* h, const float* in, float* out_stage, i
     if (cap_floats < n) return MYSLAM_ERR_CAPACITY;
     MYSLAM_HIP_CHECK(hipMemcpyAsync(out_stage, src, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (fusedNow && stage == 1 && h->f16_family()) {               // the f16 kernels keep this map as two f16 planes: a = h + m' 2^-11
+        std::vector<unsigned short> raw(2 * n);
+        memcpy(raw.data(), out_stage, n * sizeof(float));
+        for (size_t i = 0; i < n; i++) {                               // element i = (pixel, channel c): halves 32 (c / 16) + c % 16 (h) and + 16 (m') of the pixel's 128
+            _Float16 hh, mm;
+            const size_t o = (i >> 6) * 128 + ((i & 63) >> 4) * 32 + (i & 15);
+            memcpy(&hh, &raw[o], 2); memcpy(&mm, &raw[o + 16], 2);
+            out_stage[i] = (float)hh + (float)mm * (1.0f / 2048.f);
+        }
+    }
     return MYSLAM_OK;
 }
 

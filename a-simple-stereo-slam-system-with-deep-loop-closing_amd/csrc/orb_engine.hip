@@ -28,7 +28,7 @@ void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCo
                    int32_t* selCount, int32_t* status, int batch, hipStream_t s);
 void launch_describe(const OrbPlan& P, const uint8_t* pyr, const uint8_t* blur, size_t pyrStride, const uint32_t* selOut,
                      const int32_t* selCount, myslam_keypoint* kps, uint8_t* desc, int32_t* counts, int32_t* status,
-                     int cap, int detectOnly, int batch, uint16_t* order, hipStream_t s);
+                     int cap, int detectOnly, int batch, uint16_t* order, int blocks_per_cu, hipStream_t s);
 void launch_screen(const OrbPlan& P, const uint8_t* pyr, myslam_keypoint* kin, int n, myslam_keypoint* kout, uint8_t* keep,
                    hipStream_t s);
 void launch_calc_desc(const OrbPlan& P, const uint8_t* blur, const myslam_keypoint* kps, int n, uint8_t* desc, hipStream_t s);
@@ -123,6 +123,7 @@ struct myslam_orb {
     int optCopyInput = 0;              // 1 = copy every input image into the pyramid block (default 0: level 0 is read in place, see run_batch)
     int optStopAfter = 0;              // debug: stop a batched call after stage 1 ingest / 2 pyramid / 3 oct-tree / 4 blur (0 = run all)
     int tapsSet = 0, taps[7] = {0};    // myslam_orb_set_gauss_taps: replacement of the sigma = 2 Q8 taps
+    int optSideBlocksPerCu = 0;        // > 0: the descriptor kernel runs as a limited grid of this many blocks per CU (each walks several work items)
     int optBlurMfma = 0;               // 1 = the Gaussian pyramid on the int8 matrix cores (k_blur7_mfma) for every level that can take it
     uint4* d_blurTab = nullptr; bool blurTabValid = false; size_t blurOffI = 0, blurOffH[MAXL] = {0}, blurOffV[MAXL] = {0}; bool blurLvOk[MAXL] = {false}; int blurVconst = 0;
     int ensure_blur_tables();
@@ -465,7 +466,7 @@ int myslam_orb::run_batch(const uint8_t* d_imgs, int batch, int r, int c, int st
     {
         ScopedProf sp(P_DESC, stream);
         launch_describe(P, d_pyr, d_blur, full.pyrBytes, d_sel, d_selCount, d_kps, d_desc, d_counts, stat, cap,
-                        detectOnly ? 1 : 0, batch, d_order, stream);
+                        detectOnly ? 1 : 0, batch, d_order, optSideBlocksPerCu, stream);
     }
     MYSLAM_HIP_CHECK(hipGetLastError());
     return MYSLAM_OK;
@@ -580,6 +581,7 @@ int myslam_orb_set_option(myslam_orb* h, int option, int value) {
         case MYSLAM_ORB_OPT_COPY_INPUT: if (value < 0 || value > 1) return MYSLAM_ERR_INVALID; h->optCopyInput = value; return MYSLAM_OK;
         case MYSLAM_ORB_OPT_STOP_AFTER: if (value < 0 || value > 4) return MYSLAM_ERR_INVALID; h->optStopAfter = value; return MYSLAM_OK;
         case MYSLAM_ORB_OPT_BLUR_MFMA: if (value < 0 || value > 1) return MYSLAM_ERR_INVALID; h->optBlurMfma = value; return MYSLAM_OK;
+        case MYSLAM_ORB_OPT_SIDE_BLOCKS_PER_CU: if (value < 0 || value > 64) return MYSLAM_ERR_INVALID; h->optSideBlocksPerCu = value; return MYSLAM_OK;
     }
     return MYSLAM_ERR_INVALID;
 }

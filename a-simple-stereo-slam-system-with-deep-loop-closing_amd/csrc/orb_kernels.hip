@@ -2052,13 +2052,13 @@ __global__ __launch_bounds__(256) void k_sel_order(OrbPlan P, const uint32_t* __
     for (int i = t; i < n; i += 256) out[atomicAdd(&s_hist[bin_of(sel[i])], 1)] = (uint16_t)i;
 }
 
-__global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
-                                                   size_t pyrStride, const uint32_t* __restrict__ selOut,
-                                                   const int32_t* __restrict__ selCount, myslam_keypoint* __restrict__ kps,
-                                                   uint8_t* __restrict__ desc, int32_t* __restrict__ counts,
-                                                   int32_t* __restrict__ status, int cap, int nchunk, int batch, int detectOnly,
-                                                   const uint16_t* __restrict__ order) {
-    MYSLAM_SIDE_PRIO();
+__device__ __forceinline__ void describe_block(const OrbPlan& P, const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
+                                               size_t pyrStride, const uint32_t* __restrict__ selOut,
+                                               const int32_t* __restrict__ selCount, myslam_keypoint* __restrict__ kps,
+                                               uint8_t* __restrict__ desc, int32_t* __restrict__ counts,
+                                               int32_t* __restrict__ status, int cap, int nchunk, int batch, int detectOnly,
+                                               const uint16_t* __restrict__ order, const int logical_in) {
+    const int logical = __builtin_amdgcn_readfirstlane(logical_in);      // block-uniform: everything derived from it stays on the scalar unit
     // per wave: phase A parks the 32 x 32 patches of four key-points here (4 x 64 pieces of 16 bytes), phase C the 37-row BRIEF window
     __shared__ __attribute__((aligned(16))) uint4 s_b[4][256];
     static_assert(DB_N <= 256, "the BRIEF window must fit the per-wave buffer");
@@ -2070,10 +2070,11 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
     // image read overlapping windows of the same two pyramids.  Logical block ids (image-major) are handed out so that every
     // XCD walks a contiguous range of images (bijective remap, any grid size): without it every XCD pulls every image
     // through its own L2 (measured 3.2 GB instead of ~1.3 GB of HBM reads per 512 images).
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
-    const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-    const int b = logical / nchunk, t = threadIdx.x;
+    // the thread id passes through an opaque asm once per work item: inside the kernel's loop the compiler would otherwise hoist every
+    // lane-dependent invariant (BRIEF pattern coordinates, operand roles: ~75 registers) out of the loop — 124 registers instead of 47
+    int t_ = threadIdx.x;
+    asm volatile("" : "+v"(t_));
+    const int b = logical / nchunk, t = t_;
     if (b >= batch) return;
     if (t < 128) {      // weights of patch row 2 rp + (kq >> 1), columns 16 (kq & 1) .. +15: u (x moment) or v (y moment) inside the circular mask
         const int rp = t >> 3, kq = (t >> 1) & 3, jm = t & 1, row = 2 * rp + (kq >> 1), v = row - HALF_PATCH;
@@ -2262,6 +2263,32 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
 // K6/K7: per-keypoint operators of the loop-closing path (one image, n keypoints; wave per keypoint)
 // ------------------------------------------------------------------------------------------------
 // isFastCorner (ORBextractor.cpp:449-511): > 8 contiguous ring pixels darker / brighter than v -/+ th
+// The kernel: a LIMITED grid of blocks, each walking a contiguous share of the (image, 64-key-point chunk) work items of its XCD.
+// Why limited (round 4): under the pipeline this kernel runs beside the other handle's grid-FAST launch, which is what the step is bound by
+// (VALU issue).  A block here lives ~40 us against ~13 us of a FAST block, so with an unlimited grid every slot a FAST block frees is taken by
+// a long-lived block sooner or later: the latency-bound kernel ends up holding most of the CUs while the VALU-bound one starves (kernel
+// timeline of round 4: FAST made 20 % of its progress in the 2.5 ms the other handle's kernels ran, 80 % in the 1.4 ms after them).  With
+// at most `gridDim.x / 256` blocks per CU the rest of the CU stays FAST's.
+// XCD-aware order: the dispatcher places block i on XCD i % 8, each XCD has a private L2, and the ~32 blocks of one image read overlapping
+// windows of the same two pyramids: every XCD walks a contiguous range of images (measured 3.2 GB -> ~1.3 GB of HBM reads per 512 images).
+__global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
+                                                   size_t pyrStride, const uint32_t* __restrict__ selOut,
+                                                   const int32_t* __restrict__ selCount, myslam_keypoint* __restrict__ kps,
+                                                   uint8_t* __restrict__ desc, int32_t* __restrict__ counts,
+                                                   int32_t* __restrict__ status, int cap, int nchunk, int batch, int detectOnly,
+                                                   const uint16_t* __restrict__ order) {
+    MYSLAM_SIDE_PRIO();
+    const int total = nchunk * batch, nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, j = bid >> 3, per = (nwg + 7 - xcd) >> 3;              // blocks of this XCD: ids xcd, xcd + 8, ...
+    const int tq = total >> 3, tr = total & 7;
+    const int lo = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, n = tq + (xcd < tr ? 1 : 0);      // this XCD's contiguous range
+#pragma nounroll
+    for (int k = j; k < n; k += per) {
+        describe_block(P, pyr, blur, pyrStride, selOut, selCount, kps, desc, counts, status, cap, nchunk, batch, detectOnly, order, lo + k);
+        __syncthreads();                               // the next item reuses the block's LDS
+    }
+}
+
 __device__ __forceinline__ bool is_fast_corner(const uint8_t* __restrict__ img, int pitch, int x, int y, int th) {
     constexpr int RX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
     constexpr int RY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
@@ -2474,6 +2501,8 @@ void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCo
     // to come, e.g. the replay of a captured HIP graph (a memory fault, found with two extractor handles of different budgets).
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // (a grid limit as in launch_describe was measured for this kernel too, round 4: 1 / 2 / 3 blocks per CU gave 7.27 / 7.11 / 7.15 ms per step
+    // against 7.11 unlimited, and the loop itself cost 0.1 ms — not built in)
     if (batch >= OCT_WIDE_BELOW)
         hipLaunchKernelGGL(k_octree<256>, dim3(P.nlevels, batch), dim3(256), lds, s, P, cand, candCount, sortbuf, octTab, selOut, selCount, status, ncmax);
     else
@@ -2482,13 +2511,15 @@ void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCo
 
 void launch_describe(const OrbPlan& P, const uint8_t* pyr, const uint8_t* blur, size_t pyrStride, const uint32_t* selOut,
                      const int32_t* selCount, myslam_keypoint* kps, uint8_t* desc, int32_t* counts, int32_t* status,
-                     int cap, int detectOnly, int batch, uint16_t* order, hipStream_t s) {
+                     int cap, int detectOnly, int batch, uint16_t* order, int blocks_per_cu, hipStream_t s) {
     const int slots = min(cap, P.totalOut);
     const int nchunk = (slots + KD_KPB - 1) / KD_KPB;
     // the tile-order permutation pays when thousands of windows compete for L1 / L2; a handful of images is a few dozen blocks: list order
     const bool tiled = order && !detectOnly && batch >= 8;
     if (tiled) hipLaunchKernelGGL(k_sel_order, dim3(P.nlevels, batch), dim3(256), 0, s, P, selOut, selCount, order, batch);
-    hipLaunchKernelGGL(k_describe2, dim3(nchunk * batch), dim3(256), 0, s, P, pyr, blur, pyrStride, selOut, selCount,
+    const int total = nchunk * batch;
+    const int grid = blocks_per_cu > 0 ? min(total, 256 * blocks_per_cu) : total;       // MYSLAM_ORB_OPT_SIDE_BLOCKS_PER_CU
+    hipLaunchKernelGGL(k_describe2, dim3(grid), dim3(256), 0, s, P, pyr, blur, pyrStride, selOut, selCount,
                        kps, desc, counts, status, cap, nchunk, batch, detectOnly, tiled ? order : nullptr);
 }
 

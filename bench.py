@@ -180,6 +180,11 @@ def parse():
                     help="myslam_orb_set_option(COPY_INPUT): 0 = level 0 read in place (the library's default), 1 = every image copied into the pyramid block")
     ap.add_argument("--fast-mode", type=int, default=-1, choices=[-1, 0, 1],
                     help="myslam_orb_set_option(FAST_MODE): -1 = the FAST kernel picks its path per level (default), 0 = two-phase, 1 = dense")
+    ap.add_argument("--side-blocks-per-cu", type=int, default=-1,
+                    help="myslam_orb_set_option(SIDE_BLOCKS_PER_CU): the descriptor kernel runs as a limited grid of this many blocks per CU, each walking "
+                         "several work items, so that its long-lived blocks do not crowd the other handle's FAST blocks out of the CUs (0 = one block per "
+                         "work item, the library's default; -1 = 2 under the pipelined schedule, else 0)")
+    ap.add_argument("--lcd-skip", type=int, default=0, help="diagnostic, timing only: myslam_lcd_set_option(SKIP_KERNELS) bit mask (1 input, 2 conv1, 4 conv2, 8 pool2, 16 conv3)")
     ap.add_argument("--side-skip", default="", help="diagnostic: comma list of side-chain parts to leave out (lcd, db, ba) — measures what each part costs the step")
     ap.add_argument("--blur-mfma", type=int, default=0, choices=[0, 1],
                     help="myslam_orb_set_option(BLUR_MFMA): 1 = the Gaussian pyramid on the int8 matrix cores (k_blur7_mfma), 0 = register-strip kernel")
@@ -188,6 +193,8 @@ def parse():
     args = ap.parse_args()
     if args.pipeline < 0:
         args.pipeline = 1 if (args.streams == 2 and args.orb_split != 1) else 0
+    if args.side_blocks_per_cu < 0:
+        args.side_blocks_per_cu = 2 if args.pipeline else 0
     if args.orb_split == 0:
         args.orb_split = 2 if (args.streams == 2 or args.pipeline) else 1
     if args.pipeline:
@@ -425,6 +432,7 @@ def main():
         e.set_option(e.OPT_FAST_MODE, args.fast_mode)
         e.set_option(e.OPT_COPY_INPUT, args.orb_copy_input)
         e.set_option(e.OPT_BLUR_MFMA, args.blur_mfma)
+        e.set_option(e.OPT_SIDE_BLOCKS_PER_CU, args.side_blocks_per_cu)
     NB = 2 if args.pipeline else 1          # pipeline: extractor outputs are double-buffered (step k+1 extracts while step k is matched)
     d_kps_b = [torch.zeros(2 * P * cap * 28, dtype=torch.uint8, device=dev) for _ in range(NB)]
     d_desc_b = [torch.zeros(2 * P * cap * 32, dtype=torch.uint8, device=dev) for _ in range(NB)]
@@ -442,6 +450,8 @@ def main():
     db_np = None
     if use_lcd:
         lcd = api.DeepLCD(synth.calc_weights(), stream=stream2)
+        if args.lcd_skip:
+            lcd.set_option(lcd.OPT_SKIP_KERNELS, args.lcd_skip)
         d_descr = torch.zeros(P, 1064, device=dev)
         db_np = synth.lcd_database(n_db_local, seed=0xDB + rank)
         D = api.LoopDatabase(n_db_local, stream=stream2)

@@ -91,12 +91,18 @@ int myslam_orb_set_fast_gate(myslam_orb* h, void* hip_event);
  *   STOP_AFTER       debug: a batched call returns after stage 1 ingest / 2 pyramid / 3 oct-tree / 4 blur (0 = complete call)
  *   BLUR_MFMA        1 = the 7 x 7 Gaussian pyramid runs on the int8 matrix cores (two banded Toeplitz products per 32 x 32 tile, bit-identical
  *                    to the register-strip kernel; levels narrower than 64 columns or tap tables with a folded coefficient above 127 keep
- *                    the strip kernel), 0 = register-strip kernel on the vector units.  The step is VALU-issue bound: see DESIGN.md section 6 */
+ *                    the strip kernel), 0 = register-strip kernel on the vector units.  The step is VALU-issue bound: see DESIGN.md section 6
+ *   SIDE_BLOCKS_PER_CU  n > 0: the descriptor kernel of a batched call is launched as a LIMITED grid of 256 n blocks, each walking several
+ *                    (image, 64-key-point chunk) work items.  For callers that run two handles beside each other: a descriptor block lives
+ *                    three times as long as a FAST block, so an unlimited grid gradually takes the CUs from the other handle's FAST launch —
+ *                    the VALU-bound kernel starves under the latency-bound one (measured: 7.12 -> 7.02 ms per 512-pair step with n = 2).
+ *                    0 (default) = one block per work item */
 #define MYSLAM_ORB_OPT_FAST_MODE 1
 #define MYSLAM_ORB_OPT_INTERNAL_STREAM 2
 #define MYSLAM_ORB_OPT_STOP_AFTER 3
 #define MYSLAM_ORB_OPT_COPY_INPUT 4
 #define MYSLAM_ORB_OPT_BLUR_MFMA 5
+#define MYSLAM_ORB_OPT_SIDE_BLOCKS_PER_CU 6
 int myslam_orb_set_option(myslam_orb* h, int option, int value);
 /* The 7 x 7 sigma = 2 Gaussian before rBRIEF (ORBextractor.cpp:966, :1197) runs in OpenCV's 8-bit fixed-point form; how OpenCV 3.4.8
  * rounds the taps to Q8 could not be checked in the build environment (parity unpinned).  Default
@@ -242,6 +248,8 @@ int myslam_lcd_conv2_products(const myslam_lcd* h);
 #define MYSLAM_LCD_OPT_CONV2_BF16X6 2          /* value != 0: conv2 of the fused path on the six-product bf16 kernel and conv1 on its f32 vector kernel even when
                                                 * the model's ranges allow the three-product f16 matrix-core kernels (all reach f32-level accuracy; tests and
                                                 * tools/gpu_fuzz_lcd.py compare the two families) */
+#define MYSLAM_LCD_OPT_SKIP_KERNELS 3          /* DIAGNOSIS, timing only (results are garbage): bit mask of fused-path kernels that are not launched —
+                                                * 1 input, 2 conv1, 4 conv2, 8 pool2, 16 conv3 + norm: what each costs a step that runs beside the extractor */
 int myslam_lcd_set_option(myslam_lcd* h, int option, int value);
 int myslam_lcd_destroy(myslam_lcd* h);
 int myslam_lcd_set_stream(myslam_lcd* h, void* hip_stream);

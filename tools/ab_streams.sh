@@ -2,13 +2,5 @@
 run() { tag=$1; shift; timeout 600 python bench.py --no-cpu-baseline --stream-input 0 --parity-frames 0 --no-extra-passes --graph 0 "$@" > gpurun_out/ab_$tag.json 2> gpurun_out/ab_$tag.err; python -c "
 import json; d=json.load(open('gpurun_out/ab_$tag.json')); print('$tag', round(d['value']), round(d['ms_per_step'],3), 'host', round(d['host_launch_ms_per_step'],3))" || tail -3 gpurun_out/ab_$tag.err; }
 for rep in 1 2; do
-run full
-run skip_all --side-skip lcd,db,ba
-run skip_lcd --side-skip lcd
-run skip_db --side-skip db
-run skip_ba --side-skip ba
-run only_lcd --side-skip db,ba
-run only_db --side-skip lcd,ba
-run only_ba --side-skip lcd,db
+for l in 0 1 2 3 4; do run d2_l$l --side-blocks-per-cu 2 --lcd-blocks-per-cu $l; done
 done
-rocm-smi --showclocks 2>/dev/null | head -20
