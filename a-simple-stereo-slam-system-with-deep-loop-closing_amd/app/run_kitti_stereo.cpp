@@ -1,0 +1,103 @@
+// run_kitti_stereo — BASELINE configs[0]'s entry point as a compiled program: the reference's
+//     run_kitti_stereo <config.yaml> <sequence dir>                                              (app/run_kitti_stereo.cpp:20-111)
+// with the per-frame dense path running through libmyslam_hip.so.  Plain C++17 over the C ABI: no OpenCV, no Eigen, no g2o, no Caffe.
+//
+//   run_kitti_stereo config/stereo/gray/KITTI00-02.yaml /data/kitti/sequences/00 [--frames 200] [--out result]
+//                    [--calc-prototxt calc_model/deploy.prototxt --calc-model calc_model/calc.caffemodel | --calc-weights file.calcw]
+//                    [--kf-every N] [--frontend-wins-race] [--correct-threshold X] [--frame-poses]
+//
+// Reads <sequence>/times.txt and image_0 / image_1/%06d.png (LoadImages + cv::imread(…, IMREAD_GRAYSCALE): host/myslam_io.hpp,
+// host/myslam_png.hpp), tracks every frame through host/myslam_system.hpp (Frontend / Backend / LoopClosing / Map as one sequential
+// schedule), writes <out>/trajectory.txt and <out>/loop_edges.txt in the reference's format (src/system.cpp:153-224).  The CALC model
+// defaults to the reference's calc_model/ files relative to the working directory (include/myslam/deeplcd.h:33).
+// Built by build.py (g++, links libmyslam_hip.so); tests/test_gpu_runner.py runs it on a rendered 200-frame KITTI-layout sequence and
+// compares its trajectory with the Python chain's.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+
+#include "../host/myslam_io.hpp"
+#include "../host/myslam_png.hpp"
+#include "../host/myslam_system.hpp"
+
+static std::shared_ptr<myslam::Image> imread_gray(const std::string& path) {
+    auto im = std::make_shared<myslam::Image>();
+    if (!myslam::io::ReadPngGray(path, im->px, im->rows, im->cols)) return nullptr;
+    return im;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) {
+        std::fprintf(stderr, "Usage: %s path_to_config path_to_sequence [--frames N] [--out dir] [--calc-prototxt P --calc-model M | --calc-weights F] "
+                             "[--kf-every N] [--frontend-wins-race] [--correct-threshold X] [--frame-poses]\n", argv[0]);
+        return 1;
+    }
+    const std::string configPath = argv[1], sequence = argv[2];
+    std::string out = "result", proto = "calc_model/deploy.prototxt", model = "calc_model/calc.caffemodel", weights;
+    int frames = 0; bool framePoses = false;
+    myslam::SystemConfig sc;
+    for (int i = 3; i < argc; i++) {
+        const std::string a = argv[i];
+        auto next = [&]() -> const char* { if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", a.c_str()); std::exit(1); } return argv[++i]; };
+        if (a == "--frames") frames = std::atoi(next());
+        else if (a == "--out") out = next();
+        else if (a == "--calc-prototxt") proto = next();
+        else if (a == "--calc-model") model = next();
+        else if (a == "--calc-weights") weights = next();
+        else if (a == "--kf-every") sc.kfEvery = std::atoi(next());
+        else if (a == "--frontend-wins-race") sc.lcdBlurReachesTracker = false;
+        else if (a == "--correct-threshold") sc.correctThreshold = std::atof(next());
+        else if (a == "--frame-poses") framePoses = true;
+        else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
+    }
+    myslam::io::Config cfg;
+    if (!cfg.SetParameterFile(configPath)) { std::fprintf(stderr, "parameter file %s does not exist.\n", configPath.c_str()); return 1; }
+    sc.Override(cfg);
+    const myslam::StereoCamera cam = myslam::StereoCamera::FromConfig(cfg);
+
+    std::vector<std::string> left, right; std::vector<double> ts;
+    const int listed = myslam::io::LoadImages(sequence, left, right, ts);
+    const int n = frames <= 0 ? listed : std::min(frames, listed);
+    if (n < 2) { std::fprintf(stderr, "%s: times.txt lists %d frames\n", sequence.c_str(), listed); return 1; }
+
+    try {
+        std::unique_ptr<myslam::DeepLCD> lcd(weights.empty() ? new myslam::DeepLCD(proto, model) : new myslam::DeepLCD(weights));
+        myslam::StereoSystem slam(cam, sc, std::move(lcd));
+        double tRead = 0.0;
+        int done = 0, rows = 0, cols = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < n; i++) {
+            const auto r0 = std::chrono::steady_clock::now();
+            auto L = imread_gray(left[i]), R = imread_gray(right[i]);      // cv::imread per step, app/run_kitti_stereo.cpp:66-67
+            tRead += std::chrono::duration<double>(std::chrono::steady_clock::now() - r0).count();
+            if (!L || !R) { std::fprintf(stderr, "Failed to load image at: %s\n", left[i].c_str()); return 1; }
+            rows = L->rows; cols = L->cols;
+            if (!slam.GrabStereoImage(std::move(L), std::move(R), ts[i])) {
+                std::printf("System failed, now quited (frame %d: tracking LOST)\n", i);            // app/run_kitti_stereo.cpp:83-86
+                break;
+            }
+            done++;
+        }
+        const double tRun = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() - tRead;
+        std::filesystem::create_directories(out);
+        slam.Save(out);
+        if (framePoses) {
+            std::ofstream f(out + "/frame_poses_cw.txt");
+            f.precision(17);
+            for (const auto& p : slam.framePoses) { for (int k = 0; k < 7; k++) f << p.v[k] << (k == 6 ? "\n" : " "); }
+            std::ofstream g(out + "/key_frame_frames.txt");
+            for (unsigned long id : slam.keyFrameFrames) g << id << "\n";
+        }
+        std::printf("%d frames (%dx%d), %zu key-frames, %zu map points, %zu loops; read %.1f s, tracked + mapped in %.1f s = %.1f frames/s "
+                    "(compiled host, one call per operator and frame; %ld pose-only, %ld local-BA, %ld DeepLCD, %ld loop queries); wrote %s/trajectory.txt, loop_edges.txt\n",
+                    done, cols, rows, slam.NumKeyFrames(), slam.NumMapPoints(), slam.NumLoops(), tRead, tRun, done / std::max(tRun, 1e-9),
+                    slam.stats.poseOnly, slam.stats.ba, slam.stats.lcd, slam.stats.detectLoop, out.c_str());
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "run_kitti_stereo: %s\n", e.what());
+        return 2;
+    }
+    return 0;
+}

@@ -1,4 +1,5 @@
-"""Builds libmyslam_hip.so (gfx950) in-tree with hipcc.  No torch, no cmake: plain hipcc invocations.
+"""Builds libmyslam_hip.so (gfx950) in-tree with hipcc, and bin/run_kitti_stereo (the compiled host program of BASELINE configs[0],
+app/run_kitti_stereo.cpp: plain C++ over the C ABI) with g++.  No torch, no cmake: plain compiler invocations.
 
     python build.py            # incremental
     python build.py --force
@@ -12,6 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmyslam_hip.so")
 OBJDIR = os.path.join(HERE, "build")
+APP_SRC = os.path.join(HERE, "app", "run_kitti_stereo.cpp")
+APP_OUT = os.path.join(HERE, "bin", "run_kitti_stereo")
+CXX = os.environ.get("CXX", "g++")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
@@ -61,7 +65,7 @@ def build(force=False, verbose=False):
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
-            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+            raise RuntimeError("compiler failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
         return r.stderr
 
     with ThreadPoolExecutor(max_workers=4) as ex:
@@ -71,7 +75,21 @@ def build(force=False, verbose=False):
     objs = [os.path.join(OBJDIR, src.replace(".hip", ".o")) for src in UNITS]
     if force or jobs or _stale(OUT, objs):
         run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT] + objs)
+    build_app(force or _stale(APP_OUT, [APP_SRC, OUT] + deps), verbose)
     return OUT
+
+
+def build_app(force=False, verbose=False):
+    """bin/run_kitti_stereo: host C++ only (g++), links the library next to it"""
+    if force or not os.path.exists(APP_OUT):
+        os.makedirs(os.path.dirname(APP_OUT), exist_ok=True)
+        cmd = [CXX, "-O2", "-std=c++17", "-ffp-contract=off", "-Wall", APP_SRC, "-o", APP_OUT, "-L" + HERE, "-lmyslam_hip", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("compiler failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    return APP_OUT
 
 
 if __name__ == "__main__":

@@ -40,15 +40,36 @@ DEFAULT_CONFIG = {"numFeatures.initGood": 100, "numFeatures.trackingGood": 50, "
 
 
 # ---- SE3 as (qx qy qz qw tx ty tz), Tcw --------------------------------------------------------------------------------------------
+# Every sum below is written out in the order host/myslam_system.hpp (the compiled twin of this file) uses — no BLAS call, no reduction
+# whose order is numpy's choice: the pose-only optimiser stops on an iteration budget, so a last-bit difference in its start is a 1e-9
+# difference in its result and a different LK start a few frames later.  With the order pinned the two hosts agree bit for bit
+# (tests/test_gpu_runner.py).
+def mm(A, B):
+    """A @ B for the small matrices of this file: sum over k in ascending order, plain multiplies and adds"""
+    C = A[:, 0:1] * B[0:1, :]
+    for k in range(1, A.shape[1]):
+        C = C + A[:, k:k + 1] * B[k:k + 1, :]
+    return C
+
+
+def mv(R, v):
+    """R @ v, columns in ascending order"""
+    r = R[:, 0] * v[0]
+    for k in range(1, R.shape[1]):
+        r = r + R[:, k] * v[k]
+    return r
+
+
 def q_to_R(q):
-    x, y, z, w = q / np.linalg.norm(q)
+    n = np.sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3])
+    x, y, z, w = q[0] / n, q[1] / n, q[2] / n, q[3] / n
     return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
 
 
 def R_to_q(R):
-    t = np.trace(R)
+    t = R[0, 0] + R[1, 1] + R[2, 2]
     if t > 0:
         s = np.sqrt(t + 1.0) * 2; q = [(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s]
     elif R[0, 0] > R[1, 1] and R[0, 0] > R[2, 2]:
@@ -71,7 +92,7 @@ def p7_of(T):
 
 
 def T_inv(T):
-    Ti = np.eye(4); Ti[:3, :3] = T[:3, :3].T; Ti[:3, 3] = -T[:3, :3].T @ T[:3, 3]
+    Ti = np.eye(4); Ti[:3, :3] = T[:3, :3].T; Ti[:3, 3] = mv(-T[:3, :3].T, T[:3, 3])
     return Ti
 
 
@@ -79,7 +100,7 @@ def se3_log_norm(T):
     """|Sophus::SE3d::log()| (the 6-vector (upsilon, omega)): Map::RemoveOldActiveKeyframe's distance (map.cpp:88), the `error > 1` test of
     ComputeCorrectPose (loopclosing.cpp:283)"""
     R, t = T[:3, :3], T[:3, 3]
-    c = min(1.0, max(-1.0, (np.trace(R) - 1.0) / 2.0))
+    c = min(1.0, max(-1.0, (R[0, 0] + R[1, 1] + R[2, 2] - 1.0) / 2.0))
     th = np.arccos(c)
     w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
     if th < 1e-10:
@@ -89,19 +110,21 @@ def se3_log_norm(T):
         ax = np.sqrt(np.maximum(np.diag(A), 0.0))
         k = int(np.argmax(ax))
         ax = A[:, k] / max(ax[k], 1e-300)
-        ax /= np.linalg.norm(ax)
-        if np.dot(ax, w) < 0:
+        ax = ax / np.sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2])
+        if ax[0] * w[0] + ax[1] * w[1] + ax[2] * w[2] < 0:
             ax = -ax
         om = th * ax
     else:
         om = th / (2.0 * np.sin(th)) * w
     Om = np.array([[0, -om[2], om[1]], [om[2], 0, -om[0]], [-om[1], om[0], 0]])
     if th < 1e-10:
-        Vinv = np.eye(3) - 0.5 * Om + Om @ Om / 12.0
+        coef = 1.0 / 12.0
     else:
         h = 0.5 * th
-        Vinv = np.eye(3) - 0.5 * Om + (1.0 - th * np.cos(h) / (2.0 * np.sin(h))) / (th * th) * (Om @ Om)
-    return float(np.sqrt(np.sum((Vinv @ t) ** 2) + np.sum(om ** 2)))
+        coef = (1.0 - th * np.cos(h) / (2.0 * np.sin(h))) / (th * th)
+    Vinv = np.eye(3) - 0.5 * Om + coef * mm(Om, Om)
+    u = mv(Vinv, t)
+    return float(np.sqrt((u[0] * u[0] + u[1] * u[1] + u[2] * u[2]) + (om[0] * om[0] + om[1] * om[1] + om[2] * om[2])))
 
 
 IDENT = np.array([0, 0, 0, 1, 0, 0, 0], float)
@@ -274,7 +297,7 @@ class Chain:
 
     # ---------------------------------------------------------------- cameras (camera.cpp:7-45; left extrinsics = identity, right = (-baseline, 0, 0))
     def world2pixel(self, pw, Tcw, right=False):
-        pc = Tcw[:3, :3] @ pw + Tcw[:3, 3]
+        pc = mv(Tcw[:3, :3], pw) + Tcw[:3, 3]
         if right:
             pc = pc + np.array([-self.K["baseline"], 0.0, 0.0])
         return np.array([self.K["fx"] * pc[0] / pc[2] + self.K["cx"], self.K["fy"] * pc[1] / pc[2] + self.K["cy"]])
@@ -292,7 +315,7 @@ class Chain:
         else:
             return False
         if self.ref_kf is not None:
-            self.poses.append(p7_of(self.cur.rel @ T_of(self.ref_kf.pose)))
+            self.poses.append(p7_of(mm(self.cur.rel, T_of(self.ref_kf.pose))))
         else:
             self.poses.append(IDENT.copy())
         self.last = self.cur
@@ -315,7 +338,7 @@ class Chain:
 
     def track(self):                                # frontend.cpp:85-124
         cur, last = self.cur, self.last
-        cur.rel = self.rel_motion @ last.rel
+        cur.rel = mm(self.rel_motion, last.rel)
         self.track_last_frame()
         n_inl = self.estimate_current_pose()
         if n_inl > self.n_good:
@@ -324,7 +347,7 @@ class Chain:
             self.status = TRACKING_BAD
         else:
             self.status = LOST
-        self.rel_motion = cur.rel @ T_inv(last.rel)
+        self.rel_motion = mm(cur.rel, T_inv(last.rel))
         insert = self.status == TRACKING_BAD if self.kf_every <= 0 else (self.status != LOST and cur.id % self.kf_every == 0)
         if insert:
             self.detect_features()
@@ -334,7 +357,7 @@ class Chain:
 
     def track_last_frame(self):                     # frontend.cpp:129-172
         cur, last = self.cur, self.last
-        Tcw = cur.rel @ T_of(self.ref_kf.pose)
+        Tcw = mm(cur.rel, T_of(self.ref_kf.pose))
         p0 = np.zeros((len(last.feats), 2), np.float32); p1 = np.zeros((len(last.feats), 2), np.float32)
         for i, f in enumerate(last.feats):
             p0[i] = (f.x, f.y)
@@ -358,10 +381,10 @@ class Chain:
         feats = [f for f in cur.feats if f.live() is not None and not f.mp.outlier]
         p3 = np.array([f.mp.pos for f in feats], float).reshape(-1, 3)
         obs = np.array([[f.x, f.y] for f in feats], np.float64).reshape(-1, 2)
-        pose0 = p7_of(cur.rel @ T_of(self.ref_kf.pose))
+        pose0 = p7_of(mm(cur.rel, T_of(self.ref_kf.pose)))
         pose, outl, n_inl = self.be.pose_only(pose0, p3, obs, self.Kt)
         self.rec("pose_only", pose, outl, np.array([n_inl]))
-        cur.rel = T_of(pose) @ T_inv(T_of(self.ref_kf.pose))
+        cur.rel = mm(T_of(pose), T_inv(T_of(self.ref_kf.pose)))
         for f, o in zip(feats, outl):
             if o:
                 mp = f.live()
@@ -388,7 +411,7 @@ class Chain:
 
     def find_features_in_right(self):               # frontend.cpp:335-379
         cur = self.cur
-        Tcw = cur.rel @ T_of(self.ref_kf.pose) if self.ref_kf is not None else np.eye(4)
+        Tcw = mm(cur.rel, T_of(self.ref_kf.pose)) if self.ref_kf is not None else np.eye(4)
         n = len(cur.feats)
         p0 = np.zeros((n, 2), np.float32); p1 = np.zeros((n, 2), np.float32)
         for i, f in enumerate(cur.feats):
@@ -430,13 +453,13 @@ class Chain:
 
     def triangulate_new_points(self):               # frontend.cpp:451-488
         cur = self.cur
-        Twc = T_inv(cur.rel @ T_of(self.ref_kf.pose))
+        Twc = T_inv(mm(cur.rel, T_of(self.ref_kf.pose)))
         idx = [i for i, f in enumerate(cur.feats) if f.live() is None and cur.right[i] is not None]      # !expired() -> skip
         if idx:
             xyz, ok = self._triangulate(idx)
             for j, i in enumerate(idx):
                 if ok[j]:
-                    self._new_map_point(Twc[:3, :3] @ xyz[j] + Twc[:3, 3], cur.feats[i])
+                    self._new_map_point(mv(Twc[:3, :3], xyz[j]) + Twc[:3, 3], cur.feats[i])
 
     def insert_keyframe(self):                      # frontend.cpp:424-447 + KeyFrame::CreateKF (keyframe.cpp:29-44)
         cur = self.cur
@@ -450,7 +473,7 @@ class Chain:
         if self.status == INITING:
             kf.pose = IDENT.copy()
         else:
-            kf.pose = p7_of(cur.rel @ T_of(self.ref_kf.pose))
+            kf.pose = p7_of(mm(cur.rel, T_of(self.ref_kf.pose)))
             kf.last_kf = self.ref_kf
             kf.rel_to_last = p7_of(cur.rel)
         self.ref_kf = kf
@@ -486,7 +509,7 @@ class Chain:
             kf = self.active_kfs[kid]
             if kf is cur:
                 continue
-            dis = se3_log_norm(T_of(kf.pose) @ Twc)
+            dis = se3_log_norm(mm(T_of(kf.pose), Twc))
             if dis > max_dis:
                 max_dis, max_id = dis, kid
             elif dis < min_dis:
@@ -634,9 +657,9 @@ class Chain:
         valid = [v for v, o in zip(valid, outl) if not o]
         if len(valid) < 10:
             return False
-        self.need_correct = se3_log_norm(T_of(kf.pose) @ T_inv(T_of(pose2))) > self.correct_threshold
+        self.need_correct = se3_log_norm(mm(T_of(kf.pose), T_inv(T_of(pose2)))) > self.correct_threshold
         kf.loop_kf = loop
-        kf.rel_to_loop = p7_of(T_of(pose2) @ T_inv(T_of(loop.pose)))
+        kf.rel_to_loop = p7_of(mm(T_of(pose2), T_inv(T_of(loop.pose))))
         self.last_closed_kf = kf
         self.loops.append((kf, loop))
         self._corrected, self._valid = pose2, valid

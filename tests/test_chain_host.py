@@ -85,3 +85,39 @@ def test_committed_trajectory_fixture_is_what_its_script_writes(pkg, synth, orac
         assert abs(row[1] - k.ts) < 1e-6 and np.allclose(row[2:5], Twc[:3, 3], atol=2e-6)
     rmse, worst = kitti_layout.ate(chain, synth, c.poses, C, yaw)
     assert rmse < 0.6                               # 0.445 m over a 120 m path
+
+
+def test_compiled_host_helpers_match_chain_py(pkg, tmp_path):
+    """host/myslam_system.hpp (the C++ twin of chain.py behind bin/run_kitti_stereo): its SE3 helpers against chain.py's numpy ones, and the
+    compiled runner builds, links the library and reports usage / a missing config like the reference's main()."""
+    import subprocess
+    chain = pkg.chain
+    exe = str(tmp_path / "system_se3_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", os.path.join(ROOT, "tests", "cpp", "system_se3_test.cpp"), "-o", exe, "-I" + os.path.join(ROOT, "include")])
+    rng = np.random.default_rng(5)
+    cases = []
+    for i in range(200):
+        q = rng.normal(size=(2, 4)); t = rng.normal(size=(2, 3)) * rng.choice([1e-3, 1.0, 50.0])
+        if i % 10 == 0:
+            q[1] = q[0]; t[1] = t[0] + rng.normal(size=3) * 1e-12          # log of (nearly) the identity: the small-angle branch
+        if i % 10 == 1:
+            ax = rng.normal(size=3); ax /= np.linalg.norm(ax); ang = np.pi - 1e-8 * (i % 3)      # relative rotation by (nearly) pi
+            A = chain.T_of(np.concatenate([q[0] / np.linalg.norm(q[0]), t[0]]))
+            Rel = np.eye(4); Rel[:3, :3] = chain.q_to_R(np.concatenate([np.sin(ang / 2) * ax, [np.cos(ang / 2)]]))
+            p = chain.p7_of(chain.T_inv(Rel) @ A); q[1] = p[:4]; t[1] = p[4:]
+        cases.append((np.concatenate([q[0], t[0]]), np.concatenate([q[1], t[1]])))
+    text = "".join(" ".join(repr(float(x)) for x in a) + "\n" + " ".join(repr(float(x)) for x in b) + "\n" for a, b in cases)
+    r = subprocess.run([exe], input=text, capture_output=True, text=True, timeout=60)
+    rows = np.array([[float(x) for x in l.split()] for l in r.stdout.strip().split("\n")])
+    assert rows.shape == (len(cases), 8)
+    for (a, b), row in zip(cases, rows):
+        Cm = chain.mm(chain.T_of(a), chain.T_inv(chain.T_of(b)))
+        # products, inverses and the quaternion extraction are written in one summation order on both sides: identical bits
+        assert np.array_equal(row[:7], chain.p7_of(Cm)), (row, chain.p7_of(Cm))
+        ref = chain.se3_log_norm(Cm)                 # acos / sin / cos come from two maths libraries: rounding, not bits
+        assert abs(row[7] - ref) <= 1e-9 * max(1.0, ref), (row[7], ref)
+    app = pkg._build.build_app()
+    u = subprocess.run([app], capture_output=True, text=True)
+    assert u.returncode == 1 and "path_to_config path_to_sequence" in u.stderr
+    m = subprocess.run([app, str(tmp_path / "missing.yaml"), str(tmp_path)], capture_output=True, text=True)
+    assert m.returncode == 1 and "does not exist" in m.stderr

@@ -2,6 +2,8 @@
 image_0 / image_1/%06d.png, a config in the reference's YAML form): plumbing from files to trajectory.txt.
   * 200 frames at 1241 x 376 with the KITTI00-02 intrinsics and the reference's YAML values, key-frames by the reference's rule: the
     runner end to end, the HIP chain against the oracle chain entry by entry, the trajectory against the committed fixture;
+  * the same 200 frames through the COMPILED runner (app/run_kitti_stereo.cpp over host/myslam_system.hpp, plain C++ above the C ABI):
+    the same key-frames, frame poses and trajectory file as the Python chain;
   * 60 frames at 720 x 240 with a key-frame every 6th frame (`--kf-every`).
 (The KITTI data itself is not available here: configs[0] proper stays untested.)"""
 import os
@@ -31,14 +33,22 @@ def _rows(path):
     return np.array([[float(x) for x in l.split()] for l in open(path).read().strip().split("\n")])
 
 
-def test_runner_200_frames_at_kitti_resolution(api, oracle, synth, pkg, tmp_path):
-    chain = pkg.chain
+@pytest.fixture(scope="module")
+def kitti_seq(synth, tmp_path_factory):
+    """the rendered 200-frame sequence in KITTI layout + the reference's YAML, written once for the tests of this module"""
+    d = tmp_path_factory.mktemp("kitti")
     frames, C, yaw = kitti_layout.render(synth)
+    seq = d / "sequences" / "00"
+    ts = kitti_layout.write(str(seq), frames, png_files)
+    cfg_path = d / "KITTI00-02.yaml"; cfg_path.write_text(kitti_layout.KITTI00_02_YAML)
+    return dict(frames=frames, C=C, yaw=yaw, seq=seq, ts=ts, cfg_path=cfg_path)
+
+
+def test_runner_200_frames_at_kitti_resolution(api, oracle, synth, pkg, tmp_path, kitti_seq):
+    chain = pkg.chain
+    frames, C, yaw, seq, ts, cfg_path = (kitti_seq[k] for k in ("frames", "C", "yaw", "seq", "ts", "cfg_path"))
     n = len(frames)
     assert n == 200 and frames[0][0].shape == (376, 1241)
-    seq = tmp_path / "sequences" / "00"
-    ts = kitti_layout.write(str(seq), frames, png_files)
-    cfg_path = tmp_path / "KITTI00-02.yaml"; cfg_path.write_text(kitti_layout.KITTI00_02_YAML)
     out = tmp_path / "result"
     stdout = _run(cfg_path, seq, n, out)
     assert "200 frames (1241x376)" in stdout and "frames/s" in stdout
@@ -80,6 +90,76 @@ def test_runner_200_frames_at_kitti_resolution(api, oracle, synth, pkg, tmp_path
           f"{({k: float(f'{v:.2e}') for k, v in chk.dev.items()})}; free run HIP vs oracle chain: {rep}; {a.stats['lk_init_from_projection']} LK starts from a "
           f"re-projection; trajectory.txt vs the committed fixture: max deviation {dev_gold:.3e}; ATE rmse {rmse:.3f} m (oracle chain {rmse_o:.3f} m), worst {worst:.3f} m over a {path_len:.0f} m path; {stdout.strip().splitlines()[-1]}")
     assert rmse < 1.5 and rmse_o < 1.5 and abs(rmse - rmse_o) < 0.25
+
+
+def test_compiled_runner_equals_the_python_chain(api, synth, pkg, tmp_path, kitti_seq):
+    """bin/run_kitti_stereo (C++17 over the C ABI: host/myslam_system.hpp is Frontend / Backend / LoopClosing / Map, the operators are the
+    facade's) on the 200-frame sequence: the same operator calls in the same order as chain.py, so the same key-frames, the same pose of
+    every frame bit for bit and the same trajectory.txt."""
+    import numpy as np
+    chain = pkg.chain
+    exe = pkg._build.build_app()
+    frames, seq, ts, cfg_path = (kitti_seq[k] for k in ("frames", "seq", "ts", "cfg_path"))
+    w = np.ascontiguousarray(synth.calc_weights_handcrafted(), np.float32).ravel()
+    wfile = tmp_path / "handcrafted.calcw"
+    with open(wfile, "wb") as f:
+        f.write(b"CALCW1\0\0"); f.write(np.uint64(w.size).tobytes()); f.write(w.tobytes())
+    out = tmp_path / "cpp"
+    r = subprocess.run([exe, str(cfg_path), str(seq), "--frames", str(len(frames)), "--out", str(out), "--calc-weights", str(wfile), "--frame-poses"],
+                       capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "200 frames (1241x376)" in r.stdout
+    cfg = kitti_layout.parse_yaml(kitti_layout.KITTI00_02_YAML)
+    a = chain.Chain(chain.HipBackend(api, w, cfg), pkg.api, chain.camera_from_config(cfg), frames, cfg=cfg, timestamps=ts, log=False).run()
+    a.save(str(tmp_path / "py"))
+    kf_frames = [int(x) for x in open(out / "key_frame_frames.txt").read().split()]
+    assert kf_frames == a.kf_frames
+    poses = _rows(out / "frame_poses_cw.txt")
+    ref = np.stack(a.poses)
+    assert poses.shape == ref.shape
+    # both hosts write every sum in one order (chain.py's mm / mv, the header's loops) and call the same operators on the same bytes: the pose
+    # of every frame is the same double (%.17g round-trips), the files are the same text
+    assert np.array_equal(poses, ref), float(np.abs(poses - ref).max())
+    assert open(out / "trajectory.txt").read() == open(tmp_path / "py" / "trajectory.txt").read()
+    assert open(out / "loop_edges.txt").read() == ""
+    print(f"compiled runner: {r.stdout.strip().splitlines()[-1]}; key-frames at frames {kf_frames}; the pose of every frame and trajectory.txt "
+          f"are bit-identical to the Python chain's")
+
+
+def test_compiled_runner_closes_the_loop_like_the_python_chain(api, synth, pkg, tmp_path):
+    """The sequence of tests/test_gpu_sequence.py (720 x 240, a key-frame every 6th frame, database gate 25, a loop back to key-frame 0 that
+    goes through matching, PnP, pose refinement, LoopLocalFusion and the pose graph) through bin/run_kitti_stereo: the compiled host's loop
+    closer makes the same calls as chain.py's — same loop edge, same poses, same files."""
+    chain = pkg.chain
+    exe = pkg._build.build_app()
+    n = 200
+    scene = synth.sequence_scene(); C, yaw = synth.sequence_poses(n)
+    frames = [synth.render_stereo(scene, C[t], yaw[t], t) for t in range(n)]
+    seq = tmp_path / "sequences" / "00"
+    ts = kitti_layout.write(str(seq), frames, png_files)
+    K = synth.SEQ_K
+    yaml = ("%YAML:1.0\n" + "".join(f"Camera.{s}.{k}: {K[k]!r}\n" for s in ("left", "right") for k in ("fx", "fy", "cx", "cy")) + f"Camera.bf: {K['bf']!r}\n"
+            "Map.activeMap.size: 7\nLCD.nDatabaseMinSize: 25\nLCD.similarityScoreThreshold.high: 0.94\nLCD.similarityScoreThreshold.low: 0.92\n")
+    cfg_path = tmp_path / "cam.yaml"; cfg_path.write_text(yaml)
+    w = np.ascontiguousarray(synth.calc_weights_handcrafted(), np.float32).ravel()
+    wfile = tmp_path / "handcrafted.calcw"
+    with open(wfile, "wb") as f:
+        f.write(b"CALCW1\0\0"); f.write(np.uint64(w.size).tobytes()); f.write(w.tobytes())
+    out = tmp_path / "cpp"
+    r = subprocess.run([exe, str(cfg_path), str(seq), "--out", str(out), "--calc-weights", str(wfile), "--kf-every", "6", "--correct-threshold", "0", "--frame-poses"],
+                       capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    cfg = kitti_layout.parse_yaml(yaml)
+    a = chain.Chain(chain.HipBackend(api, w, cfg), pkg.api, chain.camera_from_config(cfg), frames, cfg=cfg, kf_every=6, correct_threshold=0.0,
+                    timestamps=ts, log=False).run()
+    a.save(str(tmp_path / "py"))
+    assert [(x.id, y.id) for x, y in a.loops] == [(33, 0)] and "34 key-frames" in r.stdout and " 1 loops" in r.stdout
+    poses = _rows(out / "frame_poses_cw.txt")
+    assert np.array_equal(poses, np.stack(a.poses)), float(np.abs(poses - np.stack(a.poses)).max())
+    for name in ("trajectory.txt", "loop_edges.txt"):
+        assert open(out / name).read() == open(tmp_path / "py" / name).read(), name
+    assert len(open(out / "loop_edges.txt").read().strip().split("\n")) == 2          # the current key-frame's line, then the loop key-frame's
+    print(f"compiled runner, loop sequence: {r.stdout.strip().splitlines()[-1]}; every frame pose, trajectory.txt and loop_edges.txt bit-identical to chain.py's")
 
 
 def test_runner_on_a_rendered_kitti_layout_sequence(api, synth, pkg, tmp_path):

@@ -26,6 +26,9 @@ for it in range(N):
     p = o.params(nf); p.scale_factor = sf; p.nlevels = nl
     mode = int(rng.choice([-1, -1, 0, 1]))
     ext.set_option(ext.OPT_FAST_MODE, mode)
+    # round-4 options, both must leave every byte unchanged: the descriptor kernel as a limited (persistent) grid, the Gaussian on the matrix cores
+    side = int(rng.choice([0, 0, 1, 2, 3])); mf = int(rng.random() < 0.3)
+    ext.set_option(ext.OPT_SIDE_BLOCKS_PER_CU, side); ext.set_option(ext.OPT_BLUR_MFMA, mf)
     if mode < 0 and rng.random() < 0.5:
         try:
             ext.DetectAndCompute(np.ascontiguousarray(synth.random_image(int(rng.integers(1 << 30)), h, w, "noise")))     # primes the path statistics
@@ -77,6 +80,6 @@ for it in range(N):
         ext.set_stream(0)
     if not ok:
         bad += 1
-        print("MISMATCH", dict(h=h, w=w, nf=nf, nl=nl, sf=sf, kind=kind, n_gpu=len(gk), n_ref=len(rk)))
+        print("MISMATCH", dict(h=h, w=w, nf=nf, nl=nl, sf=sf, kind=kind, mode=mode, side=side, mfma=mf, n_gpu=len(gk), n_ref=len(rk)))
 print(f"fuzz done: {N} cases, {bad} mismatches")
 sys.exit(1 if bad else 0)
