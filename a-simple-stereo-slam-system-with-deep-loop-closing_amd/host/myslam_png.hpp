@@ -13,6 +13,9 @@
 #pragma once
 #include <stdint.h>
 
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <string>
 #include <vector>
@@ -21,20 +24,37 @@ namespace myslam {
 namespace io {
 namespace png_detail {
 
-struct BitReader {
-    const uint8_t* p; size_t n, pos = 0; uint32_t buf = 0; int cnt = 0; bool bad = false;
+struct BitReader {                                           // LSB-first bit stream with a 64-bit window
+    const uint8_t* p; size_t n, pos = 0; uint64_t buf = 0; int cnt = 0; bool bad = false;
     BitReader(const uint8_t* p_, size_t n_) : p(p_), n(n_) {}
-    uint32_t bits(int k) {                                   // k <= 16, LSB first
-        while (cnt < k) { if (pos >= n) { bad = true; return 0; } buf |= (uint32_t)p[pos++] << cnt; cnt += 8; }
-        const uint32_t v = buf & ((1u << k) - 1);
+    void refill() {                                          // afterwards cnt >= 56 unless the input is exhausted
+        if (pos + 8 <= n) {
+            uint64_t w;
+            std::memcpy(&w, p + pos, 8);                     // little-endian host (x86-64 / the MI355X boxes)
+            buf |= w << cnt;
+            const int take = (63 - cnt) >> 3;
+            pos += (size_t)take; cnt += take * 8;
+        } else {
+            while (cnt <= 56 && pos < n) { buf |= (uint64_t)p[pos++] << cnt; cnt += 8; }
+        }
+    }
+    uint32_t bits(int k) {                                   // k <= 16
+        if (cnt < k) { refill(); if (cnt < k) { bad = true; return 0; } }
+        const uint32_t v = (uint32_t)(buf & ((1u << k) - 1));
         buf >>= k; cnt -= k;
         return v;
     }
-    void align() { buf = 0; cnt = 0; }
+    void align() {                                           // drop the rest of the current byte, give whole unread bytes back
+        const int drop = cnt & 7;
+        buf >>= drop; cnt -= drop;
+        pos -= (size_t)(cnt >> 3); buf = 0; cnt = 0;
+    }
 };
 
-struct Huffman {                                             // canonical code: counts per length + symbols sorted by (length, value)
+struct Huffman {                                             // canonical code; decode = one 10-bit table look-up, long codes bit by bit
+    enum { FAST = 10 };
     uint16_t count[16] = {0}; std::vector<uint16_t> sym;
+    uint16_t fast[1 << FAST];                                // symbol << 4 | length; 0 = code longer than FAST bits (or invalid)
     bool build(const uint8_t* len, int n) {
         for (int i = 0; i < 16; i++) count[i] = 0;
         for (int i = 0; i < n; i++) count[len[i]]++;
@@ -45,9 +65,27 @@ struct Huffman {                                             // canonical code: 
         for (int l = 1; l < 15; l++) offs[l + 1] = offs[l] + count[l];
         sym.assign(n, 0);
         for (int i = 0; i < n; i++) if (len[i]) sym[offs[len[i]]++] = (uint16_t)i;
+        for (auto& f : fast) f = 0;
+        int code = 0, index = 0;
+        for (int l = 1; l <= FAST; l++) {                    // canonical codes are MSB first, the stream delivers them LSB first: reverse
+            for (int k = 0; k < count[l]; k++, code++, index++) {
+                int rev = 0;
+                for (int b = 0; b < l; b++) rev |= ((code >> b) & 1) << (l - 1 - b);
+                for (int fill = rev; fill < (1 << FAST); fill += 1 << l) fast[fill] = (uint16_t)((sym[index] << 4) | l);
+            }
+            code <<= 1;
+        }
         return true;
     }
     int decode(BitReader& br) const {
+        if (br.cnt < 16) br.refill();
+        const uint16_t f = fast[br.buf & ((1u << FAST) - 1)];
+        if (f) {
+            const int l = f & 15;
+            if (l > br.cnt) { br.bad = true; return -1; }
+            br.buf >>= l; br.cnt -= l;
+            return f >> 4;
+        }
         int code = 0, first = 0, index = 0;
         for (int l = 1; l < 16; l++) {
             code |= (int)br.bits(1);
@@ -67,7 +105,10 @@ inline bool inflate(const uint8_t* src, size_t n, std::vector<uint8_t>& out, siz
     static const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
     static const uint16_t dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
     static const uint8_t dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
-    out.clear(); out.reserve(expect);
+    // the caller knows the size of the unfiltered image: the output is one pre-sized block, anything longer is an error
+    out.assign(expect, 0);
+    uint8_t* const o = out.data();
+    size_t op = 0;
     for (bool last = false; !last;) {
         last = br.bits(1) != 0;
         const uint32_t type = br.bits(2);
@@ -77,9 +118,9 @@ inline bool inflate(const uint8_t* src, size_t n, std::vector<uint8_t>& out, siz
             if (br.pos + 4 > br.n) return false;
             const uint32_t len = br.p[br.pos] | (br.p[br.pos + 1] << 8), nlen = br.p[br.pos + 2] | (br.p[br.pos + 3] << 8);
             br.pos += 4;
-            if ((len ^ 0xffffu) != nlen || br.pos + len > br.n) return false;
-            out.insert(out.end(), br.p + br.pos, br.p + br.pos + len);
-            br.pos += len;
+            if ((len ^ 0xffffu) != nlen || br.pos + len > br.n || op + len > expect) return false;
+            std::memcpy(o + op, br.p + br.pos, len);
+            op += len; br.pos += len;
             continue;
         }
         if (type == 3) return false;
@@ -114,37 +155,59 @@ inline bool inflate(const uint8_t* src, size_t n, std::vector<uint8_t>& out, siz
             }
             if (lens[256] == 0 || !lit.build(lens, nlen) || !dist.build(lens + nlen, ndist)) return false;
         }
+        // the symbol loop works on a LOCAL copy of the bit window: the byte stores into `o` may alias the reader's fields, which would
+        // otherwise be re-loaded after every literal
+        BitReader lr = br;
+        const uint16_t* const lfast = lit.fast;
         for (;;) {
-            const int s = lit.decode(br);
-            if (s < 0 || br.bad) return false;
-            if (s < 256) { out.push_back((uint8_t)s); continue; }
+            if (lr.cnt < 32) lr.refill();
+            int s;
+            const uint16_t f = lfast[lr.buf & ((1u << Huffman::FAST) - 1)];
+            if (f && (f & 15) <= lr.cnt) { lr.buf >>= (f & 15); lr.cnt -= (f & 15); s = f >> 4; }
+            else s = lit.decode(lr);
+            if (s < 256) { if (s < 0 || op >= expect) return false; o[op++] = (uint8_t)s; continue; }
             if (s == 256) break;
             if (s > 285) return false;
-            const int len = lbase[s - 257] + (int)br.bits(lext[s - 257]);
-            const int ds = dist.decode(br);
+            const size_t len = (size_t)lbase[s - 257] + lr.bits(lext[s - 257]);
+            const int ds = dist.decode(lr);
             if (ds < 0 || ds > 29) return false;
-            const size_t d = dbase[ds] + br.bits(dext[ds]);
-            if (br.bad || d > out.size()) return false;
-            const size_t from = out.size() - d;
-            for (int k = 0; k < len; k++) out.push_back(out[from + k]);
+            const size_t d = dbase[ds] + lr.bits(dext[ds]);
+            if (lr.bad || d > op || op + len > expect) return false;
+            const uint8_t* from = o + op - d;
+            if (d >= len) std::memcpy(o + op, from, len);
+            else for (size_t k = 0; k < len; k++) o[op + k] = from[k];           // overlapping run: byte by byte, as the format defines it
+            op += len;
         }
+        if (lr.bad) return false;
+        br = lr;
     }
+    out.resize(op);
     br.align();
     if (br.pos + 4 > br.n) return false;
-    uint32_t a = 1, b = 0;                                   // Adler-32
-    for (size_t i = 0; i < out.size(); i++) { a = (a + out[i]) % 65521u; b = (b + a) % 65521u; }
+    uint32_t a = 1, b = 0;                                   // Adler-32, the modulo taken once per 5552 bytes (the largest run that cannot overflow)
+    for (size_t i = 0; i < op;) {
+        const size_t e = std::min(op, i + 5552);
+        for (; i < e; i++) { a += o[i]; b += a; }
+        a %= 65521u; b %= 65521u;
+    }
     const uint32_t want = ((uint32_t)br.p[br.pos] << 24) | (br.p[br.pos + 1] << 16) | (br.p[br.pos + 2] << 8) | br.p[br.pos + 3];
     return ((b << 16) | a) == want;
 }
 
-inline uint32_t crc32(const uint8_t* p, size_t n) {
-    static uint32_t table[256]; static bool init = false;
+inline uint32_t crc32(const uint8_t* p, size_t n) {             // slicing-by-4
+    static uint32_t table[4][256]; static bool init = false;
     if (!init) {
-        for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1; table[i] = c; }
+        for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1; table[0][i] = c; }
+        for (uint32_t i = 0; i < 256; i++) for (int t = 1; t < 4; t++) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xff];
         init = true;
     }
     uint32_t c = 0xffffffffu;
-    for (size_t i = 0; i < n; i++) c = table[(c ^ p[i]) & 0xff] ^ (c >> 8);
+    size_t i = 0;
+    for (; i + 4 <= n; i += 4) {
+        c ^= (uint32_t)p[i] | ((uint32_t)p[i + 1] << 8) | ((uint32_t)p[i + 2] << 16) | ((uint32_t)p[i + 3] << 24);
+        c = table[3][c & 0xff] ^ table[2][(c >> 8) & 0xff] ^ table[1][(c >> 16) & 0xff] ^ table[0][c >> 24];
+    }
+    for (; i < n; i++) c = table[0][(c ^ p[i]) & 0xff] ^ (c >> 8);
     return c ^ 0xffffffffu;
 }
 
@@ -191,20 +254,44 @@ inline bool DecodePngGray(const uint8_t* data, size_t size, std::vector<uint8_t>
     if (!inflate(z.data(), z.size(), raw, (stride + 1) * h) || raw.size() != (stride + 1) * h) return false;
     auto grey8 = [](uint32_t r, uint32_t g, uint32_t b) -> uint8_t { return (r == g && r == b) ? (uint8_t)r : (uint8_t)((9797u * r + 19234u * g + 3737u * b) >> 15); };
     // undo the per-row filters in place (row r occupies raw[r*(stride+1)+1 ...])
-    std::vector<uint8_t> prev(stride, 0);
+    const std::vector<uint8_t> zero(stride, 0);
     pixels.assign((size_t)w * h, 0);
     for (uint32_t r = 0; r < h; r++) {
         uint8_t* cur = &raw[(size_t)r * (stride + 1) + 1];
         const int f = cur[-1];
         if (f > 4) return false;
-        for (size_t i = 0; i < stride; i++) {
-            const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
-            int pr = 0;
-            if (f == 1) pr = a;
-            else if (f == 2) pr = b;
-            else if (f == 3) pr = (a + b) >> 1;
-            else if (f == 4) { const int p = a + b - c, pa = p > a ? p - a : a - p, pb = p > b ? p - b : b - p, pc = p > c ? p - c : c - p; pr = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
-            cur[i] = (uint8_t)(cur[i] + pr);
+        const uint8_t* up = r ? cur - (stride + 1) : zero.data();              // the row above, already unfiltered in place
+        // the left neighbour is carried in a register (a store-to-load round trip per byte otherwise); one loop per byte distance for the
+        // grey formats KITTI uses (bpp 1), the general loop for the rest
+        if (f == 1) {
+            if (bpp == 1) { unsigned a = 0; for (size_t i = 0; i < stride; i++) { a = (cur[i] + a) & 255u; cur[i] = (uint8_t)a; } }
+            else for (size_t i = bpp; i < stride; i++) cur[i] = (uint8_t)(cur[i] + cur[i - bpp]);
+        } else if (f == 2) { for (size_t i = 0; i < stride; i++) cur[i] = (uint8_t)(cur[i] + up[i]); }
+        else if (f == 3) {
+            if (bpp == 1) { unsigned a = 0; for (size_t i = 0; i < stride; i++) { a = (cur[i] + ((a + up[i]) >> 1)) & 255u; cur[i] = (uint8_t)a; } }
+            else {
+                for (size_t i = 0; i < bpp && i < stride; i++) cur[i] = (uint8_t)(cur[i] + (up[i] >> 1));
+                for (size_t i = bpp; i < stride; i++) cur[i] = (uint8_t)(cur[i] + ((cur[i - bpp] + up[i]) >> 1));
+            }
+        } else if (f == 4) {                                                                     // |p - a| = |b - c|, |p - b| = |a - c|, |p - c| = |a + b - 2c|
+            if (bpp == 1) {
+                int a = 0, c = 0;
+                for (size_t i = 0; i < stride; i++) {
+                    const int b = up[i];
+                    const int pa = std::abs(b - c), pb = std::abs(a - c), pc = std::abs(a + b - 2 * c);
+                    const int bc = pb <= pc ? b : c;                                             // selects, no branches: noise-like rows mispredict every other byte
+                    a = (cur[i] + ((pa <= pb) & (pa <= pc) ? a : bc)) & 255;
+                    cur[i] = (uint8_t)a; c = b;
+                }
+            } else {
+                for (size_t i = 0; i < bpp && i < stride; i++) cur[i] = (uint8_t)(cur[i] + up[i]);      // a = c = 0: the predictor is b
+                for (size_t i = bpp; i < stride; i++) {
+                    const int a = cur[i - bpp], b = up[i], c = up[i - bpp];
+                    const int pa = std::abs(b - c), pb = std::abs(a - c), pc = std::abs(a + b - 2 * c);
+                    const int bc = pb <= pc ? b : c;
+                    cur[i] = (uint8_t)(cur[i] + ((pa <= pb) & (pa <= pc) ? a : bc));
+                }
+            }
         }
         uint8_t* dst = &pixels[(size_t)r * w];
         if (depth < 8) {                                                     // packed samples, most significant bits first
@@ -229,16 +316,19 @@ inline bool DecodePngGray(const uint8_t* data, size_t size, std::vector<uint8_t>
                 dst[x] = (uint8_t)(g16 >> 8);
             }
         }
-        prev.assign(cur, cur + stride);
     }
     rows = (int)h; cols = (int)w;
     return true;
 }
 
 inline bool ReadPngGray(const std::string& path, std::vector<uint8_t>& pixels, int& rows, int& cols) {
-    std::ifstream f(path, std::ios::binary);
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
     if (!f.is_open()) return false;
-    std::vector<uint8_t> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    const std::streamoff size = f.tellg();
+    if (size <= 0) return false;
+    std::vector<uint8_t> buf((size_t)size);
+    f.seekg(0);
+    if (!f.read((char*)buf.data(), size)) return false;
     return DecodePngGray(buf.data(), buf.size(), pixels, rows, cols);
 }
 
