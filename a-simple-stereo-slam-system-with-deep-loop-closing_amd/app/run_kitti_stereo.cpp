@@ -4,7 +4,7 @@
 //
 //   run_kitti_stereo config/stereo/gray/KITTI00-02.yaml /data/kitti/sequences/00 [--frames 200] [--out result]
 //                    [--calc-prototxt calc_model/deploy.prototxt --calc-model calc_model/calc.caffemodel | --calc-weights file.calcw]
-//                    [--kf-every N] [--frontend-wins-race] [--correct-threshold X] [--frame-poses]
+//                    [--kf-every N] [--frontend-wins-race] [--correct-threshold X] [--frame-poses] [--no-prefetch]
 //
 // Reads <sequence>/times.txt and image_0 / image_1/%06d.png (LoadImages + cv::imread(…, IMREAD_GRAYSCALE): host/myslam_io.hpp,
 // host/myslam_png.hpp), tracks every frame through host/myslam_system.hpp (Frontend / Backend / LoopClosing / Map as one sequential
@@ -18,6 +18,7 @@
 #include <cstring>
 #include <filesystem>
 #include <fstream>
+#include <future>
 
 #include "../host/myslam_io.hpp"
 #include "../host/myslam_png.hpp"
@@ -32,12 +33,12 @@ static std::shared_ptr<myslam::Image> imread_gray(const std::string& path) {
 int main(int argc, char** argv) {
     if (argc < 3) {
         std::fprintf(stderr, "Usage: %s path_to_config path_to_sequence [--frames N] [--out dir] [--calc-prototxt P --calc-model M | --calc-weights F] "
-                             "[--kf-every N] [--frontend-wins-race] [--correct-threshold X] [--frame-poses]\n", argv[0]);
+                             "[--kf-every N] [--frontend-wins-race] [--correct-threshold X] [--frame-poses] [--no-prefetch]\n", argv[0]);
         return 1;
     }
     const std::string configPath = argv[1], sequence = argv[2];
     std::string out = "result", proto = "calc_model/deploy.prototxt", model = "calc_model/calc.caffemodel", weights;
-    int frames = 0; bool framePoses = false;
+    int frames = 0; bool framePoses = false, prefetch = true;
     myslam::SystemConfig sc;
     for (int i = 3; i < argc; i++) {
         const std::string a = argv[i];
@@ -51,6 +52,7 @@ int main(int argc, char** argv) {
         else if (a == "--frontend-wins-race") sc.lcdBlurReachesTracker = false;
         else if (a == "--correct-threshold") sc.correctThreshold = std::atof(next());
         else if (a == "--frame-poses") framePoses = true;
+        else if (a == "--no-prefetch") prefetch = false;
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
     }
     myslam::io::Config cfg;
@@ -69,9 +71,17 @@ int main(int argc, char** argv) {
         double tRead = 0.0;
         int done = 0, rows = 0, cols = 0;
         const auto t0 = std::chrono::steady_clock::now();
+        // cv::imread per step (app/run_kitti_stereo.cpp:66-67), decoded ahead of the tracker: the two images of frame i + 1 are read on two
+        // threads while frame i is tracked (`--no-prefetch`: read them in the loop, as the reference does)
+        using ImgFuture = std::future<std::shared_ptr<myslam::Image>>;
+        auto ahead = [&](int i) { return std::make_pair(std::async(std::launch::async, imread_gray, left[i]), std::async(std::launch::async, imread_gray, right[i])); };
+        std::pair<ImgFuture, ImgFuture> next;
+        if (prefetch) next = ahead(0);
         for (int i = 0; i < n; i++) {
             const auto r0 = std::chrono::steady_clock::now();
-            auto L = imread_gray(left[i]), R = imread_gray(right[i]);      // cv::imread per step, app/run_kitti_stereo.cpp:66-67
+            std::shared_ptr<myslam::Image> L, R;
+            if (prefetch) { L = next.first.get(); R = next.second.get(); if (i + 1 < n) next = ahead(i + 1); }
+            else { L = imread_gray(left[i]); R = imread_gray(right[i]); }
             tRead += std::chrono::duration<double>(std::chrono::steady_clock::now() - r0).count();
             if (!L || !R) { std::fprintf(stderr, "Failed to load image at: %s\n", left[i].c_str()); return 1; }
             rows = L->rows; cols = L->cols;
@@ -91,9 +101,9 @@ int main(int argc, char** argv) {
             std::ofstream g(out + "/key_frame_frames.txt");
             for (unsigned long id : slam.keyFrameFrames) g << id << "\n";
         }
-        std::printf("%d frames (%dx%d), %zu key-frames, %zu map points, %zu loops; read %.1f s, tracked + mapped in %.1f s = %.1f frames/s "
+        std::printf("%d frames (%dx%d), %zu key-frames, %zu map points, %zu loops; waited %.2f s for images, tracked + mapped in %.2f s = %.1f frames/s, %.1f frames/s end to end "
                     "(compiled host, one call per operator and frame; %ld pose-only, %ld local-BA, %ld DeepLCD, %ld loop queries); wrote %s/trajectory.txt, loop_edges.txt\n",
-                    done, cols, rows, slam.NumKeyFrames(), slam.NumMapPoints(), slam.NumLoops(), tRead, tRun, done / std::max(tRun, 1e-9),
+                    done, cols, rows, slam.NumKeyFrames(), slam.NumMapPoints(), slam.NumLoops(), tRead, tRun, done / std::max(tRun, 1e-9), done / std::max(tRun + tRead, 1e-9),
                     slam.stats.poseOnly, slam.stats.ba, slam.stats.lcd, slam.stats.detectLoop, out.c_str());
     } catch (const std::exception& e) {
         std::fprintf(stderr, "run_kitti_stereo: %s\n", e.what());

@@ -83,7 +83,7 @@ def build_app(force=False, verbose=False):
     """bin/run_kitti_stereo: host C++ only (g++), links the library next to it"""
     if force or not os.path.exists(APP_OUT):
         os.makedirs(os.path.dirname(APP_OUT), exist_ok=True)
-        cmd = [CXX, "-O2", "-std=c++17", "-ffp-contract=off", "-Wall", APP_SRC, "-o", APP_OUT, "-L" + HERE, "-lmyslam_hip", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
+        cmd = [CXX, "-O2", "-std=c++17", "-ffp-contract=off", "-Wall", APP_SRC, "-o", APP_OUT, "-L" + HERE, "-lmyslam_hip", "-pthread", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

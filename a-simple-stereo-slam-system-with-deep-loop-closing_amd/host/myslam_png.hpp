@@ -194,13 +194,17 @@ inline bool inflate(const uint8_t* src, size_t n, std::vector<uint8_t>& out, siz
     return ((b << 16) | a) == want;
 }
 
-inline uint32_t crc32(const uint8_t* p, size_t n) {             // slicing-by-4
-    static uint32_t table[4][256]; static bool init = false;
-    if (!init) {
-        for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1; table[0][i] = c; }
-        for (uint32_t i = 0; i < 256; i++) for (int t = 1; t < 4; t++) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xff];
-        init = true;
+struct CrcTable {
+    uint32_t t[4][256];
+    CrcTable() {
+        for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1; t[0][i] = c; }
+        for (uint32_t i = 0; i < 256; i++) for (int k = 1; k < 4; k++) t[k][i] = (t[k - 1][i] >> 8) ^ t[0][t[k - 1][i] & 0xff];
     }
+};
+
+inline uint32_t crc32(const uint8_t* p, size_t n) {             // slicing-by-4
+    static const CrcTable T;                                    // function-local static: initialised once, thread-safe (images are read on several threads)
+    const uint32_t (*table)[256] = T.t;
     uint32_t c = 0xffffffffu;
     size_t i = 0;
     for (; i + 4 <= n; i += 4) {
