@@ -84,6 +84,27 @@ SYMBOL = {"resize": "k_resize_strip", "fast": "k_fast_strip", "octree": "k_octre
           "ba_build": "k_ba_build", "screen": "k_screen"}
 
 
+_masked = []
+
+
+def masked_stream(n_cus, first=0):
+    """A HIP stream whose kernels may only run on `n_cus` compute units (hipExtStreamCreateWithCUMask; bits first .. first + n_cus - 1 of the
+    device's CU mask) as a torch stream — an experiment: does confining the latency-bound side chains to a few CUs keep their long-lived blocks
+    out of FAST's way?  (--side-cus / --match-cus; DESIGN_APPENDIX.md section 8 has the result.)"""
+    import ctypes
+    import torch
+    hip = ctypes.CDLL("libamdhip64.so")
+    words = 8                                              # 256 CUs
+    mask = (ctypes.c_uint32 * words)()
+    for b in range(first, first + n_cus):
+        mask[(b // 32) % words] |= 1 << (b % 32)
+    st = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), mask)
+    assert rc == 0 and st.value, f"hipExtStreamCreateWithCUMask failed: {rc}"
+    _masked.append(st)
+    return torch.cuda.ExternalStream(st.value)
+
+
 def pmc_file():
     """The newest committed counter summary of this build family (tools/pmc_collect.py writes it): profiles/r<NN>_pmc_<tag>.json."""
     files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json")) if re.search(r"r(\d+)_pmc_[^/]*\.json$", f) and "traffic" not in f and "mfma" not in f]
@@ -169,6 +190,8 @@ def parse():
                          "latency-bound; 0 = eager launches on the four-stream schedule; -1 (default) = 1 when --pairs <= 64 on one GPU, else 0.  The "
                          "other mode is timed in an extra pass (`step_graph` / `step_eager`)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes of --graph 1 (0 = 16 for <= 16 pairs per step, 8 up to 64, else 4)")
+    ap.add_argument("--side-cus", type=int, default=0, help="experiment: the DeepLCD / DB / BA stream may use only this many CUs (hipExtStreamCreateWithCUMask); 0 = all")
+    ap.add_argument("--match-cus", type=int, default=0, help="experiment: likewise for the match + triangulation stream")
     ap.add_argument("--created-main-stream", action="store_true", help="debug: the four-stream schedule's main chain on a created stream instead of the legacy NULL stream")
     ap.add_argument("--verify", action="store_true",
                     help="after the timed region: run one joined, un-gated step and check that it reproduces the pipeline's last outputs bit for bit")
@@ -410,7 +433,7 @@ def main():
     main_stream = torch.cuda.current_stream()
     stream = main_stream.cuda_stream
     # the LCD -> DB -> BA chain only reads the input images: it runs beside the ORB chain on its own stream
-    side_stream = torch.cuda.Stream() if args.streams == 2 else main_stream
+    side_stream = (masked_stream(args.side_cus) if args.side_cus > 0 else torch.cuda.Stream()) if args.streams == 2 else main_stream
     stream2 = side_stream.cuda_stream
     P = args.pairs
     K = synth.KITTI00
@@ -514,7 +537,7 @@ def main():
         # descriptor launches; match + triangulation of step k run on a third stream once both handles are done with step k, while the
         # handles already extract step k+1 into the other output buffer
         exts = [ext] + orb_exts
-        sX, sM = [main_stream] + orb_streams, torch.cuda.Stream()
+        sX, sM = [main_stream] + orb_streams, (masked_stream(args.match_cus) if args.match_cus > 0 else torch.cuda.Stream())
         G = 2 * P // S
         ev_fast = [torch.cuda.Event() for _ in range(S)]
         ev_done = [[torch.cuda.Event() for _ in range(S)] for _ in range(NB)]

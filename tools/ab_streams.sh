@@ -2,5 +2,8 @@
 run() { tag=$1; shift; timeout 600 python bench.py --no-cpu-baseline --stream-input 0 --parity-frames 0 --no-extra-passes --graph 0 "$@" > gpurun_out/ab_$tag.json 2> gpurun_out/ab_$tag.err; python -c "
 import json; d=json.load(open('gpurun_out/ab_$tag.json')); print('$tag', round(d['value']), round(d['ms_per_step'],3), 'host', round(d['host_launch_ms_per_step'],3))" || tail -3 gpurun_out/ab_$tag.err; }
 for rep in 1 2; do
-for l in 0 1 2 3 4; do run d2_l$l --side-blocks-per-cu 2 --lcd-blocks-per-cu $l; done
+run base
+for n in 32 64 96 128 192; do run side$n --side-cus $n; done
+run side64_match64 --side-cus 64 --match-cus 64
+run side96_match32 --side-cus 96 --match-cus 32
 done
