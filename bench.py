@@ -190,6 +190,7 @@ def parse():
                          "latency-bound; 0 = eager launches on the four-stream schedule; -1 (default) = 1 when --pairs <= 64 on one GPU, else 0.  The "
                          "other mode is timed in an extra pass (`step_graph` / `step_eager`)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes of --graph 1 (0 = 16 for <= 16 pairs per step, 8 up to 64, else 4)")
+    ap.add_argument("--ba-stream", choices=["side", "match"], default="match", help="the BA block build behind the triangulation on the match stream (default: +0.4 %, three alternating runs) or behind the DB scan on the side stream")
     ap.add_argument("--side-cus", type=int, default=0, help="experiment: the DeepLCD / DB / BA stream may use only this many CUs (hipExtStreamCreateWithCUMask); 0 = all")
     ap.add_argument("--match-cus", type=int, default=0, help="experiment: likewise for the match + triangulation stream")
     ap.add_argument("--created-main-stream", action="store_true", help="debug: the four-stream schedule's main chain on a created stream instead of the legacy NULL stream")
@@ -510,7 +511,7 @@ def main():
 
     skip = set(args.side_skip.split(",")) if args.side_skip else set()      # diagnostic: the marginal cost of the side chain's parts
 
-    def side_chain():
+    def side_chain(with_ba=True):
         if use_lcd and "lcd" not in skip:
             lcd.describe_batch(cur["imgs"].data_ptr(), P, H, W, W, H * W, d_descr.data_ptr(), blur_in_place=False)
         if use_lcd and "db" not in skip:
@@ -526,12 +527,15 @@ def main():
             else:
                 D.query_batch(d_descr.data_ptr(), cur_ids, NQ, d_best.data_ptr(), d_max.data_ptr(), d_dbcnt.data_ptr())
         if use_ba and "ba" not in skip:
-            api.ba_build_batch(*[t.data_ptr() for t in b_in], P, maxP, maxL, maxE, Kt, 5.991, *[t.data_ptr() for t in b_out], stream2)
+            if with_ba or solve_windows[0]:
+                api.ba_build_batch(*[t.data_ptr() for t in b_in], P, maxP, maxL, maxE, Kt, 5.991, *[t.data_ptr() for t in b_out], stream2)
             if solve_windows[0]:
                 solve(solve_windows[0])
 
+    ba_on_match = [False]
     step_no = [0]           # steps issued so far: step k writes extractor output buffer k % NB
     if args.pipeline:
+        ba_on_match[0] = args.ba_stream == "match" and use_ba
         # two extractor handles take turns: handle A (left images, main stream) and handle B (right images, its own stream) each wait
         # for the other's FAST stage, so a FAST launch never runs beside the other FAST launch but under the other handle's oct-tree /
         # descriptor launches; match + triangulation of step k run on a third stream once both handles are done with step k, while the
@@ -571,9 +575,11 @@ def main():
             api.triangulate_stereo_batch(kps.data_ptr(), kps.data_ptr() + P * cap * 28, d_midx.data_ptr(), cnt.data_ptr(), P, cap,
                                          Kt, K["bf"] / K["fx"], d_xyz.data_ptr(), d_ok.data_ptr(), sM.cuda_stream)
             ev_match[p].record(sM)
+            if ba_on_match[0] and "ba" not in skip and not solve_windows[0]:
+                api.ba_build_batch(*[t.data_ptr() for t in b_in], P, maxP, maxL, maxE, Kt, 5.991, *[t.data_ptr() for t in b_out], sM.cuda_stream)
             side_stream.wait_event(ev_start)            # the LCD / DB / BA chain of step k starts with step k
             with torch.cuda.stream(side_stream):
-                side_chain()
+                side_chain(with_ba=not ba_on_match[0])
 
     def step_joined():
         if S == 1:
