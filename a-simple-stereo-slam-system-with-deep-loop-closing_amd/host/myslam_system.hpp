@@ -495,6 +495,7 @@ class StereoSystem {
         for (KeyFrame* k : kfs) ba.AddKeyFrame(k->id, k->pose.v);
         std::vector<std::pair<MapPoint*, Feature*>> rows;
         for (MapPoint* m : mps) {
+            if (m->obs.empty() && m->activeObs.empty()) throw std::runtime_error("active map point without observations");
             const unsigned long first = !m->obs.empty() ? m->obs[0]->kf->id : m->activeObs[0]->kf->id;      // GetObservations().front()->mpKF (:175)
             ba.AddMapPoint(m->id, m->pos, m->outlier, first);
             for (Feature* f : m->activeObs) { ba.AddObservation(m->id, f->kf->id, f->x, f->y, f->outlier); rows.emplace_back(m, f); }
