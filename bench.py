@@ -814,6 +814,32 @@ def main():
                  "note": "as the timed region, plus the OptimizeActiveMap solve stage on EVERY frame's window (configs[3] read as 'every frame is a "
                          "key-frame'; = --workload full_solve)"}
 
+    # ---- pass 5b: the same step on a KITTI-LIKE scene.  The headline stream is deliberately hard on FAST (6 000 rectangles: 30 % of all
+    # pixels are FAST-7 corners, 76 % of the pixel pairs survive the compass pre-test); street scenes are sparse (a few % corners, ~14 % of
+    # the pairs survive), which is what 300 rectangles give — there FAST takes its two-phase path (pre-test, compaction, scoring of the
+    # survivors only).  Reported beside `value`, never instead of it ----
+    sparse = None
+    if not args.no_extra_passes and world == 1 and args.scene_rects > 1000 and args.pipeline:
+        fr2 = synth.stereo_batch(P, stream_id=rank, n_rect=300)
+        d_sparse = torch.from_numpy(np.concatenate([fr2[:, 0], fr2[:, 1]], axis=0)).to(dev)
+        keep_imgs = cur["imgs"]
+        cur["imgs"] = d_sparse
+        for _ in range(4):                  # the per-level path statistics of both handles settle on the new scene
+            step()
+        barrier()
+        dt_sp = timed(args.steps)
+        kp_sp = float(torch.stack([c.float().mean() for c in d_cnt_b]).mean().item())
+        assert all(int(t.abs().sum()) == 0 for t in d_stat_b)
+        sparse = {"value": world * P * args.steps / dt_sp, "unit": "stereo frames/s", "ms_per_step": dt_sp / args.steps * 1e3, "scene_rects": 300,
+                  "keypoints_per_image": kp_sp,
+                  "note": "the timed region on a sparse, street-like scene (300 rectangles instead of 6 000): FAST chooses its two-phase path per level "
+                          "from the previous launch's statistics; same kernels, same outputs (tests/test_gpu_fallbacks.py)"}
+        cur["imgs"] = keep_imgs
+        for _ in range(4):
+            step()
+        barrier()
+        del d_sparse
+
     # ---- pass 6: the extractor ALONE on an otherwise idle chip (three calls of one handle, event pair around every launch): what a launch
     # of each ORB kernel takes when nothing shares its CUs — under the pipeline a launch is resident for longer BY DESIGN (blocks of the
     # other streams move in beside FAST's), so the per-launch durations of pass 2 price the schedule, these price the kernel ----
@@ -1038,7 +1064,7 @@ def main():
                                                            pcie_h2d_measured_GBps=(peaks or {}).get("h2d_GBps"),
                                                            pcie_bound_frames_per_s=None if not (peaks or {}).get("h2d_GBps") else
                                                            world * (peaks["h2d_GBps"] * 1e9) / (2 * H * W)),
-            "full_solve_cadence6": cadence, "full_solve_every_frame": every,
+            "full_solve_cadence6": cadence, "full_solve_every_frame": every, "kitti_like_scene": sparse,
             "launch_mode": f"HIP graph replay on {n_lanes} single-stream lanes (step k on lane k mod {n_lanes})" if use_graph else
                            "eager launches (two extractor handles + match + side chain on four streams, consecutive steps overlap)",
             "host_launch_ms_per_step": host_launch_ms,      # CPU time of enqueuing one step of the timed region
