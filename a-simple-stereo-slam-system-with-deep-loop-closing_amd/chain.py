@@ -647,8 +647,8 @@ class Chain:
         p2 = np.array([[kf.feats[cf].x, kf.feats[cf].y] for cf, _ in valid], np.float32).reshape(-1, 2)
         try:
             pose, inl, n = self.be.pnp(p3, p2, self.Kt)
-        except Exception:                           # the reference's try / catch around solvePnPRansac (:262-270)
-            return False
+        except RuntimeError:                        # the reference's try / catch around solvePnPRansac (:262-270): "no model" is how both back
+            return False                            # ends report OpenCV's `false`; anything else (a checker's assertion) is not swallowed
         self.rec("pnp", inl, np.array([n]), pose)
         # OptimizeCurrentPose (:339-433): the map points in double, the pixels through toVec2
         P3 = np.array([loop.feats[lf].mp.pos for _, lf in valid], float).reshape(-1, 3)

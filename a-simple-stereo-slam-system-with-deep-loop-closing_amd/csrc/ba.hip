@@ -253,6 +253,19 @@ constexpr int BA_NW = BA_NT / 64;
 constexpr int BA_CL = 32;              // landmarks per Schur chunk
 constexpr int BA_VS = 3 * BA_CL + 2;   // row stride of the staged V chunk (doubles): 2 mod 32 -> conflict-free MFMA operand reads
 
+template <int NW>
+__device__ __forceinline__ double block_sum_n(double v, double* s_red) {
+    v = wave_reduce_sum(v);
+    if (NW == 1) return v;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) s += s_red[i];
+    return s;
+}
+
 __device__ __forceinline__ double block_sum(double v, double* s_red) {
     v = wave_reduce_sum(v);
     __syncthreads();
@@ -891,16 +904,22 @@ struct PoseOnlyArgs {
     uint8_t* outlier; int32_t* n_inliers; int32_t* status;
 };
 
-__global__ __launch_bounds__(BA_NT) void k_pose_only(PoseOnlyArgs a) {
-    __shared__ double s_red[BA_NW];
-    __shared__ double sT[12], sTb[12], sH[27], sx[6], s_part[BA_NW][27];
+// NT = threads per frame: 512 for large batches of frames with many matches; the one-frame call of the tracker (150 - 400 matches) runs 64
+// or 128 threads — one or two waves pass the ~45 dependent Levenberg steps of a frame faster than eight waves that meet at every barrier.
+// The edge -> thread map (edge t + k NT) and with it the summation order depend on NT: results of different NT agree to rounding, the
+// parity bars against the oracle (1e-8 relative on the pose, identical flags) hold for each.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_pose_only(PoseOnlyArgs a) {
+    constexpr int NW = NT / 64;
+    __shared__ double s_red[NW];
+    __shared__ double sT[12], sTb[12], sH[27], sx[6], s_part[NW][27];
     __shared__ double s_sc[4];          // [0] lambda [1] ni [2] ok
     const int f = blockIdx.x, t = threadIdx.x, wv = t >> 6, lane = t & 63;
     const int n = a.counts ? a.counts[f] : a.n_fixed;
     const double* P3 = a.pts3d + (size_t)f * a.cap * 3;
     const double* Z2 = a.obs + (size_t)f * a.cap * 2;
     double* pose = a.poses + (size_t)f * 7;
-    if (n > PO_EPT * BA_NT) { if (t == 0) { a.status[f] = MYSLAM_ERR_CAPACITY; a.n_inliers[f] = 0; } return; }
+    if (n > PO_EPT * NT) { if (t == 0) { a.status[f] = MYSLAM_ERR_CAPACITY; a.n_inliers[f] = 0; } return; }
     if (t == 0) {
         double x = pose[0], y = pose[1], z = pose[2], q = pose[3];
         const double nn = sqrt(x * x + y * y + z * z + q * q);
@@ -911,7 +930,7 @@ __global__ __launch_bounds__(BA_NT) void k_pose_only(PoseOnlyArgs a) {
         sT[9] = pose[4]; sT[10] = pose[5]; sT[11] = pose[6];
     }
     __syncthreads();
-    unsigned level = 0, outl = 0;                          // bit k <-> edge t + k*BA_NT
+    unsigned level = 0, outl = 0;                          // bit k <-> edge t + k*NT
     double echi[PO_EPT];
 #pragma unroll
     for (int k = 0; k < PO_EPT; k++) echi[k] = 0.0;
@@ -929,7 +948,7 @@ __global__ __launch_bounds__(BA_NT) void k_pose_only(PoseOnlyArgs a) {
         double s = 0;
 #pragma unroll
         for (int k = 0; k < PO_EPT; k++) {
-            const int i = t + k * BA_NT;
+            const int i = t + k * NT;
             if (i < n && !((level >> k) & 1)) {
                 double e0, e1, pc[3];
                 edge_err(i, e0, e1, pc);
@@ -938,14 +957,14 @@ __global__ __launch_bounds__(BA_NT) void k_pose_only(PoseOnlyArgs a) {
                 s += (!robust || e2 <= 1.0) ? e2 : 2 * sqrt(e2) - 1.0;
             }
         }
-        return block_sum(s, s_red);
+        return block_sum_n<NW>(s, s_red);
     };
     int cntOut = 0;
     for (int round = -a.pre; round < a.rounds; round++) {       // round < 0: the unclassified optimize() of LoopClosing::OptimizeCurrentPose
         double na = 0;
 #pragma unroll
-        for (int k = 0; k < PO_EPT; k++) na += (t + k * BA_NT < n && !((level >> k) & 1)) ? 1.0 : 0.0;
-        const int nact = (int)block_sum(na, s_red);
+        for (int k = 0; k < PO_EPT; k++) na += (t + k * NT < n && !((level >> k) & 1)) ? 1.0 : 0.0;
+        const int nact = (int)block_sum_n<NW>(na, s_red);
         if (nact > 0) {
             for (int it = 0; it < a.iters; it++) {
                 double currentChi = active_chi2();
@@ -955,7 +974,7 @@ __global__ __launch_bounds__(BA_NT) void k_pose_only(PoseOnlyArgs a) {
                 for (int u = 0; u < 27; u++) h[u] = 0.0;
 #pragma unroll
                 for (int k = 0; k < PO_EPT; k++) {
-                    const int i = t + k * BA_NT;
+                    const int i = t + k * NT;
                     if (i < n && !((level >> k) & 1)) {
                         double e0, e1, pc[3];
                         edge_err(i, e0, e1, pc);
@@ -981,7 +1000,7 @@ __global__ __launch_bounds__(BA_NT) void k_pose_only(PoseOnlyArgs a) {
                     for (int u = 0; u < 27; u++) s_part[wv][u] = h[u];
                 }
                 __syncthreads();
-                if (t < 27) { double s = 0; for (int w2 = 0; w2 < BA_NW; w2++) s += s_part[w2][t]; sH[t] = s; }
+                if (t < 27) { double s = 0; for (int w2 = 0; w2 < NW; w2++) s += s_part[w2][t]; sH[t] = s; }
                 __syncthreads();
                 if (it == 0 && t == 0) {
                     double mx = 0;
@@ -1054,19 +1073,19 @@ __global__ __launch_bounds__(BA_NT) void k_pose_only(PoseOnlyArgs a) {
         double co = 0;
 #pragma unroll
         for (int k = 0; k < PO_EPT; k++) {
-            const int i = t + k * BA_NT;
+            const int i = t + k * NT;
             if (i < n) {
                 if ((outl >> k) & 1) { double e0, e1, pc[3]; edge_err(i, e0, e1, pc); echi[k] = e0 * e0 + e1 * e1; }
                 if (echi[k] > a.chi2_th) { outl |= 1u << k; level |= 1u << k; co += 1.0; }
                 else { outl &= ~(1u << k); level &= ~(1u << k); }
             }
         }
-        cntOut = (int)block_sum(co, s_red);
+        cntOut = (int)block_sum_n<NW>(co, s_red);
         if (round == a.rounds - 2) robust = false;            // :244-246
     }
     // ---- write back ----
 #pragma unroll
-    for (int k = 0; k < PO_EPT; k++) { const int i = t + k * BA_NT; if (i < n) a.outlier[(size_t)f * a.cap + i] = (outl >> k) & 1; }
+    for (int k = 0; k < PO_EPT; k++) { const int i = t + k * NT; if (i < n) a.outlier[(size_t)f * a.cap + i] = (outl >> k) & 1; }
     if (t == 0) {
         const double* R = sT;
         const double tr = R[0] + R[4] + R[8];
@@ -1215,6 +1234,20 @@ int myslam_ba_optimize_active_map(double* poses, int nposes, double* points, int
     return st[0];
 }
 
+// Block size (measured on MI355X, tools/frontend_time.py + tools/latency_frontend.py; PO_EPT = 8 edges per thread is the kernel's limit).
+// Many frames: small blocks, several frames per CU — 1024 frames x 150 / 500 / 1000 matches take 0.42 / 0.63 / 0.93 ms with 64 / 128 / 128
+// threads against 1.46 / 1.56 / 1.84 ms with 512.  A few frames (the tracker's one-frame call): the latency of ~45 dependent Levenberg steps,
+// 0.29 - 0.44 ms whatever the size; 256 threads are best from 150 to 1000 matches (0.29 ms at 150 against 0.36 with 512).
+static void pose_only_launch(const PoseOnlyArgs& a, int batch, int max_edges, hipStream_t s) {
+    int nt;
+    if (batch >= 64) nt = max_edges <= 256 ? 64 : (max_edges <= 1024 ? 128 : (max_edges <= 2048 ? 256 : 512));
+    else nt = max_edges <= 128 ? 128 : (max_edges <= 2048 ? 256 : 512);
+    if (nt == 64) hipLaunchKernelGGL(k_pose_only<64>, dim3(batch), dim3(64), 0, s, a);
+    else if (nt == 128) hipLaunchKernelGGL(k_pose_only<128>, dim3(batch), dim3(128), 0, s, a);
+    else if (nt == 256) hipLaunchKernelGGL(k_pose_only<256>, dim3(batch), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_pose_only<512>, dim3(batch), dim3(512), 0, s, a);
+}
+
 int myslam_pose_only_optimize_batch(double* d_poses, const double* d_pts3d, const double* d_obs, const int32_t* d_counts, int batch, int cap,
                                     double fx, double fy, double cx, double cy, double chi2_th, int rounds, int iters, int pre_optimize,
                                     uint8_t* d_outlier, int32_t* d_n_inliers, int32_t* d_status, void* hip_stream) {
@@ -1223,7 +1256,7 @@ int myslam_pose_only_optimize_batch(double* d_poses, const double* d_pts3d, cons
         return MYSLAM_ERR_INVALID;
     PoseOnlyArgs a{d_poses, d_pts3d, d_obs, d_counts, 0, cap, fx, fy, cx, cy, chi2_th, rounds, iters, pre_optimize, d_outlier, d_n_inliers, d_status};
     ScopedProf sp(P_BA, (hipStream_t)hip_stream);
-    hipLaunchKernelGGL(k_pose_only, dim3(batch), dim3(BA_NT), 0, (hipStream_t)hip_stream, a);
+    pose_only_launch(a, batch, cap, (hipStream_t)hip_stream);
     MYSLAM_HIP_CHECK(hipGetLastError());
     return MYSLAM_OK;
 }
@@ -1243,7 +1276,7 @@ int myslam_pose_only_optimize(double* pose7, const double* pts3d, const double* 
     int32_t* d_i = hc.dev<int32_t>(o_st);
     PoseOnlyArgs a{hc.dev<double>(i_p), hc.dev<double>(i_x), hc.dev<double>(i_o), nullptr, n, m, fx, fy, cx, cy, chi2_th, rounds, iters, pre_optimize,
                    hc.dev<uint8_t>(o_out), d_i, d_i + 1};
-    hipLaunchKernelGGL(k_pose_only, dim3(1), dim3(BA_NT), 0, hc.stream(), a);
+    pose_only_launch(a, 1, n, hc.stream());
     MYSLAM_HIP_CHECK(hipGetLastError());
     if ((rc = hc.download())) return rc;
     if (n_inliers) *n_inliers = st[0];
