@@ -190,6 +190,7 @@ def parse():
                          "latency-bound; 0 = eager launches on the four-stream schedule; -1 (default) = 1 when --pairs <= 64 on one GPU, else 0.  The "
                          "other mode is timed in an extra pass (`step_graph` / `step_eager`)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes of --graph 1 (0 = 16 for <= 16 pairs per step, 8 up to 64, else 4)")
+    ap.add_argument("--lcd-split", type=int, default=1, help="the DeepLCD chain of a step in this many parts on as many handles / streams (1 = one chain on the side stream)")
     ap.add_argument("--ba-stream", choices=["side", "match"], default="match", help="the BA block build behind the triangulation on the match stream (default: +0.4 %, three alternating runs) or behind the DB scan on the side stream")
     ap.add_argument("--side-cus", type=int, default=0, help="experiment: the DeepLCD / DB / BA stream may use only this many CUs (hipExtStreamCreateWithCUMask); 0 = all")
     ap.add_argument("--match-cus", type=int, default=0, help="experiment: likewise for the match + triangulation stream")
@@ -474,6 +475,14 @@ def main():
     db_np = None
     if use_lcd:
         lcd = api.DeepLCD(synth.calc_weights(), stream=stream2)
+        # the DeepLCD chain in `lcd_split` parts on as many handles / streams (part 0 on the side stream): every stream of the schedule is
+        # busy for about the whole step, and the side stream's chain was the longest — two half-length chains overlap better (+0.9 %)
+        lcd_parts = []
+        if args.lcd_split > 1 and P % args.lcd_split == 0 and args.streams == 2:
+            for _ in range(args.lcd_split - 1):
+                st_ = torch.cuda.Stream()
+                lcd_parts.append((api.DeepLCD(synth.calc_weights(), stream=st_.cuda_stream), st_, torch.cuda.Event()))
+            ev_lfork = torch.cuda.Event()
         if args.lcd_skip:
             lcd.set_option(lcd.OPT_SKIP_KERNELS, args.lcd_skip)
         d_descr = torch.zeros(P, 1064, device=dev)
@@ -513,7 +522,19 @@ def main():
 
     def side_chain(with_ba=True):
         if use_lcd and "lcd" not in skip:
-            lcd.describe_batch(cur["imgs"].data_ptr(), P, H, W, W, H * W, d_descr.data_ptr(), blur_in_place=False)
+            if lcd_parts:
+                n_part = P // (len(lcd_parts) + 1)
+                ev_lfork.record(side_stream)
+                for i, (h_, st_, ev_) in enumerate(lcd_parts):
+                    st_.wait_event(ev_lfork)
+                    h_.describe_batch(cur["imgs"].data_ptr() + (i + 1) * n_part * H * W, n_part, H, W, W, H * W,
+                                      d_descr.data_ptr() + (i + 1) * n_part * 1064 * 4, blur_in_place=False)
+                    ev_.record(st_)
+                lcd.describe_batch(cur["imgs"].data_ptr(), n_part, H, W, W, H * W, d_descr.data_ptr(), blur_in_place=False)
+                for _, _, ev_ in lcd_parts:
+                    side_stream.wait_event(ev_)
+            else:
+                lcd.describe_batch(cur["imgs"].data_ptr(), P, H, W, W, H * W, d_descr.data_ptr(), blur_in_place=False)
         if use_lcd and "db" not in skip:
             if world > 1:       # every shard scores every rank's queries; the 16-byte candidate records are merged after an all-gather
                 if via_cpu:
