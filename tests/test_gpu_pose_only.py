@@ -64,3 +64,30 @@ def test_pose_only_batch(api, oracle, synth):
         rp, rout, rni = oracle.pose_only_optimize(p[0], p[1], p[2], p[3])
         assert np.allclose(d[0][b].cpu().numpy(), rp, rtol=1e-8, atol=1e-9) and int(ni[b]) == rni
         assert np.array_equal(out[b, :cnt[b]].cpu().numpy().astype(bool), rout)
+
+
+@pytest.mark.parametrize("cap,frames", [(200, 80), (600, 70), (1500, 64), (3000, 66)])
+def test_pose_only_block_sizes(api, oracle, synth, cap, frames):
+    """The kernel runs 64 / 128 / 256 / 512 threads per frame by batch size and match capacity (csrc/ba.hip pose_only_launch): the edge ->
+    thread map and so the summation order differ, the answer may not — every block size against the oracle, and a frame of a many-frame
+    batch (small blocks) against the same frame alone (the latency choice)."""
+    import torch
+    n = cap - 7
+    probs = [_problem(synth, oracle, 40 + b, n, n // 12) for b in range(3)]
+    poses = np.stack([probs[b % 3][0] for b in range(frames)]); pts = np.zeros((frames, cap, 3)); obs = np.zeros((frames, cap, 2))
+    for b in range(frames):
+        pts[b, :n] = probs[b % 3][1]; obs[b, :n] = probs[b % 3][2]
+    cnt = np.full(frames, n, np.int32)
+    d = [torch.from_numpy(x).cuda() for x in (poses, pts, obs, cnt)]
+    out = torch.zeros(frames, cap, dtype=torch.uint8, device="cuda"); ni = torch.zeros(frames, dtype=torch.int32, device="cuda"); st = torch.ones(frames, dtype=torch.int32, device="cuda")
+    api.pose_only_optimize_batch(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), frames, cap, probs[0][3], 5.991, 4, 10,
+                                 out.data_ptr(), ni.data_ptr(), st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert (st.cpu().numpy() == 0).all()
+    bp = d[0].cpu().numpy(); bo = out.cpu().numpy()[:, :n].astype(bool); bn = ni.cpu().numpy()
+    for b in range(3):
+        rp, rout, rni = oracle.pose_only_optimize(*probs[b][:4])
+        sp, sout, sni = api.pose_only_optimize(*probs[b][:4])                     # one frame per call: the other block size
+        for gp, gout, gn in ((bp[b], bo[b], bn[b]), (sp, sout, sni)):
+            assert np.allclose(gp, rp, rtol=1e-8, atol=1e-9) and gn == rni and np.array_equal(gout, rout)
+        assert np.array_equal(bp[b], bp[b + 3]) and np.array_equal(bo[b], bo[b + 3])       # the same frame twice in one batch: the same bits
