@@ -152,8 +152,8 @@ def pmc_lookup(pmc, slot):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (default 200 = 1.4 s of work: the fill and drain of the three-step pipeline are 0.6 % of a 50-step run)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=512, help="stereo pairs per step per GPU")
     ap.add_argument("--workload", default="full", choices=["full", "orb_match", "orb_match_lcd", "full_solve", "latency"])
     ap.add_argument("--db", type=int, default=0, help="key-frame database size (default 10000, or 6250 per GPU when sharded)")
