@@ -31,8 +31,9 @@ import numpy as np
 
 # The ROCm runtime multiplexes HIP streams onto GPU_MAX_HW_QUEUES (default 4) HSA hardware queues, and streams that share a queue
 # serialise — a host->device copy on one of them stalls the kernels of the other (measured: the streamed pass ran at copy + compute
-# instead of max(copy, compute)).  The default schedule uses 5 streams (two extractor handles, match, LCD / BA chain, input copies):
-# one hardware queue each.  A runtime setting of the application, stated in the JSON (config.hip_hw_queues); the library reads no
+# instead of max(copy, compute)).  The default schedule uses 6 streams (two extractor handles, match + BA build, DeepLCD + DB scan, two
+# input-copy streams: the left and the right images of a streamed step cross PCIe as two concurrent copies): one hardware queue each
+# (4, 5 and 6 queues measure the same on the resident pass).  A runtime setting of the application, stated in the JSON (config.hip_hw_queues); the library reads no
 # environment variable.  Must be set before the HIP runtime initialises (i.e. before `import torch`).
 def _ranks_wanted():
     if "WORLD_SIZE" in os.environ:
@@ -55,7 +56,7 @@ def _small_batch():
 
 # N > 1: torch's process group brings one more stream (the collectives' own) — one more queue; small batches run on up to 16 lanes, and
 # lanes that share a hardware queue serialise (8 pairs per step, 16 lanes: 17.1 k frames/s on 8 queues, 19.0 k on 16, 26.5 k on 24)
-HW_QUEUES = os.environ.setdefault("GPU_MAX_HW_QUEUES", ("24" if _small_batch() else "5") if _ranks_wanted() == 1 else "6")
+HW_QUEUES = os.environ.setdefault("GPU_MAX_HW_QUEUES", ("24" if _small_batch() else "6") if _ranks_wanted() == 1 else "7")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -190,6 +191,7 @@ def parse():
                          "latency-bound; 0 = eager launches on the four-stream schedule; -1 (default) = 1 when --pairs <= 64 on one GPU, else 0.  The "
                          "other mode is timed in an extra pass (`step_graph` / `step_eager`)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes of --graph 1 (0 = 16 for <= 16 pairs per step, 8 up to 64, else 4)")
+    ap.add_argument("--stream-split", type=int, default=2, help="streamed pass: the left and the right images of a step as separate copies with an event each, on this many copy streams (0 = one copy of the whole batch; 2 (default): 56.9-57.1 k frames/s against 51.6-54.1 k; 4: 53-55.6 k)")
     ap.add_argument("--lcd-split", type=int, default=1, help="the DeepLCD chain of a step in this many parts on as many handles / streams (1 = one chain on the side stream)")
     ap.add_argument("--ba-stream", choices=["side", "match"], default="match", help="the BA block build behind the triangulation on the match stream (default: +0.4 %, three alternating runs) or behind the DB scan on the side stream")
     ap.add_argument("--side-cus", type=int, default=0, help="experiment: the DeepLCD / DB / BA stream may use only this many CUs (hipExtStreamCreateWithCUMask); 0 = all")
@@ -620,7 +622,9 @@ def main():
                                 P, cap, d_midx.data_ptr(), d_mdist.data_ptr(), stream)
         api.triangulate_stereo_batch(d_kps.data_ptr(), d_kps.data_ptr() + P * cap * 28, d_midx.data_ptr(), d_cnt.data_ptr(), P, cap,
                                      Kt, K["bf"] / K["fx"], d_xyz.data_ptr(), d_ok.data_ptr(), stream)
-        with torch.cuda.stream(side_stream):
+        if side_stream is not main_stream:
+            side_stream.wait_stream(main_stream)            # a joined step starts behind everything issued before it (found by --verify on two
+        with torch.cuda.stream(side_stream):                # ranks sharing a GPU: the zeroing of the outputs raced with this chain)
             side_chain()
         if side_stream is not main_stream:
             main_stream.wait_stream(side_stream)            # a step is complete when both chains are
@@ -767,6 +771,9 @@ def main():
         sC = torch.cuda.Stream()
         readers = [main_stream] + orb_streams + ([side_stream] if side_stream is not main_stream else [])
         ev_ready = [torch.cuda.Event() for _ in range(NBUF)]
+        ev_ready2 = [torch.cuda.Event() for _ in range(NBUF)]
+        sCs = [sC] + [torch.cuda.Stream() for _ in range(max(0, args.stream_split - 1))]
+        ev_piece = [[torch.cuda.Event(), torch.cuda.Event()] for _ in range(NBUF)]
         ev_read = [[torch.cuda.Event() for _ in readers] for _ in range(NBUF)]
         bytes_step = h_bat[0].numel()
         k_stream = [0]
@@ -779,12 +786,38 @@ def main():
                 sC.wait_event(e)                    # the readers of step k - NBUF (same buffer) have finished: level 0 is read in place
             ec = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ec[0].record(sC)
-            with torch.cuda.stream(sC):
-                d_in[b].copy_(h_bat[k % NBAT], non_blocking=True)
-            ec[1].record(sC); copy_ev.append(ec)
-            ev_ready[b].record(sC)
-            for st in readers:
-                st.wait_event(ev_ready[b])
+            if args.stream_split and args.pipeline and S == 2:
+                # the left images (extractor handle A, DeepLCD) and the right images (handle B) arrive as separate copies with an event each —
+                # handle A starts when ITS half is there — on `stream_split` copy streams (1: both on one; 2: one each; 4: two each):
+                # concurrent copies use more of the link (one stream sustains 51 GB/s, two 53)
+                hb = h_bat[k % NBAT]
+                nC = len(sCs)
+                per = max(1, nC // 2)                       # copy streams per half
+                for half in range(2):
+                    lo, hi = half * P, (half + 1) * P
+                    cs = [sCs[(half * per + j) % nC] for j in range(per)]
+                    for j, c in enumerate(cs):
+                        if c is not sC:
+                            for e in ev_read[b]:
+                                c.wait_event(e)
+                        a0, a1 = lo + (hi - lo) * j // per, lo + (hi - lo) * (j + 1) // per
+                        with torch.cuda.stream(c):
+                            d_in[b][a0:a1].copy_(hb[a0:a1], non_blocking=True)
+                    evh = ev_ready[b] if half == 0 else ev_ready2[b]
+                    for c in cs[1:]:                        # the half is ready when all of its pieces are
+                        ev_piece[b][half].record(c); cs[0].wait_event(ev_piece[b][half])
+                    evh.record(cs[0])
+                sC.wait_event(ev_ready2[b])
+                ec[1].record(sC); copy_ev.append(ec)
+                for st in readers:
+                    st.wait_event(ev_ready2[b] if st is orb_streams[0] else ev_ready[b])
+            else:
+                with torch.cuda.stream(sC):
+                    d_in[b].copy_(h_bat[k % NBAT], non_blocking=True)
+                ec[1].record(sC); copy_ev.append(ec)
+                ev_ready[b].record(sC)
+                for st in readers:
+                    st.wait_event(ev_ready[b])
             cur["imgs"] = d_in[b]
             step()
             for e, st in zip(ev_read[b], readers):
@@ -819,7 +852,7 @@ def main():
                     "h2d_GBps": bytes_step * args.steps / dt_s / 1e9, "h2d_bytes_per_step": bytes_step, "distinct_batches": NBAT,
                     "host_render_s": t_gen, "h2d_copy_ms_avg": float(np.mean([a.elapsed_time(b) for a, b in copy_ev])),
                     "note": "every step extracts images that crossed PCIe for that step: consecutive frames of the synthetic stream in pinned host "
-                            "memory, one host->device copy per step on a copy stream, three device input buffers (a buffer is overwritten only after "
+                            "memory, the left and the right images as two concurrent host->device copies per step (two copy streams), three device input buffers (a buffer is overwritten only after "
                             "every reader of the step that used it has finished — level 0 is read in place)"}
 
     # ---- pass 5: configs[3] read strictly — every frame is a key-frame, the solve runs on every frame's window ----
