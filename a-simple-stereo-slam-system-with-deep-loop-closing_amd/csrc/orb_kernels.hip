@@ -1482,7 +1482,9 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
     MYSLAM_SIDE_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int t = threadIdx.x;
-    const int level = blockIdx.x, b = blockIdx.y;
+    // images along x, levels along y: blocks are dispatched x-fastest, so all level-0 blocks (a third of the candidates sit there) start first
+    // and the launch ends on the small top levels, not on a few long blocks
+    const int level = blockIdx.y, b = blockIdx.x;
     const LevelGeom& g = P.lv[level];
     const int NC = NCmax;
 
@@ -2504,9 +2506,9 @@ void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCo
     // (a grid limit as in launch_describe was measured for this kernel too, round 4: 1 / 2 / 3 blocks per CU gave 7.27 / 7.11 / 7.15 ms per step
     // against 7.11 unlimited, and the loop itself cost 0.1 ms — not built in)
     if (batch >= OCT_WIDE_BELOW)
-        hipLaunchKernelGGL(k_octree<256>, dim3(P.nlevels, batch), dim3(256), lds, s, P, cand, candCount, sortbuf, octTab, selOut, selCount, status, ncmax);
+        hipLaunchKernelGGL(k_octree<256>, dim3(batch, P.nlevels), dim3(256), lds, s, P, cand, candCount, sortbuf, octTab, selOut, selCount, status, ncmax);
     else
-        hipLaunchKernelGGL(k_octree<512>, dim3(P.nlevels, batch), dim3(512), lds, s, P, cand, candCount, sortbuf, octTab, selOut, selCount, status, ncmax);
+        hipLaunchKernelGGL(k_octree<512>, dim3(batch, P.nlevels), dim3(512), lds, s, P, cand, candCount, sortbuf, octTab, selOut, selCount, status, ncmax);
 }
 
 void launch_describe(const OrbPlan& P, const uint8_t* pyr, const uint8_t* blur, size_t pyrStride, const uint32_t* selOut,
