@@ -25,10 +25,11 @@ bool resize_uses_strips(const ResizeArgs& a);
 void launch_fast(const OrbPlan& P, const uint8_t* pyr, size_t pyrStride, const uint8_t* maskPyr, uint32_t* cand,
                  int32_t* candCount, const uint32_t* statPrev, uint32_t* statCur, int forceMode, int batch, hipStream_t s);
 void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCount, uint32_t* sortbuf, const uint32_t* octTab, uint32_t* selOut,
-                   int32_t* selCount, int32_t* status, int batch, hipStream_t s);
+                   int32_t* selCount, int32_t* status, int batch, uint16_t* order, hipStream_t s);
+bool describe_uses_tile_order(bool have_order, int detectOnly, int batch);
 void launch_describe(const OrbPlan& P, const uint8_t* pyr, const uint8_t* blur, size_t pyrStride, const uint32_t* selOut,
                      const int32_t* selCount, myslam_keypoint* kps, uint8_t* desc, int32_t* counts, int32_t* status,
-                     int cap, int detectOnly, int batch, uint16_t* order, int blocks_per_cu, hipStream_t s);
+                     int cap, int detectOnly, int batch, uint16_t* order, bool order_ready, int blocks_per_cu, hipStream_t s);
 void launch_screen(const OrbPlan& P, const uint8_t* pyr, myslam_keypoint* kin, int n, myslam_keypoint* kout, uint8_t* keep,
                    hipStream_t s);
 void launch_calc_desc(const OrbPlan& P, const uint8_t* blur, const myslam_keypoint* kps, int n, uint8_t* desc, hipStream_t s);
@@ -457,7 +458,9 @@ int myslam_orb::run_batch(const uint8_t* d_imgs, int batch, int r, int c, int st
     if (fork && aux_mode != 2 && (rc = fork_blur())) return rc;
     {
         ScopedProf sp(P_OCTREE, stream);
-        launch_octree(P, d_cand, d_candCount, d_sort, d_octTab, d_sel, d_selCount, stat, batch, stream);
+        // the descriptor kernel's processing order is written by the oct-tree blocks themselves (one launch less on the chain)
+        launch_octree(P, d_cand, d_candCount, d_sort, d_octTab, d_sel, d_selCount, stat, batch,
+                      describe_uses_tile_order(d_order != nullptr, detectOnly ? 1 : 0, batch) ? d_order : nullptr, stream);
     }
     if (stop == 3) return MYSLAM_OK;
     if (fork) MYSLAM_HIP_CHECK(hipStreamWaitEvent(stream, evJoin, 0));
@@ -466,7 +469,7 @@ int myslam_orb::run_batch(const uint8_t* d_imgs, int batch, int r, int c, int st
     {
         ScopedProf sp(P_DESC, stream);
         launch_describe(P, d_pyr, d_blur, full.pyrBytes, d_sel, d_selCount, d_kps, d_desc, d_counts, stat, cap,
-                        detectOnly ? 1 : 0, batch, d_order, optSideBlocksPerCu, stream);
+                        detectOnly ? 1 : 0, batch, d_order, true, optSideBlocksPerCu, stream);
     }
     MYSLAM_HIP_CHECK(hipGetLastError());
     return MYSLAM_OK;

@@ -1471,6 +1471,16 @@ __device__ __forceinline__ uint32_t half_row_max_u32(uint32_t v) {
     return v;
 }
 
+// tile bin of a selected key for the descriptor kernel's processing order (k_sel_order and phase E of k_octree): column high bits | Z-order of
+// the low 4 + 4 tile bits
+__device__ __forceinline__ int sel_order_bin(uint32_t pay, int ts) {
+    const int tx = (int)((pay >> 8) & 0xfff) >> ts, ty = (int)(pay >> 20) >> ts;
+    int z = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) z |= (((tx >> k) & 1) << (2 * k)) | (((ty >> k) & 1) << (2 * k + 1));
+    return ((tx >> 4) << 8) | z;
+}
+
 constexpr int OCT_WIDE_BELOW = 64;      // batches smaller than this run 512-thread blocks
 constexpr int OCT_FL = 4;              // candidates in flight per thread in the two candidate passes (8: same time, batched and one-frame)
 template <int OT>
@@ -1478,7 +1488,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
                                                const int32_t* __restrict__ candCount, uint32_t* __restrict__ sortbuf,
                                                const uint32_t* __restrict__ octTab,
                                                uint32_t* __restrict__ selOut, int32_t* __restrict__ selCount,
-                                               int32_t* __restrict__ status, int NCmax) {
+                                               int32_t* __restrict__ status, int NCmax, uint16_t* __restrict__ order) {
     MYSLAM_SIDE_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int t = threadIdx.x;
@@ -1873,6 +1883,41 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
         }
     }
     if (t == 0) *myCount = min(m, g.nodeCap);
+    // ---- E (batches): the descriptor kernel's processing order of this level's keys — Z-order of small pixel tiles, a counting sort over
+    // <= 1024 tile bins (what the separate k_sel_order launch computes for other callers; fused here: one launch boundary less on the
+    // extractor's chain).  The counting-sort buckets of phase B are free by now.
+    if (order) {
+        __threadfence_block();
+        __syncthreads();
+        int* s_hist = reinterpret_cast<int*>(s_cursor);                    // OT_MAXB = 1024 bins
+        int* s_ws = reinterpret_cast<int*>(s_w);                           // 4 wave totals
+        const int n = min(m, g.nodeCap);
+        int ts = 4;
+        while ((g.w >> ts) >= 64 || (g.h >> ts) >= 16) ts++;
+        uint16_t* ord = order + (size_t)b * P.totalOut + g.outBase;
+        for (int i = t; i < 1024; i += OT) s_hist[i] = 0;
+        __syncthreads();
+        // (the keys were stored by other lanes of this block a moment ago: read them back at agent scope, not through this CU's L1)
+        for (int i = t; i < n; i += OT) atomicAdd(&s_hist[sel_order_bin(__hip_atomic_load(&out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), ts)], 1);
+        __syncthreads();
+        int base = 0, v0 = 0, v1 = 0, v2 = 0, v = 0, incl = 0;
+        if (t < 256) {                                                     // exclusive scan: 4 consecutive bins per thread of the first four waves
+            v0 = s_hist[4 * t]; v1 = s_hist[4 * t + 1]; v2 = s_hist[4 * t + 2];
+            v = v0 + v1 + v2 + s_hist[4 * t + 3];
+            incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int nb = __shfl_up(incl, o, 64); if ((t & 63) >= o) incl += nb; }
+            if ((t & 63) == 63) s_ws[t >> 6] = incl;
+        }
+        __syncthreads();
+        if (t < 256) {
+            base = incl - v;
+            for (int w = 0; w < (t >> 6); w++) base += s_ws[w];
+            s_hist[4 * t] = base; s_hist[4 * t + 1] = base + v0; s_hist[4 * t + 2] = base + v0 + v1; s_hist[4 * t + 3] = base + v0 + v1 + v2;
+        }
+        __syncthreads();
+        for (int i = t; i < n; i += OT) ord[atomicAdd(&s_hist[sel_order_bin(__hip_atomic_load(&out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), ts)], 1)] = (uint16_t)i;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2029,13 +2074,7 @@ __global__ __launch_bounds__(256) void k_sel_order(OrbPlan P, const uint32_t* __
     uint16_t* out = order + (size_t)b * P.totalOut + g.outBase;
     for (int i = t; i < NB; i += 256) s_hist[i] = 0;
     __syncthreads();
-    auto bin_of = [&](uint32_t pay) -> int {
-        const int tx = (int)((pay >> 8) & 0xfff) >> ts, ty = (int)(pay >> 20) >> ts;
-        int z = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) z |= (((tx >> k) & 1) << (2 * k)) | (((ty >> k) & 1) << (2 * k + 1));
-        return ((tx >> 4) << 8) | z;
-    };
+    auto bin_of = [&](uint32_t pay) -> int { return sel_order_bin(pay, ts); };
     for (int i = t; i < n; i += 256) atomicAdd(&s_hist[bin_of(sel[i])], 1);
     __syncthreads();
     {   // exclusive scan of the bins: 4 consecutive bins per thread, wave scans, 4 wave totals
@@ -2493,7 +2532,7 @@ void launch_fast(const OrbPlan& P, const uint8_t* pyr, size_t pyrStride, const u
 size_t octree_lds_bytes(int nodeCap) { return 192 + 4 * (size_t)OT_MAXB + 4 * (size_t)(OT_MAXB + 2) + (size_t)nodeCap * 54 + 16; }
 
 void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCount, uint32_t* sortbuf, const uint32_t* octTab, uint32_t* selOut,
-                   int32_t* selCount, int32_t* status, int batch, hipStream_t s) {
+                   int32_t* selCount, int32_t* status, int batch, uint16_t* order, hipStream_t s) {
     // one launch for all levels: the small levels fill the gaps the large ones leave
     int ncmax = 0;
     for (int l = 0; l < P.nlevels; l++) ncmax = max(ncmax, P.lv[l].nodeCap);
@@ -2506,19 +2545,21 @@ void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCo
     // (a grid limit as in launch_describe was measured for this kernel too, round 4: 1 / 2 / 3 blocks per CU gave 7.27 / 7.11 / 7.15 ms per step
     // against 7.11 unlimited, and the loop itself cost 0.1 ms — not built in)
     if (batch >= OCT_WIDE_BELOW)
-        hipLaunchKernelGGL(k_octree<256>, dim3(batch, P.nlevels), dim3(256), lds, s, P, cand, candCount, sortbuf, octTab, selOut, selCount, status, ncmax);
+        hipLaunchKernelGGL(k_octree<256>, dim3(batch, P.nlevels), dim3(256), lds, s, P, cand, candCount, sortbuf, octTab, selOut, selCount, status, ncmax, order);
     else
-        hipLaunchKernelGGL(k_octree<512>, dim3(batch, P.nlevels), dim3(512), lds, s, P, cand, candCount, sortbuf, octTab, selOut, selCount, status, ncmax);
+        hipLaunchKernelGGL(k_octree<512>, dim3(batch, P.nlevels), dim3(512), lds, s, P, cand, candCount, sortbuf, octTab, selOut, selCount, status, ncmax, order);
 }
+
+bool describe_uses_tile_order(bool have_order, int detectOnly, int batch) { return have_order && !detectOnly && batch >= 8; }
 
 void launch_describe(const OrbPlan& P, const uint8_t* pyr, const uint8_t* blur, size_t pyrStride, const uint32_t* selOut,
                      const int32_t* selCount, myslam_keypoint* kps, uint8_t* desc, int32_t* counts, int32_t* status,
-                     int cap, int detectOnly, int batch, uint16_t* order, int blocks_per_cu, hipStream_t s) {
+                     int cap, int detectOnly, int batch, uint16_t* order, bool order_ready, int blocks_per_cu, hipStream_t s) {
     const int slots = min(cap, P.totalOut);
     const int nchunk = (slots + KD_KPB - 1) / KD_KPB;
     // the tile-order permutation pays when thousands of windows compete for L1 / L2; a handful of images is a few dozen blocks: list order
-    const bool tiled = order && !detectOnly && batch >= 8;
-    if (tiled) hipLaunchKernelGGL(k_sel_order, dim3(P.nlevels, batch), dim3(256), 0, s, P, selOut, selCount, order, batch);
+    const bool tiled = describe_uses_tile_order(order != nullptr, detectOnly, batch);
+    if (tiled && !order_ready) hipLaunchKernelGGL(k_sel_order, dim3(P.nlevels, batch), dim3(256), 0, s, P, selOut, selCount, order, batch);
     const int total = nchunk * batch;
     const int grid = blocks_per_cu > 0 ? min(total, 256 * blocks_per_cu) : total;       // MYSLAM_ORB_OPT_SIDE_BLOCKS_PER_CU
     hipLaunchKernelGGL(k_describe2, dim3(grid), dim3(256), 0, s, P, pyr, blur, pyrStride, selOut, selCount,
