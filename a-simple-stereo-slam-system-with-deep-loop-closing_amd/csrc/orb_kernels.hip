@@ -2533,7 +2533,8 @@ size_t octree_lds_bytes(int nodeCap) { return 192 + 4 * (size_t)OT_MAXB + 4 * (s
 
 void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCount, uint32_t* sortbuf, const uint32_t* octTab, uint32_t* selOut,
                    int32_t* selCount, int32_t* status, int batch, uint16_t* order, hipStream_t s) {
-    // one launch for all levels: the small levels fill the gaps the large ones leave
+    // one launch for all levels, grid (image, level): dispatched x-fastest, the long level-0 blocks all start first and the small levels fill
+    // the gaps at the end (with the level along x the launch ended on the last images' level-0 blocks: 0.37 instead of 0.22 ms per 512 images)
     int ncmax = 0;
     for (int l = 0; l < P.nlevels; l++) ncmax = max(ncmax, P.lv[l].nodeCap);
     const size_t lds = octree_lds_bytes(ncmax);
