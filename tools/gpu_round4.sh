@@ -15,3 +15,8 @@ rm -rf gpurun_out/prof_$TAG
 f=$(find gpurun_out/prof1_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/kernel_stats_1stream_$TAG.csv && head -8 "$f"
 rm -rf gpurun_out/prof1_$TAG
 timeout 600 python bench.py --workload latency > gpurun_out/latency_$TAG.json 2> gpurun_out/latency_$TAG.err; echo "latency rc=$?"
+# the timed region alone under rocprofv3 (warm-up + K pipelined steps, no other pass): its per-kernel averages are the per-launch durations the
+# bench line's roofline objects quote from the HIP events of pass 2
+( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/proft_$TAG -o orb -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --parity-frames 0 --no-extra-passes --graph 0 --stream-input 0 > $GRAFT_REPO_ROOT/gpurun_out/proft_$TAG.json 2> $GRAFT_REPO_ROOT/gpurun_out/proft_$TAG.err )
+f=$(find gpurun_out/proft_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/kernel_stats_timed_$TAG.csv && head -4 "$f" | cut -c1-40,180-320
+rm -rf gpurun_out/proft_$TAG
