@@ -916,13 +916,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
     uint32_t* const s_recz = reinterpret_cast<uint32_t*>(s_tile);
     __shared__ int s_ini[G], s_wc[G], s_nlist, s_npair, s_ncorner;
     // LDS footprint on purpose (1241 x 376: cells of at most 32 x 40 pixels): a block of this instance needs 22.4 KB, seven would fit a CU — and
-    // with seven waves per SIMD FAST holds 504 of the 512 registers per lane, nothing of the other streams can move in (measured: FAST alone 3 %
-    // faster, the pipelined step 1 % slower).  Padded to just over 160 KB / 7 it stays at six blocks, which leaves 22 KB of LDS and 80 registers per
-    // lane free: together with what ONE retiring FAST block frees, a conv2 block (43.5 KB) or a descriptor / oct-tree block fits at once
-    // instead of waiting for the launch to drain (+1.5 % frames/s; the 25.1 KB instance left 9 KB: only blur / resize blocks fitted).
+    // with seven waves per SIMD FAST holds 504 of the 512 registers per lane (measured: FAST alone 3 % faster, the pipelined step 1 % slower).
+    // Six blocks it is; the question is what the remaining LDS of a CU is open to.  History: 25.1 KB per block (9 KB free: only blur / resize
+    // blocks fitted) -> round 3: just over 160 KB / 7 = 23.7 KB (22 KB free: a descriptor, conv1 or conv2 block moves in beside six FAST
+    // blocks, +1.5 % then) -> end of round 4: 160 KB / 6 - 128 = 27.2 KB, NOTHING with LDS beside six FAST blocks.  Since the descriptor
+    // kernel runs as a limited grid and the oct-tree kernel no longer ends on its long blocks, the kernels of the other streams find their
+    // CUs where FAST blocks retire; a block that squeezes in beside six FAST blocks only slows the launch the whole step waits for
+    // (block size 27.2 / 26.0 / 25.0 / 24.4 / 23.7 KB: 75.0 / 74.3 / 74.5 / 73.9 / 74.3 k frames/s, two runs each on one box).
     constexpr int LDS_EST = TROWS * TP + 16 + G * (SROWS * SP + 16) + 2 * NPAIR + 64;
-    constexpr int LDS_PAD = (CW <= 32 && LDS_EST < 163840 / 7) ? 163840 / 7 + 256 - LDS_EST : 4;
-    static_assert(CW > 32 || 6 * (LDS_EST + LDS_PAD) + 21504 <= 163840, "six blocks + one descriptor block per CU");
+    constexpr int LDS_PAD = (CW <= 32 && LDS_EST < 163840 / 7) ? 163840 / 6 - 128 - LDS_EST : 4;
+    static_assert(CW > 32 || (6 * (LDS_EST + LDS_PAD) <= 163840 && 7 * (LDS_EST + LDS_PAD) > 163840), "exactly six blocks per CU");
     __shared__ volatile uint8_t s_padx[LDS_PAD]; s_padx[threadIdx.x & 1] = 0;
 
     // XCD-aware block order (bijective remap of the 1-D grid): the dispatcher places block i on XCD i % 8 and every XCD has a private

@@ -1,3 +1,4 @@
+# pairs-per-step curve of the bench line (resident input): tools/pairs_sweep_r4.sh
 for P in 8 16 32 64 128 256; do
   timeout 600 python bench.py --pairs $P --steps $((P >= 128 ? 100 : 400)) --warmup 5 --no-cpu-baseline --stream-input 0 > gpurun_out/sweep_$P.json 2> gpurun_out/sweep_$P.err || { echo "pairs $P failed"; tail -3 gpurun_out/sweep_$P.err; continue; }
   python -c "
