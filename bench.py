@@ -671,7 +671,7 @@ def main():
     lanes = []
     can_graph = world == 1
     use_graph = can_graph and (args.graph == 1 or (args.graph < 0 and P <= 64))
-    n_lanes = args.lanes if args.lanes > 0 else (16 if P <= 16 else 8 if P <= 64 else 4)
+    n_lanes = args.lanes if args.lanes > 0 else (16 if P <= 32 else 8 if P <= 64 else 4)       # measured: 32 pairs 70.5 k on 16 lanes, 68.1 k on 8; 64 pairs 72.4 k on 8 or 12, 71.4 k on 16
 
     def build_lane():
         st = torch.cuda.Stream(); s_ = st.cuda_stream
