@@ -720,6 +720,15 @@ void blur_mfma_ident(std::vector<uint4>& tab, size_t& offI) {
 #define FAST_RING_X {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1}
 #define FAST_RING_Y {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3}
 
+// Profiling builds only (tools/fast_phase_pmc.sh): MYSLAM_FAST_PHASE = n truncates the DENSE path of the strip kernel after phase n so that
+// the hardware counters of consecutive builds difference into per-phase instruction counts.  1: block decode + staging + score-map
+// clearing; 2: + the scoring loop's control and window loads (score replaced by an XOR over the 24 window dwords); 3: + the byte-pair
+// picks (score = XOR over the 17 picks of a pixel pair); 4: + the min / max network (= the whole scoring phase); 5: + NMS and the
+// strip's record list; 0 (the product): + path statistics, filter and global append.
+#ifndef MYSLAM_FAST_PHASE
+#define MYSLAM_FAST_PHASE 0
+#endif
+
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ s16x2 pmin(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ s16x2 pmax(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
@@ -758,6 +767,9 @@ __device__ __forceinline__ s16x2 fast9_score_pair(const uint32_t (&r)[NR][3], s1
     s16x2 p[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) p[i] = pick(ROW + 3 + RY[i], xc + RX[i]);
+#if MYSLAM_FAST_PHASE == 3
+    { s16x2 x = vv ^ thv; for (int i = 0; i < 16; i++) x = x ^ p[i]; return x; }
+#endif
     s16x2 n2[8], x2[8], n4[8], x4[8], ub[8], ud[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) { n2[k] = pmin(p[2 * k], p[2 * k + 1]); x2[k] = pmax(p[2 * k], p[2 * k + 1]); }
@@ -965,8 +977,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
     const bool ext = level == 0 && b < P.ext0N;                      // level 0 read in place (block-uniform)
     const uint8_t* img = ext ? P.ext0 + (size_t)b * P.ext0Stride : pyr + (size_t)b * pyrStride + g.imgOff;
     const int ipitch = ext ? P.ext0Pitch : g.pitch;
-    {   // all loads of a thread are issued before its LDS stores.  Unaligned 16-byte loads (a cell starts at any column); a load may run up
-        // to 15 bytes past its row or, in the last row of the last plane, into the slack behind the pyramid block — those bytes are never used
+    if constexpr (G * NQC <= 16) {
+        // all loads of a thread are issued before its LDS stores.  Unaligned 16-byte loads (a cell starts at any column); a load may run up
+        // to 15 bytes past its row or, in the last row of the last plane, into the slack behind the pyramid block — those bytes are never used.
+        // 16 lanes per tile row (G * NQC of them busy): (row, cell, 16-byte group) of a lane are bit fields of the thread index and its rows
+        // are 16 apart — no division, one address increment per load (round 5: the index arithmetic of three loads was 66 of the ~120 vector
+        // instructions a wave spent before the first barrier)
+        constexpr int CPR = G * NQC, NIT = (TROWS + 15) / 16;
+        const int col = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+        const int c = col / NQC, k = col - c * NQC;
+        const int x = iniX0 + c * g.wCell + 16 * k;
+        const bool lane_on = col < CPR && c < ncell, in_row = x < ipitch;
+        const uint8_t* src = img + (size_t)(iniY + r0) * ipitch + x;
+        uint4 v[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; u++) {
+            if (lane_on && in_row && r0 + 16 * u < hr) {
+                uint4 t;
+                __builtin_memcpy(&t, src + (size_t)(16 * u) * ipitch, 16);
+                v[u] = t;
+            } else v[u] = make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; u++)
+            if (lane_on && r0 + 16 * u < hr) *reinterpret_cast<uint4*>(&s_tile[(r0 + 16 * u) * TP + 16 * col]) = v[u];      // c * CP + 16 k = 16 col
+    } else {
         constexpr int NIT = (TROWS * G * NQC + T - 1) / T;
         uint4 v[NIT];
 #pragma unroll
@@ -1001,15 +1036,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
         dense = ctl.force >= 0 ? ctl.force != 0 : (pt > 0.f && (was_dense ? ps > 0.165f * pt : ps > 0.41f * pt));
     }
     __syncthreads();
+#if MYSLAM_FAST_PHASE == 1
+    if (dense) return;
+#endif
 
     const s16x2 thv = {(short)P.minTh, (short)P.minTh};
     const int zoff = P.minTh - 1;                                      // the score map holds z = score - zoff
     // work item = 4 pixels x 2 rows
     const int hc2 = (hc + 1) >> 1;
     const int ngr = (g.wCell + 3) >> 2, per_cell = ngr * hc2, nitems = ncell * per_cell;
-    // q -> (cell c, row pair cy2, 4-pixel group gi) without integer division: q < 2^12, so a float reciprocal + one fix-up is exact
-    const float inv_pc = 1.0f / (float)per_cell, inv_ngr = 1.0f / (float)ngr;
-    auto split = [&](int q, int& c, int& cy, int& gi) __attribute__((always_inline)) {
+    // q -> (cell c, row pair cy2, 4-pixel group gi) without integer division: q < 2^12, so a float reciprocal + one fix-up is exact.
+    // (Used by the two-phase path and by plans with cells wider than 32 pixels; the dense path of the usual plans maps by bit fields, below.)
+    auto split = [&](int q, float inv_pc, float inv_ngr, int& c, int& cy, int& gi) __attribute__((always_inline)) {
         c = (int)(((float)q + 0.5f) * inv_pc);
         int rem = q - c * per_cell;
         if (rem < 0) { c--; rem += per_cell; } else if (rem >= per_cell) { c++; rem -= per_cell; }
@@ -1043,14 +1081,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
         }
     };
 
+    // Cells of at most 32 x CH pixels in strips of 4 (every level of a 1241 x 376 plan): eight 4-pixel groups span a cell row, so an item
+    // index is the bit fields  group | cell << 3 | row block << 5  — a lane keeps its (cell, group) for the whole launch, its items are
+    // 8 row blocks apart, and the loops carry one add.  (Round 5, from the per-phase counter split profiles/r05_fast_phase_valu.json: the
+    // float-reciprocal decomposition, its two divisions and the carry chain that advanced it cost ~150 of the ~1 300 vector instructions of a wave.)
+    constexpr bool BITMAP = CW <= 32 && G == 4;
     if (!dense) {
+        const float inv_pc = 1.0f / (float)per_cell, inv_ngr = 1.0f / (float)ngr;
         // ---- 1. compass pre-test, surviving pixel pairs -> s_pairs ----
         for (int q0 = 0; q0 < nitems; q0 += T) {                       // uniform trip count: the wave-wide scan needs every lane
             const int q = q0 + threadIdx.x;
             int pm = 0, c = 0, cy = 0, cx = 0;                         // pm bit 2 r + k: pair k of row cy + r survives
             if (q < nitems) {
                 int cy2, gi;
-                split(q, c, cy2, gi);
+                split(q, inv_pc, inv_ngr, c, cy2, gi);
                 cx = 4 * gi; cy = 2 * cy2;
                 const int wc = wc_of(c);
                 if (cx < wc) {
@@ -1147,26 +1191,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
         }
     } else {
         // ---- dense path: score every pixel ----
-        // a lane's work items are q = tid, tid + T, ...: (cell, row pair, group) is split once and then advanced by the split of T
-        int c, cy2, gi;
-        split((int)threadIdx.x, c, cy2, gi);
-        const int dc = T / per_cell, drem = T - dc * per_cell, dcy = drem / ngr, dgi = drem - dcy * ngr;       // block-uniform
-        auto advance = [&](int& c_, int& cy2_, int& gi_) __attribute__((always_inline)) {
-            gi_ += dgi; cy2_ += dcy; c_ += dc;
-            if (gi_ >= ngr) { gi_ -= ngr; cy2_++; }
-            if (cy2_ >= hc2) { cy2_ -= hc2; c_++; }
-        };
-        for (int q = threadIdx.x; q < nitems; q += T, advance(c, cy2, gi)) {
-            const int wc = wc_of(c);
-            const int cx = 4 * gi, cy = 2 * cy2;
-            if (cx >= wc) continue;
+        auto score_item = [&](int c, int cy, int cx, uint32_t keepm) __attribute__((always_inline)) {
             uint32_t r[8][3];                                              // tile rows cy .. cy+7 (row cy+7 may lie below the ROI: staged as zeros / unused)
 #pragma unroll
             for (int j = 0; j < 8; j++) {                                  // ROI column cx of cell c: dword-aligned
                 const uint32_t* rp = reinterpret_cast<const uint32_t*>(&s_tile[(cy + j) * TP + c * CP + cx]);
                 r[j][0] = rp[0]; r[j][1] = rp[1]; r[j][2] = rp[2];
             }
-            const uint32_t keepm = (wc - cx < 4) ? (1u << (8 * (wc - cx))) - 1u : 0xffffffffu;
+#if MYSLAM_FAST_PHASE == 2
+            {
+                uint32_t x = 0;
+                for (int j = 0; j < 8; j++) x ^= r[j][0] ^ r[j][1] ^ r[j][2];
+                *reinterpret_cast<uint32_t*>(&s_score[c][(cy + 1) * SP + 4 + cx]) = x & keepm;
+                if (cy + 1 < hc) *reinterpret_cast<uint32_t*>(&s_score[c][(cy + 2) * SP + 4 + cx]) = ~x & keepm;
+                return;
+            }
+#endif
             {
                 const s16x2 za = fast9_score_pair<0, 0, 8>(r, thv), zb = fast9_score_pair<1, 0, 8>(r, thv);
                 uint32_t ua, ub;
@@ -1181,15 +1221,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
                 const uint32_t z4 = __builtin_amdgcn_perm(ub, ua, 0x06040200u) & keepm;
                 *reinterpret_cast<uint32_t*>(&s_score[c][(cy + 2) * SP + 4 + cx]) = z4;
             }
+        };
+        if constexpr (BITMAP) {
+            const int gi = (int)threadIdx.x & 7, c = ((int)threadIdx.x >> 3) & 3, cx = 4 * gi;
+            const int wc = wc_of(c);
+            if (cx < wc) {
+                const uint32_t keepm = (wc - cx < 4) ? (1u << (8 * (wc - cx))) - 1u : 0xffffffffu;
+                for (int cy2 = (int)threadIdx.x >> 5; cy2 < hc2; cy2 += T / 32) score_item(c, 2 * cy2, cx, keepm);
+            }
+        } else {
+            // a lane's work items are q = tid, tid + T, ...: (cell, row pair, group) is split once and then advanced by the split of T
+            const float inv_pc = 1.0f / (float)per_cell, inv_ngr = 1.0f / (float)ngr;
+            int c, cy2, gi;
+            split((int)threadIdx.x, inv_pc, inv_ngr, c, cy2, gi);
+            const int dc = T / per_cell, drem = T - dc * per_cell, dcy = drem / ngr, dgi = drem - dcy * ngr;       // block-uniform
+            auto advance = [&](int& c_, int& cy2_, int& gi_) __attribute__((always_inline)) {
+                gi_ += dgi; cy2_ += dcy; c_ += dc;
+                if (gi_ >= ngr) { gi_ -= ngr; cy2_++; }
+                if (cy2_ >= hc2) { cy2_ -= hc2; c_++; }
+            };
+            for (int q = threadIdx.x; q < nitems; q += T, advance(c, cy2, gi)) {
+                const int wc = wc_of(c);
+                const int cx = 4 * gi, cy = 2 * cy2;
+                if (cx >= wc) continue;
+                score_item(c, cy, cx, (wc - cx < 4) ? (1u << (8 * (wc - cx))) - 1u : 0xffffffffu);
+            }
         }
         __syncthreads();
+#if MYSLAM_FAST_PHASE >= 2 && MYSLAM_FAST_PHASE <= 4
+        return;
+#endif
         int nquad = 0;                     // 4-pixel rows that hold a corner: counted on the scalar unit (ballot + s_bcnt1), the statistic of this path
         // NMS on 4 x 4 pixel blocks (6 score-map rows x 3 dwords per lane, separable 3x3 maximum).  Every 4-pixel row that holds a strict
         // maximum leaves ONE record (its filtered z dword) in the strip's list — four ballots and one LDS atomic per wave and
         // iteration; the records are expanded into candidates by the append phase below, where every lane has work.
-        const int hc4 = (hc + 3) >> 2, per_cell4 = ngr * hc4, nitems4 = ncell * per_cell4;
-        int cy4;
-        {   // q -> (cell, row block, group) as split() does for the scoring items
+        const int hc4 = (hc + 3) >> 2, per_cell4 = ngr * hc4;
+        const int nitems4 = BITMAP ? 32 * hc4 : ncell * per_cell4;         // BITMAP: item = group | cell << 3 | row block << 5 (lanes of absent cells idle)
+        int c, gi, cy4;
+        int ec = 0, ecy = 0, egi = 0;                                      // !BITMAP: the split of T (block-uniform)
+        if constexpr (BITMAP) {
+            gi = (int)threadIdx.x & 7; c = ((int)threadIdx.x >> 3) & 3; cy4 = (int)threadIdx.x >> 5;
+        } else {   // q -> (cell, row block, group) as split() does for the scoring items
+            const float inv_ngr = 1.0f / (float)ngr;
             const int q = (int)threadIdx.x;
             c = (int)(((float)q + 0.5f) * (1.0f / (float)per_cell4));
             int rem = q - c * per_cell4;
@@ -1197,14 +1270,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
             cy4 = (int)(((float)rem + 0.5f) * inv_ngr);
             gi = rem - cy4 * ngr;
             if (gi < 0) { cy4--; gi += ngr; } else if (gi >= ngr) { cy4++; gi -= ngr; }
+            ec = T / per_cell4; const int erem = T - ec * per_cell4; ecy = erem / ngr; egi = erem - ecy * ngr;
         }
-        const int ec = T / per_cell4, erem = T - ec * per_cell4, ecy = erem / ngr, egi = erem - ecy * ngr;     // block-uniform
+        const int wc_lane = BITMAP ? wc_of(c) : 0;
         const int zini = P.iniTh - zoff;                                   // z of a corner at the initial threshold
         for (int q0 = 0; q0 < nitems4; q0 += T) {                          // uniform trip count: the ballot needs every lane
             const int q = q0 + threadIdx.x;
             uint32_t zm[4] = {0u, 0u, 0u, 0u};                             // rows 4 cy4 .. + 3: z where the pixel is a strict maximum, else 0
             u16x2 zacc = {0, 0};
-            if (q < nitems4 && 4 * gi < wc_of(c)) {
+            if (BITMAP ? (cy4 < hc4 && 4 * gi < wc_lane) : (q < nitems4 && 4 * gi < wc_of(c))) {
                 uint32_t m[6][3];                                          // score-map rows 4 cy4 - 1 .. 4 cy4 + 4 (zero border rows around the cell)
 #pragma unroll
                 for (int j = 0; j < 6; j++) {
@@ -1240,11 +1314,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
                     }
                 if (max((int)zacc.x, (int)zacc.y) >= zini) s_ini[c] = 1;
             }
-            gi += egi; cy4 += ecy; c += ec;
-            if (gi >= ngr) { gi -= ngr; cy4++; }
-            if (cy4 >= hc4) { cy4 -= hc4; c++; }
+            if constexpr (BITMAP) cy4 += T / 32;
+            else {
+                gi += egi; cy4 += ecy; c += ec;
+                if (gi >= ngr) { gi -= ngr; cy4++; }
+                if (cy4 >= hc4) { cy4 -= hc4; c++; }
+            }
         }
         if (lane == 0 && nquad) atomicAdd(&s_ncorner, nquad);
+#if MYSLAM_FAST_PHASE == 5
+        return;
+#endif
     }
     __syncthreads();
     // what the next launch of this handle decides on: a SAMPLE of the strips reports (a ratio of sums needs no more, and a few
