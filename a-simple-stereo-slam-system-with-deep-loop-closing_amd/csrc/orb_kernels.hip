@@ -2291,9 +2291,13 @@ __device__ __forceinline__ void describe_block(const OrbPlan& P, const uint8_t* 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             kd_v4i acc = {0, 0, 0, 0};
 #pragma unroll
-            for (int rp = 0; rp < 16; rp++) {                             // operand row r4 (< 4) = key-point r4 of the round, k block kq
-                const uint4 pv = (r4 < 4) ? s_b[wave][64 * r4 + 2 * (2 * rp + (kq >> 1)) + (kq & 1)] : make_uint4(0, 0, 0, 0);
-                const uint4 wv = (jb < 2) ? s_bw[(rp * 4 + kq) * 2 + jb] : make_uint4(0, 0, 0, 0);
+            // operand row r4 (< 4) = key-point r4 of the round, k block kq.  Row i of the product depends on row i of A only and column j
+            // on column j of B only, and only rows 0 .. 3 / columns 0, 1 are read back: the idle rows and columns simply repeat the live ones
+            // (r4 & 3, jb & 1) — round 5: selecting zeros for them cost 8 v_mov + two exec-masked LDS reads + a full wait PER MFMA
+            // (544 of a wave's ~3 000 vector instructions)
+            for (int rp = 0; rp < 16; rp++) {
+                const uint4 pv = s_b[wave][64 * (r4 & 3) + 2 * (2 * rp + (kq >> 1)) + (kq & 1)];
+                const uint4 wv = s_bw[(rp * 4 + kq) * 2 + (jb & 1)];
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(kd_v4i, pv), __builtin_bit_cast(kd_v4i, wv), acc, 0, 0, 0);
             }
             // C/D: column = lane & 15 (0 -> m10, 1 -> m01), row (key-point of the round) = 4 (lane >> 4) + register: rows 0 .. 3 in lanes 0, 1
