@@ -460,6 +460,42 @@ class LoopDatabase:
         cur = np.ascontiguousarray(cur_ids, np.uint64)
         _check(lib().myslam_lcddb_query_batch_sharded(self._h, d_q, _p(cur), nq, thr_low, d_cand), "myslam_lcddb_query_batch_sharded")
 
+    def generation(self):
+        """number of times the descriptor matrix has moved (growth): recorded steps are valid for the generation they were recorded in"""
+        return lib().myslam_lcddb_generation(self._h)
+
+    def context(self, stream):
+        """A query context on `stream` (myslam_lcddb_query_ctx): several streams scan this ONE database concurrently."""
+        return LoopQueryContext(self, stream)
+
+
+class LoopQueryContext:
+    """myslam_lcddb_query_ctx: the per-stream half of a loop database (row-limit staging, partial results, recorded-step state).
+    LoopClosing::_mvDatabase is one std::map per process (loopclosing.h:120): L streams of one GPU scan it through L contexts."""
+
+    def __init__(self, db, stream):
+        self._db = db                       # keeps the database alive: contexts are destroyed before it
+        self._h = C.c_void_p()
+        _check(lib().myslam_lcddb_query_ctx_create(C.byref(self._h), db._h, C.c_void_p(stream)), "myslam_lcddb_query_ctx_create")
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value and _lib is not None and getattr(self._db, "_h", None) and self._db._h.value:
+            _lib.myslam_lcddb_query_ctx_destroy(self._h)
+        self._h = C.c_void_p()
+
+    def query_batch(self, d_q, cur_ids, nq, d_best, d_max, d_cnt, thr_low=0.92):
+        cur = np.ascontiguousarray(cur_ids, np.uint64)
+        _check(lib().myslam_lcddb_ctx_query_batch(self._h, C.c_void_p(d_q), _p(cur), nq, C.c_float(thr_low), C.c_void_p(d_best),
+                                                  C.c_void_p(d_max), C.c_void_p(d_cnt)), "myslam_lcddb_ctx_query_batch")
+
+    def update_query_limits(self, cur_ids):
+        cur = np.ascontiguousarray(cur_ids, np.uint64)
+        _check(lib().myslam_lcddb_ctx_update_query_limits(self._h, _p(cur), len(cur)), "myslam_lcddb_ctx_update_query_limits")
+
+    def query_batch_sharded(self, d_q, cur_ids, nq, d_cand, thr_low=0.92):
+        cur = np.ascontiguousarray(cur_ids, np.uint64)
+        _check(lib().myslam_lcddb_ctx_query_batch_sharded(self._h, d_q, _p(cur), nq, thr_low, d_cand), "myslam_lcddb_ctx_query_batch_sharded")
+
 
 class StepGraph:
     """One batched step recorded into a HIP graph (myslam_graph_begin / _end) and replayed with one launch.

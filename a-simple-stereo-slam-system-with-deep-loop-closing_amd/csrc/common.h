@@ -2,6 +2,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <atomic>
+#include <memory>
+#include <mutex>
+#include <vector>
 #include <stdio.h>
 #include <string.h>
 
@@ -88,6 +93,45 @@ class HostCall {
     Piece pc[MAXP]; int npc = 0; bool overflow = false;
     size_t endIn = 0, begOut = 0, endOut = 0;
 };
+
+// ---- what a recorded step (graph.hip) and a loop-database query context (lcddb.hip) know about each other ------------------------
+// A scan recorded into a HIP graph names the descriptor matrix by address and reads its row limits from the context's pinned buffer at
+// every replay, on whatever stream the replay is launched.  The link is shared (shared_ptr) by the context and by every step that
+// captured one of its scans:
+//   * `generation` = generation of the matrix the context scans NOW (UINT64_MAX once the context is gone); a step remembers the
+//     generation it was recorded against and myslam_graph_launch refuses to replay it when they differ (MYSLAM_ERR_CAPACITY);
+//   * every recorded step owns one event here, recorded behind each of its replays ON THE LAUNCH STREAM; the context waits for all of
+//     them (wait()) before it rewrites the pinned limits, frees scratch or lets the matrix move.
+struct DbGraphLink {
+    std::atomic<uint64_t> generation{0};
+    std::mutex mu;
+    std::vector<hipEvent_t> events;
+    std::vector<char> launched;
+    ~DbGraphLink() { for (hipEvent_t e : events) (void)hipEventDestroy(e); }
+    void invalidate() { generation.store(UINT64_MAX); }
+    int add_event() {                      // -> index of a new event, or -1
+        std::lock_guard<std::mutex> lk(mu);
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return -1; }
+        events.push_back(e); launched.push_back(0);
+        return (int)events.size() - 1;
+    }
+    int mark_replay(int idx, hipStream_t s) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (hipEventRecord(events[idx], s) != hipSuccess) { (void)hipGetLastError(); return MYSLAM_ERR_HIP; }
+        launched[idx] = 1;
+        return MYSLAM_OK;
+    }
+    int wait() {
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t i = 0; i < events.size(); i++)
+            if (launched[i] && hipEventSynchronize(events[i]) != hipSuccess) { (void)hipGetLastError(); return MYSLAM_ERR_HIP; }
+        return MYSLAM_OK;
+    }
+};
+// called by a context whose scan is being captured: the step being recorded on this thread (myslam_graph_begin) takes note.
+// MYSLAM_ERR_UNSUPPORTED when the capture was not started by myslam_graph_begin on this thread (nobody would check the generation).
+int graph_note_db_link(const std::shared_ptr<DbGraphLink>& link, uint64_t generation);
 
 template <typename T>
 __device__ __forceinline__ T wave_reduce_sum(T v) {

@@ -15,15 +15,19 @@
 
 using namespace myslam_hip;
 
+struct StepDbDep { std::shared_ptr<myslam_hip::DbGraphLink> link; uint64_t generation; int event; };
+
 struct myslam_step_graph {
     hipGraph_t graph = nullptr;          // kept alive beside the executable (ROCm 7.2: see orb_engine.hip HostGraph)
     hipGraphExec_t exec = nullptr;
     size_t nodes = 0;
+    std::vector<StepDbDep> deps;         // loop-database scans inside the step: which matrix generation they name (common.h DbGraphLink)
 };
 
 namespace {
 thread_local std::vector<hipEvent_t> t_events;      // fork / join markers of the capture in flight on this thread
 thread_local bool t_capturing = false;
+thread_local std::vector<StepDbDep> t_deps;         // loop-database contexts whose scans the capture in flight has recorded
 
 int make_event(hipEvent_t* e) {
     MYSLAM_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -36,6 +40,16 @@ void drop_events() {
 }
 }  // namespace
 
+namespace myslam_hip {
+int graph_note_db_link(const std::shared_ptr<DbGraphLink>& link, uint64_t generation) {
+    if (!t_capturing) return MYSLAM_ERR_UNSUPPORTED;
+    for (StepDbDep& d : t_deps)
+        if (d.link == link) { d.generation = generation; return MYSLAM_OK; }
+    t_deps.push_back({link, generation, -1});
+    return MYSLAM_OK;
+}
+}  // namespace myslam_hip
+
 extern "C" {
 
 int myslam_graph_begin(void* origin_stream, void* const* side_streams, int n_side) {
@@ -44,6 +58,7 @@ int myslam_graph_begin(void* origin_stream, void* const* side_streams, int n_sid
     hipStream_t o = (hipStream_t)origin_stream;
     MYSLAM_HIP_CHECK(hipStreamBeginCapture(o, hipStreamCaptureModeThreadLocal));
     t_capturing = true;
+    t_deps.clear();
     auto fork = [&]() -> int {
         hipEvent_t e;
         int rc = make_event(&e);
@@ -61,7 +76,7 @@ int myslam_graph_begin(void* origin_stream, void* const* side_streams, int n_sid
         (void)hipStreamEndCapture(o, &g);
         if (g) (void)hipGraphDestroy(g);
         (void)hipGetLastError();
-        drop_events(); t_capturing = false;
+        drop_events(); t_capturing = false; t_deps.clear();
     }
     return rc;
 }
@@ -81,13 +96,20 @@ int myslam_graph_end(void* origin_stream, void* const* side_streams, int n_side,
     const hipError_t ec = hipStreamEndCapture(o, &g);
     t_capturing = false;
     drop_events();
+    std::vector<StepDbDep> deps;
+    deps.swap(t_deps);
     if (rc != MYSLAM_OK || ec != hipSuccess || !g) {
         (void)hipGetLastError();
         if (g) (void)hipGraphDestroy(g);
         return rc != MYSLAM_OK ? rc : MYSLAM_ERR_HIP;
     }
+    for (StepDbDep& d : deps) {
+        d.event = d.link->add_event();
+        if (d.event < 0) { (void)hipGraphDestroy(g); return MYSLAM_ERR_HIP; }
+    }
     myslam_step_graph* sg = new myslam_step_graph();
     sg->graph = g;
+    sg->deps = std::move(deps);
     (void)hipGraphGetNodes(g, nullptr, &sg->nodes);
     if (hipGraphInstantiate(&sg->exec, g, nullptr, nullptr, 0) != hipSuccess) {
         (void)hipGetLastError();
@@ -101,7 +123,15 @@ int myslam_graph_end(void* origin_stream, void* const* side_streams, int n_side,
 
 int myslam_graph_launch(myslam_step_graph* g, void* hip_stream) {
     if (!g || !g->exec) return MYSLAM_ERR_INVALID;
+    // a loop-database scan inside the step names the descriptor matrix by address: refuse the replay when that matrix has moved since
+    // (growth beyond its allocation) or its query context is gone — the step has to be recorded again
+    for (const StepDbDep& d : g->deps)
+        if (d.link->generation.load() != d.generation) return MYSLAM_ERR_CAPACITY;
     MYSLAM_HIP_CHECK(hipGraphLaunch(g->exec, (hipStream_t)hip_stream));
+    for (const StepDbDep& d : g->deps) {           // the context waits for THIS replay, on the stream it actually went to, before it touches its pinned limits
+        const int rc = d.link->mark_replay(d.event, (hipStream_t)hip_stream);
+        if (rc) return rc;
+    }
     return MYSLAM_OK;
 }
 

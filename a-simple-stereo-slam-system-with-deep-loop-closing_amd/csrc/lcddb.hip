@@ -7,6 +7,8 @@
 // Scan kernel: one wave per database row, the row lives in registers (17 floats per lane) and is dotted
 // against every query of the batch, so a batch of queries streams the database from HBM exactly once.
 #include <algorithm>
+#include <memory>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -25,6 +27,14 @@ __global__ __launch_bounds__(256) void k_db_scan(const float* __restrict__ db, c
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_db[];
     Partial* s_p = reinterpret_cast<Partial*>(smem_db);          // [DB_WAVES][nq]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {   // a launch covers the allocation (recorded steps outlive appends): blocks behind every query's row limit leave an empty partial
+        int lim = 0;
+        for (int qi = 0; qi < nq; qi++) lim = max(lim, nvalid[qi]);
+        if ((int)blockIdx.x * DB_WAVES * DB_ROWS_PER_WAVE >= lim) {
+            for (int qi = threadIdx.x; qi < nq; qi += 256) partials[(size_t)blockIdx.x * nq + qi] = {0.f, -1, 0};
+            return;
+        }
+    }
     for (int i = threadIdx.x; i < DB_WAVES * nq; i += 256) s_p[i] = {0.f, -1, 0};
     __syncthreads();
     const int row0 = (blockIdx.x * DB_WAVES + wave) * DB_ROWS_PER_WAVE;
@@ -96,6 +106,14 @@ __global__ __launch_bounds__(256) void k_db_scan_bf16x6(const float* __restrict_
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int m0 = blockIdx.x * GM, n0 = blockIdx.y * GN;
+    {   // blocks behind the row limits of all of their queries leave empty partials (see k_db_scan)
+        const int n = n0 + (t & (GN - 1));
+        const bool live = n < nq && nvalid[n] > m0;
+        if (__syncthreads_or(live ? 1 : 0) == 0) {
+            if (t < GN && n0 + t < nq) partials[(size_t)blockIdx.x * nq + n0 + t] = {0.f, -1, 0};
+            return;
+        }
+    }
     const int row = t >> 1, kk = (t & 1) * 8;
     const bool a_ok = (m0 + row) < rows_alloc, b_ok = (n0 + row) < nq;
     // unconditional loads from clamped rows + a select at store time keep the prefetch in registers
@@ -211,10 +229,11 @@ __global__ __launch_bounds__(256) void k_db_reduce(const Partial* __restrict__ p
 
 // per-shard result of a query in the layout that travels between ranks: cnt bit 31 = this shard's scan hit the break (:133)
 __global__ __launch_bounds__(256) void k_db_pack_candidates(const uint64_t* __restrict__ best_id, const float* __restrict__ max_score,
-                                                            const int32_t* __restrict__ cnt, const int32_t* __restrict__ nvalid, int nrows,
-                                                            int nq, myslam_lcd_candidate* __restrict__ out) {
+                                                            const int32_t* __restrict__ cnt, const int32_t* __restrict__ nvalid,
+                                                            const int32_t* __restrict__ nrows_p, int nq, myslam_lcd_candidate* __restrict__ out) {
     const int qi = blockIdx.x * 256 + threadIdx.x;
     if (qi >= nq) return;
+    const int nrows = *nrows_p;                                   // rows the shard held when the limits were written (device memory: replays see appends)
     myslam_lcd_candidate c;
     c.best_id = best_id[qi]; c.max_score = max_score[qi];
     c.cnt = (cnt[qi] & 0x7fffffff) | (nvalid[qi] < nrows ? (int32_t)0x80000000 : 0);
@@ -247,20 +266,46 @@ __global__ __launch_bounds__(256) void k_db_merge_candidates(const myslam_lcd_ca
 
 using namespace myslam_hip;
 
+// ---- storage and query contexts ------------------------------------------------------------------------------------------------
+// LoopClosing::_mvDatabase is ONE std::map that every key-frame of the process goes into (loopclosing.h:120, loopclosing.cpp:651-659).
+// The device form is split accordingly (round 5): `myslam_lcddb` owns the descriptor matrix and the ids — appends go there — and a
+// `myslam_lcddb_query_ctx` owns what ONE stream of queries needs (row-limit staging, partial results, shard scratch, recorded-step
+// state).  L concurrent streams (L cameras of one GPU, or L lanes of a bench) scan ONE matrix through L contexts; the handle itself
+// carries a built-in context on its own stream, which is what the myslam_lcddb_query* entry points use.
+//
+// Ordering rules:
+//   * appends copy on the storage's stream and return when the rows are in HBM; a scan only reads rows below its own row limits
+//     (fixed on the host at call time), so appends never race with scans in flight on other streams;
+//   * growth (db_reserve) moves the matrix: it waits for every context's stream AND for the replays of every recorded step that
+//     captured a scan (DbGraphLink::wait), bumps the generation, and parks the old matrix until no recorded step can read it (a
+//     stale step's launch fails with MYSLAM_ERR_CAPACITY instead of reading freed memory);
+//   * a recorded scan covers the whole ALLOCATION (blocks behind the row limits return at once), so appends inside the capacity
+//     need no re-recording — only myslam_lcddb_ctx_update_query_limits before the next replay.
+struct myslam_lcddb_query_ctx {
+    myslam_lcddb* db = nullptr;
+    hipStream_t stream = nullptr;
+    bool builtin = false;
+    Partial* d_partials = nullptr; size_t partialsCap = 0;
+    int32_t* d_nvalid = nullptr; int nvalidCap = 0;                 // nq row limits + 1: the row count they were computed against
+    int32_t* h_nvalid = nullptr; hipEvent_t nvEvent = nullptr;      // pinned staging of the per-query row limits + "copy done" event
+    uint64_t* d_bestS = nullptr; float* d_maxS = nullptr; int32_t* d_cntS = nullptr; int shardCap = 0;     // scratch of the sharded query
+    int graphRows = 0, graphQueries = 0;      // > 0: a query of this context was recorded into a HIP graph covering this many rows / queries
+    uint64_t graphGen = 0;                    // generation of the matrix that recording reads
+    std::vector<int32_t> lastLimits, scratchLimits; int lastRows = -1; bool nvFresh = false, nvPending = false;      // what d_nvalid holds (skip identical uploads)
+    std::shared_ptr<DbGraphLink> link;        // shared with the recorded steps (graph.hip): generation check at launch, replay-done events
+};
+
 struct myslam_lcddb {
     hipStream_t stream = nullptr;
     int capacity = 0, n = 0;
     float* d_db = nullptr;
     uint64_t* d_ids = nullptr;
     std::vector<uint64_t> ids;
-    Partial* d_partials = nullptr; size_t partialsCap = 0;
-    int32_t* d_nvalid = nullptr; int nvalidCap = 0;
-    int32_t* h_nvalid = nullptr; hipEvent_t nvEvent = nullptr;      // pinned staging of the per-query row limits + "copy done" event
+    uint64_t generation = 0;                  // bumped whenever the matrix moves
+    std::vector<std::pair<float*, uint64_t*>> retired;      // matrices a recorded step of an older generation may still name
+    std::vector<myslam_lcddb_query_ctx*> ctxs;              // every live context (ctxs[0] = the built-in one)
+    std::mutex mu;                            // host state: ids, n, capacity, pointers, context list
     float* d_q1 = nullptr; uint64_t* d_best1 = nullptr; float* d_max1 = nullptr; int32_t* d_cnt1 = nullptr;
-    uint64_t* d_bestS = nullptr; float* d_maxS = nullptr; int32_t* d_cntS = nullptr; int shardCap = 0;     // scratch of the sharded query
-    int graphRows = 0, graphQueries = 0;      // > 0: a query of this handle was recorded into a HIP graph covering this many rows / queries
-    std::vector<int32_t> lastLimits, scratchLimits; bool nvFresh = false, nvPending = false;      // what d_nvalid holds (skip identical uploads)
-    bool graphStale = false;                  // the matrix moved (db_reserve) after a query was recorded: the recorded step reads freed memory
 
     // index of the first row the reference's scan does NOT look at: it breaks at the first id with
     // (cur - id) < 20 in unsigned arithmetic (loopclosing.cpp:133), i.e. id in [cur-19, cur] mod 2^64
@@ -275,6 +320,30 @@ struct myslam_lcddb {
     }
 };
 
+static void ctx_free(myslam_lcddb_query_ctx* c) {
+    void* ptrs[] = {c->d_partials, c->d_nvalid, c->d_bestS, c->d_maxS, c->d_cntS};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (c->h_nvalid) (void)hipHostFree(c->h_nvalid);
+    if (c->nvEvent) (void)hipEventDestroy(c->nvEvent);
+    if (c->link) c->link->invalidate();       // recorded steps that captured this context can no longer be launched
+    delete c;
+}
+
+// everything that may still be reading a context's pinned limits or the matrix through it: its stream + the replays of recorded steps
+static int ctx_quiesce(myslam_lcddb_query_ctx* c) {
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->link) { const int rc = c->link->wait(); if (rc) return rc; }
+    return MYSLAM_OK;
+}
+
+static myslam_lcddb_query_ctx* ctx_new(myslam_lcddb* db, hipStream_t s, bool builtin) {
+    myslam_lcddb_query_ctx* c = new myslam_lcddb_query_ctx();
+    c->db = db; c->stream = s; c->builtin = builtin;
+    c->link = std::make_shared<DbGraphLink>();
+    c->link->generation.store(db->generation);
+    return c;
+}
+
 extern "C" {
 
 int myslam_lcddb_create(myslam_lcddb** out, int capacity) {
@@ -282,6 +351,7 @@ int myslam_lcddb_create(myslam_lcddb** out, int capacity) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MYSLAM_ERR_HIP;
     myslam_lcddb* h = new myslam_lcddb();
+    h->ctxs.push_back(ctx_new(h, nullptr, true));
     const int rowsPerBlock = DB_WAVES * DB_ROWS_PER_WAVE;
     h->capacity = (capacity + rowsPerBlock - 1) / rowsPerBlock * rowsPerBlock;      // scan reads whole blocks of rows
     auto alloc_all = [&]() -> int {
@@ -302,31 +372,63 @@ int myslam_lcddb_create(myslam_lcddb** out, int capacity) {
 int myslam_lcddb_destroy(myslam_lcddb* h) {
     if (!h) return MYSLAM_ERR_INVALID;
     (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->d_db, h->d_ids, h->d_partials, h->d_nvalid, h->d_q1, h->d_best1, h->d_max1, h->d_cnt1, h->d_bestS, h->d_maxS, h->d_cntS};
+    for (myslam_lcddb_query_ctx* c : h->ctxs) { (void)ctx_quiesce(c); ctx_free(c); }      // contexts die with their database
+    void* ptrs[] = {h->d_db, h->d_ids, h->d_q1, h->d_best1, h->d_max1, h->d_cnt1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    if (h->h_nvalid) (void)hipHostFree(h->h_nvalid);
-    if (h->nvEvent) (void)hipEventDestroy(h->nvEvent);
+    for (auto& r : h->retired) { (void)hipFree(r.first); (void)hipFree(r.second); }
     delete h;
     return MYSLAM_OK;
 }
 
 int myslam_lcddb_set_stream(myslam_lcddb* h, void* s) {
     if (!h) return MYSLAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
     (void)hipStreamSynchronize(h->stream);
+    (void)ctx_quiesce(h->ctxs[0]);
     h->stream = (hipStream_t)s;
+    h->ctxs[0]->stream = (hipStream_t)s;
     return MYSLAM_OK;
 }
 
 int myslam_lcddb_size(const myslam_lcddb* h) { return h ? h->n : MYSLAM_ERR_INVALID; }
 
+int myslam_lcddb_generation(const myslam_lcddb* h) { return h ? (int)h->generation : MYSLAM_ERR_INVALID; }
+
+int myslam_lcddb_query_ctx_create(myslam_lcddb_query_ctx** out, myslam_lcddb* db, void* hip_stream) {
+    if (!out || !db) return MYSLAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(db->mu);
+    myslam_lcddb_query_ctx* c = ctx_new(db, (hipStream_t)hip_stream, false);
+    db->ctxs.push_back(c);
+    *out = c;
+    return MYSLAM_OK;
+}
+
+int myslam_lcddb_query_ctx_destroy(myslam_lcddb_query_ctx* c) {
+    if (!c || c->builtin) return MYSLAM_ERR_INVALID;
+    myslam_lcddb* db = c->db;
+    std::lock_guard<std::mutex> lk(db->mu);
+    const int rc = ctx_quiesce(c);
+    auto it = std::find(db->ctxs.begin(), db->ctxs.end(), c);
+    if (it != db->ctxs.end()) db->ctxs.erase(it);
+    ctx_free(c);
+    return rc;
+}
+
 // LoopClosing::_mvDatabase is an unbounded std::map (loopclosing.h:120, loopclosing.cpp:651-659): the device matrix grows with it.
 // New storage, one device-to-device copy of the rows held so far, zeroed tail (the scan kernels read whole blocks of rows).
+// Caller holds h->mu.
 static int db_reserve(myslam_lcddb* h, long long rows) {
     const int rowsPerBlock = DB_WAVES * DB_ROWS_PER_WAVE;
     if (rows <= h->capacity) return MYSLAM_OK;
     if (rows > (long long)INT32_MAX - rowsPerBlock) return MYSLAM_ERR_CAPACITY;
     const int cap = (int)((rows + rowsPerBlock - 1) / rowsPerBlock * rowsPerBlock);
-    MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));                    // nothing in flight reads the old matrix
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    bool recorded = false;
+    for (myslam_lcddb_query_ctx* c : h->ctxs) {                           // nothing in flight reads the old matrix: every context's stream and
+        const int rc = ctx_quiesce(c);                                    // every replay of a recorded step that scans through it
+        if (rc) return rc;
+        recorded = recorded || c->graphRows > 0;
+    }
     float* nd = nullptr; uint64_t* ni = nullptr;
     if (hipMalloc((void**)&nd, (size_t)cap * DIM * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return MYSLAM_ERR_CAPACITY; }
     if (hipMalloc((void**)&ni, (size_t)cap * sizeof(uint64_t)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(nd); return MYSLAM_ERR_CAPACITY; }
@@ -341,26 +443,32 @@ static int db_reserve(myslam_lcddb* h, long long rows) {
     };
     const int rc = move_rows();
     if (rc) { (void)hipFree(nd); (void)hipFree(ni); return rc; }
-    (void)hipFree(h->d_db); (void)hipFree(h->d_ids);
+    // A recorded step names the old pointers in its kernel nodes.  Its launch is refused from now on (generation check in
+    // myslam_graph_launch), but a caller that ignores the status must still not touch freed memory: the old matrix stays allocated
+    // until the database is destroyed (geometric growth: all retired matrices together are smaller than the live one).
+    if (recorded) h->retired.emplace_back(h->d_db, h->d_ids);
+    else { (void)hipFree(h->d_db); (void)hipFree(h->d_ids); }
     h->d_db = nd; h->d_ids = ni; h->capacity = cap;
-    if (h->graphRows) h->graphStale = true;
+    h->generation++;
+    for (myslam_lcddb_query_ctx* c : h->ctxs) c->link->generation.store(h->generation);
     return MYSLAM_OK;
 }
 
 static int db_append(myslam_lcddb* h, const uint64_t* ids, const float* src, int n, hipMemcpyKind kind) {
     if (!h || !ids || !src || n < 0) return MYSLAM_ERR_INVALID;
-    if ((long long)h->n + n > h->capacity) {                              // geometric growth: AddToDatabase never fails for lack of room
-        const int rc = db_reserve(h, std::max<long long>((long long)h->n + n, 2LL * h->capacity));
-        if (rc) return rc;
-    }
+    std::lock_guard<std::mutex> lk(h->mu);
     for (int i = 0; i < n; i++) {
         const uint64_t prev = (i == 0) ? (h->ids.empty() ? 0 : h->ids.back()) : ids[i - 1];
         const bool first = (i == 0 && h->ids.empty());
         if (!first && ids[i] <= prev) return MYSLAM_ERR_INVALID;          // std::map order: strictly ascending keys
     }
+    if ((long long)h->n + n > h->capacity) {                              // geometric growth: AddToDatabase never fails for lack of room
+        const int rc = db_reserve(h, std::max<long long>((long long)h->n + n, 2LL * h->capacity));
+        if (rc) return rc;
+    }
     MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_db + (size_t)h->n * DIM, src, (size_t)n * DIM * sizeof(float), kind, h->stream));
     MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_ids + h->n, ids, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
-    MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));                    // ids is a host pointer
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));                    // ids is a host pointer; the rows are in HBM when the call returns
     h->ids.insert(h->ids.end(), ids, ids + n);
     h->n += n;
     return MYSLAM_OK;
@@ -370,6 +478,7 @@ int myslam_lcddb_capacity(const myslam_lcddb* h) { return h ? h->capacity : MYSL
 
 int myslam_lcddb_reserve(myslam_lcddb* h, int rows) {
     if (!h || rows < 0) return MYSLAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
     return db_reserve(h, rows);
 }
 
@@ -379,113 +488,166 @@ int myslam_lcddb_append_batch(myslam_lcddb* h, const uint64_t* ids, const float*
     return db_append(h, ids, d_descr, n, hipMemcpyDeviceToDevice);
 }
 
+}  // extern "C"
+
 static bool stream_is_capturing(hipStream_t s) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
     return st == hipStreamCaptureStatusActive;
 }
 
-static int db_query(myslam_lcddb* h, const float* d_q, const uint64_t* cur_ids_host, int nq, float thr_low, uint64_t* d_best,
+static int db_query(myslam_lcddb_query_ctx* c, const float* d_q, const uint64_t* cur_ids_host, int nq, float thr_low, uint64_t* d_best,
                     float* d_max, int32_t* d_cnt) {
+    myslam_lcddb* h = c->db;
     const int rowsPerBlock = DB_WAVES * DB_ROWS_PER_WAVE;
     // Recorded into a HIP graph (graph.hip)?  Then nothing here may synchronise or allocate, the copy node of the row limits reads the
-    // pinned buffer at EVERY replay (myslam_lcddb_update_query_limits rewrites it), and the launch covers every row the database holds
-    // (not only the rows today's limits reach), so that later limits stay inside the captured grid.
-    const bool cap = stream_is_capturing(h->stream);
-    if (nq > h->nvalidCap) {
+    // pinned buffer at EVERY replay (myslam_lcddb_ctx_update_query_limits rewrites it), and the launch covers every row of the
+    // ALLOCATION (not only the rows today's limits reach), so that later limits and appends stay inside the captured grid.
+    const bool cap = stream_is_capturing(c->stream);
+    if (nq > c->nvalidCap) {
         if (cap) return MYSLAM_ERR_UNSUPPORTED;                          // first call with this many queries: run it once outside the capture
-        MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
-        if (h->d_nvalid) (void)hipFree(h->d_nvalid);
-        if (h->h_nvalid) (void)hipHostFree(h->h_nvalid);
-        h->d_nvalid = nullptr; h->h_nvalid = nullptr; h->nvalidCap = 0;
-        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_nvalid, sizeof(int32_t) * nq));
-        MYSLAM_HIP_CHECK(hipHostMalloc((void**)&h->h_nvalid, sizeof(int32_t) * nq));
-        if (!h->nvEvent) MYSLAM_HIP_CHECK(hipEventCreateWithFlags(&h->nvEvent, hipEventDisableTiming));
-        h->nvalidCap = nq; h->nvFresh = false;
+        const int rq = ctx_quiesce(c);
+        if (rq) return rq;
+        if (c->d_nvalid) (void)hipFree(c->d_nvalid);
+        if (c->h_nvalid) (void)hipHostFree(c->h_nvalid);
+        c->d_nvalid = nullptr; c->h_nvalid = nullptr; c->nvalidCap = 0;
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&c->d_nvalid, sizeof(int32_t) * (nq + 1)));
+        MYSLAM_HIP_CHECK(hipHostMalloc((void**)&c->h_nvalid, sizeof(int32_t) * (nq + 1)));
+        if (!c->nvEvent) MYSLAM_HIP_CHECK(hipEventCreateWithFlags(&c->nvEvent, hipEventDisableTiming));
+        c->nvalidCap = nq; c->nvFresh = false;
     }
     // the row limits of this call; when they equal what the device buffer already holds (the same cur_ids against the same rows, the
     // usual case of a batch of queries per step) nothing is uploaded and the host never waits for the device
-    int maxv = 0;
-    bool same = h->nvFresh && !cap && (int)h->lastLimits.size() == nq;
-    h->scratchLimits.resize(nq);
-    for (int i = 0; i < nq; i++) {
-        const int v = h->n_valid(cur_ids_host[i]);
-        h->scratchLimits[i] = v; maxv = std::max(maxv, v);
-        if (same && h->lastLimits[i] != v) same = false;
+    int maxv = 0, rows_now, cap_now; float* d_db; uint64_t* d_ids; uint64_t gen;
+    bool same;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        rows_now = h->n; cap_now = h->capacity; d_db = h->d_db; d_ids = h->d_ids; gen = h->generation;
+        same = c->nvFresh && !cap && (int)c->lastLimits.size() == nq && c->lastRows == rows_now;
+        c->scratchLimits.resize(nq);
+        for (int i = 0; i < nq; i++) {
+            const int v = h->n_valid(cur_ids_host[i]);
+            c->scratchLimits[i] = v; maxv = std::max(maxv, v);
+            if (same && c->lastLimits[i] != v) same = false;
+        }
     }
-    if (cap) { maxv = std::max(maxv, h->n); h->graphRows = maxv; h->graphQueries = nq; h->graphStale = false; }
+    if (cap) maxv = cap_now;
     const int nblocks = std::max(1, (maxv + rowsPerBlock - 1) / rowsPerBlock);
-    const size_t need = (size_t)std::max(nblocks, std::max(1, (maxv + GM - 1) / GM)) * nq;
-    if (need > h->partialsCap) {
+    // partial results: sized for the whole allocation and this call's kernel (a later recording of the same query covers the allocation
+    // and must find its scratch in place: nothing may be allocated inside a capture)
+    const size_t need = (size_t)std::max(1, nq >= 32 ? (cap_now + GM - 1) / GM : (cap_now + rowsPerBlock - 1) / rowsPerBlock) * nq;
+    if (need > c->partialsCap) {
         if (cap) return MYSLAM_ERR_UNSUPPORTED;
-        MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
-        if (h->d_partials) (void)hipFree(h->d_partials);
-        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_partials, need * sizeof(Partial)));
-        h->partialsCap = need;
+        const int rq = ctx_quiesce(c);
+        if (rq) return rq;
+        if (c->d_partials) (void)hipFree(c->d_partials);
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&c->d_partials, need * sizeof(Partial)));
+        c->partialsCap = need;
+    }
+    if (cap) {
+        c->graphRows = maxv; c->graphQueries = nq; c->graphGen = gen;
+        const int rn = graph_note_db_link(c->link, gen);                 // the step being recorded learns which matrix it reads (graph.hip)
+        if (rn) return rn;
     }
     if (!same) {
         if (!cap) {
-            if (h->graphRows) MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));      // a recorded step also reads the pinned buffer: wait for its replays
-            else if (h->nvPending) MYSLAM_HIP_CHECK(hipEventSynchronize(h->nvEvent));   // the previous upload has left the pinned buffer
+            if (c->graphRows) { const int rw = c->link->wait(); if (rw) return rw; MYSLAM_HIP_CHECK(hipStreamSynchronize(c->stream)); }      // a recorded step also reads the pinned buffer: wait for its replays, wherever they were launched
+            else if (c->nvPending) MYSLAM_HIP_CHECK(hipEventSynchronize(c->nvEvent));   // the previous upload has left the pinned buffer
         }
-        memcpy(h->h_nvalid, h->scratchLimits.data(), sizeof(int32_t) * nq);
-        MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_nvalid, h->h_nvalid, sizeof(int32_t) * nq, hipMemcpyHostToDevice, h->stream));      // pinned -> no host sync
-        if (!cap) { MYSLAM_HIP_CHECK(hipEventRecord(h->nvEvent, h->stream)); h->nvPending = true; }
-        h->lastLimits = h->scratchLimits; h->nvFresh = !cap;             // (a recorded copy re-runs at every replay with whatever the pinned buffer holds then)
+        memcpy(c->h_nvalid, c->scratchLimits.data(), sizeof(int32_t) * nq);
+        c->h_nvalid[nq] = rows_now;
+        MYSLAM_HIP_CHECK(hipMemcpyAsync(c->d_nvalid, c->h_nvalid, sizeof(int32_t) * (nq + 1), hipMemcpyHostToDevice, c->stream));      // pinned -> no host sync
+        if (!cap) { MYSLAM_HIP_CHECK(hipEventRecord(c->nvEvent, c->stream)); c->nvPending = true; }
+        c->lastLimits = c->scratchLimits; c->lastRows = rows_now; c->nvFresh = !cap;             // (a recorded copy re-runs at every replay with whatever the pinned buffer holds then)
     }
     {
-        ScopedProf sp(P_DBSCAN, h->stream);
+        ScopedProf sp(P_DBSCAN, c->stream);
         int nparts = nblocks;
         if (nq >= 32) {           // batched: GEMM on the matrix cores with the per-query reduction fused into the epilogue
             nparts = std::max(1, (maxv + GM - 1) / GM);
-            hipLaunchKernelGGL(k_db_scan_bf16x6, dim3(nparts, (nq + GN - 1) / GN), dim3(256), 0, h->stream, h->d_db, h->capacity, d_q, nq,
-                               h->d_nvalid, thr_low, h->d_partials);
+            hipLaunchKernelGGL(k_db_scan_bf16x6, dim3(nparts, (nq + GN - 1) / GN), dim3(256), 0, c->stream, d_db, cap_now, d_q, nq,
+                               c->d_nvalid, thr_low, c->d_partials);
         } else {                  // a few queries: bandwidth-bound GEMV, one wave per database row
             const size_t lds = sizeof(Partial) * DB_WAVES * nq;
-            hipLaunchKernelGGL(k_db_scan, dim3(nblocks), dim3(256), lds, h->stream, h->d_db, d_q, nq, h->d_nvalid, thr_low, h->d_partials);
+            hipLaunchKernelGGL(k_db_scan, dim3(nblocks), dim3(256), lds, c->stream, d_db, d_q, nq, c->d_nvalid, thr_low, c->d_partials);
         }
-        hipLaunchKernelGGL(k_db_reduce, dim3((nq + 255) / 256), dim3(256), 0, h->stream, h->d_partials, nparts, nq, h->d_ids, d_best,
+        hipLaunchKernelGGL(k_db_reduce, dim3((nq + 255) / 256), dim3(256), 0, c->stream, c->d_partials, nparts, nq, d_ids, d_best,
                            d_max, d_cnt);
     }
     MYSLAM_HIP_CHECK(hipGetLastError());
     return MYSLAM_OK;
 }
 
+static int db_update_limits(myslam_lcddb_query_ctx* c, const uint64_t* cur_ids, int nq) {
+    myslam_lcddb* h = c->db;
+    if (!c->graphRows || nq > c->graphQueries || nq > c->nvalidCap) return MYSLAM_ERR_INVALID;      // no recorded query to feed
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (c->graphGen != h->generation || h->n > c->graphRows) return MYSLAM_ERR_CAPACITY;      // the database moved: record the step again
+    const int rw = c->link->wait();                                   // no replay — on whatever stream it was launched — is reading the pinned buffer
+    if (rw) return rw;
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < nq; i++) c->h_nvalid[i] = h->n_valid(cur_ids[i]);
+    c->h_nvalid[c->graphQueries] = h->n;
+    c->nvFresh = false;                                               // the next replay rewrites d_nvalid behind the eager path's back
+    return MYSLAM_OK;
+}
+
+static int db_query_sharded(myslam_lcddb_query_ctx* c, const float* d_q, const uint64_t* cur_ids, int nq, float thr_low, myslam_lcd_candidate* d_cand) {
+    if (nq > c->shardCap) {
+        if (stream_is_capturing(c->stream)) return MYSLAM_ERR_UNSUPPORTED;
+        const int rq = ctx_quiesce(c);
+        if (rq) return rq;
+        void* old[] = {c->d_bestS, c->d_maxS, c->d_cntS};
+        for (void* p : old) if (p) (void)hipFree(p);
+        c->d_bestS = nullptr; c->d_maxS = nullptr; c->d_cntS = nullptr; c->shardCap = 0;
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&c->d_bestS, sizeof(uint64_t) * nq));
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&c->d_maxS, sizeof(float) * nq));
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&c->d_cntS, sizeof(int32_t) * nq));
+        c->shardCap = nq;
+    }
+    int rc = db_query(c, d_q, cur_ids, nq, thr_low, c->d_bestS, c->d_maxS, c->d_cntS);
+    if (rc) return rc;
+    // the row count sits behind the nq limits of THIS call in d_nvalid (a recorded step's count is refreshed with its limits)
+    hipLaunchKernelGGL(k_db_pack_candidates, dim3((nq + 255) / 256), dim3(256), 0, c->stream, c->d_bestS, c->d_maxS, c->d_cntS, c->d_nvalid,
+                       c->d_nvalid + nq, nq, d_cand);
+    MYSLAM_HIP_CHECK(hipGetLastError());
+    return MYSLAM_OK;
+}
+
+extern "C" {
+
 int myslam_lcddb_query_batch(myslam_lcddb* h, const float* d_q, const uint64_t* cur_ids, int nq, float thr_low,
                              uint64_t* d_best_id, float* d_max_score, int32_t* d_cnt) {
     if (!h || !d_q || !cur_ids || nq < 1 || nq > 65536 || !d_best_id || !d_max_score || !d_cnt) return MYSLAM_ERR_INVALID;
-    return db_query(h, d_q, cur_ids, nq, thr_low, d_best_id, d_max_score, d_cnt);
+    return db_query(h->ctxs[0], d_q, cur_ids, nq, thr_low, d_best_id, d_max_score, d_cnt);
+}
+
+int myslam_lcddb_ctx_query_batch(myslam_lcddb_query_ctx* c, const float* d_q, const uint64_t* cur_ids, int nq, float thr_low,
+                                 uint64_t* d_best_id, float* d_max_score, int32_t* d_cnt) {
+    if (!c || !d_q || !cur_ids || nq < 1 || nq > 65536 || !d_best_id || !d_max_score || !d_cnt) return MYSLAM_ERR_INVALID;
+    return db_query(c, d_q, cur_ids, nq, thr_low, d_best_id, d_max_score, d_cnt);
 }
 
 int myslam_lcddb_update_query_limits(myslam_lcddb* h, const uint64_t* cur_ids, int nq) {
     if (!h || !cur_ids || nq < 1) return MYSLAM_ERR_INVALID;
-    if (!h->graphRows || nq > h->graphQueries || nq > h->nvalidCap) return MYSLAM_ERR_INVALID;      // no recorded query to feed
-    if (h->graphStale || h->n > h->graphRows) return MYSLAM_ERR_CAPACITY;      // the database moved or outgrew the recorded launch: record the step again
-    MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));               // no replay is reading the pinned buffer
-    for (int i = 0; i < nq; i++) h->h_nvalid[i] = h->n_valid(cur_ids[i]);
-    h->nvFresh = false;                                              // the next replay rewrites d_nvalid behind the eager path's back
-    return MYSLAM_OK;
+    return db_update_limits(h->ctxs[0], cur_ids, nq);
+}
+
+int myslam_lcddb_ctx_update_query_limits(myslam_lcddb_query_ctx* c, const uint64_t* cur_ids, int nq) {
+    if (!c || !cur_ids || nq < 1) return MYSLAM_ERR_INVALID;
+    return db_update_limits(c, cur_ids, nq);
 }
 
 int myslam_lcddb_query_batch_sharded(myslam_lcddb* h, const float* d_q, const uint64_t* cur_ids, int nq, float thr_low,
                                      myslam_lcd_candidate* d_cand) {
     if (!h || !d_q || !cur_ids || nq < 1 || nq > 65536 || !d_cand) return MYSLAM_ERR_INVALID;
-    if (nq > h->shardCap) {
-        MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
-        void* old[] = {h->d_bestS, h->d_maxS, h->d_cntS};
-        for (void* p : old) if (p) (void)hipFree(p);
-        h->d_bestS = nullptr; h->d_maxS = nullptr; h->d_cntS = nullptr; h->shardCap = 0;
-        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_bestS, sizeof(uint64_t) * nq));
-        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_maxS, sizeof(float) * nq));
-        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_cntS, sizeof(int32_t) * nq));
-        h->shardCap = nq;
-    }
-    int rc = db_query(h, d_q, cur_ids, nq, thr_low, h->d_bestS, h->d_maxS, h->d_cntS);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_db_pack_candidates, dim3((nq + 255) / 256), dim3(256), 0, h->stream, h->d_bestS, h->d_maxS, h->d_cntS, h->d_nvalid,
-                       h->n, nq, d_cand);
-    MYSLAM_HIP_CHECK(hipGetLastError());
-    return MYSLAM_OK;
+    return db_query_sharded(h->ctxs[0], d_q, cur_ids, nq, thr_low, d_cand);
+}
+
+int myslam_lcddb_ctx_query_batch_sharded(myslam_lcddb_query_ctx* c, const float* d_q, const uint64_t* cur_ids, int nq, float thr_low,
+                                         myslam_lcd_candidate* d_cand) {
+    if (!c || !d_q || !cur_ids || nq < 1 || nq > 65536 || !d_cand) return MYSLAM_ERR_INVALID;
+    return db_query_sharded(c, d_q, cur_ids, nq, thr_low, d_cand);
 }
 
 int myslam_lcd_merge_candidates(const myslam_lcd_candidate* gathered, int nshards, int nq, uint64_t* best_id, float* max_score, int32_t* cnt) {
@@ -507,7 +669,7 @@ int myslam_lcddb_query(myslam_lcddb* h, const float* descr, uint64_t cur_id, flo
                        int* cnt) {
     if (!h || !descr || !best_id || !max_score || !cnt) return MYSLAM_ERR_INVALID;
     MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_q1, descr, DIM * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    int rc = db_query(h, h->d_q1, &cur_id, 1, thr_low, h->d_best1, h->d_max1, h->d_cnt1);
+    int rc = db_query(h->ctxs[0], h->d_q1, &cur_id, 1, thr_low, h->d_best1, h->d_max1, h->d_cnt1);
     if (rc) return rc;
     int32_t c = 0;
     MYSLAM_HIP_CHECK(hipMemcpyAsync(best_id, h->d_best1, 8, hipMemcpyDeviceToHost, h->stream));

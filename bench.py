@@ -683,8 +683,7 @@ def main():
              "midx": z(P * cap, torch.int32), "mdist": z(P * cap, torch.int32), "xyz": z(P * cap * 3, torch.float64), "ok": z(P * cap, torch.uint8)}
         if use_lcd:
             ln["lcd"] = api.DeepLCD(synth.calc_weights(), stream=s_)
-            ln["D"] = api.LoopDatabase(n_db_local, stream=s_)             # (every lane holds its own copy of the database: the handle owns the scan's scratch)
-            ln["D"].append_batch(ids, t_db.data_ptr(), n_db_local)
+            ln["D"] = D.context(s_)                                       # ONE database for all lanes (LoopClosing::_mvDatabase is one std::map per process, loopclosing.h:120): a query context per lane
             o.update({"descr": torch.zeros(P, 1064, device=dev), "best": z(P, torch.int64), "max": z(P, torch.float32), "dbcnt": z(P, torch.int32)})
         if use_ba:
             o["ba"] = [torch.zeros(P, n, dtype=torch.float64, device=dev) for n in (maxP * 36, maxL * 9, maxE * 18, maxP * 6, maxL * 3, maxE)]

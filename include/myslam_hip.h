@@ -299,6 +299,31 @@ int myslam_lcddb_query_batch(myslam_lcddb* h, const float* d_q, const uint64_t* 
  * allocation) or holds more rows than the recorded launch covers: record the step again.  nq <= the recorded query count. */
 int myslam_lcddb_update_query_limits(myslam_lcddb* h, const uint64_t* cur_ids /*host*/, int nq);
 
+/* Query contexts: ONE database, several concurrent streams of queries.  LoopClosing::_mvDatabase is a single std::map that every
+ * key-frame of the process goes into (include/myslam/loopclosing.h:120, src/loopclosing.cpp:651-659); with L cameras on one GPU the
+ * L loop-closing streams must scan the SAME matrix, not L copies of it.  A myslam_lcddb owns the descriptor matrix and the ids
+ * (append / reserve); a myslam_lcddb_query_ctx owns what one stream of scans needs (row-limit staging, partial results, shard
+ * scratch, recorded-step state) and is bound to one HIP stream.  The handle's own entry points above use a built-in context on the
+ * handle's stream.  Rules:
+ *   - appends return when the new rows are in HBM; scans in flight on any context only read rows below the limits they were
+ *     issued with, so appends and scans need no ordering between them;
+ *   - growth beyond the allocation moves the matrix: append / reserve wait for every context's stream and for every replay of a
+ *     recorded step that scans through a context, then bump myslam_lcddb_generation();
+ *   - a scan recorded into a step graph covers the whole ALLOCATION (blocks behind the row limits return at once): appends inside the
+ *     capacity only need myslam_lcddb_ctx_update_query_limits before the next replay.  After a move, myslam_graph_launch of a step
+ *     that captured a scan returns MYSLAM_ERR_CAPACITY (record it again); the old matrix stays allocated until the database is
+ *     destroyed, so even an unchecked replay reads valid memory;
+ *   - contexts are destroyed before their database (myslam_lcddb_destroy frees any that are left: their pointers die with it).
+ * One thread per context; append / reserve may come from any thread. */
+typedef struct myslam_lcddb_query_ctx myslam_lcddb_query_ctx;
+int myslam_lcddb_query_ctx_create(myslam_lcddb_query_ctx** out, myslam_lcddb* db, void* hip_stream);
+int myslam_lcddb_query_ctx_destroy(myslam_lcddb_query_ctx* c);
+int myslam_lcddb_ctx_query_batch(myslam_lcddb_query_ctx* c, const float* d_q, const uint64_t* cur_ids /*host*/, int nq, float thr_low,
+                                 uint64_t* d_best_id, float* d_max_score, int32_t* d_cnt);
+int myslam_lcddb_ctx_update_query_limits(myslam_lcddb_query_ctx* c, const uint64_t* cur_ids /*host*/, int nq);
+/* number of times the descriptor matrix has moved (growth): a recorded step is valid for the generation it was recorded in */
+int myslam_lcddb_generation(const myslam_lcddb* h);
+
 /* Multi-GPU form: the database is sharded by contiguous key-frame id range, shard r on rank r, every shard scores
  * every query.  A shard's answer travels as one 16-byte record; the records of all shards (rank order = id order) are reduced to what
  * ONE scan of src/loopclosing.cpp:124-161 over the whole std::map returns: strict '>' keeps the first (lowest-id) maximum, counts
@@ -311,6 +336,8 @@ typedef struct myslam_lcd_candidate {
 } myslam_lcd_candidate;
 /* as myslam_lcddb_query_batch, one record per query (device memory, asynchronous on the handle's stream) */
 int myslam_lcddb_query_batch_sharded(myslam_lcddb* h, const float* d_q, const uint64_t* cur_ids /*host*/, int nq, float thr_low,
+                                     myslam_lcd_candidate* d_cand);
+int myslam_lcddb_ctx_query_batch_sharded(myslam_lcddb_query_ctx* c, const float* d_q, const uint64_t* cur_ids /*host*/, int nq, float thr_low,
                                      myslam_lcd_candidate* d_cand);
 /* gathered: [nshards][nq] records, shard-major in ascending id-range order.  Host pointers (plain C++, no device needed). */
 int myslam_lcd_merge_candidates(const myslam_lcd_candidate* gathered, int nshards, int nq, uint64_t* best_id, float* max_score, int32_t* cnt);

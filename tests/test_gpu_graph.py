@@ -80,30 +80,39 @@ def test_recorded_step_equals_the_eager_step_bit_for_bit(api, synth, oracle):
         torch.cuda.synchronize()
         for i, (a, r) in enumerate(zip(c["outs"], ref)):
             assert torch.equal(a.view(torch.uint8), r.view(torch.uint8)), f"replay {k}: output {i} differs from the eager step"
-    # the loop database grows and the queries move on: the recorded copy node reads the pinned row limits at every replay
+    # the loop database grows INSIDE its allocation and the queries move on: the recorded scan covers the allocation and its copy node reads
+    # the pinned row limits (and the row count) at every replay — the same graphs keep serving (round 5)
     D, P, n_db = c["D"], c["P"], c["n_db"]
     add = 100
     D.append_batch(np.arange(n_db, n_db + add, dtype=np.uint64), c["t_db"].data_ptr() + n_db * 1064 * 4, add)
-    with pytest.raises(api.MyslamError):                          # more rows than the recorded launch covers: record again
-        D.update_query_limits(np.full(P, n_db + add + 20, np.uint64))
-    c["cur_ids"][0] = np.array([n_db + add + 20, 150, 40, n_db + 5][:P], np.uint64)
-    c["eager"]()
+    assert D.generation() == 0 and len(D) <= D.capacity()
+    descr = c["o"]["descr"].cpu().numpy(); ids = np.arange(n_db + add, dtype=np.uint64)
+    for k, new_ids in enumerate([np.array([n_db + add + 20, 150, 40, n_db + 5][:P], np.uint64), np.array([60, n_db + add + 20, 25, 330][:P], np.uint64)]):
+        D.update_query_limits(new_ids)                            # same graphs, other cut-offs, more rows
+        c["clear"](); graphs[k % 2].launch(s_main.cuda_stream); torch.cuda.synchronize()
+        for q in range(P):
+            rb, rm, rc = oracle.lcddb_query(c["db"][:n_db + add], ids, descr[q], int(new_ids[q]))
+            assert int(c["o"]["best"][q]) == rb and abs(float(c["o"]["max"][q]) - rm) < 2e-5 and int(c["o"]["dbcnt"][q]) == rc, (k, q)
+    c["cur_ids"][0] = new_ids
+    c["clear"](); c["eager"]()                                    # the eager step agrees with the replay, every output bit for bit
     ref2 = c["snap"]()
+    c["clear"](); graphs[0].launch(s_main.cuda_stream); torch.cuda.synchronize()
+    for i, (a, r) in enumerate(zip(c["outs"], ref2)):
+        assert torch.equal(a.view(torch.uint8), r.view(torch.uint8)), f"replay after appends: output {i}"
+    # a database that moved (it outgrew its allocation) cannot serve a recorded step: the limits are refused and so is the launch —
+    # and a caller that ignores both still reads valid memory (the old matrix stays allocated)
+    D.reserve(4096)
+    assert D.generation() == 1
+    with pytest.raises(api.MyslamError) as e1:
+        D.update_query_limits(new_ids)
+    with pytest.raises(api.MyslamError) as e2:
+        graphs[0].launch(s_main.cuda_stream)
+    assert e1.value.code == -3 and e2.value.code == -3
+    c["eager"](); c["eager"]()
     graphs = [api.StepGraph.record(s_main.cuda_stream, [s_b.cuda_stream, s_side.cuda_stream], c["body"]) for _ in range(2)]
     c["clear"](); graphs[0].launch(s_main.cuda_stream); torch.cuda.synchronize()
     for i, (a, r) in enumerate(zip(c["outs"], ref2)):
         assert torch.equal(a.view(torch.uint8), r.view(torch.uint8)), f"re-recorded step: output {i}"
-    new_ids = np.array([60, n_db + add + 20, 25, 330][:P], np.uint64)
-    D.update_query_limits(new_ids)                                # same graph, other cut-offs
-    c["clear"](); graphs[1].launch(s_main.cuda_stream); torch.cuda.synchronize()
-    descr = c["o"]["descr"].cpu().numpy(); ids = np.arange(n_db + add, dtype=np.uint64)
-    for q in range(P):
-        rb, rm, rc = oracle.lcddb_query(c["db"][:n_db + add], ids, descr[q], int(new_ids[q]))
-        assert int(c["o"]["best"][q]) == rb and abs(float(c["o"]["max"][q]) - rm) < 2e-5 and int(c["o"]["dbcnt"][q]) == rc, q
-    # a database that moved (it outgrew its allocation) cannot serve a recorded step
-    D.reserve(4096)
-    with pytest.raises(api.MyslamError):
-        D.update_query_limits(new_ids)
 
 
 def test_recording_rules(api, synth):
