@@ -91,8 +91,13 @@ __device__ __forceinline__ double bcast_lane(double v, int srcLane) {       // s
 //                    program order — nothing depends on how the four waves interleave); the four copies are added in wave order.
 //   A landmark whose edges are scattered over several runs takes the slow road: its edges are evaluated one per thread (pose terms
 //   as above) and its block is summed by one thread scanning the edge list in order.
-__global__ __launch_bounds__(256) void k_ba_build(BaArgs a) {
+//   NT = threads per window: 256 for batches (one block per window fills the chip), 1024 for a handful of windows (a live stream builds ONE
+//   window per key-frame: every landmark's lane pair then exists at once — 83 -> ~30 us per window).  One copy of the pose blocks per
+//   wave either way, merged in wave order: each variant is bit-reproducible, the two differ in the last bits (both 1e-11 from the oracle).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_ba_build(BaArgs a) {
     MYSLAM_SIDE_PRIO();
+    constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) double s_d[];
     const int w = blockIdx.x, t = threadIdx.x, wv = t >> 6;
     int P = a.sizes ? a.sizes[3 * w] : a.nposes;
@@ -102,8 +107,8 @@ __global__ __launch_bounds__(256) void k_ba_build(BaArgs a) {
     const bool oversize = P < 0 || L < 0 || E < 0 || P > a.maxP || L > a.maxL || E > a.maxE;
     if (oversize) { P = 0; L = 0; E = 0; if (t == 0) a.chi2[(size_t)w * a.maxE] = -1.0; }
     double* sR = s_d;                                           // maxP x 12 (R row-major, t)
-    double* sAcc = sR + a.maxP * 12;                            // 4 waves x maxP x 27 (6x6 upper triangle row-major, then b)
-    int* s_runs = reinterpret_cast<int*>(sAcc + 4 * a.maxP * 27);      // maxL: contiguous runs of each landmark in the edge list
+    double* sAcc = sR + a.maxP * 12;                            // NW waves x maxP x 27 (6x6 upper triangle row-major, then b)
+    int* s_runs = reinterpret_cast<int*>(sAcc + NW * a.maxP * 27);      // maxL: contiguous runs of each landmark in the edge list
     int* s_start = s_runs + a.maxL;                             // maxL: first edge of the landmark's run (meaningful when it has exactly one)
     int* s_len = s_start + a.maxL;                              // maxL: length of that run
     const double* poses = a.poses + (size_t)w * a.maxP * 7;
@@ -115,9 +120,9 @@ __global__ __launch_bounds__(256) void k_ba_build(BaArgs a) {
     const double d2 = a.delta * a.delta;
     double* myAcc = sAcc + (size_t)wv * a.maxP * 27;
 
-    for (int i = t; i < 4 * a.maxP * 27; i += 256) sAcc[i] = 0.0;
-    for (int l = t; l < L; l += 256) s_runs[l] = 0;
-    for (int p = t; p < P; p += 256) {
+    for (int i = t; i < NW * a.maxP * 27; i += NT) sAcc[i] = 0.0;
+    for (int l = t; l < L; l += NT) s_runs[l] = 0;
+    for (int p = t; p < P; p += NT) {
         double x = poses[7 * p], y = poses[7 * p + 1], z = poses[7 * p + 2], q = poses[7 * p + 3];
         const double n = sqrt(x * x + y * y + z * z + q * q);
         x /= n; y /= n; z /= n; q /= n;
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256) void k_ba_build(BaArgs a) {
     }
     __syncthreads();
     // runs of every landmark: a run starts where the landmark index changes (integer counts: the order of the adds does not matter)
-    for (int k = t; k < E; k += 256) {
+    for (int k = t; k < E; k += NT) {
         const int il = el[k];
         if (il >= 0 && il < L && (k == 0 || el[k - 1] != il)) {
             const int earlier = atomicAdd(&s_runs[il], 1);
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(256) void k_ba_build(BaArgs a) {
         double* bl = a.bl + ((size_t)w * a.maxL + il) * 3;
         bl[0] = hl[6]; bl[1] = hl[7]; bl[2] = hl[8];
     };
-    for (int k = t; k < E; k += 256) {                          // edges outside single-run landmarks: one per thread
+    for (int k = t; k < E; k += NT) {                          // edges outside single-run landmarks: one per thread
         const int il = el[k];
         if (il < 0 || il >= L) {                                // malformed edge: contributes nothing
             a.chi2[(size_t)w * a.maxE + k] = 0.0;
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256) void k_ba_build(BaArgs a) {
     }
     // single-run landmarks: a lane PAIR per landmark, each lane walks one half of the run (every lane of the wave has work; a thread
     // per run start would leave nine lanes in ten idle); the two halves are added first + second
-    for (int i0 = 0; i0 < 2 * L; i0 += 256) {                   // uniform trip count: the pair exchange needs both lanes
+    for (int i0 = 0; i0 < 2 * L; i0 += NT) {                   // uniform trip count: the pair exchange needs both lanes
         const int idx = i0 + t, il = idx >> 1, half = idx & 1;
         double hl[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         const bool own = il < L && s_runs[il] == 1;
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(256) void k_ba_build(BaArgs a) {
         for (int u = 0; u < 9; u++) hl[u] += __shfl_down(hl[u], 1, 64);       // even lane: first half + second half
         if (own && half == 0) lm_store(il, hl);
     }
-    for (int il = t; il < L; il += 256) {                       // landmarks without edges (zeros) or with scattered edges (full scan, edge order)
+    for (int il = t; il < L; il += NT) {                       // landmarks without edges (zeros) or with scattered edges (full scan, edge order)
         const int nr = s_runs[il];
         if (nr == 1) continue;
         double hl[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -234,17 +239,23 @@ __global__ __launch_bounds__(256) void k_ba_build(BaArgs a) {
     }
     __syncthreads();
     // pose blocks: the four wave copies in wave order
-    for (int i = t; i < P * 36; i += 256) {
+    for (int i = t; i < P * 36; i += NT) {
         const int p = i / 36, r = (i % 36) / 6, c = i % 6;
         const int rr = min(r, c), cc = max(r, c);
         const int u = rr * 6 - rr * (rr - 1) / 2 + (cc - rr);       // index in the row-major upper triangle
         const size_t o = (size_t)27 * p + u, ws = (size_t)a.maxP * 27;
-        a.Hpp[((size_t)w * a.maxP + p) * 36 + r * 6 + c] = ((sAcc[o] + sAcc[ws + o]) + sAcc[2 * ws + o]) + sAcc[3 * ws + o];
+        double acc = sAcc[o];
+#pragma unroll
+        for (int q = 1; q < NW; q++) acc += sAcc[q * ws + o];
+        a.Hpp[((size_t)w * a.maxP + p) * 36 + r * 6 + c] = acc;
     }
-    for (int i = t; i < P * 6; i += 256) {
+    for (int i = t; i < P * 6; i += NT) {
         const int p = i / 6, r = i % 6;
         const size_t o = (size_t)27 * p + 21 + r, ws = (size_t)a.maxP * 27;
-        a.bp[(size_t)w * a.maxP * 6 + i] = ((sAcc[o] + sAcc[ws + o]) + sAcc[2 * ws + o]) + sAcc[3 * ws + o];
+        double acc = sAcc[o];
+#pragma unroll
+        for (int q = 1; q < NW; q++) acc += sAcc[q * ws + o];
+        a.bp[(size_t)w * a.maxP * 6 + i] = acc;
     }
 }
 
@@ -1099,15 +1110,21 @@ __global__ __launch_bounds__(NT) void k_pose_only(PoseOnlyArgs a) {
     }
 }
 
-static size_t ba_lds(int maxP, int maxL) { return sizeof(double) * ((size_t)maxP * (12 + 4 * 27)) + sizeof(int) * 3 * (size_t)maxL; }
+static size_t ba_lds(int maxP, int maxL, int nwaves) { return sizeof(double) * ((size_t)maxP * (12 + nwaves * 27)) + sizeof(int) * 3 * (size_t)maxL; }
+
+constexpr int BA_WIDE_BELOW = 32;      // fewer windows than this per call: 1024 threads per window (latency), else 256 (throughput)
 
 static int ba_launch(const BaArgs& a, int nwin, hipStream_t s) {
-    const size_t lds = ba_lds(a.maxP, a.maxL);
+    const bool wide = nwin < BA_WIDE_BELOW && ba_lds(a.maxP, a.maxL, 16) <= 150 * 1024;
+    const size_t lds = ba_lds(a.maxP, a.maxL, wide ? 16 : 4);
     if (lds > 150 * 1024) return MYSLAM_ERR_CAPACITY;
-    if (lds > 48 * 1024)
-        MYSLAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // (the limit is state of the function, not of the launch: always raised to what any plan may need — see launch_octree)
+    static const bool raised = (hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess) &
+                               (hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess);
+    (void)raised;
     ScopedProf sp(P_BA, s);
-    hipLaunchKernelGGL(k_ba_build, dim3(nwin), dim3(256), lds, s, a);
+    if (wide) hipLaunchKernelGGL(k_ba_build<1024>, dim3(nwin), dim3(1024), lds, s, a);
+    else hipLaunchKernelGGL(k_ba_build<256>, dim3(nwin), dim3(256), lds, s, a);
     MYSLAM_HIP_CHECK(hipGetLastError());
     return MYSLAM_OK;
 }

@@ -29,6 +29,7 @@ namespace myslam_hip {
 // (History: xor / popcount on the VALU ran at its issue peak, 1.00 ms per 512 pairs; int8 MFMA 0.40 ms; this FP4 form 0.23 ms.)
 constexpr int HQ_TILES = 4;                       // query tiles of 32 per wave -> 512 queries per block
 constexpr int HQ_BLOCK = 4 * HQ_TILES * 32;
+constexpr int HQ_NARROW_BELOW = 16;               // fewer pairs than this per call: one query tile per wave (k_hamming_fp4<1>)
 
 // The product runs on the FP4 path of the matrix cores (v_mfma_scale_f32_32x32x64_f8f6f4, K = 64 per instruction, twice the int8
 // rate): E2M1 represents +-1 exactly (0x2 / 0xA), the factor 32 of the query operand is its E8M0 block scale (2^5), sums of at most
@@ -38,6 +39,10 @@ typedef int hq_v8i __attribute__((ext_vector_type(8)));
 typedef float hq_v16f __attribute__((ext_vector_type(16)));
 constexpr int HF_ROWB = 144;                      // LDS bytes per expanded train row (128 + 16)
 
+// TILES = query tiles of 32 per wave: 4 (512 queries per block) for batches; 1 (128 per block) for a handful of pairs — the block's loop
+// over the train chunks is a chain of barrier-separated steps, and with one tile per wave a step is a quarter as long while four times
+// as many blocks run side by side (one pair of 2 000 x 2 000: 50 -> ~25 us).  Same bits either way (integer arg-min, ties by row).
+template <int TILES>
 __global__ __launch_bounds__(256) void k_hamming_fp4(const uint8_t* __restrict__ q, const int32_t* __restrict__ nqv,
                                                      const uint8_t* __restrict__ tr, const int32_t* __restrict__ ntv,
                                                      int cap, int nq_single, int nt_single,
@@ -48,7 +53,8 @@ __global__ __launch_bounds__(256) void k_hamming_fp4(const uint8_t* __restrict__
     const int p = blockIdx.y;
     const int nq = nqv ? min(nqv[p], cap) : nq_single;
     const int nt = ntv ? min(ntv[p], cap) : nt_single;
-    const int q0 = blockIdx.x * HQ_BLOCK;
+    constexpr int QBLOCK = 4 * TILES * 32;
+    const int q0 = blockIdx.x * QBLOCK;
     if (q0 >= nq) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     {
@@ -61,10 +67,10 @@ __global__ __launch_bounds__(256) void k_hamming_fp4(const uint8_t* __restrict__
     const uint32_t* T = reinterpret_cast<const uint32_t*>(tr + (size_t)p * cap * 32);
     auto expand32 = [&](uint32_t w) { return make_uint4(s_lut[w & 0xff], s_lut[(w >> 8) & 0xff], s_lut[(w >> 16) & 0xff], s_lut[w >> 24]); };
     // query operands: k block m of tile t takes descriptor dword 2 m + (lane >> 5) of query qb + 32 t + (lane & 31)
-    const int qb = q0 + wv * (HQ_TILES * 32);
-    hq_v8i B[HQ_TILES][4];
+    const int qb = q0 + wv * (TILES * 32);
+    hq_v8i B[TILES][4];
 #pragma unroll
-    for (int t = 0; t < HQ_TILES; t++) {
+    for (int t = 0; t < TILES; t++) {
         const int qi = qb + 32 * t + (lane & 31);
 #pragma unroll
         for (int m = 0; m < 4; m++) {
@@ -81,9 +87,9 @@ __global__ __launch_bounds__(256) void k_hamming_fp4(const uint8_t* __restrict__
         cinit[r] = (float)(31 - row);
         ctail[r] = (last0 + row < nt) ? (float)(31 - row) : -16777216.f;
     }
-    int bestv[HQ_TILES], bestor[HQ_TILES], bestc[HQ_TILES];
+    int bestv[TILES], bestor[TILES], bestc[TILES];
 #pragma unroll
-    for (int t = 0; t < HQ_TILES; t++) { bestv[t] = -(1 << 30); bestor[t] = -(1 << 30); bestc[t] = 0; }
+    for (int t = 0; t < TILES; t++) { bestv[t] = -(1 << 30); bestor[t] = -(1 << 30); bestc[t] = 0; }
     const int er = tid >> 3, ed = tid & 7;                   // expansion job: dword ed of chunk row er
     auto expand = [&](int buf, uint32_t w) { *reinterpret_cast<uint4*>(&s_exp[buf][er * HF_ROWB + ed * 16]) = expand32(w); };
     const int nchunk = (nt + 31) >> 5;
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(256) void k_hamming_fp4(const uint8_t* __restrict__
         }
         const hq_v16f c0 = (c + 1 == nchunk) ? ctail : cinit;
 #pragma unroll
-        for (int t = 0; t < HQ_TILES; t++) {
+        for (int t = 0; t < TILES; t++) {
             // A: FP4, scale 2^0 (E8M0 127); B: FP4, scale 2^5 (132)
             hq_v16f acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[0], B[t][0], c0, 4, 4, 0, 127, 0, 132);
 #pragma unroll
@@ -120,7 +126,7 @@ __global__ __launch_bounds__(256) void k_hamming_fp4(const uint8_t* __restrict__
         }
     }
 #pragma unroll
-    for (int t = 0; t < HQ_TILES; t++) {
+    for (int t = 0; t < TILES; t++) {
         const int dot = bestv[t] >> 5, row = 31 - (bestv[t] & 31);
         const uint32_t key = bestv[t] < -(1 << 20) ? 0u
                                                      : ((uint32_t)(dot + 256) << 20) | (0xfffffu - (uint32_t)(bestc[t] * 32 + row));
@@ -243,8 +249,11 @@ int myslam_hamming_match_batch(const uint8_t* d_q, const int32_t* d_nq, const ui
     if (cap >= (1 << 20)) return MYSLAM_ERR_UNSUPPORTED;          // the running minimum packs (distance, train index) into 32 bits
     hipStream_t s = (hipStream_t)hip_stream;
     ScopedProf sp(P_MATCH, s);
-    hipLaunchKernelGGL(k_hamming_fp4, dim3((cap + HQ_BLOCK - 1) / HQ_BLOCK, batch), dim3(256), 0, s, d_q, d_nq, d_t, d_nt, cap, 0, 0,
-                       d_train_idx, d_dist);
+    if (batch < HQ_NARROW_BELOW)
+        hipLaunchKernelGGL(k_hamming_fp4<1>, dim3((cap + 127) / 128, batch), dim3(256), 0, s, d_q, d_nq, d_t, d_nt, cap, 0, 0, d_train_idx, d_dist);
+    else
+        hipLaunchKernelGGL(k_hamming_fp4<HQ_TILES>, dim3((cap + HQ_BLOCK - 1) / HQ_BLOCK, batch), dim3(256), 0, s, d_q, d_nq, d_t, d_nt, cap, 0, 0,
+                           d_train_idx, d_dist);
     MYSLAM_HIP_CHECK(hipGetLastError());
     return MYSLAM_OK;
 }
@@ -266,7 +275,7 @@ int myslam_hamming_match(const uint8_t* query, int nq, const uint8_t* train, int
     int32_t* di = hc.dev<int32_t>(pi); int32_t* dd = hc.dev<int32_t>(pd);
     {
         ScopedProf sp(P_MATCH, hc.stream());
-        hipLaunchKernelGGL(k_hamming_fp4, dim3((nq + HQ_BLOCK - 1) / HQ_BLOCK, 1), dim3(256), 0, hc.stream(), dq, (const int32_t*)nullptr, dt,
+        hipLaunchKernelGGL(k_hamming_fp4<1>, dim3((nq + 127) / 128, 1), dim3(256), 0, hc.stream(), dq, (const int32_t*)nullptr, dt,
                            (const int32_t*)nullptr, cap, nq, nt, di, dd);
     }
     MYSLAM_HIP_CHECK(hipGetLastError());

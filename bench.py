@@ -215,6 +215,11 @@ def parse():
     ap.add_argument("--side-skip", default="", help="diagnostic: comma list of side-chain parts to leave out (lcd, db, ba) — measures what each part costs the step")
     ap.add_argument("--blur-mfma", type=int, default=0, choices=[0, 1],
                     help="myslam_orb_set_option(BLUR_MFMA): 1 = the Gaussian pyramid on the int8 matrix cores (k_blur7_mfma), 0 = register-strip kernel")
+    ap.add_argument("--stream-mode", default="1x16,2x16,4x16",
+                    help="live-stream operating points, 'PAIRSxLANES,...' ('' = skip): after the other passes each point is run as a child process "
+                         "(bench.py --pairs P --lanes L --graph 1: recorded steps on L lanes scanning ONE loop database through L query contexts; its own "
+                         "GPU_MAX_HW_QUEUES) and reported as `stream_mode` — the reference's call pattern is one frame per call (src/frontend.cpp:41-77)")
+    ap.add_argument("--frame-latency", action="store_true", help="(child of --stream-mode) also time every step on its lane with an event pair: `frame_latency_ms`")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = debugging aid: several ranks share GPU 0 and the collectives go through host memory")
     args = ap.parse_args()
@@ -729,6 +734,24 @@ def main():
     api.prof_enable(False)
     dt = timed(args.steps)
     host_launch_ms = host_ms[0]
+    frame_latency = None
+    if use_graph and args.frame_latency:
+        # every step timed on ITS lane (event pair around the replay) while all lanes are busy, then one lane alone: what a camera sees
+        n_probe = min(args.steps, 64 * len(lanes))
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_probe)]
+        barrier()
+        for a_, b_ in evs:
+            ln = lanes[step_no[0] % len(lanes)]
+            a_.record(ln["stream"]); step(); b_.record(ln["stream"])
+        barrier()
+        loaded = sorted(a_.elapsed_time(b_) for a_, b_ in evs)
+        ln = lanes[0]; alone = []
+        for _ in range(32):
+            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a_.record(ln["stream"]); ln["graphs"][ln["k"] & 1].launch(ln["stream"].cuda_stream); ln["k"] += 1; b_.record(ln["stream"])
+            ln["stream"].synchronize(); alone.append(a_.elapsed_time(b_))
+        frame_latency = {"loaded_median_ms": loaded[len(loaded) // 2], "loaded_p90_ms": loaded[int(0.9 * (len(loaded) - 1))],
+                         "one_lane_alone_ms": float(np.median(alone)), "steps_probed": n_probe}
     if not use_graph:
         step = step_eager
 
@@ -1014,6 +1037,29 @@ def main():
         solve_ms = (time.perf_counter() - t1) / 5 * 1e3
         assert int(s_st.abs().sum()) == 0
 
+    stream_mode = None
+    if rank == 0 and world == 1 and args.stream_mode and not args.no_extra_passes and args.workload in ("full", "orb_match_lcd"):
+        barrier()
+        pts = []
+        for spec in args.stream_mode.split(","):
+            pp, ll = [int(v) for v in spec.lower().split("x")]
+            cmd = [sys.executable, os.path.abspath(__file__), "--pairs", str(pp), "--lanes", str(ll), "--graph", "1", "--steps", str(max(400, 1600 // pp)), "--warmup", "2",
+                   "--workload", args.workload, "--no-extra-passes", "--no-cpu-baseline", "--parity-frames", str(min(2, pp)), "--frame-latency", "--stream-mode", "",
+                   "--scene-rects", str(args.scene_rects)]
+            r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, GPU_MAX_HW_QUEUES="24"), timeout=600)
+            try:
+                cd = json.loads(r.stdout.strip().splitlines()[-1])
+                pts.append({"pairs_per_step": pp, "lanes": ll, "value": cd["value"], "ms_per_step": cd["ms_per_step"], "frame_latency_ms": cd["frame_latency"],
+                            "host_launch_ms_per_step": cd["host_launch_ms_per_step"], "graph_nodes": cd["graph_nodes"], "parity_ok": (cd["parity_sample"] or {}).get("ok")})
+            except Exception as e:               # a failed point is reported, not hidden
+                pts.append({"pairs_per_step": pp, "lanes": ll, "error": f"{type(e).__name__}: {e}", "rc": r.returncode, "stderr_tail": r.stderr[-300:]})
+        if pts:
+            head = dict(pts[0])
+            stream_mode = dict(head, unit="stereo frames/s", sweep=pts,
+                               note="recorded steps (HIP graph replay) on L lanes, step k on lane k mod L; every lane has its own extractor / DeepLCD handles and a QUERY CONTEXT "
+                                    "of the ONE shared loop database (myslam_lcddb_query_ctx); child processes of this run, GPU_MAX_HW_QUEUES=24.  The GPU runs ~4.4 in-order "
+                                    "chains side by side whatever the queue count (profiles/r05_queue_concurrency.json), so frames/s ~ 4.4 x pairs_per_step / chain latency: lanes "
+                                    "beyond ~16 add nothing, batching frames of several cameras into one step does")
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = world * P * args.steps / dt
@@ -1125,6 +1171,7 @@ def main():
             ("step_eager" if use_graph else "step_graph"): other_mode, "step_lanes_eager": lanes_eager,
             "ba_solve_all_windows_ms": solve_ms,     # OptimizeActiveMap solve stage for all P windows, outside the timed region
             "parity_sample": parity,
+            "stream_mode": stream_mode, "frame_latency": frame_latency,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(synth, args.workload, args.cpu_pairs, db_np if db_np is not None else synth.lcd_database(16), frames,

@@ -59,6 +59,11 @@ def test_bench_json_contract(extra):
         assert ps["lcd_max_abs"] < 2e-5 and ps["db_score_max_abs"] < 2e-5 and ps["ba_max_rel"] <= 1e-11
     else:
         assert ps["lcd_max_abs"] is None and ps["ba_max_rel"] is None
+    # live-stream operating points (children of the run): one pair per step first, every point parity-checked against the oracle
+    if "lcd" in d["config"]["workload"].lower():
+        sm = d["stream_mode"]
+        assert sm and sm["pairs_per_step"] == 1 and sm["lanes"] >= 8 and sm["value"] > 0 and len(sm["sweep"]) >= 3
+        assert all(p.get("parity_ok") is True and p["frame_latency_ms"]["one_lane_alone_ms"] > 0 for p in sm["sweep"]), sm["sweep"]
     if "--no-cpu-baseline" in extra:
         assert d["cpu_baseline"] is None
     else:
