@@ -194,6 +194,7 @@ def parse():
     ap.add_argument("--stream-split", type=int, default=2, help="streamed pass: the left and the right images of a step as separate copies with an event each, on this many copy streams (0 = one copy of the whole batch; 2 (default): 56.9-57.1 k frames/s against 51.6-54.1 k; 4: 53-55.6 k)")
     ap.add_argument("--lcd-split", type=int, default=1, help="the DeepLCD chain of a step in this many parts on as many handles / streams (1 = one chain on the side stream)")
     ap.add_argument("--ba-stream", choices=["side", "match"], default="match", help="the BA block build behind the triangulation on the match stream (default: +0.4 %, three alternating runs) or behind the DB scan on the side stream")
+    ap.add_argument("--solve-stream", choices=["own", "side"], default="own", help="the OptimizeActiveMap solve of the cadence passes on its own stream (the reference's Backend thread) or behind the side chain")
     ap.add_argument("--side-cus", type=int, default=0, help="experiment: the DeepLCD / DB / BA stream may use only this many CUs (hipExtStreamCreateWithCUMask); 0 = all")
     ap.add_argument("--match-cus", type=int, default=0, help="experiment: likewise for the match + triangulation stream")
     ap.add_argument("--created-main-stream", action="store_true", help="debug: the four-stream schedule's main chain on a created stream instead of the legacy NULL stream")
@@ -518,16 +519,26 @@ def main():
         s_rd = torch.zeros(P, dtype=torch.int32, device=dev); s_no = torch.zeros(P, dtype=torch.int32, device=dev)
         s_st = torch.zeros(P, dtype=torch.int32, device=dev)
 
+        # The solve has its own stream (round 5): Backend::OptimizeActiveMap runs on the Backend thread, beside LoopClosing's DeepLCD / DB chain
+        # (src/backend.cpp:36-49, src/loopclosing.cpp:66-81), and needs nothing from it.  Behind the side chain it made that chain the step's
+        # longest (+0.75 ms per step for 86 windows of 1.1 ms each); on its own stream the step pays only for the CUs the solve's blocks hold.
+        solve_stream = torch.cuda.Stream() if (args.solve_stream == "own" and args.streams == 2) else side_stream
+        s_hpl = torch.zeros(P, maxE * 18, dtype=torch.float64, device=dev) if solve_stream is not side_stream else b_out[2]     # the solve's scratch (the build writes b_out[2] at the same time)
+
         def solve(nwin=P):   # Backend::OptimizeActiveMap solve stage: rounds of optimize(10) + outlier flags (backend.cpp:208-243)
-            s_poses[:nwin].copy_(b_in[0][:nwin]); s_pts[:nwin].copy_(b_in[1][:nwin])
-            api.ba_optimize_active_map_batch(s_poses.data_ptr(), s_pts.data_ptr(), *[t.data_ptr() for t in b_in[2:]], nwin, maxP, maxL, maxE, Kt,
-                                             5.991, 5.991, 5, 10, b_out[2].data_ptr(), s_echi.data_ptr(), s_out.data_ptr(), s_rd.data_ptr(),
-                                             s_no.data_ptr(), s_st.data_ptr(), stream2)
+            with torch.cuda.stream(solve_stream):
+                s_poses[:nwin].copy_(b_in[0][:nwin]); s_pts[:nwin].copy_(b_in[1][:nwin])
+                api.ba_optimize_active_map_batch(s_poses.data_ptr(), s_pts.data_ptr(), *[t.data_ptr() for t in b_in[2:]], nwin, maxP, maxL, maxE, Kt,
+                                                 5.991, 5.991, 5, 10, s_hpl.data_ptr(), s_echi.data_ptr(), s_out.data_ptr(), s_rd.data_ptr(),
+                                                 s_no.data_ptr(), s_st.data_ptr(), solve_stream.cuda_stream)
     solve_windows = [P if use_solve else 0]          # windows the side chain also SOLVES per step (pass 3 sets ceil(P / 6))
 
     skip = set(args.side_skip.split(",")) if args.side_skip else set()      # diagnostic: the marginal cost of the side chain's parts
 
     def side_chain(with_ba=True):
+        if use_ba and "ba" not in skip and solve_windows[0] and solve_stream is not side_stream:
+            solve_stream.wait_stream(side_stream)      # starts with the step (the side stream has just waited for the step's start event), runs beside the chain below
+            solve(solve_windows[0])
         if use_lcd and "lcd" not in skip:
             if lcd_parts:
                 n_part = P // (len(lcd_parts) + 1)
@@ -557,7 +568,7 @@ def main():
         if use_ba and "ba" not in skip:
             if with_ba or solve_windows[0]:
                 api.ba_build_batch(*[t.data_ptr() for t in b_in], P, maxP, maxL, maxE, Kt, 5.991, *[t.data_ptr() for t in b_out], stream2)
-            if solve_windows[0]:
+            if solve_windows[0] and solve_stream is side_stream:
                 solve(solve_windows[0])
 
     ba_on_match = [False]
@@ -1026,7 +1037,7 @@ def main():
         parity = parity_sample(api, synth, frames, sample, cap, Kt, K, bufs, db_np, ids if use_lcd else None, int(cur_ids[0]) if use_lcd else 0,
                                ba_w, synth.calc_weights())
 
-    solve_ms = None
+    solve_ms = None; solve_roof = None
     if use_ba and not use_solve and not args.no_extra_passes:        # the solve of ALL P windows, timed on its own (not part of `value`)
         with torch.cuda.stream(side_stream):
             solve(); torch.cuda.synchronize()
@@ -1036,6 +1047,22 @@ def main():
             torch.cuda.synchronize()
         solve_ms = (time.perf_counter() - t1) / 5 * 1e3
         assert int(s_st.abs().sum()) == 0
+        # k_ba_optimize against the f64 peaks: a flop MODEL of what one Levenberg iteration of a window executes (not a counter): edge evaluation +
+        # Jacobians + block products ~410 flop per edge, Schur complement sum_l W_l Hll^-1 W_l^T = (108 k + 216 k^2) flop
+        # for a landmark seen by k key-frames, 6x6-blocked Cholesky n^3 / 3 and two triangular solves 2 n^2 with n = 6 P; rounds x 10 iterations
+        # (optimize(10), backend.cpp:212-214: every round runs its iteration budget unless a Levenberg trial fails ten times)
+        rounds_mean = float(s_rd.float().mean().item())
+        szs = ba_w[6]                                                    # [P, 3] = poses, landmarks, edges per window
+        npo, nla, ned = [float(np.mean(szs[:, i])) for i in range(3)]
+        kobs = ned / max(1.0, nla)
+        flop_it = 410.0 * ned + nla * (108.0 * kobs + 216.0 * kobs * kobs) + (6 * npo) ** 3 / 3.0 + 2 * (6 * npo) ** 2
+        flops = P * rounds_mean * 10 * flop_it
+        solve_roof = {"bound": "f64 (vector + matrix cores)", "kernel": "k_ba_optimize", "unit": "TFLOP/s (f64, modelled flops)", "avg_launch_ms": solve_ms,
+                      "windows_per_launch": P, "rounds_mean": rounds_mean, "modelled_flop_per_iteration": flop_it, "achieved": flops / (solve_ms * 1e-3) / 1e12,
+                      "peak": 78.6, "peak_f64_mfma_measured": 48.0, "frac": flops / (solve_ms * 1e-3) / 1e12 / 78.6,
+                      "note": "one 512-thread block per window with the window's state in 133 KB of LDS (one block per CU): iterations are chains of barrier-separated "
+                              "phases (pose blocks, landmark blocks, Schur chunks on v_mfma_f64_16x16x4_f64, 6x6-blocked Cholesky, back-substitution, update, chi2); "
+                              "peak = MI355X f64 vector 78.6 TFLOP/s, measured f64 MFMA 48 (profiles/r03_peaks.json)"}
 
     stream_mode = None
     if rank == 0 and world == 1 and args.stream_mode and not args.no_extra_passes and args.workload in ("full", "orb_match_lcd"):
@@ -1170,6 +1197,7 @@ def main():
             "graph_nodes": lanes[0]["graphs"][0].node_count() if (use_graph and lanes) else None,
             ("step_eager" if use_graph else "step_graph"): other_mode, "step_lanes_eager": lanes_eager,
             "ba_solve_all_windows_ms": solve_ms,     # OptimizeActiveMap solve stage for all P windows, outside the timed region
+            "roofline_ba_optimize": solve_roof,
             "parity_sample": parity,
             "stream_mode": stream_mode, "frame_latency": frame_latency,
         }

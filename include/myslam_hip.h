@@ -411,7 +411,12 @@ int myslam_ba_optimize_batch(double* d_poses, double* d_points, const int32_t* d
  * { initializeOptimization(); optimize(iters_per_round = 10) }, stopping as soon as more than half of the edges have
  * chi2() <= chi2_th (5.991); then the outlier flags of :232-249.  edge_chi2[k] is what edge->chi2() returns there: e^T e of
  * the last error evaluation (the last Levenberg trial, accepted or not — a g2o property the reference inherits).
- * *rounds = the reference's `iteration` counter (rounds that failed the inlier test).  Edges grouped by landmark, max_poses <= MYSLAM_BA_MAX_WINDOW_POSES. */
+ * *rounds = the reference's `iteration` counter (rounds that failed the inlier test).  *rounds == max_rounds means EVERY round failed:
+ * the window did NOT converge to a majority-inlier solution (the reference carries on with the result regardless, backend.cpp:232-266;
+ * on such windows the Levenberg iteration is chaotic — one ulp in an observation moves the final poses by decimetres in the reference
+ * arithmetic itself — so poses / flags agree with another implementation only in distribution: tests/golden/ba_chaotic_window.npz).
+ * MYSLAM_BA_CONVERGED(rounds, max_rounds) spells the test.  Edges grouped by landmark, max_poses <= MYSLAM_BA_MAX_WINDOW_POSES. */
+#define MYSLAM_BA_CONVERGED(rounds, max_rounds) ((rounds) < (max_rounds))
 int myslam_ba_optimize_active_map(double* poses, int nposes, double* points, int npts, const int32_t* edge_pose, const int32_t* edge_pt,
                                   const double* obs, int nedges, const uint8_t* fixed_pt, double fx, double fy, double cx, double cy,
                                   double huber_delta, double chi2_th, int max_rounds, int iters_per_round,

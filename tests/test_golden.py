@@ -70,3 +70,19 @@ def test_hip_reproduces_golden(api, synth):
     g = np.load(os.path.join(G, "pnp_small.npz"))
     pose, inl, ni = api.solve_pnp_ransac(g["pts3d"], g["pts2d"], tuple(g["K"]))
     assert np.array_equal(inl, g["inlier"]) and ni == int(g["n_inliers"]) and np.abs(pose - g["pose"]).max() < 1e-9
+
+
+def test_chaotic_window_fixture_is_the_oracle_and_is_chaotic(oracle):
+    """tests/golden/ba_chaotic_window.npz (make_ba_chaotic_window.py): the fixture is what the oracle computes, every round of the solve
+    fails on it, and the oracle run on one-ulp-different observations departs from itself ten-fold per Levenberg iteration — the property
+    the GPU test (tests/test_gpu_ba.py::test_chaotic_window_is_pinned) and the BA fuzzer's acceptance rule rest on."""
+    d = np.load(os.path.join(G, "ba_chaotic_window.npz"))
+    args = (d["poses"], d["pts"], d["ep"], d["el"], d["obs"], d["fixed"], tuple(d["K"]))
+    ref = oracle.ba_optimize_active_map(*args)
+    assert ref[4] == int(d["ref_rounds"]) == 5 and ref[5] == int(d["ref_nout"]) and np.array_equal(ref[3], d["ref_out"])
+    assert ref[5] > len(d["ep"]) // 2                                    # mostly outliers: no round can reach the 50 % inlier bar
+    a = oracle.ba_optimize(*args, iters=3)
+    assert np.abs(a[0] - d["it3_poses"]).max() < 1e-13 and a[3] == 3
+    sp = d["self_spread"].max(0)                                         # one-ulp self spread after 1, 2, 3, 5, 10 iterations
+    assert sp[0] < 1e-13 and sp[4] > 1e-8 and sp[4] > 1e5 * sp[0]        # rounding noise -> visible in ten iterations
+    assert all(int(r) == 5 for r in d["self_final"][:, 0]) and d["self_final"][:, 2].min() > 1e-3      # finals 0.4 apart, all rounds fail every time

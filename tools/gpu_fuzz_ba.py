@@ -42,15 +42,25 @@ for it in range(N):
         okb = oko = False; print("exception", e)
     if okb and not oko and gr == rr == 5:
         # A window that fails the inlier test in all five rounds (50 Levenberg iterations on data that is mostly gross outliers) can be
-        # CHAOTIC: the iterates of the two implementations agree to 1e-14 after one iteration and drift apart ten-fold per iteration (seen:
-        # 4 key-frames x 25 landmarks, 62 of 96 edges outliers — 6.6e-7 after 10 iterations, different outlier counts after 50).  The
-        # reference would do the same against itself with another FMA setting.  Such a case counts as chaotic, not as a mismatch, when the
-        # early iterates agree to rounding.
+        # CHAOTIC (tests/golden/ba_chaotic_window.npz, tests/test_gpu_ba.py::test_chaotic_window_is_pinned).  It is accepted as such only
+        # when that is PROVEN for the case at hand: (a) the first three iterates agree to rounding, and (b) the oracle run on observations
+        # that differ by ONE ULP moves its own answer at least a fifth as far as the HIP answer is from the oracle's — i.e. the
+        # disagreement is no larger than what input rounding noise does to the reference arithmetic itself.  Anything else is a mismatch.
         a3 = api.ba_optimize(poses, pts, ep, el, obs, fixed, K, iters=3); b3 = o.ba_optimize(poses, pts, ep, el, obs, fixed, K, iters=3)
-        if a3[3] == b3[3] and np.abs(a3[0] - b3[0]).max() < 1e-9 and abs(a3[2] - b3[2]) <= 1e-9 * abs(b3[2]):
+        early = a3[3] == b3[3] and np.abs(a3[0] - b3[0]).max() < 1e-9 and abs(a3[2] - b3[2]) <= 1e-9 * abs(b3[2])
+        prng = np.random.default_rng(it); self_d, self_n = 0.0, []
+        for _ in range(3):
+            obs2 = obs * (1.0 + prng.choice([-1, 1], obs.shape) * 2.0 ** -52)
+            r2 = o.ba_optimize_active_map(poses, pts, ep, el, obs2, fixed, K)
+            self_d = max(self_d, float(np.abs(r2[0] - rp).max())); self_n.append(r2[5])
+        dev = float(np.abs(gp - rp).max())
+        inl = 1.0 - rn / max(1, len(ep))
+        if early and dev <= 5.0 * self_d and min(self_n + [rn]) - 1 <= gn <= max(self_n + [rn]) + 1:
             chaotic += 1
-            print("chaotic window (early iterates agree, all five rounds fail)", dict(it=it, n_kf=n_kf, n_mp=n_mp, E=len(ep), mode=mode, nout=(gn, rn)))
+            print("chaotic window (early iterates agree; oracle's one-ulp self-spread covers the difference)",
+                  dict(it=it, n_kf=n_kf, n_mp=n_mp, E=len(ep), mode=mode, nout=(gn, rn), inlier_ratio=round(inl, 3), hip_vs_oracle=dev, oracle_one_ulp_spread=self_d))
             continue
+        print("   all rounds failed but NOT provably chaotic:", dict(early=bool(early), hip_vs_oracle=dev, oracle_one_ulp_spread=self_d, nout=(gn, rn, self_n), inlier_ratio=round(inl, 3)))
     if not (okb and oko):
         bad += 1
         print("MISMATCH", dict(it=it, n_kf=n_kf, n_mp=n_mp, E=len(ep), mode=mode, build=okb, opt=oko))
