@@ -8,7 +8,7 @@
 //
 // Reads <sequence>/times.txt and image_0 / image_1/%06d.png (LoadImages + cv::imread(…, IMREAD_GRAYSCALE): host/myslam_io.hpp,
 // host/myslam_png.hpp), tracks every frame through host/myslam_system.hpp (Frontend / Backend / LoopClosing / Map as one sequential
-// schedule), writes <out>/trajectory.txt and <out>/loop_edges.txt in the reference's format (src/system.cpp:153-224).  The CALC model
+// schedule), writes <out>/trajectory.txt and <out>/loopEdges.txt in the reference's format (src/system.cpp:153-224).  The CALC model
 // defaults to the reference's calc_model/ files relative to the working directory (include/myslam/deeplcd.h:33).
 // Built by build.py (g++, links libmyslam_hip.so); tests/test_gpu_runner.py runs it on a rendered 200-frame KITTI-layout sequence and
 // compares its trajectory with the Python chain's.
@@ -101,8 +101,10 @@ int main(int argc, char** argv) {
             std::ofstream g(out + "/key_frame_frames.txt");
             for (unsigned long id : slam.keyFrameFrames) g << id << "\n";
         }
+        // the reference's closing lines (app/run_kitti_stereo.cpp:101-105), for scripts that scrape them
+        std::printf("\n-------\nsystem stop.\ntotal time cost: %g, average fps: %g\n", tRun + tRead, done / std::max(tRun + tRead, 1e-9));
         std::printf("%d frames (%dx%d), %zu key-frames, %zu map points, %zu loops; waited %.2f s for images, tracked + mapped in %.2f s = %.1f frames/s, %.1f frames/s end to end "
-                    "(compiled host, one call per operator and frame; %ld pose-only, %ld local-BA, %ld DeepLCD, %ld loop queries); wrote %s/trajectory.txt, loop_edges.txt\n",
+                    "(compiled host, one call per operator and frame; %ld pose-only, %ld local-BA, %ld DeepLCD, %ld loop queries); wrote %s/trajectory.txt, loopEdges.txt\n",
                     done, cols, rows, slam.NumKeyFrames(), slam.NumMapPoints(), slam.NumLoops(), tRead, tRun, done / std::max(tRun, 1e-9), done / std::max(tRun + tRead, 1e-9),
                     slam.stats.poseOnly, slam.stats.ba, slam.stats.lcd, slam.stats.detectLoop, out.c_str());
     } catch (const std::exception& e) {

@@ -26,6 +26,10 @@ What a sequential program has to DECIDE (the reference runs three threads whose 
     the tracker sees the blurred image (`lcd_blur_reaches_tracker=True`, the default; False = the frontend wins the race);
   * std::unordered_map iteration order (Map::RemoveOldActiveKeyframe's max / min search, the edge order of the pose graph) is taken as
     ascending id.
+Two deliberate deviations from the reference's text (host/myslam_system.hpp: the same): LoopLocalFusion skips a matched pair whose two
+features already share one map point (loopclosing.cpp:516-527 would re-add its observations to itself and RemoveMapPoint() it); a live
+active map point without any observation is an error (backend.cpp:175 would take front() of an empty list), an outlier one is skipped
+first as backend.cpp:163 does.
 `kf_every > 0` replaces the inlier-count rule by "every n-th frame" (the schedule of rounds 2-3, kept as an option)."""
 import numpy as np
 
@@ -558,7 +562,10 @@ class Chain:
         if not kfs or not mps:
             return
         rows = [(mp, f) for mp in mps for f in mp.active_obs]
-        first = [(mp.obs[0].kf.id if mp.obs else mp.active_obs[0].kf.id) for mp in mps]        # GetObservations().front()->mpKF (:175)
+        # GetObservations().front()->mpKF (:175); an outlier point is dropped by the flatten rules (:163) before :175 could touch it
+        first = [(mp.obs[0].kf.id if mp.obs else mp.active_obs[0].kf.id if mp.active_obs else 0) for mp in mps]
+        if any(not m.outlier and not m.obs and not m.active_obs for m in mps):
+            raise RuntimeError("active map point without observations")
         # the graph-build rules of :139-206 live behind the C ABI (myslam_ba_flatten_window): skip outlier map points / features, fix the
         # landmarks whose first observer left the window, vertices by id, edges grouped by landmark
         fl = self.api.ba_flatten_window([k.id for k in kfs], [m.id for m in mps], [1 if m.outlier else 0 for m in mps], first,
@@ -731,6 +738,6 @@ class Chain:
                                  np.array([k.ts for k in kfs]), np.stack([k.pose for k in kfs]))
         lp = [k for k in kfs if k.loop_kf is not None]
         z7 = np.zeros((0, 7))
-        self.api.save_loop_edges(os.path.join(out_dir, "loop_edges.txt"), np.array([k.id for k in lp], np.uint64), np.array([k.ts for k in lp]),
+        self.api.save_loop_edges(os.path.join(out_dir, "loopEdges.txt"), np.array([k.id for k in lp], np.uint64), np.array([k.ts for k in lp]),
                                  np.stack([k.pose for k in lp]) if lp else z7, np.array([k.loop_kf.id for k in lp], np.uint64),
                                  np.array([k.loop_kf.ts for k in lp]), np.stack([k.loop_kf.pose for k in lp]) if lp else z7)

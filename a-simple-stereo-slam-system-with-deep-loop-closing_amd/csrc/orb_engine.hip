@@ -663,6 +663,9 @@ static int host_extract(myslam_orb* h, const uint8_t* img, int rows, int cols, i
     const int dcap = std::max(cap, std::max(h->full.totalOut, h->det.totalOut));
     const size_t imgBytes = (size_t)rows * step, maskBytes = mask ? imgBytes : 0;
     if ((rc = h->ensure_stage(imgBytes, maskBytes, dcap))) return rc;
+    // the matrix-core Gaussian's tables are built (allocation, upload, synchronisation) BEFORE a capture can begin: inside one they would
+    // break it and pin this key to the eager path (advisor, round 4); building them bumps `gen`, so it also precedes the graph-key test
+    if (h->optBlurMfma && !detectOnly && (rc = h->ensure_blur_tables())) return rc;
     // pinned staging: [image][mask][a mirror of the device output block: counts (256 bytes) | key-points | descriptors]
     const size_t oOut = (imgBytes + maskBytes + 255) & ~(size_t)255, oCnt = oOut, oKps = oOut + 256, oDesc = oOut + h->stageDescOff;
     // what a call copies back: everything up to the last slot it can fill (Detect: no descriptors)

@@ -19,6 +19,8 @@
 #include <fstream>
 #include <string>
 #include <vector>
+#include <new>
+#include <stdexcept>
 
 namespace myslam {
 namespace io {
@@ -219,8 +221,7 @@ inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | (p[1] <
 
 }  // namespace png_detail
 
-// Decodes PNG bytes into a tight rows x cols u8 grey plane.  false: not a PNG this reader supports, or a corrupt one.
-inline bool DecodePngGray(const uint8_t* data, size_t size, std::vector<uint8_t>& pixels, int& rows, int& cols) {
+inline bool DecodePngGrayUnguarded(const uint8_t* data, size_t size, std::vector<uint8_t>& pixels, int& rows, int& cols) {
     using namespace png_detail;
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     if (size < 8 + 25 || std::char_traits<char>::compare((const char*)data, (const char*)sig, 8) != 0) return false;
@@ -255,7 +256,11 @@ inline bool DecodePngGray(const uint8_t* data, size_t size, std::vector<uint8_t>
     else return false;
     const size_t bits = (size_t)ch * depth, bpp = bits >= 8 ? bits / 8 : 1, stride = (bits * w + 7) / 8;
     std::vector<uint8_t> raw;
-    if (!inflate(z.data(), z.size(), raw, (stride + 1) * h) || raw.size() != (stride + 1) * h) return false;
+    // deflate expands by at most 1032 : 1 (a 258-byte match for 2 bits): an IHDR that promises more than the IDAT bytes could ever hold is
+    // refused BEFORE anything of its size is allocated (65535 x 65535 RGBA16 would be 34 GB from a 60-byte file)
+    const size_t expect = (stride + 1) * (size_t)h;
+    if (expect > 1032 * z.size() + 64) return false;
+    if (!inflate(z.data(), z.size(), raw, expect) || raw.size() != expect) return false;
     auto grey8 = [](uint32_t r, uint32_t g, uint32_t b) -> uint8_t { return (r == g && r == b) ? (uint8_t)r : (uint8_t)((9797u * r + 19234u * g + 3737u * b) >> 15); };
     // undo the per-row filters in place (row r occupies raw[r*(stride+1)+1 ...])
     const std::vector<uint8_t> zero(stride, 0);
@@ -323,6 +328,14 @@ inline bool DecodePngGray(const uint8_t* data, size_t size, std::vector<uint8_t>
     }
     rows = (int)h; cols = (int)w;
     return true;
+}
+
+// Decodes PNG bytes into a tight rows x cols u8 grey plane.  false: not a PNG this reader supports, a corrupt one, or one the process
+// has no memory for (the documented contract is "returns false": no exception leaves the reader).
+inline bool DecodePngGray(const uint8_t* data, size_t size, std::vector<uint8_t>& pixels, int& rows, int& cols) {
+    try { return DecodePngGrayUnguarded(data, size, pixels, rows, cols); }
+    catch (const std::bad_alloc&) { return false; }
+    catch (const std::length_error&) { return false; }
 }
 
 inline bool ReadPngGray(const std::string& path, std::vector<uint8_t>& pixels, int& rows, int& cols) {

@@ -21,6 +21,13 @@
 //   * DeepLCD blurs the key-frame's image in place and that image IS the frame's left image (cv::Mat copies share pixels): the next
 //     TrackLastFrame sees the blurred pixels (`lcdBlurReachesTracker`, default true; false = the frontend wins the race);
 //   * unordered_map iteration order is taken as ascending id.
+// Two places where this host deliberately does NOT do what the reference's text does (chain.py: the same):
+//   * LoopLocalFusion, a matched pair whose two features already share ONE map point: skipped.  The reference (loopclosing.cpp:516-527)
+//     would re-add that point's observations to itself and then RemoveMapPoint() the point both key-frames use — it flags its own live
+//     landmark as an outlier; a sequential host has no later pass that would notice, so the pair is left alone;
+//   * OptimizeActiveMap, an active map point with no observation at all: an outlier one is skipped first, as backend.cpp:163 does before
+//     it ever looks at GetObservations().front() (:175); a NON-outlier one would be undefined behaviour there (front() of an empty list)
+//     and is an error here.
 // Every arithmetic operator is a call into libmyslam_hip.so; what is computed here is bookkeeping and a handful of 4x4 products.
 #pragma once
 #include <cmath>
@@ -246,7 +253,7 @@ class StereoSystem {
             ci.push_back(k->id); ct.push_back(k->ts); cp.insert(cp.end(), k->pose.v, k->pose.v + 7);
             li.push_back(k->loopKF->id); lt.push_back(k->loopKF->ts); lp.insert(lp.end(), k->loopKF->pose.v, k->loopKF->pose.v + 7);
         }
-        check(myslam_io_save_loop_edges((dir + "/loop_edges.txt").c_str(), ci.data(), ct.data(), cp.data(), li.data(), lt.data(), lp.data(), (int)ci.size()),
+        check(myslam_io_save_loop_edges((dir + "/loopEdges.txt").c_str(), ci.data(), ct.data(), cp.data(), li.data(), lt.data(), lp.data(), (int)ci.size()),
               "myslam_io_save_loop_edges");
     }
 
@@ -495,8 +502,9 @@ class StereoSystem {
         for (KeyFrame* k : kfs) ba.AddKeyFrame(k->id, k->pose.v);
         std::vector<std::pair<MapPoint*, Feature*>> rows;
         for (MapPoint* m : mps) {
-            if (m->obs.empty() && m->activeObs.empty()) throw std::runtime_error("active map point without observations");
-            const unsigned long first = !m->obs.empty() ? m->obs[0]->kf->id : m->activeObs[0]->kf->id;      // GetObservations().front()->mpKF (:175)
+            // an outlier point is dropped by Flatten (:163) before :175 could touch obs.front(): only a live point must have an observation
+            if (!m->outlier && m->obs.empty() && m->activeObs.empty()) throw std::runtime_error("active map point without observations");
+            const unsigned long first = !m->obs.empty() ? m->obs[0]->kf->id : !m->activeObs.empty() ? m->activeObs[0]->kf->id : 0ul;      // GetObservations().front()->mpKF (:175)
             ba.AddMapPoint(m->id, m->pos, m->outlier, first);
             for (Feature* f : m->activeObs) { ba.AddObservation(m->id, f->kf->id, f->x, f->y, f->outlier); rows.emplace_back(m, f); }
         }

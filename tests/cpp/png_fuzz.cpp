@@ -26,6 +26,16 @@ int main(int argc, char** argv) {
             }
             pos += 12 + len;
         }
+        if (it % 5 == 0 && b.size() > 33) {
+            // IHDR mutation (CRC fixed up): width / height / depth / colour type the stream does not match, up to 65535 x 65535 RGBA16 —
+            // the reader must refuse before it allocates what the header promises
+            const int what = rng() % 4;
+            if (what == 0) { b[16] = 0; b[17] = 0; b[18] = 0xff; b[19] = 0xff; b[20] = 0; b[21] = 0; b[22] = 0xff; b[23] = 0xff; b[24] = 16; b[25] = 6; }
+            else if (what == 1) { const uint32_t v = rng() % 70000; size_t o = 16 + 4 * (rng() & 1); b[o] = v >> 24; b[o+1] = v >> 16; b[o+2] = v >> 8; b[o+3] = v; }
+            else if (what == 2) { static const uint8_t dd[6] = {1, 2, 4, 8, 16, 3}; b[24] = dd[rng() % 6]; }
+            else { b[25] = (uint8_t)(rng() % 8); }
+            uint32_t c = crc32(&b[12], 4 + 13); b[29] = c >> 24; b[30] = c >> 16; b[31] = c >> 8; b[32] = c;
+        }
         std::vector<uint8_t> px; int r, c;
         if (myslam::io::DecodePngGray(b.data(), b.size(), px, r, c)) ok++; else bad++;
     }

@@ -23,6 +23,6 @@ c = chain.Chain(OracleBackend(Oracle(), synth.calc_weights_handcrafted(), cfg, c
 out = os.path.join(HERE, "_traj_tmp")
 c.save(out)
 os.replace(os.path.join(out, "trajectory.txt"), os.path.join(HERE, "kitti_layout_200_trajectory.txt"))
-os.remove(os.path.join(out, "loop_edges.txt")); os.rmdir(out)
+os.remove(os.path.join(out, "loopEdges.txt")); os.rmdir(out)
 rmse, worst = kitti_layout.ate(chain, synth, c.poses, C, yaw)
 print(f"{len(frames)} frames, {len(c.all_kfs)} key-frames at frames {c.kf_frames}, {len(c.all_mps)} map points, ATE rmse {rmse:.4f} m worst {worst:.4f} m")

@@ -47,7 +47,7 @@ def test_trajectory_writer_and_ate(short_run, pkg, synth, tmp_path):
     c, C, yaw = short_run
     c.save(str(tmp_path))
     lines = open(tmp_path / "trajectory.txt").read().strip().split("\n")
-    assert len(lines) == len(c.all_kfs) and open(tmp_path / "loop_edges.txt").read() == ""
+    assert len(lines) == len(c.all_kfs) and open(tmp_path / "loopEdges.txt").read() == ""
     r = np.array([[float(x) for x in l.split()] for l in lines])
     assert r[:, 0].tolist() == list(range(len(lines))) and np.allclose(r[:, 1], c.kf_frames)
     for row, k in zip(r, [c.all_kfs[i] for i in sorted(c.all_kfs)]):

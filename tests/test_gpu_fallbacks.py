@@ -148,3 +148,24 @@ def test_matrix_core_gaussian_bitexact(api, oracle, synth, shape):
         assert gk2.tobytes() == rk2.tobytes() and np.array_equal(gd2, rd2)
     finally:
         oracle.set_gauss_taps(None)
+
+
+@pytest.mark.gpu
+def test_option_change_between_host_calls_takes_effect(api, oracle, synth):
+    """An option that changes the launched kernels, set between the first (eager) and the second (capturing) host-pointer call: the handle's
+    generation moves, the cached graph of the old setting is dropped, the matrix-core Gaussian's tables are built before the capture begins
+    (advisor, round 4) — every call equals the oracle and later calls still take the graph path (same results, no error)."""
+    img = synth.random_image(77, 240, 420, "texture")
+    par = oracle.params(500)
+    rk, rd = oracle.detect_and_compute(par, img)
+    ext = api.ORBextractor(500)
+    gk, gd = ext.DetectAndCompute(img)                                   # eager call of this key
+    assert gk.tobytes() == rk.tobytes() and np.array_equal(gd, rd)
+    ext.set_option(ext.OPT_BLUR_MFMA, 1)                                 # now the second call captures: tables must exist before it does
+    for rep in range(3):
+        gk, gd = ext.DetectAndCompute(img)
+        assert gk.tobytes() == rk.tobytes() and np.array_equal(gd, rd), rep
+    ext.set_option(ext.OPT_BLUR_MFMA, 0)
+    for rep in range(3):
+        gk, gd = ext.DetectAndCompute(img)
+        assert gk.tobytes() == rk.tobytes() and np.array_equal(gd, rd), rep

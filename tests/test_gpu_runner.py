@@ -77,7 +77,7 @@ def test_runner_200_frames_at_kitti_resolution(api, oracle, synth, pkg, tmp_path
     # tests/golden/make_kitti_layout_trajectory.py) up to the 6 printed decimals
     a.save(str(tmp_path / "again"))
     assert open(out / "trajectory.txt").read() == open(tmp_path / "again" / "trajectory.txt").read()
-    assert open(out / "loop_edges.txt").read() == ""
+    assert open(out / "loopEdges.txt").read() == ""
     gold = _rows(os.path.join(ROOT, "tests", "golden", "kitti_layout_200_trajectory.txt"))
     assert gold.shape == rows.shape and np.array_equal(gold[:, :2], rows[:, :2])
     dev_gold = float(np.abs(gold[:, 2:] - rows[:, 2:]).max())
@@ -121,7 +121,7 @@ def test_compiled_runner_equals_the_python_chain(api, synth, pkg, tmp_path, kitt
     # of every frame is the same double (%.17g round-trips), the files are the same text
     assert np.array_equal(poses, ref), float(np.abs(poses - ref).max())
     assert open(out / "trajectory.txt").read() == open(tmp_path / "py" / "trajectory.txt").read()
-    assert open(out / "loop_edges.txt").read() == ""
+    assert open(out / "loopEdges.txt").read() == ""
     print(f"compiled runner: {r.stdout.strip().splitlines()[-1]}; key-frames at frames {kf_frames}; the pose of every frame and trajectory.txt "
           f"are bit-identical to the Python chain's")
 
@@ -156,10 +156,10 @@ def test_compiled_runner_closes_the_loop_like_the_python_chain(api, synth, pkg, 
     assert [(x.id, y.id) for x, y in a.loops] == [(33, 0)] and "34 key-frames" in r.stdout and " 1 loops" in r.stdout
     poses = _rows(out / "frame_poses_cw.txt")
     assert np.array_equal(poses, np.stack(a.poses)), float(np.abs(poses - np.stack(a.poses)).max())
-    for name in ("trajectory.txt", "loop_edges.txt"):
+    for name in ("trajectory.txt", "loopEdges.txt"):
         assert open(out / name).read() == open(tmp_path / "py" / name).read(), name
-    assert len(open(out / "loop_edges.txt").read().strip().split("\n")) == 2          # the current key-frame's line, then the loop key-frame's
-    print(f"compiled runner, loop sequence: {r.stdout.strip().splitlines()[-1]}; every frame pose, trajectory.txt and loop_edges.txt bit-identical to chain.py's")
+    assert len(open(out / "loopEdges.txt").read().strip().split("\n")) == 2          # the current key-frame's line, then the loop key-frame's
+    print(f"compiled runner, loop sequence: {r.stdout.strip().splitlines()[-1]}; every frame pose, trajectory.txt and loopEdges.txt bit-identical to chain.py's")
 
 
 def test_runner_on_a_rendered_kitti_layout_sequence(api, synth, pkg, tmp_path):
@@ -178,7 +178,7 @@ def test_runner_on_a_rendered_kitti_layout_sequence(api, synth, pkg, tmp_path):
     rows = _rows(out / "trajectory.txt")
     assert len(rows) == (n - 1) // 6 + 1                                     # a key-frame every 6th frame
     assert rows[:, 0].tolist() == list(range(len(rows))) and np.allclose(rows[:, 1], [0.1 * 6 * i for i in range(len(rows))], atol=1e-6)
-    assert open(out / "loop_edges.txt").read() == ""                          # the gate of 50 key-frames never opens on 60 frames
+    assert open(out / "loopEdges.txt").read() == ""                          # the gate of 50 key-frames never opens on 60 frames
     # the written camera centres (Twc translation) against the rendered path, both in the frame of camera 0
     T0 = chain.T_of(synth.pose7_from_twc(C[0], yaw[0]))
     gt = np.array([chain.T_inv(chain.T_of(synth.pose7_from_twc(C[6 * i], yaw[6 * i])) @ chain.T_inv(T0))[:3, 3] for i in range(len(rows))])

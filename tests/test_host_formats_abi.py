@@ -46,7 +46,7 @@ def test_trajectory_and_loop_edge_files(api_host, tmp_path):
     assert f[0] == 5 and f[1] == 0.5 and np.allclose(f[2:5], twc, atol=1e-6)
     assert np.allclose(f[5:9], [0, -np.sin(yaw / 2), 0, np.cos(yaw / 2)], atol=1e-6)       # Rwc = Rcw^T, quaternion with w >= 0
     assert all(len(x.split(".")[1]) == 6 for x in lines[1].split()[1:])
-    e = str(tmp_path / "loop_edges.txt")
+    e = str(tmp_path / "loopEdges.txt")
     api_host.save_loop_edges(e, [9, 4], [0.9, 0.4], np.stack([poses[0], poses[1]]), [1, 0], [0.1, 0.0], np.stack([poses[1], poses[0]]))
     el = open(e).read().strip().split("\n")
     assert len(el) == 4 and el[0].startswith("4 0.400000") and el[1].startswith("0 0.000000") and el[2].startswith("9 0.900000") and el[3].startswith("1 0.100000")

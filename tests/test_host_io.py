@@ -95,6 +95,18 @@ def test_png_reader(tmp_path):
     assert run(bytes(bad), "crc") is None
     assert run(bytes(good[:len(good) // 2]), "trunc") is None
     assert run(b"P5 4 4 255 " + bytes(16), "pgm") is None
+    # a ~70-byte file whose IHDR promises 65535 x 65535 RGBA16 (34 GB unfiltered): refused before anything of that size is allocated or
+    # zero-filled (advisor, round 4) — run under a 2 GB address-space limit so that a regression fails instead of thrashing the box
+    import resource
+    import struct
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body) & 0xffffffff)
+    bomb = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 65535, 65535, 16, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(bytes(16))) + chunk(b"IEND", b"")
+    p = tmp_path / "bomb.png"; p.write_bytes(bomb)
+    r = subprocess.run([exe, str(p), str(tmp_path / "bomb.raw")], capture_output=True, text=True, timeout=20,
+                       preexec_fn=lambda: resource.setrlimit(resource.RLIMIT_AS, (2 << 30, 2 << 30)))
+    assert r.returncode == 2 and "DECODE FAILED" in r.stdout, (r.returncode, r.stderr[-500:])        # the reader's "false", not a signal or an uncaught bad_alloc
 
 
 def test_png_reader_survives_corrupt_streams(tmp_path):

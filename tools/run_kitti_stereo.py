@@ -6,7 +6,7 @@ per-frame dense path running through libmyslam_hip.so.
 
 Reads <sequence>/times.txt and image_0 / image_1/%06d.png (the library's own PNG reader: no OpenCV), tracks every frame, inserts
 key-frames by the reference's rule (pose-only inlier count against numFeatures.trackingGood / trackingBad of the YAML,
-src/frontend.cpp:97-120), runs the local BA and the loop closer per key-frame, and writes <out>/trajectory.txt and <out>/loop_edges.txt in
+src/frontend.cpp:97-120), runs the local BA and the loop closer per key-frame, and writes <out>/trajectory.txt and <out>/loopEdges.txt in
 the reference's format (src/system.cpp:153-224).  The orchestration is the package's chain.py (Frontend / Backend / LoopClosing / Map
 restated as one sequential schedule; its header lists what a sequential program has to decide where the reference's threads race).
 `--kf-every N` replaces the key-frame rule by "every N-th frame".  The KITTI data set is not part of this repository;
@@ -77,7 +77,7 @@ def main():
     shape = sysm.last.R.shape
     print(f"{done} frames ({shape[1]}x{shape[0]}), {len(sysm.all_kfs)} key-frames, {len(sysm.all_mps)} map points, "
           f"{len(sysm.loops)} loops; read {t_read[0]:.1f} s, tracked + mapped in {t_run:.1f} s = {done / max(t_run, 1e-9):.1f} frames/s "
-          f"(Python orchestration, one call per operator and frame); wrote {args.out}/trajectory.txt, loop_edges.txt")
+          f"(Python orchestration, one call per operator and frame); wrote {args.out}/trajectory.txt, loopEdges.txt")
 
 
 if __name__ == "__main__":
