@@ -631,6 +631,14 @@ def ba_optimize_active_map(poses, points, edge_pose, edge_pt, obs, fixed, K, del
     return poses, points, chi, out, r.value, no.value
 
 
+BA_OPT_LANDMARKS_IN_HBM = 1
+
+
+def ba_set_option(option, value):
+    """myslam_ba_set_option: process-wide scheduling knob of the solve kernel (include/myslam_hip.h)."""
+    _check(lib().myslam_ba_set_option(int(option), int(value)), "myslam_ba_set_option")
+
+
 def ba_optimize_active_map_batch(d_poses, d_points, d_ep, d_el, d_obs, d_fixed, d_sizes, nwin, maxP, maxL, maxE, K, delta, chi2_th,
                                  rounds, iters, d_scratch, d_edge_chi2, d_outlier, d_rounds, d_nout, d_status, stream=0):
     _check(lib().myslam_ba_optimize_active_map_batch(

@@ -7,7 +7,11 @@
 //   4. ncclAllGather of the raw candidate bytes (W x NQ x 16)
 //   5. myslam_lcd_merge_candidates_device -> (best id, max score, count) of ONE ascending scan over the whole database
 // Rank 0 also holds the whole database in one handle and checks 5. against its single scan.
-//   usage: sharded_db_rccl <db.f32> <queries.f32> <cur_ids.u64> <n_db> <nq>      (nq divisible by WORLD_SIZE)
+// After the check the same exchange is repeated `reps` times with HIP events around its four stages: every rank prints one line
+// "rank r: allgather_queries_ms … shard_scan_ms … allgather_candidates_ms … merge_ms …" — the per-step collective / scan cost a multi-GPU
+// run of bench.py reports under the same names (DESIGN.md section 4 holds the predicted values for N = 2 / 4 / 8).
+// Built by build.py into bin/sharded_db_rccl (g++; -D__HIP_PLATFORM_AMD__ is what the HIP runtime headers need from a plain host compiler).
+//   usage: sharded_db_rccl <db.f32> <queries.f32> <cur_ids.u64> <n_db> <nq> [reps = 20]      (nq divisible by WORLD_SIZE)
 //   the ncclUniqueId travels through the file $MYSLAM_NCCL_ID_FILE (rank 0 writes it; a launcher with MPI would broadcast it instead)
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -44,7 +48,7 @@ int main(int argc, char** argv) {
     if (argc < 6) { fprintf(stderr, "usage: %s db.f32 queries.f32 cur_ids.u64 n_db nq\n", argv[0]); return 1; }
     const int world = env_int("WORLD_SIZE", 1), rank = env_int("RANK", 0), local = env_int("LOCAL_RANK", rank);
     g_rank = rank;
-    const int n_db = atoi(argv[4]), nq = atoi(argv[5]);
+    const int n_db = atoi(argv[4]), nq = atoi(argv[5]), reps = argc > 6 ? atoi(argv[6]) : 20;
     if (world < 1 || rank < 0 || rank >= world || nq % world != 0 || n_db < world) { fprintf(stderr, "bad sizes\n"); return 1; }
     const int P = nq / world, D = MYSLAM_LCD_DIM;
     std::vector<float> db, q; std::vector<uint64_t> cur;
@@ -144,6 +148,29 @@ int main(int argc, char** argv) {
                bad ? "SHARDED DB RCCL FAILED" : "SHARDED DB RCCL OK", world, n_db, nq, P, loops, breaks, bad);
         (void)myslam_lcddb_destroy(whole);
         (void)hipFree(d_db); (void)hipFree(d_b1); (void)hipFree(d_m1); (void)hipFree(d_c1);
+    }
+    // ---- the exchange again, timed stage by stage (HIP events on the stream all four stages run on) -----------------------------------
+    if (reps > 0 && !bad) {
+        hipEvent_t ev[5];
+        for (auto& e : ev) HIPOK(hipEventCreate(&e));
+        double acc[4] = {0, 0, 0, 0};
+        for (int it = -2; it < reps; it++) {                        // two untimed warm-up rounds
+            HIPOK(hipEventRecord(ev[0], s));
+            NCCLOK(ncclAllGather(d_myq, d_allq, (size_t)P * D, ncclFloat, comm, s));
+            HIPOK(hipEventRecord(ev[1], s));
+            MYOK(myslam_lcddb_query_batch_sharded(shard, d_allq, cur.data(), nq, thr_low, d_cand));
+            HIPOK(hipEventRecord(ev[2], s));
+            NCCLOK(ncclAllGather(d_cand, d_gath, sizeof(myslam_lcd_candidate) * (size_t)nq, ncclChar, comm, s));
+            HIPOK(hipEventRecord(ev[3], s));
+            MYOK(myslam_lcd_merge_candidates_device(d_gath, world, nq, d_best, d_max, d_cnt, s));
+            HIPOK(hipEventRecord(ev[4], s));
+            HIPOK(hipStreamSynchronize(s));
+            if (it < 0) continue;
+            for (int k = 0; k < 4; k++) { float ms = 0; HIPOK(hipEventElapsedTime(&ms, ev[k], ev[k + 1])); acc[k] += ms; }
+        }
+        printf("rank %d: allgather_queries_ms %.4f (%zu B per rank) shard_scan_ms %.4f (%d rows x %d queries) allgather_candidates_ms %.4f (%zu B per rank) merge_ms %.4f  [mean of %d]\n",
+               rank, acc[0] / reps, sizeof(float) * (size_t)P * D, acc[1] / reps, hi - lo, nq, acc[2] / reps, sizeof(myslam_lcd_candidate) * (size_t)nq, acc[3] / reps, reps);
+        for (auto& e : ev) (void)hipEventDestroy(e);
     }
     (void)myslam_lcddb_destroy(shard);
     void* fr[] = {d_myq, d_allq, d_cand, d_gath, d_best, d_max, d_cnt};

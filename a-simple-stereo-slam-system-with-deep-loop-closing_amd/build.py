@@ -1,5 +1,6 @@
-"""Builds libmyslam_hip.so (gfx950) in-tree with hipcc, and bin/run_kitti_stereo (the compiled host program of BASELINE configs[0],
-app/run_kitti_stereo.cpp: plain C++ over the C ABI) with g++.  No torch, no cmake: plain compiler invocations.
+"""Builds libmyslam_hip.so (gfx950) in-tree with hipcc, and with g++ the two compiled host programs: bin/run_kitti_stereo (BASELINE configs[0],
+app/run_kitti_stereo.cpp: plain C++ over the C ABI) and bin/sharded_db_rccl (BASELINE configs[4]'s loop-database exchange,
+app/sharded_db_rccl.cpp: C++ + librccl + the C ABI, one process per GPU).  No torch, no cmake: plain compiler invocations.
 
     python build.py            # incremental
     python build.py --force
@@ -15,6 +16,8 @@ OUT = os.path.join(HERE, "libmyslam_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 APP_SRC = os.path.join(HERE, "app", "run_kitti_stereo.cpp")
 APP_OUT = os.path.join(HERE, "bin", "run_kitti_stereo")
+RCCL_SRC = os.path.join(HERE, "app", "sharded_db_rccl.cpp")
+RCCL_OUT = os.path.join(HERE, "bin", "sharded_db_rccl")
 CXX = os.environ.get("CXX", "g++")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
@@ -76,6 +79,7 @@ def build(force=False, verbose=False):
     if force or jobs or _stale(OUT, objs):
         run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT] + objs)
     build_app(force or _stale(APP_OUT, [APP_SRC, OUT] + deps), verbose)
+    build_rccl_host(force or _stale(RCCL_OUT, [RCCL_SRC, OUT] + deps), verbose)
     return OUT
 
 
@@ -90,6 +94,20 @@ def build_app(force=False, verbose=False):
         if r.returncode != 0:
             raise RuntimeError("compiler failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
     return APP_OUT
+
+
+def build_rccl_host(force=False, verbose=False):
+    """bin/sharded_db_rccl: the multi-GPU loop-database host (g++ + the HIP runtime + librccl + the library next to it)"""
+    if force or not os.path.exists(RCCL_OUT):
+        os.makedirs(os.path.dirname(RCCL_OUT), exist_ok=True)
+        cmd = [CXX, "-O2", "-std=c++17", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(HERE, "..", "include"), RCCL_SRC, "-o", RCCL_OUT,
+               "-L" + HERE, "-lmyslam_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lrccl", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("compiler failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    return RCCL_OUT
 
 
 if __name__ == "__main__":

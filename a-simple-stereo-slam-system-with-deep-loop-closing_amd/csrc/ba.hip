@@ -7,6 +7,7 @@
 // give the same bits, see k_ba_build), the per-edge 6x3 Hpl blocks stream straight to HBM.  The order differs
 // from the oracle's plain edge loop -> agreement to ~1e-12 relative, not bit-exactly (stated in the tests).
 #include <algorithm>
+#include <atomic>
 #include <unordered_map>
 #include <vector>
 #include "common.h"
@@ -880,10 +881,12 @@ static size_t ba_opt_lds(int maxP, int maxL, bool gl) {
            sizeof(int) * (2 * lm);
 }
 
+static std::atomic<int> g_ba_landmarks_in_hbm{0};         // MYSLAM_BA_OPT_LANDMARKS_IN_HBM
+
 static int ba_opt_launch(const BaOptArgs& a, int nwin, hipStream_t s) {
     if (a.maxP > MYSLAM_BA_MAX_WINDOW_POSES) return MYSLAM_ERR_UNSUPPORTED;          // substitution runs on one wave: 6P <= 64; 55 pose pairs x 8 slices <= 512 threads
     size_t lds = ba_opt_lds(a.maxP, a.maxL, false);
-    const bool gl = lds > 160 * 1024 - 512;                // large window: per-landmark state goes to the HBM scratch
+    const bool gl = lds > 160 * 1024 - 512 || g_ba_landmarks_in_hbm.load(std::memory_order_relaxed) != 0;   // large window (or by option): per-landmark state goes to the HBM scratch
     if (gl) {
         lds = ba_opt_lds(a.maxP, a.maxL, true);
         // the scratch (maxE x 18 doubles per window) must hold the pose-sorted edge list + 22 doubles per landmark
@@ -1206,6 +1209,11 @@ int myslam_ba_optimize(double* poses, int nposes, double* points, int npts, cons
     if (final_chi2) *final_chi2 = chi;
     if (iters) *iters = st[1];
     return st[0];
+}
+
+int myslam_ba_set_option(int option, int value) {
+    if (option == MYSLAM_BA_OPT_LANDMARKS_IN_HBM) { if (value < 0 || value > 1) return MYSLAM_ERR_INVALID; g_ba_landmarks_in_hbm.store(value); return MYSLAM_OK; }
+    return MYSLAM_ERR_INVALID;
 }
 
 int myslam_ba_optimize_active_map_batch(double* d_poses, double* d_points, const int32_t* d_edge_pose, const int32_t* d_edge_pt,

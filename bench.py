@@ -194,6 +194,9 @@ def parse():
     ap.add_argument("--stream-split", type=int, default=2, help="streamed pass: the left and the right images of a step as separate copies with an event each, on this many copy streams (0 = one copy of the whole batch; 2 (default): 56.9-57.1 k frames/s against 51.6-54.1 k; 4: 53-55.6 k)")
     ap.add_argument("--lcd-split", type=int, default=1, help="the DeepLCD chain of a step in this many parts on as many handles / streams (1 = one chain on the side stream)")
     ap.add_argument("--ba-stream", choices=["side", "match"], default="match", help="the BA block build behind the triangulation on the match stream (default: +0.4 %, three alternating runs) or behind the DB scan on the side stream")
+    ap.add_argument("--solve-lm-hbm", type=int, default=0, help="cadence-6 pass: 1 = the solve keeps its per-landmark state in its HBM scratch (81 KB of LDS per window instead of 133: "
+                    "its CU keeps room for two more of the extractor's blocks).  Measured negative (same box, two runs each: 7.06 / 7.07 ms per step against 7.02 / 7.01 "
+                    "with the state in LDS): the solve's cost is the CU TIME of its blocks, and the HBM form holds its CUs longer")
     ap.add_argument("--solve-stream", choices=["own", "side"], default="own", help="the OptimizeActiveMap solve of the cadence passes on its own stream (the reference's Backend thread) or behind the side chain")
     ap.add_argument("--side-cus", type=int, default=0, help="experiment: the DeepLCD / DB / BA stream may use only this many CUs (hipExtStreamCreateWithCUMask); 0 = all")
     ap.add_argument("--match-cus", type=int, default=0, help="experiment: likewise for the match + triangulation stream")
@@ -654,6 +657,7 @@ def main():
         torch.cuda.synchronize()
 
     host_ms = [0.0]
+    rank_dts = []           # multi-rank runs: every rank's wall time of the last timed() call
 
     def timed(n, fn=None):
         """n steps bracketed by barrier + synchronize on both sides; the slowest rank's wall time.  host_ms[0] = CPU time the launches of
@@ -667,9 +671,13 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
+            # every rank's own wall time (the closing barrier makes them nearly equal by construction; the device-side time of a rank's
+            # own chains is in rank_gpu_ms below) and the slowest one, which is the job's time
             t = torch.tensor([dt], dtype=torch.float64, device="cpu" if via_cpu else dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            allt = torch.empty(world, dtype=torch.float64, device=t.device)
+            dist.all_gather_into_tensor(allt, t)
+            rank_dts[:] = [float(v) for v in allt.cpu()]
+            dt = max(rank_dts)
         return dt
 
     for _ in range(args.warmup):
@@ -745,6 +753,55 @@ def main():
     api.prof_enable(False)
     dt = timed(args.steps)
     host_launch_ms = host_ms[0]
+    per_rank_ms = [v / args.steps * 1e3 for v in rank_dts] if world > 1 else None
+    # ---- multi-rank runs: what the loop-database exchange costs, stage by stage, on an otherwise idle chip (after the timed region).  The two
+    # all-gathers (queries: P x 4 256 B per rank in, N P x 4 256 B out; candidates: N P x 16 B per rank) and the N x larger scan are the only
+    # work a rank does for the others: scaling efficiency below 1 is these numbers (DESIGN.md section 4 holds the predicted values).
+    collective = None
+    if world > 1 and use_lcd:
+        reps = 20
+        acc = np.zeros(4)
+        with torch.cuda.stream(side_stream):
+            for it in range(-2, reps):
+                if via_cpu:      # gloo stages through the host: wall clock around synchronised stages
+                    torch.cuda.synchronize(); t_ = [time.perf_counter()]
+                    h_all = torch.empty(d_allq.shape, dtype=d_allq.dtype); dist.all_gather_into_tensor(h_all, d_descr.cpu()); d_allq.copy_(h_all)
+                    torch.cuda.synchronize(); t_.append(time.perf_counter())
+                    D.query_batch_sharded(d_allq.data_ptr(), cur_ids, NQ, d_cand.data_ptr())
+                    torch.cuda.synchronize(); t_.append(time.perf_counter())
+                    mine = d_cand.cpu(); gathered = torch.empty(world * NQ * 16, dtype=torch.uint8); dist.all_gather_into_tensor(gathered, mine)
+                    t_.append(time.perf_counter())
+                    b_, m_, c_ = api.lcd_merge_candidates(gathered.numpy().view(api.CAND_DTYPE).reshape(world, NQ))
+                    t_.append(time.perf_counter())
+                    ms = [(t_[k + 1] - t_[k]) * 1e3 for k in range(4)]
+                else:            # RCCL: HIP events on the stream the collectives and the two library calls are ordered on
+                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+                    ev[0].record(side_stream)
+                    dist.all_gather_into_tensor(d_allq, d_descr); ev[1].record(side_stream)
+                    D.query_batch_sharded(d_allq.data_ptr(), cur_ids, NQ, d_cand.data_ptr()); ev[2].record(side_stream)
+                    gathered = torch.empty(world * NQ * 16, dtype=torch.uint8, device=dev)
+                    dist.all_gather_into_tensor(gathered, d_cand); ev[3].record(side_stream)
+                    api.lcd_merge_candidates_device(gathered.data_ptr(), world, NQ, d_best.data_ptr(), d_max.data_ptr(), d_dbcnt.data_ptr(), side_stream.cuda_stream)
+                    ev[4].record(side_stream)
+                    side_stream.synchronize()
+                    ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(4)]
+                if it >= 0:
+                    acc += np.array(ms)
+        acc /= reps
+        mine_t = torch.tensor(acc, dtype=torch.float64, device="cpu" if via_cpu else dev)
+        all_t = torch.empty(world * 4, dtype=torch.float64, device=mine_t.device)
+        dist.all_gather_into_tensor(all_t, mine_t)
+        all_t = all_t.cpu().numpy().reshape(world, 4)
+        collective = {"collective_ms_per_step": float((all_t[:, 0] + all_t[:, 2]).max()), "shard_scan_ms_per_step": float(all_t[:, 1].max()),
+                      "merge_ms_per_step": float(all_t[:, 3].max()),
+                      "allgather_queries_ms": [float(v) for v in all_t[:, 0]], "allgather_candidates_ms": [float(v) for v in all_t[:, 2]],
+                      "shard_scan_ms": [float(v) for v in all_t[:, 1]],
+                      "allgather_queries_bytes_per_rank": int(P * 1064 * 4), "allgather_candidates_bytes_per_rank": int(NQ * 16),
+                      "shard_rows": int(n_db_local), "queries_scanned_per_rank": int(NQ), "reps": reps,
+                      "timing": "wall clock around synchronised stages (gloo stages through host memory)" if via_cpu else "HIP events on the side stream",
+                      "note": "measured after the timed region on an otherwise idle chip: the cost of the loop-database exchange alone; inside a step it runs on the side "
+                              "stream under the extractor"}
+        barrier()
     frame_latency = None
     if use_graph and args.frame_latency:
         # every step timed on ITS lane (event pair around the replay) while all lanes are busy, then one lane alone: what a camera sees
@@ -780,12 +837,14 @@ def main():
     cadence = None
     if use_ba and not use_solve and not args.no_extra_passes:
         solve_windows[0] = (P + 5) // 6
+        api.ba_set_option(api.BA_OPT_LANDMARKS_IN_HBM, 1 if args.solve_lm_hbm else 0)
         step(); barrier()
         dt_c = timed(args.steps)
         solve_windows[0] = 0
+        barrier(); api.ba_set_option(api.BA_OPT_LANDMARKS_IN_HBM, 0)
         assert int(s_st.abs().sum()) == 0
         cadence = {"value": world * P * args.steps / dt_c, "unit": "stereo frames/s", "ms_per_step": dt_c / args.steps * 1e3,
-                   "solved_windows_per_step": (P + 5) // 6,
+                   "solved_windows_per_step": (P + 5) // 6, "landmark_state": "hbm scratch" if args.solve_lm_hbm else "lds",
                    "note": "as the timed region, plus Backend::OptimizeActiveMap's solve stage (rounds of Levenberg-Marquardt optimize(10), Schur + "
                            "Cholesky, outlier flags) on every 6th frame's window — the reference solves per key-frame, about 1 frame in 6"}
 
@@ -1051,14 +1110,16 @@ def main():
         # Jacobians + block products ~410 flop per edge, Schur complement sum_l W_l Hll^-1 W_l^T = (108 k + 216 k^2) flop
         # for a landmark seen by k key-frames, 6x6-blocked Cholesky n^3 / 3 and two triangular solves 2 n^2 with n = 6 P; rounds x 10 iterations
         # (optimize(10), backend.cpp:212-214: every round runs its iteration budget unless a Levenberg trial fails ten times)
-        rounds_mean = float(s_rd.float().mean().item())
+        # *rounds = the reference's `iteration` counter = rounds that FAILED the inlier test (backend.cpp:212-232): a window runs that many + 1
+        # rounds of optimize(10), at most max_rounds = 5 (round 5 fix: the model multiplied by the counter itself, 0 for well-posed windows)
+        rounds_mean = float((s_rd.float() + 1.0).clamp(max=5.0).mean().item())
         szs = ba_w[6]                                                    # [P, 3] = poses, landmarks, edges per window
         npo, nla, ned = [float(np.mean(szs[:, i])) for i in range(3)]
         kobs = ned / max(1.0, nla)
         flop_it = 410.0 * ned + nla * (108.0 * kobs + 216.0 * kobs * kobs) + (6 * npo) ** 3 / 3.0 + 2 * (6 * npo) ** 2
         flops = P * rounds_mean * 10 * flop_it
         solve_roof = {"bound": "f64 (vector + matrix cores)", "kernel": "k_ba_optimize", "unit": "TFLOP/s (f64, modelled flops)", "avg_launch_ms": solve_ms,
-                      "windows_per_launch": P, "rounds_mean": rounds_mean, "modelled_flop_per_iteration": flop_it, "achieved": flops / (solve_ms * 1e-3) / 1e12,
+                      "windows_per_launch": P, "rounds_executed_mean": rounds_mean, "modelled_flop_per_iteration": flop_it, "achieved": flops / (solve_ms * 1e-3) / 1e12,
                       "peak": 78.6, "peak_f64_mfma_measured": 48.0, "frac": flops / (solve_ms * 1e-3) / 1e12 / 78.6,
                       "note": "one 512-thread block per window with the window's state in 133 KB of LDS (one block per CU): iterations are chains of barrier-separated "
                               "phases (pose blocks, landmark blocks, Schur chunks on v_mfma_f64_16x16x4_f64, 6x6-blocked Cholesky, back-substitution, update, chi2); "
@@ -1180,6 +1241,10 @@ def main():
                        "parallelism": f"frame-sharded x{world}" + (", id-range sharded DB + all-gather of 16-byte candidate records" if world > 1 else "")},
             "rccl_ranks": rccl_ranks if not via_cpu else None, "collective_backend": (args.backend if world > 1 else None),
             "collective_ranks": rccl_ranks,
+            "per_rank_ms_per_step": per_rank_ms,
+            "collective_ms_per_step": None if collective is None else collective["collective_ms_per_step"],
+            "shard_scan_ms_per_step": None if collective is None else collective["shard_scan_ms_per_step"],
+            "db_exchange": collective,
             "roofline": roof, "roofline_valu": roof_valu, "roofline_mfma": mf,
             "profiled_pass": None if dt_prof is None else {"ms_per_step": dt_prof / args.steps * 1e3,
                                                            "kernel_ms_per_step": {SYMBOL.get(k, k): v[0] / args.steps for k, v in busy.items()}},

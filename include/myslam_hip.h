@@ -428,6 +428,14 @@ int myslam_ba_optimize_active_map_batch(double* d_poses, double* d_points, const
                                         double chi2_th, int max_rounds, int iters_per_round, double* d_scratch, double* d_edge_chi2,
                                         uint8_t* d_outlier, int32_t* d_rounds, int32_t* d_n_outliers, int32_t* d_status, void* hip_stream);
 
+/* Scheduling knob of the solve kernel (process-wide, no reference counterpart; results do not depend on it beyond f64 rounding of
+ * nothing: the arithmetic and its order are the same).  MYSLAM_BA_OPT_LANDMARKS_IN_HBM: 0 (default) = a window's per-landmark state lives
+ * in LDS whenever it fits (133 KB for 10 key-frames x 300 landmarks: one window per CU and almost nothing beside it); 1 = always in the
+ * window's HBM scratch (81 KB of LDS: the form for a solve that runs BESIDE other kernels, e.g. on the Backend's stream under the
+ * extractor — its CU keeps room for their blocks).  d_scratch sizes are the same in both forms. */
+#define MYSLAM_BA_OPT_LANDMARKS_IN_HBM 1
+int myslam_ba_set_option(int option, int value);
+
 /* ------------------------------------------------------------------------------------------
  * Pose-only optimisation of the current frame — replaces the g2o part of Frontend::EstimateCurrentPose
  * (src/frontend.cpp:176-276): one VertexPose, one EdgeProjectionPoseOnly (include/myslam/g2o_types.h:62-100) per tracked

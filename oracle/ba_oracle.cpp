@@ -297,6 +297,13 @@ int orc_ba_build(const double* poses, int nposes, const double* points, int npts
     return 0;
 }
 
+// Iteration trace for the maintainer-side pin (tools/dump_reference_goldens.cpp records the same three numbers from g2o's post-iteration
+// hook: activeRobustChi2() — the robust chi2 of the LAST Levenberg trial, accepted or not —, currentLambda(), levenbergIteration()).
+// Rows of 4 doubles: {robust chi2 of the last trial, chi2 of the accepted state, lambda after the iteration, trials}.  Test infrastructure.
+static double* g_trace = nullptr; static int g_trace_cap = 0, g_trace_n = 0;
+extern "C" void orc_ba_set_trace(double* rows4, int cap_rows) { g_trace = rows4; g_trace_cap = rows4 ? cap_rows : 0; g_trace_n = 0; }
+extern "C" int orc_ba_trace_rows() { return g_trace_n; }
+
 // g2o OptimizationAlgorithmLevenberg::solve x max_iters (Appendix A.7)
 static int lm_optimize(double* poses, int nposes, double* points, int npts,
                        const int32_t* edge_pose, const int32_t* edge_pt, const double* obs, int nedges,
@@ -350,6 +357,7 @@ static int lm_optimize(double* poses, int nposes, double* points, int npts,
             }
             qmax++;
         } while (rho < 0 && qmax < 10);
+        if (g_trace && g_trace_n < g_trace_cap) { double* r = g_trace + 4 * g_trace_n++; r[0] = tempChi; r[1] = currentChi; r[2] = lambda; r[3] = qmax; }
         if (qmax == 10 || rho == 0 || !std::isfinite(lambda)) { it++; break; }
     }
     for (int i = 0; i < nposes; i++) {

@@ -344,6 +344,18 @@ class Oracle:
         assert rc == 0, rc
         return poses, points, chi, out, r.value, no.value
 
+    def ba_optimize_active_map_traced(self, *a, **kw):
+        """ba_optimize_active_map + the per-iteration trace: rows of (robust chi2 of the last Levenberg trial, chi2 of the accepted state,
+        lambda after the iteration, trials) over all rounds — what g2o's post-iteration hook sees (tools/dump_reference_goldens.cpp)."""
+        buf = np.zeros((256, 4))
+        self.lib.orc_ba_set_trace(_p(buf), len(buf))
+        try:
+            out = self.ba_optimize_active_map(*a, **kw)
+            n = self.lib.orc_ba_trace_rows()
+        finally:
+            self.lib.orc_ba_set_trace(None, 0)
+        return out, buf[:n].copy()
+
     def bench_frames(self, frames, K, weights, db, ids, ba_windows, stages=3, threads=1, nfeatures=2000, n_warmup=0, n_tasks=None):
         """CPU-baseline driver (bench_oracle.cpp): frames [n,2,H,W] u8 through the whole per-frame pipeline on `threads` threads.
         ba_windows = (poses [nw,maxP,7], points [nw,maxL,3], ep [nw,maxE], el [nw,maxE], obs [nw,maxE,2], fixed [nw,maxL],

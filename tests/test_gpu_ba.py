@@ -212,6 +212,26 @@ def test_large_window_uses_hbm_scratch(api, oracle, synth):
     assert np.array_equal(gout[far], rout[far]) and abs(gn - rn) <= int((~far).sum())
 
 
+def test_landmark_state_option_is_bit_identical(api, oracle, synth):
+    """MYSLAM_BA_OPT_LANDMARKS_IN_HBM: the same arithmetic in the same order with the per-landmark arrays in the window's HBM scratch
+    (81 KB of LDS instead of 133: the form the cadence passes of bench.py use beside the extractor) — bit-identical to the LDS form, and
+    equal to the oracle to the usual bar."""
+    poses, pts, ep, el, obs, fixed, K = synth.ba_problem(seed=0xBA, outlier_frac=0.3)
+    a = api.ba_optimize_active_map(poses, pts, ep, el, obs, fixed, K)
+    api.ba_set_option(api.BA_OPT_LANDMARKS_IN_HBM, 1)
+    try:
+        b = api.ba_optimize_active_map(poses, pts, ep, el, obs, fixed, K)
+    finally:
+        api.ba_set_option(api.BA_OPT_LANDMARKS_IN_HBM, 0)
+    for x, y in zip(a[:4], b[:4]):
+        assert np.asarray(x).tobytes() == np.asarray(y).tobytes()
+    assert a[4:] == b[4:]
+    rp, rx, rchi, rout, rr, rn = oracle.ba_optimize_active_map(poses, pts, ep, el, obs, fixed, K)
+    assert (b[4], b[5]) == (rr, rn) and np.allclose(b[0], rp, rtol=1e-7, atol=1e-8) and np.allclose(b[1], rx, rtol=1e-7, atol=1e-7)
+    with pytest.raises(Exception):
+        api.ba_set_option(99, 1)
+
+
 def test_ba_build_is_bit_reproducible_and_order_tolerant(api, oracle, synth):
     """The block build uses no floating-point atomics: repeated calls return identical bytes.  Edges that are NOT grouped by landmark
     (scattered runs; the reference emits them grouped) still give the oracle's blocks."""

@@ -91,6 +91,12 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None        # CPU baseline: rank 0 at N=1 only
     assert abs(d["value"] - 2 * 16 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]       # whole-job rate: both ranks' pairs
     assert "x2" in d["config"]["parallelism"] and d["collective_ranks"] == 2
+    # the self-explaining part of a multi-rank line: every rank's own time, and the loop-database exchange stage by stage
+    assert len(d["per_rank_ms_per_step"]) == 2 and max(d["per_rank_ms_per_step"]) == pytest.approx(d["ms_per_step"], rel=1e-9)
+    x = d["db_exchange"]
+    assert d["collective_ms_per_step"] == x["collective_ms_per_step"] > 0 and d["shard_scan_ms_per_step"] == x["shard_scan_ms_per_step"] > 0
+    assert len(x["allgather_queries_ms"]) == len(x["allgather_candidates_ms"]) == len(x["shard_scan_ms"]) == 2
+    assert x["allgather_queries_bytes_per_rank"] == 16 * 1064 * 4 and x["allgather_candidates_bytes_per_rank"] == 32 * 16 and x["queries_scanned_per_rank"] == 32
 
 
 def test_bench_self_launch_two_ranks():
@@ -123,3 +129,4 @@ def test_bench_self_launch_eight_ranks():
     assert abs(d["value"] - 8 * 8 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]        # whole-job rate over all 8 ranks
     assert "x8" in d["config"]["parallelism"] and "5120-KF" in d["config"]["workload"]
     assert d["streamed"]["value"] > 0 and d["full_solve_cadence6"]["value"] > 0
+    assert len(d["per_rank_ms_per_step"]) == 8 and len(d["db_exchange"]["shard_scan_ms"]) == 8 and d["db_exchange"]["shard_rows"] == 640

@@ -31,16 +31,13 @@ def test_c_abi_gated_handles(tmp_path):
 
 
 def test_cpp_sharded_db_over_rccl(synth, tmp_path):
-    """The multi-GPU loop-database exchange as a compiled program (tests/cpp/sharded_db_rccl.cpp): C++ + librccl + the C ABI, no Python in
+    """The multi-GPU loop-database exchange as a compiled program (app/sharded_db_rccl.cpp -> bin/sharded_db_rccl, built by build.py): C++ + librccl + the C ABI, no Python in
     the loop — ncclCommInitRank, ncclAllGather of the queries, myslam_lcddb_query_batch_sharded, ncclAllGather of the 16-byte records,
     myslam_lcd_merge_candidates_device, checked against one scan of the whole database.  One rank per visible GPU (1 on this pool's boxes)."""
     import numpy as np
     import torch
-    exe = str(tmp_path / "sharded_db_rccl")
-    cmd = ["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "tests", "cpp", "sharded_db_rccl.cpp"), "-o", exe, "-L" + PKG_DIR, "-lmyslam_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lrccl",
-           "-Wl,-rpath," + PKG_DIR, "-Wl,-rpath,/opt/rocm/lib"]
-    subprocess.check_call(cmd)
+    exe = os.path.join(PKG_DIR, "bin", "sharded_db_rccl")          # built by build.py (g++ + librccl + the library), as bin/run_kitti_stereo is
+    assert os.path.exists(exe), "build.py did not produce bin/sharded_db_rccl"
     n_db, nq = 3000, 64
     db = synth.lcd_database(n_db)
     rng = np.random.default_rng(11)
@@ -57,4 +54,8 @@ def test_cpp_sharded_db_over_rccl(synth, tmp_path):
     outs = [p.communicate(timeout=600) for p in procs]
     assert all(p.returncode == 0 for p in procs), [(p.returncode, o[1][-1500:]) for p, o in zip(procs, outs)]
     assert f"SHARDED DB RCCL OK ranks={world}" in outs[0][0] and "mismatches=0" in outs[0][0], outs[0][0]
+    # every rank reports the per-stage times of the repeated exchange (the names bench.py --gpus N uses in its line)
+    for r, o in enumerate(outs):
+        line = [l for l in o[0].splitlines() if l.startswith(f"rank {r}:")]
+        assert line and all(k in line[0] for k in ("allgather_queries_ms", "shard_scan_ms", "allgather_candidates_ms", "merge_ms")), o[0]
     print(outs[0][0].strip())
