@@ -27,7 +27,7 @@ def write_pgm(path, img):
         f.write(np.ascontiguousarray(img, np.uint8).tobytes())
 
 
-def main():
+def main(OUT=OUT):
     synth = load_package().synth
     os.makedirs(OUT, exist_ok=True)
     L, R = synth.stereo_pair(0, 0)
@@ -49,7 +49,7 @@ def main():
     for c in range(2):
         pc = pw @ poses34[c, :, :3].T + poses34[c, :, 3]
         pn[:, c, 0] = pc[:, 0] / pc[:, 2] + rng.normal(0, 2e-4, 64); pn[:, c, 1] = pc[:, 1] / pc[:, 2] + rng.normal(0, 2e-4, 64); pn[:, c, 2] = 1.0
-    pn[60:, 1, 0] = pn[60:, 0, 0]                                   # four parallel-ray cases: the sigma3 / sigma2 test must reject them
+    pn[60:, 1, 1] += np.array([0.05, 0.1, 0.2, 0.4])                # four rays that miss each other (epipolar mismatch): sigma3 / sigma2 decides, some rejected
     np.save(os.path.join(OUT, "in_tri_poses34.npy"), poses34); np.save(os.path.join(OUT, "in_tri_points.npy"), pn)
     np.save(os.path.join(OUT, "in_K.npy"), np.array([K["fx"], K["fy"], K["cx"], K["cy"]], np.float64))
     for name, frac, seed in (("ba", 0.03, 0xBA), ("ba_bad", 0.6, 5)):
