@@ -41,6 +41,8 @@ struct BaOptArgs {
     double* final_chi2; int32_t* iters; int32_t* status;
     // Backend::OptimizeActiveMap outer loop (backend.cpp:208-243); edge_chi2 == nullptr -> a single optimize(max_iters)
     int rounds; double chi2_th; double* edge_chi2; uint8_t* outlier; int32_t* rounds_out; int32_t* nout_out;
+    size_t wstride = 0;   // scratch doubles per window; 0 = maxE x 18 (the batch entry points' contract).  The host-pointer entry points size it
+                          // themselves: a window with many short-lived landmarks (22 doubles each in the HBM form) may need more than its edges give
 };
 
 __device__ __forceinline__ void ba_edge(const double* R, const double* pw, const double* z, double fx, double fy, double cx, double cy,
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
     double* sRb = sR + a.maxP * 12;
     double* sHpp = sRb + a.maxP * 12;         // maxP x 21
     double* sbp = sHpp + a.maxP * 21;         // maxP x 6
-    double* const lmBase = GL ? a.W + (size_t)w * a.maxE * 18 + ((size_t)a.maxE + 1) / 2 + 8 : sbp + a.maxP * 6;      // behind plist / in LDS
+    double* const lmBase = GL ? a.W + (size_t)w * a.wstride + ((size_t)a.maxE + 1) / 2 + 8 : sbp + a.maxP * 6;      // behind plist / in LDS
     double* sPt = lmBase;                     // maxL x 3
     double* sPtb = sPt + a.maxL * 3;
     double* sHll = sPtb + a.maxL * 3;         // maxL x 6
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
     const int32_t* el = a.el + (size_t)w * a.maxE;
     const double* obs = a.obs + (size_t)w * a.maxE * 2;
     const uint8_t* fixed = a.fixed ? a.fixed + (size_t)w * a.maxL : nullptr;
-    int* plist = reinterpret_cast<int*>(a.W + (size_t)w * a.maxE * 18);     // edges sorted by pose (stable)
+    int* plist = reinterpret_cast<int*>(a.W + (size_t)w * a.wstride);       // edges sorted by pose (stable)
     const double d2 = a.delta * a.delta;
 
     // ---- load state, landmark -> edge range ----
@@ -883,14 +885,19 @@ static size_t ba_opt_lds(int maxP, int maxL, bool gl) {
 
 static std::atomic<int> g_ba_landmarks_in_hbm{0};         // MYSLAM_BA_OPT_LANDMARKS_IN_HBM
 
-static int ba_opt_launch(const BaOptArgs& a, int nwin, hipStream_t s) {
+// scratch doubles one window needs: the pose-sorted edge list, and in the HBM form the per-landmark arrays behind it
+static size_t ba_opt_scratch_need(int maxL, int maxE, bool gl) { return ((size_t)maxE + 1) / 2 + 8 + (gl ? 22 * (size_t)maxL + 2 : 0); }
+
+static int ba_opt_launch(const BaOptArgs& a_in, int nwin, hipStream_t s) {
+    BaOptArgs a = a_in;
+    if (!a.wstride) a.wstride = (size_t)a.maxE * 18;
     if (a.maxP > MYSLAM_BA_MAX_WINDOW_POSES) return MYSLAM_ERR_UNSUPPORTED;          // substitution runs on one wave: 6P <= 64; 55 pose pairs x 8 slices <= 512 threads
     size_t lds = ba_opt_lds(a.maxP, a.maxL, false);
     const bool gl = lds > 160 * 1024 - 512 || g_ba_landmarks_in_hbm.load(std::memory_order_relaxed) != 0;   // large window (or by option): per-landmark state goes to the HBM scratch
     if (gl) {
         lds = ba_opt_lds(a.maxP, a.maxL, true);
-        // the scratch (maxE x 18 doubles per window) must hold the pose-sorted edge list + 22 doubles per landmark
-        if (((size_t)a.maxE + 1) / 2 + 8 + 22 * (size_t)a.maxL + 2 > (size_t)a.maxE * 18 || lds > 160 * 1024 - 512) return MYSLAM_ERR_CAPACITY;
+        // the scratch (wstride doubles per window) must hold the pose-sorted edge list + 22 doubles per landmark
+        if (ba_opt_scratch_need(a.maxL, a.maxE, true) > a.wstride || lds > 160 * 1024 - 512) return MYSLAM_ERR_CAPACITY;
     }
     const void* fn = gl ? reinterpret_cast<const void*>(k_ba_optimize<true>) : reinterpret_cast<const void*>(k_ba_optimize<false>);
     // the limit belongs to the function (per device and process), not to a launch: always the device's whole LDS minus the kernel's static
@@ -980,8 +987,18 @@ __global__ __launch_bounds__(NT) void k_pose_only(PoseOnlyArgs a) {
         for (int k = 0; k < PO_EPT; k++) na += (t + k * NT < n && !((level >> k) & 1)) ? 1.0 : 0.0;
         const int nact = (int)block_sum_n<NW>(na, s_red);
         if (nact > 0) {
+            // g2o evaluates the active errors at the start of every iteration (computeActiveErrors + activeRobustChi2).  A new iteration only
+            // follows an ACCEPTED trial, whose evaluation was made at exactly this state by exactly these operations: its chi2 is carried over
+            // instead of being recomputed (the same double).  Only a round's first iteration evaluates — with the same function, so that every
+            // sum keeps the order the oracle's has (accept / reject decisions of nearly converged iterations hang on the last bits; a first
+            // attempt that let this evaluation ride in the H pass below, with another summation order, left the 1e-6 lock-step bar on one frame
+            // in 200).  Round 5: one edge evaluation per iteration + one per trial instead of two + one — the tracker's one-frame call spends
+            // its time in ~45 dependent Levenberg steps (frontend.cpp:176-276).
+            double currentChi = active_chi2();
             for (int it = 0; it < a.iters; it++) {
-                double currentChi = active_chi2();
+#ifdef MYSLAM_POSE_ONLY_RECOMPUTE_CHI                         // A/B builds only (tools/build_variants.sh): the round-4 form, one more evaluation per iteration
+                if (it > 0) currentChi = active_chi2();
+#endif
                 // ---- H (upper triangle, 21) and b (6) ----
                 double h[27];
 #pragma unroll
@@ -1026,9 +1043,9 @@ __global__ __launch_bounds__(NT) void k_pose_only(PoseOnlyArgs a) {
                 do {
                     const double lambda = s_sc[0];
                     if (t < 12) sTb[t] = sT[t];
-                    if (t == 0) {                              // (H + lambda I) x = b, dense Cholesky (LinearSolverDense)
-                        double A[36], x[6];
-#pragma unroll
+                    if (t == 0) {                              // (H + lambda I) x = b, dense Cholesky (LinearSolverDense) — the oracle's operations one for one:
+                        double A[36], x[6];                    // with 1 / sqrt(pivot) and multiplications instead (measured: -0.03 ms per one-frame call) the
+#pragma unroll                                                 // unconverged iterates of short rounds leave the 1e-8 bar (cond(H) ~ 1e8), so the divisions stay
                         for (int r = 0; r < 6; r++)
 #pragma unroll
                             for (int c = 0; c < 6; c++) { const int rr = min(r, c), cc = max(r, c); A[r * 6 + c] = sH[rr * 6 - rr * (rr - 1) / 2 + (cc - rr)] + (r == c ? lambda : 0.0); }
@@ -1197,13 +1214,14 @@ int myslam_ba_optimize(double* poses, int nposes, double* points, int npts, cons
     int32_t st[2] = {0, 0}; double chi = 0;
     const int i_p = hc.inout(poses, (size_t)nposes * 7), i_x = hc.inout(points, (size_t)npts * 3), i_o = hc.in(obs, (size_t)nedges * 2);
     const int i_ep = hc.in(edge_pose, (size_t)nedges), i_el = hc.in(edge_pt, (size_t)nedges), i_f = hc.in(fixed_pt, fixed_pt ? (size_t)npts : 0);
-    const int o_st = hc.out(st, 2), o_chi = hc.out(&chi, 1), t_w = hc.tmp<double>((size_t)nedges * 18);
+    const size_t wneed = std::max((size_t)nedges * 18, ba_opt_scratch_need(npts, nedges, true));
+    const int o_st = hc.out(st, 2), o_chi = hc.out(&chi, 1), t_w = hc.tmp<double>(wneed);
     int rc = hc.upload();
     if (rc) return rc;
     int32_t* d_st = hc.dev<int32_t>(o_st);
     BaOptArgs a{hc.dev<double>(i_p), hc.dev<double>(i_x), hc.dev<int32_t>(i_ep), hc.dev<int32_t>(i_el), hc.dev<double>(i_o),
                 fixed_pt ? hc.dev<uint8_t>(i_f) : nullptr, nullptr, nposes, npts, nedges, nposes, npts, nedges,
-                fx, fy, cx, cy, huber_delta, max_iters, hc.dev<double>(t_w), hc.dev<double>(o_chi), d_st + 1, d_st, 1, 0.0, nullptr, nullptr, nullptr, nullptr};
+                fx, fy, cx, cy, huber_delta, max_iters, hc.dev<double>(t_w), hc.dev<double>(o_chi), d_st + 1, d_st, 1, 0.0, nullptr, nullptr, nullptr, nullptr, wneed};
     if ((rc = ba_opt_launch(a, 1, hc.stream()))) return rc;
     if ((rc = hc.download())) return rc;
     if (final_chi2) *final_chi2 = chi;
@@ -1244,14 +1262,15 @@ int myslam_ba_optimize_active_map(double* poses, int nposes, double* points, int
     const int i_p = hc.inout(poses, (size_t)nposes * 7), i_x = hc.inout(points, (size_t)npts * 3), i_o = hc.in(obs, (size_t)nedges * 2);
     const int i_ep = hc.in(edge_pose, (size_t)nedges), i_el = hc.in(edge_pt, (size_t)nedges), i_f = hc.in(fixed_pt, fixed_pt ? (size_t)npts : 0);
     const int o_st = hc.out(st, 3), o_chi = hc.out(edge_chi2, (size_t)nedges), o_out = hc.out(outlier, (size_t)nedges);
-    const int t_w = hc.tmp<double>((size_t)nedges * 18);
+    const size_t wneed = std::max((size_t)nedges * 18, ba_opt_scratch_need(npts, nedges, true));
+    const int t_w = hc.tmp<double>(wneed);
     int rc = hc.upload();
     if (rc) return rc;
     int32_t* d_st = hc.dev<int32_t>(o_st);
     BaOptArgs a{hc.dev<double>(i_p), hc.dev<double>(i_x), hc.dev<int32_t>(i_ep), hc.dev<int32_t>(i_el), hc.dev<double>(i_o),
                 fixed_pt ? hc.dev<uint8_t>(i_f) : nullptr, nullptr, nposes, npts, nedges, nposes, npts, nedges,
                 fx, fy, cx, cy, huber_delta, iters_per_round, hc.dev<double>(t_w), nullptr, nullptr, d_st, max_rounds, chi2_th,
-                hc.dev<double>(o_chi), hc.dev<uint8_t>(o_out), d_st + 1, d_st + 2};
+                hc.dev<double>(o_chi), hc.dev<uint8_t>(o_out), d_st + 1, d_st + 2, wneed};
     if ((rc = ba_opt_launch(a, 1, hc.stream()))) return rc;
     if ((rc = hc.download())) return rc;
     if (rounds) *rounds = st[1];

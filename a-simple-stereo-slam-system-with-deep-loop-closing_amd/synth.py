@@ -378,15 +378,15 @@ def pnp_problem(n=120, outlier_frac=0.3, noise_px=0.5, seed=0x919, K=KITTI00, w=
 SEQ_K = {"fx": 420.0, "fy": 420.0, "cx": 359.5, "cy": 119.5, "bf": 420.0 * 0.54}       # a 720 x 240 camera, 0.54 m baseline
 
 
-def sequence_scene(seed=0x5E0, tex_w=4096, tex_h=1024, texels_per_m=40.0, x_min=-45.0, x_max=55.0):
+def sequence_scene(seed=0x5E0, tex_w=4096, tex_h=1024, texels_per_m=40.0, x_min=-45.0, x_max=55.0, z_lo=8.0, z_hi=24.0):
     rng = _rng(seed)
     xs = [x_min]
     while xs[-1] < x_max:
         xs.append(xs[-1] + rng.uniform(3.0, 7.0))
     xs = np.array(xs)
-    zs = np.empty(len(xs)); zs[0] = 14.0
-    for i in range(1, len(xs)):                       # depth between 8 and 24 m, slope at most 1.0
-        lo = max(8.0, zs[i - 1] - (xs[i] - xs[i - 1])); hi = min(24.0, zs[i - 1] + (xs[i] - xs[i - 1]))
+    zs = np.empty(len(xs)); zs[0] = min(max(14.0, z_lo), z_hi)
+    for i in range(1, len(xs)):                       # depth between z_lo and z_hi (8 and 24 m), slope at most 1.0
+        lo = max(z_lo, zs[i - 1] - (xs[i] - xs[i - 1])); hi = min(z_hi, zs[i - 1] + (xs[i] - xs[i - 1]))
         zs[i] = rng.uniform(lo, hi)
     seg = np.sqrt(np.diff(xs) ** 2 + np.diff(zs) ** 2)
     arc = np.concatenate([[0.0], np.cumsum(seg)])     # arc length of the wall at every knot: the texture is not stretched by the slant
@@ -401,12 +401,33 @@ def sequence_scene(seed=0x5E0, tex_w=4096, tex_h=1024, texels_per_m=40.0, x_min=
     return {"x": xs, "z": zs, "arc": arc, "tex": t, "texels_per_m": texels_per_m}
 
 
-def sequence_poses(n=200, kind="figure", reach=25.0):
+def sequence_poses(n=200, kind="figure", reach=25.0, laps=1):
     """camera position [x, y, z] and yaw of frame t.  "figure": a flat figure along the wall that starts in full sideways motion (a
     vehicle that is already driving: the first key-frames see parallax), swings 3 m to either side and ends where it started.
     "outback": a drive of `reach` metres along the wall and back to the start (up to reach * pi / n metres per frame: tens of pixels of
     flow per frame at KITTI resolution, features leave the view for good, the way back revisits every place)"""
     t = np.arange(n) / (n - 1)
+    if kind == "ramp":          # `laps` times out to `reach` and back, starting from rest: x = reach sin^2(pi laps t); up to reach pi laps / n metres per frame mid-leg
+        x = reach * np.sin(np.pi * laps * t) ** 2
+        zc = 1.0 * np.sin(2 * np.pi * laps * t) ** 2
+        yaw = np.deg2rad(3.0) * np.sin(6 * np.pi * laps * t)
+        return np.stack([x, np.zeros(n), zc], 1), yaw
+    if kind == "legs":          # `laps` times out and back at a CONSTANT `reach` metres per frame (cosine-eased starts, turns and stops of 12 frames):
+        # the reference's key-frame rule (inliers <= trackingGood) then fires at a steady rate instead of in bursts at a sine's peak speed
+        half = n // (2 * laps); ease = 12
+        prof = np.ones(half)
+        prof[:ease] = 0.5 - 0.5 * np.cos(np.pi * (np.arange(ease) + 0.5) / ease); prof[half - ease:] = prof[:ease][::-1]
+        vel = np.concatenate([np.concatenate([prof, -prof]) for _ in range(laps)])
+        vel = np.concatenate([vel, np.zeros(n - len(vel))])
+        x = reach * np.concatenate([[0.0], np.cumsum(vel)[:-1]])
+        tt = np.arange(n) / max(half, 1)
+        zc = 1.0 * np.sin(np.pi * tt) ** 2
+        yaw = np.deg2rad(3.0) * np.sin(3 * np.pi * tt)
+        return np.stack([x, np.zeros(n), zc], 1), yaw
+    if kind == "oneway":        # a drive in ONE direction at `reach` metres per frame (eased start): no place is seen twice
+        x = reach * np.concatenate([[0.0], np.cumsum(np.minimum(1.0, (np.arange(n - 1) + 0.5) / 12.0))])
+        tt = np.arange(n) / 100.0
+        return np.stack([x, np.zeros(n), np.sin(np.pi * tt) ** 2], 1), np.deg2rad(3.0) * np.sin(3 * np.pi * tt)
     if kind == "outback":
         x = reach * np.sin(np.pi * t)
         zc = 1.0 * np.sin(2 * np.pi * t) ** 2

@@ -16,6 +16,12 @@ Passes (all after the warm-up, each bracketed by barrier + synchronize):
   2. a profiled pass: the same K steps with a HIP event pair around every launch (on the launch's stream) -> roofline
   3. (full workload) K steps with the OptimizeActiveMap solve on 1 frame in 6 (the reference's key-frame cadence) -> full_solve_cadence6
 Prints ONE JSON line (rank 0).  PyTorch is used for device memory, streams and torch.distributed only.
+
+This file is the entry point and the timed schedule (set-up, the step functions, passes 1-6, the verification steps, the JSON line).  Everything
+else lives in the package bench/ (round 5 split, no behaviour change): args.py (command line), config.py (constants, algorithmic bytes),
+runtime.py (self-launch, host cores), profiles.py (committed counter / peak files), report.py (roofline objects), passes_multirank.py (the
+loop-database exchange stage by stage), passes_stream_mode.py (live-stream operating points), cpu_baseline.py and parity_sample.py (the two
+oracle legs: the only importers of oracle/ outside tests/ and smoke()).
 """
 import argparse
 import glob
@@ -61,343 +67,14 @@ HW_QUEUES = os.environ.setdefault("GPU_MAX_HW_QUEUES", ("24" if _small_batch() e
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package  # noqa: E402
-
-H, W = 376, 1241
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-VALU_PEAK_TLANEOPS = 39.3      # spec-derived: 256 CUs x 4 SIMDs x 16 lanes per cycle x 2.4 GHz (packed-16 / VOP3 integer classes: 4 cycles per wave64)
-MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense
-# The MEASURED peaks of the same machine class live in profiles/r<NN>_peaks.json (tools/peaks.hip via tools/peaks.py): HBM copy rate,
-# issue rate of the instruction classes the FAST kernel is made of, bf16 MFMA rate.  The roofline objects carry both: `peak` is the
-# vendor figure the contract names (HBM) or the measured ceiling (VALU: no vendor figure exists), the other one sits beside it.
-PYR_PX = 1444097               # sum of the 8 level areas
-# algorithmic bytes per IMAGE of each ORB stage (SURVEY.md §8(d) accounting)
-ALGO_BYTES = {
-    "resize": 1407767 + 977481,            # read levels 0-6, write levels 1-7
-    "fast": PYR_PX + 4 * 20000,            # read every level once + candidate list
-    "blur7": 2 * PYR_PX,                   # read + write every level
-    "describe": 2000 * (749 + 512 + 60),   # IC patch + BRIEF samples + outputs
-    "octree": 2 * 4 * 56000,               # candidates in, selected out (latency bound in practice)
-}
-# profiling slot (csrc/prof.hip) -> kernel symbol prefix as rocprofv3 prints it
-SYMBOL = {"resize": "k_resize_strip", "fast": "k_fast_strip", "octree": "k_octree", "blur7": "k_blur7", "describe": "k_describe2",
-          "hamming_match": "k_hamming_fp4", "triangulate": "k_triangulate", "lcd_preproc": "k_lcd_input_fused",
-          "calc_conv1": "k_conv1_f16x3_pool_lrn", "calc_conv2": "k_conv2_f16x3", "calc_pool2": "k_pool_lrn128_2x2", "calc_conv3": "k_conv3_norm", "lcddb_scan": "k_db_scan_bf16x6",
-          "ba_build": "k_ba_build", "screen": "k_screen"}
-
-
-_masked = []
-
-
-def masked_stream(n_cus, first=0):
-    """A HIP stream whose kernels may only run on `n_cus` compute units (hipExtStreamCreateWithCUMask; bits first .. first + n_cus - 1 of the
-    device's CU mask) as a torch stream — an experiment: does confining the latency-bound side chains to a few CUs keep their long-lived blocks
-    out of FAST's way?  (--side-cus / --match-cus; DESIGN_APPENDIX.md section 8 has the result.)"""
-    import ctypes
-    import torch
-    hip = ctypes.CDLL("libamdhip64.so")
-    words = 8                                              # 256 CUs
-    mask = (ctypes.c_uint32 * words)()
-    for b in range(first, first + n_cus):
-        mask[(b // 32) % words] |= 1 << (b % 32)
-    st = ctypes.c_void_p()
-    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), mask)
-    assert rc == 0 and st.value, f"hipExtStreamCreateWithCUMask failed: {rc}"
-    _masked.append(st)
-    return torch.cuda.ExternalStream(st.value)
-
-
-def pmc_file():
-    """The newest committed counter summary of this build family (tools/pmc_collect.py writes it): profiles/r<NN>_pmc_<tag>.json."""
-    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json")) if re.search(r"r(\d+)_pmc_[^/]*\.json$", f) and "traffic" not in f and "mfma" not in f]
-    if not files:
-        return None, None
-
-    def key(f):
-        m = re.search(r"r(\d+)_pmc_.*?(\d+)\.json$", f)
-        return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
-    f = max(files, key=key)
-    try:
-        d = json.load(open(f))
-    except Exception:
-        return None, None
-    return (d, os.path.relpath(f, ROOT)) if "kernels" in d and "calibration" in d else (None, None)
-
-
-def peaks_file():
-    """The newest committed machine-peak measurement (tools/peaks.py): profiles/r<NN>_peaks.json -> (summary dict, relative path)."""
-    files = glob.glob(os.path.join(ROOT, "profiles", "r*_peaks.json"))
-    best = (None, None, -1)
-    for f in files:
-        m = re.search(r"r(\d+)_peaks\.json$", f)
-        if not m or int(m.group(1)) <= best[2]:
-            continue
-        try:
-            d = json.load(open(f))
-            best = (d["summary"], os.path.relpath(f, ROOT), int(m.group(1)))
-        except Exception:
-            pass
-    return best[0], best[1]
-
-
-def pmc_lookup(pmc, slot):
-    """(full kernel symbol, per-image record) of the profiling slot's kernel in the counter summary"""
-    if not pmc:
-        return None, None
-    pre = SYMBOL.get(slot)
-    for name, rec in pmc["kernels"].items():
-        if pre and name.startswith(pre):
-            return name, rec
-    return None, None
-
-
-def parse():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200, help="timed steps (default 200 = 1.4 s of work: the fill and drain of the three-step pipeline are 0.6 % of a 50-step run)")
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs", type=int, default=512, help="stereo pairs per step per GPU")
-    ap.add_argument("--workload", default="full", choices=["full", "orb_match", "orb_match_lcd", "full_solve", "latency"])
-    ap.add_argument("--db", type=int, default=0, help="key-frame database size (default 10000, or 6250 per GPU when sharded)")
-    ap.add_argument("--scene-rects", type=int, default=6000,
-                    help="rectangles of the synthetic scene (SURVEY.md §8(d): 6000 = the corner-dense BASELINE stream; 300 = a sparse stream "
-                         "closer to real imagery, on which the two-phase FAST path pays most)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--parity-frames", type=int, default=8,
-                    help="K > 0 (default 8): after the timed region one more step of the same workload is run and K of its frames (evenly spread over "
-                         "the batch) are compared with the CPU oracle at the bars of the parity tests -> `parity_sample`; a mismatch exits non-zero.  0 = skip")
-    ap.add_argument("--cpu-pairs", type=int, default=13,
-                    help="timed frames PER THREAD of the all-cores CPU baseline (after one warm-up frame per thread); the default 13 is raised until "
-                         "the threads together time >= 200 frames (BASELINE.md section 3)")
-    ap.add_argument("--no-extra-passes", action="store_true", help="skip the profiled, the solve-cadence and the streamed-input passes (timed region only)")
-    ap.add_argument("--stream-input", type=int, default=4,
-                    help="B > 0 (default 4): after the timed region, K more steps in which every step's images arrive over PCIe — B distinct batches "
-                         "(consecutive frames of the synthetic stream) in pinned host memory, host->device copies on a copy stream, double-buffered "
-                         "device input; reported as `streamed` beside the resident `value`.  0 = skip")
-    ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
-                    help="2 = the DeepLCD / loop-DB / BA chain runs on its own HIP stream beside ORB + match + triangulation")
-    ap.add_argument("--orb-split", type=int, default=0, choices=[0, 1, 2, 3, 4, 8],
-                    help="S > 1 = the 2P images go through S extractor handles on S streams (S equal groups).  0 (default) = 2 with "
-                         "--streams 2, 1 with --streams 1")
-    ap.add_argument("--pipeline", type=int, default=-1, choices=[-1, 0, 1, 2],
-                    help="1 = the left and the right images go through two extractor handles that take turns (myslam_orb_set_fast_event): "
-                         "one handle's VALU-bound FAST stage runs under the other's latency-bound oct-tree / descriptor stages, match + "
-                         "triangulation follow on a third stream, outputs are double-buffered and consecutive steps overlap (every step's "
-                         "work is complete at the closing barrier).  0 = every step is joined before the next starts.  "
-                         "-1 (default) = 1 with --streams 2, else 0")
-    ap.add_argument("--graph", type=int, default=-1, choices=[-1, 0, 1],
-                    help="1 = the timed region replays recorded steps: the whole step (extractor for the 2P images, match, triangulation, DeepLCD, "
-                         "database scan, BA build) is recorded per LANE on one stream (myslam_graph_begin / _end) and --lanes lanes (own handles and "
-                         "buffers each) replay their graphs concurrently, step k on lane k mod L — for small batches, where a step is launch- and "
-                         "latency-bound; 0 = eager launches on the four-stream schedule; -1 (default) = 1 when --pairs <= 64 on one GPU, else 0.  The "
-                         "other mode is timed in an extra pass (`step_graph` / `step_eager`)")
-    ap.add_argument("--lanes", type=int, default=0, help="lanes of --graph 1 (0 = 16 for <= 16 pairs per step, 8 up to 64, else 4)")
-    ap.add_argument("--stream-split", type=int, default=2, help="streamed pass: the left and the right images of a step as separate copies with an event each, on this many copy streams (0 = one copy of the whole batch; 2 (default): 56.9-57.1 k frames/s against 51.6-54.1 k; 4: 53-55.6 k)")
-    ap.add_argument("--lcd-split", type=int, default=1, help="the DeepLCD chain of a step in this many parts on as many handles / streams (1 = one chain on the side stream)")
-    ap.add_argument("--ba-stream", choices=["side", "match"], default="match", help="the BA block build behind the triangulation on the match stream (default: +0.4 %, three alternating runs) or behind the DB scan on the side stream")
-    ap.add_argument("--solve-lm-hbm", type=int, default=0, help="cadence-6 pass: 1 = the solve keeps its per-landmark state in its HBM scratch (81 KB of LDS per window instead of 133: "
-                    "its CU keeps room for two more of the extractor's blocks).  Measured negative (same box, two runs each: 7.06 / 7.07 ms per step against 7.02 / 7.01 "
-                    "with the state in LDS): the solve's cost is the CU TIME of its blocks, and the HBM form holds its CUs longer")
-    ap.add_argument("--solve-stream", choices=["own", "side"], default="own", help="the OptimizeActiveMap solve of the cadence passes on its own stream (the reference's Backend thread) or behind the side chain")
-    ap.add_argument("--side-cus", type=int, default=0, help="experiment: the DeepLCD / DB / BA stream may use only this many CUs (hipExtStreamCreateWithCUMask); 0 = all")
-    ap.add_argument("--match-cus", type=int, default=0, help="experiment: likewise for the match + triangulation stream")
-    ap.add_argument("--created-main-stream", action="store_true", help="debug: the four-stream schedule's main chain on a created stream instead of the legacy NULL stream")
-    ap.add_argument("--verify", action="store_true",
-                    help="after the timed region: run one joined, un-gated step and check that it reproduces the pipeline's last outputs bit for bit")
-    ap.add_argument("--orb-internal-stream", type=int, default=0, choices=[0, 1, 2],
-                    help="myslam_orb_set_option(INTERNAL_STREAM): 1 = Gaussian pyramid on the extractor's internal stream beside the oct-tree kernel "
-                         "(the library's default), 2 = beside FAST, 0 = one stream per extractor handle (default here: with one HSA hardware queue "
-                         "per HIP stream — see HW_QUEUES — the internal streams gain nothing, measured)")
-    ap.add_argument("--orb-copy-input", type=int, default=0, choices=[0, 1],
-                    help="myslam_orb_set_option(COPY_INPUT): 0 = level 0 read in place (the library's default), 1 = every image copied into the pyramid block")
-    ap.add_argument("--fast-mode", type=int, default=-1, choices=[-1, 0, 1],
-                    help="myslam_orb_set_option(FAST_MODE): -1 = the FAST kernel picks its path per level (default), 0 = two-phase, 1 = dense")
-    ap.add_argument("--side-blocks-per-cu", type=int, default=-1,
-                    help="myslam_orb_set_option(SIDE_BLOCKS_PER_CU): the descriptor kernel runs as a limited grid of this many blocks per CU, each walking "
-                         "several work items, so that its long-lived blocks do not crowd the other handle's FAST blocks out of the CUs (0 = one block per "
-                         "work item, the library's default; -1 = 2 under the pipelined schedule, else 0)")
-    ap.add_argument("--lcd-skip", type=int, default=0, help="diagnostic, timing only: myslam_lcd_set_option(SKIP_KERNELS) bit mask (1 input, 2 conv1, 4 conv2, 8 pool2, 16 conv3)")
-    ap.add_argument("--side-skip", default="", help="diagnostic: comma list of side-chain parts to leave out (lcd, db, ba) — measures what each part costs the step")
-    ap.add_argument("--blur-mfma", type=int, default=0, choices=[0, 1],
-                    help="myslam_orb_set_option(BLUR_MFMA): 1 = the Gaussian pyramid on the int8 matrix cores (k_blur7_mfma), 0 = register-strip kernel")
-    ap.add_argument("--stream-mode", default="1x16,2x16,4x16",
-                    help="live-stream operating points, 'PAIRSxLANES,...' ('' = skip): after the other passes each point is run as a child process "
-                         "(bench.py --pairs P --lanes L --graph 1: recorded steps on L lanes scanning ONE loop database through L query contexts; its own "
-                         "GPU_MAX_HW_QUEUES) and reported as `stream_mode` — the reference's call pattern is one frame per call (src/frontend.cpp:41-77)")
-    ap.add_argument("--frame-latency", action="store_true", help="(child of --stream-mode) also time every step on its lane with an event pair: `frame_latency_ms`")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo = debugging aid: several ranks share GPU 0 and the collectives go through host memory")
-    args = ap.parse_args()
-    if args.pipeline < 0:
-        args.pipeline = 1 if (args.streams == 2 and args.orb_split != 1) else 0
-    if args.side_blocks_per_cu < 0:
-        args.side_blocks_per_cu = 2 if args.pipeline else 0
-    if args.orb_split == 0:
-        args.orb_split = 2 if (args.streams == 2 or args.pipeline) else 1
-    if args.pipeline:
-        assert args.orb_split >= 2, "--pipeline runs the images on two or more extractor handles (--orb-split >= 2)"
-    return args
-
-
-def self_launch(n):
-    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks (one per GPU) ourselves and pass rank 0's output on."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
-    sys.exit(rc)
-
-
-def physical_cores():
-    """(hardware threads this process may run on, physical cores among them — SMT siblings counted once —, CPU quota of the container's
-    cgroup in CPUs or None)"""
-    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
-    cores = set()
-    for c in cpus:
-        try:
-            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
-        except OSError:
-            sib = str(c)
-        cores.add(sib)
-    n_cores = max(1, len(cores))
-    # a container's CPU-time quota (cgroup) can be far below its CPU affinity: threads beyond it only time-slice
-    quota = None
-    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else float(t.split()[0]) / float(t.split()[1])),
-                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: None if int(t) <= 0 else int(t) / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()))):
-        try:
-            quota = parse(open(path).read().strip())
-            break
-        except (OSError, ValueError, IndexError, ZeroDivisionError):
-            continue
-    return len(cpus), n_cores, quota
-
-
-def cpu_baseline(synth, workload, frames_per_thread, db_np, gpu_frames, ba_w):
-    """The oracle (a plain C++ port of the reference arithmetic, oracle/) timed on this host over a bounded sample of the same frames
-    and stages, SURVEY.md §8(d) protocol: (i) one thread — the reference runs every stage single-threaded inside its std::thread —
-    and (ii) frame-parallel on every PHYSICAL core the host really grants (affinity mask, cgroup quota and a measured spin test) (std::thread pool, one frame per task, oracle/bench_oracle.cpp; SMT siblings add
-    nothing to this integer / f32 code): one warm-up frame per thread, then `frames_per_thread` (>= 4) timed frames per thread, the
-    GPU run's frames in a cycle; wall clock over the timed frames, per-stage medians, parallel efficiency = all-cores rate /
-    (threads x one-thread rate).  Bounded to roughly 10-30 s of CPU work."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from pyoracle import Oracle
-    o = Oracle()
-    hw_threads, phys, quota = physical_cores()
-    cores = phys if not quota else max(1, min(phys, int(quota + 0.5)))          # threads the host will actually run at the same time
-    # ... as far as the container can see.  Measured: `cores` spinning threads against one (the GPU boxes of this pool show 256
-    # hardware threads and deliver about 12 CPUs' worth of time)
-    capacity = max(o.cpu_capacity(cores, 200) for _ in range(4))     # the best of four probes: a noisy moment must not shrink the baseline
-    if capacity < 0.75 * cores:
-        cores = max(1, int(capacity + 0.5))
-    stages = {"orb_match": 1, "orb_match_lcd": 2, "full": 3, "full_solve": 4}[workload]
-    ids = np.arange(len(db_np), dtype=np.uint64)
-    args = (synth.KITTI00, synth.calc_weights(), db_np, ids, ba_w)
-    names = ["orb_extract_LR", "match_triangulate", "deeplcd_dbscan", "ba_build", "ba_solve"][:max(2, stages + 1)]
-    # (i) one thread: 5 warm-up + 50 timed frames (~0.3 s per frame; BASELINE.md section 3 asks for >= 200 frames over the whole baseline,
-    # (ii) supplies them)
-    n1 = min(len(gpu_frames), 55); w1 = min(5, n1 - 1)
-    dt1, st1 = o.bench_frames(gpu_frames[:n1], *args, stages=stages, threads=1, n_warmup=w1)
-    fps1 = (n1 - w1) / dt1
-    # (ii) every physical core: 1 warm-up + frames_per_thread timed frames per thread
-    fpt = max(1, int(frames_per_thread), -(-200 // cores) if frames_per_thread >= 13 else 1)       # default: >= 200 timed frames in total
-    wn, n = cores, cores * fpt
-    dt, st = o.bench_frames(gpu_frames, *args, stages=stages, threads=cores, n_warmup=wn, n_tasks=wn + n)
-    med = lambda a, k0: {nm: float(np.median(a[k0:, i]) * 1e3) for i, nm in enumerate(names)}
-    return {"value": n / dt, "unit": "stereo frames/s", "cores": cores, "hardware_threads": hw_threads, "physical_cores": phys,
-            "cgroup_cpu_quota": quota, "measured_concurrent_threads": capacity, "kind": "port", "value_1thread": fps1,
-            "parallel_efficiency": (n / dt) / (cores * fps1),
-            "stage_median_ms_1thread": med(st1, w1), "stage_median_ms_allcores": med(st, wn),
-            "sample": f"{n} stereo pairs ({fpt} per thread, the GPU run's synthetic 1241x376 frames in a cycle) after {wn} warm-up frames, same stages, "
-                      f"oracle frame-parallel on {cores} threads ({phys} physical cores / {hw_threads} hardware threads visible, cgroup CPU quota "
-                      f"{'none' if not quota else round(quota, 1)}) in {dt:.1f} s; "
-                      f"single thread: {n1 - w1} pairs after {w1} warm-up in {dt1:.1f} s"}
-
-
-def parity_sample(api, synth, frames, sample, cap, Kt, K, bufs, db_np, db_ids, cur_id, ba_w, calc_w):
-    """K frames of ONE 512-pair step of the timed workload (the step function of the timed region, run once more after it) against the
-    oracle at the bars of the parity tests: key-point structs and descriptor bytes of both images, match indices and distances,
-    triangulation flags (identical) and coordinates (1e-9), DeepLCD descriptor (2e-5), the database scan's (best id, max score, count),
-    one BA window's blocks (1e-11 of the largest entry).  `bufs` holds host copies of the step's output buffers.  Returns the
-    `parity_sample` object; "ok": False on any mismatch (the caller exits non-zero)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from pyoracle import Oracle
-    o = Oracle()
-    P = len(frames)
-    res = {"frames": len(sample), "frame_indices": [int(i) for i in sample], "pairs_per_step": P, "ok": True, "mismatches": []}
-    bad = lambda what: (res["mismatches"].append(what), res.__setitem__("ok", False))
-    par = o.params(2000)
-    kps = bufs["kps"].view(api.KP_DTYPE).reshape(2 * P, cap); desc = bufs["desc"].reshape(2 * P, cap, 32); cnt = bufs["cnt"]
-    n_kp = 0; lcd_dev = 0.0; xyz_dev = 0.0; score_dev = 0.0; ba_dev = 0.0; n_match = 0; n_ok = 0
-    for i in sample:
-        ref = []
-        for side in (0, 1):
-            rk, rd = o.detect_and_compute(par, frames[i, side])
-            b = i + side * P
-            n = int(cnt[b]); n_kp += n
-            if n != len(rk) or kps[b, :n].tobytes() != rk.tobytes():
-                bad(f"frame {i} {'LR'[side]}: key-points")
-            elif not np.array_equal(desc[b, :n], rd):
-                bad(f"frame {i} {'LR'[side]}: descriptors")
-            ref.append((rk, rd))
-        (kl, dl), (kr, dr) = ref
-        ridx, rdist = o.hamming_match(dl, dr)
-        nl = len(kl); n_match += nl
-        if not (np.array_equal(bufs["midx"][i * cap:i * cap + nl], ridx) and np.array_equal(bufs["mdist"][i * cap:i * cap + nl], rdist)):
-            bad(f"frame {i}: Hamming match")
-        rxyz, rok = o.triangulate_stereo(kl["x"], kl["y"], kr["x"][ridx], kr["y"][ridx], K["fx"], K["fy"], K["cx"], K["cy"], K["bf"] / K["fx"])
-        ok = bufs["ok"][i * cap:i * cap + nl].astype(bool); xyz = bufs["xyz"].reshape(-1, 3)[i * cap:i * cap + nl]
-        n_ok += int(rok.sum())
-        # a match of exactly zero disparity is a point at infinity: the DLT's homogeneous coordinate is rounding noise and so is the sign of z
-        # (1e17 m here, 1e17 m behind the camera in the oracle; Eigen's bdcSvd in the reference is no different) — such points are not compared
-        finite = (np.abs(rxyz[:, 2]) < 1e9) & (np.abs(xyz[:, 2]) < 1e9)
-        rok = rok & finite
-        if not np.array_equal(ok[finite], rok[finite]):
-            bad(f"frame {i}: triangulation flags")
-        elif rok.any():
-            d = float(np.max(np.abs(xyz[rok] - rxyz[rok]) / np.maximum(1.0, np.abs(rxyz[rok]))))
-            xyz_dev = max(xyz_dev, d)
-            if d > 1e-9:
-                bad(f"frame {i}: triangulated coordinates ({d:.2e})")
-        if "descr" in bufs:
-            x, _ = o.calc_preproc(frames[i, 0])
-            rd_ = o.calc_forward(calc_w, x)
-            d = float(np.abs(bufs["descr"][i] - rd_).max()); lcd_dev = max(lcd_dev, d)
-            if d >= 2e-5:
-                bad(f"frame {i}: DeepLCD descriptor ({d:.2e})")
-            rb, rm, rc = o.lcddb_query(db_np, db_ids, bufs["descr"][i], cur_id)         # the scan of the descriptor the device scanned with
-            near = int((np.abs(db_np @ bufs["descr"][i] - 0.92) < 1e-5).sum())          # counts may differ only for scores within float noise of the threshold
-            d = abs(float(bufs["max"][i]) - rm); score_dev = max(score_dev, d)
-            if int(bufs["best"][i]) != rb or d >= 2e-5 or abs(int(bufs["dbcnt"][i]) - rc) > near:
-                bad(f"frame {i}: database scan ({int(bufs['best'][i])}, {float(bufs['max'][i])}, {int(bufs['dbcnt'][i])}) vs ({rb}, {rm}, {rc})")
-    if "ba" in bufs:
-        for i in sample[:1] + sample[-1:]:
-            po, pt, ep, el, ob, fx, sz = [a[i] for a in ba_w]
-            np_, nl_, ne_ = [int(v) for v in sz]
-            ref = o.ba_build(po[:np_], pt[:nl_], ep[:ne_], el[:ne_], ob[:ne_], fx[:nl_], Kt)
-            got = [bufs["ba"][0][i].reshape(-1, 6, 6)[:np_], bufs["ba"][1][i].reshape(-1, 3, 3)[:nl_], bufs["ba"][2][i].reshape(-1, 6, 3)[:ne_],
-                   bufs["ba"][3][i].reshape(-1, 6)[:np_], bufs["ba"][4][i].reshape(-1, 3)[:nl_], bufs["ba"][5][i][:ne_]]
-            for nm, g, r in zip(("Hpp", "Hll", "Hpl", "bp", "bl", "chi2"), got, ref):
-                d = float(np.abs(g - r).max() / max(1.0, np.abs(r).max())); ba_dev = max(ba_dev, d)
-                if d > 1e-11:
-                    bad(f"window {i}: BA block {nm} ({d:.2e})")
-    res.update({"orb": "bit-exact" if not any("key-points" in m or "descriptors" in m for m in res["mismatches"]) else "MISMATCH",
-                "keypoints_compared": n_kp, "matches_compared": n_match, "triangulated_compared": n_ok,
-                "match": "bit-exact" if not any("Hamming" in m for m in res["mismatches"]) else "MISMATCH",
-                "triangulation_max_rel": xyz_dev, "lcd_max_abs": lcd_dev if "descr" in bufs else None,
-                "db_score_max_abs": score_dev if "descr" in bufs else None, "ba_max_rel": ba_dev if "ba" in bufs else None,
-                "bars": "ORB / match / flags identical; xyz 1e-9 rel; DeepLCD 2e-5 abs; DB best id identical, score 2e-5, count up to scores within 1e-5 "
-                        "of the threshold; BA blocks 1e-11 of the largest entry (tests/test_gpu_*.py)",
-                "note": "one more step of the timed workload (same step function, same batch, same buffers) run after the timed region; K frames of "
-                        "it pulled to the host and compared with the CPU oracle (oracle/, parity unpinned — DESIGN.md section 5)"})
-    return res
-
+from bench.args import parse  # noqa: E402
+from bench.config import H, SYMBOL, W  # noqa: E402
+from bench.cpu_baseline import cpu_baseline  # noqa: E402
+from bench.parity_sample import parity_sample  # noqa: E402
+from bench.report import ba_solve_roofline, rooflines  # noqa: E402
+from bench.passes_multirank import db_exchange  # noqa: E402
+from bench.passes_stream_mode import stream_mode_sweep  # noqa: E402
+from bench.runtime import masked_stream, self_launch  # noqa: E402
 
 def main():
     args = parse()
@@ -661,13 +338,17 @@ def main():
 
     def timed(n, fn=None):
         """n steps bracketed by barrier + synchronize on both sides; the slowest rank's wall time.  host_ms[0] = CPU time the launches of
-        one step took (the loop that enqueues the n steps, before the closing barrier waits for the device)"""
+        one step took: the enqueue loop's time per step over its first 8 steps — after ~10 steps of 512 pairs the runtime's queues are
+        full and the loop runs at the DEVICE's pace (back-pressure: 3 ms per step over 200 steps, 0.2 ms over the first 8), which is not
+        a cost of launching"""
         fn = fn or step
         barrier()
         t0 = time.perf_counter()
-        for _ in range(n):
+        n_host = min(n, 8)
+        for i in range(n):
             fn()
-        host_ms[0] = (time.perf_counter() - t0) / n * 1e3
+            if i + 1 == n_host:
+                host_ms[0] = (time.perf_counter() - t0) / n_host * 1e3
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -754,53 +435,10 @@ def main():
     dt = timed(args.steps)
     host_launch_ms = host_ms[0]
     per_rank_ms = [v / args.steps * 1e3 for v in rank_dts] if world > 1 else None
-    # ---- multi-rank runs: what the loop-database exchange costs, stage by stage, on an otherwise idle chip (after the timed region).  The two
-    # all-gathers (queries: P x 4 256 B per rank in, N P x 4 256 B out; candidates: N P x 16 B per rank) and the N x larger scan are the only
-    # work a rank does for the others: scaling efficiency below 1 is these numbers (DESIGN.md section 4 holds the predicted values).
+    # ---- multi-rank runs: the loop-database exchange timed stage by stage on an otherwise idle chip (bench/passes_multirank.py) ----
     collective = None
     if world > 1 and use_lcd:
-        reps = 20
-        acc = np.zeros(4)
-        with torch.cuda.stream(side_stream):
-            for it in range(-2, reps):
-                if via_cpu:      # gloo stages through the host: wall clock around synchronised stages
-                    torch.cuda.synchronize(); t_ = [time.perf_counter()]
-                    h_all = torch.empty(d_allq.shape, dtype=d_allq.dtype); dist.all_gather_into_tensor(h_all, d_descr.cpu()); d_allq.copy_(h_all)
-                    torch.cuda.synchronize(); t_.append(time.perf_counter())
-                    D.query_batch_sharded(d_allq.data_ptr(), cur_ids, NQ, d_cand.data_ptr())
-                    torch.cuda.synchronize(); t_.append(time.perf_counter())
-                    mine = d_cand.cpu(); gathered = torch.empty(world * NQ * 16, dtype=torch.uint8); dist.all_gather_into_tensor(gathered, mine)
-                    t_.append(time.perf_counter())
-                    b_, m_, c_ = api.lcd_merge_candidates(gathered.numpy().view(api.CAND_DTYPE).reshape(world, NQ))
-                    t_.append(time.perf_counter())
-                    ms = [(t_[k + 1] - t_[k]) * 1e3 for k in range(4)]
-                else:            # RCCL: HIP events on the stream the collectives and the two library calls are ordered on
-                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-                    ev[0].record(side_stream)
-                    dist.all_gather_into_tensor(d_allq, d_descr); ev[1].record(side_stream)
-                    D.query_batch_sharded(d_allq.data_ptr(), cur_ids, NQ, d_cand.data_ptr()); ev[2].record(side_stream)
-                    gathered = torch.empty(world * NQ * 16, dtype=torch.uint8, device=dev)
-                    dist.all_gather_into_tensor(gathered, d_cand); ev[3].record(side_stream)
-                    api.lcd_merge_candidates_device(gathered.data_ptr(), world, NQ, d_best.data_ptr(), d_max.data_ptr(), d_dbcnt.data_ptr(), side_stream.cuda_stream)
-                    ev[4].record(side_stream)
-                    side_stream.synchronize()
-                    ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(4)]
-                if it >= 0:
-                    acc += np.array(ms)
-        acc /= reps
-        mine_t = torch.tensor(acc, dtype=torch.float64, device="cpu" if via_cpu else dev)
-        all_t = torch.empty(world * 4, dtype=torch.float64, device=mine_t.device)
-        dist.all_gather_into_tensor(all_t, mine_t)
-        all_t = all_t.cpu().numpy().reshape(world, 4)
-        collective = {"collective_ms_per_step": float((all_t[:, 0] + all_t[:, 2]).max()), "shard_scan_ms_per_step": float(all_t[:, 1].max()),
-                      "merge_ms_per_step": float(all_t[:, 3].max()),
-                      "allgather_queries_ms": [float(v) for v in all_t[:, 0]], "allgather_candidates_ms": [float(v) for v in all_t[:, 2]],
-                      "shard_scan_ms": [float(v) for v in all_t[:, 1]],
-                      "allgather_queries_bytes_per_rank": int(P * 1064 * 4), "allgather_candidates_bytes_per_rank": int(NQ * 16),
-                      "shard_rows": int(n_db_local), "queries_scanned_per_rank": int(NQ), "reps": reps,
-                      "timing": "wall clock around synchronised stages (gloo stages through host memory)" if via_cpu else "HIP events on the side stream",
-                      "note": "measured after the timed region on an otherwise idle chip: the cost of the loop-database exchange alone; inside a step it runs on the side "
-                              "stream under the extractor"}
+        collective = db_exchange(api, D, world, via_cpu, dev, side_stream, d_allq, d_descr, d_cand, d_best, d_max, d_dbcnt, cur_ids, NQ, P, n_db_local)
         barrier()
     frame_latency = None
     if use_graph and args.frame_latency:
@@ -1106,119 +744,16 @@ def main():
             torch.cuda.synchronize()
         solve_ms = (time.perf_counter() - t1) / 5 * 1e3
         assert int(s_st.abs().sum()) == 0
-        # k_ba_optimize against the f64 peaks: a flop MODEL of what one Levenberg iteration of a window executes (not a counter): edge evaluation +
-        # Jacobians + block products ~410 flop per edge, Schur complement sum_l W_l Hll^-1 W_l^T = (108 k + 216 k^2) flop
-        # for a landmark seen by k key-frames, 6x6-blocked Cholesky n^3 / 3 and two triangular solves 2 n^2 with n = 6 P; rounds x 10 iterations
-        # (optimize(10), backend.cpp:212-214: every round runs its iteration budget unless a Levenberg trial fails ten times)
-        # *rounds = the reference's `iteration` counter = rounds that FAILED the inlier test (backend.cpp:212-232): a window runs that many + 1
-        # rounds of optimize(10), at most max_rounds = 5 (round 5 fix: the model multiplied by the counter itself, 0 for well-posed windows)
-        rounds_mean = float((s_rd.float() + 1.0).clamp(max=5.0).mean().item())
-        szs = ba_w[6]                                                    # [P, 3] = poses, landmarks, edges per window
-        npo, nla, ned = [float(np.mean(szs[:, i])) for i in range(3)]
-        kobs = ned / max(1.0, nla)
-        flop_it = 410.0 * ned + nla * (108.0 * kobs + 216.0 * kobs * kobs) + (6 * npo) ** 3 / 3.0 + 2 * (6 * npo) ** 2
-        flops = P * rounds_mean * 10 * flop_it
-        solve_roof = {"bound": "f64 (vector + matrix cores)", "kernel": "k_ba_optimize", "unit": "TFLOP/s (f64, modelled flops)", "avg_launch_ms": solve_ms,
-                      "windows_per_launch": P, "rounds_executed_mean": rounds_mean, "modelled_flop_per_iteration": flop_it, "achieved": flops / (solve_ms * 1e-3) / 1e12,
-                      "peak": 78.6, "peak_f64_mfma_measured": 48.0, "frac": flops / (solve_ms * 1e-3) / 1e12 / 78.6,
-                      "note": "one 512-thread block per window with the window's state in 133 KB of LDS (one block per CU): iterations are chains of barrier-separated "
-                              "phases (pose blocks, landmark blocks, Schur chunks on v_mfma_f64_16x16x4_f64, 6x6-blocked Cholesky, back-substitution, update, chi2); "
-                              "peak = MI355X f64 vector 78.6 TFLOP/s, measured f64 MFMA 48 (profiles/r03_peaks.json)"}
+        solve_roof = ba_solve_roofline(s_rd.cpu().numpy(), ba_w[6], P, solve_ms)
 
     stream_mode = None
     if rank == 0 and world == 1 and args.stream_mode and not args.no_extra_passes and args.workload in ("full", "orb_match_lcd"):
         barrier()
-        pts = []
-        for spec in args.stream_mode.split(","):
-            pp, ll = [int(v) for v in spec.lower().split("x")]
-            cmd = [sys.executable, os.path.abspath(__file__), "--pairs", str(pp), "--lanes", str(ll), "--graph", "1", "--steps", str(max(400, 1600 // pp)), "--warmup", "2",
-                   "--workload", args.workload, "--no-extra-passes", "--no-cpu-baseline", "--parity-frames", str(min(2, pp)), "--frame-latency", "--stream-mode", "",
-                   "--scene-rects", str(args.scene_rects)]
-            r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, GPU_MAX_HW_QUEUES="24"), timeout=600)
-            try:
-                cd = json.loads(r.stdout.strip().splitlines()[-1])
-                pts.append({"pairs_per_step": pp, "lanes": ll, "value": cd["value"], "ms_per_step": cd["ms_per_step"], "frame_latency_ms": cd["frame_latency"],
-                            "host_launch_ms_per_step": cd["host_launch_ms_per_step"], "graph_nodes": cd["graph_nodes"], "parity_ok": (cd["parity_sample"] or {}).get("ok")})
-            except Exception as e:               # a failed point is reported, not hidden
-                pts.append({"pairs_per_step": pp, "lanes": ll, "error": f"{type(e).__name__}: {e}", "rc": r.returncode, "stderr_tail": r.stderr[-300:]})
-        if pts:
-            head = dict(pts[0])
-            stream_mode = dict(head, unit="stereo frames/s", sweep=pts,
-                               note="recorded steps (HIP graph replay) on L lanes, step k on lane k mod L; every lane has its own extractor / DeepLCD handles and a QUERY CONTEXT "
-                                    "of the ONE shared loop database (myslam_lcddb_query_ctx); child processes of this run, GPU_MAX_HW_QUEUES=24.  The GPU runs ~4.4 in-order "
-                                    "chains side by side whatever the queue count (profiles/r05_queue_concurrency.json), so frames/s ~ 4.4 x pairs_per_step / chain latency: lanes "
-                                    "beyond ~16 add nothing, batching frames of several cameras into one step does")
+        stream_mode = stream_mode_sweep(args)
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = world * P * args.steps / dt
-        pmc, pmc_path = pmc_file()
-        peaks, peaks_path = peaks_file()
-        valu_peak = (peaks or {}).get("valu_packed16_tlaneops") or VALU_PEAK_TLANEOPS
-        busy = {k: v for k, v in prof.items() if v[1] > 0}
-        roof = {"bound": "hbm", "kernel": None, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                "peak_measured": (peaks or {}).get("hbm_copy_GBps"), "peaks_source": peaks_path}
-        roof_valu = None
-        if busy:
-            # the dominant kernel of the critical (ORB) chain: the one with the largest event-timed total among the chain's stages
-            chain = [k for k in busy if k in ("resize", "fast", "octree", "blur7", "describe", "hamming_match", "triangulate")]
-            # event-timed durations of overlapped launches say how long a kernel was resident, not how much of the chip it used (the
-            # latency-bound oct-tree runs under FAST for as long as FAST takes): among the chain's stages the dominant kernel is the
-            # one with the largest VALU instruction volume (counter summary) when that is known, else the largest duration
-            def volume(k):
-                _, rec = pmc_lookup(pmc, k)
-                return ((rec or {}).get("valu_wave_insts_per_image", 0.0), busy[k][0])
-            dom = max(chain or busy, key=volume)
-            dom_ms, dom_n = busy[dom]
-            per_launch_ms = dom_ms / dom_n
-            launches_per_step = dom_n / args.steps
-            imgs_per_launch = 2 * P / launches_per_step
-            sym, rec = pmc_lookup(pmc, dom)
-            roof.update({"kernel": sym or SYMBOL.get(dom, dom), "stage": dom, "avg_launch_ms": per_launch_ms, "images_per_launch": imgs_per_launch})
-            alone_ms = alone[dom][0] / alone[dom][1] if dom in alone else None      # the same launch (same images per launch) on an idle chip
-            if dom in ALGO_BYTES:
-                algo = ALGO_BYTES[dom] * imgs_per_launch                        # bytes per launch
-                achieved = algo / (per_launch_ms * 1e-3) / 1e9
-                roof.update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo})
-                if roof["peak_measured"]:
-                    roof["frac_of_measured"] = achieved / roof["peak_measured"]
-                if alone_ms:
-                    roof["alone"] = {"avg_launch_ms": alone_ms, "achieved": algo / (alone_ms * 1e-3) / 1e9,
-                                     "frac": algo / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                     "note": "the same launch with nothing else on the chip (pass 6)"}
-            if rec:
-                # HBM bytes per launch from the counter summary: FETCH_SIZE scaled by the factor that makes k_ingest's FETCH_SIZE equal
-                # the bytes it provably reads (MI355X_MICROARCH.md: gfx950 tallies 128-byte requests at 64 bytes), + WRITE_SIZE
-                roof["traffic"] = (rec["fetch_bytes_per_image_corrected"] + rec["write_bytes_per_image"]) * imgs_per_launch
-                roof["traffic_detail"] = {"source": pmc_path, "fetch_scale": pmc["calibration"]["fetch_scale"],
-                                          "fetch_bytes_per_image_corrected": rec["fetch_bytes_per_image_corrected"],
-                                          "write_bytes_per_image": rec["write_bytes_per_image"]}
-                v = rec.get("valu_wave_insts_per_image")
-                if v:
-                    ach = v * imgs_per_launch * 64 / (per_launch_ms * 1e-3) / 1e12
-                    roof_valu = {"bound": "valu", "kernel": roof["kernel"], "unit": "Tlane-op/s", "peak": valu_peak, "achieved": ach,
-                                 "frac": ach / valu_peak, "frac_alone": (v * imgs_per_launch * 64 / (alone_ms * 1e-3) / 1e12 / valu_peak) if alone_ms else None,
-                                 "peak_spec_16_lanes_per_cycle": VALU_PEAK_TLANEOPS, "peaks_source": peaks_path,
-                                 "valu_wave_insts_per_image": v, "source": pmc_path,
-                                 "note": "peak = measured issue rate of v_pk_max_i16 / v_pk_min_i16 / v_pk_maximum3_f16 / v_pk_minimum3_f16 (4 cycles "
-                                         "per wave64 instruction per SIMD; v_perm_b32, v_dot4, v_alignbyte and every VOP3 integer class measure the same; "
-                                         "only VOP2 add / and / or / lshr / 16-bit min-max and f32 add / mul / fma issue in 2 cycles) — the classes "
-                                         "k_fast_strip's scoring network consists of"}
-            roof["note"] = ("avg_launch_ms = HIP-event duration of one launch on its own stream in the profiled pass (same schedule as the timed "
-                            "region); a launch covers images_per_launch images and shares the chip with the other streams' launches; the kernel "
-                            "is packed-integer VALU bound in practice (roofline_valu, DESIGN.md section 6)")
-        mf = None
-        if "calc_conv2" in busy:
-            c2 = busy["calc_conv2"][0] / busy["calc_conv2"][1]
-            f32eq = 2 * 176160768 * P / (c2 * 1e-3) / 1e12
-            nprod = lcd.conv2_products()          # 3 = f16 x 3 (the default model), 6 = the bf16 x 6 kernel a model outside f16's range falls back to
-            mf = {"bound": "mfma", "kernel": SYMBOL["calc_conv2"] if nprod == 3 else "k_conv2_bf16x6", "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s (bf16 dense)",
-                  "partial_products": nprod,
-                  "achieved": nprod * f32eq, "frac": nprod * f32eq / MFMA_BF16_PEAK_TFLOPS, "peak_measured": (peaks or {}).get("mfma_bf16_tflops"),
-                  "peaks_source": peaks_path, "f32_equivalent_tflops": f32eq, "avg_launch_ms": c2,
-                  "note": "CALC conv2 as an implicit GEMM on the 16-bit matrix cores with f32 accuracy (every f32 operand split exactly into two f16 "
-                          "pieces, 3 partial products per useful f32 multiply-add; f16 and bf16 run at the same dense rate): `achieved` counts the "
-                          "flops the matrix pipe executes, priced against the 16-bit dense peak; f32_equivalent_tflops counts the USEFUL f32 flops "
-                          "(the f32-input MFMA peak would be 157.3)"}
+        roof, roof_valu, mf, busy, peaks = rooflines(prof, alone, args.steps, P, lcd.conv2_products() if use_lcd else 3)
         n_internal = S if args.orb_internal_stream else 0        # every extractor handle runs its Gaussian pyramid on an internal stream
         out = {
             "metric": "stereo frames/sec (ORB+match+LCD+BA-build) @1241x376",

@@ -397,7 +397,11 @@ int myslam_ba_flatten_window(const uint64_t* active_kf_ids, int n_kf, const uint
 /* Levenberg-Marquardt with Schur complement on device — replaces optimizer.optimize(n) of
  * Backend::OptimizeActiveMap (src/backend.cpp:212-214: g2o OptimizationAlgorithmLevenberg + BlockSolver_6_3 +
  * CSparse).  poses/points are updated in place.  Edges must be grouped by landmark
- * (backend.cpp:161-205 builds them that way; myslam_ba_flatten_window does); max_poses <= MYSLAM_BA_MAX_WINDOW_POSES.  d_scratch: nwin x max_edges x 18 doubles. */
+ * (backend.cpp:161-205 builds them that way; myslam_ba_flatten_window does); max_poses <= MYSLAM_BA_MAX_WINDOW_POSES.  d_scratch: nwin x max_edges x 18 doubles.
+ * Windows too large for the all-in-LDS solver (more than ~470 landmarks at 10 key-frames) keep 22 doubles per landmark behind the edge list in
+ * that scratch: the batch entry points return MYSLAM_ERR_CAPACITY when max_edges x 18 < max_edges / 2 + 22 max_pts + 10 — windows of many
+ * short-lived landmarks with one or two observations each; max_edges is only a capacity, raise it.  The host-pointer entry points size
+ * their scratch themselves and have no such limit. */
 int myslam_ba_optimize(double* poses, int nposes, double* points, int npts, const int32_t* edge_pose, const int32_t* edge_pt,
                        const double* obs, int nedges, const uint8_t* fixed_pt, double fx, double fy, double cx, double cy,
                        double huber_delta, int max_iters, double* final_chi2, int* iters);

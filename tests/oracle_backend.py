@@ -178,8 +178,27 @@ class CheckedBackend:
 
     def pgo(self, poses, fixed, e0, e1, meas):
         g, r = self.h.pgo(poses, fixed, e0, e1, meas), self.o.pgo(poses, fixed, e0, e1, meas)
-        assert abs(g[1] - r[1]) <= 1e-3 * abs(r[1]) + 1e-12 and np.abs(g[0] - r[0]).max() < 5e-4
-        self._note("pgo", "pgo_pose_abs", np.abs(g[0] - r[0]).max())
+        dev = float(np.abs(g[0] - r[0]).max())
+        ok = abs(g[1] - r[1]) <= 1e-3 * abs(r[1]) + 1e-12 and dev < 5e-4
+        spread = None
+        if not ok and abs(g[1] - r[1]) <= 1e-6 * abs(r[1]) + 1e-12:
+            # A long chain closed by ONE loop edge (52 key-frames, 52 edges: tests/golden/pgo_flat_valley.npz) leaves the 20 Levenberg iterations of
+            # LoopClosing::PoseGraphOptimization in a flat valley: chi2 agrees to 1e-9 while the poses still move by 1e-3 per further iteration, and
+            # the ORACLE's own result moves by 2e-3 .. 6e-3 when one measurement changes by one ulp.  There the bar is the oracle's own spread
+            # (the rule of the chaotic local-BA window, tests/golden/ba_chaotic_window.npz): chi2 to 1e-6, poses within twice that spread.
+            rng = np.random.default_rng(0)
+            spread = max(float(np.abs(self.o.pgo(poses, fixed, e0, e1, meas * (1 + rng.choice([-1.0, 1.0], size=meas.shape) * 2.2e-16))[0] - r[0]).max())
+                         for _ in range(4))
+            ok = dev <= 2.0 * spread
+            self.dev["pgo_oracle_one_ulp_spread"] = max(self.dev.get("pgo_oracle_one_ulp_spread", 0.0), spread)
+        if not ok:          # keep the failing problem for an offline look (gpurun_out/ travels back from the GPU box)
+            import os
+            d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+            os.makedirs(d, exist_ok=True)
+            np.savez(os.path.join(d, "pgo_mismatch.npz"), poses=poses, fixed=fixed, e0=e0, e1=e1, meas=meas, hip_poses=g[0], hip_chi2=g[1], oracle_poses=r[0], oracle_chi2=r[1])
+        assert ok, ("pose graph: chi2 (HIP, oracle)", float(g[1]), float(r[1]), "largest pose deviation", dev, "oracle one-ulp self-spread", spread,
+                    "key-frames", len(poses), "edges", len(e0))
+        self._note("pgo", "pgo_pose_abs", dev)
         return g
 
     def correct_points(self, old, new, first, pts):

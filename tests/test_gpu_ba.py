@@ -212,6 +212,30 @@ def test_large_window_uses_hbm_scratch(api, oracle, synth):
     assert np.array_equal(gout[far], rout[far]) and abs(gn - rn) <= int((~far).sum())
 
 
+def test_window_of_many_short_lived_landmarks(api, oracle, synth):
+    """A window as a fast drive produces it (found by the lock-step run on tests/kitti_layout.py's "fast" sequence): 7 key-frames, ~1000
+    landmarks with one observation each (a fifth of them two): 1.2 edges per landmark.  Too many landmarks for the all-in-LDS solver, and the
+    HBM form's 22 doubles per landmark no longer fit into 18 doubles per EDGE: the host-pointer entry points size their scratch by need."""
+    rng = np.random.default_rng(17)
+    poses, pts, ep, el, obs, fixed, K = synth.ba_problem(seed=0xFA57, n_kf=7, n_mp=1000, outlier_frac=0.02)
+    keep = np.zeros(len(ep), bool)
+    for l in range(1000):
+        idx = np.where(el == l)[0]
+        if len(idx):
+            keep[idx[rng.permutation(len(idx))[:(2 if rng.uniform() < 0.2 else 1)]]] = True
+    keep = np.where(keep)[0]                                            # still grouped by landmark (ascending edge index)
+    ep, el, obs = ep[keep], el[keep], obs[keep]
+    assert len(ep) * 18 < len(ep) // 2 + 22 * 1000 + 10
+    g = api.ba_optimize_active_map(poses, pts, ep, el, obs, fixed, K)
+    r = oracle.ba_optimize_active_map(poses, pts, ep, el, obs, fixed, K)
+    assert g[4] == r[4] and np.allclose(g[0], r[0], rtol=1e-6, atol=1e-7) and np.allclose(g[1], r[1], rtol=1e-6, atol=1e-6)
+    far = np.abs(r[2] - 5.991) > 1e-6
+    assert np.array_equal(g[3][far], r[3][far])
+    gp, gx, gchi, git = api.ba_optimize(poses, pts, ep, el, obs, fixed, K, iters=10)
+    rp, rx, rchi, rit = oracle.ba_optimize(poses, pts, ep, el, obs, fixed, K, iters=10)
+    assert git == rit and gchi == pytest.approx(rchi, rel=1e-7)
+
+
 def test_landmark_state_option_is_bit_identical(api, oracle, synth):
     """MYSLAM_BA_OPT_LANDMARKS_IN_HBM: the same arithmetic in the same order with the per-landmark arrays in the window's HBM scratch
     (81 KB of LDS instead of 133: the form the cadence passes of bench.py use beside the extractor) — bit-identical to the LDS form, and
