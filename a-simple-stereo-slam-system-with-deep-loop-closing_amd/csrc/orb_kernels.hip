@@ -876,6 +876,11 @@ __device__ __forceinline__ int wave_incl_scan_dpp(int v) {
     return v;
 }
 
+// number of set bits of a 64-bit ballot below this lane, added to acc: two v_mbcnt (the mask-and-popcount form costs five)
+__device__ __forceinline__ int rank_below(unsigned long long ballot, int acc) {
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, (uint32_t)acc));
+}
+
 // Path selection of the strip kernel (per level): `prev` = what the previous launch of this extractor handle measured,
 // `cur` = what this launch accumulates (zeroed by the host): [level][4] = {pixel pairs that survived the pre-test (two-phase path) or
 // 4-pixel rows holding a corner (dense path), pixel pairs looked at, path used, -}.  force: -1 = choose, 0 = two-phase, 1 = dense.
@@ -948,6 +953,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
     const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const int b = logical / P.nstrips, sidx = logical - b * P.nstrips;
     if (b >= batch) return;
+    // what the next launch of this handle decides on is reported by a SAMPLE of the strips (a ratio of sums needs no more, and a few thousand
+    // same-address atomics per launch cost nothing where 300 k of them serialise into milliseconds)
+    const bool sampled = logical % max(1, nwg >> 12) == 0;
     int level = 0;
     for (int l = 1; l < P.nlevels; l++) if (sidx >= P.lv[l].stripBase) level = l;
     const LevelGeom& g = P.lv[level];
@@ -1285,9 +1293,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
                     const uint32_t* rp = reinterpret_cast<const uint32_t*>(&s_score[c][(4 * cy4 + j) * SP + 4 * gi]);
                     m[j][0] = rp[0]; m[j][1] = rp[1]; m[j][2] = rp[2];
                 }
-                const bool h0 = m[1][1] != 0, h1 = m[2][1] != 0, h2 = m[3][1] != 0, h3 = m[4][1] != 0;    // rows past the cell hold zeros
-                nquad += __popcll(__ballot(h0)) + __popcll(__ballot(h1)) + __popcll(__ballot(h2)) + __popcll(__ballot(h3));
-                if (h0 || h1 || h2 || h3) {                                // else none of the 16 pixels is a corner
+                // the path statistic (4-pixel rows that hold a corner) is only reported by a sample of the strips (below): only those count it
+                if (sampled)                                               // block-uniform
+                    nquad += __popcll(__ballot(m[1][1] != 0)) + __popcll(__ballot(m[2][1] != 0)) + __popcll(__ballot(m[3][1] != 0)) + __popcll(__ballot(m[4][1] != 0));
+                if ((m[1][1] | m[2][1] | m[3][1] | m[4][1]) != 0) {        // else none of the 16 pixels is a corner (rows past the cell hold zeros)
                     NmsRow R[6];
 #pragma unroll
                     for (int j = 0; j < 6; j++) R[j] = nms_row(m[j][0], m[j][1], m[j][2]);
@@ -1301,15 +1310,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
                 int base = 0;
                 if (lane == 0) base = atomicAdd(&s_nlist, total);
                 base = __builtin_amdgcn_readfirstlane(base);
-                const unsigned long long below = (1ull << lane) - 1ull;
                 const int code = (c << 10) | (cy4 << 6) | gi;              // row = 4 cy4 + j
                 // lane-major order (a lane's rows stay together, lanes = blocks adjacent in x): the oct-tree kernel that consumes the
-                // candidate list is measurably faster on spatially coherent input (table lookups, scatter coalescing)
-                int pos = base + (int)__popcll(b0 & below) + (int)__popcll(b1 & below) + (int)__popcll(b2 & below) + (int)__popcll(b3 & below);
+                // candidate list is measurably faster on spatially coherent input (table lookups, scatter coalescing).
+                // No capacity test: a record is a 4-pixel row with a strict 3x3 maximum, strict maxima are never 8-neighbours, so a cell of
+                // a x b pixels holds at most ceil(a/2) ceil(b/2) of them and a strip at most NLIST (static_assert above).
+                int pos = rank_below(b0, rank_below(b1, rank_below(b2, rank_below(b3, base))));
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     if (zm[j] != 0) {
-                        if (pos < NLIST) { s_recz[pos] = zm[j]; s_pairs[pos] = (uint16_t)(code | (j << 4)); }
+                        s_recz[pos] = zm[j]; s_pairs[pos] = (uint16_t)(code | (j << 4));
                         pos++;
                     }
                 if (max((int)zacc.x, (int)zacc.y) >= zini) s_ini[c] = 1;
@@ -1327,10 +1337,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
 #endif
     }
     __syncthreads();
-    // what the next launch of this handle decides on: a SAMPLE of the strips reports (a ratio of sums needs no more, and a few
-    // thousand same-address atomics per launch cost nothing where 300 k of them serialise into milliseconds)
-    const int sample_stride = max(1, nwg >> 12);
-    if (threadIdx.x == 0 && logical % sample_stride == 0) {
+    if (threadIdx.x == 0 && sampled) {                                 // the path statistics of this launch (see `sampled` above)
         atomicAdd(&ctl.cur[level * 4], (uint32_t)(dense ? s_ncorner : min(s_npair, NPAIR)));
         atomicAdd(&ctl.cur[level * 4 + 1], (uint32_t)pairs_total);
         ctl.cur[level * 4 + 2] = dense ? 1u : 0u;
@@ -1355,6 +1362,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
             }
             uint32_t kp[2];
             unsigned long long bm[2];
+            bool passk[2];
 #pragma unroll
             for (int k = 0; k < 2; k++) {
                 const uint32_t h = k ? z >> 16 : z & 0xffffu;
@@ -1364,20 +1372,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
                 bool pass = h != 0 && !(ini && sc < P.iniTh);
                 if (pass && mimg) pass = mimg[(size_t)py * g.pitch + px] != 0;         // (no +16: reference quirk)
                 kp[k] = ((uint32_t)py << 20) | ((uint32_t)px << 8) | (uint32_t)sc;
-                bm[k] = __ballot(pass);
+                bm[k] = __ballot(pass); passk[k] = pass;
             }
             const int total = (int)(__popcll(bm[0]) + __popcll(bm[1]));
             if (total == 0) continue;                                      // wave-uniform
             int gbase = 0;
             if (lane == 0) gbase = atomicAdd(&candCount[b * MAXL + level], total);
             gbase = __builtin_amdgcn_readfirstlane(gbase);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            int dst = gbase + (int)__popcll(bm[0] & below) + (int)__popcll(bm[1] & below);     // lane-major, as above
-            if ((bm[0] >> lane) & 1ull) {
+            int dst = rank_below(bm[0], rank_below(bm[1], gbase));                             // lane-major, as above
+            if (passk[0]) {
                 if (dst < g.keyCap) out[dst] = kp[0];
                 dst++;
             }
-            if ((bm[1] >> lane) & 1ull) {
+            if (passk[1]) {
                 if (dst < g.keyCap) out[dst] = kp[1];
             }
         }

@@ -439,6 +439,102 @@ def sequence_poses(n=200, kind="figure", reach=25.0, laps=1):
     return np.stack([x, np.zeros(n), zc], 1), yaw
 
 
+# ---- a corridor driven FORWARD (round 5): the motion of a car on a road — features stream outwards from the vanishing point, grow, change
+# pyramid level and leave through the image border, depth runs from 3 m to infinity.  Two textured side walls (x = -a, x = +a, up to `wall_h`
+# above the camera), a textured ground plane (y = +cam_h, y down) and a featureless sky; every surface is sampled through a small mip chain
+# chosen by its texel rate per pixel, so that distant parts do not alias into frame-to-frame noise.
+def _mips(t, n=5):
+    out = [t]
+    for _ in range(n - 1):
+        a = out[-1]
+        h, w = (a.shape[0] // 2) * 2, (a.shape[1] // 2) * 2
+        out.append(0.25 * (a[0:h:2, 0:w:2] + a[1:h:2, 0:w:2] + a[0:h:2, 1:w:2] + a[1:h:2, 1:w:2]))
+    return out
+
+
+def _texture(rng, th, tw, nrect):
+    t = 128.0 + 50.0 * (_value_noise(rng, th, tw, 64) + 0.5 * _value_noise(rng, th, tw, 16) + 0.25 * _value_noise(rng, th, tw, 4)) / 1.75
+    rx = rng.integers(0, tw, nrect); ry = rng.integers(0, th, nrect); sw = rng.integers(4, 36, nrect); sh = rng.integers(4, 36, nrect)
+    val = rng.uniform(-80.0, 80.0, nrect)
+    diff = np.zeros((th + 1, tw + 1))
+    np.add.at(diff, (ry, rx), val); np.add.at(diff, (ry, np.minimum(rx + sw, tw)), -val)
+    np.add.at(diff, (np.minimum(ry + sh, th), rx), -val); np.add.at(diff, (np.minimum(ry + sh, th), np.minimum(rx + sw, tw)), val)
+    return t + np.cumsum(np.cumsum(diff, axis=0), axis=1)[:th, :tw]
+
+
+def corridor_scene(seed=0xC0881D0, half_width=7.0, cam_h=1.65, wall_h=9.0, texels_per_m=32.0, tex_len=8192):
+    rng = _rng(seed)
+    wall_rows = int((wall_h + cam_h) * texels_per_m)
+    ground_rows = int(2 * half_width * texels_per_m)
+    walls = [_mips(_texture(rng, wall_rows, tex_len, 7000)) for _ in range(2)]
+    ground = _mips(128.0 + 0.6 * (_texture(rng, ground_rows, tex_len, 5000) - 128.0))       # a road: lower contrast than the walls
+    return {"a": half_width, "cam_h": cam_h, "wall_h": wall_h, "s": texels_per_m, "walls": walls, "ground": ground, "tex_len": tex_len}
+
+
+def _sample_mips(mips, tu, tv, rate):
+    """trilinear sample: (tu, tv) texel coordinates at level 0 (tu wraps), rate = texels per pixel"""
+    lvl = np.clip(np.log2(np.maximum(rate, 1.0)), 0.0, len(mips) - 1.001)
+    l0 = np.floor(lvl).astype(int); fl = lvl - l0
+    out = np.zeros(tu.shape)
+    for k in range(len(mips)):
+        for which, wgt in ((0, 1.0 - fl), (1, fl)):
+            m = (l0 + which) == k
+            if not m.any():
+                continue
+            t = mips[k]; th, tw = t.shape
+            u = np.mod(tu[m] / (1 << k) - 0.5 * (1 - 1.0 / (1 << k)), tw - 1); v = np.clip(tv[m] / (1 << k) - 0.5 * (1 - 1.0 / (1 << k)), 0, th - 1.001)
+            u0 = np.floor(u).astype(int); v0 = np.floor(v).astype(int); fu = u - u0; fv = v - v0
+            val = (t[v0, u0] * (1 - fu) + t[v0, u0 + 1] * fu) * (1 - fv) + (t[v0 + 1, u0] * (1 - fu) + t[v0 + 1, u0 + 1] * fu) * fv
+            out[m] += wgt[m] * val
+    return out
+
+
+def render_corridor_camera(scene, c, yaw, h=IMG_H, w=IMG_W, K=KITTI00, noise_seed=None):
+    a, ch, wh, s = scene["a"], scene["cam_h"], scene["wall_h"], scene["s"]
+    xn = (np.arange(w) - K["cx"]) / K["fx"]; yn = (np.arange(h) - K["cy"]) / K["fy"]
+    dx = (np.cos(yaw) * xn + np.sin(yaw))[None, :].repeat(h, 0); dz = (-np.sin(yaw) * xn + np.cos(yaw))[None, :].repeat(h, 0)
+    dy = yn[:, None].repeat(w, 1)
+    big = 1e9
+    with np.errstate(divide="ignore", invalid="ignore"):
+        lam_l = np.where(dx < -1e-9, (-a - c[0]) / dx, big); lam_r = np.where(dx > 1e-9, (a - c[0]) / dx, big)
+        lam_g = np.where(dy > 1e-9, (ch - c[1]) / dy, big)
+    lam_w = np.minimum(lam_l, lam_r)
+    yw = c[1] + lam_w * dy                                         # height on the wall (y down): sky above -wall_h
+    wall_ok = (lam_w < big) & (yw > -wh) & (yw <= ch + 1e-6) & (lam_w * dz > 0.3)
+    use_wall = wall_ok & (lam_w <= lam_g)
+    use_ground = ~use_wall & (lam_g < big) & (np.abs(c[0] + lam_g * dx) <= a + 1e-6) & (lam_g * dz > 0.3)
+    img = np.full((h, w), 150.0) - 25.0 * np.clip((yn[:, None] + 0.6), 0, 1)           # sky: a smooth vertical gradient, no corners
+    px = 1.0 / K["fx"]
+    for side, sel in ((0, use_wall & (lam_l <= lam_r)), (1, use_wall & (lam_r < lam_l))):
+        if sel.any():
+            lam = lam_w[sel]
+            z = c[2] + lam * dz[sel]; y = c[1] + lam * dy[sel]
+            rate = lam * px * s / np.maximum(np.abs(dx[sel]) / np.sqrt(dx[sel] ** 2 + dz[sel] ** 2), 0.05)       # grazing angle stretches the footprint along z
+            img[sel] = _sample_mips(scene["walls"][side], (z + 1000.0) * s, (y + wh) * s, rate)
+    if use_ground.any():
+        lam = lam_g[use_ground]
+        z = c[2] + lam * dz[use_ground]; x = c[0] + lam * dx[use_ground]
+        rate = lam * px * s / np.maximum(dy[use_ground] / np.sqrt(dy[use_ground] ** 2 + dz[use_ground] ** 2), 0.05)
+        img[use_ground] = _sample_mips(scene["ground"], (z + 1000.0) * s, (x + a) * s, rate)
+    if noise_seed is not None:
+        img = img + _rng(noise_seed).uniform(-1.5, 1.5, size=img.shape)
+    return np.ascontiguousarray(np.clip(np.rint(img), 0, 255).astype(np.uint8))
+
+
+def render_corridor_stereo(scene, c, yaw, t=0, **kw):
+    K = kw.get("K", KITTI00)
+    bl = K["bf"] / K["fx"]
+    cr = np.asarray(c, float) + bl * np.array([np.cos(yaw), 0.0, -np.sin(yaw)])
+    return render_corridor_camera(scene, c, yaw, noise_seed=3000 + 2 * t, **kw), render_corridor_camera(scene, cr, yaw, noise_seed=3001 + 2 * t, **kw)
+
+
+def corridor_poses(n=200, speed=0.9):
+    """a drive along +z at `speed` metres per frame (eased start), a slow lateral sway of +-1.2 m and +-2.5 degrees of yaw"""
+    z = speed * np.concatenate([[0.0], np.cumsum(np.minimum(1.0, (np.arange(n - 1) + 0.5) / 10.0))])
+    tt = np.arange(n) / 60.0
+    return np.stack([1.2 * np.sin(2 * np.pi * tt / 3.0), np.zeros(n), z], 1), np.deg2rad(2.5) * np.sin(2 * np.pi * tt / 2.0)
+
+
 def pose7_from_twc(c, yaw):
     """(qx qy qz qw tx ty tz) of Tcw for a camera at position c with yaw (rotation about the camera's y axis)"""
     Rwc = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]])

@@ -334,7 +334,8 @@ def main():
         torch.cuda.synchronize()
 
     host_ms = [0.0]
-    rank_dts = []           # multi-rank runs: every rank's wall time of the last timed() call
+    rank_dts = []           # multi-rank runs: every rank's wall time of the last timed() call ...
+    rank_own = []           # ... and the time at which its own device had finished, before the closing barrier
 
     def timed(n, fn=None):
         """n steps bracketed by barrier + synchronize on both sides; the slowest rank's wall time.  host_ms[0] = CPU time the launches of
@@ -349,15 +350,20 @@ def main():
             fn()
             if i + 1 == n_host:
                 host_ms[0] = (time.perf_counter() - t0) / n_host * 1e3
+        t_own = 0.0
+        if world > 1:                       # when THIS rank's device finished its own work, before it waits for the others
+            torch.cuda.synchronize()
+            t_own = time.perf_counter() - t0
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            # every rank's own wall time (the closing barrier makes them nearly equal by construction; the device-side time of a rank's
-            # own chains is in rank_gpu_ms below) and the slowest one, which is the job's time
-            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if via_cpu else dev)
-            allt = torch.empty(world, dtype=torch.float64, device=t.device)
+            # every rank's wall time up to the closing barrier (nearly equal by construction), the time at which its own device was done, and
+            # the slowest one, which is the job's time
+            t = torch.tensor([dt, t_own], dtype=torch.float64, device="cpu" if via_cpu else dev)
+            allt = torch.empty(2 * world, dtype=torch.float64, device=t.device)
             dist.all_gather_into_tensor(allt, t)
-            rank_dts[:] = [float(v) for v in allt.cpu()]
+            v = [float(x) for x in allt.cpu()]
+            rank_dts[:] = v[0::2]; rank_own[:] = v[1::2]
             dt = max(rank_dts)
         return dt
 
@@ -435,6 +441,7 @@ def main():
     dt = timed(args.steps)
     host_launch_ms = host_ms[0]
     per_rank_ms = [v / args.steps * 1e3 for v in rank_dts] if world > 1 else None
+    per_rank_own_ms = [v / args.steps * 1e3 for v in rank_own] if world > 1 else None
     # ---- multi-rank runs: the loop-database exchange timed stage by stage on an otherwise idle chip (bench/passes_multirank.py) ----
     collective = None
     if world > 1 and use_lcd:
@@ -776,7 +783,7 @@ def main():
                        "parallelism": f"frame-sharded x{world}" + (", id-range sharded DB + all-gather of 16-byte candidate records" if world > 1 else "")},
             "rccl_ranks": rccl_ranks if not via_cpu else None, "collective_backend": (args.backend if world > 1 else None),
             "collective_ranks": rccl_ranks,
-            "per_rank_ms_per_step": per_rank_ms,
+            "per_rank_ms_per_step": per_rank_ms, "per_rank_own_device_done_ms_per_step": per_rank_own_ms,
             "collective_ms_per_step": None if collective is None else collective["collective_ms_per_step"],
             "shard_scan_ms_per_step": None if collective is None else collective["shard_scan_ms_per_step"],
             "db_exchange": collective,

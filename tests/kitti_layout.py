@@ -76,13 +76,21 @@ def render(synth, n=N_FRAMES):
 #   "two_laps": 420 frames, the same road twice               -> ~62 key-frames: the 50-key-frame gate of DetectLoop opens on lap 2, the loop
 #                                                                closes at full resolution (matching, PnP, pose refinement, fusion, pose graph)
 #   "one_way":  380 frames in one direction (no place twice)  -> ~67 key-frames: DetectLoop runs on every key-frame behind the gate, no loop
-VARIANTS = {"fast": dict(n=200, kind="legs", reach=2.5, laps=1, tex_w=16384, texels_per_m=40.0),
+#   "corridor": 200 frames FORWARD through a corridor at 0.9 m per frame (the motion of a car: features stream out of the vanishing point, grow,
+#               change pyramid level, leave through the border; depth 3 m .. infinity) -> 24 key-frames, as many as KITTI-00 itself
+VARIANTS = {"corridor": dict(n=200, kind="corridor", reach=0.9, laps=1, tex_w=8192, texels_per_m=32.0),
+            "fast": dict(n=200, kind="legs", reach=2.5, laps=1, tex_w=16384, texels_per_m=40.0),
             "two_laps": dict(n=420, kind="legs", reach=2.5, laps=2, tex_w=16384, texels_per_m=40.0),
             "one_way": dict(n=380, kind="oneway", reach=2.5, laps=1, tex_w=32768, texels_per_m=30.0)}
 
 
 def render_variant(synth, name):
     v = VARIANTS[name]
+    if v["kind"] == "corridor":
+        scene = synth.corridor_scene(texels_per_m=v["texels_per_m"], tex_len=v["tex_w"])
+        C, yaw = synth.corridor_poses(v["n"], v["reach"])
+        K = camera(synth)
+        return [synth.render_corridor_stereo(scene, C[t], yaw[t], t, h=H, w=W, K=K) for t in range(v["n"])], C, yaw
     C, yaw = synth.sequence_poses(v["n"], kind=v["kind"], reach=v["reach"], laps=v["laps"])
     scene = synth.sequence_scene(x_max=float(C[:, 0].max()) + 35.0, tex_w=v["tex_w"], texels_per_m=v["texels_per_m"])
     K = camera(synth)

@@ -93,6 +93,8 @@ def test_bench_two_ranks_on_one_gpu():
     assert "x2" in d["config"]["parallelism"] and d["collective_ranks"] == 2
     # the self-explaining part of a multi-rank line: every rank's own time, and the loop-database exchange stage by stage
     assert len(d["per_rank_ms_per_step"]) == 2 and max(d["per_rank_ms_per_step"]) == pytest.approx(d["ms_per_step"], rel=1e-9)
+    own = d["per_rank_own_device_done_ms_per_step"]
+    assert len(own) == 2 and all(0 < o <= w + 1e-9 for o, w in zip(own, d["per_rank_ms_per_step"]))
     x = d["db_exchange"]
     assert d["collective_ms_per_step"] == x["collective_ms_per_step"] > 0 and d["shard_scan_ms_per_step"] == x["shard_scan_ms_per_step"] > 0
     assert len(x["allgather_queries_ms"]) == len(x["allgather_candidates_ms"]) == len(x["shard_scan_ms"]) == 2

@@ -31,3 +31,26 @@ def test_fast_variant_key_frames_by_the_references_rule(pkg, synth, oracle):
     print(f"fast variant, oracle chain: {len(c.all_kfs)} key-frames, min inliers {min(ninl)}, ATE {rmse:.3f} m anchored at frame 0, {rmse_al:.3f} m after rigid alignment "
           f"(rotation {rot:.2f} deg) over a {path:.0f} m path")
     assert rmse < 0.6 and rmse_al <= rmse + 1e-9
+
+
+CORRIDOR_KF_FRAMES = [0, 17, 26, 34, 42, 51, 60, 69, 76, 84, 92, 100, 108, 116, 125, 133, 141, 149, 157, 165, 174, 183, 192, 199]
+
+
+def test_corridor_variant_forward_motion(pkg, synth, oracle):
+    """The forward drive through a corridor (tests/kitti_layout.py "corridor": 0.9 m per frame along the optical axis, features stream out of the
+    vanishing point, grow and change pyramid level) through the oracle chain: 24 key-frames in 200 frames by the reference's rule (its own
+    KITTI-00 run: 27), never LOST, drift below 1 % of the path."""
+    chain = pkg.chain
+    frames, C, yaw = kitti_layout.render_variant(synth, "corridor")
+    cfg = kitti_layout.parse_yaml(kitti_layout.KITTI00_02_YAML)
+    c = chain.Chain(OracleBackend(oracle, synth.calc_weights_handcrafted(), cfg, chain), pkg.api, chain.camera_from_config(cfg), frames, cfg=cfg,
+                    timestamps=[0.1 * t for t in range(len(frames))]).run()
+    ninl = [int(x[2][0]) for t, x in c.log if t == "pose_only"]
+    assert [i + 1 for i, v in enumerate(ninl) if 10 < v <= 50] == c.kf_frames[1:] and min(ninl) > 10
+    assert c.kf_frames == CORRIDOR_KF_FRAMES, c.kf_frames
+    rmse, _ = kitti_layout.ate(chain, synth, c.poses, C, yaw)
+    rmse_al, rot = kitti_layout.ate_aligned(chain, synth, c.poses, C, yaw)
+    path = float(np.sum(np.linalg.norm(np.diff(C, axis=0), axis=1)))
+    print(f"corridor variant, oracle chain: {len(c.all_kfs)} key-frames, min inliers {min(ninl)}, ATE {rmse:.3f} m anchored at frame 0, {rmse_al:.3f} m after rigid "
+          f"alignment (rotation {rot:.2f} deg) over a {path:.0f} m path")
+    assert rmse < 0.01 * path and rmse_al < rmse
