@@ -162,14 +162,22 @@ __global__ __launch_bounds__(256) void k_resize_strip(ResizeArgs a, int nstrips,
         }
         // horizontal pass: raw[rr][k] <- 16 x the row-cache value (<= 32640) of source row rfirst + rr at this lane's 4 columns
         // (the low four bits are cleared instead of shifted out: the vertical step multiplies 24-bit operands and keeps bits 32..)
+        // (a band of 8 destination rows at scale 1.2 spans 10 or 11 source rows, RS_MAXR = 12 is the bound for 1.25: the rows a band does not
+        // have are skipped by a scalar branch — the vertical pass below never reads them — instead of being interpolated from zeros)
         uint32_t raw[RS_MAXR][4];
 #pragma unroll
-        for (int rr = 0; rr < RS_MAXR; rr++)
+        for (int rr = 0; rr < RS_MAXR; rr++) {
+            if (rr >= RS_R + 1 && rr >= nrows) {                          // wave-uniform; rows 0 .. RS_R always exist for scale >= 1
+#pragma unroll
+                for (int k = 0; k < 4; k++) raw[rr][k] = 0u;
+                continue;
+            }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t pp = __builtin_amdgcn_perm(raw8[rr].y, raw8[rr].x, selk[k]);       // (p0, p1) as two u16
                 raw[rr][k] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pp), __builtin_bit_cast(u16x2, aw[k]), 0u, false) & ~15u;
             }
+        }
         // vertical pass: walk the source rows statically (the row cache stays in registers, no run-time register indexing) and emit the
         // destination rows whose upper source row is the current one — at most one per source row for scale >= 1; the row coordinates
         // are wave-uniform scalars.  (b * t) >> 16 with b <= 2048 and t <= 32640 is the high word of (b << 12) * (16 t): both factors
