@@ -36,6 +36,16 @@ def test_lock_step_on_fast_sequences(api, oracle, synth, pkg, name):
     path = float(np.sum(np.linalg.norm(np.diff(C, axis=0), axis=1)))
     if name == "corridor":
         assert 20 <= counts["ba"] <= 30 and "detect_loop" not in counts and rmse_al < 1.5        # KITTI-00's first 200 frames: 27 key-frames
+        # against the committed fixture (the ORACLE chain's trajectory, tests/golden/make_kitti_layout_trajectory.py corridor): two free runs whose
+        # key-frames fall a frame apart after the third — every key-frame's camera centre against the fixture's path interpolated at its time
+        import os
+        gold = np.array([[float(x) for x in l.split()] for l in open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kitti_layout_corridor_trajectory.txt"))])
+        dev_fix = 0.0
+        for k in a.all_kfs.values():
+            c_k = chain.T_inv(chain.T_of(k.pose))[:3, 3]
+            g = np.array([np.interp(k.ts, gold[:, 1], gold[:, 2 + i]) for i in range(3)])
+            dev_fix = max(dev_fix, float(np.abs(c_k - g).max()))
+        assert dev_fix < 0.5, dev_fix
     elif name == "fast":
         assert 25 <= counts["ba"] <= 36 and "detect_loop" not in counts
     elif name == "two_laps":
@@ -55,3 +65,37 @@ def test_lock_step_on_fast_sequences(api, oracle, synth, pkg, name):
           f"lock-step: {sum(chk.calls.values())} operator calls checked on identical inputs {dict(chk.calls)}, largest deviations "
           f"{({k: float(f'{v:.2e}') for k, v in chk.dev.items()})}; ATE {rmse:.3f} m anchored at frame 0, {rmse_al:.3f} m after rigid alignment (rotation {rot:.2f} deg) "
           f"over a {path:.0f} m path; lock-step totals so far {tot}")
+
+
+def test_compiled_runner_on_the_corridor(api, synth, pkg, tmp_path):
+    """bin/run_kitti_stereo (the compiled host: app/run_kitti_stereo.cpp over host/myslam_system.hpp) on the corridor drive written as PNG files in
+    KITTI layout: 23 key-frames instead of the 7 of tests/test_gpu_runner.py's sequence, so local BA, DeepLCD and the map's bookkeeping run three
+    times as often through the C++ host — the same key-frames, the same pose of every frame bit for bit and the same trajectory.txt as chain.py."""
+    import os
+    import subprocess
+
+    import png_files
+    chain = pkg.chain
+    exe = pkg._build.build_app()
+    frames, C, yaw = kitti_layout.render_variant(synth, "corridor")
+    seq = tmp_path / "sequences" / "00"
+    ts = kitti_layout.write(str(seq), frames, png_files)
+    cfg_path = tmp_path / "KITTI00-02.yaml"; cfg_path.write_text(kitti_layout.KITTI00_02_YAML)
+    w = np.ascontiguousarray(synth.calc_weights_handcrafted(), np.float32).ravel()
+    wfile = tmp_path / "handcrafted.calcw"
+    with open(wfile, "wb") as f:
+        f.write(b"CALCW1\0\0"); f.write(np.uint64(w.size).tobytes()); f.write(w.tobytes())
+    out = tmp_path / "cpp"
+    r = subprocess.run([exe, str(cfg_path), str(seq), "--frames", str(len(frames)), "--out", str(out), "--calc-weights", str(wfile), "--frame-poses"],
+                       capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "system stop." in r.stdout and "average fps" in r.stdout          # the reference's closing lines (app/run_kitti_stereo.cpp:101-105)
+    cfg = kitti_layout.parse_yaml(kitti_layout.KITTI00_02_YAML)
+    a = chain.Chain(chain.HipBackend(api, w, cfg), pkg.api, chain.camera_from_config(cfg), frames, cfg=cfg, timestamps=ts, log=False).run()
+    a.save(str(tmp_path / "py"))
+    assert [int(x) for x in open(out / "key_frame_frames.txt").read().split()] == a.kf_frames and 20 <= len(a.kf_frames) <= 30
+    poses = np.array([[float(x) for x in l.split()] for l in open(out / "frame_poses_cw.txt").read().strip().split("\n")])
+    assert np.array_equal(poses, np.stack(a.poses)), float(np.abs(poses - np.stack(a.poses)).max())
+    assert open(out / "trajectory.txt").read() == open(tmp_path / "py" / "trajectory.txt").read()
+    assert open(out / "loopEdges.txt").read() == ""
+    print(f"compiled runner, corridor: {r.stdout.strip().splitlines()[-1]}; key-frames at frames {a.kf_frames}; every frame pose and trajectory.txt bit-identical to chain.py's")

@@ -36,7 +36,7 @@ def test_fast_variant_key_frames_by_the_references_rule(pkg, synth, oracle):
 CORRIDOR_KF_FRAMES = [0, 17, 26, 34, 42, 51, 60, 69, 76, 84, 92, 100, 108, 116, 125, 133, 141, 149, 157, 165, 174, 183, 192, 199]
 
 
-def test_corridor_variant_forward_motion(pkg, synth, oracle):
+def test_corridor_variant_forward_motion(pkg, synth, oracle, tmp_path):
     """The forward drive through a corridor (tests/kitti_layout.py "corridor": 0.9 m per frame along the optical axis, features stream out of the
     vanishing point, grow and change pyramid level) through the oracle chain: 24 key-frames in 200 frames by the reference's rule (its own
     KITTI-00 run: 27), never LOST, drift below 1 % of the path."""
@@ -54,3 +54,8 @@ def test_corridor_variant_forward_motion(pkg, synth, oracle):
     print(f"corridor variant, oracle chain: {len(c.all_kfs)} key-frames, min inliers {min(ninl)}, ATE {rmse:.3f} m anchored at frame 0, {rmse_al:.3f} m after rigid "
           f"alignment (rotation {rot:.2f} deg) over a {path:.0f} m path")
     assert rmse < 0.01 * path and rmse_al < rmse
+    # the committed fixture is what this chain writes (tests/golden/make_kitti_layout_trajectory.py corridor): same text on a CPU
+    import os
+    c.save(str(tmp_path))
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kitti_layout_corridor_trajectory.txt")
+    assert open(tmp_path / "trajectory.txt").read() == open(gold).read()
