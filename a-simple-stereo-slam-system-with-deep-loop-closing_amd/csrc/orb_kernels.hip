@@ -949,7 +949,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
     // CUs where FAST blocks retire; a block that squeezes in beside six FAST blocks only slows the launch the whole step waits for
     // (block size 27.2 / 26.0 / 25.0 / 24.4 / 23.7 KB: 75.0 / 74.3 / 74.5 / 73.9 / 74.3 k frames/s, two runs each on one box).
     constexpr int LDS_EST = TROWS * TP + 16 + G * (SROWS * SP + 16) + 2 * NPAIR + 64;
-    constexpr int LDS_PAD = (CW <= 32 && LDS_EST < 163840 / 7) ? 163840 / 6 - 128 - LDS_EST : 4;
+#ifndef MYSLAM_FAST_LDS_BLOCK                                  // A/B builds (tools/build_variants.sh): another block footprint, e.g. 24300 = just over 160 KB / 7
+#define MYSLAM_FAST_LDS_BLOCK (163840 / 6 - 128)
+#endif
+    constexpr int LDS_PAD = (CW <= 32 && LDS_EST < 163840 / 7) ? MYSLAM_FAST_LDS_BLOCK - LDS_EST : 4;
     static_assert(CW > 32 || (6 * (LDS_EST + LDS_PAD) <= 163840 && 7 * (LDS_EST + LDS_PAD) > 163840), "exactly six blocks per CU");
     __shared__ volatile uint8_t s_padx[LDS_PAD]; s_padx[threadIdx.x & 1] = 0;
 
