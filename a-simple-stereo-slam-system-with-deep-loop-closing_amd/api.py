@@ -676,6 +676,22 @@ class LKTracker:
                                      _p(pp), _p(npts), n, _p(st), _p(err)), "myslam_lk_track")
         return npts, st[:n].astype(bool), err[:n]
 
+    def track_cached(self, prev, prev_token, nxt, next_token, prev_pts, next_pts):
+        """track() with the handle's two-image cache: a non-zero token names an image whose bytes never change (myslam_lk_track_cached)"""
+        prev = np.ascontiguousarray(prev, np.uint8); nxt = np.ascontiguousarray(nxt, np.uint8)
+        pp = np.ascontiguousarray(prev_pts, np.float32).reshape(-1, 2)
+        npts = np.ascontiguousarray(next_pts, np.float32).reshape(-1, 2).copy()
+        n = len(pp); st = np.zeros(max(n, 1), np.uint8); err = np.zeros(max(n, 1), np.float32)
+        _check(lib().myslam_lk_track_cached(self._h, _p(prev), C.c_uint64(prev_token), _p(nxt), C.c_uint64(next_token), prev.shape[0], prev.shape[1],
+                                            prev.strides[0], nxt.strides[0], _p(pp), _p(npts), n, _p(st), _p(err)), "myslam_lk_track_cached")
+        return npts, st[:n].astype(bool), err[:n]
+
+    def prefetch(self, img, token):
+        """asynchronous upload + pyramid of an image the next track_cached() call will name by `token`; the array must stay alive until then"""
+        img = np.ascontiguousarray(img, np.uint8)
+        self._keep = img
+        _check(lib().myslam_lk_prefetch(self._h, _p(img), C.c_uint64(token), img.shape[0], img.shape[1], img.strides[0]), "myslam_lk_prefetch")
+
     def track_batch(self, d_prev, d_next, batch, rows, cols, step, stride, d_prev_pts, d_next_pts, d_counts, cap, d_status, d_err=0):
         _check(lib().myslam_lk_track_batch(self._h, C.c_void_p(d_prev), C.c_void_p(d_next), batch, rows, cols, step, C.c_size_t(stride),
                                            C.c_void_p(d_prev_pts), C.c_void_p(d_next_pts), C.c_void_p(d_counts), cap,

@@ -264,6 +264,11 @@ struct myslam_lk {
     uint8_t *d_pyrP = nullptr, *d_pyrN = nullptr;
     // host-entry staging
     uint8_t* d_img = nullptr; size_t imgBytes = 0; float* d_pts = nullptr; uint8_t* d_st = nullptr; int ptsCap = 0;
+    // myslam_lk_track_cached / myslam_lk_prefetch: two (image, pyramid) slots that remember WHICH image they hold (a caller's token): the
+    // `next` image of one tracked frame is the `prev` image of the following one (Frontend::TrackLastFrame, frontend.cpp:150-153), and the
+    // frame after that can be uploaded while the current one is still being optimised
+    struct Slot { uint8_t* img = nullptr; size_t imgBytes = 0; uint8_t* pyr = nullptr; size_t pyrBytes = 0; uint64_t tok = 0; int rows = 0, cols = 0, step = 0; };
+    Slot slot[2]; int lastNext = 0;
 };
 
 static int lk_plan(myslam_lk* h, int rows, int cols) {
@@ -298,28 +303,72 @@ static int lk_ensure(myslam_lk* h, int batch, int rows, int cols) {
     return MYSLAM_OK;
 }
 
+// levels 1 .. of `batch` images (level 0 at src0, row pitch step0, image stride stride0) into pyr
+static void lk_pyramid(myslam_lk* h, const uint8_t* src0, int step0, size_t stride0, uint8_t* pyr, int batch) {
+    const LkGeom& g = h->g;
+    for (int l = 1; l <= g.levels; l++) {
+        const uint8_t* src = (l == 1) ? src0 : pyr + g.off[l - 1];
+        const int sstep = (l == 1) ? step0 : g.w[l - 1];
+        const size_t sstride = (l == 1) ? stride0 : g.bytes;
+        hipLaunchKernelGGL(k_pyr_down, dim3((g.w[l] + 63) / 64, (g.h[l] + 3) / 4, batch), dim3(256), 0, h->stream, src, g.w[l - 1], g.h[l - 1], sstep, sstride,
+                           pyr + g.off[l], g.w[l], g.h[l], g.bytes);
+    }
+}
+
+static int lk_track_launch(myslam_lk* h, const uint8_t* d_prev, const uint8_t* d_next, const uint8_t* pyrP, const uint8_t* pyrN, int batch, int rows, int cols,
+                           int pstep, int nstep, size_t pstride, size_t nstride, const float* d_prev_pts, float* d_next_pts, const int32_t* d_counts,
+                           int n_fixed, int cap, uint8_t* d_status, float* d_err) {
+    LkArgs a{d_prev, d_next, rows, cols, pstep, nstep, pstride, nstride, pyrP, pyrN, h->g, d_prev_pts, d_next_pts, d_counts, n_fixed, cap,
+             h->win, h->max_iters, h->eps * h->eps, h->min_eig, d_status, d_err};
+    hipLaunchKernelGGL(k_lk_track, dim3((cap + 3) / 4, batch), dim3(256), 0, h->stream, a);
+    MYSLAM_HIP_CHECK(hipGetLastError());
+    return MYSLAM_OK;
+}
+
 static int lk_run(myslam_lk* h, const uint8_t* d_prev, const uint8_t* d_next, int batch, int rows, int cols, int pstep, int nstep,
                   size_t pstride, size_t nstride, const float* d_prev_pts, float* d_next_pts, const int32_t* d_counts, int n_fixed, int cap,
                   uint8_t* d_status, float* d_err) {
     int rc = lk_ensure(h, batch, rows, cols);
     if (rc) return rc;
-    hipStream_t s = h->stream;
-    const LkGeom& g = h->g;
-    for (int which = 0; which < 2; which++) {
-        const uint8_t* src0 = which ? d_next : d_prev; uint8_t* pyr = which ? h->d_pyrN : h->d_pyrP;
-        for (int l = 1; l <= g.levels; l++) {
-            const uint8_t* src = (l == 1) ? src0 : pyr + g.off[l - 1];
-            const int sstep = (l == 1) ? (which ? nstep : pstep) : g.w[l - 1];
-            const size_t sstride = (l == 1) ? (which ? nstride : pstride) : g.bytes;
-            hipLaunchKernelGGL(k_pyr_down, dim3((g.w[l] + 63) / 64, (g.h[l] + 3) / 4, batch), dim3(256), 0, s, src, g.w[l - 1], g.h[l - 1], sstep, sstride,
-                               pyr + g.off[l], g.w[l], g.h[l], g.bytes);
-        }
-    }
-    LkArgs a{d_prev, d_next, rows, cols, pstep, nstep, pstride, nstride, h->d_pyrP, h->d_pyrN, g, d_prev_pts, d_next_pts, d_counts, n_fixed, cap,
-             h->win, h->max_iters, h->eps * h->eps, h->min_eig, d_status, d_err};
-    hipLaunchKernelGGL(k_lk_track, dim3((cap + 3) / 4, batch), dim3(256), 0, s, a);
-    MYSLAM_HIP_CHECK(hipGetLastError());
+    lk_pyramid(h, d_prev, pstep, pstride, h->d_pyrP, batch);
+    lk_pyramid(h, d_next, nstep, nstride, h->d_pyrN, batch);
+    return lk_track_launch(h, d_prev, d_next, h->d_pyrP, h->d_pyrN, batch, rows, cols, pstep, nstep, pstride, nstride, d_prev_pts, d_next_pts, d_counts, n_fixed,
+                           cap, d_status, d_err);
+}
+
+// ---- cached form: slots that remember their image ----
+static int lk_plan_cached(myslam_lk* h, int rows, int cols) {
+    if (rows == h->rows && cols == h->cols) return MYSLAM_OK;
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+    lk_plan(h, rows, cols);
+    h->slot[0].tok = h->slot[1].tok = 0;                     // another geometry: nothing cached is usable
     return MYSLAM_OK;
+}
+
+// image -> slot i (one contiguous copy with the caller's row pitch, then the pyramid levels), asynchronous on the handle's stream
+static int lk_fill_slot(myslam_lk* h, int i, const uint8_t* img, uint64_t tok, int rows, int cols, int step) {
+    myslam_lk::Slot& S = h->slot[i];
+    const size_t ib = (size_t)rows * step, pb = std::max<size_t>(256, h->g.bytes);
+    if (ib > S.imgBytes || pb > S.pyrBytes) {
+        MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (S.img) (void)hipFree(S.img);
+        if (S.pyr) (void)hipFree(S.pyr);
+        S = myslam_lk::Slot();
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&S.img, ib)); S.imgBytes = ib;
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&S.pyr, pb)); S.pyrBytes = pb;
+    }
+    S.tok = 0;                                               // not valid until everything below is enqueued
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(S.img, img, ib - (size_t)(step - cols), hipMemcpyHostToDevice, h->stream));     // the last row ends at its last pixel
+    lk_pyramid(h, S.img, step, ib, S.pyr, 1);
+    MYSLAM_HIP_CHECK(hipGetLastError());
+    S.tok = tok; S.rows = rows; S.cols = cols; S.step = step;
+    return MYSLAM_OK;
+}
+
+static int lk_find_slot(const myslam_lk* h, uint64_t tok, int rows, int cols, int step) {
+    if (!tok) return -1;
+    for (int i = 0; i < 2; i++) if (h->slot[i].tok == tok && h->slot[i].rows == rows && h->slot[i].cols == cols && h->slot[i].step == step) return i;
+    return -1;
 }
 
 extern "C" {
@@ -337,7 +386,7 @@ int myslam_lk_create(myslam_lk** out, int win, int max_level, int max_iters, flo
 int myslam_lk_destroy(myslam_lk* h) {
     if (!h) return MYSLAM_ERR_INVALID;
     (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->d_pyrP, h->d_pyrN, h->d_img, h->d_pts, h->d_st};
+    void* ptrs[] = {h->d_pyrP, h->d_pyrN, h->d_img, h->d_pts, h->d_st, h->slot[0].img, h->slot[0].pyr, h->slot[1].img, h->slot[1].pyr};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete h;
     return MYSLAM_OK;
@@ -386,6 +435,48 @@ int myslam_lk_track(myslam_lk* h, const uint8_t* prev, const uint8_t* next, int 
     MYSLAM_HIP_CHECK(hipMemcpyAsync(d_np, next_pts, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
     int rc = lk_run(h, h->d_img, h->d_img + pb, 1, rows, cols, prev_step, next_step, pb, nb, d_pp, d_np, nullptr, n, n, h->d_st, d_err);
     if (rc) return rc;
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(next_pts, d_np, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, s));
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(status, h->d_st, n, hipMemcpyDeviceToHost, s));
+    if (err) MYSLAM_HIP_CHECK(hipMemcpyAsync(err, d_err, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    return MYSLAM_OK;
+}
+
+int myslam_lk_prefetch(myslam_lk* h, const uint8_t* img, uint64_t token, int rows, int cols, int step) {
+    if (!h || !img || !token || rows < 1 || cols < 1 || step < cols) return MYSLAM_ERR_INVALID;
+    int rc = lk_plan_cached(h, rows, cols);
+    if (rc) return rc;
+    if (lk_find_slot(h, token, rows, cols, step) >= 0) return MYSLAM_OK;                  // already there
+    return lk_fill_slot(h, 1 - h->lastNext, img, token, rows, cols, step);                // never the slot the next call tracks FROM
+}
+
+int myslam_lk_track_cached(myslam_lk* h, const uint8_t* prev, uint64_t prev_token, const uint8_t* next, uint64_t next_token, int rows, int cols,
+                           int prev_step, int next_step, const float* prev_pts, float* next_pts, int n, uint8_t* status, float* err) {
+    if (!h || n < 0 || (n > 0 && (!prev_pts || !next_pts || !status))) return MYSLAM_ERR_INVALID;
+    if (n == 0) return MYSLAM_OK;
+    if (!prev || !next || rows < 1 || cols < 1 || prev_step < cols || next_step < cols) return MYSLAM_ERR_INVALID;
+    int rc = lk_plan_cached(h, rows, cols);
+    if (rc) return rc;
+    int sp = lk_find_slot(h, prev_token, rows, cols, prev_step), sn = lk_find_slot(h, next_token, rows, cols, next_step);
+    if (sp >= 0 && sp == sn) sn = -1;                                                     // one token for both images: the second is uploaded
+    if (sp < 0) { sp = sn < 0 ? 0 : 1 - sn; if ((rc = lk_fill_slot(h, sp, prev, prev_token, rows, cols, prev_step))) return rc; }
+    if (sn < 0) { sn = 1 - sp; if ((rc = lk_fill_slot(h, sn, next, next_token, rows, cols, next_step))) return rc; }
+    if (n > h->ptsCap) {
+        MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
+        if (h->d_pts) (void)hipFree(h->d_pts);
+        if (h->d_st) (void)hipFree(h->d_st);
+        h->d_pts = nullptr; h->d_st = nullptr; h->ptsCap = 0;
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_pts, sizeof(float) * 5 * (size_t)n)); MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_st, (size_t)n));
+        h->ptsCap = n;
+    }
+    hipStream_t s = h->stream;
+    float* d_pp = h->d_pts; float* d_np = d_pp + 2 * (size_t)h->ptsCap; float* d_err = d_np + 2 * (size_t)h->ptsCap;
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(d_pp, prev_pts, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(d_np, next_pts, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
+    const myslam_lk::Slot &P = h->slot[sp], &N = h->slot[sn];
+    if ((rc = lk_track_launch(h, P.img, N.img, P.pyr, N.pyr, 1, rows, cols, prev_step, next_step, P.imgBytes, N.imgBytes, d_pp, d_np, nullptr, n, n, h->d_st, d_err)))
+        return rc;
+    h->lastNext = sn;
     MYSLAM_HIP_CHECK(hipMemcpyAsync(next_pts, d_np, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, s));
     MYSLAM_HIP_CHECK(hipMemcpyAsync(status, h->d_st, n, hipMemcpyDeviceToHost, s));
     if (err) MYSLAM_HIP_CHECK(hipMemcpyAsync(err, d_err, sizeof(float) * n, hipMemcpyDeviceToHost, s));

@@ -347,6 +347,19 @@ public:
                               reinterpret_cast<const float*>(prevPts.data()), reinterpret_cast<float*>(nextPts.data()), n, status.data(), err.data()),
               "myslam_lk_track");
     }
+    // the same with the handle's two-image cache (myslam_lk_track_cached): a non-zero token names an image whose bytes never change
+    void calcOpticalFlowPyrLK(const ImageView& prevImg, uint64_t prevToken, const ImageView& nextImg, uint64_t nextToken, const std::vector<Point2f>& prevPts,
+                              std::vector<Point2f>& nextPts, std::vector<uint8_t>& status, std::vector<float>& err) {
+        const int n = (int)prevPts.size();
+        if ((int)nextPts.size() != n) nextPts = prevPts;
+        status.assign(n, 0); err.assign(n, 0.f);
+        if (n == 0) return;
+        check(myslam_lk_track_cached(h_, prevImg.data, prevToken, nextImg.data, nextToken, prevImg.rows, prevImg.cols, prevImg.step, nextImg.step,
+                                     reinterpret_cast<const float*>(prevPts.data()), reinterpret_cast<float*>(nextPts.data()), n, status.data(), err.data()),
+              "myslam_lk_track_cached");
+    }
+    // asynchronous upload + pyramid of the image the next cached call will name by `token` (it must stay valid and unchanged until then)
+    void Prefetch(const ImageView& img, uint64_t token) { check(myslam_lk_prefetch(h_, img.data, token, img.rows, img.cols, img.step), "myslam_lk_prefetch"); }
 };
 
 // the g2o stage of Frontend::EstimateCurrentPose (src/frontend.cpp:176-276); returns features.size() - cntOutliers.

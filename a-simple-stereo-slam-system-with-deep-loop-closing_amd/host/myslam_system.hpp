@@ -181,6 +181,7 @@ struct SystemConfig {
 // ---- the map's objects -------------------------------------------------------------------------------------------------------------
 struct Image {                              // cv::Mat CV_8UC1; shared_ptr<Image> copies share pixels as cv::Mat copies do
     std::vector<uint8_t> px; int rows = 0, cols = 0;
+    uint64_t token = 0;                     // names these BYTES for the tracker's image cache (myslam_lk_track_cached): new token whenever px changes
     ImageView view() { return ImageView{px.data(), rows, cols, cols}; }
 };
 struct MapPoint; struct KeyFrame;
@@ -221,7 +222,7 @@ struct KeyFrame {                           // include/myslam/keyframe.h:14-60
 class StereoSystem {
    public:
     enum Status { INITING, TRACKING_GOOD, TRACKING_BAD, LOST };
-    struct Counters { long lkInitFromProjection = 0, lkInitFromLast = 0, poseOnly = 0, ba = 0, lcd = 0, detectLoop = 0, pnp = 0, pgo = 0; } stats;
+    struct Counters { long lkInitFromProjection = 0, lkInitFromLast = 0, poseOnly = 0, ba = 0, lcd = 0, detectLoop = 0, pnp = 0, pgo = 0, lkPrefetched = 0; } stats;
 
     StereoSystem(const StereoCamera& cam, const SystemConfig& cfg, std::unique_ptr<DeepLCD> lcd)
         : K_(cam), c_(cfg),
@@ -230,7 +231,13 @@ class StereoSystem {
           lcd_(std::move(lcd)), db_(64, cfg.lcdThresHigh, cfg.lcdThresLow) {}
 
     // Frontend::GrabStereoImage (frontend.cpp:41-80); false = the tracker is LOST (the reference quits)
-    bool GrabStereoImage(std::shared_ptr<Image> left, std::shared_ptr<Image> right, double timestamp) {
+    // nextLeft (optional): the left image of the FOLLOWING frame when the caller already has it — it is uploaded and down-sampled on the
+    // tracker's stream while this frame's pose is optimised (the reference reads one pair per call, app/run_kitti_stereo.cpp:66-67; a reader
+    // that decodes ahead can hand the next image over).  Results do not depend on it.
+    bool GrabStereoImage(std::shared_ptr<Image> left, std::shared_ptr<Image> right, double timestamp, std::shared_ptr<Image> nextLeft = nullptr) {
+        if (left && !left->token) left->token = ++imageTokens_;
+        if (nextLeft && !nextLeft->token) nextLeft->token = ++imageTokens_;
+        nextLeft_ = std::move(nextLeft);
         cur_ = std::make_shared<Frame>();
         cur_->id = nextFrameId_++; cur_->ts = timestamp; cur_->L = std::move(left); cur_->R = std::move(right);
         if (status_ == INITING) StereoInit();
@@ -315,7 +322,10 @@ class StereoSystem {
         }
         std::vector<uint8_t> st; std::vector<float> err;
         auto a = last_->L->view(), b = cur_->L->view();
-        lk_.calcOpticalFlowPyrLK(a, b, p0, p1, st, err);
+        // the last frame's image is still on the device under its token (it was this call's `next` one frame ago) unless DeepLCD has blurred
+        // it in place since (a key-frame: new token, uploaded again)
+        lk_.calcOpticalFlowPyrLK(a, last_->L->token, b, cur_->L->token, p0, p1, st, err);
+        if (nextLeft_) { lk_.Prefetch(nextLeft_->view(), nextLeft_->token); stats.lkPrefetched++; }     // runs beside EstimateCurrentPose
         for (size_t i = 0; i < n; i++)
             if (st[i] && last_->feats[i]->Live()) {  // status && !mpMapPoint.expired()
                 auto g = std::make_shared<Feature>(p1[i].x, p1[i].y);
@@ -555,6 +565,7 @@ class StereoSystem {
     void ProcessNewKF(KeyFrame& kf) {                // loopclosing.cpp:83-121
         if (!c_.lcdBlurReachesTracker) kf.img = std::make_shared<Image>(*kf.img);          // the frontend wins the race: the blur hits a private copy
         kf.descr = lcd_->calcDescrOriginalImg(kf.img->view());          // blurs the key-frame's image in place (reference quirk 7)
+        kf.img->token = ++imageTokens_;                                 // other bytes now: the tracker's cached copy of the sharp image is stale
         std::vector<KeyPoint> feats(kf.feats.size());
         for (size_t i = 0; i < feats.size(); i++) feats[i] = KeyPoint{kf.feats[i]->x, kf.feats[i]->y, 7.f, -1.f, 0.f, 0, -1};
         kf.pyr.Compute(orb_, kf.img->view(), feats);
@@ -664,6 +675,8 @@ class StereoSystem {
     StereoCamera K_; SystemConfig c_;
     ORBextractor orbInit_, orb_;
     PyrLKTracker lk_;
+    uint64_t imageTokens_ = 0;
+    std::shared_ptr<Image> nextLeft_;
     std::unique_ptr<DeepLCD> lcd_;
     LoopDatabase db_;
     // Frontend

@@ -473,6 +473,17 @@ int myslam_lk_set_stream(myslam_lk* h, void* hip_stream);
 /* host pointers (uploads, runs, downloads, synchronises); pts = n x (x, y) float */
 int myslam_lk_track(myslam_lk* h, const uint8_t* prev, const uint8_t* next, int rows, int cols, int prev_step, int next_step,
                     const float* prev_pts, float* next_pts, int n, uint8_t* status, float* err);
+/* The same call for a TRACKER that sees one new image per frame (Frontend::TrackLastFrame, src/frontend.cpp:129-172: the `next` image of frame
+ * t is the `prev` image of frame t + 1): the handle keeps the device copy and the pyramid of the two images it saw last, named by caller
+ * tokens.  A non-zero token promises "the bytes behind this token never change" — an image found under its token is neither uploaded nor
+ * down-sampled again; 0 = do not look up, do not remember.  A caller that modifies an image in place (DeepLCD blurs a key-frame's image,
+ * src/deeplcd.cpp:46, and cv::Mat copies share pixels) gives it a new token.  Results are bit-identical to myslam_lk_track.
+ * myslam_lk_prefetch uploads an image and builds its pyramid asynchronously on the handle's stream into the slot the next
+ * myslam_lk_track_cached call does not track FROM (the image must stay valid and unchanged until that call returns): the upload of frame
+ * t + 1 then runs beside whatever the caller does with frame t (its pose optimisation). */
+int myslam_lk_track_cached(myslam_lk* h, const uint8_t* prev, uint64_t prev_token, const uint8_t* next, uint64_t next_token, int rows, int cols,
+                           int prev_step, int next_step, const float* prev_pts, float* next_pts, int n, uint8_t* status, float* err);
+int myslam_lk_prefetch(myslam_lk* h, const uint8_t* img, uint64_t token, int rows, int cols, int step);
 /* device pointers, asynchronous on the handle's stream: `batch` image pairs (image b at base + b*stride), points of pair b at
  * pts + b*cap*2, d_counts[b] of them valid; d_status batch x cap, d_err batch x cap or NULL */
 int myslam_lk_track_batch(myslam_lk* h, const uint8_t* d_prev, const uint8_t* d_next, int batch, int rows, int cols, int step, size_t stride,

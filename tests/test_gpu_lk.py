@@ -88,3 +88,40 @@ def test_lk_batch(api, oracle, synth):
         r_pts, r_st, r_err = oracle.lk_track(prev[b], nxt[b], pts[b, :n], init[b, :n])
         assert np.array_equal(st[b, :n].cpu().numpy().astype(bool), r_st)
         assert np.array_equal(d[3][b, :n].cpu().numpy().view(np.uint32), r_pts.view(np.uint32))
+
+
+def test_lk_image_cache_and_prefetch(api, oracle, synth):
+    """myslam_lk_track_cached / myslam_lk_prefetch: the handle keeps the device copy and the pyramid of the two images it saw last under caller
+    tokens (the `next` image of frame t is the `prev` image of frame t + 1; the image of frame t + 1 can be uploaded ahead).  Every call must
+    return what the uncached call returns, bit for bit: a walk through five frames with hits, misses, a prefetch, an image modified in place
+    (new token: must be uploaded again; the OLD token would still name the old bytes), an uncached stereo call in between, token 0, and a change
+    of geometry."""
+    imgs = [synth.stereo_pair(0, t)[0] for t in range(5)]
+    R2 = synth.stereo_pair(0, 2)[1]
+    pts = _points(oracle, imgs[0])
+    plain, lk = api.LKTracker(), api.LKTracker()
+
+    def same(a, b):
+        return np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1], b[1]) and np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
+    tok = {i: 100 + i for i in range(5)}
+    assert same(lk.track_cached(imgs[0], tok[0], imgs[1], tok[1], pts, pts), plain.track(imgs[0], imgs[1], pts, pts))          # two misses
+    lk.prefetch(imgs[2], tok[2])                                                                                               # frame 2 ahead of its call
+    assert same(lk.track_cached(imgs[1], tok[1], imgs[2], tok[2], pts, pts), plain.track(imgs[1], imgs[2], pts, pts))          # two hits
+    # an uncached call on the same handle (FindFeaturesInRight: left -> right of the key-frame) leaves the cache alone
+    assert same(lk.track(imgs[2], R2, pts, pts - [12.0, 0.0]), plain.track(imgs[2], R2, pts, pts - [12.0, 0.0]))
+    # DeepLCD blurs the key-frame's image in place: other bytes, a NEW token -> uploaded again
+    blurred = imgs[2].copy(); blurred[1:-1, 1:-1] = ((blurred[:-2, 1:-1].astype(np.int32) + blurred[2:, 1:-1] + blurred[1:-1, :-2] + blurred[1:-1, 2:]) // 4).astype(np.uint8)
+    want = plain.track(blurred, imgs[3], pts, pts)
+    assert same(lk.track_cached(blurred, 999, imgs[3], tok[3], pts, pts), want)
+    assert not same(want, plain.track(imgs[2], imgs[3], pts, pts))                                                             # (the blur does change the tracks)
+    assert same(lk.track_cached(imgs[3], tok[3], imgs[4], 0, pts, pts), plain.track(imgs[3], imgs[4], pts, pts))               # token 0: never looked up or kept
+    assert same(lk.track_cached(imgs[3], tok[3], imgs[4], 0, pts, pts), plain.track(imgs[3], imgs[4], pts, pts))
+    assert same(lk.track_cached(imgs[4], 7, imgs[4], 7, pts, pts), plain.track(imgs[4], imgs[4], pts, pts))                    # one token for both images
+    # another geometry under a token seen before: nothing cached is usable
+    small = [np.ascontiguousarray(im[40:300, 100:900]) for im in imgs[:2]]
+    ps = _points(oracle, small[0])
+    assert same(lk.track_cached(small[0], tok[0], small[1], tok[1], ps, ps), plain.track(small[0], small[1], ps, ps))
+    assert same(lk.track_cached(imgs[0], tok[0], imgs[1], tok[1], pts, pts), plain.track(imgs[0], imgs[1], pts, pts))
+    r = oracle.lk_track(imgs[0], imgs[1], pts, pts)
+    g = lk.track_cached(imgs[0], tok[0], imgs[1], tok[1], pts, pts)
+    assert np.array_equal(g[0].view(np.uint32), r[0].view(np.uint32)) and np.array_equal(g[1], r[1])
