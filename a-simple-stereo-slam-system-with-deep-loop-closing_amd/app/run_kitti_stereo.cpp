@@ -18,8 +18,10 @@
 #include <cstring>
 #include <filesystem>
 #include <fstream>
-#include <deque>
-#include <future>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 #include "../host/myslam_io.hpp"
 #include "../host/myslam_png.hpp"
@@ -30,6 +32,53 @@ static std::shared_ptr<myslam::Image> imread_gray(const std::string& path) {
     if (!myslam::io::ReadPngGray(path, im->px, im->rows, im->cols)) return nullptr;
     return im;
 }
+
+// cv::imread per step (app/run_kitti_stereo.cpp:66-67), decoded AHEAD of the tracker by a pool of threads: task 2 i + side = image `side` of
+// frame i, handed out in order, at most `window` frames ahead of the frame the tracker has taken (a 1241 x 376 PNG takes ~4 ms to decode, a
+// tracked frame 0.6 ms: twelve threads keep up).  (Round 5; one std::async per image cost the tracking loop two thread creations per frame.)
+class ImageReader {
+    const std::vector<std::string>&left_, &right_;
+    const int n_, window_;
+    std::vector<std::shared_ptr<myslam::Image>> img_;        // 2 n slots
+    std::vector<char> done_;
+    std::mutex mu_; std::condition_variable cv_;
+    int nextTask_ = 0, taken_ = 0; bool stop_ = false;
+    std::vector<std::thread> workers_;
+    void work() {
+        for (;;) {
+            int task;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || (nextTask_ < 2 * n_ && nextTask_ / 2 < taken_ + window_); });
+                if (stop_) return;
+                task = nextTask_++;
+            }
+            auto im = imread_gray((task & 1) ? right_[task >> 1] : left_[task >> 1]);
+            { std::lock_guard<std::mutex> lk(mu_); img_[task] = std::move(im); done_[task] = 1; }
+            cv_.notify_all();
+        }
+    }
+public:
+    ImageReader(const std::vector<std::string>& left, const std::vector<std::string>& right, int n, int window, int threads)
+        : left_(left), right_(right), n_(n), window_(window), img_(2 * (size_t)n), done_(2 * (size_t)n, 0) {
+        for (int i = 0; i < threads; i++) workers_.emplace_back([this] { work(); });
+    }
+    ~ImageReader() { { std::lock_guard<std::mutex> lk(mu_); stop_ = true; } cv_.notify_all(); for (auto& t : workers_) t.join(); }
+    // blocks until both images of frame i are decoded; the tracker has then taken frames 0 .. i
+    void Take(int i, std::shared_ptr<myslam::Image>& L, std::shared_ptr<myslam::Image>& R) {
+        std::unique_lock<std::mutex> lk(mu_);
+        taken_ = std::max(taken_, i + 1);
+        cv_.notify_all();
+        cv_.wait(lk, [&] { return done_[2 * i] && done_[2 * i + 1]; });
+        L = std::move(img_[2 * i]); R = std::move(img_[2 * i + 1]);
+    }
+    // the left image of frame i if it is decoded already (it stays in its slot for Take)
+    std::shared_ptr<myslam::Image> PeekLeft(int i) {
+        if (i >= n_) return nullptr;
+        std::lock_guard<std::mutex> lk(mu_);
+        return done_[2 * i] ? img_[2 * i] : nullptr;
+    }
+};
 
 int main(int argc, char** argv) {
     if (argc < 3) {
@@ -72,31 +121,15 @@ int main(int argc, char** argv) {
         double tRead = 0.0;
         int done = 0, rows = 0, cols = 0;
         const auto t0 = std::chrono::steady_clock::now();
-        // cv::imread per step (app/run_kitti_stereo.cpp:66-67), decoded ahead of the tracker: the two images of frame i + 1 are read on two
-        // threads while frame i is tracked (`--no-prefetch`: read them in the loop, as the reference does)
-        using ImgFuture = std::future<std::shared_ptr<myslam::Image>>;
-        auto ahead = [&](int i) { return std::make_pair(std::async(std::launch::async, imread_gray, left[i]), std::async(std::launch::async, imread_gray, right[i])); };
-        // up to kAhead frames are being decoded while frame i is tracked; a frame whose left image is ready early is also handed to the tracker
-        // as `nextLeft`, which uploads it beside the pose optimisation of frame i
-        constexpr int kAhead = 6;                                            // 12 decode threads: a 1241 x 376 PNG takes ~4 ms to decode, a tracked frame 0.7 ms
-        std::deque<std::pair<ImgFuture, ImgFuture>> queue;
-        std::shared_ptr<myslam::Image> readyL, readyR;                          // frame i + 1, taken out of its futures early
-        int issued = 0;
-        auto top_up = [&]() { while (prefetch && issued < n && (int)queue.size() < kAhead) queue.push_back(ahead(issued++)); };
-        top_up();
+        // `--no-prefetch`: read the two images in the loop, as the reference does.  Otherwise a reader pool decodes up to 6 frames ahead, and a
+        // following frame whose left image is ready early is handed to the tracker as `nextLeft` (uploaded beside this frame's pose optimisation)
+        std::unique_ptr<ImageReader> reader;
+        if (prefetch) reader.reset(new ImageReader(left, right, n, 6, 12));
         for (int i = 0; i < n; i++) {
             const auto r0 = std::chrono::steady_clock::now();
             std::shared_ptr<myslam::Image> L, R, nextL;
-            if (prefetch) {
-                if (readyL) { L = std::move(readyL); R = std::move(readyR); readyL.reset(); readyR.reset(); }
-                else { L = queue.front().first.get(); R = queue.front().second.get(); queue.pop_front(); }
-                top_up();
-                if (!queue.empty() && queue.front().first.wait_for(std::chrono::seconds(0)) == std::future_status::ready &&
-                    queue.front().second.wait_for(std::chrono::seconds(0)) == std::future_status::ready) {
-                    readyL = queue.front().first.get(); readyR = queue.front().second.get(); queue.pop_front(); top_up();
-                    nextL = readyL;
-                }
-            } else { L = imread_gray(left[i]); R = imread_gray(right[i]); }
+            if (prefetch) { reader->Take(i, L, R); nextL = reader->PeekLeft(i + 1); }
+            else { L = imread_gray(left[i]); R = imread_gray(right[i]); }
             tRead += std::chrono::duration<double>(std::chrono::steady_clock::now() - r0).count();
             if (!L || !R) { std::fprintf(stderr, "Failed to load image at: %s\n", left[i].c_str()); return 1; }
             rows = L->rows; cols = L->cols;
@@ -116,6 +149,9 @@ int main(int argc, char** argv) {
             std::ofstream g(out + "/key_frame_frames.txt");
             for (unsigned long id : slam.keyFrameFrames) g << id << "\n";
         }
+        std::printf("per tracked frame: LK call %.3f ms, pose-only call %.3f ms, host bookkeeping %.3f ms; key-frame insertion (detect, right image, triangulation, local BA, loop "
+                    "closer) %.2f ms per key-frame\n", 1e3 * slam.stats.secLK / std::max(1L, slam.stats.poseOnly), 1e3 * slam.stats.secPoseOnly / std::max(1L, slam.stats.poseOnly),
+                    1e3 * (tRun - slam.stats.secLK - slam.stats.secPoseOnly - slam.stats.secKeyFrame) / std::max(1, done), 1e3 * slam.stats.secKeyFrame / std::max<size_t>(1, slam.NumKeyFrames()));
         // the reference's closing lines (app/run_kitti_stereo.cpp:101-105), for scripts that scrape them
         std::printf("\n-------\nsystem stop.\ntotal time cost: %g, average fps: %g\n", tRun + tRead, done / std::max(tRun + tRead, 1e-9));
         std::printf("%d frames (%dx%d), %zu key-frames, %zu map points, %zu loops; waited %.2f s for images, tracked + mapped in %.2f s = %.1f frames/s, %.1f frames/s end to end "

@@ -30,6 +30,7 @@
 //     and is an error here.
 // Every arithmetic operator is a call into libmyslam_hip.so; what is computed here is bookkeeping and a handful of 4x4 products.
 #pragma once
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <map>
@@ -222,7 +223,8 @@ struct KeyFrame {                           // include/myslam/keyframe.h:14-60
 class StereoSystem {
    public:
     enum Status { INITING, TRACKING_GOOD, TRACKING_BAD, LOST };
-    struct Counters { long lkInitFromProjection = 0, lkInitFromLast = 0, poseOnly = 0, ba = 0, lcd = 0, detectLoop = 0, pnp = 0, pgo = 0, lkPrefetched = 0; } stats;
+    struct Counters { long lkInitFromProjection = 0, lkInitFromLast = 0, poseOnly = 0, ba = 0, lcd = 0, detectLoop = 0, pnp = 0, pgo = 0, lkPrefetched = 0;
+                      double secLK = 0, secPoseOnly = 0, secKeyFrame = 0; } stats;     // wall time inside the tracker's two per-frame calls and inside key-frame insertion
 
     StereoSystem(const StereoCamera& cam, const SystemConfig& cfg, std::unique_ptr<DeepLCD> lcd)
         : K_(cam), c_(cfg),
@@ -299,10 +301,12 @@ class StereoSystem {
         relMotion_ = cur_->rel * T_inv(last_->rel);
         const bool insert = c_.kfEvery <= 0 ? status_ == TRACKING_BAD : (status_ != LOST && cur_->id % (unsigned long)c_.kfEvery == 0);
         if (insert) {
+            const auto ti0 = std::chrono::steady_clock::now();
             DetectFeatures();
             FindFeaturesInRight();
             TriangulateNewPoints();
             InsertKeyFrame();
+            stats.secKeyFrame += std::chrono::duration<double>(std::chrono::steady_clock::now() - ti0).count();
         }
     }
 
@@ -324,7 +328,9 @@ class StereoSystem {
         auto a = last_->L->view(), b = cur_->L->view();
         // the last frame's image is still on the device under its token (it was this call's `next` one frame ago) unless DeepLCD has blurred
         // it in place since (a key-frame: new token, uploaded again)
+        const auto tk0 = std::chrono::steady_clock::now();
         lk_.calcOpticalFlowPyrLK(a, last_->L->token, b, cur_->L->token, p0, p1, st, err);
+        stats.secLK += std::chrono::duration<double>(std::chrono::steady_clock::now() - tk0).count();
         if (nextLeft_) { lk_.Prefetch(nextLeft_->view(), nextLeft_->token); stats.lkPrefetched++; }     // runs beside EstimateCurrentPose
         for (size_t i = 0; i < n; i++)
             if (st[i] && last_->feats[i]->Live()) {  // status && !mpMapPoint.expired()
@@ -341,7 +347,9 @@ class StereoSystem {
         for (Feature* f : feats) { p3.insert(p3.end(), f->mp->pos, f->mp->pos + 3); obs.push_back((double)f->x); obs.push_back((double)f->y); }
         Pose7 pose = p7_of(cur_->rel * T_of(refKF_->pose));
         std::vector<uint8_t> outl;
+        const auto tp0 = std::chrono::steady_clock::now();
         const int nInl = myslam::EstimateCurrentPose(pose.v, p3, obs, K_.fx, K_.fy, K_.cx, K_.cy, outl);
+        stats.secPoseOnly += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count();
         stats.poseOnly++;
         cur_->rel = T_of(pose) * T_inv(T_of(refKF_->pose));
         for (size_t i = 0; i < feats.size(); i++)

@@ -122,6 +122,7 @@ def test_compiled_runner_equals_the_python_chain(api, synth, pkg, tmp_path, kitt
     assert np.array_equal(poses, ref), float(np.abs(poses - ref).max())
     assert open(out / "trajectory.txt").read() == open(tmp_path / "py" / "trajectory.txt").read()
     assert open(out / "loopEdges.txt").read() == ""
+    print("compiled runner: " + " ".join(l for l in r.stdout.splitlines() if l.startswith("per tracked frame")))
     print(f"compiled runner: {r.stdout.strip().splitlines()[-1]}; key-frames at frames {kf_frames}; the pose of every frame and trajectory.txt "
           f"are bit-identical to the Python chain's")
 
