@@ -965,6 +965,17 @@ __global__ __launch_bounds__(NT) void k_pose_only(PoseOnlyArgs a) {
         const double u = a.fx * pc[0] + 0.0 * pc[1] + a.cx * pc[2], v = 0.0 * pc[0] + a.fy * pc[1] + a.cy * pc[2];
         e0 = Z2[2 * i] - u / pc[2]; e1 = Z2[2 * i + 1] - v / pc[2];
     };
+    // One- and two-wave blocks (the tracker's one-frame call) keep every edge's last evaluation — residual and camera-frame point — in
+    // registers: the H pass of an iteration always follows an evaluation at exactly its state (the round's first, or the accepted trial's), so
+    // it reads them back instead of evaluating again (the same doubles; two f64 divisions per edge and iteration less on a chain of ~45
+    // dependent steps).  Eight-wave blocks of large batches keep their registers for occupancy and evaluate again.
+#ifdef MYSLAM_POSE_ONLY_NO_KEEP                              // A/B builds only
+    constexpr bool KEEP = false;
+#else
+    constexpr bool KEEP = NT <= 128;
+#endif
+    constexpr int NK = KEEP ? PO_EPT : 1;
+    double ke0[NK], ke1[NK], kx[NK], ky[NK], kz[NK];
     auto active_chi2 = [&]() -> double {                   // computeActiveErrors + activeRobustChi2
         double s = 0;
 #pragma unroll
@@ -973,6 +984,7 @@ __global__ __launch_bounds__(NT) void k_pose_only(PoseOnlyArgs a) {
             if (i < n && !((level >> k) & 1)) {
                 double e0, e1, pc[3];
                 edge_err(i, e0, e1, pc);
+                if constexpr (KEEP) { ke0[k] = e0; ke1[k] = e1; kx[k] = pc[0]; ky[k] = pc[1]; kz[k] = pc[2]; }
                 const double e2 = e0 * e0 + e1 * e1;
                 echi[k] = e2;
                 s += (!robust || e2 <= 1.0) ? e2 : 2 * sqrt(e2) - 1.0;
@@ -995,7 +1007,11 @@ __global__ __launch_bounds__(NT) void k_pose_only(PoseOnlyArgs a) {
             // in 200).  Round 5: one edge evaluation per iteration + one per trial instead of two + one — the tracker's one-frame call spends
             // its time in ~45 dependent Levenberg steps (frontend.cpp:176-276).
             double currentChi = active_chi2();
+            bool fresh = true;                                // the kept evaluations (and currentChi) belong to the CURRENT state (block-uniform)
             for (int it = 0; it < a.iters; it++) {
+                // a new iteration normally follows an accepted trial; the one exception (a NaN gain ratio leaves the trial loop with the state
+                // restored and no exit condition met) evaluates again, as g2o does at the start of every iteration
+                if (!fresh) { currentChi = active_chi2(); fresh = true; }
 #ifdef MYSLAM_POSE_ONLY_RECOMPUTE_CHI                         // A/B builds only (tools/build_variants.sh): the round-4 form, one more evaluation per iteration
                 if (it > 0) currentChi = active_chi2();
 #endif
@@ -1008,7 +1024,8 @@ __global__ __launch_bounds__(NT) void k_pose_only(PoseOnlyArgs a) {
                     const int i = t + k * NT;
                     if (i < n && !((level >> k) & 1)) {
                         double e0, e1, pc[3];
-                        edge_err(i, e0, e1, pc);
+                        if constexpr (KEEP) { e0 = ke0[k]; e1 = ke1[k]; pc[0] = kx[k]; pc[1] = ky[k]; pc[2] = kz[k]; }
+                        else edge_err(i, e0, e1, pc);
                         const double X = pc[0], Y = pc[1], Zc = pc[2], Zinv = 1.0 / (Zc + 1e-18), Zinv2 = Zinv * Zinv;      // g2o_types.h:79-92
                         const double J[12] = {-a.fx * Zinv, 0, a.fx * X * Zinv2, a.fx * X * Y * Zinv2, -a.fx - a.fx * X * X * Zinv2, a.fx * Y * Zinv,
                                               0, -a.fy * Zinv, a.fy * Y * Zinv2, a.fy + a.fy * Y * Y * Zinv2, -a.fy * X * Y * Zinv2, -a.fy * X * Zinv};
@@ -1088,10 +1105,11 @@ __global__ __launch_bounds__(NT) void k_pose_only(PoseOnlyArgs a) {
                             alpha = fmin(alpha, 2. / 3.);
                             s_sc[0] = lambda * fmax(1. / 3., alpha); s_sc[1] = 2.0;
                         }
-                        currentChi = tempChi;
+                        currentChi = tempChi; fresh = true;
                     } else {
                         if (t == 0) { s_sc[0] = lambda * s_sc[1]; s_sc[1] *= 2.0; }
                         if (t < 12) sT[t] = sTb[t];
+                        fresh = false;
                     }
                     __syncthreads();
                     qmax++;
