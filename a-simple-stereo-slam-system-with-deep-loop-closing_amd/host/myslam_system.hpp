@@ -32,6 +32,9 @@
 #pragma once
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <map>
 #include <memory>
@@ -329,9 +332,10 @@ class StereoSystem {
         // the last frame's image is still on the device under its token (it was this call's `next` one frame ago) unless DeepLCD has blurred
         // it in place since (a key-frame: new token, uploaded again)
         const auto tk0 = std::chrono::steady_clock::now();
+        uploader_.Wait();                                                   // the handle serves one thread at a time
         lk_.calcOpticalFlowPyrLK(a, last_->L->token, b, cur_->L->token, p0, p1, st, err);
         stats.secLK += std::chrono::duration<double>(std::chrono::steady_clock::now() - tk0).count();
-        if (nextLeft_) { lk_.Prefetch(nextLeft_->view(), nextLeft_->token); stats.lkPrefetched++; }     // runs beside EstimateCurrentPose
+        if (nextLeft_) { uploader_.Post(&lk_, nextLeft_); stats.lkPrefetched++; }     // uploaded by a helper thread beside EstimateCurrentPose
         for (size_t i = 0; i < n; i++)
             if (st[i] && last_->feats[i]->Live()) {  // status && !mpMapPoint.expired()
                 auto g = std::make_shared<Feature>(p1[i].x, p1[i].y);
@@ -393,6 +397,7 @@ class StereoSystem {
         }
         std::vector<float> err;
         auto a = cur_->L->view(), b = cur_->R->view();
+        uploader_.Wait();
         lk_.calcOpticalFlowPyrLK(a, b, p0, p1, cur_->hasRight, err);
         cur_->right = p1;
         int cnt = 0;
@@ -685,6 +690,40 @@ class StereoSystem {
     PyrLKTracker lk_;
     uint64_t imageTokens_ = 0;
     std::shared_ptr<Image> nextLeft_;
+    // The upload of the next frame's left image (myslam_lk_prefetch) copies 466 KB out of pageable memory before it returns: a helper thread
+    // makes that call, so the tracking thread goes straight on to the pose optimisation.  One job in flight; Wait() before the next call on
+    // the handle (it serves one thread at a time) — by then the job is long done.
+    class Uploader {
+        std::thread th_; std::mutex mu_; std::condition_variable cv_;
+        PyrLKTracker* lk_ = nullptr; std::shared_ptr<Image> job_; bool busy_ = false, stop_ = false; std::string error_;
+        void Run() {
+            for (;;) {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || busy_; });
+                if (stop_) return;
+                std::shared_ptr<Image> img = job_; PyrLKTracker* t = lk_;
+                lk.unlock();
+                std::string err;
+                try { t->Prefetch(img->view(), img->token); } catch (const std::exception& e) { err = e.what(); }
+                lk.lock();
+                busy_ = false; job_.reset(); if (!err.empty()) error_ = err;
+                cv_.notify_all();
+            }
+        }
+    public:
+        ~Uploader() { if (th_.joinable()) { { std::lock_guard<std::mutex> lk(mu_); stop_ = true; } cv_.notify_all(); th_.join(); } }
+        void Post(PyrLKTracker* t, std::shared_ptr<Image> img) {
+            Wait();
+            { std::lock_guard<std::mutex> lk(mu_); lk_ = t; job_ = std::move(img); busy_ = true; }
+            if (!th_.joinable()) th_ = std::thread([this] { Run(); });
+            cv_.notify_all();
+        }
+        void Wait() {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return !busy_; });
+            if (!error_.empty()) { const std::string e = error_; error_.clear(); throw std::runtime_error("image upload: " + e); }
+        }
+    } uploader_;
     std::unique_ptr<DeepLCD> lcd_;
     LoopDatabase db_;
     // Frontend
