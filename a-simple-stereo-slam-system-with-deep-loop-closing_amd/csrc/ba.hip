@@ -1157,8 +1157,9 @@ static int ba_launch(const BaArgs& a, int nwin, hipStream_t s) {
     const size_t lds = ba_lds(a.maxP, a.maxL, wide ? 16 : 4);
     if (lds > 150 * 1024) return MYSLAM_ERR_CAPACITY;
     // (the limit is state of the function, not of the launch: always raised to what any plan may need — see launch_octree)
-    static const bool raised = (hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess) &
-                               (hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess);
+    static const bool raised256 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
+    static const bool raised1024 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
+    const bool raised = raised256 && raised1024;
     (void)raised;
     ScopedProf sp(P_BA, s);
     if (wide) hipLaunchKernelGGL(k_ba_build<1024>, dim3(nwin), dim3(1024), lds, s, a);

@@ -289,7 +289,7 @@ inline bool DecodePngGrayUnguarded(const uint8_t* data, size_t size, std::vector
                     const int b = up[i];
                     const int pa = std::abs(b - c), pb = std::abs(a - c), pc = std::abs(a + b - 2 * c);
                     const int bc = pb <= pc ? b : c;                                             // selects, no branches: noise-like rows mispredict every other byte
-                    a = (cur[i] + ((pa <= pb) & (pa <= pc) ? a : bc)) & 255;
+                    a = (cur[i] + (((pa <= pb) & (pa <= pc)) ? a : bc)) & 255;
                     cur[i] = (uint8_t)a; c = b;
                 }
             } else {
@@ -298,7 +298,7 @@ inline bool DecodePngGrayUnguarded(const uint8_t* data, size_t size, std::vector
                     const int a = cur[i - bpp], b = up[i], c = up[i - bpp];
                     const int pa = std::abs(b - c), pb = std::abs(a - c), pc = std::abs(a + b - 2 * c);
                     const int bc = pb <= pc ? b : c;
-                    cur[i] = (uint8_t)(cur[i] + ((pa <= pb) & (pa <= pc) ? a : bc));
+                    cur[i] = (uint8_t)(cur[i] + (((pa <= pb) & (pa <= pc)) ? a : bc));
                 }
             }
         }
