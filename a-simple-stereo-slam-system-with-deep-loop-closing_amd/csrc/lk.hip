@@ -269,6 +269,8 @@ struct myslam_lk {
     // frame after that can be uploaded while the current one is still being optimised
     struct Slot { uint8_t* img = nullptr; size_t imgBytes = 0; uint8_t* pyr = nullptr; size_t pyrBytes = 0; uint64_t tok = 0; int rows = 0, cols = 0, step = 0; };
     Slot slot[2]; int lastNext = 0;
+    // the cached call's points travel as ONE pinned upload [prev_pts | next_pts] and ONE pinned download [next_pts | err | status]
+    uint8_t* h_pin = nullptr; uint8_t* d_stage = nullptr; int stageCap = 0;
 };
 
 static int lk_plan(myslam_lk* h, int rows, int cols) {
@@ -386,7 +388,8 @@ int myslam_lk_create(myslam_lk** out, int win, int max_level, int max_iters, flo
 int myslam_lk_destroy(myslam_lk* h) {
     if (!h) return MYSLAM_ERR_INVALID;
     (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->d_pyrP, h->d_pyrN, h->d_img, h->d_pts, h->d_st, h->slot[0].img, h->slot[0].pyr, h->slot[1].img, h->slot[1].pyr};
+    void* ptrs[] = {h->d_pyrP, h->d_pyrN, h->d_img, h->d_pts, h->d_st, h->slot[0].img, h->slot[0].pyr, h->slot[1].img, h->slot[1].pyr, h->d_stage};
+    if (h->h_pin) (void)hipHostFree(h->h_pin);
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete h;
     return MYSLAM_OK;
@@ -461,26 +464,31 @@ int myslam_lk_track_cached(myslam_lk* h, const uint8_t* prev, uint64_t prev_toke
     if (sp >= 0 && sp == sn) sn = -1;                                                     // one token for both images: the second is uploaded
     if (sp < 0) { sp = sn < 0 ? 0 : 1 - sn; if ((rc = lk_fill_slot(h, sp, prev, prev_token, rows, cols, prev_step))) return rc; }
     if (sn < 0) { sn = 1 - sp; if ((rc = lk_fill_slot(h, sn, next, next_token, rows, cols, next_step))) return rc; }
-    if (n > h->ptsCap) {
+    if (n > h->stageCap) {
         MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
-        if (h->d_pts) (void)hipFree(h->d_pts);
-        if (h->d_st) (void)hipFree(h->d_st);
-        h->d_pts = nullptr; h->d_st = nullptr; h->ptsCap = 0;
-        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_pts, sizeof(float) * 5 * (size_t)n)); MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_st, (size_t)n));
-        h->ptsCap = n;
+        if (h->d_stage) (void)hipFree(h->d_stage);
+        if (h->h_pin) (void)hipHostFree(h->h_pin);
+        h->d_stage = nullptr; h->h_pin = nullptr; h->stageCap = 0;
+        const int cap = std::max(n, 512);
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_stage, (size_t)21 * cap + 16)); MYSLAM_HIP_CHECK(hipHostMalloc((void**)&h->h_pin, (size_t)21 * cap + 16));
+        h->stageCap = cap;
     }
     hipStream_t s = h->stream;
-    float* d_pp = h->d_pts; float* d_np = d_pp + 2 * (size_t)h->ptsCap; float* d_err = d_np + 2 * (size_t)h->ptsCap;
-    MYSLAM_HIP_CHECK(hipMemcpyAsync(d_pp, prev_pts, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
-    MYSLAM_HIP_CHECK(hipMemcpyAsync(d_np, next_pts, sizeof(float) * 2 * n, hipMemcpyHostToDevice, s));
+    // device block: [prev_pts 8n][next_pts 8n][err 4n][status n]; upload = the first 16n bytes, download = the last 13n
+    float* d_pp = reinterpret_cast<float*>(h->d_stage); float* d_np = d_pp + 2 * (size_t)n; float* d_err = d_np + 2 * (size_t)n;
+    uint8_t* d_st = reinterpret_cast<uint8_t*>(d_err + n);
+    memcpy(h->h_pin, prev_pts, sizeof(float) * 2 * n); memcpy(h->h_pin + sizeof(float) * 2 * n, next_pts, sizeof(float) * 2 * n);
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_stage, h->h_pin, sizeof(float) * 4 * n, hipMemcpyHostToDevice, s));
     const myslam_lk::Slot &P = h->slot[sp], &N = h->slot[sn];
-    if ((rc = lk_track_launch(h, P.img, N.img, P.pyr, N.pyr, 1, rows, cols, prev_step, next_step, P.imgBytes, N.imgBytes, d_pp, d_np, nullptr, n, n, h->d_st, d_err)))
+    if ((rc = lk_track_launch(h, P.img, N.img, P.pyr, N.pyr, 1, rows, cols, prev_step, next_step, P.imgBytes, N.imgBytes, d_pp, d_np, nullptr, n, n, d_st, d_err)))
         return rc;
     h->lastNext = sn;
-    MYSLAM_HIP_CHECK(hipMemcpyAsync(next_pts, d_np, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, s));
-    MYSLAM_HIP_CHECK(hipMemcpyAsync(status, h->d_st, n, hipMemcpyDeviceToHost, s));
-    if (err) MYSLAM_HIP_CHECK(hipMemcpyAsync(err, d_err, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+    uint8_t* hp = h->h_pin + sizeof(float) * 2 * n;
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(hp, d_np, (size_t)13 * n, hipMemcpyDeviceToHost, s));
     MYSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    memcpy(next_pts, hp, sizeof(float) * 2 * n);
+    if (err) memcpy(err, hp + sizeof(float) * 2 * n, sizeof(float) * n);
+    memcpy(status, hp + sizeof(float) * 3 * n, n);
     return MYSLAM_OK;
 }
 
