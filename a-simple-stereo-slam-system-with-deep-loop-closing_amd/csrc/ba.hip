@@ -439,10 +439,16 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
 
     double* echi = a.edge_chi2 ? a.edge_chi2 + (size_t)w * a.maxE : nullptr;      // what edge->chi2() returns: e^T e of the last evaluation
     auto robust_chi2 = [&](bool record) -> double {          // computeActiveErrors() + activeRobustChi2()
+        // (every edge loop of this kernel fetches the NEXT edge's indices and observation before it evaluates the current one: a block has two
+        // waves per SIMD, so nothing else hides the L2 latency of these loads behind the ~250 f64 instructions of an evaluation — round 5)
         double acc = 0;
+        int pn = 0, ln = 0; double zn0 = 0, zn1 = 0;
+        if (t < E) { pn = ep[t]; ln = el[t]; zn0 = obs[2 * t]; zn1 = obs[2 * t + 1]; }
         for (int k = t; k < E; k += BA_NT) {
+            const int pk = pn, lk = ln; const double z[2] = {zn0, zn1};
+            if (k + BA_NT < E) { pn = ep[k + BA_NT]; ln = el[k + BA_NT]; zn0 = obs[2 * (k + BA_NT)]; zn1 = obs[2 * (k + BA_NT) + 1]; }
             double e0, e1;
-            ba_edge(sR + 12 * ep[k], sPt + 3 * el[k], obs + 2 * k, a.fx, a.fy, a.cx, a.cy, e0, e1, nullptr, nullptr);
+            ba_edge(sR + 12 * pk, sPt + 3 * lk, z, a.fx, a.fy, a.cx, a.cy, e0, e1, nullptr, nullptr);
             const double e2 = e0 * e0 + e1 * e1;
             if (record && echi) echi[k] = e2;
             acc += (e2 <= d2) ? e2 : 2 * sqrt(e2) * a.delta - d2;
@@ -461,10 +467,14 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
             double h[27];
 #pragma unroll
             for (int u = 0; u < 27; u++) h[u] = 0.0;
-            for (int i = s_poff[p] + lane; i < s_poff[p + 1]; i += 64) {
-                const int k = plist[i];
+            const int iend = s_poff[p + 1];
+            int kn = 0, ln = 0; double zn0 = 0, zn1 = 0;
+            if (s_poff[p] + lane < iend) { kn = plist[s_poff[p] + lane]; ln = el[kn]; zn0 = obs[2 * kn]; zn1 = obs[2 * kn + 1]; }
+            for (int i = s_poff[p] + lane; i < iend; i += 64) {
+                const int lk = ln; const double z[2] = {zn0, zn1};
+                if (i + 64 < iend) { kn = plist[i + 64]; ln = el[kn]; zn0 = obs[2 * kn]; zn1 = obs[2 * kn + 1]; }
                 double e0, e1, J[12], Jp[6];
-                ba_edge(sR + 12 * p, sPt + 3 * el[k], obs + 2 * k, a.fx, a.fy, a.cx, a.cy, e0, e1, J, Jp);
+                ba_edge(sR + 12 * p, sPt + 3 * lk, z, a.fx, a.fy, a.cx, a.cy, e0, e1, J, Jp);
                 const double e2 = e0 * e0 + e1 * e1;
                 const double wgt = (e2 <= d2) ? 1.0 : a.delta / sqrt(e2);
                 int u = 0;
@@ -491,9 +501,14 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
 #pragma unroll
             for (int u = 0; u < 9; u++) hl[u] = 0.0;
             const bool fx_pt = fixed && fixed[l];
-            for (int k = lbeg[l]; k < lend[l]; k++) {
+            const int kb = lbeg[l], ke = lend[l];
+            int pn = 0; double zn0 = 0, zn1 = 0;
+            if (kb < ke) { pn = ep[kb]; zn0 = obs[2 * kb]; zn1 = obs[2 * kb + 1]; }
+            for (int k = kb; k < ke; k++) {
+                const int pk = pn; const double z[2] = {zn0, zn1};
+                if (k + 1 < ke) { pn = ep[k + 1]; zn0 = obs[2 * k + 2]; zn1 = obs[2 * k + 3]; }
                 double e0, e1, J[12], Jp[6];
-                ba_edge(sR + 12 * ep[k], sPt + 3 * l, obs + 2 * k, a.fx, a.fy, a.cx, a.cy, e0, e1, J, Jp);
+                ba_edge(sR + 12 * pk, sPt + 3 * l, z, a.fx, a.fy, a.cx, a.cy, e0, e1, J, Jp);
                 const double e2 = e0 * e0 + e1 * e1;
                 const double wgt = (e2 <= d2) ? 1.0 : a.delta / sqrt(e2);
                 acc += (e2 <= d2) ? e2 : 2 * sqrt(e2) * a.delta - d2;
@@ -802,10 +817,12 @@ __global__ __launch_bounds__(BA_NT) void k_ba_optimize(BaOptArgs a) {
                 const int kb = lbeg[l], ke = lend[l];
                 if ((fixed && fixed[l]) || ke <= kb) continue;
                 double r0 = sbl[3 * l], r1 = sbl[3 * l + 1], r2 = sbl[3 * l + 2];
+                int pn = ep[kb]; double zn0 = obs[2 * kb], zn1 = obs[2 * kb + 1];
                 for (int k = kb; k < ke; k++) {
-                    const int p = ep[k];
+                    const int p = pn; const double z[2] = {zn0, zn1};
+                    if (k + 1 < ke) { pn = ep[k + 1]; zn0 = obs[2 * k + 2]; zn1 = obs[2 * k + 3]; }
                     double e0, e1, J[12], Jp[6];
-                    ba_edge(sRb + 12 * p, sPtb + 3 * l, obs + 2 * k, a.fx, a.fy, a.cx, a.cy, e0, e1, J, Jp);
+                    ba_edge(sRb + 12 * p, sPtb + 3 * l, z, a.fx, a.fy, a.cx, a.cy, e0, e1, J, Jp);
                     const double e2 = e0 * e0 + e1 * e1;
                     const double wgt = (e2 <= d2) ? 1.0 : a.delta / sqrt(e2);
                     const double* xp = srhs + 6 * p;
