@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <filesystem>
+#include <malloc.h>
 #include <fstream>
 #include <atomic>
 #include <condition_variable>
@@ -35,7 +36,7 @@ static std::shared_ptr<myslam::Image> imread_gray(const std::string& path) {
 
 // cv::imread per step (app/run_kitti_stereo.cpp:66-67), decoded AHEAD of the tracker by a pool of threads: task 2 i + side = image `side` of
 // frame i, handed out in order, at most `window` frames ahead of the frame the tracker has taken (a 1241 x 376 PNG takes ~4 ms to decode, a
-// tracked frame 0.6 ms: twelve threads keep up).  (Round 5; one std::async per image cost the tracking loop two thread creations per frame.)
+// tracked frame 0.5 ms: see main() for the thread count).  (Round 5; one std::async per image cost the tracking loop two thread creations per frame.)
 class ImageReader {
     const std::vector<std::string>&left_, &right_;
     const int n_, window_;
@@ -86,6 +87,10 @@ int main(int argc, char** argv) {
                              "[--kf-every N] [--frontend-wins-race] [--correct-threshold X] [--frame-poses] [--no-prefetch]\n", argv[0]);
         return 1;
     }
+    // A 1241 x 376 image is 467 KB: above glibc's mmap threshold every decoded image is its own mapping, and the tracker's release of the frame
+    // before last is two munmap calls per frame — with a dozen decoder threads running, each one interrupts every core of the process (measured:
+    // 0.19 ms of the tracker's 0.7 ms per frame).  Image buffers come from the heap instead and stay there.
+    mallopt(M_MMAP_THRESHOLD, 32 << 20); mallopt(M_TRIM_THRESHOLD, 512 << 20);
     const std::string configPath = argv[1], sequence = argv[2];
     std::string out = "result", proto = "calc_model/deploy.prototxt", model = "calc_model/calc.caffemodel", weights;
     int frames = 0; bool framePoses = false, prefetch = true;
@@ -121,10 +126,13 @@ int main(int argc, char** argv) {
         double tRead = 0.0;
         int done = 0, rows = 0, cols = 0;
         const auto t0 = std::chrono::steady_clock::now();
-        // `--no-prefetch`: read the two images in the loop, as the reference does.  Otherwise a reader pool decodes up to 6 frames ahead, and a
+        // `--no-prefetch`: read the two images in the loop, as the reference does.  Otherwise a reader pool decodes some frames ahead, and a
         // following frame whose left image is ready early is handed to the tracker as `nextLeft` (uploaded beside this frame's pose optimisation)
         std::unique_ptr<ImageReader> reader;
-        if (prefetch) reader.reset(new ImageReader(left, right, n, 6, 12));
+        // (a 1241 x 376 PNG takes ~4 ms to decode and a tracked frame 0.5 ms: 16 decodes in flight keep up, a quarter of the machine's cores up to
+        // 32 leave a margin; the window is what that many threads can hold in flight plus two frames)
+        const int readers = std::min(32, std::max(4, (int)std::thread::hardware_concurrency() / 4));
+        if (prefetch) reader.reset(new ImageReader(left, right, n, readers / 2 + 2, readers));
         for (int i = 0; i < n; i++) {
             const auto r0 = std::chrono::steady_clock::now();
             std::shared_ptr<myslam::Image> L, R, nextL;
@@ -149,14 +157,18 @@ int main(int argc, char** argv) {
             std::ofstream g(out + "/key_frame_frames.txt");
             for (unsigned long id : slam.keyFrameFrames) g << id << "\n";
         }
-        std::printf("per tracked frame: LK call %.3f ms, pose-only call %.3f ms, host bookkeeping %.3f ms; key-frame insertion (detect, right image, triangulation, local BA, loop "
-                    "closer) %.2f ms per key-frame\n", 1e3 * slam.stats.secLK / std::max(1L, slam.stats.poseOnly), 1e3 * slam.stats.secPoseOnly / std::max(1L, slam.stats.poseOnly),
-                    1e3 * (tRun - slam.stats.secLK - slam.stats.secPoseOnly - slam.stats.secKeyFrame) / std::max(1, done), 1e3 * slam.stats.secKeyFrame / std::max<size_t>(1, slam.NumKeyFrames()));
+        std::printf("per tracked frame: LK call %.3f ms, pose-only call %.3f ms, host bookkeeping %.3f ms (%.3f around LK, %.3f around the pose call, %.3f releasing the frame before last, %.3f "
+                    "outside GrabStereoImage); stereo initialisation (first frame, with the library's lazy set-up) %.1f ms; key-frame insertion (detect, right image, triangulation, local BA, loop closer) %.2f ms per key-frame\n",
+                    1e3 * slam.stats.secLK / std::max(1L, slam.stats.poseOnly), 1e3 * slam.stats.secPoseOnly / std::max(1L, slam.stats.poseOnly),
+                    1e3 * (tRun - slam.stats.secLK - slam.stats.secPoseOnly - slam.stats.secKeyFrame - slam.stats.secInit) / std::max(1, done),
+                    1e3 * slam.stats.secTrackHost / std::max(1L, slam.stats.poseOnly), 1e3 * slam.stats.secPoseHost / std::max(1L, slam.stats.poseOnly),
+                    1e3 * slam.stats.secRelease / std::max(1, done), 1e3 * (tRun - slam.stats.secGrab) / std::max(1, done), 1e3 * slam.stats.secInit,
+                    1e3 * slam.stats.secKeyFrame / std::max<size_t>(1, slam.NumKeyFrames()));
         // the reference's closing lines (app/run_kitti_stereo.cpp:101-105), for scripts that scrape them
         std::printf("\n-------\nsystem stop.\ntotal time cost: %g, average fps: %g\n", tRun + tRead, done / std::max(tRun + tRead, 1e-9));
-        std::printf("%d frames (%dx%d), %zu key-frames, %zu map points, %zu loops; waited %.2f s for images, tracked + mapped in %.2f s = %.1f frames/s, %.1f frames/s end to end "
+        std::printf("%d frames (%dx%d), %zu key-frames, %zu map points, %zu loops; waited %.2f s for images, tracked + mapped in %.2f s = %.1f frames/s (%.1f after the first frame), %.1f frames/s end to end "
                     "(compiled host, one call per operator and frame; %ld pose-only, %ld local-BA, %ld DeepLCD, %ld loop queries, %ld next images uploaded ahead); wrote %s/trajectory.txt, loopEdges.txt\n",
-                    done, cols, rows, slam.NumKeyFrames(), slam.NumMapPoints(), slam.NumLoops(), tRead, tRun, done / std::max(tRun, 1e-9), done / std::max(tRun + tRead, 1e-9),
+                    done, cols, rows, slam.NumKeyFrames(), slam.NumMapPoints(), slam.NumLoops(), tRead, tRun, done / std::max(tRun, 1e-9), (done - 1) / std::max(tRun - slam.stats.secInit, 1e-9), done / std::max(tRun + tRead, 1e-9),
                     slam.stats.poseOnly, slam.stats.ba, slam.stats.lcd, slam.stats.detectLoop, slam.stats.lkPrefetched, out.c_str());
     } catch (const std::exception& e) {
         std::fprintf(stderr, "run_kitti_stereo: %s\n", e.what());

@@ -81,6 +81,34 @@ __device__ __forceinline__ double wave_sum_lane63(double v) {
     v = dpp_shift_add<0x143, 0xc>(v);     // row_bcast31 into rows 2 and 3
     return v;
 }
+// 32 f64 wave sums at once by halving: each step exchanges HALF of the values a lane still holds with a partner lane and adds the other half,
+// so 32 values cost 16 + 8 + 4 + 2 + 1 + 1 exchange-and-add steps instead of 32 x 6 (v_permlane32/16_swap for the two widest steps: one
+// instruction moves both directions).  On return lane l holds the total of value l >> 1 in h[0] (both lanes of a pair).
+template <int CTRL>
+__device__ __forceinline__ double dpp_fetch(double v) {
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ void wave_sum32_halving(double* h, int lane) {
+#pragma unroll
+    for (int u = 0; u < 16; u++) {                        // lanes 0..31 <- value u of lanes l, l + 32; lanes 32..63 <- value u + 16
+        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(h[u]), (unsigned)__double2loint(h[u + 16]), false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(h[u]), (unsigned)__double2hiint(h[u + 16]), false, false);
+        h[u] = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {                         // even rows of 16 lanes <- value u, odd rows <- value u + 8
+        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(h[u]), (unsigned)__double2loint(h[u + 8]), false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(h[u]), (unsigned)__double2hiint(h[u + 8]), false, false);
+        h[u] = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+    }
+    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+#pragma unroll
+    for (int u = 0; u < 4; u++) h[u] = (b3 ? h[u + 4] : h[u]) + dpp_fetch<0x128>(b3 ? h[u] : h[u + 4]);      // row_ror:8 = lane ^ 8
+#pragma unroll
+    for (int u = 0; u < 2; u++) h[u] = (b2 ? h[u + 2] : h[u]) + dpp_fetch<0x141>(b2 ? h[u] : h[u + 2]);      // row_half_mirror: flips bits 0..2
+    h[0] = (b1 ? h[1] : h[0]) + dpp_fetch<0x4E>(b1 ? h[0] : h[1]);                                          // quad_perm [2,3,0,1]
+    h[0] += dpp_fetch<0xB1>(h[0]);                                                                          // quad_perm [1,0,3,2]
+}
 __device__ __forceinline__ double bcast_lane(double v, int srcLane) {       // srcLane must be wave-uniform
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), srcLane), __builtin_amdgcn_readlane(__double2loint(v), srcLane));
 }
@@ -942,8 +970,9 @@ struct PoseOnlyArgs {
     uint8_t* outlier; int32_t* n_inliers; int32_t* status;
 };
 
-// NT = threads per frame: 512 for large batches of frames with many matches; the one-frame call of the tracker (150 - 400 matches) runs 64
-// or 128 threads — one or two waves pass the ~45 dependent Levenberg steps of a frame faster than eight waves that meet at every barrier.
+// NT = threads per frame (pose_only_launch): 64 / 128 for large batches of frames, 256 for the one-frame call of the tracker (150 - 400
+// matches: four waves pass the ~45 dependent Levenberg steps of a frame faster than eight that meet at every barrier, and faster than one
+// or two that walk several edges each), 512 for frames of thousands of matches.
 // The edge -> thread map (edge t + k NT) and with it the summation order depend on NT: results of different NT agree to rounding, the
 // parity bars against the oracle (1e-8 relative on the pose, identical flags) hold for each.
 template <int NT>
@@ -1033,9 +1062,9 @@ __global__ __launch_bounds__(NT) void k_pose_only(PoseOnlyArgs a) {
                 if (it > 0) currentChi = active_chi2();
 #endif
                 // ---- H (upper triangle, 21) and b (6) ----
-                double h[27];
+                double h[32];
 #pragma unroll
-                for (int u = 0; u < 27; u++) h[u] = 0.0;
+                for (int u = 0; u < 32; u++) h[u] = 0.0;
 #pragma unroll
                 for (int k = 0; k < PO_EPT; k++) {
                     const int i = t + k * NT;
@@ -1058,12 +1087,17 @@ __global__ __launch_bounds__(NT) void k_pose_only(PoseOnlyArgs a) {
                         for (int r = 0; r < 6; r++) h[21 + r] += -w * (J[r] * e0 + J[6 + r] * e1);
                     }
                 }
+#ifdef MYSLAM_POSE_ONLY_SUM_PER_VALUE                        // A/B builds only: 27 six-step wave sums (the form up to round 5)
 #pragma unroll
                 for (int u = 0; u < 27; u++) h[u] = wave_sum_lane63(h[u]);
                 if (lane == 63) {
 #pragma unroll
                     for (int u = 0; u < 27; u++) s_part[wv][u] = h[u];
                 }
+#else
+                wave_sum32_halving(h, lane);
+                if (!(lane & 1) && (lane >> 1) < 27) s_part[wv][lane >> 1] = h[0];
+#endif
                 __syncthreads();
                 if (t < 27) { double s = 0; for (int w2 = 0; w2 < NW; w2++) s += s_part[w2][t]; sH[t] = s; }
                 __syncthreads();
@@ -1317,7 +1351,8 @@ int myslam_ba_optimize_active_map(double* poses, int nposes, double* points, int
 // Block size (measured on MI355X, tools/frontend_time.py + tools/latency_frontend.py; PO_EPT = 8 edges per thread is the kernel's limit).
 // Many frames: small blocks, several frames per CU — 1024 frames x 150 / 500 / 1000 matches take 0.42 / 0.63 / 0.93 ms with 64 / 128 / 128
 // threads against 1.46 / 1.56 / 1.84 ms with 512.  A few frames (the tracker's one-frame call): the latency of ~45 dependent Levenberg steps,
-// 0.29 - 0.44 ms whatever the size; 256 threads are best from 150 to 1000 matches (0.29 ms at 150 against 0.36 with 512).
+// 0.24 - 0.31 ms at 150 - 400 matches; 256 threads are best there (round 5, with the halving sums: 0.238 / 0.314 ms with 256 threads, 0.31 / 0.34
+// with 128, 0.33 / 0.34 with 64, 0.345 at 400 matches with 512).
 static void pose_only_launch(const PoseOnlyArgs& a, int batch, int max_edges, hipStream_t s) {
     int nt;
     if (batch >= 64) nt = max_edges <= 256 ? 64 : (max_edges <= 1024 ? 128 : (max_edges <= 2048 ? 256 : 512));

@@ -227,7 +227,7 @@ class StereoSystem {
    public:
     enum Status { INITING, TRACKING_GOOD, TRACKING_BAD, LOST };
     struct Counters { long lkInitFromProjection = 0, lkInitFromLast = 0, poseOnly = 0, ba = 0, lcd = 0, detectLoop = 0, pnp = 0, pgo = 0, lkPrefetched = 0;
-                      double secLK = 0, secPoseOnly = 0, secKeyFrame = 0; } stats;     // wall time inside the tracker's two per-frame calls and inside key-frame insertion
+                      double secLK = 0, secPoseOnly = 0, secKeyFrame = 0, secTrackHost = 0, secPoseHost = 0, secGrab = 0, secRelease = 0, secInit = 0; } stats;     // wall time inside the tracker's two per-frame calls and inside key-frame insertion
 
     StereoSystem(const StereoCamera& cam, const SystemConfig& cfg, std::unique_ptr<DeepLCD> lcd)
         : K_(cam), c_(cfg),
@@ -240,16 +240,23 @@ class StereoSystem {
     // tracker's stream while this frame's pose is optimised (the reference reads one pair per call, app/run_kitti_stereo.cpp:66-67; a reader
     // that decodes ahead can hand the next image over).  Results do not depend on it.
     bool GrabStereoImage(std::shared_ptr<Image> left, std::shared_ptr<Image> right, double timestamp, std::shared_ptr<Image> nextLeft = nullptr) {
+        const auto tg0 = std::chrono::steady_clock::now();
         if (left && !left->token) left->token = ++imageTokens_;
         if (nextLeft && !nextLeft->token) nextLeft->token = ++imageTokens_;
         nextLeft_ = std::move(nextLeft);
         cur_ = std::make_shared<Frame>();
         cur_->id = nextFrameId_++; cur_->ts = timestamp; cur_->L = std::move(left); cur_->R = std::move(right);
-        if (status_ == INITING) StereoInit();
+        if (status_ == INITING) {                    // (the first call also pays for the library's lazy set-up: code objects, recorded graphs, tables)
+            StereoInit();
+            stats.secInit += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg0).count();
+        }
         else if (status_ == TRACKING_GOOD || status_ == TRACKING_BAD) Track();
         else return false;
         framePoses.push_back(refKF_ ? p7_of(cur_->rel * T_of(refKF_->pose)) : Pose7());
-        last_ = cur_;
+        const auto tr0 = std::chrono::steady_clock::now();
+        last_ = cur_;                                // releases the frame before last (its images, unless a key-frame holds them)
+        const auto tg1 = std::chrono::steady_clock::now();
+        stats.secRelease += std::chrono::duration<double>(tg1 - tr0).count(); stats.secGrab += std::chrono::duration<double>(tg1 - tg0).count();
         return true;
     }
 
@@ -314,6 +321,7 @@ class StereoSystem {
     }
 
     void TrackLastFrame() {                          // frontend.cpp:129-172
+        const auto th0 = std::chrono::steady_clock::now();
         const Mat4 Tcw = cur_->rel * T_of(refKF_->pose);
         const size_t n = last_->feats.size();
         std::vector<Point2f> p0(n), p1(n);
@@ -334,7 +342,8 @@ class StereoSystem {
         const auto tk0 = std::chrono::steady_clock::now();
         uploader_.Wait();                                                   // the handle serves one thread at a time
         lk_.calcOpticalFlowPyrLK(a, last_->L->token, b, cur_->L->token, p0, p1, st, err);
-        stats.secLK += std::chrono::duration<double>(std::chrono::steady_clock::now() - tk0).count();
+        const auto tk1 = std::chrono::steady_clock::now();
+        stats.secLK += std::chrono::duration<double>(tk1 - tk0).count();
         if (nextLeft_) { uploader_.Post(&lk_, nextLeft_); stats.lkPrefetched++; }     // uploaded by a helper thread beside EstimateCurrentPose
         for (size_t i = 0; i < n; i++)
             if (st[i] && last_->feats[i]->Live()) {  // status && !mpMapPoint.expired()
@@ -342,9 +351,11 @@ class StereoSystem {
                 g->mp = last_->feats[i]->mp;
                 cur_->feats.push_back(std::move(g));
             }
+        stats.secTrackHost += std::chrono::duration<double>((tk0 - th0) + (std::chrono::steady_clock::now() - tk1)).count();
     }
 
     int EstimateCurrentPose() {                      // frontend.cpp:176-276
+        const auto th0 = std::chrono::steady_clock::now();
         std::vector<Feature*> feats;
         for (auto& f : cur_->feats) if (f->Live() && !f->mp->outlier) feats.push_back(f.get());
         std::vector<double> p3, obs;
@@ -353,7 +364,8 @@ class StereoSystem {
         std::vector<uint8_t> outl;
         const auto tp0 = std::chrono::steady_clock::now();
         const int nInl = myslam::EstimateCurrentPose(pose.v, p3, obs, K_.fx, K_.fy, K_.cx, K_.cy, outl);
-        stats.secPoseOnly += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count();
+        const auto tp1 = std::chrono::steady_clock::now();
+        stats.secPoseOnly += std::chrono::duration<double>(tp1 - tp0).count();
         stats.poseOnly++;
         cur_->rel = T_of(pose) * T_inv(T_of(refKF_->pose));
         for (size_t i = 0; i < feats.size(); i++)
@@ -365,6 +377,7 @@ class StereoSystem {
                 }
                 f->mp.reset(); f->outlier = false;
             }
+        stats.secPoseHost += std::chrono::duration<double>((tp0 - th0) + (std::chrono::steady_clock::now() - tp1)).count();
         return nInl;
     }
 

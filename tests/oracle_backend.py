@@ -112,7 +112,23 @@ class CheckedBackend:
         (gp, go, gi), (rp, ro, ri) = self.h.pose_only(pose, p3, obs, Kt, pre), self.o.pose_only(pose, p3, obs, Kt, pre)
         self._note("pose_only", "pose_only_abs", np.abs(gp - rp).max())
         # (the operator test holds 1e-8 on well-conditioned synthetic problems; a real frame's last Levenberg steps sit at the noise floor)
-        assert np.allclose(gp, rp, rtol=1e-6, atol=1e-6) and np.array_equal(go, ro) and gi == ri, (f"pose-only call {self.calls['pose_only'] - 1}", np.abs(gp - rp).max(), gi, ri)
+        ok = np.allclose(gp, rp, rtol=1e-6, atol=1e-6) and np.array_equal(go, ro) and gi == ri
+        if not ok:
+            # A frame that keeps ~35 of its matches (the tracker is about to ask for a key-frame) can leave a Levenberg accept / reject decision on
+            # the last bits of a sum: the ORACLE's own result then moves by more than the bar when one observation changes by one ulp
+            # (tests/golden/pose_only_weak_frame.npz, tests/test_gpu_pose_only.py::test_weak_frame).  The rule of the chaotic local-BA window and of
+            # the flat-valley pose graph: the bar is three times the oracle's own one-ulp spread, the flags those of one of the oracle's runs.
+            import os
+            d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+            os.makedirs(d, exist_ok=True)
+            np.savez(os.path.join(d, f"pose_only_mismatch_{self.calls['pose_only'] - 1}.npz"), pose=pose, p3=p3, obs=obs, Kt=np.array(Kt), pre=pre, hip_pose=gp, hip_outlier=go,
+                     oracle_pose=rp, oracle_outlier=ro)
+            rng = np.random.default_rng(0)
+            runs = [self.o.pose_only(pose, p3, obs * (1 + rng.choice([-1.0, 1.0], size=obs.shape) * 2.2e-16), Kt, pre) for _ in range(4)]
+            spread = max(float(np.abs(q[0] - rp).max()) for q in runs)
+            self.dev["pose_only_oracle_one_ulp_spread"] = max(self.dev.get("pose_only_oracle_one_ulp_spread", 0.0), spread)
+            ok = float(np.abs(gp - rp).max()) <= 3.0 * spread and any(np.array_equal(go, q[1]) and gi == q[2] for q in runs + [(rp, ro, ri)])
+            assert ok, (f"pose-only call {self.calls['pose_only'] - 1}", np.abs(gp - rp).max(), gi, ri, "oracle one-ulp spread", spread)
         return gp, go, gi
 
     def ba(self, poses, pts, ep, el, obs, fixed, Kt):

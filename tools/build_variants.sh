@@ -7,7 +7,9 @@ P=a-simple-stereo-slam-system-with-deep-loop-closing_amd
 UNIT=$1; shift
 python $P/build.py > /dev/null
 OUT=tools/build/ab; mkdir -p $OUT
-EXTRA="-ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form"
+# the unit's own switches, as build.py compiles it (ba.hip, for one, is built WITHOUT -ffp-contract=off: a variant built with other switches is
+# not comparable with the in-tree library)
+EXTRA=$(python -c "import sys; sys.path.insert(0, '$P'); import build; print(' '.join(build.UNITS['$UNIT']))")
 for spec in "$@"; do
   name=${spec%%:*}; defs=${spec#*:}
   (
