@@ -632,6 +632,7 @@ def ba_optimize_active_map(poses, points, edge_pose, edge_pt, obs, fixed, K, del
 
 
 BA_OPT_LANDMARKS_IN_HBM = 1
+BA_OPT_BUILD_POSE_ATOMICS = 2
 
 
 def ba_set_option(option, value):

@@ -113,19 +113,29 @@ __device__ __forceinline__ double bcast_lane(double v, int srcLane) {       // s
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), srcLane), __builtin_amdgcn_readlane(__double2loint(v), srcLane));
 }
 
-// Block build of one window with ONE evaluation per edge and a fixed summation order (two runs give the same bits):
+// Block build of one window with a fixed summation order (two runs give the same bits):
 //   landmark blocks  the edges of a landmark normally form one contiguous run (the order Backend::OptimizeActiveMap emits them,
 //                    backend.cpp:166-206): a lane pair walks the run (one half each), sums Hll / bl in registers and writes the
 //                    edges' chi2 and Hpl;
-//   pose blocks      the same lanes add each edge's 27 pose terms into ITS WAVE's private copy of the pose blocks in LDS
-//                    (ds_add_f64: lanes of one instruction that hit the same address are served in lane order, instructions in
-//                    program order — nothing depends on how the four waves interleave); the four copies are added in wave order.
-//   A landmark whose edges are scattered over several runs takes the slow road: its edges are evaluated one per thread (pose terms
-//   as above) and its block is summed by one thread scanning the edge list in order.
+//   pose blocks      LISTS (the default): the window's edges are counting-sorted by pose into an index list in LDS (integer ballots and
+//                    prefix sums: a pose's edges in edge order), then ONE WAVE PER POSE walks its list — lane l takes entries l, l + 64, … —,
+//                    evaluates each edge a second time and keeps the 27 pose terms (upper triangle of w Jx^T Jx, -w Jx^T e) in registers;
+//                    the 27 wave sums are taken together by halving (wave_sum32_halving) and go straight to Hpp / bp.  Round 5: the
+//                    earlier form added every edge's 27 terms into per-wave LDS copies with ds_add_f64 — 81 k atomic lane operations
+//                    per window, most of them on the SAME few addresses (a landmark's run visits the poses in order, so half of a
+//                    wave's lanes hit one pose at a time): the LDS pipe of the CU serialised them and was what the kernel waited for.
+//                    A second evaluation of an edge (~100 f64 operations) is cheaper for a LONE window (63 -> 44 us; with the window's
+//                    arrays staged in LDS first, see below, less); a batch of 512 windows is not bound there (0.167 -> 0.181 ms) and stays
+//                    on the earlier form.
+//                    !LISTS (batches, and windows whose arrays do not fit LDS): the earlier form — the same lanes add each edge's 27
+//                    pose terms into ITS WAVE's private copy of the pose blocks in LDS (ds_add_f64: lanes of one instruction that hit
+//                    the same address are served in lane order, instructions in program order — nothing depends on how the waves
+//                    interleave); the copies are added in wave order.
+//   A landmark whose edges are scattered over several runs takes the slow road: its edges are evaluated one per thread and its block
+//   is summed by one thread scanning the edge list in order.
 //   NT = threads per window: 256 for batches (one block per window fills the chip), 1024 for a handful of windows (a live stream builds ONE
-//   window per key-frame: every landmark's lane pair then exists at once — 83 -> ~30 us per window).  One copy of the pose blocks per
-//   wave either way, merged in wave order: each variant is bit-reproducible, the two differ in the last bits (both 1e-11 from the oracle).
-template <int NT>
+//   window per key-frame: every landmark's lane pair then exists at once).
+template <int NT, bool LISTS>
 __global__ __launch_bounds__(NT) void k_ba_build(BaArgs a) {
     MYSLAM_SIDE_PRIO();
     constexpr int NW = NT / 64;
@@ -138,20 +148,38 @@ __global__ __launch_bounds__(NT) void k_ba_build(BaArgs a) {
     const bool oversize = P < 0 || L < 0 || E < 0 || P > a.maxP || L > a.maxL || E > a.maxE;
     if (oversize) { P = 0; L = 0; E = 0; if (t == 0) a.chi2[(size_t)w * a.maxE] = -1.0; }
     double* sR = s_d;                                           // maxP x 12 (R row-major, t)
-    double* sAcc = sR + a.maxP * 12;                            // NW waves x maxP x 27 (6x6 upper triangle row-major, then b)
-    int* s_runs = reinterpret_cast<int*>(sAcc + NW * a.maxP * 27);      // maxL: contiguous runs of each landmark in the edge list
+    double* sAcc = sR + a.maxP * 12;                            // !LISTS: NW waves x maxP x 27 (6x6 upper triangle row-major, then b)
+    double* s_obs = sAcc;                                       // LISTS: maxE x 2 — the window's observations, landmarks and edge indices are
+    double* s_pts = s_obs + 2 * a.maxE;                         //        staged once (coalesced): a lone window's time is a chain of dependent loads
+    int* s_runs = reinterpret_cast<int*>(LISTS ? s_pts + 3 * a.maxL : sAcc + NW * a.maxP * 27);   // maxL: contiguous runs of each landmark in the edge list
     int* s_start = s_runs + a.maxL;                             // maxL: first edge of the landmark's run (meaningful when it has exactly one)
     int* s_len = s_start + a.maxL;                              // maxL: length of that run
+    const int nch = (a.maxE + 63) >> 6;                         // LISTS: chunks of 64 consecutive edges
+    int* s_cnt = s_len + a.maxL;                                // LISTS: maxP x nch — edges of pose p in chunk c, then their exclusive prefix
+    int* s_ptot = s_cnt + a.maxP * nch;                         // LISTS: maxP — edges of pose p
+    int* s_poff = s_ptot + a.maxP;                              // LISTS: maxP — where pose p's entries start in the list
+    int* s_list = s_poff + a.maxP;                              // LISTS: maxE — edge indices grouped by pose, edge order within a pose
+    int* s_el = s_list + a.maxE;                                // LISTS: maxE
+    int* s_ep = s_el + a.maxE;                                  // LISTS: maxE
     const double* poses = a.poses + (size_t)w * a.maxP * 7;
-    const double* pts = a.points + (size_t)w * a.maxL * 3;
-    const int32_t* ep = a.ep + (size_t)w * a.maxE;
-    const int32_t* el = a.el + (size_t)w * a.maxE;
-    const double* obs = a.obs + (size_t)w * a.maxE * 2;
+    const double* gpts = a.points + (size_t)w * a.maxL * 3;
+    const int32_t* gep = a.ep + (size_t)w * a.maxE;
+    const int32_t* gel = a.el + (size_t)w * a.maxE;
+    const double* gobs = a.obs + (size_t)w * a.maxE * 2;
+    const double* pts = LISTS ? s_pts : gpts;
+    const int32_t* ep = LISTS ? s_ep : gep;
+    const int32_t* el = LISTS ? s_el : gel;
+    const double* obs = LISTS ? s_obs : gobs;
     const uint8_t* fixed = a.fixed ? a.fixed + (size_t)w * a.maxL : nullptr;
     const double d2 = a.delta * a.delta;
     double* myAcc = sAcc + (size_t)wv * a.maxP * 27;
 
-    for (int i = t; i < NW * a.maxP * 27; i += NT) sAcc[i] = 0.0;
+    if (LISTS) {
+        for (int i = t; i < E; i += NT) { s_el[i] = gel[i]; s_ep[i] = gep[i]; }
+        for (int i = t; i < 2 * E; i += NT) s_obs[i] = gobs[i];
+        for (int i = t; i < 3 * L; i += NT) s_pts[i] = gpts[i];
+    } else
+        for (int i = t; i < NW * a.maxP * 27; i += NT) sAcc[i] = 0.0;
     for (int l = t; l < L; l += NT) s_runs[l] = 0;
     for (int p = t; p < P; p += NT) {
         double x = poses[7 * p], y = poses[7 * p + 1], z = poses[7 * p + 2], q = poses[7 * p + 3];
@@ -174,8 +202,49 @@ __global__ __launch_bounds__(NT) void k_ba_build(BaArgs a) {
             if (earlier == 0) { s_start[il] = k; s_len[il] = n; }      // one writer per landmark (a landmark with several runs does not use these)
         }
     }
+    if (LISTS) {
+        // counting sort of the well-formed edges by pose.  Pass 1: per chunk of 64 edges and pose, the number of edges (a ballot per pose).
+        const int lane = t & 63, nchE = (E + 63) >> 6;
+        for (int c = wv; c < nchE; c += NW) {
+            const int k = c * 64 + lane;
+            int ip = -1;
+            if (k < E) { const int il = el[k]; ip = (il >= 0 && il < L) ? ep[k] : -1; }
+            for (int p = 0; p < P; p++) {
+                const unsigned long long m = __ballot(ip == p);
+                if (lane == 0) s_cnt[p * nch + c] = __popcll(m);
+            }
+        }
+        __syncthreads();
+        // exclusive prefix over the chunks of each pose (a wave per pose, 64 chunks per step) and the pose totals
+        for (int p = wv; p < P; p += NW) {
+            int carry = 0;
+            for (int c0 = 0; c0 < nchE; c0 += 64) {
+                const int c = c0 + lane;
+                const int v = c < nchE ? s_cnt[p * nch + c] : 0;
+                int incl = v;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(incl, d, 64); if (lane >= d) incl += u; }
+                if (c < nchE) s_cnt[p * nch + c] = carry + incl - v;
+                carry += __shfl(incl, 63, 64);
+            }
+            if (lane == 0) s_ptot[p] = carry;
+        }
+        __syncthreads();
+        if (t < P) { int o = 0; for (int q = 0; q < t; q++) o += s_ptot[q]; s_poff[t] = o; }
+        __syncthreads();
+        // Pass 2: every edge to its slot (pose start + edges of the pose in earlier chunks + rank in its chunk)
+        for (int c = wv; c < nchE; c += NW) {
+            const int k = c * 64 + lane;
+            int ip = -1;
+            if (k < E) { const int il = el[k]; ip = (il >= 0 && il < L) ? ep[k] : -1; }
+            for (int p = 0; p < P; p++) {
+                const unsigned long long m = __ballot(ip == p);
+                if (ip == p) s_list[s_poff[p] + s_cnt[p * nch + c] + __popcll(m & ((1ull << lane) - 1ull))] = k;
+            }
+        }
+    }
     __syncthreads();
-    // one edge: chi2, Hpl, the pose terms into this wave's copy; hl (may be null) collects the landmark terms
+    // one edge: chi2, Hpl, (!LISTS) the pose terms into this wave's copy; hl (may be null) collects the landmark terms
     auto edge = [&](int k, int il, double* hl) {
         double* hpl = a.Hpl + ((size_t)w * a.maxE + k) * 18;
         const int ip = ep[k];
@@ -190,15 +259,17 @@ __global__ __launch_bounds__(NT) void k_ba_build(BaArgs a) {
         const double e2 = e0 * e0 + e1 * e1;
         a.chi2[(size_t)w * a.maxE + k] = e2;
         const double wgt = (e2 <= d2) ? 1.0 : a.delta / sqrt(e2);   // Huber rho'
-        double* hp = myAcc + 27 * ip;
-        int u = 0;
+        if (!LISTS) {
+            double* hp = myAcc + 27 * ip;
+            int u = 0;
 #pragma unroll
-        for (int r = 0; r < 6; r++) {
+            for (int r = 0; r < 6; r++) {
 #pragma unroll
-            for (int c = r; c < 6; c++) atomicAdd(&hp[u++], wgt * (J[r] * J[c] + J[6 + r] * J[6 + c]));
+                for (int c = r; c < 6; c++) atomicAdd(&hp[u++], wgt * (J[r] * J[c] + J[6 + r] * J[6 + c]));
+            }
+#pragma unroll
+            for (int r = 0; r < 6; r++) atomicAdd(&hp[21 + r], -wgt * (J[r] * e0 + J[6 + r] * e1));
         }
-#pragma unroll
-        for (int r = 0; r < 6; r++) atomicAdd(&hp[21 + r], -wgt * (J[r] * e0 + J[6 + r] * e1));
         const bool fx_pt = fixed && fixed[il];
         if (hl && !fx_pt) {
             int v = 0;
@@ -268,8 +339,44 @@ __global__ __launch_bounds__(NT) void k_ba_build(BaArgs a) {
             }
         lm_store(il, hl);
     }
+    if (LISTS) {
+        // pose blocks: a wave per pose walks the pose's edge list; nothing here depends on the passes above except the list
+        const int lane = t & 63;
+        for (int p = wv; p < P; p += NW) {
+            const int n = s_ptot[p], o = s_poff[p];
+            double h[32];
+#pragma unroll
+            for (int u = 0; u < 32; u++) h[u] = 0.0;
+            for (int i = lane; i < n; i += 64) {
+                const int k = s_list[o + i];
+                double e0, e1, J[12], Jp[6];
+                ba_edge(sR + 12 * p, pts + 3 * el[k], obs + 2 * k, a.fx, a.fy, a.cx, a.cy, e0, e1, J, Jp);
+                const double e2 = e0 * e0 + e1 * e1;
+                const double wgt = (e2 <= d2) ? 1.0 : a.delta / sqrt(e2);   // Huber rho'
+                int u = 0;
+#pragma unroll
+                for (int r = 0; r < 6; r++) {
+#pragma unroll
+                    for (int c = r; c < 6; c++) h[u++] += wgt * (J[r] * J[c] + J[6 + r] * J[6 + c]);
+                }
+#pragma unroll
+                for (int r = 0; r < 6; r++) h[21 + r] += -wgt * (J[r] * e0 + J[6 + r] * e1);
+            }
+            wave_sum32_halving(h, lane);                        // lane l: the total of value l >> 1
+            const int u = lane >> 1;
+            if (!(lane & 1) && u < 27) {
+                if (u < 21) {
+                    const int r = (u >= 6) + (u >= 11) + (u >= 15) + (u >= 18) + (u >= 20);
+                    const int c = r + u - (r * 6 - r * (r - 1) / 2);
+                    double* H = a.Hpp + ((size_t)w * a.maxP + p) * 36;
+                    H[r * 6 + c] = h[0]; H[c * 6 + r] = h[0];
+                } else a.bp[((size_t)w * a.maxP + p) * 6 + (u - 21)] = h[0];
+            }
+        }
+        return;
+    }
     __syncthreads();
-    // pose blocks: the four wave copies in wave order
+    // pose blocks: the wave copies in wave order
     for (int i = t; i < P * 36; i += NT) {
         const int p = i / 36, r = (i % 36) / 6, c = i % 6;
         const int rr = min(r, c), cc = max(r, c);
@@ -1199,22 +1306,38 @@ __global__ __launch_bounds__(NT) void k_pose_only(PoseOnlyArgs a) {
     }
 }
 
-static size_t ba_lds(int maxP, int maxL, int nwaves) { return sizeof(double) * ((size_t)maxP * (12 + nwaves * 27)) + sizeof(int) * 3 * (size_t)maxL; }
+// nwaves == 0: the pose-list form (no per-wave copies of the pose blocks; chunk counts, pose totals / starts and the edge list instead)
+static std::atomic<int> g_ba_build_pose_atomics{0};      // MYSLAM_BA_OPT_BUILD_POSE_ATOMICS
+static size_t ba_lds(int maxP, int maxL, int maxE, int nwaves) {
+    const size_t lists = nwaves ? 0 : (size_t)maxP * (((size_t)maxE + 63) / 64) + 2 * (size_t)maxP + 3 * (size_t)maxE;
+    const size_t staged = nwaves ? 0 : 2 * (size_t)maxE + 3 * (size_t)maxL;
+    return sizeof(double) * ((size_t)maxP * (12 + nwaves * 27) + staged) + sizeof(int) * (3 * (size_t)maxL + lists);
+}
 
 constexpr int BA_WIDE_BELOW = 32;      // fewer windows than this per call: 1024 threads per window (latency), else 256 (throughput)
 
 static int ba_launch(const BaArgs& a, int nwin, hipStream_t s) {
-    const bool wide = nwin < BA_WIDE_BELOW && ba_lds(a.maxP, a.maxL, 16) <= 150 * 1024;
-    const size_t lds = ba_lds(a.maxP, a.maxL, wide ? 16 : 4);
+    // a handful of windows (a live stream's key-frame): 1024 threads per window and, when the window fits LDS, the pose-list form.  Batches keep
+    // 256 threads and the ds_add_f64 form: with two blocks per CU their time is the latency of a few resident waves either way, and the second
+    // evaluation only adds to it (512 windows: 0.167 ms against 0.181, tools/ba_build_time.py).
+    const bool wide_req = nwin < BA_WIDE_BELOW;
+    const bool lists = wide_req && !g_ba_build_pose_atomics.load() && ba_lds(a.maxP, a.maxL, a.maxE, 0) <= 150 * 1024;
+    const bool wide = wide_req && (lists || ba_lds(a.maxP, a.maxL, a.maxE, 16) <= 150 * 1024);
+    const size_t lds = ba_lds(a.maxP, a.maxL, a.maxE, lists ? 0 : wide ? 16 : 4);
     if (lds > 150 * 1024) return MYSLAM_ERR_CAPACITY;
     // (the limit is state of the function, not of the launch: always raised to what any plan may need — see launch_octree)
-    static const bool raised256 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
-    static const bool raised1024 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
-    const bool raised = raised256 && raised1024;
+    static const bool raised = [] {
+        bool ok = true;
+        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
+        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
+        ok &= hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_build<1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
+        return ok;
+    }();
     (void)raised;
     ScopedProf sp(P_BA, s);
-    if (wide) hipLaunchKernelGGL(k_ba_build<1024>, dim3(nwin), dim3(1024), lds, s, a);
-    else hipLaunchKernelGGL(k_ba_build<256>, dim3(nwin), dim3(256), lds, s, a);
+    if (lists) hipLaunchKernelGGL((k_ba_build<1024, true>), dim3(nwin), dim3(1024), lds, s, a);
+    else if (wide) hipLaunchKernelGGL((k_ba_build<1024, false>), dim3(nwin), dim3(1024), lds, s, a);
+    else hipLaunchKernelGGL((k_ba_build<256, false>), dim3(nwin), dim3(256), lds, s, a);
     MYSLAM_HIP_CHECK(hipGetLastError());
     return MYSLAM_OK;
 }
@@ -1300,6 +1423,7 @@ int myslam_ba_optimize(double* poses, int nposes, double* points, int npts, cons
 }
 
 int myslam_ba_set_option(int option, int value) {
+    if (option == MYSLAM_BA_OPT_BUILD_POSE_ATOMICS) { if (value < 0 || value > 1) return MYSLAM_ERR_INVALID; g_ba_build_pose_atomics.store(value); return MYSLAM_OK; }
     if (option == MYSLAM_BA_OPT_LANDMARKS_IN_HBM) { if (value < 0 || value > 1) return MYSLAM_ERR_INVALID; g_ba_landmarks_in_hbm.store(value); return MYSLAM_OK; }
     return MYSLAM_ERR_INVALID;
 }

@@ -438,6 +438,11 @@ int myslam_ba_optimize_active_map_batch(double* d_poses, double* d_points, const
  * window's HBM scratch (81 KB of LDS: the form for a solve that runs BESIDE other kernels, e.g. on the Backend's stream under the
  * extractor — its CU keeps room for their blocks).  d_scratch sizes are the same in both forms. */
 #define MYSLAM_BA_OPT_LANDMARKS_IN_HBM 1
+/* MYSLAM_BA_OPT_BUILD_POSE_ATOMICS (block build, myslam_ba_build[_batch]): 0 (default) = calls of fewer than 32 windows stage a window's arrays in
+ * LDS and sum the pose blocks by one wave per pose over a counting-sorted edge list whenever that fits (33 bytes of LDS per edge slot + 24 per
+ * landmark slot); 1 = always the form batches use (every edge's 27 pose terms added into per-wave LDS copies with ds_add_f64).  Both forms are
+ * bit-reproducible; they differ from each other in the last bits of Hpp / bp (another summation order), in nothing else. */
+#define MYSLAM_BA_OPT_BUILD_POSE_ATOMICS 2
 int myslam_ba_set_option(int option, int value);
 
 /* ------------------------------------------------------------------------------------------

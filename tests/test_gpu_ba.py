@@ -280,6 +280,82 @@ def test_ba_build_is_bit_reproducible_and_order_tolerant(api, oracle, synth):
         api.ba_build(poses, pts, bad, el2, obs2, fixed, K)
 
 
+def _build_batch(api, probs, W, maxP, maxL, maxE):
+    """one problem replicated into W slots of a batch with the given capacities -> numpy outputs of slot 0 and whether all slots agree"""
+    import torch
+    p, x, a, b, o, f, K = probs
+    P, L, E = len(p), len(x), len(a)
+    poses = np.zeros((W, maxP, 7)); poses[..., 3] = 1; poses[:, :P] = p
+    pts = np.zeros((W, maxL, 3)); pts[:, :L] = x
+    ep = np.zeros((W, maxE), np.int32); ep[:, :E] = a
+    el = np.zeros((W, maxE), np.int32); el[:, :E] = b
+    obs = np.zeros((W, maxE, 2)); obs[:, :E] = o
+    fixed = np.zeros((W, maxL), np.uint8); fixed[:, :L] = f
+    sizes = np.tile(np.array([P, L, E], np.int32), (W, 1))
+    d = [torch.from_numpy(v).cuda() for v in (poses, pts, ep, el, obs, fixed, sizes)]
+    out = [torch.zeros(W, n, dtype=torch.float64, device="cuda") for n in (maxP * 36, maxL * 9, maxE * 18, maxP * 6, maxL * 3, maxE)]
+    api.ba_build_batch(*[t.data_ptr() for t in d], W, maxP, maxL, maxE, K, 5.991, *[t.data_ptr() for t in out],
+                       torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    same = all(torch.equal(t.view(torch.int64), t[:1].expand_as(t).contiguous().view(torch.int64)) for t in out)
+    o0 = [t[0].cpu().numpy() for t in out]
+    return (o0[0][:P * 36].reshape(P, 6, 6), o0[1][:L * 9].reshape(L, 3, 3), o0[2][:E * 18].reshape(E, 6, 3), o0[3][:P * 6].reshape(P, 6),
+            o0[4][:L * 3].reshape(L, 3), o0[5][:E]), same
+
+
+def test_ba_build_pose_list_form_and_atomic_form(api, oracle, synth):
+    """Round 5: calls of fewer than 32 windows (a live stream builds ONE window per key-frame) stage the window in LDS and sum the pose blocks by
+    one wave per pose over a counting-sorted edge list (csrc/ba.hip k_ba_build<1024, true>); batches, windows that do not fit LDS (here: a
+    capacity of 40 000 edges) and MYSLAM_BA_OPT_BUILD_POSE_ATOMICS take the ds_add_f64 form.  All give the oracle's blocks; everything but the
+    pose blocks is the same code and must agree bit for bit."""
+    prob = synth.ba_problem(seed=21, n_kf=9, n_mp=280)
+    ref = oracle.ba_build(*prob[:6], prob[6])
+    names = ["Hpp", "Hll", "Hpl", "bp", "bl", "chi2"]
+    wide, same_w = _build_batch(api, prob, 3, 10, 300, 3000)          # 3 windows: the list form
+    narrow, same_n = _build_batch(api, prob, 40, 10, 300, 3000)       # 40 windows: 256 threads each, atomic form
+    assert same_w and same_n
+    for got in (wide, narrow):
+        for g, r, name in zip(got, ref, names):
+            _close(g, r, name)
+    for k in (1, 2, 4, 5):                                            # landmark blocks, Hpl, chi2: the same arithmetic in both forms
+        assert wide[k].tobytes() == narrow[k].tobytes()
+    for W in (2, 33):                                                 # the list does not fit: atomic form, both block sizes
+        got, same = _build_batch(api, prob, W, 10, 300, 40000)
+        assert same
+        for g, r, name in zip(got, ref, names):
+            _close(g, r, name)
+    api.ba_set_option(api.BA_OPT_BUILD_POSE_ATOMICS, 1)              # the same form by option, 1024 threads
+    try:
+        got, same = _build_batch(api, prob, 3, 10, 300, 3000)
+    finally:
+        api.ba_set_option(api.BA_OPT_BUILD_POSE_ATOMICS, 0)
+    assert same
+    for g, r, name in zip(got, ref, names):
+        _close(g, r, name)
+    for k in (1, 2, 4, 5):
+        assert got[k].tobytes() == wide[k].tobytes()
+    assert got[0].tobytes() != wide[0].tobytes() or got[3].tobytes() != wide[3].tobytes()      # it really was another form
+    for E_cap, L_cap in ((2600, 280), (2999, 333)):                   # capacities that are no multiples of anything (LDS layout, alignment)
+        got, same = _build_batch(api, prob, 1, 9, L_cap, E_cap)
+        assert same
+        for g, r, name in zip(got, ref, names):
+            _close(g, r, name)
+    # scattered edges and malformed edges (skipped by the batch entry point) through the list form
+    rng = np.random.default_rng(8)
+    p, x, a, b, o, f, K = prob
+    perm = rng.permutation(len(a))
+    a2, b2, o2 = a[perm].copy(), b[perm].copy(), o[perm].copy()
+    bad = rng.choice(len(a2), 40, replace=False)
+    a2[bad[:20]] = -1; b2[bad[20:30]] = len(x) + 5; a2[bad[30:]] = len(p)
+    keep = np.ones(len(a2), bool); keep[bad] = False
+    got, same = _build_batch(api, (p, x, a2, b2, o2, f, K), 2, 10, 300, 3000)
+    assert same
+    want = oracle.ba_build(p, x, a2[keep], b2[keep], o2[keep], f, K)
+    _close(got[0], want[0], "Hpp"); _close(got[1], want[1], "Hll"); _close(got[3], want[3], "bp"); _close(got[4], want[4], "bl")
+    _close(got[2][keep], want[2], "Hpl"); _close(got[5][keep], want[5], "chi2")
+    assert not got[2][~keep].any() and not got[5][~keep].any()
+
+
 def test_chaotic_window_is_pinned(api, oracle):
     """tests/golden/ba_chaotic_window.npz (tools/gpu_fuzz_ba.py seed 5300, case 637): 4 key-frames x 25 landmarks, 62 of 96 edges gross
     outliers, every one of the five rounds fails the inlier test (backend.cpp:212-232) — 50 Levenberg iterations on data no pose explains.
