@@ -1314,14 +1314,21 @@ static size_t ba_lds(int maxP, int maxL, int maxE, int nwaves) {
     return sizeof(double) * ((size_t)maxP * (12 + nwaves * 27) + staged) + sizeof(int) * (3 * (size_t)maxL + lists);
 }
 
-constexpr int BA_WIDE_BELOW = 32;      // fewer windows than this per call: 1024 threads per window (latency), else 256 (throughput)
+#ifndef MYSLAM_BA_WIDE_BELOW           // A/B builds (tools/build_variants.sh)
+#define MYSLAM_BA_WIDE_BELOW 32
+#endif
+#ifndef MYSLAM_BA_LISTS_BELOW
+#define MYSLAM_BA_LISTS_BELOW 32
+#endif
+constexpr int BA_WIDE_BELOW = MYSLAM_BA_WIDE_BELOW;      // fewer windows than this per call: 1024 threads per window (latency), else 256 (throughput)
+constexpr int BA_LISTS_BELOW = MYSLAM_BA_LISTS_BELOW;    // fewer windows than this per call: the staged pose-list form when it fits LDS
 
 static int ba_launch(const BaArgs& a, int nwin, hipStream_t s) {
     // a handful of windows (a live stream's key-frame): 1024 threads per window and, when the window fits LDS, the pose-list form.  Batches keep
     // 256 threads and the ds_add_f64 form: with two blocks per CU their time is the latency of a few resident waves either way, and the second
     // evaluation only adds to it (512 windows: 0.167 ms against 0.181, tools/ba_build_time.py).
     const bool wide_req = nwin < BA_WIDE_BELOW;
-    const bool lists = wide_req && !g_ba_build_pose_atomics.load() && ba_lds(a.maxP, a.maxL, a.maxE, 0) <= 150 * 1024;
+    const bool lists = wide_req && nwin < BA_LISTS_BELOW && !g_ba_build_pose_atomics.load() && ba_lds(a.maxP, a.maxL, a.maxE, 0) <= 150 * 1024;
     const bool wide = wide_req && (lists || ba_lds(a.maxP, a.maxL, a.maxE, 16) <= 150 * 1024);
     const size_t lds = ba_lds(a.maxP, a.maxL, a.maxE, lists ? 0 : wide ? 16 : 4);
     if (lds > 150 * 1024) return MYSLAM_ERR_CAPACITY;

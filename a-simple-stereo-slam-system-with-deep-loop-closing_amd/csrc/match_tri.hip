@@ -29,7 +29,11 @@ namespace myslam_hip {
 // (History: xor / popcount on the VALU ran at its issue peak, 1.00 ms per 512 pairs; int8 MFMA 0.40 ms; this FP4 form 0.23 ms.)
 constexpr int HQ_TILES = 4;                       // query tiles of 32 per wave -> 512 queries per block
 constexpr int HQ_BLOCK = 4 * HQ_TILES * 32;
-constexpr int HQ_NARROW_BELOW = 16;               // fewer pairs than this per call: one query tile per wave (k_hamming_fp4<1>)
+constexpr int HQ_NARROW_BELOW = 16;               // fewer pairs than this per call: one query tile per wave (k_hamming_fp4<1, HQ_SPLIT>)
+#ifndef MYSLAM_HQ_SPLIT                           // A/B builds (tools/build_variants.sh)
+#define MYSLAM_HQ_SPLIT 4
+#endif
+constexpr int HQ_SPLIT = MYSLAM_HQ_SPLIT;         // ... and this many wave groups per block, each on every HQ_SPLIT-th train chunk
 
 // The product runs on the FP4 path of the matrix cores (v_mfma_scale_f32_32x32x64_f8f6f4, K = 64 per instruction, twice the int8
 // rate): E2M1 represents +-1 exactly (0x2 / 0xA), the factor 32 of the query operand is its E8M0 block scale (2^5), sums of at most
@@ -42,13 +46,17 @@ constexpr int HF_ROWB = 144;                      // LDS bytes per expanded trai
 // TILES = query tiles of 32 per wave: 4 (512 queries per block) for batches; 1 (128 per block) for a handful of pairs — the block's loop
 // over the train chunks is a chain of barrier-separated steps, and with one tile per wave a step is a quarter as long while four times
 // as many blocks run side by side (one pair of 2 000 x 2 000: 50 -> ~25 us).  Same bits either way (integer arg-min, ties by row).
-template <int TILES>
-__global__ __launch_bounds__(256) void k_hamming_fp4(const uint8_t* __restrict__ q, const int32_t* __restrict__ nqv,
+// SPLIT = groups of 4 waves per block, each taking every SPLIT-th train chunk for the block's queries (round 5, one-pair calls: 16 blocks
+// walk 63 chunks as a chain of barrier-separated steps — 32 us on 16 of 256 CUs; with 4 groups the chain is 16 steps and the groups' keys
+// merge through LDS at the end.  The key is an integer maximum: the same bits whatever the split).
+template <int TILES, int SPLIT = 1>
+__global__ __launch_bounds__(256 * SPLIT) void k_hamming_fp4(const uint8_t* __restrict__ q, const int32_t* __restrict__ nqv,
                                                      const uint8_t* __restrict__ tr, const int32_t* __restrict__ ntv,
                                                      int cap, int nq_single, int nt_single,
                                                      int32_t* __restrict__ out_idx, int32_t* __restrict__ out_dist) {
     MYSLAM_SIDE_PRIO();
-    __shared__ __attribute__((aligned(16))) uint8_t s_exp[2][32 * HF_ROWB];
+    __shared__ __attribute__((aligned(16))) uint8_t s_exp[SPLIT][2][32 * HF_ROWB];
+    __shared__ uint32_t s_key[SPLIT > 1 ? SPLIT : 1][SPLIT > 1 ? 128 * TILES : 1];
     __shared__ uint32_t s_lut[256];                // byte -> 8 FP4 codes (bit i -> nibble i): bit 1 -> -1.0 (0xA), bit 0 -> +1.0 (0x2)
     const int p = blockIdx.y;
     const int nq = nqv ? min(nqv[p], cap) : nq_single;
@@ -56,8 +64,9 @@ __global__ __launch_bounds__(256) void k_hamming_fp4(const uint8_t* __restrict__
     constexpr int QBLOCK = 4 * TILES * 32;
     const int q0 = blockIdx.x * QBLOCK;
     if (q0 >= nq) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    {
+    const int grp = SPLIT > 1 ? (int)threadIdx.x >> 8 : 0;      // train split of this wave group
+    const int tid = threadIdx.x & 255, lane = tid & 63, wv = tid >> 6;
+    if (grp == 0) {
         uint32_t v = 0;
         for (int i = 0; i < 8; i++) v |= (((tid >> i) & 1) ? 0xAu : 0x2u) << (4 * i);
         s_lut[tid] = v;
@@ -91,16 +100,19 @@ __global__ __launch_bounds__(256) void k_hamming_fp4(const uint8_t* __restrict__
 #pragma unroll
     for (int t = 0; t < TILES; t++) { bestv[t] = -(1 << 30); bestor[t] = -(1 << 30); bestc[t] = 0; }
     const int er = tid >> 3, ed = tid & 7;                   // expansion job: dword ed of chunk row er
-    auto expand = [&](int buf, uint32_t w) { *reinterpret_cast<uint4*>(&s_exp[buf][er * HF_ROWB + ed * 16]) = expand32(w); };
+    auto expand = [&](int buf, uint32_t w) { *reinterpret_cast<uint4*>(&s_exp[grp][buf][er * HF_ROWB + ed * 16]) = expand32(w); };
     const int nchunk = (nt + 31) >> 5;
-    uint32_t wnext = (er < nt) ? T[(size_t)er * 8 + ed] : 0u;
-    if (nchunk > 0) expand(0, wnext);
-    for (int c = 0; c < nchunk; c++) {
+    const int nstep = (nchunk + SPLIT - 1) / SPLIT;          // block-uniform: every group meets every barrier
+    uint32_t wnext = (32 * grp + er < nt) ? T[(size_t)(32 * grp + er) * 8 + ed] : 0u;
+    if (grp < nchunk) expand(0, wnext);
+    for (int i = 0; i < nstep; i++) {
+        const int c = i * SPLIT + grp;                       // this group's chunk of the step (may lie past the end)
         const int t0 = c << 5;
-        if (c + 1 < nchunk) { const int row = t0 + 32 + er; wnext = (row < nt) ? T[(size_t)row * 8 + ed] : 0u; }
+        if (c + SPLIT < nchunk) { const int row = t0 + 32 * SPLIT + er; wnext = (row < nt) ? T[(size_t)row * 8 + ed] : 0u; }
         __syncthreads();
-        if (c + 1 < nchunk) expand((c + 1) & 1, wnext);
-        const uint8_t* sb = &s_exp[c & 1][(lane & 31) * HF_ROWB + (lane >> 5) * 16];
+        if (c + SPLIT < nchunk) expand((i + 1) & 1, wnext);
+        if (c >= nchunk) continue;
+        const uint8_t* sb = &s_exp[grp][i & 1][(lane & 31) * HF_ROWB + (lane >> 5) * 16];
         hq_v8i A[4];
 #pragma unroll
         for (int m = 0; m < 4; m++) {
@@ -130,9 +142,16 @@ __global__ __launch_bounds__(256) void k_hamming_fp4(const uint8_t* __restrict__
         const int dot = bestv[t] >> 5, row = 31 - (bestv[t] & 31);
         const uint32_t key = bestv[t] < -(1 << 20) ? 0u
                                                      : ((uint32_t)(dot + 256) << 20) | (0xfffffu - (uint32_t)(bestc[t] * 32 + row));
-        const uint32_t b = max(key, (uint32_t)__shfl_xor((int)key, 32, 64));
+        uint32_t b = max(key, (uint32_t)__shfl_xor((int)key, 32, 64));
+        if (SPLIT > 1) {                                     // the groups' keys of this query: maximum through LDS, written by group 0
+            if (lane < 32) s_key[grp][(wv * TILES + t) * 32 + lane] = b;
+            __syncthreads();
+            if (grp == 0 && lane < 32)
+#pragma unroll
+                for (int g2 = 1; g2 < SPLIT; g2++) b = max(b, s_key[g2][(wv * TILES + t) * 32 + lane]);
+        }
         const int qi = qb + 32 * t + lane;
-        if (lane < 32 && qi < nq) {
+        if (grp == 0 && lane < 32 && qi < nq) {
             const bool any = nt > 0;
             out_idx[(size_t)p * cap + qi] = any ? (int32_t)(0xfffffu - (b & 0xfffffu)) : -1;
             out_dist[(size_t)p * cap + qi] = any ? (int32_t)((512u - (b >> 20)) >> 1) : -1;
@@ -250,7 +269,7 @@ int myslam_hamming_match_batch(const uint8_t* d_q, const int32_t* d_nq, const ui
     hipStream_t s = (hipStream_t)hip_stream;
     ScopedProf sp(P_MATCH, s);
     if (batch < HQ_NARROW_BELOW)
-        hipLaunchKernelGGL(k_hamming_fp4<1>, dim3((cap + 127) / 128, batch), dim3(256), 0, s, d_q, d_nq, d_t, d_nt, cap, 0, 0, d_train_idx, d_dist);
+        hipLaunchKernelGGL((k_hamming_fp4<1, HQ_SPLIT>), dim3((cap + 127) / 128, batch), dim3(256 * HQ_SPLIT), 0, s, d_q, d_nq, d_t, d_nt, cap, 0, 0, d_train_idx, d_dist);
     else
         hipLaunchKernelGGL(k_hamming_fp4<HQ_TILES>, dim3((cap + HQ_BLOCK - 1) / HQ_BLOCK, batch), dim3(256), 0, s, d_q, d_nq, d_t, d_nt, cap, 0, 0,
                            d_train_idx, d_dist);
@@ -275,7 +294,7 @@ int myslam_hamming_match(const uint8_t* query, int nq, const uint8_t* train, int
     int32_t* di = hc.dev<int32_t>(pi); int32_t* dd = hc.dev<int32_t>(pd);
     {
         ScopedProf sp(P_MATCH, hc.stream());
-        hipLaunchKernelGGL(k_hamming_fp4<1>, dim3((nq + 127) / 128, 1), dim3(256), 0, hc.stream(), dq, (const int32_t*)nullptr, dt,
+        hipLaunchKernelGGL((k_hamming_fp4<1, HQ_SPLIT>), dim3((nq + 127) / 128, 1), dim3(256 * HQ_SPLIT), 0, hc.stream(), dq, (const int32_t*)nullptr, dt,
                            (const int32_t*)nullptr, cap, nq, nt, di, dd);
     }
     MYSLAM_HIP_CHECK(hipGetLastError());

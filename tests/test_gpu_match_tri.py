@@ -38,11 +38,15 @@ def test_hamming_on_real_descriptors_and_filter(api, oracle, synth):
     assert np.array_equal(sidx[uniq], uniq)
 
 
-def test_hamming_batch(api, oracle):
+@pytest.mark.parametrize("rep", [1, 4])
+def test_hamming_batch(api, oracle, rep):
+    """5 pairs: fewer than 16 per call = one query tile per wave, four wave groups per block on every fourth train chunk (k_hamming_fp4<1, 4>);
+    20 pairs: the batch form (k_hamming_fp4<4>).  Counts cover: fewer train chunks than wave groups, one row, none."""
     import torch
     rng = np.random.default_rng(3)
-    B, cap = 5, 700
-    nq = np.array([700, 1, 350, 0, 512], np.int32); nt = np.array([650, 700, 2, 10, 0], np.int32)
+    B, cap = 5 * rep, 700
+    nq = np.tile(np.array([700, 1, 350, 0, 512], np.int32), rep); nt = np.tile(np.array([650, 700, 2, 10, 0], np.int32), rep)
+    if rep > 1: nt[5:10] = [33, 64, 65, 127, 129]                     # chunk counts 2, 2, 3, 4, 5
     q = rng.integers(0, 256, (B, cap, 32), dtype=np.uint8); t = rng.integers(0, 256, (B, cap, 32), dtype=np.uint8)
     dq, dt = torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()
     dnq, dnt = torch.from_numpy(nq).cuda(), torch.from_numpy(nt).cuda()
