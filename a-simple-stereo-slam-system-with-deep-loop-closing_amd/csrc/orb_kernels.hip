@@ -1583,6 +1583,9 @@ __device__ __forceinline__ int sel_order_bin(uint32_t pay, int ts) {
 }
 
 constexpr int OCT_WIDE_BELOW = 64;      // batches smaller than this run 512-thread blocks
+// (1024-thread blocks for a lone pair, end of round 5: 42.3 -> 41.1 us in the recorded one-pair chain — the time is the chain of phases, not
+// their width; not kept.  Likewise FAST in strips of 2 cells instead of 4 for a lone pair, so that a block's chain of phases is shorter: its
+// generic item mapping made the launch 91 us instead of 33; not kept.)
 constexpr int OCT_FL = 4;              // candidates in flight per thread in the two candidate passes (8: same time, batched and one-frame)
 template <int OT>
 __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __restrict__ cand,
