@@ -19,6 +19,9 @@
 namespace myslam_hip {
 
 void launch_resize(const ResizeArgs& a, int batch, hipStream_t s);
+void launch_resize_chain(const ResizeArgs* lv, int n, int batch, hipStream_t s);
+bool resize_is_little(const ResizeArgs& a, int batch);
+int resize_chain_max();
 void launch_blur(const BlurArgs& a, int batch, hipStream_t s);
 bool blur_uses_strips(const BlurArgs& a);
 bool resize_uses_strips(const ResizeArgs& a);
@@ -331,11 +334,24 @@ int myslam_orb::build_pyramids(const uint8_t* d_imgs, int batch, int step, size_
                 launch_ingest(src + (size_t)n0 * stride, P.rows, P.cols, step, stride, dst0, P.lv[0].pitch, P.pyrBytes, batch - n0, stream);
             }
         }
-        for (int l = 1; l < nlev; l++) {                       // ComputePyramid, ORBextractor.cpp:1235-1246
+        for (int l = 1; l < nlev;) {                           // ComputePyramid, ORBextractor.cpp:1235-1246
             ScopedProf sp(P_RESIZE, stream);
             ResizeArgs a = level_resize_args(base, l);
             if (l == 1 && n0 > 0) { a.src0 = d_imgs; a.spitch0 = step; a.sstride0 = stride; a.n0 = n0; }
-            launch_resize(a, batch, stream);
+            // launches with little work (a live stream's frame): up to three consecutive levels share one launch (k_resize_chain) — such a
+            // step is bound by the number of its dependent launches
+            ResizeArgs grp[3]; int ng = 0;
+            const int gmax = resize_chain_max();
+            if (gmax > 1 && resize_is_little(a, batch)) {
+                grp[ng++] = a;
+                while (ng < gmax && l + ng < nlev) {
+                    const ResizeArgs nx = level_resize_args(base, l + ng);
+                    if (!resize_is_little(nx, batch)) break;
+                    grp[ng++] = nx;
+                }
+            }
+            if (ng > 1) { launch_resize_chain(grp, ng, batch, stream); l += ng; }
+            else { launch_resize(a, batch, stream); l++; }
         }
     }
     return MYSLAM_OK;

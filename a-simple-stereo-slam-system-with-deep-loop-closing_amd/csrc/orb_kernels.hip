@@ -89,6 +89,59 @@ __global__ __launch_bounds__(256) void k_resize(ResizeArgs a) {
     *reinterpret_cast<uint32_t*>(a.dst + (size_t)b * a.dstride + (size_t)dy * a.dpitch + dx4) = packed;
 }
 
+// K1c: up to RC_MAX consecutive pyramid levels in ONE launch, for launches with little work (a live stream's frame, the one-frame drop-ins).  A
+// recorded one-pair step is bound by the NUMBER of its dependent launches, not by the work in them (tools/node_count_probe.sh: ~4.6 us per
+// graph node whatever it does, chip-wide), and seven of its 24 launches were pyramid levels.  Level l + 1 is written from level l as k_resize
+// does; the threads of level l + 2 do not wait for it: each computes the four pixels of level l + 1 it needs itself (and those of level l + 3
+// the sixteen below) — integer arithmetic, so the value is the one the other thread stores: 5 (21) interpolations per pixel instead of 1, on
+// levels that shrink by 1.44 each, at a batch size where the chip is idle.  Same bits as k_resize / k_resize_strip (tests/test_gpu_fallbacks.py).
+constexpr int RC_MAX = 3;
+struct ResizeChain {
+    const uint8_t* src; int sw, sh, spitch; size_t sstride;      // the level in memory the chain starts from
+    int n;                                                      // levels produced (1 .. RC_MAX)
+    uint8_t* dst[RC_MAX]; int dw[RC_MAX], dh[RC_MAX], dpitch[RC_MAX]; size_t dstride;
+    double scale_x[RC_MAX], scale_y[RC_MAX];                    // of produced level j against level j - 1
+    int blk0[RC_MAX + 1];                                       // first block of produced level j; blk0[n] = blocks per image
+};
+
+// pixel (x, y) of produced level J (J = 0: the level in memory), computed from the level in memory
+template <int J>
+__device__ __forceinline__ int rc_pix(const ResizeChain& c, const uint8_t* S, int x, int y) {
+    if constexpr (J == 0) {
+        return S[(size_t)y * c.spitch + x];
+    } else {
+        const int sw = J == 1 ? c.sw : c.dw[J - 2], sh = J == 1 ? c.sh : c.dh[J - 2];
+        int sx, a0, a1, sy, b0, b1;
+        resize_coord(x, c.scale_x[J - 1], sw, true, sx, a0, a1);
+        resize_coord(y, c.scale_y[J - 1], sh, false, sy, b0, b1);
+        const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
+        const int sx1 = min(sx + 1, sw - 1);                    // at the right border the weight of sx + 1 is 0 (OpenCV clamps fx there)
+        const int r0 = rc_pix<J - 1>(c, S, sx, sy0) * a0 + rc_pix<J - 1>(c, S, sx1, sy0) * a1;
+        const int r1 = rc_pix<J - 1>(c, S, sx, sy1) * a0 + rc_pix<J - 1>(c, S, sx1, sy1) * a1;
+        const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        return min(max(v, 0), 255);
+    }
+}
+
+template <int J>
+__device__ __forceinline__ void rc_store4(const ResizeChain& c, const uint8_t* S, uint8_t* D, int item) {
+    const int dw = c.dw[J - 1], dh = c.dh[J - 1], gpr = (dw + 3) >> 2;
+    const int dy = item / gpr, dx4 = (item - dy * gpr) * 4;
+    if (dy >= dh) return;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) packed |= (uint32_t)rc_pix<J>(c, S, min(dx4 + k, dw - 1), dy) << (8 * k);
+    *reinterpret_cast<uint32_t*>(D + (size_t)dy * c.dpitch[J - 1] + dx4) = packed;      // row pitches are multiples of 64: the padding takes the last group
+}
+
+__global__ __launch_bounds__(256) void k_resize_chain(ResizeChain c) {
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const uint8_t* S = c.src + (size_t)b * c.sstride;
+    if (blk < c.blk0[1]) rc_store4<1>(c, S, c.dst[0] + (size_t)b * c.dstride, blk * 256 + (int)threadIdx.x);
+    else if (blk < c.blk0[2]) rc_store4<2>(c, S, c.dst[1] + (size_t)b * c.dstride, (blk - c.blk0[1]) * 256 + (int)threadIdx.x);
+    else rc_store4<3>(c, S, c.dst[2] + (size_t)b * c.dstride, (blk - c.blk0[2]) * 256 + (int)threadIdx.x);
+}
+
 // K1b: the same arithmetic, register-only column strips.  Lane l owns destination columns 4l..4l+3 of a 256-column strip
 // and walks RS_R destination rows: x coordinates / weights are computed once, every needed source row is sampled once
 // (one unaligned 2-byte load per pixel = the two horizontal taps, v_perm + v_dot2_u32_u16 = the 11-bit interpolation) and
@@ -2582,12 +2635,32 @@ void launch_ingest_clear(const uint8_t* src, int rows, int cols, int step, size_
 // ------------------------------------------------------------------------------------------------
 bool resize_uses_strips(const ResizeArgs& a) { return (double)RS_R * a.scale_y + 2.0 <= (double)RS_MAXR && a.scale_x <= 1.6; }
 
+bool resize_is_little(const ResizeArgs& a, int batch) { return a.n0 == 0 && (size_t)batch * a.dw * a.dh < (size_t)1500000; }
+
+#ifndef MYSLAM_RESIZE_CHAIN_MAX        // A/B builds (tools/build_variants.sh): levels per launch of the small-batch pyramid (1 = a launch per level)
+#define MYSLAM_RESIZE_CHAIN_MAX 3
+#endif
+int resize_chain_max() { return MYSLAM_RESIZE_CHAIN_MAX < RC_MAX ? MYSLAM_RESIZE_CHAIN_MAX : RC_MAX; }
+
+// n consecutive levels (lv[j].src is lv[j - 1].dst), every one of them "little": one launch
+void launch_resize_chain(const ResizeArgs* lv, int n, int batch, hipStream_t s) {
+    ResizeChain c;
+    c.src = lv[0].src; c.sw = lv[0].sw; c.sh = lv[0].sh; c.spitch = lv[0].spitch; c.sstride = lv[0].sstride;
+    c.n = n; c.dstride = lv[0].dstride; c.blk0[0] = 0;
+    for (int j = 0; j < RC_MAX; j++) {
+        const ResizeArgs& a = lv[j < n ? j : n - 1];
+        c.dst[j] = a.dst; c.dw[j] = a.dw; c.dh[j] = a.dh; c.dpitch[j] = a.dpitch; c.scale_x[j] = a.scale_x; c.scale_y[j] = a.scale_y;
+        c.blk0[j + 1] = c.blk0[j] + (j < n ? (((a.dw + 3) / 4) * a.dh + 255) / 256 : 0);
+    }
+    hipLaunchKernelGGL(k_resize_chain, dim3(c.blk0[RC_MAX], batch), dim3(256), 0, s, c);
+}
+
 void launch_resize(const ResizeArgs& a, int batch, hipStream_t s) {
     // register strips cover pyramid scale factors up to 1.25 (rows) / 1.6 (columns); larger steps take the generic kernel — and so do
     // launches with little work (a one-frame call: a level is ~100 strip waves that each walk their band serially, 8.5 us per level and
     // seven dependent levels; one thread per four destination pixels finishes a level in a third of that).  Same arithmetic, bit for bit
     // (tests/test_gpu_fallbacks.py); images read in place (n0 > 0: batched calls only) need the strip form.
-    const bool little = a.n0 == 0 && (size_t)batch * a.dw * a.dh < (size_t)1500000;
+    const bool little = resize_is_little(a, batch);
     if (resize_uses_strips(a) && !little) {
         const int nstrips = (a.dw + 255) / 256, nbands = (a.dh + RS_R - 1) / RS_R;
         const int ngroups = (nbands + RS_NB - 1) / RS_NB;

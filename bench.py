@@ -407,10 +407,11 @@ def main():
                                     P, cap, o["midx"].data_ptr(), o["mdist"].data_ptr(), s_)
             api.triangulate_stereo_batch(o["kps"].data_ptr(), o["kps"].data_ptr() + P * cap * 28, o["midx"].data_ptr(), o["cnt"].data_ptr(), P, cap,
                                          Kt, K["bf"] / K["fx"], o["xyz"].data_ptr(), o["ok"].data_ptr(), s_)
-            if use_lcd:
+            if use_lcd and "lcd" not in skip:
                 ln["lcd"].describe_batch(d_imgs.data_ptr(), P, H, W, W, H * W, o["descr"].data_ptr(), blur_in_place=False)
+            if use_lcd and "db" not in skip:
                 ln["D"].query_batch(o["descr"].data_ptr(), cur_ids[:P], P, o["best"].data_ptr(), o["max"].data_ptr(), o["dbcnt"].data_ptr())
-            if use_ba:
+            if use_ba and "ba" not in skip:
                 api.ba_build_batch(*[t.data_ptr() for t in b_in], P, maxP, maxL, maxE, Kt, 5.991, *[t.data_ptr() for t in o["ba"]], s_)
         ln["body"] = body
         for _ in range(2):                               # eager first: lazy allocations, both FAST-statistics parities

@@ -73,7 +73,7 @@ def test_recorded_step_equals_the_eager_step_bit_for_bit(api, synth, oracle):
     ref = c["snap"]()
     assert int(c["o"]["cnt"].min()) > 100 and int(c["o"]["stat"].abs().sum()) == 0
     graphs = [api.StepGraph.record(s_main.cuda_stream, [s_b.cuda_stream, s_side.cuda_stream], c["body"]) for _ in range(2)]
-    assert all(g.node_count() >= 30 for g in graphs), [g.node_count() for g in graphs]
+    assert all(g.node_count() >= 20 for g in graphs), [g.node_count() for g in graphs]      # (38 before the small-batch pyramid took three levels per launch)
     for k in range(6):                                            # the two recorded steps alternate (FAST statistics ping-pong)
         c["clear"]()
         graphs[k % 2].launch(s_main.cuda_stream)
