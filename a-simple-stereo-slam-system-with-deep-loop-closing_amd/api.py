@@ -305,6 +305,15 @@ def triangulate_stereo_batch(d_kl, d_kr, d_match, d_nl, batch, cap, K, baseline,
                                                  C.c_void_p(stream or None)), "myslam_triangulate_stereo_batch")
 
 
+def hamming_match_triangulate_batch(d_q, d_nq, d_t, d_nt, d_kl, d_kr, batch, cap, K, baseline, d_idx, d_dist, d_xyz, d_ok, stream=0):
+    """myslam_hamming_match_triangulate_batch: match + triangulation of every match, one launch for fewer than 16 pairs."""
+    _check(lib().myslam_hamming_match_triangulate_batch(C.c_void_p(d_q), C.c_void_p(d_nq), C.c_void_p(d_t), C.c_void_p(d_nt), C.c_void_p(d_kl),
+                                                        C.c_void_p(d_kr), batch, cap, C.c_double(K[0]), C.c_double(K[1]), C.c_double(K[2]),
+                                                        C.c_double(K[3]), C.c_double(baseline), C.c_void_p(d_idx), C.c_void_p(d_dist),
+                                                        C.c_void_p(d_xyz), C.c_void_p(d_ok), C.c_void_p(stream or None)),
+           "myslam_hamming_match_triangulate_batch")
+
+
 # ---------------------------------------------------------------------------------- DeepLCD
 def calc_default_layers():
     """the SURVEY A.6 layer list as CALC_LAYER_DTYPE records"""

@@ -26,10 +26,13 @@ __global__ __launch_bounds__(256) void k_db_scan(const float* __restrict__ db, c
                                                  Partial* __restrict__ partials /*[nblocks][nq]*/) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_db[];
     Partial* s_p = reinterpret_cast<Partial*>(smem_db);          // [DB_WAVES][nq]
+    int* s_lim = reinterpret_cast<int*>(s_p + DB_WAVES * nq);    // [nq]: the row limits, read ONCE (a recorded step reads them from pinned host memory)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int qi = threadIdx.x; qi < nq; qi += 256) s_lim[qi] = nvalid[qi];
+    __syncthreads();
     {   // a launch covers the allocation (recorded steps outlive appends): blocks behind every query's row limit leave an empty partial
         int lim = 0;
-        for (int qi = 0; qi < nq; qi++) lim = max(lim, nvalid[qi]);
+        for (int qi = 0; qi < nq; qi++) lim = max(lim, s_lim[qi]);
         if ((int)blockIdx.x * DB_WAVES * DB_ROWS_PER_WAVE >= lim) {
             for (int qi = threadIdx.x; qi < nq; qi += 256) partials[(size_t)blockIdx.x * nq + qi] = {0.f, -1, 0};
             return;
@@ -45,7 +48,7 @@ __global__ __launch_bounds__(256) void k_db_scan(const float* __restrict__ db, c
         for (int k = 0; k < 16; k++) v[k] = row[k * 64 + lane];
         v[16] = (lane < DIM - 1024) ? row[1024 + lane] : 0.f;
         for (int qi = 0; qi < nq; qi++) {
-            if (r >= nvalid[qi]) continue;                      // cut-off rule, loopclosing.cpp:133 (uniform per wave)
+            if (r >= s_lim[qi]) continue;                       // cut-off rule, loopclosing.cpp:133 (uniform per wave)
             const float* qq = q + (size_t)qi * DIM;
             float acc = 0.f;
 #pragma unroll
@@ -300,6 +303,7 @@ struct myslam_lcddb_query_ctx {
     Partial* d_partials = nullptr; size_t partialsCap = 0;
     int32_t* d_nvalid = nullptr; int nvalidCap = 0;                 // nq row limits + 1: the row count they were computed against
     int32_t* h_nvalid = nullptr; hipEvent_t nvEvent = nullptr;      // pinned staging of the per-query row limits + "copy done" event
+    const int32_t* limits = nullptr;                                // what the launches of the current call read: d_nvalid (eager) or h_nvalid itself (recorded)
     uint64_t* d_bestS = nullptr; float* d_maxS = nullptr; int32_t* d_cntS = nullptr; int shardCap = 0;     // scratch of the sharded query
     int graphRows = 0, graphQueries = 0;      // > 0: a query of this context was recorded into a HIP graph covering this many rows / queries
     uint64_t graphGen = 0;                    // generation of the matrix that recording reads
@@ -568,20 +572,26 @@ static int db_query(myslam_lcddb_query_ctx* c, const float* d_q, const uint64_t*
         }
         memcpy(c->h_nvalid, c->scratchLimits.data(), sizeof(int32_t) * nq);
         c->h_nvalid[nq] = rows_now;
-        MYSLAM_HIP_CHECK(hipMemcpyAsync(c->d_nvalid, c->h_nvalid, sizeof(int32_t) * (nq + 1), hipMemcpyHostToDevice, c->stream));      // pinned -> no host sync
-        if (!cap) { MYSLAM_HIP_CHECK(hipEventRecord(c->nvEvent, c->stream)); c->nvPending = true; }
-        c->lastLimits = c->scratchLimits; c->lastRows = rows_now; c->nvFresh = !cap;             // (a recorded copy re-runs at every replay with whatever the pinned buffer holds then)
+        // eager: one small upload.  Recorded: NO copy node — the recorded kernels read the pinned buffer itself (device-visible host memory) at
+        // every replay; a recorded one-pair step is bound by the number of its nodes (~4.6 us each, tools/node_count_probe.sh), and a few
+        // hundred 4-byte reads over the host link cost the scan ~2 us
+        if (!cap) {
+            MYSLAM_HIP_CHECK(hipMemcpyAsync(c->d_nvalid, c->h_nvalid, sizeof(int32_t) * (nq + 1), hipMemcpyHostToDevice, c->stream));      // pinned -> no host sync
+            MYSLAM_HIP_CHECK(hipEventRecord(c->nvEvent, c->stream)); c->nvPending = true;
+        }
+        c->lastLimits = c->scratchLimits; c->lastRows = rows_now; c->nvFresh = !cap;             // (a recorded scan reads whatever the pinned buffer holds at its replay)
     }
+    c->limits = cap ? c->h_nvalid : c->d_nvalid;
     {
         ScopedProf sp(P_DBSCAN, c->stream);
         int nparts = nblocks;
         if (nq >= 32) {           // batched: GEMM on the matrix cores with the per-query reduction fused into the epilogue
             nparts = std::max(1, (maxv + GM - 1) / GM);
             hipLaunchKernelGGL(k_db_scan_bf16x6, dim3(nparts, (nq + GN - 1) / GN), dim3(256), 0, c->stream, d_db, cap_now, d_q, nq,
-                               c->d_nvalid, thr_low, c->d_partials);
+                               c->limits, thr_low, c->d_partials);
         } else {                  // a few queries: bandwidth-bound GEMV, one wave per database row
-            const size_t lds = sizeof(Partial) * DB_WAVES * nq;
-            hipLaunchKernelGGL(k_db_scan, dim3(nblocks), dim3(256), lds, c->stream, d_db, d_q, nq, c->d_nvalid, thr_low, c->d_partials);
+            const size_t lds = sizeof(Partial) * DB_WAVES * nq + sizeof(int) * nq;
+            hipLaunchKernelGGL(k_db_scan, dim3(nblocks), dim3(256), lds, c->stream, d_db, d_q, nq, c->limits, thr_low, c->d_partials);
         }
         hipLaunchKernelGGL(k_db_reduce, dim3((nq + 3) / 4), dim3(256), 0, c->stream, c->d_partials, nparts, nq, d_ids, d_best,
                            d_max, d_cnt);
@@ -620,8 +630,8 @@ static int db_query_sharded(myslam_lcddb_query_ctx* c, const float* d_q, const u
     int rc = db_query(c, d_q, cur_ids, nq, thr_low, c->d_bestS, c->d_maxS, c->d_cntS);
     if (rc) return rc;
     // the row count sits behind the nq limits of THIS call in d_nvalid (a recorded step's count is refreshed with its limits)
-    hipLaunchKernelGGL(k_db_pack_candidates, dim3((nq + 255) / 256), dim3(256), 0, c->stream, c->d_bestS, c->d_maxS, c->d_cntS, c->d_nvalid,
-                       c->d_nvalid + nq, nq, d_cand);
+    hipLaunchKernelGGL(k_db_pack_candidates, dim3((nq + 255) / 256), dim3(256), 0, c->stream, c->d_bestS, c->d_maxS, c->d_cntS, c->limits,
+                       c->limits + nq, nq, d_cand);
     MYSLAM_HIP_CHECK(hipGetLastError());
     return MYSLAM_OK;
 }

@@ -39,6 +39,13 @@ constexpr int HQ_SPLIT = MYSLAM_HQ_SPLIT;         // ... and this many wave grou
 // rate): E2M1 represents +-1 exactly (0x2 / 0xA), the factor 32 of the query operand is its E8M0 block scale (2^5), sums of at most
 // 256 terms of +-32 plus the (31 - row) start value are exact in f32.  One descriptor dword (32 bits) expands to the 16 operand bytes
 // of a lane; 4 MFMAs per 32 x 32 tile instead of 8, 16 query registers per tile instead of 32, 4 KB of LDS per train chunk.
+// the triangulation of ONE left key-point against its match (defined below, behind tri_solve): also the tail of the one-pair matcher
+struct TriTail {
+    const myslam_keypoint* kl; const myslam_keypoint* kr;        // kl == nullptr: no tail
+    double fx, fy, cx, cy, baseline; double* xyz; uint8_t* ok;
+};
+__device__ __forceinline__ void tri_point(const TriTail& tt, int p, int cap, int i, int j);
+
 typedef int hq_v8i __attribute__((ext_vector_type(8)));
 typedef float hq_v16f __attribute__((ext_vector_type(16)));
 constexpr int HF_ROWB = 144;                      // LDS bytes per expanded train row (128 + 16)
@@ -49,14 +56,17 @@ constexpr int HF_ROWB = 144;                      // LDS bytes per expanded trai
 // SPLIT = groups of 4 waves per block, each taking every SPLIT-th train chunk for the block's queries (round 5, one-pair calls: 16 blocks
 // walk 63 chunks as a chain of barrier-separated steps — 32 us on 16 of 256 CUs; with 4 groups the chain is 16 steps and the groups' keys
 // merge through LDS at the end.  The key is an integer maximum: the same bits whatever the split).
-template <int TILES, int SPLIT = 1>
+// TRI: the block triangulates its 128 queries against the matches it has just found (myslam_hamming_match_triangulate_batch: a recorded
+// one-pair step is bound by the number of its launches, and the triangulation of a query needs nothing but that query's match).
+template <int TILES, int SPLIT = 1, bool TRI = false>
 __global__ __launch_bounds__(256 * SPLIT) void k_hamming_fp4(const uint8_t* __restrict__ q, const int32_t* __restrict__ nqv,
                                                      const uint8_t* __restrict__ tr, const int32_t* __restrict__ ntv,
                                                      int cap, int nq_single, int nt_single,
-                                                     int32_t* __restrict__ out_idx, int32_t* __restrict__ out_dist) {
+                                                     int32_t* __restrict__ out_idx, int32_t* __restrict__ out_dist, TriTail tt) {
     MYSLAM_SIDE_PRIO();
     __shared__ __attribute__((aligned(16))) uint8_t s_exp[SPLIT][2][32 * HF_ROWB];
     __shared__ uint32_t s_key[SPLIT > 1 ? SPLIT : 1][SPLIT > 1 ? 128 * TILES : 1];
+    __shared__ int32_t s_match[TRI ? 128 * TILES : 1];
     __shared__ uint32_t s_lut[256];                // byte -> 8 FP4 codes (bit i -> nibble i): bit 1 -> -1.0 (0xA), bit 0 -> +1.0 (0x2)
     const int p = blockIdx.y;
     const int nq = nqv ? min(nqv[p], cap) : nq_single;
@@ -155,7 +165,13 @@ __global__ __launch_bounds__(256 * SPLIT) void k_hamming_fp4(const uint8_t* __re
             const bool any = nt > 0;
             out_idx[(size_t)p * cap + qi] = any ? (int32_t)(0xfffffu - (b & 0xfffffu)) : -1;
             out_dist[(size_t)p * cap + qi] = any ? (int32_t)((512u - (b >> 20)) >> 1) : -1;
+            if (TRI) s_match[(wv * TILES + t) * 32 + lane] = any ? (int32_t)(0xfffffu - (b & 0xfffffu)) : -1;
         }
+    }
+    if (TRI) {                                               // whole waves: thread i of the block takes query q0 + i
+        __syncthreads();
+        const int i = threadIdx.x;
+        if (i < 128 * TILES && q0 + i < nq) tri_point(tt, p, cap, q0 + i, s_match[i]);
     }
 }
 
@@ -226,6 +242,22 @@ __device__ __forceinline__ void tri_solve(const double (&P)[2][12], const double
     ratio = s_min / s_2nd;                                             // algorithm.h:29
 }
 
+__device__ __forceinline__ void tri_point(const TriTail& tt, int p, int cap, int i, int j) {
+    const size_t o = (size_t)p * cap + i;
+    if (j < 0 || j >= cap) { tt.ok[o] = 0;       // no match (or an index outside the pair's slots: treated as none)
+        tt.xyz[3 * o] = tt.xyz[3 * o + 1] = tt.xyz[3 * o + 2] = 0; return; }
+    const double ul = tt.kl[o].x, vl = tt.kl[o].y;
+    const myslam_keypoint r = tt.kr[(size_t)p * cap + j];
+    const double ur = r.x, vr = r.y;
+    const double P[2][12] = {{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0},
+                             {1, 0, 0, -tt.baseline, 0, 1, 0, 0, 0, 0, 1, 0}};      // system.cpp:108-116,141-145
+    const double pt[2][2] = {{(ul - tt.cx) / tt.fx, (vl - tt.cy) / tt.fy}, {(ur - tt.cx) / tt.fx, (vr - tt.cy) / tt.fy}};   // camera.cpp:22-26
+    double X[3], ratio;
+    tri_solve(P, pt, X, ratio);
+    tt.xyz[3 * o] = X[0]; tt.xyz[3 * o + 1] = X[1]; tt.xyz[3 * o + 2] = X[2];
+    tt.ok[o] = (ratio < 1e-2 && X[2] > 0) ? 1 : 0;
+}
+
 __global__ __launch_bounds__(256) void k_triangulate(const float* __restrict__ xl, const float* __restrict__ yl,
                                                      const float* __restrict__ xr, const float* __restrict__ yr,
                                                      const myslam_keypoint* __restrict__ kl, const myslam_keypoint* __restrict__ kr,
@@ -238,15 +270,8 @@ __global__ __launch_bounds__(256) void k_triangulate(const float* __restrict__ x
     const int n = nlv ? min(nlv[p], cap) : n_single;
     if (i >= n) return;
     const size_t o = (size_t)p * cap + i;
-    double ul, vl, ur, vr;
-    if (kl) {
-        const int j = match[o];
-        if (j < 0 || j >= cap) { ok[o] = 0;      // no match (or an index outside the pair's slots: treated as none)
-            xyz[3 * o] = xyz[3 * o + 1] = xyz[3 * o + 2] = 0; return; }
-        ul = kl[o].x; vl = kl[o].y;
-        const myslam_keypoint r = kr[(size_t)p * cap + j];
-        ur = r.x; vr = r.y;
-    } else { ul = xl[i]; vl = yl[i]; ur = xr[i]; vr = yr[i]; }
+    if (kl) { tri_point(TriTail{kl, kr, fx, fy, cx, cy, baseline, xyz, ok}, p, cap, i, match[o]); return; }      // (the same code as the one-pair matcher's tail)
+    const double ul = xl[i], vl = yl[i], ur = xr[i], vr = yr[i];
     const double P[2][12] = {{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0},
                              {1, 0, 0, -baseline, 0, 1, 0, 0, 0, 0, 1, 0}};      // system.cpp:108-116,141-145
     const double pt[2][2] = {{(ul - cx) / fx, (vl - cy) / fy}, {(ur - cx) / fx, (vr - cy) / fy}};   // camera.cpp:22-26
@@ -269,10 +294,10 @@ int myslam_hamming_match_batch(const uint8_t* d_q, const int32_t* d_nq, const ui
     hipStream_t s = (hipStream_t)hip_stream;
     ScopedProf sp(P_MATCH, s);
     if (batch < HQ_NARROW_BELOW)
-        hipLaunchKernelGGL((k_hamming_fp4<1, HQ_SPLIT>), dim3((cap + 127) / 128, batch), dim3(256 * HQ_SPLIT), 0, s, d_q, d_nq, d_t, d_nt, cap, 0, 0, d_train_idx, d_dist);
+        hipLaunchKernelGGL((k_hamming_fp4<1, HQ_SPLIT>), dim3((cap + 127) / 128, batch), dim3(256 * HQ_SPLIT), 0, s, d_q, d_nq, d_t, d_nt, cap, 0, 0, d_train_idx, d_dist, TriTail{});
     else
         hipLaunchKernelGGL(k_hamming_fp4<HQ_TILES>, dim3((cap + HQ_BLOCK - 1) / HQ_BLOCK, batch), dim3(256), 0, s, d_q, d_nq, d_t, d_nt, cap, 0, 0,
-                           d_train_idx, d_dist);
+                           d_train_idx, d_dist, TriTail{});
     MYSLAM_HIP_CHECK(hipGetLastError());
     return MYSLAM_OK;
 }
@@ -295,7 +320,7 @@ int myslam_hamming_match(const uint8_t* query, int nq, const uint8_t* train, int
     {
         ScopedProf sp(P_MATCH, hc.stream());
         hipLaunchKernelGGL((k_hamming_fp4<1, HQ_SPLIT>), dim3((nq + 127) / 128, 1), dim3(256 * HQ_SPLIT), 0, hc.stream(), dq, (const int32_t*)nullptr, dt,
-                           (const int32_t*)nullptr, cap, nq, nt, di, dd);
+                           (const int32_t*)nullptr, cap, nq, nt, di, dd, TriTail{});
     }
     MYSLAM_HIP_CHECK(hipGetLastError());
     return hc.download();
@@ -359,6 +384,27 @@ int myslam_triangulate_stereo_batch(const myslam_keypoint* d_kps_l, const myslam
     hipLaunchKernelGGL(k_triangulate, dim3((cap + 255) / 256, batch), dim3(256), 0, s, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, d_kps_l, d_kps_r, d_match, d_nl, cap, 0, fx, fy, cx, cy,
                        baseline, d_xyz, d_ok);
+    MYSLAM_HIP_CHECK(hipGetLastError());
+    return MYSLAM_OK;
+}
+
+// BFMatcher.match + triangulation() of every match in one call: what the two calls above / below do, in ONE launch for a handful of pairs
+int myslam_hamming_match_triangulate_batch(const uint8_t* d_q, const int32_t* d_nq, const uint8_t* d_t, const int32_t* d_nt,
+                                           const myslam_keypoint* d_kps_l, const myslam_keypoint* d_kps_r, int batch, int cap,
+                                           double fx, double fy, double cx, double cy, double baseline,
+                                           int32_t* d_train_idx, int32_t* d_dist, double* d_xyz, uint8_t* d_ok, void* hip_stream) {
+    if (!d_kps_l || !d_kps_r || !d_xyz || !d_ok) return MYSLAM_ERR_INVALID;
+    if (batch >= HQ_NARROW_BELOW) {
+        const int rc = myslam_hamming_match_batch(d_q, d_nq, d_t, d_nt, batch, cap, d_train_idx, d_dist, hip_stream);
+        if (rc) return rc;
+        return myslam_triangulate_stereo_batch(d_kps_l, d_kps_r, d_train_idx, d_nq, batch, cap, fx, fy, cx, cy, baseline, d_xyz, d_ok, hip_stream);
+    }
+    if (!d_q || !d_t || !d_nq || !d_nt || batch <= 0 || cap <= 0 || !d_train_idx || !d_dist) return MYSLAM_ERR_INVALID;
+    if (cap >= (1 << 20)) return MYSLAM_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)hip_stream;
+    ScopedProf sp(P_MATCH, s);
+    hipLaunchKernelGGL((k_hamming_fp4<1, HQ_SPLIT, true>), dim3((cap + 127) / 128, batch), dim3(256 * HQ_SPLIT), 0, s, d_q, d_nq, d_t, d_nt, cap, 0, 0,
+                       d_train_idx, d_dist, TriTail{d_kps_l, d_kps_r, fx, fy, cx, cy, baseline, d_xyz, d_ok});
     MYSLAM_HIP_CHECK(hipGetLastError());
     return MYSLAM_OK;
 }

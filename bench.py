@@ -403,10 +403,10 @@ def main():
         def body():
             ln["ext"].detect_and_compute_batch(d_imgs.data_ptr(), 2 * P, H, W, W, H * W, o["kps"].data_ptr(), o["desc"].data_ptr(), o["cnt"].data_ptr(),
                                                o["stat"].data_ptr(), cap)
-            api.hamming_match_batch(o["desc"].data_ptr(), o["cnt"].data_ptr(), o["desc"].data_ptr() + P * cap * 32, o["cnt"].data_ptr() + 4 * P,
-                                    P, cap, o["midx"].data_ptr(), o["mdist"].data_ptr(), s_)
-            api.triangulate_stereo_batch(o["kps"].data_ptr(), o["kps"].data_ptr() + P * cap * 28, o["midx"].data_ptr(), o["cnt"].data_ptr(), P, cap,
-                                         Kt, K["bf"] / K["fx"], o["xyz"].data_ptr(), o["ok"].data_ptr(), s_)
+            # match + triangulation of every match: one call (one launch below 16 pairs; the same outputs as the two calls, tests/test_gpu_match_tri.py)
+            api.hamming_match_triangulate_batch(o["desc"].data_ptr(), o["cnt"].data_ptr(), o["desc"].data_ptr() + P * cap * 32, o["cnt"].data_ptr() + 4 * P,
+                                                o["kps"].data_ptr(), o["kps"].data_ptr() + P * cap * 28, P, cap, Kt, K["bf"] / K["fx"],
+                                                o["midx"].data_ptr(), o["mdist"].data_ptr(), o["xyz"].data_ptr(), o["ok"].data_ptr(), s_)
             if use_lcd and "lcd" not in skip:
                 ln["lcd"].describe_batch(d_imgs.data_ptr(), P, H, W, W, H * W, o["descr"].data_ptr(), blur_in_place=False)
             if use_lcd and "db" not in skip:

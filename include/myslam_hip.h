@@ -201,6 +201,16 @@ int myslam_triangulate_stereo_batch(const myslam_keypoint* d_kps_l, const myslam
                                     double fx, double fy, double cx, double cy, double baseline,
                                     double* d_xyz, uint8_t* d_ok, void* hip_stream);
 
+/* cv::BFMatcher::match (src/loopclosing.cpp:172-173) followed by triangulation() (include/myslam/algorithm.h:16-33) of every matched left
+ * key-point, as Frontend::FindFeaturesInRight + TriangulateNewPoints do in sequence (src/frontend.cpp:344-420): exactly
+ * myslam_hamming_match_batch(d_q = left descriptors, d_t = right descriptors, ...) and then myslam_triangulate_stereo_batch(d_kps_l, d_kps_r,
+ * d_train_idx, d_nq, ...) — same outputs, bit for bit.  For fewer than 16 pairs per call it is ONE launch (each matcher block triangulates
+ * its 128 queries once their matches are known): a live stream's step is bound by the number of its dependent launches. */
+int myslam_hamming_match_triangulate_batch(const uint8_t* d_q, const int32_t* d_nq, const uint8_t* d_t, const int32_t* d_nt,
+                                           const myslam_keypoint* d_kps_l, const myslam_keypoint* d_kps_r, int batch, int cap,
+                                           double fx, double fy, double cx, double cy, double baseline,
+                                           int32_t* d_train_idx, int32_t* d_dist, double* d_xyz, uint8_t* d_ok, void* hip_stream);
+
 /* ------------------------------------------------------------------------------------------
  * DeepLCD — replaces class DeepLCD (include/myslam/deeplcd.h:21-48, src/deeplcd.cpp:10-91)
  *

@@ -79,3 +79,40 @@ def test_triangulate_stereo(api, oracle, synth):
     # tolerance: f64 one-sided Jacobi on both sides; agreement far below the measurement noise
     assert np.allclose(xyz[ok], rxyz[ok], rtol=1e-9, atol=1e-9)
     assert np.median(np.abs(xyz[ok][:, 2] - Z[ok]) / Z[ok]) < 0.05       # 0.3 px noise on 5..130 px disparities
+
+
+@pytest.mark.parametrize("B", [2, 17])
+def test_match_triangulate_in_one_call_equals_the_two_calls(api, B):
+    """myslam_hamming_match_triangulate_batch = myslam_hamming_match_batch + myslam_triangulate_stereo_batch, every output bit for bit: for fewer
+    than 16 pairs it is ONE launch (each matcher block triangulates its 128 queries, k_hamming_fp4<1, 4, true>), from 16 pairs on the two launches."""
+    import torch
+    rng = np.random.default_rng(11 + B)
+    cap = 900
+    nl = rng.integers(0, cap + 1, B).astype(np.int32); nr = rng.integers(0, cap + 1, B).astype(np.int32)
+    nl[0] = cap; nr[0] = cap
+    if B > 1: nr[1] = 0                                                # a pair without right key-points: no match, xyz = 0, ok = 0
+    dl = rng.integers(0, 256, (B, cap, 32), dtype=np.uint8); dr = rng.integers(0, 256, (B, cap, 32), dtype=np.uint8)
+    kp = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+    kl = np.zeros((B, cap), kp); kr = np.zeros((B, cap), kp)
+    kl["x"] = rng.uniform(20, 1220, (B, cap)); kl["y"] = rng.uniform(20, 350, (B, cap))
+    kr["x"] = rng.uniform(20, 1220, (B, cap)); kr["y"] = kl["y"] + rng.normal(0, 0.4, (B, cap))
+    assert kp.itemsize == 28
+    K = (718.856, 718.856, 607.1928, 185.2157); base = 0.537
+    dev = lambda a: torch.from_numpy(a.view(np.uint8) if a.dtype == kp else a).cuda()
+    d = {k: dev(v) for k, v in dict(dl=dl, dr=dr, nl=nl, nr=nr, kl=kl, kr=kr).items()}
+    s = torch.cuda.current_stream().cuda_stream
+
+    def outs():
+        return [torch.full((B, cap), -7, dtype=torch.int32, device="cuda"), torch.full((B, cap), -7, dtype=torch.int32, device="cuda"),
+                torch.full((B, cap, 3), -7.0, dtype=torch.float64, device="cuda"), torch.full((B, cap), 9, dtype=torch.uint8, device="cuda")]
+    a = outs()
+    api.hamming_match_batch(d["dl"].data_ptr(), d["nl"].data_ptr(), d["dr"].data_ptr(), d["nr"].data_ptr(), B, cap, a[0].data_ptr(), a[1].data_ptr(), s)
+    api.triangulate_stereo_batch(d["kl"].data_ptr(), d["kr"].data_ptr(), a[0].data_ptr(), d["nl"].data_ptr(), B, cap, K, base, a[2].data_ptr(), a[3].data_ptr(), s)
+    b = outs()
+    api.hamming_match_triangulate_batch(d["dl"].data_ptr(), d["nl"].data_ptr(), d["dr"].data_ptr(), d["nr"].data_ptr(), d["kl"].data_ptr(), d["kr"].data_ptr(),
+                                        B, cap, K, base, b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr(), b[3].data_ptr(), s)
+    torch.cuda.synchronize()
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x.view(torch.uint8), y.view(torch.uint8)), f"output {i}"
+    assert int(a[3][0].sum()) >= 0 and (a[0][0] >= 0).all() and (a[3][:, :][a[0] == -7] == 9).all()      # slots past a pair's count are never written
+    if B > 1: assert (b[0][1, :nl[1]] == -1).all() and not b[3][1, :nl[1]].any()
