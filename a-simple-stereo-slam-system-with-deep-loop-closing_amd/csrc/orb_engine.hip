@@ -22,6 +22,9 @@ void launch_resize(const ResizeArgs& a, int batch, hipStream_t s);
 void launch_resize_chain(const ResizeArgs* lv, int n, int batch, hipStream_t s);
 bool resize_is_little(const ResizeArgs& a, int batch);
 int resize_chain_max();
+int pyr_head_levels();
+void launch_pyr_head(const ResizeArgs* lv, int n, int rows, int cols, uint8_t* dst0, int dpitch0, size_t dstride0, int b0, int batch,
+                     uint32_t* p0, int n0, uint32_t* p1, int n1, uint32_t* p2, int n2, uint32_t* p3, int n3, hipStream_t s);
 void launch_blur(const BlurArgs& a, int batch, hipStream_t s);
 bool blur_uses_strips(const BlurArgs& a);
 bool resize_uses_strips(const ResizeArgs& a);
@@ -324,7 +327,21 @@ int myslam_orb::build_pyramids(const uint8_t* d_imgs, int batch, int step, size_
         uint8_t* base = pass ? d_mask : d_pyr;
         const uint8_t* src = pass ? d_masks : d_imgs;
         const int n0 = pass ? 0 : P.ext0N;                     // images read in place have no level-0 copy (masks are always copied)
-        if (batch > n0) {
+        int l = 1;
+        // a launch with little work (a live stream's frame): ingest, counters and the first levels of all images in ONE launch (k_pyr_head)
+        const int nhead = std::min(pyr_head_levels(), nlev - 1);
+        if (nhead >= 1 && batch > n0 && (size_t)batch * P.lv[1].w * P.lv[1].h < (size_t)1500000) {
+            ScopedProf sp(P_RESIZE, stream);
+            ResizeArgs grp[3];
+            for (int j = 0; j < nhead; j++) grp[j] = level_resize_args(base, 1 + j);
+            grp[0].src = src; grp[0].spitch = step; grp[0].sstride = stride;      // level 1 (and the levels above, through it) from the caller's buffers
+            const bool c0 = pass == 0 && clr.n[0] > 0;
+            launch_pyr_head(grp, nhead, P.rows, P.cols, base + P.lv[0].imgOff, P.lv[0].pitch, P.pyrBytes, n0, batch,
+                            c0 ? clr.p[0] : nullptr, c0 ? clr.n[0] : 0, c0 ? clr.p[1] : nullptr, c0 ? clr.n[1] : 0, c0 ? clr.p[2] : nullptr,
+                            c0 ? clr.n[2] : 0, c0 ? clr.p[3] : nullptr, c0 ? clr.n[3] : 0, stream);
+            if (c0) clr.n[0] = 0;
+            l = 1 + nhead;
+        } else if (batch > n0) {
             uint8_t* dst0 = base + (size_t)n0 * P.pyrBytes + P.lv[0].imgOff;
             if (pass == 0 && clr.n[0] > 0) {       // the call's first launch also clears the per-call counters (run_batch)
                 launch_ingest_clear(src + (size_t)n0 * stride, P.rows, P.cols, step, stride, dst0, P.lv[0].pitch, P.pyrBytes, batch - n0,
@@ -334,13 +351,13 @@ int myslam_orb::build_pyramids(const uint8_t* d_imgs, int batch, int step, size_
                 launch_ingest(src + (size_t)n0 * stride, P.rows, P.cols, step, stride, dst0, P.lv[0].pitch, P.pyrBytes, batch - n0, stream);
             }
         }
-        for (int l = 1; l < nlev;) {                           // ComputePyramid, ORBextractor.cpp:1235-1246
+        for (; l < nlev;) {                                    // ComputePyramid, ORBextractor.cpp:1235-1246
             ScopedProf sp(P_RESIZE, stream);
             ResizeArgs a = level_resize_args(base, l);
             if (l == 1 && n0 > 0) { a.src0 = d_imgs; a.spitch0 = step; a.sstride0 = stride; a.n0 = n0; }
             // launches with little work (a live stream's frame): up to three consecutive levels share one launch (k_resize_chain) — such a
             // step is bound by the number of its dependent launches
-            ResizeArgs grp[3]; int ng = 0;
+            ResizeArgs grp[4]; int ng = 0;
             const int gmax = resize_chain_max();
             if (gmax > 1 && resize_is_little(a, batch)) {
                 grp[ng++] = a;

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void k_resize(ResizeArgs a) {
 // does; the threads of level l + 2 do not wait for it: each computes the four pixels of level l + 1 it needs itself (and those of level l + 3
 // the sixteen below) — integer arithmetic, so the value is the one the other thread stores: 5 (21) interpolations per pixel instead of 1, on
 // levels that shrink by 1.44 each, at a batch size where the chip is idle.  Same bits as k_resize / k_resize_strip (tests/test_gpu_fallbacks.py).
-constexpr int RC_MAX = 3;
+constexpr int RC_MAX = 4;
 struct ResizeChain {
     const uint8_t* src; int sw, sh, spitch; size_t sstride;      // the level in memory the chain starts from
     int n;                                                      // levels produced (1 .. RC_MAX)
@@ -123,24 +123,35 @@ __device__ __forceinline__ int rc_pix(const ResizeChain& c, const uint8_t* S, in
     }
 }
 
+// pixels a thread produces: 4 (one dword store) down to the third level of a chain, 1 on the fourth (85 interpolations per pixel: spread wider)
+__host__ __device__ constexpr int rc_px(int J) { return J >= 4 ? 1 : 4; }
+
 template <int J>
-__device__ __forceinline__ void rc_store4(const ResizeChain& c, const uint8_t* S, uint8_t* D, int item) {
+__device__ __forceinline__ void rc_store(const ResizeChain& c, const uint8_t* S, uint8_t* D, int item) {
     const int dw = c.dw[J - 1], dh = c.dh[J - 1], gpr = (dw + 3) >> 2;
-    const int dy = item / gpr, dx4 = (item - dy * gpr) * 4;
-    if (dy >= dh) return;
-    uint32_t packed = 0;
+    if constexpr (rc_px(J) == 4) {
+        const int dy = item / gpr, dx4 = (item - dy * gpr) * 4;
+        if (dy >= dh) return;
+        uint32_t packed = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) packed |= (uint32_t)rc_pix<J>(c, S, min(dx4 + k, dw - 1), dy) << (8 * k);
-    *reinterpret_cast<uint32_t*>(D + (size_t)dy * c.dpitch[J - 1] + dx4) = packed;      // row pitches are multiples of 64: the padding takes the last group
+        for (int k = 0; k < 4; k++) packed |= (uint32_t)rc_pix<J>(c, S, min(dx4 + k, dw - 1), dy) << (8 * k);
+        *reinterpret_cast<uint32_t*>(D + (size_t)dy * c.dpitch[J - 1] + dx4) = packed;      // row pitches are multiples of 64: the padding takes the last group
+    } else {
+        const int dy = item / (4 * gpr), dx = item - dy * 4 * gpr;                           // the same bytes, padding of the last group included
+        if (dy >= dh) return;
+        D[(size_t)dy * c.dpitch[J - 1] + dx] = (uint8_t)rc_pix<J>(c, S, min(dx, dw - 1), dy);
+    }
 }
 
-__global__ __launch_bounds__(256) void k_resize_chain(ResizeChain c) {
-    const int b = blockIdx.y, blk = blockIdx.x;
+__device__ __forceinline__ void rc_block(const ResizeChain& c, int blk, int b) {
     const uint8_t* S = c.src + (size_t)b * c.sstride;
-    if (blk < c.blk0[1]) rc_store4<1>(c, S, c.dst[0] + (size_t)b * c.dstride, blk * 256 + (int)threadIdx.x);
-    else if (blk < c.blk0[2]) rc_store4<2>(c, S, c.dst[1] + (size_t)b * c.dstride, (blk - c.blk0[1]) * 256 + (int)threadIdx.x);
-    else rc_store4<3>(c, S, c.dst[2] + (size_t)b * c.dstride, (blk - c.blk0[2]) * 256 + (int)threadIdx.x);
+    if (blk < c.blk0[1]) rc_store<1>(c, S, c.dst[0] + (size_t)b * c.dstride, blk * 256 + (int)threadIdx.x);
+    else if (blk < c.blk0[2]) rc_store<2>(c, S, c.dst[1] + (size_t)b * c.dstride, (blk - c.blk0[1]) * 256 + (int)threadIdx.x);
+    else if (blk < c.blk0[3]) rc_store<3>(c, S, c.dst[2] + (size_t)b * c.dstride, (blk - c.blk0[2]) * 256 + (int)threadIdx.x);
+    else rc_store<4>(c, S, c.dst[3] + (size_t)b * c.dstride, (blk - c.blk0[3]) * 256 + (int)threadIdx.x);
 }
+
+__global__ __launch_bounds__(256) void k_resize_chain(ResizeChain c) { rc_block(c, blockIdx.x, blockIdx.y); }
 
 // K1b: the same arithmetic, register-only column strips.  Lane l owns destination columns 4l..4l+3 of a 256-column strip
 // and walks RS_R destination rows: x coordinates / weights are computed once, every needed source row is sampled once
@@ -2572,19 +2583,16 @@ __global__ void k_unpack_cands(const uint32_t* __restrict__ cand, int n, int32_t
 // one — instead of by hipMemsetAsync: no launch of their own (a one-frame call is a chain of short dependent launches), and kernel nodes
 // are the part of a captured HIP graph that replays reliably (memset nodes of a replayed graph left garbage in the counters on ROCm 7.2).
 struct ZeroArgs { uint32_t* p[4]; int n[4]; };
-__global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ src, int rows, int cols, int step, size_t sstride,
-                                                uint8_t* __restrict__ dst, int dpitch, size_t dstride, int tpr, int rpb, ZeroArgs z) {
-    {
-        const int T = (int)(gridDim.x * gridDim.y * gridDim.z) * 256;
-        const int tid = (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256 + (int)threadIdx.x;
+__device__ __forceinline__ void zero_part(const ZeroArgs& z, int tid, int T) {
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-            for (int i = tid; i < z.n[k]; i += T) z.p[k][i] = 0u;
-    }
+    for (int k = 0; k < 4; k++)
+        for (int i = tid; i < z.n[k]; i += T) z.p[k][i] = 0u;
+}
+__device__ __forceinline__ void ingest_part(const uint8_t* __restrict__ src, int rows, int cols, int step, size_t sstride,
+                                            uint8_t* __restrict__ dst, int dpitch, size_t dstride, int tpr, int rpb, int bx, int by, int b) {
     // 16 destination bytes per thread (one aligned 16-byte store) from 5 aligned source dwords + v_alignbyte; tpr threads per row
-    const int b = blockIdx.z;
-    const int y = blockIdx.y * rpb + (int)threadIdx.x / tpr;
-    const int x16 = (blockIdx.x * 256 + (int)threadIdx.x % tpr) * 16;
+    const int y = by * rpb + (int)threadIdx.x / tpr;
+    const int x16 = (bx * 256 + (int)threadIdx.x % tpr) * 16;
     if ((int)threadIdx.x >= tpr * rpb || y >= rows || x16 >= cols) return;
     const uint8_t* s = src + (size_t)b * sstride + (size_t)y * step + x16;
     const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(s) & 3);
@@ -2599,6 +2607,24 @@ __global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ src,
     uint8_t* q = dst + (size_t)b * dstride + (size_t)y * dpitch + x16;
     if (x16 + 16 <= dpitch) *reinterpret_cast<uint4*>(q) = o;        // pitch is a multiple of 64: padding bytes may be written
     else { uint32_t w[4] = {o.x, o.y, o.z, o.w}; for (int j = 0; j < 4 && x16 + 4 * j < dpitch; j++) reinterpret_cast<uint32_t*>(q)[j] = w[j]; }
+}
+__global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ src, int rows, int cols, int step, size_t sstride,
+                                                uint8_t* __restrict__ dst, int dpitch, size_t dstride, int tpr, int rpb, ZeroArgs z) {
+    zero_part(z, (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256 + (int)threadIdx.x, (int)(gridDim.x * gridDim.y * gridDim.z) * 256);
+    ingest_part(src, rows, cols, step, sstride, dst, dpitch, dstride, tpr, rpb, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// The first launch of a call with little work (a live stream's frame): level-0 ingest of the images that are not read in place + the per-call
+// counters + the first pyramid levels of ALL images, computed from the caller's buffers (k_resize_chain's per-pixel byte loads never read past
+// a row, so the last image of a batch needs no copy for THEM) — one node of a recorded step instead of three.
+struct IngestPart { const uint8_t* src; int rows, cols, step; size_t sstride; uint8_t* dst; int dpitch; size_t dstride; int tpr, rpb, gx, b0; };
+__global__ __launch_bounds__(256) void k_pyr_head(ResizeChain c, IngestPart g, ZeroArgs z) {
+    const int blk = blockIdx.x, b = blockIdx.y;
+    zero_part(z, (int)(blockIdx.y * gridDim.x + blockIdx.x) * 256 + (int)threadIdx.x, (int)(gridDim.x * gridDim.y) * 256);
+    if (blk < c.blk0[RC_MAX]) { rc_block(c, blk, b); return; }
+    if (b < g.b0) return;                                            // read in place: no level-0 copy
+    const int ib = blk - c.blk0[RC_MAX];
+    ingest_part(g.src, g.rows, g.cols, g.step, g.sstride, g.dst, g.dpitch, g.dstride, g.tpr, g.rpb, ib % g.gx, ib / g.gx, b);
 }
 
 __global__ __launch_bounds__(256) void k_zero_u32(ZeroArgs a) {             // the same clearing on its own (debug entry points)
@@ -2642,18 +2668,38 @@ bool resize_is_little(const ResizeArgs& a, int batch) { return a.n0 == 0 && (siz
 #endif
 int resize_chain_max() { return MYSLAM_RESIZE_CHAIN_MAX < RC_MAX ? MYSLAM_RESIZE_CHAIN_MAX : RC_MAX; }
 
-// n consecutive levels (lv[j].src is lv[j - 1].dst), every one of them "little": one launch
-void launch_resize_chain(const ResizeArgs* lv, int n, int batch, hipStream_t s) {
+static ResizeChain make_chain(const ResizeArgs* lv, int n) {
     ResizeChain c;
     c.src = lv[0].src; c.sw = lv[0].sw; c.sh = lv[0].sh; c.spitch = lv[0].spitch; c.sstride = lv[0].sstride;
     c.n = n; c.dstride = lv[0].dstride; c.blk0[0] = 0;
     for (int j = 0; j < RC_MAX; j++) {
         const ResizeArgs& a = lv[j < n ? j : n - 1];
         c.dst[j] = a.dst; c.dw[j] = a.dw; c.dh[j] = a.dh; c.dpitch[j] = a.dpitch; c.scale_x[j] = a.scale_x; c.scale_y[j] = a.scale_y;
-        c.blk0[j + 1] = c.blk0[j] + (j < n ? (((a.dw + 3) / 4) * a.dh + 255) / 256 : 0);
+        c.blk0[j + 1] = c.blk0[j] + (j < n ? (((a.dw + 3) / 4) * (4 / rc_px(j + 1)) * a.dh + 255) / 256 : 0);
     }
+    return c;
+}
+// n consecutive levels (lv[j].src is lv[j - 1].dst), every one of them "little": one launch
+void launch_resize_chain(const ResizeArgs* lv, int n, int batch, hipStream_t s) {
+    const ResizeChain c = make_chain(lv, n);
     hipLaunchKernelGGL(k_resize_chain, dim3(c.blk0[RC_MAX], batch), dim3(256), 0, s, c);
 }
+// levels 1 .. n from the caller's images (lv[0].src / spitch / sstride = the caller's buffer) + ingest of images b >= b0 + the per-call counters
+void launch_pyr_head(const ResizeArgs* lv, int n, int rows, int cols, uint8_t* dst0, int dpitch0, size_t dstride0, int b0, int batch,
+                     uint32_t* p0, int n0, uint32_t* p1, int n1, uint32_t* p2, int n2, uint32_t* p3, int n3, hipStream_t s) {
+    const ResizeChain c = make_chain(lv, n);
+    const int t = (cols + 15) / 16;
+    IngestPart g{lv[0].src, rows, cols, lv[0].spitch, lv[0].sstride, dst0, dpitch0, dstride0, t < 256 ? t : 256, t < 256 ? 256 / t : 1, (t + 255) / 256, b0};
+    const int iblocks = g.gx * ((rows + g.rpb - 1) / g.rpb);
+    hipLaunchKernelGGL(k_pyr_head, dim3(c.blk0[RC_MAX] + iblocks, batch), dim3(256), 0, s, c, g, ZeroArgs{{p0, p1, p2, p3}, {n0, n1, n2, n3}});
+}
+// (measured at 1 pair x 16 lanes, tools/ab_stream_mode.sh, us per step / graph nodes: no head launch, chains of 3: 89.3 / 18; head of 2 levels + chains of 3:
+// 85.2 / 17; head of 3 + chains of 2: 86.9 / 17; head of 3 + one chain of 4: 86.5 / 16 — a node costs ~4.6 us, and the 21 / 85 interpolations per
+// pixel of a third / fourth chained level begin to cost as much)
+#ifndef MYSLAM_PYR_HEAD_LEVELS         // A/B builds: levels the head launch of a small batch produces (0 = no head launch)
+#define MYSLAM_PYR_HEAD_LEVELS 2
+#endif
+int pyr_head_levels() { return MYSLAM_PYR_HEAD_LEVELS < 3 ? MYSLAM_PYR_HEAD_LEVELS : 3; }
 
 void launch_resize(const ResizeArgs& a, int batch, hipStream_t s) {
     // register strips cover pyramid scale factors up to 1.25 (rows) / 1.6 (columns); larger steps take the generic kernel — and so do

@@ -14,7 +14,7 @@ rows = rows[-200 * 30:]                   # the tail: replayed steps only
 steps, cur = [], []
 for r in rows:
     n = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("myslam_hip::", "")
-    if n.startswith("k_ingest") and cur:
+    if (n.startswith("k_ingest") or n.startswith("k_pyr_head")) and cur:
         steps.append(cur); cur = []
     cur.append((n, int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
 steps = [s for s in steps[5:-1] if len(s) == len(steps[len(steps) // 2])]
