@@ -30,8 +30,8 @@ bool blur_uses_strips(const BlurArgs& a);
 bool resize_uses_strips(const ResizeArgs& a);
 void launch_fast(const OrbPlan& P, const uint8_t* pyr, size_t pyrStride, const uint8_t* maskPyr, uint32_t* cand,
                  int32_t* candCount, const uint32_t* statPrev, uint32_t* statCur, int forceMode, int batch, hipStream_t s);
-void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCount, uint32_t* sortbuf, const uint32_t* octTab, uint32_t* selOut,
-                   int32_t* selCount, int32_t* status, int batch, uint16_t* order, hipStream_t s);
+bool launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCount, uint32_t* sortbuf, const uint32_t* octTab, uint32_t* selOut,
+                   int32_t* selCount, int32_t* status, int batch, uint16_t* order, hipStream_t s, const BlurArgs* blurLv, int nBlur);
 bool describe_uses_tile_order(bool have_order, int detectOnly, int batch);
 void launch_describe(const OrbPlan& P, const uint8_t* pyr, const uint8_t* blur, size_t pyrStride, const uint32_t* selOut,
                      const int32_t* selCount, myslam_keypoint* kps, uint8_t* desc, int32_t* counts, int32_t* status,
@@ -162,6 +162,7 @@ struct myslam_orb {
     ResizeArgs level_resize_args(uint8_t* base, int l) const;
     BlurArgs level_blur_args(int l) const;
     int blur_levels(int batch, int nlev, hipStream_t s);
+    void fill_blur_args(BlurArgs* lv, int nlev) const;
     int run_fast(const OrbPlan& P, const uint8_t* maskPyr, int batch);
     int run_batch(const uint8_t* d_imgs, int batch, int r, int c, int step, size_t stride, const uint8_t* d_masks,
                   myslam_keypoint* d_kps, uint8_t* d_desc, int32_t* d_counts, int32_t* d_stat, int cap, bool detectOnly);
@@ -360,10 +361,15 @@ int myslam_orb::build_pyramids(const uint8_t* d_imgs, int batch, int step, size_
             ResizeArgs grp[4]; int ng = 0;
             const int gmax = resize_chain_max();
             if (gmax > 1 && resize_is_little(a, batch)) {
+                // ... as long as the recomputation stays small: 1 / 5 / 21 / 85 interpolations per pixel of the first .. fourth level of a chain
+                // (8 images: levels 3 - 5 in one launch are 18 M interpolations and cost more than the two nodes they save)
+                static const double kEvals[4] = {1, 5, 21, 85};
+                double evals = (double)batch * a.dw * a.dh;
                 grp[ng++] = a;
                 while (ng < gmax && l + ng < nlev) {
                     const ResizeArgs nx = level_resize_args(base, l + ng);
-                    if (!resize_is_little(nx, batch)) break;
+                    evals += (double)batch * nx.dw * nx.dh * kEvals[ng];
+                    if (!resize_is_little(nx, batch) || evals > 6e6) break;
                     grp[ng++] = nx;
                 }
             }
@@ -412,13 +418,16 @@ BlurArgs myslam_orb::level_blur_args(int l) const {
     if (optBlurMfma && blurTabValid && blurLvOk[l]) { a.tabH = d_blurTab + blurOffH[l]; a.tabV = d_blurTab + blurOffV[l]; a.ident = d_blurTab + blurOffI; a.vconst = blurVconst; }
     return a;
 }
-int myslam_orb::blur_levels(int batch, int nlev, hipStream_t stream) {
+void myslam_orb::fill_blur_args(BlurArgs* lv, int nlev) const {
     const OrbPlan& P = full;
-    BlurArgs lv[MAXL];
     for (int l = 0; l < nlev; l++) {                           // ORBextractor.cpp:965-966 / :1194-1199
         lv[l] = level_blur_args(l);
         if (l == 0 && P.ext0N > 0) { lv[l].src0 = P.ext0; lv[l].spitch0 = P.ext0Pitch; lv[l].sstride0 = P.ext0Stride; lv[l].n0 = P.ext0N; }
     }
+}
+int myslam_orb::blur_levels(int batch, int nlev, hipStream_t stream) {
+    BlurArgs lv[MAXL];
+    fill_blur_args(lv, nlev);
     ScopedProf sp(P_BLUR, stream);
     launch_blur_levels(lv, nlev, batch, stream);               // every level in one launch
     return MYSLAM_OK;
@@ -489,15 +498,21 @@ int myslam_orb::run_batch(const uint8_t* d_imgs, int batch, int r, int c, int st
     if ((rc = run_fast(P, d_masks ? d_mask : nullptr, batch))) return rc;
     if (evUserFast) MYSLAM_HIP_CHECK(hipEventRecord(evUserFast, stream));
     if (fork && aux_mode != 2 && (rc = fork_blur())) return rc;
+    bool blurred = false;
     {
         ScopedProf sp(P_OCTREE, stream);
-        // the descriptor kernel's processing order is written by the oct-tree blocks themselves (one launch less on the chain)
-        launch_octree(P, d_cand, d_candCount, d_sort, d_octTab, d_sel, d_selCount, stat, batch,
-                      describe_uses_tile_order(d_order != nullptr, detectOnly ? 1 : 0, batch) ? d_order : nullptr, stream);
+        // the descriptor kernel's processing order is written by the oct-tree blocks themselves (one launch less on the chain); for small
+        // batches the Gaussian of all levels rides in the same launch too (it depends on the pyramid only)
+        BlurArgs blv[MAXL];
+        const bool tryBlur = !fork && !detectOnly && stop == 0 && !optBlurMfma;
+        if (tryBlur) fill_blur_args(blv, P.nlevels);
+        blurred = launch_octree(P, d_cand, d_candCount, d_sort, d_octTab, d_sel, d_selCount, stat, batch,
+                                describe_uses_tile_order(d_order != nullptr, detectOnly ? 1 : 0, batch) ? d_order : nullptr, stream,
+                                tryBlur ? blv : nullptr, tryBlur ? P.nlevels : 0);
     }
     if (stop == 3) return MYSLAM_OK;
     if (fork) MYSLAM_HIP_CHECK(hipStreamWaitEvent(stream, evJoin, 0));
-    else if (!detectOnly && (rc = blur_levels(batch, P.nlevels, stream))) return rc;
+    else if (!detectOnly && !blurred && (rc = blur_levels(batch, P.nlevels, stream))) return rc;
     if (stop == 4) return MYSLAM_OK;
     {
         ScopedProf sp(P_DESC, stream);

@@ -413,20 +413,17 @@ __device__ __forceinline__ uint32_t dpp_wave_shl1(uint32_t v) { return (uint32_t
 // more time between its launches than inside them (8 blur launches -> 1), and the small levels fill the gaps of the large ones.
 struct BlurMulti { BlurArgs a[MAXL]; int wave0[MAXL + 1]; int nstrips[MAXL]; int n; };
 constexpr int B3_TS = 144;                     // LDS bytes per staged tile (128 + 16: the dword writes of a wave then spread over all banks)
-__global__ __launch_bounds__(256) void k_blur7_strip(BlurMulti M) {
-    MYSLAM_SIDE_PRIO();
-    // tiled destinations: a wave parks 8 output rows of its 256 columns (16 tiles) here and writes them out as 2 KB of whole cache
-    // lines — two 16-byte stores per lane instead of eight dword stores that each touch 16 lines
-    __shared__ __attribute__((aligned(16))) uint8_t s_tl[4][16 * B3_TS];
+// one wave's band: gw = wave id over all levels (wave-uniform), b = image, tl = the wave's 16 * B3_TS bytes of LDS (tiled destinations: a wave
+// parks 8 output rows of its 256 columns (16 tiles) there and writes them out as 2 KB of whole cache lines — two 16-byte stores per lane
+// instead of eight dword stores that each touch 16 lines).  Called by k_blur7_strip and by the oct-tree launch of small batches (k_octree<512>).
+__device__ __forceinline__ void blur7_strip_wave(const BlurMulti& M, int gw, int b, uint8_t* const tl) {
     const int lane = threadIdx.x & 63;
-    const int gw = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));    // wave id over all levels; scalar: row addressing goes to the SALU
     if (gw >= M.wave0[M.n]) return;
     int lvl = 0;
     while (lvl + 1 < M.n && gw >= M.wave0[lvl + 1]) lvl++;
     const BlurArgs& a = M.a[lvl];
     const int wid = gw - M.wave0[lvl], nstrips = M.nstrips[lvl];                                  // wave id -> (band, strip) of its level
     const int strip = wid % nstrips, band = wid / nstrips;
-    const int b = blockIdx.z;
     const int x0 = strip * 256 + 4 * lane, y0 = band * B3_R;
     const bool ext = b < a.n0;                                   // block-uniform: level 0 read in place (rows of any alignment; the dword
     const uint8_t* src = ext ? a.src0 + (size_t)b * a.sstride0 : a.src + (size_t)b * a.sstride;      // that holds column w-1 may reach into
@@ -505,7 +502,6 @@ __global__ __launch_bounds__(256) void k_blur7_strip(BlurMulti M) {
         h[2] = __builtin_amdgcn_udot4(A2, qa, __builtin_amdgcn_udot4(B2, qb, 0u, false), false);
         h[3] = __builtin_amdgcn_udot4(A3, qa, __builtin_amdgcn_udot4(B3, qb, 0u, false), false);
     };
-    uint8_t* const tl = s_tl[threadIdx.x >> 6];
     // the parked tile row -> memory: chunk c = lane + 64 j of the 128 (tile, row) chunks in memory order; tiles past the row pitch do not exist
     auto flush_tiles = [&](int ty) __attribute__((always_inline)) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -575,6 +571,11 @@ __global__ __launch_bounds__(256) void k_blur7_strip(BlurMulti M) {
     // interior strips: no lane sees an image border, the neighbour dwords of lanes 0 / 63 are plain loads
     const bool interior = strip > 0 && (strip + 1) * 256 + 4 <= a.w;
     if (interior) run(std::false_type{}); else run(std::true_type{});
+}
+__global__ __launch_bounds__(256) void k_blur7_strip(BlurMulti M) {
+    MYSLAM_SIDE_PRIO();
+    __shared__ __attribute__((aligned(16))) uint8_t s_tl[4][16 * B3_TS];
+    blur7_strip_wave(M, __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))), blockIdx.z, s_tl[threadIdx.x >> 6]);      // scalar wave id: row addressing goes to the SALU
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1656,10 +1657,17 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
                                                const int32_t* __restrict__ candCount, uint32_t* __restrict__ sortbuf,
                                                const uint32_t* __restrict__ octTab,
                                                uint32_t* __restrict__ selOut, int32_t* __restrict__ selCount,
-                                               int32_t* __restrict__ status, int NCmax, uint16_t* __restrict__ order) {
+                                               int32_t* __restrict__ status, int NCmax, uint16_t* __restrict__ order, BlurMulti BM) {
     MYSLAM_SIDE_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int t = threadIdx.x;
+    if constexpr (OT == 512) {                                  // small batches: rows of blocks behind the levels' are Gaussian bands (launch_octree)
+        if ((int)blockIdx.y >= P.nlevels) {
+            const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+            blur7_strip_wave(BM, ((int)blockIdx.y - P.nlevels) * 8 + wv, blockIdx.x, smem + wv * (16 * B3_TS));
+            return;
+        }
+    }
     // images along x, levels along y: blocks are dispatched x-fastest, so all level-0 blocks (a third of the candidates sit there) start first
     // and the launch ends on the small top levels, not on a few long blocks
     const int level = blockIdx.y, b = blockIdx.x;
@@ -2745,6 +2753,22 @@ void launch_blur_levels(const BlurArgs* lv, int n, int batch, hipStream_t s) {
 }
 void launch_blur(const BlurArgs& a, int batch, hipStream_t s) { launch_blur_levels(&a, 1, batch, s); }
 
+#ifndef MYSLAM_BLUR_WITH_OCTREE        // A/B builds (tools/build_variants.sh): 0 = the Gaussian keeps its own launch
+#define MYSLAM_BLUR_WITH_OCTREE 1
+#endif
+// small batches: all levels as register strips in the oct-tree's launch — possible when every level takes the strip form (no matrix-core option, aligned planes)
+bool blur_multi_for_octree(const BlurArgs* lv, int n, int batch, BlurMulti& M) {
+    if (!MYSLAM_BLUR_WITH_OCTREE || batch >= OCT_WIDE_BELOW) return false;
+    M.n = 0; M.wave0[0] = 0;
+    for (int i = 0; i < n; i++) {
+        const BlurArgs& a = lv[i];
+        if ((a.tabH && a.tabV) || !blur_uses_strips(a)) return false;
+        const int nstrips = (a.w + 255) / 256, nbands = (a.h + B3_R - 1) / B3_R;
+        M.a[M.n] = a; M.nstrips[M.n] = nstrips; M.wave0[M.n + 1] = M.wave0[M.n] + nstrips * nbands; M.n++;
+    }
+    return M.n > 0;
+}
+
 void launch_fast(const OrbPlan& P, const uint8_t* pyr, size_t pyrStride, const uint8_t* maskPyr, uint32_t* cand,
                  int32_t* candCount, const uint32_t* statPrev, uint32_t* statCur, int forceMode, int batch, hipStream_t s) {
     int cw = 0, ch = 0;
@@ -2758,13 +2782,17 @@ void launch_fast(const OrbPlan& P, const uint8_t* pyr, size_t pyrStride, const u
 
 size_t octree_lds_bytes(int nodeCap) { return 192 + 4 * (size_t)OT_MAXB + 4 * (size_t)(OT_MAXB + 2) + (size_t)nodeCap * 54 + 16; }
 
-void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCount, uint32_t* sortbuf, const uint32_t* octTab, uint32_t* selOut,
-                   int32_t* selCount, int32_t* status, int batch, uint16_t* order, hipStream_t s) {
+bool blur_multi_for_octree(const BlurArgs* lv, int n, int batch, BlurMulti& M);
+// returns true when the Gaussian of the levels blurLv[0 .. nBlur) rode in the launch (small batches; the caller then skips its blur launch)
+bool launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCount, uint32_t* sortbuf, const uint32_t* octTab, uint32_t* selOut,
+                   int32_t* selCount, int32_t* status, int batch, uint16_t* order, hipStream_t s, const BlurArgs* blurLv, int nBlur) {
+    BlurMulti BMh;
+    const BlurMulti* blurWith = (blurLv && nBlur > 0 && blur_multi_for_octree(blurLv, nBlur, batch, BMh)) ? &BMh : nullptr;
     // one launch for all levels, grid (image, level): dispatched x-fastest, the long level-0 blocks all start first and the small levels fill
     // the gaps at the end (with the level along x the launch ended on the last images' level-0 blocks: 0.37 instead of 0.22 ms per 512 images)
     int ncmax = 0;
     for (int l = 0; l < P.nlevels; l++) ncmax = max(ncmax, P.lv[l].nodeCap);
-    const size_t lds = octree_lds_bytes(ncmax);
+    const size_t lds = std::max(octree_lds_bytes(ncmax), (size_t)8 * 16 * B3_TS);
     // The limit is state of the FUNCTION (per device and process), not of a launch: it is always raised to the device's whole LDS, never
     // to this launch's own size — a handle with a smaller plan (or another thread) would otherwise lower it under a launch that is still
     // to come, e.g. the replay of a captured HIP graph (a memory fault, found with two extractor handles of different budgets).
@@ -2773,9 +2801,16 @@ void launch_octree(const OrbPlan& P, const uint32_t* cand, const int32_t* candCo
     // (a grid limit as in launch_describe was measured for this kernel too, round 4: 1 / 2 / 3 blocks per CU gave 7.27 / 7.11 / 7.15 ms per step
     // against 7.11 unlimited, and the loop itself cost 0.1 ms — not built in)
     if (batch >= OCT_WIDE_BELOW)
-        hipLaunchKernelGGL(k_octree<256>, dim3(batch, P.nlevels), dim3(256), lds, s, P, cand, candCount, sortbuf, octTab, selOut, selCount, status, ncmax, order);
+        hipLaunchKernelGGL(k_octree<256>, dim3(batch, P.nlevels), dim3(256), lds, s, P, cand, candCount, sortbuf, octTab, selOut, selCount, status, ncmax, order, BlurMulti{});
     else
-        hipLaunchKernelGGL(k_octree<512>, dim3(batch, P.nlevels), dim3(512), lds, s, P, cand, candCount, sortbuf, octTab, selOut, selCount, status, ncmax, order);
+    {   // small batches: the Gaussian of all levels rides in the same launch (blocks behind the oct-tree's, 8 bands each) — it depends on the
+        // pyramid only, and a recorded step of a few frames is bound by the number of its launches
+        BlurMulti M = blurWith ? *blurWith : BlurMulti{};
+        if (!blurWith) M.n = 0;
+        const int brows = blurWith ? (M.wave0[M.n] + 7) / 8 : 0;
+        hipLaunchKernelGGL(k_octree<512>, dim3(batch, P.nlevels + brows), dim3(512), lds, s, P, cand, candCount, sortbuf, octTab, selOut, selCount, status, ncmax, order, M);
+    }
+    return blurWith != nullptr;
 }
 
 bool describe_uses_tile_order(bool have_order, int detectOnly, int batch) { return have_order && !detectOnly && batch >= 8; }
