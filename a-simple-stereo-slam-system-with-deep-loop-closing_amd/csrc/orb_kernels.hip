@@ -2758,7 +2758,9 @@ void launch_blur(const BlurArgs& a, int batch, hipStream_t s) { launch_blur_leve
 #endif
 // small batches: all levels as register strips in the oct-tree's launch — possible when every level takes the strip form (no matrix-core option, aligned planes)
 bool blur_multi_for_octree(const BlurArgs* lv, int n, int batch, BlurMulti& M) {
-    if (!MYSLAM_BLUR_WITH_OCTREE || batch >= OCT_WIDE_BELOW) return false;
+    // (up to 4 pairs per call: +5 % frames/s at 1 - 2 pairs, even at 4; at 8 and 16 pairs the bands, which then wait for 512-thread blocks with the
+    // oct-tree's LDS, cost 1 - 3 %: profiles/r05_ab_pairs_8_16.log)
+    if (!MYSLAM_BLUR_WITH_OCTREE || batch >= OCT_WIDE_BELOW || batch >= 16) return false;
     M.n = 0; M.wave0[0] = 0;
     for (int i = 0; i < n; i++) {
         const BlurArgs& a = lv[i];
