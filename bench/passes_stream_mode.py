@@ -27,7 +27,7 @@ def stream_mode_sweep(args):
         head = dict(pts[0])
         stream_mode = dict(head, unit="stereo frames/s", sweep=pts,
                            note="recorded steps (HIP graph replay) on L lanes, step k on lane k mod L; every lane has its own extractor / DeepLCD handles and a QUERY CONTEXT "
-                                "of the ONE shared loop database (myslam_lcddb_query_ctx); child processes of this run, GPU_MAX_HW_QUEUES=24.  The GPU runs ~4.4 in-order "
-                                "chains side by side whatever the queue count (profiles/r05_queue_concurrency.json), so frames/s ~ 4.4 x pairs_per_step / chain latency: lanes "
-                                "beyond ~16 add nothing, batching frames of several cameras into one step does")
+                                "of the ONE shared loop database (myslam_lcddb_query_ctx); child processes of this run, GPU_MAX_HW_QUEUES=24.  A step of a few frames is bound by the NUMBER "
+                                "of its dependent launches (~4.6 us per graph node chip-wide, whatever the node does: profiles/r05_node_count_probe.json), so the small-batch forms "
+                                "of the library fold a step's launches (graph_nodes); batching frames of several cameras into one step amortises them")
     return stream_mode
