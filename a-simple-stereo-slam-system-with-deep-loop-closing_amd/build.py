@@ -96,8 +96,19 @@ def build_app(force=False, verbose=False):
     return APP_OUT
 
 
+def rccl_available():
+    return os.path.exists("/opt/rocm/include/rccl/rccl.h") and any(os.path.exists(os.path.join("/opt/rocm/lib", n)) for n in ("librccl.so", "librccl.so.1"))
+
+
 def build_rccl_host(force=False, verbose=False):
-    """bin/sharded_db_rccl: the multi-GPU loop-database host (g++ + the HIP runtime + librccl + the library next to it)"""
+    """bin/sharded_db_rccl: the multi-GPU loop-database host (g++ + the HIP runtime + librccl + the library next to it).  Only this program needs RCCL:
+    on a box without its header or library it is skipped with a warning (the library, run_kitti_stereo and every single-GPU path build and run
+    without it; tests/test_gpu_facade.py skips the program's test when the binary is absent)."""
+    if not rccl_available():
+        if os.path.exists(RCCL_OUT):
+            os.remove(RCCL_OUT)                    # never leave a stale binary behind a library it was not linked against
+        sys.stderr.write("[build.py] rccl.h / librccl not found under /opt/rocm: bin/sharded_db_rccl (the multi-GPU loop-database host) is not built\n")
+        return None
     if force or not os.path.exists(RCCL_OUT):
         os.makedirs(os.path.dirname(RCCL_OUT), exist_ok=True)
         cmd = [CXX, "-O2", "-std=c++17", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(HERE, "..", "include"), RCCL_SRC, "-o", RCCL_OUT,

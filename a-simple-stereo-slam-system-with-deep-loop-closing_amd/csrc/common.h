@@ -104,20 +104,37 @@ class HostCall {
 //     them (wait()) before it rewrites the pinned limits, frees scratch or lets the matrix move.
 struct DbGraphLink {
     std::atomic<uint64_t> generation{0};
+    // bumped when the CONTEXT's own scratch (pinned row limits, partial results, shard scratch) is reallocated while a recorded step names it: the
+    // matrix generation is unchanged then, so a step remembers this number as well and a launch with another one is refused (round 6)
+    std::atomic<uint64_t> scratch_epoch{0};
+    // captures (myslam_graph_begin .. _end) that have recorded a scan of this context and are still open: while one is, nobody may synchronise the
+    // context's stream (hipStreamSynchronize on a capturing stream invalidates the capture) — growth / scratch changes are refused instead
+    std::atomic<int> captures_open{0};
     std::mutex mu;
-    std::vector<hipEvent_t> events;
+    std::vector<hipEvent_t> events;        // one per recorded step that is still alive; a destroyed step's slot is nullptr and is reused
     std::vector<char> launched;
-    ~DbGraphLink() { for (hipEvent_t e : events) (void)hipEventDestroy(e); }
+    ~DbGraphLink() { for (hipEvent_t e : events) if (e) (void)hipEventDestroy(e); }
     void invalidate() { generation.store(UINT64_MAX); }
     int add_event() {                      // -> index of a new event, or -1
         std::lock_guard<std::mutex> lk(mu);
         hipEvent_t e;
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return -1; }
+        for (size_t i = 0; i < events.size(); i++)
+            if (!events[i]) { events[i] = e; launched[i] = 0; return (int)i; }
         events.push_back(e); launched.push_back(0);
         return (int)events.size() - 1;
     }
+    // the step that owned this event is gone (myslam_graph_destroy): its last replay is waited for once, then nobody synchronises on it again
+    void drop_event(int idx) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (idx < 0 || idx >= (int)events.size() || !events[idx]) return;
+        if (launched[idx]) (void)hipEventSynchronize(events[idx]);
+        (void)hipEventDestroy(events[idx]);
+        events[idx] = nullptr; launched[idx] = 0;
+    }
     int mark_replay(int idx, hipStream_t s) {
         std::lock_guard<std::mutex> lk(mu);
+        if (idx < 0 || idx >= (int)events.size() || !events[idx]) return MYSLAM_ERR_INVALID;
         if (hipEventRecord(events[idx], s) != hipSuccess) { (void)hipGetLastError(); return MYSLAM_ERR_HIP; }
         launched[idx] = 1;
         return MYSLAM_OK;
@@ -125,8 +142,14 @@ struct DbGraphLink {
     int wait() {
         std::lock_guard<std::mutex> lk(mu);
         for (size_t i = 0; i < events.size(); i++)
-            if (launched[i] && hipEventSynchronize(events[i]) != hipSuccess) { (void)hipGetLastError(); return MYSLAM_ERR_HIP; }
+            if (events[i] && launched[i] && hipEventSynchronize(events[i]) != hipSuccess) { (void)hipGetLastError(); return MYSLAM_ERR_HIP; }
         return MYSLAM_OK;
+    }
+    size_t live_events() {
+        std::lock_guard<std::mutex> lk(mu);
+        size_t n = 0;
+        for (hipEvent_t e : events) n += e != nullptr;
+        return n;
     }
 };
 // called by a context whose scan is being captured: the step being recorded on this thread (myslam_graph_begin) takes note.

@@ -15,7 +15,7 @@
 
 using namespace myslam_hip;
 
-struct StepDbDep { std::shared_ptr<myslam_hip::DbGraphLink> link; uint64_t generation; int event; };
+struct StepDbDep { std::shared_ptr<myslam_hip::DbGraphLink> link; uint64_t generation; uint64_t scratch_epoch; int event; };
 
 struct myslam_step_graph {
     hipGraph_t graph = nullptr;          // kept alive beside the executable (ROCm 7.2: see orb_engine.hip HostGraph)
@@ -38,14 +38,19 @@ void drop_events() {
     for (hipEvent_t e : t_events) (void)hipEventDestroy(e);
     t_events.clear();
 }
+// the capture that recorded these scans is over (ended, failed or abandoned): their contexts may synchronise their streams again
+void close_deps(std::vector<StepDbDep>& deps) {
+    for (StepDbDep& d : deps) d.link->captures_open.fetch_sub(1);
+}
 }  // namespace
 
 namespace myslam_hip {
 int graph_note_db_link(const std::shared_ptr<DbGraphLink>& link, uint64_t generation) {
     if (!t_capturing) return MYSLAM_ERR_UNSUPPORTED;
     for (StepDbDep& d : t_deps)
-        if (d.link == link) { d.generation = generation; return MYSLAM_OK; }
-    t_deps.push_back({link, generation, -1});
+        if (d.link == link) { d.generation = generation; d.scratch_epoch = link->scratch_epoch.load(); return MYSLAM_OK; }
+    link->captures_open.fetch_add(1);                                 // until myslam_graph_end (graph.hip close_deps)
+    t_deps.push_back({link, generation, link->scratch_epoch.load(), -1});
     return MYSLAM_OK;
 }
 }  // namespace myslam_hip
@@ -58,7 +63,7 @@ int myslam_graph_begin(void* origin_stream, void* const* side_streams, int n_sid
     hipStream_t o = (hipStream_t)origin_stream;
     MYSLAM_HIP_CHECK(hipStreamBeginCapture(o, hipStreamCaptureModeThreadLocal));
     t_capturing = true;
-    t_deps.clear();
+    close_deps(t_deps); t_deps.clear();                                // (a capture abandoned without myslam_graph_end on this thread)
     auto fork = [&]() -> int {
         hipEvent_t e;
         int rc = make_event(&e);
@@ -76,7 +81,7 @@ int myslam_graph_begin(void* origin_stream, void* const* side_streams, int n_sid
         (void)hipStreamEndCapture(o, &g);
         if (g) (void)hipGraphDestroy(g);
         (void)hipGetLastError();
-        drop_events(); t_capturing = false; t_deps.clear();
+        drop_events(); t_capturing = false; close_deps(t_deps); t_deps.clear();
     }
     return rc;
 }
@@ -98,6 +103,7 @@ int myslam_graph_end(void* origin_stream, void* const* side_streams, int n_side,
     drop_events();
     std::vector<StepDbDep> deps;
     deps.swap(t_deps);
+    close_deps(deps);
     if (rc != MYSLAM_OK || ec != hipSuccess || !g) {
         (void)hipGetLastError();
         if (g) (void)hipGraphDestroy(g);
@@ -105,7 +111,11 @@ int myslam_graph_end(void* origin_stream, void* const* side_streams, int n_side,
     }
     for (StepDbDep& d : deps) {
         d.event = d.link->add_event();
-        if (d.event < 0) { (void)hipGraphDestroy(g); return MYSLAM_ERR_HIP; }
+        if (d.event < 0) {
+            for (StepDbDep& e : deps) if (e.event >= 0) e.link->drop_event(e.event);
+            (void)hipGraphDestroy(g);
+            return MYSLAM_ERR_HIP;
+        }
     }
     myslam_step_graph* sg = new myslam_step_graph();
     sg->graph = g;
@@ -114,6 +124,7 @@ int myslam_graph_end(void* origin_stream, void* const* side_streams, int n_side,
     if (hipGraphInstantiate(&sg->exec, g, nullptr, nullptr, 0) != hipSuccess) {
         (void)hipGetLastError();
         (void)hipGraphDestroy(g);
+        for (StepDbDep& d : sg->deps) d.link->drop_event(d.event);
         delete sg;
         return MYSLAM_ERR_HIP;
     }
@@ -126,7 +137,7 @@ int myslam_graph_launch(myslam_step_graph* g, void* hip_stream) {
     // a loop-database scan inside the step names the descriptor matrix by address: refuse the replay when that matrix has moved since
     // (growth beyond its allocation) or its query context is gone — the step has to be recorded again
     for (const StepDbDep& d : g->deps)
-        if (d.link->generation.load() != d.generation) return MYSLAM_ERR_CAPACITY;
+        if (d.link->generation.load() != d.generation || d.link->scratch_epoch.load() != d.scratch_epoch) return MYSLAM_ERR_CAPACITY;
     MYSLAM_HIP_CHECK(hipGraphLaunch(g->exec, (hipStream_t)hip_stream));
     for (const StepDbDep& d : g->deps) {           // the context waits for THIS replay, on the stream it actually went to, before it touches its pinned limits
         const int rc = d.link->mark_replay(d.event, (hipStream_t)hip_stream);
@@ -139,6 +150,7 @@ int myslam_graph_node_count(const myslam_step_graph* g) { return g ? (int)g->nod
 
 int myslam_graph_destroy(myslam_step_graph* g) {
     if (!g) return MYSLAM_ERR_INVALID;
+    for (StepDbDep& d : g->deps) d.link->drop_event(d.event);         // waits for this step's last replay, then the contexts stop synchronising on it
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
     if (g->graph) (void)hipGraphDestroy(g->graph);
     delete g;

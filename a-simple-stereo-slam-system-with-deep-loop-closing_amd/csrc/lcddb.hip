@@ -347,9 +347,23 @@ static void ctx_free(myslam_lcddb_query_ctx* c) {
 
 // everything that may still be reading a context's pinned limits or the matrix through it: its stream + the replays of recorded steps
 static int ctx_quiesce(myslam_lcddb_query_ctx* c) {
+    // a step that scans through this context is being RECORDED (between myslam_graph_begin and _end, possibly on another thread): synchronising the
+    // capturing stream would invalidate the capture, and nothing of the recording is in flight yet — the caller's change (growth, scratch, stream) is
+    // refused until the recording has ended
+    if (c->link && c->link->captures_open.load() > 0) return MYSLAM_ERR_UNSUPPORTED;
     MYSLAM_HIP_CHECK(hipStreamSynchronize(c->stream));
     if (c->link) { const int rc = c->link->wait(); if (rc) return rc; }
     return MYSLAM_OK;
+}
+
+// The context's own scratch (pinned / device row limits, partial results, shard scratch) is about to be freed.  A recorded step names those buffers by
+// address and its matrix generation is unchanged: give the link a new scratch epoch so that myslam_graph_launch refuses the old step
+// (MYSLAM_ERR_CAPACITY: record it again) instead of replaying reads and writes of freed memory.  Called after ctx_quiesce (no replay in flight).
+static void ctx_scratch_moves(myslam_lcddb_query_ctx* c) {
+    if (c->graphRows > 0) {
+        c->link->scratch_epoch.fetch_add(1);
+        c->graphRows = 0; c->graphQueries = 0;
+    }
 }
 
 static myslam_lcddb_query_ctx* ctx_new(myslam_lcddb* db, hipStream_t s, bool builtin) {
@@ -438,6 +452,8 @@ static int db_reserve(myslam_lcddb* h, long long rows) {
     if (rows <= h->capacity) return MYSLAM_OK;
     if (rows > (long long)INT32_MAX - rowsPerBlock) return MYSLAM_ERR_CAPACITY;
     const int cap = (int)((rows + rowsPerBlock - 1) / rowsPerBlock * rowsPerBlock);
+    for (myslam_lcddb_query_ctx* c : h->ctxs)                              // before anything synchronises: a recording in progress is not disturbed (see ctx_quiesce)
+        if (c->link && c->link->captures_open.load() > 0) return MYSLAM_ERR_UNSUPPORTED;
     MYSLAM_HIP_CHECK(hipStreamSynchronize(h->stream));
     bool recorded = false;
     for (myslam_lcddb_query_ctx* c : h->ctxs) {                           // nothing in flight reads the old matrix: every context's stream and
@@ -524,6 +540,7 @@ static int db_query(myslam_lcddb_query_ctx* c, const float* d_q, const uint64_t*
         if (cap) return MYSLAM_ERR_UNSUPPORTED;                          // first call with this many queries: run it once outside the capture
         const int rq = ctx_quiesce(c);
         if (rq) return rq;
+        ctx_scratch_moves(c);
         if (c->d_nvalid) (void)hipFree(c->d_nvalid);
         if (c->h_nvalid) (void)hipHostFree(c->h_nvalid);
         c->d_nvalid = nullptr; c->h_nvalid = nullptr; c->nvalidCap = 0;
@@ -534,10 +551,13 @@ static int db_query(myslam_lcddb_query_ctx* c, const float* d_q, const uint64_t*
     }
     // the row limits of this call; when they equal what the device buffer already holds (the same cur_ids against the same rows, the
     // usual case of a batch of queries per step) nothing is uploaded and the host never waits for the device
+    // h->mu is held from here until the scan and the reduce are ENQUEUED (round 6): the launches name the matrix by address, and an append from another
+    // thread may grow the database (db_reserve) — it takes the same mutex, then synchronises this context's stream, which now covers these launches;
+    // released earlier, the old matrix could be freed between the pointer read and the launch
     int maxv = 0, rows_now, cap_now; float* d_db; uint64_t* d_ids; uint64_t gen;
     bool same;
+    std::lock_guard<std::mutex> lk(h->mu);
     {
-        std::lock_guard<std::mutex> lk(h->mu);
         rows_now = h->n; cap_now = h->capacity; d_db = h->d_db; d_ids = h->d_ids; gen = h->generation;
         same = c->nvFresh && !cap && (int)c->lastLimits.size() == nq && c->lastRows == rows_now;
         c->scratchLimits.resize(nq);
@@ -556,6 +576,7 @@ static int db_query(myslam_lcddb_query_ctx* c, const float* d_q, const uint64_t*
         if (cap) return MYSLAM_ERR_UNSUPPORTED;
         const int rq = ctx_quiesce(c);
         if (rq) return rq;
+        ctx_scratch_moves(c);
         if (c->d_partials) (void)hipFree(c->d_partials);
         MYSLAM_HIP_CHECK(hipMalloc((void**)&c->d_partials, need * sizeof(Partial)));
         c->partialsCap = need;
@@ -619,6 +640,7 @@ static int db_query_sharded(myslam_lcddb_query_ctx* c, const float* d_q, const u
         if (stream_is_capturing(c->stream)) return MYSLAM_ERR_UNSUPPORTED;
         const int rq = ctx_quiesce(c);
         if (rq) return rq;
+        ctx_scratch_moves(c);
         void* old[] = {c->d_bestS, c->d_maxS, c->d_cntS};
         for (void* p : old) if (p) (void)hipFree(p);
         c->d_bestS = nullptr; c->d_maxS = nullptr; c->d_cntS = nullptr; c->shardCap = 0;

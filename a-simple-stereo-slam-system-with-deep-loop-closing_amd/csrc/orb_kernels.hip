@@ -21,6 +21,38 @@ namespace myslam_hip {
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
+// ---- block trace (profiling builds only: tools/build_variants.sh orb_kernels.hip bt:-DMYSLAM_BLOCK_TRACE; tools/block_trace_report.py) --------------
+// Every block (describe: every work item) that runs on XCD 0 leaves one 16-byte record {start, duration | kernel | CU | block id} in a caller-provided
+// buffer: which kernel's blocks are resident on which CU at what time, i.e. the measured form of "where do the idle issue slots sit".  The product
+// build carries none of this (no symbol, no instruction).
+#ifdef MYSLAM_BLOCK_TRACE
+__device__ unsigned long long* g_bt_buf = nullptr;
+__device__ unsigned int g_bt_cap = 0, g_bt_n = 0;
+struct BlockTrace {
+    unsigned long long t0 = 0; int kid; unsigned hw = 0; bool on = false;
+    __device__ __forceinline__ BlockTrace(int kid_) : kid(kid_) {
+        if (threadIdx.x != 0 || g_bt_buf == nullptr) return;
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf;            // HW_REG_XCC_ID
+        if (xcc != 0) return;
+        hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);                                   // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
+        on = true; t0 = __builtin_amdgcn_s_memrealtime();                                 // 100 MHz
+    }
+    __device__ __forceinline__ ~BlockTrace() {
+        if (!on) return;
+        const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t0;
+        const unsigned i = atomicAdd(&g_bt_n, 1u);
+        if (i < g_bt_cap) {
+            g_bt_buf[2 * i] = t0;
+            g_bt_buf[2 * i + 1] = (dt & 0xffffffull) | ((unsigned long long)(kid & 0xf) << 24) | ((unsigned long long)((hw >> 8) & 0xff) << 32) |
+                                  ((unsigned long long)(blockIdx.x & 0xffffff) << 40);
+        }
+    }
+};
+#define MYSLAM_BT(kid) BlockTrace bt_(kid)
+#else
+#define MYSLAM_BT(kid) ((void)0)
+#endif
+
 __constant__ int8_t c_pattern[1024] = {
 #include "orb_pattern.inc"
 };
@@ -163,6 +195,7 @@ constexpr int RS_MAXR = 12;                  // source rows a band may span: RS_
 
 __global__ __launch_bounds__(256) void k_resize_strip(ResizeArgs a, int nstrips, int nbands) {
     MYSLAM_SIDE_PRIO();
+    MYSLAM_BT(1);
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));   // scalar: row addressing goes to the SALU
     const int ngroups = (nbands + RS_NB - 1) / RS_NB;                                              // a wave walks RS_NB consecutive bands of its strip
@@ -574,6 +607,7 @@ __device__ __forceinline__ void blur7_strip_wave(const BlurMulti& M, int gw, int
 }
 __global__ __launch_bounds__(256) void k_blur7_strip(BlurMulti M) {
     MYSLAM_SIDE_PRIO();
+    MYSLAM_BT(3);
     __shared__ __attribute__((aligned(16))) uint8_t s_tl[4][16 * B3_TS];
     blur7_strip_wave(M, __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))), blockIdx.z, s_tl[threadIdx.x >> 6]);      // scalar wave id: row addressing goes to the SALU
 }
@@ -981,6 +1015,7 @@ template <int CW, int G, int CH = CW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 6 : 3))) void k_fast_strip(OrbPlan P, const uint8_t* __restrict__ pyr, size_t pyrStride,
                                                     const uint8_t* __restrict__ maskPyr,
                                                     uint32_t* __restrict__ cand, int32_t* __restrict__ candCount, FastCtl ctl, int batch) {
+    MYSLAM_BT(0);
     constexpr int T = 256;
     constexpr int CP = (CW + 6 + 15) & ~15;                            // every cell's ROI (cell + 6 halo columns) is staged at its own 16-byte aligned offset:
     constexpr int TP = G * CP;                                         //   a lane's 12-byte windows are then dword-aligned and need no byte alignment
@@ -1018,7 +1053,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
 #define MYSLAM_FAST_LDS_BLOCK (163840 / 6 - 128)
 #endif
     constexpr int LDS_PAD = (CW <= 32 && LDS_EST < 163840 / 7) ? MYSLAM_FAST_LDS_BLOCK - LDS_EST : 4;
-    static_assert(CW > 32 || (6 * (LDS_EST + LDS_PAD) <= 163840 && 7 * (LDS_EST + LDS_PAD) > 163840), "exactly six blocks per CU");
+#ifndef MYSLAM_FAST_BLOCKS_PER_CU                              // A/B builds that set another MYSLAM_FAST_LDS_BLOCK say how many blocks it is meant to admit
+#define MYSLAM_FAST_BLOCKS_PER_CU 6
+#endif
+    static_assert(CW > 32 || (MYSLAM_FAST_BLOCKS_PER_CU * (LDS_EST + LDS_PAD) <= 163840 && (MYSLAM_FAST_BLOCKS_PER_CU + 1) * (LDS_EST + LDS_PAD) > 163840), "exactly six blocks per CU");
     __shared__ volatile uint8_t s_padx[LDS_PAD]; s_padx[threadIdx.x & 1] = 0;
 
     // XCD-aware block order (bijective remap of the 1-D grid): the dispatcher places block i on XCD i % 8 and every XCD has a private
@@ -1659,6 +1697,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
                                                uint32_t* __restrict__ selOut, int32_t* __restrict__ selCount,
                                                int32_t* __restrict__ status, int NCmax, uint16_t* __restrict__ order, BlurMulti BM) {
     MYSLAM_SIDE_PRIO();
+    MYSLAM_BT(2);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int t = threadIdx.x;
     if constexpr (OT == 512) {                                  // small batches: rows of blocks behind the levels' are Gaussian bands (launch_octree)
@@ -2505,6 +2544,7 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
     const int lo = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, n = tq + (xcd < tr ? 1 : 0);      // this XCD's contiguous range
 #pragma nounroll
     for (int k = j; k < n; k += per) {
+        MYSLAM_BT(4);
         describe_block(P, pyr, blur, pyrStride, selOut, selCount, kps, desc, counts, status, cap, nchunk, batch, detectOnly, order, lo + k);
         __syncthreads();                               // the next item reuses the block's LDS
     }
@@ -2846,3 +2886,17 @@ void launch_unpack_cands(const uint32_t* cand, int n, int32_t* xs, int32_t* ys, 
 }
 
 }  // namespace myslam_hip
+
+#ifdef MYSLAM_BLOCK_TRACE
+// profiling builds only (see BlockTrace above): d_buf = cap_records x 16 bytes of device memory, nullptr = stop recording; *n = records written so far
+extern "C" int myslam_debug_block_trace(void* d_buf, unsigned cap_records, unsigned* n) {
+    using namespace myslam_hip;
+    unsigned long long* p = (unsigned long long*)d_buf;
+    const unsigned zero = 0;
+    if (n) MYSLAM_HIP_CHECK(hipMemcpyFromSymbol(n, HIP_SYMBOL(g_bt_n), sizeof(unsigned)));
+    if (d_buf) MYSLAM_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_bt_n), &zero, sizeof(unsigned)));
+    MYSLAM_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_bt_cap), &cap_records, sizeof(unsigned)));
+    MYSLAM_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_bt_buf), &p, sizeof(p)));
+    return MYSLAM_OK;
+}
+#endif

@@ -443,6 +443,24 @@ def main():
     host_launch_ms = host_ms[0]
     per_rank_ms = [v / args.steps * 1e3 for v in rank_dts] if world > 1 else None
     per_rank_own_ms = [v / args.steps * 1e3 for v in rank_own] if world > 1 else None
+    if args.block_trace:                # profiling builds only: which kernel's blocks sit on which CU of XCD 0 at what time (tools/block_trace_report.py)
+        import ctypes
+        fn = getattr(api.lib(), "myslam_debug_block_trace")        # AttributeError = this library was not built with -DMYSLAM_BLOCK_TRACE
+        fn.restype = ctypes.c_int; fn.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p]
+        n_cap = 1 << 21
+        d_bt = torch.zeros(2 * n_cap, dtype=torch.int64, device=dev)
+        barrier()
+        assert fn(d_bt.data_ptr(), n_cap, None) == 0
+        t_bt = time.perf_counter()
+        for _ in range(4):
+            step()
+        barrier()
+        t_bt = time.perf_counter() - t_bt
+        n_bt = ctypes.c_uint(0)
+        assert fn(None, 0, ctypes.byref(n_bt)) == 0
+        np.save(args.block_trace, d_bt[:2 * min(n_cap, n_bt.value)].cpu().numpy().view(np.uint64).reshape(-1, 2))
+        print(f"block trace: {n_bt.value} records, 4 steps in {t_bt * 1e3:.2f} ms", file=sys.stderr)
+        del d_bt
     # ---- multi-rank runs: the loop-database exchange timed stage by stage on an otherwise idle chip (bench/passes_multirank.py) ----
     collective = None
     if world > 1 and use_lcd:

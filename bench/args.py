@@ -77,6 +77,8 @@ def parse():
                          "(bench.py --pairs P --lanes L --graph 1: recorded steps on L lanes scanning ONE loop database through L query contexts; its own "
                          "GPU_MAX_HW_QUEUES) and reported as `stream_mode` — the reference's call pattern is one frame per call (src/frontend.cpp:41-77)")
     ap.add_argument("--frame-latency", action="store_true", help="(child of --stream-mode) also time every step on its lane with an event pair: `frame_latency_ms`")
+    ap.add_argument("--block-trace", default="", help="profiling builds only (a library built with -DMYSLAM_BLOCK_TRACE, tools/build_variants.sh): after the timed region run 4 more "
+                    "steps with the block trace on and write the records (npy, 2 x u64 per block that ran on XCD 0) to this file; tools/block_trace_report.py reads it")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = debugging aid: several ranks share GPU 0 and the collectives go through host memory")
     args = ap.parse_args()

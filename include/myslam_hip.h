@@ -323,6 +323,14 @@ int myslam_lcddb_update_query_limits(myslam_lcddb* h, const uint64_t* cur_ids /*
  *     capacity only need myslam_lcddb_ctx_update_query_limits before the next replay.  After a move, myslam_graph_launch of a step
  *     that captured a scan returns MYSLAM_ERR_CAPACITY (record it again); the old matrix stays allocated until the database is
  *     destroyed, so even an unchecked replay reads valid memory;
+ *   - a recorded scan also names the CONTEXT's scratch (row limits, partial results): an eager call on the same context that needs more of it
+ *     (more queries than any call before) replaces that scratch after waiting for the step's replays, and the step is refused from then on
+ *     (MYSLAM_ERR_CAPACITY: record it again) — round 6;
+ *   - while a step that scans through a context is being RECORDED (myslam_graph_begin .. _end, on any thread), nothing may synchronise that
+ *     context's stream: an append / reserve that would have to move the matrix, and myslam_lcddb_set_stream, return MYSLAM_ERR_UNSUPPORTED until
+ *     the recording has ended (appends inside the allocation are unaffected) — round 6;
+ *   - a query holds the database's host lock until its launches are enqueued, so a growing append from another thread waits for them (its stream
+ *     synchronisation then covers the scan) instead of freeing the matrix under a launch that is about to be issued — round 6;
  *   - contexts are destroyed before their database (myslam_lcddb_destroy frees any that are left: their pointers die with it).
  * One thread per context; append / reserve may come from any thread. */
 typedef struct myslam_lcddb_query_ctx myslam_lcddb_query_ctx;

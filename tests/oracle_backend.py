@@ -83,6 +83,13 @@ class CheckedBackend:
         self.calls = {}
         self.dev = {}
 
+    def _soft(self, op, budget):
+        """One more call of `op` was accepted on the oracle's one-ulp self-spread instead of the fixed bar: counted (soft_bar_uses) and budgeted."""
+        self.soft = getattr(self, "soft", {})
+        self.soft[op] = self.soft.get(op, 0) + 1
+        self.dev["soft_bar_uses_" + op] = float(self.soft[op])
+        assert self.soft[op] <= budget, f"{op}: the soft bar (oracle self-spread) was needed {self.soft[op]} times, budget {budget}: an ordering / accept-reject regression, not a weak problem"
+
     def _note(self, op, key=None, val=0.0):
         self.calls[op] = self.calls.get(op, 0) + 1
         if key:
@@ -127,6 +134,9 @@ class CheckedBackend:
             runs = [self.o.pose_only(pose, p3, obs * (1 + rng.choice([-1.0, 1.0], size=obs.shape) * 2.2e-16), Kt, pre) for _ in range(4)]
             spread = max(float(np.abs(q[0] - rp).max()) for q in runs)
             self.dev["pose_only_oracle_one_ulp_spread"] = max(self.dev.get("pose_only_oracle_one_ulp_spread", 0.0), spread)
+            # (advisor, round 5) the soft bar has a BUDGET: it is for the rare weak frame, not a way round an ordering regression — the lock-step runs
+            # of rounds 4 / 5 took it on 0 .. 2 of ~300 frames per sequence; more than max(2, 1 %) of the calls fails the run whatever the spreads say
+            self._soft("pose_only", max(2, self.calls["pose_only"] // 100))
             ok = float(np.abs(gp - rp).max()) <= 3.0 * spread and any(np.array_equal(go, q[1]) and gi == q[2] for q in runs + [(rp, ro, ri)])
             assert ok, (f"pose-only call {self.calls['pose_only'] - 1}", np.abs(gp - rp).max(), gi, ri, "oracle one-ulp spread", spread)
         return gp, go, gi
@@ -209,6 +219,7 @@ class CheckedBackend:
                          for _ in range(4))
             ok = dev <= 3.0 * spread
             self.dev["pgo_oracle_one_ulp_spread"] = max(self.dev.get("pgo_oracle_one_ulp_spread", 0.0), spread)
+            self._soft("pgo", 2)                                  # budget: the two flat-valley graphs of the two-lap drive, nothing more
         if not ok:          # keep the failing problem for an offline look (gpurun_out/ travels back from the GPU box)
             import os
             d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")

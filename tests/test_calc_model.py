@@ -103,3 +103,27 @@ def test_parse_refuses_non_chains_and_deep_nesting(pkg, synth, tmp_path):
     open(pp, "w").write(text)                      # and the untouched file still parses
     L2, _ = api.calc_parse_caffe(pp, mp)
     assert len(L2) == len(L)
+
+
+def test_real_calc_model_if_present(pkg):
+    """The published CALC model (get_model.sh:3-5 of the reference unpacks it into calc_model/) is not in this repository and cannot be
+    downloaded here.  A maintainer who drops calc_model/deploy.prototxt + calc_model/calc.caffemodel at the repository root gets the real
+    file through the dependency-free reader: the layer list must be a chain the library can run and must end in the 1064 values
+    src/deeplcd.cpp:80 asserts.  (tools/pin_kit.md)"""
+    import os
+    from conftest import ROOT
+    pp, mp = os.path.join(ROOT, "calc_model", "deploy.prototxt"), os.path.join(ROOT, "calc_model", "calc.caffemodel")
+    if not (os.path.exists(pp) and os.path.exists(mp)):
+        pytest.skip("calc_model/ (the published CALC weights) is not present")
+    L, w = pkg.api.calc_parse_caffe(pp, mp)
+    h, wd, ch = 120, 160, 1
+    for l in L:
+        t = int(l["type"])
+        if t == 1:                                        # convolution
+            k, s, p = int(l["kernel"]), int(l["stride"]), int(l["pad"])
+            h, wd, ch = (h + 2 * p - k) // s + 1, (wd + 2 * p - k) // s + 1, int(l["num_output"])
+        elif t == 3:                                      # max pooling, Caffe's ceil mode
+            k, s = int(l["kernel"]), int(l["stride"])
+            h, wd = -(-(h - k) // s) + 1, -(-(wd - k) // s) + 1
+    assert h * wd * ch == 1064, (h, wd, ch)
+    assert w.size > 0 and np.isfinite(w).all()

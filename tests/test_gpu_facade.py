@@ -37,6 +37,8 @@ def test_cpp_sharded_db_over_rccl(synth, tmp_path):
     import numpy as np
     import torch
     exe = os.path.join(PKG_DIR, "bin", "sharded_db_rccl")          # built by build.py (g++ + librccl + the library), as bin/run_kitti_stereo is
+    if not os.path.exists(exe) and not (os.path.exists("/opt/rocm/include/rccl/rccl.h") and os.path.exists("/opt/rocm/lib/librccl.so")):
+        pytest.skip("no RCCL on this box: build.py does not build the multi-GPU host (round 6: only this program needs librccl)")
     assert os.path.exists(exe), "build.py did not produce bin/sharded_db_rccl"
     n_db, nq = 3000, 64
     db = synth.lcd_database(n_db)

@@ -176,3 +176,84 @@ def test_sharded_scan_through_a_context_reports_the_break_after_appends(api, ora
     ctx.query_batch_sharded(d_q.data_ptr(), np.array([n + 32 + 20, n + 32 + 20, n + 25], np.uint64), nq, d_cand.data_ptr()); torch.cuda.synchronize()
     rec = d_cand.cpu().numpy().view(api.CAND_DTYPE)
     assert [(int(c) >> 31) & 1 for c in rec["cnt"]] == [0, 0, 1]
+
+
+def test_scratch_reallocation_invalidates_recorded_steps(api, oracle, synth):
+    """Advisor, round 5: a recorded scan names the context's OWN scratch by address (pinned row limits, partial results).  An eager call with
+    more queries on the same context frees and reallocates that scratch while the matrix generation stays what it was — the old step must be
+    refused (MYSLAM_ERR_CAPACITY: record it again), not replayed against freed memory."""
+    import torch
+    n0 = 900
+    db = synth.lcd_database(n0, seed=31); ids = np.arange(n0, dtype=np.uint64)
+    t_db = torch.from_numpy(db).cuda()
+    D = api.LoopDatabase(n0 + 100)
+    D.append_batch(ids, t_db.data_ptr(), n0)
+    st = torch.cuda.Stream(); ctx = D.context(st.cuda_stream)
+
+    def bufs(nq):
+        return (torch.zeros(nq, dtype=torch.int64, device="cuda"), torch.zeros(nq, device="cuda"), torch.zeros(nq, dtype=torch.int32, device="cuda"))
+    q2 = db[[4, 444]].copy(); d_q2 = torch.from_numpy(q2).cuda(); o2 = bufs(2)
+    cur2 = np.full(2, n0 + 20, np.uint64)
+    body2 = lambda: ctx.query_batch(d_q2.data_ptr(), cur2, 2, *[t.data_ptr() for t in o2])
+    torch.cuda.synchronize()
+    body2(); torch.cuda.synchronize()
+    g = api.StepGraph.record(st.cuda_stream, [], body2)
+    g.launch(st.cuda_stream); torch.cuda.synchronize()
+    _check(oracle, db, ids, n0, q2, cur2, *[t.cpu().numpy() for t in o2], tag="recorded, 2 queries")
+    # an eager call with 9 queries: row-limit staging (nq + 1 ints) and partial results are reallocated
+    q9 = db[np.arange(9) * 97].copy(); d_q9 = torch.from_numpy(q9).cuda(); o9 = bufs(9)
+    cur9 = np.full(9, n0 + 20, np.uint64)
+    g.launch(st.cuda_stream)                                       # a replay in flight while the scratch is replaced: the call waits for it
+    ctx.query_batch(d_q9.data_ptr(), cur9, 9, *[t.data_ptr() for t in o9]); torch.cuda.synchronize()
+    _check(oracle, db, ids, n0, q9, cur9, *[t.cpu().numpy() for t in o9], tag="eager, 9 queries")
+    assert D.generation() == 0
+    with pytest.raises(api.MyslamError) as e:
+        g.launch(st.cuda_stream)
+    assert e.value.code == -3                                      # MYSLAM_ERR_CAPACITY
+    with pytest.raises(api.MyslamError):
+        ctx.update_query_limits(cur2)                              # no recorded query to feed any more
+    # recorded again (now against the larger scratch), it replays; 40 record / destroy cycles leave no growing list of events to wait on
+    for k in range(40):
+        g2 = api.StepGraph.record(st.cuda_stream, [], body2)
+        for t in o2:
+            t.zero_()
+        g2.launch(st.cuda_stream); torch.cuda.synchronize()
+        if k % 13 == 0:
+            _check(oracle, db, ids, n0, q2, cur2, *[t.cpu().numpy() for t in o2], tag=f"re-recorded {k}")
+        del g2
+
+
+def test_growth_is_refused_while_a_step_is_being_recorded(api, synth):
+    """db_reserve synchronises every context's stream; a stream that is capturing must not be synchronised (the capture would be invalidated).  While
+    a recording that scans through a context is open, an append that has to MOVE the matrix returns MYSLAM_ERR_UNSUPPORTED (before it synchronises
+    anything); after myslam_graph_end the growth goes through and the step (recorded against the old matrix) is refused."""
+    import torch
+    n0 = 256
+    db = synth.lcd_database(n0 + 600, seed=41); ids = np.arange(n0 + 600, dtype=np.uint64)
+    t_db = torch.from_numpy(db).cuda()
+    D = api.LoopDatabase(n0 + 32)
+    D.append_batch(ids[:n0], t_db.data_ptr(), n0)
+    st = torch.cuda.Stream(); ctx = D.context(st.cuda_stream)
+    d_q = torch.from_numpy(db[[1, 2]].copy()).cuda()
+    o = (torch.zeros(2, dtype=torch.int64, device="cuda"), torch.zeros(2, device="cuda"), torch.zeros(2, dtype=torch.int32, device="cuda"))
+    cur = np.full(2, n0 + 700, np.uint64)
+    seen = {}
+
+    def body():
+        ctx.query_batch(d_q.data_ptr(), cur, 2, *[t.data_ptr() for t in o])
+        try:
+            D.append_batch(ids[n0 + 8:n0 + 600], t_db.data_ptr() + (n0 + 8) * 1064 * 4, 592)    # must move the matrix
+            seen["code"] = 0
+        except api.MyslamError as e:
+            seen["code"] = e.code
+    D.append_batch(ids[n0:n0 + 8], t_db.data_ptr() + n0 * 1064 * 4, 8)
+    torch.cuda.synchronize()
+    ctx.query_batch(d_q.data_ptr(), cur, 2, *[t.data_ptr() for t in o]); torch.cuda.synchronize()
+    g = api.StepGraph.record(st.cuda_stream, [], body)
+    assert seen["code"] == -4, seen                                # MYSLAM_ERR_UNSUPPORTED
+    assert len(D) == n0 + 8 and D.generation() == 0
+    g.launch(st.cuda_stream); torch.cuda.synchronize()
+    D.append_batch(ids[n0 + 8:n0 + 600], t_db.data_ptr() + (n0 + 8) * 1064 * 4, 592)    # recording closed: the matrix moves
+    assert D.generation() == 1 and len(D) == n0 + 600
+    with pytest.raises(api.MyslamError):
+        g.launch(st.cuda_stream)
