@@ -37,6 +37,9 @@ assert CALC_LAYER_DTYPE.itemsize == 36
 CALC_CONV, CALC_RELU, CALC_POOL_MAX, CALC_LRN = 1, 2, 3, 4
 CAND_DTYPE = np.dtype([("best_id", "<u8"), ("max_score", "<f4"), ("cnt", "<i4")])      # myslam_lcd_candidate
 assert CAND_DTYPE.itemsize == 16
+OWNED_DTYPE = np.dtype([("pre_best_id", "<u8"), ("pre_max_score", "<f4"), ("pre_cnt", "<i4"),
+                        ("suf_best_id", "<u8"), ("suf_max_score", "<f4"), ("suf_cnt", "<i4")])      # myslam_lcd_owned_candidate
+assert OWNED_DTYPE.itemsize == 32
 
 _lib = None
 _SCALARS = {"int": C.c_int, "float": C.c_float, "double": C.c_double, "size_t": C.c_size_t, "uint64_t": C.c_uint64, "long": C.c_long,
@@ -91,6 +94,22 @@ def _p(a):
 
 def device_count():
     return lib().myslam_hip_device_count()
+
+
+def version():
+    """'myslam_hip <version> (gfx950) build <digest of the sources>'"""
+    return lib().myslam_hip_version().decode()
+
+
+def build_id():
+    return version().rsplit(" ", 1)[-1]
+
+
+def shader_clock_mhz(stream=0, spin_us=200.0):
+    """the shader clock right now, measured on the device (one wave spins for spin_us); synchronises `stream`"""
+    v = C.c_float()
+    _check(lib().myslam_prof_shader_clock_mhz(stream, float(spin_us), C.byref(v)), "myslam_prof_shader_clock_mhz")
+    return float(v.value)
 
 
 # ---------------------------------------------------------------------------------- profiling
@@ -469,6 +488,11 @@ class LoopDatabase:
         cur = np.ascontiguousarray(cur_ids, np.uint64)
         _check(lib().myslam_lcddb_query_batch_sharded(self._h, d_q, _p(cur), nq, thr_low, d_cand), "myslam_lcddb_query_batch_sharded")
 
+    def query_batch_owned(self, d_q, cur_ids, nq, d_cand, thr_low=0.92):
+        """records of a shard whose ids interleave with the other shards' (myslam_lcd_owned_candidate, 32 bytes each, device memory)"""
+        cur = np.ascontiguousarray(cur_ids, np.uint64)
+        _check(lib().myslam_lcddb_query_batch_owned(self._h, d_q, _p(cur), nq, thr_low, d_cand), "myslam_lcddb_query_batch_owned")
+
     def generation(self):
         """number of times the descriptor matrix has moved (growth): recorded steps are valid for the generation they were recorded in"""
         return lib().myslam_lcddb_generation(self._h)
@@ -504,6 +528,11 @@ class LoopQueryContext:
     def query_batch_sharded(self, d_q, cur_ids, nq, d_cand, thr_low=0.92):
         cur = np.ascontiguousarray(cur_ids, np.uint64)
         _check(lib().myslam_lcddb_ctx_query_batch_sharded(self._h, d_q, _p(cur), nq, thr_low, d_cand), "myslam_lcddb_ctx_query_batch_sharded")
+
+
+    def query_batch_owned(self, d_q, cur_ids, nq, d_cand, thr_low=0.92):
+        cur = np.ascontiguousarray(cur_ids, np.uint64)
+        _check(lib().myslam_lcddb_ctx_query_batch_owned(self._h, d_q, _p(cur), nq, thr_low, d_cand), "myslam_lcddb_ctx_query_batch_owned")
 
 
 class StepGraph:
@@ -557,6 +586,21 @@ def lcd_merge_candidates(gathered):
 def lcd_merge_candidates_device(d_gathered, nshards, nq, d_best, d_max, d_cnt, stream=0):
     _check(lib().myslam_lcd_merge_candidates_device(d_gathered, nshards, nq, d_best, d_max, d_cnt, stream or None),
            "myslam_lcd_merge_candidates_device")
+
+
+def lcd_merge_owned_candidates(gathered):
+    """gathered: [nshards, nq] OWNED_DTYPE records, any shard order (host) -> (best_id u64, max_score f32, cnt i32) of ONE scan of the whole map"""
+    g = np.ascontiguousarray(gathered, OWNED_DTYPE)
+    assert g.ndim == 2
+    ns, nq = g.shape
+    best = np.zeros(nq, np.uint64); mx = np.zeros(nq, np.float32); cnt = np.zeros(nq, np.int32)
+    _check(lib().myslam_lcd_merge_owned_candidates(_p(g), ns, nq, _p(best), _p(mx), _p(cnt)), "myslam_lcd_merge_owned_candidates")
+    return best, mx, cnt
+
+
+def lcd_merge_owned_candidates_device(d_gathered, nshards, nq, d_best, d_max, d_cnt, stream=0):
+    _check(lib().myslam_lcd_merge_owned_candidates_device(d_gathered, nshards, nq, d_best, d_max, d_cnt, stream or None),
+           "myslam_lcd_merge_owned_candidates_device")
 
 
 # ---------------------------------------------------------------------------------- BA

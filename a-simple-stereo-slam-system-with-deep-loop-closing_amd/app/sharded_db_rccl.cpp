@@ -11,7 +11,9 @@
 // "rank r: allgather_queries_ms … shard_scan_ms … allgather_candidates_ms … merge_ms …" — the per-step collective / scan cost a multi-GPU
 // run of bench.py reports under the same names (DESIGN.md section 4 holds the predicted values for N = 2 / 4 / 8).
 // Built by build.py into bin/sharded_db_rccl (g++; -D__HIP_PLATFORM_AMD__ is what the HIP runtime headers need from a plain host compiler).
-//   usage: sharded_db_rccl <db.f32> <queries.f32> <cur_ids.u64> <n_db> <nq> [reps = 20]      (nq divisible by WORLD_SIZE)
+//   usage: sharded_db_rccl <db.f32> <queries.f32> <cur_ids.u64> <n_db> <nq> [reps = 20] [grow_steps = 0]      (nq divisible by WORLD_SIZE)
+//   grow_steps > 0: after the static exchange, the GROWING database of round 6 (see below): appends and queries interleaved for that many steps, ownership by
+//   arrival over WORLD_SIZE x $MYSLAM_LOCAL_SHARDS shards, every answer checked against one map on rank 0
 //   the ncclUniqueId travels through the file $MYSLAM_NCCL_ID_FILE (rank 0 writes it; a launcher with MPI would broadcast it instead)
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -171,6 +173,96 @@ int main(int argc, char** argv) {
         printf("rank %d: allgather_queries_ms %.4f (%zu B per rank) shard_scan_ms %.4f (%d rows x %d queries) allgather_candidates_ms %.4f (%zu B per rank) merge_ms %.4f  [mean of %d]\n",
                rank, acc[0] / reps, sizeof(float) * (size_t)P * D, acc[1] / reps, hi - lo, nq, acc[2] / reps, sizeof(myslam_lcd_candidate) * (size_t)nq, acc[3] / reps, reps);
         for (auto& e : ev) (void)hipEventDestroy(e);
+    }
+    // ---- a database that GROWS under the ranks (round 6) ------------------------------------------------------------------------------------------
+    // The reference appends per key-frame (LoopClosing::AddToDatabase, src/loopclosing.cpp:651-659).  `grow_steps` steps; in each, every rank brings K new
+    // key-frames (id, descriptor), all ranks all-gather them, every SHARD scores every query (myslam_lcddb_query_batch_owned: 32-byte records, the shard's
+    // ids interleave with the others'), the records are all-gathered and merged (myslam_lcd_merge_owned_candidates_device), and then the step's key-frames
+    // are appended: the j-th in id order goes to shard (appended so far + j) mod S — every rank computes the same owners from the same gathered list, no
+    // further collective, row counts never more than 1 apart.  S = WORLD_SIZE x MYSLAM_LOCAL_SHARDS (L shards per process: on a one-GPU box L > 1 still
+    // interleaves ownership for real).  Rank 0 keeps ONE map with everything in it and checks every merged answer against its single scan, bit for bit.
+    const int grow_steps = argc > 7 ? atoi(argv[7]) : 0;
+    if (grow_steps > 0 && !bad) {
+        const int L = std::max(1, env_int("MYSLAM_LOCAL_SHARDS", 1)), S = world * L, K = 2, NQg = world * K;
+        std::vector<myslam_lcddb*> gs(L, nullptr);
+        for (auto& g : gs) { MYOK(myslam_lcddb_create(&g, 16)); MYOK(myslam_lcddb_set_stream(g, s)); }
+        myslam_lcddb* one = nullptr;
+        if (rank == 0) { MYOK(myslam_lcddb_create(&one, 16)); MYOK(myslam_lcddb_set_stream(one, s)); }
+        float *d_new = nullptr, *d_alln = nullptr; uint64_t *d_ids = nullptr, *d_allids = nullptr;
+        myslam_lcd_owned_candidate *d_rec = nullptr, *d_grec = nullptr;
+        uint64_t *d_gb = nullptr, *d_rb = nullptr; float *d_gm = nullptr, *d_rm = nullptr; int32_t *d_gc = nullptr, *d_rc = nullptr;
+        HIPOK(hipMalloc((void**)&d_new, sizeof(float) * K * D)); HIPOK(hipMalloc((void**)&d_alln, sizeof(float) * NQg * D));
+        HIPOK(hipMalloc((void**)&d_ids, 8 * K)); HIPOK(hipMalloc((void**)&d_allids, 8 * NQg));
+        HIPOK(hipMalloc((void**)&d_rec, sizeof(myslam_lcd_owned_candidate) * L * NQg)); HIPOK(hipMalloc((void**)&d_grec, sizeof(myslam_lcd_owned_candidate) * S * NQg));
+        HIPOK(hipMalloc((void**)&d_gb, 8 * NQg)); HIPOK(hipMalloc((void**)&d_gm, 4 * NQg)); HIPOK(hipMalloc((void**)&d_gc, 4 * NQg));
+        HIPOK(hipMalloc((void**)&d_rb, 8 * NQg)); HIPOK(hipMalloc((void**)&d_rm, 4 * NQg)); HIPOK(hipMalloc((void**)&d_rc, 4 * NQg));
+        long long total = 0; int gbad = 0, gq = 0, gloop = 0, spread = 0;
+        std::vector<uint64_t> hid(K), allid(NQg), gb(NQg), rb(NQg); std::vector<float> gm(NQg), rm(NQg); std::vector<int32_t> gc(NQg), rc(NQg);
+        for (int st = 0; st < grow_steps && !gbad; st++) {
+            // this rank's K new key-frames: rows of the database file (they repeat when the file is exhausted: equal rows in different shards, the tie rule)
+            for (int j = 0; j < K; j++) {
+                hid[j] = (uint64_t)st * (uint64_t)(NQg + 3) + (uint64_t)((long long)(rank * K + j) * (NQg - 1) % NQg);      // ids grow step by step; within a step the ranks' ids interleave (x -> -x mod NQg: distinct)
+                const size_t row = ((size_t)st * NQg + (size_t)rank * K + j) % (size_t)std::min(n_db, 97);
+                HIPOK(hipMemcpyAsync(d_new + (size_t)j * D, db.data() + row * D, sizeof(float) * D, hipMemcpyHostToDevice, s));
+            }
+            HIPOK(hipMemcpyAsync(d_ids, hid.data(), 8 * K, hipMemcpyHostToDevice, s));
+            NCCLOK(ncclAllGather(d_new, d_alln, (size_t)K * D, ncclFloat, comm, s));
+            NCCLOK(ncclAllGather(d_ids, d_allids, (size_t)K, ncclUint64, comm, s));
+            HIPOK(hipMemcpyAsync(allid.data(), d_allids, 8 * NQg, hipMemcpyDeviceToHost, s));
+            HIPOK(hipStreamSynchronize(s));                                     // the row ranges of a query are computed on the host from its id
+            for (int l = 0; l < L; l++) MYOK(myslam_lcddb_query_batch_owned(gs[l], d_alln, allid.data(), NQg, thr_low, d_rec + (size_t)l * NQg));
+            NCCLOK(ncclAllGather(d_rec, d_grec, sizeof(myslam_lcd_owned_candidate) * (size_t)L * NQg, ncclChar, comm, s));
+            MYOK(myslam_lcd_merge_owned_candidates_device(d_grec, S, NQg, d_gb, d_gm, d_gc, s));
+            if (rank == 0) {
+                if (myslam_lcddb_size(one) > 0) {
+                    MYOK(myslam_lcddb_query_batch(one, d_alln, allid.data(), NQg, thr_low, d_rb, d_rm, d_rc));
+                    HIPOK(hipMemcpyAsync(gb.data(), d_gb, 8 * NQg, hipMemcpyDeviceToHost, s)); HIPOK(hipMemcpyAsync(gm.data(), d_gm, 4 * NQg, hipMemcpyDeviceToHost, s));
+                    HIPOK(hipMemcpyAsync(gc.data(), d_gc, 4 * NQg, hipMemcpyDeviceToHost, s)); HIPOK(hipMemcpyAsync(rb.data(), d_rb, 8 * NQg, hipMemcpyDeviceToHost, s));
+                    HIPOK(hipMemcpyAsync(rm.data(), d_rm, 4 * NQg, hipMemcpyDeviceToHost, s)); HIPOK(hipMemcpyAsync(rc.data(), d_rc, 4 * NQg, hipMemcpyDeviceToHost, s));
+                    HIPOK(hipStreamSynchronize(s));
+                    for (int i = 0; i < NQg; i++) {
+                        gq++;
+                        if (gb[i] != rb[i] || gc[i] != rc[i] || memcmp(&gm[i], &rm[i], 4) != 0) {
+                            if (gbad++ < 5) fprintf(stderr, "growing step %d query %d (id %llu): shards (%llu, %.9g, %d) vs one map (%llu, %.9g, %d)\n", st, i, (unsigned long long)allid[i],
+                                                    (unsigned long long)gb[i], gm[i], gc[i], (unsigned long long)rb[i], rm[i], rc[i]);
+                        }
+                        gloop += (gm[i] >= 0.94f && gc[i] <= 3);
+                    }
+                }
+            }
+            // AddToDatabase after DetectLoop: the step's key-frames in id order, the j-th to shard (total + j) mod S
+            std::vector<int> order(NQg);
+            for (int i = 0; i < NQg; i++) order[i] = i;
+            std::sort(order.begin(), order.end(), [&](int a, int b) { return allid[a] < allid[b]; });
+            for (int j = 0; j < NQg; j++) {
+                const int slot = order[j], owner = (int)((total + j) % S);
+                if (j && allid[order[j]] == allid[order[j - 1]]) { fprintf(stderr, "duplicate key-frame id in one step\n"); return 7; }
+                if (owner / L == rank) MYOK(myslam_lcddb_append_batch(gs[owner % L], &allid[slot], d_alln + (size_t)slot * D, 1));
+                if (rank == 0) MYOK(myslam_lcddb_append_batch(one, &allid[slot], d_alln + (size_t)slot * D, 1));
+            }
+            total += NQg;
+            int lo_rows = INT32_MAX, hi_rows = 0;
+            for (auto g : gs) { lo_rows = std::min(lo_rows, myslam_lcddb_size(g)); hi_rows = std::max(hi_rows, myslam_lcddb_size(g)); }
+            spread = std::max(spread, hi_rows - lo_rows);
+        }
+        // every shard of the job within one row of every other: the counts travel once at the end (the owners were computed identically everywhere)
+        std::vector<int32_t> cnts(L), allc((size_t)S); int32_t *d_c = nullptr, *d_ac = nullptr;
+        for (int l = 0; l < L; l++) cnts[l] = myslam_lcddb_size(gs[l]);
+        HIPOK(hipMalloc((void**)&d_c, 4 * L)); HIPOK(hipMalloc((void**)&d_ac, 4 * S));
+        HIPOK(hipMemcpyAsync(d_c, cnts.data(), 4 * L, hipMemcpyHostToDevice, s));
+        NCCLOK(ncclAllGather(d_c, d_ac, (size_t)L, ncclInt32, comm, s));
+        HIPOK(hipMemcpyAsync(allc.data(), d_ac, 4 * S, hipMemcpyDeviceToHost, s)); HIPOK(hipStreamSynchronize(s));
+        const int cmin = *std::min_element(allc.begin(), allc.end()), cmax = *std::max_element(allc.begin(), allc.end());
+        long long csum = 0; for (int v : allc) csum += v;
+        if (cmax - cmin > 1 || csum != total || spread > 1) { fprintf(stderr, "rank %d: unbalanced shards (%d .. %d rows, sum %lld of %lld)\n", rank, cmin, cmax, csum, total); gbad++; }
+        if (rank == 0)
+            printf("%s shards=%d (ranks=%d x local=%d) steps=%d key_frames=%lld queries_checked=%d accepted_loops=%d rows_per_shard=%d..%d mismatches=%d\n",
+                   gbad ? "GROWING SHARDED DB FAILED" : "GROWING SHARDED DB OK", S, world, L, grow_steps, total, gq, gloop, cmin, cmax, gbad);
+        bad += gbad;
+        for (auto g : gs) (void)myslam_lcddb_destroy(g);
+        if (one) (void)myslam_lcddb_destroy(one);
+        void* fg[] = {d_new, d_alln, d_ids, d_allids, d_rec, d_grec, d_gb, d_gm, d_gc, d_rb, d_rm, d_rc, d_c, d_ac};
+        for (void* p : fg) (void)hipFree(p);
     }
     (void)myslam_lcddb_destroy(shard);
     void* fr[] = {d_myq, d_allq, d_cand, d_gath, d_best, d_max, d_cnt};

@@ -53,14 +53,30 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+def build_id():
+    """Digest of every source the library is built from (csrc/, host/, include/myslam_hip.h, this file's flags): myslam_hip_version() carries it"""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted([os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc"))] + [d for d in _deps() if not d.startswith(CSRC)])
+    for f in files:
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    h.update(repr((COMMON, sorted(UNITS.items()))).encode())
+    return h.hexdigest()[:12]
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJDIR, exist_ok=True)
     deps = _deps()
     jobs = []
+    bid = build_id()
+    bid_file = os.path.join(OBJDIR, "build_id.txt")
+    bid_changed = not os.path.exists(bid_file) or open(bid_file).read().strip() != bid
     for src, extra in UNITS.items():
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + deps):
+        if src == "prof.hip":                   # carries the digest: recompiled whenever any source changed
+            extra = extra + ['-DMYSLAM_BUILD_ID="%s"' % bid]
+        if force or _stale(o, [s] + deps) or (src == "prof.hip" and bid_changed):
             jobs.append([HIPCC] + COMMON + extra + ["-c", s, "-o", o])
 
     def run(cmd):
@@ -75,6 +91,8 @@ def build(force=False, verbose=False):
         for warn in ex.map(run, jobs):
             if verbose and warn.strip():
                 print(warn)
+    with open(bid_file, "w") as f:
+        f.write(bid + "\n")
     objs = [os.path.join(OBJDIR, src.replace(".hip", ".o")) for src in UNITS]
     if force or jobs or _stale(OUT, objs):
         run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT] + objs)

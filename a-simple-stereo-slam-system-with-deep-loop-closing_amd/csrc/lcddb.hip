@@ -21,14 +21,17 @@ constexpr int DB_ROWS_PER_WAVE = 8;
 
 struct Partial { float score; int32_t idx; int32_t cnt; };
 
+// nstart (may be null = 0 for every query): first row a query looks at — a query's rows are [nstart, nvalid) (round 6: the scan BEHIND the cut-off window of a
+// shard that owns interleaved ids, myslam_lcddb_query_batch_owned)
 __global__ __launch_bounds__(256) void k_db_scan(const float* __restrict__ db, const float* __restrict__ q, int nq,
-                                                 const int32_t* __restrict__ nvalid, float thr_low,
+                                                 const int32_t* __restrict__ nvalid, const int32_t* __restrict__ nstart, float thr_low,
                                                  Partial* __restrict__ partials /*[nblocks][nq]*/) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_db[];
     Partial* s_p = reinterpret_cast<Partial*>(smem_db);          // [DB_WAVES][nq]
     int* s_lim = reinterpret_cast<int*>(s_p + DB_WAVES * nq);    // [nq]: the row limits, read ONCE (a recorded step reads them from pinned host memory)
+    int* s_beg = s_lim + nq;                                     // [nq]: first rows
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int qi = threadIdx.x; qi < nq; qi += 256) s_lim[qi] = nvalid[qi];
+    for (int qi = threadIdx.x; qi < nq; qi += 256) { s_lim[qi] = nvalid[qi]; s_beg[qi] = nstart ? nstart[qi] : 0; }
     __syncthreads();
     {   // a launch covers the allocation (recorded steps outlive appends): blocks behind every query's row limit leave an empty partial
         int lim = 0;
@@ -48,7 +51,7 @@ __global__ __launch_bounds__(256) void k_db_scan(const float* __restrict__ db, c
         for (int k = 0; k < 16; k++) v[k] = row[k * 64 + lane];
         v[16] = (lane < DIM - 1024) ? row[1024 + lane] : 0.f;
         for (int qi = 0; qi < nq; qi++) {
-            if (r >= s_lim[qi]) continue;                       // cut-off rule, loopclosing.cpp:133 (uniform per wave)
+            if (r >= s_lim[qi] || r < s_beg[qi]) continue;      // cut-off rule, loopclosing.cpp:133 (uniform per wave)
             const float* qq = q + (size_t)qi * DIM;
             float acc = 0.f;
 #pragma unroll
@@ -100,7 +103,7 @@ __device__ __forceinline__ void db_split3(float a0, float a1, uint32_t& h, uint3
 }
 
 __global__ __launch_bounds__(256) void k_db_scan_bf16x6(const float* __restrict__ db, int rows_alloc, const float* __restrict__ q,
-                                                        int nq, const int32_t* __restrict__ nvalid, float thr_low,
+                                                        int nq, const int32_t* __restrict__ nvalid, const int32_t* __restrict__ nstart, float thr_low,
                                                         Partial* __restrict__ partials) {
     MYSLAM_SIDE_PRIO();
     __shared__ uint4 s_a[2][3][GM * 2];                // [piece][row][k half] x 8 bf16
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256) void k_db_scan_bf16x6(const float* __restrict_
     const int m0 = blockIdx.x * GM, n0 = blockIdx.y * GN;
     {   // blocks behind the row limits of all of their queries leave empty partials (see k_db_scan)
         const int n = n0 + (t & (GN - 1));
-        const bool live = n < nq && nvalid[n] > m0;
+        const bool live = n < nq && nvalid[n] > m0 && (!nstart || nstart[n] < m0 + GM);
         if (__syncthreads_or(live ? 1 : 0) == 0) {
             if (t < GN && n0 + t < nq) partials[(size_t)blockIdx.x * nq + n0 + t] = {0.f, -1, 0};
             return;
@@ -188,6 +191,7 @@ __global__ __launch_bounds__(256) void k_db_scan_bf16x6(const float* __restrict_
     for (int j = 0; j < 2; j++) {
         const int n = n0 + wn + j * 32 + lr;
         const int nv = (n < nq) ? nvalid[n] : 0;
+        const int ns = (nstart && n < nq) ? nstart[n] : 0;
         float bs = 0.f; int bi = -1, cnt = 0;
 #pragma unroll
         for (int i = 0; i < 2; i++)
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(256) void k_db_scan_bf16x6(const float* __restrict_
             for (int r = 0; r < 16; r++) {
                 const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 const float sc = acc[i][j][r];
-                if (m < nv) {
+                if (m < nv && m >= ns) {
                     if (better(sc, m, bs, bi)) { bs = sc; bi = m; }
                     cnt += (sc > thr_low);
                 }
@@ -277,6 +281,53 @@ __global__ __launch_bounds__(256) void k_db_merge_candidates(const myslam_lcd_ca
     best_id[qi] = b; max_score[qi] = m; cnt[qi] = c;
 }
 
+// ---- shards that own INTERLEAVED ids (round 6: a sharded database that grows) -----------------------------------------------------------------------
+// With contiguous id ranges every new key-frame lands on the last rank.  When ownership is by arrival order (key-frame k of the job goes to rank k mod N,
+// any rule that puts every id into exactly one shard will do) a shard's ids interleave with the others', and "the first shard that broke ends the scan"
+// no longer describes the reference's ONE ascending scan (loopclosing.cpp:124-161).  What does: the scan looks at every id BELOW the cut-off window
+// W = {id : cur - id < 20 (mod 2^64)}, stops if the map holds any id inside W, and otherwise goes on with every id above cur.  So a shard reports both
+// parts and whether it holds an id in W; the merge adds the parts above cur only when NO shard holds one.  Ties: strict '>' in ascending order keeps the
+// LOWEST id among equal scores — compared explicitly, since shard order no longer is id order.
+__global__ __launch_bounds__(256) void k_db_pack_owned(const uint64_t* __restrict__ bestP, const float* __restrict__ maxP, const int32_t* __restrict__ cntP,
+                                                       const uint64_t* __restrict__ bestS, const float* __restrict__ maxS, const int32_t* __restrict__ cntS,
+                                                       const int32_t* __restrict__ broke, int has_suffix, int nq, myslam_lcd_owned_candidate* __restrict__ out) {
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    myslam_lcd_owned_candidate c;
+    c.pre_best_id = bestP[qi]; c.pre_max_score = maxP[qi];
+    c.pre_cnt = (cntP[qi] & 0x7fffffff) | (broke[qi] ? (int32_t)0x80000000 : 0);
+    c.suf_best_id = has_suffix ? bestS[qi] : 0; c.suf_max_score = has_suffix ? maxS[qi] : 0.f; c.suf_cnt = has_suffix ? cntS[qi] : 0;
+    out[qi] = c;
+}
+
+__host__ __device__ inline void merge_owned_one(const myslam_lcd_owned_candidate* g, int nshards, int nq, int qi, uint64_t& best, float& ms, int32_t& cnt) {
+    best = 0; ms = 0.f; cnt = 0;
+    bool broke = false;
+    for (int s = 0; s < nshards; s++) {                            // everything below the window: highest score, lowest id among equals
+        const myslam_lcd_owned_candidate c = g[(size_t)s * nq + qi];
+        if (c.pre_max_score > ms || (c.pre_max_score == ms && ms > 0.f && c.pre_best_id < best)) { ms = c.pre_max_score; best = c.pre_best_id; }
+        cnt += c.pre_cnt & 0x7fffffff;
+        broke = broke || c.pre_cnt < 0;
+    }
+    if (broke) return;                                             // the map holds an id with cur - id < 20: the scan ended there (:133)
+    float ss = 0.f; uint64_t sb = 0;
+    for (int s = 0; s < nshards; s++) {                            // the ids above cur, scanned after all of the above
+        const myslam_lcd_owned_candidate c = g[(size_t)s * nq + qi];
+        if (c.suf_max_score > ss || (c.suf_max_score == ss && ss > 0.f && c.suf_best_id < sb)) { ss = c.suf_max_score; sb = c.suf_best_id; }
+        cnt += c.suf_cnt;
+    }
+    if (ss > ms) { ms = ss; best = sb; }                           // strict: an equal score further up the map does not replace the earlier one
+}
+
+__global__ __launch_bounds__(256) void k_db_merge_owned(const myslam_lcd_owned_candidate* __restrict__ g, int nshards, int nq,
+                                                        uint64_t* __restrict__ best_id, float* __restrict__ max_score, int32_t* __restrict__ cnt) {
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    uint64_t b; float m; int32_t c;
+    merge_owned_one(g, nshards, nq, qi, b, m, c);
+    best_id[qi] = b; max_score[qi] = m; cnt[qi] = c;
+}
+
 }  // namespace myslam_hip
 
 using namespace myslam_hip;
@@ -305,6 +356,9 @@ struct myslam_lcddb_query_ctx {
     int32_t* h_nvalid = nullptr; hipEvent_t nvEvent = nullptr;      // pinned staging of the per-query row limits + "copy done" event
     const int32_t* limits = nullptr;                                // what the launches of the current call read: d_nvalid (eager) or h_nvalid itself (recorded)
     uint64_t* d_bestS = nullptr; float* d_maxS = nullptr; int32_t* d_cntS = nullptr; int shardCap = 0;     // scratch of the sharded query
+    // scratch of the owned-shard query (round 6): row ranges [0, pLim) and [sBeg, sLim) + break flags per query (pinned staging + device copy), results of both parts
+    int32_t* h_own = nullptr; int32_t* d_own = nullptr; uint64_t* d_bestO = nullptr; float* d_maxO = nullptr; int32_t* d_cntO = nullptr; int ownCap = 0;
+    hipEvent_t ownEvent = nullptr; bool ownPending = false;
     int graphRows = 0, graphQueries = 0;      // > 0: a query of this context was recorded into a HIP graph covering this many rows / queries
     uint64_t graphGen = 0;                    // generation of the matrix that recording reads
     std::vector<int32_t> lastLimits, scratchLimits; int lastRows = -1; bool nvFresh = false, nvPending = false;      // what d_nvalid holds (skip identical uploads)
@@ -330,6 +384,21 @@ struct myslam_lcddb {
         if (it != ids.end() && *it <= b) return (int)(it - ids.begin());
         return (int)ids.size();
     }
+    // the three row ranges of the reference's scan for one query (ids ascending): rows [0, p) lie below the cut-off window, `broke` = row p is inside it,
+    // rows [sb, se) are the ids above cur that the scan reaches when nothing is inside the window (for cur < 19 the window wraps: ids >= 2^64 - (19 - cur) end the scan too)
+    void scan_ranges(uint64_t cur, int& p, bool& broke, int& sb, int& se) const {
+        const uint64_t lo = cur >= 19 ? cur - 19 : 0;
+        auto it = std::lower_bound(ids.begin(), ids.end(), lo);
+        p = (int)(it - ids.begin());
+        broke = it != ids.end() && *it <= cur;
+        sb = (int)(std::upper_bound(ids.begin(), ids.end(), cur) - ids.begin());
+        se = (int)ids.size();
+        if (cur < 19) {
+            auto hi = std::lower_bound(ids.begin(), ids.end(), UINT64_MAX - (18 - cur));
+            if (hi != ids.end()) { se = (int)(hi - ids.begin()); }
+        }
+        if (se < sb) se = sb;
+    }
     int n_valid(uint64_t cur) const {
         if (cur >= 19) return first_in(cur - 19, cur);
         return std::min(first_in(0, cur), first_in(UINT64_MAX - (18 - cur), UINT64_MAX));
@@ -337,10 +406,12 @@ struct myslam_lcddb {
 };
 
 static void ctx_free(myslam_lcddb_query_ctx* c) {
-    void* ptrs[] = {c->d_partials, c->d_nvalid, c->d_bestS, c->d_maxS, c->d_cntS};
+    void* ptrs[] = {c->d_partials, c->d_nvalid, c->d_bestS, c->d_maxS, c->d_cntS, c->d_own, c->d_bestO, c->d_maxO, c->d_cntO};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->h_nvalid) (void)hipHostFree(c->h_nvalid);
+    if (c->h_own) (void)hipHostFree(c->h_own);
     if (c->nvEvent) (void)hipEventDestroy(c->nvEvent);
+    if (c->ownEvent) (void)hipEventDestroy(c->ownEvent);
     if (c->link) c->link->invalidate();       // recorded steps that captured this context can no longer be launched
     delete c;
 }
@@ -609,10 +680,10 @@ static int db_query(myslam_lcddb_query_ctx* c, const float* d_q, const uint64_t*
         if (nq >= 32) {           // batched: GEMM on the matrix cores with the per-query reduction fused into the epilogue
             nparts = std::max(1, (maxv + GM - 1) / GM);
             hipLaunchKernelGGL(k_db_scan_bf16x6, dim3(nparts, (nq + GN - 1) / GN), dim3(256), 0, c->stream, d_db, cap_now, d_q, nq,
-                               c->limits, thr_low, c->d_partials);
+                               c->limits, (const int32_t*)nullptr, thr_low, c->d_partials);
         } else {                  // a few queries: bandwidth-bound GEMV, one wave per database row
-            const size_t lds = sizeof(Partial) * DB_WAVES * nq + sizeof(int) * nq;
-            hipLaunchKernelGGL(k_db_scan, dim3(nblocks), dim3(256), lds, c->stream, d_db, d_q, nq, c->limits, thr_low, c->d_partials);
+            const size_t lds = sizeof(Partial) * DB_WAVES * nq + 2 * sizeof(int) * nq;
+            hipLaunchKernelGGL(k_db_scan, dim3(nblocks), dim3(256), lds, c->stream, d_db, d_q, nq, c->limits, (const int32_t*)nullptr, thr_low, c->d_partials);
         }
         hipLaunchKernelGGL(k_db_reduce, dim3((nq + 3) / 4), dim3(256), 0, c->stream, c->d_partials, nparts, nq, d_ids, d_best,
                            d_max, d_cnt);
@@ -658,7 +729,101 @@ static int db_query_sharded(myslam_lcddb_query_ctx* c, const float* d_q, const u
     return MYSLAM_OK;
 }
 
+// One shard of a database whose ids interleave across shards: both parts of the reference's scan + the break flag, 32 bytes per query.
+// Two scans of the same kernels (rows below the window; rows above cur — launched only when some query has such rows), not recordable into a step graph.
+static int db_query_owned(myslam_lcddb_query_ctx* c, const float* d_q, const uint64_t* cur_ids, int nq, float thr_low, myslam_lcd_owned_candidate* d_cand) {
+    myslam_lcddb* h = c->db;
+    if (stream_is_capturing(c->stream)) return MYSLAM_ERR_UNSUPPORTED;
+    const int rowsPerBlock = DB_WAVES * DB_ROWS_PER_WAVE;
+    if (nq > c->ownCap) {
+        const int rq = ctx_quiesce(c);
+        if (rq) return rq;
+        void* old[] = {c->d_own, c->d_bestO, c->d_maxO, c->d_cntO};
+        for (void* p : old) if (p) (void)hipFree(p);
+        if (c->h_own) (void)hipHostFree(c->h_own);
+        c->d_own = nullptr; c->h_own = nullptr; c->d_bestO = nullptr; c->d_maxO = nullptr; c->d_cntO = nullptr; c->ownCap = 0; c->ownPending = false;
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&c->d_own, sizeof(int32_t) * 4 * nq));
+        MYSLAM_HIP_CHECK(hipHostMalloc((void**)&c->h_own, sizeof(int32_t) * 4 * nq));
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&c->d_bestO, sizeof(uint64_t) * 2 * nq));
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&c->d_maxO, sizeof(float) * 2 * nq));
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&c->d_cntO, sizeof(int32_t) * 2 * nq));
+        if (!c->ownEvent) MYSLAM_HIP_CHECK(hipEventCreateWithFlags(&c->ownEvent, hipEventDisableTiming));
+        c->ownCap = nq;
+    }
+    if (c->ownPending) MYSLAM_HIP_CHECK(hipEventSynchronize(c->ownEvent));          // the previous call's upload has left the pinned block
+    std::lock_guard<std::mutex> lk(h->mu);                                          // held until everything is enqueued (see db_query)
+    const int cap_now = h->capacity;
+    int32_t* pLim = c->h_own; int32_t* sBeg = pLim + nq; int32_t* sLim = sBeg + nq; int32_t* brk = sLim + nq;
+    int maxP = 0, maxS = 0; bool any_suffix = false;
+    for (int i = 0; i < nq; i++) {
+        int p, sb, se; bool broke;
+        h->scan_ranges(cur_ids[i], p, broke, sb, se);
+        pLim[i] = p; sBeg[i] = sb; sLim[i] = se; brk[i] = broke ? 1 : 0;
+        maxP = std::max(maxP, p);
+        if (se > sb) { any_suffix = true; maxS = std::max(maxS, se); }
+    }
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(c->d_own, c->h_own, sizeof(int32_t) * 4 * nq, hipMemcpyHostToDevice, c->stream));
+    MYSLAM_HIP_CHECK(hipEventRecord(c->ownEvent, c->stream)); c->ownPending = true;
+    const size_t need = (size_t)std::max(1, nq >= 32 ? (cap_now + GM - 1) / GM : (cap_now + rowsPerBlock - 1) / rowsPerBlock) * nq;
+    if (need > c->partialsCap) {
+        const int rq = ctx_quiesce(c);
+        if (rq) return rq;
+        ctx_scratch_moves(c);
+        if (c->d_partials) (void)hipFree(c->d_partials);
+        c->d_partials = nullptr; c->partialsCap = 0;
+        MYSLAM_HIP_CHECK(hipMalloc((void**)&c->d_partials, need * sizeof(Partial)));
+        c->partialsCap = need;
+    }
+    const int32_t* dP = c->d_own; const int32_t* dSb = dP + nq; const int32_t* dSl = dSb + nq; const int32_t* dBr = dSl + nq;
+    auto scan = [&](const int32_t* lim, const int32_t* beg, int maxv, uint64_t* best, float* mx, int32_t* cnt) {
+        int nparts;
+        if (nq >= 32) {
+            nparts = std::max(1, (maxv + GM - 1) / GM);
+            hipLaunchKernelGGL(k_db_scan_bf16x6, dim3(nparts, (nq + GN - 1) / GN), dim3(256), 0, c->stream, h->d_db, cap_now, d_q, nq, lim, beg, thr_low, c->d_partials);
+        } else {
+            nparts = std::max(1, (maxv + rowsPerBlock - 1) / rowsPerBlock);
+            const size_t lds = sizeof(Partial) * DB_WAVES * nq + 2 * sizeof(int) * nq;
+            hipLaunchKernelGGL(k_db_scan, dim3(nparts), dim3(256), lds, c->stream, h->d_db, d_q, nq, lim, beg, thr_low, c->d_partials);
+        }
+        hipLaunchKernelGGL(k_db_reduce, dim3((nq + 3) / 4), dim3(256), 0, c->stream, c->d_partials, nparts, nq, h->d_ids, best, mx, cnt);
+    };
+    {
+        ScopedProf sp(P_DBSCAN, c->stream);
+        scan(dP, nullptr, maxP, c->d_bestO, c->d_maxO, c->d_cntO);
+        if (any_suffix) scan(dSl, dSb, maxS, c->d_bestO + nq, c->d_maxO + nq, c->d_cntO + nq);       // (the partials are reused: same stream, in order)
+    }
+    hipLaunchKernelGGL(k_db_pack_owned, dim3((nq + 255) / 256), dim3(256), 0, c->stream, c->d_bestO, c->d_maxO, c->d_cntO, c->d_bestO + nq, c->d_maxO + nq,
+                       c->d_cntO + nq, dBr, any_suffix ? 1 : 0, nq, d_cand);
+    MYSLAM_HIP_CHECK(hipGetLastError());
+    return MYSLAM_OK;
+}
+
 extern "C" {
+
+int myslam_lcddb_query_batch_owned(myslam_lcddb* h, const float* d_q, const uint64_t* cur_ids, int nq, float thr_low, myslam_lcd_owned_candidate* d_cand) {
+    if (!h || !d_q || !cur_ids || nq < 1 || nq > 65536 || !d_cand) return MYSLAM_ERR_INVALID;
+    return db_query_owned(h->ctxs[0], d_q, cur_ids, nq, thr_low, d_cand);
+}
+
+int myslam_lcddb_ctx_query_batch_owned(myslam_lcddb_query_ctx* c, const float* d_q, const uint64_t* cur_ids, int nq, float thr_low,
+                                       myslam_lcd_owned_candidate* d_cand) {
+    if (!c || !d_q || !cur_ids || nq < 1 || nq > 65536 || !d_cand) return MYSLAM_ERR_INVALID;
+    return db_query_owned(c, d_q, cur_ids, nq, thr_low, d_cand);
+}
+
+int myslam_lcd_merge_owned_candidates(const myslam_lcd_owned_candidate* gathered, int nshards, int nq, uint64_t* best_id, float* max_score, int32_t* cnt) {
+    if (!gathered || nshards < 1 || nq < 0 || !best_id || !max_score || !cnt) return MYSLAM_ERR_INVALID;
+    for (int qi = 0; qi < nq; qi++) merge_owned_one(gathered, nshards, nq, qi, best_id[qi], max_score[qi], cnt[qi]);
+    return MYSLAM_OK;
+}
+
+int myslam_lcd_merge_owned_candidates_device(const myslam_lcd_owned_candidate* d_gathered, int nshards, int nq, uint64_t* d_best_id, float* d_max_score,
+                                             int32_t* d_cnt, void* hip_stream) {
+    if (!d_gathered || nshards < 1 || nq < 1 || !d_best_id || !d_max_score || !d_cnt) return MYSLAM_ERR_INVALID;
+    hipLaunchKernelGGL(k_db_merge_owned, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, d_gathered, nshards, nq, d_best_id, d_max_score, d_cnt);
+    MYSLAM_HIP_CHECK(hipGetLastError());
+    return MYSLAM_OK;
+}
 
 int myslam_lcddb_query_batch(myslam_lcddb* h, const float* d_q, const uint64_t* cur_ids, int nq, float thr_low,
                              uint64_t* d_best_id, float* d_max_score, int32_t* d_cnt) {

@@ -22,19 +22,24 @@ namespace myslam_hip {
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 // ---- block trace (profiling builds only: tools/build_variants.sh orb_kernels.hip bt:-DMYSLAM_BLOCK_TRACE; tools/block_trace_report.py) --------------
-// Every block (describe: every work item) that runs on XCD 0 leaves one 16-byte record {start, duration | kernel | CU | block id} in a caller-provided
+// Every block (describe: every work item) that runs on shader engine 0 of XCD 0 leaves one 32-byte record {start, duration | kernel | CU | block id, phase marks, -} in a caller-provided
 // buffer: which kernel's blocks are resident on which CU at what time, i.e. the measured form of "where do the idle issue slots sit".  The product
 // build carries none of this (no symbol, no instruction).
 #ifdef MYSLAM_BLOCK_TRACE
 __device__ unsigned long long* g_bt_buf = nullptr;
 __device__ unsigned int g_bt_cap = 0, g_bt_n = 0;
 struct BlockTrace {
-    unsigned long long t0 = 0; int kid; unsigned hw = 0; bool on = false;
+    unsigned long long t0 = 0, marks = 0; int kid; unsigned hw = 0; bool on = false;
+    // phase boundary i (0..3) of the block: time since its start in 10 ns units, 16 bits each (k_fast_strip: tile staged / scored / NMS done)
+    __device__ __forceinline__ void mark(int i) {
+        if (on) marks |= ((__builtin_amdgcn_s_memrealtime() - t0) & 0xffffull) << (16 * i);
+    }
     __device__ __forceinline__ BlockTrace(int kid_) : kid(kid_) {
         if (threadIdx.x != 0 || g_bt_buf == nullptr) return;
         const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf;            // HW_REG_XCC_ID
         if (xcc != 0) return;
         hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);                                   // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
+        if (((hw >> 13) & 7) != 0) return;                                                // shader engine 0 only (8 CUs): all blocks of XCD 0 on one counter slowed the step by half
         on = true; t0 = __builtin_amdgcn_s_memrealtime();                                 // 100 MHz
     }
     __device__ __forceinline__ ~BlockTrace() {
@@ -42,15 +47,17 @@ struct BlockTrace {
         const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t0;
         const unsigned i = atomicAdd(&g_bt_n, 1u);
         if (i < g_bt_cap) {
-            g_bt_buf[2 * i] = t0;
-            g_bt_buf[2 * i + 1] = (dt & 0xffffffull) | ((unsigned long long)(kid & 0xf) << 24) | ((unsigned long long)((hw >> 8) & 0xff) << 32) |
+            g_bt_buf[4 * i] = t0; g_bt_buf[4 * i + 2] = marks; g_bt_buf[4 * i + 3] = 0;
+            g_bt_buf[4 * i + 1] = (dt & 0xffffffull) | ((unsigned long long)(kid & 0xf) << 24) | ((unsigned long long)((hw >> 8) & 0xff) << 32) |
                                   ((unsigned long long)(blockIdx.x & 0xffffff) << 40);
         }
     }
 };
 #define MYSLAM_BT(kid) BlockTrace bt_(kid)
+#define MYSLAM_BT_MARK(i) bt_.mark(i)
 #else
 #define MYSLAM_BT(kid) ((void)0)
+#define MYSLAM_BT_MARK(i) ((void)0)
 #endif
 
 __constant__ int8_t c_pattern[1024] = {
@@ -1015,7 +1022,6 @@ template <int CW, int G, int CH = CW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 6 : 3))) void k_fast_strip(OrbPlan P, const uint8_t* __restrict__ pyr, size_t pyrStride,
                                                     const uint8_t* __restrict__ maskPyr,
                                                     uint32_t* __restrict__ cand, int32_t* __restrict__ candCount, FastCtl ctl, int batch) {
-    MYSLAM_BT(0);
     constexpr int T = 256;
     constexpr int CP = (CW + 6 + 15) & ~15;                            // every cell's ROI (cell + 6 halo columns) is staged at its own 16-byte aligned offset:
     constexpr int TP = G * CP;                                         //   a lane's 12-byte windows are then dword-aligned and need no byte alignment
@@ -1061,10 +1067,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
 
     // XCD-aware block order (bijective remap of the 1-D grid): the dispatcher places block i on XCD i % 8 and every XCD has a private
     // L2; logical ids (image-major, strips row by row) are handed out so that each XCD walks a contiguous range of strips, whose
-    // shared halo rows / columns then hit in that L2 instead of being fetched once per XCD
+    // shared halo rows / columns then hit in that L2 instead of being fetched once per XCD.
+    // (Round 6 tried a PERSISTENT grid — n blocks per CU, each walking several strips: the FAST launch got 25 % shorter under the pipeline and the
+    // step no shorter, and the loop cost the kernel 26 spilled registers; profiles/r06_ab_fast_persistent_grid.json.  One block per strip it is.)
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
     const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    MYSLAM_BT(0);
     const int b = logical / P.nstrips, sidx = logical - b * P.nstrips;
     if (b >= batch) return;
     // what the next launch of this handle decides on is reported by a SAMPLE of the strips (a ratio of sums needs no more, and a few thousand
@@ -1158,6 +1167,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
         dense = ctl.force >= 0 ? ctl.force != 0 : (pt > 0.f && (was_dense ? ps > 0.165f * pt : ps > 0.41f * pt));
     }
     __syncthreads();
+    MYSLAM_BT_MARK(0);
 #if MYSLAM_FAST_PHASE == 1
     if (dense) return;
 #endif
@@ -1370,6 +1380,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
             }
         }
         __syncthreads();
+        MYSLAM_BT_MARK(1);
 #if MYSLAM_FAST_PHASE >= 2 && MYSLAM_FAST_PHASE <= 4
         return;
 #endif
@@ -1451,6 +1462,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
 #endif
     }
     __syncthreads();
+    MYSLAM_BT_MARK(2);
     if (threadIdx.x == 0 && sampled) {                                 // the path statistics of this launch (see `sampled` above)
         atomicAdd(&ctl.cur[level * 4], (uint32_t)(dense ? s_ncorner : min(s_npair, NPAIR)));
         atomicAdd(&ctl.cur[level * 4 + 1], (uint32_t)pairs_total);
@@ -2888,7 +2900,7 @@ void launch_unpack_cands(const uint32_t* cand, int n, int32_t* xs, int32_t* ys, 
 }  // namespace myslam_hip
 
 #ifdef MYSLAM_BLOCK_TRACE
-// profiling builds only (see BlockTrace above): d_buf = cap_records x 16 bytes of device memory, nullptr = stop recording; *n = records written so far
+// profiling builds only (see BlockTrace above): d_buf = cap_records x 32 bytes of device memory, nullptr = stop recording; *n = records written so far
 extern "C" int myslam_debug_block_trace(void* d_buf, unsigned cap_records, unsigned* n) {
     using namespace myslam_hip;
     unsigned long long* p = (unsigned long long*)d_buf;

@@ -33,7 +33,9 @@
 
 namespace myslam_hip {
 
-constexpr int PG_MAXS = 96;          // separator key-frames supported (dense Schur system up to 576 x 576)
+constexpr int PG_MAXS = 96;          // separator key-frames of the FAST path (dense Schur system up to 576 x 576: pivots in LDS, the back substitution in registers)
+constexpr int PG_MAXS_BIG = 1024;    // separator key-frames of the general path (round 6): the same factorisation with its pivots and right-hand side in device
+                                     // memory — g2o + CSparse take any graph (src/loopclosing.cpp:538-543); slower is fine, refusing is not
 constexpr int PG_KS = 32;            // K chunks of the Z^T Z product
 constexpr double PG_EPS = 1e-10;     // Sophus::Constants<double>::epsilon()
 
@@ -412,12 +414,14 @@ __device__ __forceinline__ double pg_ztz(const double* __restrict__ P, int ntile
 // The backward substitution runs in wave 0 alone (rows of L are contiguous).
 #define PG_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+template <bool BIG>
 __global__ void __launch_bounds__(1024) k_pg_schur(const double* __restrict__ Hss, const double* __restrict__ bS, const double* __restrict__ P,
                                                    double* __restrict__ A, double* __restrict__ xS, int mS, int ldz, int ntile, int haveZ,
-                                                   double lambda, int* __restrict__ status) {
+                                                   double lambda, int* __restrict__ status, double* __restrict__ gInv) {
     const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5, lane = tid & 63, wv = tid >> 6;
     __shared__ double sD[16][17];
-    __shared__ double sInv[6 * PG_MAXS + 16];
+    __shared__ double sInvLds[BIG ? 16 : 6 * PG_MAXS + 16];
+    double* const sInv = BIG ? gInv : sInvLds;          // BIG (more than PG_MAXS separators): the reciprocal pivots live in device memory (written by one lane, read after barriers)
     __shared__ int sbad;
     if (tid == 0) sbad = 0;
     for (int i = ty; i < ldz; i += 32)
@@ -493,6 +497,19 @@ __global__ void __launch_bounds__(1024) k_pg_schur(const double* __restrict__ Hs
         }
         __syncthreads();
     }
+    if constexpr (BIG) {
+        // backward substitution L^T x = y with y = row mS of A in device memory, the whole workgroup on every column (same order of subtractions per entry)
+        double* y = A + (size_t)mS * ldz;
+        for (int j = mS - 1; j >= 0; j--) {
+            __syncthreads();
+            const double xj = y[j] * sInv[j];
+            const double* Lj = A + (size_t)j * ldz;
+            for (int k = tid; k < j; k += 1024) y[k] -= Lj[k] * xj;
+            if (tid == 0) xS[j] = xj;
+        }
+        if (tid == 0 && sbad) *status = 1;
+        return;
+    }
     // backward substitution L^T x = y in wave 0: lane l owns x[l], x[l + 64], ...
     if (tid < 64) {
         constexpr int PER = (6 * PG_MAXS + 63) / 64;
@@ -521,13 +538,15 @@ __global__ void __launch_bounds__(1024) k_pg_schur(const double* __restrict__ Hs
 // y = z - Z[:, 0..mS) xS, one thread per row
 __global__ void __launch_bounds__(256) k_pg_y(const double* __restrict__ Z, const double* __restrict__ xS, double* __restrict__ y, int rows, int ldz, int mS) {
     __shared__ double sx[6 * PG_MAXS];
-    for (int i = threadIdx.x; i < mS; i += 256) sx[i] = xS[i];
+    const bool big = mS > 6 * PG_MAXS;                  // the general path reads xS from device memory (block-uniform)
+    if (!big) for (int i = threadIdx.x; i < mS; i += 256) sx[i] = xS[i];
     __syncthreads();
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= rows) return;
     const double* zr = Z + (size_t)k * ldz;
     double s = zr[mS];
-    for (int j = 0; j < mS; j++) s -= zr[j] * sx[j];
+    if (!big) { for (int j = 0; j < mS; j++) s -= zr[j] * sx[j]; }
+    else { for (int j = 0; j < mS; j++) s -= zr[j] * xS[j]; }
     y[k] = s;
 }
 
@@ -670,8 +689,9 @@ int myslam_pose_graph_optimize(double* poses, int n, const uint8_t* fixed, const
         int best = -1;                                   // the key-frame on the most off-chain edges, latest on ties
         for (int i = 0; i < n; i++) if (deg[i] > 0 && (best < 0 || deg[i] >= deg[best])) best = i;
         inS[best] = 1;
-        if (++nS > PG_MAXS) return MYSLAM_ERR_UNSUPPORTED;
+        if (++nS > PG_MAXS_BIG) return MYSLAM_ERR_UNSUPPORTED;
     }
+    const int sepBudget = nS <= PG_MAXS ? PG_MAXS : PG_MAXS_BIG;      // graphs that fit the fast path keep it (and their results of rounds 3-5)
     // Cut long chain runs with extra separators so that the serial sweeps (one step per key-frame of a run) become short and
     // run in parallel: run length ~ sqrt(11 nT) (measured optimum at 1500 key-frames) balances them against the dense Schur system, which grows by 6 per cut.
     auto chain_links = [&](std::vector<char>& link) {     // link[t] = an edge joins chain positions t-1 and t
@@ -698,7 +718,7 @@ int myslam_pose_graph_optimize(double* poses, int n, const uint8_t* fixed, const
                 for (int i = 1; i < parts; i++) cuts.push_back(s0 + (int)((long long)i * len / parts));
                 s0 = e;
             }
-            if (nS + (int)cuts.size() > PG_MAXS) continue;
+            if (nS + (int)cuts.size() > sepBudget) { if (cuts.empty()) return MYSLAM_ERR_UNSUPPORTED; continue; }
             for (int t : cuts) inS[tvert[t]] = 1;
             nS += (int)cuts.size();
             break;
@@ -767,6 +787,9 @@ int myslam_pose_graph_optimize(double* poses, int n, const uint8_t* fixed, const
     MYSLAM_HIP_CHECK(mem.alloc(&d_e0, (size_t)E)); MYSLAM_HIP_CHECK(mem.alloc(&d_e1, (size_t)E)); MYSLAM_HIP_CHECK(mem.alloc(&d_slot, (size_t)n));
     MYSLAM_HIP_CHECK(mem.alloc(&d_fx, (size_t)n)); MYSLAM_HIP_CHECK(mem.alloc(&d_jobs, jobs.size())); MYSLAM_HIP_CHECK(mem.alloc(&d_list, list.size()));
     MYSLAM_HIP_CHECK(mem.alloc(&d_status, 1)); MYSLAM_HIP_CHECK(mem.alloc(&d_seg, seg.size()));
+    double* d_inv = nullptr;
+    const bool bigS = nS > PG_MAXS;
+    MYSLAM_HIP_CHECK(mem.alloc(&d_inv, (size_t)ldz + 16));
     MYSLAM_HIP_CHECK(hipMemcpy(d_seg, seg.data(), sizeof(int32_t) * seg.size(), hipMemcpyHostToDevice));
     MYSLAM_HIP_CHECK(hipMemcpy(d_pose, poses, sizeof(double) * 7 * n, hipMemcpyHostToDevice));
     MYSLAM_HIP_CHECK(hipMemcpy(d_fx, fx.data(), n, hipMemcpyHostToDevice));
@@ -823,8 +846,10 @@ int myslam_pose_graph_optimize(double* poses, int n, const uint8_t* fixed, const
                     hipLaunchKernelGGL(k_pg_sweep, dim3((ldz + 63) / 64, nseg), dim3(64), 0, st, d_D, d_B, d_C, d_Z, d_Lw, d_seg, ldz, lambda, d_status);
                     hipLaunchKernelGGL(k_pg_syrk, dim3(ntile, PG_KS), dim3(64), 0, st, d_Z, d_P, ldz, k4, ntile);
                 }
-                if (mS > 0)
-                    hipLaunchKernelGGL(k_pg_schur, dim3(1), dim3(1024), 0, st, d_Hss, d_bS, d_P, d_A, d_xS, mS, ldz, ntile, nT > 0 ? 1 : 0, lambda, d_status);
+                if (mS > 0) {
+                    if (bigS) hipLaunchKernelGGL(k_pg_schur<true>, dim3(1), dim3(1024), 0, st, d_Hss, d_bS, d_P, d_A, d_xS, mS, ldz, ntile, nT > 0 ? 1 : 0, lambda, d_status, d_inv);
+                    else hipLaunchKernelGGL(k_pg_schur<false>, dim3(1), dim3(1024), 0, st, d_Hss, d_bS, d_P, d_A, d_xS, mS, ldz, ntile, nT > 0 ? 1 : 0, lambda, d_status, d_inv);
+                }
                 if (nT > 0) {
                     hipLaunchKernelGGL(k_pg_y, dim3((rows + 255) / 256), dim3(256), 0, st, d_Z, d_xS, d_y, rows, ldz, mS);
                     hipLaunchKernelGGL(k_pg_back, dim3(nseg), dim3(64), 0, st, d_Lw, d_y, d_xT, d_seg);

@@ -113,6 +113,15 @@ static void drain() {
     g_pending.clear();
 }
 
+// one wave spins for `ticks` of the constant 100 MHz clock and reports how many SHADER cycles went by: the clock the chip runs at right now
+__global__ void k_clock_probe(unsigned long long ticks, unsigned long long* out) {
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_readcyclecounter();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < ticks) { __builtin_amdgcn_s_sleep(8); r1 = __builtin_amdgcn_s_memrealtime(); }
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+}
+
 }  // namespace myslam_hip
 
 using namespace myslam_hip;
@@ -125,7 +134,24 @@ int myslam_hip_device_count(void) {
     return n;
 }
 
-const char* myslam_hip_version(void) { return "myslam_hip 0.1 (gfx950)"; }
+// build.py passes a digest of every source the library is built from: profiles taken on one build can be told from another's (bench.py: roofline.traffic_stale)
+#ifndef MYSLAM_BUILD_ID
+#define MYSLAM_BUILD_ID "unidentified"
+#endif
+const char* myslam_hip_version(void) { return "myslam_hip 0.6 (gfx950) build " MYSLAM_BUILD_ID; }
+
+int myslam_prof_shader_clock_mhz(void* hip_stream, float spin_us, float* mhz) {
+    if (!mhz || !(spin_us > 0.f) || spin_us > 1e6f) return MYSLAM_ERR_INVALID;
+    static thread_local unsigned long long* d_t = nullptr;            // two counters, allocated once per calling thread
+    if (!d_t) MYSLAM_HIP_CHECK(hipMalloc((void**)&d_t, 16));
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, (unsigned long long)(spin_us * 100.f), d_t);
+    MYSLAM_HIP_CHECK(hipGetLastError());
+    unsigned long long h[2] = {0, 0};
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(h, d_t, 16, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+    MYSLAM_HIP_CHECK(hipStreamSynchronize((hipStream_t)hip_stream));
+    *mhz = h[1] ? (float)((double)h[0] / (double)h[1] * 100.0) : 0.f;      // shader cycles per 10 ns tick x 100 MHz
+    return MYSLAM_OK;
+}
 
 int myslam_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);

@@ -21,6 +21,7 @@ def parse():
     ap.add_argument("--cpu-pairs", type=int, default=13,
                     help="timed frames PER THREAD of the all-cores CPU baseline (after one warm-up frame per thread); the default 13 is raised until "
                          "the threads together time >= 200 frames (BASELINE.md section 3)")
+    ap.add_argument("--no-repeats", action="store_true", help="skip the two repeat regions behind the timed one (`repeats_ms_per_step` then holds one value)")
     ap.add_argument("--no-extra-passes", action="store_true", help="skip the profiled, the solve-cadence and the streamed-input passes (timed region only)")
     ap.add_argument("--stream-input", type=int, default=4,
                     help="B > 0 (default 4): after the timed region, K more steps in which every step's images arrive over PCIe — B distinct batches "
@@ -77,6 +78,10 @@ def parse():
                          "(bench.py --pairs P --lanes L --graph 1: recorded steps on L lanes scanning ONE loop database through L query contexts; its own "
                          "GPU_MAX_HW_QUEUES) and reported as `stream_mode` — the reference's call pattern is one frame per call (src/frontend.cpp:41-77)")
     ap.add_argument("--frame-latency", action="store_true", help="(child of --stream-mode) also time every step on its lane with an event pair: `frame_latency_ms`")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="N > 1 on ONE GPU, one process, no collective: per step this rank scans N x pairs queries (its own + (N - 1) x pairs resident ones) against a "
+                         "6 250-row shard and merges N candidate sets — the per-rank compute of an N-GPU job inside the pipeline (`emulated_world` in the line; "
+                         "the two all-gathers are what a real job adds)")
     ap.add_argument("--block-trace", default="", help="profiling builds only (a library built with -DMYSLAM_BLOCK_TRACE, tools/build_variants.sh): after the timed region run 4 more "
                     "steps with the block trace on and write the records (npy, 2 x u64 per block that ran on XCD 0) to this file; tools/block_trace_report.py reads it")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],

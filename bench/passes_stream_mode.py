@@ -20,7 +20,7 @@ def stream_mode_sweep(args):
         try:
             cd = json.loads(r.stdout.strip().splitlines()[-1])
             pts.append({"pairs_per_step": pp, "lanes": ll, "value": cd["value"], "ms_per_step": cd["ms_per_step"], "frame_latency_ms": cd["frame_latency"],
-                        "host_launch_ms_per_step": cd["host_launch_ms_per_step"], "graph_nodes": cd["graph_nodes"], "parity_ok": (cd["parity_sample"] or {}).get("ok")})
+                        "host_launch_ms_per_step": cd["host_launch_ms_per_step"], "graph_nodes": cd["graph_nodes"], "repeats_ms_per_step": cd.get("repeats_ms_per_step"), "parity_ok": (cd["parity_sample"] or {}).get("ok")})
         except Exception as e:               # a failed point is reported, not hidden
             pts.append({"pairs_per_step": pp, "lanes": ll, "error": f"{type(e).__name__}: {e}", "rc": r.returncode, "stderr_tail": r.stderr[-300:]})
     if pts:

@@ -10,7 +10,7 @@ from .config import ALGO_BYTES, HBM_PEAK_GBS, MFMA_BF16_PEAK_TFLOPS, SYMBOL, VAL
 from .profiles import peaks_file, pmc_file, pmc_lookup
 
 
-def rooflines(prof, alone, steps, P, conv2_products):
+def rooflines(prof, alone, steps, P, conv2_products, build_id=None):
     """-> (roofline, roofline_valu, roofline_mfma, busy, peaks).  prof / alone: {slot: (total ms, launches)} of the profiled pass / the extractor-alone pass"""
     pmc, pmc_path = pmc_file()
     peaks, peaks_path = peaks_file()
@@ -50,6 +50,10 @@ def rooflines(prof, alone, steps, P, conv2_products):
             # HBM bytes per launch from the counter summary: FETCH_SIZE scaled by the factor that makes k_ingest's FETCH_SIZE equal
             # the bytes it provably reads (MI355X_MICROARCH.md: gfx950 tallies 128-byte requests at 64 bytes), + WRITE_SIZE
             roof["traffic"] = (rec["fetch_bytes_per_image_corrected"] + rec["write_bytes_per_image"]) * imgs_per_launch
+            # the counters are a COMMITTED measurement (separate --pmc passes cannot run inside this process): name the build they were taken on and say
+            # so when it is not the library running now (round 6; counter files older than round 6 carry no digest: stale by definition)
+            roof["traffic_build"] = pmc.get("build_id") or pmc.get("build")
+            roof["traffic_stale"] = (pmc.get("build_id") != build_id) if build_id else None
             roof["traffic_detail"] = {"source": pmc_path, "fetch_scale": pmc["calibration"]["fetch_scale"],
                                       "fetch_bytes_per_image_corrected": rec["fetch_bytes_per_image_corrected"],
                                       "write_bytes_per_image": rec["write_bytes_per_image"]}

@@ -46,7 +46,13 @@ typedef struct myslam_keypoint {
  * Library-wide
  * ------------------------------------------------------------------------------------------ */
 int myslam_hip_device_count(void);
+/* "myslam_hip <version> (gfx950) build <digest>": the digest covers every source file the library was built from (build.py), so a measurement
+ * file can name the build it was taken on (profiles/r<NN>_pmc_*.json "build_id"; bench.py sets roofline.traffic_stale when it differs) */
 const char* myslam_hip_version(void);
+/* The shader clock the device runs at NOW: one wave spins for spin_us (0 < spin_us <= 1e6) on the given stream and compares the shader cycle counter
+ * with the constant 100 MHz counter; synchronises the stream.  bench.py samples it around its timed regions ("clock_mhz"): box-to-box and
+ * run-to-run differences of a few per cent are clock states more often than code */
+int myslam_prof_shader_clock_mhz(void* hip_stream, float spin_us, float* mhz);
 /* per-kernel HIP-event timing: enable, run, synchronise, then read (name, total ms, launches) */
 int myslam_prof_enable(int on);
 int myslam_prof_reset(void);
@@ -362,6 +368,31 @@ int myslam_lcd_merge_candidates(const myslam_lcd_candidate* gathered, int nshard
 /* the same reduce on device pointers, asynchronous on hip_stream */
 int myslam_lcd_merge_candidates_device(const myslam_lcd_candidate* d_gathered, int nshards, int nq, uint64_t* d_best_id,
                                        float* d_max_score, int32_t* d_cnt, void* hip_stream);
+
+/* A sharded database that GROWS (round 6).  With contiguous id ranges every new key-frame belongs to the last rank; a job that appends (the reference
+ * does, per key-frame: LoopClosing::AddToDatabase, src/loopclosing.cpp:651-659) spreads the rows instead — e.g. the k-th key-frame of the job goes to rank
+ * k mod N (sharded_db.py GrowingShardedDatabase; app/sharded_db_rccl.cpp) — and a shard's ids then INTERLEAVE with the others'.  Any rule works that puts
+ * every id into exactly one shard and keeps each shard's own ids ascending.  The reference's one ascending scan (:124-161) looks at every id below the
+ * cut-off window {id : cur - id < 20}, stops if the map holds an id inside it, and otherwise goes on with the ids above cur; so a shard reports BOTH parts
+ * and whether it holds an id inside the window (32 bytes per query), and the merge — highest score, LOWEST ID among equal scores (shard order is not id
+ * order here), counts added — takes the parts above cur only when no shard reported the break.  Bit-identical to one scan of the whole map. */
+typedef struct myslam_lcd_owned_candidate {
+    uint64_t pre_best_id;  /* over this shard's ids below the window: 0 when nothing scored above 0 */
+    float pre_max_score;
+    int32_t pre_cnt;       /* bits 0..30: #{score > thr_low}; bit 31: this shard holds an id with cur - id < 20 */
+    uint64_t suf_best_id;  /* over this shard's ids above cur */
+    float suf_max_score;
+    int32_t suf_cnt;
+} myslam_lcd_owned_candidate;
+/* one record per query (device memory, asynchronous on the stream; not recordable into a step graph) */
+int myslam_lcddb_query_batch_owned(myslam_lcddb* h, const float* d_q, const uint64_t* cur_ids /*host*/, int nq, float thr_low,
+                                   myslam_lcd_owned_candidate* d_cand);
+int myslam_lcddb_ctx_query_batch_owned(myslam_lcddb_query_ctx* c, const float* d_q, const uint64_t* cur_ids /*host*/, int nq, float thr_low,
+                                       myslam_lcd_owned_candidate* d_cand);
+/* gathered: [nshards][nq] records, shard-major, ANY shard order.  Host pointers / device pointers (asynchronous on hip_stream). */
+int myslam_lcd_merge_owned_candidates(const myslam_lcd_owned_candidate* gathered, int nshards, int nq, uint64_t* best_id, float* max_score, int32_t* cnt);
+int myslam_lcd_merge_owned_candidates_device(const myslam_lcd_owned_candidate* d_gathered, int nshards, int nq, uint64_t* d_best_id,
+                                             float* d_max_score, int32_t* d_cnt, void* hip_stream);
 
 /* ------------------------------------------------------------------------------------------
  * Local BA linear-system build — replaces the per-edge work g2o does for

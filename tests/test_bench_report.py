@@ -44,6 +44,9 @@ def test_roofline_objects_from_event_times():
     assert valu["achieved"] == pytest.approx(valu["valu_wave_insts_per_image"] * 512 * 64 / 3.0e-3 / 1e12) and 0.3 < valu["frac"] < 0.6 and 0.8 < valu["frac_alone"] < 1.1
     assert mfma["kernel"] == "k_conv2_f16x3" and mfma["partial_products"] == 3
     assert mfma["achieved"] == pytest.approx(3 * 2 * 176160768 * P / 3.1e-3 / 1e12) and mfma["frac"] == pytest.approx(mfma["achieved"] / 2500.0)
+    assert roof["traffic_stale"] is None and roof["traffic_build"]            # no library named: staleness unknown, the counter file still names its build
+    roof_s = rooflines(prof, alone, steps, P, 3, build_id="not-the-profiled-build")[0]
+    assert roof_s["traffic_stale"] is True
     json.dumps([roof, valu, mfma])                                            # everything in the line is JSON
     # nothing profiled: the contract's object with nulls, no exception
     roof0, valu0, mfma0, _, _ = rooflines({}, {}, steps, P, 3)
@@ -57,7 +60,7 @@ def test_roofline_objects_from_event_times():
 def test_committed_profiles_are_the_newest_of_their_kind():
     from bench.profiles import peaks_file, pmc_file
     pmc, path = pmc_file()
-    assert pmc is not None and path.startswith("profiles/r05_pmc_") and "k_fast_strip<32, 4, 40>" in pmc["kernels"]
+    assert pmc is not None and path.startswith(("profiles/r05_pmc_", "profiles/r06_pmc_")) and "k_fast_strip<32, 4, 40>" in pmc["kernels"]
     assert abs(pmc["calibration"]["fetch_scale"] - 1.93) < 0.05                # gfx950 counts 128-byte requests as 64 bytes (MI355X_MICROARCH.md)
     peaks, ppath = peaks_file()
     assert peaks and os.path.exists(os.path.join(ROOT, ppath)) and 5500 < peaks["hbm_copy_GBps"] < 8000

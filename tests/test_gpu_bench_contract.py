@@ -27,9 +27,18 @@ def test_bench_json_contract(extra):
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and d["value"] > 0
     assert abs(d["value"] - 16 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    # round 6: the line carries its own spread — the timed region behind `value` plus two identical regions straight after it, the shader clock measured
+    # on the device around them, and the library's build digest; the committed counter file says which build it was taken on and whether that is this one
+    rp = d["repeats_ms_per_step"]
+    assert len(rp) == 3 and rp[0] == d["ms_per_step"] and all(v > 0 for v in rp)
+    assert len(d["clock_mhz"]) == 4 and all(300.0 < c < 3000.0 for c in d["clock_mhz"]), d["clock_mhz"]
+    assert d["library"].startswith("myslam_hip ") and " build " in d["library"]
     roof = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in roof, k
+    if roof["traffic"] is not None:
+        assert isinstance(roof["traffic_stale"], bool) and roof["traffic_build"]
+        assert roof["traffic_stale"] == (roof["traffic_build"] != d["library"].rsplit(" ", 1)[-1])
     assert roof["bound"] in ("hbm", "mfma") and roof["peak"] > 0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     # the streamed-input pass: every step's images cross PCIe; three distinct host batches here
     st = d["streamed"]

@@ -61,3 +61,32 @@ def test_cpp_sharded_db_over_rccl(synth, tmp_path):
         line = [l for l in o[0].splitlines() if l.startswith(f"rank {r}:")]
         assert line and all(k in line[0] for k in ("allgather_queries_ms", "shard_scan_ms", "allgather_candidates_ms", "merge_ms")), o[0]
     print(outs[0][0].strip())
+
+
+@pytest.mark.parametrize("local_shards", [1, 4])
+def test_cpp_growing_sharded_db(synth, tmp_path, local_shards):
+    """The GROWING database of round 6 in the compiled host (app/sharded_db_rccl.cpp, last argument = steps): per step the ranks all-gather their new
+    key-frames, every shard answers with 32-byte owned records (myslam_lcddb_query_batch_owned), the records are all-gathered and merged on the device, the
+    key-frames are appended by arrival order over WORLD_SIZE x MYSLAM_LOCAL_SHARDS shards; rank 0 checks every answer against ONE map, bit for bit, and the
+    shards' row counts stay within one of each other.  One rank per visible GPU; 4 local shards interleave ownership for real on a one-GPU box."""
+    import numpy as np
+    import torch
+    exe = os.path.join(PKG_DIR, "bin", "sharded_db_rccl")
+    if not os.path.exists(exe) and not (os.path.exists("/opt/rocm/include/rccl/rccl.h") and os.path.exists("/opt/rocm/lib/librccl.so")):
+        pytest.skip("no RCCL on this box")
+    n_db, nq = 400, 8
+    db = synth.lcd_database(n_db); q = db[:nq].copy(); cur = np.full(nq, n_db + 20, np.uint64)
+    (tmp_path / "db.f32").write_bytes(db.astype(np.float32).tobytes()); (tmp_path / "q.f32").write_bytes(q.tobytes()); (tmp_path / "cur.u64").write_bytes(cur.tobytes())
+    world = max(1, torch.cuda.device_count())
+    while nq % world:
+        world -= 1
+    env = dict(os.environ, WORLD_SIZE=str(world), MYSLAM_NCCL_ID_FILE=str(tmp_path / "nccl_id"), MYSLAM_LOCAL_SHARDS=str(local_shards),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    args = [exe, str(tmp_path / "db.f32"), str(tmp_path / "q.f32"), str(tmp_path / "cur.u64"), str(n_db), str(nq), "0", "200"]
+    procs = [subprocess.Popen(args, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [(p.returncode, o[0][-500:], o[1][-1500:]) for p, o in zip(procs, outs)]
+    line = [l for l in outs[0][0].splitlines() if l.startswith("GROWING SHARDED DB")]
+    assert line and line[0].startswith(f"GROWING SHARDED DB OK shards={world * local_shards} ") and "steps=200" in line[0] and "mismatches=0" in line[0], outs[0][0]
+    assert "accepted_loops=0 " not in line[0]                        # the file's rows repeat after 97 key-frames: equal rows in different shards are found as loops
+    print(line[0])

@@ -214,9 +214,11 @@ def test_batch_equals_single_and_oracle(api, oracle, synth):
             assert np.array_equal(desc[b, :cnt[b]], rd)
 
 
-def test_large_batch_takes_the_batch_kernels(api, oracle, synth):
+@pytest.mark.parametrize("fast_mode", [-1, 1, 0])
+def test_large_batch_takes_the_batch_kernels(api, oracle, synth, fast_mode):
     """72 different images in one call: batches of 64 and more run the 256-thread oct-tree blocks (`k_octree<256>`; smaller ones the 512-thread
-    form) and the tile-ordered descriptor pass — every image must still equal the oracle's single-image result."""
+    form) and the tile-ordered descriptor pass — every image must still equal the oracle's single-image result.
+    fast_mode: the dense path, the two-phase path or whichever the statistics choose — same candidates, same key-points."""
     import torch
     B, h, w, nf = 72, 240, 328, 300
     kinds = ("texture", "noise", "texture")
@@ -224,6 +226,7 @@ def test_large_batch_takes_the_batch_kernels(api, oracle, synth):
     imgs[5] = synth.stereo_batch(1, stream_id=3, n_rect=40, h=h, w=w)[0, 0]          # a sparse scene and a flat image among them
     imgs[9] = 128
     ext = api.ORBextractor(nf)
+    ext.set_option(ext.OPT_FAST_MODE, fast_mode)
     cap = ext.max_keypoints(h, w)
     d_imgs = torch.from_numpy(np.ascontiguousarray(imgs)).cuda()
     d_kps = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda"); d_desc = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")

@@ -112,14 +112,41 @@ def test_pose_graph_rejects_bad_input(api, synth):
         api.pose_graph_optimize(poses, fixed, bad, e1, meas)
     with pytest.raises(Exception):
         api.pose_graph_optimize(poses, fixed, e1, e1, meas)           # self edges
-    # a graph that is nowhere near a chain: half of the key-frames linked to up to 80 others -> more separators than supported
-    n = 240
-    p = np.tile(np.array([0, 0, 0, 1, 0, 0, 0.0]), (n, 1)); p[:, 4] = np.arange(n)
-    a, b = np.meshgrid(np.arange(n), np.arange(n)); m = (a - b) >= 120
+
+
+def _dense_graph(oracle, n=240, noise=0.02, seed=3):
+    """a graph that is nowhere near a chain: every key-frame of the upper half linked to up to 120 of the lower half (7 260 edges, no chain edge at all)"""
+    rng = np.random.default_rng(seed)
+    gt = np.tile(np.array([0, 0, 0, 1, 0, 0, 0.0]), (n, 1)); gt[:, 4] = np.arange(n)
+    for i in range(n):                                               # a gently turning drive
+        gt[i] = oracle.se3_compose(oracle.se3_exp(np.array([0.0, 0.02 * np.sin(i / 9.0), 0.0, 0.0, 0.004 * i, 0.0])), gt[i])
+    a, b = np.meshgrid(np.arange(n), np.arange(n)); m = (a - b) >= n // 2
     ea, eb = a[m].astype(np.int32), b[m].astype(np.int32)
-    ms = np.tile(np.array([0, 0, 0, 1, 0, 0, 0.0]), (len(ea), 1)); ms[:, 4] = ea - eb
-    with pytest.raises(Exception):
-        api.pose_graph_optimize(p, np.zeros(n, np.uint8), ea, eb, ms)
+    ms = np.stack([oracle.se3_compose(oracle.se3_compose(gt[i], gt[j], invert_b=True), oracle.se3_exp(noise * rng.standard_normal(6) * np.array([1, 1, 1, 0.1, 0.1, 0.1])))
+                   for i, j in zip(ea, eb)])
+    p0 = np.stack([oracle.se3_compose(oracle.se3_exp(0.05 * rng.standard_normal(6) * np.array([1, 1, 1, 0.1, 0.1, 0.1])), g) for g in gt])
+    fixed = np.zeros(n, np.uint8); fixed[0] = 1; p0[0] = gt[0]
+    return p0, fixed, ea, eb, ms
+
+
+def test_pose_graph_with_more_separators_than_the_fast_path(api, oracle):
+    """Round 6 (task 7): g2o + CSparse take ANY graph (src/loopclosing.cpp:538-543); up to round 5 this library refused graphs that need more
+    than 96 separator key-frames (MYSLAM_ERR_UNSUPPORTED).  The general path keeps the same elimination (chain sweeps + dense Schur system) with the Schur
+    factorisation's pivots and right-hand side in device memory: the 240-key-frame graph without a single chain edge (~120 separators, a 720+ x 720+
+    Schur system) solves and lands on the oracle's optimum — chi2 to 1e-6, poses to 1e-6 (a dense graph is stiff: no soft modes to drift along)."""
+    p0, fixed, ea, eb, ms = _dense_graph(oracle)
+    ref = oracle.pose_graph_optimize(p0, fixed, ea, eb, ms)
+    got = api.pose_graph_optimize(p0, fixed, ea, eb, ms)
+    chi0 = oracle.pose_graph_optimize(p0, fixed, ea, eb, ms, iters=0)[1]
+    assert ref[1] < 0.2 * chi0 and ref[1] > 1e-3                     # a real optimisation with a non-zero optimum
+    assert abs(got[1] - ref[1]) <= 1e-6 * ref[1], (got[1], ref[1])
+    s = np.sign(np.sum(got[0][:, :4] * ref[0][:, :4], axis=1))[:, None]
+    assert max(np.abs(got[0][:, :4] * s - ref[0][:, :4]).max(), np.abs(got[0][:, 4:] - ref[0][:, 4:]).max()) < 1e-6
+    assert got[2] == ref[2]
+    chk = oracle.pose_graph_optimize(got[0], fixed, ea, eb, ms, iters=0)[1]
+    assert abs(chk - got[1]) <= 1e-9 * got[1]
+    assert np.abs(got[0][0] - ref[0][0]).max() < 1e-15
+    # a chain of 900 with 130 loops: more separators than the fast path AND long chain runs between them (sweeps + general Schur together)
 
 
 def test_correct_map_points(api, oracle, synth):

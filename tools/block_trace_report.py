@@ -55,13 +55,21 @@ def main():
     for k, name in PMC_KEY.items():
         rec = next((v for kk, v in pmc.items() if kk.startswith(name)), None)
         per_img[k] = rec["valu_wave_insts_per_image"] if rec else 0.0
-    # launches: FAST launches are separated by gaps in FAST block starts > 30 us
-    fs = t0[kid == 0]
-    cuts = np.where(np.diff(fs) > 30000)[0]
-    l_start = np.concatenate([[fs[0]], fs[cuts + 1]])
-    l_end = np.concatenate([fs[cuts], [fs[-1]]])
-    launches = [(int(a), int(b)) for a, b in zip(l_start, l_end) if b - a > 500000]
-    if len(launches) < 4:
+    # FAST launches: within a launch the block ids of the started blocks grow from 0 (per XCD in steps of 8); a new launch begins where they fall back
+    bid = ((w[order] >> np.uint64(40)) & np.uint64(0xffffff)).astype(np.int64)
+    fi = np.where(kid == 0)[0]
+    launches = []
+    cur_start, hi = None, 0
+    for i in fi:
+        if cur_start is None:
+            cur_start, hi, last = int(t0[i]), int(bid[i]), int(t0[i])
+            continue
+        if bid[i] < hi // 4 and hi > 5000:
+            launches.append((cur_start, last)); cur_start, hi = int(t0[i]), int(bid[i])
+        hi = max(hi, int(bid[i])); last = int(t0[i])
+    launches.append((cur_start, last))
+    launches = [(a, b) for a, b in launches if b - a > 300000]
+    if len(launches) < 5:
         raise SystemExit(f"only {len(launches)} FAST launches in the trace")
     # one steady-state step = FAST launches 2 and 3 (two handles): from the start of launch 2 to the start of launch 4
     wa, wb = launches[2][0], (launches[4][0] if len(launches) > 4 else launches[3][1])
@@ -69,7 +77,7 @@ def main():
     blocks_per_img = {}
     for k in KID:
         n_in = int(((kid == k) & (t0 >= wa) & (t0 < wb)).sum())
-        blocks_per_img[k] = n_in * 8.0 / (2 * args.images_per_launch) if n_in else 0.0           # x 8 XCDs, two launches of images_per_launch images per step
+        blocks_per_img[k] = n_in * (256.0 / ncu) / (2 * args.images_per_launch) if n_in else 0.0           # x (256 / traced CUs), two launches of images_per_launch images per step
     inst_per_block = {k: (per_img[k] / blocks_per_img[k] if blocks_per_img[k] else 0.0) for k in KID}
     sl = args.slice_us * 1e3
     nsl = int(np.ceil((wb - wa) / sl))
@@ -115,6 +123,19 @@ def main():
         e[3] += row["util"]
     fast_rate = {k: {"slices": v[0], "fast_blocks_started_per_ms": round(v[1] / (v[0] * args.slice_us / 1e3), 1), "fast_resident_per_cu": round(v[2] / v[0], 2),
                      "issue_util": round(v[3] / v[0], 3)} for k, v in rate.items()}
+    # where a FAST block's life goes (thread 0's clock at the barriers that end its phases): tile staged | scored | NMS + record list | filter + append
+    phases = None
+    if r.shape[1] >= 3:
+        mk = r[order][:, 2]
+        fm = (kid == 0) & (t0 >= wa) & (t0 < wb)
+        m0 = ((mk >> np.uint64(0)) & np.uint64(0xffff)).astype(np.float64)[fm] / 100.0
+        m1 = ((mk >> np.uint64(16)) & np.uint64(0xffff)).astype(np.float64)[fm] / 100.0
+        m2 = ((mk >> np.uint64(32)) & np.uint64(0xffff)).astype(np.float64)[fm] / 100.0
+        life_us = dt[fm] / 1e3
+        ok = (m0 > 0) & (m1 >= m0) & (m2 >= m1) & (life_us >= m2)
+        seg = {"decode_and_stage_tile": m0[ok], "score": (m1 - m0)[ok], "nms_and_record_list": (m2 - m1)[ok], "filter_and_append": (life_us - m2)[ok], "whole_block": life_us[ok]}
+        phases = {k: {"median_us": round(float(np.median(v)), 2), "mean_us": round(float(v.mean()), 2), "p90_us": round(float(np.percentile(v, 90)), 2)} for k, v in seg.items()}
+        phases["blocks"] = int(ok.sum())
     util = np.array([row["util"] for row in slices])
     out = {
         "source": os.path.basename(args.npy), "counter_source": os.path.relpath(pmc_path, root), "cus_traced": ncu, "xcd": 0, "slice_us": args.slice_us,
@@ -122,6 +143,7 @@ def main():
         "blocks_per_image": {KID[k]: round(v, 2) for k, v in blocks_per_img.items()},
         "valu_wave_insts_per_block": {KID[k]: round(v, 1) for k, v in inst_per_block.items()},
         "step_issue_util_orb_kernels": round(float(util.mean()), 3),
+        "fast_block_phases_us": phases,
         "fast_block_lifetime_by_co_runner": fast_life,
         "fast_rate_by_co_runner": fast_rate,
         "slices": slices,
@@ -130,7 +152,7 @@ def main():
                   "x clock / 4 cycles.  The side chain's kernels (DeepLCD, DB scan, matcher, BA) are not traced: `util` is the ORB kernels' share only",
     }
     json.dump(out, sys.stdout, indent=1)
-    sys.stderr.write(json.dumps({k: out[k] for k in ("step_ms", "cus_traced", "blocks_per_image", "valu_wave_insts_per_block", "step_issue_util_orb_kernels",
+    sys.stderr.write(json.dumps({k: out[k] for k in ("step_ms", "cus_traced", "blocks_per_image", "valu_wave_insts_per_block", "step_issue_util_orb_kernels", "fast_block_phases_us",
                                                      "fast_block_lifetime_by_co_runner", "fast_rate_by_co_runner")}, indent=1) + "\n")
     for row, d in zip(slices, dom):
         sys.stderr.write(f"{row['t_ms']:6.2f} util {row['util']:.2f} [{d:14s}] " +

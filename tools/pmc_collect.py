@@ -130,8 +130,10 @@ def main():
     for k, rec in kernels.items():
         if k.startswith(("k_blur7", "k_resize", "k_fast")) and "fetch_bytes_per_image_corrected" in rec:
             cross[k] = {"corrected_fetch_over_pyramid_bytes": rec["fetch_bytes_per_image_corrected"] / pyr_px}
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import load_package
     out = {
-        "build": args.tag, "round": args.round,
+        "build": args.tag, "round": args.round, "build_id": load_package().api.build_id(),      # digest of the library's sources (myslam_hip_version)
         "command": f"rocprofv3 --kernel-trace --pmc <set> -- python bench.py --steps 2 --warmup 2 --pairs {P} --workload {args.workload} --streams 1 "
                    f"--orb-internal-stream 0 --orb-copy-input 1 --no-cpu-baseline --no-extra-passes --scene-rects {args.scene_rects}   (one pass per counter set; counters of the LAST "
                    f"step; COPY_INPUT 1 so that the calibration kernel k_ingest sees every image — by default it copies only the last image of a batch)",
