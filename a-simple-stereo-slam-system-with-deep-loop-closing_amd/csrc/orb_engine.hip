@@ -229,6 +229,7 @@ int myslam_orb::make_plan(int r, int c) {
         g.imgOff = imgOff; imgOff += align_up((size_t)g.pitch * align_up((size_t)g.h, 8), 256);      // whole 8-row tiles: the blurred planes are tiled (orb_plan.h)
         g.keyOff = keyOff; keyOff += g.keyCap;
     }
+    for (int l = 0; l < MAXL; l++) P.stripBaseOf[l] = l < P.nlevels ? P.lv[l].stripBase : INT32_MAX;
     P.ncells = cellBase; P.nstrips = stripBase; P.totalKeyCap = (int)keyOff; P.totalOut = outBase; P.pyrBytes = imgOff;
     // Oct-tree lookup tables.  A key's quad-tree path splits x and y independently (ExtractorNode::DivideNode halves each
     // axis with ceil, ORBextractor.cpp:526-582), so its path code is xcode[px] | ycode[py]: root index (:616) and the x

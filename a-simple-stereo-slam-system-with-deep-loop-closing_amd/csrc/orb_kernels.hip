@@ -1074,14 +1074,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
     const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
     const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     MYSLAM_BT(0);
-    const int b = logical / P.nstrips, sidx = logical - b * P.nstrips;
-    if (b >= batch) return;
+    // Round 6: the per-block trace (profiles/r06_fast_block_phases_alone.json) showed a block spending 2.1 of its 9.9 us between its start and its first tile
+    // load: ~19 scalar loads out of the kernel arguments, each behind its own s_waitcnt (one per level of the level search, the level's fields and the
+    // call's scalars re-read wherever a branch first needed them).  Now the arguments the head needs leave as TWO groups of loads — the call's scalars with the
+    // levels' first strips, then the level's record — each pinned to scalar registers before the first branch that could delay it.
+    int a_nstrips = P.nstrips, a_batch = batch, a_ext0N = P.ext0N, a_ext0Pitch = P.ext0Pitch;
+    const uint8_t* a_ext0 = P.ext0; size_t a_ext0Stride = P.ext0Stride;
+    int a_sb[MAXL];
+#pragma unroll
+    for (int l = 0; l < MAXL; l++) a_sb[l] = P.stripBaseOf[l];
+    asm volatile("" : "+s"(a_nstrips), "+s"(a_batch), "+s"(a_ext0N), "+s"(a_ext0Pitch), "+s"(a_ext0Stride), "+s"(a_sb[1]), "+s"(a_sb[9]));      // (not the pointer: laundered, it would be loaded from with flat instructions)
+    const int b = logical / a_nstrips, sidx = logical - b * a_nstrips;
+    if (b >= a_batch) return;
     // what the next launch of this handle decides on is reported by a SAMPLE of the strips (a ratio of sums needs no more, and a few thousand
     // same-address atomics per launch cost nothing where 300 k of them serialise into milliseconds)
     const bool sampled = logical % max(1, nwg >> 12) == 0;
     int level = 0;
-    for (int l = 1; l < P.nlevels; l++) if (sidx >= P.lv[l].stripBase) level = l;
-    const LevelGeom& g = P.lv[level];
+#pragma unroll
+    for (int l = 1; l < MAXL; l++) level += sidx >= a_sb[l] ? 1 : 0;               // ascending bases, INT_MAX behind the last level
+    const LevelGeom g = P.lv[level];
     const int spr = (g.nCols + G - 1) / G;                             // strips per cell row
     const int strip = sidx - g.stripBase;
     const int ci = strip / spr, cj0 = (strip - ci * spr) * G;
@@ -1105,9 +1116,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
     if (ncell == 0) return;
     auto wc_of = [&](int c) __attribute__((always_inline)) -> int { return s_wc[c]; };
     const int iniX0 = MIN_BORDER + cj0 * g.wCell;
-    const bool ext = level == 0 && b < P.ext0N;                      // level 0 read in place (block-uniform)
-    const uint8_t* img = ext ? P.ext0 + (size_t)b * P.ext0Stride : pyr + (size_t)b * pyrStride + g.imgOff;
-    const int ipitch = ext ? P.ext0Pitch : g.pitch;
+    const bool ext = level == 0 && b < a_ext0N;                      // level 0 read in place (block-uniform)
+    const uint8_t* img = ext ? a_ext0 + (size_t)b * a_ext0Stride : pyr + (size_t)b * pyrStride + g.imgOff;
+    const int ipitch = ext ? a_ext0Pitch : g.pitch;
+    MYSLAM_BT_MARK(3);                                                 // (trace builds: the block's decode is done, its tile loads start here)
     if constexpr (G * NQC <= 16) {
         // all loads of a thread are issued before its LDS stores.  Unaligned 16-byte loads (a cell starts at any column); a load may run up
         // to 15 bytes past its row or, in the last row of the last plane, into the slack behind the pyramid block — those bytes are never used.

@@ -49,6 +49,9 @@ struct OrbPlan {
     // ext0Pitch) instead of a copy inside the pyramid block.  The kernels' unaligned 8 / 16-byte loads may run a few bytes past a row:
     // harmless inside the caller's batch, which is why the LAST image of a batch is always copied (ext0N <= batch - 1).
     const uint8_t* ext0; size_t ext0Stride; int ext0Pitch, ext0N;
+    // the levels' first strips once more, side by side (round 6): the grid-FAST kernel finds a strip's level with ONE scalar load of this array instead of one
+    // dependent load per level out of lv[] (8 cache lines); levels >= nlevels hold INT_MAX
+    int stripBaseOf[MAXL];
     LevelGeom lv[MAXL];
 };
 

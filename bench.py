@@ -64,6 +64,11 @@ def _small_batch():
 # lanes that share a hardware queue serialise (8 pairs per step, 16 lanes: 17.1 k frames/s on 8 queues, 19.0 k on 16, 26.5 k on 24)
 HW_QUEUES = os.environ.setdefault("GPU_MAX_HW_QUEUES", ("24" if _small_batch() else "6") if _ranks_wanted() == 1 else "7")
 
+# Kernel arguments in device memory instead of host-visible memory (round 6): every block of every kernel starts with scalar loads out of its argument block, and the FAST
+# kernel's blocks live ~10 us of which ~2 are that head (DESIGN_APPENDIX.md section 10).  Same-box A/B: 6.484 / 6.447 / 6.449 -> 6.428 / 6.419 / 6.432 ms per step.  Like the
+# queue count a runtime setting of the APPLICATION, stated in the line (config.hip_dev_kernarg); the library reads no environment variable.
+DEV_KERNARG = os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package  # noqa: E402
@@ -847,7 +852,7 @@ def main():
                        "pairs_per_step_per_gpu": P, "image": "1241x376 u8", "scene_rects": args.scene_rects, "keypoints_per_image": n_kp,
                        "hip_streams": {"caller": len({stream, stream2} | {s.cuda_stream for s in orb_streams}) + (1 if args.pipeline else 0),
                                        "extractor_internal": n_internal},
-                       "hip_hw_queues": int(HW_QUEUES), "orb_extractor_handles": S, "pipelined_steps": bool(args.pipeline),
+                       "hip_hw_queues": int(HW_QUEUES), "hip_dev_kernarg": DEV_KERNARG, "orb_extractor_handles": S, "pipelined_steps": bool(args.pipeline),
                        "input_level0": "read in place (resident input images; the last image of each extractor call is copied)" if not args.orb_copy_input
                                        else "copied into the pyramid block",
                        "parallelism": f"frame-sharded x{world}" + (", id-range sharded DB + all-gather of 16-byte candidate records" if world > 1 else "")},

@@ -73,7 +73,7 @@ def parse():
     ap.add_argument("--side-skip", default="", help="diagnostic: comma list of side-chain parts to leave out (lcd, db, ba) — measures what each part costs the step")
     ap.add_argument("--blur-mfma", type=int, default=0, choices=[0, 1],
                     help="myslam_orb_set_option(BLUR_MFMA): 1 = the Gaussian pyramid on the int8 matrix cores (k_blur7_mfma), 0 = register-strip kernel")
-    ap.add_argument("--stream-mode", default="1x16,2x16,4x16",
+    ap.add_argument("--stream-mode", default="1x16,1x4,2x16,4x16",
                     help="live-stream operating points, 'PAIRSxLANES,...' ('' = skip): after the other passes each point is run as a child process "
                          "(bench.py --pairs P --lanes L --graph 1: recorded steps on L lanes scanning ONE loop database through L query contexts; its own "
                          "GPU_MAX_HW_QUEUES) and reported as `stream_mode` — the reference's call pattern is one frame per call (src/frontend.cpp:41-77)")

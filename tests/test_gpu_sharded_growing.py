@@ -17,7 +17,7 @@ def test_n_shards_on_one_gpu_grow_and_answer_like_one_map(api, oracle, synth, N,
     shards = [api.LoopDatabase(32) for _ in range(N)]            # small first allocation: every shard grows (moves) several times on the way
     rng = np.random.default_rng(N * 100 + P)
     ref_ids, ref_db = [], []
-    total, nq_seen, above, broke = 0, 0, 0, 0
+    total, nq_seen, above, broke, reached = 0, 0, 0, 0, 0
     for step in range(steps):
         nq = P
         base = step * (P + 3) + 60 * (step // 10)                             # every tenth step the ids jump by 60: windows that hold no id exist
@@ -31,7 +31,12 @@ def test_n_shards_on_one_gpu_grow_and_answer_like_one_map(api, oracle, synth, N,
         if step % 5 == 4 and step > 25:                                       # a query from the PAST: rows above cur are reached when nothing sits in its window
             g = 1 + (step // 5) % (step // 10 - 1)                                # a jump of the past: ids ... e | 60 free ids | ...
             e = (10 * g - 1) * (P + 3) + 60 * (g - 1) + P + 2                    # the largest id the step before the jump could have used
-            cur[0] = np.uint64(e + (30 if step % 10 == 4 else 3))                 # 30: the window lies in the free range (scan goes on above cur); 3: it holds ids (break)
+            cur[0] = np.uint64(e + 30)                                            # the window lies in the free range: the scan goes on above cur ...
+            if step % 10 == 4:
+                d[0] = ref_db[-1 - step % 7]                                      # ... and finds its best row there (a copy of a recent key-frame)
+        if step % 5 == 3 and step > 25:                                       # a query from the past whose window holds ids: the scan breaks there
+            g = 1 + (step // 5) % (step // 10 - 1)
+            cur[0] = np.uint64((10 * g - 1) * (P + 3) + 60 * (g - 1) + P + 2 + 3)
         d_q = torch.from_numpy(d).cuda()
         d_gath = torch.zeros(N, nq * 32, dtype=torch.uint8, device="cuda")
         for s, D in enumerate(shards):
@@ -48,7 +53,8 @@ def test_n_shards_on_one_gpu_grow_and_answer_like_one_map(api, oracle, synth, N,
                 rb, rm, rc = oracle.lcddb_query(R_db, R_ids, d[i], int(cur[i]))
                 near = int((np.abs(R_db @ d[i] - 0.92) < 1e-5).sum())
                 assert int(best[i]) == rb and abs(float(mx[i]) - rm) < SCORE_ATOL and abs(int(cnt[i]) - rc) <= near, (step, i, int(cur[i]), int(best[i]), rb, float(mx[i]), rm, int(cnt[i]), rc)
-                nq_seen += 1; above += rb > int(cur[i]); broke += bool(((R_ids <= cur[i]) & (R_ids + np.uint64(19) >= cur[i])).any())
+                in_window = bool(((R_ids <= cur[i]) & (R_ids + np.uint64(19) >= cur[i])).any())
+                nq_seen += 1; above += rb > int(cur[i]); broke += in_window; reached += (not in_window) and bool((R_ids > cur[i]).any())
         # AddToDatabase after DetectLoop; the j-th key-frame of the step goes to shard (total + j) mod N
         for j in range(nq):
             shards[(total + j) % N].append_batch(ids[j:j + 1], d_q.data_ptr() + j * 1064 * 4, 1)
@@ -56,7 +62,8 @@ def test_n_shards_on_one_gpu_grow_and_answer_like_one_map(api, oracle, synth, N,
         total += nq
         rows = [len(D) for D in shards]
         assert max(rows) - min(rows) <= 1 and sum(rows) == total
-    assert nq_seen > steps * P // 2 and broke > nq_seen // 4 and above >= 3, (nq_seen, broke, above)      # both ends of the rule are exercised: scans that end at the break, scans that go on above cur
+    # both ends of the rule are exercised: scans that end at the break, scans that go on above cur (and some of those find their best row there)
+    assert nq_seen > steps * P // 2 and broke > nq_seen // 4 and reached >= 3 and above >= 1, (nq_seen, broke, reached, above)
     assert all(D.generation() >= 1 for D in shards)
 
 

@@ -11,9 +11,9 @@ import numpy as np, json
 r = np.load("gpurun_out/bt_alone_$TAG.npy")
 w = r[:, 1]; kid = ((w >> np.uint64(24)) & np.uint64(0xf)).astype(int); dt = (w & np.uint64(0xffffff)).astype(float) / 100.0
 mk = r[:, 2]; f = kid == 0
-m = [((mk >> np.uint64(16 * i)) & np.uint64(0xffff)).astype(float)[f] / 100.0 for i in range(3)]
+m = [((mk >> np.uint64(16 * i)) & np.uint64(0xffff)).astype(float)[f] / 100.0 for i in range(4)]
 life = dt[f]; ok = (m[0] > 0) & (m[1] >= m[0]) & (m[2] >= m[1]) & (life >= m[2])
-seg = {"decode_and_stage_tile": m[0][ok], "score": (m[1] - m[0])[ok], "nms_and_record_list": (m[2] - m[1])[ok], "filter_and_append": (life - m[2])[ok], "whole_block": life[ok]}
+seg = {"decode_before_the_tile_loads": m[3][ok], "decode_and_stage_tile": m[0][ok], "score": (m[1] - m[0])[ok], "nms_and_record_list": (m[2] - m[1])[ok], "filter_and_append": (life - m[2])[ok], "whole_block": life[ok]}
 out = {k: {"median_us": round(float(np.median(v)), 2), "mean_us": round(float(v.mean()), 2), "p90_us": round(float(np.percentile(v, 90)), 2)} for k, v in seg.items()}
 out["blocks"] = int(ok.sum())
 for k in (1, 2, 3, 4):

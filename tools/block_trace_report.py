@@ -133,7 +133,8 @@ def main():
         m2 = ((mk >> np.uint64(32)) & np.uint64(0xffff)).astype(np.float64)[fm] / 100.0
         life_us = dt[fm] / 1e3
         ok = (m0 > 0) & (m1 >= m0) & (m2 >= m1) & (life_us >= m2)
-        seg = {"decode_and_stage_tile": m0[ok], "score": (m1 - m0)[ok], "nms_and_record_list": (m2 - m1)[ok], "filter_and_append": (life_us - m2)[ok], "whole_block": life_us[ok]}
+        m3 = ((mk >> np.uint64(48)) & np.uint64(0xffff)).astype(np.float64)[fm] / 100.0
+        seg = {"decode_before_the_tile_loads": m3[ok], "decode_and_stage_tile": m0[ok], "score": (m1 - m0)[ok], "nms_and_record_list": (m2 - m1)[ok], "filter_and_append": (life_us - m2)[ok], "whole_block": life_us[ok]}
         phases = {k: {"median_us": round(float(np.median(v)), 2), "mean_us": round(float(v.mean()), 2), "p90_us": round(float(np.percentile(v, 90)), 2)} for k, v in seg.items()}
         phases["blocks"] = int(ok.sum())
     util = np.array([row["util"] for row in slices])

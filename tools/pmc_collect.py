@@ -42,7 +42,7 @@ def run_pass(counters, pairs, workload, outdir, scene_rects, extra=()):
         shutil.rmtree(outdir)
     cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", outdir, "-o", "a", "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "2", "--pairs", str(pairs), "--workload", workload,
-           "--streams", "1", "--orb-internal-stream", "0", "--orb-copy-input", "1", "--no-cpu-baseline", "--no-extra-passes", "--graph", "0", "--parity-frames", "0",
+           "--streams", "1", "--orb-internal-stream", "0", "--orb-copy-input", "1", "--no-cpu-baseline", "--no-extra-passes", "--no-repeats", "--graph", "0", "--parity-frames", "0",
            "--scene-rects", str(scene_rects)] + list(extra)
     env = dict(os.environ, TMPDIR="/tmp")
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
