@@ -1,0 +1,70 @@
+"""GPU fuzz of round 6's new paths against the oracle: (1) a loop database split over N shards by a random ownership rule, scanned through
+myslam_lcddb_query_batch_owned (both scan kernels, queries from the past / present / below id 19, duplicates, shards that grow while queried) and merged
+on the device; (2) pose graphs that need more separators than the fast path (the general Schur path).     python tools/gpu_fuzz_round6.py <seed> <n_db_cases> <n_pgo_cases>"""
+import sys, numpy as np
+sys.path.insert(0, ".")
+import torch
+import __graft_entry__ as g
+pkg = g.load_package(); api, synth = pkg.api, pkg.synth
+sys.path.insert(0, "oracle")
+from pyoracle import Oracle
+o = Oracle()
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+rng = np.random.default_rng(seed)
+NDB = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+NPG = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+bad = 0
+for it in range(NDB):
+    N = int(rng.choice([1, 2, 3, 4, 8, 16])); n = int(rng.integers(1, 1500)); nq = int(rng.choice([1, 2, 5, 31, 32, 33, 70, 200]))
+    span = int(rng.choice([n + 5, 3 * n + 50, 40 * n + 100]))
+    ids = np.sort(rng.choice(np.arange(0, span), n, replace=False)).astype(np.uint64)
+    db = synth.lcd_database(n, seed=int(rng.integers(1 << 30)))
+    for _ in range(int(rng.integers(0, 4))):
+        a, b = rng.integers(0, n, 2); db[a] = db[b]
+    rule = rng.choice(["arrival", "mod", "random"])
+    own = {"arrival": np.arange(n) % N, "mod": (ids % np.uint64(N)).astype(int), "random": rng.integers(0, N, n)}[rule]
+    shards = [api.LoopDatabase(int(rng.choice([8, 64, 2048]))) for _ in range(N)]
+    t_db = torch.from_numpy(db).cuda()
+    half = n // 2 if rng.random() < 0.5 else n            # half of the rows first, a query round, then the rest: the shards grow between scans
+    def append(lo, hi):
+        for i in range(lo, hi):
+            shards[own[i]].append_batch(ids[i:i + 1], t_db.data_ptr() + i * 1064 * 4, 1)
+    def check(nrows, tag):
+        global bad
+        cur = np.concatenate([rng.integers(0, span + 60, nq - nq // 3), ids[rng.integers(0, max(1, nrows), nq // 3)] + rng.integers(0, 30, nq // 3).astype(np.uint64)]).astype(np.uint64)[:nq]
+        if nq > 3: cur[:3] = [0, 7, 19]
+        q = db[rng.integers(0, n, nq)] * 0.95 + 0.05 * synth.lcd_database(nq, seed=int(rng.integers(1 << 30)))
+        q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+        if nq > 1: q[-1] = db[int(rng.integers(0, n))]
+        d_q = torch.from_numpy(q).cuda(); d_g = torch.zeros(N, nq * 32, dtype=torch.uint8, device="cuda")
+        for s_, D in enumerate(shards):
+            D.query_batch_owned(d_q.data_ptr(), cur, nq, d_g[s_].data_ptr())
+        d_b = torch.zeros(nq, dtype=torch.int64, device="cuda"); d_m = torch.zeros(nq, device="cuda"); d_c = torch.zeros(nq, dtype=torch.int32, device="cuda")
+        api.lcd_merge_owned_candidates_device(d_g.data_ptr(), N, nq, d_b.data_ptr(), d_m.data_ptr(), d_c.data_ptr()); torch.cuda.synchronize()
+        bb, mm, cc = d_b.cpu().numpy().view(np.uint64), d_m.cpu().numpy(), d_c.cpu().numpy()
+        for i in range(nq):
+            if nrows == 0:
+                rb, rm, rc = 0, 0.0, 0
+            else:
+                rb, rm, rc = o.lcddb_query(db[:nrows], ids[:nrows], q[i], int(cur[i]))
+            sc = db[:nrows] @ q[i] if nrows else np.zeros(0)
+            near = int((np.abs(sc - 0.92) < 1e-5).sum())
+            tie = nrows and int((np.abs(sc - rm) < 2e-6).sum()) > 1 and abs(float(mm[i]) - rm) < 2e-5          # two different rows within float noise of the maximum: either id
+            if not ((int(bb[i]) == rb or tie) and abs(float(mm[i]) - rm) < 2e-5 and abs(int(cc[i]) - rc) <= near):
+                bad += 1; print("OWNED DB MISMATCH", tag, dict(N=N, n=n, nq=nq, rule=str(rule), rows=nrows, i=i, cur=int(cur[i])), (int(bb[i]), float(mm[i]), int(cc[i])), (rb, rm, rc)); break
+    append(0, half); check(half, "first"); append(half, n); check(n, "all")
+    assert sum(len(D) for D in shards) == n
+for it in range(NPG):
+    n = int(rng.integers(200, 320)); nsep = int(rng.integers(100, 150))
+    poses, fixed, e0, e1, meas, gt = synth.pose_graph(n, 2, seed=int(rng.integers(1 << 30)))
+    # extra edges between random key-frame pairs at their (noisy) true relative pose: every one of them needs a separator
+    ea = rng.choice(np.arange(5, n - 12), nsep, replace=False); eb = (ea - rng.integers(3, 60, nsep)).clip(0, None)
+    ok = ea - eb > 1; ea, eb = ea[ok], eb[ok]
+    extra = np.stack([o.se3_compose(o.se3_compose(gt[i], gt[j], invert_b=True), o.se3_exp(0.003 * rng.standard_normal(6))) for i, j in zip(ea, eb)])
+    E0 = np.concatenate([e0, ea.astype(np.int32)]); E1 = np.concatenate([e1, eb.astype(np.int32)]); M = np.concatenate([meas, extra])
+    ref = o.pose_graph_optimize(poses, fixed, E0, E1, M); got = api.pose_graph_optimize(poses, fixed, E0, E1, M)
+    dev = max(np.abs(got[0][:, 4:] - ref[0][:, 4:]).max(), np.abs(np.abs(np.sum(got[0][:, :4] * ref[0][:, :4], axis=1)) - 1).max())
+    if not (abs(got[1] - ref[1]) <= 1e-5 * ref[1] and dev < 5e-4):
+        bad += 1; print("PGO GENERAL PATH MISMATCH", n, len(ea), got[1], ref[1], dev, got[2], ref[2])
+print(f"fuzz done: {NDB} owned-database cases, {NPG} pose graphs beyond the fast path, {bad} mismatches")
+sys.exit(1 if bad else 0)
