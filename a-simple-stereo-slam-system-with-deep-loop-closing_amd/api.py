@@ -458,6 +458,11 @@ class LoopDatabase:
         ids = np.ascontiguousarray(ids, np.uint64)
         _check(lib().myslam_lcddb_append_batch(self._h, _p(ids), C.c_void_p(d_descr), n), "myslam_lcddb_append_batch")
 
+    def append_batch_async(self, ids, d_descr, n, stream):
+        """AddToDatabase inside a pipelined step: copies enqueued on `stream`, no wait (MyslamError(CAPACITY) when the rows do not fit: reserve ahead)"""
+        ids = np.ascontiguousarray(ids, np.uint64)
+        _check(lib().myslam_lcddb_append_batch_async(self._h, _p(ids), C.c_void_p(d_descr), n, C.c_void_p(stream or None)), "myslam_lcddb_append_batch_async")
+
     def query(self, descr, cur_id, thr_low=0.92):
         d = np.ascontiguousarray(descr, np.float32)
         best = C.c_uint64(); mx = C.c_float(); cnt = C.c_int()

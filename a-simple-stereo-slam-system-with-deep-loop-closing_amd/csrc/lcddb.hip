@@ -354,6 +354,11 @@ struct myslam_lcddb_query_ctx {
     Partial* d_partials = nullptr; size_t partialsCap = 0;
     int32_t* d_nvalid = nullptr; int nvalidCap = 0;                 // nq row limits + 1: the row count they were computed against
     int32_t* h_nvalid = nullptr; hipEvent_t nvEvent = nullptr;      // pinned staging of the per-query row limits + "copy done" event
+    // round 6: eager uploads go through a RING of pinned slots behind slot 0 (slot 0 is what recorded scans read at their replays): a call whose limits changed — a
+    // database that grows every step — used to wait for the previous call's upload to leave the one pinned buffer, i.e. for the stream to drain up to it; now it waits for
+    // the upload three calls back, which has long gone
+    static constexpr int NV_RING = 3;
+    hipEvent_t nvRingEv[NV_RING] = {nullptr, nullptr, nullptr}; bool nvRingPending[NV_RING] = {false, false, false}; int nvSlot = 0;
     const int32_t* limits = nullptr;                                // what the launches of the current call read: d_nvalid (eager) or h_nvalid itself (recorded)
     uint64_t* d_bestS = nullptr; float* d_maxS = nullptr; int32_t* d_cntS = nullptr; int shardCap = 0;     // scratch of the sharded query
     // scratch of the owned-shard query (round 6): row ranges [0, pLim) and [sBeg, sLim) + break flags per query (pinned staging + device copy), results of both parts
@@ -376,6 +381,9 @@ struct myslam_lcddb {
     std::vector<myslam_lcddb_query_ctx*> ctxs;              // every live context (ctxs[0] = the built-in one)
     std::mutex mu;                            // host state: ids, n, capacity, pointers, context list
     float* d_q1 = nullptr; uint64_t* d_best1 = nullptr; float* d_max1 = nullptr; int32_t* d_cnt1 = nullptr;
+    // pinned staging of the ids of asynchronous appends (a copy out of pageable host memory makes the runtime wait for the stream): a ring of slots, each with its event
+    static constexpr int ID_RING = 4, ID_SLOT = 1024;
+    uint64_t* h_idring = nullptr; hipEvent_t idEv[ID_RING] = {nullptr, nullptr, nullptr, nullptr}; bool idPending[ID_RING] = {false, false, false, false}; int idSlot = 0;
 
     // index of the first row the reference's scan does NOT look at: it breaks at the first id with
     // (cur - id) < 20 in unsigned arithmetic (loopclosing.cpp:133), i.e. id in [cur-19, cur] mod 2^64
@@ -411,6 +419,7 @@ static void ctx_free(myslam_lcddb_query_ctx* c) {
     if (c->h_nvalid) (void)hipHostFree(c->h_nvalid);
     if (c->h_own) (void)hipHostFree(c->h_own);
     if (c->nvEvent) (void)hipEventDestroy(c->nvEvent);
+    for (hipEvent_t e : c->nvRingEv) if (e) (void)hipEventDestroy(e);
     if (c->ownEvent) (void)hipEventDestroy(c->ownEvent);
     if (c->link) c->link->invalidate();       // recorded steps that captured this context can no longer be launched
     delete c;
@@ -476,6 +485,8 @@ int myslam_lcddb_destroy(myslam_lcddb* h) {
     for (myslam_lcddb_query_ctx* c : h->ctxs) { (void)ctx_quiesce(c); ctx_free(c); }      // contexts die with their database
     void* ptrs[] = {h->d_db, h->d_ids, h->d_q1, h->d_best1, h->d_max1, h->d_cnt1};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (int r = 0; r < myslam_lcddb::ID_RING; r++) { if (h->idPending[r]) (void)hipEventSynchronize(h->idEv[r]); if (h->idEv[r]) (void)hipEventDestroy(h->idEv[r]); }
+    if (h->h_idring) (void)hipHostFree(h->h_idring);
     for (auto& r : h->retired) { (void)hipFree(r.first); (void)hipFree(r.second); }
     delete h;
     return MYSLAM_OK;
@@ -577,7 +588,43 @@ static int db_append(myslam_lcddb* h, const uint64_t* ids, const float* src, int
     return MYSLAM_OK;
 }
 
+// AddToDatabase inside a pipelined step (round 6): the rows are copied on the CALLER's stream and the call does not wait for them — the caller orders later scans
+// behind the copy (same stream, or an event), as it orders everything else of the step.  The host state (ids, row count) is updated at once, so the row limits of the next
+// query already cover the new rows.  Never moves the matrix: MYSLAM_ERR_CAPACITY when the rows do not fit (myslam_lcddb_reserve ahead of the run).
+static int db_append_async(myslam_lcddb* h, const uint64_t* ids, const float* d_src, int n, hipStream_t s) {
+    if (!h || !ids || !d_src || n < 0) return MYSLAM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    for (int i = 0; i < n; i++) {
+        const uint64_t prev = (i == 0) ? (h->ids.empty() ? 0 : h->ids.back()) : ids[i - 1];
+        if (!(i == 0 && h->ids.empty()) && ids[i] <= prev) return MYSLAM_ERR_INVALID;
+    }
+    if ((long long)h->n + n > h->capacity) return MYSLAM_ERR_CAPACITY;
+    if (n == 0) return MYSLAM_OK;
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_db + (size_t)h->n * DIM, d_src, (size_t)n * DIM * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (n <= myslam_lcddb::ID_SLOT) {                                  // ids through a pinned ring slot: the call never waits for the stream
+        if (!h->h_idring) {
+            MYSLAM_HIP_CHECK(hipHostMalloc((void**)&h->h_idring, sizeof(uint64_t) * myslam_lcddb::ID_RING * myslam_lcddb::ID_SLOT));
+            for (auto& e : h->idEv) MYSLAM_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        const int r = h->idSlot; h->idSlot = (h->idSlot + 1) % myslam_lcddb::ID_RING;
+        if (h->idPending[r]) MYSLAM_HIP_CHECK(hipEventSynchronize(h->idEv[r]));
+        uint64_t* st = h->h_idring + (size_t)r * myslam_lcddb::ID_SLOT;
+        memcpy(st, ids, sizeof(uint64_t) * n);
+        MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_ids + h->n, st, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        MYSLAM_HIP_CHECK(hipEventRecord(h->idEv[r], s)); h->idPending[r] = true;
+    } else {
+        MYSLAM_HIP_CHECK(hipMemcpyAsync(h->d_ids + h->n, ids, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, s));      // pageable source: staged before the call returns
+    }
+    h->ids.insert(h->ids.end(), ids, ids + n);
+    h->n += n;
+    return MYSLAM_OK;
+}
+
 int myslam_lcddb_capacity(const myslam_lcddb* h) { return h ? h->capacity : MYSLAM_ERR_INVALID; }
+
+int myslam_lcddb_append_batch_async(myslam_lcddb* h, const uint64_t* ids, const float* d_descr, int n, void* hip_stream) {
+    return db_append_async(h, ids, d_descr, n, (hipStream_t)hip_stream);
+}
 
 int myslam_lcddb_reserve(myslam_lcddb* h, int rows) {
     if (!h || rows < 0) return MYSLAM_ERR_INVALID;
@@ -616,8 +663,12 @@ static int db_query(myslam_lcddb_query_ctx* c, const float* d_q, const uint64_t*
         if (c->h_nvalid) (void)hipHostFree(c->h_nvalid);
         c->d_nvalid = nullptr; c->h_nvalid = nullptr; c->nvalidCap = 0;
         MYSLAM_HIP_CHECK(hipMalloc((void**)&c->d_nvalid, sizeof(int32_t) * (nq + 1)));
-        MYSLAM_HIP_CHECK(hipHostMalloc((void**)&c->h_nvalid, sizeof(int32_t) * (nq + 1)));
+        MYSLAM_HIP_CHECK(hipHostMalloc((void**)&c->h_nvalid, sizeof(int32_t) * (nq + 1) * (1 + myslam_lcddb_query_ctx::NV_RING)));
         if (!c->nvEvent) MYSLAM_HIP_CHECK(hipEventCreateWithFlags(&c->nvEvent, hipEventDisableTiming));
+        for (int r = 0; r < myslam_lcddb_query_ctx::NV_RING; r++) {
+            if (!c->nvRingEv[r]) MYSLAM_HIP_CHECK(hipEventCreateWithFlags(&c->nvRingEv[r], hipEventDisableTiming));
+            c->nvRingPending[r] = false;                              // (ctx_quiesce above: nothing of the old buffer is in flight)
+        }
         c->nvalidCap = nq; c->nvFresh = false;
     }
     // the row limits of this call; when they equal what the device buffer already holds (the same cur_ids against the same rows, the
@@ -658,18 +709,21 @@ static int db_query(myslam_lcddb_query_ctx* c, const float* d_q, const uint64_t*
         if (rn) return rn;
     }
     if (!same) {
+        // eager: one small upload out of a ring slot (slots are nvalidCap + 1 ints apart; slot 0 belongs to the recorded scans).  Recorded: NO copy node — the
+        // recorded kernels read slot 0 of the pinned buffer itself (device-visible host memory) at every replay; a recorded one-pair step is bound by the number of
+        // its nodes (~4.6 us each, tools/node_count_probe.sh), and a few hundred 4-byte reads over the host link cost the scan ~2 us
+        int32_t* stage = c->h_nvalid;
+        int ring = -1;
         if (!cap) {
-            if (c->graphRows) { const int rw = c->link->wait(); if (rw) return rw; MYSLAM_HIP_CHECK(hipStreamSynchronize(c->stream)); }      // a recorded step also reads the pinned buffer: wait for its replays, wherever they were launched
-            else if (c->nvPending) MYSLAM_HIP_CHECK(hipEventSynchronize(c->nvEvent));   // the previous upload has left the pinned buffer
+            ring = c->nvSlot; c->nvSlot = (c->nvSlot + 1) % myslam_lcddb_query_ctx::NV_RING;
+            if (c->nvRingPending[ring]) MYSLAM_HIP_CHECK(hipEventSynchronize(c->nvRingEv[ring]));      // the upload NV_RING calls back has left this slot
+            stage = c->h_nvalid + (size_t)(1 + ring) * (c->nvalidCap + 1);
         }
-        memcpy(c->h_nvalid, c->scratchLimits.data(), sizeof(int32_t) * nq);
-        c->h_nvalid[nq] = rows_now;
-        // eager: one small upload.  Recorded: NO copy node — the recorded kernels read the pinned buffer itself (device-visible host memory) at
-        // every replay; a recorded one-pair step is bound by the number of its nodes (~4.6 us each, tools/node_count_probe.sh), and a few
-        // hundred 4-byte reads over the host link cost the scan ~2 us
+        memcpy(stage, c->scratchLimits.data(), sizeof(int32_t) * nq);
+        stage[nq] = rows_now;
         if (!cap) {
-            MYSLAM_HIP_CHECK(hipMemcpyAsync(c->d_nvalid, c->h_nvalid, sizeof(int32_t) * (nq + 1), hipMemcpyHostToDevice, c->stream));      // pinned -> no host sync
-            MYSLAM_HIP_CHECK(hipEventRecord(c->nvEvent, c->stream)); c->nvPending = true;
+            MYSLAM_HIP_CHECK(hipMemcpyAsync(c->d_nvalid, stage, sizeof(int32_t) * (nq + 1), hipMemcpyHostToDevice, c->stream));      // pinned -> no host sync
+            MYSLAM_HIP_CHECK(hipEventRecord(c->nvRingEv[ring], c->stream)); c->nvRingPending[ring] = true;
         }
         c->lastLimits = c->scratchLimits; c->lastRows = rows_now; c->nvFresh = !cap;             // (a recorded scan reads whatever the pinned buffer holds at its replay)
     }

@@ -233,6 +233,7 @@ def main():
     solve_windows = [P if use_solve else 0]          # windows the side chain also SOLVES per step (pass 3 sets ceil(P / 6))
 
     skip = set(args.side_skip.split(",")) if args.side_skip else set()      # diagnostic: the marginal cost of the side chain's parts
+    grow = [False, 0, []]                            # pass "db_grow": [on, next key-frame id, the appended row blocks (kept for the check after the pass)]
 
     def side_chain(with_ba=True):
         if use_ba and "ba" not in skip and solve_windows[0] and solve_stream is not side_stream:
@@ -268,6 +269,13 @@ def main():
                 pkg.sharded_db.exchange_and_merge(d_cand, world, d_best, d_max, d_dbcnt, via_cpu=via_cpu)
             else:
                 D.query_batch(d_descr.data_ptr(), cur_ids, NQ, d_best.data_ptr(), d_max.data_ptr(), d_dbcnt.data_ptr())
+            if grow[0]:         # LoopClosing::AddToDatabase (src/loopclosing.cpp:651-659) after DetectLoop: the step's key-frames (1 frame in 6) join the database, on this stream, no host wait
+                nkf = (P + 5) // 6
+                d_kf = d_descr[::6][:nkf].contiguous()
+                kf_ids = np.arange(grow[1], grow[1] + nkf, dtype=np.uint64)
+                D.append_batch_async(kf_ids, d_kf.data_ptr(), nkf, stream2)
+                grow[1] += nkf; grow[2].append(d_kf)
+                cur_ids[:] = grow[1] + 20 + P              # the next step's frames: ids beyond everything in the database (no cut-off), as in the other passes
         if use_ba and "ba" not in skip:
             if with_ba or solve_windows[0]:
                 api.ba_build_batch(*[t.data_ptr() for t in b_in], P, maxP, maxL, maxE, Kt, 5.991, *[t.data_ptr() for t in b_out], stream2)
@@ -825,6 +833,38 @@ def main():
         assert int(s_st.abs().sum()) == 0
         solve_roof = ba_solve_roofline(s_rd.cpu().numpy(), ba_w[6], P, solve_ms)
 
+    # ---- pass: the database GROWS inside the step (round 6).  The reference appends every key-frame (AddToDatabase) after its DetectLoop; the timed region scans a
+    # database that was loaded once.  Here every step appends its key-frames (1 frame in 6) behind its scan, asynchronously on the side stream (myslam_lcddb_append_batch_async),
+    # and the next step scans them too.  After everything that reads the original database (parity sample above) ----
+    db_grow = None
+    if use_lcd and world == 1 and not emu and not args.no_extra_passes and args.pipeline:
+        nkf = (P + 5) // 6
+        n0 = len(D)
+        D.reserve(n0 + (args.steps + 4) * nkf)             # growth moves the matrix (a synchronising operation): room for the whole pass up front
+        keep_cur = cur_ids.copy()
+        grow[0], grow[1], grow[2] = True, int(ids[-1]) + 1, []
+        step(); step(); barrier()
+        dt_g = timed(args.steps)
+        grow[0] = False
+        n1 = len(D)
+        dt_big = timed(args.steps)                          # the same steps against the database as it has become, nothing appended: what the larger scan alone costs
+        # check: the key-frames of the LAST step are in the database under their ids — queried with their own descriptors they come back with score 1
+        last = grow[2][-1]
+        qb = torch.zeros(nkf, dtype=torch.int64, device=dev); qm = torch.zeros(nkf, device=dev); qc = torch.zeros(nkf, dtype=torch.int32, device=dev)
+        with torch.cuda.stream(side_stream):
+            D.query_batch(last.data_ptr(), np.full(nkf, grow[1] + 1000, np.uint64), nkf, qb.data_ptr(), qm.data_ptr(), qc.data_ptr())
+        torch.cuda.synchronize()
+        # (every step of the bench extracts the same 512 pairs, so every step appends the same 86 descriptors: the strict-'>' scan returns the FIRST copy of each)
+        first_ids = np.arange(int(ids[-1]) + 1, int(ids[-1]) + 1 + nkf, dtype=np.uint64)
+        found = int((torch.from_numpy(first_ids.view(np.int64)).to(dev) == qb).sum()); smin = float(qm.min())
+        copies = int(qc.min())                            # every query sees all copies of its row above the 0.92 threshold: at least one per step
+        db_grow = {"value": world * P * args.steps / dt_g, "unit": "stereo frames/s", "ms_per_step": dt_g / args.steps * 1e3, "key_frames_appended_per_step": nkf,
+                   "rows_before": n0, "rows_after": n1, "ms_per_step_at_rows_after_without_appends": dt_big / args.steps * 1e3, "last_step_key_frames_found_at_their_first_copy": found, "of": nkf, "their_min_score": smin, "min_rows_above_threshold": copies,
+                   "ok": bool(n1 == n0 + (args.steps + 2) * nkf and found == nkf and smin > 0.9999 and copies >= args.steps + 2),
+                   "note": "as the timed region, plus LoopClosing::AddToDatabase inside the step: every step appends its key-frames (1 frame in 6) behind its scan with "
+                           "myslam_lcddb_append_batch_async on the side stream (no host wait) and the following steps scan them; rows reserved up front"}
+        cur_ids[:] = keep_cur; grow[2] = []
+        assert db_grow["ok"], db_grow
     stream_mode = None
     if rank == 0 and world == 1 and args.stream_mode and not args.no_extra_passes and args.workload in ("full", "orb_match_lcd"):
         barrier()
@@ -861,7 +901,7 @@ def main():
             "per_rank_ms_per_step": per_rank_ms, "per_rank_own_device_done_ms_per_step": per_rank_own_ms,
             "collective_ms_per_step": None if collective is None else collective["collective_ms_per_step"],
             "shard_scan_ms_per_step": None if collective is None else collective["shard_scan_ms_per_step"],
-            "db_exchange": collective, "emulated_world": emulated,
+            "db_exchange": collective, "emulated_world": emulated, "db_grow": db_grow,
             "roofline": roof, "roofline_valu": roof_valu, "roofline_mfma": mf,
             "profiled_pass": None if dt_prof is None else {"ms_per_step": dt_prof / args.steps * 1e3,
                                                            "kernel_ms_per_step": {SYMBOL.get(k, k): v[0] / args.steps for k, v in busy.items()}},

@@ -303,6 +303,10 @@ int myslam_lcddb_capacity(const myslam_lcddb* h);
 int myslam_lcddb_reserve(myslam_lcddb* h, int rows);
 int myslam_lcddb_append(myslam_lcddb* h, uint64_t id, const float* descr1064);
 int myslam_lcddb_append_batch(myslam_lcddb* h, const uint64_t* ids /*host*/, const float* d_descr, int n);
+/* AddToDatabase inside a pipelined step (round 6): as myslam_lcddb_append_batch, but the device copies are enqueued on `hip_stream` and the call does NOT wait for them — the
+ * caller orders later scans of those rows behind the copy (same stream, or an event).  Ids and row count are updated before the call returns (the next query's row limits
+ * cover the new rows).  Never moves the matrix: MYSLAM_ERR_CAPACITY when the rows do not fit the allocation (myslam_lcddb_reserve ahead of the run). */
+int myslam_lcddb_append_batch_async(myslam_lcddb* h, const uint64_t* ids /*host*/, const float* d_descr, int n, void* hip_stream);
 int myslam_lcddb_query(myslam_lcddb* h, const float* descr1064, uint64_t cur_id, float thr_low,
                        uint64_t* best_id, float* max_score, int* cnt);
 /* nq queries at once: d_q nq x 1064 (device), cur_ids nq (HOST); outputs nq each (device).  nq <= 65536; no host synchronisation. */

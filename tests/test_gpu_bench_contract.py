@@ -33,6 +33,10 @@ def test_bench_json_contract(extra):
     assert len(rp) == 3 and rp[0] == d["ms_per_step"] and all(v > 0 for v in rp)
     assert len(d["clock_mhz"]) == 4 and all(300.0 < c < 3000.0 for c in d["clock_mhz"]), d["clock_mhz"]
     assert d["library"].startswith("myslam_hip ") and " build " in d["library"]
+    if "lcd" in d["config"]["workload"].lower():
+        # round 6: the database GROWS inside the step (AddToDatabase behind every step's DetectLoop, asynchronously on the side stream), checked after the pass
+        g = d["db_grow"]
+        assert g and g["ok"] is True and g["rows_after"] == g["rows_before"] + (d["steps"] + 2) * g["key_frames_appended_per_step"] and g["value"] > 0
     roof = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in roof, k

@@ -257,3 +257,43 @@ def test_growth_is_refused_while_a_step_is_being_recorded(api, synth):
     assert D.generation() == 1 and len(D) == n0 + 600
     with pytest.raises(api.MyslamError):
         g.launch(st.cuda_stream)
+
+
+def test_asynchronous_appends_inside_a_stream_of_scans(api, oracle, synth):
+    """myslam_lcddb_append_batch_async (round 6): AddToDatabase inside a pipelined step — the rows are copied on the caller's stream, the call does not wait, and scans issued
+    afterwards ON THAT STREAM see them (their row limits are computed from the ids, which are updated at once).  60 rounds of scan + append with no host synchronisation in between,
+    every scan checked against the oracle on the rows present at its call; beyond the allocation the call refuses (no growth without a synchronisation)."""
+    import torch
+    n0, step, rounds, nq = 300, 23, 60, 5
+    total = n0 + step * rounds
+    db = synth.lcd_database(total, seed=51); ids = np.arange(total, dtype=np.uint64) * 3 + 1
+    t_db = torch.from_numpy(db).cuda()
+    st = torch.cuda.Stream()
+    D = api.LoopDatabase(total, stream=st.cuda_stream)
+    D.append_batch(ids[:n0], t_db.data_ptr(), n0)
+    rng = np.random.default_rng(9)
+    outs = []
+    n = n0
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        qs = db[rng.integers(0, n, nq)] * 0.97 + 0.03 * synth.lcd_database(nq, seed=900 + r)
+        qs = (qs / np.linalg.norm(qs, axis=1, keepdims=True)).astype(np.float32); qs[0] = db[n - 1]                  # the row appended LAST round must be found
+        cur = np.where(rng.random(nq) < 0.6, ids[n - 1] + 25, ids[rng.integers(n // 2, n, nq)]).astype(np.uint64); cur[0] = ids[n - 1] + 25
+        with torch.cuda.stream(st):
+            d_q = torch.from_numpy(qs).cuda()
+            o = (torch.zeros(nq, dtype=torch.int64, device="cuda"), torch.zeros(nq, device="cuda"), torch.zeros(nq, dtype=torch.int32, device="cuda"))
+        D.query_batch(d_q.data_ptr(), cur, nq, *[t.data_ptr() for t in o])
+        outs.append((n, qs, cur, o, d_q))
+        D.append_batch_async(ids[n:n + step], t_db.data_ptr() + n * 1064 * 4, step, st.cuda_stream)
+        n += step
+        assert len(D) == n
+    torch.cuda.synchronize()
+    for k, (n_at, qs, cur, o, _) in enumerate(outs):
+        _check(oracle, db, ids, n_at, qs, cur, o[0].cpu().numpy(), o[1].cpu().numpy(), o[2].cpu().numpy(), tag=f"round {k}")
+        assert int(o[0][0]) == int(ids[n_at - 1])
+    room = D.capacity() - len(D)                                   # (the allocation is rounded up to whole blocks of rows)
+    over = np.arange(room + 1, dtype=np.uint64) + ids[-1] + 5
+    t_over = torch.zeros(room + 1, 1064, device="cuda")
+    with pytest.raises(api.MyslamError) as e:
+        D.append_batch_async(over, t_over.data_ptr(), room + 1, st.cuda_stream)
+    assert e.value.code == -3 and D.generation() == 0 and len(D) == total
