@@ -963,18 +963,32 @@ __device__ __forceinline__ NmsRow nms_row(uint32_t d0, uint32_t d1, uint32_t d2)
     r.cA = p0; r.cB = p2;
     return r;
 }
+// rows that only lend their neighbourhood maxima (the row above and the row below a 4-row block): h alone, one three-input maximum per pixel pair (round 6)
+struct NmsRowH { s16x2 hA, hB; };
+__device__ __forceinline__ NmsRowH nms_row_h(uint32_t d0, uint32_t d1, uint32_t d2) {
+    const s16x2 pm1 = pick16<3>(d0, d1), p0 = pick16<0>(d1, d1), p1 = pick16<1>(d1, d1), p2 = pick16<2>(d1, d1), p3 = pick16<3>(d1, d2);
+    NmsRowH r;
+    r.hA = pmax3(pm1, p0, p1); r.hB = pmax3(p1, p2, p3);
+    return r;
+}
 // the four z bytes of row M with everything that is not a STRICT 3x3 maximum set to zero: t = sat(c - neighbours) is non-zero exactly
 // at strict maxima and t << 8 >= 256 > c there, so min(c, t << 8) keeps c at maxima and gives 0 elsewhere.  zacc collects the largest
 // surviving z of the caller's rows (two 16-bit lanes).
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t nms_strict4(const NmsRow& U, const NmsRow& M, const NmsRow& D, u16x2& zacc) {
-    auto keep = [](s16x2 c, s16x2 nb) -> u16x2 {
+// (U / D: any record with hA, hB — a full NmsRow or the h-only form.  The three-input maxima are v_pk_maximum3_f16 on zero-extended bytes, as in the scoring network.)
+template <class RU, class RD>
+__device__ __forceinline__ uint32_t nms_strict4(const RU& U, const NmsRow& M, const RD& D, u16x2& zacc) {
+    auto keep = [](s16x2 c, s16x2 nb) -> s16x2 {
         u16x2 cu, nu; __builtin_memcpy(&cu, &c, 4); __builtin_memcpy(&nu, &nb, 4);
         const u16x2 t = __builtin_elementwise_sub_sat(cu, nu);
-        return __builtin_elementwise_min(cu, (u16x2)(t << (unsigned short)8));
+        const u16x2 k = __builtin_elementwise_min(cu, (u16x2)(t << (unsigned short)8));
+        s16x2 ks; __builtin_memcpy(&ks, &k, 4);
+        return ks;
     };
-    const u16x2 ka = keep(M.cA, pmax(pmax(U.hA, D.hA), M.lrA)), kb = keep(M.cB, pmax(pmax(U.hB, D.hB), M.lrB));
-    zacc = __builtin_elementwise_max(zacc, __builtin_elementwise_max(ka, kb));
+    const s16x2 ka = keep(M.cA, pmax3(U.hA, D.hA, M.lrA)), kb = keep(M.cB, pmax3(U.hB, D.hB, M.lrB));
+    s16x2 zs; __builtin_memcpy(&zs, &zacc, 4);
+    zs = pmax3(zs, ka, kb);                                             // surviving z are bytes: the f16 order is the integer order
+    __builtin_memcpy(&zacc, &zs, 4);
     uint32_t za, zb; __builtin_memcpy(&za, &ka, 4); __builtin_memcpy(&zb, &kb, 4);
     return __builtin_amdgcn_perm(zb, za, 0x06040200u);
 }
@@ -1434,11 +1448,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
                 if (sampled)                                               // block-uniform
                     nquad += __popcll(__ballot(m[1][1] != 0)) + __popcll(__ballot(m[2][1] != 0)) + __popcll(__ballot(m[3][1] != 0)) + __popcll(__ballot(m[4][1] != 0));
                 if ((m[1][1] | m[2][1] | m[3][1] | m[4][1]) != 0) {        // else none of the 16 pixels is a corner (rows past the cell hold zeros)
-                    NmsRow R[6];
+                    const NmsRowH Rt = nms_row_h(m[0][0], m[0][1], m[0][2]), Rb = nms_row_h(m[5][0], m[5][1], m[5][2]);
+                    NmsRow R[4];
 #pragma unroll
-                    for (int j = 0; j < 6; j++) R[j] = nms_row(m[j][0], m[j][1], m[j][2]);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) zm[j] = nms_strict4(R[j], R[j + 1], R[j + 2], zacc);
+                    for (int j = 0; j < 4; j++) R[j] = nms_row(m[j + 1][0], m[j + 1][1], m[j + 1][2]);
+                    zm[0] = nms_strict4(Rt, R[0], R[1], zacc);
+                    zm[1] = nms_strict4(R[0], R[1], R[2], zacc);
+                    zm[2] = nms_strict4(R[1], R[2], R[3], zacc);
+                    zm[3] = nms_strict4(R[2], R[3], Rb, zacc);
                 }
             }
             const unsigned long long b0 = __ballot(zm[0] != 0), b1 = __ballot(zm[1] != 0), b2 = __ballot(zm[2] != 0), b3 = __ballot(zm[3] != 0);
