@@ -122,6 +122,7 @@ struct myslam_orb {
     uint32_t* d_sel = nullptr;
     uint16_t* d_order = nullptr;       // processing order of the descriptor kernel (tile order of the selected keys, orb_kernels.hip k_sel_order)
     uint32_t* d_octTab = nullptr;      // per-level oct-tree path-code / cell-index tables (see make_plan)
+    uint32_t* d_stripTab = nullptr;    // per-strip head of the grid-FAST kernel (see make_plan, orb_plan.h)
     // FAST path selection (orb_kernels.hip FastCtl): two [MAXL][4] counter blocks, the launch accumulates into one and reads the other
     uint32_t* d_fastStat = nullptr; int fastFlip = 0;
     // options (myslam_orb_set_option)
@@ -273,6 +274,42 @@ int myslam_orb::make_plan(int r, int c) {
         int rc = dev_alloc(d_octTab, tab.size());
         if (rc) return rc;
         MYSLAM_HIP_CHECK(hipMemcpy(d_octTab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    {   // per-strip head of the grid-FAST kernel (orb_plan.h stripTab): the arithmetic k_fast_strip did per block, ORBextractor.cpp:838-852 for strips of 4 cells
+        std::vector<uint32_t> st((size_t)P.nstrips * 8, 0u);
+        for (int l = 0; l < nlevels; l++) {
+            const LevelGeom& g = P.lv[l];
+            const int spr = (g.nCols + 3) / 4;
+            for (int strip = 0; strip < g.nRows * spr; strip++) {
+                uint32_t* e = st.data() + (size_t)(g.stripBase + strip) * 8;
+                const int ci = strip / spr, cj0 = (strip - ci * spr) * 4;
+                const int iniY = MIN_BORDER + ci * g.hCell;
+                int ncell = 0, pairs = 0; uint32_t wcs = 0; int hr = 0;
+                if (iniY < g.maxBY - 3) {
+                    hr = std::min(iniY + g.hCell + 6, g.maxBY) - iniY;
+                    const int hc = hr - 6;
+                    if (hc > 0)
+                        for (int c = 0; c < 4; c++) {
+                            const int cj = cj0 + c, iniX = MIN_BORDER + cj * g.wCell;
+                            int wc = 0;
+                            if (cj < g.nCols && iniX < g.maxBX - 6) wc = std::max(0, std::min(iniX + g.wCell + 6, g.maxBX) - iniX - 6);
+                            if (wc > 0) ncell = c + 1;
+                            wcs |= (uint32_t)wc << (8 * c);
+                            pairs += ((wc + 1) >> 1) * hc;
+                        }
+                }
+                if (ncell == 0) wcs = 0;
+                e[0] = (uint32_t)l | ((uint32_t)ci << 8) | ((uint32_t)cj0 << 16) | ((uint32_t)ncell << 24);
+                e[1] = (uint32_t)iniY | ((uint32_t)hr << 16);
+                e[2] = (uint32_t)(MIN_BORDER + cj0 * g.wCell) | ((uint32_t)g.wCell << 16);
+                e[3] = wcs; e[4] = (uint32_t)g.pitch; e[5] = (uint32_t)pairs;
+                e[6] = (uint32_t)(g.imgOff & 0xffffffffu); e[7] = (uint32_t)(g.imgOff >> 32);
+            }
+        }
+        int rc = dev_alloc(d_stripTab, st.size());
+        if (rc) return rc;
+        MYSLAM_HIP_CHECK(hipMemcpy(d_stripTab, st.data(), st.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        P.stripTab = d_stripTab;
     }
     full = P;
     // Detect(): level 0 only, budget = nfeatures (ORBextractor.cpp:1064-1065)
@@ -571,7 +608,7 @@ int myslam_orb::ensure_stage(size_t imgBytes, size_t maskBytes, int cap) {
 }
 
 void myslam_orb::free_all() {
-    void* ptrs[] = {d_blurTab, d_fastStat, d_octTab, d_pyr, d_blur, d_mask, d_cand, d_sort, d_candCount, d_selCount, d_status, d_sel, d_order, d_stageImg, d_stageMask,
+    void* ptrs[] = {d_blurTab, d_fastStat, d_octTab, d_stripTab, d_pyr, d_blur, d_mask, d_cand, d_sort, d_candCount, d_selCount, d_status, d_sel, d_order, d_stageImg, d_stageMask,
                     d_stageOut, d_stageKps2, d_stageKeep};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); (void)hipEventDestroy(evFork); (void)hipEventDestroy(evJoin); aux = nullptr; }

@@ -1089,50 +1089,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
     const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     MYSLAM_BT(0);
     // Round 6: the per-block trace (profiles/r06_fast_block_phases_alone.json) showed a block spending 2.1 of its 9.9 us between its start and its first tile
-    // load: ~19 scalar loads out of the kernel arguments, each behind its own s_waitcnt (one per level of the level search, the level's fields and the
-    // call's scalars re-read wherever a branch first needed them).  Now the arguments the head needs leave as TWO groups of loads — the call's scalars with the
-    // levels' first strips, then the level's record — each pinned to scalar registers before the first branch that could delay it.
+    // load: ~19 dependent scalar loads out of the kernel arguments (one per level of a level search, the level's fields, the call's scalars wherever a branch first
+    // needed them) and ~250 scalar instructions deriving the strip's geometry — in each of the block's four waves.  Now the head is TWO dependent loads: the call's
+    // scalars, then the strip's 32-byte record of the plan's per-strip table (orb_engine.hip make_plan); the level's full record follows for the later phases.
     int a_nstrips = P.nstrips, a_batch = batch, a_ext0N = P.ext0N, a_ext0Pitch = P.ext0Pitch;
-    const uint8_t* a_ext0 = P.ext0; size_t a_ext0Stride = P.ext0Stride;
-    int a_sb[MAXL];
-#pragma unroll
-    for (int l = 0; l < MAXL; l++) a_sb[l] = P.stripBaseOf[l];
-    asm volatile("" : "+s"(a_nstrips), "+s"(a_batch), "+s"(a_ext0N), "+s"(a_ext0Pitch), "+s"(a_ext0Stride), "+s"(a_sb[1]), "+s"(a_sb[9]));      // (not the pointer: laundered, it would be loaded from with flat instructions)
+    size_t a_ext0Stride = P.ext0Stride, a_pyrStride = pyrStride;
+    // (pointers travel as integers through the pin and come back as GLOBAL / CONSTANT address-space pointers: a laundered generic pointer is loaded from with flat_ instructions)
+    uintptr_t a_ext0i = (uintptr_t)P.ext0, a_pyri = (uintptr_t)pyr, a_tabi = (uintptr_t)P.stripTab;
+    asm volatile("" : "+s"(a_nstrips), "+s"(a_batch), "+s"(a_ext0N), "+s"(a_ext0Pitch), "+s"(a_ext0Stride), "+s"(a_pyrStride), "+s"(a_ext0i), "+s"(a_pyri), "+s"(a_tabi));
+    typedef const uint8_t __attribute__((address_space(1))) * GlobalU8;
+    const GlobalU8 a_ext0 = (GlobalU8)a_ext0i, a_pyr = (GlobalU8)a_pyri;
     const int b = logical / a_nstrips, sidx = logical - b * a_nstrips;
     if (b >= a_batch) return;
     // what the next launch of this handle decides on is reported by a SAMPLE of the strips (a ratio of sums needs no more, and a few thousand
     // same-address atomics per launch cost nothing where 300 k of them serialise into milliseconds)
     const bool sampled = logical % max(1, nwg >> 12) == 0;
-    int level = 0;
-#pragma unroll
-    for (int l = 1; l < MAXL; l++) level += sidx >= a_sb[l] ? 1 : 0;               // ascending bases, INT_MAX behind the last level
-    const LevelGeom g = P.lv[level];
-    const int spr = (g.nCols + G - 1) / G;                             // strips per cell row
-    const int strip = sidx - g.stripBase;
-    const int ci = strip / spr, cj0 = (strip - ci * spr) * G;
-    const int iniY = MIN_BORDER + ci * g.hCell;
-    if (iniY >= g.maxBY - 3) return;                                   // :843
-    const int maxY = min(iniY + g.hCell + 6, g.maxBY);
-    const int hr = maxY - iniY, hc = hr - 6;
-    if (hc <= 0) return;
-    // cells of this strip: interior widths (0 = cell skipped, :852)
-    int ncell = 0, pairs_total = 0;
-#pragma unroll
-    for (int c = 0; c < G; c++) {
-        const int cj = cj0 + c;
-        const int iniX = MIN_BORDER + cj * g.wCell;
-        int wc = 0;
-        if (cj < g.nCols && iniX < g.maxBX - 6) wc = max(0, min(iniX + g.wCell + 6, g.maxBX) - iniX - 6);
-        if ((int)threadIdx.x == c) s_wc[c] = wc;                       // per-cell widths are looked up from LDS (a register array would be indexed dynamically)
-        if (wc > 0) ncell = c + 1;
-        pairs_total += ((wc + 1) >> 1) * hc;
-    }
-    if (ncell == 0) return;
+    // (read through the CONSTANT address space: a uniform address there is one s_load_dwordx8 on the scalar unit; as plain global memory the compiler issues
+    // per-lane vector loads with a wait of their own)
+    typedef const uint32_t __attribute__((address_space(4))) * ConstU32;
+    const ConstU32 tb = (ConstU32)(a_tabi + (uintptr_t)sidx * 32);
+    uint32_t t0 = tb[0], t1 = tb[1], t2 = tb[2], t3 = tb[3], t4 = tb[4], t5 = tb[5], t6 = tb[6], t7 = tb[7];
+    asm volatile("" : "+s"(t0), "+s"(t1), "+s"(t2), "+s"(t3), "+s"(t4), "+s"(t5), "+s"(t6), "+s"(t7));      // all eight before the first branch: ONE load, one wait
+    const uint4 e0 = make_uint4(t0, t1, t2, t3), e1 = make_uint4(t4, t5, t6, t7);
+    const int level = (int)(e0.x & 0xffu), ci = (int)((e0.x >> 8) & 0xffu), cj0 = (int)((e0.x >> 16) & 0xffu), ncell = (int)(e0.x >> 24);
+    if (ncell == 0) return;                                            // :843 / :852 (decided when the plan was made)
+    const int iniY = (int)(e0.y & 0xffffu), hr = (int)(e0.y >> 16), hc = hr - 6;
+    const int iniX0 = (int)(e0.z & 0xffffu), t_wCell = (int)(e0.z >> 16);
+    const int pairs_total = (int)e1.y;
+    if ((int)threadIdx.x < G) s_wc[threadIdx.x] = (int)((e0.w >> (8 * threadIdx.x)) & 0xffu);      // per-cell widths are looked up from LDS (a register array would be indexed dynamically)
     auto wc_of = [&](int c) __attribute__((always_inline)) -> int { return s_wc[c]; };
-    const int iniX0 = MIN_BORDER + cj0 * g.wCell;
     const bool ext = level == 0 && b < a_ext0N;                      // level 0 read in place (block-uniform)
-    const uint8_t* img = ext ? a_ext0 + (size_t)b * a_ext0Stride : pyr + (size_t)b * pyrStride + g.imgOff;
-    const int ipitch = ext ? a_ext0Pitch : g.pitch;
+    const uint8_t* img = (const uint8_t*)(ext ? a_ext0 + (size_t)b * a_ext0Stride : a_pyr + (size_t)b * a_pyrStride + ((size_t)e1.z | ((size_t)e1.w << 32)));
+    const int ipitch = ext ? a_ext0Pitch : (int)e1.x;
+    const LevelGeom g = P.lv[level];                                   // for the phases behind the tile loads (coordinates, list capacity, mask plane)
+    // everything of the head that does not need the tile — clearing the score maps, the strip's counters, the path decision (three scalar loads of the previous
+    // launch's statistics) — sits BETWEEN the issue of the tile's global loads and their stores to LDS (round 6: it used to follow the stores, i.e. the loads' latency)
+    bool dense = false;
+    auto prep = [&]() __attribute__((always_inline)) {
+        {   // zero the score maps (16-byte stores; the dword tail only exists when the array size is not a multiple of 16)
+            constexpr int NB = G * (SROWS * SP + 16), NV = NB / 16;
+            for (int i = threadIdx.x; i < NV; i += T) reinterpret_cast<uint4*>(&s_score[0][0])[i] = make_uint4(0, 0, 0, 0);
+            if (NB % 16 != 0 && threadIdx.x < (NB - 16 * NV) / 4) reinterpret_cast<uint32_t*>(&s_score[0][0])[4 * NV + threadIdx.x] = 0;
+        }
+        if (threadIdx.x < G) s_ini[threadIdx.x] = 0;
+        if (threadIdx.x == 0) { s_nlist = 0; s_npair = 0; s_ncorner = 0; }
+        // path of this launch: what the previous launch of the handle saw on this level decides (block-uniform)
+        {
+            // (scalar loads through the constant address space — the record was written by the handle's PREVIOUS launch: as a vector load its wait (vmcnt) also
+            // waited for the tile loads issued just before)
+            typedef const uint32_t __attribute__((address_space(4))) * ConstStat;
+            const ConstStat pv = (ConstStat)((uintptr_t)ctl.prev + (uintptr_t)level * 16);
+            const uint32_t pv0 = pv[0], pv1 = pv[1], pv2 = pv[2];
+            const float ps = (float)pv0, pt = (float)pv1;
+            const bool was_dense = pv2 != 0;
+            dense = ctl.force >= 0 ? ctl.force != 0 : (pt > 0.f && (was_dense ? ps > 0.165f * pt : ps > 0.41f * pt));
+        }
+    };
     MYSLAM_BT_MARK(3);                                                 // (trace builds: the block's decode is done, its tile loads start here)
     if constexpr (G * NQC <= 16) {
         // all loads of a thread are issued before its LDS stores.  Unaligned 16-byte loads (a cell starts at any column); a load may run up
@@ -1143,7 +1155,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
         constexpr int CPR = G * NQC, NIT = (TROWS + 15) / 16;
         const int col = threadIdx.x & 15, r0 = threadIdx.x >> 4;
         const int c = col / NQC, k = col - c * NQC;
-        const int x = iniX0 + c * g.wCell + 16 * k;
+        const int x = iniX0 + c * t_wCell + 16 * k;
         const bool lane_on = col < CPR && c < ncell, in_row = x < ipitch;
         const uint8_t* src = img + (size_t)(iniY + r0) * ipitch + x;
         uint4 v[NIT];
@@ -1155,6 +1167,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
                 v[u] = t;
             } else v[u] = make_uint4(0, 0, 0, 0);
         }
+        prep();
 #pragma unroll
         for (int u = 0; u < NIT; u++)
             if (lane_on && r0 + 16 * u < hr) *reinterpret_cast<uint4*>(&s_tile[(r0 + 16 * u) * TP + 16 * col]) = v[u];      // c * CP + 16 k = 16 col
@@ -1164,7 +1177,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
 #pragma unroll
         for (int u = 0; u < NIT; u++) {
             const int i = threadIdx.x + u * T, r = i / (G * NQC), rem = i - r * (G * NQC), c = rem / NQC, k = rem - c * NQC;
-            const int x = iniX0 + c * g.wCell + 16 * k;
+            const int x = iniX0 + c * t_wCell + 16 * k;
             if (r < hr && c < ncell && x < ipitch) {
                 const uint8_t* src = img + (size_t)(iniY + r) * ipitch + x;
                 uint4 t;
@@ -1172,25 +1185,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
                 v[u] = t;
             } else v[u] = make_uint4(0, 0, 0, 0);
         }
+        prep();
 #pragma unroll
         for (int u = 0; u < NIT; u++) {
             const int i = threadIdx.x + u * T, r = i / (G * NQC), rem = i - r * (G * NQC), c = rem / NQC, k = rem - c * NQC;
             if (r < hr && c < ncell) *reinterpret_cast<uint4*>(&s_tile[r * TP + c * CP + 16 * k]) = v[u];
         }
-    }
-    {   // zero the score maps (16-byte stores; the dword tail only exists when the array size is not a multiple of 16)
-        constexpr int NB = G * (SROWS * SP + 16), NV = NB / 16;
-        for (int i = threadIdx.x; i < NV; i += T) reinterpret_cast<uint4*>(&s_score[0][0])[i] = make_uint4(0, 0, 0, 0);
-        if (NB % 16 != 0 && threadIdx.x < (NB - 16 * NV) / 4) reinterpret_cast<uint32_t*>(&s_score[0][0])[4 * NV + threadIdx.x] = 0;
-    }
-    if (threadIdx.x < G) s_ini[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { s_nlist = 0; s_npair = 0; s_ncorner = 0; }
-    // path of this launch: what the previous launch of the handle saw on this level decides (block-uniform)
-    bool dense;
-    {
-        const float ps = (float)ctl.prev[level * 4], pt = (float)ctl.prev[level * 4 + 1];
-        const bool was_dense = ctl.prev[level * 4 + 2] != 0;
-        dense = ctl.force >= 0 ? ctl.force != 0 : (pt > 0.f && (was_dense ? ps > 0.165f * pt : ps > 0.41f * pt));
     }
     __syncthreads();
     MYSLAM_BT_MARK(0);

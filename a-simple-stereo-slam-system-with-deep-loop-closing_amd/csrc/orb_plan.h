@@ -52,6 +52,11 @@ struct OrbPlan {
     // the levels' first strips once more, side by side (round 6): the grid-FAST kernel finds a strip's level with ONE scalar load of this array instead of one
     // dependent load per level out of lv[] (8 cache lines); levels >= nlevels hold INT_MAX
     int stripBaseOf[MAXL];
+    // what the grid-FAST kernel needs before it can load a strip's tile, precomputed per strip (round 6: a block spent 1.9 of its 9.9 us deriving this on the scalar
+    // unit, each of its four waves for itself): 8 dwords per strip of the FULL plan in device memory (the level-0 strips come first, so Detect()'s one-level plan reads
+    // the same entries).  [0] level | ci << 8 | cj0 << 16 | ncell << 24 (ncell = 0: nothing to do, ORBextractor.cpp:843 / :852)   [1] iniY | hr << 16
+    // [2] iniX0 | wCell << 16   [3] the four cells' interior widths, a byte each   [4] plane pitch   [5] pixel pairs of the strip   [6..7] plane offset in the pyramid block
+    const uint32_t* stripTab;
     LevelGeom lv[MAXL];
 };
 
