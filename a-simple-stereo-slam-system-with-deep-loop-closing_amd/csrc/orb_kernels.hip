@@ -55,9 +55,15 @@ struct BlockTrace {
 };
 #define MYSLAM_BT(kid) BlockTrace bt_(kid)
 #define MYSLAM_BT_MARK(i) bt_.mark(i)
+#define MYSLAM_BT_PARAM , BlockTrace* btp_
+#define MYSLAM_BT_ARG , &bt_
+#define MYSLAM_BT_MARKP(i) btp_->mark(i)
 #else
 #define MYSLAM_BT(kid) ((void)0)
 #define MYSLAM_BT_MARK(i) ((void)0)
+#define MYSLAM_BT_PARAM
+#define MYSLAM_BT_ARG
+#define MYSLAM_BT_MARKP(i) ((void)0)
 #endif
 
 __constant__ int8_t c_pattern[1024] = {
@@ -2354,7 +2360,7 @@ __device__ __forceinline__ void describe_block(const OrbPlan& P, const uint8_t* 
                                                const int32_t* __restrict__ selCount, myslam_keypoint* __restrict__ kps,
                                                uint8_t* __restrict__ desc, int32_t* __restrict__ counts,
                                                int32_t* __restrict__ status, int cap, int nchunk, int batch, int detectOnly,
-                                               const uint16_t* __restrict__ order, const int logical_in) {
+                                               const uint16_t* __restrict__ order, const int logical_in MYSLAM_BT_PARAM) {
     const int logical = __builtin_amdgcn_readfirstlane(logical_in);      // block-uniform: everything derived from it stays on the scalar unit
     // per wave: phase A parks the 32 x 32 patches of four key-points here (4 x 64 pieces of 16 bytes), phase C the 37-row BRIEF window
     __shared__ __attribute__((aligned(16))) uint4 s_b[4][256];
@@ -2429,6 +2435,7 @@ __device__ __forceinline__ void describe_block(const OrbPlan& P, const uint8_t* 
     }
     if (detectOnly) return;                        // block-uniform
     __syncthreads();
+    MYSLAM_BT_MARKP(0);
     // ---- A ----  intensity-centroid moments on the int8 matrix cores:
     //   [key-points x 64 k] x [64 k x {u weights, v weights}],  k = two patch rows of 32 pixels, v_mfma_i32_16x16x64_i8
     // A operand = the patch as it lies in memory (p - 128 as int8: the weights sum to zero over the symmetric mask, so the offset
@@ -2482,6 +2489,7 @@ __device__ __forceinline__ void describe_block(const OrbPlan& P, const uint8_t* 
         }
     }
     __syncthreads();
+    MYSLAM_BT_MARKP(1);
     // ---- B ----
     if (t < KD_KPB && s_lv[t] >= 0) {
         const int level = s_lv[t];
@@ -2499,6 +2507,7 @@ __device__ __forceinline__ void describe_block(const OrbPlan& P, const uint8_t* 
         kps[(size_t)b * cap + s_out[t]] = kp;
     }
     __syncthreads();
+    MYSLAM_BT_MARKP(2);
     // ---- C ----
     float pat[16];                                                    // this lane's 4 test pairs (x0 y0 x1 y1), ORBextractor.cpp:101-359
 #pragma unroll
@@ -2586,7 +2595,7 @@ __global__ __launch_bounds__(256) void k_describe2(OrbPlan P, const uint8_t* __r
 #pragma nounroll
     for (int k = j; k < n; k += per) {
         MYSLAM_BT(4);
-        describe_block(P, pyr, blur, pyrStride, selOut, selCount, kps, desc, counts, status, cap, nchunk, batch, detectOnly, order, lo + k);
+        describe_block(P, pyr, blur, pyrStride, selOut, selCount, kps, desc, counts, status, cap, nchunk, batch, detectOnly, order, lo + k MYSLAM_BT_ARG);
         __syncthreads();                               // the next item reuses the block's LDS
     }
 }

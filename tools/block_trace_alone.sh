@@ -6,7 +6,7 @@ cp $P/libmyslam_hip.so /tmp/orig_lib.so; cp tools/build/ab/libbt.so $P/libmyslam
 timeout 600 python bench.py --no-cpu-baseline --no-extra-passes --parity-frames 0 --steps 10 --workload orb_match --streams 1 --block-trace gpurun_out/bt_alone_$TAG.npy > gpurun_out/bt_alone_bench_$TAG.json 2> gpurun_out/bt_alone_bench_$TAG.err
 echo "bench rc=$?"; tail -1 gpurun_out/bt_alone_bench_$TAG.err
 cp /tmp/orig_lib.so $P/libmyslam_hip.so
-python - <<PY
+python tools/block_trace_phases.py gpurun_out/bt_alone_$TAG.npy; python - <<PY
 import numpy as np, json
 r = np.load("gpurun_out/bt_alone_$TAG.npy")
 w = r[:, 1]; kid = ((w >> np.uint64(24)) & np.uint64(0xf)).astype(int); dt = (w & np.uint64(0xffffff)).astype(float) / 100.0
