@@ -1038,8 +1038,35 @@ struct FastCtl { const uint32_t* prev; uint32_t* cur; int force; };
 //                    separable form; every 4-pixel row with a strict maximum leaves one list record, expanded by the append phase.
 // Blocks are handed out XCD-aware: consecutive strips (which share halo rows and columns) go to the same XCD's L2.
 // CW / CH = the widest / tallest grid cell of the plan (columns cost LDS in 16-byte steps, rows one by one)
+#ifndef MYSLAM_FAST_LDS_BLOCK                                  // A/B builds (tools/build_variants.sh): another block footprint, e.g. 24300 = just over 160 KB / 7
+#define MYSLAM_FAST_LDS_BLOCK (163840 / 6 - 128)
+#endif
+#ifndef MYSLAM_FAST_BLOCKS_PER_CU                              // A/B builds that set another MYSLAM_FAST_LDS_BLOCK say how many blocks it is meant to admit
+#define MYSLAM_FAST_BLOCKS_PER_CU 6
+#endif
+// LDS a block of k_fast_strip<CW, G, CH> declares (an upper estimate: the arrays below plus their alignment) and the PAD that brings the block to
+// MYSLAM_FAST_LDS_BLOCK.  The pad is DYNAMIC LDS, passed by the launcher (round 6): as a static array it made the compiler conclude "six waves per SIMD at
+// most" and — to honour that bound by registers as well — raise the kernel's register allocation from its 68 to 73, i.e. from 72 to 80 registers per lane
+// in the hardware's granules of 8.  Alone that costs nothing (LDS admits six blocks either way); under the pipeline the blocks of the other streams hold
+// part of every CU's register file and the 8 registers decide how many FAST blocks fit beside them (beside two descriptor blocks: 5 instead of 4).
+template <int CW, int G, int CH>
+struct FastLds {
+    static constexpr int CP = (CW + 6 + 15) & ~15, TP = G * CP, TROWS = CH + 6 + 1, SP = (CW + 4 + 8 + 3) & ~3, SROWS = CH + 2 + 4;
+    static constexpr int NPAIR = G * CH * ((CW + 1) / 2);
+    static constexpr int EST = TROWS * TP + 16 + G * (SROWS * SP + 16) + 2 * NPAIR + 64;
+    static constexpr int PAD = (CW <= 32 && EST < 163840 / 7) ? MYSLAM_FAST_LDS_BLOCK - EST : 0;
+    static_assert(CW > 32 || (MYSLAM_FAST_BLOCKS_PER_CU * (EST + PAD) <= 163840 && (MYSLAM_FAST_BLOCKS_PER_CU + 1) * (EST + PAD) > 163840), "exactly six blocks per CU");
+};
+#ifndef MYSLAM_FAST_WAVES_PER_EU
+#define MYSLAM_FAST_WAVES_PER_EU 6
+#endif
+#ifdef MYSLAM_FAST_NUM_VGPR
+#define MYSLAM_FAST_VGPR_ATTR __attribute__((amdgpu_num_vgpr(MYSLAM_FAST_NUM_VGPR)))
+#else
+#define MYSLAM_FAST_VGPR_ATTR
+#endif
 template <int CW, int G, int CH = CW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 6 : 3))) void k_fast_strip(OrbPlan P, const uint8_t* __restrict__ pyr, size_t pyrStride,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? MYSLAM_FAST_WAVES_PER_EU : 3))) MYSLAM_FAST_VGPR_ATTR void k_fast_strip(OrbPlan P, const uint8_t* __restrict__ pyr, size_t pyrStride,
                                                     const uint8_t* __restrict__ maskPyr,
                                                     uint32_t* __restrict__ cand, int32_t* __restrict__ candCount, FastCtl ctl, int batch) {
     constexpr int T = 256;
@@ -1074,16 +1101,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
     // kernel runs as a limited grid and the oct-tree kernel no longer ends on its long blocks, the kernels of the other streams find their
     // CUs where FAST blocks retire; a block that squeezes in beside six FAST blocks only slows the launch the whole step waits for
     // (block size 27.2 / 26.0 / 25.0 / 24.4 / 23.7 KB: 75.0 / 74.3 / 74.5 / 73.9 / 74.3 k frames/s, two runs each on one box).
-    constexpr int LDS_EST = TROWS * TP + 16 + G * (SROWS * SP + 16) + 2 * NPAIR + 64;
-#ifndef MYSLAM_FAST_LDS_BLOCK                                  // A/B builds (tools/build_variants.sh): another block footprint, e.g. 24300 = just over 160 KB / 7
-#define MYSLAM_FAST_LDS_BLOCK (163840 / 6 - 128)
-#endif
-    constexpr int LDS_PAD = (CW <= 32 && LDS_EST < 163840 / 7) ? MYSLAM_FAST_LDS_BLOCK - LDS_EST : 4;
-#ifndef MYSLAM_FAST_BLOCKS_PER_CU                              // A/B builds that set another MYSLAM_FAST_LDS_BLOCK say how many blocks it is meant to admit
-#define MYSLAM_FAST_BLOCKS_PER_CU 6
-#endif
-    static_assert(CW > 32 || (MYSLAM_FAST_BLOCKS_PER_CU * (LDS_EST + LDS_PAD) <= 163840 && (MYSLAM_FAST_BLOCKS_PER_CU + 1) * (LDS_EST + LDS_PAD) > 163840), "exactly six blocks per CU");
-    __shared__ volatile uint8_t s_padx[LDS_PAD]; s_padx[threadIdx.x & 1] = 0;
+    static_assert(FastLds<CW, G, CH>::CP == CP && FastLds<CW, G, CH>::TROWS == TROWS && FastLds<CW, G, CH>::SP == SP && FastLds<CW, G, CH>::SROWS == SROWS && FastLds<CW, G, CH>::NPAIR == NPAIR,
+                  "FastLds restates this kernel's LDS arrays");            // (the pad itself: dynamic LDS of FastLds<>::PAD bytes, see there)
 
     // XCD-aware block order (bijective remap of the 1-D grid): the dispatcher places block i on XCD i % 8 and every XCD has a private
     // L2; logical ids (image-major, strips row by row) are handed out so that each XCD walks a contiguous range of strips, whose
@@ -2867,7 +2886,8 @@ void launch_fast(const OrbPlan& P, const uint8_t* pyr, size_t pyrStride, const u
     for (int l = 0; l < P.nlevels; l++) { cw = max(cw, P.lv[l].wCell); ch = max(ch, P.lv[l].hCell); }
     const FastCtl ctl{statPrev, statCur, forceMode};
     const dim3 grid((unsigned)P.nstrips * (unsigned)batch);
-    if (cw <= 32 && ch <= 40) hipLaunchKernelGGL((k_fast_strip<32, 4, 40>), grid, dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount, ctl, batch);
+    constexpr int pad = FastLds<32, 4, 40>::PAD;                          // dynamic LDS: see FastLds
+    if (cw <= 32 && ch <= 40) hipLaunchKernelGGL((k_fast_strip<32, 4, 40>), grid, dim3(256), pad, s, P, pyr, pyrStride, maskPyr, cand, candCount, ctl, batch);
     else if (max(cw, ch) <= 40) hipLaunchKernelGGL((k_fast_strip<40, 4>), grid, dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount, ctl, batch);
     else hipLaunchKernelGGL((k_fast_strip<MAX_CELL, 4>), grid, dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount, ctl, batch);
 }
