@@ -85,6 +85,12 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)
+    # The live-stream operating points are measured by child processes (their own GPU_MAX_HW_QUEUES) FIRST, before this process creates its GPU context: a
+    # child that ran beside the parent's idle context — its hardware queues stay mapped — measured 10.1 k frames/s at 1 pair x 16 lanes where the same command
+    # alone on the chip measures 12.3 k (tools/ab_stream_mode.sh).
+    stream_mode = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.stream_mode and not args.no_extra_passes and args.workload in ("full", "orb_match_lcd") and not args.stream_mode_late:
+        stream_mode = stream_mode_sweep(args)
     import torch
     import torch.distributed as dist
 
@@ -398,7 +404,11 @@ def main():
             dt = max(rank_dts)
         return dt
 
-    for _ in range(args.warmup):
+    # Two untimed steps for the run's own checks (capacity overflow, key-points per image).  The W warm-up steps of the contract run further down, STRAIGHT before
+    # the timed region (build v68): up to v67 they ran here, and the checks' host synchronisations, the lanes' set-up and the clock probe (a one-wave kernel on an
+    # idle chip) lay between them and the region — after that idle gap the chip took ~0.1 s to return to its loaded state, 2 - 3 % of a 20-step region
+    # (tools/ab_warmup_gap.sh: first region 6.40 / 6.36 / 6.54 ms per step against 6.22 / 6.18 / 6.38 for the identical regions that followed it).
+    for _ in range(args.warmup if args.gap_before_timed else 2):
         step()
     barrier()
     assert all(int(t.abs().sum()) == 0 for t in d_stat_b), "ORB capacity overflow"
@@ -470,7 +480,10 @@ def main():
 
     # ---- pass 1: the timed region (no per-kernel events) ----
     api.prof_enable(False)
-    clock_mhz = [api.shader_clock_mhz(stream)]          # the shader clock, measured on the device: before the timed region, between the repeats, after them
+    clock_mhz = [api.shader_clock_mhz(stream)]          # the shader clock, measured on the device: before the warm-up and the timed region, between the repeats, after them
+    if not args.gap_before_timed:
+        for _ in range(args.warmup):                     # the contract's W untimed warm-up steps, of the timed region's own kind; timed() opens with barrier + synchronize
+            step()
     dt = timed(args.steps)
     host_launch_ms = host_ms[0]
     per_rank_ms = [v / args.steps * 1e3 for v in rank_dts] if world > 1 else None            # of THIS region (the repeats below overwrite rank_dts)
@@ -865,10 +878,9 @@ def main():
                            "myslam_lcddb_append_batch_async on the side stream (no host wait) and the following steps scan them; rows reserved up front"}
         cur_ids[:] = keep_cur; grow[2] = []
         assert db_grow["ok"], db_grow
-    stream_mode = None
-    if rank == 0 and world == 1 and args.stream_mode and not args.no_extra_passes and args.workload in ("full", "orb_match_lcd"):
+    if rank == 0 and world == 1 and args.stream_mode and not args.no_extra_passes and args.workload in ("full", "orb_match_lcd") and args.stream_mode_late:
         barrier()
-        stream_mode = stream_mode_sweep(args)
+        stream_mode = stream_mode_sweep(args)       # (A/B only: the children run beside this process's idle GPU context)
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = world * P * args.steps / dt

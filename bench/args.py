@@ -77,6 +77,8 @@ def parse():
                     help="live-stream operating points, 'PAIRSxLANES,...' ('' = skip): after the other passes each point is run as a child process "
                          "(bench.py --pairs P --lanes L --graph 1: recorded steps on L lanes scanning ONE loop database through L query contexts; its own "
                          "GPU_MAX_HW_QUEUES) and reported as `stream_mode` — the reference's call pattern is one frame per call (src/frontend.cpp:41-77)")
+    ap.add_argument("--stream-mode-late", action="store_true", help="A/B: run the --stream-mode children after the other passes, beside this process's idle GPU context (the order up to build v67)")
+    ap.add_argument("--gap-before-timed", action="store_true", help="A/B: the order up to build v67 (warm-up steps, then the run's checks / lane set-up / clock probe, then the timed region)")
     ap.add_argument("--frame-latency", action="store_true", help="(child of --stream-mode) also time every step on its lane with an event pair: `frame_latency_ms`")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="N > 1 on ONE GPU, one process, no collective: per step this rank scans N x pairs queries (its own + (N - 1) x pairs resident ones) against a "

@@ -13,7 +13,7 @@ def stream_mode_sweep(args):
     pts = []
     for spec in args.stream_mode.split(","):
         pp, ll = [int(v) for v in spec.lower().split("x")]
-        cmd = [sys.executable, BENCH_PY, "--pairs", str(pp), "--lanes", str(ll), "--graph", "1", "--steps", str(max(400, 1600 // pp)), "--warmup", "2",
+        cmd = [sys.executable, BENCH_PY, "--pairs", str(pp), "--lanes", str(ll), "--graph", "1", "--steps", str(int(os.environ.get("MYSLAM_SM_STEPS", "0")) or max(400, 1600 // pp)), "--warmup", "2",
                "--workload", args.workload, "--no-extra-passes", "--no-cpu-baseline", "--parity-frames", str(min(2, pp)), "--frame-latency", "--stream-mode", "",
                "--scene-rects", str(args.scene_rects)]
         r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, GPU_MAX_HW_QUEUES="24"), timeout=600)
