@@ -374,12 +374,16 @@ def main():
     rank_dts = []           # multi-rank runs: every rank's wall time of the last timed() call ...
     rank_own = []           # ... and the time at which its own device had finished, before the closing barrier
 
-    def timed(n, fn=None):
-        """n steps bracketed by barrier + synchronize on both sides; the slowest rank's wall time.  host_ms[0] = CPU time the launches of
+    def timed(n, fn=None, lead=3):
+        """n steps bracketed by barrier + synchronize on both sides; the slowest rank's wall time.  `lead` untimed steps of the same kind run straight before the
+        opening barrier (the secondary passes: their set-up leaves the chip idle, and after an idle gap the first ~0.1 s run 2 - 3 % slow —
+        profiles/r06_ab_warmup_gap.json; the timed region itself follows the contract's W warm-up steps and passes lead=0).  host_ms[0] = CPU time the launches of
         one step took: the enqueue loop's time per step over its first 8 steps — after ~10 steps of 512 pairs the runtime's queues are
         full and the loop runs at the DEVICE's pace (back-pressure: 3 ms per step over 200 steps, 0.2 ms over the first 8), which is not
         a cost of launching"""
         fn = fn or step
+        for _ in range(lead):
+            fn()
         barrier()
         t0 = time.perf_counter()
         n_host = min(n, 8)
@@ -484,7 +488,7 @@ def main():
     if not args.gap_before_timed:
         for _ in range(args.warmup):                     # the contract's W untimed warm-up steps, of the timed region's own kind; timed() opens with barrier + synchronize
             step()
-    dt = timed(args.steps)
+    dt = timed(args.steps, lead=0)
     host_launch_ms = host_ms[0]
     per_rank_ms = [v / args.steps * 1e3 for v in rank_dts] if world > 1 else None            # of THIS region (the repeats below overwrite rank_dts)
     per_rank_own_ms = [v / args.steps * 1e3 for v in rank_own] if world > 1 else None
@@ -493,7 +497,7 @@ def main():
     repeats_ms = [dt / args.steps * 1e3]
     for _ in range(0 if args.no_repeats else 2):
         clock_mhz.append(api.shader_clock_mhz(stream))
-        repeats_ms.append(timed(args.steps) / args.steps * 1e3)
+        repeats_ms.append(timed(args.steps, lead=0) / args.steps * 1e3)
     clock_mhz.append(api.shader_clock_mhz(stream))
     if args.block_trace:                # profiling builds only: which kernel's blocks sit on which CU of XCD 0 at what time (tools/block_trace_report.py)
         import ctypes
@@ -857,7 +861,7 @@ def main():
         keep_cur = cur_ids.copy()
         grow[0], grow[1], grow[2] = True, int(ids[-1]) + 1, []
         step(); step(); barrier()
-        dt_g = timed(args.steps)
+        dt_g = timed(args.steps, lead=0)                   # (the two steps above are its lead; every step appends, and the row count below is checked)
         grow[0] = False
         n1 = len(D)
         dt_big = timed(args.steps)                          # the same steps against the database as it has become, nothing appended: what the larger scan alone costs
