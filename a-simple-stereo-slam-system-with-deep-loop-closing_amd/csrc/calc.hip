@@ -970,10 +970,10 @@ int myslam_lcd::ensure_tables(int r, int c) {
     if ((rc = lcd_alloc(d_xofs, xo.size())) || (rc = lcd_alloc(d_xa, xa.size())) || (rc = lcd_alloc(d_yofs, yo.size())) ||
         (rc = lcd_alloc(d_yb, yb.size())))
         return rc;
-    MYSLAM_HIP_CHECK(hipMemcpy(d_xofs, xo.data(), xo.size() * 4, hipMemcpyHostToDevice));
-    MYSLAM_HIP_CHECK(hipMemcpy(d_xa, xa.data(), xa.size() * 2, hipMemcpyHostToDevice));
-    MYSLAM_HIP_CHECK(hipMemcpy(d_yofs, yo.data(), yo.size() * 4, hipMemcpyHostToDevice));
-    MYSLAM_HIP_CHECK(hipMemcpy(d_yb, yb.data(), yb.size() * 2, hipMemcpyHostToDevice));
+    if ((rc = upload_table(d_xofs, xo.data(), xo.size() * 4))) return rc;
+    if ((rc = upload_table(d_xa, xa.data(), xa.size() * 2))) return rc;
+    if ((rc = upload_table(d_yofs, yo.data(), yo.size() * 4))) return rc;
+    if ((rc = upload_table(d_yb, yb.data(), yb.size() * 2))) return rc;
     rows = r; cols = c; batchCap = 0;
     return MYSLAM_OK;
 }

@@ -54,6 +54,13 @@ struct ScopedProf {
     ~ScopedProf() { prof_end(id, s); }
 };
 
+// ---- table uploads that stay off the legacy stream ----------------------------------------------------------------------------
+// Host table -> a device buffer no stream uses yet (plan tables, resize tables), complete on return.  A plain hipMemcpy runs on the legacy NULL stream, which
+// synchronises with every BLOCKING stream of the process: while another thread records a graph on such a stream it fails ("operation would make the legacy
+// stream depend on a capturing blocking stream") and poisons that thread's recording (tests/test_gpu_threads.py: one thread makes a plan while another
+// records its one-frame call).  This one copies on a process-wide NON-BLOCKING stream and waits for that stream only.
+int upload_table(void* dst, const void* src, size_t bytes);
+
 // ---- staging of the host-pointer ("drop-in", B = 1) entry points --------------------------------------------------------------
 // One grow-only device block, one pinned host block and one stream per calling THREAD, carved into 256-byte aligned pieces per
 // call: no hipMalloc / hipFree per call, one host->device and one device->host copy per call, and nothing to free on an error

@@ -24,6 +24,19 @@ struct myslam_step_graph {
     std::vector<StepDbDep> deps;         // loop-database scans inside the step: which matrix generation they name (common.h DbGraphLink)
 };
 
+namespace myslam_hip {
+int upload_table(void* dst, const void* src, size_t bytes) {
+    static std::mutex mu;
+    static hipStream_t up = nullptr;                    // lives as long as the process
+    if (bytes == 0) return MYSLAM_OK;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!up) MYSLAM_HIP_CHECK(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, up));
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(up));
+    return MYSLAM_OK;
+}
+}  // namespace myslam_hip
+
 namespace {
 thread_local std::vector<hipEvent_t> t_events;      // fork / join markers of the capture in flight on this thread
 thread_local bool t_capturing = false;

@@ -357,8 +357,10 @@ struct myslam_lcddb_query_ctx {
     // round 6: eager uploads go through a RING of pinned slots behind slot 0 (slot 0 is what recorded scans read at their replays): a call whose limits changed — a
     // database that grows every step — used to wait for the previous call's upload to leave the one pinned buffer, i.e. for the stream to drain up to it; now it waits for
     // the upload three calls back, which has long gone
-    static constexpr int NV_RING = 3;
-    hipEvent_t nvRingEv[NV_RING] = {nullptr, nullptr, nullptr}; bool nvRingPending[NV_RING] = {false, false, false}; int nvSlot = 0;
+    // (16 slots since the end of round 6: with three the host could enqueue at most three steps ahead of the side stream — the step's upload sits at the END of its
+    // DeepLCD chain — so any hiccup of the host thread stalled the device: the growing-database pass of a 20-step region read 6.3 or 9.5 ms per step, bimodal)
+    static constexpr int NV_RING = 16;
+    hipEvent_t nvRingEv[NV_RING] = {}; bool nvRingPending[NV_RING] = {}; int nvSlot = 0;
     const int32_t* limits = nullptr;                                // what the launches of the current call read: d_nvalid (eager) or h_nvalid itself (recorded)
     uint64_t* d_bestS = nullptr; float* d_maxS = nullptr; int32_t* d_cntS = nullptr; int shardCap = 0;     // scratch of the sharded query
     // scratch of the owned-shard query (round 6): row ranges [0, pLim) and [sBeg, sLim) + break flags per query (pinned staging + device copy), results of both parts
@@ -382,8 +384,8 @@ struct myslam_lcddb {
     std::mutex mu;                            // host state: ids, n, capacity, pointers, context list
     float* d_q1 = nullptr; uint64_t* d_best1 = nullptr; float* d_max1 = nullptr; int32_t* d_cnt1 = nullptr;
     // pinned staging of the ids of asynchronous appends (a copy out of pageable host memory makes the runtime wait for the stream): a ring of slots, each with its event
-    static constexpr int ID_RING = 4, ID_SLOT = 1024;
-    uint64_t* h_idring = nullptr; hipEvent_t idEv[ID_RING] = {nullptr, nullptr, nullptr, nullptr}; bool idPending[ID_RING] = {false, false, false, false}; int idSlot = 0;
+    static constexpr int ID_RING = 16, ID_SLOT = 1024;
+    uint64_t* h_idring = nullptr; hipEvent_t idEv[ID_RING] = {}; bool idPending[ID_RING] = {}; int idSlot = 0;
 
     // index of the first row the reference's scan does NOT look at: it breaks at the first id with
     // (cur - id) < 20 in unsigned arithmetic (loopclosing.cpp:133), i.e. id in [cur-19, cur] mod 2^64

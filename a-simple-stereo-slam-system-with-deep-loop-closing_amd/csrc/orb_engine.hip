@@ -273,7 +273,7 @@ int myslam_orb::make_plan(int r, int c) {
         }
         int rc = dev_alloc(d_octTab, tab.size());
         if (rc) return rc;
-        MYSLAM_HIP_CHECK(hipMemcpy(d_octTab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if ((rc = upload_table(d_octTab, tab.data(), tab.size() * sizeof(uint32_t)))) return rc;
     }
     {   // per-strip head of the grid-FAST kernel (orb_plan.h stripTab): the arithmetic k_fast_strip did per block, ORBextractor.cpp:838-852 for strips of 4 cells
         std::vector<uint32_t> st((size_t)P.nstrips * 8, 0u);
@@ -308,7 +308,7 @@ int myslam_orb::make_plan(int r, int c) {
         }
         int rc = dev_alloc(d_stripTab, st.size());
         if (rc) return rc;
-        MYSLAM_HIP_CHECK(hipMemcpy(d_stripTab, st.data(), st.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if ((rc = upload_table(d_stripTab, st.data(), st.size() * sizeof(uint32_t)))) return rc;
         P.stripTab = d_stripTab;
     }
     full = P;
@@ -440,7 +440,7 @@ int myslam_orb::ensure_blur_tables() {
     MYSLAM_HIP_CHECK(hipStreamSynchronize(stream));
     int rc = dev_alloc(d_blurTab, tab.size());
     if (rc) return rc;
-    MYSLAM_HIP_CHECK(hipMemcpy(d_blurTab, tab.data(), tab.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    if ((rc = upload_table(d_blurTab, tab.data(), tab.size() * sizeof(uint4)))) return rc;
     blurTabValid = true; gen++;
     return MYSLAM_OK;
 }

@@ -2337,6 +2337,9 @@ __device__ __forceinline__ int wave_sum_lane63_i32(int v) {
 }
 
 constexpr int KD_KPB = 64;                                       // keypoints per block
+#ifndef MYSLAM_KD_GLDS                                              // windows a wave of the descriptor kernel keeps in flight in phase C (direct-to-LDS loads); 0 = the register-staged form
+#define MYSLAM_KD_GLDS 2
+#endif
 
 // Processing order of the descriptor kernel: the selected keys of a level in Z-order of small pixel tiles (a counting sort over
 // <= 1024 tile bins per (image, level); 32 x 32 pixels at 1241 x 376).  The oct-tree's list order scatters consecutive key-points all over the level; in tile order
@@ -2382,7 +2385,13 @@ __device__ __forceinline__ void describe_block(const OrbPlan& P, const uint8_t* 
                                                const uint16_t* __restrict__ order, const int logical_in MYSLAM_BT_PARAM) {
     const int logical = __builtin_amdgcn_readfirstlane(logical_in);      // block-uniform: everything derived from it stays on the scalar unit
     // per wave: phase A parks the 32 x 32 patches of four key-points here (4 x 64 pieces of 16 bytes), phase C the 37-row BRIEF window
+#if MYSLAM_KD_GLDS
+    // phase C keeps KD_NBUF windows per wave in flight (direct-to-LDS loads, below): KD_NBUF x 148 pieces per wave, and no less than phase A's 256
+    constexpr int KD_WB = DB_N * MYSLAM_KD_GLDS > 256 ? DB_N * MYSLAM_KD_GLDS : 256;
+    __shared__ __attribute__((aligned(16))) uint4 s_b[4][KD_WB];
+#else
     __shared__ __attribute__((aligned(16))) uint4 s_b[4][256];
+#endif
     static_assert(DB_N <= 256, "the BRIEF window must fit the per-wave buffer");
     __shared__ int s_x[KD_KPB], s_y[KD_KPB], s_lv[KD_KPB], s_m10[KD_KPB], s_m01[KD_KPB], s_out[KD_KPB];
     __shared__ float s_ca[KD_KPB], s_sb[KD_KPB];
@@ -2533,6 +2542,86 @@ __device__ __forceinline__ void describe_block(const OrbPlan& P, const uint8_t* 
     for (int q = 0; q < 16; q++) pat[q] = (float)c_pattern[lane * 16 + q];
 #pragma unroll
     for (int q = 0; q < 16; q++) asm volatile("" : "+v"(pat[q]));      // kept as floats: the compiler otherwise re-converts the packed int8 pattern for every key-point
+#if MYSLAM_KD_GLDS
+    // Direct-to-LDS form (global_load_lds_dwordx4): a wave keeps the windows of its next MYSLAM_KD_GLDS - 1 key-points in flight while it tests the current one.  Under
+    // the pipeline this kernel runs two blocks per CU and a key-point costs its wave one memory latency (~1.5 us on the loaded chip: 25 of an item's 39 us); a
+    // register prefetch one window deep hid nothing of that (profiles/r06_ab_describe_prefetch.json) and cost 14 registers, i.e. FAST blocks.  The LDS-DMA load
+    // needs no registers for its data: lane i of a load writes LDS at (wave-uniform base) + 16 i, so the ROW-MAJOR window (row r at 64 r, as the test points
+    // address it) is had by letting lane i fetch piece (row i >> 2, 16-byte column i & 3) from the TILED plane — the global address is per lane, any pattern.
+    // Three loads per window as before: rows 0-15, 16-31, 32-36 (20 lanes).  Completion: vmcnt, waited for by hand (the compiler does not see the asm loads);
+    // loads retire in order among themselves, so `3 x (windows issued after this one)` outstanding operations prove this window landed whatever the stores do.
+    {
+        constexpr int NBUF = MYSLAM_KD_GLDS, NJ = KD_KPB / 4;
+        static_assert(NBUF >= 2 && NBUF <= 4, "windows in flight per wave");
+        const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)&s_b[0][0]) + (uint32_t)wave * (uint32_t)sizeof(s_b[0]);
+        auto level_of = [&](int j) -> int { return j < NJ ? __builtin_amdgcn_readfirstlane(s_lv[4 * j + wave]) : -1; };
+        auto issue = [&](int j, int level) __attribute__((always_inline)) {            // window of key-point 4 j + wave -> buffer j % NBUF (level >= 0, wave-uniform)
+            const int k = 4 * j + wave;
+            const LevelGeom& g = P.lv[level];
+            const int x = __builtin_amdgcn_readfirstlane(s_x[k]), y = __builtin_amdgcn_readfirstlane(s_y[k]);
+            const int xb0 = (x - DB_R) & ~15, y0 = y - DB_R, pitch8 = g.pitch * 8;
+            const uint8_t* base = blur + (size_t)b * pyrStride + g.imgOff + (size_t)(xb0 >> 4) * 128;
+            const int yy = y0 + (lane >> 2);                                           // this lane's row of the first load; the others are 16 and 32 rows = 2 and 4 tile rows below
+            const uint32_t voff = (uint32_t)__mul24(yy >> 3, pitch8) + (uint32_t)((yy & 7) << 4) + (uint32_t)((lane & 3) << 7);
+            const uint32_t dst = lds0 + (uint32_t)(j % NBUF) * (uint32_t)(DB_N * 16);
+#pragma unroll
+            for (int q = 0; q < DB_IT; q++) {
+                const uint8_t* src = base + (size_t)voff + (size_t)q * 2 * (size_t)pitch8;
+                const uint32_t d = dst + 1024u * (uint32_t)q;
+                uint32_t keep;
+                if (q < 2 || lane < DB_N - 128)
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(d) : "memory");
+            }
+        };
+        int lv_cur = level_of(0);
+        int lv_n[NBUF - 1];
+#pragma unroll
+        for (int u = 0; u < NBUF - 1; u++) { lv_n[u] = level_of(u + 1); }
+        if (lv_cur >= 0) issue(0, lv_cur);
+#pragma unroll
+        for (int u = 0; u + 1 < NBUF - 1; u++) if (lv_n[u] >= 0) issue(u + 1, lv_n[u]);
+        for (int j = 0; j < NJ; j++) {
+            // the window NBUF - 1 key-points ahead goes into the buffer key-point j - 1 has just been tested from
+            if (lv_n[NBUF - 2] >= 0) issue(j + NBUF - 1, lv_n[NBUF - 2]);
+            int newer = 0;
+#pragma unroll
+            for (int u = 0; u < NBUF - 1; u++) newer += lv_n[u] >= 0 ? 1 : 0;
+            const int level = lv_cur;
+            lv_cur = lv_n[0];
+#pragma unroll
+            for (int u = 0; u + 1 < NBUF - 1; u++) lv_n[u] = lv_n[u + 1];
+            lv_n[NBUF - 2] = level_of(j + NBUF);
+            if (level < 0) continue;
+            if (newer == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (newer == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (newer == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            const int k = 4 * j + wave;
+            const int x = __builtin_amdgcn_readfirstlane(s_x[k]);
+            const float ca = s_ca[k], sb = s_sb[k];
+            const int offB = (x - DB_R) & 15;
+            const uint8_t* center = reinterpret_cast<const uint8_t*>(s_b[wave]) + (j % NBUF) * (DB_N * 16) + DB_R * DB_P + offB + DB_R;
+            uint32_t nib = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float x0 = pat[4 * q], y0 = pat[4 * q + 1], x1 = pat[4 * q + 2], y1 = pat[4 * q + 3];
+                constexpr float RM = 12582912.f; constexpr uint32_t RK = 0x4B400000u;            // cvRound by the magic-number add, as in the register-staged form below
+                const uint32_t r0 = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(x0, sb), __fmul_rn(y0, ca)), RM));
+                const uint32_t c0 = __float_as_uint(__fadd_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sb)), RM));
+                const uint32_t r1 = __float_as_uint(__fadd_rn(__fadd_rn(__fmul_rn(x1, sb), __fmul_rn(y1, ca)), RM));
+                const uint32_t c1 = __float_as_uint(__fadd_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sb)), RM));
+                static_assert(DB_P == 64, "row pitch of the LDS window as a shift");
+                const int t0 = center[(int)((r0 << 6) + c0 - 65u * RK)], t1 = center[(int)((r1 << 6) + c1 - 65u * RK)];
+                nib |= (uint32_t)(t0 < t1) << q;
+            }
+            const uint32_t byte = nib | (__shfl_down(nib, 1, 64) << 4);
+            uint32_t w = byte | (__shfl_down(byte, 2, 64) << 8);
+            w |= (__shfl_down(byte, 4, 64) << 16) | (__shfl_down(byte, 6, 64) << 24);
+            if ((lane & 7) == 0) reinterpret_cast<uint32_t*>(desc + ((size_t)b * cap + s_out[k]) * 32)[lane >> 3] = w;
+        }
+    }
+    return;
+#endif
     for (int j = 0; j < KD_KPB / 4; j++) {
         const int k = 4 * j + wave;                                   // the four waves work on neighbouring key-points of the tile order: their windows overlap in L1
         const int level = __builtin_amdgcn_readfirstlane(s_lv[k]);

@@ -239,7 +239,7 @@ def main():
     solve_windows = [P if use_solve else 0]          # windows the side chain also SOLVES per step (pass 3 sets ceil(P / 6))
 
     skip = set(args.side_skip.split(",")) if args.side_skip else set()      # diagnostic: the marginal cost of the side chain's parts
-    grow = [False, 0, []]                            # pass "db_grow": [on, next key-frame id, the appended row blocks (kept for the check after the pass)]
+    grow = [False, 0, [], None]                            # pass "db_grow": [on, next key-frame id, the appended row blocks (kept for the check after the pass)]
 
     def side_chain(with_ba=True):
         if use_ba and "ba" not in skip and solve_windows[0] and solve_stream is not side_stream:
@@ -277,7 +277,10 @@ def main():
                 D.query_batch(d_descr.data_ptr(), cur_ids, NQ, d_best.data_ptr(), d_max.data_ptr(), d_dbcnt.data_ptr())
             if grow[0]:         # LoopClosing::AddToDatabase (src/loopclosing.cpp:651-659) after DetectLoop: the step's key-frames (1 frame in 6) join the database, on this stream, no host wait
                 nkf = (P + 5) // 6
-                d_kf = d_descr[::6][:nkf].contiguous()
+                # (rows of a pool allocated before the pass: a fresh tensor per step made torch's caching allocator call hipMalloc inside the timed region —
+                # a device-synchronising call of milliseconds, bimodal 6.5 / 9 ms per step in a 20-step region)
+                d_kf = grow[3][len(grow[2]) % grow[3].shape[0]]
+                d_kf.copy_(d_descr[::6][:nkf])
                 kf_ids = np.arange(grow[1], grow[1] + nkf, dtype=np.uint64)
                 D.append_batch_async(kf_ids, d_kf.data_ptr(), nkf, stream2)
                 grow[1] += nkf; grow[2].append(d_kf)
@@ -860,6 +863,7 @@ def main():
         D.reserve(n0 + (args.steps + 4) * nkf)             # growth moves the matrix (a synchronising operation): room for the whole pass up front
         keep_cur = cur_ids.copy()
         grow[0], grow[1], grow[2] = True, int(ids[-1]) + 1, []
+        grow[3] = torch.empty(args.steps + 4, nkf, 1064, device=dev)       # the key-frame rows of every step of the pass (kept for the check below)
         step(); step(); barrier()
         dt_g = timed(args.steps, lead=0)                   # (the two steps above are its lead; every step appends, and the row count below is checked)
         grow[0] = False
@@ -880,7 +884,7 @@ def main():
                    "ok": bool(n1 == n0 + (args.steps + 2) * nkf and found == nkf and smin > 0.9999 and copies >= args.steps + 2),
                    "note": "as the timed region, plus LoopClosing::AddToDatabase inside the step: every step appends its key-frames (1 frame in 6) behind its scan with "
                            "myslam_lcddb_append_batch_async on the side stream (no host wait) and the following steps scan them; rows reserved up front"}
-        cur_ids[:] = keep_cur; grow[2] = []
+        cur_ids[:] = keep_cur; grow[2] = []; grow[3] = None
         assert db_grow["ok"], db_grow
     if rank == 0 and world == 1 and args.stream_mode and not args.no_extra_passes and args.workload in ("full", "orb_match_lcd") and args.stream_mode_late:
         barrier()

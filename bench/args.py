@@ -68,7 +68,8 @@ def parse():
     ap.add_argument("--side-blocks-per-cu", type=int, default=-1,
                     help="myslam_orb_set_option(SIDE_BLOCKS_PER_CU): the descriptor kernel runs as a limited grid of this many blocks per CU, each walking "
                          "several work items, so that its long-lived blocks do not crowd the other handle's FAST blocks out of the CUs (0 = one block per "
-                         "work item, the library's default; -1 = 2 under the pipelined schedule, else 0)")
+                         "work item, the library's default; -1 = 0.  Up to build v68 the pipelined schedule ran 2: with the kernel's direct-to-LDS form — three times "
+                         "the windows in flight per block — the unlimited grid is the faster one, profiles/r06_ab_describe_glds.json)")
     ap.add_argument("--lcd-skip", type=int, default=0, help="diagnostic, timing only: myslam_lcd_set_option(SKIP_KERNELS) bit mask (1 input, 2 conv1, 4 conv2, 8 pool2, 16 conv3)")
     ap.add_argument("--side-skip", default="", help="diagnostic: comma list of side-chain parts to leave out (lcd, db, ba) — measures what each part costs the step")
     ap.add_argument("--blur-mfma", type=int, default=0, choices=[0, 1],
@@ -92,7 +93,7 @@ def parse():
     if args.pipeline < 0:
         args.pipeline = 1 if (args.streams == 2 and args.orb_split != 1) else 0
     if args.side_blocks_per_cu < 0:
-        args.side_blocks_per_cu = 2 if args.pipeline else 0
+        args.side_blocks_per_cu = 0
     if args.orb_split == 0:
         args.orb_split = 2 if (args.streams == 2 or args.pipeline) else 1
     if args.pipeline:
