@@ -1049,23 +1049,32 @@ struct FastCtl { const uint32_t* prev; uint32_t* cur; int force; };
 // most" and — to honour that bound by registers as well — raise the kernel's register allocation from its 68 to 73, i.e. from 72 to 80 registers per lane
 // in the hardware's granules of 8.  Alone that costs nothing (LDS admits six blocks either way); under the pipeline the blocks of the other streams hold
 // part of every CU's register file and the 8 registers decide how many FAST blocks fit beside them (beside two descriptor blocks: 5 instead of 4).
-template <int CW, int G, int CH>
+// NS > 1 (round 6, the multi-strip form): a second tile buffer and a second set of the strip's counters; such blocks are sized for MYSLAM_FAST_MS_BLOCKS_PER_CU per CU
+#ifndef MYSLAM_FAST_MS_BLOCKS_PER_CU
+#define MYSLAM_FAST_MS_BLOCKS_PER_CU 5
+#endif
+template <int CW, int G, int CH, int NS = 1>
 struct FastLds {
     static constexpr int CP = (CW + 6 + 15) & ~15, TP = G * CP, TROWS = CH + 6 + 1, SP = (CW + 4 + 8 + 3) & ~3, SROWS = CH + 2 + 4;
     static constexpr int NPAIR = G * CH * ((CW + 1) / 2);
-    static constexpr int EST = TROWS * TP + 16 + G * (SROWS * SP + 16) + 2 * NPAIR + 64;
-    static constexpr int PAD = (CW <= 32 && EST < 163840 / 7) ? MYSLAM_FAST_LDS_BLOCK - EST : 0;
-    static_assert(CW > 32 || (MYSLAM_FAST_BLOCKS_PER_CU * (EST + PAD) <= 163840 && (MYSLAM_FAST_BLOCKS_PER_CU + 1) * (EST + PAD) > 163840), "exactly six blocks per CU");
+    static constexpr int EST = (NS > 1 ? 2 : 1) * (TROWS * TP + 16) + G * (SROWS * SP + 16) + 2 * NPAIR + (NS > 1 ? 128 : 64);
+    static constexpr int BLOCKS = NS > 1 ? MYSLAM_FAST_MS_BLOCKS_PER_CU : MYSLAM_FAST_BLOCKS_PER_CU;
+    static constexpr int BLOCK = NS > 1 ? 163840 / MYSLAM_FAST_MS_BLOCKS_PER_CU - 128 : MYSLAM_FAST_LDS_BLOCK;
+    static constexpr int PAD = (CW <= 32 && EST < (NS > 1 ? BLOCK : 163840 / 7)) ? BLOCK - EST : 0;
+    static_assert(CW > 32 || (BLOCKS * (EST + PAD) <= 163840 && (BLOCKS + 1) * (EST + PAD) > 163840), "exactly BLOCKS blocks per CU");
 };
 #ifndef MYSLAM_FAST_WAVES_PER_EU
 #define MYSLAM_FAST_WAVES_PER_EU 6
+#endif
+#ifndef MYSLAM_FAST_NS                                          // strips per block of the grid-FAST kernel (1 = one block per strip; > 1 = the multi-strip form for large launches)
+#define MYSLAM_FAST_NS 1
 #endif
 #ifdef MYSLAM_FAST_NUM_VGPR
 #define MYSLAM_FAST_VGPR_ATTR __attribute__((amdgpu_num_vgpr(MYSLAM_FAST_NUM_VGPR)))
 #else
 #define MYSLAM_FAST_VGPR_ATTR
 #endif
-template <int CW, int G, int CH = CW>
+template <int CW, int G, int CH = CW, int NS = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? MYSLAM_FAST_WAVES_PER_EU : 3))) MYSLAM_FAST_VGPR_ATTR void k_fast_strip(OrbPlan P, const uint8_t* __restrict__ pyr, size_t pyrStride,
                                                     const uint8_t* __restrict__ maskPyr,
                                                     uint32_t* __restrict__ cand, int32_t* __restrict__ candCount, FastCtl ctl, int batch) {
@@ -1079,20 +1088,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
     constexpr int NLIST = G * ((CW + 1) / 2) * ((CH + 1) / 2);         // a cell of a x b pixels holds at most ceil(a/2) ceil(b/2) strict maxima
     constexpr int NPAIR = G * CH * ((CW + 1) / 2);                     // pixel pairs of a strip
     static_assert(CW <= 63 && CH <= 63 && G <= 4, "pair list entry = cell << 11 | row << 5 | pair index");
-    __shared__ __attribute__((aligned(16))) uint8_t s_tile[TROWS * TP + 16];
+    // NS > 1 (the multi-strip form, see the loop below): two tile buffers — the next strip's tile lands in one by LDS-DMA while the current strip is worked on in the
+    // other — and two sets of the strip's small state (a wave that has nothing to append runs ahead into the next strip's set-up)
+    constexpr int NB2 = NS > 1 ? 2 : 1;
+    static_assert(NS == 1 || (CW <= 32 && G == 4 && MYSLAM_FAST_PHASE == 0), "the multi-strip form exists for the usual plans' instance only");
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile0[TROWS * TP + 16];
+    // (the second tile buffer of the multi-strip form is DYNAMIC LDS, as the pad is: the compiler sizes the kernel's register allocation by the occupancy its STATIC
+    // LDS admits — with 31 KB declared it concludes "five waves per SIMD at most" and spends 83 registers where the block's co-runners leave room for 72)
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     __shared__ __attribute__((aligned(16))) uint8_t s_score[G][SROWS * SP + 16];
     __shared__ uint16_t s_pairs[NPAIR];
     // strict maxima of the strip (py<<20 | px<<8 | z) and their cells: the list lives in the tile's LDS, which is dead once the
     // scores are computed (5 bytes per entry, NLIST entries always fit: checked below)
     static_assert(NLIST * 5 <= TROWS * TP, "maxima list must fit into the staged tile");
-    uint32_t* const s_list = reinterpret_cast<uint32_t*>(s_tile);
-    uint8_t* const s_listc = s_tile + 4 * NLIST;
     // dense path: one record per 4-pixel ROW that holds a strict maximum = its NMS-filtered z dword (s_recz, in the dead tile) + the
     // row's (cell << 10 | row << 4 | group) (s_pairs, which only the two-phase path uses otherwise).  A cell of a x b pixels has at
     // most ceil(a/2) ceil(b/2) strict maxima, hence at most NLIST such rows.
     static_assert(NLIST * 4 <= TROWS * TP && NLIST <= NPAIR, "row records must fit");
-    uint32_t* const s_recz = reinterpret_cast<uint32_t*>(s_tile);
-    __shared__ int s_ini[G], s_wc[G], s_nlist, s_npair, s_ncorner;
+    __shared__ int s_ini2[NB2][G], s_wc2[NB2][G], s_cnt2[NB2][4];      // [.][0] = records / maxima listed, [1] = pairs listed, [2] = corner rows (the path statistic)
     // LDS footprint on purpose (1241 x 376: cells of at most 32 x 40 pixels): a block of this instance needs 22.4 KB, seven would fit a CU — and
     // with seven waves per SIMD FAST holds 504 of the 512 registers per lane (measured: FAST alone 3 % faster, the pipelined step 1 % slower).
     // Six blocks it is; the question is what the remaining LDS of a CU is open to.  History: 25.1 KB per block (9 KB free: only blur / resize
@@ -1101,7 +1114,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
     // kernel runs as a limited grid and the oct-tree kernel no longer ends on its long blocks, the kernels of the other streams find their
     // CUs where FAST blocks retire; a block that squeezes in beside six FAST blocks only slows the launch the whole step waits for
     // (block size 27.2 / 26.0 / 25.0 / 24.4 / 23.7 KB: 75.0 / 74.3 / 74.5 / 73.9 / 74.3 k frames/s, two runs each on one box).
-    static_assert(FastLds<CW, G, CH>::CP == CP && FastLds<CW, G, CH>::TROWS == TROWS && FastLds<CW, G, CH>::SP == SP && FastLds<CW, G, CH>::SROWS == SROWS && FastLds<CW, G, CH>::NPAIR == NPAIR,
+    static_assert(FastLds<CW, G, CH, NS>::CP == CP && FastLds<CW, G, CH, NS>::TROWS == TROWS && FastLds<CW, G, CH, NS>::SP == SP && FastLds<CW, G, CH, NS>::SROWS == SROWS && FastLds<CW, G, CH, NS>::NPAIR == NPAIR,
                   "FastLds restates this kernel's LDS arrays");            // (the pad itself: dynamic LDS of FastLds<>::PAD bytes, see there)
 
     // XCD-aware block order (bijective remap of the 1-D grid): the dispatcher places block i on XCD i % 8 and every XCD has a private
@@ -1124,24 +1137,78 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
     asm volatile("" : "+s"(a_nstrips), "+s"(a_batch), "+s"(a_ext0N), "+s"(a_ext0Pitch), "+s"(a_ext0Stride), "+s"(a_pyrStride), "+s"(a_ext0i), "+s"(a_pyri), "+s"(a_tabi));
     typedef const uint8_t __attribute__((address_space(1))) * GlobalU8;
     const GlobalU8 a_ext0 = (GlobalU8)a_ext0i, a_pyr = (GlobalU8)a_pyri;
-    const int b = logical / a_nstrips, sidx = logical - b * a_nstrips;
-    if (b >= a_batch) return;
+    // ---- the strips of this block: one (NS == 1), or NS consecutive ones (the multi-strip form, round 6) ----
+    // Multi-strip form: a FAST block lives ~8.3 us of which ~2.2 are the latency of its tile's global loads, and under the pipeline FAST holds only 2 - 3 blocks per CU
+    // (the co-runners' registers), too few to hide it.  Here a block walks NS consecutive strips and the NEXT strip's tile lands in a second LDS buffer by LDS-DMA
+    // (global_load_lds_dwordx4: no registers for the data) while the current strip is scored: only the first strip of a block waits for memory.
+    const int total_strips = a_nstrips * a_batch;
+    const int gs_first = logical * NS, gs_end = min(gs_first + NS, total_strips);
+    if (gs_first >= total_strips) return;
+    typedef const uint32_t __attribute__((address_space(4))) * ConstU32;
+    // strip gs -> its image and the 8 dwords of its record in the plan's per-strip table (scalar: ONE s_load_dwordx8 through the constant address space)
+    struct StripRec { uint32_t t[8]; int b; };
+    auto load_rec = [&](int gs) __attribute__((always_inline)) -> StripRec {
+        StripRec r;
+        r.b = gs / a_nstrips;
+        const int sidx = gs - r.b * a_nstrips;
+        const ConstU32 tb = (ConstU32)(a_tabi + (uintptr_t)sidx * 32);
+        uint32_t t0 = tb[0], t1 = tb[1], t2 = tb[2], t3 = tb[3], t4 = tb[4], t5 = tb[5], t6 = tb[6], t7 = tb[7];
+        asm volatile("" : "+s"(t0), "+s"(t1), "+s"(t2), "+s"(t3), "+s"(t4), "+s"(t5), "+s"(t6), "+s"(t7));      // all eight before the first branch: ONE load, one wait
+        r.t[0] = t0; r.t[1] = t1; r.t[2] = t2; r.t[3] = t3; r.t[4] = t4; r.t[5] = t5; r.t[6] = t6; r.t[7] = t7;
+        return r;
+    };
+    // multi-strip form: the tile of strip `rec` -> tile buffer q by LDS-DMA.  Lane i of a load writes LDS at (wave-uniform base) + 16 i, and a tile row is 12 pieces of
+    // 16 bytes (4 cells x 3), so piece p = 256 j + thread lies at 16 p: row p / 12, cell (p % 12) / 3, 16-byte group p % 3 — the global address is per lane.  Rows below the
+    // ROI, cells the strip does not have and columns past the row are CLAMPED to valid memory instead of staged as zeros: nothing ever reads them unmasked.
+    auto issue_tile = [&](const StripRec& r, int q, int tid) __attribute__((always_inline)) {
+        const int level = (int)(r.t[0] & 0xffu), hr = (int)(r.t[1] >> 16), iniY = (int)(r.t[1] & 0xffffu), iniX0 = (int)(r.t[2] & 0xffffu), wCell = (int)(r.t[2] >> 16);
+        const bool ext = level == 0 && r.b < a_ext0N;
+        const uint8_t* img = (const uint8_t*)(ext ? a_ext0 + (size_t)r.b * a_ext0Stride : a_pyr + (size_t)r.b * a_pyrStride + ((size_t)r.t[6] | ((size_t)r.t[7] << 32)));
+        const int ipitch = ext ? a_ext0Pitch : (int)r.t[4];
+        const uint32_t lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(q ? &s_dyn[0] : &s_tile0[0])) + 1024u * (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+        for (int j = 0; j < (TROWS * 12 + 255) / 256; j++) {
+            const int pc = 256 * j + tid;
+            const int rr = pc / 12, col = pc - 12 * rr, c = col / 3, k = col - 3 * c;
+            const int x = min(iniX0 + c * wCell + 16 * k, ipitch - 16);
+            const uint8_t* src = img + (size_t)(iniY + min(rr, hr - 1)) * ipitch + x;
+            const uint32_t d = lds + 4096u * (uint32_t)j;
+            uint32_t keep;
+            if (pc < TROWS * 12)
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(d) : "memory");
+        }
+    };
+    StripRec rec = load_rec(gs_first);
+    if constexpr (NS > 1) {
+        static_assert(NS == 1 || (G * ((CW + 6 + 15) / 16) == 12), "a tile row of the multi-strip form is 12 pieces");
+        if ((rec.t[0] >> 24) != 0) issue_tile(rec, 0, (int)threadIdx.x);
+    }
+    int par = 0;                                                       // tile buffer / state set of the current strip (NS > 1)
+    bool fresh = true;                                                 // the current strip's tile was issued after this wave's last wait for its loads (NS > 1, wave-uniform)
+  for (int gs = gs_first; gs < gs_end; gs++) {
+    int tid_ = threadIdx.x;
+    if constexpr (NS > 1) asm volatile("" : "+v"(tid_));               // (inside a loop the compiler would hoist every lane-dependent invariant of the body into registers of its own)
+    const int tid = tid_;
+    uint8_t* const s_tile = (NS > 1 && par) ? s_dyn : s_tile0;
+    uint32_t* const s_list = reinterpret_cast<uint32_t*>(s_tile);
+    uint8_t* const s_listc = s_tile + 4 * NLIST;
+    uint32_t* const s_recz = reinterpret_cast<uint32_t*>(s_tile);
+    int* const s_ini = s_ini2[par];
+    int* const s_wc = s_wc2[par];
+    int& s_nlist = s_cnt2[par][0]; int& s_npair = s_cnt2[par][1]; int& s_ncorner = s_cnt2[par][2];
+    const int b = rec.b;
+    StripRec rec_next = rec;
+    if constexpr (NS > 1) { if (gs + 1 < gs_end) rec_next = load_rec(gs + 1); }      // scalar loads, in flight under this strip's work
     // what the next launch of this handle decides on is reported by a SAMPLE of the strips (a ratio of sums needs no more, and a few thousand
     // same-address atomics per launch cost nothing where 300 k of them serialise into milliseconds)
-    const bool sampled = logical % max(1, nwg >> 12) == 0;
-    // (read through the CONSTANT address space: a uniform address there is one s_load_dwordx8 on the scalar unit; as plain global memory the compiler issues
-    // per-lane vector loads with a wait of their own)
-    typedef const uint32_t __attribute__((address_space(4))) * ConstU32;
-    const ConstU32 tb = (ConstU32)(a_tabi + (uintptr_t)sidx * 32);
-    uint32_t t0 = tb[0], t1 = tb[1], t2 = tb[2], t3 = tb[3], t4 = tb[4], t5 = tb[5], t6 = tb[6], t7 = tb[7];
-    asm volatile("" : "+s"(t0), "+s"(t1), "+s"(t2), "+s"(t3), "+s"(t4), "+s"(t5), "+s"(t6), "+s"(t7));      // all eight before the first branch: ONE load, one wait
-    const uint4 e0 = make_uint4(t0, t1, t2, t3), e1 = make_uint4(t4, t5, t6, t7);
+    const bool sampled = gs % max(1, total_strips >> 12) == 0;
+    const uint4 e0 = make_uint4(rec.t[0], rec.t[1], rec.t[2], rec.t[3]), e1 = make_uint4(rec.t[4], rec.t[5], rec.t[6], rec.t[7]);
     const int level = (int)(e0.x & 0xffu), ci = (int)((e0.x >> 8) & 0xffu), cj0 = (int)((e0.x >> 16) & 0xffu), ncell = (int)(e0.x >> 24);
-    if (ncell == 0) return;                                            // :843 / :852 (decided when the plan was made)
+    if (ncell == 0) { rec = rec_next; if constexpr (NS > 1) { if (gs + 1 < gs_end && (rec.t[0] >> 24) != 0) { issue_tile(rec, par, tid); fresh = true; } } continue; }      // :843 / :852 (decided when the plan was made); nothing of this strip was in flight
     const int iniY = (int)(e0.y & 0xffffu), hr = (int)(e0.y >> 16), hc = hr - 6;
     const int iniX0 = (int)(e0.z & 0xffffu), t_wCell = (int)(e0.z >> 16);
     const int pairs_total = (int)e1.y;
-    if ((int)threadIdx.x < G) s_wc[threadIdx.x] = (int)((e0.w >> (8 * threadIdx.x)) & 0xffu);      // per-cell widths are looked up from LDS (a register array would be indexed dynamically)
+    if (tid < G) s_wc[tid] = (int)((e0.w >> (8 * tid)) & 0xffu);      // per-cell widths are looked up from LDS (a register array would be indexed dynamically)
     auto wc_of = [&](int c) __attribute__((always_inline)) -> int { return s_wc[c]; };
     const bool ext = level == 0 && b < a_ext0N;                      // level 0 read in place (block-uniform)
     const uint8_t* img = (const uint8_t*)(ext ? a_ext0 + (size_t)b * a_ext0Stride : a_pyr + (size_t)b * a_pyrStride + ((size_t)e1.z | ((size_t)e1.w << 32)));
@@ -1153,11 +1220,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
     auto prep = [&]() __attribute__((always_inline)) {
         {   // zero the score maps (16-byte stores; the dword tail only exists when the array size is not a multiple of 16)
             constexpr int NB = G * (SROWS * SP + 16), NV = NB / 16;
-            for (int i = threadIdx.x; i < NV; i += T) reinterpret_cast<uint4*>(&s_score[0][0])[i] = make_uint4(0, 0, 0, 0);
-            if (NB % 16 != 0 && threadIdx.x < (NB - 16 * NV) / 4) reinterpret_cast<uint32_t*>(&s_score[0][0])[4 * NV + threadIdx.x] = 0;
+            for (int i = tid; i < NV; i += T) reinterpret_cast<uint4*>(&s_score[0][0])[i] = make_uint4(0, 0, 0, 0);
+            if (NB % 16 != 0 && tid < (NB - 16 * NV) / 4) reinterpret_cast<uint32_t*>(&s_score[0][0])[4 * NV + tid] = 0;
         }
-        if (threadIdx.x < G) s_ini[threadIdx.x] = 0;
-        if (threadIdx.x == 0) { s_nlist = 0; s_npair = 0; s_ncorner = 0; }
+        if (tid < G) s_ini[tid] = 0;
+        if (tid == 0) { s_nlist = 0; s_npair = 0; s_ncorner = 0; }
         // path of this launch: what the previous launch of the handle saw on this level decides (block-uniform)
         {
             // (scalar loads through the constant address space — the record was written by the handle's PREVIOUS launch: as a vector load its wait (vmcnt) also
@@ -1171,7 +1238,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
         }
     };
     MYSLAM_BT_MARK(3);                                                 // (trace builds: the block's decode is done, its tile loads start here)
-    if constexpr (G * NQC <= 16) {
+    if constexpr (NS > 1) {
+        // this strip's tile is in flight (the block's first) or has landed (every wave waited for its own pieces before the previous strip's append)
+        prep();
+        if (fresh) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); fresh = false; }
+        __syncthreads();
+        // the next strip's tile -> the other buffer: the strip before this one kept its record list there, and every wave has left that strip (the barrier)
+        if (gs + 1 < gs_end && (rec_next.t[0] >> 24) != 0) issue_tile(rec_next, par ^ 1, tid);
+    } else if constexpr (G * NQC <= 16) {
         // all loads of a thread are issued before its LDS stores.  Unaligned 16-byte loads (a cell starts at any column); a load may run up
         // to 15 bytes past its row or, in the last row of the last plane, into the slack behind the pyramid block — those bytes are never used.
         // 16 lanes per tile row (G * NQC of them busy): (row, cell, 16-byte group) of a lane are bit fields of the thread index and its rows
@@ -1196,6 +1270,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
 #pragma unroll
         for (int u = 0; u < NIT; u++)
             if (lane_on && r0 + 16 * u < hr) *reinterpret_cast<uint4*>(&s_tile[(r0 + 16 * u) * TP + 16 * col]) = v[u];      // c * CP + 16 k = 16 col
+        __syncthreads();
     } else {
         constexpr int NIT = (TROWS * G * NQC + T - 1) / T;
         uint4 v[NIT];
@@ -1216,8 +1291,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
             const int i = threadIdx.x + u * T, r = i / (G * NQC), rem = i - r * (G * NQC), c = rem / NQC, k = rem - c * NQC;
             if (r < hr && c < ncell) *reinterpret_cast<uint4*>(&s_tile[r * TP + c * CP + 16 * k]) = v[u];
         }
+        __syncthreads();
     }
-    __syncthreads();
     MYSLAM_BT_MARK(0);
 #if MYSLAM_FAST_PHASE == 1
     if (dense) return;
@@ -1238,7 +1313,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
         gi = rem - cy * ngr;
         if (gi < 0) { cy--; gi += ngr; } else if (gi >= ngr) { cy++; gi -= ngr; }
     };
-    const int lane = threadIdx.x & 63;
+    const int lane = (unsigned)tid & 63;
     // append the strict maxima a lane found (bit k of mk = pixel k of its group, z of pixel k at bits [8 sh k, 8 sh k + 8) of zc) to the
     // strip's LDS list: ONE returning LDS atomic per wave and call (DPP prefix sum over the lanes' counts).  Wave-uniform call sites only.
     auto push_maxima = [&](int mk, uint32_t zc0, uint32_t zc1, int zshift, int c, int px0, int py0) __attribute__((always_inline)) {
@@ -1273,7 +1348,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
         const float inv_pc = 1.0f / (float)per_cell, inv_ngr = 1.0f / (float)ngr;
         // ---- 1. compass pre-test, surviving pixel pairs -> s_pairs ----
         for (int q0 = 0; q0 < nitems; q0 += T) {                       // uniform trip count: the wave-wide scan needs every lane
-            const int q = q0 + threadIdx.x;
+            const int q = q0 + (unsigned)tid;
             int pm = 0, c = 0, cy = 0, cx = 0;                         // pm bit 2 r + k: pair k of row cy + r survives
             if (q < nitems) {
                 int cy2, gi;
@@ -1324,7 +1399,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
         __syncthreads();
         const int np = min(s_npair, NPAIR);
         // ---- 2. score of the listed pairs ----
-        for (int q = threadIdx.x; q < np; q += T) {
+        for (int q = (unsigned)tid; q < np; q += T) {
             const uint32_t e = s_pairs[q];
             const int c = (int)(e >> 11), row = (int)((e >> 5) & 63), cx = 2 * (int)(e & 31);
             const int col = c * CP + cx;
@@ -1348,7 +1423,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
         __syncthreads();
         // ---- 3. NMS of the listed pairs ----
         for (int q0 = 0; q0 < np; q0 += T) {                           // uniform trip count
-            const int q = q0 + threadIdx.x;
+            const int q = q0 + (unsigned)tid;
             int mk = 0, c = 0, row = 0, cx = 0;
             uint32_t zc = 0;
             if (q < np) {
@@ -1406,24 +1481,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
             }
         };
         if constexpr (BITMAP) {
-            const int gi = (int)threadIdx.x & 7, c = ((int)threadIdx.x >> 3) & 3, cx = 4 * gi;
+            const int gi = tid & 7, c = (tid >> 3) & 3, cx = 4 * gi;
             const int wc = wc_of(c);
             if (cx < wc) {
                 const uint32_t keepm = (wc - cx < 4) ? (1u << (8 * (wc - cx))) - 1u : 0xffffffffu;
-                for (int cy2 = (int)threadIdx.x >> 5; cy2 < hc2; cy2 += T / 32) score_item(c, 2 * cy2, cx, keepm);
+                for (int cy2 = tid >> 5; cy2 < hc2; cy2 += T / 32) score_item(c, 2 * cy2, cx, keepm);
             }
         } else {
             // a lane's work items are q = tid, tid + T, ...: (cell, row pair, group) is split once and then advanced by the split of T
             const float inv_pc = 1.0f / (float)per_cell, inv_ngr = 1.0f / (float)ngr;
             int c, cy2, gi;
-            split((int)threadIdx.x, inv_pc, inv_ngr, c, cy2, gi);
+            split(tid, inv_pc, inv_ngr, c, cy2, gi);
             const int dc = T / per_cell, drem = T - dc * per_cell, dcy = drem / ngr, dgi = drem - dcy * ngr;       // block-uniform
             auto advance = [&](int& c_, int& cy2_, int& gi_) __attribute__((always_inline)) {
                 gi_ += dgi; cy2_ += dcy; c_ += dc;
                 if (gi_ >= ngr) { gi_ -= ngr; cy2_++; }
                 if (cy2_ >= hc2) { cy2_ -= hc2; c_++; }
             };
-            for (int q = threadIdx.x; q < nitems; q += T, advance(c, cy2, gi)) {
+            for (int q = (unsigned)tid; q < nitems; q += T, advance(c, cy2, gi)) {
                 const int wc = wc_of(c);
                 const int cx = 4 * gi, cy = 2 * cy2;
                 if (cx >= wc) continue;
@@ -1444,10 +1519,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
         int c, gi, cy4;
         int ec = 0, ecy = 0, egi = 0;                                      // !BITMAP: the split of T (block-uniform)
         if constexpr (BITMAP) {
-            gi = (int)threadIdx.x & 7; c = ((int)threadIdx.x >> 3) & 3; cy4 = (int)threadIdx.x >> 5;
+            gi = tid & 7; c = (tid >> 3) & 3; cy4 = tid >> 5;
         } else {   // q -> (cell, row block, group) as split() does for the scoring items
             const float inv_ngr = 1.0f / (float)ngr;
-            const int q = (int)threadIdx.x;
+            const int q = tid;
             c = (int)(((float)q + 0.5f) * (1.0f / (float)per_cell4));
             int rem = q - c * per_cell4;
             if (rem < 0) { c--; rem += per_cell4; } else if (rem >= per_cell4) { c++; rem -= per_cell4; }
@@ -1459,7 +1534,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
         const int wc_lane = BITMAP ? wc_of(c) : 0;
         const int zini = P.iniTh - zoff;                                   // z of a corner at the initial threshold
         for (int q0 = 0; q0 < nitems4; q0 += T) {                          // uniform trip count: the ballot needs every lane
-            const int q = q0 + threadIdx.x;
+            const int q = q0 + (unsigned)tid;
             uint32_t zm[4] = {0u, 0u, 0u, 0u};                             // rows 4 cy4 .. + 3: z where the pixel is a strict maximum, else 0
             u16x2 zacc = {0, 0};
             if (BITMAP ? (cy4 < hc4 && 4 * gi < wc_lane) : (q < nitems4 && 4 * gi < wc_of(c))) {
@@ -1517,7 +1592,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
     }
     __syncthreads();
     MYSLAM_BT_MARK(2);
-    if (threadIdx.x == 0 && sampled) {                                 // the path statistics of this launch (see `sampled` above)
+    // multi-strip form: the next strip's tile was requested a whole scoring pass ago — this wave's pieces have landed by now; waiting for them HERE, in front of the
+    // append's own memory operations, keeps the wait from ever covering this strip's candidate stores
+    if constexpr (NS > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((unsigned)tid == 0 && sampled) {                                 // the path statistics of this launch (see `sampled` above)
         atomicAdd(&ctl.cur[level * 4], (uint32_t)(dense ? s_ncorner : min(s_npair, NPAIR)));
         atomicAdd(&ctl.cur[level * 4 + 1], (uint32_t)pairs_total);
         ctl.cur[level * 4 + 2] = dense ? 1u : 0u;
@@ -1529,8 +1607,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
         // every record = a 4-pixel row: two halves, at most one strict maximum each; all passes of a wave are appended with one global atomic
         const int nrec = min(s_nlist, NLIST);
         for (int i0 = 0; i0 < nrec; i0 += T) {
-            if (i0 + (int)(threadIdx.x & ~63u) >= nrec) continue;          // this wave has no record in this round (no barrier in the loop)
-            const int i = i0 + threadIdx.x;
+            if (i0 + (int)((unsigned)tid & ~63u) >= nrec) continue;          // this wave has no record in this round (no barrier in the loop)
+            const int i = i0 + (unsigned)tid;
             uint32_t z = 0;
             int px0 = 0, py = 0, ini = 0;
             if (i < nrec) {
@@ -1568,11 +1646,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
                 if (dst < g.keyCap) out[dst] = kp[1];
             }
         }
-        return;
-    }
+    } else {
     const int nl = min(s_nlist, NLIST);
     for (int i0 = 0; i0 < nl; i0 += T) {
-        const int i = i0 + threadIdx.x;
+        const int i = i0 + (unsigned)tid;
         bool pass = false;
         uint32_t kp = 0;
         if (i < nl) {
@@ -1592,6 +1669,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CW <= 40 ? 
             if (dst < g.keyCap) out[dst] = kp;
         }
     }
+    }
+    rec = rec_next; par ^= (NS > 1 ? 1 : 0);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2976,6 +3056,15 @@ void launch_fast(const OrbPlan& P, const uint8_t* pyr, size_t pyrStride, const u
     const FastCtl ctl{statPrev, statCur, forceMode};
     const dim3 grid((unsigned)P.nstrips * (unsigned)batch);
     constexpr int pad = FastLds<32, 4, 40>::PAD;                          // dynamic LDS: see FastLds
+#if MYSLAM_FAST_NS > 1
+    // the multi-strip form (blocks of MYSLAM_FAST_NS consecutive strips, the next strip's tile prefetched by LDS-DMA) for launches that fill the chip several times over
+    if (cw <= 32 && ch <= 40 && (size_t)P.nstrips * batch >= (size_t)MYSLAM_FAST_NS * 256 * 6 * 4) {
+        const dim3 gridms((unsigned)(((size_t)P.nstrips * batch + MYSLAM_FAST_NS - 1) / MYSLAM_FAST_NS));
+        constexpr int padms = FastLds<32, 4, 40, MYSLAM_FAST_NS>::PAD + FastLds<32, 4, 40, MYSLAM_FAST_NS>::TROWS * FastLds<32, 4, 40, MYSLAM_FAST_NS>::TP + 16;      // the second tile buffer + the pad
+        hipLaunchKernelGGL((k_fast_strip<32, 4, 40, MYSLAM_FAST_NS>), gridms, dim3(256), padms, s, P, pyr, pyrStride, maskPyr, cand, candCount, ctl, batch);
+        return;
+    }
+#endif
     if (cw <= 32 && ch <= 40) hipLaunchKernelGGL((k_fast_strip<32, 4, 40>), grid, dim3(256), pad, s, P, pyr, pyrStride, maskPyr, cand, candCount, ctl, batch);
     else if (max(cw, ch) <= 40) hipLaunchKernelGGL((k_fast_strip<40, 4>), grid, dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount, ctl, batch);
     else hipLaunchKernelGGL((k_fast_strip<MAX_CELL, 4>), grid, dim3(256), 0, s, P, pyr, pyrStride, maskPyr, cand, candCount, ctl, batch);
