@@ -1130,8 +1130,8 @@ static int lcd_create(myslam_lcd** out, const myslam_calc_layer* layers, int nla
         h->d_wt.push_back(dw);
         if (hipMalloc((void**)&db, (size_t)OC * sizeof(float)) != hipSuccess) return fail(MYSLAM_ERR_HIP);
         h->d_b.push_back(db);
-        if (hipMemcpy(dw, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(db, w + (size_t)OC * ic * KK, (size_t)OC * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        if (upload_table(dw, wt.data(), wt.size() * sizeof(float)) != MYSLAM_OK ||
+            upload_table(db, w + (size_t)OC * ic * KK, (size_t)OC * sizeof(float)) != MYSLAM_OK)
             return fail(MYSLAM_ERR_HIP);
         if (conv == 1) w2t.swap(wt);
         w += (size_t)OC * ic * KK + OC; ic = OC; conv++;
@@ -1158,7 +1158,7 @@ static int lcd_create(myslam_lcd** out, const myslam_calc_layer* layers, int nla
             }
         }
         if (hipMalloc((void**)&h->d_w2s, w2s.size() * 2) != hipSuccess ||
-            hipMemcpy(h->d_w2s, w2s.data(), w2s.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
+            upload_table(h->d_w2s, w2s.data(), w2s.size() * 2) != MYSLAM_OK)
             return fail(MYSLAM_ERR_HIP);
     }
     if (h->fused.ok) {
@@ -1188,7 +1188,7 @@ static int lcd_create(myslam_lcd** out, const myslam_calc_layer* layers, int nla
                 }
             }
             if (hipMalloc((void**)&h->d_w2h, w2h.size() * 2) != hipSuccess ||
-                hipMemcpy(h->d_w2h, w2h.data(), w2h.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
+                upload_table(h->d_w2h, w2h.data(), w2h.size() * 2) != MYSLAM_OK)
                 return fail(MYSLAM_ERR_HIP);
             double wmax1 = 0;
             for (int i = 0; i < n1 * k1; i++) wmax1 = std::max(wmax1, (double)std::fabs(w1[i]));
@@ -1207,7 +1207,7 @@ static int lcd_create(myslam_lcd** out, const myslam_calc_layer* layers, int nla
                                 for (int pc = 0; pc < 3; pc++) w1h[((((size_t)(nt * 2 + ks) * 3 + pc) * 64 + ln) * 8) + j] = pcs[pc];
                             }
                 if (hipMalloc((void**)&h->d_w1h, w1h.size() * 2) != hipSuccess ||
-                    hipMemcpy(h->d_w1h, w1h.data(), w1h.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
+                    upload_table(h->d_w1h, w1h.data(), w1h.size() * 2) != MYSLAM_OK)
                     return fail(MYSLAM_ERR_HIP);
             }
         }

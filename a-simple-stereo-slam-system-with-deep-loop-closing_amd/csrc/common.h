@@ -60,6 +60,17 @@ struct ScopedProf {
 // stream depend on a capturing blocking stream") and poisons that thread's recording (tests/test_gpu_threads.py: one thread makes a plan while another
 // records its one-frame call).  This one copies on a process-wide NON-BLOCKING stream and waits for that stream only.
 int upload_table(void* dst, const void* src, size_t bytes);
+// The stream of the synchronous host-pointer entry points that bring no stream of their own (PnP-RANSAC, pose graph, map-point correction): one NON-BLOCKING
+// stream per calling thread, created on first use — kernels, copies and memsets of such a call all go through it, and the call synchronises it before it reads
+// a result or returns.  nullptr = the stream could not be created.
+hipStream_t host_call_stream();
+// copy through `st`, complete on return (pageable host memory on either side)
+inline int copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
+    if (bytes == 0) return MYSLAM_OK;
+    MYSLAM_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, kind, st));
+    MYSLAM_HIP_CHECK(hipStreamSynchronize(st));
+    return MYSLAM_OK;
+}
 
 // ---- staging of the host-pointer ("drop-in", B = 1) entry points --------------------------------------------------------------
 // One grow-only device block, one pinned host block and one stream per calling THREAD, carved into 256-byte aligned pieces per

@@ -35,6 +35,15 @@ int upload_table(void* dst, const void* src, size_t bytes) {
     MYSLAM_HIP_CHECK(hipStreamSynchronize(up));
     return MYSLAM_OK;
 }
+hipStream_t host_call_stream() {
+    struct Holder {
+        hipStream_t s = nullptr;
+        ~Holder() { if (s) (void)hipStreamDestroy(s); }
+    };
+    static thread_local Holder h;
+    if (!h.s && hipStreamCreateWithFlags(&h.s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); h.s = nullptr; }
+    return h.s;
+}
 }  // namespace myslam_hip
 
 namespace {

@@ -468,7 +468,12 @@ int myslam_lcddb_create(myslam_lcddb** out, int capacity) {
     h->capacity = (capacity + rowsPerBlock - 1) / rowsPerBlock * rowsPerBlock;      // scan reads whole blocks of rows
     auto alloc_all = [&]() -> int {
         MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_db, (size_t)h->capacity * DIM * sizeof(float)));
-        MYSLAM_HIP_CHECK(hipMemset(h->d_db, 0, (size_t)h->capacity * DIM * sizeof(float)));
+        {   // (not hipMemset: the legacy stream may not be touched while another thread records a graph on a blocking stream, common.h)
+            const hipStream_t us = host_call_stream();
+            if (!us) return MYSLAM_ERR_HIP;
+            MYSLAM_HIP_CHECK(hipMemsetAsync(h->d_db, 0, (size_t)h->capacity * DIM * sizeof(float), us));
+            MYSLAM_HIP_CHECK(hipStreamSynchronize(us));
+        }
         MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_ids, (size_t)h->capacity * sizeof(uint64_t)));
         MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_q1, DIM * sizeof(float)));
         MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_best1, 8)); MYSLAM_HIP_CHECK(hipMalloc((void**)&h->d_max1, 4));

@@ -774,6 +774,8 @@ int myslam_pose_graph_optimize(double* poses, int n, const uint8_t* fixed, const
         *d_sc, *d_part, *d_res;
     int32_t *d_e0, *d_e1, *d_slot, *d_seg; uint8_t* d_fx; PgJob* d_jobs; int2* d_list; int* d_status;
     const int nchi = (E + 255) / 256;
+    const hipStream_t st = host_call_stream();             // this thread's own non-blocking stream for every kernel, copy and memset of the call (never the legacy stream: common.h)
+    if (!st) return MYSLAM_ERR_HIP;
     MYSLAM_HIP_CHECK(mem.alloc(&d_pose, (size_t)7 * n)); MYSLAM_HIP_CHECK(mem.alloc(&d_save, (size_t)7 * n));
     MYSLAM_HIP_CHECK(mem.alloc(&d_meas, (size_t)7 * E)); MYSLAM_HIP_CHECK(mem.alloc(&d_minv, (size_t)7 * E));
     MYSLAM_HIP_CHECK(mem.alloc(&d_J, (size_t)72 * E)); MYSLAM_HIP_CHECK(mem.alloc(&d_err, (size_t)6 * E));
@@ -790,35 +792,34 @@ int myslam_pose_graph_optimize(double* poses, int n, const uint8_t* fixed, const
     double* d_inv = nullptr;
     const bool bigS = nS > PG_MAXS;
     MYSLAM_HIP_CHECK(mem.alloc(&d_inv, (size_t)ldz + 16));
-    MYSLAM_HIP_CHECK(hipMemcpy(d_seg, seg.data(), sizeof(int32_t) * seg.size(), hipMemcpyHostToDevice));
-    MYSLAM_HIP_CHECK(hipMemcpy(d_pose, poses, sizeof(double) * 7 * n, hipMemcpyHostToDevice));
-    MYSLAM_HIP_CHECK(hipMemcpy(d_fx, fx.data(), n, hipMemcpyHostToDevice));
-    MYSLAM_HIP_CHECK(hipMemcpy(d_slot, slot.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    { const int rc_ = copy_sync(d_seg, seg.data(), sizeof(int32_t) * seg.size(), hipMemcpyHostToDevice, st); if (rc_) return rc_; }
+    { const int rc_ = copy_sync(d_pose, poses, sizeof(double) * 7 * n, hipMemcpyHostToDevice, st); if (rc_) return rc_; }
+    { const int rc_ = copy_sync(d_fx, fx.data(), n, hipMemcpyHostToDevice, st); if (rc_) return rc_; }
+    { const int rc_ = copy_sync(d_slot, slot.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st); if (rc_) return rc_; }
     if (E) {
-        MYSLAM_HIP_CHECK(hipMemcpy(d_meas, meas, sizeof(double) * 7 * E, hipMemcpyHostToDevice));
-        MYSLAM_HIP_CHECK(hipMemcpy(d_e0, edge_v0, sizeof(int32_t) * E, hipMemcpyHostToDevice));
-        MYSLAM_HIP_CHECK(hipMemcpy(d_e1, edge_v1, sizeof(int32_t) * E, hipMemcpyHostToDevice));
+        { const int rc_ = copy_sync(d_meas, meas, sizeof(double) * 7 * E, hipMemcpyHostToDevice, st); if (rc_) return rc_; }
+        { const int rc_ = copy_sync(d_e0, edge_v0, sizeof(int32_t) * E, hipMemcpyHostToDevice, st); if (rc_) return rc_; }
+        { const int rc_ = copy_sync(d_e1, edge_v1, sizeof(int32_t) * E, hipMemcpyHostToDevice, st); if (rc_) return rc_; }
     }
     if (!jobs.empty()) {
-        MYSLAM_HIP_CHECK(hipMemcpy(d_jobs, jobs.data(), sizeof(PgJob) * jobs.size(), hipMemcpyHostToDevice));
-        MYSLAM_HIP_CHECK(hipMemcpy(d_list, list.data(), sizeof(int2) * list.size(), hipMemcpyHostToDevice));
+        { const int rc_ = copy_sync(d_jobs, jobs.data(), sizeof(PgJob) * jobs.size(), hipMemcpyHostToDevice, st); if (rc_) return rc_; }
+        { const int rc_ = copy_sync(d_list, list.data(), sizeof(int2) * list.size(), hipMemcpyHostToDevice, st); if (rc_) return rc_; }
     }
     // blocks no job writes stay zero for the whole run (the sparsity pattern is fixed)
-    MYSLAM_HIP_CHECK(hipMemset(d_D, 0, sizeof(double) * 36 * std::max(nT, 1))); MYSLAM_HIP_CHECK(hipMemset(d_B, 0, sizeof(double) * 36 * std::max(nT, 1)));
-    MYSLAM_HIP_CHECK(hipMemset(d_C, 0, sizeof(double) * std::max<size_t>((size_t)rowsPad * ldz, 1)));
-    MYSLAM_HIP_CHECK(hipMemset(d_Z, 0, sizeof(double) * std::max<size_t>((size_t)rowsPad * ldz, 1)));
-    MYSLAM_HIP_CHECK(hipMemset(d_Hss, 0, sizeof(double) * ldz * ldz)); MYSLAM_HIP_CHECK(hipMemset(d_bS, 0, sizeof(double) * ldz));
-    MYSLAM_HIP_CHECK(hipMemset(d_diag, 0, sizeof(double) * std::max(6 * nF, 1)));
-    MYSLAM_HIP_CHECK(hipMemset(d_xS, 0, sizeof(double) * ldz)); MYSLAM_HIP_CHECK(hipMemset(d_xT, 0, sizeof(double) * std::max(rowsPad, 1)));
+    MYSLAM_HIP_CHECK(hipMemsetAsync(d_D, 0, sizeof(double) * 36 * std::max(nT, 1), st)); MYSLAM_HIP_CHECK(hipMemsetAsync(d_B, 0, sizeof(double) * 36 * std::max(nT, 1), st));
+    MYSLAM_HIP_CHECK(hipMemsetAsync(d_C, 0, sizeof(double) * std::max<size_t>((size_t)rowsPad * ldz, 1), st));
+    MYSLAM_HIP_CHECK(hipMemsetAsync(d_Z, 0, sizeof(double) * std::max<size_t>((size_t)rowsPad * ldz, 1), st));
+    MYSLAM_HIP_CHECK(hipMemsetAsync(d_Hss, 0, sizeof(double) * ldz * ldz, st)); MYSLAM_HIP_CHECK(hipMemsetAsync(d_bS, 0, sizeof(double) * ldz, st));
+    MYSLAM_HIP_CHECK(hipMemsetAsync(d_diag, 0, sizeof(double) * std::max(6 * nF, 1), st));
+    MYSLAM_HIP_CHECK(hipMemsetAsync(d_xS, 0, sizeof(double) * ldz, st)); MYSLAM_HIP_CHECK(hipMemsetAsync(d_xT, 0, sizeof(double) * std::max(rowsPad, 1), st));
 
-    hipStream_t st = nullptr;
     const int npe = std::max(n, E);
     hipLaunchKernelGGL(k_pg_prepare, dim3((npe + 255) / 256), dim3(256), 0, st, d_pose, n, d_meas, d_minv, E);
     auto chi2 = [&](double* out) -> int {               // d_res[0] <- sum of e^T e over all edges
         if (E == 0) { *out = 0; return MYSLAM_OK; }
         hipLaunchKernelGGL(k_pg_chi2, dim3(nchi), dim3(256), 0, st, d_pose, d_minv, d_e0, d_e1, E, d_part);
         hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, st, d_part, nchi, d_res, 0);
-        MYSLAM_HIP_CHECK(hipMemcpy(out, d_res, sizeof(double), hipMemcpyDeviceToHost));
+        { const int rc_ = copy_sync(out, d_res, sizeof(double), hipMemcpyDeviceToHost, st); if (rc_) return rc_; }
         return MYSLAM_OK;
     };
     int it = 0, rc;
@@ -834,7 +835,7 @@ int myslam_pose_graph_optimize(double* poses, int n, const uint8_t* fixed, const
             if (it == 0) {                              // computeLambdaInit: tau * max diagonal
                 double mx = 0;
                 hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, st, d_diag, 6 * nF, d_res, 1);
-                MYSLAM_HIP_CHECK(hipMemcpy(&mx, d_res, sizeof(double), hipMemcpyDeviceToHost));
+                { const int rc_ = copy_sync(&mx, d_res, sizeof(double), hipMemcpyDeviceToHost, st); if (rc_) return rc_; }
                 lambda = 1e-5 * mx; ni = 2;
             }
             double rho = 0;
@@ -860,8 +861,8 @@ int myslam_pose_graph_optimize(double* poses, int n, const uint8_t* fixed, const
                 hipLaunchKernelGGL(k_pg_reduce, dim3(1), dim3(256), 0, st, d_part, nchi, d_res, 0);
                 MYSLAM_HIP_CHECK(hipGetLastError());
                 double res[2]; int bad = 0;
-                MYSLAM_HIP_CHECK(hipMemcpy(res, d_res, sizeof(res), hipMemcpyDeviceToHost));
-                MYSLAM_HIP_CHECK(hipMemcpy(&bad, d_status, sizeof(int), hipMemcpyDeviceToHost));
+                { const int rc_ = copy_sync(res, d_res, sizeof(res), hipMemcpyDeviceToHost, st); if (rc_) return rc_; }
+                { const int rc_ = copy_sync(&bad, d_status, sizeof(int), hipMemcpyDeviceToHost, st); if (rc_) return rc_; }
                 const bool ok = !bad;
                 tempChi = ok ? res[0] : 1e300;
                 rho = currentChi - tempChi;
@@ -882,7 +883,7 @@ int myslam_pose_graph_optimize(double* poses, int n, const uint8_t* fixed, const
             if (qmax == 10 || rho == 0 || !std::isfinite(lambda)) { it++; break; }
         }
     }
-    MYSLAM_HIP_CHECK(hipMemcpy(poses, d_pose, sizeof(double) * 7 * n, hipMemcpyDeviceToHost));
+    { const int rc_ = copy_sync(poses, d_pose, sizeof(double) * 7 * n, hipMemcpyDeviceToHost, st); if (rc_) return rc_; }
     if (final_chi2) *final_chi2 = currentChi;
     if (iters) *iters = it;
     return MYSLAM_OK;
@@ -965,23 +966,25 @@ int myslam_correct_map_points(const double* old_poses, const double* new_poses, 
     if (n_points == 0) return MYSLAM_OK;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return MYSLAM_ERR_HIP;
+    const hipStream_t st = host_call_stream();
+    if (!st) return MYSLAM_ERR_HIP;
     DevBuf mem;
     double *d_o, *d_n, *d_p; int32_t *d_k, *d_s;
     MYSLAM_HIP_CHECK(mem.alloc(&d_o, (size_t)7 * n_poses)); MYSLAM_HIP_CHECK(mem.alloc(&d_n, (size_t)7 * n_poses));
     MYSLAM_HIP_CHECK(mem.alloc(&d_p, (size_t)3 * n_points)); MYSLAM_HIP_CHECK(mem.alloc(&d_k, (size_t)n_points)); MYSLAM_HIP_CHECK(mem.alloc(&d_s, 1));
     if (n_poses) {
-        MYSLAM_HIP_CHECK(hipMemcpy(d_o, old_poses, sizeof(double) * 7 * n_poses, hipMemcpyHostToDevice));
-        MYSLAM_HIP_CHECK(hipMemcpy(d_n, new_poses, sizeof(double) * 7 * n_poses, hipMemcpyHostToDevice));
+        { const int rc_ = copy_sync(d_o, old_poses, sizeof(double) * 7 * n_poses, hipMemcpyHostToDevice, st); if (rc_) return rc_; }
+        { const int rc_ = copy_sync(d_n, new_poses, sizeof(double) * 7 * n_poses, hipMemcpyHostToDevice, st); if (rc_) return rc_; }
     }
-    MYSLAM_HIP_CHECK(hipMemcpy(d_p, points, sizeof(double) * 3 * n_points, hipMemcpyHostToDevice));
-    MYSLAM_HIP_CHECK(hipMemcpy(d_k, first_kf, sizeof(int32_t) * n_points, hipMemcpyHostToDevice));
-    MYSLAM_HIP_CHECK(hipMemset(d_s, 0, sizeof(int32_t)));
-    int rc = myslam_correct_map_points_device(d_o, d_n, n_poses, d_k, d_p, n_points, d_s, nullptr);
+    { const int rc_ = copy_sync(d_p, points, sizeof(double) * 3 * n_points, hipMemcpyHostToDevice, st); if (rc_) return rc_; }
+    { const int rc_ = copy_sync(d_k, first_kf, sizeof(int32_t) * n_points, hipMemcpyHostToDevice, st); if (rc_) return rc_; }
+    MYSLAM_HIP_CHECK(hipMemsetAsync(d_s, 0, sizeof(int32_t), st));
+    int rc = myslam_correct_map_points_device(d_o, d_n, n_poses, d_k, d_p, n_points, d_s, st);
     if (rc != MYSLAM_OK) return rc;
     int32_t stt = 0;
-    MYSLAM_HIP_CHECK(hipMemcpy(&stt, d_s, sizeof(int32_t), hipMemcpyDeviceToHost));
+    { const int rc_ = copy_sync(&stt, d_s, sizeof(int32_t), hipMemcpyDeviceToHost, st); if (rc_) return rc_; }
     if (stt != 0) return stt;
-    MYSLAM_HIP_CHECK(hipMemcpy(points, d_p, sizeof(double) * 3 * n_points, hipMemcpyDeviceToHost));
+    { const int rc_ = copy_sync(points, d_p, sizeof(double) * 3 * n_points, hipMemcpyDeviceToHost, st); if (rc_) return rc_; }
     return MYSLAM_OK;
 }
 

@@ -545,26 +545,28 @@ int myslam_solve_pnp_ransac(const float* pts3d, const float* pts2d, int n, doubl
             }
         }
     }
+    const hipStream_t st = host_call_stream();             // everything below runs on this thread's own non-blocking stream (never the legacy stream: common.h)
+    if (!st) return MYSLAM_ERR_HIP;
     PnpBuf mem;
     float *d_p3, *d_p2; int32_t *d_samples, *d_counts, *d_result; double *d_models, *d_pose; uint8_t* d_mask;
     MYSLAM_HIP_CHECK(mem.alloc(&d_p3, (size_t)3 * n)); MYSLAM_HIP_CHECK(mem.alloc(&d_p2, (size_t)2 * n));
     MYSLAM_HIP_CHECK(mem.alloc(&d_samples, samples.size())); MYSLAM_HIP_CHECK(mem.alloc(&d_counts, (size_t)iterations));
     MYSLAM_HIP_CHECK(mem.alloc(&d_result, 2)); MYSLAM_HIP_CHECK(mem.alloc(&d_models, (size_t)12 * iterations));
     MYSLAM_HIP_CHECK(mem.alloc(&d_pose, 7)); MYSLAM_HIP_CHECK(mem.alloc(&d_mask, (size_t)n));
-    MYSLAM_HIP_CHECK(hipMemcpy(d_p3, pts3d, sizeof(float) * 3 * n, hipMemcpyHostToDevice));
-    MYSLAM_HIP_CHECK(hipMemcpy(d_p2, pts2d, sizeof(float) * 2 * n, hipMemcpyHostToDevice));
-    MYSLAM_HIP_CHECK(hipMemcpy(d_samples, samples.data(), sizeof(int32_t) * samples.size(), hipMemcpyHostToDevice));
+    { const int rc_ = copy_sync(d_p3, pts3d, sizeof(float) * 3 * n, hipMemcpyHostToDevice, st); if (rc_) return rc_; }
+    { const int rc_ = copy_sync(d_p2, pts2d, sizeof(float) * 2 * n, hipMemcpyHostToDevice, st); if (rc_) return rc_; }
+    { const int rc_ = copy_sync(d_samples, samples.data(), sizeof(int32_t) * samples.size(), hipMemcpyHostToDevice, st); if (rc_) return rc_; }
     const PnpCam K{fx, fy, cx, cy};
     const float thr = (float)(reproj_error * reproj_error);
-    hipLaunchKernelGGL(k_pnp_hypotheses, dim3(iterations), dim3(64), 0, nullptr, d_p3, d_p2, n, d_samples, K, thr, d_models, d_counts);
-    hipLaunchKernelGGL(k_pnp_select_refine, dim3(1), dim3(64), 0, nullptr, d_p3, d_p2, n, d_models, d_counts, iterations, K, thr, confidence, d_pose,
+    hipLaunchKernelGGL(k_pnp_hypotheses, dim3(iterations), dim3(64), 0, st, d_p3, d_p2, n, d_samples, K, thr, d_models, d_counts);
+    hipLaunchKernelGGL(k_pnp_select_refine, dim3(1), dim3(64), 0, st, d_p3, d_p2, n, d_models, d_counts, iterations, K, thr, confidence, d_pose,
                        d_mask, d_result);
     MYSLAM_HIP_CHECK(hipGetLastError());
     int32_t res[2];
-    MYSLAM_HIP_CHECK(hipMemcpy(res, d_result, sizeof(res), hipMemcpyDeviceToHost));
+    { const int rc_ = copy_sync(res, d_result, sizeof(res), hipMemcpyDeviceToHost, st); if (rc_) return rc_; }
     if (res[0] <= 0) return MYSLAM_ERR_UNSUPPORTED;         // no model: OpenCV returns false and leaves rvec / tvec alone
-    MYSLAM_HIP_CHECK(hipMemcpy(pose7, d_pose, sizeof(double) * 7, hipMemcpyDeviceToHost));
-    if (inlier) MYSLAM_HIP_CHECK(hipMemcpy(inlier, d_mask, (size_t)n, hipMemcpyDeviceToHost));
+    { const int rc_ = copy_sync(pose7, d_pose, sizeof(double) * 7, hipMemcpyDeviceToHost, st); if (rc_) return rc_; }
+    if (inlier) { const int rc_ = copy_sync(inlier, d_mask, (size_t)n, hipMemcpyDeviceToHost, st); if (rc_) return rc_; }
     if (n_inliers) *n_inliers = res[0];
     return MYSLAM_OK;
 }

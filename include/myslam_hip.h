@@ -623,6 +623,11 @@ int myslam_io_save_loop_edges(const char* path, const uint64_t* cur_ids, const d
  * streams the step uses must stay as they were; host code is not replayed — record TWO consecutive steps and replay them alternately so
  * that the extractor's FAST statistics keep ping-ponging, and feed the loop database's row limits through
  * myslam_lcddb_update_query_limits.  Results are bit-identical to the eager step (tests/test_gpu_graph.py).
+ * Other threads: HIP's legacy NULL stream synchronises with every blocking stream, so while ANY thread records on a blocking stream no thread may
+ * issue work on the legacy stream (HIP refuses it and the recording is lost).  The library stays off the legacy stream: handles and plans, the batch
+ * entry points, and the synchronous host-pointer calls (PnP-RANSAC, pose graph, map-point correction: a non-blocking stream per calling thread) —
+ * tests/test_gpu_threads.py runs four threads, each recording its own one-frame calls while the others create plans.  Only the myslam_*_debug_*
+ * getters copy through it.
  * ------------------------------------------------------------------------------------------ */
 typedef struct myslam_step_graph myslam_step_graph;
 int myslam_graph_begin(void* origin_stream, void* const* side_streams, int n_side);

@@ -24,8 +24,12 @@ def test_four_threads_with_their_own_handles(api, oracle, synth):
         lk = oracle.lk_track(imgs[0], np.roll(imgs[0], -3, axis=1), pts0, pts0)
         poses, pts, ep, el, obs, fixed, Kt = synth.ba_problem(seed=0xBA + t, n_kf=5 + t % 2, n_mp=60 + 10 * t)
         ba = oracle.ba_optimize_active_map(poses, pts, ep, el, obs, fixed, Kt)
+        # a synchronous host-pointer call without a stream of its own (it runs on a non-blocking stream per calling thread: never the legacy
+        # stream, which HIP refuses to touch while ANOTHER thread records a graph on a blocking stream — the one-frame extractor calls here do)
+        pw, uv, Kp, _, _ = synth.pnp_problem(120 + 30 * t, 0.4, 0.5, seed=70 + t)
+        pnp = oracle.solve_pnp_ransac(pw, uv, Kp)
         work.append(dict(imgs=imgs, nf=300 + 100 * t, nd=100 + 20 * t, ref=ref, det=det, ham=ham, pts0=pts0, lk=lk,
-                         ba_in=(poses, pts, ep, el, obs, fixed, Kt), ba=ba))
+                         ba_in=(poses, pts, ep, el, obs, fixed, Kt), ba=ba, pnp_in=(pw, uv, Kp), pnp=pnp))
     errors = []
     start = threading.Barrier(nthreads)
 
@@ -40,6 +44,9 @@ def test_four_threads_with_their_own_handles(api, oracle, synth):
                     assert k.tobytes() == wk["ref"][i][0].tobytes() and np.array_equal(d, wk["ref"][i][1]), ("DetectAndCompute", t, r, i)
                     kd = dex.Detect(im)
                     assert kd.tobytes() == wk["det"][i].tobytes(), ("Detect", t, r, i)
+                    if wk["pnp"][0] == 0:
+                        gp, gin, gn = api.solve_pnp_ransac(*wk["pnp_in"])
+                        assert gn == wk["pnp"][3] and np.array_equal(gin, wk["pnp"][2]), ("pnp", t, r, i)
                 idx, dist = api.hamming_match(wk["ref"][0][1], wk["ref"][1][1])
                 assert np.array_equal(idx, wk["ham"][0]) and np.array_equal(dist, wk["ham"][1]), ("hamming", t, r)
                 o, s, _ = lkt.track(wk["imgs"][0], np.roll(wk["imgs"][0], -3, axis=1), wk["pts0"], wk["pts0"])

@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 H, W = 376, 1241
 PASSES = [["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_INSTS_VALU_MFMA_MOPS_I8"],
           ["FETCH_SIZE"], ["WRITE_SIZE"]]
-STEPS_TOTAL = 4          # bench --warmup 2 --steps 2
+STEPS_TOTAL = 6          # bench --warmup 2 --steps 2, preceded by the two untimed steps of the run's own checks (bench.py, build v68)
 ORB_KERNELS = ("k_ingest", "k_resize", "k_fast", "k_octree", "k_blur7", "k_describe")      # unit = image; everything else: unit = stereo pair
 
 
