@@ -551,8 +551,10 @@ def main():
     step_timed = step
     step = step_eager                  # every pass below launches eagerly: the profiling events, the solve cadence and the streamed input change per step
     if not args.no_extra_passes:
+        for _ in range(3):                  # the pass's lead steps, BEFORE the per-launch events are switched on: the roofline objects divide event times and launch counts by args.steps
+            step()
         api.prof_reset(); api.prof_enable(True)
-        dt_prof = timed(args.steps)
+        dt_prof = timed(args.steps, lead=0)
         api.prof_enable(False)
         prof = api.prof_read()
 
