@@ -29,7 +29,7 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ unsigned long long* g_bt_buf = nullptr;
 __device__ unsigned int g_bt_cap = 0, g_bt_n = 0;
 struct BlockTrace {
-    unsigned long long t0 = 0, marks = 0; int kid; unsigned hw = 0; bool on = false;
+    unsigned long long t0 = 0, marks = 0, aux = 0; int kid; unsigned hw = 0; bool on = false;      // aux: a per-kernel note (k_octree: level | candidates << 8 | rounds << 32)
     // phase boundary i (0..3) of the block: time since its start in 10 ns units, 16 bits each (k_fast_strip: tile staged / scored / NMS done)
     __device__ __forceinline__ void mark(int i) {
         if (on) marks |= ((__builtin_amdgcn_s_memrealtime() - t0) & 0xffffull) << (16 * i);
@@ -47,7 +47,7 @@ struct BlockTrace {
         const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t0;
         const unsigned i = atomicAdd(&g_bt_n, 1u);
         if (i < g_bt_cap) {
-            g_bt_buf[4 * i] = t0; g_bt_buf[4 * i + 2] = marks; g_bt_buf[4 * i + 3] = 0;
+            g_bt_buf[4 * i] = t0; g_bt_buf[4 * i + 2] = marks; g_bt_buf[4 * i + 3] = aux;
             g_bt_buf[4 * i + 1] = (dt & 0xffffffull) | ((unsigned long long)(kid & 0xf) << 24) | ((unsigned long long)((hw >> 8) & 0xff) << 32) |
                                   ((unsigned long long)(blockIdx.x & 0xffffff) << 40);
         }
@@ -55,12 +55,14 @@ struct BlockTrace {
 };
 #define MYSLAM_BT(kid) BlockTrace bt_(kid)
 #define MYSLAM_BT_MARK(i) bt_.mark(i)
+#define MYSLAM_BT_AUX(v) bt_.aux = (v)
 #define MYSLAM_BT_PARAM , BlockTrace* btp_
 #define MYSLAM_BT_ARG , &bt_
 #define MYSLAM_BT_MARKP(i) btp_->mark(i)
 #else
 #define MYSLAM_BT(kid) ((void)0)
 #define MYSLAM_BT_MARK(i) ((void)0)
+#define MYSLAM_BT_AUX(v) ((void)0)
 #define MYSLAM_BT_PARAM
 #define MYSLAM_BT_ARG
 #define MYSLAM_BT_MARKP(i) ((void)0)
@@ -1989,6 +1991,8 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
     };
     if (tabLds) passes(std::true_type{}); else passes(std::false_type{});
 
+    MYSLAM_BT_MARK(0);                                                 // (trace builds: the two candidate passes are done)
+    MYSLAM_BT_AUX((unsigned long long)level | ((unsigned long long)n << 8));
     // ---- C: node list simulation ----
     // roots (:599-632): non-empty roots in index order
     if (t == 0) {
@@ -2189,6 +2193,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
         }
     }
 
+    MYSLAM_BT_MARK(1);
     // ---- D: best key per node (:788-807), list order.  8 or 16 lanes per node.  Payload levels: pass 1 finds the node's largest response;
     // pass 2 breaks ties by the reference's candidate order (cell-major, row-major inside a cell), so the cell tables
     // are only read for keys that carry that response. ----
@@ -2244,6 +2249,7 @@ __global__ __launch_bounds__(OT) void k_octree(OrbPlan P, const uint32_t* __rest
         }
     }
     if (t == 0) *myCount = min(m, g.nodeCap);
+    MYSLAM_BT_MARK(2);
     // ---- E (batches): the descriptor kernel's processing order of this level's keys — Z-order of small pixel tiles, a counting sort over
     // <= 1024 tile bins (what the separate k_sel_order launch computes for other callers; fused here: one launch boundary less on the
     // extractor's chain).  The counting-sort buckets of phase B are free by now.

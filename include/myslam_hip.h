@@ -101,8 +101,9 @@ int myslam_orb_set_fast_gate(myslam_orb* h, void* hip_event);
  *   SIDE_BLOCKS_PER_CU  n > 0: the descriptor kernel of a batched call is launched as a LIMITED grid of 256 n blocks, each walking several
  *                    (image, 64-key-point chunk) work items.  For callers that run two handles beside each other: a descriptor block lives
  *                    three times as long as a FAST block, so an unlimited grid gradually takes the CUs from the other handle's FAST launch —
- *                    the VALU-bound kernel starves under the latency-bound one (measured: 7.12 -> 7.02 ms per 512-pair step with n = 2).
- *                    0 (default) = one block per work item */
+ *                    the VALU-bound kernel starves under the latency-bound one (measured: 7.12 -> 7.02 ms per 512-pair step with n = 2, round 4).
+ *                    Since the kernel fetches its BRIEF windows by LDS-DMA (end of round 6) its blocks are short and the unlimited grid measures
+ *                    faster (6.25 -> 6.09 ms): 0 (default) = one block per work item */
 #define MYSLAM_ORB_OPT_FAST_MODE 1
 #define MYSLAM_ORB_OPT_INTERNAL_STREAM 2
 #define MYSLAM_ORB_OPT_STOP_AFTER 3
