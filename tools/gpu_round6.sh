@@ -1,6 +1,6 @@
 # One GPU session of round 6: the whole GPU suite, the counter summary of the CURRENT build (it carries the library's build digest: bench.py's roofline.traffic_stale
 # turns false), the bench line, rocprofv3 kernel stats of the timed region / the one-stream run / the whole command, B = 1 latencies.   TAG=v64 bash tools/gpu_round6.sh
-TAG=${TAG:-v71}
+TAG=${TAG:-v72}
 timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_$TAG.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_$TAG.log
 timeout 1200 python tools/pmc_collect.py --round 6 --tag $TAG > gpurun_out/pmc_$TAG.log 2>&1; echo "pmc rc=$?"; tail -12 gpurun_out/pmc_$TAG.log
 [ -f gpurun_out/r06_pmc_$TAG.json ] && cp gpurun_out/r06_pmc_$TAG.json profiles/r06_pmc_$TAG.json      # so that the bench line below normalises against THIS build's counters
